@@ -1,0 +1,116 @@
+"""ctypes binding of libcnfhip.so (include/cnfhip.h).  The library is the product; this
+module only loads it and declares the signatures.  There is no CPU fallback: if the
+library is missing, or no gfx950 device is visible when a handle is created, the call
+raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcnfhip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# enums (include/cnfhip.h)
+OK, ERR_BAD_ARG, ERR_BAD_SHAPE, ERR_HIP, ERR_NO_DEVICE, ERR_MAXITERS, ERR_UNSUPPORTED, \
+    ERR_NO_PARAMS, ERR_NONFINITE = range(9)
+MODE_TEST, MODE_TRAIN = 0, 1
+AD_VJP, AD_JVP = 0, 1
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
+ACT = {"identity": 0, "tanh": 1, "sigmoid": 2, "softplus": 3, "relu": 4, "swish": 5, "elu": 6}
+
+
+class cnf_config(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("dims", C.POINTER(C.c_int32)),
+                ("acts", C.POINTER(C.c_int32)), ("nvars", C.c_int32), ("naugs", C.c_int32),
+                ("ad", C.c_int32), ("lambda1", C.c_float), ("lambda2", C.c_float),
+                ("lambda3", C.c_float), ("device", C.c_int32)]
+
+
+class cnf_solve_opts(C.Structure):
+    _fields_ = [("t0", C.c_float), ("t1", C.c_float), ("abstol", C.c_float),
+                ("reltol", C.c_float), ("dt", C.c_float), ("adaptive", C.c_int32),
+                ("maxiters", C.c_int32), ("kernel", C.c_int32)]
+
+
+class cnf_solve_stats(C.Structure):
+    _fields_ = [("nf", C.c_int32), ("naccept", C.c_int32), ("nreject", C.c_int32),
+                ("t_final", C.c_float), ("dt_last", C.c_float), ("kernel_used", C.c_int32),
+                ("launches", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_fp = C.c_void_p  # device or host float*; passed as raw addresses
+_SIGNATURES = {
+    "cnf_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(cnf_config)]),
+    "cnf_destroy": (C.c_int, [C.c_void_p]),
+    "cnf_set_params_host": (C.c_int, [C.c_void_p, _fp, C.c_size_t]),
+    "cnf_set_params": (C.c_int, [C.c_void_p, _fp, C.c_size_t, C.c_void_p]),
+    "cnf_rhs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, C.c_void_p]),
+    "cnf_rhs_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int]),
+    "cnf_solve_tsit5": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int,
+                                  C.POINTER(cnf_solve_opts), C.POINTER(cnf_solve_stats), C.c_void_p]),
+    "cnf_build_u0": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, C.c_int, C.c_void_p]),
+    "cnf_inference_post": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int, C.c_void_p]),
+    "cnf_inference": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int,
+                                C.POINTER(cnf_solve_opts), C.POINTER(cnf_solve_stats), C.c_void_p]),
+    "cnf_inference_host": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int,
+                                     C.POINTER(cnf_solve_opts), C.POINTER(cnf_solve_stats)]),
+    "cnf_loss_sums": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, _fp, C.c_void_p]),
+    "cnf_loss_from_sums": (C.c_int, [C.c_void_p, C.c_int, _fp, C.POINTER(C.c_float)]),
+    "cnf_status_string": (C.c_char_p, [C.c_int]),
+    "cnf_last_error": (C.c_char_p, [C.c_void_p]),
+    "cnf_abi_version": (C.c_int, []),
+    "cnf_state_rows": (C.c_int, [C.c_void_p, C.c_int]),
+    "cnf_kernel_for": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "cnf_rhs_work": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class CNFError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__(f"libcnfhip status {status}: {detail}")
+
+
+def build(verbose=False):
+    """Compile libcnfhip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout + r.stderr)
+    if r.returncode:
+        raise RuntimeError("building libcnfhip.so failed")
+    return LIB_PATH
+
+
+def lib():
+    """Load libcnfhip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` or "
+                f"`make -C {CSRC}`.  There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            f = getattr(l, name)
+            f.restype, f.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(status, handle=None):
+    if status != OK:
+        l = lib()
+        detail = l.cnf_status_string(status).decode()
+        if handle:
+            extra = l.cnf_last_error(handle).decode()
+            if extra:
+                detail += ": " + extra
+        raise CNFError(status, detail)

@@ -1,0 +1,404 @@
+"""Host-side mirror of src/base_icnf.jl for the batched (MatrixMode) hot path: ``construct``,
+``inference_prob``, ``base_sol``, ``inference_sol``, ``inference`` and ``loss`` keep the
+reference's names, argument meaning and error behaviour; every number is produced by
+libcnfhip on the GPU.  Arrays follow the reference's shapes (``xs`` is ``nvars x B``, states
+are ``D x B``) and may be numpy arrays (copied through the *_host entry points) or torch
+CUDA tensors (used in place, on torch's current stream)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Any
+
+import numpy as np
+
+from . import _lib
+from .layers import Chain
+from .types import (AbstractICNF, FFJORD, RNODE, HIPMatrixMode, HIPVecJacMatrixMode, Mode,
+                    TestMode, TrainMode, _OutOfScope)
+
+_KERNEL = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "mfma": _lib.KERNEL_MFMA}
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _mode_id(mode) -> int:
+    if isinstance(mode, type):
+        mode = mode()
+    if not isinstance(mode, Mode):
+        raise TypeError("mode must be TrainMode() or TestMode()")
+    return mode.cnf
+
+
+# ---------------------------------------------------------------------------------------
+# array plumbing: logical (rows, B) <-> Julia column-major bytes
+# ---------------------------------------------------------------------------------------
+class _Buf:
+    """A float32 matrix with logical shape (rows, B) stored column-major (each column's
+    rows contiguous), either host (numpy) or device (torch)."""
+
+    def __init__(self, arr, rows, B, torch_mod=None):
+        self.arr, self.rows, self.B, self.torch = arr, rows, B, torch_mod
+
+    @property
+    def ptr(self):
+        if self.torch is not None:
+            return self.arr.data_ptr()
+        return self.arr.ctypes.data
+
+    def view(self):
+        """logical (rows, B) view without copying"""
+        if self.torch is not None:
+            return self.arr.view(self.B, self.rows).t()
+        return self.arr.reshape(self.B, self.rows).T
+
+
+def _as_colmajor(x, rows=None, name="array"):
+    """Return a _Buf over x's data laid out column-major (copying only if needed)."""
+    if _is_torch(x):
+        import torch
+        if x.dim() != 2:
+            raise ValueError(f"{name} must be a matrix")
+        if rows is not None and x.shape[0] != rows:
+            raise ValueError(f"{name} has {x.shape[0]} rows, expected {rows}")
+        if not x.is_cuda:
+            raise ValueError(f"{name}: torch tensors must live on the GPU (pass numpy for host data)")
+        t = x.t().contiguous().to(torch.float32).reshape(-1)   # (B, rows) row-major == col-major
+        return _Buf(t, x.shape[0], x.shape[1], torch)
+    a = np.asarray(x)
+    if a.ndim != 2:
+        raise ValueError(f"{name} must be a matrix")
+    if rows is not None and a.shape[0] != rows:
+        raise ValueError(f"{name} has {a.shape[0]} rows, expected {rows}")
+    flat = np.ascontiguousarray(a.T, dtype=np.float32).reshape(-1)
+    return _Buf(flat, a.shape[0], a.shape[1], None)
+
+
+def _empty_like(ref: _Buf, rows, B):
+    if ref.torch is not None:
+        return _Buf(ref.torch.empty(rows * B, dtype=ref.torch.float32, device=ref.arr.device), rows, B, ref.torch)
+    return _Buf(np.empty(rows * B, dtype=np.float32), rows, B, None)
+
+
+def _stream(buf: _Buf):
+    if buf.torch is not None:
+        return C.c_void_p(buf.torch.cuda.current_stream(buf.arr.device).cuda_stream)
+    return None
+
+
+# ---------------------------------------------------------------------------------------
+# ICNF (src/icnf.jl:69-104) + construct (src/base_icnf.jl:1-77)
+# ---------------------------------------------------------------------------------------
+@dataclass
+class ICNF:
+    tag: type
+    nn: Chain
+    nvars: int
+    naugmented: int
+    compute_mode: HIPMatrixMode
+    inplace: bool
+    tspan: tuple
+    steer_rate: float
+    sol_kwargs: dict
+    rng: Any
+    lambda1: float
+    lambda2: float
+    lambda3: float
+    device: int = 0
+    _handle: Any = field(default=None, repr=False)
+    _params_id: Any = field(default=None, repr=False)
+
+    # type parameters of the reference struct (src/base_icnf.jl:42-51)
+    @property
+    def AUGMENTED(self): return self.naugmented != 0
+    @property
+    def STEER(self): return self.steer_rate != 0
+    @property
+    def NORM_Z(self): return self.lambda1 != 0
+    @property
+    def NORM_J(self): return self.lambda2 != 0
+    @property
+    def NORM_Z_AUG(self): return self.lambda3 != 0
+
+    def handle(self):
+        if self._handle is None:
+            l = _lib.lib()
+            dims = (C.c_int32 * len(self.nn.dims))(*self.nn.dims)
+            acts = (C.c_int32 * len(self.nn.acts))(*self.nn.acts)
+            cfg = _lib.cnf_config(len(self.nn.layers), dims, acts, self.nvars, self.naugmented,
+                                  self.compute_mode.ad, self.lambda1, self.lambda2, self.lambda3,
+                                  self.device)
+            h = C.c_void_p()
+            _lib.check(l.cnf_create(C.byref(h), C.byref(cfg)))
+            self._handle = h
+        return self._handle
+
+    def close(self):
+        if self._handle is not None:
+            _lib.lib().cnf_destroy(self._handle)
+            self._handle = None
+            self._params_id = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, ps):
+        """Upload ``ps`` (the ``p`` of augmented_f) unless it is the vector already resident."""
+        h = self.handle()
+        l = _lib.lib()
+        if _is_torch(ps):
+            key = ("t", ps.data_ptr(), ps._version, ps.numel())
+            if key == self._params_id:
+                return
+            import torch
+            p = ps.detach().to(torch.float32).contiguous().reshape(-1)
+            if p.is_cuda:
+                st = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+                _lib.check(l.cnf_set_params(h, p.data_ptr(), p.numel(), st), h)
+            else:
+                _lib.check(l.cnf_set_params_host(h, p.data_ptr(), p.numel()), h)
+        else:
+            p = np.ascontiguousarray(np.asarray(ps), dtype=np.float32).reshape(-1)
+            key = ("n", p.tobytes())
+            if key == self._params_id:
+                return
+            _lib.check(l.cnf_set_params_host(h, p.ctypes.data, p.size), h)
+        self._params_id = key
+
+
+def n_augment(icnf: ICNF, mode) -> int:
+    """src/icnf.jl:106-108 (TrainMode -> 2), src/base_icnf.jl:79-81 (otherwise 0)."""
+    return 2 if _mode_id(mode) == _lib.MODE_TRAIN else 0
+
+
+def n_augment_input(icnf: ICNF) -> int:
+    """src/base_icnf.jl:98-106."""
+    return icnf.naugmented if icnf.AUGMENTED else 0
+
+
+def construct(aicnf, nn: Chain, nvars: int, naugmented: int = 0, *, data_type=np.float32,
+              compute_mode=None, inplace: bool = False, cond=None, resource=None,
+              tspan=(0.0, 1.0), steer_rate: float = 0.0, sol_kwargs=None, rng=None,
+              lambda1=None, lambda2=None, lambda3=0.0, device: int = 0, **kw) -> ICNF:
+    """src/base_icnf.jl:1-77.  Keyword names follow the reference; the lambdas may also be
+    given under their Julia names via ``**{"λ₁": ...}``.  RNODE defaults lambda1 = lambda2 = 1e-2
+    (src/base_icnf.jl:28-37), everything else 0."""
+    for jl, py in (("λ₁", "lambda1"), ("λ₂", "lambda2"), ("λ₃", "lambda3")):
+        if jl in kw:
+            v = kw.pop(jl)
+            if py == "lambda1": lambda1 = v
+            elif py == "lambda2": lambda2 = v
+            else: lambda3 = v
+    if kw:
+        raise TypeError(f"unknown keyword(s) {sorted(kw)}")
+    if not (isinstance(aicnf, type) and issubclass(aicnf, AbstractICNF)):
+        raise TypeError("first argument must be a model tag such as RNODE or FFJORD")
+    if issubclass(aicnf, _OutOfScope) or cond:
+        raise NotImplementedError(f"{aicnf.__name__}: only the MLP hot path (RNODE, FFJORD) is built")
+    if np.dtype(data_type) != np.float32:
+        raise NotImplementedError("the HIP backend computes in Float32 (the reference default, base_icnf.jl:6)")
+    if compute_mode is None:
+        compute_mode = HIPVecJacMatrixMode()
+    if not isinstance(compute_mode, HIPMatrixMode):
+        raise TypeError("compute_mode must be HIPVecJacMatrixMode() or HIPJacVecMatrixMode()")
+    n_in = nvars + naugmented
+    if nn.dims[0] != n_in or nn.dims[-1] != n_in:
+        raise ValueError(f"nn must map {n_in} -> {n_in} (nvars + naugmented)")
+    rn = issubclass(aicnf, RNODE)
+    if lambda1 is None: lambda1 = 1e-2 if rn else 0.0
+    if lambda2 is None: lambda2 = 1e-2 if rn else 0.0
+    if rng is None:
+        rng = np.random.default_rng()
+    elif isinstance(rng, (int, np.integer)):
+        rng = np.random.default_rng(int(rng))
+    return ICNF(aicnf, nn, int(nvars), int(naugmented), compute_mode, bool(inplace),
+                (float(tspan[0]), float(tspan[1])), float(steer_rate), dict(sol_kwargs or {}), rng,
+                float(np.float32(lambda1)), float(np.float32(lambda2)), float(np.float32(lambda3)),
+                int(device))
+
+
+def steer_tspan(icnf: ICNF, mode):
+    """src/base_icnf.jl:108-121: TrainMode + STEER -> t1' = t1 + |t1 - t0| * r, r ~ U(-s, s)."""
+    t0, t1 = icnf.tspan
+    if icnf.STEER and _mode_id(mode) == _lib.MODE_TRAIN:
+        r = np.float32(icnf.rng.uniform(-icnf.steer_rate, icnf.steer_rate))
+        return (t0, float(np.float32(abs(t1 - t0)) * r + np.float32(t1)))
+    return (t0, t1)
+
+
+# ---------------------------------------------------------------------------------------
+# problem assembly, solve, post-processing
+# ---------------------------------------------------------------------------------------
+@dataclass
+class ODEProblem:
+    """What inference_prob returns in the reference (an SciMLBase.ODEProblem): here the
+    pieces libcnfhip needs."""
+    icnf: ICNF
+    mode: Any
+    u0: _Buf
+    eps: Any          # _Buf or None
+    tspan: tuple
+    ps: Any
+    stats: dict = field(default_factory=dict)
+
+
+def draw_eps(icnf: ICNF, like: _Buf, B: int):
+    """``rand!(icnf.rng, icnf.epsdist, eps)`` (src/base_icnf.jl:277-278): N(0, I) probes."""
+    n_in = icnf.nvars + n_augment_input(icnf)
+    e = icnf.rng.standard_normal((B, n_in)).astype(np.float32).reshape(-1)
+    if like.torch is not None:
+        return _Buf(like.torch.from_numpy(e).to(like.arr.device), n_in, B, like.torch)
+    return _Buf(e, n_in, B, None)
+
+
+def inference_prob(icnf: ICNF, mode, xs, ps, st=None, *, eps=None) -> ODEProblem:
+    """src/base_icnf.jl:266-286.  ``eps`` may be supplied (n_in x B) to make the call
+    deterministic; by default it is drawn from icnf.rng as the reference does."""
+    m = _mode_id(mode)
+    xb = _as_colmajor(xs, icnf.nvars, "xs")
+    B = xb.B
+    D = icnf.nvars + n_augment_input(icnf) + 1 + n_augment(icnf, mode)
+    icnf.set_params(ps)
+    u0 = _empty_like(xb, D, B)
+    if xb.torch is not None:
+        _lib.check(_lib.lib().cnf_build_u0(icnf.handle(), m, xb.ptr, u0.ptr, B, _stream(xb)), icnf.handle())
+    else:
+        v = u0.arr.reshape(B, D)
+        v[:, :icnf.nvars] = xb.arr.reshape(B, icnf.nvars)
+        v[:, icnf.nvars:] = 0.0
+    if eps is not None:
+        eb = _as_colmajor(eps, icnf.nvars + n_augment_input(icnf), "eps")
+        if eb.B != B:
+            raise ValueError("eps must have one column per sample")
+    else:
+        eb = draw_eps(icnf, xb, B)
+    return ODEProblem(icnf, mode, u0, eb, steer_tspan(icnf, mode), ps)
+
+
+def _solve_opts(icnf: ICNF, tspan):
+    kw = dict(icnf.sol_kwargs)
+    kernel = _KERNEL[icnf.compute_mode.kernel]
+    adaptive = bool(kw.pop("adaptive", True))
+    dt = float(kw.pop("dt", 0.0))
+    if not adaptive and dt <= 0:
+        raise ValueError("sol_kwargs: adaptive=false needs dt > 0")
+    opts = _lib.cnf_solve_opts(
+        tspan[0], tspan[1],
+        float(kw.pop("abstol", 1e-6)), float(kw.pop("reltol", 1e-3)),   # OrdinaryDiffEq defaults
+        dt, int(adaptive), int(min(kw.pop("maxiters", 100000), 2**31 - 1)), kernel)
+    for ignored in ("progress", "save_everystep", "alg", "save_start", "save_end", "dense"):
+        kw.pop(ignored, None)
+    if kw:
+        raise TypeError(f"unsupported sol_kwargs {sorted(kw)} (Tsit5 is fixed as the algorithm)")
+    return opts
+
+
+def base_sol(icnf: ICNF, prob: ODEProblem):
+    """src/base_icnf.jl:137-143: solve and return the final ``D x B`` state (what
+    ``get_fsol`` extracts).  The whole Tsit5 solve runs on the device in one C call."""
+    l, h = _lib.lib(), icnf.handle()
+    m = _mode_id(prob.mode)
+    u0 = prob.u0
+    out = _empty_like(u0, u0.rows, u0.B)
+    opts = _solve_opts(icnf, prob.tspan)
+    stats = _lib.cnf_solve_stats()
+    if u0.torch is not None:
+        _lib.check(l.cnf_solve_tsit5(h, m, u0.ptr, prob.eps.ptr if prob.eps else None, out.ptr,
+                                     u0.B, C.byref(opts), C.byref(stats), _stream(u0)), h)
+    else:
+        import torch  # host arrays: stage through device memory held by torch
+        raise_if_no_gpu()
+        dev = torch.device("cuda", icnf.device)
+        du0 = torch.from_numpy(u0.arr).to(dev)
+        deps = torch.from_numpy(prob.eps.arr).to(dev) if prob.eps else None
+        dout = torch.empty_like(du0)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(l.cnf_solve_tsit5(h, m, du0.data_ptr(), deps.data_ptr() if deps is not None else None,
+                                     dout.data_ptr(), u0.B, C.byref(opts), C.byref(stats), st), h)
+        out.arr[:] = dout.cpu().numpy()
+    prob.stats = stats.as_dict()
+    return out
+
+
+def raise_if_no_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X visible: the HIP backend has no CPU fallback")
+
+
+def inference_sol(icnf: ICNF, mode, prob: ODEProblem):
+    """src/base_icnf.jl:167-189: returns ``(logp_x, (E, n, A))``; each entry has B elements."""
+    fsol = base_sol(icnf, prob)
+    return _post(icnf, mode, fsol)
+
+
+def _post(icnf, mode, fsol: _Buf):
+    l, h = _lib.lib(), icnf.handle()
+    m = _mode_id(mode)
+    B = fsol.B
+    if fsol.torch is not None:
+        t = fsol.torch
+        logpx = t.empty(B, dtype=t.float32, device=fsol.arr.device)
+        regs = t.empty(3 * B, dtype=t.float32, device=fsol.arr.device)
+        _lib.check(l.cnf_inference_post(h, m, fsol.ptr, logpx.data_ptr(), regs.data_ptr(), B, _stream(fsol)), h)
+        r = regs.view(3, B)
+    else:
+        import torch
+        raise_if_no_gpu()
+        dev = torch.device("cuda", icnf.device)
+        df = torch.from_numpy(fsol.arr).to(dev)
+        dl = torch.empty(B, dtype=torch.float32, device=dev)
+        dr = torch.empty(3 * B, dtype=torch.float32, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(l.cnf_inference_post(h, m, df.data_ptr(), dl.data_ptr(), dr.data_ptr(), B, st), h)
+        logpx = dl.cpu().numpy()
+        r = dr.cpu().numpy().reshape(3, B)
+    return logpx, (r[0], r[1], r[2])
+
+
+def inference(icnf: ICNF, mode, xs, ps, st=None, *, eps=None):
+    """src/base_icnf.jl:407-415."""
+    prob = inference_prob(icnf, mode, xs, ps, st, eps=eps)
+    res = inference_sol(icnf, mode, prob)
+    icnf.last_stats = prob.stats
+    return res
+
+
+def loss(icnf: ICNF, mode, xs, ps, st=None, *, eps=None):
+    """TrainMode: mean(-logpx + l1 E + l2 n + l3 A) (src/icnf.jl:481-490); otherwise
+    -mean(logpx) (src/base_icnf.jl:489-497).  Single process; the sharded form is
+    ``parallel.distributed_loss``."""
+    logpx, (E, n, A) = inference(icnf, mode, xs, ps, st, eps=eps)
+    sums = loss_sums(icnf, logpx, (E, n, A))
+    return loss_from_sums(icnf, mode, sums)
+
+
+def loss_sums(icnf: ICNF, logpx, regs):
+    """(sum logpx, sum E, sum n, sum A, B) -- the only cross-shard quantity.  Device
+    inputs are reduced on the device (cnf_loss_sums) and stay there."""
+    E, n, A = regs
+    if _is_torch(logpx):
+        import torch
+        B = logpx.numel()
+        r = torch.stack([E, n, A]).contiguous().reshape(-1)
+        out = torch.empty(5, dtype=torch.float32, device=logpx.device)
+        st = C.c_void_p(torch.cuda.current_stream(logpx.device).cuda_stream)
+        _lib.check(_lib.lib().cnf_loss_sums(icnf.handle(), logpx.contiguous().data_ptr(), r.data_ptr(), B,
+                                            out.data_ptr(), st), icnf.handle())
+        return out
+    return np.array([np.sum(logpx, dtype=np.float64), np.sum(E, dtype=np.float64),
+                     np.sum(n, dtype=np.float64), np.sum(A, dtype=np.float64), len(logpx)], dtype=np.float32)
+
+
+def loss_from_sums(icnf: ICNF, mode, sums) -> float:
+    s = sums.detach().cpu().numpy() if _is_torch(sums) else np.asarray(sums)
+    s = np.ascontiguousarray(s, dtype=np.float32)
+    out = C.c_float()
+    _lib.check(_lib.lib().cnf_loss_from_sums(icnf.handle(), _mode_id(mode), s.ctypes.data, C.byref(out)),
+               icnf.handle())
+    return float(out.value)

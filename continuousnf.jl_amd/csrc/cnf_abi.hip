@@ -1,0 +1,619 @@
+// C ABI of libcnfhip.so (see include/cnfhip.h): handle management, parameter upload, the
+// RHS entry point, the on-device Tsit5 driver, post-processing and the loss sums.
+#include "../../include/cnfhip.h"
+#include "cnf_dev.h"
+#include "cnf_kernels.h"
+#include "cnf_mfma.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#define CNF_ABI_VERSION 1
+
+struct cnf_ctx {
+    NetDesc nd{};
+    float lam[3]{};
+    int device = 0;
+    size_t n_params = 0;
+    float* d_params = nullptr;
+    bool have_params = false;
+    MfmaPlan mfma{};              // packed weights etc. for the MFMA path (cnf_mfma.hip)
+
+    // scratch, sized for cap_B samples
+    size_t cap_B = 0;
+    float* arena = nullptr;       // one allocation carved into the buffers below
+    float* ws = nullptr;
+    float* U[2] = {nullptr, nullptr};
+    float* K1[2] = {nullptr, nullptr};
+    float* Ks[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* tmp_logpx = nullptr;
+    float* tmp_regs = nullptr;
+    float* partials = nullptr;    // 2 * MAX_PARTIALS floats
+    StepState* d_state = nullptr;
+    StepState* h_state = nullptr; // pinned, two slots for pipelined polling + one init slot
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::string err;
+};
+
+static const int MAX_PARTIALS = 1024;
+
+#define HIPCHK(h, call)                                                                  \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            char buf_[512];                                                              \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call,                  \
+                     hipGetErrorString(e_), __FILE__, __LINE__);                         \
+            if (h) (h)->err = buf_;                                                      \
+            return CNF_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+static cnf_status fail(cnf_handle h, cnf_status s, const char* msg) {
+    if (h) h->err = msg;
+    return s;
+}
+
+static inline int rows_of(const cnf_ctx* h, int mode) {
+    return h->nd.n_in + 1 + (mode == CNF_MODE_TRAIN ? 2 : 0);
+}
+
+extern "C" const char* cnf_status_string(cnf_status s) {
+    switch (s) {
+        case CNF_OK: return "ok";
+        case CNF_ERR_BAD_ARG: return "bad argument";
+        case CNF_ERR_BAD_SHAPE: return "bad shape";
+        case CNF_ERR_HIP: return "HIP runtime error";
+        case CNF_ERR_NO_DEVICE: return "no gfx950 device";
+        case CNF_ERR_MAXITERS: return "maxiters reached";
+        case CNF_ERR_UNSUPPORTED: return "unsupported configuration";
+        case CNF_ERR_NO_PARAMS: return "parameters not set";
+        case CNF_ERR_NONFINITE: return "non-finite solver state";
+    }
+    return "unknown status";
+}
+
+extern "C" const char* cnf_last_error(cnf_handle h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" int cnf_abi_version(void) { return CNF_ABI_VERSION; }
+extern "C" int cnf_state_rows(cnf_handle h, int mode) { return h ? rows_of(h, mode) : -1; }
+
+// ---------------------------------------------------------------------------------------
+extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
+    if (!out || !cfg || !cfg->dims || !cfg->acts) return CNF_ERR_BAD_ARG;
+    *out = nullptr;
+    if (cfg->n_layers < 1 || cfg->n_layers > CNF_MAX_LAYERS) return CNF_ERR_BAD_SHAPE;
+    if (cfg->nvars < 1 || cfg->naugs < 0) return CNF_ERR_BAD_SHAPE;
+    if (cfg->ad != CNF_AD_VJP && cfg->ad != CNF_AD_JVP) return CNF_ERR_BAD_ARG;
+    const int n_in = cfg->nvars + cfg->naugs;
+    if (cfg->dims[0] != n_in || cfg->dims[cfg->n_layers] != n_in) return CNF_ERR_BAD_SHAPE;
+    for (int l = 0; l <= cfg->n_layers; ++l)
+        if (cfg->dims[l] < 1 || cfg->dims[l] > 4096) return CNF_ERR_BAD_SHAPE;
+    for (int l = 0; l < cfg->n_layers; ++l)
+        if (cfg->acts[l] < CNF_ACT_IDENTITY || cfg->acts[l] > CNF_ACT_ELU) return CNF_ERR_BAD_ARG;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CNF_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return CNF_ERR_BAD_ARG;
+
+    cnf_ctx* h = new (std::nothrow) cnf_ctx();
+    if (!h) return CNF_ERR_BAD_ARG;
+    h->device = cfg->device;
+    NetDesc& nd = h->nd;
+    nd.n_layers = cfg->n_layers;
+    int off = 0, mx = 0, sum = 0;
+    for (int l = 0; l <= cfg->n_layers; ++l) {
+        nd.dims[l] = cfg->dims[l];
+        mx = cfg->dims[l] > mx ? cfg->dims[l] : mx;
+        sum += cfg->dims[l];
+    }
+    for (int l = 0; l < cfg->n_layers; ++l) {
+        nd.acts[l] = cfg->acts[l];
+        nd.w_off[l] = off;
+        off += nd.dims[l] * nd.dims[l + 1];
+        nd.b_off[l] = off;
+        off += nd.dims[l + 1];
+    }
+    h->n_params = (size_t)off;
+    nd.n_in = n_in;
+    nd.nvars = cfg->nvars;
+    nd.naugs = cfg->naugs;
+    nd.norm_z = cfg->lambda1 != 0.f;       // src/base_icnf.jl:48
+    nd.norm_j = cfg->lambda2 != 0.f;       // src/base_icnf.jl:49
+    nd.norm_z_aug = cfg->lambda3 != 0.f;   // src/base_icnf.jl:50
+    nd.jvp = cfg->ad == CNF_AD_JVP;
+    nd.max_dim = mx;
+    nd.sum_dims = sum;
+    h->lam[0] = cfg->lambda1; h->lam[1] = cfg->lambda2; h->lam[2] = cfg->lambda3;
+
+    hipError_t e = hipSetDevice(h->device);
+    if (e == hipSuccess) e = hipMalloc(&h->d_params, h->n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&h->d_state, sizeof(StepState));
+    if (e == hipSuccess) e = hipMalloc(&h->partials, 2 * MAX_PARTIALS * sizeof(float));
+    if (e == hipSuccess) e = hipHostMalloc(&h->h_state, 3 * sizeof(StepState), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[1], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        cnf_destroy(h);
+        return CNF_ERR_HIP;
+    }
+    mfma_plan_init(h->mfma, nd);
+    *out = h;
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_destroy(cnf_handle h) {
+    if (!h) return CNF_ERR_BAD_ARG;
+    (void)hipSetDevice(h->device);
+    mfma_plan_free(h->mfma);
+    if (h->d_params) (void)hipFree(h->d_params);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->d_state) (void)hipFree(h->d_state);
+    if (h->partials) (void)hipFree(h->partials);
+    if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->ev[0]) (void)hipEventDestroy(h->ev[0]);
+    if (h->ev[1]) (void)hipEventDestroy(h->ev[1]);
+    delete h;
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_set_params(cnf_handle h, const float* flat_dev, size_t n, void* stream) {
+    if (!h || !flat_dev) return CNF_ERR_BAD_ARG;
+    if (n != h->n_params) return fail(h, CNF_ERR_BAD_SHAPE, "parameter count does not match the layer sizes");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_params, flat_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    cnf_status ms = mfma_plan_pack(h->mfma, h->nd, h->d_params, s);
+    if (ms != CNF_OK) return fail(h, ms, "MFMA weight packing failed");
+    HIPCHK(h, hipStreamSynchronize(s));
+    h->have_params = true;
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_set_params_host(cnf_handle h, const float* flat, size_t n) {
+    if (!h || !flat) return CNF_ERR_BAD_ARG;
+    if (n != h->n_params) return fail(h, CNF_ERR_BAD_SHAPE, "parameter count does not match the layer sizes");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(h->d_params, flat, n * sizeof(float), hipMemcpyHostToDevice));
+    cnf_status ms = mfma_plan_pack(h->mfma, h->nd, h->d_params, nullptr);
+    if (ms != CNF_OK) return fail(h, ms, "MFMA weight packing failed");
+    HIPCHK(h, hipDeviceSynchronize());
+    h->have_params = true;
+    return CNF_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+static cnf_status ensure_capacity(cnf_handle h, int B) {
+    if ((size_t)B <= h->cap_B) return CNF_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    if (h->arena) { (void)hipFree(h->arena); h->arena = nullptr; h->cap_B = 0; }
+    size_t cap = ((size_t)B + 255) & ~(size_t)255;
+    const size_t Dmax = (size_t)h->nd.n_in + 3;
+    const size_t ws_f = ((size_t)2 * h->nd.sum_dims + (size_t)2 * h->nd.max_dim) * cap;
+    const size_t st_f = Dmax * cap;
+    const size_t total = ws_f + 9 * st_f + 4 * cap;
+    HIPCHK(h, hipMalloc(&h->arena, total * sizeof(float)));
+    float* p = h->arena;
+    h->ws = p; p += ws_f;
+    for (int i = 0; i < 2; ++i) { h->U[i] = p; p += st_f; }
+    for (int i = 0; i < 2; ++i) { h->K1[i] = p; p += st_f; }
+    for (int i = 0; i < 5; ++i) { h->Ks[i] = p; p += st_f; }
+    h->tmp_logpx = p; p += cap;
+    h->tmp_regs = p; p += 3 * cap;
+    h->cap_B = cap;
+    return CNF_OK;
+}
+
+static cnf_status check_call(cnf_handle h, int mode, int B) {
+    if (!h) return CNF_ERR_BAD_ARG;
+    if (mode != CNF_MODE_TEST && mode != CNF_MODE_TRAIN) return fail(h, CNF_ERR_BAD_ARG, "unknown mode");
+    if (B < 0) return fail(h, CNF_ERR_BAD_SHAPE, "negative batch");
+    if (!h->have_params) return fail(h, CNF_ERR_NO_PARAMS, "cnf_set_params has not been called");
+    return CNF_OK;
+}
+
+extern "C" int cnf_kernel_for(cnf_handle h, int mode, int B) {
+    if (!h) return -1;
+    return mfma_supported(h->mfma, h->nd, mode == CNF_MODE_TRAIN, B) ? CNF_KERNEL_MFMA
+                                                                     : CNF_KERNEL_GENERIC;
+}
+
+static cnf_status resolve_kernel(cnf_handle h, int mode, int B, int requested, int* out) {
+    const bool ok = mfma_supported(h->mfma, h->nd, mode == CNF_MODE_TRAIN, B);
+    if (requested == CNF_KERNEL_AUTO) { *out = ok ? CNF_KERNEL_MFMA : CNF_KERNEL_GENERIC; return CNF_OK; }
+    if (requested == CNF_KERNEL_GENERIC) { *out = CNF_KERNEL_GENERIC; return CNF_OK; }
+    if (requested == CNF_KERNEL_MFMA) {
+        if (!ok) return fail(h, CNF_ERR_UNSUPPORTED, "the MFMA path has no kernel for this network/mode");
+        *out = CNF_KERNEL_MFMA;
+        return CNF_OK;
+    }
+    return fail(h, CNF_ERR_BAD_ARG, "unknown kernel selector");
+}
+
+extern "C" cnf_status cnf_rhs_work(cnf_handle h, int mode, int B, double* flops, double* bytes) {
+    if (!h || !flops || !bytes) return CNF_ERR_BAD_ARG;
+    const NetDesc& nd = h->nd;
+    double M = 0, P = 0;
+    for (int l = 0; l < nd.n_layers; ++l) {
+        M += (double)nd.dims[l] * nd.dims[l + 1];
+        P += (double)nd.dims[l] * nd.dims[l + 1] + nd.dims[l + 1];
+    }
+    const double n_in = nd.n_in, D = rows_of(h, mode);
+    if (mode == CNF_MODE_TRAIN) {
+        *flops = B * (4.0 * M + 6.0 * n_in);
+        *bytes = 4.0 * B * (n_in + n_in + D) + 4.0 * P;
+    } else {
+        *flops = B * (2.0 * M + n_in * 2.0 * M);   // forward + n_in tangent sweeps
+        *bytes = 4.0 * B * (n_in + D) + 4.0 * P;
+    }
+    return CNF_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// RHS (a1/a2/a3)
+// ---------------------------------------------------------------------------------------
+extern "C" cnf_status cnf_rhs(cnf_handle h, int mode, int kernel, const float* u,
+                              const float* eps, float* du, int B, void* stream) {
+    cnf_status s = check_call(h, mode, B);
+    if (s != CNF_OK) return s;
+    if (!u || !du) return fail(h, CNF_ERR_BAD_ARG, "null state pointer");
+    if (u == du) return fail(h, CNF_ERR_BAD_ARG, "u and du must not alias");
+    if (mode == CNF_MODE_TRAIN && !eps) return fail(h, CNF_ERR_BAD_ARG, "eps is required in TrainMode");
+    if (B == 0) return CNF_OK;
+    int k;
+    if ((s = resolve_kernel(h, mode, B, kernel, &k)) != CNF_OK) return s;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (k == CNF_KERNEL_MFMA) {
+        s = mfma_rhs(h->mfma, h->nd, mode == CNF_MODE_TRAIN, u, eps, du, B, st);
+        if (s != CNF_OK) return fail(h, s, "MFMA RHS launch failed");
+    } else {
+        if ((s = ensure_capacity(h, B)) != CNF_OK) return s;
+        RhsArgs a{};
+        a.st = nullptr; a.B = B; a.S = h->cap_B; a.train = mode == CNF_MODE_TRAIN;
+        a.ws = h->ws; a.eps = eps; a.u = u; a.du = du; a.nk = 0;
+        launch_rhs_generic(h->nd, h->d_params, a, st);
+    }
+    HIPCHK(h, hipGetLastError());
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_rhs_host(cnf_handle h, int mode, int kernel, const float* u,
+                                   const float* eps, float* du, int B) {
+    cnf_status s = check_call(h, mode, B);
+    if (s != CNF_OK) return s;
+    if (!u || !du) return fail(h, CNF_ERR_BAD_ARG, "null state pointer");
+    if (B == 0) return CNF_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t D = rows_of(h, mode), n_in = h->nd.n_in;
+    float *du_d = nullptr, *u_d = nullptr, *e_d = nullptr;
+    HIPCHK(h, hipMalloc(&u_d, D * B * sizeof(float)));
+    HIPCHK(h, hipMalloc(&du_d, D * B * sizeof(float)));
+    HIPCHK(h, hipMemcpy(u_d, u, D * B * sizeof(float), hipMemcpyHostToDevice));
+    if (eps) {
+        HIPCHK(h, hipMalloc(&e_d, n_in * B * sizeof(float)));
+        HIPCHK(h, hipMemcpy(e_d, eps, n_in * B * sizeof(float), hipMemcpyHostToDevice));
+    }
+    s = cnf_rhs(h, mode, kernel, u_d, e_d, du_d, B, nullptr);
+    if (s == CNF_OK) {
+        hipError_t e = hipMemcpy(du, du_d, D * B * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(u_d); (void)hipFree(du_d);
+    if (e_d) (void)hipFree(e_d);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------
+// Tsit5 driver (a7: base_sol, src/base_icnf.jl:137-143)
+// ---------------------------------------------------------------------------------------
+static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, int B,
+                                    int nblk, hipStream_t s) {
+    RhsArgs a{};
+    a.st = h->d_state; a.B = B; a.S = h->cap_B; a.train = train; a.ws = h->ws; a.eps = eps;
+    for (int i = 0; i < 2; ++i) { a.U[i] = h->U[i]; a.K1[i] = h->K1[i]; }
+    for (int i = 0; i < 5; ++i) a.Ks[i] = h->Ks[i];
+    for (int stage = 1; stage <= 6; ++stage) {      // computes k_{stage+1}
+        a.nk = stage;
+        tsit5_row(stage, a.coef);
+        a.ustage = nullptr;
+        a.ustage_is_unew = stage == 6;
+        a.du_is_k7 = stage == 6;
+        a.du = stage < 6 ? h->Ks[stage - 1] : nullptr;
+        launch_rhs_generic(h->nd, h->d_params, a, s);
+    }
+    NormArgs n{};
+    n.st = h->d_state; n.kind = 2; n.n = (size_t)rows_of(h, train) * B;
+    for (int i = 0; i < 2; ++i) { n.U[i] = h->U[i]; n.K1[i] = h->K1[i]; }
+    for (int i = 0; i < 5; ++i) n.Ks[i] = h->Ks[i];
+    n.partials = h->partials;
+    launch_norm_partials(n, nblk, s);
+    launch_controller(h->d_state, h->partials, 2, (float)n.n, s);
+}
+
+extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
+                                      const float* eps, float* u_out, int B,
+                                      const cnf_solve_opts* opts, cnf_solve_stats* stats,
+                                      void* stream) {
+    cnf_status s = check_call(h, mode, B);
+    if (s != CNF_OK) return s;
+    if (!u0 || !u_out || !opts) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    const int train = mode == CNF_MODE_TRAIN;
+    if (train && !eps) return fail(h, CNF_ERR_BAD_ARG, "eps is required in TrainMode");
+    if (!(opts->t0 == opts->t0) || !(opts->t1 == opts->t1) || opts->t0 == opts->t1)
+        return fail(h, CNF_ERR_BAD_ARG, "empty or NaN time span");
+    if (!opts->adaptive && !(opts->dt > 0.f)) return fail(h, CNF_ERR_BAD_ARG, "fixed stepping needs dt > 0");
+    if (opts->adaptive && (!(opts->abstol >= 0.f) || !(opts->reltol >= 0.f) || (opts->abstol == 0.f && opts->reltol == 0.f)))
+        return fail(h, CNF_ERR_BAD_ARG, "bad tolerances");
+    if (opts->dt < 0.f) return fail(h, CNF_ERR_BAD_ARG, "dt must be >= 0 (direction comes from the span)");
+    if (opts->maxiters < 1) return fail(h, CNF_ERR_BAD_ARG, "maxiters must be >= 1");
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (B == 0) return CNF_OK;
+    int k;
+    if ((s = resolve_kernel(h, mode, B, opts->kernel, &k)) != CNF_OK) return s;
+    if ((s = ensure_capacity(h, B)) != CNF_OK) return s;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int D = rows_of(h, mode);
+    const size_t n = (size_t)D * B;
+    int launches = 0;
+
+    int nblk = (int)((n + 255) / 256);
+    if (nblk > 256) nblk = 256;
+
+    // initial state
+    StepState* init = &h->h_state[2];
+    memset(init, 0, sizeof *init);
+    init->t = init->t0 = opts->t0;
+    init->t1 = opts->t1;
+    init->tdir = opts->t1 >= opts->t0 ? 1.f : -1.f;
+    init->dt = opts->dt;
+    init->qold = 1e-4f;
+    init->abstol = opts->abstol; init->reltol = opts->reltol;
+    init->adaptive = opts->adaptive ? 1 : 0;
+    init->n_partials = nblk;
+    {
+        float rem = fabsf(init->t1 - init->t);
+        float hh = init->dt < rem ? init->dt : rem;
+        init->h = init->tdir * hh;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_state, init, sizeof(StepState), hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+
+    const bool use_mfma = k == CNF_KERNEL_MFMA;
+    // k1 = f(u0)
+    if (use_mfma) {
+        s = mfma_rhs(h->mfma, h->nd, train, h->U[0], eps, h->K1[0], B, st);
+        if (s != CNF_OK) return fail(h, s, "MFMA RHS launch failed");
+    } else {
+        RhsArgs a{};
+        a.B = B; a.S = h->cap_B; a.train = train; a.ws = h->ws; a.eps = eps;
+        a.u = h->U[0]; a.du = h->K1[0];
+        launch_rhs_generic(h->nd, h->d_params, a, st);
+    }
+    launches += 1;
+    int nf = 1;
+
+    NormArgs na{};
+    na.st = h->d_state; na.n = n; na.partials = h->partials;
+    for (int i = 0; i < 2; ++i) { na.U[i] = h->U[i]; na.K1[i] = h->K1[i]; }
+    for (int i = 0; i < 5; ++i) na.Ks[i] = h->Ks[i];
+
+    if (opts->adaptive && opts->dt == 0.f) {
+        // automatic initial dt (Hairer; OrdinaryDiffEq's ode_determine_initdt, third party)
+        na.kind = 0;
+        launch_norm_partials(na, nblk, st);
+        launch_controller(h->d_state, h->partials, 0, (float)n, st);
+        // f1 = f(u0 + h*f0) -> Ks[0]
+        if (use_mfma) {
+            s = mfma_rhs_stage(h->mfma, h->nd, train, h->d_state, h->U, h->K1, h->Ks, eps, 1, B, st);
+            if (s != CNF_OK) return fail(h, s, "MFMA RHS launch failed");
+        } else {
+            RhsArgs a{};
+            a.st = h->d_state; a.B = B; a.S = h->cap_B; a.train = train; a.ws = h->ws; a.eps = eps;
+            for (int i = 0; i < 2; ++i) { a.U[i] = h->U[i]; a.K1[i] = h->K1[i]; }
+            for (int i = 0; i < 5; ++i) a.Ks[i] = h->Ks[i];
+            a.nk = 1; a.coef[0] = 1.f; a.du = h->Ks[0];
+            launch_rhs_generic(h->nd, h->d_params, a, st);
+        }
+        na.kind = 1;
+        launch_norm_partials(na, nblk, st);
+        launch_controller(h->d_state, h->partials, 1, (float)n, st);
+        launches += 5;
+        nf += 1;
+    }
+    HIPCHK(h, hipGetLastError());
+
+    // attempts, enqueued in chunks; the device-side controller decides accept/reject and
+    // the next dt, the host only polls `done` one chunk behind the GPU.
+    long expected = opts->maxiters;
+    if (!opts->adaptive) {
+        double ns = std::ceil(std::fabs((double)opts->t1 - (double)opts->t0) / (double)opts->dt - 1e-6);
+        expected = (long)ns;
+        if (expected < 1) expected = 1;
+    }
+    const int chunk = opts->adaptive ? 4 : (int)(expected < 64 ? expected : 64);
+    long attempts = 0;
+    int slot = 0;
+    bool pending[2] = {false, false};
+    bool done = false;
+    StepState fin{};
+    while (!done) {
+        if (attempts >= (long)opts->maxiters) {
+            HIPCHK(h, hipStreamSynchronize(st));
+            return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
+        }
+        long todo = chunk;
+        if (!opts->adaptive) todo = attempts >= expected ? 1 : (expected - attempts < todo ? expected - attempts : todo);
+        if (attempts + todo > (long)opts->maxiters) todo = (long)opts->maxiters - attempts;
+        for (long i = 0; i < todo; ++i) {
+            if (use_mfma) {
+                s = mfma_step(h->mfma, h->nd, train, h->d_state, h->U, h->K1, h->Ks, eps,
+                              h->partials, B, st);
+                if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
+                launches += mfma_step_launches();
+            } else {
+                enqueue_attempt_generic(h, train, eps, B, nblk, st);
+                launches += 8;
+            }
+        }
+        attempts += todo;
+        HIPCHK(h, hipMemcpyAsync(&h->h_state[slot], h->d_state, sizeof(StepState), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipEventRecord(h->ev[slot], st));
+        pending[slot] = true;
+        // poll one chunk behind the GPU; wait for the chunk just enqueued only when no
+        // further run-ahead is useful (fixed dt: all expected steps are in flight)
+        const bool wait_current = (!opts->adaptive && attempts >= expected) || attempts >= (long)opts->maxiters;
+        if (pending[slot ^ 1]) {
+            HIPCHK(h, hipEventSynchronize(h->ev[slot ^ 1]));
+            pending[slot ^ 1] = false;
+            fin = h->h_state[slot ^ 1];
+            done = fin.done != 0;
+        }
+        if (!done && wait_current) {
+            HIPCHK(h, hipEventSynchronize(h->ev[slot]));
+            pending[slot] = false;
+            fin = h->h_state[slot];
+            done = fin.done != 0;
+        }
+        slot ^= 1;
+    }
+    // drain a possibly outstanding newer chunk (its kernels early-exit once done is set)
+    for (int i = 0; i < 2; ++i)
+        if (pending[i]) {
+            HIPCHK(h, hipEventSynchronize(h->ev[i]));
+            fin = h->h_state[i];
+        }
+    launch_copy_final(h->d_state, h->U[0], h->U[1], u_out, n, st);
+    launches += 1;
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(st));
+    nf += 6 * (fin.naccept + fin.nreject);
+    if (stats) {
+        stats->nf = nf;
+        stats->naccept = fin.naccept;
+        stats->nreject = fin.nreject;
+        stats->t_final = fin.t;
+        stats->dt_last = fin.dt;
+        stats->kernel_used = k;
+        stats->launches = launches;
+    }
+    if (fin.nonfinite) return fail(h, CNF_ERR_NONFINITE, "solver state became NaN/Inf");
+    return CNF_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// assembly / post-processing / loss (a6, a8, a9)
+// ---------------------------------------------------------------------------------------
+extern "C" cnf_status cnf_build_u0(cnf_handle h, int mode, const float* xs, float* u0, int B,
+                                   void* stream) {
+    if (!h || !xs || !u0) return CNF_ERR_BAD_ARG;
+    if (mode != CNF_MODE_TEST && mode != CNF_MODE_TRAIN) return fail(h, CNF_ERR_BAD_ARG, "unknown mode");
+    if (B < 0) return fail(h, CNF_ERR_BAD_SHAPE, "negative batch");
+    if (B == 0) return CNF_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_build_u0(xs, u0, h->nd.nvars, rows_of(h, mode), B, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_inference_post(cnf_handle h, int mode, const float* u_final,
+                                         float* logpx, float* regs, int B, void* stream) {
+    if (!h || !u_final || !logpx || !regs) return CNF_ERR_BAD_ARG;
+    if (mode != CNF_MODE_TEST && mode != CNF_MODE_TRAIN) return fail(h, CNF_ERR_BAD_ARG, "unknown mode");
+    if (B < 0) return fail(h, CNF_ERR_BAD_SHAPE, "negative batch");
+    if (B == 0) return CNF_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_post(h->nd, mode == CNF_MODE_TRAIN, u_final, logpx, regs, B, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_inference(cnf_handle h, int mode, const float* xs, const float* eps,
+                                    float* logpx, float* regs, float* u_final, int B,
+                                    const cnf_solve_opts* opts, cnf_solve_stats* stats,
+                                    void* stream) {
+    cnf_status s = check_call(h, mode, B);
+    if (s != CNF_OK) return s;
+    if (!xs || !logpx || !regs || !opts) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (B == 0) return CNF_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t D = rows_of(h, mode);
+    float* buf = u_final;
+    float* owned = nullptr;
+    if (!buf) {
+        HIPCHK(h, hipMalloc(&owned, 2 * D * B * sizeof(float)));
+        buf = owned;
+    }
+    float* u0 = nullptr;
+    float* u0_owned = nullptr;
+    if (owned) u0 = owned + D * B;
+    else { HIPCHK(h, hipMalloc(&u0_owned, D * B * sizeof(float))); u0 = u0_owned; }
+    s = cnf_build_u0(h, mode, xs, u0, B, stream);
+    if (s == CNF_OK) s = cnf_solve_tsit5(h, mode, u0, eps, buf, B, opts, stats, stream);
+    if (s == CNF_OK) s = cnf_inference_post(h, mode, buf, logpx, regs, B, stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (owned) (void)hipFree(owned);
+    if (u0_owned) (void)hipFree(u0_owned);
+    if (s == CNF_OK && e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
+    return s;
+}
+
+extern "C" cnf_status cnf_inference_host(cnf_handle h, int mode, const float* xs,
+                                         const float* eps, float* logpx, float* regs,
+                                         float* u_final, int B, const cnf_solve_opts* opts,
+                                         cnf_solve_stats* stats) {
+    cnf_status s = check_call(h, mode, B);
+    if (s != CNF_OK) return s;
+    if (!xs || !logpx || !regs || !opts) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    if (B == 0) { if (stats) memset(stats, 0, sizeof *stats); return CNF_OK; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t D = rows_of(h, mode), n_in = h->nd.n_in, nv = h->nd.nvars;
+    float *xs_d = nullptr, *e_d = nullptr, *out_d = nullptr;
+    const size_t out_f = (size_t)B * (4 + D);
+    HIPCHK(h, hipMalloc(&xs_d, nv * B * sizeof(float)));
+    HIPCHK(h, hipMalloc(&out_d, out_f * sizeof(float)));
+    HIPCHK(h, hipMemcpy(xs_d, xs, nv * B * sizeof(float), hipMemcpyHostToDevice));
+    if (eps) {
+        HIPCHK(h, hipMalloc(&e_d, n_in * B * sizeof(float)));
+        HIPCHK(h, hipMemcpy(e_d, eps, n_in * B * sizeof(float), hipMemcpyHostToDevice));
+    }
+    float* lp = out_d; float* rg = out_d + B; float* uf = out_d + 4 * (size_t)B;
+    s = cnf_inference(h, mode, xs_d, e_d, lp, rg, uf, B, opts, stats, nullptr);
+    if (s == CNF_OK) {
+        hipError_t e = hipMemcpy(logpx, lp, (size_t)B * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(regs, rg, 3 * (size_t)B * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && u_final) e = hipMemcpy(u_final, uf, D * B * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(xs_d); (void)hipFree(out_d);
+    if (e_d) (void)hipFree(e_d);
+    return s;
+}
+
+extern "C" cnf_status cnf_loss_sums(cnf_handle h, const float* logpx, const float* regs, int B,
+                                    float* sums5, void* stream) {
+    if (!h || !logpx || !regs || !sums5) return CNF_ERR_BAD_ARG;
+    if (B < 0) return fail(h, CNF_ERR_BAD_SHAPE, "negative batch");
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_loss_sums(logpx, regs, B, sums5, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_loss_from_sums(cnf_handle h, int mode, const float* sums5, float* loss) {
+    if (!h || !sums5 || !loss) return CNF_ERR_BAD_ARG;
+    const double cnt = sums5[4];
+    if (!(cnt > 0)) return fail(h, CNF_ERR_BAD_SHAPE, "empty batch");
+    if (mode == CNF_MODE_TRAIN)      // src/icnf.jl:489
+        *loss = (float)((-(double)sums5[0] + (double)h->lam[0] * sums5[1] + (double)h->lam[1] * sums5[2] +
+                         (double)h->lam[2] * sums5[3]) / cnt);
+    else                             // src/base_icnf.jl:496
+        *loss = (float)(-(double)sums5[0] / cnt);
+    return CNF_OK;
+}

@@ -1,0 +1,118 @@
+// Shared device/host definitions for libcnfhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CNF_MAX_LAYERS 8
+
+// Network description, passed to kernels by value (kernarg segment -> scalar loads).
+struct NetDesc {
+    int n_layers;
+    int dims[CNF_MAX_LAYERS + 1];   // n_in, h1, ..., n_out
+    int acts[CNF_MAX_LAYERS];
+    int w_off[CNF_MAX_LAYERS];      // float offset of layer l's weight in the flat vector
+    int b_off[CNF_MAX_LAYERS];      // float offset of layer l's bias
+    int n_in;                       // nvars + naugs
+    int nvars, naugs;
+    int norm_z, norm_j, norm_z_aug; // !iszero(lambda) (src/base_icnf.jl:42-51)
+    int jvp;                        // 0: VJP (DIVecJacMatrixMode), 1: JVP (DIJacVecMatrixMode)
+    int max_dim, sum_dims;          // max_l dims[l]; sum_{l=0..L} dims[l]
+};
+
+// Device-resident integrator state: lets the step controller run on the GPU so that a
+// solve needs no host round trip per step.
+struct StepState {
+    float t, dt, qold;      // current time, proposed step size (>0), PI controller memory
+    float t0, t1, tdir;     // span and direction (+1/-1)
+    float h;                // signed step of the attempt in flight (clipped to t1)
+    float abstol, reltol;
+    float eest;             // last error estimate
+    float d0, d1;           // initial-dt intermediates
+    int adaptive;
+    int cur;                // which of the two (u, k1) buffer sets holds the current state
+    int done;               // reached t1
+    int naccept, nreject;
+    int nonfinite;
+    int n_partials;         // entries of the error-partials array
+};
+
+// Tsit5 (Tsitouras 2011); same digits as oracle/cnf_oracle.py.
+#define TS_A21 0.161f
+#define TS_A31 -0.008480655492356989f
+#define TS_A32 0.335480655492357f
+#define TS_A41 2.8971530571054935f
+#define TS_A42 -6.359448489975075f
+#define TS_A43 4.3622954328695815f
+#define TS_A51 5.325864828439257f
+#define TS_A52 -11.748883564062828f
+#define TS_A53 7.4955393428898365f
+#define TS_A54 -0.09249506636175525f
+#define TS_A61 5.86145544294642f
+#define TS_A62 -12.92096931784711f
+#define TS_A63 8.159367898576159f
+#define TS_A64 -0.071584973281401f
+#define TS_A65 -0.028269050394068383f
+#define TS_A71 0.09646076681806523f
+#define TS_A72 0.01f
+#define TS_A73 0.4798896504144996f
+#define TS_A74 1.379008574103742f
+#define TS_A75 -3.290069515436081f
+#define TS_A76 2.324710524099774f
+#define TS_BT1 -0.00178001105222577714f
+#define TS_BT2 -0.0008164344596567469f
+#define TS_BT3 0.007880878010261995f
+#define TS_BT4 -0.1447110071732629f
+#define TS_BT5 0.5823571654525552f
+#define TS_BT6 -0.45808210592918697f
+#define TS_BT7 0.015151515151515152f
+
+// Tsit5 stage coefficient row s (0-based stage index 1..6 -> a_{s+1, 1..s}).
+__host__ __device__ inline void tsit5_row(int s, float* a) {
+    const float A[7][6] = {
+        {0, 0, 0, 0, 0, 0},
+        {TS_A21, 0, 0, 0, 0, 0},
+        {TS_A31, TS_A32, 0, 0, 0, 0},
+        {TS_A41, TS_A42, TS_A43, 0, 0, 0},
+        {TS_A51, TS_A52, TS_A53, TS_A54, 0, 0},
+        {TS_A61, TS_A62, TS_A63, TS_A64, TS_A65, 0},
+        {TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76}};
+    for (int j = 0; j < 6; ++j) a[j] = A[s][j];
+}
+
+#ifdef __HIPCC__
+// ---- activations: value and derivative w.r.t. the pre-activation ------------------------
+__device__ __forceinline__ float cnf_sigmoid(float a) { return 1.0f / (1.0f + __expf(-a)); }
+
+// tanh accurate to ~2 ulp over the whole range without the cancellation of
+// 1 - 2/(exp(2a)+1) near 0 (needed: outputs are compared at 1e-4 relative).
+__device__ __forceinline__ float cnf_tanh(float a) {
+    float x = fabsf(a);
+    float r;
+    if (x < 0.3f) {
+                float x2 = x * x;
+        // tanh(x) = x * (1 + x2*p(x2)) ; Taylor up to x^11 (truncation < 2e-9 rel for x<0.3)
+        float p = -0.0088632355f;                  // -1382/155925
+        p = fmaf(p, x2, 0.021869488f);             // 62/2835
+        p = fmaf(p, x2, -0.053968254f);            // -17/315
+        p = fmaf(p, x2, 0.13333333f);              // 2/15
+        p = fmaf(p, x2, -0.33333334f);             // -1/3
+        r = fmaf(x * x2, p, x);
+    } else {
+        float e = __expf(2.0f * x);                // v_exp_f32 path
+        r = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+    }
+    return copysignf(r, a);
+}
+
+__device__ __forceinline__ void cnf_act(int kind, float a, float& h, float& d) {
+    switch (kind) {
+        case 0: h = a; d = 1.0f; break;
+        case 1: h = cnf_tanh(a); d = fmaf(-h, h, 1.0f); break;
+        case 2: { float s = cnf_sigmoid(a); h = s; d = s * (1.0f - s); } break;
+        case 3: { h = (a > 15.0f) ? a : log1pf(__expf(a)); d = cnf_sigmoid(a); } break;
+        case 4: h = fmaxf(a, 0.0f); d = (a > 0.0f) ? 1.0f : 0.0f; break;
+        case 5: { float s = cnf_sigmoid(a); h = a * s; d = s * (1.0f + a * (1.0f - s)); } break;
+        default: { float e = __expf(fminf(a, 0.0f)); h = (a > 0.0f) ? a : e - 1.0f; d = (a > 0.0f) ? 1.0f : e; } break;
+    }
+}
+#endif

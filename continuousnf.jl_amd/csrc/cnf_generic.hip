@@ -1,0 +1,488 @@
+// Generic (any layer sizes, any activation) kernels of libcnfhip: one lane per sample,
+// activations in an HBM/L2 workspace laid out feature-major ([feature][sample], so a
+// wave's 64 lanes read 64 consecutive floats), weights read through scalar loads (they are
+// wave-uniform).  This is the shape-agnostic path; the MFMA path (cnf_mfma.hip) takes over
+// for the layer sizes it is built for.  Also here: the Tsit5 bookkeeping kernels shared by
+// both paths (error norms, on-device step controller, post-processing, loss sums).
+//
+// Reference functions restated (file:line under /root/reference):
+//   augmented_f Matrix/Train/VJP  src/icnf.jl:318-350     Matrix/Train/JVP  src/icnf.jl:384-420
+//   augmented_f Matrix/Test       src/icnf.jl:148-164  +  jacobian_batched  src/utils.jl:1-36
+//   inference_sol                 src/base_icnf.jl:167-189      loss  src/icnf.jl:481-490
+#include "cnf_dev.h"
+#include "cnf_kernels.h"
+
+// ---------------------------------------------------------------------------------------
+// dense layer helpers (lane = sample b; W is out x in, column-major: W[o + k*out])
+// ---------------------------------------------------------------------------------------
+// y[o] = sum_k W[o,k] x[k]   for o in [0,out), written via `emit(o, acc)`
+template <typename Emit>
+__device__ __forceinline__ void gemv_fwd(const float* __restrict__ W, int out, int in,
+                                         const float* __restrict__ x, size_t xs, Emit emit) {
+    int o = 0;
+    for (; o + 4 <= out; o += 4) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int k = 0; k < in; ++k) {
+            float xv = x[(size_t)k * xs];
+            const float* w = W + o + (size_t)k * out;
+            a0 = fmaf(w[0], xv, a0); a1 = fmaf(w[1], xv, a1);
+            a2 = fmaf(w[2], xv, a2); a3 = fmaf(w[3], xv, a3);
+        }
+        emit(o, a0); emit(o + 1, a1); emit(o + 2, a2); emit(o + 3, a3);
+    }
+    for (; o < out; ++o) {
+        float a = 0.f;
+        for (int k = 0; k < in; ++k) a = fmaf(W[o + (size_t)k * out], x[(size_t)k * xs], a);
+        emit(o, a);
+    }
+}
+// y[k] = sum_o W[o,k] g[o]   for k in [0,in)
+template <typename Emit>
+__device__ __forceinline__ void gemv_bwd(const float* __restrict__ W, int out, int in,
+                                         const float* __restrict__ g, size_t gs, Emit emit) {
+    int k = 0;
+    for (; k + 4 <= in; k += 4) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float* w0 = W + (size_t)k * out;
+        for (int o = 0; o < out; ++o) {
+            float gv = g[(size_t)o * gs];
+            a0 = fmaf(w0[o], gv, a0); a1 = fmaf(w0[o + out], gv, a1);
+            a2 = fmaf(w0[o + 2 * out], gv, a2); a3 = fmaf(w0[o + 3 * out], gv, a3);
+        }
+        emit(k, a0); emit(k + 1, a1); emit(k + 2, a2); emit(k + 3, a3);
+    }
+    for (; k < in; ++k) {
+        float a = 0.f;
+        const float* w0 = W + (size_t)k * out;
+        for (int o = 0; o < out; ++o) a = fmaf(w0[o], g[(size_t)o * gs], a);
+        emit(k, a);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// RHS, generic.  Optional fused Tsit5 stage prologue:
+//   u_stage = u + h * sum_j coef[j] * k_j   (nk = 0: u_stage = u)
+// ws layout (floats, S = padded sample count of the launch):
+//   H  : sum_dims * S   activations h_0..h_L       (h_l at hoff[l]*S)
+//   Dv : sum_dims * S   sigma'(a_l) for l = 1..L   (same offsets, slot 0 unused)
+//   G  : 2*max_dim * S  ping-pong cotangent / tangent
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_rhs_generic(NetDesc nd, const float* __restrict__ P, RhsArgs a) {
+    const StepState* st = a.st;
+    if (st && st->done) return;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int train = a.train;
+    const int n_in = nd.n_in;
+    const int D = n_in + 1 + (train ? 2 : 0);
+    const size_t S = a.S;
+    const int L = nd.n_layers;
+    float* H = a.ws;
+    float* Dv = a.ws + (size_t)nd.sum_dims * S;
+    float* G0 = Dv + (size_t)nd.sum_dims * S;
+    float* G1 = G0 + (size_t)nd.max_dim * S;
+
+    // ---- prologue: stage state ------------------------------------------------------
+    const float* u;
+    const float* kb[6];
+    float hstep = 0.f;
+    if (st) {
+        const int cur = st->cur;
+        u = a.U[cur];
+        kb[0] = a.K1[cur];
+        for (int j = 1; j < 6; ++j) kb[j] = a.Ks[j - 1];
+        hstep = st->h;
+    } else {
+        u = a.u;
+    }
+    float* ust = a.ustage;
+    if (st && a.ustage_is_unew) ust = a.U[1 - st->cur];
+    for (int r = 0; r < D; ++r) {
+        float v = u[(size_t)b * D + r];
+        if (a.nk > 0) {
+            float acc = 0.f;
+            for (int j = 0; j < a.nk; ++j) acc = fmaf(a.coef[j], kb[j][(size_t)b * D + r], acc);
+            v = fmaf(hstep, acc, v);
+        }
+        if (r < n_in) H[(size_t)r * S + b] = v;
+        if (ust) ust[(size_t)b * D + r] = v;
+    }
+
+    // ---- forward (a5: snn(z), src/icnf.jl:329,331) -------------------------------------
+    int hoff = 0;
+    for (int l = 0; l < L; ++l) {
+        const int in = nd.dims[l], out = nd.dims[l + 1];
+        const float* W = P + nd.w_off[l];
+        const float* bias = P + nd.b_off[l];
+        const float* x = H + (size_t)hoff * S + b;
+        float* y = H + (size_t)(hoff + in) * S + b;
+        float* dv = Dv + (size_t)(hoff + in) * S + b;
+        const int act = nd.acts[l];
+        gemv_fwd(W, out, in, x, S, [&](int o, float acc) {
+            float h, d;
+            cnf_act(act, acc + bias[o], h, d);
+            y[(size_t)o * S] = h;
+            dv[(size_t)o * S] = d;
+        });
+        hoff += in;
+    }
+    const float* zdot = H + (size_t)hoff * S + b;   // h_L, n_in entries
+    const int hoffL = hoff;
+
+    float* du = a.du;
+    if (st && a.du_is_k7) du = a.K1[1 - st->cur];
+    float* dub = du + (size_t)b * D;
+
+    float ldot = 0.f, nsq = 0.f, esq = 0.f;
+    for (int i = 0; i < n_in; ++i) {
+        float v = zdot[(size_t)i * S];
+        dub[i] = v;
+        esq = fmaf(v, v, esq);
+    }
+
+    if (train) {
+        const float* eps = a.eps + (size_t)b * n_in;
+        if (!nd.jvp) {
+            // ---- VJP sweep: g_L = eps .* d_L; g_{l-1} = (W_l^T g_l) .* d_{l-1}; eJ = W_1^T g_1
+            float* g = G0 + b;
+            float* gn = G1 + b;
+            {
+                const float* dv = Dv + (size_t)hoffL * S + b;
+                for (int i = 0; i < n_in; ++i) g[(size_t)i * S] = eps[i] * dv[(size_t)i * S];
+            }
+            int ho = hoffL;
+            for (int l = L - 1; l >= 0; --l) {
+                const int in = nd.dims[l], out = nd.dims[l + 1];
+                const float* W = P + nd.w_off[l];
+                ho -= in;  // offset of h_l's input = h_{l}
+                const float* dprev = Dv + (size_t)ho * S + b;  // sigma' of layer l-1's output (l>0)
+                if (l > 0) {
+                    gemv_bwd(W, out, in, g, S, [&](int k, float acc) {
+                        gn[(size_t)k * S] = acc * dprev[(size_t)k * S];
+                    });
+                    float* t = g; g = gn; gn = t;
+                } else {
+                    gemv_bwd(W, out, in, g, S, [&](int k, float acc) {
+                        ldot = fmaf(-acc, eps[k], ldot);     // icnf.jl:334
+                        nsq = fmaf(acc, acc, nsq);           // icnf.jl:343
+                    });
+                }
+            }
+        } else {
+            // ---- JVP sweep: tau_0 = eps; tau_l = d_l .* (W_l tau_{l-1}); J eps = tau_L
+            float* tg = G0 + b;
+            float* tn = G1 + b;
+            for (int i = 0; i < n_in; ++i) tg[(size_t)i * S] = eps[i];
+            int ho = 0;
+            for (int l = 0; l < L; ++l) {
+                const int in = nd.dims[l], out = nd.dims[l + 1];
+                const float* W = P + nd.w_off[l];
+                const float* dv = Dv + (size_t)(ho + in) * S + b;
+                if (l < L - 1) {
+                    gemv_fwd(W, out, in, tg, S, [&](int o, float acc) {
+                        tn[(size_t)o * S] = acc * dv[(size_t)o * S];
+                    });
+                    float* t = tg; tg = tn; tn = t;
+                } else {
+                    gemv_fwd(W, out, in, tg, S, [&](int o, float acc) {
+                        float je = acc * dv[(size_t)o * S];
+                        ldot = fmaf(-je, eps[o], ldot);      // icnf.jl:404
+                        nsq = fmaf(je, je, nsq);             // icnf.jl:413
+                    });
+                }
+                ho += in;
+            }
+        }
+        dub[n_in] = ldot;
+        dub[n_in + 1] = nd.norm_z ? sqrtf(esq) : 0.f;         // icnf.jl:335-341
+        dub[n_in + 2] = nd.norm_j ? sqrtf(nsq) : 0.f;         // icnf.jl:342-348
+    } else {
+        // ---- exact trace (a3/a4): n_in one-hot tangent sweeps, tr J = sum_i (J e_i)_i.
+        // (utils.jl:19-36 fills column i from the pushforward of e_i; the pullback form
+        // utils.jl:1-17 gives the same diagonal.)  J is never materialised.
+        float tr = 0.f;
+        for (int i = 0; i < n_in; ++i) {
+            float* tg = G0 + b;
+            float* tn = G1 + b;
+            int ho = 0;
+            for (int l = 0; l < L; ++l) {
+                const int in = nd.dims[l], out = nd.dims[l + 1];
+                const float* W = P + nd.w_off[l];
+                const float* dv = Dv + (size_t)(ho + in) * S + b;
+                if (l == 0) {
+                    // tau_0 = e_i  ->  W_1 e_i = column i of W_1
+                    if (L == 1) {
+                        tr = fmaf(W[i + (size_t)i * out], dv[(size_t)i * S], tr);
+                    } else {
+                        for (int o = 0; o < out; ++o)
+                            tn[(size_t)o * S] = W[o + (size_t)i * out] * dv[(size_t)o * S];
+                    }
+                } else if (l < L - 1) {
+                    gemv_fwd(W, out, in, tg, S, [&](int o, float acc) {
+                        tn[(size_t)o * S] = acc * dv[(size_t)o * S];
+                    });
+                } else {
+                    // only output row i is needed
+                    float acc = 0.f;
+                    for (int k = 0; k < in; ++k) acc = fmaf(W[i + (size_t)k * out], tg[(size_t)k * S], acc);
+                    tr = fmaf(acc, dv[(size_t)i * S], tr);
+                }
+                float* t = tg; tg = tn; tn = t;
+                ho += in;
+            }
+        }
+        dub[n_in] = -tr;                                       // icnf.jl:162
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// block reduction helper (256 threads), deterministic order
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sm[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += sm[i];
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// squared-norm partials over all D*B entries.
+//  kind 0 (init A):  p0 = sum (u/sk)^2, p1 = sum (f0/sk)^2, sk = abstol + |u| reltol
+//  kind 1 (init B):  p0 = sum ((f1 - f0)/sk)^2
+//  kind 2 (step)  :  p0 = sum (err/sc)^2, err = h*sum_j btilde_j k_j,
+//                    sc = abstol + max(|u|,|u_new|) reltol;  p1 = nonfinite count
+// partials[2*blockIdx.x + {0,1}]
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_norm_partials(NormArgs a) {
+    __shared__ float sm[8];
+    const StepState* st = a.st;
+    float p0 = 0.f, p1 = 0.f;
+    if (!st->done) {
+        const int cur = st->cur;
+        const float* u = a.U[cur];
+        const float* k1 = a.K1[cur];
+        const float abstol = st->abstol, reltol = st->reltol;
+        const size_t n = a.n;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+             i += (size_t)gridDim.x * blockDim.x) {
+            if (a.kind == 0) {
+                float uv = u[i];
+                float sk = fmaf(fabsf(uv), reltol, abstol);
+                float x = uv / sk, y = k1[i] / sk;
+                p0 = fmaf(x, x, p0);
+                p1 = fmaf(y, y, p1);
+            } else if (a.kind == 1) {
+                float uv = u[i];
+                float sk = fmaf(fabsf(uv), reltol, abstol);
+                float x = (a.Ks[0][i] - k1[i]) / sk;
+                p0 = fmaf(x, x, p0);
+            } else {
+                const float* un = a.U[1 - cur];
+                const float* k7 = a.K1[1 - cur];
+                float e = TS_BT1 * k1[i];
+                e = fmaf(TS_BT2, a.Ks[0][i], e);
+                e = fmaf(TS_BT3, a.Ks[1][i], e);
+                e = fmaf(TS_BT4, a.Ks[2][i], e);
+                e = fmaf(TS_BT5, a.Ks[3][i], e);
+                e = fmaf(TS_BT6, a.Ks[4][i], e);
+                e = fmaf(TS_BT7, k7[i], e);
+                e *= st->h;
+                float uv = u[i], nv = un[i];
+                float sc = fmaf(fmaxf(fabsf(uv), fabsf(nv)), reltol, abstol);
+                float x = e / sc;
+                p0 = fmaf(x, x, p0);
+                if (!(fabsf(nv) <= 3.0e38f)) p1 += 1.f;
+            }
+        }
+    }
+    float s0 = block_sum(p0, sm);
+    float s1 = block_sum(p1, sm);
+    if (threadIdx.x == 0) {
+        a.partials[2 * blockIdx.x] = s0;
+        a.partials[2 * blockIdx.x + 1] = s1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// on-device controller (one block).  phase 0: initial-dt part A; 1: part B; 2: after a step.
+// Control law: OrdinaryDiffEq-style PI controller for Tsit5 (third
+// party in the reference, restated from the published scheme, mirrored by the oracle).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void set_attempt_h(StepState* st) {
+    float rem = fabsf(st->t1 - st->t);
+    float h = st->dt < rem ? st->dt : rem;
+    st->h = st->tdir * h;
+}
+
+__global__ void __launch_bounds__(256)
+k_controller(StepState* st, const float* __restrict__ partials, int phase, float n_total) {
+    __shared__ float sm[8];
+    if (st->done) return;
+    float p0 = 0.f, p1 = 0.f;
+    for (int i = threadIdx.x; i < st->n_partials; i += blockDim.x) {
+        p0 += partials[2 * i];
+        p1 += partials[2 * i + 1];
+    }
+    // deterministic: fixed thread->entry map and fixed reduction tree
+    p0 = block_sum(p0, sm);
+    p1 = block_sum(p1, sm);
+    if (threadIdx.x != 0) return;
+    const float span = fabsf(st->t1 - st->t0);
+    if (phase == 0) {
+        float d0 = sqrtf(p0 / n_total), d1 = sqrtf(p1 / n_total);
+        float dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+        dt0 = fminf(dt0, span);
+        st->d0 = dt0;   // keep dt0
+        st->d1 = d1;
+        st->h = st->tdir * dt0;
+    } else if (phase == 1) {
+        float dt0 = st->d0, d1 = st->d1;
+        float d2 = sqrtf(p0 / n_total) / dt0;
+        float m = fmaxf(d1, d2);
+        float dt1 = (m <= 1e-15f) ? fmaxf(1e-6f, dt0 * 1e-3f) : powf(0.01f / m, 0.2f);
+        st->dt = fminf(fminf(100.f * dt0, dt1), span);
+        set_attempt_h(st);
+    } else {
+        const float habs = fabsf(st->h);
+        bool accept = true;
+        float q = 1.f, q11 = 1.f, eest = 0.f;
+        if (p1 > 0.f) st->nonfinite = 1;
+        if (st->adaptive) {
+            eest = sqrtf(p0 / n_total);
+            if (!(eest == eest)) { st->nonfinite = 1; eest = 1e30f; }
+            accept = eest <= 1.0f;
+            const float beta1 = 7.f / 50.f, beta2 = 2.f / 25.f, gamma = 0.9f;
+            const float qmin = 0.2f, qmax = 10.f;
+            q11 = powf(fmaxf(eest, 1e-30f), beta1);
+            q = q11 / powf(st->qold, beta2);
+            q = fmaxf(1.f / qmax, fminf(1.f / qmin, q / gamma));
+            st->eest = eest;
+            if (accept) {
+                if (q >= 1.0f && q <= 1.2f) q = 1.f;
+                st->qold = fmaxf(eest, 1e-4f);
+                st->dt = habs / q;
+            } else {
+                st->dt = habs / fminf(1.f / qmin, q11 / gamma);
+            }
+        }
+        if (accept) {
+            st->naccept += 1;
+            st->t = st->t + st->h;
+            st->cur ^= 1;
+            float tol = 100.f * 1.1920929e-7f * fmaxf(1.f, fabsf(st->t1));
+            if (fabsf(st->t1 - st->t) <= tol) { st->t = st->t1; st->done = 1; }
+        } else {
+            st->nreject += 1;
+        }
+        if (st->nonfinite) st->done = 1;
+        if (!st->done) set_attempt_h(st);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// small elementwise kernels
+// ---------------------------------------------------------------------------------------
+// u0 = vcat(xs, zeros(naugs + n_aug + 1, B))      src/base_icnf.jl:275-276, 282
+__global__ void k_build_u0(const float* __restrict__ xs, float* __restrict__ u0, int nvars,
+                           int D, int B) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)D * B) return;
+    int r = (int)(i % D);
+    size_t b = i / D;
+    u0[i] = r < nvars ? xs[b * nvars + r] : 0.f;
+}
+
+__global__ void k_copy_final(const StepState* st, const float* U0, const float* U1,
+                             float* __restrict__ out, size_t n) {
+    const float* src = st->cur ? U1 : U0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        out[i] = src[i];
+}
+
+// inference_sol (src/base_icnf.jl:167-189), one lane per column
+__global__ void k_post(NetDesc nd, int train, const float* __restrict__ fsol,
+                       float* __restrict__ logpx, float* __restrict__ regs, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n_in = nd.n_in;
+    const int D = n_in + 1 + (train ? 2 : 0);
+    const float* c = fsol + (size_t)b * D;
+    float ss = 0.f, sa = 0.f;
+    for (int i = 0; i < n_in; ++i) {
+        float v = c[i];
+        ss = fmaf(v, v, ss);
+        if (i >= nd.nvars) sa = fmaf(v, v, sa);
+    }
+    const float log2pi = 1.8378770664093453f;
+    float logpz = -0.5f * fmaf((float)n_in, log2pi, ss);      // base_icnf.jl:177
+    logpx[b] = logpz - c[n_in];                                // base_icnf.jl:178
+    regs[b] = train ? c[n_in + 1] : 0.f;
+    regs[(size_t)B + b] = train ? c[n_in + 2] : 0.f;
+    regs[2 * (size_t)B + b] = (nd.norm_z_aug && nd.naugs > 0) ? sqrtf(sa) : 0.f;  // :179-187
+}
+
+// loss sums (src/icnf.jl:489): one block, deterministic; sums5 = (S logpx, S E, S n, S A, B)
+__global__ void __launch_bounds__(256)
+k_loss_sums(const float* __restrict__ logpx, const float* __restrict__ regs, int B,
+            float* __restrict__ sums5) {
+    __shared__ float sm[8];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        s[0] += logpx[b];
+        s[1] += regs[b];
+        s[2] += regs[(size_t)B + b];
+        s[3] += regs[2 * (size_t)B + b];
+    }
+    for (int j = 0; j < 4; ++j) {
+        float r = block_sum(s[j], sm);
+        if (threadIdx.x == 0) sums5[j] = r;
+    }
+    if (threadIdx.x == 0) sums5[4] = (float)B;
+}
+
+// ---------------------------------------------------------------------------------------
+// host-callable launch wrappers
+// ---------------------------------------------------------------------------------------
+void launch_rhs_generic(const NetDesc& nd, const float* P, const RhsArgs& a, hipStream_t s) {
+    const int tpb = 64;
+    hipLaunchKernelGGL(k_rhs_generic, dim3((a.B + tpb - 1) / tpb), dim3(tpb), 0, s, nd, P, a);
+}
+void launch_norm_partials(const NormArgs& a, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_norm_partials, dim3(nblocks), dim3(256), 0, s, a);
+}
+void launch_controller(StepState* st, const float* partials, int phase, float n_total,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_controller, dim3(1), dim3(256), 0, s, st, partials, phase, n_total);
+}
+void launch_build_u0(const float* xs, float* u0, int nvars, int D, int B, hipStream_t s) {
+    size_t n = (size_t)D * B;
+    hipLaunchKernelGGL(k_build_u0, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xs, u0,
+                       nvars, D, B);
+}
+void launch_copy_final(const StepState* st, const float* U0, const float* U1, float* out,
+                       size_t n, hipStream_t s) {
+    unsigned nb = (unsigned)((n + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_copy_final, dim3(nb), dim3(256), 0, s, st, U0, U1, out, n);
+}
+void launch_post(const NetDesc& nd, int train, const float* fsol, float* logpx, float* regs,
+                 int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_post, dim3((B + 255) / 256), dim3(256), 0, s, nd, train, fsol, logpx,
+                       regs, B);
+}
+void launch_loss_sums(const float* logpx, const float* regs, int B, float* sums5,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(256), 0, s, logpx, regs, B, sums5);
+}

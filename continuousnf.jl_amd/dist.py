@@ -1,0 +1,34 @@
+"""``ICNFDist`` (src/exts/dist_ext/core_icnf.jl:1-31): the Distributions-style front end of
+log-density evaluation.  ``logpdf(d, A)`` is ``first(inference(d.m, d.mode, A, d.ps, d.st))``
+(core_icnf.jl:27)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any
+
+import numpy as np
+
+from .base_icnf import ICNF, _is_torch, inference
+
+
+@dataclass
+class ICNFDist:
+    m: ICNF
+    mode: Any
+    ps: Any
+    st: Any = None
+
+
+def logpdf(d: ICNFDist, A, *, eps=None):
+    if not isinstance(d.m, ICNF):
+        raise NotImplementedError("Not Implemented")      # core_icnf.jl:19
+    vec = (A.dim() if _is_torch(A) else np.ndim(A)) == 1
+    if vec:                                               # core_icnf.jl:13-21: hcat(x)
+        A = A.reshape(-1, 1)
+    lp = inference(d.m, d.mode, A, d.ps, d.st, eps=eps)[0]
+    return lp[0] if vec else lp
+
+
+def pdf(d: ICNFDist, A, *, eps=None):
+    lp = logpdf(d, A, eps=eps)
+    return lp.exp() if _is_torch(lp) else np.exp(lp)

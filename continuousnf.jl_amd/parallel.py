@@ -1,0 +1,55 @@
+"""Batch-axis sharding.  Columns are independent in the RHS
+(src/icnf.jl:330-349) and in post-processing (src/base_icnf.jl:174-187), so each rank
+solves its own contiguous block of columns with no data-path collective; the only
+exchange is one all-reduce (RCCL ncclSum over xGMI; gloo on CPU) of the five floats
+(sum logpx, sum E, sum n, sum A, count) behind ``loss`` (src/icnf.jl:489)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(B: int, world_size: int, rank: int):
+    """Contiguous column block of ``rank``: the first ``B % world_size`` ranks get one more."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    q, r = divmod(B, world_size)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def allreduce_sums(sums, group=None):
+    """All-reduce the 5-float vector.  ``sums`` is a torch tensor (CUDA with the nccl
+    backend = RCCL, CPU with gloo) or array-like (moved to the backend's device)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sums
+    if not isinstance(sums, torch.Tensor):
+        sums = torch.as_tensor(np.asarray(sums, dtype=np.float32))
+    backend = dist.get_backend(group)
+    if backend == "nccl" and not sums.is_cuda:
+        sums = sums.cuda()
+    if backend == "gloo" and sums.is_cuda:
+        sums = sums.cpu()
+    sums = sums.clone()
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums
+
+
+def loss_from_global_sums(sums, mode_train: bool, lambdas):
+    """Host formula of cnf_loss_from_sums, for callers that hold no handle (CPU tests)."""
+    s = np.asarray(sums.detach().cpu() if hasattr(sums, "detach") else sums, dtype=np.float64)
+    if not s[4] > 0:
+        raise ValueError("empty batch")
+    if mode_train:
+        return float((-s[0] + lambdas[0] * s[1] + lambdas[1] * s[2] + lambdas[2] * s[3]) / s[4])
+    return float(-s[0] / s[4])
+
+
+def distributed_loss(icnf, mode, xs_local, ps, st=None, *, eps=None, group=None):
+    """``loss`` over a batch sharded by columns: local inference on this rank's columns,
+    then the 5-float all-reduce, then the mean."""
+    from .base_icnf import inference, loss_from_sums, loss_sums
+    logpx, regs = inference(icnf, mode, xs_local, ps, st, eps=eps)
+    sums = allreduce_sums(loss_sums(icnf, logpx, regs), group)
+    return loss_from_sums(icnf, mode, sums)

@@ -1,0 +1,173 @@
+/* cnfhip.h -- C ABI of libcnfhip.so: the MI355X (gfx950) backend for the batched
+ * augmented-ODE right-hand side of ContinuousNormalizingFlows.jl.
+ *
+ * The reference is 100 % Julia and has no FFI of its own, so every entry point below
+ * names the reference function (file:line under /root/reference) whose work it takes
+ * over.  The Julia-side binding a maintainer would add is shown in INTEGRATION.md and
+ * shipped (untested: no Julia here) as julia/ContinuousNormalizingFlowsHIPExt.jl.
+ *
+ * Conventions
+ *  - every function returns a cnf_status (0 = OK); nothing throws or aborts across the ABI;
+ *  - the caller owns every buffer; a handle owns only the weights and its scratch space;
+ *  - pointers are DEVICE pointers unless the function name ends in _host;
+ *  - matrices use the reference's layout: Julia column-major `D x B`, i.e. the D floats
+ *    of one sample (column) are contiguous and column b starts at float b*D;
+ *  - state rows (src/base_icnf.jl:275-282, src/icnf.jl:349):
+ *      0..nvars-1 data | nvars..n_in-1 augmented dims | n_in: dlogp | n_in+1: E | n_in+2: n
+ *    (the last two rows exist in TrainMode only; n_in = nvars + naugs);
+ *  - eps (the Hutchinson probe, `n_in x B`) is always an INPUT: the reference draws it
+ *    once per inference call outside the RHS (src/base_icnf.jl:277-278);
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ *    asynchronous on it unless stated otherwise; a handle may be used from one stream
+ *    at a time; there is no global state.
+ */
+#ifndef CNFHIP_H
+#define CNFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cnf_ctx* cnf_handle;
+
+typedef enum {
+    CNF_OK = 0,
+    CNF_ERR_BAD_ARG = 1,      /* null pointer, negative size, unknown enum value     */
+    CNF_ERR_BAD_SHAPE = 2,    /* dims / parameter count / batch inconsistent          */
+    CNF_ERR_HIP = 3,          /* a HIP runtime call failed (see cnf_last_error)       */
+    CNF_ERR_NO_DEVICE = 4,    /* no gfx950 device visible                             */
+    CNF_ERR_MAXITERS = 5,     /* solver hit maxiters before reaching t1               */
+    CNF_ERR_UNSUPPORTED = 6,  /* valid request this build has no kernel for           */
+    CNF_ERR_NO_PARAMS = 7,    /* cnf_set_params has not been called                   */
+    CNF_ERR_NONFINITE = 8     /* solver state became NaN/Inf                          */
+} cnf_status;
+
+/* Mode (src/types.jl:1-3). */
+enum { CNF_MODE_TEST = 0, CNF_MODE_TRAIN = 1 };
+
+/* Dense activations (Lux `Dense(in => out, act)`). */
+enum {
+    CNF_ACT_IDENTITY = 0, CNF_ACT_TANH = 1, CNF_ACT_SIGMOID = 2, CNF_ACT_SOFTPLUS = 3,
+    CNF_ACT_RELU = 4, CNF_ACT_SWISH = 5, CNF_ACT_ELU = 6
+};
+
+/* Compute-mode flag: which AD product drives the trace estimate and the n-row.
+ * VJP <-> DIVecJacMatrixMode (src/icnf.jl:318-382), JVP <-> DIJacVecMatrixMode
+ * (src/icnf.jl:384-456); type lattice at src/types.jl:17-23. */
+enum { CNF_AD_VJP = 0, CNF_AD_JVP = 1 };
+
+/* Kernel selection (for tests and benchmarks; AUTO is what a caller wants). */
+enum { CNF_KERNEL_AUTO = 0, CNF_KERNEL_GENERIC = 1, CNF_KERNEL_MFMA = 2 };
+
+typedef struct {
+    int32_t n_layers;          /* number of Dense layers (1..8)                        */
+    const int32_t* dims;       /* n_layers+1 entries: n_in, h1, ..., n_out (= n_in)    */
+    const int32_t* acts;       /* n_layers entries: CNF_ACT_*                          */
+    int32_t nvars;             /* src/icnf.jl:89                                       */
+    int32_t naugs;             /* naugmented, src/icnf.jl:90                           */
+    int32_t ad;                /* CNF_AD_VJP | CNF_AD_JVP                              */
+    float lambda1, lambda2, lambda3;  /* src/icnf.jl:100-102; NORM_Z / NORM_J /
+                                  NORM_Z_AUG are derived as `!iszero(lambda)` exactly as
+                                  construct does (src/base_icnf.jl:42-51)              */
+    int32_t device;            /* HIP device ordinal                                   */
+} cnf_config;
+
+typedef struct {
+    float t0, t1;              /* tspan (src/icnf.jl:83); t1 < t0 integrates backwards */
+    float abstol, reltol;      /* sol_kwargs (README.md:64-65)                         */
+    float dt;                  /* adaptive: initial dt, 0 = automatic; fixed: the step */
+    int32_t adaptive;          /* 1 = PI-controlled Tsit5, 0 = fixed steps of `dt`     */
+    int32_t maxiters;          /* bound on step attempts (accepted + rejected)         */
+    int32_t kernel;            /* CNF_KERNEL_*                                         */
+} cnf_solve_opts;
+
+typedef struct {
+    int32_t nf;                /* RHS evaluations performed (sol.stats.nf)             */
+    int32_t naccept, nreject;
+    float t_final, dt_last;
+    int32_t kernel_used;       /* CNF_KERNEL_GENERIC | CNF_KERNEL_MFMA                 */
+    int32_t launches;          /* kernel launches enqueued for this solve              */
+} cnf_solve_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+
+/* Takes the role of `construct` (src/base_icnf.jl:1-77) for the device side: records
+ * the network shape and the static switches. Synchronous. */
+cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg);
+cnf_status cnf_destroy(cnf_handle h);
+
+/* Upload the flat parameter vector `ps` = ComponentArray(Lux.setup(rng, nn)[1]): per
+ * layer `weight` (out x in, column-major) then `bias` (out), layers in order -- the `p`
+ * argument of augmented_f (src/icnf.jl:320, used at :329).  Synchronous. */
+cnf_status cnf_set_params_host(cnf_handle h, const float* flat, size_t n);
+cnf_status cnf_set_params(cnf_handle h, const float* flat_dev, size_t n, void* stream);
+
+/* ---- the hot path ---------------------------------------------------------------- */
+
+/* One evaluation of augmented_f over the whole batch:
+ *   TrainMode/VJP  src/icnf.jl:318-350 (out-of-place), :352-382 (in-place)
+ *   TrainMode/JVP  src/icnf.jl:384-420, :422-456
+ *   TestMode       src/icnf.jl:148-164, :166-184 with jacobian_batched src/utils.jl:1-36
+ * u: D x B, eps: n_in x B (ignored in TestMode, may be NULL), du: D x B; u and du must
+ * not alias.  The ODE is autonomous, so `t` is not an argument (icnf.jl:321 ignores it). */
+cnf_status cnf_rhs(cnf_handle h, int mode, int kernel, const float* u, const float* eps,
+                   float* du, int B, void* stream);
+cnf_status cnf_rhs_host(cnf_handle h, int mode, int kernel, const float* u,
+                        const float* eps, float* du, int B);
+
+/* base_sol (src/base_icnf.jl:137-143) with Tsit5 fixed as the algorithm: integrates
+ * u' = augmented_f(u) from opts->t0 to opts->t1 on the device and writes the final
+ * `D x B` state -- what `get_fsol(sol)` returns (src/base_icnf.jl:213-215).  Blocks until
+ * the solve has finished (the step count of an adaptive solve is data dependent). */
+cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0, const float* eps,
+                           float* u_out, int B, const cnf_solve_opts* opts,
+                           cnf_solve_stats* stats, void* stream);
+
+/* inference_prob's state assembly (src/base_icnf.jl:275-276, 282):
+ * u0 = vcat(xs, zeros(naugs + n_aug + 1, B)); xs: nvars x B. */
+cnf_status cnf_build_u0(cnf_handle h, int mode, const float* xs, float* u0, int B,
+                        void* stream);
+
+/* inference_sol (src/base_icnf.jl:167-189): from the final state computes
+ * logpx[b] = logpdf(MvNormal(0, I), z_b) - dlogp_b and the rows (E, n, A) into
+ * regs (3 x B, row-major: regs[0*B+b]=E, [1*B+b]=n, [2*B+b]=A; E and n are 0 in
+ * TestMode, where the reference has no such rows). */
+cnf_status cnf_inference_post(cnf_handle h, int mode, const float* u_final, float* logpx,
+                              float* regs, int B, void* stream);
+
+/* inference (src/base_icnf.jl:407-415) = build_u0 + solve + post, all on device. */
+cnf_status cnf_inference(cnf_handle h, int mode, const float* xs, const float* eps,
+                         float* logpx, float* regs, float* u_final /* may be NULL */,
+                         int B, const cnf_solve_opts* opts, cnf_solve_stats* stats,
+                         void* stream);
+cnf_status cnf_inference_host(cnf_handle h, int mode, const float* xs, const float* eps,
+                              float* logpx, float* regs, float* u_final, int B,
+                              const cnf_solve_opts* opts, cnf_solve_stats* stats);
+
+/* The local part of `loss` (src/icnf.jl:481-490; src/base_icnf.jl:489-497): writes
+ * sums[5] = (sum logpx, sum E, sum n, sum A, B) to DEVICE memory.  These five floats are
+ * the only cross-shard quantity: the caller all-reduces them (RCCL, ncclSum) and then
+ * cnf_loss_from_sums gives mean(-logpx + l1 E + l2 n + l3 A) (Train) or -mean(logpx). */
+cnf_status cnf_loss_sums(cnf_handle h, const float* logpx, const float* regs, int B,
+                         float* sums5, void* stream);
+cnf_status cnf_loss_from_sums(cnf_handle h, int mode, const float* sums5_host, float* loss);
+
+/* ---- introspection --------------------------------------------------------------- */
+const char* cnf_status_string(cnf_status s);
+const char* cnf_last_error(cnf_handle h);   /* detail for the last non-OK status       */
+int cnf_abi_version(void);
+/* Rows of the state: n_in + 1 + (mode == TRAIN ? 2 : 0)  (src/icnf.jl:106-108). */
+int cnf_state_rows(cnf_handle h, int mode);
+/* Which kernel AUTO resolves to for this handle and batch (CNF_KERNEL_*). */
+int cnf_kernel_for(cnf_handle h, int mode, int B);
+/* Algorithmic work of ONE RHS evaluation over B samples:
+ * bytes = 4*B*(n_in + [train] n_in + D) + 4*P; flops = B*(4M + 6 n_in) (Train). */
+cnf_status cnf_rhs_work(cnf_handle h, int mode, int B, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNFHIP_H */

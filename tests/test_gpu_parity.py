@@ -1,0 +1,324 @@
+"""Parity of the HIP path with the oracle, through the C ABI (via the host mirror), on a
+real MI355X.  Bar: 1e-4 relative in fp32 (tests/helpers.py:RTOL)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import continuousnf.jl_amd as cnf
+from continuousnf.jl_amd import _lib
+from oracle import c_oracle as CO
+from oracle import cnf_oracle as O
+from tests.helpers import GOLDEN_CASES, assert_parity, load_golden, make_icnf
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+KERNELS = ["generic", "mfma"]
+
+
+def _skip_if_unsupported(icnf, mode, B):
+    if icnf.compute_mode.kernel == "mfma":
+        l = _lib.lib()
+        if l.cnf_kernel_for(icnf.handle(), mode.cnf, B) != _lib.KERNEL_MFMA:
+            pytest.skip("no MFMA kernel for this shape")
+
+
+def _dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+# ---------------------------------------------------------------------------------------
+# RHS level (rows a1, a2, a3)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_rhs_matches_golden(name, kernel):
+    g, cfg = load_golden(name)
+    for jvp in (False, True):
+        icnf = make_icnf(cnf, cfg, jvp=jvp, kernel=kernel)
+        _skip_if_unsupported(icnf, cnf.TrainMode(), g["u_train"].shape[1])
+        tag = "jvp" if jvp else "vjp"
+        # host arrays -> cnf_rhs_host; device tensors -> cnf_rhs
+        du = cnf.augmented_f(g["u_train"], g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, g["eps"])
+        assert_parity(du, g[f"du_train_{tag}"], f"{name} train {tag} host")
+        du_d = cnf.augmented_f(_dev(g["u_train"]), g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, _dev(g["eps"]))
+        assert du_d.shape == g["u_train"].shape
+        assert_parity(du_d.cpu().numpy(), g[f"du_train_{tag}"], f"{name} train {tag} device")
+        dt = cnf.augmented_f(g["u_train"][: cfg.n_in + 1], g["flat"], 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)
+        assert_parity(dt, g["du_test"], f"{name} test")
+        icnf.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_rhs_inplace_form(kernel):
+    g, cfg = load_golden("cfg2_regression")
+    icnf = make_icnf(cnf, cfg, kernel=kernel)
+    _skip_if_unsupported(icnf, cnf.TrainMode(), g["u_train"].shape[1])
+    u, eps = _dev(g["u_train"]), _dev(g["eps"])
+    du = torch.full_like(u, float("nan"))
+    r = cnf.augmented_f(du, u, g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, eps)   # icnf.jl:352-382
+    assert r is None
+    assert_parity(du.cpu().numpy(), g["du_train_vjp"], "in-place")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 257, 1000])
+def test_rhs_ragged_batches(B, kernel):
+    cfg, _, _ = O.baseline_cfg(2)
+    rng = np.random.default_rng(B)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    u = rng.standard_normal((cfg.D(True), B)).astype(np.float32)
+    eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+    icnf = make_icnf(cnf, cfg, kernel=kernel)
+    _skip_if_unsupported(icnf, cnf.TrainMode(), B)
+    du = cnf.augmented_f(u, flat, 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, eps)
+    ref = cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True)(u.astype(np.float64))
+    assert_parity(du, ref, f"B={B}")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("i", [1, 2, 3, 5])
+def test_rhs_baseline_configs_vs_c_oracle(i, kernel):
+    """Seeded inputs at sizes the C oracle finishes in seconds; all three modes."""
+    cfg, B, _ = O.baseline_cfg(i)
+    B = min(B, 1024 if i != 5 else 128)
+    rng = np.random.default_rng(100 + i)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.05)
+    u = rng.standard_normal((cfg.D(True), B)).astype(np.float32)
+    eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+    for jvp in (False, True):
+        cfg.use_jvp = jvp
+        icnf = make_icnf(cnf, cfg, jvp=jvp, kernel=kernel)
+        _skip_if_unsupported(icnf, cnf.TrainMode(), B)
+        du = cnf.augmented_f(u, flat, 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, eps)
+        ref = cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True)(u.astype(np.float64))
+        assert_parity(du, ref, f"cfg{i} train jvp={jvp}")
+        assert_parity(du, CO.rhs(cfg, flat, u, eps, True), f"cfg{i} vs C oracle")
+        icnf.close()
+    cfg.use_jvp = False
+    icnf = make_icnf(cnf, cfg, kernel=kernel)
+    Bt = min(B, 64)
+    dt = cnf.augmented_f(u[: cfg.n_in + 1, :Bt], flat, 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)
+    assert_parity(dt, CO.rhs(cfg, flat, u[: cfg.n_in + 1, :Bt], None, False), f"cfg{i} test")
+
+
+# ---------------------------------------------------------------------------------------
+# solve level (rows a6, a7, a8, a9)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_fixed_dt_inference_matches_golden(name, kernel):
+    g, cfg = load_golden(name)
+    kw = dict(adaptive=False, dt=float(g["dt"]))
+    for jvp in (False, True):
+        tag = "jvp" if jvp else "vjp"
+        icnf = make_icnf(cnf, cfg, jvp=jvp, kernel=kernel, sol_kwargs=kw)
+        _skip_if_unsupported(icnf, cnf.TrainMode(), g["xs"].shape[1])
+        prob = cnf.inference_prob(icnf, cnf.TrainMode(), _dev(g["xs"]), g["flat"], {}, eps=_dev(g["eps"]))
+        fsol = cnf.base_sol(icnf, prob)
+        assert prob.stats["nf"] == int(g[f"nf_train_{tag}"])
+        assert_parity(fsol.view().cpu().numpy(), g[f"fsol_train_{tag}"], f"{name} fsol {tag}")
+        logpx, (E, n, A) = cnf.inference(icnf, cnf.TrainMode(), _dev(g["xs"]), g["flat"], {}, eps=_dev(g["eps"]))
+        assert_parity(logpx.cpu().numpy(), g[f"logpx_train_{tag}"], f"{name} logpx {tag}")
+        assert_parity(torch.stack([E, n, A]).cpu().numpy(), g[f"regs_train_{tag}"], f"{name} regs {tag}")
+        L = cnf.loss(icnf, cnf.TrainMode(), _dev(g["xs"]), g["flat"], {}, eps=_dev(g["eps"]))
+        assert abs(L - float(g[f"loss_train_{tag}"])) <= 1e-4 * max(1.0, abs(float(g[f"loss_train_{tag}"])))
+        icnf.close()
+    icnf = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=kw)
+    logpx, (E, n, A) = cnf.inference(icnf, cnf.TestMode(), g["xs"], g["flat"], {})      # host arrays
+    assert_parity(logpx, g["logpx_test"], f"{name} logpx test")
+    assert np.all(E == 0) and np.all(n == 0)
+    assert_parity(A, g["A_test"], f"{name} A test") if np.any(g["A_test"]) else None
+    L = cnf.loss(icnf, cnf.TestMode(), g["xs"], g["flat"], {})
+    assert abs(L - float(g["loss_test"])) <= 1e-4 * max(1.0, abs(float(g["loss_test"])))
+    d = cnf.ICNFDist(icnf, cnf.TestMode(), g["flat"], {})                              # dist_ext/core_icnf.jl:23-31
+    assert_parity(cnf.logpdf(d, g["xs"]), g["logpx_test"], f"{name} logpdf")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("i", [1, 2, 3])
+def test_adaptive_solve_vs_oracles(i, kernel):
+    """README tolerances (README.md:64-65).  Step-for-step the GPU controller must follow
+    the float32 C oracle (same control law); values agree with a tight float64 solve to
+    the solver tolerance."""
+    cfg, B, _ = O.baseline_cfg(i)
+    B = min(B, 512)
+    rng = np.random.default_rng(200 + i)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.05)
+    xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+    eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+    kw = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+    icnf = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=kw)
+    _skip_if_unsupported(icnf, cnf.TrainMode(), B)
+    prob = cnf.inference_prob(icnf, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    fsol = cnf.base_sol(icnf, prob).view()
+    st = prob.stats
+    u0 = O.inference_u0(cfg, xs, True)
+    cref, cst = CO.solve(cfg, flat, u0, eps, True, **kw)
+    assert st["nf"] == 2 + 6 * (st["naccept"] + st["nreject"])
+    assert abs(st["naccept"] - cst["naccept"]) <= 2, (st, cst)
+    assert abs(st["t_final"] - cfg.tspan[1]) < 1e-6
+    ref64, _ = O.tsit5_solve(cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True),
+                             u0.astype(np.float64), *cfg.tspan, reltol=1e-10, abstol=1e-10)
+    assert_parity(fsol, ref64, f"cfg{i} adaptive vs float64", rtol=5e-3)
+    assert_parity(fsol, cref, f"cfg{i} adaptive vs C oracle", rtol=2e-3)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_backward_time_roundtrip(kernel):
+    """Integrating t0->t1 and back returns the data rows (the direction `generate` uses)."""
+    cfg, _, _ = O.baseline_cfg(2)
+    rng = np.random.default_rng(7)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.05)
+    B = 100
+    xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+    eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+    kw = dict(adaptive=False, dt=1 / 64)
+    icnf = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=kw)
+    _skip_if_unsupported(icnf, cnf.TrainMode(), B)
+    prob = cnf.inference_prob(icnf, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    u0 = prob.u0.view().copy()
+    fwd = cnf.base_sol(icnf, prob)
+    prob2 = cnf.ODEProblem(icnf, cnf.TrainMode(), fwd, prob.eps, (1.0, 0.0), flat)
+    back = cnf.base_sol(icnf, prob2).view()
+    assert np.max(np.abs(back[: cfg.n_in] - u0[: cfg.n_in])) < 2e-5
+    assert np.max(np.abs(back[cfg.n_in])) < 2e-4           # dlogp integrates back to 0
+
+
+# ---------------------------------------------------------------------------------------
+# full BASELINE sizes: size-independent properties (the oracle is too slow there)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_full_size_cfg3_properties(kernel):
+    cfg, B, _ = O.baseline_cfg(3)
+    rng = np.random.default_rng(33)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.05)
+    u = rng.standard_normal((cfg.D(True), B)).astype(np.float32)
+    eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+    icnf = make_icnf(cnf, cfg, kernel=kernel)
+    _skip_if_unsupported(icnf, cnf.TrainMode(), B)
+    ud, ed = _dev(u), _dev(eps)
+    f = lambda uu, ee: cnf.augmented_f(uu, flat, 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, ee)
+    du = f(ud, ed)
+    assert torch.isfinite(du).all()
+    # columns are independent: any permutation of the columns permutes the output bit for bit
+    perm = torch.from_numpy(rng.permutation(B)).cuda()
+    assert torch.equal(f(ud[:, perm].contiguous(), ed[:, perm].contiguous()), du[:, perm])
+    # a sub-batch reproduces its columns bit for bit (no cross-column coupling, ragged tail)
+    assert torch.equal(f(ud[:, 5:1234].contiguous(), ed[:, 5:1234].contiguous()), du[:, 5:1234])
+    # the RHS reads only the z rows of u (src/icnf.jl:330)
+    u2 = ud.clone(); u2[cfg.n_in:] += 7.0
+    assert torch.equal(f(u2, ed), du)
+    # eps -> -eps leaves eps^T J eps and both norms unchanged; zdot does not depend on eps
+    dm = f(ud, -ed)
+    assert torch.equal(dm[: cfg.n_in], du[: cfg.n_in])
+    assert torch.allclose(dm[cfg.n_in:], du[cfg.n_in:], rtol=1e-5, atol=1e-6)
+    # E row is the column norm of zdot; sampled columns against the float64 oracle
+    assert torch.allclose(du[cfg.n_in + 1], du[: cfg.n_in].norm(dim=0), rtol=1e-5)
+    idx = rng.choice(B, 256, replace=False)
+    ref = cfg.rhs(flat.astype(np.float64), eps[:, idx].astype(np.float64), True)(u[:, idx].astype(np.float64))
+    assert_parity(du[:, torch.from_numpy(idx).cuda()].cpu().numpy(), ref, "cfg3 sampled columns")
+    # FFJORD switches (lambda = 0): regulariser rows are exactly zero (icnf.jl:337-340, 344-347)
+    cfg4, _, _ = O.baseline_cfg(4)
+    ic4 = make_icnf(cnf, cfg4, kernel=kernel)
+    d4 = cnf.augmented_f(ud, flat, 0.0, ic4, cnf.TrainMode(), ic4.nn, {}, ed)
+    assert torch.all(d4[cfg.n_in + 1:] == 0) and torch.equal(d4[: cfg.n_in + 1], du[: cfg.n_in + 1])
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_full_size_cfg3_solve_is_shard_invariant(kernel):
+    """Fixed dt: solving the whole batch equals solving two column shards separately
+    (what the multi-GPU path relies on), bit for bit."""
+    cfg, B, _ = O.baseline_cfg(3)
+    rng = np.random.default_rng(34)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.05)
+    xs = _dev(rng.standard_normal((cfg.nvars, B)).astype(np.float32))
+    eps = _dev(rng.standard_normal((cfg.n_in, B)).astype(np.float32))
+    icnf = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=dict(adaptive=False, dt=1 / 8))
+    _skip_if_unsupported(icnf, cnf.TrainMode(), B)
+    lp, (E, n, A) = cnf.inference(icnf, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    assert icnf.last_stats["nf"] == 1 + 6 * 8
+    h = 3000
+    lp1, r1 = cnf.inference(icnf, cnf.TrainMode(), xs[:, :h].contiguous(), flat, {}, eps=eps[:, :h].contiguous())
+    lp2, r2 = cnf.inference(icnf, cnf.TrainMode(), xs[:, h:].contiguous(), flat, {}, eps=eps[:, h:].contiguous())
+    assert torch.equal(torch.cat([lp1, lp2]), lp)
+    assert torch.equal(torch.cat([r1[0], r2[0]]), E) and torch.equal(torch.cat([r1[1], r2[1]]), n)
+    # the 5-float reduction composes: sums of shards == sums of the whole (to fp32 rounding)
+    s = cnf.loss_sums(icnf, lp, (E, n, A)).cpu().numpy()
+    s12 = (cnf.loss_sums(icnf, lp1, r1) + cnf.loss_sums(icnf, lp2, r2)).cpu().numpy()
+    assert s[4] == B and np.allclose(s, s12, rtol=1e-5)
+
+
+def test_hutchinson_mean_approaches_exact_trace():
+    """TrainMode's -eps^T J eps averages to TestMode's -tr J (the two estimators of row
+    n_in+1 agree in expectation)."""
+    cfg, _, _ = O.baseline_cfg(2)
+    rng = np.random.default_rng(9)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.05)
+    icnf = make_icnf(cnf, cfg)
+    z = rng.standard_normal((cfg.n_in, 1)).astype(np.float32)
+    N = 32768
+    u = np.vstack([np.repeat(z, N, 1), np.zeros((3, N), np.float32)])
+    eps = rng.standard_normal((cfg.n_in, N)).astype(np.float32)
+    tr_h = cnf.augmented_f(_dev(u), flat, 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, _dev(eps))[cfg.n_in].cpu().numpy()
+    tr_e = cnf.augmented_f(u[: cfg.n_in + 1, :1], flat, 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)[cfg.n_in, 0]
+    assert abs(tr_h.mean() - tr_e) < 4 * tr_h.std() / np.sqrt(N)
+
+
+# ---------------------------------------------------------------------------------------
+# edge cases and error behaviour
+# ---------------------------------------------------------------------------------------
+def test_empty_batch_and_errors():
+    g, cfg = load_golden("calltests_aug")
+    icnf = make_icnf(cnf, cfg, sol_kwargs=dict(adaptive=False, dt=0.25))
+    D = cfg.D(True)
+    du = cnf.augmented_f(np.zeros((D, 0), np.float32), g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {},
+                         np.zeros((cfg.n_in, 0), np.float32))
+    assert du.shape == (D, 0)
+    with pytest.raises(ValueError):      # wrong row count
+        cnf.augmented_f(np.zeros((D + 1, 3), np.float32), g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {},
+                        np.zeros((cfg.n_in, 3), np.float32))
+    with pytest.raises(ValueError):      # TrainMode without eps
+        cnf.augmented_f(np.zeros((D, 3), np.float32), g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, None)
+    with pytest.raises(cnf.CNFError) as e:   # wrong parameter count
+        cnf.augmented_f(np.zeros((D, 3), np.float32), g["flat"][:-1], 0.0, icnf, cnf.TrainMode(), icnf.nn, {},
+                        np.zeros((cfg.n_in, 3), np.float32))
+    assert e.value.status == _lib.ERR_BAD_SHAPE
+    # raw ABI: params not set, aliasing, maxiters
+    l = _lib.lib()
+    ic2 = make_icnf(cnf, cfg)
+    h = ic2.handle()
+    x = torch.zeros(D * 4, device="cuda")
+    assert l.cnf_rhs(h, 1, 0, x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, None) == _lib.ERR_NO_PARAMS
+    ic2.set_params(g["flat"])
+    assert l.cnf_rhs(h, 1, 0, x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, None) == _lib.ERR_BAD_ARG
+    assert b"alias" in l.cnf_last_error(h)
+    assert l.cnf_rhs(h, 7, 0, x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, None) == _lib.ERR_BAD_ARG
+    ic3 = make_icnf(cnf, cfg, sol_kwargs=dict(reltol=1e-6, abstol=1e-9, maxiters=2))
+    with pytest.raises(cnf.CNFError) as e:
+        cnf.inference(ic3, cnf.TrainMode(), g["xs"], g["flat"], {}, eps=g["eps"])
+    assert e.value.status == _lib.ERR_MAXITERS
+
+
+def test_explicit_mfma_request_fails_loudly_when_unsupported():
+    net = O.Net((5, 7, 3, 5), (O.ACT_SOFTPLUS, O.ACT_SWISH, O.ACT_IDENTITY))
+    cfg = O.Cfg(net, 3, 2)
+    icnf = make_icnf(cnf, cfg, kernel="mfma")
+    flat = O.glorot_params(net, np.random.default_rng(0), np.float32)
+    if _lib.lib().cnf_kernel_for(icnf.handle(), 1, 8) == _lib.KERNEL_MFMA:
+        pytest.skip("MFMA path covers this shape")
+    with pytest.raises(cnf.CNFError) as e:
+        cnf.augmented_f(np.zeros((8, 8), np.float32), flat, 0.0, icnf, cnf.TrainMode(), icnf.nn, {},
+                        np.zeros((5, 8), np.float32))
+    assert e.value.status == _lib.ERR_UNSUPPORTED
+
+
+def test_rhs_work_model():
+    cfg, B, _ = O.baseline_cfg(3)
+    icnf = make_icnf(cnf, cfg)
+    fl, by = C.c_double(), C.c_double()
+    _lib.check(_lib.lib().cnf_rhs_work(icnf.handle(), 1, B, C.byref(fl), C.byref(by)))
+    M = 32 * 128 + 128 * 128 + 128 * 32
+    P = M + 128 + 128 + 32
+    assert fl.value == B * (4 * M + 6 * 32) and by.value == 4 * B * (32 + 32 + 35) + 4 * P

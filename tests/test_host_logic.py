@@ -1,0 +1,122 @@
+"""Host-side mirror of the reference API: construct defaults, type switches, layouts,
+argument checking.  No GPU needed."""
+import numpy as np
+import pytest
+
+import continuousnf.jl_amd as cnf
+from continuousnf.jl_amd import base_icnf as B
+from continuousnf.jl_amd.parallel import loss_from_global_sums, shard_range
+
+
+def _nn(n_in):
+    return cnf.Chain(cnf.Dense(n_in, 3 * n_in, "tanh"), cnf.Dense(3 * n_in, n_in, "tanh"))
+
+
+def test_construct_defaults_follow_reference():
+    # src/base_icnf.jl:28-38: RNODE -> lambda1 = lambda2 = 1e-2, lambda3 = 0; FFJORD -> all 0
+    r = cnf.construct(cnf.RNODE, _nn(2), 1, 1)
+    assert np.float32(r.lambda1) == np.float32(1e-2) and np.float32(r.lambda2) == np.float32(1e-2) and r.lambda3 == 0
+    assert r.NORM_Z and r.NORM_J and not r.NORM_Z_AUG and r.AUGMENTED and not r.STEER
+    f = cnf.construct(cnf.FFJORD, _nn(2), 2)
+    assert (f.lambda1, f.lambda2, f.lambda3) == (0, 0, 0) and not f.AUGMENTED
+    assert f.tspan == (0.0, 1.0) and not f.inplace                      # base_icnf.jl:13, 20
+    assert isinstance(f.compute_mode, cnf.HIPVecJacMatrixMode)
+    j = cnf.construct(cnf.RNODE, _nn(2), 1, 1, **{"λ₁": 0.5, "λ₂": 0.0, "λ₃": 2.0})
+    assert (j.lambda1, j.lambda2, j.lambda3) == (0.5, 0.0, 2.0) and not j.NORM_J and j.NORM_Z_AUG
+
+
+def test_construct_rejects_what_is_out_of_scope_or_malformed():
+    with pytest.raises(NotImplementedError):
+        cnf.construct(cnf.Planar, _nn(2), 2)
+    with pytest.raises(NotImplementedError):
+        cnf.construct(cnf.CondRNODE, _nn(2), 2)
+    with pytest.raises(NotImplementedError):
+        cnf.construct(cnf.RNODE, _nn(2), 2, data_type=np.float64)
+    with pytest.raises(ValueError):
+        cnf.construct(cnf.RNODE, _nn(3), 1, 1)          # nn maps 3->3 but n_in = 2
+    with pytest.raises(TypeError):
+        cnf.construct(cnf.RNODE, _nn(2), 2, compute_mode="DIVecJacMatrixMode")
+    with pytest.raises(TypeError):
+        cnf.construct(cnf.RNODE, _nn(2), 2, bogus=1)
+    with pytest.raises(ValueError):
+        cnf.Chain(cnf.Dense(2, 3), cnf.Dense(4, 2))
+    with pytest.raises(ValueError):
+        cnf.Dense(2, 3, "gelu")
+
+
+def test_n_augment_and_modes():
+    r = cnf.construct(cnf.RNODE, _nn(4), 2, 2)
+    assert cnf.n_augment(r, cnf.TrainMode()) == 2 and cnf.n_augment(r, cnf.TestMode()) == 0
+    assert cnf.n_augment_input(r) == 2
+    assert cnf.n_augment_input(cnf.construct(cnf.RNODE, _nn(4), 4)) == 0
+    with pytest.raises(TypeError):
+        cnf.n_augment(r, "train")
+
+
+def test_steer_tspan():
+    r = cnf.construct(cnf.RNODE, _nn(2), 2, tspan=(0.0, 13.0), steer_rate=0.1, rng=3)
+    assert cnf.steer_tspan(r, cnf.TestMode()) == (0.0, 13.0)        # base_icnf.jl:118-120
+    ts = [cnf.steer_tspan(r, cnf.TrainMode())[1] for _ in range(200)]
+    assert all(13.0 - 1.3 - 1e-4 <= t <= 13.0 + 1.3 + 1e-4 for t in ts) and np.std(ts) > 0.3
+    r0 = cnf.construct(cnf.RNODE, _nn(2), 2, tspan=(0.0, 13.0))
+    assert cnf.steer_tspan(r0, cnf.TrainMode()) == (0.0, 13.0)
+
+
+def test_setup_layout_and_size():
+    nn = cnf.Chain(cnf.Dense(2, 3, "tanh"), cnf.Dense(3, 2))
+    ps, st = cnf.setup(0, nn)
+    assert ps.dtype == np.float32 and ps.size == nn.n_params == 2 * 3 + 3 + 3 * 2 + 2 and st == {}
+    assert np.all(ps[6:9] == 0) and np.all(ps[-2:] == 0)            # biases
+    assert nn.dims == (2, 3, 2) and nn.acts == (1, 0)
+
+
+def test_column_major_plumbing_roundtrip():
+    x = np.arange(12, dtype=np.float64).reshape(3, 4)               # logical D x B
+    b = B._as_colmajor(x, 3, "x")
+    assert b.arr.dtype == np.float32 and b.rows == 3 and b.B == 4
+    assert np.array_equal(b.arr[:3], x[:, 0])                       # column 0 contiguous
+    assert np.array_equal(b.view(), x)
+    with pytest.raises(ValueError):
+        B._as_colmajor(x, 4, "x")
+    with pytest.raises(ValueError):
+        B._as_colmajor(np.zeros(3), None, "x")
+
+
+def test_sol_kwargs_mapping():
+    r = cnf.construct(cnf.RNODE, _nn(2), 2, sol_kwargs=dict(progress=True, save_everystep=False,
+                      reltol=3e-4, abstol=1e-7, maxiters=2**31 - 1))
+    o = B._solve_opts(r, (0.0, 1.0))
+    assert o.adaptive == 1 and abs(o.reltol - 3e-4) < 1e-9 and o.dt == 0 and o.maxiters == 2**31 - 1
+    r2 = cnf.construct(cnf.RNODE, _nn(2), 2, sol_kwargs=dict(adaptive=False, dt=1 / 64))
+    o2 = B._solve_opts(r2, (0.0, 1.0))
+    assert o2.adaptive == 0 and o2.dt == 1 / 64
+    with pytest.raises(ValueError):
+        B._solve_opts(cnf.construct(cnf.RNODE, _nn(2), 2, sol_kwargs=dict(adaptive=False)), (0.0, 1.0))
+    with pytest.raises(TypeError):
+        B._solve_opts(cnf.construct(cnf.RNODE, _nn(2), 2, sol_kwargs=dict(callback=1)), (0.0, 1.0))
+
+
+def test_shard_range_partitions_columns():
+    for Bn in (0, 1, 7, 8192, 65536, 65537):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(Bn, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == Bn
+            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
+
+
+def test_loss_from_global_sums_formula():
+    s = np.array([-10.0, 2.0, 3.0, 4.0, 5.0])
+    assert np.isclose(loss_from_global_sums(s, True, (0.1, 0.2, 0.3)), (10 + 0.2 + 0.6 + 1.2) / 5)
+    assert np.isclose(loss_from_global_sums(s, False, (0.1, 0.2, 0.3)), 2.0)
+    with pytest.raises(ValueError):
+        loss_from_global_sums(np.zeros(5), True, (0, 0, 0))
+
+
+def test_augmented_f_argument_count_dispatch():
+    r = cnf.construct(cnf.RNODE, _nn(2), 2)
+    with pytest.raises(TypeError):
+        cnf.augmented_f(1, 2, 3)
