@@ -97,6 +97,14 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` or "
                 f"`make -C {CSRC}`.  There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; the dynamic
+        # loader shares one HIP runtime per soname, so torch's copy has to be the one that
+        # gets loaded (a system runtime loaded first, paired with torch's HSA, sees no
+        # device).  Without torch the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             f = getattr(l, name)
