@@ -362,8 +362,11 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
     const size_t n = (size_t)D * B;
     int launches = 0;
 
+    const bool use_mfma = k == CNF_KERNEL_MFMA;
+    // number of error partials = blocks of whichever kernel writes them
     int nblk = (int)((n + 255) / 256);
     if (nblk > 256) nblk = 256;
+    if (use_mfma) nblk = mfma_grid_for(B);
 
     // initial state
     StepState* init = &h->h_state[2];
@@ -384,7 +387,6 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
     HIPCHK(h, hipMemcpyAsync(h->d_state, init, sizeof(StepState), hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
 
-    const bool use_mfma = k == CNF_KERNEL_MFMA;
     // k1 = f(u0)
     if (use_mfma) {
         s = mfma_rhs(h->mfma, h->nd, train, h->U[0], eps, h->K1[0], B, st);

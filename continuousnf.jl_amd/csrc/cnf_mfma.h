@@ -1,13 +1,34 @@
-// MFMA (v_mfma_f32_*_f32) path of libcnfhip: fused RHS and fused Tsit5 step kernels.
+// MFMA (v_mfma_f32_16x16x4_f32) path of libcnfhip: fused RHS and fused Tsit5 step kernels.
 #pragma once
 #include "../../include/cnfhip.h"
 #include "cnf_dev.h"
 
+#define MF_NB 32          // samples per workgroup tile (two 16-sample MFMA column tiles)
+#define MF_THREADS 512    // 8 waves: 2 per SIMD
+#define MF_LDS_BYTES 163840
+
+// LDS plan, computed on the host and passed by value.
+struct MfmaLayout {
+    int L;
+    int P[CNF_MAX_LAYERS + 1];      // layer sizes padded to a multiple of 16
+    int dims[CNF_MAX_LAYERS + 1];   // true sizes
+    int acts[CNF_MAX_LAYERS];
+    int SW[CNF_MAX_LAYERS];         // row stride of layer l's weight image (floats)
+    int w_off[CNF_MAX_LAYERS];      // offsets inside the weight+bias image
+    int b_off[CNF_MAX_LAYERS];
+    int img_floats;                 // image size (multiple of 4)
+    int SX[CNF_MAX_LAYERS + 1];     // row stride of activation region l ([sample][feature])
+    int x_off[CNF_MAX_LAYERS + 1];  // LDS offsets (floats) of the activation regions
+    int eps_off, du_off, red_off;   // EPS [NB][SX0], DU [NB][SX0], RED [3][P0/16][NB]
+    int total_floats;
+    int n_in, norm_z, norm_j;
+    int ept;                        // state elements per thread: ceil(NB*(n_in+3)/MF_THREADS)
+};
+
 struct MfmaPlan {
-    int variant = 0;            // 0: unsupported shape
-    float* d_packed = nullptr;  // weights re-laid for the kernel (padded, LDS image order)
-    size_t packed_floats = 0;
-    int pdims[CNF_MAX_LAYERS + 1] = {0};
+    int variant = 0;                // 0: shape not supported by the MFMA path
+    MfmaLayout ly{};
+    float* d_img = nullptr;         // weight+bias image in HBM (LDS order), refreshed by pack
 };
 
 void mfma_plan_init(MfmaPlan& p, const NetDesc& nd);
@@ -16,12 +37,14 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
 bool mfma_supported(const MfmaPlan& p, const NetDesc& nd, bool train, int B);
 cnf_status mfma_rhs(const MfmaPlan& p, const NetDesc& nd, bool train, const float* u,
                     const float* eps, float* du, int B, hipStream_t s);
-// f(u + h*sum_j a_j k_j) with nk = 1 (initial-dt probe) -> Ks[0]
+// f(u + h*k1) -> Ks[0]  (initial-dt probe; h and the buffer set come from *st)
 cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st,
                           float* const U[2], float* const K1[2], float* const Ks[5],
                           const float* eps, int nk, int B, hipStream_t s);
-// one full Tsit5 step attempt (6 RHS evaluations + error partials + controller)
+// one full Tsit5 step attempt: 6 RHS evaluations + error partials in ONE launch, then the
+// one-block controller launch
 cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st,
                      float* const U[2], float* const K1[2], float* const Ks[5],
                      const float* eps, float* partials, int B, hipStream_t s);
 int mfma_step_launches();
+int mfma_grid_for(int B);

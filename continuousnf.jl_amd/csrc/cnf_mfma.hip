@@ -1,12 +1,560 @@
-// MFMA path -- placeholder until the fused kernels land: reports "unsupported" so that
-// AUTO resolves to the generic path and an explicit MFMA request fails loudly.
+// Fused MFMA kernels of libcnfhip (gfx950): the whole augmented RHS -- Dense+activation
+// forward, the reverse (VJP) sweep, the eps^T J eps trace estimate and the regulariser
+// rows -- and, one level up, a whole Tsit5 step (6 RHS evaluations, the stage
+// combinations, the embedded error estimate) in ONE launch, with the stage vectors in
+// registers and every activation in LDS.  HBM traffic per step and sample tile: read u, k1
+// and eps, write u_new and k7.
+//
+// Reference functions taken over (file:line under /root/reference): augmented_f
+// Matrix/Train/VJP src/icnf.jl:318-350 (and its in-place twin :352-382); the Dense layers
+// and the pullback are Lux/Enzyme there (third party), restated per SURVEY.md Appendix B.
+//
+// Work decomposition (one workgroup = 8 waves = 512 lanes, 2 waves per SIMD, 1 per CU):
+//   - a workgroup owns a tile of 32 samples (= two 16-sample MFMA column tiles);
+//   - every layer is a GEMM  Out[o][s] = sum_k W[o][k] X[k][s]  on v_mfma_f32_16x16x4_f32:
+//     A = a 16-row slab of W (forward) or of W^T (reverse), B = 16 samples of X; wave w
+//     takes column tile (w & 1) and the 16-row output tiles (w >> 1) + 4n;
+//   - the accumulator layout (lane = sample, 4 consecutive rows per lane) is exactly what
+//     one ds_write_b128 stores into the [sample][feature] activation image, and what one
+//     ds_read_b128 fetches as the next layer's B operand for 4 consecutive MFMA k-steps:
+//     k-step c of block u contracts feature 16u + 4*(lane>>4) + c on both operands;
+//   - the reverse sweep writes g_l over h_l in place (sigma' is recomputed from h), so one
+//     image per layer serves both sweeps;
+//   - weights live in LDS for the whole launch (one padded row-major copy per layer: read
+//     as b128 along rows forward, as 4 x b32 down columns in reverse).
 #include "cnf_mfma.h"
+#include "cnf_kernels.h"
 
-void mfma_plan_init(MfmaPlan& p, const NetDesc&) { p.variant = 0; }
-void mfma_plan_free(MfmaPlan& p) { if (p.d_packed) (void)hipFree(p.d_packed); p.d_packed = nullptr; }
-cnf_status mfma_plan_pack(MfmaPlan&, const NetDesc&, const float*, hipStream_t) { return CNF_OK; }
-bool mfma_supported(const MfmaPlan&, const NetDesc&, bool, int) { return false; }
-cnf_status mfma_rhs(const MfmaPlan&, const NetDesc&, bool, const float*, const float*, float*, int, hipStream_t) { return CNF_ERR_UNSUPPORTED; }
-cnf_status mfma_rhs_stage(const MfmaPlan&, const NetDesc&, bool, const StepState*, float* const[2], float* const[2], float* const[5], const float*, int, int, hipStream_t) { return CNF_ERR_UNSUPPORTED; }
-cnf_status mfma_step(const MfmaPlan&, const NetDesc&, bool, StepState*, float* const[2], float* const[2], float* const[5], const float*, float*, int, hipStream_t) { return CNF_ERR_UNSUPPORTED; }
-int mfma_step_launches() { return 1; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MfmaArgs {
+    int mode;                 // 0: plain RHS (u -> du), 1: probe f(u + h k1) -> Ks[0], 2: Tsit5 step
+    int B;
+    const float* img;         // weight+bias image
+    const float* eps;         // n_in x B
+    const float* u;           // mode 0
+    float* du;                // mode 0
+    const StepState* st;      // mode 1, 2
+    float* U[2];
+    float* K1[2];
+    float* Ks0;               // mode 1 output
+    float* partials;          // mode 2: 2 floats per workgroup
+};
+
+// ---- activation helpers ------------------------------------------------------------------
+__device__ __forceinline__ float d_from_h(int kind, float h) {
+    switch (kind) {
+        case 0: return 1.0f;
+        case 1: return fmaf(-h, h, 1.0f);
+        case 2: return h * (1.0f - h);
+        case 3: return 1.0f - __expf(-h);            // softplus: sigma'(a) = 1 - exp(-softplus(a))
+        case 4: return h > 0.0f ? 1.0f : 0.0f;
+        default: return h > 0.0f ? 1.0f : h + 1.0f;  // elu
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma4(const f32x4& a, const f32x4& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+
+// Forward GEMM for up to two output tiles of this wave.
+//  xb : this lane's B row  = region_in + (16*sw + s)*SX + 4q
+//  wa0/wa1 : this lane's A rows = W + (16*ot + s)*SW + 4q  for the two tiles
+// ntl == 2: acc0/acc1 are two tiles; ntl == 1: acc0/acc1 split the k-blocks of one tile.
+__device__ __forceinline__ void gemm_fwd(f32x4& acc0, f32x4& acc1, int ntl, int U,
+                                         const float* xb, const float* wa0, const float* wa1) {
+    if (ntl == 2) {
+#pragma unroll 2
+        for (int u = 0; u < U; ++u) {
+            f32x4 b = *(const f32x4*)(xb + 16 * u);
+            f32x4 a0 = *(const f32x4*)(wa0 + 16 * u);
+            f32x4 a1 = *(const f32x4*)(wa1 + 16 * u);
+            acc0 = mfma4(a0, b, acc0);
+            acc1 = mfma4(a1, b, acc1);
+        }
+    } else {
+        int u = 0;
+        for (; u + 2 <= U; u += 2) {
+            f32x4 b0 = *(const f32x4*)(xb + 16 * u);
+            f32x4 b1 = *(const f32x4*)(xb + 16 * u + 16);
+            f32x4 a0 = *(const f32x4*)(wa0 + 16 * u);
+            f32x4 a1 = *(const f32x4*)(wa0 + 16 * u + 16);
+            acc0 = mfma4(a0, b0, acc0);
+            acc1 = mfma4(a1, b1, acc1);
+        }
+        if (u < U) {
+            f32x4 b0 = *(const f32x4*)(xb + 16 * u);
+            f32x4 a0 = *(const f32x4*)(wa0 + 16 * u);
+            acc0 = mfma4(a0, b0, acc0);
+        }
+        acc0 += acc1;
+    }
+}
+
+// Reverse GEMM: Out[k][s] = sum_o W[o][k] G[o][s].
+//  gb : this lane's B row = region_{l+1} + (16*sw + s)*SX + 4q
+//  wc0/wc1 : W + (4q)*SW + 16*kt + s  (column of W, walked down in steps of SW)
+__device__ __forceinline__ void gemm_bwd(f32x4& acc0, f32x4& acc1, int ntl, int U, int SW,
+                                         const float* gb, const float* wc0, const float* wc1) {
+    if (ntl == 2) {
+#pragma unroll 2
+        for (int u = 0; u < U; ++u) {
+            f32x4 b = *(const f32x4*)(gb + 16 * u);
+            const float* p0 = wc0 + 16 * u * SW;
+            const float* p1 = wc1 + 16 * u * SW;
+            f32x4 a0 = {p0[0], p0[SW], p0[2 * SW], p0[3 * SW]};
+            f32x4 a1 = {p1[0], p1[SW], p1[2 * SW], p1[3 * SW]};
+            acc0 = mfma4(a0, b, acc0);
+            acc1 = mfma4(a1, b, acc1);
+        }
+    } else {
+        int u = 0;
+        for (; u + 2 <= U; u += 2) {
+            f32x4 b0 = *(const f32x4*)(gb + 16 * u);
+            f32x4 b1 = *(const f32x4*)(gb + 16 * u + 16);
+            const float* p0 = wc0 + 16 * u * SW;
+            const float* p1 = p0 + 16 * SW;
+            f32x4 a0 = {p0[0], p0[SW], p0[2 * SW], p0[3 * SW]};
+            f32x4 a1 = {p1[0], p1[SW], p1[2 * SW], p1[3 * SW]};
+            acc0 = mfma4(a0, b0, acc0);
+            acc1 = mfma4(a1, b1, acc1);
+        }
+        if (u < U) {
+            f32x4 b0 = *(const f32x4*)(gb + 16 * u);
+            const float* p0 = wc0 + 16 * u * SW;
+            f32x4 a0 = {p0[0], p0[SW], p0[2 * SW], p0[3 * SW]};
+            acc0 = mfma4(a0, b0, acc0);
+        }
+        acc0 += acc1;
+    }
+}
+
+__device__ __forceinline__ float quad_sum(float v) {     // sum over the 4 lanes l, l^16, l^32, l^48
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// ---- the RHS on the tile resident in LDS ---------------------------------------------------
+// In: region_0 holds z ([sample][feature]); EPS holds eps.  Out: DU holds zdot, RED the
+// per-tile partial sums of (|zdot|^2, -eps.(J^T eps), |J^T eps|^2).  Ends with a barrier.
+__device__ __forceinline__ void rhs_tile(const MfmaLayout& ly, float* lds, int lane, int wave) {
+    const int s = lane & 15, q = lane >> 4, sw = wave & 1, fg = wave >> 1;
+    const int row = 16 * sw + s;
+    const int L = ly.L;
+    // ---- forward ----
+    for (int l = 0; l < L; ++l) {
+        const int ntiles = ly.P[l + 1] >> 4, U = ly.P[l] >> 4, SW = ly.SW[l];
+        const float* xb = lds + ly.x_off[l] + row * ly.SX[l] + 4 * q;
+        const float* W = lds + ly.w_off[l];
+        const float* bias = lds + ly.b_off[l];
+        float* out = lds + ly.x_off[l + 1] + row * ly.SX[l + 1] + 4 * q;
+        const int act = ly.acts[l];
+        const bool last = l == L - 1;
+        for (int t0 = fg; t0 < ntiles; t0 += 8) {
+            const int t1 = t0 + 4;
+            const int ntl = t1 < ntiles ? 2 : 1;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float* wa0 = W + (16 * t0 + s) * SW + 4 * q;
+            const float* wa1 = W + (16 * t1 + s) * SW + 4 * q;
+            gemm_fwd(acc0, acc1, ntl, U, xb, wa0, wa1);
+            for (int n = 0; n < ntl; ++n) {
+                const int ot = n ? t1 : t0;
+                f32x4 acc = n ? acc1 : acc0;
+                f32x4 bv = *(const f32x4*)(bias + 16 * ot + 4 * q);
+                float h0, h1, h2, h3, d0, d1, d2, d3;
+                cnf_act(act, acc.x + bv.x, h0, d0);
+                cnf_act(act, acc.y + bv.y, h1, d1);
+                cnf_act(act, acc.z + bv.z, h2, d2);
+                cnf_act(act, acc.w + bv.w, h3, d3);
+                const f32x4 h = {h0, h1, h2, h3}, d = {d0, d1, d2, d3};
+                if (!last) {
+                    *(f32x4*)(out + 16 * ot) = h;
+                } else {
+                    // zdot -> DU, seed g_L = eps .* sigma'_L -> region_L, |zdot|^2 partial -> RED[0]
+                    const int r0 = 16 * ot + 4 * q;
+                    f32x4 ev = *(const f32x4*)(lds + ly.eps_off + row * ly.SX[0] + r0);
+                    f32x4 zd = {r0 + 0 < ly.n_in ? h.x : 0.f, r0 + 1 < ly.n_in ? h.y : 0.f,
+                                r0 + 2 < ly.n_in ? h.z : 0.f, r0 + 3 < ly.n_in ? h.w : 0.f};
+                    *(f32x4*)(lds + ly.du_off + row * ly.SX[0] + r0) = zd;
+                    *(f32x4*)(out + 16 * ot) = ev * d;
+                    float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
+                    if (q == 0) lds[ly.red_off + ot * MF_NB + row] = e2;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- reverse (VJP): g_{l} = (W_{l+1}^T g_{l+1}) .* sigma'_l, in place over h_l ----
+    for (int l = L - 1; l >= 0; --l) {
+        const int ntiles = ly.P[l] >> 4, U = ly.P[l + 1] >> 4, SW = ly.SW[l];
+        const float* gb = lds + ly.x_off[l + 1] + row * ly.SX[l + 1] + 4 * q;
+        const float* W = lds + ly.w_off[l];
+        float* out = lds + ly.x_off[l] + row * ly.SX[l] + 4 * q;
+        const int nt0 = ly.P[0] >> 4;
+        for (int t0 = fg; t0 < ntiles; t0 += 8) {
+            const int t1 = t0 + 4;
+            const int ntl = t1 < ntiles ? 2 : 1;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float* wc0 = W + (4 * q) * SW + 16 * t0 + s;
+            const float* wc1 = W + (4 * q) * SW + 16 * t1 + s;
+            gemm_bwd(acc0, acc1, ntl, U, SW, gb, wc0, wc1);
+            for (int n = 0; n < ntl; ++n) {
+                const int kt = n ? t1 : t0;
+                f32x4 acc = n ? acc1 : acc0;
+                if (l > 0) {
+                    const int pact = ly.acts[l - 1];
+                    f32x4 hv = *(const f32x4*)(out + 16 * kt);
+                    f32x4 g = {acc.x * d_from_h(pact, hv.x), acc.y * d_from_h(pact, hv.y),
+                               acc.z * d_from_h(pact, hv.z), acc.w * d_from_h(pact, hv.w)};
+                    *(f32x4*)(out + 16 * kt) = g;
+                } else {
+                    // eJ = W_1^T g_1 : trace and norm partials (src/icnf.jl:334, :343)
+                    f32x4 ev = *(const f32x4*)(lds + ly.eps_off + row * ly.SX[0] + 16 * kt + 4 * q);
+                    float ld = -(acc.x * ev.x + acc.y * ev.y + acc.z * ev.z + acc.w * ev.w);
+                    float n2 = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+                    ld = quad_sum(ld);
+                    n2 = quad_sum(n2);
+                    if (q == 0) {
+                        lds[ly.red_off + (nt0 + kt) * MF_NB + row] = ld;
+                        lds[ly.red_off + (2 * nt0 + kt) * MF_NB + row] = n2;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// du element (sample sl, row r) from DU / RED after rhs_tile
+__device__ __forceinline__ float du_elem(const MfmaLayout& ly, const float* lds, int sl, int r) {
+    const int n_in = ly.n_in, nt0 = ly.P[0] >> 4;
+    if (r < n_in) return lds[ly.du_off + sl * ly.SX[0] + r];
+    const int kind = r - n_in;            // 0: ldot, 1: Edot, 2: ndot
+    const int base = ly.red_off + (kind == 0 ? nt0 : kind == 1 ? 0 : 2 * nt0) * MF_NB + sl;
+    float v = 0.f;
+    for (int t = 0; t < nt0; ++t) v += lds[base + t * MF_NB];
+    if (kind == 0) return v;
+    if (kind == 1) return ly.norm_z ? sqrtf(v) : 0.f;
+    return ly.norm_j ? sqrtf(v) : 0.f;
+}
+
+template <int S>
+__device__ __forceinline__ float stage_acc(const float (&k)[7], int) {
+    constexpr float A[7][6] = {
+        {0, 0, 0, 0, 0, 0},
+        {TS_A21, 0, 0, 0, 0, 0},
+        {TS_A31, TS_A32, 0, 0, 0, 0},
+        {TS_A41, TS_A42, TS_A43, 0, 0, 0},
+        {TS_A51, TS_A52, TS_A53, TS_A54, 0, 0},
+        {TS_A61, TS_A62, TS_A63, TS_A64, TS_A65, 0},
+        {TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76}};
+    float acc = A[S][0] * k[0];
+#pragma unroll
+    for (int j = 1; j < S; ++j) acc = fmaf(A[S][j], k[j], acc);
+    return acc;
+}
+
+template <int EPT>
+__global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(MfmaLayout ly, MfmaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const StepState* st = a.st;
+    if (st && st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_in = ly.n_in, D = n_in + 3;
+    const int mode = a.mode;
+
+    // weights + biases -> LDS (once per workgroup), activation images zeroed (padding
+    // columns must hold finite values: they meet zero weights)
+    for (int i = tid * 4; i < ly.img_floats; i += MF_THREADS * 4)
+        *(f32x4*)(lds + i) = *(const f32x4*)(a.img + i);
+    for (int i = ly.img_floats + tid; i < ly.total_floats; i += MF_THREADS) lds[i] = 0.f;
+
+    // element ownership: thread t holds state elements e = t + 512 j of the tile's
+    // [sample][row] block (the HBM order: coalesced loads and stores)
+    int esl[EPT], er[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int e = tid + MF_THREADS * j;
+        esl[j] = e / D;
+        er[j] = e - esl[j] * D;
+    }
+    int cur = 0;
+    float hstep = 0.f, abstol = 0.f, reltol = 0.f;
+    if (st) { cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol; }
+    const float* Uin = mode == 0 ? a.u : a.U[cur];
+    const float* K1in = mode == 0 ? nullptr : a.K1[cur];
+    float errsum = 0.f, badcnt = 0.f;
+
+    const int ntile = (a.B + MF_NB - 1) / MF_NB;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int b0 = tile * MF_NB;
+        const int nvalid = min(MF_NB, a.B - b0);
+        const int nel = nvalid * D;
+        const size_t gbase = (size_t)b0 * D;
+        __syncthreads();   // previous tile's LDS reads are done
+        // eps tile -> EPS[sample][feature]
+        for (int i = tid; i < MF_NB * n_in; i += MF_THREADS) {
+            const int sl = i / n_in, r = i - sl * n_in;
+            lds[ly.eps_off + sl * ly.SX[0] + r] = sl < nvalid ? a.eps[(size_t)(b0 + sl) * n_in + r] : 0.f;
+        }
+        float u[EPT], k[EPT][7];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int e = tid + MF_THREADS * j;
+            const bool v = e < nel;
+            u[j] = v ? Uin[gbase + e] : 0.f;
+            k[j][0] = (v && K1in) ? K1in[gbase + e] : 0.f;
+#pragma unroll
+            for (int i = 1; i < 7; ++i) k[j][i] = 0.f;
+        }
+        const int nstage = mode == 2 ? 6 : 1;
+        float unew[EPT];
+        for (int stg = 1; stg <= nstage; ++stg) {
+            // stage state -> region_0 (z rows), kept as u_new at the last stage
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                float v = u[j];
+                if (mode == 1) v = fmaf(hstep, k[j][0], v);
+                if (mode == 2) {
+                    float acc;
+                    switch (stg) {
+                        case 1: acc = stage_acc<1>(k[j], 0); break;
+                        case 2: acc = stage_acc<2>(k[j], 0); break;
+                        case 3: acc = stage_acc<3>(k[j], 0); break;
+                        case 4: acc = stage_acc<4>(k[j], 0); break;
+                        case 5: acc = stage_acc<5>(k[j], 0); break;
+                        default: acc = stage_acc<6>(k[j], 0); break;
+                    }
+                    v = fmaf(hstep, acc, v);
+                }
+                unew[j] = v;
+                if (er[j] < n_in && esl[j] < MF_NB) lds[ly.x_off[0] + esl[j] * ly.SX[0] + er[j]] = v;
+            }
+            __syncthreads();
+            rhs_tile(ly, lds, lane, wave);
+            // du -> k_{stg+1} (mode 2) or straight out
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                float dv = esl[j] < MF_NB ? du_elem(ly, lds, esl[j], er[j]) : 0.f;
+                if (mode == 2) {
+                    switch (stg) {
+                        case 1: k[j][1] = dv; break;
+                        case 2: k[j][2] = dv; break;
+                        case 3: k[j][3] = dv; break;
+                        case 4: k[j][4] = dv; break;
+                        case 5: k[j][5] = dv; break;
+                        default: k[j][6] = dv; break;
+                    }
+                } else {
+                    k[j][1] = dv;
+                }
+            }
+            // (the next stage's region_0 / RED writes are ordered behind these reads by the
+            //  barrier that follows the region_0 write)
+            __syncthreads();
+        }
+        // ---- outputs ----
+        if (mode == 0 || mode == 1) {
+            float* out = mode == 0 ? a.du : a.Ks0;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const int e = tid + MF_THREADS * j;
+                if (e < nel) out[gbase + e] = k[j][1];
+            }
+        } else {
+            float* Un = a.U[1 - cur];
+            float* K7 = a.K1[1 - cur];
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const int e = tid + MF_THREADS * j;
+                if (e < nel) {
+                    Un[gbase + e] = unew[j];
+                    K7[gbase + e] = k[j][6];
+                    float er_ = TS_BT1 * k[j][0];
+                    er_ = fmaf(TS_BT2, k[j][1], er_);
+                    er_ = fmaf(TS_BT3, k[j][2], er_);
+                    er_ = fmaf(TS_BT4, k[j][3], er_);
+                    er_ = fmaf(TS_BT5, k[j][4], er_);
+                    er_ = fmaf(TS_BT6, k[j][5], er_);
+                    er_ = fmaf(TS_BT7, k[j][6], er_);
+                    er_ *= hstep;
+                    const float sc = fmaf(fmaxf(fabsf(u[j]), fabsf(unew[j])), reltol, abstol);
+                    const float x = er_ / sc;
+                    errsum = fmaf(x, x, errsum);
+                    if (!(fabsf(unew[j]) <= 3.0e38f)) badcnt += 1.f;
+                }
+            }
+        }
+    }
+    if (mode == 2) {
+        // deterministic block reduction of the error partial (fixed tree, fixed order)
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) {
+            errsum += __shfl_down(errsum, off, 64);
+            badcnt += __shfl_down(badcnt, off, 64);
+        }
+        if (lane == 0) { lds[ly.red_off + wave] = errsum; lds[ly.red_off + 8 + wave] = badcnt; }
+        __syncthreads();
+        if (tid == 0) {
+            float e = 0.f, b = 0.f;
+            for (int w = 0; w < MF_THREADS / 64; ++w) { e += lds[ly.red_off + w]; b += lds[ly.red_off + 8 + w]; }
+            a.partials[2 * blockIdx.x] = e;
+            a.partials[2 * blockIdx.x + 1] = b;
+        }
+    }
+}
+
+// ---- weight image packing -------------------------------------------------------------------
+__global__ void k_pack_image(MfmaLayout ly, NetDesc nd, const float* __restrict__ P,
+                             float* __restrict__ img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ly.img_floats) return;
+    float v = 0.f;
+    for (int l = 0; l < ly.L; ++l) {
+        const int wsz = ly.P[l + 1] * ly.SW[l];
+        if (i >= ly.w_off[l] && i < ly.w_off[l] + wsz) {
+            const int o = (i - ly.w_off[l]) / ly.SW[l], k = (i - ly.w_off[l]) % ly.SW[l];
+            if (o < nd.dims[l + 1] && k < nd.dims[l]) v = P[nd.w_off[l] + o + (size_t)k * nd.dims[l + 1]];
+        }
+        if (i >= ly.b_off[l] && i < ly.b_off[l] + ly.P[l + 1]) {
+            const int o = i - ly.b_off[l];
+            if (o < nd.dims[l + 1]) v = P[nd.b_off[l] + o];
+        }
+    }
+    img[i] = v;
+}
+
+// ---- host side ----------------------------------------------------------------------------
+static inline int pad_to(int x, int residue, int modulus) {   // smallest y >= x with y % modulus == residue
+    int y = x + ((residue - x) % modulus + modulus) % modulus;
+    return y;
+}
+
+void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
+    p.variant = 0;
+    MfmaLayout& ly = p.ly;
+    ly = MfmaLayout{};
+    ly.L = nd.n_layers;
+    for (int l = 0; l <= nd.n_layers; ++l) {
+        ly.dims[l] = nd.dims[l];
+        ly.P[l] = (nd.dims[l] + 15) & ~15;
+    }
+    int off = 0;
+    for (int l = 0; l < nd.n_layers; ++l) {
+        ly.acts[l] = nd.acts[l];
+        if (nd.acts[l] == CNF_ACT_SWISH && l < nd.n_layers - 1) return;  // sigma' not recoverable from h
+        ly.SW[l] = pad_to(ly.P[l], 4, 16);   // b32 column reads conflict-free, b128 row reads 1 conflict
+        ly.w_off[l] = off;
+        off += ly.P[l + 1] * ly.SW[l];
+    }
+    for (int l = 0; l < nd.n_layers; ++l) { ly.b_off[l] = off; off += ly.P[l + 1]; }
+    ly.img_floats = (off + 3) & ~3;
+    off = ly.img_floats;
+    for (int l = 0; l <= nd.n_layers; ++l) {
+        ly.SX[l] = pad_to(ly.P[l], 8, 16);   // conflict-free ds_read/write_b128 of [sample][feature]
+        ly.x_off[l] = off;
+        off += MF_NB * ly.SX[l];
+    }
+    ly.eps_off = off; off += MF_NB * ly.SX[0];
+    ly.du_off = off;  off += MF_NB * ly.SX[0];
+    ly.red_off = off;
+    int red = 3 * (ly.P[0] >> 4) * MF_NB;
+    off += red < 16 ? 16 : red;
+    ly.total_floats = off;
+    ly.n_in = nd.n_in;
+    ly.norm_z = nd.norm_z;
+    ly.norm_j = nd.norm_j;
+    ly.ept = (MF_NB * (nd.n_in + 3) + MF_THREADS - 1) / MF_THREADS;
+    if ((size_t)ly.total_floats * sizeof(float) > MF_LDS_BYTES) return;   // weights do not fit in LDS
+    if (ly.ept > 9) return;
+    if (nd.jvp) return;                                                    // forward-mode sweep: generic path
+    p.variant = 1;
+}
+
+void mfma_plan_free(MfmaPlan& p) {
+    if (p.d_img) (void)hipFree(p.d_img);
+    p.d_img = nullptr;
+}
+
+template <int EPT>
+static hipError_t set_attr() {
+    return hipFuncSetAttribute((const void*)k_mfma<EPT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               MF_LDS_BYTES);
+}
+
+cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params, hipStream_t s) {
+    if (!p.variant) return CNF_OK;
+    if (!p.d_img) {
+        if (hipMalloc(&p.d_img, (size_t)p.ly.img_floats * sizeof(float)) != hipSuccess) return CNF_ERR_HIP;
+        hipError_t e = set_attr<1>();
+        if (e == hipSuccess) e = set_attr<2>();
+        if (e == hipSuccess) e = set_attr<3>();
+        if (e == hipSuccess) e = set_attr<5>();
+        if (e == hipSuccess) e = set_attr<9>();
+        if (e != hipSuccess) return CNF_ERR_HIP;
+    }
+    hipLaunchKernelGGL(k_pack_image, dim3((p.ly.img_floats + 255) / 256), dim3(256), 0, s, p.ly, nd,
+                       d_params, p.d_img);
+    return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+bool mfma_supported(const MfmaPlan& p, const NetDesc&, bool train, int) {
+    return p.variant != 0 && train;      // TestMode (exact trace) runs on the generic path
+}
+
+int mfma_grid_for(int B) {
+    int nt = (B + MF_NB - 1) / MF_NB;
+    return nt < 512 ? (nt < 1 ? 1 : nt) : 512;
+}
+
+static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a, hipStream_t s) {
+    const dim3 grid(mfma_grid_for(a.B)), block(MF_THREADS);
+    const size_t shm = (size_t)p.ly.total_floats * sizeof(float);
+    const int ept = p.ly.ept;
+    if (ept <= 1) hipLaunchKernelGGL(k_mfma<1>, grid, block, shm, s, p.ly, a);
+    else if (ept <= 2) hipLaunchKernelGGL(k_mfma<2>, grid, block, shm, s, p.ly, a);
+    else if (ept <= 3) hipLaunchKernelGGL(k_mfma<3>, grid, block, shm, s, p.ly, a);
+    else if (ept <= 5) hipLaunchKernelGGL(k_mfma<5>, grid, block, shm, s, p.ly, a);
+    else hipLaunchKernelGGL(k_mfma<9>, grid, block, shm, s, p.ly, a);
+    return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+cnf_status mfma_rhs(const MfmaPlan& p, const NetDesc&, bool train, const float* u,
+                    const float* eps, float* du, int B, hipStream_t s) {
+    if (!p.variant || !train) return CNF_ERR_UNSUPPORTED;
+    MfmaArgs a{};
+    a.mode = 0; a.B = B; a.img = p.d_img; a.eps = eps; a.u = u; a.du = du;
+    return launch(p, a, s);
+}
+
+cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc&, bool train, const StepState* st,
+                          float* const U[2], float* const K1[2], float* const Ks[5],
+                          const float* eps, int nk, int B, hipStream_t s) {
+    if (!p.variant || !train || nk != 1) return CNF_ERR_UNSUPPORTED;
+    MfmaArgs a{};
+    a.mode = 1; a.B = B; a.img = p.d_img; a.eps = eps; a.st = st;
+    a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1]; a.Ks0 = Ks[0];
+    return launch(p, a, s);
+}
+
+
+cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st,
+                     float* const U[2], float* const K1[2], float* const Ks[5],
+                     const float* eps, float* partials, int B, hipStream_t s) {
+    if (!p.variant || !train) return CNF_ERR_UNSUPPORTED;
+    MfmaArgs a{};
+    a.mode = 2; a.B = B; a.img = p.d_img; a.eps = eps; a.st = st;
+    a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1]; a.Ks0 = Ks[0];
+    a.partials = partials;
+    cnf_status r = launch(p, a, s);
+    if (r != CNF_OK) return r;
+    launch_controller(st, partials, 2, (float)((size_t)(nd.n_in + 3) * B), s);
+    return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+int mfma_step_launches() { return 2; }

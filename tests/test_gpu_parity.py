@@ -24,6 +24,12 @@ def _skip_if_unsupported(icnf, mode, B):
             pytest.skip("no MFMA kernel for this shape")
 
 
+def _supported(icnf, mode, B):
+    if icnf.compute_mode.kernel != "mfma":
+        return True
+    return _lib.lib().cnf_kernel_for(icnf.handle(), mode.cnf, B) == _lib.KERNEL_MFMA
+
+
 def _dev(x):
     return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
 
@@ -37,7 +43,9 @@ def test_rhs_matches_golden(name, kernel):
     g, cfg = load_golden(name)
     for jvp in (False, True):
         icnf = make_icnf(cnf, cfg, jvp=jvp, kernel=kernel)
-        _skip_if_unsupported(icnf, cnf.TrainMode(), g["u_train"].shape[1])
+        if not _supported(icnf, cnf.TrainMode(), g["u_train"].shape[1]):
+            icnf.close()
+            continue
         tag = "jvp" if jvp else "vjp"
         # host arrays -> cnf_rhs_host; device tensors -> cnf_rhs
         du = cnf.augmented_f(g["u_train"], g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, g["eps"])
@@ -45,8 +53,13 @@ def test_rhs_matches_golden(name, kernel):
         du_d = cnf.augmented_f(_dev(g["u_train"]), g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, _dev(g["eps"]))
         assert du_d.shape == g["u_train"].shape
         assert_parity(du_d.cpu().numpy(), g[f"du_train_{tag}"], f"{name} train {tag} device")
-        dt = cnf.augmented_f(g["u_train"][: cfg.n_in + 1], g["flat"], 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)
-        assert_parity(dt, g["du_test"], f"{name} test")
+        if _supported(icnf, cnf.TestMode(), g["u_train"].shape[1]):
+            dt = cnf.augmented_f(g["u_train"][: cfg.n_in + 1], g["flat"], 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)
+            assert_parity(dt, g["du_test"], f"{name} test")
+        else:   # an explicit request for a kernel that does not exist fails loudly
+            with pytest.raises(cnf.CNFError) as e:
+                cnf.augmented_f(g["u_train"][: cfg.n_in + 1], g["flat"], 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)
+            assert e.value.status == _lib.ERR_UNSUPPORTED
         icnf.close()
 
 
@@ -90,7 +103,9 @@ def test_rhs_baseline_configs_vs_c_oracle(i, kernel):
     for jvp in (False, True):
         cfg.use_jvp = jvp
         icnf = make_icnf(cnf, cfg, jvp=jvp, kernel=kernel)
-        _skip_if_unsupported(icnf, cnf.TrainMode(), B)
+        if not _supported(icnf, cnf.TrainMode(), B):
+            icnf.close()
+            continue
         du = cnf.augmented_f(u, flat, 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, eps)
         ref = cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True)(u.astype(np.float64))
         assert_parity(du, ref, f"cfg{i} train jvp={jvp}")
@@ -99,6 +114,8 @@ def test_rhs_baseline_configs_vs_c_oracle(i, kernel):
     cfg.use_jvp = False
     icnf = make_icnf(cnf, cfg, kernel=kernel)
     Bt = min(B, 64)
+    if not _supported(icnf, cnf.TestMode(), Bt):
+        return
     dt = cnf.augmented_f(u[: cfg.n_in + 1, :Bt], flat, 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)
     assert_parity(dt, CO.rhs(cfg, flat, u[: cfg.n_in + 1, :Bt], None, False), f"cfg{i} test")
 
@@ -114,7 +131,9 @@ def test_fixed_dt_inference_matches_golden(name, kernel):
     for jvp in (False, True):
         tag = "jvp" if jvp else "vjp"
         icnf = make_icnf(cnf, cfg, jvp=jvp, kernel=kernel, sol_kwargs=kw)
-        _skip_if_unsupported(icnf, cnf.TrainMode(), g["xs"].shape[1])
+        if not _supported(icnf, cnf.TrainMode(), g["xs"].shape[1]):
+            icnf.close()
+            continue
         prob = cnf.inference_prob(icnf, cnf.TrainMode(), _dev(g["xs"]), g["flat"], {}, eps=_dev(g["eps"]))
         fsol = cnf.base_sol(icnf, prob)
         assert prob.stats["nf"] == int(g[f"nf_train_{tag}"])
@@ -126,6 +145,8 @@ def test_fixed_dt_inference_matches_golden(name, kernel):
         assert abs(L - float(g[f"loss_train_{tag}"])) <= 1e-4 * max(1.0, abs(float(g[f"loss_train_{tag}"])))
         icnf.close()
     icnf = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=kw)
+    if not _supported(icnf, cnf.TestMode(), g["xs"].shape[1]):
+        return
     logpx, (E, n, A) = cnf.inference(icnf, cnf.TestMode(), g["xs"], g["flat"], {})      # host arrays
     assert_parity(logpx, g["logpx_test"], f"{name} logpx test")
     assert np.all(E == 0) and np.all(n == 0)
