@@ -22,8 +22,15 @@
 //     image per layer serves both sweeps;
 //   - weights live in LDS for the whole launch (one padded row-major copy per layer: read
 //     as b128 along rows forward, as 4 x b32 down columns in reverse).
+//
+// Two layout flavours drive the same kernel template: RtLayout (every size a run-time
+// value: any network whose images fit in LDS) and StLayout<...> (sizes and activations
+// are compile-time constants: LDS offsets become instruction immediates, layer loops
+// unroll, no integer address arithmetic is left in the GEMM phases).
 #include "cnf_mfma.h"
 #include "cnf_kernels.h"
+
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -41,7 +48,107 @@ struct MfmaArgs {
     float* partials;          // mode 2: 2 floats per workgroup
 };
 
+// ---- layouts -------------------------------------------------------------------------------
+__host__ __device__ constexpr int pad_to(int x, int residue, int modulus) {  // smallest y >= x, y % modulus == residue
+    return x + ((residue - x) % modulus + modulus) % modulus;
+}
+__host__ __device__ constexpr int sw_of(int p_in) { return pad_to(p_in, 4, 16); }  // weight row stride
+__host__ __device__ constexpr int sx_of(int p) { return pad_to(p, 8, 16); }        // activation row stride
+
+// run-time layout: thin accessor wrapper over the plan's MfmaLayout
+struct RtLayout {
+    static constexpr bool kStatic = false;
+    MfmaLayout m;
+    __device__ __forceinline__ int L() const { return m.L; }
+    __device__ __forceinline__ int P(int l) const { return m.P[l]; }
+    __device__ __forceinline__ int act(int l) const { return m.acts[l]; }
+    __device__ __forceinline__ int SW(int l) const { return m.SW[l]; }
+    __device__ __forceinline__ int SX(int l) const { return m.SX[l]; }
+    __device__ __forceinline__ int w_off(int l) const { return m.w_off[l]; }
+    __device__ __forceinline__ int b_off(int l) const { return m.b_off[l]; }
+    __device__ __forceinline__ int x_off(int l) const { return m.x_off[l]; }
+    __device__ __forceinline__ int img_floats() const { return m.img_floats; }
+    __device__ __forceinline__ int eps_off() const { return m.eps_off; }
+    __device__ __forceinline__ int du_off() const { return m.du_off; }
+    __device__ __forceinline__ int red_off() const { return m.red_off; }
+    __device__ __forceinline__ int total_floats() const { return m.total_floats; }
+    __device__ __forceinline__ int n_in() const { return m.n_in; }
+    __device__ __forceinline__ int norm_z() const { return m.norm_z; }
+    __device__ __forceinline__ int norm_j() const { return m.norm_j; }
+};
+
+// compile-time layout: same formulas as mfma_plan_init, evaluated by the compiler
+template <int ACT, int... PD>
+struct StLayout {
+    static constexpr bool kStatic = true;
+    static constexpr int kL = sizeof...(PD) - 1;
+    int n_in_, norm_z_, norm_j_;
+    __host__ __device__ static constexpr int pd(int l) { constexpr int a[] = {PD...}; return a[l]; }
+    __host__ __device__ static constexpr int L() { return kL; }
+    __host__ __device__ static constexpr int P(int l) { return pd(l); }
+    __host__ __device__ static constexpr int act(int) { return ACT; }
+    __host__ __device__ static constexpr int SW(int l) { return sw_of(pd(l)); }
+    __host__ __device__ static constexpr int SX(int l) { return sx_of(pd(l)); }
+    __host__ __device__ static constexpr int w_off(int l) {
+        int off = 0;
+        for (int i = 0; i < l; ++i) off += pd(i + 1) * sw_of(pd(i));
+        return off;
+    }
+    __host__ __device__ static constexpr int b_off(int l) {
+        int off = w_off(kL);
+        for (int i = 0; i < l; ++i) off += pd(i + 1);
+        return off;
+    }
+    __host__ __device__ static constexpr int img_floats() { return (b_off(kL) + 3) & ~3; }
+    __host__ __device__ static constexpr int x_off(int l) {
+        int off = img_floats();
+        for (int i = 0; i < l; ++i) off += MF_NB * sx_of(pd(i));
+        return off;
+    }
+    __host__ __device__ static constexpr int eps_off() { return x_off(kL + 1); }
+    __host__ __device__ static constexpr int du_off() { return eps_off() + MF_NB * sx_of(pd(0)); }
+    __host__ __device__ static constexpr int red_off() { return du_off() + MF_NB * sx_of(pd(0)); }
+    __host__ __device__ static constexpr int red_floats() {
+        return 3 * (pd(0) / 16) * MF_NB < 16 ? 16 : 3 * (pd(0) / 16) * MF_NB;
+    }
+    __host__ __device__ static constexpr int total_floats() { return red_off() + red_floats(); }
+    __device__ __forceinline__ int n_in() const { return n_in_; }
+    __device__ __forceinline__ int norm_z() const { return norm_z_; }
+    __device__ __forceinline__ int norm_j() const { return norm_j_; }
+};
+
+// layer loops: unrolled with compile-time indices for static layouts, plain loops otherwise
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_up(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_up<I + 1, N>(f); }
+}
+template <int I, class F>
+__device__ __forceinline__ void static_for_down(F&& f) {
+    if constexpr (I >= 0) { f(std::integral_constant<int, I>{}); static_for_down<I - 1>(f); }
+}
+template <class LY, class F>
+__device__ __forceinline__ void for_layers_up(const LY& ly, F&& f) {
+    if constexpr (LY::kStatic) static_for_up<0, LY::kL>(f);
+    else for (int l = 0; l < ly.L(); ++l) f(l);
+}
+template <class LY, class F>
+__device__ __forceinline__ void for_layers_down(const LY& ly, F&& f) {
+    if constexpr (LY::kStatic) static_for_down<LY::kL - 1>(f);
+    else for (int l = ly.L() - 1; l >= 0; --l) f(l);
+}
+
 // ---- activation helpers ------------------------------------------------------------------
+// tanh(a) = 1 - 2/(exp(2a) + 1): v_mul, v_exp, v_add, v_rcp, v_fma.  Absolute error
+// <= 2e-7 (one rounding of values near 1), which is what every other fp32 activation value
+// carries; measured against the parity metric it is indistinguishable from libm's tanh.
+__device__ __forceinline__ float tanh_fast(float a) {
+    const float t = __builtin_amdgcn_exp2f(a * 2.8853900817779268f);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
+}
+__device__ __forceinline__ void act_fast(int kind, float a, float& h, float& d) {
+    if (kind == 1) { h = tanh_fast(a); d = fmaf(-h, h, 1.0f); }
+    else cnf_act(kind, a, h, d);
+}
 __device__ __forceinline__ float d_from_h(int kind, float h) {
     switch (kind) {
         case 0: return 1.0f;
@@ -61,75 +168,100 @@ __device__ __forceinline__ f32x4 mfma4(const f32x4& a, const f32x4& b, f32x4 c) 
     return c;
 }
 
-// Forward GEMM for up to two output tiles of this wave.
-//  xb : this lane's B row  = region_in + (16*sw + s)*SX + 4q
-//  wa0/wa1 : this lane's A rows = W + (16*ot + s)*SW + 4q  for the two tiles
-// ntl == 2: acc0/acc1 are two tiles; ntl == 1: acc0/acc1 split the k-blocks of one tile.
-__device__ __forceinline__ void gemm_fwd(f32x4& acc0, f32x4& acc1, int ntl, int U,
-                                         const float* xb, const float* wa0, const float* wa1) {
-    if (ntl == 2) {
-#pragma unroll 2
-        for (int u = 0; u < U; ++u) {
-            f32x4 b = *(const f32x4*)(xb + 16 * u);
-            f32x4 a0 = *(const f32x4*)(wa0 + 16 * u);
-            f32x4 a1 = *(const f32x4*)(wa1 + 16 * u);
-            acc0 = mfma4(a0, b, acc0);
-            acc1 = mfma4(a1, b, acc1);
+// GEMM bodies, fully unrolled over NU k-blocks (16 features each): every LDS operand is
+// requested first, then the MFMA chain runs behind counted lgkmcnt waits.
+//  NTL == 2: acc0/acc1 are two output tiles sharing the B operand;
+//  NTL == 1: one output tile, even k-blocks -> acc0, odd -> acc1 (two independent MFMA
+//            chains; the caller adds them).
+// Forward:  xb = region_in + (16*sw + s)*SX + 4q;  wa = W + (16*ot + s)*SW + 4q
+template <int NU, int NTL>
+__device__ __forceinline__ void fwd_body(f32x4& acc0, f32x4& acc1, const float* xb,
+                                         const float* wa0, const float* wa1) {
+    f32x4 b[NU], a0[NU], a1[NTL == 2 ? NU : 1];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        b[u] = *(const f32x4*)(xb + 16 * u);
+        a0[u] = *(const f32x4*)(wa0 + 16 * u);
+        if (NTL == 2) a1[u] = *(const f32x4*)(wa1 + 16 * u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        if (NTL == 2) {
+            acc0 = mfma4(a0[u], b[u], acc0);
+            acc1 = mfma4(a1[u], b[u], acc1);
+        } else if (u & 1) {
+            acc1 = mfma4(a0[u], b[u], acc1);
+        } else {
+            acc0 = mfma4(a0[u], b[u], acc0);
         }
-    } else {
-        int u = 0;
-        for (; u + 2 <= U; u += 2) {
-            f32x4 b0 = *(const f32x4*)(xb + 16 * u);
-            f32x4 b1 = *(const f32x4*)(xb + 16 * u + 16);
-            f32x4 a0 = *(const f32x4*)(wa0 + 16 * u);
-            f32x4 a1 = *(const f32x4*)(wa0 + 16 * u + 16);
-            acc0 = mfma4(a0, b0, acc0);
-            acc1 = mfma4(a1, b1, acc1);
+    }
+}
+// Reverse: Out[k][s] = sum_o W[o][k] G[o][s].
+//  gb = region_{l+1} + (16*sw + s)*SX + 4q;  wc = W + (4q)*SW + 16*kt + s (walked down a column)
+template <int NU, int NTL>
+__device__ __forceinline__ void bwd_body(f32x4& acc0, f32x4& acc1, int SW, const float* gb,
+                                         const float* wc0, const float* wc1) {
+    f32x4 b[NU], a0[NU], a1[NTL == 2 ? NU : 1];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        b[u] = *(const f32x4*)(gb + 16 * u);
+        const float* p0 = wc0 + 16 * u * SW;
+        a0[u] = f32x4{p0[0], p0[SW], p0[2 * SW], p0[3 * SW]};
+        if (NTL == 2) {
+            const float* p1 = wc1 + 16 * u * SW;
+            a1[u] = f32x4{p1[0], p1[SW], p1[2 * SW], p1[3 * SW]};
         }
-        if (u < U) {
-            f32x4 b0 = *(const f32x4*)(xb + 16 * u);
-            f32x4 a0 = *(const f32x4*)(wa0 + 16 * u);
-            acc0 = mfma4(a0, b0, acc0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        if (NTL == 2) {
+            acc0 = mfma4(a0[u], b[u], acc0);
+            acc1 = mfma4(a1[u], b[u], acc1);
+        } else if (u & 1) {
+            acc1 = mfma4(a0[u], b[u], acc1);
+        } else {
+            acc0 = mfma4(a0[u], b[u], acc0);
         }
-        acc0 += acc1;
     }
 }
 
-// Reverse GEMM: Out[k][s] = sum_o W[o][k] G[o][s].
-//  gb : this lane's B row = region_{l+1} + (16*sw + s)*SX + 4q
-//  wc0/wc1 : W + (4q)*SW + 16*kt + s  (column of W, walked down in steps of SW)
-__device__ __forceinline__ void gemm_bwd(f32x4& acc0, f32x4& acc1, int ntl, int U, int SW,
-                                         const float* gb, const float* wc0, const float* wc1) {
-    if (ntl == 2) {
-#pragma unroll 2
-        for (int u = 0; u < U; ++u) {
-            f32x4 b = *(const f32x4*)(gb + 16 * u);
-            const float* p0 = wc0 + 16 * u * SW;
-            const float* p1 = wc1 + 16 * u * SW;
-            f32x4 a0 = {p0[0], p0[SW], p0[2 * SW], p0[3 * SW]};
-            f32x4 a1 = {p1[0], p1[SW], p1[2 * SW], p1[3 * SW]};
-            acc0 = mfma4(a0, b, acc0);
-            acc1 = mfma4(a1, b, acc1);
-        }
-    } else {
-        int u = 0;
-        for (; u + 2 <= U; u += 2) {
-            f32x4 b0 = *(const f32x4*)(gb + 16 * u);
-            f32x4 b1 = *(const f32x4*)(gb + 16 * u + 16);
-            const float* p0 = wc0 + 16 * u * SW;
-            const float* p1 = p0 + 16 * SW;
-            f32x4 a0 = {p0[0], p0[SW], p0[2 * SW], p0[3 * SW]};
-            f32x4 a1 = {p1[0], p1[SW], p1[2 * SW], p1[3 * SW]};
-            acc0 = mfma4(a0, b0, acc0);
-            acc1 = mfma4(a1, b1, acc1);
-        }
-        if (u < U) {
-            f32x4 b0 = *(const f32x4*)(gb + 16 * u);
-            const float* p0 = wc0 + 16 * u * SW;
-            f32x4 a0 = {p0[0], p0[SW], p0[2 * SW], p0[3 * SW]};
-            acc0 = mfma4(a0, b0, acc0);
-        }
-        acc0 += acc1;
+// run-time k-block count: blocks of 8, then an exact tail
+template <int NTL>
+__device__ __forceinline__ void gemm_fwd(f32x4& acc0, f32x4& acc1, int U, const float* xb,
+                                         const float* wa0, const float* wa1) {
+    while (U > 8) {
+        fwd_body<8, NTL>(acc0, acc1, xb, wa0, wa1);
+        xb += 128; wa0 += 128; wa1 += 128; U -= 8;
+    }
+    switch (U) {
+        case 1: fwd_body<1, NTL>(acc0, acc1, xb, wa0, wa1); break;
+        case 2: fwd_body<2, NTL>(acc0, acc1, xb, wa0, wa1); break;
+        case 3: fwd_body<3, NTL>(acc0, acc1, xb, wa0, wa1); break;
+        case 4: fwd_body<4, NTL>(acc0, acc1, xb, wa0, wa1); break;
+        case 5: fwd_body<5, NTL>(acc0, acc1, xb, wa0, wa1); break;
+        case 6: fwd_body<6, NTL>(acc0, acc1, xb, wa0, wa1); break;
+        case 7: fwd_body<7, NTL>(acc0, acc1, xb, wa0, wa1); break;
+        default: fwd_body<8, NTL>(acc0, acc1, xb, wa0, wa1); break;
+    }
+}
+template <int NTL>
+__device__ __forceinline__ void gemm_bwd(f32x4& acc0, f32x4& acc1, int U, int SW, const float* gb,
+                                         const float* wc0, const float* wc1) {
+    while (U > 8) {
+        bwd_body<8, NTL>(acc0, acc1, SW, gb, wc0, wc1);
+        gb += 128; wc0 += 128 * SW; wc1 += 128 * SW; U -= 8;
+    }
+    switch (U) {
+        case 1: bwd_body<1, NTL>(acc0, acc1, SW, gb, wc0, wc1); break;
+        case 2: bwd_body<2, NTL>(acc0, acc1, SW, gb, wc0, wc1); break;
+        case 3: bwd_body<3, NTL>(acc0, acc1, SW, gb, wc0, wc1); break;
+        case 4: bwd_body<4, NTL>(acc0, acc1, SW, gb, wc0, wc1); break;
+        case 5: bwd_body<5, NTL>(acc0, acc1, SW, gb, wc0, wc1); break;
+        case 6: bwd_body<6, NTL>(acc0, acc1, SW, gb, wc0, wc1); break;
+        case 7: bwd_body<7, NTL>(acc0, acc1, SW, gb, wc0, wc1); break;
+        default: bwd_body<8, NTL>(acc0, acc1, SW, gb, wc0, wc1); break;
     }
 }
 
@@ -139,112 +271,136 @@ __device__ __forceinline__ float quad_sum(float v) {     // sum over the 4 lanes
     return v;
 }
 
+// ---- epilogues ---------------------------------------------------------------------------------
+// forward tile: bias + activation; hidden layers store h, the last layer stores
+// zdot -> DU, g_L = eps .* sigma'_L -> region_L and |zdot|^2 partials -> RED[0]
+template <class LY>
+__device__ __forceinline__ void fwd_epilogue(const LY& ly, float* lds, int l, bool last, int ot, f32x4 acc,
+                                             int row, int q) {
+    const int r0 = 16 * ot + 4 * q;
+    const f32x4 bv = *(const f32x4*)(lds + ly.b_off(l) + r0);
+    const int act = ly.act(l);
+    float h0, h1, h2, h3, d0, d1, d2, d3;
+    act_fast(act, acc.x + bv.x, h0, d0);
+    act_fast(act, acc.y + bv.y, h1, d1);
+    act_fast(act, acc.z + bv.z, h2, d2);
+    act_fast(act, acc.w + bv.w, h3, d3);
+    float* out = lds + ly.x_off(l + 1) + row * ly.SX(l + 1) + r0;
+    if (!last) {
+        *(f32x4*)out = f32x4{h0, h1, h2, h3};
+    } else {
+        const int n_in = ly.n_in();
+        const f32x4 ev = *(const f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r0);
+        const f32x4 zd = {r0 + 0 < n_in ? h0 : 0.f, r0 + 1 < n_in ? h1 : 0.f,
+                          r0 + 2 < n_in ? h2 : 0.f, r0 + 3 < n_in ? h3 : 0.f};
+        *(f32x4*)(lds + ly.du_off() + row * ly.SX(0) + r0) = zd;
+        *(f32x4*)out = f32x4{ev.x * d0, ev.y * d1, ev.z * d2, ev.w * d3};
+        const float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
+        if (q == 0) lds[ly.red_off() + ot * MF_NB + row] = e2;
+    }
+}
+// reverse tile: hidden layers scale by sigma'(h) in place; layer 0 reduces eJ = W_1^T g_1 to
+// the trace and norm partials (src/icnf.jl:334, :343)
+template <class LY>
+__device__ __forceinline__ void bwd_epilogue(const LY& ly, float* lds, int l, int kt, f32x4 acc, int row,
+                                             int q) {
+    const int r0 = 16 * kt + 4 * q;
+    if (l > 0) {
+        const int pact = ly.act(l - 1);
+        float* out = lds + ly.x_off(l) + row * ly.SX(l) + r0;
+        const f32x4 hv = *(const f32x4*)out;
+        *(f32x4*)out = f32x4{acc.x * d_from_h(pact, hv.x), acc.y * d_from_h(pact, hv.y),
+                             acc.z * d_from_h(pact, hv.z), acc.w * d_from_h(pact, hv.w)};
+    } else {
+        const int nt0 = ly.P(0) >> 4;
+        const f32x4 ev = *(const f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r0);
+        float ld = -(acc.x * ev.x + acc.y * ev.y + acc.z * ev.z + acc.w * ev.w);
+        float n2 = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+        ld = quad_sum(ld);
+        n2 = quad_sum(n2);
+        if (q == 0) {
+            lds[ly.red_off() + (nt0 + kt) * MF_NB + row] = ld;
+            lds[ly.red_off() + (2 * nt0 + kt) * MF_NB + row] = n2;
+        }
+    }
+}
+
 // ---- the RHS on the tile resident in LDS ---------------------------------------------------
 // In: region_0 holds z ([sample][feature]); EPS holds eps.  Out: DU holds zdot, RED the
 // per-tile partial sums of (|zdot|^2, -eps.(J^T eps), |J^T eps|^2).  Ends with a barrier.
-__device__ __forceinline__ void rhs_tile(const MfmaLayout& ly, float* lds, int lane, int wave) {
+template <class LY>
+__device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int wave) {
     const int s = lane & 15, q = lane >> 4, sw = wave & 1, fg = wave >> 1;
     const int row = 16 * sw + s;
-    const int L = ly.L;
     // ---- forward ----
-    for (int l = 0; l < L; ++l) {
-        const int ntiles = ly.P[l + 1] >> 4, U = ly.P[l] >> 4, SW = ly.SW[l];
-        const float* xb = lds + ly.x_off[l] + row * ly.SX[l] + 4 * q;
-        const float* W = lds + ly.w_off[l];
-        const float* bias = lds + ly.b_off[l];
-        float* out = lds + ly.x_off[l + 1] + row * ly.SX[l + 1] + 4 * q;
-        const int act = ly.acts[l];
-        const bool last = l == L - 1;
+    for_layers_up(ly, [&](auto l) {
+        const int ntiles = ly.P(l + 1) >> 4, SW = ly.SW(l);
+        const float* xb = lds + ly.x_off(l) + row * ly.SX(l) + 4 * q;
+        const float* W = lds + ly.w_off(l);
+        const bool last = l == ly.L() - 1;
         for (int t0 = fg; t0 < ntiles; t0 += 8) {
             const int t1 = t0 + 4;
-            const int ntl = t1 < ntiles ? 2 : 1;
+            const bool two = t1 < ntiles;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* wa0 = W + (16 * t0 + s) * SW + 4 * q;
             const float* wa1 = W + (16 * t1 + s) * SW + 4 * q;
-            gemm_fwd(acc0, acc1, ntl, U, xb, wa0, wa1);
-            for (int n = 0; n < ntl; ++n) {
-                const int ot = n ? t1 : t0;
-                f32x4 acc = n ? acc1 : acc0;
-                f32x4 bv = *(const f32x4*)(bias + 16 * ot + 4 * q);
-                float h0, h1, h2, h3, d0, d1, d2, d3;
-                cnf_act(act, acc.x + bv.x, h0, d0);
-                cnf_act(act, acc.y + bv.y, h1, d1);
-                cnf_act(act, acc.z + bv.z, h2, d2);
-                cnf_act(act, acc.w + bv.w, h3, d3);
-                const f32x4 h = {h0, h1, h2, h3}, d = {d0, d1, d2, d3};
-                if (!last) {
-                    *(f32x4*)(out + 16 * ot) = h;
-                } else {
-                    // zdot -> DU, seed g_L = eps .* sigma'_L -> region_L, |zdot|^2 partial -> RED[0]
-                    const int r0 = 16 * ot + 4 * q;
-                    f32x4 ev = *(const f32x4*)(lds + ly.eps_off + row * ly.SX[0] + r0);
-                    f32x4 zd = {r0 + 0 < ly.n_in ? h.x : 0.f, r0 + 1 < ly.n_in ? h.y : 0.f,
-                                r0 + 2 < ly.n_in ? h.z : 0.f, r0 + 3 < ly.n_in ? h.w : 0.f};
-                    *(f32x4*)(lds + ly.du_off + row * ly.SX[0] + r0) = zd;
-                    *(f32x4*)(out + 16 * ot) = ev * d;
-                    float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
-                    if (q == 0) lds[ly.red_off + ot * MF_NB + row] = e2;
-                }
+            if constexpr (LY::kStatic) {
+                constexpr int U = LY::P(decltype(l)::value) >> 4;
+                if (two) fwd_body<U, 2>(acc0, acc1, xb, wa0, wa1);
+                else { fwd_body<U, 1>(acc0, acc1, xb, wa0, wa1); acc0 += acc1; }
+            } else {
+                const int U = ly.P(l) >> 4;
+                if (two) gemm_fwd<2>(acc0, acc1, U, xb, wa0, wa1);
+                else { gemm_fwd<1>(acc0, acc1, U, xb, wa0, wa1); acc0 += acc1; }
             }
+            fwd_epilogue(ly, lds, l, last, t0, acc0, row, q);
+            if (two) fwd_epilogue(ly, lds, l, last, t1, acc1, row, q);
         }
         __syncthreads();
-    }
-    // ---- reverse (VJP): g_{l} = (W_{l+1}^T g_{l+1}) .* sigma'_l, in place over h_l ----
-    for (int l = L - 1; l >= 0; --l) {
-        const int ntiles = ly.P[l] >> 4, U = ly.P[l + 1] >> 4, SW = ly.SW[l];
-        const float* gb = lds + ly.x_off[l + 1] + row * ly.SX[l + 1] + 4 * q;
-        const float* W = lds + ly.w_off[l];
-        float* out = lds + ly.x_off[l] + row * ly.SX[l] + 4 * q;
-        const int nt0 = ly.P[0] >> 4;
+    });
+    // ---- reverse (VJP): g_l = (W_{l+1}^T g_{l+1}) .* sigma'_l, in place over h_l ----
+    for_layers_down(ly, [&](auto l) {
+        const int ntiles = ly.P(l) >> 4, SW = ly.SW(l);
+        const float* gb = lds + ly.x_off(l + 1) + row * ly.SX(l + 1) + 4 * q;
+        const float* W = lds + ly.w_off(l);
         for (int t0 = fg; t0 < ntiles; t0 += 8) {
             const int t1 = t0 + 4;
-            const int ntl = t1 < ntiles ? 2 : 1;
+            const bool two = t1 < ntiles;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* wc0 = W + (4 * q) * SW + 16 * t0 + s;
             const float* wc1 = W + (4 * q) * SW + 16 * t1 + s;
-            gemm_bwd(acc0, acc1, ntl, U, SW, gb, wc0, wc1);
-            for (int n = 0; n < ntl; ++n) {
-                const int kt = n ? t1 : t0;
-                f32x4 acc = n ? acc1 : acc0;
-                if (l > 0) {
-                    const int pact = ly.acts[l - 1];
-                    f32x4 hv = *(const f32x4*)(out + 16 * kt);
-                    f32x4 g = {acc.x * d_from_h(pact, hv.x), acc.y * d_from_h(pact, hv.y),
-                               acc.z * d_from_h(pact, hv.z), acc.w * d_from_h(pact, hv.w)};
-                    *(f32x4*)(out + 16 * kt) = g;
-                } else {
-                    // eJ = W_1^T g_1 : trace and norm partials (src/icnf.jl:334, :343)
-                    f32x4 ev = *(const f32x4*)(lds + ly.eps_off + row * ly.SX[0] + 16 * kt + 4 * q);
-                    float ld = -(acc.x * ev.x + acc.y * ev.y + acc.z * ev.z + acc.w * ev.w);
-                    float n2 = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
-                    ld = quad_sum(ld);
-                    n2 = quad_sum(n2);
-                    if (q == 0) {
-                        lds[ly.red_off + (nt0 + kt) * MF_NB + row] = ld;
-                        lds[ly.red_off + (2 * nt0 + kt) * MF_NB + row] = n2;
-                    }
-                }
+            if constexpr (LY::kStatic) {
+                constexpr int U = LY::P(decltype(l)::value + 1) >> 4;
+                if (two) bwd_body<U, 2>(acc0, acc1, SW, gb, wc0, wc1);
+                else { bwd_body<U, 1>(acc0, acc1, SW, gb, wc0, wc1); acc0 += acc1; }
+            } else {
+                const int U = ly.P(l + 1) >> 4;
+                if (two) gemm_bwd<2>(acc0, acc1, U, SW, gb, wc0, wc1);
+                else { gemm_bwd<1>(acc0, acc1, U, SW, gb, wc0, wc1); acc0 += acc1; }
             }
+            bwd_epilogue(ly, lds, l, t0, acc0, row, q);
+            if (two) bwd_epilogue(ly, lds, l, t1, acc1, row, q);
         }
         __syncthreads();
-    }
+    });
 }
 
 // du element (sample sl, row r) from DU / RED after rhs_tile
-__device__ __forceinline__ float du_elem(const MfmaLayout& ly, const float* lds, int sl, int r) {
-    const int n_in = ly.n_in, nt0 = ly.P[0] >> 4;
-    if (r < n_in) return lds[ly.du_off + sl * ly.SX[0] + r];
+template <class LY>
+__device__ __forceinline__ float du_elem(const LY& ly, const float* lds, int sl, int r) {
+    const int n_in = ly.n_in(), nt0 = ly.P(0) >> 4;
+    if (r < n_in) return lds[ly.du_off() + sl * ly.SX(0) + r];
     const int kind = r - n_in;            // 0: ldot, 1: Edot, 2: ndot
-    const int base = ly.red_off + (kind == 0 ? nt0 : kind == 1 ? 0 : 2 * nt0) * MF_NB + sl;
+    const int base = ly.red_off() + (kind == 0 ? nt0 : kind == 1 ? 0 : 2 * nt0) * MF_NB + sl;
     float v = 0.f;
     for (int t = 0; t < nt0; ++t) v += lds[base + t * MF_NB];
     if (kind == 0) return v;
-    if (kind == 1) return ly.norm_z ? sqrtf(v) : 0.f;
-    return ly.norm_j ? sqrtf(v) : 0.f;
+    if (kind == 1) return ly.norm_z() ? sqrtf(v) : 0.f;
+    return ly.norm_j() ? sqrtf(v) : 0.f;
 }
 
 template <int S>
-__device__ __forceinline__ float stage_acc(const float (&k)[7], int) {
+__device__ __forceinline__ float stage_acc(const float (&k)[7]) {
     constexpr float A[7][6] = {
         {0, 0, 0, 0, 0, 0},
         {TS_A21, 0, 0, 0, 0, 0},
@@ -259,20 +415,34 @@ __device__ __forceinline__ float stage_acc(const float (&k)[7], int) {
     return acc;
 }
 
-template <int EPT>
-__global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(MfmaLayout ly, MfmaArgs a) {
+template <class LY, int EPT>
+__global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StepState* st = a.st;
     if (st && st->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_in = ly.n_in, D = n_in + 3;
+    const int n_in = ly.n_in(), D = n_in + 3;
     const int mode = a.mode;
 
-    // weights + biases -> LDS (once per workgroup), activation images zeroed (padding
-    // columns must hold finite values: they meet zero weights)
-    for (int i = tid * 4; i < ly.img_floats; i += MF_THREADS * 4)
-        *(f32x4*)(lds + i) = *(const f32x4*)(a.img + i);
-    for (int i = ly.img_floats + tid; i < ly.total_floats; i += MF_THREADS) lds[i] = 0.f;
+    // weights + biases -> LDS (once per workgroup; 4 x 16 B in flight per lane), the rest of
+    // LDS zeroed (padding columns of the activation images meet zero weights but must be finite)
+    {
+        const int n = ly.img_floats();
+        int i = tid * 4;
+        for (; i + 3 * MF_THREADS * 4 < n; i += 4 * MF_THREADS * 4) {
+            const f32x4 v0 = *(const f32x4*)(a.img + i);
+            const f32x4 v1 = *(const f32x4*)(a.img + i + MF_THREADS * 4);
+            const f32x4 v2 = *(const f32x4*)(a.img + i + 2 * MF_THREADS * 4);
+            const f32x4 v3 = *(const f32x4*)(a.img + i + 3 * MF_THREADS * 4);
+            *(f32x4*)(lds + i) = v0;
+            *(f32x4*)(lds + i + MF_THREADS * 4) = v1;
+            *(f32x4*)(lds + i + 2 * MF_THREADS * 4) = v2;
+            *(f32x4*)(lds + i + 3 * MF_THREADS * 4) = v3;
+        }
+        for (; i < n; i += MF_THREADS * 4) *(f32x4*)(lds + i) = *(const f32x4*)(a.img + i);
+        for (int z = n + tid * 4; z < ly.total_floats(); z += MF_THREADS * 4)
+            *(f32x4*)(lds + z) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // element ownership: thread t holds state elements e = t + 512 j of the tile's
     // [sample][row] block (the HBM order: coalesced loads and stores)
@@ -296,11 +466,11 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(MfmaLayout ly, MfmaArgs 
         const int nvalid = min(MF_NB, a.B - b0);
         const int nel = nvalid * D;
         const size_t gbase = (size_t)b0 * D;
-        __syncthreads();   // previous tile's LDS reads are done
+        __syncthreads();   // image filled / previous tile's LDS reads are done
         // eps tile -> EPS[sample][feature]
         for (int i = tid; i < MF_NB * n_in; i += MF_THREADS) {
             const int sl = i / n_in, r = i - sl * n_in;
-            lds[ly.eps_off + sl * ly.SX[0] + r] = sl < nvalid ? a.eps[(size_t)(b0 + sl) * n_in + r] : 0.f;
+            lds[ly.eps_off() + sl * ly.SX(0) + r] = sl < nvalid ? a.eps[(size_t)(b0 + sl) * n_in + r] : 0.f;
         }
         float u[EPT], k[EPT][7];
 #pragma unroll
@@ -323,24 +493,25 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(MfmaLayout ly, MfmaArgs 
                 if (mode == 2) {
                     float acc;
                     switch (stg) {
-                        case 1: acc = stage_acc<1>(k[j], 0); break;
-                        case 2: acc = stage_acc<2>(k[j], 0); break;
-                        case 3: acc = stage_acc<3>(k[j], 0); break;
-                        case 4: acc = stage_acc<4>(k[j], 0); break;
-                        case 5: acc = stage_acc<5>(k[j], 0); break;
-                        default: acc = stage_acc<6>(k[j], 0); break;
+                        case 1: acc = stage_acc<1>(k[j]); break;
+                        case 2: acc = stage_acc<2>(k[j]); break;
+                        case 3: acc = stage_acc<3>(k[j]); break;
+                        case 4: acc = stage_acc<4>(k[j]); break;
+                        case 5: acc = stage_acc<5>(k[j]); break;
+                        default: acc = stage_acc<6>(k[j]); break;
                     }
                     v = fmaf(hstep, acc, v);
                 }
                 unew[j] = v;
-                if (er[j] < n_in && esl[j] < MF_NB) lds[ly.x_off[0] + esl[j] * ly.SX[0] + er[j]] = v;
+                if (er[j] < n_in && esl[j] < MF_NB) lds[ly.x_off(0) + esl[j] * ly.SX(0) + er[j]] = v;
             }
             __syncthreads();
             rhs_tile(ly, lds, lane, wave);
-            // du -> k_{stg+1} (mode 2) or straight out
+            // du -> k_{stg+1} (mode 2) or straight out.  No barrier afterwards: the next
+            // stage's DU / RED writes come after the barrier that follows its region_0 write.
 #pragma unroll
             for (int j = 0; j < EPT; ++j) {
-                float dv = esl[j] < MF_NB ? du_elem(ly, lds, esl[j], er[j]) : 0.f;
+                const float dv = esl[j] < MF_NB ? du_elem(ly, lds, esl[j], er[j]) : 0.f;
                 if (mode == 2) {
                     switch (stg) {
                         case 1: k[j][1] = dv; break;
@@ -354,9 +525,6 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(MfmaLayout ly, MfmaArgs 
                     k[j][1] = dv;
                 }
             }
-            // (the next stage's region_0 / RED writes are ordered behind these reads by the
-            //  barrier that follows the region_0 write)
-            __syncthreads();
         }
         // ---- outputs ----
         if (mode == 0 || mode == 1) {
@@ -398,11 +566,11 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(MfmaLayout ly, MfmaArgs 
             errsum += __shfl_down(errsum, off, 64);
             badcnt += __shfl_down(badcnt, off, 64);
         }
-        if (lane == 0) { lds[ly.red_off + wave] = errsum; lds[ly.red_off + 8 + wave] = badcnt; }
+        if (lane == 0) { lds[ly.red_off() + wave] = errsum; lds[ly.red_off() + 8 + wave] = badcnt; }
         __syncthreads();
         if (tid == 0) {
             float e = 0.f, b = 0.f;
-            for (int w = 0; w < MF_THREADS / 64; ++w) { e += lds[ly.red_off + w]; b += lds[ly.red_off + 8 + w]; }
+            for (int w = 0; w < MF_THREADS / 64; ++w) { e += lds[ly.red_off() + w]; b += lds[ly.red_off() + 8 + w]; }
             a.partials[2 * blockIdx.x] = e;
             a.partials[2 * blockIdx.x + 1] = b;
         }
@@ -430,9 +598,20 @@ __global__ void k_pack_image(MfmaLayout ly, NetDesc nd, const float* __restrict_
 }
 
 // ---- host side ----------------------------------------------------------------------------
-static inline int pad_to(int x, int residue, int modulus) {   // smallest y >= x with y % modulus == residue
-    int y = x + ((residue - x) % modulus + modulus) % modulus;
-    return y;
+// static instantiations: (activation, padded sizes...) -> kernel.  Variant ids >= 2.
+using LyCfg3 = StLayout<CNF_ACT_TANH, 32, 128, 128, 32>;   // BASELINE configs 3/4
+using LyCfg2 = StLayout<CNF_ACT_TANH, 16, 48, 16>;         // BASELINE config 2
+using LyCfg1 = StLayout<CNF_ACT_TANH, 16, 16, 16>;         // BASELINE config 1 (2->6->2 padded)
+
+template <class LY>
+static bool matches(const MfmaLayout& m) {
+    if (m.L != LY::kL) return false;
+    for (int l = 0; l <= m.L; ++l)
+        if (m.P[l] != LY::P(l)) return false;
+    for (int l = 0; l < m.L; ++l)
+        if (m.acts[l] != LY::act(l)) return false;
+    return m.img_floats == LY::img_floats() && m.total_floats == LY::total_floats() &&
+           m.red_off == LY::red_off() && m.x_off[m.L] == LY::x_off(LY::kL);
 }
 
 void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
@@ -448,7 +627,7 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     for (int l = 0; l < nd.n_layers; ++l) {
         ly.acts[l] = nd.acts[l];
         if (nd.acts[l] == CNF_ACT_SWISH && l < nd.n_layers - 1) return;  // sigma' not recoverable from h
-        ly.SW[l] = pad_to(ly.P[l], 4, 16);   // b32 column reads conflict-free, b128 row reads 1 conflict
+        ly.SW[l] = sw_of(ly.P[l]);
         ly.w_off[l] = off;
         off += ly.P[l + 1] * ly.SW[l];
     }
@@ -456,7 +635,7 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     ly.img_floats = (off + 3) & ~3;
     off = ly.img_floats;
     for (int l = 0; l <= nd.n_layers; ++l) {
-        ly.SX[l] = pad_to(ly.P[l], 8, 16);   // conflict-free ds_read/write_b128 of [sample][feature]
+        ly.SX[l] = sx_of(ly.P[l]);
         ly.x_off[l] = off;
         off += MF_NB * ly.SX[l];
     }
@@ -474,6 +653,9 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     if (ly.ept > 9) return;
     if (nd.jvp) return;                                                    // forward-mode sweep: generic path
     p.variant = 1;
+    if (matches<LyCfg3>(ly)) p.variant = 2;
+    else if (matches<LyCfg2>(ly)) p.variant = 3;
+    else if (matches<LyCfg1>(ly)) p.variant = 4;
 }
 
 void mfma_plan_free(MfmaPlan& p) {
@@ -481,9 +663,9 @@ void mfma_plan_free(MfmaPlan& p) {
     p.d_img = nullptr;
 }
 
-template <int EPT>
+template <class LY, int EPT>
 static hipError_t set_attr() {
-    return hipFuncSetAttribute((const void*)k_mfma<EPT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    return hipFuncSetAttribute((const void*)k_mfma<LY, EPT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                MF_LDS_BYTES);
 }
 
@@ -491,11 +673,14 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
     if (!p.variant) return CNF_OK;
     if (!p.d_img) {
         if (hipMalloc(&p.d_img, (size_t)p.ly.img_floats * sizeof(float)) != hipSuccess) return CNF_ERR_HIP;
-        hipError_t e = set_attr<1>();
-        if (e == hipSuccess) e = set_attr<2>();
-        if (e == hipSuccess) e = set_attr<3>();
-        if (e == hipSuccess) e = set_attr<5>();
-        if (e == hipSuccess) e = set_attr<9>();
+        hipError_t e = set_attr<RtLayout, 1>();
+        if (e == hipSuccess) e = set_attr<RtLayout, 2>();
+        if (e == hipSuccess) e = set_attr<RtLayout, 3>();
+        if (e == hipSuccess) e = set_attr<RtLayout, 5>();
+        if (e == hipSuccess) e = set_attr<RtLayout, 9>();
+        if (e == hipSuccess) e = set_attr<LyCfg3, 3>();
+        if (e == hipSuccess) e = set_attr<LyCfg2, 2>();
+        if (e == hipSuccess) e = set_attr<LyCfg1, 2>();
         if (e != hipSuccess) return CNF_ERR_HIP;
     }
     hipLaunchKernelGGL(k_pack_image, dim3((p.ly.img_floats + 255) / 256), dim3(256), 0, s, p.ly, nd,
@@ -512,15 +697,29 @@ int mfma_grid_for(int B) {
     return nt < 512 ? (nt < 1 ? 1 : nt) : 512;
 }
 
+template <class LY, int EPT>
+static void launch_static(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStream_t s) {
+    LY ly;
+    ly.n_in_ = p.ly.n_in; ly.norm_z_ = p.ly.norm_z; ly.norm_j_ = p.ly.norm_j;
+    hipLaunchKernelGGL((k_mfma<LY, EPT>), grid, dim3(MF_THREADS), (size_t)LY::total_floats() * sizeof(float), s,
+                       ly, a);
+}
+
 static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a, hipStream_t s) {
     const dim3 grid(mfma_grid_for(a.B)), block(MF_THREADS);
     const size_t shm = (size_t)p.ly.total_floats * sizeof(float);
     const int ept = p.ly.ept;
-    if (ept <= 1) hipLaunchKernelGGL(k_mfma<1>, grid, block, shm, s, p.ly, a);
-    else if (ept <= 2) hipLaunchKernelGGL(k_mfma<2>, grid, block, shm, s, p.ly, a);
-    else if (ept <= 3) hipLaunchKernelGGL(k_mfma<3>, grid, block, shm, s, p.ly, a);
-    else if (ept <= 5) hipLaunchKernelGGL(k_mfma<5>, grid, block, shm, s, p.ly, a);
-    else hipLaunchKernelGGL(k_mfma<9>, grid, block, shm, s, p.ly, a);
+    if (p.variant == 2) launch_static<LyCfg3, 3>(p, a, grid, s);
+    else if (p.variant == 3) launch_static<LyCfg2, 2>(p, a, grid, s);
+    else if (p.variant == 4) launch_static<LyCfg1, 2>(p, a, grid, s);
+    else {
+        RtLayout ly{p.ly};
+        if (ept <= 1) hipLaunchKernelGGL((k_mfma<RtLayout, 1>), grid, block, shm, s, ly, a);
+        else if (ept <= 2) hipLaunchKernelGGL((k_mfma<RtLayout, 2>), grid, block, shm, s, ly, a);
+        else if (ept <= 3) hipLaunchKernelGGL((k_mfma<RtLayout, 3>), grid, block, shm, s, ly, a);
+        else if (ept <= 5) hipLaunchKernelGGL((k_mfma<RtLayout, 5>), grid, block, shm, s, ly, a);
+        else hipLaunchKernelGGL((k_mfma<RtLayout, 9>), grid, block, shm, s, ly, a);
+    }
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 
@@ -541,7 +740,6 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc&, bool train, const S
     a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1]; a.Ks0 = Ks[0];
     return launch(p, a, s);
 }
-
 
 cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st,
                      float* const U[2], float* const K1[2], float* const Ks[5],

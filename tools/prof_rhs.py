@@ -1,0 +1,53 @@
+"""Profiling driver: runs N plain RHS launches and/or N fused Tsit5 steps on BASELINE cfg3
+(B = 8192) so that rocprofv3 sees only the kernels of interest.
+usage: python3 tools/prof_rhs.py [rhs|step] [n] [kernel]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import continuousnf.jl_amd as cnf
+from continuousnf.jl_amd import _lib
+from oracle import cnf_oracle as O
+from tests.helpers import make_icnf
+
+what = sys.argv[1] if len(sys.argv) > 1 else "step"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+kernel = sys.argv[3] if len(sys.argv) > 3 else "mfma"
+cfgi = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+cfg, B, _ = O.baseline_cfg(cfgi)
+if cfgi == 5:
+    cfg.lam3 = 1e-2
+rng = np.random.default_rng(0)
+flat = O.glorot_params(cfg.net, rng, np.float32)
+icnf = make_icnf(cnf, cfg, kernel=kernel)
+icnf.set_params(flat)
+l, h = _lib.lib(), icnf.handle()
+D = cfg.D(True)
+dev = torch.device("cuda", 0)
+u = torch.randn(B * D, device=dev)
+eps = torch.randn(B * cfg.n_in, device=dev)
+du = torch.empty_like(u)
+sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+k = {"mfma": 2, "generic": 1, "auto": 0}[kernel]
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+if what == "rhs":
+    for _ in range(3):
+        _lib.check(l.cnf_rhs(h, 1, k, u.data_ptr(), eps.data_ptr(), du.data_ptr(), B, sp), h)
+    e0.record()
+    for _ in range(n):
+        _lib.check(l.cnf_rhs(h, 1, k, u.data_ptr(), eps.data_ptr(), du.data_ptr(), B, sp), h)
+    e1.record(); e1.synchronize()
+    print(f"rhs: {e0.elapsed_time(e1) * 1e3 / n:.2f} us per launch")
+else:
+    opts = _lib.cnf_solve_opts(0.0, 1.0, 0.0, 0.0, 1.0 / n, 0, 1 << 20, k)
+    stats = _lib.cnf_solve_stats()
+    run = lambda: _lib.check(l.cnf_solve_tsit5(h, 1, u.data_ptr(), eps.data_ptr(), du.data_ptr(), B,
+                                               C.byref(opts), C.byref(stats), sp), h)
+    run()
+    e0.record(); run(); e1.record(); e1.synchronize()
+    print(f"step: {e0.elapsed_time(e1) * 1e3 / n:.2f} us per step, nf={stats.nf}")
