@@ -72,6 +72,7 @@ struct RtLayout {
     __device__ __forceinline__ int du_off() const { return m.du_off; }
     __device__ __forceinline__ int red_off() const { return m.red_off; }
     __device__ __forceinline__ int total_floats() const { return m.total_floats; }
+    __device__ __forceinline__ int bar_off() const { return m.total_floats - 16; }
     __device__ __forceinline__ int n_in() const { return m.n_in; }
     __device__ __forceinline__ int norm_z() const { return m.norm_z; }
     __device__ __forceinline__ int norm_j() const { return m.norm_j; }
@@ -111,7 +112,8 @@ struct StLayout {
     __host__ __device__ static constexpr int red_floats() {
         return 3 * (pd(0) / 16) * MF_NB < 16 ? 16 : 3 * (pd(0) / 16) * MF_NB;
     }
-    __host__ __device__ static constexpr int total_floats() { return red_off() + red_floats(); }
+    __host__ __device__ static constexpr int bar_off() { return red_off() + red_floats(); }
+    __host__ __device__ static constexpr int total_floats() { return bar_off() + 16; }
     __device__ __forceinline__ int n_in() const { return n_in_; }
     __device__ __forceinline__ int norm_z() const { return norm_z_; }
     __device__ __forceinline__ int norm_j() const { return norm_j_; }
@@ -146,6 +148,9 @@ __device__ __forceinline__ float tanh_fast(float a) {
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
 }
 __device__ __forceinline__ void act_fast(int kind, float a, float& h, float& d) {
+#ifdef MF_ABL_NOACT
+    h = a; d = 1.0f; return;
+#endif
     if (kind == 1) { h = tanh_fast(a); d = fmaf(-h, h, 1.0f); }
     else cnf_act(kind, a, h, d);
 }
@@ -168,32 +173,70 @@ __device__ __forceinline__ f32x4 mfma4(const f32x4& a, const f32x4& b, f32x4 c) 
     return c;
 }
 
-// GEMM bodies, fully unrolled over NU k-blocks (16 features each): every LDS operand is
-// requested first, then the MFMA chain runs behind counted lgkmcnt waits.
+// GEMM bodies, fully unrolled over NU k-blocks (16 features each) as a rolling software
+// pipeline: the LDS operands of k-block u+2 are requested right after the MFMAs of block u
+// have been issued, so LDS traffic is spread over the phase (no burst of every wave's loads
+// at the phase start) and each request has a whole block of MFMAs (256 cycles) to land.
 //  NTL == 2: acc0/acc1 are two output tiles sharing the B operand;
-//  NTL == 1: one output tile, even k-blocks -> acc0, odd -> acc1 (two independent MFMA
-//            chains; the caller adds them).
+//  NTL == 1: one output tile, k-steps alternate between acc0 and acc1 (two independent
+//            MFMA chains; the caller adds them).
+template <int NTL>
+__device__ __forceinline__ void mfma_block(f32x4& acc0, f32x4& acc1, const f32x4& b, const f32x4& a0,
+                                           const f32x4& a1) {
+#ifdef MF_ABL_NOMFMA
+    acc0 += a0 * b; if (NTL == 2) acc1 += a1 * b; return;
+#endif
+#ifdef MF_ABL_NODEP
+    {   // loads stay live (asm sink) but the MFMAs run on constants
+        asm volatile("" ::"v"(a0), "v"(b));
+        if (NTL == 2) asm volatile("" ::"v"(a1));
+        const f32x4 c = {1.f, 2.f, 3.f, 4.f};
+        for (int i = 0; i < 4; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c[i], c[i], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c[i], c[i], acc1, 0, 0, 0);
+        }
+        return;
+    }
+#endif
+    if (NTL == 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], b[c], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], b[c], acc1, 0, 0, 0);
+        }
+    } else {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0], b[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1], b[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[2], b[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[3], b[3], acc1, 0, 0, 0);
+    }
+}
 // Forward:  xb = region_in + (16*sw + s)*SX + 4q;  wa = W + (16*ot + s)*SW + 4q
 template <int NU, int NTL>
 __device__ __forceinline__ void fwd_body(f32x4& acc0, f32x4& acc1, const float* xb,
                                          const float* wa0, const float* wa1) {
-    f32x4 b[NU], a0[NU], a1[NTL == 2 ? NU : 1];
+#ifdef MF_ABL_NOLOAD
+    { f32x4 c = {1.f, 2.f, 3.f, 4.f};
+      for (int u = 0; u < NU; ++u) mfma_block<NTL>(acc0, acc1, c, c, c);
+      return; }
+#endif
+    f32x4 b[3], a0[3], a1[3];   // ring of 3: a prefetch never lands in registers that the
+                                // MFMAs issued just before it still have to read
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    for (int u = 0; u < 2 && u < NU; ++u) {
         b[u] = *(const f32x4*)(xb + 16 * u);
         a0[u] = *(const f32x4*)(wa0 + 16 * u);
         if (NTL == 2) a1[u] = *(const f32x4*)(wa1 + 16 * u);
     }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        if (NTL == 2) {
-            acc0 = mfma4(a0[u], b[u], acc0);
-            acc1 = mfma4(a1[u], b[u], acc1);
-        } else if (u & 1) {
-            acc1 = mfma4(a0[u], b[u], acc1);
-        } else {
-            acc0 = mfma4(a0[u], b[u], acc0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block<NTL>(acc0, acc1, b[u % 3], a0[u % 3], a1[u % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 2 < NU) {
+            b[(u + 2) % 3] = *(const f32x4*)(xb + 16 * (u + 2));
+            a0[(u + 2) % 3] = *(const f32x4*)(wa0 + 16 * (u + 2));
+            if (NTL == 2) a1[(u + 2) % 3] = *(const f32x4*)(wa1 + 16 * (u + 2));
         }
     }
 }
@@ -202,9 +245,14 @@ __device__ __forceinline__ void fwd_body(f32x4& acc0, f32x4& acc1, const float* 
 template <int NU, int NTL>
 __device__ __forceinline__ void bwd_body(f32x4& acc0, f32x4& acc1, int SW, const float* gb,
                                          const float* wc0, const float* wc1) {
-    f32x4 b[NU], a0[NU], a1[NTL == 2 ? NU : 1];
+#ifdef MF_ABL_NOLOAD
+    { f32x4 c = {1.f, 2.f, 3.f, 4.f};
+      for (int u = 0; u < NU; ++u) mfma_block<NTL>(acc0, acc1, c, c, c);
+      return; }
+#endif
+    f32x4 b[3], a0[3], a1[3];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    for (int u = 0; u < 2 && u < NU; ++u) {
         b[u] = *(const f32x4*)(gb + 16 * u);
         const float* p0 = wc0 + 16 * u * SW;
         a0[u] = f32x4{p0[0], p0[SW], p0[2 * SW], p0[3 * SW]};
@@ -213,16 +261,19 @@ __device__ __forceinline__ void bwd_body(f32x4& acc0, f32x4& acc1, int SW, const
             a1[u] = f32x4{p1[0], p1[SW], p1[2 * SW], p1[3 * SW]};
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        if (NTL == 2) {
-            acc0 = mfma4(a0[u], b[u], acc0);
-            acc1 = mfma4(a1[u], b[u], acc1);
-        } else if (u & 1) {
-            acc1 = mfma4(a0[u], b[u], acc1);
-        } else {
-            acc0 = mfma4(a0[u], b[u], acc0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block<NTL>(acc0, acc1, b[u % 3], a0[u % 3], a1[u % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 2 < NU) {
+            b[(u + 2) % 3] = *(const f32x4*)(gb + 16 * (u + 2));
+            const float* p0 = wc0 + 16 * (u + 2) * SW;
+            a0[(u + 2) % 3] = f32x4{p0[0], p0[SW], p0[2 * SW], p0[3 * SW]};
+            if (NTL == 2) {
+                const float* p1 = wc1 + 16 * (u + 2) * SW;
+                a1[(u + 2) % 3] = f32x4{p1[0], p1[SW], p1[2 * SW], p1[3 * SW]};
+            }
         }
     }
 }
@@ -265,6 +316,33 @@ __device__ __forceinline__ void gemm_bwd(f32x4& acc0, f32x4& acc1, int U, int SW
     }
 }
 
+// Team barrier.  The 8 waves form two teams of 4 (team = wave >> 2), one per 16-sample
+// column tile, and a SIMD hosts one wave of each team.  All synchronisation inside the
+// stage loop is team-local -- a monotonic arrival counter in LDS -- so the two teams drift
+// out of phase and one team's MFMA chains run while the other team sits in an epilogue, an
+// LDS round trip or a barrier.  (s_barrier would force both waves of every SIMD into the
+// same phase and leave the matrix pipe idle in every non-MFMA phase.)
+#ifndef MF_TEAM_SYNC
+#define MF_TEAM_SYNC 0   // 0: s_barrier (faster as measured); 1: team-local LDS barriers
+#endif
+__device__ __forceinline__ void team_barrier(unsigned* cnt, unsigned& gen, int lane) {
+#ifdef MF_ABL_NOBAR
+    return;
+#endif
+#if !MF_TEAM_SYNC
+    __syncthreads();
+    return;
+#endif
+    gen += 4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // my LDS writes are done
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int spins = 0;
+    while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - gen) < 0) {
+        if (++spins > (1 << 22)) break;                             // bounded: never hang the GPU
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ __forceinline__ float quad_sum(float v) {     // sum over the 4 lanes l, l^16, l^32, l^48
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -272,11 +350,13 @@ __device__ __forceinline__ float quad_sum(float v) {     // sum over the 4 lanes
 }
 
 // ---- epilogues ---------------------------------------------------------------------------------
-// forward tile: bias + activation; hidden layers store h, the last layer stores
-// zdot -> DU, g_L = eps .* sigma'_L -> region_L and |zdot|^2 partials -> RED[0]
+// forward tile: bias + activation; hidden layers store h.  The last layer keeps zdot in
+// registers (returned through zd: the lane that computes rows 4q..4q+3 of sample s also owns
+// those rows of the Runge-Kutta state), stores g_L = eps .* sigma'_L to region_L and the
+// |zdot|^2 partial of its 16 rows to RED[0].
 template <class LY>
 __device__ __forceinline__ void fwd_epilogue(const LY& ly, float* lds, int l, bool last, int ot, f32x4 acc,
-                                             int row, int q) {
+                                             int row, int q, f32x4& zd) {
     const int r0 = 16 * ot + 4 * q;
     const f32x4 bv = *(const f32x4*)(lds + ly.b_off(l) + r0);
     const int act = ly.act(l);
@@ -291,9 +371,8 @@ __device__ __forceinline__ void fwd_epilogue(const LY& ly, float* lds, int l, bo
     } else {
         const int n_in = ly.n_in();
         const f32x4 ev = *(const f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r0);
-        const f32x4 zd = {r0 + 0 < n_in ? h0 : 0.f, r0 + 1 < n_in ? h1 : 0.f,
-                          r0 + 2 < n_in ? h2 : 0.f, r0 + 3 < n_in ? h3 : 0.f};
-        *(f32x4*)(lds + ly.du_off() + row * ly.SX(0) + r0) = zd;
+        zd = f32x4{r0 + 0 < n_in ? h0 : 0.f, r0 + 1 < n_in ? h1 : 0.f,
+                   r0 + 2 < n_in ? h2 : 0.f, r0 + 3 < n_in ? h3 : 0.f};
         *(f32x4*)out = f32x4{ev.x * d0, ev.y * d1, ev.z * d2, ev.w * d3};
         const float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
         if (q == 0) lds[ly.red_off() + ot * MF_NB + row] = e2;
@@ -326,12 +405,26 @@ __device__ __forceinline__ void bwd_epilogue(const LY& ly, float* lds, int l, in
 }
 
 // ---- the RHS on the tile resident in LDS ---------------------------------------------------
-// In: region_0 holds z ([sample][feature]); EPS holds eps.  Out: DU holds zdot, RED the
-// per-tile partial sums of (|zdot|^2, -eps.(J^T eps), |J^T eps|^2).  Ends with a barrier.
+// In: region_0 holds z ([sample][feature]); EPS holds eps.  Out: zd0/zd1 = zdot of the (up
+// to two) 16-row tiles this wave owns, RED = per-tile partial sums of
+// (|zdot|^2, -eps.(J^T eps), |J^T eps|^2).  Ends with a barrier.
+#ifdef MF_STAMPS
+#define STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+                      stamps[i] += t_ - tlast; tlast = t_; } while (0)
+#define STAMP_ARGS , unsigned long long* stamps, unsigned long long& tlast
+#define STAMP_PASS , stamps, tlast
+#else
+#define STAMP(i) do {} while (0)
+#define STAMP_ARGS
+#define STAMP_PASS
+#endif
 template <class LY>
-__device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int wave) {
-    const int s = lane & 15, q = lane >> 4, sw = wave & 1, fg = wave >> 1;
-    const int row = 16 * sw + s;
+__device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int wave, unsigned* bar,
+                                         unsigned& gen, f32x4& zd0, f32x4& zd1 STAMP_ARGS) {
+    // team = column tile; the feature-group index is rotated by 2 for team 1 so that the
+    // narrow layers (fewer than 4 output tiles) of the two teams land on different SIMDs
+    const int s = lane & 15, q = lane >> 4, team = wave >> 2, fg = (wave + 2 * team) & 3;
+    const int row = 16 * team + s;
     // ---- forward ----
     for_layers_up(ly, [&](auto l) {
         const int ntiles = ly.P(l + 1) >> 4, SW = ly.SW(l);
@@ -353,10 +446,11 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int
                 if (two) gemm_fwd<2>(acc0, acc1, U, xb, wa0, wa1);
                 else { gemm_fwd<1>(acc0, acc1, U, xb, wa0, wa1); acc0 += acc1; }
             }
-            fwd_epilogue(ly, lds, l, last, t0, acc0, row, q);
-            if (two) fwd_epilogue(ly, lds, l, last, t1, acc1, row, q);
+            fwd_epilogue(ly, lds, l, last, t0, acc0, row, q, zd0);
+            if (two) fwd_epilogue(ly, lds, l, last, t1, acc1, row, q, zd1);
         }
-        __syncthreads();
+        team_barrier(bar, gen, lane);
+        STAMP(1 + (int)l);
     });
     // ---- reverse (VJP): g_l = (W_{l+1}^T g_{l+1}) .* sigma'_l, in place over h_l ----
     for_layers_down(ly, [&](auto l) {
@@ -381,26 +475,14 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int
             bwd_epilogue(ly, lds, l, t0, acc0, row, q);
             if (two) bwd_epilogue(ly, lds, l, t1, acc1, row, q);
         }
-        __syncthreads();
+        team_barrier(bar, gen, lane);
+        STAMP(8 + (int)l);
     });
 }
 
-// du element (sample sl, row r) from DU / RED after rhs_tile
-template <class LY>
-__device__ __forceinline__ float du_elem(const LY& ly, const float* lds, int sl, int r) {
-    const int n_in = ly.n_in(), nt0 = ly.P(0) >> 4;
-    if (r < n_in) return lds[ly.du_off() + sl * ly.SX(0) + r];
-    const int kind = r - n_in;            // 0: ldot, 1: Edot, 2: ndot
-    const int base = ly.red_off() + (kind == 0 ? nt0 : kind == 1 ? 0 : 2 * nt0) * MF_NB + sl;
-    float v = 0.f;
-    for (int t = 0; t < nt0; ++t) v += lds[base + t * MF_NB];
-    if (kind == 0) return v;
-    if (kind == 1) return ly.norm_z() ? sqrtf(v) : 0.f;
-    return ly.norm_j() ? sqrtf(v) : 0.f;
-}
-
+// Tsit5 stage combination sum_j a_{S+1,j} k_j (S = 1..6) on 4 rows at once
 template <int S>
-__device__ __forceinline__ float stage_acc(const float (&k)[7]) {
+__device__ __forceinline__ f32x4 stage_acc4(const f32x4 (&k)[7]) {
     constexpr float A[7][6] = {
         {0, 0, 0, 0, 0, 0},
         {TS_A21, 0, 0, 0, 0, 0},
@@ -409,13 +491,60 @@ __device__ __forceinline__ float stage_acc(const float (&k)[7]) {
         {TS_A51, TS_A52, TS_A53, TS_A54, 0, 0},
         {TS_A61, TS_A62, TS_A63, TS_A64, TS_A65, 0},
         {TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76}};
-    float acc = A[S][0] * k[0];
+    f32x4 acc = A[S][0] * k[0];
 #pragma unroll
-    for (int j = 1; j < S; ++j) acc = fmaf(A[S][j], k[j], acc);
+    for (int j = 1; j < S; ++j) acc += A[S][j] * k[j];
     return acc;
 }
+__device__ __forceinline__ f32x4 stage_acc4_rt(int stg, const f32x4 (&k)[7]) {
+    switch (stg) {
+        case 1: return stage_acc4<1>(k);
+        case 2: return stage_acc4<2>(k);
+        case 3: return stage_acc4<3>(k);
+        case 4: return stage_acc4<4>(k);
+        case 5: return stage_acc4<5>(k);
+        default: return stage_acc4<6>(k);
+    }
+}
+__device__ __forceinline__ void set_k(f32x4 (&k)[7], int idx, const f32x4& v) {
+    // select per slot: keeps every k[i] in registers (a switch turns into an indexed store
+    // and sends the array to scratch)
+#pragma unroll
+    for (int i = 1; i < 7; ++i) k[i] = idx == i ? v : k[i];
+}
+__device__ __forceinline__ f32x4 ld4(const float* p, int nvalid4) {   // rows beyond n_in read as 0
+    return f32x4{nvalid4 > 0 ? p[0] : 0.f, nvalid4 > 1 ? p[1] : 0.f, nvalid4 > 2 ? p[2] : 0.f,
+                 nvalid4 > 3 ? p[3] : 0.f};
+}
+__device__ __forceinline__ void st4(float* p, const f32x4& v, int nvalid4) {
+    if (nvalid4 > 0) p[0] = v.x;
+    if (nvalid4 > 1) p[1] = v.y;
+    if (nvalid4 > 2) p[2] = v.z;
+    if (nvalid4 > 3) p[3] = v.w;
+}
+__device__ __forceinline__ void err_acc(float& errsum, float& badcnt, const f32x4 (&k)[7], const f32x4& u,
+                                        const f32x4& un, float h, float abstol, float reltol, int nvalid4) {
+    f32x4 e = TS_BT1 * k[0] + TS_BT2 * k[1] + TS_BT3 * k[2] + TS_BT4 * k[3] + TS_BT5 * k[4] + TS_BT6 * k[5] +
+              TS_BT7 * k[6];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c < nvalid4) {
+            const float sc = fmaf(fmaxf(fabsf(u[c]), fabsf(un[c])), reltol, abstol);
+            const float x = h * e[c] / sc;
+            errsum = fmaf(x, x, errsum);
+            if (!(fabsf(un[c]) <= 3.0e38f)) badcnt += 1.f;
+        }
+    }
+}
 
-template <class LY, int EPT>
+// One workgroup = one 32-sample tile (two teams of 16 samples).  The Runge-Kutta state is
+// kept in registers in the MFMA accumulator layout: the lane that produces rows 4q..4q+3
+// of zdot for sample s (wave fg owns the 16-row tiles fg and fg+4 of the n_in rows) holds
+// u and k1..k7 of exactly those rows, so the stage combination needs no data movement and
+// lands in region_0 with one ds_write_b128.  The three scalar rows (dlogp, E, n) of sample s
+// live in lane s of the team's wave fg == 0; their RHS values are read back from the RED
+// partials one barrier later, off the critical path.
+template <class LY>
 __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StepState* st = a.st;
@@ -444,121 +573,140 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
             *(f32x4*)(lds + z) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // element ownership: thread t holds state elements e = t + 512 j of the tile's
-    // [sample][row] block (the HBM order: coalesced loads and stores)
-    int esl[EPT], er[EPT];
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-        const int e = tid + MF_THREADS * j;
-        esl[j] = e / D;
-        er[j] = e - esl[j] * D;
-    }
+    constexpr int TT = MF_THREADS / 2, TNB = MF_NB / 2;
+    const int team = wave >> 2, tt = tid & (TT - 1);
+    const int s = lane & 15, q = lane >> 4, fg = (wave + 2 * team) & 3;
+    const int nt0 = ly.P(0) >> 4;
+    const bool own0 = fg < nt0, own1 = fg + 4 < nt0;      // z-row tiles fg, fg+4
+    const bool sown = fg == 0 && q == 0;                  // scalar rows of sample s
+    const int r00 = 16 * fg + 4 * q, r01 = r00 + 64;      // first owned row of each tile
+    const int nv0 = own0 ? n_in - r00 : 0, nv1 = own1 ? n_in - r01 : 0;   // valid rows (may be <= 0 or > 4)
+    const int row = TNB * team + s;
     int cur = 0;
     float hstep = 0.f, abstol = 0.f, reltol = 0.f;
     if (st) { cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol; }
     const float* Uin = mode == 0 ? a.u : a.U[cur];
     const float* K1in = mode == 0 ? nullptr : a.K1[cur];
     float errsum = 0.f, badcnt = 0.f;
+    unsigned* bar = (unsigned*)(lds + ly.bar_off()) + team;
+    unsigned gen = 0;
+#ifdef MF_STAMPS
+    unsigned long long stamps[16] = {0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tlast;
+#endif
+    __syncthreads();       // image filled, counters zeroed
+    STAMP(15);
+#if MF_TEAM_SYNC
+    if (team == 0) __builtin_amdgcn_s_setprio(2);
+#endif
 
     const int ntile = (a.B + MF_NB - 1) / MF_NB;
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const int b0 = tile * MF_NB;
-        const int nvalid = min(MF_NB, a.B - b0);
-        const int nel = nvalid * D;
-        const size_t gbase = (size_t)b0 * D;
-        __syncthreads();   // image filled / previous tile's LDS reads are done
-        // eps tile -> EPS[sample][feature]
-        for (int i = tid; i < MF_NB * n_in; i += MF_THREADS) {
+        const int b0 = tile * MF_NB + TNB * team;                 // first sample of this team
+        const int nvalid = max(0, min(TNB, a.B - b0));
+        const bool live = s < nvalid;                             // this lane's sample exists
+        const size_t gcol = (size_t)(b0 + s) * D;
+        // eps tile -> EPS[sample][feature] (this team's rows; its previous readers are this
+        // team's waves, ordered by the last team barrier of the previous tile)
+        for (int i = tt; i < TNB * n_in; i += TT) {
             const int sl = i / n_in, r = i - sl * n_in;
-            lds[ly.eps_off() + sl * ly.SX(0) + r] = sl < nvalid ? a.eps[(size_t)(b0 + sl) * n_in + r] : 0.f;
+            lds[ly.eps_off() + (TNB * team + sl) * ly.SX(0) + r] =
+                sl < nvalid ? a.eps[(size_t)(b0 + sl) * n_in + r] : 0.f;
         }
-        float u[EPT], k[EPT][7];
+        // state: z rows in the accumulator layout, scalar rows in the fg == 0, q == 0 lanes
+        f32x4 uz0 = {0.f, 0.f, 0.f, 0.f}, uz1 = uz0, kz0[7], kz1[7], us = uz0, ks[7];
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const int e = tid + MF_THREADS * j;
-            const bool v = e < nel;
-            u[j] = v ? Uin[gbase + e] : 0.f;
-            k[j][0] = (v && K1in) ? K1in[gbase + e] : 0.f;
-#pragma unroll
-            for (int i = 1; i < 7; ++i) k[j][i] = 0.f;
+        for (int i = 0; i < 7; ++i) { kz0[i] = uz0; kz1[i] = uz0; ks[i] = uz0; }
+        if (live) {
+            if (own0) uz0 = ld4(Uin + gcol + r00, nv0);
+            if (own1) uz1 = ld4(Uin + gcol + r01, nv1);
+            if (sown) us = ld4(Uin + gcol + n_in, 3);
+            if (K1in) {
+                if (own0) kz0[0] = ld4(K1in + gcol + r00, nv0);
+                if (own1) kz1[0] = ld4(K1in + gcol + r01, nv1);
+                if (sown) ks[0] = ld4(K1in + gcol + n_in, 3);
+            }
         }
         const int nstage = mode == 2 ? 6 : 1;
-        float unew[EPT];
+        f32x4 un0 = uz0, un1 = uz1;
         for (int stg = 1; stg <= nstage; ++stg) {
-            // stage state -> region_0 (z rows), kept as u_new at the last stage
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                float v = u[j];
-                if (mode == 1) v = fmaf(hstep, k[j][0], v);
-                if (mode == 2) {
-                    float acc;
-                    switch (stg) {
-                        case 1: acc = stage_acc<1>(k[j]); break;
-                        case 2: acc = stage_acc<2>(k[j]); break;
-                        case 3: acc = stage_acc<3>(k[j]); break;
-                        case 4: acc = stage_acc<4>(k[j]); break;
-                        case 5: acc = stage_acc<5>(k[j]); break;
-                        default: acc = stage_acc<6>(k[j]); break;
-                    }
-                    v = fmaf(hstep, acc, v);
-                }
-                unew[j] = v;
-                if (er[j] < n_in && esl[j] < MF_NB) lds[ly.x_off(0) + esl[j] * ly.SX(0) + er[j]] = v;
+            // stage state (z rows) -> region_0; the last stage's state is u_new (a7 = b)
+            if (own0) {
+                if (mode == 1) un0 = uz0 + hstep * kz0[0];
+                else if (mode == 2) un0 = uz0 + hstep * stage_acc4_rt(stg, kz0);
+                *(f32x4*)(lds + ly.x_off(0) + row * ly.SX(0) + r00) = un0;
             }
-            __syncthreads();
-            rhs_tile(ly, lds, lane, wave);
-            // du -> k_{stg+1} (mode 2) or straight out.  No barrier afterwards: the next
-            // stage's DU / RED writes come after the barrier that follows its region_0 write.
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                const float dv = esl[j] < MF_NB ? du_elem(ly, lds, esl[j], er[j]) : 0.f;
-                if (mode == 2) {
-                    switch (stg) {
-                        case 1: k[j][1] = dv; break;
-                        case 2: k[j][2] = dv; break;
-                        case 3: k[j][3] = dv; break;
-                        case 4: k[j][4] = dv; break;
-                        case 5: k[j][5] = dv; break;
-                        default: k[j][6] = dv; break;
-                    }
-                } else {
-                    k[j][1] = dv;
-                }
+            if (own1) {
+                if (mode == 1) un1 = uz1 + hstep * kz1[0];
+                else if (mode == 2) un1 = uz1 + hstep * stage_acc4_rt(stg, kz1);
+                *(f32x4*)(lds + ly.x_off(0) + row * ly.SX(0) + r01) = un1;
             }
+            team_barrier(bar, gen, lane);
+            STAMP(0);
+            // scalar rows of the PREVIOUS evaluation, from its RED partials (these are
+            // overwritten only two barriers from here)
+            if (stg > 1 && sown) {
+                float ld = 0.f, e2 = 0.f, n2 = 0.f;
+                for (int t = 0; t < nt0; ++t) {
+                    e2 += lds[ly.red_off() + t * MF_NB + row];
+                    ld += lds[ly.red_off() + (nt0 + t) * MF_NB + row];
+                    n2 += lds[ly.red_off() + (2 * nt0 + t) * MF_NB + row];
+                }
+                set_k(ks, stg - 1, f32x4{ld, ly.norm_z() ? __builtin_sqrtf(e2) : 0.f,
+                                         ly.norm_j() ? __builtin_sqrtf(n2) : 0.f, 0.f});
+            }
+            f32x4 zd0 = {0.f, 0.f, 0.f, 0.f}, zd1 = zd0;
+            rhs_tile(ly, lds, lane, wave, bar, gen, zd0, zd1 STAMP_PASS);
+            if (mode == 2) { set_k(kz0, stg, zd0); set_k(kz1, stg, zd1); }
+            else { kz0[1] = zd0; kz1[1] = zd1; }
+        }
+        // scalar rows of the last evaluation (rhs_tile ended with a barrier)
+        if (sown) {
+            float ld = 0.f, e2 = 0.f, n2 = 0.f;
+            for (int t = 0; t < nt0; ++t) {
+                e2 += lds[ly.red_off() + t * MF_NB + row];
+                ld += lds[ly.red_off() + (nt0 + t) * MF_NB + row];
+                n2 += lds[ly.red_off() + (2 * nt0 + t) * MF_NB + row];
+            }
+            const f32x4 v = {ld, ly.norm_z() ? __builtin_sqrtf(e2) : 0.f, ly.norm_j() ? __builtin_sqrtf(n2) : 0.f, 0.f};
+            if (mode == 2) ks[6] = v; else ks[1] = v;
         }
         // ---- outputs ----
-        if (mode == 0 || mode == 1) {
-            float* out = mode == 0 ? a.du : a.Ks0;
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                const int e = tid + MF_THREADS * j;
-                if (e < nel) out[gbase + e] = k[j][1];
-            }
-        } else {
-            float* Un = a.U[1 - cur];
-            float* K7 = a.K1[1 - cur];
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                const int e = tid + MF_THREADS * j;
-                if (e < nel) {
-                    Un[gbase + e] = unew[j];
-                    K7[gbase + e] = k[j][6];
-                    float er_ = TS_BT1 * k[j][0];
-                    er_ = fmaf(TS_BT2, k[j][1], er_);
-                    er_ = fmaf(TS_BT3, k[j][2], er_);
-                    er_ = fmaf(TS_BT4, k[j][3], er_);
-                    er_ = fmaf(TS_BT5, k[j][4], er_);
-                    er_ = fmaf(TS_BT6, k[j][5], er_);
-                    er_ = fmaf(TS_BT7, k[j][6], er_);
-                    er_ *= hstep;
-                    const float sc = fmaf(fmaxf(fabsf(u[j]), fabsf(unew[j])), reltol, abstol);
-                    const float x = er_ / sc;
-                    errsum = fmaf(x, x, errsum);
-                    if (!(fabsf(unew[j]) <= 3.0e38f)) badcnt += 1.f;
+        if (live) {
+            if (mode == 0 || mode == 1) {
+                float* out = (mode == 0 ? a.du : a.Ks0) + gcol;
+                if (own0) st4(out + r00, kz0[1], nv0);
+                if (own1) st4(out + r01, kz1[1], nv1);
+                if (sown) st4(out + n_in, ks[1], 3);
+            } else {
+                float* Un = a.U[1 - cur] + gcol;
+                float* K7 = a.K1[1 - cur] + gcol;
+                if (own0) {
+                    st4(Un + r00, un0, nv0); st4(K7 + r00, kz0[6], nv0);
+                    err_acc(errsum, badcnt, kz0, uz0, un0, hstep, abstol, reltol, nv0);
+                }
+                if (own1) {
+                    st4(Un + r01, un1, nv1); st4(K7 + r01, kz1[6], nv1);
+                    err_acc(errsum, badcnt, kz1, uz1, un1, hstep, abstol, reltol, nv1);
+                }
+                if (sown) {
+                    const f32x4 uns = us + hstep * stage_acc4<6>(ks);
+                    st4(Un + n_in, uns, 3); st4(K7 + n_in, ks[6], 3);
+                    err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
                 }
             }
         }
+        // this team's RED / EPS reads of this tile precede its next-tile writes
+        team_barrier(bar, gen, lane);
     }
+#ifdef MF_STAMPS
+    STAMP(14);
+    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 5) && mode == 2) {
+        printf("wave %d total %llu | fill %llu | elem %llu | fwd %llu %llu %llu | bwd %llu %llu %llu | tail %llu\n", wave,
+               tlast - tstart, stamps[15], stamps[0], stamps[1], stamps[2], stamps[3], stamps[10], stamps[9], stamps[8], stamps[14]);
+    }
+#endif
     if (mode == 2) {
         // deterministic block reduction of the error partial (fixed tree, fixed order)
         __syncthreads();
@@ -644,13 +792,14 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     ly.red_off = off;
     int red = 3 * (ly.P[0] >> 4) * MF_NB;
     off += red < 16 ? 16 : red;
+    off += 16;                      // team-barrier counters
     ly.total_floats = off;
     ly.n_in = nd.n_in;
     ly.norm_z = nd.norm_z;
     ly.norm_j = nd.norm_j;
-    ly.ept = (MF_NB * (nd.n_in + 3) + MF_THREADS - 1) / MF_THREADS;
+    ly.ept = ((MF_NB / 2) * (nd.n_in + 3) + MF_THREADS / 2 - 1) / (MF_THREADS / 2);
     if ((size_t)ly.total_floats * sizeof(float) > MF_LDS_BYTES) return;   // weights do not fit in LDS
-    if (ly.ept > 9) return;
+    if (ly.P[0] > 128) return;                                             // state tiles fg, fg+4 only
     if (nd.jvp) return;                                                    // forward-mode sweep: generic path
     p.variant = 1;
     if (matches<LyCfg3>(ly)) p.variant = 2;
@@ -663,9 +812,9 @@ void mfma_plan_free(MfmaPlan& p) {
     p.d_img = nullptr;
 }
 
-template <class LY, int EPT>
+template <class LY>
 static hipError_t set_attr() {
-    return hipFuncSetAttribute((const void*)k_mfma<LY, EPT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    return hipFuncSetAttribute((const void*)k_mfma<LY>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                MF_LDS_BYTES);
 }
 
@@ -673,14 +822,10 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
     if (!p.variant) return CNF_OK;
     if (!p.d_img) {
         if (hipMalloc(&p.d_img, (size_t)p.ly.img_floats * sizeof(float)) != hipSuccess) return CNF_ERR_HIP;
-        hipError_t e = set_attr<RtLayout, 1>();
-        if (e == hipSuccess) e = set_attr<RtLayout, 2>();
-        if (e == hipSuccess) e = set_attr<RtLayout, 3>();
-        if (e == hipSuccess) e = set_attr<RtLayout, 5>();
-        if (e == hipSuccess) e = set_attr<RtLayout, 9>();
-        if (e == hipSuccess) e = set_attr<LyCfg3, 3>();
-        if (e == hipSuccess) e = set_attr<LyCfg2, 2>();
-        if (e == hipSuccess) e = set_attr<LyCfg1, 2>();
+        hipError_t e = set_attr<RtLayout>();
+        if (e == hipSuccess) e = set_attr<LyCfg3>();
+        if (e == hipSuccess) e = set_attr<LyCfg2>();
+        if (e == hipSuccess) e = set_attr<LyCfg1>();
         if (e != hipSuccess) return CNF_ERR_HIP;
     }
     hipLaunchKernelGGL(k_pack_image, dim3((p.ly.img_floats + 255) / 256), dim3(256), 0, s, p.ly, nd,
@@ -697,28 +842,23 @@ int mfma_grid_for(int B) {
     return nt < 512 ? (nt < 1 ? 1 : nt) : 512;
 }
 
-template <class LY, int EPT>
+template <class LY>
 static void launch_static(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStream_t s) {
     LY ly;
     ly.n_in_ = p.ly.n_in; ly.norm_z_ = p.ly.norm_z; ly.norm_j_ = p.ly.norm_j;
-    hipLaunchKernelGGL((k_mfma<LY, EPT>), grid, dim3(MF_THREADS), (size_t)LY::total_floats() * sizeof(float), s,
+    hipLaunchKernelGGL((k_mfma<LY>), grid, dim3(MF_THREADS), (size_t)LY::total_floats() * sizeof(float), s,
                        ly, a);
 }
 
 static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a, hipStream_t s) {
     const dim3 grid(mfma_grid_for(a.B)), block(MF_THREADS);
     const size_t shm = (size_t)p.ly.total_floats * sizeof(float);
-    const int ept = p.ly.ept;
-    if (p.variant == 2) launch_static<LyCfg3, 3>(p, a, grid, s);
-    else if (p.variant == 3) launch_static<LyCfg2, 2>(p, a, grid, s);
-    else if (p.variant == 4) launch_static<LyCfg1, 2>(p, a, grid, s);
+    if (p.variant == 2) launch_static<LyCfg3>(p, a, grid, s);
+    else if (p.variant == 3) launch_static<LyCfg2>(p, a, grid, s);
+    else if (p.variant == 4) launch_static<LyCfg1>(p, a, grid, s);
     else {
         RtLayout ly{p.ly};
-        if (ept <= 1) hipLaunchKernelGGL((k_mfma<RtLayout, 1>), grid, block, shm, s, ly, a);
-        else if (ept <= 2) hipLaunchKernelGGL((k_mfma<RtLayout, 2>), grid, block, shm, s, ly, a);
-        else if (ept <= 3) hipLaunchKernelGGL((k_mfma<RtLayout, 3>), grid, block, shm, s, ly, a);
-        else if (ept <= 5) hipLaunchKernelGGL((k_mfma<RtLayout, 5>), grid, block, shm, s, ly, a);
-        else hipLaunchKernelGGL((k_mfma<RtLayout, 9>), grid, block, shm, s, ly, a);
+        hipLaunchKernelGGL((k_mfma<RtLayout>), grid, block, shm, s, ly, a);
     }
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }

@@ -24,6 +24,9 @@ if cfgi == 5:
     cfg.lam3 = 1e-2
 rng = np.random.default_rng(0)
 flat = O.glorot_params(cfg.net, rng, np.float32)
+ZERO = os.environ.get("PROF_ZERO") == "1"
+if ZERO:
+    flat = flat * 0
 icnf = make_icnf(cnf, cfg, kernel=kernel)
 icnf.set_params(flat)
 l, h = _lib.lib(), icnf.handle()
@@ -31,6 +34,8 @@ D = cfg.D(True)
 dev = torch.device("cuda", 0)
 u = torch.randn(B * D, device=dev)
 eps = torch.randn(B * cfg.n_in, device=dev)
+if ZERO:
+    u.zero_(); eps.zero_()
 du = torch.empty_like(u)
 sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 k = {"mfma": 2, "generic": 1, "auto": 0}[kernel]
