@@ -33,7 +33,7 @@ struct cnf_ctx {
     float* tmp_logpx = nullptr;
     float* tmp_regs = nullptr;
     float* partials = nullptr;    // 2 * MAX_PARTIALS floats
-    StepState* d_state = nullptr;
+    StepState* d_state = nullptr;   // two slots: [0] canonical, [1] ping-pong partner of the fused MFMA path
     StepState* h_state = nullptr; // pinned, two slots for pipelined polling + one init slot
     hipEvent_t ev[2] = {nullptr, nullptr};
     std::string err;
@@ -131,8 +131,8 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
 
     hipError_t e = hipSetDevice(h->device);
     if (e == hipSuccess) e = hipMalloc(&h->d_params, h->n_params * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&h->d_state, sizeof(StepState));
-    if (e == hipSuccess) e = hipMalloc(&h->partials, 2 * MAX_PARTIALS * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&h->d_state, 2 * sizeof(StepState));
+    if (e == hipSuccess) e = hipMalloc(&h->partials, 4 * MAX_PARTIALS * sizeof(float));
     if (e == hipSuccess) e = hipHostMalloc(&h->h_state, 3 * sizeof(StepState), hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[1], hipEventDisableTiming);
@@ -438,7 +438,9 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
         expected = (long)ns;
         if (expected < 1) expected = 1;
     }
-    const int chunk = opts->adaptive ? 4 : (int)(expected < 64 ? expected : 64);
+    StepState* cur_state = h->d_state;   // slot holding the live integrator state
+    int pp = 0;                          // partials buffer the NEXT launch reads
+    const int chunk = opts->adaptive ? 8 : (int)(expected < 64 ? expected : 64);
     long attempts = 0;
     int slot = 0;
     bool pending[2] = {false, false};
@@ -454,17 +456,24 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
         if (attempts + todo > (long)opts->maxiters) todo = (long)opts->maxiters - attempts;
         for (long i = 0; i < todo; ++i) {
             if (use_mfma) {
-                s = mfma_step(h->mfma, h->nd, train, h->d_state, h->U, h->K1, h->Ks, eps,
-                              h->partials, B, st);
+                // fused path: the controller of attempt i-1 runs inside launch i; only the
+                // last launch of a chunk is followed by the stand-alone controller
+                const bool apply = i > 0, fin = i == todo - 1;
+                StepState* st_next = cur_state == h->d_state ? h->d_state + 1 : h->d_state;
+                s = mfma_step(h->mfma, h->nd, train, cur_state, st_next, h->U, h->K1, h->Ks, eps,
+                              h->partials + 2 * MAX_PARTIALS * pp, h->partials + 2 * MAX_PARTIALS * (pp ^ 1),
+                              apply, fin, B, st);
                 if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
-                launches += mfma_step_launches();
+                if (apply) cur_state = st_next;
+                pp ^= 1;
+                launches += fin ? 2 : 1;
             } else {
                 enqueue_attempt_generic(h, train, eps, B, nblk, st);
                 launches += 8;
             }
         }
         attempts += todo;
-        HIPCHK(h, hipMemcpyAsync(&h->h_state[slot], h->d_state, sizeof(StepState), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(&h->h_state[slot], cur_state, sizeof(StepState), hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipEventRecord(h->ev[slot], st));
         pending[slot] = true;
         // poll one chunk behind the GPU; wait for the chunk just enqueued only when no
@@ -490,7 +499,7 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
             HIPCHK(h, hipEventSynchronize(h->ev[i]));
             fin = h->h_state[i];
         }
-    launch_copy_final(h->d_state, h->U[0], h->U[1], u_out, n, st);
+    launch_copy_final(cur_state, h->U[0], h->U[1], u_out, n, st);
     launches += 1;
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(st));

@@ -80,6 +80,51 @@ __host__ __device__ inline void tsit5_row(int s, float* a) {
 }
 
 #ifdef __HIPCC__
+// ---- step controller (shared by k_controller and the fused MFMA step kernel) -----------------
+// OrdinaryDiffEq-style PI controller for Tsit5 (third party in the
+// reference, restated from the published scheme, mirrored by the oracle).
+__device__ __forceinline__ void ctrl_set_attempt_h(StepState* st) {
+    float rem = fabsf(st->t1 - st->t);
+    float h = st->dt < rem ? st->dt : rem;
+    st->h = st->tdir * h;
+}
+// p0 = sum (err/sc)^2 over all D*B entries, p1 = non-finite count of the attempt just made
+__device__ __forceinline__ void ctrl_after_step(StepState* st, float p0, float p1, float n_total) {
+    const float habs = fabsf(st->h);
+    bool accept = true;
+    float q = 1.f, q11 = 1.f, eest = 0.f;
+    if (p1 > 0.f) st->nonfinite = 1;
+    if (st->adaptive) {
+        eest = sqrtf(p0 / n_total);
+        if (!(eest == eest)) { st->nonfinite = 1; eest = 1e30f; }
+        accept = eest <= 1.0f;
+        const float beta1 = 7.f / 50.f, beta2 = 2.f / 25.f, gamma = 0.9f;
+        const float qmin = 0.2f, qmax = 10.f;
+        q11 = powf(fmaxf(eest, 1e-30f), beta1);
+        q = q11 / powf(st->qold, beta2);
+        q = fmaxf(1.f / qmax, fminf(1.f / qmin, q / gamma));
+        st->eest = eest;
+        if (accept) {
+            if (q >= 1.0f && q <= 1.2f) q = 1.f;
+            st->qold = fmaxf(eest, 1e-4f);
+            st->dt = habs / q;
+        } else {
+            st->dt = habs / fminf(1.f / qmin, q11 / gamma);
+        }
+    }
+    if (accept) {
+        st->naccept += 1;
+        st->t = st->t + st->h;
+        st->cur ^= 1;
+        float tol = 100.f * 1.1920929e-7f * fmaxf(1.f, fabsf(st->t1));
+        if (fabsf(st->t1 - st->t) <= tol) { st->t = st->t1; st->done = 1; }
+    } else {
+        st->nreject += 1;
+    }
+    if (st->nonfinite) st->done = 1;
+    if (!st->done) ctrl_set_attempt_h(st);
+}
+
 // ---- activations: value and derivative w.r.t. the pre-activation ------------------------
 __device__ __forceinline__ float cnf_sigmoid(float a) { return 1.0f / (1.0f + __expf(-a)); }
 

@@ -319,12 +319,6 @@ k_norm_partials(NormArgs a) {
 // Control law: OrdinaryDiffEq-style PI controller for Tsit5 (third
 // party in the reference, restated from the published scheme, mirrored by the oracle).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void set_attempt_h(StepState* st) {
-    float rem = fabsf(st->t1 - st->t);
-    float h = st->dt < rem ? st->dt : rem;
-    st->h = st->tdir * h;
-}
-
 __global__ void __launch_bounds__(256)
 k_controller(StepState* st, const float* __restrict__ partials, int phase, float n_total) {
     __shared__ float sm[8];
@@ -352,41 +346,9 @@ k_controller(StepState* st, const float* __restrict__ partials, int phase, float
         float m = fmaxf(d1, d2);
         float dt1 = (m <= 1e-15f) ? fmaxf(1e-6f, dt0 * 1e-3f) : powf(0.01f / m, 0.2f);
         st->dt = fminf(fminf(100.f * dt0, dt1), span);
-        set_attempt_h(st);
+        ctrl_set_attempt_h(st);
     } else {
-        const float habs = fabsf(st->h);
-        bool accept = true;
-        float q = 1.f, q11 = 1.f, eest = 0.f;
-        if (p1 > 0.f) st->nonfinite = 1;
-        if (st->adaptive) {
-            eest = sqrtf(p0 / n_total);
-            if (!(eest == eest)) { st->nonfinite = 1; eest = 1e30f; }
-            accept = eest <= 1.0f;
-            const float beta1 = 7.f / 50.f, beta2 = 2.f / 25.f, gamma = 0.9f;
-            const float qmin = 0.2f, qmax = 10.f;
-            q11 = powf(fmaxf(eest, 1e-30f), beta1);
-            q = q11 / powf(st->qold, beta2);
-            q = fmaxf(1.f / qmax, fminf(1.f / qmin, q / gamma));
-            st->eest = eest;
-            if (accept) {
-                if (q >= 1.0f && q <= 1.2f) q = 1.f;
-                st->qold = fmaxf(eest, 1e-4f);
-                st->dt = habs / q;
-            } else {
-                st->dt = habs / fminf(1.f / qmin, q11 / gamma);
-            }
-        }
-        if (accept) {
-            st->naccept += 1;
-            st->t = st->t + st->h;
-            st->cur ^= 1;
-            float tol = 100.f * 1.1920929e-7f * fmaxf(1.f, fabsf(st->t1));
-            if (fabsf(st->t1 - st->t) <= tol) { st->t = st->t1; st->done = 1; }
-        } else {
-            st->nreject += 1;
-        }
-        if (st->nonfinite) st->done = 1;
-        if (!st->done) set_attempt_h(st);
+        ctrl_after_step(st, p0, p1, n_total);
     }
 }
 

@@ -41,10 +41,14 @@ cnf_status mfma_rhs(const MfmaPlan& p, const NetDesc& nd, bool train, const floa
 cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st,
                           float* const U[2], float* const K1[2], float* const Ks[5],
                           const float* eps, int nk, int B, hipStream_t s);
-// one full Tsit5 step attempt: 6 RHS evaluations + error partials in ONE launch, then the
-// one-block controller launch
-cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st,
-                     float* const U[2], float* const K1[2], float* const Ks[5],
-                     const float* eps, float* partials, int B, hipStream_t s);
-int mfma_step_launches();
+// one full Tsit5 step attempt: 6 RHS evaluations + error partials in ONE launch.
+//  apply_ctrl: the launch first applies the step controller to (st_in, partials_in) -- the
+//              outcome of the previous attempt -- redundantly in every workgroup, block 0
+//              stores the new state to st_out; otherwise the launch runs from st_in as is.
+//  finalize  : follow the launch by the one-block controller kernel (in place on the state
+//              slot the launch ran from), so that the host can poll an up-to-date state.
+cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st_in,
+                     StepState* st_out, float* const U[2], float* const K1[2], float* const Ks[5],
+                     const float* eps, const float* partials_in, float* partials_out, bool apply_ctrl,
+                     bool finalize, int B, hipStream_t s);
 int mfma_grid_for(int B);

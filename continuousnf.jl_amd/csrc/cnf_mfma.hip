@@ -41,7 +41,11 @@ struct MfmaArgs {
     const float* eps;         // n_in x B
     const float* u;           // mode 0
     float* du;                // mode 0
-    const StepState* st;      // mode 1, 2
+    const StepState* st;      // mode 1, 2: state to run from (mode 2 + apply_ctrl: state BEFORE the controller)
+    StepState* st_out;        // mode 2 + apply_ctrl: where block 0 stores the state after the controller
+    const float* partials_in; // mode 2 + apply_ctrl: error partials of the previous attempt
+    int apply_ctrl;
+    float n_total;            // D * B
     float* U[2];
     float* K1[2];
     float* Ks0;               // mode 1 output
@@ -418,9 +422,9 @@ __device__ __forceinline__ void bwd_epilogue(const LY& ly, float* lds, int l, in
 #define STAMP_ARGS
 #define STAMP_PASS
 #endif
-template <class LY>
+template <class LY, class F>
 __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int wave, unsigned* bar,
-                                         unsigned& gen, f32x4& zd0, f32x4& zd1 STAMP_ARGS) {
+                                         unsigned& gen, f32x4& zd0, f32x4& zd1, F&& after_zdot STAMP_ARGS) {
     // team = column tile; the feature-group index is rotated by 2 for team 1 so that the
     // narrow layers (fewer than 4 output tiles) of the two teams land on different SIMDs
     const int s = lane & 15, q = lane >> 4, team = wave >> 2, fg = (wave + 2 * team) & 3;
@@ -449,6 +453,10 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int
             fwd_epilogue(ly, lds, l, last, t0, acc0, row, q, zd0);
             if (two) fwd_epilogue(ly, lds, l, last, t1, acc1, row, q, zd1);
         }
+        // zdot is known: the owner lanes can already form the NEXT stage state and put it
+        // into region_0 (last read two barriers ago), which takes the stage combination and
+        // one barrier off the critical path of every stage
+        if (last) after_zdot();
         team_barrier(bar, gen, lane);
         STAMP(1 + (int)l);
     });
@@ -548,10 +556,20 @@ template <class LY>
 __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StepState* st = a.st;
-    if (st && st->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_in = ly.n_in(), D = n_in + 3;
     const int mode = a.mode;
+    if (st && st->done) {
+        // keep the state chain intact for the launches queued behind this one
+        if (a.apply_ctrl && blockIdx.x == 0 && tid == 0) *a.st_out = *st;
+        return;
+    }
+    // error partials of the previous attempt: requested first, consumed after the image fill
+    float cp0 = 0.f, cp1 = 0.f;
+    if (a.apply_ctrl) {
+        const int np = st->n_partials;
+        for (int i = tid; i < np; i += MF_THREADS) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
+    }
 
     // weights + biases -> LDS (once per workgroup; 4 x 16 B in flight per lane), the rest of
     // LDS zeroed (padding columns of the activation images meet zero weights but must be finite)
@@ -573,6 +591,35 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
             *(f32x4*)(lds + z) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    int cur = 0;
+    float hstep = 0.f, abstol = 0.f, reltol = 0.f;
+    if (a.apply_ctrl) {
+        // In-kernel step controller: every workgroup reduces the same partials in the same
+        // order and takes the same accept/reject decision; block 0 publishes the new state
+        // for the next launch (kernel boundary = release/acquire).
+        float* sc = lds + ly.bar_off() + 4;      // 12 spare words behind the team counters
+        __syncthreads();                          // zero fill done before the scratch is used
+        for (int off = 32; off > 0; off >>= 1) { cp0 += __shfl_down(cp0, off, 64); cp1 += __shfl_down(cp1, off, 64); }
+        float* red = lds + ly.red_off();
+        if (lane == 0) { red[wave] = cp0; red[8 + wave] = cp1; }
+        __syncthreads();
+        if (tid == 0) {
+            float p0 = 0.f, p1 = 0.f;
+            for (int w = 0; w < MF_THREADS / 64; ++w) { p0 += red[w]; p1 += red[8 + w]; }
+            StepState ns = *st;
+            ctrl_after_step(&ns, p0, p1, a.n_total);
+            if (blockIdx.x == 0) *a.st_out = ns;
+            sc[0] = __int_as_float(ns.cur); sc[1] = ns.h; sc[2] = ns.abstol; sc[3] = ns.reltol;
+            sc[4] = __int_as_float(ns.done);
+        }
+        __syncthreads();
+        cur = __float_as_int(sc[0]); hstep = sc[1]; abstol = sc[2]; reltol = sc[3];
+        if (__float_as_int(sc[4])) return;        // the controller just finished the solve
+        __syncthreads();                          // scratch (RED) is free again
+    } else if (st) {
+        cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol;
+    }
+
     constexpr int TT = MF_THREADS / 2, TNB = MF_NB / 2;
     const int team = wave >> 2, tt = tid & (TT - 1);
     const int s = lane & 15, q = lane >> 4, fg = (wave + 2 * team) & 3;
@@ -582,9 +629,6 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
     const int r00 = 16 * fg + 4 * q, r01 = r00 + 64;      // first owned row of each tile
     const int nv0 = own0 ? n_in - r00 : 0, nv1 = own1 ? n_in - r01 : 0;   // valid rows (may be <= 0 or > 4)
     const int row = TNB * team + s;
-    int cur = 0;
-    float hstep = 0.f, abstol = 0.f, reltol = 0.f;
-    if (st) { cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol; }
     const float* Uin = mode == 0 ? a.u : a.U[cur];
     const float* K1in = mode == 0 ? nullptr : a.K1[cur];
     float errsum = 0.f, badcnt = 0.f;
@@ -630,8 +674,8 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
         }
         const int nstage = mode == 2 ? 6 : 1;
         f32x4 un0 = uz0, un1 = uz1;
-        for (int stg = 1; stg <= nstage; ++stg) {
-            // stage state (z rows) -> region_0; the last stage's state is u_new (a7 = b)
+        // state of stage `stg` (z rows) -> region_0; the last stage's state is u_new (a7 = b)
+        auto put_stage = [&](int stg) {
             if (own0) {
                 if (mode == 1) un0 = uz0 + hstep * kz0[0];
                 else if (mode == 2) un0 = uz0 + hstep * stage_acc4_rt(stg, kz0);
@@ -642,34 +686,34 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
                 else if (mode == 2) un1 = uz1 + hstep * stage_acc4_rt(stg, kz1);
                 *(f32x4*)(lds + ly.x_off(0) + row * ly.SX(0) + r01) = un1;
             }
-            team_barrier(bar, gen, lane);
-            STAMP(0);
-            // scalar rows of the PREVIOUS evaluation, from its RED partials (these are
-            // overwritten only two barriers from here)
-            if (stg > 1 && sown) {
-                float ld = 0.f, e2 = 0.f, n2 = 0.f;
-                for (int t = 0; t < nt0; ++t) {
-                    e2 += lds[ly.red_off() + t * MF_NB + row];
-                    ld += lds[ly.red_off() + (nt0 + t) * MF_NB + row];
-                    n2 += lds[ly.red_off() + (2 * nt0 + t) * MF_NB + row];
-                }
-                set_k(ks, stg - 1, f32x4{ld, ly.norm_z() ? __builtin_sqrtf(e2) : 0.f,
-                                         ly.norm_j() ? __builtin_sqrtf(n2) : 0.f, 0.f});
-            }
-            f32x4 zd0 = {0.f, 0.f, 0.f, 0.f}, zd1 = zd0;
-            rhs_tile(ly, lds, lane, wave, bar, gen, zd0, zd1 STAMP_PASS);
-            if (mode == 2) { set_k(kz0, stg, zd0); set_k(kz1, stg, zd1); }
-            else { kz0[1] = zd0; kz1[1] = zd1; }
-        }
-        // scalar rows of the last evaluation (rhs_tile ended with a barrier)
-        if (sown) {
+        };
+        auto read_scalars = [&]() {
             float ld = 0.f, e2 = 0.f, n2 = 0.f;
             for (int t = 0; t < nt0; ++t) {
                 e2 += lds[ly.red_off() + t * MF_NB + row];
                 ld += lds[ly.red_off() + (nt0 + t) * MF_NB + row];
                 n2 += lds[ly.red_off() + (2 * nt0 + t) * MF_NB + row];
             }
-            const f32x4 v = {ld, ly.norm_z() ? __builtin_sqrtf(e2) : 0.f, ly.norm_j() ? __builtin_sqrtf(n2) : 0.f, 0.f};
+            return f32x4{ld, ly.norm_z() ? __builtin_sqrtf(e2) : 0.f, ly.norm_j() ? __builtin_sqrtf(n2) : 0.f, 0.f};
+        };
+        put_stage(1);
+        team_barrier(bar, gen, lane);
+        STAMP(0);
+        for (int stg = 1; stg <= nstage; ++stg) {
+            // scalar rows of the PREVIOUS evaluation, from its RED partials (RED[0] is
+            // rewritten only in this evaluation's last forward epilogue, two barriers on)
+            if (stg > 1 && sown) set_k(ks, stg - 1, read_scalars());
+            f32x4 zd0 = {0.f, 0.f, 0.f, 0.f}, zd1 = zd0;
+            rhs_tile(ly, lds, lane, wave, bar, gen, zd0, zd1, [&]() {
+                if (mode == 2) {
+                    set_k(kz0, stg, zd0); set_k(kz1, stg, zd1);
+                    if (stg < nstage) put_stage(stg + 1);
+                } else { kz0[1] = zd0; kz1[1] = zd1; }
+            } STAMP_PASS);
+        }
+        // scalar rows of the last evaluation (rhs_tile ended with a barrier)
+        if (sown) {
+            const f32x4 v = read_scalars();
             if (mode == 2) ks[6] = v; else ks[1] = v;
         }
         // ---- outputs ----
@@ -881,18 +925,22 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc&, bool train, const S
     return launch(p, a, s);
 }
 
-cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st,
-                     float* const U[2], float* const K1[2], float* const Ks[5],
-                     const float* eps, float* partials, int B, hipStream_t s) {
+cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st_in,
+                     StepState* st_out, float* const U[2], float* const K1[2], float* const Ks[5],
+                     const float* eps, const float* partials_in, float* partials_out, bool apply_ctrl,
+                     bool finalize, int B, hipStream_t s) {
     if (!p.variant || !train) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
-    a.mode = 2; a.B = B; a.img = p.d_img; a.eps = eps; a.st = st;
+    a.mode = 2; a.B = B; a.img = p.d_img; a.eps = eps; a.st = st_in; a.st_out = st_out;
+    a.partials_in = partials_in; a.apply_ctrl = apply_ctrl ? 1 : 0;
+    a.n_total = (float)((size_t)(nd.n_in + 3) * B);
     a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1]; a.Ks0 = Ks[0];
-    a.partials = partials;
+    a.partials = partials_out;
     cnf_status r = launch(p, a, s);
     if (r != CNF_OK) return r;
-    launch_controller(st, partials, 2, (float)((size_t)(nd.n_in + 3) * B), s);
-    return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+    if (finalize) {
+        launch_controller(apply_ctrl ? st_out : const_cast<StepState*>(st_in), partials_out, 2, a.n_total, s);
+        if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
+    }
+    return CNF_OK;
 }
-
-int mfma_step_launches() { return 2; }
