@@ -440,6 +440,7 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
     }
     StepState* cur_state = h->d_state;   // slot holding the live integrator state
     int pp = 0;                          // partials buffer the NEXT launch reads
+    long est_left = 0;                   // adaptive: estimated attempts still needed (0 = unknown)
     const int chunk = opts->adaptive ? 8 : (int)(expected < 64 ? expected : 64);
     long attempts = 0;
     int slot = 0;
@@ -453,6 +454,7 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
         }
         long todo = chunk;
         if (!opts->adaptive) todo = attempts >= expected ? 1 : (expected - attempts < todo ? expected - attempts : todo);
+        else if (est_left > 0 && est_left < todo) todo = est_left;   // do not run far past t1
         if (attempts + todo > (long)opts->maxiters) todo = (long)opts->maxiters - attempts;
         for (long i = 0; i < todo; ++i) {
             if (use_mfma) {
@@ -478,18 +480,30 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
         pending[slot] = true;
         // poll one chunk behind the GPU; wait for the chunk just enqueued only when no
         // further run-ahead is useful (fixed dt: all expected steps are in flight)
-        const bool wait_current = (!opts->adaptive && attempts >= expected) || attempts >= (long)opts->maxiters;
+        bool wait_current = (!opts->adaptive && attempts >= expected) || attempts >= (long)opts->maxiters;
         if (pending[slot ^ 1]) {
             HIPCHK(h, hipEventSynchronize(h->ev[slot ^ 1]));
             pending[slot ^ 1] = false;
             fin = h->h_state[slot ^ 1];
             done = fin.done != 0;
+            // fin is the state BEFORE the chunk just enqueued: estimate what is left after it
+            if (opts->adaptive && !done && fin.dt > 0.f) {
+                long need = (long)std::ceil(std::fabs((double)fin.t1 - (double)fin.t) / (double)fin.dt);
+                est_left = need - todo;
+                if (est_left <= 0) { est_left = 1; wait_current = true; }   // the queued chunk should finish it
+            }
+        } else if (opts->adaptive) {
+            wait_current = true;       // first chunk: learn t and dt before queueing more
         }
         if (!done && wait_current) {
             HIPCHK(h, hipEventSynchronize(h->ev[slot]));
             pending[slot] = false;
             fin = h->h_state[slot];
             done = fin.done != 0;
+            if (opts->adaptive && !done && fin.dt > 0.f) {
+                est_left = (long)std::ceil(std::fabs((double)fin.t1 - (double)fin.t) / (double)fin.dt);
+                if (est_left < 1) est_left = 1;
+            }
         }
         slot ^= 1;
     }

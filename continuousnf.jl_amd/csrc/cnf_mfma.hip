@@ -552,21 +552,23 @@ __device__ __forceinline__ void err_acc(float& errsum, float& badcnt, const f32x
 // lands in region_0 with one ds_write_b128.  The three scalar rows (dlogp, E, n) of sample s
 // live in lane s of the team's wave fg == 0; their RHS values are read back from the RED
 // partials one barrier later, off the critical path.
-template <class LY>
+// STEP = true: one Tsit5 step attempt (mode 2); STEP = false: one RHS evaluation (modes 0, 1).
+// Two instantiations so that profiles name the step kernel and the plain RHS kernel apart.
+template <class LY, bool STEP>
 __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StepState* st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_in = ly.n_in(), D = n_in + 3;
-    const int mode = a.mode;
+    const int mode = STEP ? 2 : a.mode;
     if (st && st->done) {
         // keep the state chain intact for the launches queued behind this one
-        if (a.apply_ctrl && blockIdx.x == 0 && tid == 0) *a.st_out = *st;
+        if (STEP && a.apply_ctrl && blockIdx.x == 0 && tid == 0) *a.st_out = *st;
         return;
     }
     // error partials of the previous attempt: requested first, consumed after the image fill
     float cp0 = 0.f, cp1 = 0.f;
-    if (a.apply_ctrl) {
+    if (STEP && a.apply_ctrl) {
         const int np = st->n_partials;
         for (int i = tid; i < np; i += MF_THREADS) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
     }
@@ -593,7 +595,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
 
     int cur = 0;
     float hstep = 0.f, abstol = 0.f, reltol = 0.f;
-    if (a.apply_ctrl) {
+    if (STEP && a.apply_ctrl) {
         // In-kernel step controller: every workgroup reduces the same partials in the same
         // order and takes the same accept/reject decision; block 0 publishes the new state
         // for the next launch (kernel boundary = release/acquire).
@@ -858,7 +860,10 @@ void mfma_plan_free(MfmaPlan& p) {
 
 template <class LY>
 static hipError_t set_attr() {
-    return hipFuncSetAttribute((const void*)k_mfma<LY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       MF_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_mfma<LY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                MF_LDS_BYTES);
 }
 
@@ -890,8 +895,9 @@ template <class LY>
 static void launch_static(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStream_t s) {
     LY ly;
     ly.n_in_ = p.ly.n_in; ly.norm_z_ = p.ly.norm_z; ly.norm_j_ = p.ly.norm_j;
-    hipLaunchKernelGGL((k_mfma<LY>), grid, dim3(MF_THREADS), (size_t)LY::total_floats() * sizeof(float), s,
-                       ly, a);
+    const size_t shm = (size_t)LY::total_floats() * sizeof(float);
+    if (a.mode == 2) hipLaunchKernelGGL((k_mfma<LY, true>), grid, dim3(MF_THREADS), shm, s, ly, a);
+    else hipLaunchKernelGGL((k_mfma<LY, false>), grid, dim3(MF_THREADS), shm, s, ly, a);
 }
 
 static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a, hipStream_t s) {
@@ -902,7 +908,8 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a, hipStream_t s) {
     else if (p.variant == 4) launch_static<LyCfg1>(p, a, grid, s);
     else {
         RtLayout ly{p.ly};
-        hipLaunchKernelGGL((k_mfma<RtLayout>), grid, block, shm, s, ly, a);
+        if (a.mode == 2) hipLaunchKernelGGL((k_mfma<RtLayout, true>), grid, block, shm, s, ly, a);
+        else hipLaunchKernelGGL((k_mfma<RtLayout, false>), grid, block, shm, s, ly, a);
     }
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
