@@ -165,10 +165,17 @@ def main():
             e1.record(stream); e1.synchronize()
             per_launch_s = e0.elapsed_time(e1) * 1e-3 / n
             units, kname = 1.0, "k_rhs_generic (1 RHS evaluation per launch)"
+        # HBM bytes per launch of that kernel from the PMC counters: collected in separate
+        # rocprofv3 --pmc passes (tools/collect_profiles.sh; FETCH_SIZE and WRITE_SIZE cannot
+        # share a pass) and committed under profiles/; bench.py cannot profile itself.
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "round1_step_kernel_pmc.json")
+        if kernel_used == _lib.KERNEL_MFMA and os.path.exists(pmc) and B == 8192:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         tf = units * fl.value / per_launch_s / 1e12
         gbs = units * by.value / per_launch_s / 1e9
         roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / PEAK_F32_TFLOPS, "traffic": None, "kernel": kname,
+                "frac": tf / PEAK_F32_TFLOPS, "traffic": traffic, "kernel": kname,
                 "launch_us": per_launch_s * 1e6,
                 "algorithmic_flops_per_launch": units * fl.value,
                 "algorithmic_bytes_per_launch": units * by.value,

@@ -53,6 +53,8 @@ _SIGNATURES = {
     "cnf_rhs_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int]),
     "cnf_solve_tsit5": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int,
                                   C.POINTER(cnf_solve_opts), C.POINTER(cnf_solve_stats), C.c_void_p]),
+    "cnf_solve_tsit5_host": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int,
+                                       C.POINTER(cnf_solve_opts), C.POINTER(cnf_solve_stats)]),
     "cnf_build_u0": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, C.c_int, C.c_void_p]),
     "cnf_inference_post": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int, C.c_void_p]),
     "cnf_inference": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int,

@@ -311,16 +311,8 @@ def base_sol(icnf: ICNF, prob: ODEProblem):
         _lib.check(l.cnf_solve_tsit5(h, m, u0.ptr, prob.eps.ptr if prob.eps else None, out.ptr,
                                      u0.B, C.byref(opts), C.byref(stats), _stream(u0)), h)
     else:
-        import torch  # host arrays: stage through device memory held by torch
-        raise_if_no_gpu()
-        dev = torch.device("cuda", icnf.device)
-        du0 = torch.from_numpy(u0.arr).to(dev)
-        deps = torch.from_numpy(prob.eps.arr).to(dev) if prob.eps else None
-        dout = torch.empty_like(du0)
-        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(l.cnf_solve_tsit5(h, m, du0.data_ptr(), deps.data_ptr() if deps is not None else None,
-                                     dout.data_ptr(), u0.B, C.byref(opts), C.byref(stats), st), h)
-        out.arr[:] = dout.cpu().numpy()
+        _lib.check(l.cnf_solve_tsit5_host(h, m, u0.ptr, prob.eps.ptr if prob.eps else None, out.ptr,
+                                          u0.B, C.byref(opts), C.byref(stats)), h)
     prob.stats = stats.as_dict()
     return out
 

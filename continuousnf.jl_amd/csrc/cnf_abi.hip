@@ -531,6 +531,33 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
     return CNF_OK;
 }
 
+extern "C" cnf_status cnf_solve_tsit5_host(cnf_handle h, int mode, const float* u0, const float* eps,
+                                           float* u_out, int B, const cnf_solve_opts* opts,
+                                           cnf_solve_stats* stats) {
+    cnf_status s = check_call(h, mode, B);
+    if (s != CNF_OK) return s;
+    if (!u0 || !u_out || !opts) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    if (B == 0) { if (stats) memset(stats, 0, sizeof *stats); return CNF_OK; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t D = rows_of(h, mode), n_in = h->nd.n_in;
+    float *u_d = nullptr, *o_d = nullptr, *e_d = nullptr;
+    HIPCHK(h, hipMalloc(&u_d, D * B * sizeof(float)));
+    HIPCHK(h, hipMalloc(&o_d, D * B * sizeof(float)));
+    HIPCHK(h, hipMemcpy(u_d, u0, D * B * sizeof(float), hipMemcpyHostToDevice));
+    if (eps) {
+        HIPCHK(h, hipMalloc(&e_d, n_in * B * sizeof(float)));
+        HIPCHK(h, hipMemcpy(e_d, eps, n_in * B * sizeof(float), hipMemcpyHostToDevice));
+    }
+    s = cnf_solve_tsit5(h, mode, u_d, e_d, o_d, B, opts, stats, nullptr);
+    if (s == CNF_OK) {
+        hipError_t e = hipMemcpy(u_out, o_d, D * B * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(u_d); (void)hipFree(o_d);
+    if (e_d) (void)hipFree(e_d);
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------
 // assembly / post-processing / loss (a6, a8, a9)
 // ---------------------------------------------------------------------------------------

@@ -126,6 +126,12 @@ cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0, const float*
                            float* u_out, int B, const cnf_solve_opts* opts,
                            cnf_solve_stats* stats, void* stream);
 
+/* Same with HOST matrices (copied to the device and back explicitly): the form a CPU-array
+ * caller such as the Julia shim binds when it has no device arrays of its own. */
+cnf_status cnf_solve_tsit5_host(cnf_handle h, int mode, const float* u0, const float* eps,
+                                float* u_out, int B, const cnf_solve_opts* opts,
+                                cnf_solve_stats* stats);
+
 /* inference_prob's state assembly (src/base_icnf.jl:275-276, 282):
  * u0 = vcat(xs, zeros(naugs + n_aug + 1, B)); xs: nvars x B. */
 cnf_status cnf_build_u0(cnf_handle h, int mode, const float* xs, float* u0, int B,
