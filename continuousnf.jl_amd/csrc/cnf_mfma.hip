@@ -190,6 +190,41 @@ __device__ __forceinline__ void mfma_block(f32x4& acc0, f32x4& acc1, const f32x4
 #ifdef MF_ABL_NOMFMA
     acc0 += a0 * b; if (NTL == 2) acc1 += a1 * b; return;
 #endif
+#ifdef MF_ABL_SAMEREG
+    {   // MFMAs depend on the loaded B operand only (A = B register): isolates operand-fetch effects
+        asm volatile("" ::"v"(a0));
+        if (NTL == 2) asm volatile("" ::"v"(a1));
+        for (int i = 0; i < 4; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i], b[i], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i], b[i], acc1, 0, 0, 0);
+        }
+        return;
+    }
+#endif
+#ifdef MF_ABL_AONLY
+    {   // MFMAs depend on the loaded A operands only
+        asm volatile("" ::"v"(b));
+        for (int i = 0; i < 4; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], a0[i], acc0, 0, 0, 0);
+            if (NTL == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], a1[i], acc1, 0, 0, 0);
+            else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], a0[i], acc1, 0, 0, 0);
+        }
+        return;
+    }
+#endif
+#ifdef MF_ABL_TWOCONST
+    {   // loads stay live, MFMAs run on two different constant register sets
+        asm volatile("" ::"v"(a0), "v"(b));
+        if (NTL == 2) asm volatile("" ::"v"(a1));
+        f32x4 ca = {1.f, 2.f, 3.f, 4.f}, cb = {5.f, 6.f, 7.f, 8.f};
+        asm volatile("" : "+v"(ca), "+v"(cb));
+        for (int i = 0; i < 4; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[i], cb[i], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[i], cb[i], acc1, 0, 0, 0);
+        }
+        return;
+    }
+#endif
 #ifdef MF_ABL_NODEP
     {   // loads stay live (asm sink) but the MFMAs run on constants
         asm volatile("" ::"v"(a0), "v"(b));
@@ -450,6 +485,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int
                 if (two) gemm_fwd<2>(acc0, acc1, U, xb, wa0, wa1);
                 else { gemm_fwd<1>(acc0, acc1, U, xb, wa0, wa1); acc0 += acc1; }
             }
+            STAMP(16 + 3 * (int)l);
             fwd_epilogue(ly, lds, l, last, t0, acc0, row, q, zd0);
             if (two) fwd_epilogue(ly, lds, l, last, t1, acc1, row, q, zd1);
         }
@@ -457,8 +493,9 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int
         // into region_0 (last read two barriers ago), which takes the stage combination and
         // one barrier off the critical path of every stage
         if (last) after_zdot();
+        STAMP(17 + 3 * (int)l);
         team_barrier(bar, gen, lane);
-        STAMP(1 + (int)l);
+        STAMP(18 + 3 * (int)l);
     });
     // ---- reverse (VJP): g_l = (W_{l+1}^T g_{l+1}) .* sigma'_l, in place over h_l ----
     for_layers_down(ly, [&](auto l) {
@@ -480,11 +517,13 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int
                 if (two) gemm_bwd<2>(acc0, acc1, U, SW, gb, wc0, wc1);
                 else { gemm_bwd<1>(acc0, acc1, U, SW, gb, wc0, wc1); acc0 += acc1; }
             }
+            STAMP(32 + 3 * (int)l);
             bwd_epilogue(ly, lds, l, t0, acc0, row, q);
             if (two) bwd_epilogue(ly, lds, l, t1, acc1, row, q);
         }
+        STAMP(33 + 3 * (int)l);
         team_barrier(bar, gen, lane);
-        STAMP(8 + (int)l);
+        STAMP(34 + 3 * (int)l);
     });
 }
 
@@ -637,7 +676,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
     unsigned* bar = (unsigned*)(lds + ly.bar_off()) + team;
     unsigned gen = 0;
 #ifdef MF_STAMPS
-    unsigned long long stamps[16] = {0};
+    unsigned long long stamps[48] = {0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
     const unsigned long long tstart = tlast;
 #endif
@@ -748,9 +787,11 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
     }
 #ifdef MF_STAMPS
     STAMP(14);
-    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 5) && mode == 2) {
-        printf("wave %d total %llu | fill %llu | elem %llu | fwd %llu %llu %llu | bwd %llu %llu %llu | tail %llu\n", wave,
-               tlast - tstart, stamps[15], stamps[0], stamps[1], stamps[2], stamps[3], stamps[10], stamps[9], stamps[8], stamps[14]);
+    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 2 || wave == 5) && mode == 2) {
+        printf("wave %d total %llu pre %llu elem %llu tail %llu | F1 %llu %llu %llu | F2 %llu %llu %llu | F3 %llu %llu %llu | B3 %llu %llu %llu | B2 %llu %llu %llu | B1 %llu %llu %llu\n",
+               wave, tlast - tstart, stamps[15], stamps[0], stamps[14], stamps[16], stamps[17], stamps[18], stamps[19], stamps[20],
+               stamps[21], stamps[22], stamps[23], stamps[24], stamps[38], stamps[39], stamps[40], stamps[35], stamps[36],
+               stamps[37], stamps[32], stamps[33], stamps[34]);
     }
 #endif
     if (mode == 2) {
