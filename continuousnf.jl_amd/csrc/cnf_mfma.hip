@@ -158,6 +158,13 @@ __device__ __forceinline__ void act_fast(int kind, float a, float& h, float& d) 
     if (kind == 1) { h = tanh_fast(a); d = fmaf(-h, h, 1.0f); }
     else cnf_act(kind, a, h, d);
 }
+__device__ __forceinline__ void act4(int kind, const f32x4& a, f32x4& h, f32x4& d) {
+    float h0, h1, h2, h3, d0, d1, d2, d3;
+    act_fast(kind, a.x, h0, d0); act_fast(kind, a.y, h1, d1);
+    act_fast(kind, a.z, h2, d2); act_fast(kind, a.w, h3, d3);
+    h = f32x4{h0, h1, h2, h3};
+    d = f32x4{d0, d1, d2, d3};
+}
 __device__ __forceinline__ float d_from_h(int kind, float h) {
     switch (kind) {
         case 0: return 1.0f;
@@ -812,6 +819,479 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
     }
 }
 
+// =================================================================================================
+// Fused-phase kernel for compile-time layouts with n_in <= 32 (one or two 16-row state tiles).
+//
+// The narrow GEMMs at both ends of the network (last layer forward: n_in outputs; first layer
+// reverse: n_in outputs) keep only 1-2 of a team's 4 waves busy when they run as phases of
+// their own, and every phase costs a barrier, an LDS round trip and an epilogue.  Here they
+// are folded into their wide neighbours as split-K partial products taken straight from
+// registers (an accumulator tile IS the B operand of the next product over its rows):
+//   P1      h_1 = act(W_1 z)                       [... hidden layers ...]
+//   P(L-1)  h_{L-1} = act(W_{L-1} h_{L-2});  partial zdot_w = W_L[:, own rows] h_{L-1}[own rows]  -> scratch
+//   Pmid    every wave sums the 4 partials: zdot, g_L = eps .* sigma'_L (registers);
+//           g_{L-1} = (W_L^T g_L) .* sigma'  straight from those registers
+//   ...     reverse hidden layers ...
+//   Plast   g_1 (registers);  partial eJ_w = W_1^T[:, own rows] g_1[own rows]          -> scratch
+//   (the eJ partials are summed by otherwise idle waves at the start of the next evaluation)
+// Config 3: 4 barriers per evaluation instead of 7, every wave busy in every phase.
+template <int ACT, int... PD>
+struct FsLayout {
+    static constexpr bool kStatic = true;
+    static constexpr int kL = sizeof...(PD) - 1;
+    int n_in_, norm_z_, norm_j_;
+    __host__ __device__ static constexpr int pd(int l) { constexpr int a[] = {PD...}; return a[l]; }
+    __host__ __device__ static constexpr int L() { return kL; }
+    __host__ __device__ static constexpr int P(int l) { return pd(l); }
+    __host__ __device__ static constexpr int act(int) { return ACT; }
+    __host__ __device__ static constexpr int SW(int l) { return sw_of(pd(l)); }
+    __host__ __device__ static constexpr int SX(int l) { return sx_of(pd(l)); }
+    __host__ __device__ static constexpr int w_off(int l) {
+        int off = 0;
+        for (int i = 0; i < l; ++i) off += pd(i + 1) * sw_of(pd(i));
+        return off;
+    }
+    __host__ __device__ static constexpr int b_off(int l) {
+        int off = w_off(kL);
+        for (int i = 0; i < l; ++i) off += pd(i + 1);
+        return off;
+    }
+    __host__ __device__ static constexpr int img_floats() { return (b_off(kL) + 3) & ~3; }
+    __host__ __device__ static constexpr int x_off(int l) {          // regions 0 .. L-1 only
+        int off = img_floats();
+        for (int i = 0; i < l; ++i) off += MF_NB * sx_of(pd(i));
+        return off;
+    }
+    static constexpr int kNT0 = pd(0) / 16;
+    __host__ __device__ static constexpr int scr_off() { return x_off(kL); }   // zdot partials [team][wave][tile][16][16]
+    // eJ partials: with L >= 3 a barrier separates their last reader (phase 1) from the next
+    // zdot-partial writer (phase L-1), so they share the area; with L == 2 they need their own
+    __host__ __device__ static constexpr int scr2_off() { return scr_off() + (kL >= 3 ? 0 : 2 * 4 * kNT0 * 256); }
+    __host__ __device__ static constexpr int red_off() { return scr2_off() + 2 * 4 * kNT0 * 256; }
+    __host__ __device__ static constexpr int bar_off() { return red_off() + (3 * kNT0 * MF_NB < 16 ? 16 : 3 * kNT0 * MF_NB); }
+    __host__ __device__ static constexpr int total_floats() { return bar_off() + 16; }
+    __device__ __forceinline__ int n_in() const { return n_in_; }
+    __device__ __forceinline__ int norm_z() const { return norm_z_; }
+    __device__ __forceinline__ int norm_j() const { return norm_j_; }
+    static constexpr bool kOK = kL >= 2 && pd(0) <= 32 && pd(0) == pd(kL);
+};
+
+// 4 MFMAs: acc += A-block (row fragment a) x B (a register tile b)
+__device__ __forceinline__ f32x4 mfma_ab(const f32x4& a, const f32x4& b, f32x4 acc) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], acc, 0, 0, 0);
+    return acc;
+}
+
+template <class FS, bool STEP>
+__global__ void __launch_bounds__(MF_THREADS, 2) k_fused(FS ly, MfmaArgs a) {
+    static_assert(FS::kOK, "layout not fusable");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int L = FS::kL, NT0 = FS::kNT0;
+    const StepState* st = a.st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_in = ly.n_in(), D = n_in + 3;
+    const int mode = STEP ? 2 : a.mode;
+    if (st && st->done) {
+        if (STEP && a.apply_ctrl && blockIdx.x == 0 && tid == 0) *a.st_out = *st;
+        return;
+    }
+    float cp0 = 0.f, cp1 = 0.f;
+    if (STEP && a.apply_ctrl) {
+        const int np = st->n_partials;
+        for (int i = tid; i < np; i += MF_THREADS) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
+    }
+    {   // weights + biases -> LDS, rest zeroed
+        constexpr int n = FS::img_floats();
+        int i = tid * 4;
+        for (; i + 3 * MF_THREADS * 4 < n; i += 4 * MF_THREADS * 4) {
+            const f32x4 v0 = *(const f32x4*)(a.img + i);
+            const f32x4 v1 = *(const f32x4*)(a.img + i + MF_THREADS * 4);
+            const f32x4 v2 = *(const f32x4*)(a.img + i + 2 * MF_THREADS * 4);
+            const f32x4 v3 = *(const f32x4*)(a.img + i + 3 * MF_THREADS * 4);
+            *(f32x4*)(lds + i) = v0;
+            *(f32x4*)(lds + i + MF_THREADS * 4) = v1;
+            *(f32x4*)(lds + i + 2 * MF_THREADS * 4) = v2;
+            *(f32x4*)(lds + i + 3 * MF_THREADS * 4) = v3;
+        }
+        for (; i < n; i += MF_THREADS * 4) *(f32x4*)(lds + i) = *(const f32x4*)(a.img + i);
+        for (int z = n + tid * 4; z < FS::total_floats(); z += MF_THREADS * 4)
+            *(f32x4*)(lds + z) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int cur = 0;
+    float hstep = 0.f, abstol = 0.f, reltol = 0.f;
+    if (STEP && a.apply_ctrl) {
+        float* sc = lds + FS::bar_off() + 4;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) { cp0 += __shfl_down(cp0, off, 64); cp1 += __shfl_down(cp1, off, 64); }
+        float* red = lds + FS::red_off();
+        if (lane == 0) { red[wave] = cp0; red[8 + wave] = cp1; }
+        __syncthreads();
+        if (tid == 0) {
+            float p0 = 0.f, p1 = 0.f;
+            for (int w = 0; w < MF_THREADS / 64; ++w) { p0 += red[w]; p1 += red[8 + w]; }
+            StepState ns = *st;
+            ctrl_after_step(&ns, p0, p1, a.n_total);
+            if (blockIdx.x == 0) *a.st_out = ns;
+            sc[0] = __int_as_float(ns.cur); sc[1] = ns.h; sc[2] = ns.abstol; sc[3] = ns.reltol;
+            sc[4] = __int_as_float(ns.done);
+        }
+        __syncthreads();
+        cur = __float_as_int(sc[0]); hstep = sc[1]; abstol = sc[2]; reltol = sc[3];
+        if (__float_as_int(sc[4])) return;
+        __syncthreads();
+    } else if (st) {
+        cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol;
+    }
+
+    constexpr int TNB = MF_NB / 2;
+    const int team = wave >> 2, fg = (wave + 2 * team) & 3;
+    const int s = lane & 15, q = lane >> 4;
+    const int row = TNB * team + s;
+    const bool own = fg < NT0;                       // owns z-row tile fg
+    const bool sown = fg == 0 && q == 0;             // owns the scalar rows of sample s
+    const int r0 = 16 * fg + 4 * q;
+    const int nv = own ? n_in - r0 : 0;
+    const float* Uin = mode == 0 ? a.u : a.U[cur];
+    const float* K1in = mode == 0 ? nullptr : a.K1[cur];
+    float errsum = 0.f, badcnt = 0.f;
+    float* scr = lds + FS::scr_off() + team * (4 * NT0 * 256);
+    float* scr2 = lds + FS::scr2_off() + team * (4 * NT0 * 256);
+    float* red = lds + FS::red_off();
+#ifdef MF_STAMPS
+    unsigned long long stamps[48] = {0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tlast;
+#endif
+    __syncthreads();
+    STAMP(0);
+
+    const int ntile = (a.B + MF_NB - 1) / MF_NB;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int b0 = tile * MF_NB + TNB * team;
+        const int nvalid = max(0, min(TNB, a.B - b0));
+        const bool live = s < nvalid;
+        const size_t gcol = (size_t)(b0 + s) * D;
+        // eps of this lane's sample, all NT0 row tiles, accumulator layout
+        f32x4 ev[NT0];
+#pragma unroll
+        for (int t = 0; t < NT0; ++t)
+            ev[t] = live ? ld4(a.eps + (size_t)(b0 + s) * n_in + 16 * t + 4 * q, n_in - (16 * t + 4 * q))
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 uz = {0.f, 0.f, 0.f, 0.f}, kz[7], us = uz, ks[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { kz[i] = uz; ks[i] = uz; }
+        if (live) {
+            if (own) uz = ld4(Uin + gcol + r0, nv);
+            if (sown) us = ld4(Uin + gcol + n_in, 3);
+            if (K1in) {
+                if (own) kz[0] = ld4(K1in + gcol + r0, nv);
+                if (sown) ks[0] = ld4(K1in + gcol + n_in, 3);
+            }
+        }
+        const int nstage = mode == 2 ? 6 : 1;
+        f32x4 un = uz;
+        auto put_stage = [&](int stg) {
+            if (own) {
+                if (mode == 1) un = uz + hstep * kz[0];
+                else if (mode == 2) un = uz + hstep * stage_acc4_rt(stg, kz);
+                *(f32x4*)(lds + FS::x_off(0) + row * FS::SX(0) + r0) = un;
+            }
+        };
+        // sum of the eJ partials of the previous evaluation -> trace / norm partials in RED
+        auto reduce_eJ = [&]() {
+#pragma unroll
+            for (int kt = 0; kt < NT0; ++kt) {
+                if (fg == 3 - kt) {
+                    constexpr int NW = FS::P(1) / 16 < 4 ? FS::P(1) / 16 : 4;
+                    f32x4 e = *(const f32x4*)(scr2 + ((0 * NT0 + kt) * 16 + s) * 16 + 4 * q);
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) e += *(const f32x4*)(scr2 + ((w * NT0 + kt) * 16 + s) * 16 + 4 * q);
+                    float ld = -(e.x * ev[kt].x + e.y * ev[kt].y + e.z * ev[kt].z + e.w * ev[kt].w);
+                    float n2 = e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
+                    ld = quad_sum(ld);
+                    n2 = quad_sum(n2);
+                    if (q == 0) { red[(NT0 + kt) * MF_NB + row] = ld; red[(2 * NT0 + kt) * MF_NB + row] = n2; }
+                }
+            }
+        };
+        float e2s = 0.f;                       // scalar owner: |zdot|^2 of the previous evaluation
+        auto read_E = [&]() { e2s = 0.f; for (int t = 0; t < NT0; ++t) e2s += red[t * MF_NB + row]; };
+        auto read_ln = [&]() {
+            float ld = 0.f, n2 = 0.f;
+            for (int t = 0; t < NT0; ++t) { ld += red[(NT0 + t) * MF_NB + row]; n2 += red[(2 * NT0 + t) * MF_NB + row]; }
+            return f32x4{ld, ly.norm_z() ? __builtin_sqrtf(e2s) : 0.f, ly.norm_j() ? __builtin_sqrtf(n2) : 0.f, 0.f};
+        };
+        put_stage(1);
+        __syncthreads();
+        STAMP(1);
+
+        for (int stg = 1; stg <= nstage; ++stg) {
+            f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;     // this wave's tiles of the current layer (registers)
+            // A fragments (weights: independent of any barrier) requested one phase early
+            f32x4 ra0[NT0], ra1[NT0];                     // W_L^T columns for the reverse of the last layer
+            // ---------------- forward hidden layers 0 .. L-2 ----------------
+            static_for_up<0, L - 1>([&](auto lc) {
+                constexpr int l = decltype(lc)::value;
+                constexpr int ntiles = FS::P(l + 1) / 16, U = FS::P(l) / 16, SW = FS::SW(l);
+                static_assert(ntiles <= 8, "one pass per layer");
+                if (l == 0 && stg > 1) {
+                    if (sown) read_E();
+                    reduce_eJ();
+                }
+                const float* xb = lds + FS::x_off(l) + row * FS::SX(l) + 4 * q;
+                const float* W = lds + FS::w_off(l);
+                const int t0 = fg, t1 = fg + 4;
+                const bool has = t0 < ntiles, two = t1 < ntiles;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+                f32x4 pa0[NT0], pa1[NT0];                 // W_L row fragments for the split-K partial
+                if (l == L - 2 && has) {
+                    constexpr int SWL = FS::SW(L - 1);
+                    const float* WL = lds + FS::w_off(L - 1);
+#pragma unroll
+                    for (int ot = 0; ot < NT0; ++ot) {
+                        pa0[ot] = *(const f32x4*)(WL + (16 * ot + s) * SWL + 16 * t0 + 4 * q);
+                        if (two) pa1[ot] = *(const f32x4*)(WL + (16 * ot + s) * SWL + 16 * t1 + 4 * q);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (has) {
+                    const float* wa0 = W + (16 * t0 + s) * SW + 4 * q;
+                    const float* wa1 = W + (16 * t1 + s) * SW + 4 * q;
+                    STAMP(41);
+                    if (two) fwd_body<U, 2>(acc0, acc1, xb, wa0, wa1);
+                    else { fwd_body<U, 1>(acc0, acc1, xb, wa0, wa1); acc0 += acc1; }
+                    STAMP(42 + (l == L - 2 ? 1 : 0));
+                    const f32x4 bv0 = *(const f32x4*)(lds + FS::b_off(l) + 16 * t0 + 4 * q);
+                    f32x4 dd_;
+                    act4(FS::act(l), acc0 + bv0, h0, dd_);
+                    *(f32x4*)(lds + FS::x_off(l + 1) + row * FS::SX(l + 1) + 16 * t0 + 4 * q) = h0;
+                    if (two) {
+                        const f32x4 bv1 = *(const f32x4*)(lds + FS::b_off(l) + 16 * t1 + 4 * q);
+                        act4(FS::act(l), acc1 + bv1, h1, dd_);
+                        *(f32x4*)(lds + FS::x_off(l + 1) + row * FS::SX(l + 1) + 16 * t1 + 4 * q) = h1;
+                    }
+                }
+                STAMP(4 + 4 * l);
+                if (l == L - 2) {
+                    // split-K partial of the last layer from the register tiles:
+                    // zdot_w[ot] = W_L[ot, own rows] h[own rows]; NT0 independent chains, interleaved
+                    if (has) {
+                        f32x4 pz[NT0];
+#pragma unroll
+                        for (int ot = 0; ot < NT0; ++ot) pz[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int ot = 0; ot < NT0; ++ot)
+                                pz[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa0[ot][c], h0[c], pz[ot], 0, 0, 0);
+                        if (two) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                                for (int ot = 0; ot < NT0; ++ot)
+                                    pz[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa1[ot][c], h1[c], pz[ot], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int ot = 0; ot < NT0; ++ot)
+                            *(f32x4*)(scr + ((fg * NT0 + ot) * 16 + s) * 16 + 4 * q) = pz[ot];
+                    }
+                    // weights for the reverse of the last layer: requested before the barrier
+                    {
+                        constexpr int SWr = FS::SW(L - 1);
+                        const float* Wr = lds + FS::w_off(L - 1);
+                        constexpr int ntr = FS::P(L - 1) / 16;
+                        if (fg < ntr) {
+#pragma unroll
+                            for (int u = 0; u < NT0; ++u) {
+                                const float* p0 = Wr + (16 * u + 4 * q) * SWr + 16 * fg + s;
+                                ra0[u] = f32x4{p0[0], p0[SWr], p0[2 * SWr], p0[3 * SWr]};
+                                if (fg + 4 < ntr) {
+                                    const float* p1 = p0 + 64;
+                                    ra1[u] = f32x4{p1[0], p1[SWr], p1[2 * SWr], p1[3 * SWr]};
+                                }
+                            }
+                        }
+                    }
+                }
+                STAMP(5 + 4 * l);
+                __syncthreads();
+                STAMP(6 + 4 * l);
+                if (l == 0 && stg > 1 && sown) set_k(ks, stg - 1, read_ln());
+            });
+            // ---------------- middle: zdot, g_L; reverse of the last layer from registers ----------------
+            f32x4 gL[NT0];
+            {
+                constexpr int NW = FS::P(L - 1) / 16 < 4 ? FS::P(L - 1) / 16 : 4;
+                f32x4 zp[NT0][NW], bvv[NT0];
+#pragma unroll
+                for (int ot = 0; ot < NT0; ++ot) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) zp[ot][w] = *(const f32x4*)(scr + ((w * NT0 + ot) * 16 + s) * 16 + 4 * q);
+                    bvv[ot] = *(const f32x4*)(lds + FS::b_off(L - 1) + 16 * ot + 4 * q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ot = 0; ot < NT0; ++ot) {
+                    f32x4 z = zp[ot][0];
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) z += zp[ot][w];
+                    const f32x4 bv = bvv[ot];
+                    f32x4 zd, dd;
+                    act4(FS::act(L - 1), z + bv, zd, dd);
+                    gL[ot] = ev[ot] * dd;           // eps is zero on padding rows -> g_L too
+                    if (fg == ot) {
+                        const int rr = 16 * ot + 4 * q;
+                        zd = f32x4{rr + 0 < n_in ? zd.x : 0.f, rr + 1 < n_in ? zd.y : 0.f,
+                                   rr + 2 < n_in ? zd.z : 0.f, rr + 3 < n_in ? zd.w : 0.f};
+                        const float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
+                        if (q == 0) red[ot * MF_NB + row] = e2;
+                        if (mode == 2) { set_k(kz, stg, zd); if (stg < nstage) put_stage(stg + 1); }
+                        else kz[1] = zd;
+                    }
+                }
+            }
+            STAMP(20);
+            // reverse sweep, layers L-1 .. 1; output tiles of layer l's input (P(l) rows)
+            static_for_down<L - 1>([&](auto lc) {
+                constexpr int l = decltype(lc)::value;
+                if constexpr (l >= 1) {
+                    constexpr int ntiles = FS::P(l) / 16, SW = FS::SW(l);
+                    static_assert(ntiles <= 8, "one pass per layer");
+                    const float* W = lds + FS::w_off(l);
+                    const int t0 = fg, t1 = fg + 4;
+                    const bool has = t0 < ntiles, two = t1 < ntiles;
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+                    f32x4 g0 = acc0, g1 = acc0;
+                    f32x4 ea0[NT0], ea1[NT0];             // W_1^T fragments for the split-K partial of eJ
+                    if (l == 1 && has) {
+                        constexpr int SW0 = FS::SW(0);
+                        const float* W0 = lds + FS::w_off(0);
+#pragma unroll
+                        for (int kt = 0; kt < NT0; ++kt) {
+                            const float* p0 = W0 + (16 * t0 + 4 * q) * SW0 + 16 * kt + s;
+                            ea0[kt] = f32x4{p0[0], p0[SW0], p0[2 * SW0], p0[3 * SW0]};
+                            if (two) {
+                                const float* p1 = W0 + (16 * t1 + 4 * q) * SW0 + 16 * kt + s;
+                                ea1[kt] = f32x4{p1[0], p1[SW0], p1[2 * SW0], p1[3 * SW0]};
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (has) {
+                        const float* wc0 = W + (4 * q) * SW + 16 * t0 + s;
+                        const float* wc1 = W + (4 * q) * SW + 16 * t1 + s;
+                        if constexpr (l == L - 1) {
+                            // B operand = g_L register tiles, A = fragments requested before the barrier
+#pragma unroll
+                            for (int u = 0; u < NT0; ++u)
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[u][c], gL[u][c], acc0, 0, 0, 0);
+                                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[u][c], gL[u][c], acc1, 0, 0, 0);
+                                }
+                        } else {
+                            constexpr int U = FS::P(l + 1) / 16;
+                            const float* gb = lds + FS::x_off(l + 1) + row * FS::SX(l + 1) + 4 * q;
+                            if (two) bwd_body<U, 2>(acc0, acc1, SW, gb, wc0, wc1);
+                            else { bwd_body<U, 1>(acc0, acc1, SW, gb, wc0, wc1); acc0 += acc1; }
+                        }
+                        // g_l = acc .* sigma'(h_l), h_l read back from region_l at this lane's own position
+                        float* o0 = lds + FS::x_off(l) + row * FS::SX(l) + 16 * t0 + 4 * q;
+                        const f32x4 hv0 = *(const f32x4*)o0;
+                        g0 = f32x4{acc0.x * d_from_h(FS::act(l - 1), hv0.x), acc0.y * d_from_h(FS::act(l - 1), hv0.y),
+                                   acc0.z * d_from_h(FS::act(l - 1), hv0.z), acc0.w * d_from_h(FS::act(l - 1), hv0.w)};
+                        if (l > 1) *(f32x4*)o0 = g0;
+                        if (two) {
+                            float* o1 = lds + FS::x_off(l) + row * FS::SX(l) + 16 * t1 + 4 * q;
+                            const f32x4 hv1 = *(const f32x4*)o1;
+                            g1 = f32x4{acc1.x * d_from_h(FS::act(l - 1), hv1.x), acc1.y * d_from_h(FS::act(l - 1), hv1.y),
+                                       acc1.z * d_from_h(FS::act(l - 1), hv1.z), acc1.w * d_from_h(FS::act(l - 1), hv1.w)};
+                            if (l > 1) *(f32x4*)o1 = g1;
+                        }
+                        STAMP(24 + 4 * l);
+                        if constexpr (l == 1) {
+                            // split-K partial of eJ = W_1^T g_1 from the register tiles (NT0 chains)
+                            f32x4 pe[NT0];
+#pragma unroll
+                            for (int kt = 0; kt < NT0; ++kt) pe[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                                for (int kt = 0; kt < NT0; ++kt)
+                                    pe[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0[kt][c], g0[c], pe[kt], 0, 0, 0);
+                            if (two) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                                    for (int kt = 0; kt < NT0; ++kt)
+                                        pe[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1[kt][c], g1[c], pe[kt], 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int kt = 0; kt < NT0; ++kt)
+                                *(f32x4*)(scr2 + ((fg * NT0 + kt) * 16 + s) * 16 + 4 * q) = pe[kt];
+                        }
+                    }
+                    STAMP(25 + 4 * l);
+                    __syncthreads();
+                    STAMP(26 + 4 * l);
+                }
+            });
+        }
+        // last evaluation: eJ partials -> RED, then the scalar rows
+        if (sown) read_E();
+        reduce_eJ();
+        __syncthreads();
+        if (sown) {
+            const f32x4 v = read_ln();
+            if (mode == 2) ks[6] = v; else ks[1] = v;
+        }
+        // ---- outputs ----
+        if (live) {
+            if (mode == 0 || mode == 1) {
+                float* out = (mode == 0 ? a.du : a.Ks0) + gcol;
+                if (own) st4(out + r0, kz[1], nv);
+                if (sown) st4(out + n_in, ks[1], 3);
+            } else {
+                float* Un = a.U[1 - cur] + gcol;
+                float* K7 = a.K1[1 - cur] + gcol;
+                if (own) {
+                    st4(Un + r0, un, nv); st4(K7 + r0, kz[6], nv);
+                    err_acc(errsum, badcnt, kz, uz, un, hstep, abstol, reltol, nv);
+                }
+                if (sown) {
+                    const f32x4 uns = us + hstep * stage_acc4<6>(ks);
+                    st4(Un + n_in, uns, 3); st4(K7 + n_in, ks[6], 3);
+                    err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
+                }
+            }
+        }
+        __syncthreads();      // RED / scratch reads of this tile precede the next tile's writes
+    }
+#ifdef MF_STAMPS
+    STAMP(40);
+    if (blockIdx.x == 0 && lane == 0 && mode == 2) {
+        printf("wave %d total %llu fill %llu pre %llu tail %llu | P1 g+e %llu wait %llu | P2 g+e %llu part %llu wait %llu | mid %llu | B3(l=2) g+e %llu wait %llu | B2(l=1) g+e %llu part %llu wait %llu || pre-gemm %llu gemmP1 %llu gemmP2 %llu\n",
+               wave, tlast - tstart, stamps[0], stamps[1], stamps[40], stamps[4] + stamps[5], stamps[6], stamps[8], stamps[9], stamps[10],
+               stamps[20], stamps[32] + stamps[33], stamps[34], stamps[28], stamps[29], stamps[30], stamps[41], stamps[42], stamps[43]);
+    }
+#endif
+    if (mode == 2) {
+        for (int off = 32; off > 0; off >>= 1) {
+            errsum += __shfl_down(errsum, off, 64);
+            badcnt += __shfl_down(badcnt, off, 64);
+        }
+        if (lane == 0) { red[wave] = errsum; red[8 + wave] = badcnt; }
+        __syncthreads();
+        if (tid == 0) {
+            float e = 0.f, b = 0.f;
+            for (int w = 0; w < MF_THREADS / 64; ++w) { e += red[w]; b += red[8 + w]; }
+            a.partials[2 * blockIdx.x] = e;
+            a.partials[2 * blockIdx.x + 1] = b;
+        }
+    }
+}
+
 // ---- weight image packing -------------------------------------------------------------------
 __global__ void k_pack_image(MfmaLayout ly, NetDesc nd, const float* __restrict__ P,
                              float* __restrict__ img) {
@@ -834,9 +1314,9 @@ __global__ void k_pack_image(MfmaLayout ly, NetDesc nd, const float* __restrict_
 
 // ---- host side ----------------------------------------------------------------------------
 // static instantiations: (activation, padded sizes...) -> kernel.  Variant ids >= 2.
-using LyCfg3 = StLayout<CNF_ACT_TANH, 32, 128, 128, 32>;   // BASELINE configs 3/4
-using LyCfg2 = StLayout<CNF_ACT_TANH, 16, 48, 16>;         // BASELINE config 2
-using LyCfg1 = StLayout<CNF_ACT_TANH, 16, 16, 16>;         // BASELINE config 1 (2->6->2 padded)
+using LyCfg3 = FsLayout<CNF_ACT_TANH, 32, 128, 128, 32>;   // BASELINE configs 3/4
+using LyCfg2 = FsLayout<CNF_ACT_TANH, 16, 48, 16>;         // BASELINE config 2
+using LyCfg1 = FsLayout<CNF_ACT_TANH, 16, 16, 16>;         // BASELINE config 1 (2->6->2 padded)
 
 template <class LY>
 static bool matches(const MfmaLayout& m) {
@@ -845,8 +1325,7 @@ static bool matches(const MfmaLayout& m) {
         if (m.P[l] != LY::P(l)) return false;
     for (int l = 0; l < m.L; ++l)
         if (m.acts[l] != LY::act(l)) return false;
-    return m.img_floats == LY::img_floats() && m.total_floats == LY::total_floats() &&
-           m.red_off == LY::red_off() && m.x_off[m.L] == LY::x_off(LY::kL);
+    return m.img_floats == LY::img_floats() && (size_t)LY::total_floats() * sizeof(float) <= MF_LDS_BYTES;
 }
 
 void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
@@ -908,14 +1387,23 @@ static hipError_t set_attr() {
                                MF_LDS_BYTES);
 }
 
+template <class FS>
+static hipError_t set_attr_fused() {
+    hipError_t e = hipFuncSetAttribute((const void*)k_fused<FS, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       MF_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_fused<FS, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               MF_LDS_BYTES);
+}
+
 cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params, hipStream_t s) {
     if (!p.variant) return CNF_OK;
     if (!p.d_img) {
         if (hipMalloc(&p.d_img, (size_t)p.ly.img_floats * sizeof(float)) != hipSuccess) return CNF_ERR_HIP;
         hipError_t e = set_attr<RtLayout>();
-        if (e == hipSuccess) e = set_attr<LyCfg3>();
-        if (e == hipSuccess) e = set_attr<LyCfg2>();
-        if (e == hipSuccess) e = set_attr<LyCfg1>();
+        if (e == hipSuccess) e = set_attr_fused<LyCfg3>();
+        if (e == hipSuccess) e = set_attr_fused<LyCfg2>();
+        if (e == hipSuccess) e = set_attr_fused<LyCfg1>();
         if (e != hipSuccess) return CNF_ERR_HIP;
     }
     hipLaunchKernelGGL(k_pack_image, dim3((p.ly.img_floats + 255) / 256), dim3(256), 0, s, p.ly, nd,
@@ -937,8 +1425,8 @@ static void launch_static(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipSt
     LY ly;
     ly.n_in_ = p.ly.n_in; ly.norm_z_ = p.ly.norm_z; ly.norm_j_ = p.ly.norm_j;
     const size_t shm = (size_t)LY::total_floats() * sizeof(float);
-    if (a.mode == 2) hipLaunchKernelGGL((k_mfma<LY, true>), grid, dim3(MF_THREADS), shm, s, ly, a);
-    else hipLaunchKernelGGL((k_mfma<LY, false>), grid, dim3(MF_THREADS), shm, s, ly, a);
+    if (a.mode == 2) hipLaunchKernelGGL((k_fused<LY, true>), grid, dim3(MF_THREADS), shm, s, ly, a);
+    else hipLaunchKernelGGL((k_fused<LY, false>), grid, dim3(MF_THREADS), shm, s, ly, a);
 }
 
 static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a, hipStream_t s) {

@@ -20,6 +20,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 kernel = sys.argv[3] if len(sys.argv) > 3 else "mfma"
 cfgi = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 cfg, B, _ = O.baseline_cfg(cfgi)
+B = int(os.environ.get("PROF_B", B))
 if cfgi == 5:
     cfg.lam3 = 1e-2
 rng = np.random.default_rng(0)
