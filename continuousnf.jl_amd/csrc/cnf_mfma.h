@@ -27,6 +27,8 @@ struct MfmaLayout {
 
 struct MfmaPlan {
     int variant = 0;                // 0: shape not supported by the MFMA path
+    int schedule = 0;               // static shapes: 0 phase-per-layer (default, fastest measured),
+                                    // 1 fused narrow layers, 2 fused + ping-pong teams (CNF_MFMA_SCHEDULE)
     MfmaLayout ly{};
     float* d_img = nullptr;         // weight+bias image in HBM (LDS order), refreshed by pack
 };

@@ -30,6 +30,7 @@
 #include "cnf_mfma.h"
 #include "cnf_kernels.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1292,6 +1293,459 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_fused(FS ly, MfmaArgs a) {
     }
 }
 
+// Ping-pong variant of k_fused (same layout, same arithmetic, different schedule).
+template <class FS, bool STEP>
+__global__ void __launch_bounds__(MF_THREADS, 2) k_pp(FS ly, MfmaArgs a) {
+    static_assert(FS::kOK, "layout not fusable");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int L = FS::kL, NT0 = FS::kNT0;
+    const StepState* st = a.st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_in = ly.n_in(), D = n_in + 3;
+    const int mode = STEP ? 2 : a.mode;
+    if (st && st->done) {
+        if (STEP && a.apply_ctrl && blockIdx.x == 0 && tid == 0) *a.st_out = *st;
+        return;
+    }
+    float cp0 = 0.f, cp1 = 0.f;
+    if (STEP && a.apply_ctrl) {
+        const int np = st->n_partials;
+        for (int i = tid; i < np; i += MF_THREADS) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
+    }
+    {   // weights + biases -> LDS, rest zeroed
+        constexpr int n = FS::img_floats();
+        int i = tid * 4;
+        for (; i + 3 * MF_THREADS * 4 < n; i += 4 * MF_THREADS * 4) {
+            const f32x4 v0 = *(const f32x4*)(a.img + i);
+            const f32x4 v1 = *(const f32x4*)(a.img + i + MF_THREADS * 4);
+            const f32x4 v2 = *(const f32x4*)(a.img + i + 2 * MF_THREADS * 4);
+            const f32x4 v3 = *(const f32x4*)(a.img + i + 3 * MF_THREADS * 4);
+            *(f32x4*)(lds + i) = v0;
+            *(f32x4*)(lds + i + MF_THREADS * 4) = v1;
+            *(f32x4*)(lds + i + 2 * MF_THREADS * 4) = v2;
+            *(f32x4*)(lds + i + 3 * MF_THREADS * 4) = v3;
+        }
+        for (; i < n; i += MF_THREADS * 4) *(f32x4*)(lds + i) = *(const f32x4*)(a.img + i);
+        for (int z = n + tid * 4; z < FS::total_floats(); z += MF_THREADS * 4)
+            *(f32x4*)(lds + z) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int cur = 0;
+    float hstep = 0.f, abstol = 0.f, reltol = 0.f;
+    if (STEP && a.apply_ctrl) {
+        float* sc = lds + FS::bar_off() + 4;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) { cp0 += __shfl_down(cp0, off, 64); cp1 += __shfl_down(cp1, off, 64); }
+        float* red = lds + FS::red_off();
+        if (lane == 0) { red[wave] = cp0; red[8 + wave] = cp1; }
+        __syncthreads();
+        if (tid == 0) {
+            float p0 = 0.f, p1 = 0.f;
+            for (int w = 0; w < MF_THREADS / 64; ++w) { p0 += red[w]; p1 += red[8 + w]; }
+            StepState ns = *st;
+            ctrl_after_step(&ns, p0, p1, a.n_total);
+            if (blockIdx.x == 0) *a.st_out = ns;
+            sc[0] = __int_as_float(ns.cur); sc[1] = ns.h; sc[2] = ns.abstol; sc[3] = ns.reltol;
+            sc[4] = __int_as_float(ns.done);
+        }
+        __syncthreads();
+        cur = __float_as_int(sc[0]); hstep = sc[1]; abstol = sc[2]; reltol = sc[3];
+        if (__float_as_int(sc[4])) return;
+        __syncthreads();
+    } else if (st) {
+        cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol;
+    }
+
+    constexpr int TNB = MF_NB / 2;
+    const int team = wave >> 2, fg = (wave + 2 * team) & 3;
+    const int s = lane & 15, q = lane >> 4;
+    const int row = TNB * team + s;
+    const bool own = fg < NT0;                       // owns z-row tile fg
+    const bool sown = fg == 0 && q == 0;             // owns the scalar rows of sample s
+    const int r0 = 16 * fg + 4 * q;
+    const int nv = own ? n_in - r0 : 0;
+    const float* Uin = mode == 0 ? a.u : a.U[cur];
+    const float* K1in = mode == 0 ? nullptr : a.K1[cur];
+    float errsum = 0.f, badcnt = 0.f;
+    float* scr = lds + FS::scr_off() + team * (4 * NT0 * 256);
+    float* scr2 = lds + FS::scr2_off() + team * (4 * NT0 * 256);
+    float* red = lds + FS::red_off();
+    __syncthreads();
+
+    const int ntile = (a.B + MF_NB - 1) / MF_NB;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int b0 = tile * MF_NB + TNB * team;
+        const int nvalid = max(0, min(TNB, a.B - b0));
+        const bool live = s < nvalid;
+        const size_t gcol = (size_t)(b0 + s) * D;
+        // eps of this lane's sample, all NT0 row tiles, accumulator layout
+        f32x4 ev[NT0];
+#pragma unroll
+        for (int t = 0; t < NT0; ++t)
+            ev[t] = live ? ld4(a.eps + (size_t)(b0 + s) * n_in + 16 * t + 4 * q, n_in - (16 * t + 4 * q))
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 uz = {0.f, 0.f, 0.f, 0.f}, kz[7], us = uz, ks[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { kz[i] = uz; ks[i] = uz; }
+        if (live) {
+            if (own) uz = ld4(Uin + gcol + r0, nv);
+            if (sown) us = ld4(Uin + gcol + n_in, 3);
+            if (K1in) {
+                if (own) kz[0] = ld4(K1in + gcol + r0, nv);
+                if (sown) ks[0] = ld4(K1in + gcol + n_in, 3);
+            }
+        }
+        const int nstage = mode == 2 ? 6 : 1;
+        f32x4 un = uz;
+        auto put_stage = [&](int stg) {
+            if (own) {
+                if (mode == 1) un = uz + hstep * kz[0];
+                else if (mode == 2) un = uz + hstep * stage_acc4_rt(stg, kz);
+                *(f32x4*)(lds + FS::x_off(0) + row * FS::SX(0) + r0) = un;
+            }
+        };
+        // sum of the eJ partials of the previous evaluation -> trace / norm partials in RED
+        auto reduce_eJ = [&]() {
+#pragma unroll
+            for (int kt = 0; kt < NT0; ++kt) {
+                if (fg == 3 - kt) {
+                    constexpr int NW = FS::P(1) / 16 < 4 ? FS::P(1) / 16 : 4;
+                    f32x4 e = *(const f32x4*)(scr2 + ((0 * NT0 + kt) * 16 + s) * 16 + 4 * q);
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) e += *(const f32x4*)(scr2 + ((w * NT0 + kt) * 16 + s) * 16 + 4 * q);
+                    float ld = -(e.x * ev[kt].x + e.y * ev[kt].y + e.z * ev[kt].z + e.w * ev[kt].w);
+                    float n2 = e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
+                    ld = quad_sum(ld);
+                    n2 = quad_sum(n2);
+                    if (q == 0) { red[(NT0 + kt) * MF_NB + row] = ld; red[(2 * NT0 + kt) * MF_NB + row] = n2; }
+                }
+            }
+        };
+        float e2s = 0.f;                       // scalar owner: |zdot|^2 of the previous evaluation
+        auto read_E = [&]() { e2s = 0.f; for (int t = 0; t < NT0; ++t) e2s += red[t * MF_NB + row]; };
+        auto read_ln = [&]() {
+            float ld = 0.f, n2 = 0.f;
+            for (int t = 0; t < NT0; ++t) { ld += red[(NT0 + t) * MF_NB + row]; n2 += red[(2 * NT0 + t) * MF_NB + row]; }
+            return f32x4{ld, ly.norm_z() ? __builtin_sqrtf(e2s) : 0.f, ly.norm_j() ? __builtin_sqrtf(n2) : 0.f, 0.f};
+        };
+        put_stage(1);
+        __syncthreads();
+
+        // ------------------------------------------------------------------------------------------
+        // Ping-pong schedule.  Every phase of an evaluation is cut into a G sub-step (LDS operand
+        // reads + the MFMA chain) and an E sub-step (activation epilogue, LDS writes, the small
+        // split-K products).  Team 1 runs one sub-step behind team 0, so in every barrier
+        // interval one team of a SIMD's two waves is in a G sub-step and the other in an E
+        // sub-step: the matrix pipe sees one MFMA chain at a time, back to back, instead of two
+        // chains together followed by two epilogues together.
+        //   sub-steps: fwd layer l: G 2l, E 2l+1 (l = 0..L-2) | last layer reverse from registers:
+        //   G 2(L-1), E 2(L-1)+1 | reverse layers l = L-2..1: G, E
+        // ------------------------------------------------------------------------------------------
+        constexpr int NSUB = 4 * (L - 1);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;     // carried from a G sub-step to its E sub-step
+        f32x4 pa0[NT0], pa1[NT0], ra0[NT0], ra1[NT0], ea0[NT0], ea1[NT0];
+#pragma unroll
+        for (int t = 0; t < NT0; ++t) { pa0[t] = acc0; pa1[t] = acc0; ra0[t] = acc0; ra1[t] = acc0; ea0[t] = acc0; ea1[t] = acc0; }
+        int stg = 1;
+
+        // ---- forward hidden layer l: G ----
+        auto fwdG = [&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            constexpr int ntiles = FS::P(l + 1) / 16, U = FS::P(l) / 16, SW = FS::SW(l);
+            static_assert(ntiles <= 8, "one pass per layer");
+            if (l == 0 && stg > 1) {
+                if (sown) read_E();
+                reduce_eJ();
+            }
+            const float* xb = lds + FS::x_off(l) + row * FS::SX(l) + 4 * q;
+            const float* W = lds + FS::w_off(l);
+            const int t0 = fg, t1 = fg + 4;
+            const bool has = t0 < ntiles, two = t1 < ntiles;
+            acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0;
+            if (l == L - 2 && has) {
+                constexpr int SWL = FS::SW(L - 1);
+                const float* WL = lds + FS::w_off(L - 1);
+#pragma unroll
+                for (int ot = 0; ot < NT0; ++ot) {
+                    pa0[ot] = *(const f32x4*)(WL + (16 * ot + s) * SWL + 16 * t0 + 4 * q);
+                    if (two) pa1[ot] = *(const f32x4*)(WL + (16 * ot + s) * SWL + 16 * t1 + 4 * q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (has) {
+                const float* wa0 = W + (16 * t0 + s) * SW + 4 * q;
+                const float* wa1 = W + (16 * t1 + s) * SW + 4 * q;
+                if (two) fwd_body<U, 2>(acc0, acc1, xb, wa0, wa1);
+                else { fwd_body<U, 1>(acc0, acc1, xb, wa0, wa1); acc0 += acc1; }
+            }
+        };
+        // ---- forward hidden layer l: E ----
+        auto fwdE = [&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            constexpr int ntiles = FS::P(l + 1) / 16;
+            if (l == 0 && stg > 1 && sown) set_k(ks, stg - 1, read_ln());
+            const int t0 = fg, t1 = fg + 4;
+            const bool has = t0 < ntiles, two = t1 < ntiles;
+            f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0, dd_;
+            if (has) {
+                const f32x4 bv0 = *(const f32x4*)(lds + FS::b_off(l) + 16 * t0 + 4 * q);
+                act4(FS::act(l), acc0 + bv0, h0, dd_);
+                *(f32x4*)(lds + FS::x_off(l + 1) + row * FS::SX(l + 1) + 16 * t0 + 4 * q) = h0;
+                if (two) {
+                    const f32x4 bv1 = *(const f32x4*)(lds + FS::b_off(l) + 16 * t1 + 4 * q);
+                    act4(FS::act(l), acc1 + bv1, h1, dd_);
+                    *(f32x4*)(lds + FS::x_off(l + 1) + row * FS::SX(l + 1) + 16 * t1 + 4 * q) = h1;
+                }
+            }
+            if (l == L - 2) {
+                if (has) {
+                    f32x4 pz[NT0];
+#pragma unroll
+                    for (int ot = 0; ot < NT0; ++ot) pz[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int ot = 0; ot < NT0; ++ot)
+                            pz[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa0[ot][c], h0[c], pz[ot], 0, 0, 0);
+                    if (two) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int ot = 0; ot < NT0; ++ot)
+                                pz[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa1[ot][c], h1[c], pz[ot], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int ot = 0; ot < NT0; ++ot)
+                        *(f32x4*)(scr + ((fg * NT0 + ot) * 16 + s) * 16 + 4 * q) = pz[ot];
+                }
+                constexpr int SWr = FS::SW(L - 1);
+                const float* Wr = lds + FS::w_off(L - 1);
+                constexpr int ntr = FS::P(L - 1) / 16;
+                if (fg < ntr) {
+#pragma unroll
+                    for (int u = 0; u < NT0; ++u) {
+                        const float* p0 = Wr + (16 * u + 4 * q) * SWr + 16 * fg + s;
+                        ra0[u] = f32x4{p0[0], p0[SWr], p0[2 * SWr], p0[3 * SWr]};
+                        if (fg + 4 < ntr) {
+                            const float* p1 = p0 + 64;
+                            ra1[u] = f32x4{p1[0], p1[SWr], p1[2 * SWr], p1[3 * SWr]};
+                        }
+                    }
+                }
+            }
+        };
+        // ---- reverse layer l (input side P(l) rows): prefetch of the eJ-partial fragments ----
+        auto load_ea = [&](int t0, int t1, bool two) {
+            constexpr int SW0 = FS::SW(0);
+            const float* W0 = lds + FS::w_off(0);
+#pragma unroll
+            for (int kt = 0; kt < NT0; ++kt) {
+                const float* p0 = W0 + (16 * t0 + 4 * q) * SW0 + 16 * kt + s;
+                ea0[kt] = f32x4{p0[0], p0[SW0], p0[2 * SW0], p0[3 * SW0]};
+                if (two) {
+                    const float* p1 = W0 + (16 * t1 + 4 * q) * SW0 + 16 * kt + s;
+                    ea1[kt] = f32x4{p1[0], p1[SW0], p1[2 * SW0], p1[3 * SW0]};
+                }
+            }
+        };
+        // ---- middle G: zdot, g_L, next stage state; reverse of the last layer from registers ----
+        auto midG = [&]() {
+            constexpr int NW = FS::P(L - 1) / 16 < 4 ? FS::P(L - 1) / 16 : 4;
+            constexpr int l = L - 1;
+            constexpr int ntiles = FS::P(l) / 16;
+            const int t0 = fg, t1 = fg + 4;
+            const bool has = t0 < ntiles, two = t1 < ntiles;
+            f32x4 zp[NT0][NW], bvv[NT0], gL[NT0];
+#pragma unroll
+            for (int ot = 0; ot < NT0; ++ot) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) zp[ot][w] = *(const f32x4*)(scr + ((w * NT0 + ot) * 16 + s) * 16 + 4 * q);
+                bvv[ot] = *(const f32x4*)(lds + FS::b_off(L - 1) + 16 * ot + 4 * q);
+            }
+            if (l == 1 && has) load_ea(t0, t1, two);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ot = 0; ot < NT0; ++ot) {
+                f32x4 z = zp[ot][0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) z += zp[ot][w];
+                f32x4 zd, dd;
+                act4(FS::act(L - 1), z + bvv[ot], zd, dd);
+                gL[ot] = ev[ot] * dd;
+                if (fg == ot) {
+                    const int rr = 16 * ot + 4 * q;
+                    zd = f32x4{rr + 0 < n_in ? zd.x : 0.f, rr + 1 < n_in ? zd.y : 0.f,
+                               rr + 2 < n_in ? zd.z : 0.f, rr + 3 < n_in ? zd.w : 0.f};
+                    const float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
+                    if (q == 0) red[ot * MF_NB + row] = e2;
+                    if (mode == 2) { set_k(kz, stg, zd); if (stg < nstage) put_stage(stg + 1); }
+                    else kz[1] = zd;
+                }
+            }
+            acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0;
+            if (has) {
+#pragma unroll
+                for (int u = 0; u < NT0; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[u][c], gL[u][c], acc0, 0, 0, 0);
+                        if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[u][c], gL[u][c], acc1, 0, 0, 0);
+                    }
+            }
+        };
+        // ---- reverse layer l: G (B operand from LDS) ----
+        auto bwdG = [&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            constexpr int ntiles = FS::P(l) / 16, SW = FS::SW(l), U = FS::P(l + 1) / 16;
+            static_assert(ntiles <= 8, "one pass per layer");
+            const float* W = lds + FS::w_off(l);
+            const int t0 = fg, t1 = fg + 4;
+            const bool has = t0 < ntiles, two = t1 < ntiles;
+            acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0;
+            if (l == 1 && has) { load_ea(t0, t1, two); __builtin_amdgcn_sched_barrier(0); }
+            if (has) {
+                const float* wc0 = W + (4 * q) * SW + 16 * t0 + s;
+                const float* wc1 = W + (4 * q) * SW + 16 * t1 + s;
+                const float* gb = lds + FS::x_off(l + 1) + row * FS::SX(l + 1) + 4 * q;
+                if (two) bwd_body<U, 2>(acc0, acc1, SW, gb, wc0, wc1);
+                else { bwd_body<U, 1>(acc0, acc1, SW, gb, wc0, wc1); acc0 += acc1; }
+            }
+        };
+        // ---- reverse layer l: E (scale by sigma'(h_l); layer 1 also forms the eJ partial) ----
+        auto bwdE = [&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            constexpr int ntiles = FS::P(l) / 16;
+            const int t0 = fg, t1 = fg + 4;
+            const bool has = t0 < ntiles, two = t1 < ntiles;
+            if (has) {
+                f32x4 g0, g1 = {0.f, 0.f, 0.f, 0.f};
+                float* o0 = lds + FS::x_off(l) + row * FS::SX(l) + 16 * t0 + 4 * q;
+                const f32x4 hv0 = *(const f32x4*)o0;
+                g0 = f32x4{acc0.x * d_from_h(FS::act(l - 1), hv0.x), acc0.y * d_from_h(FS::act(l - 1), hv0.y),
+                           acc0.z * d_from_h(FS::act(l - 1), hv0.z), acc0.w * d_from_h(FS::act(l - 1), hv0.w)};
+                if (l > 1) *(f32x4*)o0 = g0;
+                if (two) {
+                    float* o1 = lds + FS::x_off(l) + row * FS::SX(l) + 16 * t1 + 4 * q;
+                    const f32x4 hv1 = *(const f32x4*)o1;
+                    g1 = f32x4{acc1.x * d_from_h(FS::act(l - 1), hv1.x), acc1.y * d_from_h(FS::act(l - 1), hv1.y),
+                               acc1.z * d_from_h(FS::act(l - 1), hv1.z), acc1.w * d_from_h(FS::act(l - 1), hv1.w)};
+                    if (l > 1) *(f32x4*)o1 = g1;
+                }
+                if constexpr (l == 1) {
+                    f32x4 pe[NT0];
+#pragma unroll
+                    for (int kt = 0; kt < NT0; ++kt) pe[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int kt = 0; kt < NT0; ++kt)
+                            pe[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0[kt][c], g0[c], pe[kt], 0, 0, 0);
+                    if (two) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int kt = 0; kt < NT0; ++kt)
+                                pe[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1[kt][c], g1[c], pe[kt], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < NT0; ++kt)
+                        *(f32x4*)(scr2 + ((fg * NT0 + kt) * 16 + s) * 16 + 4 * q) = pe[kt];
+                }
+            }
+        };
+        // sub-step dispatch (compile-time layer indices behind a wave-uniform switch)
+        auto run_sub = [&](int sub) {
+            static_assert(L == 2 || L == 3 || L == 4, "sub-step table written for 2..4 layers");
+            if constexpr (L == 2) {
+                switch (sub) {
+                    case 0: fwdG(std::integral_constant<int, 0>{}); break;
+                    case 1: fwdE(std::integral_constant<int, 0>{}); break;
+                    case 2: midG(); break;
+                    default: bwdE(std::integral_constant<int, 1>{}); break;
+                }
+            } else if constexpr (L == 3) {
+                switch (sub) {
+                    case 0: fwdG(std::integral_constant<int, 0>{}); break;
+                    case 1: fwdE(std::integral_constant<int, 0>{}); break;
+                    case 2: fwdG(std::integral_constant<int, 1>{}); break;
+                    case 3: fwdE(std::integral_constant<int, 1>{}); break;
+                    case 4: midG(); break;
+                    case 5: bwdE(std::integral_constant<int, 2>{}); break;
+                    case 6: bwdG(std::integral_constant<int, 1>{}); break;
+                    default: bwdE(std::integral_constant<int, 1>{}); break;
+                }
+            } else {
+                switch (sub) {
+                    case 0: fwdG(std::integral_constant<int, 0>{}); break;
+                    case 1: fwdE(std::integral_constant<int, 0>{}); break;
+                    case 2: fwdG(std::integral_constant<int, 1>{}); break;
+                    case 3: fwdE(std::integral_constant<int, 1>{}); break;
+                    case 4: fwdG(std::integral_constant<int, 2>{}); break;
+                    case 5: fwdE(std::integral_constant<int, 2>{}); break;
+                    case 6: midG(); break;
+                    case 7: bwdE(std::integral_constant<int, 3>{}); break;
+                    case 8: bwdG(std::integral_constant<int, 2>{}); break;
+                    case 9: bwdE(std::integral_constant<int, 2>{}); break;
+                    case 10: bwdG(std::integral_constant<int, 1>{}); break;
+                    default: bwdE(std::integral_constant<int, 1>{}); break;
+                }
+            }
+        };
+        const int total = NSUB * nstage;
+        for (int i = 0; i <= total; ++i) {
+            const int j = i - team;                       // team 1 runs one sub-step behind
+            if (j >= 0 && j < total) {
+                stg = j / NSUB + 1;
+                run_sub(j - (stg - 1) * NSUB);
+            }
+            __syncthreads();
+        }
+        // last evaluation: eJ partials -> RED, then the scalar rows
+        if (sown) read_E();
+        reduce_eJ();
+        __syncthreads();
+        if (sown) {
+            const f32x4 v = read_ln();
+            if (mode == 2) ks[6] = v; else ks[1] = v;
+        }
+        // ---- outputs ----
+        if (live) {
+            if (mode == 0 || mode == 1) {
+                float* out = (mode == 0 ? a.du : a.Ks0) + gcol;
+                if (own) st4(out + r0, kz[1], nv);
+                if (sown) st4(out + n_in, ks[1], 3);
+            } else {
+                float* Un = a.U[1 - cur] + gcol;
+                float* K7 = a.K1[1 - cur] + gcol;
+                if (own) {
+                    st4(Un + r0, un, nv); st4(K7 + r0, kz[6], nv);
+                    err_acc(errsum, badcnt, kz, uz, un, hstep, abstol, reltol, nv);
+                }
+                if (sown) {
+                    const f32x4 uns = us + hstep * stage_acc4<6>(ks);
+                    st4(Un + n_in, uns, 3); st4(K7 + n_in, ks[6], 3);
+                    err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
+                }
+            }
+        }
+        __syncthreads();      // RED / scratch reads of this tile precede the next tile's writes
+    }
+    if (mode == 2) {
+        for (int off = 32; off > 0; off >>= 1) {
+            errsum += __shfl_down(errsum, off, 64);
+            badcnt += __shfl_down(badcnt, off, 64);
+        }
+        if (lane == 0) { red[wave] = errsum; red[8 + wave] = badcnt; }
+        __syncthreads();
+        if (tid == 0) {
+            float e = 0.f, b = 0.f;
+            for (int w = 0; w < MF_THREADS / 64; ++w) { e += red[w]; b += red[8 + w]; }
+            a.partials[2 * blockIdx.x] = e;
+            a.partials[2 * blockIdx.x + 1] = b;
+        }
+    }
+}
+
+
 // ---- weight image packing -------------------------------------------------------------------
 __global__ void k_pack_image(MfmaLayout ly, NetDesc nd, const float* __restrict__ P,
                              float* __restrict__ img) {
@@ -1314,9 +1768,12 @@ __global__ void k_pack_image(MfmaLayout ly, NetDesc nd, const float* __restrict_
 
 // ---- host side ----------------------------------------------------------------------------
 // static instantiations: (activation, padded sizes...) -> kernel.  Variant ids >= 2.
-using LyCfg3 = FsLayout<CNF_ACT_TANH, 32, 128, 128, 32>;   // BASELINE configs 3/4
-using LyCfg2 = FsLayout<CNF_ACT_TANH, 16, 48, 16>;         // BASELINE config 2
-using LyCfg1 = FsLayout<CNF_ACT_TANH, 16, 16, 16>;         // BASELINE config 1 (2->6->2 padded)
+using LyCfg3 = StLayout<CNF_ACT_TANH, 32, 128, 128, 32>;   // BASELINE configs 3/4
+using LyCfg2 = StLayout<CNF_ACT_TANH, 16, 48, 16>;         // BASELINE config 2
+using LyCfg1 = StLayout<CNF_ACT_TANH, 16, 16, 16>;         // BASELINE config 1 (2->6->2 padded)
+using FsCfg3 = FsLayout<CNF_ACT_TANH, 32, 128, 128, 32>;   // same shapes, fused-phase layout
+using FsCfg2 = FsLayout<CNF_ACT_TANH, 16, 48, 16>;
+using FsCfg1 = FsLayout<CNF_ACT_TANH, 16, 16, 16>;
 
 template <class LY>
 static bool matches(const MfmaLayout& m) {
@@ -1325,7 +1782,8 @@ static bool matches(const MfmaLayout& m) {
         if (m.P[l] != LY::P(l)) return false;
     for (int l = 0; l < m.L; ++l)
         if (m.acts[l] != LY::act(l)) return false;
-    return m.img_floats == LY::img_floats() && (size_t)LY::total_floats() * sizeof(float) <= MF_LDS_BYTES;
+    return m.img_floats == LY::img_floats() && m.total_floats == LY::total_floats() &&
+           m.red_off == LY::red_off() && m.x_off[m.L] == LY::x_off(LY::kL);
 }
 
 void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
@@ -1368,6 +1826,10 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     if (ly.P[0] > 128) return;                                             // state tiles fg, fg+4 only
     if (nd.jvp) return;                                                    // forward-mode sweep: generic path
     p.variant = 1;
+    // experimental schedules for the static shapes (kept for A/B measurements)
+    const char* sch = getenv("CNF_MFMA_SCHEDULE");
+    p.schedule = sch ? atoi(sch) : 0;
+    if (p.schedule < 0 || p.schedule > 2) p.schedule = 0;
     if (matches<LyCfg3>(ly)) p.variant = 2;
     else if (matches<LyCfg2>(ly)) p.variant = 3;
     else if (matches<LyCfg1>(ly)) p.variant = 4;
@@ -1392,8 +1854,11 @@ static hipError_t set_attr_fused() {
     hipError_t e = hipFuncSetAttribute((const void*)k_fused<FS, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        MF_LDS_BYTES);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_fused<FS, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               MF_LDS_BYTES);
+    e = hipFuncSetAttribute((const void*)k_fused<FS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_pp<FS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_pp<FS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
 }
 
 cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params, hipStream_t s) {
@@ -1401,9 +1866,12 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
     if (!p.d_img) {
         if (hipMalloc(&p.d_img, (size_t)p.ly.img_floats * sizeof(float)) != hipSuccess) return CNF_ERR_HIP;
         hipError_t e = set_attr<RtLayout>();
-        if (e == hipSuccess) e = set_attr_fused<LyCfg3>();
-        if (e == hipSuccess) e = set_attr_fused<LyCfg2>();
-        if (e == hipSuccess) e = set_attr_fused<LyCfg1>();
+        if (e == hipSuccess) e = set_attr<LyCfg3>();
+        if (e == hipSuccess) e = set_attr<LyCfg2>();
+        if (e == hipSuccess) e = set_attr<LyCfg1>();
+        if (e == hipSuccess) e = set_attr_fused<FsCfg3>();
+        if (e == hipSuccess) e = set_attr_fused<FsCfg2>();
+        if (e == hipSuccess) e = set_attr_fused<FsCfg1>();
         if (e != hipSuccess) return CNF_ERR_HIP;
     }
     hipLaunchKernelGGL(k_pack_image, dim3((p.ly.img_floats + 255) / 256), dim3(256), 0, s, p.ly, nd,
@@ -1425,14 +1893,32 @@ static void launch_static(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipSt
     LY ly;
     ly.n_in_ = p.ly.n_in; ly.norm_z_ = p.ly.norm_z; ly.norm_j_ = p.ly.norm_j;
     const size_t shm = (size_t)LY::total_floats() * sizeof(float);
-    if (a.mode == 2) hipLaunchKernelGGL((k_fused<LY, true>), grid, dim3(MF_THREADS), shm, s, ly, a);
-    else hipLaunchKernelGGL((k_fused<LY, false>), grid, dim3(MF_THREADS), shm, s, ly, a);
+    if (a.mode == 2) hipLaunchKernelGGL((k_mfma<LY, true>), grid, dim3(MF_THREADS), shm, s, ly, a);
+    else hipLaunchKernelGGL((k_mfma<LY, false>), grid, dim3(MF_THREADS), shm, s, ly, a);
+}
+template <class FS>
+static void launch_fused(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStream_t s) {
+    FS ly;
+    ly.n_in_ = p.ly.n_in; ly.norm_z_ = p.ly.norm_z; ly.norm_j_ = p.ly.norm_j;
+    const size_t shm = (size_t)FS::total_floats() * sizeof(float);
+    if (p.schedule == 2) {     // fused narrow layers + ping-pong teams
+        if (a.mode == 2) hipLaunchKernelGGL((k_pp<FS, true>), grid, dim3(MF_THREADS), shm, s, ly, a);
+        else hipLaunchKernelGGL((k_pp<FS, false>), grid, dim3(MF_THREADS), shm, s, ly, a);
+    } else {                   // fused narrow layers, both teams in the same phase
+        if (a.mode == 2) hipLaunchKernelGGL((k_fused<FS, true>), grid, dim3(MF_THREADS), shm, s, ly, a);
+        else hipLaunchKernelGGL((k_fused<FS, false>), grid, dim3(MF_THREADS), shm, s, ly, a);
+    }
 }
 
 static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a, hipStream_t s) {
     const dim3 grid(mfma_grid_for(a.B)), block(MF_THREADS);
     const size_t shm = (size_t)p.ly.total_floats * sizeof(float);
-    if (p.variant == 2) launch_static<LyCfg3>(p, a, grid, s);
+    if (p.variant >= 2 && p.schedule > 0) {
+        if (p.variant == 2) launch_fused<FsCfg3>(p, a, grid, s);
+        else if (p.variant == 3) launch_fused<FsCfg2>(p, a, grid, s);
+        else launch_fused<FsCfg1>(p, a, grid, s);
+    }
+    else if (p.variant == 2) launch_static<LyCfg3>(p, a, grid, s);
     else if (p.variant == 3) launch_static<LyCfg2>(p, a, grid, s);
     else if (p.variant == 4) launch_static<LyCfg1>(p, a, grid, s);
     else {

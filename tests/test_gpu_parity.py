@@ -343,3 +343,18 @@ def test_rhs_work_model():
     M = 32 * 128 + 128 * 128 + 128 * 32
     P = M + 128 + 128 + 32
     assert fl.value == B * (4 * M + 6 * 32) and by.value == 4 * B * (32 + 32 + 35) + 4 * P
+
+
+@pytest.mark.parametrize("schedule", ["1", "2"])
+def test_experimental_mfma_schedules_keep_parity(schedule, monkeypatch):
+    """CNF_MFMA_SCHEDULE=1 (narrow layers fused as split-K partials) and =2 (that plus the
+    ping-pong team schedule) are alternative orderings of the same arithmetic."""
+    monkeypatch.setenv("CNF_MFMA_SCHEDULE", schedule)
+    for name in ("cfg3_headline_small", "cfg2_regression", "cfg1_readme"):
+        g, cfg = load_golden(name)
+        icnf = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=float(g["dt"])))
+        du = cnf.augmented_f(g["u_train"], g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, g["eps"])
+        assert_parity(du, g["du_train_vjp"], f"{name} schedule {schedule} rhs")
+        logpx, _ = cnf.inference(icnf, cnf.TrainMode(), g["xs"], g["flat"], {}, eps=g["eps"])
+        assert_parity(logpx, g["logpx_train_vjp"], f"{name} schedule {schedule} logpx")
+        icnf.close()
