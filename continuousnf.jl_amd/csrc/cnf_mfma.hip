@@ -73,6 +73,9 @@ struct RtLayout {
     __device__ __forceinline__ int b_off(int l) const { return m.b_off[l]; }
     __device__ __forceinline__ int x_off(int l) const { return m.x_off[l]; }
     __device__ __forceinline__ int img_floats() const { return m.img_floats; }
+    __device__ __forceinline__ bool wlds() const { return m.wlds != 0; }
+    __device__ __forceinline__ int SWT(int l) const { return m.SWT[l]; }
+    __device__ __forceinline__ int wt_off(int l) const { return m.wt_off[l]; }
     __device__ __forceinline__ int eps_off() const { return m.eps_off; }
     __device__ __forceinline__ int du_off() const { return m.du_off; }
     __device__ __forceinline__ int red_off() const { return m.red_off; }
@@ -84,8 +87,8 @@ struct RtLayout {
 };
 
 // compile-time layout: same formulas as mfma_plan_init, evaluated by the compiler
-template <int ACT, int... PD>
-struct StLayout {
+template <bool WLDS, int ACT, int... PD>
+struct StLayoutX {
     static constexpr bool kStatic = true;
     static constexpr int kL = sizeof...(PD) - 1;
     int n_in_, norm_z_, norm_j_;
@@ -105,9 +108,18 @@ struct StLayout {
         for (int i = 0; i < l; ++i) off += pd(i + 1);
         return off;
     }
-    __host__ __device__ static constexpr int img_floats() { return (b_off(kL) + 3) & ~3; }
+    __host__ __device__ static constexpr bool wlds() { return WLDS; }
+    __host__ __device__ static constexpr int SWT(int l) { return sw_of(pd(l + 1)); }
+    __host__ __device__ static constexpr int wt_off(int l) {            // transposed images (WLDS == false)
+        int off = (b_off(kL) + 3) & ~3;
+        for (int i = 0; i < l; ++i) off += pd(i) * sw_of(pd(i + 1));
+        return off;
+    }
+    __host__ __device__ static constexpr int img_floats() {
+        return WLDS ? (b_off(kL) + 3) & ~3 : (wt_off(kL) + 3) & ~3;
+    }
     __host__ __device__ static constexpr int x_off(int l) {
-        int off = img_floats();
+        int off = WLDS ? img_floats() : 0;
         for (int i = 0; i < l; ++i) off += MF_NB * sx_of(pd(i));
         return off;
     }
@@ -123,6 +135,9 @@ struct StLayout {
     __device__ __forceinline__ int norm_z() const { return norm_z_; }
     __device__ __forceinline__ int norm_j() const { return norm_j_; }
 };
+
+template <int ACT, int... PD>
+using StLayout = StLayoutX<true, ACT, PD...>;
 
 // layer loops: unrolled with compile-time indices for static layouts, plain loops otherwise
 template <int I, int N, class F>
@@ -259,18 +274,16 @@ __device__ __forceinline__ void mfma_block(f32x4& acc0, f32x4& acc1, const f32x4
     }
 }
 // Forward:  xb = region_in + (16*sw + s)*SX + 4q;  wa = W + (16*ot + s)*SW + 4q
-template <int NU, int NTL>
+// AHEAD = how many k-blocks the operand requests run ahead of the MFMAs: 2 for weights in
+// LDS, 4 for weights read straight from HBM/L2 (longer latency).
+template <int NU, int NTL, int AHEAD = 2>
 __device__ __forceinline__ void fwd_body(f32x4& acc0, f32x4& acc1, const float* xb,
                                          const float* wa0, const float* wa1) {
-#ifdef MF_ABL_NOLOAD
-    { f32x4 c = {1.f, 2.f, 3.f, 4.f};
-      for (int u = 0; u < NU; ++u) mfma_block<NTL>(acc0, acc1, c, c, c);
-      return; }
-#endif
-    f32x4 b[3], a0[3], a1[3];   // ring of 3: a prefetch never lands in registers that the
-                                // MFMAs issued just before it still have to read
+    constexpr int R = AHEAD + 1;   // ring: a prefetch never lands in registers that the
+                                   // MFMAs issued just before it still have to read
+    f32x4 b[R], a0[R], a1[R];
 #pragma unroll
-    for (int u = 0; u < 2 && u < NU; ++u) {
+    for (int u = 0; u < AHEAD && u < NU; ++u) {
         b[u] = *(const f32x4*)(xb + 16 * u);
         a0[u] = *(const f32x4*)(wa0 + 16 * u);
         if (NTL == 2) a1[u] = *(const f32x4*)(wa1 + 16 * u);
@@ -278,12 +291,12 @@ __device__ __forceinline__ void fwd_body(f32x4& acc0, f32x4& acc1, const float* 
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         __builtin_amdgcn_sched_barrier(0);
-        mfma_block<NTL>(acc0, acc1, b[u % 3], a0[u % 3], a1[u % 3]);
+        mfma_block<NTL>(acc0, acc1, b[u % R], a0[u % R], a1[u % R]);
         __builtin_amdgcn_sched_barrier(0);
-        if (u + 2 < NU) {
-            b[(u + 2) % 3] = *(const f32x4*)(xb + 16 * (u + 2));
-            a0[(u + 2) % 3] = *(const f32x4*)(wa0 + 16 * (u + 2));
-            if (NTL == 2) a1[(u + 2) % 3] = *(const f32x4*)(wa1 + 16 * (u + 2));
+        if (u + AHEAD < NU) {
+            b[(u + AHEAD) % R] = *(const f32x4*)(xb + 16 * (u + AHEAD));
+            a0[(u + AHEAD) % R] = *(const f32x4*)(wa0 + 16 * (u + AHEAD));
+            if (NTL == 2) a1[(u + AHEAD) % R] = *(const f32x4*)(wa1 + 16 * (u + AHEAD));
         }
     }
 }
@@ -326,22 +339,22 @@ __device__ __forceinline__ void bwd_body(f32x4& acc0, f32x4& acc1, int SW, const
 }
 
 // run-time k-block count: blocks of 8, then an exact tail
-template <int NTL>
+template <int NTL, int AHEAD = 2>
 __device__ __forceinline__ void gemm_fwd(f32x4& acc0, f32x4& acc1, int U, const float* xb,
                                          const float* wa0, const float* wa1) {
     while (U > 8) {
-        fwd_body<8, NTL>(acc0, acc1, xb, wa0, wa1);
+        fwd_body<8, NTL, AHEAD>(acc0, acc1, xb, wa0, wa1);
         xb += 128; wa0 += 128; wa1 += 128; U -= 8;
     }
     switch (U) {
-        case 1: fwd_body<1, NTL>(acc0, acc1, xb, wa0, wa1); break;
-        case 2: fwd_body<2, NTL>(acc0, acc1, xb, wa0, wa1); break;
-        case 3: fwd_body<3, NTL>(acc0, acc1, xb, wa0, wa1); break;
-        case 4: fwd_body<4, NTL>(acc0, acc1, xb, wa0, wa1); break;
-        case 5: fwd_body<5, NTL>(acc0, acc1, xb, wa0, wa1); break;
-        case 6: fwd_body<6, NTL>(acc0, acc1, xb, wa0, wa1); break;
-        case 7: fwd_body<7, NTL>(acc0, acc1, xb, wa0, wa1); break;
-        default: fwd_body<8, NTL>(acc0, acc1, xb, wa0, wa1); break;
+        case 1: fwd_body<1, NTL, AHEAD>(acc0, acc1, xb, wa0, wa1); break;
+        case 2: fwd_body<2, NTL, AHEAD>(acc0, acc1, xb, wa0, wa1); break;
+        case 3: fwd_body<3, NTL, AHEAD>(acc0, acc1, xb, wa0, wa1); break;
+        case 4: fwd_body<4, NTL, AHEAD>(acc0, acc1, xb, wa0, wa1); break;
+        case 5: fwd_body<5, NTL, AHEAD>(acc0, acc1, xb, wa0, wa1); break;
+        case 6: fwd_body<6, NTL, AHEAD>(acc0, acc1, xb, wa0, wa1); break;
+        case 7: fwd_body<7, NTL, AHEAD>(acc0, acc1, xb, wa0, wa1); break;
+        default: fwd_body<8, NTL, AHEAD>(acc0, acc1, xb, wa0, wa1); break;
     }
 }
 template <int NTL>
@@ -402,10 +415,10 @@ __device__ __forceinline__ float quad_sum(float v) {     // sum over the 4 lanes
 // those rows of the Runge-Kutta state), stores g_L = eps .* sigma'_L to region_L and the
 // |zdot|^2 partial of its 16 rows to RED[0].
 template <class LY>
-__device__ __forceinline__ void fwd_epilogue(const LY& ly, float* lds, int l, bool last, int ot, f32x4 acc,
-                                             int row, int q, f32x4& zd) {
+__device__ __forceinline__ void fwd_epilogue(const LY& ly, float* lds, const float* wimg, int l, bool last, int ot,
+                                             f32x4 acc, int row, int q, f32x4& zd) {
     const int r0 = 16 * ot + 4 * q;
-    const f32x4 bv = *(const f32x4*)(lds + ly.b_off(l) + r0);
+    const f32x4 bv = *(const f32x4*)(wimg + ly.b_off(l) + r0);
     const int act = ly.act(l);
     float h0, h1, h2, h3, d0, d1, d2, d3;
     act_fast(act, acc.x + bv.x, h0, d0);
@@ -466,8 +479,11 @@ __device__ __forceinline__ void bwd_epilogue(const LY& ly, float* lds, int l, in
 #define STAMP_PASS
 #endif
 template <class LY, class F>
-__device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int wave, unsigned* bar,
-                                         unsigned& gen, f32x4& zd0, f32x4& zd1, F&& after_zdot STAMP_ARGS) {
+__device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* wimg, int lane, int wave,
+                                         unsigned* bar, unsigned& gen, f32x4& zd0, f32x4& zd1,
+                                         F&& after_zdot STAMP_ARGS) {
+    // wimg: where the weight image is read from -- the LDS copy, or (networks too large for
+    // LDS) the HBM/L2-resident image, with a row-major transposed copy for the reverse sweep
     // team = column tile; the feature-group index is rotated by 2 for team 1 so that the
     // narrow layers (fewer than 4 output tiles) of the two teams land on different SIMDs
     const int s = lane & 15, q = lane >> 4, team = wave >> 2, fg = (wave + 2 * team) & 3;
@@ -476,7 +492,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int
     for_layers_up(ly, [&](auto l) {
         const int ntiles = ly.P(l + 1) >> 4, SW = ly.SW(l);
         const float* xb = lds + ly.x_off(l) + row * ly.SX(l) + 4 * q;
-        const float* W = lds + ly.w_off(l);
+        const float* W = wimg + ly.w_off(l);
         const bool last = l == ly.L() - 1;
         for (int t0 = fg; t0 < ntiles; t0 += 8) {
             const int t1 = t0 + 4;
@@ -486,16 +502,27 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int
             const float* wa1 = W + (16 * t1 + s) * SW + 4 * q;
             if constexpr (LY::kStatic) {
                 constexpr int U = LY::P(decltype(l)::value) >> 4;
-                if (two) fwd_body<U, 2>(acc0, acc1, xb, wa0, wa1);
-                else { fwd_body<U, 1>(acc0, acc1, xb, wa0, wa1); acc0 += acc1; }
+                constexpr int AH = LY::wlds() ? 2 : 4;
+                if constexpr (U <= 8) {
+                    if (two) fwd_body<U, 2, AH>(acc0, acc1, xb, wa0, wa1);
+                    else { fwd_body<U, 1, AH>(acc0, acc1, xb, wa0, wa1); acc0 += acc1; }
+                } else {       // long contractions: blocks of 8 k-blocks, not one giant unroll
+                    if (two) gemm_fwd<2, AH>(acc0, acc1, U, xb, wa0, wa1);
+                    else { gemm_fwd<1, AH>(acc0, acc1, U, xb, wa0, wa1); acc0 += acc1; }
+                }
             } else {
                 const int U = ly.P(l) >> 4;
-                if (two) gemm_fwd<2>(acc0, acc1, U, xb, wa0, wa1);
-                else { gemm_fwd<1>(acc0, acc1, U, xb, wa0, wa1); acc0 += acc1; }
+                if (ly.wlds()) {
+                    if (two) gemm_fwd<2>(acc0, acc1, U, xb, wa0, wa1);
+                    else { gemm_fwd<1>(acc0, acc1, U, xb, wa0, wa1); acc0 += acc1; }
+                } else {
+                    if (two) gemm_fwd<2, 4>(acc0, acc1, U, xb, wa0, wa1);
+                    else { gemm_fwd<1, 4>(acc0, acc1, U, xb, wa0, wa1); acc0 += acc1; }
+                }
             }
             STAMP(16 + 3 * (int)l);
-            fwd_epilogue(ly, lds, l, last, t0, acc0, row, q, zd0);
-            if (two) fwd_epilogue(ly, lds, l, last, t1, acc1, row, q, zd1);
+            fwd_epilogue(ly, lds, wimg, l, last, t0, acc0, row, q, zd0);
+            if (two) fwd_epilogue(ly, lds, wimg, l, last, t1, acc1, row, q, zd1);
         }
         // zdot is known: the owner lanes can already form the NEXT stage state and put it
         // into region_0 (last read two barriers ago), which takes the stage combination and
@@ -509,7 +536,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int
     for_layers_down(ly, [&](auto l) {
         const int ntiles = ly.P(l) >> 4, SW = ly.SW(l);
         const float* gb = lds + ly.x_off(l + 1) + row * ly.SX(l + 1) + 4 * q;
-        const float* W = lds + ly.w_off(l);
+        const float* W = wimg + ly.w_off(l);
         for (int t0 = fg; t0 < ntiles; t0 += 8) {
             const int t1 = t0 + 4;
             const bool two = t1 < ntiles;
@@ -518,12 +545,34 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, int lane, int
             const float* wc1 = W + (4 * q) * SW + 16 * t1 + s;
             if constexpr (LY::kStatic) {
                 constexpr int U = LY::P(decltype(l)::value + 1) >> 4;
-                if (two) bwd_body<U, 2>(acc0, acc1, SW, gb, wc0, wc1);
-                else { bwd_body<U, 1>(acc0, acc1, SW, gb, wc0, wc1); acc0 += acc1; }
+                if constexpr (LY::wlds()) {
+                    if (two) bwd_body<U, 2>(acc0, acc1, SW, gb, wc0, wc1);
+                    else { bwd_body<U, 1>(acc0, acc1, SW, gb, wc0, wc1); acc0 += acc1; }
+                } else {
+                    const float* WT = wimg + ly.wt_off(l);
+                    const float* ra = WT + (16 * t0 + s) * ly.SWT(l) + 4 * q;
+                    const float* rb = WT + (16 * t1 + s) * ly.SWT(l) + 4 * q;
+                    if constexpr (U <= 8) {
+                        if (two) fwd_body<U, 2, 4>(acc0, acc1, gb, ra, rb);
+                        else { fwd_body<U, 1, 4>(acc0, acc1, gb, ra, rb); acc0 += acc1; }
+                    } else {
+                        if (two) gemm_fwd<2, 4>(acc0, acc1, U, gb, ra, rb);
+                        else { gemm_fwd<1, 4>(acc0, acc1, U, gb, ra, rb); acc0 += acc1; }
+                    }
+                }
             } else {
                 const int U = ly.P(l + 1) >> 4;
-                if (two) gemm_bwd<2>(acc0, acc1, U, SW, gb, wc0, wc1);
-                else { gemm_bwd<1>(acc0, acc1, U, SW, gb, wc0, wc1); acc0 += acc1; }
+                if (ly.wlds()) {
+                    if (two) gemm_bwd<2>(acc0, acc1, U, SW, gb, wc0, wc1);
+                    else { gemm_bwd<1>(acc0, acc1, U, SW, gb, wc0, wc1); acc0 += acc1; }
+                } else {
+                    // rows of the transposed image: the same row-fragment GEMM as forward
+                    const float* WT = wimg + ly.wt_off(l);
+                    const float* ra = WT + (16 * t0 + s) * ly.SWT(l) + 4 * q;
+                    const float* rb = WT + (16 * t1 + s) * ly.SWT(l) + 4 * q;
+                    if (two) gemm_fwd<2, 4>(acc0, acc1, U, gb, ra, rb);
+                    else { gemm_fwd<1, 4>(acc0, acc1, U, gb, ra, rb); acc0 += acc1; }
+                }
             }
             STAMP(32 + 3 * (int)l);
             bwd_epilogue(ly, lds, l, t0, acc0, row, q);
@@ -622,8 +671,9 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
 
     // weights + biases -> LDS (once per workgroup; 4 x 16 B in flight per lane), the rest of
     // LDS zeroed (padding columns of the activation images meet zero weights but must be finite)
+    const float* wimg = ly.wlds() ? (const float*)lds : a.img;
     {
-        const int n = ly.img_floats();
+        const int n = ly.wlds() ? ly.img_floats() : 0;
         int i = tid * 4;
         for (; i + 3 * MF_THREADS * 4 < n; i += 4 * MF_THREADS * 4) {
             const f32x4 v0 = *(const f32x4*)(a.img + i);
@@ -753,7 +803,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
             // rewritten only in this evaluation's last forward epilogue, two barriers on)
             if (stg > 1 && sown) set_k(ks, stg - 1, read_scalars());
             f32x4 zd0 = {0.f, 0.f, 0.f, 0.f}, zd1 = zd0;
-            rhs_tile(ly, lds, lane, wave, bar, gen, zd0, zd1, [&]() {
+            rhs_tile(ly, lds, wimg, lane, wave, bar, gen, zd0, zd1, [&]() {
                 if (mode == 2) {
                     set_k(kz0, stg, zd0); set_k(kz1, stg, zd1);
                     if (stg < nstage) put_stage(stg + 1);
@@ -1762,6 +1812,10 @@ __global__ void k_pack_image(MfmaLayout ly, NetDesc nd, const float* __restrict_
             const int o = i - ly.b_off[l];
             if (o < nd.dims[l + 1]) v = P[nd.b_off[l] + o];
         }
+        if (!ly.wlds && i >= ly.wt_off[l] && i < ly.wt_off[l] + ly.P[l] * ly.SWT[l]) {
+            const int k = (i - ly.wt_off[l]) / ly.SWT[l], o = (i - ly.wt_off[l]) % ly.SWT[l];
+            if (o < nd.dims[l + 1] && k < nd.dims[l]) v = P[nd.w_off[l] + o + (size_t)k * nd.dims[l + 1]];
+        }
     }
     img[i] = v;
 }
@@ -1771,6 +1825,7 @@ __global__ void k_pack_image(MfmaLayout ly, NetDesc nd, const float* __restrict_
 using LyCfg3 = StLayout<CNF_ACT_TANH, 32, 128, 128, 32>;   // BASELINE configs 3/4
 using LyCfg2 = StLayout<CNF_ACT_TANH, 16, 48, 16>;         // BASELINE config 2
 using LyCfg1 = StLayout<CNF_ACT_TANH, 16, 16, 16>;         // BASELINE config 1 (2->6->2 padded)
+using LyCfg5 = StLayoutX<false, CNF_ACT_TANH, 128, 384, 128>;   // BASELINE config 5: weights stay in HBM/L2
 using FsCfg3 = FsLayout<CNF_ACT_TANH, 32, 128, 128, 32>;   // same shapes, fused-phase layout
 using FsCfg2 = FsLayout<CNF_ACT_TANH, 16, 48, 16>;
 using FsCfg1 = FsLayout<CNF_ACT_TANH, 16, 16, 16>;
@@ -1782,7 +1837,7 @@ static bool matches(const MfmaLayout& m) {
         if (m.P[l] != LY::P(l)) return false;
     for (int l = 0; l < m.L; ++l)
         if (m.acts[l] != LY::act(l)) return false;
-    return m.img_floats == LY::img_floats() && m.total_floats == LY::total_floats() &&
+    return (m.wlds != 0) == LY::wlds() && m.img_floats == LY::img_floats() && m.total_floats == LY::total_floats() &&
            m.red_off == LY::red_off() && m.x_off[m.L] == LY::x_off(LY::kL);
 }
 
@@ -1805,24 +1860,41 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     }
     for (int l = 0; l < nd.n_layers; ++l) { ly.b_off[l] = off; off += ly.P[l + 1]; }
     ly.img_floats = (off + 3) & ~3;
-    off = ly.img_floats;
-    for (int l = 0; l <= nd.n_layers; ++l) {
-        ly.SX[l] = sx_of(ly.P[l]);
-        ly.x_off[l] = off;
-        off += MF_NB * ly.SX[l];
+    ly.wlds = 1;
+    auto place_lds = [&](int start) {
+        int o = start;
+        for (int l = 0; l <= nd.n_layers; ++l) {
+            ly.SX[l] = sx_of(ly.P[l]);
+            ly.x_off[l] = o;
+            o += MF_NB * ly.SX[l];
+        }
+        ly.eps_off = o; o += MF_NB * ly.SX[0];
+        ly.du_off = o;  o += MF_NB * ly.SX[0];
+        ly.red_off = o;
+        int red = 3 * (ly.P[0] >> 4) * MF_NB;
+        o += red < 16 ? 16 : red;
+        o += 16;                      // team-barrier counters / controller scratch
+        ly.total_floats = o;
+    };
+    place_lds(ly.img_floats);
+    if ((size_t)ly.total_floats * sizeof(float) > MF_LDS_BYTES) {
+        // weights do not fit in LDS next to the activation images: leave them in HBM/L2 and add
+        // a row-major transposed copy per layer for the reverse sweep
+        ly.wlds = 0;
+        int o = ly.img_floats;
+        for (int l = 0; l < nd.n_layers; ++l) {
+            ly.SWT[l] = sw_of(ly.P[l + 1]);
+            ly.wt_off[l] = o;
+            o += ly.P[l] * ly.SWT[l];
+        }
+        ly.img_floats = (o + 3) & ~3;
+        place_lds(0);
     }
-    ly.eps_off = off; off += MF_NB * ly.SX[0];
-    ly.du_off = off;  off += MF_NB * ly.SX[0];
-    ly.red_off = off;
-    int red = 3 * (ly.P[0] >> 4) * MF_NB;
-    off += red < 16 ? 16 : red;
-    off += 16;                      // team-barrier counters
-    ly.total_floats = off;
     ly.n_in = nd.n_in;
     ly.norm_z = nd.norm_z;
     ly.norm_j = nd.norm_j;
-    ly.ept = ((MF_NB / 2) * (nd.n_in + 3) + MF_THREADS / 2 - 1) / (MF_THREADS / 2);
-    if ((size_t)ly.total_floats * sizeof(float) > MF_LDS_BYTES) return;   // weights do not fit in LDS
+    ly.ept = 0;
+    if ((size_t)ly.total_floats * sizeof(float) > MF_LDS_BYTES) return;   // activations alone exceed LDS
     if (ly.P[0] > 128) return;                                             // state tiles fg, fg+4 only
     if (nd.jvp) return;                                                    // forward-mode sweep: generic path
     p.variant = 1;
@@ -1833,6 +1905,7 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     if (matches<LyCfg3>(ly)) p.variant = 2;
     else if (matches<LyCfg2>(ly)) p.variant = 3;
     else if (matches<LyCfg1>(ly)) p.variant = 4;
+    else if (matches<LyCfg5>(ly)) p.variant = 5;
 }
 
 void mfma_plan_free(MfmaPlan& p) {
@@ -1869,6 +1942,7 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
         if (e == hipSuccess) e = set_attr<LyCfg3>();
         if (e == hipSuccess) e = set_attr<LyCfg2>();
         if (e == hipSuccess) e = set_attr<LyCfg1>();
+        if (e == hipSuccess) e = set_attr<LyCfg5>();
         if (e == hipSuccess) e = set_attr_fused<FsCfg3>();
         if (e == hipSuccess) e = set_attr_fused<FsCfg2>();
         if (e == hipSuccess) e = set_attr_fused<FsCfg1>();
@@ -1913,7 +1987,7 @@ static void launch_fused(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStr
 static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a, hipStream_t s) {
     const dim3 grid(mfma_grid_for(a.B)), block(MF_THREADS);
     const size_t shm = (size_t)p.ly.total_floats * sizeof(float);
-    if (p.variant >= 2 && p.schedule > 0) {
+    if (p.variant >= 2 && p.variant <= 4 && p.schedule > 0) {
         if (p.variant == 2) launch_fused<FsCfg3>(p, a, grid, s);
         else if (p.variant == 3) launch_fused<FsCfg2>(p, a, grid, s);
         else launch_fused<FsCfg1>(p, a, grid, s);
@@ -1921,6 +1995,7 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a, hipStream_t s) {
     else if (p.variant == 2) launch_static<LyCfg3>(p, a, grid, s);
     else if (p.variant == 3) launch_static<LyCfg2>(p, a, grid, s);
     else if (p.variant == 4) launch_static<LyCfg1>(p, a, grid, s);
+    else if (p.variant == 5) launch_static<LyCfg5>(p, a, grid, s);
     else {
         RtLayout ly{p.ly};
         if (a.mode == 2) hipLaunchKernelGGL((k_mfma<RtLayout, true>), grid, block, shm, s, ly, a);

@@ -1,0 +1,84 @@
+"""Runs every BASELINE.json configuration at its full size on cuda:0 and prints one JSON line
+per configuration: which kernel ran, RHS evaluations per second of an adaptive solve (README
+tolerances) and of a fixed-dt solve, plain-RHS launch time, and the parity error of the RHS
+against the float32 C oracle on a column sample.  Not part of the product; used to fill the
+tables of DESIGN.md / README.md.    python tools/measure_configs.py [cfg ...]"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import continuousnf.jl_amd as cnf
+from continuousnf.jl_amd import _lib
+from oracle import c_oracle as CO
+from oracle import cnf_oracle as O
+from tests.helpers import make_icnf, parity_err
+
+which = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 5]
+dev = torch.device("cuda", 0)
+for i in which:
+    cfg, B, train = O.baseline_cfg(i)
+    if i == 4:
+        B = 8192                      # per-GPU shard of the 65536-column batch
+    rng = np.random.default_rng(i)
+    flat = O.glorot_params(cfg.net, rng, np.float32)
+    modes = [("train", True)] if train else [("test", False), ("train", True)]
+    for mname, tr in modes:
+        icnf = make_icnf(cnf, cfg, kernel="auto")
+        icnf.set_params(flat)
+        l, h = _lib.lib(), icnf.handle()
+        D = cfg.D(tr)
+        u_h = rng.standard_normal((D, B)).astype(np.float32)
+        eps_h = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+        u = torch.from_numpy(np.ascontiguousarray(u_h.T)).to(dev).reshape(-1)
+        eps = torch.from_numpy(np.ascontiguousarray(eps_h.T)).to(dev).reshape(-1)
+        du = torch.empty_like(u)
+        sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        m = 1 if tr else 0
+        kern = l.cnf_kernel_for(h, m, B)
+        # plain RHS
+        nrep = 20 if kern == 2 or i < 5 else 3
+        _lib.check(l.cnf_rhs(h, m, 0, u.data_ptr(), eps.data_ptr(), du.data_ptr(), B, sp), h)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nrep):
+            _lib.check(l.cnf_rhs(h, m, 0, u.data_ptr(), eps.data_ptr(), du.data_ptr(), B, sp), h)
+        torch.cuda.synchronize()
+        rhs_us = (time.perf_counter() - t0) / nrep * 1e6
+        # parity on a column sample
+        ns = min(B, 128 if (i == 5 and not tr) else 512)
+        got = du.view(B, D)[:ns].cpu().numpy().T
+        ref = CO.rhs(cfg, flat, u_h[:, :ns], eps_h[:, :ns], tr)
+        perr = parity_err(got, ref)
+        fl, by = C.c_double(), C.c_double()
+        l.cnf_rhs_work(h, m, B, C.byref(fl), C.byref(by))
+        out = {"cfg": i, "mode": mname, "B": B, "kernel": {1: "generic", 2: "mfma"}[kern], "rhs_us": round(rhs_us, 1),
+               "rhs_TFLOPs": round(fl.value / rhs_us / 1e6, 2), "parity_err_vs_c_oracle": float(f"{perr:.2e}")}
+        # solves
+        u0 = u.clone()
+        u0.view(B, D)[:, cfg.n_in:] = 0
+        for tag, opts in (("adaptive", _lib.cnf_solve_opts(cfg.tspan[0], cfg.tspan[1], 1.1920929e-7, 3.4526698e-4, 0.0, 1, 1 << 20, 0)),
+                          ("fixed", _lib.cnf_solve_opts(cfg.tspan[0], cfg.tspan[1], 0.0, 0.0, (cfg.tspan[1] - cfg.tspan[0]) / 32, 0, 1 << 20, 0))):
+            if kern == 1 and i == 5 and not tr and tag == "fixed":
+                continue
+            stats = _lib.cnf_solve_stats()
+            run = lambda: _lib.check(l.cnf_solve_tsit5(h, m, u0.data_ptr(), eps.data_ptr(), du.data_ptr(), B,
+                                                       C.byref(opts), C.byref(stats), sp), h)
+            run()
+            n = 5 if kern == 2 else 1
+            t0 = time.perf_counter()
+            for _ in range(n):
+                run()
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / n
+            out[f"{tag}_ms"] = round(el * 1e3, 3)
+            out[f"{tag}_nf"] = stats.nf
+            out[f"{tag}_rhs_evals_per_s"] = round(stats.nf / el, 1)
+        print(json.dumps(out), flush=True)
+        icnf.close()

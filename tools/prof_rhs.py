@@ -49,6 +49,21 @@ if what == "rhs":
         _lib.check(l.cnf_rhs(h, 1, k, u.data_ptr(), eps.data_ptr(), du.data_ptr(), B, sp), h)
     e1.record(); e1.synchronize()
     print(f"rhs: {e0.elapsed_time(e1) * 1e3 / n:.2f} us per launch")
+elif what == "adaptive":
+    import time
+    opts = _lib.cnf_solve_opts(0.0, 1.0, 1.1920929e-7, 3.4526698e-4, 0.0, 1, 1 << 20, k)
+    stats = _lib.cnf_solve_stats()
+    u.view(B, D)[:, cfg.n_in:] = 0
+    run = lambda: _lib.check(l.cnf_solve_tsit5(h, 1, u.data_ptr(), eps.data_ptr(), du.data_ptr(), B,
+                                               C.byref(opts), C.byref(stats), sp), h)
+    run(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / n
+    print(f"adaptive: {el * 1e6:.1f} us per solve, nf={stats.nf} naccept={stats.naccept} nreject={stats.nreject} "
+          f"launches={stats.launches} -> {stats.nf / el:.0f} RHS-evals/s")
 else:
     opts = _lib.cnf_solve_opts(0.0, 1.0, 0.0, 0.0, 1.0 / n, 0, 1 << 20, k)
     stats = _lib.cnf_solve_stats()
