@@ -247,7 +247,10 @@ extern "C" cnf_status cnf_rhs_work(cnf_handle h, int mode, int B, double* flops,
         *flops = B * (4.0 * M + 6.0 * n_in);
         *bytes = 4.0 * B * (n_in + n_in + D) + 4.0 * P;
     } else {
-        *flops = B * (2.0 * M + n_in * 2.0 * M);   // forward + n_in tangent sweeps
+        // exact trace: minimal formulation for 2-layer nets, tr J = d1^T (W1 .* W2^T) d2 = forward
+        // + one h x n_in product (B*3M); otherwise forward + n_in tangent sweeps
+        if (nd.n_layers == 2) *flops = B * 3.0 * M;
+        else *flops = B * (2.0 * M + n_in * 2.0 * M);
         *bytes = 4.0 * B * (n_in + D) + 4.0 * P;
     }
     return CNF_OK;

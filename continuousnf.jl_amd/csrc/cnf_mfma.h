@@ -16,10 +16,13 @@ struct MfmaLayout {
     int SW[CNF_MAX_LAYERS];         // row stride of layer l's weight image (floats)
     int w_off[CNF_MAX_LAYERS];      // offsets inside the weight+bias image
     int b_off[CNF_MAX_LAYERS];
-    int img_floats;                 // image size (multiple of 4)
+    int img_floats;                 // size of the whole HBM image (multiple of 4)
+    int core_img;                   // weights + biases (+ transposes): the part the kernel layouts know;
+                                    // with wlds this many floats are copied to LDS
     int wlds;                       // 1: the image is copied to LDS; 0: weights stay in HBM/L2 (big nets)
     int SWT[CNF_MAX_LAYERS];        // wlds == 0: row stride of the transposed weight image of layer l
     int wt_off[CNF_MAX_LAYERS];     // wlds == 0: its offset in the image
+    int c_off, SWC;                 // 2-layer nets: image of C = W_1 .* W_2^T (P1 x n_in) for the exact trace, -1 if none
     int SX[CNF_MAX_LAYERS + 1];     // row stride of activation region l ([sample][feature])
     int x_off[CNF_MAX_LAYERS + 1];  // LDS offsets (floats) of the activation regions
     int eps_off, du_off, red_off;   // EPS [NB][SX0], DU [NB][SX0], RED [3][P0/16][NB]

@@ -47,6 +47,9 @@ struct MfmaArgs {
     const float* partials_in; // mode 2 + apply_ctrl: error partials of the previous attempt
     int apply_ctrl;
     float n_total;            // D * B
+    int test;                 // TestMode: exact trace (2-layer closed form), state rows = n_in + 1
+    const float* cimg;        // TestMode: row-major image of C = W_1 .* W_2^T  (P1 x SWC)
+    int SWC;
     float* U[2];
     float* K1[2];
     float* Ks0;               // mode 1 output
@@ -72,7 +75,7 @@ struct RtLayout {
     __device__ __forceinline__ int w_off(int l) const { return m.w_off[l]; }
     __device__ __forceinline__ int b_off(int l) const { return m.b_off[l]; }
     __device__ __forceinline__ int x_off(int l) const { return m.x_off[l]; }
-    __device__ __forceinline__ int img_floats() const { return m.img_floats; }
+    __device__ __forceinline__ int img_floats() const { return m.core_img; }
     __device__ __forceinline__ bool wlds() const { return m.wlds != 0; }
     __device__ __forceinline__ int SWT(int l) const { return m.SWT[l]; }
     __device__ __forceinline__ int wt_off(int l) const { return m.wt_off[l]; }
@@ -416,7 +419,7 @@ __device__ __forceinline__ float quad_sum(float v) {     // sum over the 4 lanes
 // |zdot|^2 partial of its 16 rows to RED[0].
 template <class LY>
 __device__ __forceinline__ void fwd_epilogue(const LY& ly, float* lds, const float* wimg, int l, bool last, int ot,
-                                             f32x4 acc, int row, int q, f32x4& zd) {
+                                             f32x4 acc, int row, int q, f32x4& zd, bool test = false) {
     const int r0 = 16 * ot + 4 * q;
     const f32x4 bv = *(const f32x4*)(wimg + ly.b_off(l) + r0);
     const int act = ly.act(l);
@@ -433,7 +436,10 @@ __device__ __forceinline__ void fwd_epilogue(const LY& ly, float* lds, const flo
         const f32x4 ev = *(const f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r0);
         zd = f32x4{r0 + 0 < n_in ? h0 : 0.f, r0 + 1 < n_in ? h1 : 0.f,
                    r0 + 2 < n_in ? h2 : 0.f, r0 + 3 < n_in ? h3 : 0.f};
-        *(f32x4*)out = f32x4{ev.x * d0, ev.y * d1, ev.z * d2, ev.w * d3};
+        // Hutchinson: g_L = eps .* sigma'_L; exact trace (2 layers): the image holds sigma'_L itself
+        *(f32x4*)out = test ? f32x4{r0 + 0 < n_in ? d0 : 0.f, r0 + 1 < n_in ? d1 : 0.f, r0 + 2 < n_in ? d2 : 0.f,
+                                    r0 + 3 < n_in ? d3 : 0.f}
+                            : f32x4{ev.x * d0, ev.y * d1, ev.z * d2, ev.w * d3};
         const float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
         if (q == 0) lds[ly.red_off() + ot * MF_NB + row] = e2;
     }
@@ -481,7 +487,7 @@ __device__ __forceinline__ void bwd_epilogue(const LY& ly, float* lds, int l, in
 template <class LY, class F>
 __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* wimg, int lane, int wave,
                                          unsigned* bar, unsigned& gen, f32x4& zd0, f32x4& zd1,
-                                         F&& after_zdot STAMP_ARGS) {
+                                         F&& after_zdot, const float* cimg = nullptr, int SWC = 0 STAMP_ARGS) {
     // wimg: where the weight image is read from -- the LDS copy, or (networks too large for
     // LDS) the HBM/L2-resident image, with a row-major transposed copy for the reverse sweep
     // team = column tile; the feature-group index is rotated by 2 for team 1 so that the
@@ -521,8 +527,8 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
                 }
             }
             STAMP(16 + 3 * (int)l);
-            fwd_epilogue(ly, lds, wimg, l, last, t0, acc0, row, q, zd0);
-            if (two) fwd_epilogue(ly, lds, wimg, l, last, t1, acc1, row, q, zd1);
+            fwd_epilogue(ly, lds, wimg, l, last, t0, acc0, row, q, zd0, cimg != nullptr);
+            if (two) fwd_epilogue(ly, lds, wimg, l, last, t1, acc1, row, q, zd1, cimg != nullptr);
         }
         // zdot is known: the owner lanes can already form the NEXT stage state and put it
         // into region_0 (last read two barriers ago), which takes the stage combination and
@@ -532,6 +538,36 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
         team_barrier(bar, gen, lane);
         STAMP(18 + 3 * (int)l);
     });
+    if (cimg) {
+        // ---- exact trace of a 2-layer net (TestMode; src/icnf.jl:148-164 with utils.jl:1-36 in closed
+        // form): tr J = sum_k sigma'_1[k] * (C sigma'_2)[k],  C = W_1 .* W_2^T.  One GEMM with the rows
+        // of C (image in HBM/L2) against the sigma'_2 image, dotted with sigma'_1 recomputed from h_1.
+        const int ntiles = ly.P(1) >> 4, U = ly.P(2) >> 4;
+        const float* gb = lds + ly.x_off(2) + row * ly.SX(2) + 4 * q;
+        const int pact = ly.act(0);
+        float trp = 0.f;
+        for (int t0 = fg; t0 < ntiles; t0 += 8) {
+            const int t1 = t0 + 4;
+            const bool two = t1 < ntiles;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float* ra = cimg + (16 * t0 + s) * SWC + 4 * q;
+            const float* rb = cimg + (16 * t1 + s) * SWC + 4 * q;
+            if (two) gemm_fwd<2, 4>(acc0, acc1, U, gb, ra, rb);
+            else { gemm_fwd<1, 4>(acc0, acc1, U, gb, ra, rb); acc0 += acc1; }
+            const f32x4 h0 = *(const f32x4*)(lds + ly.x_off(1) + row * ly.SX(1) + 16 * t0 + 4 * q);
+            trp += acc0.x * d_from_h(pact, h0.x) + acc0.y * d_from_h(pact, h0.y) + acc0.z * d_from_h(pact, h0.z) +
+                   acc0.w * d_from_h(pact, h0.w);
+            if (two) {
+                const f32x4 h1 = *(const f32x4*)(lds + ly.x_off(1) + row * ly.SX(1) + 16 * t1 + 4 * q);
+                trp += acc1.x * d_from_h(pact, h1.x) + acc1.y * d_from_h(pact, h1.y) + acc1.z * d_from_h(pact, h1.z) +
+                       acc1.w * d_from_h(pact, h1.w);
+            }
+        }
+        trp = quad_sum(trp);
+        if (q == 0) lds[ly.red_off() + fg * MF_NB + row] = -trp;      // one partial per wave of the team
+        team_barrier(bar, gen, lane);
+        return;
+    }
     // ---- reverse (VJP): g_l = (W_{l+1}^T g_{l+1}) .* sigma'_l, in place over h_l ----
     for_layers_down(ly, [&](auto l) {
         const int ntiles = ly.P(l) >> 4, SW = ly.SW(l);
@@ -655,7 +691,8 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StepState* st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_in = ly.n_in(), D = n_in + 3;
+    const int nsc = a.test ? 1 : 3;                      // scalar rows: dlogp (+ E, n in TrainMode)
+    const int n_in = ly.n_in(), D = n_in + nsc;
     const int mode = STEP ? 2 : a.mode;
     if (st && st->done) {
         // keep the state chain intact for the launches queued behind this one
@@ -755,7 +792,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
         for (int i = tt; i < TNB * n_in; i += TT) {
             const int sl = i / n_in, r = i - sl * n_in;
             lds[ly.eps_off() + (TNB * team + sl) * ly.SX(0) + r] =
-                sl < nvalid ? a.eps[(size_t)(b0 + sl) * n_in + r] : 0.f;
+                (sl < nvalid && a.eps) ? a.eps[(size_t)(b0 + sl) * n_in + r] : 0.f;
         }
         // state: z rows in the accumulator layout, scalar rows in the fg == 0, q == 0 lanes
         f32x4 uz0 = {0.f, 0.f, 0.f, 0.f}, uz1 = uz0, kz0[7], kz1[7], us = uz0, ks[7];
@@ -764,11 +801,11 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
         if (live) {
             if (own0) uz0 = ld4(Uin + gcol + r00, nv0);
             if (own1) uz1 = ld4(Uin + gcol + r01, nv1);
-            if (sown) us = ld4(Uin + gcol + n_in, 3);
+            if (sown) us = ld4(Uin + gcol + n_in, nsc);
             if (K1in) {
                 if (own0) kz0[0] = ld4(K1in + gcol + r00, nv0);
                 if (own1) kz1[0] = ld4(K1in + gcol + r01, nv1);
-                if (sown) ks[0] = ld4(K1in + gcol + n_in, 3);
+                if (sown) ks[0] = ld4(K1in + gcol + n_in, nsc);
             }
         }
         const int nstage = mode == 2 ? 6 : 1;
@@ -787,6 +824,11 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
             }
         };
         auto read_scalars = [&]() {
+            if (a.test) {       // exact trace: 4 per-wave partials of -tr J
+                float ld = 0.f;
+                for (int w = 0; w < 4; ++w) ld += lds[ly.red_off() + w * MF_NB + row];
+                return f32x4{ld, 0.f, 0.f, 0.f};
+            }
             float ld = 0.f, e2 = 0.f, n2 = 0.f;
             for (int t = 0; t < nt0; ++t) {
                 e2 += lds[ly.red_off() + t * MF_NB + row];
@@ -808,7 +850,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
                     set_k(kz0, stg, zd0); set_k(kz1, stg, zd1);
                     if (stg < nstage) put_stage(stg + 1);
                 } else { kz0[1] = zd0; kz1[1] = zd1; }
-            } STAMP_PASS);
+            }, a.test ? a.cimg : nullptr, a.SWC STAMP_PASS);
         }
         // scalar rows of the last evaluation (rhs_tile ended with a barrier)
         if (sown) {
@@ -821,7 +863,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
                 float* out = (mode == 0 ? a.du : a.Ks0) + gcol;
                 if (own0) st4(out + r00, kz0[1], nv0);
                 if (own1) st4(out + r01, kz1[1], nv1);
-                if (sown) st4(out + n_in, ks[1], 3);
+                if (sown) st4(out + n_in, ks[1], nsc);
             } else {
                 float* Un = a.U[1 - cur] + gcol;
                 float* K7 = a.K1[1 - cur] + gcol;
@@ -835,8 +877,8 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
                 }
                 if (sown) {
                     const f32x4 uns = us + hstep * stage_acc4<6>(ks);
-                    st4(Un + n_in, uns, 3); st4(K7 + n_in, ks[6], 3);
-                    err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
+                    st4(Un + n_in, uns, nsc); st4(K7 + n_in, ks[6], nsc);
+                    err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, nsc);
                 }
             }
         }
@@ -1817,6 +1859,12 @@ __global__ void k_pack_image(MfmaLayout ly, NetDesc nd, const float* __restrict_
             if (o < nd.dims[l + 1] && k < nd.dims[l]) v = P[nd.w_off[l] + o + (size_t)k * nd.dims[l + 1]];
         }
     }
+    if (ly.c_off >= 0 && i >= ly.c_off && i < ly.c_off + ly.P[1] * ly.SWC) {
+        // C[k][i] = W_1[k][i] * W_2[i][k]   (layer 0: out k, in i; layer 1: out i, in k)
+        const int k = (i - ly.c_off) / ly.SWC, c = (i - ly.c_off) % ly.SWC;
+        if (k < nd.dims[1] && c < nd.dims[0])
+            v = P[nd.w_off[0] + k + (size_t)c * nd.dims[1]] * P[nd.w_off[1] + c + (size_t)k * nd.dims[2]];
+    }
     img[i] = v;
 }
 
@@ -1837,7 +1885,7 @@ static bool matches(const MfmaLayout& m) {
         if (m.P[l] != LY::P(l)) return false;
     for (int l = 0; l < m.L; ++l)
         if (m.acts[l] != LY::act(l)) return false;
-    return (m.wlds != 0) == LY::wlds() && m.img_floats == LY::img_floats() && m.total_floats == LY::total_floats() &&
+    return (m.wlds != 0) == LY::wlds() && m.core_img == LY::img_floats() && m.total_floats == LY::total_floats() &&
            m.red_off == LY::red_off() && m.x_off[m.L] == LY::x_off(LY::kL);
 }
 
@@ -1889,6 +1937,13 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
         }
         ly.img_floats = (o + 3) & ~3;
         place_lds(0);
+    }
+    ly.core_img = ly.img_floats;
+    ly.c_off = -1; ly.SWC = 0;
+    if (nd.n_layers == 2 && nd.dims[0] == nd.dims[2]) {     // exact-trace image, read from HBM/L2 in TestMode
+        ly.SWC = sw_of(ly.P[2]);
+        ly.c_off = ly.img_floats;
+        ly.img_floats = (ly.c_off + ly.P[1] * ly.SWC + 3) & ~3;
     }
     ly.n_in = nd.n_in;
     ly.norm_z = nd.norm_z;
@@ -1954,7 +2009,8 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
 }
 
 bool mfma_supported(const MfmaPlan& p, const NetDesc&, bool train, int) {
-    return p.variant != 0 && train;      // TestMode (exact trace) runs on the generic path
+    if (p.variant == 0) return false;
+    return train || p.ly.c_off >= 0;     // TestMode: exact trace in closed form for 2-layer nets
 }
 
 int mfma_grid_for(int B) {
@@ -1984,10 +2040,18 @@ static void launch_fused(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStr
     }
 }
 
-static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a, hipStream_t s) {
+static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
+    MfmaArgs a = a0;
+    if (a.test) { a.cimg = p.d_img + p.ly.c_off; a.SWC = p.ly.SWC; }
     const dim3 grid(mfma_grid_for(a.B)), block(MF_THREADS);
     const size_t shm = (size_t)p.ly.total_floats * sizeof(float);
-    if (p.variant >= 2 && p.variant <= 4 && p.schedule > 0) {
+    if (a.test && p.variant != 5) {
+        // exact trace: the run-time-layout kernel (the static BASELINE shapes 1-3 are TrainMode kernels)
+        RtLayout ly{p.ly};
+        if (a.mode == 2) hipLaunchKernelGGL((k_mfma<RtLayout, true>), grid, block, shm, s, ly, a);
+        else hipLaunchKernelGGL((k_mfma<RtLayout, false>), grid, block, shm, s, ly, a);
+    }
+    else if (p.variant >= 2 && p.variant <= 4 && p.schedule > 0) {
         if (p.variant == 2) launch_fused<FsCfg3>(p, a, grid, s);
         else if (p.variant == 3) launch_fused<FsCfg2>(p, a, grid, s);
         else launch_fused<FsCfg1>(p, a, grid, s);
@@ -2004,19 +2068,21 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 
-cnf_status mfma_rhs(const MfmaPlan& p, const NetDesc&, bool train, const float* u,
+cnf_status mfma_rhs(const MfmaPlan& p, const NetDesc& nd_, bool train, const float* u,
                     const float* eps, float* du, int B, hipStream_t s) {
-    if (!p.variant || !train) return CNF_ERR_UNSUPPORTED;
+    if (!mfma_supported(p, nd_, train, B)) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
+    a.test = train ? 0 : 1;
     a.mode = 0; a.B = B; a.img = p.d_img; a.eps = eps; a.u = u; a.du = du;
     return launch(p, a, s);
 }
 
-cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc&, bool train, const StepState* st,
+cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, const StepState* st,
                           float* const U[2], float* const K1[2], float* const Ks[5],
                           const float* eps, int nk, int B, hipStream_t s) {
-    if (!p.variant || !train || nk != 1) return CNF_ERR_UNSUPPORTED;
+    if (!mfma_supported(p, nd_, train, B) || nk != 1) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
+    a.test = train ? 0 : 1;
     a.mode = 1; a.B = B; a.img = p.d_img; a.eps = eps; a.st = st;
     a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1]; a.Ks0 = Ks[0];
     return launch(p, a, s);
@@ -2026,11 +2092,12 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
                      StepState* st_out, float* const U[2], float* const K1[2], float* const Ks[5],
                      const float* eps, const float* partials_in, float* partials_out, bool apply_ctrl,
                      bool finalize, int B, hipStream_t s) {
-    if (!p.variant || !train) return CNF_ERR_UNSUPPORTED;
+    if (!mfma_supported(p, nd, train, B)) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
+    a.test = train ? 0 : 1;
     a.mode = 2; a.B = B; a.img = p.d_img; a.eps = eps; a.st = st_in; a.st_out = st_out;
     a.partials_in = partials_in; a.apply_ctrl = apply_ctrl ? 1 : 0;
-    a.n_total = (float)((size_t)(nd.n_in + 3) * B);
+    a.n_total = (float)((size_t)(nd.n_in + (train ? 3 : 1)) * B);
     a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1]; a.Ks0 = Ks[0];
     a.partials = partials_out;
     cnf_status r = launch(p, a, s);

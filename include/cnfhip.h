@@ -170,7 +170,8 @@ int cnf_state_rows(cnf_handle h, int mode);
 /* Which kernel AUTO resolves to for this handle and batch (CNF_KERNEL_*). */
 int cnf_kernel_for(cnf_handle h, int mode, int B);
 /* Algorithmic work of ONE RHS evaluation over B samples:
- * bytes = 4*B*(n_in + [train] n_in + D) + 4*P; flops = B*(4M + 6 n_in) (Train). */
+ * bytes = 4*B*(n_in + [train] n_in + D) + 4*P; flops = B*(4M + 6 n_in) (Train);
+ * Test: B*3M for 2-layer nets (closed-form trace), else B*(2M + n_in*2M). */
 cnf_status cnf_rhs_work(cnf_handle h, int mode, int B, double* flops, double* bytes);
 
 #ifdef __cplusplus
