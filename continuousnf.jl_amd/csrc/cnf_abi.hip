@@ -443,79 +443,82 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
     }
     StepState* cur_state = h->d_state;   // slot holding the live integrator state
     int pp = 0;                          // partials buffer the NEXT launch reads
-    long est_left = 0;                   // adaptive: estimated attempts still needed (0 = unknown)
-    const int chunk = opts->adaptive ? 8 : (int)(expected < 64 ? expected : 64);
-    long attempts = 0;
-    int slot = 0;
-    bool pending[2] = {false, false};
+    // Attempts are queued in chunks, at most two chunks in flight.  After every chunk the state
+    // is copied to a pinned mirror; the host reads the mirrors one chunk behind the GPU and
+    // sizes the next chunk by the attempts still needed, (t1 - t)/dt, so that the queue
+    // neither drains (GPU idle) nor runs far past t1 (launches that exit at once).
+    const int chunk = opts->adaptive ? 8 : 64;
+    long enq = 0;                        // attempts enqueued so far
+    long est_left = opts->adaptive ? -1 : expected;   // attempts still to enqueue; -1 = unknown
+    struct Pend { int slot; long enq_at; } q[2];
+    int nq = 0;
+    bool slot_busy[2] = {false, false};
     bool done = false;
     StepState fin{};
     while (!done) {
-        if (attempts >= (long)opts->maxiters) {
+        bool can = nq < 2 && enq < (long)opts->maxiters && est_left != 0;
+        if (est_left < 0 && nq > 0) can = false;          // learn t and dt from the first chunk
+        if (can) {
+            long todo = chunk;
+            if (est_left > 0 && est_left < todo) todo = est_left;
+            if (enq + todo > (long)opts->maxiters) todo = (long)opts->maxiters - enq;
+            for (long i = 0; i < todo; ++i) {
+                if (use_mfma) {
+                    // fused path: the controller of attempt i-1 runs inside launch i; only the
+                    // last launch of a chunk is followed by the stand-alone controller
+                    const bool apply = i > 0, fin_ = i == todo - 1;
+                    StepState* st_next = cur_state == h->d_state ? h->d_state + 1 : h->d_state;
+                    s = mfma_step(h->mfma, h->nd, train, cur_state, st_next, h->U, h->K1, h->Ks, eps,
+                                  h->partials + 2 * MAX_PARTIALS * pp, h->partials + 2 * MAX_PARTIALS * (pp ^ 1),
+                                  apply, fin_, B, st);
+                    if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
+                    if (apply) cur_state = st_next;
+                    pp ^= 1;
+                    launches += fin_ ? 2 : 1;
+                } else {
+                    enqueue_attempt_generic(h, train, eps, B, nblk, st);
+                    launches += 8;
+                }
+            }
+            enq += todo;
+            if (est_left > 0) est_left -= todo;
+            const int slot = slot_busy[0] ? 1 : 0;
+            HIPCHK(h, hipMemcpyAsync(&h->h_state[slot], cur_state, sizeof(StepState), hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipEventRecord(h->ev[slot], st));
+            slot_busy[slot] = true;
+            q[nq].slot = slot; q[nq].enq_at = enq; ++nq;
+            if (nq < 2 && est_left > 0) continue;          // keep a second chunk in flight
+        }
+        if (nq == 0) {
             HIPCHK(h, hipStreamSynchronize(st));
             return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
         }
-        long todo = chunk;
-        if (!opts->adaptive) todo = attempts >= expected ? 1 : (expected - attempts < todo ? expected - attempts : todo);
-        else if (est_left > 0 && est_left < todo) todo = est_left;   // do not run far past t1
-        if (attempts + todo > (long)opts->maxiters) todo = (long)opts->maxiters - attempts;
-        for (long i = 0; i < todo; ++i) {
-            if (use_mfma) {
-                // fused path: the controller of attempt i-1 runs inside launch i; only the
-                // last launch of a chunk is followed by the stand-alone controller
-                const bool apply = i > 0, fin = i == todo - 1;
-                StepState* st_next = cur_state == h->d_state ? h->d_state + 1 : h->d_state;
-                s = mfma_step(h->mfma, h->nd, train, cur_state, st_next, h->U, h->K1, h->Ks, eps,
-                              h->partials + 2 * MAX_PARTIALS * pp, h->partials + 2 * MAX_PARTIALS * (pp ^ 1),
-                              apply, fin, B, st);
-                if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
-                if (apply) cur_state = st_next;
-                pp ^= 1;
-                launches += fin ? 2 : 1;
-            } else {
-                enqueue_attempt_generic(h, train, eps, B, nblk, st);
-                launches += 8;
+        // read the oldest pending mirror
+        const Pend pd = q[0];
+        q[0] = q[1]; --nq;
+        HIPCHK(h, hipEventSynchronize(h->ev[pd.slot]));
+        slot_busy[pd.slot] = false;
+        fin = h->h_state[pd.slot];
+        done = fin.done != 0;
+        if (!done) {
+            long need = 1;
+            if (fin.dt > 0.f) need = (long)std::ceil(std::fabs((double)fin.t1 - (double)fin.t) / (double)fin.dt);
+            if (need < 1) need = 1;
+            est_left = need - (enq - pd.enq_at);           // minus what is already queued behind this snapshot
+            if (est_left < 0) est_left = 0;
+            if (est_left == 0 && nq == 0) est_left = 1;    // the estimate fell short: one more
+            if (enq >= (long)opts->maxiters && nq == 0) {
+                HIPCHK(h, hipStreamSynchronize(st));
+                return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
             }
         }
-        attempts += todo;
-        HIPCHK(h, hipMemcpyAsync(&h->h_state[slot], cur_state, sizeof(StepState), hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipEventRecord(h->ev[slot], st));
-        pending[slot] = true;
-        // poll one chunk behind the GPU; wait for the chunk just enqueued only when no
-        // further run-ahead is useful (fixed dt: all expected steps are in flight)
-        bool wait_current = (!opts->adaptive && attempts >= expected) || attempts >= (long)opts->maxiters;
-        if (pending[slot ^ 1]) {
-            HIPCHK(h, hipEventSynchronize(h->ev[slot ^ 1]));
-            pending[slot ^ 1] = false;
-            fin = h->h_state[slot ^ 1];
-            done = fin.done != 0;
-            // fin is the state BEFORE the chunk just enqueued: estimate what is left after it
-            if (opts->adaptive && !done && fin.dt > 0.f) {
-                long need = (long)std::ceil(std::fabs((double)fin.t1 - (double)fin.t) / (double)fin.dt);
-                est_left = need - todo;
-                if (est_left <= 0) { est_left = 1; wait_current = true; }   // the queued chunk should finish it
-            }
-        } else if (opts->adaptive) {
-            wait_current = true;       // first chunk: learn t and dt before queueing more
-        }
-        if (!done && wait_current) {
-            HIPCHK(h, hipEventSynchronize(h->ev[slot]));
-            pending[slot] = false;
-            fin = h->h_state[slot];
-            done = fin.done != 0;
-            if (opts->adaptive && !done && fin.dt > 0.f) {
-                est_left = (long)std::ceil(std::fabs((double)fin.t1 - (double)fin.t) / (double)fin.dt);
-                if (est_left < 1) est_left = 1;
-            }
-        }
-        slot ^= 1;
     }
-    // drain a possibly outstanding newer chunk (its kernels early-exit once done is set)
-    for (int i = 0; i < 2; ++i)
-        if (pending[i]) {
-            HIPCHK(h, hipEventSynchronize(h->ev[i]));
-            fin = h->h_state[i];
-        }
+    // drain chunks still in flight (their launches exit at once: the state says done)
+    while (nq > 0) {
+        HIPCHK(h, hipEventSynchronize(h->ev[q[0].slot]));
+        fin = h->h_state[q[0].slot];
+        q[0] = q[1]; --nq;
+    }
     launch_copy_final(cur_state, h->U[0], h->U[1], u_out, n, st);
     launches += 1;
     HIPCHK(h, hipGetLastError());
