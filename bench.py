@@ -72,13 +72,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU; CNF_BENCH_BACKEND=gloo lets several ranks share one card for a rehearsal
+    backend = os.environ.get("CNF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg, _, _ = O.baseline_cfg(3)
     B = args.batch
@@ -91,9 +95,10 @@ def main():
     else:
         kw = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
     icnf = make_icnf(cnf, cfg, kernel=args.kernel, sol_kwargs=kw, tag=cnf.RNODE)
-    icnf.device = local_rank
-    xs = torch.from_numpy(xs_h).to(dev)
-    eps = torch.from_numpy(eps_h).to(dev)
+    icnf.device = dev_index
+    # resident in HBM in the reference's own layout (Julia column-major: a sample's rows contiguous)
+    xs = torch.from_numpy(np.ascontiguousarray(xs_h.T)).to(dev).t()
+    eps = torch.from_numpy(np.ascontiguousarray(eps_h.T)).to(dev).t()
     ps = torch.from_numpy(flat).to(dev)
     mode = cnf.TrainMode()
 
@@ -103,6 +108,7 @@ def main():
         return icnf.last_stats, sums
 
     def sync():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -118,7 +124,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     loss = cnf.loss_from_sums(icnf, mode, sums)
-    t = torch.tensor([elapsed, float(nf_total)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(nf_total)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)

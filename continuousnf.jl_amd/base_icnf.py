@@ -377,7 +377,11 @@ def loss_sums(icnf: ICNF, logpx, regs):
     if _is_torch(logpx):
         import torch
         B = logpx.numel()
-        r = torch.stack([E, n, A]).contiguous().reshape(-1)
+        if (E.data_ptr() + 4 * B == n.data_ptr() and n.data_ptr() + 4 * B == A.data_ptr()
+                and E.is_contiguous() and n.is_contiguous() and A.is_contiguous()):
+            r = E                  # the three rows are already one 3 x B buffer (as _post returns them)
+        else:
+            r = torch.stack([E, n, A]).contiguous().reshape(-1)
         out = torch.empty(5, dtype=torch.float32, device=logpx.device)
         st = C.c_void_p(torch.cuda.current_stream(logpx.device).cuda_stream)
         _lib.check(_lib.lib().cnf_loss_sums(icnf.handle(), logpx.contiguous().data_ptr(), r.data_ptr(), B,

@@ -395,11 +395,12 @@ __global__ void k_post(NetDesc nd, int train, const float* __restrict__ fsol,
     regs[2 * (size_t)B + b] = (nd.norm_z_aug && nd.naugs > 0) ? sqrtf(sa) : 0.f;  // :179-187
 }
 
-// loss sums (src/icnf.jl:489): one block, deterministic; sums5 = (S logpx, S E, S n, S A, B)
-__global__ void __launch_bounds__(256)
+// loss sums (src/icnf.jl:489): one block of 1024 lanes, deterministic (fixed lane->entry map,
+// fixed tree); sums5 = (S logpx, S E, S n, S A, B)
+__global__ void __launch_bounds__(1024)
 k_loss_sums(const float* __restrict__ logpx, const float* __restrict__ regs, int B,
             float* __restrict__ sums5) {
-    __shared__ float sm[8];
+    __shared__ float sm[4][16];
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         s[0] += logpx[b];
@@ -407,9 +408,16 @@ k_loss_sums(const float* __restrict__ logpx, const float* __restrict__ regs, int
         s[2] += regs[(size_t)B + b];
         s[3] += regs[2 * (size_t)B + b];
     }
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     for (int j = 0; j < 4; ++j) {
-        float r = block_sum(s[j], sm);
-        if (threadIdx.x == 0) sums5[j] = r;
+        float v = wave_sum(s[j]);
+        if (l == 0) sm[j][w] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float r = 0.f;
+        for (int i = 0; i < 16; ++i) r += sm[threadIdx.x][i];
+        sums5[threadIdx.x] = r;
     }
     if (threadIdx.x == 0) sums5[4] = (float)B;
 }
@@ -446,5 +454,5 @@ void launch_post(const NetDesc& nd, int train, const float* fsol, float* logpx, 
 }
 void launch_loss_sums(const float* logpx, const float* regs, int B, float* sums5,
                       hipStream_t s) {
-    hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(256), 0, s, logpx, regs, B, sums5);
+    hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(1024), 0, s, logpx, regs, B, sums5);
 }
