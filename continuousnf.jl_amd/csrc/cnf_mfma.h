@@ -22,6 +22,8 @@ struct MfmaLayout {
     int wlds;                       // 1: the image is copied to LDS; 0: weights stay in HBM/L2 (big nets)
     int SWT[CNF_MAX_LAYERS];        // wlds == 0: row stride of the transposed weight image of layer l
     int wt_off[CNF_MAX_LAYERS];     // wlds == 0: its offset in the image
+    int jvp;                        // forward-mode (J eps) sweep: a tangent image per layer, no reverse sweep
+    int tx_off[CNF_MAX_LAYERS + 1]; // LDS offsets of the tangent images tau_1..tau_{L-1} (tau_0 is the eps image)
     int c_off, SWC;                 // 2-layer nets: image of C = W_1 .* W_2^T (P1 x n_in) for the exact trace, -1 if none
     int SX[CNF_MAX_LAYERS + 1];     // row stride of activation region l ([sample][feature])
     int x_off[CNF_MAX_LAYERS + 1];  // LDS offsets (floats) of the activation regions

@@ -35,6 +35,13 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// k_mfma geometry: 2 teams (one per 16-sample column tile) of MF_WPT waves.  4 -> 512 lanes,
+// 2 waves per SIMD, <= 256 VGPRs; 8 -> 1024 lanes, 4 waves per SIMD, <= 128 VGPRs.
+#ifndef MF_WPT
+#define MF_WPT 4
+#endif
+#define MF_KTHREADS (MF_WPT * 128)
+
 struct MfmaArgs {
     int mode;                 // 0: plain RHS (u -> du), 1: probe f(u + h k1) -> Ks[0], 2: Tsit5 step
     int B;
@@ -77,6 +84,8 @@ struct RtLayout {
     __device__ __forceinline__ int x_off(int l) const { return m.x_off[l]; }
     __device__ __forceinline__ int img_floats() const { return m.core_img; }
     __device__ __forceinline__ bool wlds() const { return m.wlds != 0; }
+    __device__ __forceinline__ bool jvp() const { return m.jvp != 0; }
+    __device__ __forceinline__ int tx_off(int l) const { return m.tx_off[l]; }
     __device__ __forceinline__ int SWT(int l) const { return m.SWT[l]; }
     __device__ __forceinline__ int wt_off(int l) const { return m.wt_off[l]; }
     __device__ __forceinline__ int eps_off() const { return m.eps_off; }
@@ -112,6 +121,8 @@ struct StLayoutX {
         return off;
     }
     __host__ __device__ static constexpr bool wlds() { return WLDS; }
+    __host__ __device__ static constexpr bool jvp() { return false; }
+    __host__ __device__ static constexpr int tx_off(int) { return 0; }
     __host__ __device__ static constexpr int SWT(int l) { return sw_of(pd(l + 1)); }
     __host__ __device__ static constexpr int wt_off(int l) {            // transposed images (WLDS == false)
         int off = (b_off(kL) + 3) & ~3;
@@ -130,7 +141,7 @@ struct StLayoutX {
     __host__ __device__ static constexpr int du_off() { return eps_off() + MF_NB * sx_of(pd(0)); }
     __host__ __device__ static constexpr int red_off() { return du_off() + MF_NB * sx_of(pd(0)); }
     __host__ __device__ static constexpr int red_floats() {
-        return 3 * (pd(0) / 16) * MF_NB < 16 ? 16 : 3 * (pd(0) / 16) * MF_NB;
+        return 3 * (pd(0) / 16) * MF_NB < 256 ? 256 : 3 * (pd(0) / 16) * MF_NB;
     }
     __host__ __device__ static constexpr int bar_off() { return red_off() + red_floats(); }
     __host__ __device__ static constexpr int total_floats() { return bar_off() + 16; }
@@ -396,7 +407,7 @@ __device__ __forceinline__ void team_barrier(unsigned* cnt, unsigned& gen, int l
     __syncthreads();
     return;
 #endif
-    gen += 4;
+    gen += MF_WPT;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // my LDS writes are done
     if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     int spins = 0;
@@ -492,16 +503,77 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
     // LDS) the HBM/L2-resident image, with a row-major transposed copy for the reverse sweep
     // team = column tile; the feature-group index is rotated by 2 for team 1 so that the
     // narrow layers (fewer than 4 output tiles) of the two teams land on different SIMDs
-    const int s = lane & 15, q = lane >> 4, team = wave >> 2, fg = (wave + 2 * team) & 3;
+    const int s = lane & 15, q = lane >> 4, team = wave / MF_WPT, fg = (wave + (MF_WPT / 2) * team) % MF_WPT;
     const int row = 16 * team + s;
+    if constexpr (!LY::kStatic) {
+        if (ly.jvp() && !cimg) {
+            // ---- forward-mode sweep (DIJacVecMatrixMode, src/icnf.jl:384-420): h_l and
+            // tau_l = sigma'_l .* (W_l tau_{l-1}) side by side, tau_0 = eps; no reverse sweep.
+            // Same row fragments of W_l against two B images.
+            const int L = ly.L(), nt0 = ly.P(0) >> 4, n_in = ly.n_in();
+            for (int l = 0; l < L; ++l) {
+                const int ntiles = ly.P(l + 1) >> 4, SW = ly.SW(l), U = ly.P(l) >> 4;
+                const float* xh = lds + ly.x_off(l) + row * ly.SX(l) + 4 * q;
+                const float* xt = lds + (l == 0 ? ly.eps_off() : ly.tx_off(l)) + row * ly.SX(l) + 4 * q;
+                const float* W = wimg + ly.w_off(l);
+                const bool last = l == L - 1;
+                const int act = ly.act(l);
+                for (int t0 = fg; t0 < ntiles; t0 += 2 * MF_WPT) {
+                    const int t1 = t0 + MF_WPT;
+                    const bool two = t1 < ntiles;
+                    f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = ah0, at0 = ah0, at1 = ah0;
+                    const float* wa0 = W + (16 * t0 + s) * SW + 4 * q;
+                    const float* wa1 = W + (16 * t1 + s) * SW + 4 * q;
+                    if (ly.wlds()) {
+                        if (two) { gemm_fwd<2>(ah0, ah1, U, xh, wa0, wa1); gemm_fwd<2>(at0, at1, U, xt, wa0, wa1); }
+                        else { gemm_fwd<1>(ah0, ah1, U, xh, wa0, wa1); ah0 += ah1; gemm_fwd<1>(at0, at1, U, xt, wa0, wa1); at0 += at1; }
+                    } else {
+                        if (two) { gemm_fwd<2, 4>(ah0, ah1, U, xh, wa0, wa1); gemm_fwd<2, 4>(at0, at1, U, xt, wa0, wa1); }
+                        else { gemm_fwd<1, 4>(ah0, ah1, U, xh, wa0, wa1); ah0 += ah1; gemm_fwd<1, 4>(at0, at1, U, xt, wa0, wa1); at0 += at1; }
+                    }
+                    for (int n = 0; n < (two ? 2 : 1); ++n) {
+                        const int ot = n ? t1 : t0;
+                        const f32x4 ah = n ? ah1 : ah0, at = n ? at1 : at0;
+                        const int r0 = 16 * ot + 4 * q;
+                        const f32x4 bv = *(const f32x4*)(wimg + ly.b_off(l) + r0);
+                        f32x4 h, d;
+                        act4(act, ah + bv, h, d);
+                        const f32x4 tau = d * at;
+                        if (!last) {
+                            *(f32x4*)(lds + ly.x_off(l + 1) + row * ly.SX(l + 1) + r0) = h;
+                            *(f32x4*)(lds + ly.tx_off(l + 1) + row * ly.SX(l + 1) + r0) = tau;
+                        } else {
+                            const f32x4 ev = *(const f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r0);
+                            const f32x4 zd = {r0 + 0 < n_in ? h.x : 0.f, r0 + 1 < n_in ? h.y : 0.f,
+                                              r0 + 2 < n_in ? h.z : 0.f, r0 + 3 < n_in ? h.w : 0.f};
+                            const f32x4 tm = {r0 + 0 < n_in ? tau.x : 0.f, r0 + 1 < n_in ? tau.y : 0.f,
+                                              r0 + 2 < n_in ? tau.z : 0.f, r0 + 3 < n_in ? tau.w : 0.f};
+                            if (n) zd1 = zd; else zd0 = zd;
+                            const float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
+                            const float ld = quad_sum(-(ev.x * tm.x + ev.y * tm.y + ev.z * tm.z + ev.w * tm.w));   // icnf.jl:404
+                            const float n2 = quad_sum(tm.x * tm.x + tm.y * tm.y + tm.z * tm.z + tm.w * tm.w);      // icnf.jl:413
+                            if (q == 0) {
+                                lds[ly.red_off() + ot * MF_NB + row] = e2;
+                                lds[ly.red_off() + (nt0 + ot) * MF_NB + row] = ld;
+                                lds[ly.red_off() + (2 * nt0 + ot) * MF_NB + row] = n2;
+                            }
+                        }
+                    }
+                }
+                if (last) after_zdot();
+                team_barrier(bar, gen, lane);
+            }
+            return;
+        }
+    }
     // ---- forward ----
     for_layers_up(ly, [&](auto l) {
         const int ntiles = ly.P(l + 1) >> 4, SW = ly.SW(l);
         const float* xb = lds + ly.x_off(l) + row * ly.SX(l) + 4 * q;
         const float* W = wimg + ly.w_off(l);
         const bool last = l == ly.L() - 1;
-        for (int t0 = fg; t0 < ntiles; t0 += 8) {
-            const int t1 = t0 + 4;
+        for (int t0 = fg; t0 < ntiles; t0 += 2 * MF_WPT) {
+            const int t1 = t0 + MF_WPT;
             const bool two = t1 < ntiles;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* wa0 = W + (16 * t0 + s) * SW + 4 * q;
@@ -546,8 +618,8 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
         const float* gb = lds + ly.x_off(2) + row * ly.SX(2) + 4 * q;
         const int pact = ly.act(0);
         float trp = 0.f;
-        for (int t0 = fg; t0 < ntiles; t0 += 8) {
-            const int t1 = t0 + 4;
+        for (int t0 = fg; t0 < ntiles; t0 += 2 * MF_WPT) {
+            const int t1 = t0 + MF_WPT;
             const bool two = t1 < ntiles;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* ra = cimg + (16 * t0 + s) * SWC + 4 * q;
@@ -573,8 +645,8 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
         const int ntiles = ly.P(l) >> 4, SW = ly.SW(l);
         const float* gb = lds + ly.x_off(l + 1) + row * ly.SX(l + 1) + 4 * q;
         const float* W = wimg + ly.w_off(l);
-        for (int t0 = fg; t0 < ntiles; t0 += 8) {
-            const int t1 = t0 + 4;
+        for (int t0 = fg; t0 < ntiles; t0 += 2 * MF_WPT) {
+            const int t1 = t0 + MF_WPT;
             const bool two = t1 < ntiles;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* wc0 = W + (4 * q) * SW + 16 * t0 + s;
@@ -687,7 +759,7 @@ __device__ __forceinline__ void err_acc(float& errsum, float& badcnt, const f32x
 // STEP = true: one Tsit5 step attempt (mode 2); STEP = false: one RHS evaluation (modes 0, 1).
 // Two instantiations so that profiles name the step kernel and the plain RHS kernel apart.
 template <class LY, bool STEP>
-__global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
+__global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StepState* st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -703,7 +775,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
     float cp0 = 0.f, cp1 = 0.f;
     if (STEP && a.apply_ctrl) {
         const int np = st->n_partials;
-        for (int i = tid; i < np; i += MF_THREADS) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
+        for (int i = tid; i < np; i += MF_KTHREADS) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
     }
 
     // weights + biases -> LDS (once per workgroup; 4 x 16 B in flight per lane), the rest of
@@ -712,18 +784,18 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
     {
         const int n = ly.wlds() ? ly.img_floats() : 0;
         int i = tid * 4;
-        for (; i + 3 * MF_THREADS * 4 < n; i += 4 * MF_THREADS * 4) {
+        for (; i + 3 * MF_KTHREADS * 4 < n; i += 4 * MF_KTHREADS * 4) {
             const f32x4 v0 = *(const f32x4*)(a.img + i);
-            const f32x4 v1 = *(const f32x4*)(a.img + i + MF_THREADS * 4);
-            const f32x4 v2 = *(const f32x4*)(a.img + i + 2 * MF_THREADS * 4);
-            const f32x4 v3 = *(const f32x4*)(a.img + i + 3 * MF_THREADS * 4);
+            const f32x4 v1 = *(const f32x4*)(a.img + i + MF_KTHREADS * 4);
+            const f32x4 v2 = *(const f32x4*)(a.img + i + 2 * MF_KTHREADS * 4);
+            const f32x4 v3 = *(const f32x4*)(a.img + i + 3 * MF_KTHREADS * 4);
             *(f32x4*)(lds + i) = v0;
-            *(f32x4*)(lds + i + MF_THREADS * 4) = v1;
-            *(f32x4*)(lds + i + 2 * MF_THREADS * 4) = v2;
-            *(f32x4*)(lds + i + 3 * MF_THREADS * 4) = v3;
+            *(f32x4*)(lds + i + MF_KTHREADS * 4) = v1;
+            *(f32x4*)(lds + i + 2 * MF_KTHREADS * 4) = v2;
+            *(f32x4*)(lds + i + 3 * MF_KTHREADS * 4) = v3;
         }
-        for (; i < n; i += MF_THREADS * 4) *(f32x4*)(lds + i) = *(const f32x4*)(a.img + i);
-        for (int z = n + tid * 4; z < ly.total_floats(); z += MF_THREADS * 4)
+        for (; i < n; i += MF_KTHREADS * 4) *(f32x4*)(lds + i) = *(const f32x4*)(a.img + i);
+        for (int z = n + tid * 4; z < ly.total_floats(); z += MF_KTHREADS * 4)
             *(f32x4*)(lds + z) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
@@ -737,11 +809,11 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
         __syncthreads();                          // zero fill done before the scratch is used
         for (int off = 32; off > 0; off >>= 1) { cp0 += __shfl_down(cp0, off, 64); cp1 += __shfl_down(cp1, off, 64); }
         float* red = lds + ly.red_off();
-        if (lane == 0) { red[wave] = cp0; red[8 + wave] = cp1; }
+        if (lane == 0) { red[wave] = cp0; red[16 + wave] = cp1; }
         __syncthreads();
         if (tid == 0) {
             float p0 = 0.f, p1 = 0.f;
-            for (int w = 0; w < MF_THREADS / 64; ++w) { p0 += red[w]; p1 += red[8 + w]; }
+            for (int w = 0; w < MF_KTHREADS / 64; ++w) { p0 += red[w]; p1 += red[16 + w]; }
             StepState ns = *st;
             ctrl_after_step(&ns, p0, p1, a.n_total);
             if (blockIdx.x == 0) *a.st_out = ns;
@@ -756,13 +828,13 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
         cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol;
     }
 
-    constexpr int TT = MF_THREADS / 2, TNB = MF_NB / 2;
-    const int team = wave >> 2, tt = tid & (TT - 1);
-    const int s = lane & 15, q = lane >> 4, fg = (wave + 2 * team) & 3;
+    constexpr int TT = MF_KTHREADS / 2, TNB = MF_NB / 2;
+    const int team = wave / MF_WPT, tt = tid & (TT - 1);
+    const int s = lane & 15, q = lane >> 4, fg = (wave + (MF_WPT / 2) * team) % MF_WPT;
     const int nt0 = ly.P(0) >> 4;
-    const bool own0 = fg < nt0, own1 = fg + 4 < nt0;      // z-row tiles fg, fg+4
+    const bool own0 = fg < nt0, own1 = fg + MF_WPT < nt0; // z-row tiles fg, fg+MF_WPT
     const bool sown = fg == 0 && q == 0;                  // scalar rows of sample s
-    const int r00 = 16 * fg + 4 * q, r01 = r00 + 64;      // first owned row of each tile
+    const int r00 = 16 * fg + 4 * q, r01 = r00 + 16 * MF_WPT;   // first owned row of each tile
     const int nv0 = own0 ? n_in - r00 : 0, nv1 = own1 ? n_in - r01 : 0;   // valid rows (may be <= 0 or > 4)
     const int row = TNB * team + s;
     const float* Uin = mode == 0 ? a.u : a.U[cur];
@@ -826,7 +898,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
         auto read_scalars = [&]() {
             if (a.test) {       // exact trace: 4 per-wave partials of -tr J
                 float ld = 0.f;
-                for (int w = 0; w < 4; ++w) ld += lds[ly.red_off() + w * MF_NB + row];
+                for (int w = 0; w < MF_WPT; ++w) ld += lds[ly.red_off() + w * MF_NB + row];
                 return f32x4{ld, 0.f, 0.f, 0.f};
             }
             float ld = 0.f, e2 = 0.f, n2 = 0.f;
@@ -901,11 +973,11 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma(LY ly, MfmaArgs a) {
             errsum += __shfl_down(errsum, off, 64);
             badcnt += __shfl_down(badcnt, off, 64);
         }
-        if (lane == 0) { lds[ly.red_off() + wave] = errsum; lds[ly.red_off() + 8 + wave] = badcnt; }
+        if (lane == 0) { lds[ly.red_off() + wave] = errsum; lds[ly.red_off() + 16 + wave] = badcnt; }
         __syncthreads();
         if (tid == 0) {
             float e = 0.f, b = 0.f;
-            for (int w = 0; w < MF_THREADS / 64; ++w) { e += lds[ly.red_off() + w]; b += lds[ly.red_off() + 8 + w]; }
+            for (int w = 0; w < MF_KTHREADS / 64; ++w) { e += lds[ly.red_off() + w]; b += lds[ly.red_off() + 16 + w]; }
             a.partials[2 * blockIdx.x] = e;
             a.partials[2 * blockIdx.x + 1] = b;
         }
@@ -1909,6 +1981,7 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     for (int l = 0; l < nd.n_layers; ++l) { ly.b_off[l] = off; off += ly.P[l + 1]; }
     ly.img_floats = (off + 3) & ~3;
     ly.wlds = 1;
+    ly.jvp = nd.jvp;
     auto place_lds = [&](int start) {
         int o = start;
         for (int l = 0; l <= nd.n_layers; ++l) {
@@ -1918,9 +1991,11 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
         }
         ly.eps_off = o; o += MF_NB * ly.SX[0];
         ly.du_off = o;  o += MF_NB * ly.SX[0];
+        if (ly.jvp)
+            for (int l = 1; l < nd.n_layers; ++l) { ly.tx_off[l] = o; o += MF_NB * ly.SX[l]; }
         ly.red_off = o;
         int red = 3 * (ly.P[0] >> 4) * MF_NB;
-        o += red < 16 ? 16 : red;
+        o += red < 256 ? 256 : red;
         o += 16;                      // team-barrier counters / controller scratch
         ly.total_floats = o;
     };
@@ -1951,8 +2026,8 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     ly.ept = 0;
     if ((size_t)ly.total_floats * sizeof(float) > MF_LDS_BYTES) return;   // activations alone exceed LDS
     if (ly.P[0] > 128) return;                                             // state tiles fg, fg+4 only
-    if (nd.jvp) return;                                                    // forward-mode sweep: generic path
     p.variant = 1;
+    if (nd.jvp) return;                  // forward-mode sweep: run-time-layout kernel only
     // experimental schedules for the static shapes (kept for A/B measurements)
     const char* sch = getenv("CNF_MFMA_SCHEDULE");
     p.schedule = sch ? atoi(sch) : 0;
@@ -2023,8 +2098,8 @@ static void launch_static(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipSt
     LY ly;
     ly.n_in_ = p.ly.n_in; ly.norm_z_ = p.ly.norm_z; ly.norm_j_ = p.ly.norm_j;
     const size_t shm = (size_t)LY::total_floats() * sizeof(float);
-    if (a.mode == 2) hipLaunchKernelGGL((k_mfma<LY, true>), grid, dim3(MF_THREADS), shm, s, ly, a);
-    else hipLaunchKernelGGL((k_mfma<LY, false>), grid, dim3(MF_THREADS), shm, s, ly, a);
+    if (a.mode == 2) hipLaunchKernelGGL((k_mfma<LY, true>), grid, dim3(MF_KTHREADS), shm, s, ly, a);
+    else hipLaunchKernelGGL((k_mfma<LY, false>), grid, dim3(MF_KTHREADS), shm, s, ly, a);
 }
 template <class FS>
 static void launch_fused(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStream_t s) {
@@ -2043,7 +2118,7 @@ static void launch_fused(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStr
 static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
     MfmaArgs a = a0;
     if (a.test) { a.cimg = p.d_img + p.ly.c_off; a.SWC = p.ly.SWC; }
-    const dim3 grid(mfma_grid_for(a.B)), block(MF_THREADS);
+    const dim3 grid(mfma_grid_for(a.B)), block(MF_KTHREADS);
     const size_t shm = (size_t)p.ly.total_floats * sizeof(float);
     if (a.test && p.variant != 5) {
         // exact trace: the run-time-layout kernel (the static BASELINE shapes 1-3 are TrainMode kernels)

@@ -29,8 +29,11 @@ for i in which:
     rng = np.random.default_rng(i)
     flat = O.glorot_params(cfg.net, rng, np.float32)
     modes = [("train", True)] if train else [("test", False), ("train", True)]
+    if i in (3, 5):
+        modes.append(("train-jvp", True))
     for mname, tr in modes:
-        icnf = make_icnf(cnf, cfg, kernel="auto")
+        cfg.use_jvp = mname == "train-jvp"
+        icnf = make_icnf(cnf, cfg, jvp=cfg.use_jvp, kernel="auto")
         icnf.set_params(flat)
         l, h = _lib.lib(), icnf.handle()
         D = cfg.D(tr)
