@@ -4,10 +4,11 @@ ABI (``libcnfhip.so``, ``include/cnfhip.h``) plus this thin host mirror of the r
 ``construct`` / ``inference`` / ``loss`` / ``augmented_f`` / ``ICNFDist`` surface."""
 from . import _lib
 from ._lib import CNFError, build
-from .base_icnf import (ICNF, ODEProblem, base_sol, construct, inference, inference_prob,
+from .base_icnf import (ICNF, ODEProblem, base_sol, construct, generate, generate_prob, generate_sol,
+                        inference, inference_prob,
                         inference_sol, loss, loss_from_sums, loss_sums, n_augment,
                         n_augment_input, steer_tspan)
-from .dist import ICNFDist, logpdf, pdf
+from .dist import ICNFDist, logpdf, pdf, rand
 from .icnf import augmented_f
 from .layers import Chain, Dense, setup
 from .types import (FFJORD, RNODE, CondFFJORD, CondPlanar, CondRNODE, HIPJacVecMatrixMode,

@@ -353,6 +353,44 @@ def _post(icnf, mode, fsol: _Buf):
     return logpx, (r[0], r[1], r[2])
 
 
+def generate_prob(icnf: ICNF, mode, ps, st, n: int, *, z0=None, eps=None, device_arrays=False) -> ODEProblem:
+    """src/base_icnf.jl:358-380 (first row of SURVEY.md 8f): the sampling problem -- the same
+    right-hand side integrated over ``reverse(tspan)`` from a draw of the base distribution.
+    ``z0`` ((nvars+naugs) x n) and ``eps`` may be supplied to make the call deterministic;
+    by default both are drawn from icnf.rng (basedist / epsdist are N(0, I), base_icnf.jl:16-25)."""
+    m = _mode_id(mode)
+    n_in = icnf.nvars + n_augment_input(icnf)
+    D = n_in + 1 + n_augment(icnf, mode)
+    icnf.set_params(ps)
+    if z0 is None:
+        z0 = icnf.rng.standard_normal((n, n_in)).astype(np.float32).T
+    zb = _as_colmajor(z0, n_in, "z0")
+    if zb.B != n:
+        raise ValueError("z0 must have n columns")
+    if eps is None:
+        eb = draw_eps(icnf, zb, n)
+    else:
+        eb = _as_colmajor(eps, n_in, "eps")
+    u0 = _empty_like(zb, D, n)
+    v = u0.arr.view(n, D) if u0.torch is not None else u0.arr.reshape(n, D)
+    src = zb.arr.view(n, n_in) if zb.torch is not None else zb.arr.reshape(n, n_in)
+    v[:, :n_in] = src
+    v[:, n_in:] = 0.0                                   # zrs = zeros(n_aug + 1, n)  (:367-368)
+    t0, t1 = steer_tspan(icnf, mode)
+    return ODEProblem(icnf, mode, u0, eb, (t1, t0), ps)  # reverse(tspan)  (:377)
+
+
+def generate_sol(icnf: ICNF, mode, prob: ODEProblem):
+    """src/base_icnf.jl:202-211: rows 1..nvars of the final state."""
+    fsol = base_sol(icnf, prob)
+    return fsol.view()[: icnf.nvars, :]
+
+
+def generate(icnf: ICNF, mode, ps, st=None, n: int = 1, *, z0=None, eps=None):
+    """src/base_icnf.jl:447-455."""
+    return generate_sol(icnf, mode, generate_prob(icnf, mode, ps, st, n, z0=z0, eps=eps))
+
+
 def inference(icnf: ICNF, mode, xs, ps, st=None, *, eps=None):
     """src/base_icnf.jl:407-415."""
     prob = inference_prob(icnf, mode, xs, ps, st, eps=eps)

@@ -8,7 +8,7 @@ from typing import Any
 
 import numpy as np
 
-from .base_icnf import ICNF, _is_torch, inference
+from .base_icnf import ICNF, _is_torch, generate, inference
 
 
 @dataclass
@@ -32,3 +32,10 @@ def logpdf(d: ICNFDist, A, *, eps=None):
 def pdf(d: ICNFDist, A, *, eps=None):
     lp = logpdf(d, A, eps=eps)
     return lp.exp() if _is_torch(lp) else np.exp(lp)
+
+
+def rand(d: ICNFDist, n: int, *, z0=None, eps=None):
+    """``rand(d, n)`` (src/exts/dist_ext/core_icnf.jl:46-58): ``generate(d.m, d.mode, d.ps, d.st, n)``."""
+    if not isinstance(d.m, ICNF):
+        raise NotImplementedError("Not Implemented")
+    return generate(d.m, d.mode, d.ps, d.st, n, z0=z0, eps=eps)

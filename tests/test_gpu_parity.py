@@ -358,3 +358,37 @@ def test_experimental_mfma_schedules_keep_parity(schedule, monkeypatch):
         logpx, _ = cnf.inference(icnf, cnf.TrainMode(), g["xs"], g["flat"], {}, eps=g["eps"])
         assert_parity(logpx, g["logpx_train_vjp"], f"{name} schedule {schedule} logpx")
         icnf.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_generate_matches_backward_oracle_and_inverts_inference(kernel):
+    """`generate` = the same RHS over reverse(tspan) from a base-distribution
+    draw (src/base_icnf.jl:358-380, :202-211).  Checked against the float64 oracle integrated
+    backwards, and as the inverse map of `inference` (x -> z -> x)."""
+    cfg, _, _ = O.baseline_cfg(2)
+    rng = np.random.default_rng(17)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.05)
+    n = 96
+    kw = dict(adaptive=False, dt=1 / 32)
+    icnf = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=kw)
+    if not _supported(icnf, cnf.TestMode(), n):
+        pytest.skip("no MFMA kernel")
+    z0 = rng.standard_normal((cfg.n_in, n)).astype(np.float32)
+    xs = cnf.generate(icnf, cnf.TestMode(), flat, {}, n, z0=z0)
+    assert xs.shape == (cfg.nvars, n)
+    u0 = np.vstack([z0, np.zeros((1, n), np.float32)]).astype(np.float64)
+    ref, _ = O.tsit5_solve(cfg.rhs(flat.astype(np.float64), None, False), u0, 1.0, 0.0, dt=1 / 32, adaptive=False)
+    assert_parity(xs, ref[: cfg.nvars], "generate vs backward oracle")
+    # default draw: right shape, finite, reproducible from the rng seed
+    a = cnf.rand(cnf.ICNFDist(make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=kw, rng=5), cnf.TestMode(), flat, {}), 40)
+    b = cnf.rand(cnf.ICNFDist(make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=kw, rng=5), cnf.TestMode(), flat, {}), 40)
+    assert a.shape == (cfg.nvars, 40) and np.all(np.isfinite(a)) and np.array_equal(a, b)
+    # without augmentation the flow is a bijection: generate(inference's z) returns x
+    cfg0 = O.Cfg(O.Net((8, 24, 8), (O.ACT_TANH,) * 2), 8, 0, tspan=(0.0, 1.0))
+    flat0 = O.glorot_params(cfg0.net, rng, np.float32, 0.05)
+    ic0 = make_icnf(cnf, cfg0, kernel=kernel, sol_kwargs=dict(adaptive=False, dt=1 / 64))
+    x = rng.standard_normal((8, 50)).astype(np.float32)
+    prob = cnf.inference_prob(ic0, cnf.TestMode(), x, flat0, {})
+    z = cnf.base_sol(ic0, prob).view()[:8]
+    back = cnf.generate(ic0, cnf.TestMode(), flat0, {}, 50, z0=np.array(z))
+    assert np.max(np.abs(back - x)) < 5e-5
