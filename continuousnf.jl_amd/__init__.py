@@ -8,9 +8,9 @@ from .base_icnf import (ICNF, ODEProblem, base_sol, construct, generate, generat
                         inference, inference_prob,
                         inference_sol, loss, loss_from_sums, loss_sums, n_augment,
                         n_augment_input, steer_tspan)
-from .dist import ICNFDist, logpdf, pdf, rand
+from .dist import CondICNFDist, ICNFDist, logpdf, pdf, rand
 from .icnf import augmented_f
-from .layers import Chain, Dense, setup
+from .layers import Chain, CondLayer, Dense, setup
 from .types import (FFJORD, RNODE, CondFFJORD, CondPlanar, CondRNODE, HIPJacVecMatrixMode,
                     HIPMatrixMode, HIPVecJacMatrixMode, Planar, TestMode, TrainMode)
 from . import parallel

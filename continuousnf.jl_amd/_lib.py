@@ -25,7 +25,7 @@ class cnf_config(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("dims", C.POINTER(C.c_int32)),
                 ("acts", C.POINTER(C.c_int32)), ("nvars", C.c_int32), ("naugs", C.c_int32),
                 ("ad", C.c_int32), ("lambda1", C.c_float), ("lambda2", C.c_float),
-                ("lambda3", C.c_float), ("device", C.c_int32)]
+                ("lambda3", C.c_float), ("device", C.c_int32), ("n_cond", C.c_int32)]
 
 
 class cnf_solve_opts(C.Structure):
@@ -49,6 +49,8 @@ _SIGNATURES = {
     "cnf_destroy": (C.c_int, [C.c_void_p]),
     "cnf_set_params_host": (C.c_int, [C.c_void_p, _fp, C.c_size_t]),
     "cnf_set_params": (C.c_int, [C.c_void_p, _fp, C.c_size_t, C.c_void_p]),
+    "cnf_set_cond": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_void_p]),
+    "cnf_set_cond_host": (C.c_int, [C.c_void_p, _fp, C.c_int]),
     "cnf_rhs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, C.c_void_p]),
     "cnf_rhs_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int]),
     "cnf_solve_tsit5": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int,

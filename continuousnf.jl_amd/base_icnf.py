@@ -14,8 +14,8 @@ import numpy as np
 
 from . import _lib
 from .layers import Chain
-from .types import (AbstractICNF, FFJORD, RNODE, HIPMatrixMode, HIPVecJacMatrixMode, Mode,
-                    TestMode, TrainMode, _OutOfScope)
+from .types import (AbstractICNF, CondFFJORD, CondRNODE, FFJORD, RNODE, HIPMatrixMode, HIPVecJacMatrixMode,
+                    Mode, TestMode, TrainMode, _OutOfScope)
 
 _KERNEL = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "mfma": _lib.KERNEL_MFMA}
 
@@ -107,7 +107,10 @@ class ICNF:
     lambda2: float
     lambda3: float
     device: int = 0
+    cond: bool = False          # COND type parameter (src/base_icnf.jl:44)
+    n_cond: int = 0             # rows of ys = nn input size - (nvars + naugmented)
     _handle: Any = field(default=None, repr=False)
+    _cond_id: Any = field(default=None, repr=False)
     _params_id: Any = field(default=None, repr=False)
 
     # type parameters of the reference struct (src/base_icnf.jl:42-51)
@@ -129,7 +132,7 @@ class ICNF:
             acts = (C.c_int32 * len(self.nn.acts))(*self.nn.acts)
             cfg = _lib.cnf_config(len(self.nn.layers), dims, acts, self.nvars, self.naugmented,
                                   self.compute_mode.ad, self.lambda1, self.lambda2, self.lambda3,
-                                  self.device)
+                                  self.device, self.n_cond)
             h = C.c_void_p()
             _lib.check(l.cnf_create(C.byref(h), C.byref(cfg)))
             self._handle = h
@@ -140,6 +143,7 @@ class ICNF:
             _lib.lib().cnf_destroy(self._handle)
             self._handle = None
             self._params_id = None
+            self._cond_id = None
 
     def __del__(self):
         try:
@@ -169,6 +173,29 @@ class ICNF:
                 return
             _lib.check(l.cnf_set_params_host(h, p.ctypes.data, p.size), h)
         self._params_id = key
+        self._cond_id = None        # the conditioning bias depends on the parameters
+
+    def set_cond(self, ys, B):
+        """Hand ``ys`` (n_cond x B) to the device (cnf_set_cond) unless it is already resident."""
+        if not self.cond:
+            if ys is not None:
+                raise ValueError("ys given to an unconditional model")
+            return
+        if ys is None:
+            raise ValueError("conditional model: ys is required")
+        yb = _as_colmajor(ys, self.n_cond, "ys")
+        if yb.B != B:
+            raise ValueError("ys must have one column per sample")
+        key = ("t", yb.arr.data_ptr(), yb.arr._version, B) if yb.torch is not None else ("n", yb.arr.tobytes(), B)
+        if key == self._cond_id:
+            return
+        l, h = _lib.lib(), self.handle()
+        if yb.torch is not None:
+            _lib.check(l.cnf_set_cond(h, yb.ptr, B, _stream(yb)), h)
+            self._keep_ys = yb.arr
+        else:
+            _lib.check(l.cnf_set_cond_host(h, yb.ptr, B), h)
+        self._cond_id = key
 
 
 def n_augment(icnf: ICNF, mode) -> int:
@@ -198,8 +225,10 @@ def construct(aicnf, nn: Chain, nvars: int, naugmented: int = 0, *, data_type=np
         raise TypeError(f"unknown keyword(s) {sorted(kw)}")
     if not (isinstance(aicnf, type) and issubclass(aicnf, AbstractICNF)):
         raise TypeError("first argument must be a model tag such as RNODE or FFJORD")
-    if issubclass(aicnf, _OutOfScope) or cond:
-        raise NotImplementedError(f"{aicnf.__name__}: only the MLP hot path (RNODE, FFJORD) is built")
+    if issubclass(aicnf, _OutOfScope):
+        raise NotImplementedError(f"{aicnf.__name__}: only the MLP vector fields are built (planar layers are not)")
+    if cond is None:
+        cond = issubclass(aicnf, (CondRNODE, CondFFJORD))          # src/base_icnf.jl:14
     if np.dtype(data_type) != np.float32:
         raise NotImplementedError("the HIP backend computes in Float32 (the reference default, base_icnf.jl:6)")
     if compute_mode is None:
@@ -207,9 +236,10 @@ def construct(aicnf, nn: Chain, nvars: int, naugmented: int = 0, *, data_type=np
     if not isinstance(compute_mode, HIPMatrixMode):
         raise TypeError("compute_mode must be HIPVecJacMatrixMode() or HIPJacVecMatrixMode()")
     n_in = nvars + naugmented
-    if nn.dims[0] != n_in or nn.dims[-1] != n_in:
-        raise ValueError(f"nn must map {n_in} -> {n_in} (nvars + naugmented)")
-    rn = issubclass(aicnf, RNODE)
+    n_cond = nn.dims[0] - n_in if cond else 0
+    if nn.dims[-1] != n_in or (not cond and nn.dims[0] != n_in) or (cond and n_cond < 1):
+        raise ValueError(f"nn must map {n_in}{' + n_cond' if cond else ''} -> {n_in} (nvars + naugmented)")
+    rn = issubclass(aicnf, (RNODE, CondRNODE))
     if lambda1 is None: lambda1 = 1e-2 if rn else 0.0
     if lambda2 is None: lambda2 = 1e-2 if rn else 0.0
     if rng is None:
@@ -219,7 +249,7 @@ def construct(aicnf, nn: Chain, nvars: int, naugmented: int = 0, *, data_type=np
     return ICNF(aicnf, nn, int(nvars), int(naugmented), compute_mode, bool(inplace),
                 (float(tspan[0]), float(tspan[1])), float(steer_rate), dict(sol_kwargs or {}), rng,
                 float(np.float32(lambda1)), float(np.float32(lambda2)), float(np.float32(lambda3)),
-                int(device))
+                int(device), bool(cond), int(n_cond))
 
 
 def steer_tspan(icnf: ICNF, mode):
@@ -256,14 +286,29 @@ def draw_eps(icnf: ICNF, like: _Buf, B: int):
     return _Buf(e, n_in, B, None)
 
 
-def inference_prob(icnf: ICNF, mode, xs, ps, st=None, *, eps=None) -> ODEProblem:
-    """src/base_icnf.jl:266-286.  ``eps`` may be supplied (n_in x B) to make the call
-    deterministic; by default it is drawn from icnf.rng as the reference does."""
+def _split_cond_args(icnf: ICNF, args):
+    """Unconditional: (ps, st);  conditional: (ys, ps, st)  -- the reference's two method
+    families (src/base_icnf.jl:266-286 vs :288-309)."""
+    if icnf.cond:
+        if len(args) < 2:
+            raise TypeError("conditional model: call with (xs, ys, ps, st)")
+        return args[0], args[1], (args[2] if len(args) > 2 else None)
+    if len(args) < 1:
+        raise TypeError("call with (xs, ps, st)")
+    return None, args[0], (args[1] if len(args) > 1 else None)
+
+
+def inference_prob(icnf: ICNF, mode, xs, *args, eps=None) -> ODEProblem:
+    """src/base_icnf.jl:266-286 (``(xs, ps, st)``) and :288-309 (conditional: ``(xs, ys, ps, st)``).
+    ``eps`` may be supplied (n_in x B) to make the call deterministic; by default it is drawn
+    from icnf.rng as the reference does."""
+    ys, ps, st = _split_cond_args(icnf, args)
     m = _mode_id(mode)
     xb = _as_colmajor(xs, icnf.nvars, "xs")
     B = xb.B
     D = icnf.nvars + n_augment_input(icnf) + 1 + n_augment(icnf, mode)
     icnf.set_params(ps)
+    icnf.set_cond(ys, B)
     u0 = _empty_like(xb, D, B)
     if xb.torch is not None:
         _lib.check(_lib.lib().cnf_build_u0(icnf.handle(), m, xb.ptr, u0.ptr, B, _stream(xb)), icnf.handle())
@@ -353,7 +398,7 @@ def _post(icnf, mode, fsol: _Buf):
     return logpx, (r[0], r[1], r[2])
 
 
-def generate_prob(icnf: ICNF, mode, ps, st, n: int, *, z0=None, eps=None, device_arrays=False) -> ODEProblem:
+def generate_prob(icnf: ICNF, mode, ps, st, n: int, *, ys=None, z0=None, eps=None) -> ODEProblem:
     """src/base_icnf.jl:358-380 (first row of SURVEY.md 8f): the sampling problem -- the same
     right-hand side integrated over ``reverse(tspan)`` from a draw of the base distribution.
     ``z0`` ((nvars+naugs) x n) and ``eps`` may be supplied to make the call deterministic;
@@ -362,6 +407,7 @@ def generate_prob(icnf: ICNF, mode, ps, st, n: int, *, z0=None, eps=None, device
     n_in = icnf.nvars + n_augment_input(icnf)
     D = n_in + 1 + n_augment(icnf, mode)
     icnf.set_params(ps)
+    icnf.set_cond(ys, n)
     if z0 is None:
         z0 = icnf.rng.standard_normal((n, n_in)).astype(np.float32).T
     zb = _as_colmajor(z0, n_in, "z0")
@@ -386,24 +432,24 @@ def generate_sol(icnf: ICNF, mode, prob: ODEProblem):
     return fsol.view()[: icnf.nvars, :]
 
 
-def generate(icnf: ICNF, mode, ps, st=None, n: int = 1, *, z0=None, eps=None):
-    """src/base_icnf.jl:447-455."""
-    return generate_sol(icnf, mode, generate_prob(icnf, mode, ps, st, n, z0=z0, eps=eps))
+def generate(icnf: ICNF, mode, ps, st=None, n: int = 1, *, ys=None, z0=None, eps=None):
+    """src/base_icnf.jl:447-455 (conditional: :457-466, ``ys`` as keyword here)."""
+    return generate_sol(icnf, mode, generate_prob(icnf, mode, ps, st, n, ys=ys, z0=z0, eps=eps))
 
 
-def inference(icnf: ICNF, mode, xs, ps, st=None, *, eps=None):
-    """src/base_icnf.jl:407-415."""
-    prob = inference_prob(icnf, mode, xs, ps, st, eps=eps)
+def inference(icnf: ICNF, mode, xs, *args, eps=None):
+    """src/base_icnf.jl:407-415 / :417-426 (conditional: ``inference(icnf, mode, xs, ys, ps, st)``)."""
+    prob = inference_prob(icnf, mode, xs, *args, eps=eps)
     res = inference_sol(icnf, mode, prob)
     icnf.last_stats = prob.stats
     return res
 
 
-def loss(icnf: ICNF, mode, xs, ps, st=None, *, eps=None):
+def loss(icnf: ICNF, mode, xs, *args, eps=None):
     """TrainMode: mean(-logpx + l1 E + l2 n + l3 A) (src/icnf.jl:481-490); otherwise
     -mean(logpx) (src/base_icnf.jl:489-497).  Single process; the sharded form is
     ``parallel.distributed_loss``."""
-    logpx, (E, n, A) = inference(icnf, mode, xs, ps, st, eps=eps)
+    logpx, (E, n, A) = inference(icnf, mode, xs, *args, eps=eps)
     sums = loss_sums(icnf, logpx, (E, n, A))
     return loss_from_sums(icnf, mode, sums)
 

@@ -30,6 +30,8 @@ struct cnf_ctx {
     float* U[2] = {nullptr, nullptr};
     float* K1[2] = {nullptr, nullptr};
     float* Ks[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* d_cond = nullptr;      // conditional models: per-sample first-layer bias [cond_B][cbs]
+    int cond_B = 0, cbs = 0;
     float* tmp_logpx = nullptr;
     float* tmp_regs = nullptr;
     float* partials = nullptr;    // 2 * MAX_PARTIALS floats
@@ -89,7 +91,8 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     if (cfg->nvars < 1 || cfg->naugs < 0) return CNF_ERR_BAD_SHAPE;
     if (cfg->ad != CNF_AD_VJP && cfg->ad != CNF_AD_JVP) return CNF_ERR_BAD_ARG;
     const int n_in = cfg->nvars + cfg->naugs;
-    if (cfg->dims[0] != n_in || cfg->dims[cfg->n_layers] != n_in) return CNF_ERR_BAD_SHAPE;
+    if (cfg->n_cond < 0) return CNF_ERR_BAD_SHAPE;
+    if (cfg->dims[0] != n_in + cfg->n_cond || cfg->dims[cfg->n_layers] != n_in) return CNF_ERR_BAD_SHAPE;
     for (int l = 0; l <= cfg->n_layers; ++l)
         if (cfg->dims[l] < 1 || cfg->dims[l] > 4096) return CNF_ERR_BAD_SHAPE;
     for (int l = 0; l < cfg->n_layers; ++l)
@@ -106,14 +109,16 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     nd.n_layers = cfg->n_layers;
     int off = 0, mx = 0, sum = 0;
     for (int l = 0; l <= cfg->n_layers; ++l) {
-        nd.dims[l] = cfg->dims[l];
-        mx = cfg->dims[l] > mx ? cfg->dims[l] : mx;
-        sum += cfg->dims[l];
+        nd.dims[l] = l == 0 ? n_in : cfg->dims[l];     // the kernels see the z columns only
+        mx = nd.dims[l] > mx ? nd.dims[l] : mx;
+        sum += nd.dims[l];
     }
+    nd.n_cond = cfg->n_cond;
     for (int l = 0; l < cfg->n_layers; ++l) {
         nd.acts[l] = cfg->acts[l];
         nd.w_off[l] = off;
-        off += nd.dims[l] * nd.dims[l + 1];
+        if (l == 0) nd.wy_off = off + n_in * nd.dims[1];
+        off += cfg->dims[l] * nd.dims[l + 1];          // the flat vector holds every column
         nd.b_off[l] = off;
         off += nd.dims[l + 1];
     }
@@ -150,6 +155,7 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     (void)hipSetDevice(h->device);
     mfma_plan_free(h->mfma);
     if (h->d_params) (void)hipFree(h->d_params);
+    if (h->d_cond) (void)hipFree(h->d_cond);
     if (h->arena) (void)hipFree(h->arena);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->partials) (void)hipFree(h->partials);
@@ -170,6 +176,7 @@ extern "C" cnf_status cnf_set_params(cnf_handle h, const float* flat_dev, size_t
     if (ms != CNF_OK) return fail(h, ms, "MFMA weight packing failed");
     HIPCHK(h, hipStreamSynchronize(s));
     h->have_params = true;
+    h->cond_B = 0;       // the conditioning bias depends on W1 and b1
     return CNF_OK;
 }
 
@@ -182,6 +189,7 @@ extern "C" cnf_status cnf_set_params_host(cnf_handle h, const float* flat, size_
     if (ms != CNF_OK) return fail(h, ms, "MFMA weight packing failed");
     HIPCHK(h, hipDeviceSynchronize());
     h->have_params = true;
+    h->cond_B = 0;
     return CNF_OK;
 }
 
@@ -213,7 +221,45 @@ static cnf_status check_call(cnf_handle h, int mode, int B) {
     if (mode != CNF_MODE_TEST && mode != CNF_MODE_TRAIN) return fail(h, CNF_ERR_BAD_ARG, "unknown mode");
     if (B < 0) return fail(h, CNF_ERR_BAD_SHAPE, "negative batch");
     if (!h->have_params) return fail(h, CNF_ERR_NO_PARAMS, "cnf_set_params has not been called");
+    if (h->nd.n_cond > 0 && B > 0 && h->cond_B != B)
+        return fail(h, CNF_ERR_NO_PARAMS, "conditional model: call cnf_set_cond with the ys of this batch first");
+    h->mfma.cond = h->nd.n_cond > 0 ? h->d_cond : nullptr;
+    h->mfma.cbs = h->cbs;
     return CNF_OK;
+}
+
+extern "C" cnf_status cnf_set_cond(cnf_handle h, const float* ys, int B, void* stream) {
+    if (!h) return CNF_ERR_BAD_ARG;
+    if (h->nd.n_cond == 0) return fail(h, CNF_ERR_BAD_ARG, "not a conditional model (n_cond == 0)");
+    if (!h->have_params) return fail(h, CNF_ERR_NO_PARAMS, "cnf_set_params has not been called");
+    if (!ys || B < 1) return fail(h, CNF_ERR_BAD_ARG, "ys must be n_cond x B with B >= 1");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int cbs = (h->nd.dims[1] + 15) & ~15;
+    if (h->cond_B != B || h->cbs != cbs) {
+        HIPCHK(h, hipDeviceSynchronize());
+        if (h->d_cond) { (void)hipFree(h->d_cond); h->d_cond = nullptr; }
+        h->cond_B = 0;
+        HIPCHK(h, hipMalloc(&h->d_cond, (size_t)B * cbs * sizeof(float)));
+        h->cbs = cbs;
+    }
+    launch_cond_bias(h->nd, h->d_params, ys, h->d_cond, cbs, B, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
+    h->cond_B = B;
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_set_cond_host(cnf_handle h, const float* ys, int B) {
+    if (!h) return CNF_ERR_BAD_ARG;
+    if (!ys || B < 1 || h->nd.n_cond == 0) return fail(h, CNF_ERR_BAD_ARG, "bad conditioning input");
+    HIPCHK(h, hipSetDevice(h->device));
+    float* d = nullptr;
+    HIPCHK(h, hipMalloc(&d, (size_t)B * h->nd.n_cond * sizeof(float)));
+    HIPCHK(h, hipMemcpy(d, ys, (size_t)B * h->nd.n_cond * sizeof(float), hipMemcpyHostToDevice));
+    cnf_status s = cnf_set_cond(h, d, B, nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    (void)hipFree(d);
+    if (s == CNF_OK && e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
+    return s;
 }
 
 extern "C" int cnf_kernel_for(cnf_handle h, int mode, int B) {
@@ -279,6 +325,7 @@ extern "C" cnf_status cnf_rhs(cnf_handle h, int mode, int kernel, const float* u
         RhsArgs a{};
         a.st = nullptr; a.B = B; a.S = h->cap_B; a.train = mode == CNF_MODE_TRAIN;
         a.ws = h->ws; a.eps = eps; a.u = u; a.du = du; a.nk = 0;
+        a.cond = h->mfma.cond; a.cbs = h->cbs;
         launch_rhs_generic(h->nd, h->d_params, a, st);
     }
     HIPCHK(h, hipGetLastError());
@@ -318,6 +365,7 @@ static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, i
                                     int nblk, hipStream_t s) {
     RhsArgs a{};
     a.st = h->d_state; a.B = B; a.S = h->cap_B; a.train = train; a.ws = h->ws; a.eps = eps;
+    a.cond = h->mfma.cond; a.cbs = h->cbs;
     for (int i = 0; i < 2; ++i) { a.U[i] = h->U[i]; a.K1[i] = h->K1[i]; }
     for (int i = 0; i < 5; ++i) a.Ks[i] = h->Ks[i];
     for (int stage = 1; stage <= 6; ++stage) {      // computes k_{stage+1}
@@ -397,6 +445,7 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
     } else {
         RhsArgs a{};
         a.B = B; a.S = h->cap_B; a.train = train; a.ws = h->ws; a.eps = eps;
+        a.cond = h->mfma.cond; a.cbs = h->cbs;
         a.u = h->U[0]; a.du = h->K1[0];
         launch_rhs_generic(h->nd, h->d_params, a, st);
     }
@@ -420,6 +469,7 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
         } else {
             RhsArgs a{};
             a.st = h->d_state; a.B = B; a.S = h->cap_B; a.train = train; a.ws = h->ws; a.eps = eps;
+            a.cond = h->mfma.cond; a.cbs = h->cbs;
             for (int i = 0; i < 2; ++i) { a.U[i] = h->U[i]; a.K1[i] = h->K1[i]; }
             for (int i = 0; i < 5; ++i) a.Ks[i] = h->Ks[i];
             a.nk = 1; a.coef[0] = 1.f; a.du = h->Ks[0];

@@ -17,6 +17,9 @@ struct NetDesc {
     int norm_z, norm_j, norm_z_aug; // !iszero(lambda) (src/base_icnf.jl:42-51)
     int jvp;                        // 0: VJP (DIVecJacMatrixMode), 1: JVP (DIJacVecMatrixMode)
     int max_dim, sum_dims;          // max_l dims[l]; sum_{l=0..L} dims[l]
+    int n_cond;                     // conditioning rows; dims[0] stays n_in, the first layer's weight has
+                                    // n_in + n_cond columns (column-major: the z columns come first)
+    int wy_off;                     // float offset of the conditioning columns of layer 0's weight
 };
 
 // Device-resident integrator state: lets the step controller run on the GPU so that a

@@ -119,9 +119,11 @@ k_rhs_generic(NetDesc nd, const float* __restrict__ P, RhsArgs a) {
         float* y = H + (size_t)(hoff + in) * S + b;
         float* dv = Dv + (size_t)(hoff + in) * S + b;
         const int act = nd.acts[l];
+        // conditional models: layer 0 uses the per-sample bias W1[:, n_in:] ys + b1
+        const float* cb = (l == 0 && a.cond) ? a.cond + (size_t)b * a.cbs : nullptr;
         gemv_fwd(W, out, in, x, S, [&](int o, float acc) {
             float h, d;
-            cnf_act(act, acc + bias[o], h, d);
+            cnf_act(act, acc + (cb ? cb[o] : bias[o]), h, d);
             y[(size_t)o * S] = h;
             dv[(size_t)o * S] = d;
         });
@@ -395,6 +397,23 @@ __global__ void k_post(NetDesc nd, int train, const float* __restrict__ fsol,
     regs[2 * (size_t)B + b] = (nd.norm_z_aug && nd.naugs > 0) ? sqrtf(sa) : 0.f;  // :179-187
 }
 
+// conditional models: cond[b][o] = b1[o] + sum_c W1[o, n_in + c] * ys[c, b]   (padded to cbs with 0)
+__global__ void k_cond_bias(NetDesc nd, const float* __restrict__ P, const float* __restrict__ ys,
+                            float* __restrict__ cond, int cbs, int B) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * cbs) return;
+    const int o = (int)(i % cbs);
+    const size_t b = i / cbs;
+    const int out = nd.dims[1];
+    float v = 0.f;
+    if (o < out) {
+        v = P[nd.b_off[0] + o];
+        const float* Wy = P + nd.wy_off;
+        for (int c = 0; c < nd.n_cond; ++c) v = fmaf(Wy[o + (size_t)c * out], ys[b * nd.n_cond + c], v);
+    }
+    cond[i] = v;
+}
+
 // loss sums (src/icnf.jl:489): one block of 1024 lanes, deterministic (fixed lane->entry map,
 // fixed tree); sums5 = (S logpx, S E, S n, S A, B)
 __global__ void __launch_bounds__(1024)
@@ -451,6 +470,11 @@ void launch_post(const NetDesc& nd, int train, const float* fsol, float* logpx, 
                  int B, hipStream_t s) {
     hipLaunchKernelGGL(k_post, dim3((B + 255) / 256), dim3(256), 0, s, nd, train, fsol, logpx,
                        regs, B);
+}
+void launch_cond_bias(const NetDesc& nd, const float* P, const float* ys, float* cond, int cbs, int B,
+                      hipStream_t s) {
+    const size_t n = (size_t)B * cbs;
+    hipLaunchKernelGGL(k_cond_bias, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nd, P, ys, cond, cbs, B);
 }
 void launch_loss_sums(const float* logpx, const float* regs, int B, float* sums5,
                       hipStream_t s) {

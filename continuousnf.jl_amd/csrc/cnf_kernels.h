@@ -21,6 +21,8 @@ struct RhsArgs {
     float* ustage;          // optional: write the stage state here
     int ustage_is_unew;     // write the stage state to U[1-cur] (stage 7: it is u_new)
     int du_is_k7;           // write du to K1[1-cur]
+    const float* cond;      // conditional models: per-sample first-layer bias [B][cbs], else null
+    int cbs;
 };
 
 struct NormArgs {
@@ -42,5 +44,7 @@ void launch_copy_final(const StepState* st, const float* U0, const float* U1, fl
                        size_t n, hipStream_t s);
 void launch_post(const NetDesc& nd, int train, const float* fsol, float* logpx, float* regs,
                  int B, hipStream_t s);
+void launch_cond_bias(const NetDesc& nd, const float* P, const float* ys, float* cond, int cbs, int B,
+                      hipStream_t s);
 void launch_loss_sums(const float* logpx, const float* regs, int B, float* sums5,
                       hipStream_t s);

@@ -39,6 +39,8 @@ struct MfmaPlan {
                                     // 1 fused narrow layers, 2 fused + ping-pong teams (CNF_MFMA_SCHEDULE)
     MfmaLayout ly{};
     float* d_img = nullptr;         // weight+bias image in HBM (LDS order), refreshed by pack
+    const float* cond = nullptr;    // conditional models: per-sample first-layer bias [B][cbs] (owned by the handle)
+    int cbs = 0;
 };
 
 void mfma_plan_init(MfmaPlan& p, const NetDesc& nd);

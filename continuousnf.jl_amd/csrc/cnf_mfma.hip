@@ -54,6 +54,8 @@ struct MfmaArgs {
     const float* partials_in; // mode 2 + apply_ctrl: error partials of the previous attempt
     int apply_ctrl;
     float n_total;            // D * B
+    const float* cond;        // conditional models: per-sample first-layer bias [B][cbs], else null
+    int cbs;
     int test;                 // TestMode: exact trace (2-layer closed form), state rows = n_in + 1
     const float* cimg;        // TestMode: row-major image of C = W_1 .* W_2^T  (P1 x SWC)
     int SWC;
@@ -430,9 +432,11 @@ __device__ __forceinline__ float quad_sum(float v) {     // sum over the 4 lanes
 // |zdot|^2 partial of its 16 rows to RED[0].
 template <class LY>
 __device__ __forceinline__ void fwd_epilogue(const LY& ly, float* lds, const float* wimg, int l, bool last, int ot,
-                                             f32x4 acc, int row, int q, f32x4& zd, bool test = false) {
+                                             f32x4 acc, int row, int q, f32x4& zd, bool test = false,
+                                             const float* cbrow = nullptr) {
     const int r0 = 16 * ot + 4 * q;
-    const f32x4 bv = *(const f32x4*)(wimg + ly.b_off(l) + r0);
+    // conditional models: layer 0 takes this sample's bias W1[:, n_in:] ys + b1
+    const f32x4 bv = (l == 0 && cbrow) ? *(const f32x4*)(cbrow + r0) : *(const f32x4*)(wimg + ly.b_off(l) + r0);
     const int act = ly.act(l);
     float h0, h1, h2, h3, d0, d1, d2, d3;
     act_fast(act, acc.x + bv.x, h0, d0);
@@ -498,7 +502,8 @@ __device__ __forceinline__ void bwd_epilogue(const LY& ly, float* lds, int l, in
 template <class LY, class F>
 __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* wimg, int lane, int wave,
                                          unsigned* bar, unsigned& gen, f32x4& zd0, f32x4& zd1,
-                                         F&& after_zdot, const float* cimg = nullptr, int SWC = 0 STAMP_ARGS) {
+                                         F&& after_zdot, const float* cimg = nullptr, int SWC = 0,
+                                         const float* cbrow = nullptr STAMP_ARGS) {
     // wimg: where the weight image is read from -- the LDS copy, or (networks too large for
     // LDS) the HBM/L2-resident image, with a row-major transposed copy for the reverse sweep
     // team = column tile; the feature-group index is rotated by 2 for team 1 so that the
@@ -535,7 +540,8 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
                         const int ot = n ? t1 : t0;
                         const f32x4 ah = n ? ah1 : ah0, at = n ? at1 : at0;
                         const int r0 = 16 * ot + 4 * q;
-                        const f32x4 bv = *(const f32x4*)(wimg + ly.b_off(l) + r0);
+                        const f32x4 bv = (l == 0 && cbrow) ? *(const f32x4*)(cbrow + r0)
+                                                           : *(const f32x4*)(wimg + ly.b_off(l) + r0);
                         f32x4 h, d;
                         act4(act, ah + bv, h, d);
                         const f32x4 tau = d * at;
@@ -599,8 +605,8 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
                 }
             }
             STAMP(16 + 3 * (int)l);
-            fwd_epilogue(ly, lds, wimg, l, last, t0, acc0, row, q, zd0, cimg != nullptr);
-            if (two) fwd_epilogue(ly, lds, wimg, l, last, t1, acc1, row, q, zd1, cimg != nullptr);
+            fwd_epilogue(ly, lds, wimg, l, last, t0, acc0, row, q, zd0, cimg != nullptr, cbrow);
+            if (two) fwd_epilogue(ly, lds, wimg, l, last, t1, acc1, row, q, zd1, cimg != nullptr, cbrow);
         }
         // zdot is known: the owner lanes can already form the NEXT stage state and put it
         // into region_0 (last read two barriers ago), which takes the stage combination and
@@ -859,6 +865,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         const int nvalid = max(0, min(TNB, a.B - b0));
         const bool live = s < nvalid;                             // this lane's sample exists
         const size_t gcol = (size_t)(b0 + s) * D;
+        const float* cbrow = (a.cond && live) ? a.cond + (size_t)(b0 + s) * a.cbs : nullptr;
         // eps tile -> EPS[sample][feature] (this team's rows; its previous readers are this
         // team's waves, ordered by the last team barrier of the previous tile)
         for (int i = tt; i < TNB * n_in; i += TT) {
@@ -922,7 +929,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                     set_k(kz0, stg, zd0); set_k(kz1, stg, zd1);
                     if (stg < nstage) put_stage(stg + 1);
                 } else { kz0[1] = zd0; kz1[1] = zd1; }
-            }, a.test ? a.cimg : nullptr, a.SWC STAMP_PASS);
+            }, a.test ? a.cimg : nullptr, a.SWC, cbrow STAMP_PASS);
         }
         // scalar rows of the last evaluation (rhs_tile ended with a barrier)
         if (sown) {
@@ -2118,6 +2125,7 @@ static void launch_fused(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStr
 static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
     MfmaArgs a = a0;
     if (a.test) { a.cimg = p.d_img + p.ly.c_off; a.SWC = p.ly.SWC; }
+    a.cond = p.cond; a.cbs = p.cbs;
     const dim3 grid(mfma_grid_for(a.B)), block(MF_KTHREADS);
     const size_t shm = (size_t)p.ly.total_floats * sizeof(float);
     if (a.test && p.variant != 5) {
@@ -2126,7 +2134,7 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
         if (a.mode == 2) hipLaunchKernelGGL((k_mfma<RtLayout, true>), grid, block, shm, s, ly, a);
         else hipLaunchKernelGGL((k_mfma<RtLayout, false>), grid, block, shm, s, ly, a);
     }
-    else if (p.variant >= 2 && p.variant <= 4 && p.schedule > 0) {
+    else if (p.variant >= 2 && p.variant <= 4 && p.schedule > 0 && !a.cond) {
         if (p.variant == 2) launch_fused<FsCfg3>(p, a, grid, s);
         else if (p.variant == 3) launch_fused<FsCfg2>(p, a, grid, s);
         else launch_fused<FsCfg1>(p, a, grid, s);

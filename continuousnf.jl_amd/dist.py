@@ -19,13 +19,26 @@ class ICNFDist:
     st: Any = None
 
 
-def logpdf(d: ICNFDist, A, *, eps=None):
+@dataclass
+class CondICNFDist:
+    """src/exts/dist_ext/core_cond_icnf.jl:1-7."""
+    m: ICNF
+    mode: Any
+    ys: Any
+    ps: Any
+    st: Any = None
+
+
+def logpdf(d, A, *, eps=None):
     if not isinstance(d.m, ICNF):
         raise NotImplementedError("Not Implemented")      # core_icnf.jl:19
     vec = (A.dim() if _is_torch(A) else np.ndim(A)) == 1
     if vec:                                               # core_icnf.jl:13-21: hcat(x)
         A = A.reshape(-1, 1)
-    lp = inference(d.m, d.mode, A, d.ps, d.st, eps=eps)[0]
+    if isinstance(d, CondICNFDist):                        # core_cond_icnf.jl:27-35: ys[:, 1:size(A, 2)]
+        lp = inference(d.m, d.mode, A, d.ys[:, : A.shape[1]], d.ps, d.st, eps=eps)[0]
+    else:
+        lp = inference(d.m, d.mode, A, d.ps, d.st, eps=eps)[0]
     return lp[0] if vec else lp
 
 
@@ -38,4 +51,6 @@ def rand(d: ICNFDist, n: int, *, z0=None, eps=None):
     """``rand(d, n)`` (src/exts/dist_ext/core_icnf.jl:46-58): ``generate(d.m, d.mode, d.ps, d.st, n)``."""
     if not isinstance(d.m, ICNF):
         raise NotImplementedError("Not Implemented")
+    if isinstance(d, CondICNFDist):
+        return generate(d.m, d.mode, d.ps, d.st, n, ys=d.ys[:, :n], z0=z0, eps=eps)
     return generate(d.m, d.mode, d.ps, d.st, n, z0=z0, eps=eps)

@@ -4,6 +4,7 @@ src/icnf.jl:318-350 (out-of-place) and :352-382 (in-place) for
 from __future__ import annotations
 
 from . import _lib
+from .layers import CondLayer
 from .base_icnf import (ICNF, _KERNEL, _as_colmajor, _empty_like, _mode_id, _stream,
                         n_augment, n_augment_input, raise_if_no_gpu)
 
@@ -29,6 +30,8 @@ def augmented_f(*args):
     ub = _as_colmajor(u, D, "u")
     B = ub.B
     icnf.set_params(p)
+    # conditional models hand the conditioning input over inside the layer: CondLayer(nn, ys)
+    icnf.set_cond(_nn.ys if isinstance(_nn, CondLayer) else None, B)
     eb = None
     if m == _lib.MODE_TRAIN:
         if eps is None:

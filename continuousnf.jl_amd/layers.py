@@ -62,3 +62,11 @@ def setup(rng, nn: Chain):
         parts.append(rng.uniform(-lim, lim, size=l.in_dims * l.out_dims))
         parts.append(np.zeros(l.out_dims))
     return np.concatenate(parts).astype(np.float32), {}
+
+
+@dataclass
+class CondLayer:
+    """``CondLayer(nn, ys)`` (src/layers/cond_layer.jl:1-9): ``nn(vcat(z, ys))``.  Built per call by
+    ``inference_prob`` for the Cond* models (src/base_icnf.jl:302)."""
+    nn: Chain
+    ys: object

@@ -75,11 +75,11 @@ class Planar(_OutOfScope):       # rank-1 planar field: not the MLP hot path (SU
     pass
 
 
-class CondRNODE(_OutOfScope):    # conditional wrappers: SURVEY.md 8(f) f2, not built yet
+class CondRNODE(AbstractICNF):    # conditional models: nn(vcat(z, ys))
     pass
 
 
-class CondFFJORD(_OutOfScope):
+class CondFFJORD(AbstractICNF):
     pass
 
 

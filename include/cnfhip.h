@@ -73,6 +73,9 @@ typedef struct {
                                   NORM_Z_AUG are derived as `!iszero(lambda)` exactly as
                                   construct does (src/base_icnf.jl:42-51)              */
     int32_t device;            /* HIP device ordinal                                   */
+    int32_t n_cond;            /* conditional models (CondRNODE/CondFFJORD, src/layers/cond_layer.jl):
+                                  rows of `ys`; the first Dense layer then takes n_in + n_cond
+                                  inputs, dims[0] = n_in + n_cond.  0 for unconditional models */
 } cnf_config;
 
 typedef struct {
@@ -104,6 +107,14 @@ cnf_status cnf_destroy(cnf_handle h);
  * argument of augmented_f (src/icnf.jl:320, used at :329).  Synchronous. */
 cnf_status cnf_set_params_host(cnf_handle h, const float* flat, size_t n);
 cnf_status cnf_set_params(cnf_handle h, const float* flat_dev, size_t n, void* stream);
+
+/* Conditional models: nn = CondLayer(icnf.nn, ys), nn(z) = icnf.nn(vcat(z, ys))
+ * (src/layers/cond_layer.jl:7-9, built per call in inference_prob src/base_icnf.jl:288-309).
+ * ys: n_cond x B.  The call folds the conditioning columns of the first layer into a
+ * per-sample bias W1[:, n_in:] * ys + b1 held by the handle; every later RHS / solve call with
+ * the same B uses it.  Must be called again when ys, B or the parameters change. */
+cnf_status cnf_set_cond(cnf_handle h, const float* ys, int B, void* stream);
+cnf_status cnf_set_cond_host(cnf_handle h, const float* ys, int B);
 
 /* ---- the hot path ---------------------------------------------------------------- */
 

@@ -39,6 +39,7 @@ struct CnfConfig
     lambda2::Float32
     lambda3::Float32
     device::Int32
+    n_cond::Int32
 end
 struct CnfSolveOpts
     t0::Float32; t1::Float32; abstol::Float32; reltol::Float32; dt::Float32
@@ -70,7 +71,8 @@ function handle(icnf::ICNF{T, <:HIPMatrixMode}) where {T}
         GC.@preserve dims acts begin
             cfg = CnfConfig(length(layers), pointer(dims), pointer(acts), icnf.nvars,
                             n_augment_input(icnf), ad_flag(icnf.compute_mode),
-                            icnf.λ₁, icnf.λ₂, icnf.λ₃, 0)
+                            icnf.λ₁, icnf.λ₂, icnf.λ₃, 0,
+                            first(layers).in_dims - icnf.nvars - n_augment_input(icnf))   # n_cond (0 unless Cond*)
             check(@ccall(libcnfhip.cnf_create(h::Ptr{Ptr{Cvoid}}, Ref(cfg)::Ptr{CnfConfig})::Cint), C_NULL)
         end
         h[]
@@ -93,6 +95,10 @@ function augmented_f(du::Any, u::Any, p::Any, ::Any, icnf::ICNF{T, <:HIPMatrixMo
     h = handle(icnf)
     set_params!(h, p)
     B = size(u, 2)
+    if nn isa CNF.CondLayer     # src/layers/cond_layer.jl: the conditioning input rides inside the layer
+        ys = Matrix{Float32}(nn.ys)
+        check(@ccall(libcnfhip.cnf_set_cond_host(h::Ptr{Cvoid}, ys::Ptr{Float32}, B::Cint)::Cint), h)
+    end
     # Julia's column-major D x B is exactly the layout the ABI documents
     check(@ccall(libcnfhip.cnf_rhs_host(h::Ptr{Cvoid}, mode_flag(mode)::Cint, 0::Cint, u::Ptr{Float32},
                                         ϵ::Ptr{Float32}, du::Ptr{Float32}, B::Cint)::Cint), h)

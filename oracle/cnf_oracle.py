@@ -113,9 +113,13 @@ def glorot_params(net: Net, rng: np.random.Generator, dtype=np.float32, bias_sca
 # --------------------------------------------------------------------------------------
 # vector field + AD sweeps (a5)
 # --------------------------------------------------------------------------------------
-def mlp_forward(net: Net, flat, z):
-    """``snn(z)`` (src/icnf.jl:329,331): returns (zdot, [h_0..h_L], [sigma'_1..sigma'_L])."""
+def mlp_forward(net: Net, flat, z, ys=None):
+    """``snn(z)`` (src/icnf.jl:329,331): returns (zdot, [h_0..h_L], [sigma'_1..sigma'_L]).
+    With ``ys`` the network is the reference's ``CondLayer``: ``nn(vcat(z, ys))``
+    (src/layers/cond_layer.jl:7-9)."""
     Ws, bs = unflatten_params(net, flat)
+    if ys is not None:
+        z = np.vstack([z, ys])
     hs, ds = [z], []
     h = z
     for W, b, k in zip(Ws, bs, net.acts):
@@ -126,27 +130,28 @@ def mlp_forward(net: Net, flat, z):
     return h, hs, ds
 
 
-def mlp_vjp(net: Net, flat, z, ct):
-    """(nn(z), J^T ct): what ``value_and_pullback`` returns at src/icnf.jl:331-332."""
+def mlp_vjp(net: Net, flat, z, ct, ys=None):
+    """(nn(z), J^T ct): what ``value_and_pullback`` returns at src/icnf.jl:331-332.  With
+    ``ys`` the pullback is w.r.t. z only (CondLayer closes over ys)."""
     Ws, _ = unflatten_params(net, flat)
-    y, _, ds = mlp_forward(net, flat, z)
+    y, _, ds = mlp_forward(net, flat, z, ys)
     g = ct
     for W, d in zip(reversed(Ws), reversed(ds)):
         g = W.T @ (g * d)
-    return y, g
+    return y, g[: z.shape[0]]
 
 
-def mlp_jvp(net: Net, flat, z, tg):
+def mlp_jvp(net: Net, flat, z, tg, ys=None):
     """(nn(z), J tg): what ``value_and_pushforward`` returns at src/icnf.jl:397-402."""
     Ws, _ = unflatten_params(net, flat)
-    y, _, ds = mlp_forward(net, flat, z)
-    t = tg
+    y, _, ds = mlp_forward(net, flat, z, ys)
+    t = tg if ys is None else np.vstack([tg, np.zeros_like(ys)])
     for W, d in zip(Ws, ds):
         t = d * (W @ t)
     return y, t
 
 
-def jacobian_batched(net: Net, flat, xs, use_jvp=False):
+def jacobian_batched(net: Net, flat, xs, use_jvp=False, ys=None):
     """src/utils.jl:1-17 (VJP rows) / :19-36 (JVP columns): returns (y, res) with
     ``res[:, :, b]`` the Jacobian of column b (n_in x n_in x B)."""
     n, B = xs.shape
@@ -156,10 +161,10 @@ def jacobian_batched(net: Net, flat, xs, use_jvp=False):
         seed = np.zeros_like(xs)
         seed[i, :] = 1
         if use_jvp:
-            y, col = mlp_jvp(net, flat, xs, seed)
+            y, col = mlp_jvp(net, flat, xs, seed, ys)
             res[:, i, :] = col          # utils.jl:30-32
         else:
-            y, row = mlp_vjp(net, flat, xs, seed)
+            y, row = mlp_vjp(net, flat, xs, seed, ys)
             res[i, :, :] = row          # utils.jl:12-13
     return y, res
 
@@ -176,25 +181,25 @@ def _colnorm(x):
     return np.sqrt(np.sum(x * x, axis=0))
 
 
-def augmented_f_train(net: Net, flat, u, eps, norm_z: bool, norm_j: bool, use_jvp=False):
+def augmented_f_train(net: Net, flat, u, eps, norm_z: bool, norm_j: bool, use_jvp=False, ys=None):
     """Matrix/Train. VJP: src/icnf.jl:318-350; JVP: src/icnf.jl:384-420.
     u: D x B with D = n_in + 3; eps: n_in x B. Returns du: D x B."""
     n_aug = n_augment(True)
     z = u[: u.shape[0] - n_aug - 1, :]                       # icnf.jl:330
     if use_jvp:
-        zdot, eJ = mlp_jvp(net, flat, z, eps)                # icnf.jl:397-402
+        zdot, eJ = mlp_jvp(net, flat, z, eps, ys)            # icnf.jl:397-402
     else:
-        zdot, eJ = mlp_vjp(net, flat, z, eps)                # icnf.jl:331-332
+        zdot, eJ = mlp_vjp(net, flat, z, eps, ys)            # icnf.jl:331-332
     ldot = -np.sum(eJ * eps, axis=0, keepdims=True)          # icnf.jl:334 / :404
     Edot = _colnorm(zdot)[None, :] if norm_z else np.zeros_like(ldot)   # icnf.jl:335-341
     ndot = _colnorm(eJ)[None, :] if norm_j else np.zeros_like(ldot)     # icnf.jl:342-348
     return np.vstack([zdot, ldot, Edot, ndot])               # icnf.jl:349
 
 
-def augmented_f_test(net: Net, flat, u, use_jvp=False):
+def augmented_f_test(net: Net, flat, u, use_jvp=False, ys=None):
     """Matrix/Test exact trace: src/icnf.jl:148-164 with src/utils.jl:1-36."""
     z = u[: u.shape[0] - 1, :]
-    zdot, J = jacobian_batched(net, flat, z, use_jvp)
+    zdot, J = jacobian_batched(net, flat, z, use_jvp, ys)
     ldot = -np.trace(J, axis1=0, axis2=1)[None, :]           # icnf.jl:162
     return np.vstack([zdot, ldot])                           # icnf.jl:163
 
@@ -220,11 +225,12 @@ class Cfg:
     def D(self, train: bool):
         return self.n_in + 1 + n_augment(train)
 
-    def rhs(self, flat, eps, train: bool):
+    def rhs(self, flat, eps, train: bool, ys=None):
+        """ys: conditioning inputs (n_cond x B) of the Cond* models (src/base_icnf.jl:288-309)."""
         if train:
             return lambda u: augmented_f_train(self.net, flat, u, eps, self.lam1 != 0,
-                                               self.lam2 != 0, self.use_jvp)
-        return lambda u: augmented_f_test(self.net, flat, u, self.use_jvp)
+                                               self.lam2 != 0, self.use_jvp, ys)
+        return lambda u: augmented_f_test(self.net, flat, u, self.use_jvp, ys)
 
 
 def inference_u0(cfg: Cfg, xs, train: bool):
@@ -384,11 +390,11 @@ def loss(cfg: Cfg, logpx, regs, train: bool):
     return float(-np.mean(logpx))
 
 
-def inference(cfg: Cfg, flat, xs, eps, train: bool, **solve_kw):
+def inference(cfg: Cfg, flat, xs, eps, train: bool, ys=None, **solve_kw):
     """src/base_icnf.jl:407-415: inference_prob -> solve -> inference_sol, with eps given
     (drawn once per call in the reference, base_icnf.jl:277-278)."""
     u0 = inference_u0(cfg, xs, train)
-    fsol, st = tsit5_solve(cfg.rhs(flat, eps, train), u0, cfg.tspan[0], cfg.tspan[1], **solve_kw)
+    fsol, st = tsit5_solve(cfg.rhs(flat, eps, train, ys), u0, cfg.tspan[0], cfg.tspan[1], **solve_kw)
     logpx, regs = inference_sol(cfg, fsol, train)
     return fsol, logpx, regs, st
 

@@ -392,3 +392,60 @@ def test_generate_matches_backward_oracle_and_inverts_inference(kernel):
     z = cnf.base_sol(ic0, prob).view()[:8]
     back = cnf.generate(ic0, cnf.TestMode(), flat0, {}, 50, z0=np.array(z))
     assert np.max(np.abs(back - x)) < 5e-5
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("dims,nvars,naugs", [((11, 24, 8), 8, 0), ((37, 64, 48, 32), 24, 8), ((6, 5, 3), 2, 1)])
+def test_conditional_models(kernel, dims, nvars, naugs):
+    """CondRNODE -- nn(vcat(z, ys)) (src/layers/cond_layer.jl:7-9,
+    src/base_icnf.jl:288-309), AD products w.r.t. z only.  RHS in all three modes and a
+    fixed-dt inference against the float64 oracle."""
+    n_in = nvars + naugs
+    n_cond = dims[0] - n_in
+    net = O.Net(dims, (O.ACT_TANH,) * (len(dims) - 1))
+    rng = np.random.default_rng(sum(dims))
+    flat = O.glorot_params(net, rng, np.float32, 0.1)
+    B = 77
+    xs = rng.standard_normal((nvars, B)).astype(np.float32)
+    ys = rng.standard_normal((n_cond, B)).astype(np.float32)
+    eps = rng.standard_normal((n_in, B)).astype(np.float32)
+    u = rng.standard_normal((n_in + 3, B)).astype(np.float32)
+    layers = [cnf.Dense(i, o, "tanh") for i, o in zip(dims[:-1], dims[1:])]
+    f64 = lambda a: a.astype(np.float64)
+    for jvp in (False, True):
+        cm = cnf.HIPJacVecMatrixMode(kernel) if jvp else cnf.HIPVecJacMatrixMode(kernel)
+        icnf = cnf.construct(cnf.CondRNODE, cnf.Chain(*layers), nvars, naugs, compute_mode=cm,
+                             lambda3=1e-2 if naugs else 0.0, sol_kwargs=dict(adaptive=False, dt=1 / 16))
+        assert icnf.cond and icnf.n_cond == n_cond
+        if not _supported(icnf, cnf.TrainMode(), B):
+            icnf.close()
+            continue
+        cfg = O.Cfg(net, nvars, naugs, 1e-2, 1e-2, 1e-2 if naugs else 0.0, jvp)
+        nnc = cnf.CondLayer(icnf.nn, ys)
+        du = cnf.augmented_f(u, flat, 0.0, icnf, cnf.TrainMode(), nnc, {}, eps)
+        assert_parity(du, cfg.rhs(f64(flat), f64(eps), True, f64(ys))(f64(u)), f"cond train jvp={jvp}")
+        # device arrays
+        du_d = cnf.augmented_f(_dev(u), flat, 0.0, icnf, cnf.TrainMode(), cnf.CondLayer(icnf.nn, _dev(ys)), {}, _dev(eps))
+        assert_parity(du_d.cpu().numpy(), du, "cond device == host", rtol=1e-6)
+        if _supported(icnf, cnf.TestMode(), B):
+            dt = cnf.augmented_f(u[: n_in + 1], flat, 0.0, icnf, cnf.TestMode(), nnc, {}, None)
+            assert_parity(dt, cfg.rhs(f64(flat), None, False, f64(ys))(f64(u[: n_in + 1])), "cond test")
+        logpx, (E, n, A) = cnf.inference(icnf, cnf.TrainMode(), xs, ys, flat, {}, eps=eps)
+        _, ref_lp, (rE, rn, rA), st = O.inference(cfg, f64(flat), f64(xs), f64(eps), True, f64(ys), dt=1 / 16, adaptive=False)
+        assert_parity(logpx, ref_lp, f"cond logpx jvp={jvp}")
+        assert_parity(np.stack([E, n, A]), np.stack([rE, rn, rA]), f"cond regs jvp={jvp}")
+        L = cnf.loss(icnf, cnf.TrainMode(), xs, ys, flat, {}, eps=eps)
+        assert abs(L - O.loss(cfg, ref_lp, (rE, rn, rA), True)) <= 1e-4 * max(1.0, abs(L))
+        d = cnf.CondICNFDist(icnf, cnf.TrainMode(), ys, flat, {})
+        assert_parity(cnf.logpdf(d, xs, eps=eps), ref_lp, "CondICNFDist logpdf")
+        # a different ys changes the result; the stale-ys guard of the raw ABI
+        lp2, _ = cnf.inference(icnf, cnf.TrainMode(), xs, ys + 1.0, flat, {}, eps=eps)
+        assert np.max(np.abs(lp2 - logpx)) > 1e-3
+        icnf.close()
+    ic = cnf.construct(cnf.CondFFJORD, cnf.Chain(*layers), nvars, naugs, compute_mode=cnf.HIPVecJacMatrixMode(kernel))
+    if _supported(ic, cnf.TrainMode(), B):
+        with pytest.raises(ValueError):      # conditional model without ys
+            cnf.augmented_f(u, flat, 0.0, ic, cnf.TrainMode(), ic.nn, {}, eps)
+        ic.set_params(flat)
+        x = torch.zeros(B * (n_in + 3), device="cuda")
+        assert _lib.lib().cnf_rhs(ic.handle(), 1, 0, x.data_ptr(), x.data_ptr(), x.data_ptr() + 4, B, None) == _lib.ERR_NO_PARAMS

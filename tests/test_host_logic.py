@@ -29,7 +29,9 @@ def test_construct_rejects_what_is_out_of_scope_or_malformed():
     with pytest.raises(NotImplementedError):
         cnf.construct(cnf.Planar, _nn(2), 2)
     with pytest.raises(NotImplementedError):
-        cnf.construct(cnf.CondRNODE, _nn(2), 2)
+        cnf.construct(cnf.CondPlanar, _nn(2), 2)
+    with pytest.raises(ValueError):
+        cnf.construct(cnf.CondRNODE, _nn(2), 2)         # a conditional nn needs n_in + n_cond inputs
     with pytest.raises(NotImplementedError):
         cnf.construct(cnf.RNODE, _nn(2), 2, data_type=np.float64)
     with pytest.raises(ValueError):
@@ -120,3 +122,13 @@ def test_augmented_f_argument_count_dispatch():
     r = cnf.construct(cnf.RNODE, _nn(2), 2)
     with pytest.raises(TypeError):
         cnf.augmented_f(1, 2, 3)
+
+
+def test_conditional_construct():
+    nn = cnf.Chain(cnf.Dense(7, 9, "tanh"), cnf.Dense(9, 4, "tanh"))       # 4 = nvars + naugs, 3 conditioning rows
+    c = cnf.construct(cnf.CondRNODE, nn, 2, 2)
+    assert c.cond and c.n_cond == 3 and np.float32(c.lambda1) == np.float32(1e-2)      # base_icnf.jl:14, 28-37
+    f = cnf.construct(cnf.CondFFJORD, nn, 4)
+    assert f.cond and f.n_cond == 3 and f.lambda1 == 0
+    with pytest.raises(TypeError):
+        cnf.inference_prob(c, cnf.TrainMode(), np.zeros((2, 3), np.float32), np.zeros(nn.n_params, np.float32))

@@ -212,3 +212,29 @@ def test_param_layout_is_column_major_weight_then_bias():
     assert W.shape == (3, 2)
     assert np.array_equal(W[:, 0], [0, 1, 2]) and np.array_equal(W[:, 1], [3, 4, 5])
     assert np.array_equal(b, [6, 7, 8])
+
+
+def test_conditional_layer_matches_autograd():
+    """CondLayer: nn(vcat(z, ys)) (src/layers/cond_layer.jl:7-9); AD products w.r.t. z only."""
+    rng = np.random.default_rng(8)
+    n_in, n_cond, B = 4, 3, 5
+    net = O.Net((n_in + n_cond, 9, n_in), (O.ACT_TANH, O.ACT_TANH))
+    flat = O.glorot_params(net, rng, np.float64, bias_scale=0.1)
+    z = rng.standard_normal((n_in, B)); ys = rng.standard_normal((n_cond, B)); eps = rng.standard_normal((n_in, B))
+    f = _torch_mlp(net, flat)
+    y, eJ = O.mlp_vjp(net, flat, z, eps, ys)
+    _, Je = O.mlp_jvp(net, flat, z, eps, ys)
+    _, J = O.jacobian_batched(net, flat, z, ys=ys)
+    for b in range(B):
+        yb = torch.tensor(ys[:, b])
+        fz = lambda zz: f(torch.cat([zz, yb]))
+        zb, eb = torch.tensor(z[:, b]), torch.tensor(eps[:, b])
+        yt, vjp_fn = torch.func.vjp(fz, zb)
+        assert np.allclose(y[:, b], yt.numpy(), atol=1e-13)
+        assert np.allclose(eJ[:, b], vjp_fn(eb)[0].numpy(), atol=1e-12)
+        assert np.allclose(Je[:, b], torch.func.jvp(fz, (zb,), (eb,))[1].numpy(), atol=1e-12)
+        assert np.allclose(J[:, :, b], torch.func.jacrev(fz)(zb).numpy(), atol=1e-12)
+    # folding the conditioning input into a per-sample bias is the same function
+    Ws, bs = O.unflatten_params(net, flat)
+    a1 = Ws[0][:, :n_in] @ z + (Ws[0][:, n_in:] @ ys + bs[0][:, None])
+    assert np.allclose(O.mlp_forward(net, flat, z, ys)[1][1], np.tanh(a1), atol=1e-14)
