@@ -731,8 +731,12 @@ __device__ __forceinline__ void set_k(f32x4 (&k)[7], int idx, const f32x4& v) {
     for (int i = 1; i < 7; ++i) k[i] = idx == i ? v : k[i];
 }
 __device__ __forceinline__ f32x4 ld4(const float* p, int nvalid4) {   // rows beyond n_in read as 0
-    return f32x4{nvalid4 > 0 ? p[0] : 0.f, nvalid4 > 1 ? p[1] : 0.f, nvalid4 > 2 ? p[2] : 0.f,
-                 nvalid4 > 3 ? p[3] : 0.f};
+    // one branch for "nothing valid" (never touches memory then); otherwise branch-free:
+    // out-of-range elements re-read element 0 and are zeroed, so the four loads issue back to back
+    if (nvalid4 <= 0) return f32x4{0.f, 0.f, 0.f, 0.f};
+    const int i1 = nvalid4 > 1 ? 1 : 0, i2 = nvalid4 > 2 ? 2 : 0, i3 = nvalid4 > 3 ? 3 : 0;
+    const float v0 = p[0], v1 = p[i1], v2 = p[i2], v3 = p[i3];
+    return f32x4{nvalid4 > 0 ? v0 : 0.f, nvalid4 > 1 ? v1 : 0.f, nvalid4 > 2 ? v2 : 0.f, nvalid4 > 3 ? v3 : 0.f};
 }
 __device__ __forceinline__ void st4(float* p, const f32x4& v, int nvalid4) {
     if (nvalid4 > 0) p[0] = v.x;
@@ -789,18 +793,20 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
     const float* wimg = ly.wlds() ? (const float*)lds : a.img;
     {
         const int n = ly.wlds() ? ly.img_floats() : 0;
-        int i = tid * 4;
-        for (; i + 3 * MF_KTHREADS * 4 < n; i += 4 * MF_KTHREADS * 4) {
-            const f32x4 v0 = *(const f32x4*)(a.img + i);
-            const f32x4 v1 = *(const f32x4*)(a.img + i + MF_KTHREADS * 4);
-            const f32x4 v2 = *(const f32x4*)(a.img + i + 2 * MF_KTHREADS * 4);
-            const f32x4 v3 = *(const f32x4*)(a.img + i + 3 * MF_KTHREADS * 4);
-            *(f32x4*)(lds + i) = v0;
-            *(f32x4*)(lds + i + MF_KTHREADS * 4) = v1;
-            *(f32x4*)(lds + i + 2 * MF_KTHREADS * 4) = v2;
-            *(f32x4*)(lds + i + 3 * MF_KTHREADS * 4) = v3;
+        constexpr int FL = 16;                    // float4 requests in flight per lane
+        for (int base = 0; base < n; base += FL * MF_KTHREADS * 4) {
+            f32x4 v[FL];
+#pragma unroll
+            for (int j = 0; j < FL; ++j) {
+                const int i = base + (j * MF_KTHREADS + tid) * 4;
+                v[j] = *(const f32x4*)(a.img + (i < n ? i : 0));
+            }
+#pragma unroll
+            for (int j = 0; j < FL; ++j) {
+                const int i = base + (j * MF_KTHREADS + tid) * 4;
+                if (i < n) *(f32x4*)(lds + i) = v[j];
+            }
         }
-        for (; i < n; i += MF_KTHREADS * 4) *(f32x4*)(lds + i) = *(const f32x4*)(a.img + i);
         for (int z = n + tid * 4; z < ly.total_floats(); z += MF_KTHREADS * 4)
             *(f32x4*)(lds + z) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -866,24 +872,27 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         const bool live = s < nvalid;                             // this lane's sample exists
         const size_t gcol = (size_t)(b0 + s) * D;
         const float* cbrow = (a.cond && live) ? a.cond + (size_t)(b0 + s) * a.cbs : nullptr;
-        // eps tile -> EPS[sample][feature] (this team's rows; its previous readers are this
-        // team's waves, ordered by the last team barrier of the previous tile)
-        for (int i = tt; i < TNB * n_in; i += TT) {
-            const int sl = i / n_in, r = i - sl * n_in;
-            lds[ly.eps_off() + (TNB * team + sl) * ly.SX(0) + r] =
-                (sl < nvalid && a.eps) ? a.eps[(size_t)(b0 + sl) * n_in + r] : 0.f;
+        // eps tile -> EPS[sample][feature]: the lanes that own the state rows also fetch the eps
+        // rows (same addresses pattern; previous readers are this team's waves, ordered by the
+        // last team barrier of the previous tile)
+        {
+            const float* ep = a.eps ? a.eps + (size_t)(b0 + s) * n_in : nullptr;
+            if (own0) *(f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r00) =
+                (ep && live && nv0 > 0) ? ld4(ep + r00, nv0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (own1) *(f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r01) =
+                (ep && live && nv1 > 0) ? ld4(ep + r01, nv1) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // state: z rows in the accumulator layout, scalar rows in the fg == 0, q == 0 lanes
         f32x4 uz0 = {0.f, 0.f, 0.f, 0.f}, uz1 = uz0, kz0[7], kz1[7], us = uz0, ks[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) { kz0[i] = uz0; kz1[i] = uz0; ks[i] = uz0; }
         if (live) {
-            if (own0) uz0 = ld4(Uin + gcol + r00, nv0);
-            if (own1) uz1 = ld4(Uin + gcol + r01, nv1);
+            if (own0 && nv0 > 0) uz0 = ld4(Uin + gcol + r00, nv0);
+            if (own1 && nv1 > 0) uz1 = ld4(Uin + gcol + r01, nv1);
             if (sown) us = ld4(Uin + gcol + n_in, nsc);
             if (K1in) {
-                if (own0) kz0[0] = ld4(K1in + gcol + r00, nv0);
-                if (own1) kz1[0] = ld4(K1in + gcol + r01, nv1);
+                if (own0 && nv0 > 0) kz0[0] = ld4(K1in + gcol + r00, nv0);
+                if (own1 && nv1 > 0) kz1[0] = ld4(K1in + gcol + r01, nv1);
                 if (sown) ks[0] = ld4(K1in + gcol + n_in, nsc);
             }
         }
