@@ -537,7 +537,7 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
             HIPCHK(h, hipEventRecord(h->ev[slot], st));
             slot_busy[slot] = true;
             q[nq].slot = slot; q[nq].enq_at = enq; ++nq;
-            if (nq < 2 && est_left > 0) continue;          // keep a second chunk in flight
+            if (nq < 2 && est_left >= chunk) continue;     // far from t1: keep a second chunk in flight
         }
         if (nq == 0) {
             HIPCHK(h, hipStreamSynchronize(st));

@@ -17,7 +17,7 @@ os.makedirs(DST, exist_ok=True)
 
 def first(pattern):
     g = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None      # newest run
 
 
 st = first("bench/**/*kernel_stats.csv")
