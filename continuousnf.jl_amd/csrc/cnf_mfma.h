@@ -28,6 +28,7 @@ struct MfmaLayout {
     int SX[CNF_MAX_LAYERS + 1];     // row stride of activation region l ([sample][feature])
     int x_off[CNF_MAX_LAYERS + 1];  // LDS offsets (floats) of the activation regions
     int eps_off, du_off, red_off;   // EPS [NB][SX0], DU [NB][SX0], RED [3][P0/16][NB]
+    int sc_off;                     // scalar-row Runge-Kutta state [NB][8][3] (u, k1..k7 of dlogp, E, n)
     int total_floats;
     int n_in, norm_z, norm_j;
     int ept;                        // state elements per thread: ceil(NB*(n_in+3)/MF_THREADS)

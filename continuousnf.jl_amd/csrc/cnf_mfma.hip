@@ -95,6 +95,7 @@ struct RtLayout {
     __device__ __forceinline__ int red_off() const { return m.red_off; }
     __device__ __forceinline__ int total_floats() const { return m.total_floats; }
     __device__ __forceinline__ int bar_off() const { return m.total_floats - 16; }
+    __device__ __forceinline__ int sc_off() const { return m.sc_off; }
     __device__ __forceinline__ int n_in() const { return m.n_in; }
     __device__ __forceinline__ int norm_z() const { return m.norm_z; }
     __device__ __forceinline__ int norm_j() const { return m.norm_j; }
@@ -145,7 +146,8 @@ struct StLayoutX {
     __host__ __device__ static constexpr int red_floats() {
         return 3 * (pd(0) / 16) * MF_NB < 256 ? 256 : 3 * (pd(0) / 16) * MF_NB;
     }
-    __host__ __device__ static constexpr int bar_off() { return red_off() + red_floats(); }
+    __host__ __device__ static constexpr int sc_off() { return red_off() + red_floats(); }
+    __host__ __device__ static constexpr int bar_off() { return sc_off() + MF_NB * 24; }
     __host__ __device__ static constexpr int total_floats() { return bar_off() + 16; }
     __device__ __forceinline__ int n_in() const { return n_in_; }
     __device__ __forceinline__ int norm_z() const { return norm_z_; }
@@ -525,7 +527,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
                 const int act = ly.act(l);
                 for (int t0 = fg; t0 < ntiles; t0 += 2 * MF_WPT) {
                     const int t1 = t0 + MF_WPT;
-                    const bool two = t1 < ntiles;
+                    const bool two = ntiles > MF_WPT && t1 < ntiles;   // constant false for layers of <= MF_WPT tiles
                     f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = ah0, at0 = ah0, at1 = ah0;
                     const float* wa0 = W + (16 * t0 + s) * SW + 4 * q;
                     const float* wa1 = W + (16 * t1 + s) * SW + 4 * q;
@@ -580,7 +582,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
         const bool last = l == ly.L() - 1;
         for (int t0 = fg; t0 < ntiles; t0 += 2 * MF_WPT) {
             const int t1 = t0 + MF_WPT;
-            const bool two = t1 < ntiles;
+            const bool two = ntiles > MF_WPT && t1 < ntiles;   // constant false for layers of <= MF_WPT tiles
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* wa0 = W + (16 * t0 + s) * SW + 4 * q;
             const float* wa1 = W + (16 * t1 + s) * SW + 4 * q;
@@ -626,7 +628,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
         float trp = 0.f;
         for (int t0 = fg; t0 < ntiles; t0 += 2 * MF_WPT) {
             const int t1 = t0 + MF_WPT;
-            const bool two = t1 < ntiles;
+            const bool two = ntiles > MF_WPT && t1 < ntiles;   // constant false for layers of <= MF_WPT tiles
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* ra = cimg + (16 * t0 + s) * SWC + 4 * q;
             const float* rb = cimg + (16 * t1 + s) * SWC + 4 * q;
@@ -653,7 +655,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
         const float* W = wimg + ly.w_off(l);
         for (int t0 = fg; t0 < ntiles; t0 += 2 * MF_WPT) {
             const int t1 = t0 + MF_WPT;
-            const bool two = t1 < ntiles;
+            const bool two = ntiles > MF_WPT && t1 < ntiles;   // constant false for layers of <= MF_WPT tiles
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* wc0 = W + (4 * q) * SW + 16 * t0 + s;
             const float* wc1 = W + (4 * q) * SW + 16 * t1 + s;
@@ -844,7 +846,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
     const int team = wave / MF_WPT, tt = tid & (TT - 1);
     const int s = lane & 15, q = lane >> 4, fg = (wave + (MF_WPT / 2) * team) % MF_WPT;
     const int nt0 = ly.P(0) >> 4;
-    const bool own0 = fg < nt0, own1 = fg + MF_WPT < nt0; // z-row tiles fg, fg+MF_WPT
+    const bool own0 = fg < nt0, own1 = nt0 > MF_WPT && fg + MF_WPT < nt0;   // z-row tiles fg, fg+MF_WPT
     const bool sown = fg == 0 && q == 0;                  // scalar rows of sample s
     const int r00 = 16 * fg + 4 * q, r01 = r00 + 16 * MF_WPT;   // first owned row of each tile
     const int nv0 = own0 ? n_in - r00 : 0, nv1 = own1 ? n_in - r01 : 0;   // valid rows (may be <= 0 or > 4)
@@ -883,17 +885,23 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                 (ep && live && nv1 > 0) ? ld4(ep + r01, nv1) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // state: z rows in the accumulator layout, scalar rows in the fg == 0, q == 0 lanes
-        f32x4 uz0 = {0.f, 0.f, 0.f, 0.f}, uz1 = uz0, kz0[7], kz1[7], us = uz0, ks[7];
+        // (the scalar rows' u, k1..k7 live in LDS: only 16 lanes per team touch them, once per stage)
+        f32x4 uz0 = {0.f, 0.f, 0.f, 0.f}, uz1 = uz0, kz0[7], kz1[7];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) { kz0[i] = uz0; kz1[i] = uz0; ks[i] = uz0; }
+        for (int i = 0; i < 7; ++i) { kz0[i] = uz0; kz1[i] = uz0; }
+        float* sc = lds + ly.sc_off() + row * 24;
+        auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
+        auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
+        if (sown) {
+            sc_set(0, live ? ld4(Uin + gcol + n_in, nsc) : uz0);
+            sc_set(1, (live && K1in) ? ld4(K1in + gcol + n_in, nsc) : uz0);
+        }
         if (live) {
             if (own0 && nv0 > 0) uz0 = ld4(Uin + gcol + r00, nv0);
             if (own1 && nv1 > 0) uz1 = ld4(Uin + gcol + r01, nv1);
-            if (sown) us = ld4(Uin + gcol + n_in, nsc);
             if (K1in) {
                 if (own0 && nv0 > 0) kz0[0] = ld4(K1in + gcol + r00, nv0);
                 if (own1 && nv1 > 0) kz1[0] = ld4(K1in + gcol + r01, nv1);
-                if (sown) ks[0] = ld4(K1in + gcol + n_in, nsc);
             }
         }
         const int nstage = mode == 2 ? 6 : 1;
@@ -931,7 +939,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         for (int stg = 1; stg <= nstage; ++stg) {
             // scalar rows of the PREVIOUS evaluation, from its RED partials (RED[0] is
             // rewritten only in this evaluation's last forward epilogue, two barriers on)
-            if (stg > 1 && sown) set_k(ks, stg - 1, read_scalars());
+            if (stg > 1 && sown) sc_set(stg, read_scalars());        // slot j holds k_j
             f32x4 zd0 = {0.f, 0.f, 0.f, 0.f}, zd1 = zd0;
             rhs_tile(ly, lds, wimg, lane, wave, bar, gen, zd0, zd1, [&]() {
                 if (mode == 2) {
@@ -942,8 +950,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         }
         // scalar rows of the last evaluation (rhs_tile ended with a barrier)
         if (sown) {
-            const f32x4 v = read_scalars();
-            if (mode == 2) ks[6] = v; else ks[1] = v;
+            sc_set(mode == 2 ? 7 : 2, read_scalars());
         }
         // ---- outputs ----
         if (live) {
@@ -951,7 +958,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                 float* out = (mode == 0 ? a.du : a.Ks0) + gcol;
                 if (own0) st4(out + r00, kz0[1], nv0);
                 if (own1) st4(out + r01, kz1[1], nv1);
-                if (sown) st4(out + n_in, ks[1], nsc);
+                if (sown) st4(out + n_in, sc_get(2), nsc);
             } else {
                 float* Un = a.U[1 - cur] + gcol;
                 float* K7 = a.K1[1 - cur] + gcol;
@@ -964,6 +971,10 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                     err_acc(errsum, badcnt, kz1, uz1, un1, hstep, abstol, reltol, nv1);
                 }
                 if (sown) {
+                    f32x4 ks[7];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) ks[j] = sc_get(1 + j);
+                    const f32x4 us = sc_get(0);
                     const f32x4 uns = us + hstep * stage_acc4<6>(ks);
                     st4(Un + n_in, uns, nsc); st4(K7 + n_in, ks[6], nsc);
                     err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, nsc);
@@ -2012,6 +2023,7 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
         ly.red_off = o;
         int red = 3 * (ly.P[0] >> 4) * MF_NB;
         o += red < 256 ? 256 : red;
+        ly.sc_off = o; o += MF_NB * 24;   // scalar-row state
         o += 16;                      // team-barrier counters / controller scratch
         ly.total_floats = o;
     };
