@@ -10,18 +10,24 @@
 // and the pullback are Lux/Enzyme there (third party), restated per SURVEY.md Appendix B.
 //
 // Work decomposition (one workgroup = 8 waves = 512 lanes, 2 waves per SIMD, 1 per CU):
-//   - a workgroup owns a tile of 32 samples (= two 16-sample MFMA column tiles);
+//   - a workgroup owns a tile of 32 samples = two teams of 4 waves, one per 16-sample MFMA
+//     column tile (team = wave >> 2);
 //   - every layer is a GEMM  Out[o][s] = sum_k W[o][k] X[k][s]  on v_mfma_f32_16x16x4_f32:
-//     A = a 16-row slab of W (forward) or of W^T (reverse), B = 16 samples of X; wave w
-//     takes column tile (w & 1) and the 16-row output tiles (w >> 1) + 4n;
+//     A = a 16-row slab of W (forward) or of W^T (reverse), B = the team's 16 samples of X;
+//     wave fg of a team takes the 16-row output tiles fg, fg+4 (then +8, ...), with
+//     fg = (wave + 2*team) & 3 so that layers with fewer than 4 tiles use different SIMDs
+//     for the two teams;
 //   - the accumulator layout (lane = sample, 4 consecutive rows per lane) is exactly what
 //     one ds_write_b128 stores into the [sample][feature] activation image, and what one
 //     ds_read_b128 fetches as the next layer's B operand for 4 consecutive MFMA k-steps:
 //     k-step c of block u contracts feature 16u + 4*(lane>>4) + c on both operands;
 //   - the reverse sweep writes g_l over h_l in place (sigma' is recomputed from h), so one
 //     image per layer serves both sweeps;
-//   - weights live in LDS for the whole launch (one padded row-major copy per layer: read
-//     as b128 along rows forward, as 4 x b32 down columns in reverse).
+//   - weights live in LDS for the whole launch when they fit (one padded row-major copy per
+//     layer: read as b128 along rows forward, as 4 x b32 down columns in reverse); larger
+//     networks read row fragments straight from HBM/L2 (plus a transposed copy for reverse);
+//   - the Runge-Kutta state of the z rows sits in registers in the accumulator layout of the
+//     lanes that produce zdot; the three scalar rows sit in LDS.
 //
 // Two layout flavours drive the same kernel template: RtLayout (every size a run-time
 // value: any network whose images fit in LDS) and StLayout<...> (sizes and activations

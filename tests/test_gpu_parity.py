@@ -449,3 +449,38 @@ def test_conditional_models(kernel, dims, nvars, naugs):
         ic.set_params(flat)
         x = torch.zeros(B * (n_in + 3), device="cuda")
         assert _lib.lib().cnf_rhs(ic.handle(), 1, 0, x.data_ptr(), x.data_ptr(), x.data_ptr() + 4, B, None) == _lib.ERR_NO_PARAMS
+
+
+def test_full_size_cfg5_properties():
+    """BASELINE config 5 at full size (RNODE 64+64, MLP 128-384-128, B = 2048): weights stay in
+    HBM/L2, exact trace in closed form.  Size-independent checks + sampled columns vs the oracle."""
+    cfg, B, _ = O.baseline_cfg(5)
+    rng = np.random.default_rng(55)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.05)
+    icnf = make_icnf(cnf, cfg, kernel="mfma")
+    u = rng.standard_normal((cfg.D(True), B)).astype(np.float32)
+    eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+    ud, ed = _dev(u), _dev(eps)
+    tr = cnf.augmented_f(ud, flat, 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, ed)
+    te = cnf.augmented_f(ud[: cfg.n_in + 1].contiguous(), flat, 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)
+    assert torch.isfinite(tr).all() and torch.isfinite(te).all()
+    # both modes compute the same zdot; permutation of the columns permutes the output bit for bit
+    assert torch.allclose(tr[: cfg.n_in], te[: cfg.n_in], rtol=0, atol=0)
+    perm = torch.from_numpy(rng.permutation(B)).cuda()
+    assert torch.equal(cnf.augmented_f(ud[:, perm].contiguous(), flat, 0.0, icnf, cnf.TrainMode(), icnf.nn, {},
+                                       ed[:, perm].contiguous()), tr[:, perm])
+    # the Hutchinson row is an unbiased estimate of the exact-trace row: batch means agree statistically
+    d = (tr[cfg.n_in] - te[cfg.n_in]).cpu().numpy()
+    assert abs(d.mean()) < 5 * d.std() / np.sqrt(B)
+    idx = rng.choice(B, 64, replace=False)
+    ref_te = cfg.rhs(flat.astype(np.float64), None, False)(u[: cfg.n_in + 1, idx].astype(np.float64))
+    assert_parity(te[:, torch.from_numpy(idx).cuda()].cpu().numpy(), ref_te, "cfg5 exact trace, sampled columns")
+    ref_tr = cfg.rhs(flat.astype(np.float64), eps[:, idx].astype(np.float64), True)(u[:, idx].astype(np.float64))
+    assert_parity(tr[:, torch.from_numpy(idx).cuda()].cpu().numpy(), ref_tr, "cfg5 Hutchinson, sampled columns")
+    # exact logpdf (README usage: ICNFDist(icnf, TestMode(), ps, st)) vs a float64 solve on a few columns
+    ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
+    xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+    lp = cnf.logpdf(cnf.ICNFDist(ic, cnf.TestMode(), flat, {}), _dev(xs)).cpu().numpy()
+    _, ref_lp, _, _ = O.inference(cfg, flat.astype(np.float64), xs[:, :24].astype(np.float64), None, False,
+                                  dt=1 / 8, adaptive=False)
+    assert_parity(lp[:24], ref_lp, "cfg5 exact logpdf")
