@@ -44,6 +44,7 @@ class cnf_solve_stats(C.Structure):
 
 
 _fp = C.c_void_p  # device or host float*; passed as raw addresses
+shard_reduce_fn = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p)
 _SIGNATURES = {
     "cnf_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(cnf_config)]),
     "cnf_destroy": (C.c_int, [C.c_void_p]),
@@ -51,6 +52,7 @@ _SIGNATURES = {
     "cnf_set_params": (C.c_int, [C.c_void_p, _fp, C.c_size_t, C.c_void_p]),
     "cnf_set_cond": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_void_p]),
     "cnf_set_cond_host": (C.c_int, [C.c_void_p, _fp, C.c_int]),
+    "cnf_set_shard_reduce": (C.c_int, [C.c_void_p, shard_reduce_fn, C.c_void_p]),
     "cnf_rhs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, C.c_void_p]),
     "cnf_rhs_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int]),
     "cnf_solve_tsit5": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int,

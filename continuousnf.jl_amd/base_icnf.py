@@ -175,6 +175,27 @@ class ICNF:
         self._params_id = key
         self._cond_id = None        # the conditioning bias depends on the parameters
 
+    def set_shard_reduce(self, fn):
+        """Lock-step sharded solves (cnf_set_shard_reduce): ``fn(values)`` receives a
+        writable float32 numpy view of the local sums and must replace it IN PLACE by the sum over
+        all shards (``parallel.make_shard_reduce`` builds one from a torch.distributed group).
+        ``None`` switches back to independent per-shard solves."""
+        l, h = _lib.lib(), self.handle()
+        if fn is None:
+            cb = _lib.shard_reduce_fn()          # NULL function pointer
+        else:
+            def _cb(ptr, n, _user):
+                try:
+                    fn(np.ctypeslib.as_array(ptr, shape=(n,)))
+                    return 0
+                except Exception:                # never unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb = _lib.shard_reduce_fn(_cb)
+        _lib.check(l.cnf_set_shard_reduce(h, cb, None), h)
+        self._shard_cb = cb                      # keep the trampoline alive as long as the handle uses it
+
     def set_cond(self, ys, B):
         """Hand ``ys`` (n_cond x B) to the device (cnf_set_cond) unless it is already resident."""
         if not self.cond:

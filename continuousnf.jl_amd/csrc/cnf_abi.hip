@@ -38,6 +38,11 @@ struct cnf_ctx {
     StepState* d_state = nullptr;   // two slots: [0] canonical, [1] ping-pong partner of the fused MFMA path
     StepState* h_state = nullptr; // pinned, two slots for pipelined polling + one init slot
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // lock-step sharded solves: host callback summing 3 floats over the shards (null: off)
+    cnf_shard_reduce_fn shard_reduce = nullptr;
+    void* shard_user = nullptr;
+    float* d_sums = nullptr;      // 3 floats
+    float* h_sums = nullptr;      // pinned, 3 floats
     std::string err;
 };
 
@@ -139,6 +144,8 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     if (e == hipSuccess) e = hipMalloc(&h->d_state, 2 * sizeof(StepState));
     if (e == hipSuccess) e = hipMalloc(&h->partials, 4 * MAX_PARTIALS * sizeof(float));
     if (e == hipSuccess) e = hipHostMalloc(&h->h_state, 3 * sizeof(StepState), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&h->d_sums, 4 * sizeof(float));
+    if (e == hipSuccess) e = hipHostMalloc(&h->h_sums, 4 * sizeof(float), hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[1], hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -160,6 +167,8 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->partials) (void)hipFree(h->partials);
     if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->d_sums) (void)hipFree(h->d_sums);
+    if (h->h_sums) (void)hipHostFree(h->h_sums);
     if (h->ev[0]) (void)hipEventDestroy(h->ev[0]);
     if (h->ev[1]) (void)hipEventDestroy(h->ev[1]);
     delete h;
@@ -362,7 +371,7 @@ extern "C" cnf_status cnf_rhs_host(cnf_handle h, int mode, int kernel, const flo
 // Tsit5 driver (a7: base_sol, src/base_icnf.jl:137-143)
 // ---------------------------------------------------------------------------------------
 static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, int B,
-                                    int nblk, hipStream_t s) {
+                                    int nblk, hipStream_t s, bool with_controller = true) {
     RhsArgs a{};
     a.st = h->d_state; a.B = B; a.S = h->cap_B; a.train = train; a.ws = h->ws; a.eps = eps;
     a.cond = h->mfma.cond; a.cbs = h->cbs;
@@ -383,7 +392,28 @@ static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, i
     for (int i = 0; i < 5; ++i) n.Ks[i] = h->Ks[i];
     n.partials = h->partials;
     launch_norm_partials(n, nblk, s);
-    launch_controller(h->d_state, h->partials, 2, (float)n.n, s);
+    if (with_controller) launch_controller(h->d_state, h->partials, 2, (float)n.n, s);
+}
+
+extern "C" cnf_status cnf_set_shard_reduce(cnf_handle h, cnf_shard_reduce_fn fn, void* user) {
+    if (!h) return CNF_ERR_BAD_ARG;
+    h->shard_reduce = fn;
+    h->shard_user = user;
+    return CNF_OK;
+}
+
+// Lock-step controller: local partial sums -> (p0, p1, n_local) -> host -> sum over the shards ->
+// back to the device -> controller on the global sums.  One stream synchronisation per call.
+static cnf_status lockstep_controller(cnf_handle h, StepState* state, const float* partials, int phase,
+                                      float n_local, hipStream_t st) {
+    launch_reduce_partials(state, partials, h->d_sums, n_local, st);
+    HIPCHK(h, hipMemcpyAsync(h->h_sums, h->d_sums, 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    if (h->shard_reduce(h->h_sums, 3, h->shard_user) != 0)
+        return fail(h, CNF_ERR_BAD_ARG, "shard_reduce callback reported failure");
+    HIPCHK(h, hipMemcpyAsync(h->d_sums, h->h_sums, 3 * sizeof(float), hipMemcpyHostToDevice, st));
+    launch_controller_sums(state, h->d_sums, phase, st);
+    return CNF_OK;
 }
 
 extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
@@ -414,6 +444,8 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
     int launches = 0;
 
     const bool use_mfma = k == CNF_KERNEL_MFMA;
+    // lock-step over shards only matters when the controller decides something
+    const bool lockstep = h->shard_reduce != nullptr && opts->adaptive;
     // number of error partials = blocks of whichever kernel writes them
     int nblk = (int)((n + 255) / 256);
     if (nblk > 256) nblk = 256;
@@ -461,7 +493,11 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
         // automatic initial dt (Hairer; OrdinaryDiffEq's ode_determine_initdt, third party)
         na.kind = 0;
         launch_norm_partials(na, nblk, st);
-        launch_controller(h->d_state, h->partials, 0, (float)n, st);
+        if (lockstep) {
+            if ((s = lockstep_controller(h, h->d_state, h->partials, 0, (float)n, st)) != CNF_OK) return s;
+        } else {
+            launch_controller(h->d_state, h->partials, 0, (float)n, st);
+        }
         // f1 = f(u0 + h*f0) -> Ks[0]
         if (use_mfma) {
             s = mfma_rhs_stage(h->mfma, h->nd, train, h->d_state, h->U, h->K1, h->Ks, eps, 1, B, st);
@@ -477,7 +513,11 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
         }
         na.kind = 1;
         launch_norm_partials(na, nblk, st);
-        launch_controller(h->d_state, h->partials, 1, (float)n, st);
+        if (lockstep) {
+            if ((s = lockstep_controller(h, h->d_state, h->partials, 1, (float)n, st)) != CNF_OK) return s;
+        } else {
+            launch_controller(h->d_state, h->partials, 1, (float)n, st);
+        }
         launches += 5;
         nf += 1;
     }
@@ -493,6 +533,43 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
     }
     StepState* cur_state = h->d_state;   // slot holding the live integrator state
     int pp = 0;                          // partials buffer the NEXT launch reads
+    if (lockstep) {
+        // one attempt at a time: every shard must see the same global error norm before the next
+        // attempt is sized, so there is nothing to queue ahead
+        StepState* snap = &h->h_state[0];
+        for (long it = 0;; ++it) {
+            if (it >= (long)opts->maxiters) return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
+            if (use_mfma) {
+                s = mfma_step(h->mfma, h->nd, train, h->d_state, h->d_state + 1, h->U, h->K1, h->Ks, eps,
+                              h->partials, h->partials, false, false, B, st);
+                if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
+                launches += 1;
+            } else {
+                enqueue_attempt_generic(h, train, eps, B, nblk, st, false);
+                launches += 7;
+            }
+            if ((s = lockstep_controller(h, h->d_state, h->partials, 2, (float)n, st)) != CNF_OK) return s;
+            launches += 2;
+            HIPCHK(h, hipMemcpyAsync(snap, h->d_state, sizeof(StepState), hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            if (snap->done) break;
+        }
+        launch_copy_final(h->d_state, h->U[0], h->U[1], u_out, n, st);
+        launches += 1;
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(st));
+        if (stats) {
+            stats->nf = nf + 6 * (snap->naccept + snap->nreject);
+            stats->naccept = snap->naccept;
+            stats->nreject = snap->nreject;
+            stats->t_final = snap->t;
+            stats->dt_last = snap->dt;
+            stats->kernel_used = k;
+            stats->launches = launches;
+        }
+        if (snap->nonfinite) return fail(h, CNF_ERR_NONFINITE, "solver state became NaN/Inf");
+        return CNF_OK;
+    }
     // Attempts are queued in chunks, at most two chunks in flight.  After every chunk the state
     // is copied to a pinned mirror; the host reads the mirrors one chunk behind the GPU and
     // sizes the next chunk by the attempts still needed, (t1 - t)/dt, so that the queue

@@ -321,19 +321,7 @@ k_norm_partials(NormArgs a) {
 // Control law: OrdinaryDiffEq-style PI controller for Tsit5 (third
 // party in the reference, restated from the published scheme, mirrored by the oracle).
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_controller(StepState* st, const float* __restrict__ partials, int phase, float n_total) {
-    __shared__ float sm[8];
-    if (st->done) return;
-    float p0 = 0.f, p1 = 0.f;
-    for (int i = threadIdx.x; i < st->n_partials; i += blockDim.x) {
-        p0 += partials[2 * i];
-        p1 += partials[2 * i + 1];
-    }
-    // deterministic: fixed thread->entry map and fixed reduction tree
-    p0 = block_sum(p0, sm);
-    p1 = block_sum(p1, sm);
-    if (threadIdx.x != 0) return;
+__device__ __forceinline__ void ctrl_phase(StepState* st, int phase, float p0, float p1, float n_total) {
     const float span = fabsf(st->t1 - st->t0);
     if (phase == 0) {
         float d0 = sqrtf(p0 / n_total), d1 = sqrtf(p1 / n_total);
@@ -352,6 +340,45 @@ k_controller(StepState* st, const float* __restrict__ partials, int phase, float
     } else {
         ctrl_after_step(st, p0, p1, n_total);
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_controller(StepState* st, const float* __restrict__ partials, int phase, float n_total) {
+    __shared__ float sm[8];
+    if (st->done) return;
+    float p0 = 0.f, p1 = 0.f;
+    for (int i = threadIdx.x; i < st->n_partials; i += blockDim.x) {
+        p0 += partials[2 * i];
+        p1 += partials[2 * i + 1];
+    }
+    // deterministic: fixed thread->entry map and fixed reduction tree
+    p0 = block_sum(p0, sm);
+    p1 = block_sum(p1, sm);
+    if (threadIdx.x != 0) return;
+    ctrl_phase(st, phase, p0, p1, n_total);
+}
+
+// Lock-step sharded solves (option 2): every shard reduces its partial sums to
+// (p0, p1, n_local), the host sums the three numbers over the shards (cnf_set_shard_reduce), and
+// every shard runs the controller on the identical global sums -> identical accept/reject and dt.
+__global__ void __launch_bounds__(256)
+k_reduce_partials(const StepState* st, const float* __restrict__ partials, float* __restrict__ out3,
+                  float n_local) {
+    __shared__ float sm[8];
+    float p0 = 0.f, p1 = 0.f;
+    for (int i = threadIdx.x; i < st->n_partials; i += blockDim.x) {
+        p0 += partials[2 * i];
+        p1 += partials[2 * i + 1];
+    }
+    p0 = block_sum(p0, sm);
+    p1 = block_sum(p1, sm);
+    if (threadIdx.x == 0) { out3[0] = p0; out3[1] = p1; out3[2] = n_local; }
+}
+
+__global__ void k_controller_sums(StepState* st, const float* __restrict__ sums3, int phase) {
+    if (st->done) return;
+    const float p0 = sums3[0], p1 = sums3[1], n_total = sums3[2];
+    ctrl_phase(st, phase, p0, p1, n_total);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -454,6 +481,13 @@ void launch_norm_partials(const NormArgs& a, int nblocks, hipStream_t s) {
 void launch_controller(StepState* st, const float* partials, int phase, float n_total,
                        hipStream_t s) {
     hipLaunchKernelGGL(k_controller, dim3(1), dim3(256), 0, s, st, partials, phase, n_total);
+}
+void launch_reduce_partials(const StepState* st, const float* partials, float* out3, float n_local,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, st, partials, out3, n_local);
+}
+void launch_controller_sums(StepState* st, const float* sums3, int phase, hipStream_t s) {
+    hipLaunchKernelGGL(k_controller_sums, dim3(1), dim3(1), 0, s, st, sums3, phase);
 }
 void launch_build_u0(const float* xs, float* u0, int nvars, int D, int B, hipStream_t s) {
     size_t n = (size_t)D * B;

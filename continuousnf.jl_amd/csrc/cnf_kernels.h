@@ -39,6 +39,9 @@ void launch_rhs_generic(const NetDesc& nd, const float* P, const RhsArgs& a, hip
 void launch_norm_partials(const NormArgs& a, int nblocks, hipStream_t s);
 void launch_controller(StepState* st, const float* partials, int phase, float n_total,
                        hipStream_t s);
+void launch_reduce_partials(const StepState* st, const float* partials, float* out3, float n_local,
+                            hipStream_t s);
+void launch_controller_sums(StepState* st, const float* sums3, int phase, hipStream_t s);
 void launch_build_u0(const float* xs, float* u0, int nvars, int D, int B, hipStream_t s);
 void launch_copy_final(const StepState* st, const float* U0, const float* U1, float* out,
                        size_t n, hipStream_t s);

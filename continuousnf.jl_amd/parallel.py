@@ -36,6 +36,32 @@ def allreduce_sums(sums, group=None):
     return sums
 
 
+def make_shard_reduce(group=None):
+    """Callback for ``ICNF.set_shard_reduce``: sums the controller's three floats over the ranks of
+    ``group`` (gloo: on the host buffer itself; nccl = RCCL: through a 3-float device tensor)."""
+    import torch
+    import torch.distributed as dist
+
+    def reduce_(values):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        t = torch.from_numpy(values)             # shares the pinned host buffer
+        if dist.get_backend(group) == "nccl":
+            d = t.cuda()
+            dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(d)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return reduce_
+
+
+def lockstep(icnf, group=None, enable=True):
+    """Make every adaptive solve of ``icnf`` take the step sequence of the unsharded batch: the
+    error norm (and the initial-dt norms) are summed over the ranks before the controller runs."""
+    icnf.set_shard_reduce(make_shard_reduce(group) if enable else None)
+    return icnf
+
+
 def loss_from_global_sums(sums, mode_train: bool, lambdas):
     """Host formula of cnf_loss_from_sums, for callers that hold no handle (CPU tests)."""
     s = np.asarray(sums.detach().cpu() if hasattr(sums, "detach") else sums, dtype=np.float64)

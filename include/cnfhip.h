@@ -116,6 +116,19 @@ cnf_status cnf_set_params(cnf_handle h, const float* flat_dev, size_t n, void* s
 cnf_status cnf_set_cond(cnf_handle h, const float* ys, int B, void* stream);
 cnf_status cnf_set_cond_host(cnf_handle h, const float* ys, int B);
 
+/* Lock-step sharded solves.  The reference solves the whole D x B_total batch as
+ * ONE ODE system (inference_prob src/base_icnf.jl:266-286), so the adaptive controller sees one
+ * error norm over every column.  When the columns are split over GPUs, register a callback that
+ * sums `n` floats IN PLACE over all shards (MPI_Allreduce / RCCL / torch.distributed) and returns
+ * 0: every adaptive solve on this handle then takes its accept/reject decisions and step sizes
+ * from the global sums -- all shards take bit-identical decisions, namely those of the unsharded
+ * solve up to the association order of the float sum (1 ulp of the error norm).  The
+ * callback runs on the calling thread, three floats at a time, once per attempted step (plus twice
+ * for the automatic initial dt); every shard must call the solve collectively.  fn = NULL
+ * (default): independent per-shard solves.  Fixed-dt solves never call it. */
+typedef int (*cnf_shard_reduce_fn)(float* sums, int n, void* user);
+cnf_status cnf_set_shard_reduce(cnf_handle h, cnf_shard_reduce_fn fn, void* user);
+
 /* ---- the hot path ---------------------------------------------------------------- */
 
 /* One evaluation of augmented_f over the whole batch:

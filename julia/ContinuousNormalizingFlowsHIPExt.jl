@@ -105,6 +105,29 @@ function augmented_f(du::Any, u::Any, p::Any, ::Any, icnf::ICNF{T, <:HIPMatrixMo
     nothing
 end
 
+# ---- lock-step sharded solves (cnf_set_shard_reduce) ------------------------------------------
+# `reduce!` sums a Vector{Float32} in place over all shards, e.g. v -> MPI.Allreduce!(v, +, comm).
+# The adaptive controller of every shard then sees the error norm of the whole batch, as the
+# unsharded solve of inference_prob (src/base_icnf.jl:266-286) does.
+const SHARD_REDUCERS = IdDict{Any, Any}()
+function _shard_trampoline(p::Ptr{Float32}, n::Cint, user::Ptr{Cvoid})::Cint
+    try
+        unsafe_pointer_to_objref(user)[](unsafe_wrap(Array, p, Int(n)))
+        Cint(0)
+    catch
+        Cint(1)
+    end
+end
+function lockstep!(icnf::ICNF{T, <:HIPMatrixMode}, reduce!) where {T}
+    h = handle(icnf)
+    ref = Ref{Any}(reduce!)
+    SHARD_REDUCERS[icnf] = ref          # keep it rooted while the handle points at it
+    fn = @cfunction(_shard_trampoline, Cint, (Ptr{Float32}, Cint, Ptr{Cvoid}))
+    check(@ccall(libcnfhip.cnf_set_shard_reduce(h::Ptr{Cvoid}, fn::Ptr{Cvoid},
+                                                pointer_from_objref(ref)::Ptr{Cvoid})::Cint), h)
+    icnf
+end
+
 # ---- base_sol (src/base_icnf.jl:137-143): the whole solve in one C call ------------------------
 # Returns the final D x B matrix directly, which is what inference_sol slices
 # (src/base_icnf.jl:173-176).  The closure built by make_ode_func carries mode and ϵ; the

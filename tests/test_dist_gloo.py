@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from continuousnf.jl_amd.parallel import allreduce_sums, loss_from_global_sums, shard_range
+from continuousnf.jl_amd.parallel import allreduce_sums, loss_from_global_sums, make_shard_reduce, shard_range
 from oracle import cnf_oracle as O
 
 
@@ -45,6 +45,10 @@ def _worker(rank, world, port, q):
             sums = torch.tensor([logpx.sum(), E.sum(), n.sum(), A.sum(), hi - lo], dtype=torch.float32)
             g = allreduce_sums(sums)
             out[train] = (loss_from_global_sums(g, train, (cfg.lam1, cfg.lam2, cfg.lam3)), float(g[4]))
+        # the lock-step controller's callback (cnf_set_shard_reduce): in-place sum of 3 floats
+        v = np.array([1.5 + rank, 0.0, 100.0 * (rank + 1)], dtype=np.float32)
+        make_shard_reduce()(v)
+        out["lockstep"] = v.tolist()
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -71,8 +75,12 @@ def test_sharded_loss_matches_unsharded_gloo_ws2():
             assert cnt == xs.shape[1]
             assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (got, ref)
     assert res[0] == res[1]      # every rank holds the same mean
+    assert res[0]["lockstep"] == [4.0, 0.0, 300.0]
 
 
 def test_allreduce_is_identity_without_process_group():
     s = torch.arange(5, dtype=torch.float32)
     assert allreduce_sums(s) is s
+    v = np.array([1.0, 2.0, 3.0], dtype=np.float32)
+    make_shard_reduce()(v)
+    assert v.tolist() == [1.0, 2.0, 3.0]

@@ -484,3 +484,83 @@ def test_full_size_cfg5_properties():
     _, ref_lp, _, _ = O.inference(cfg, flat.astype(np.float64), xs[:, :24].astype(np.float64), None, False,
                                   dt=1 / 8, adaptive=False)
     assert_parity(lp[:24], ref_lp, "cfg5 exact logpdf")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_lockstep_shards_follow_the_unsharded_solve(kernel):
+    """SURVEY 8(e) option 2 through cnf_set_shard_reduce: two shards (two handles driven from two
+    threads; the callback is an in-process all-reduce) take exactly the step sequence of the
+    unsharded adaptive solve, whereas independent shard solves do not."""
+    import threading
+    cfg, _, _ = O.baseline_cfg(2)
+    B, cut = 300, 130                         # ragged shards on purpose
+    rng = np.random.default_rng(77)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.3)
+    xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+    xs[:, cut:] *= 2.5                        # make the shards differ in stiffness
+    eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+    kw = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+    full = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=kw)
+    _skip_if_unsupported(full, cnf.TrainMode(), B)
+    prob = cnf.inference_prob(full, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    ref = cnf.base_sol(full, prob).view().copy()
+    ref_st = dict(prob.stats)
+
+    shards = [(0, cut), (cut, B)]
+
+    def run(lock):
+        icnfs = [make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=kw) for _ in shards]
+        bar, bufs = threading.Barrier(len(shards)), [None] * len(shards)
+        calls = [0] * len(shards)
+
+        def reducer(r):
+            def f(v):
+                calls[r] += 1
+                bufs[r] = v.copy()
+                bar.wait()
+                tot = bufs[0] + bufs[1]
+                bar.wait()
+                v[:] = tot
+            return f
+        out, stats, errs = [None] * 2, [None] * 2, []
+
+        def work(r):
+            try:
+                lo, hi = shards[r]
+                if lock:
+                    icnfs[r].set_shard_reduce(reducer(r))
+                p = cnf.inference_prob(icnfs[r], cnf.TrainMode(), np.ascontiguousarray(xs[:, lo:hi]), flat, {},
+                                       eps=np.ascontiguousarray(eps[:, lo:hi]))
+                out[r] = cnf.base_sol(icnfs[r], p).view().copy()
+                stats[r] = dict(p.stats)
+            except Exception as e:            # pragma: no cover
+                errs.append(e)
+                bar.abort()
+        th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(120)
+        assert not errs, errs
+        return np.concatenate(out, axis=1), stats, calls
+
+    got, st, calls = run(True)
+    # every shard takes bit-identical decisions; against the unsharded solve the global sums differ
+    # only by the association order of the float additions (1 ulp), which the controller follows
+    # smoothly except at its dead zone (1 <= q <= 1.2 -> q = 1), so dt is compared loosely
+    assert st[0]["dt_last"] == st[1]["dt_last"] and st[0]["naccept"] == st[1]["naccept"]
+    assert abs(st[0]["naccept"] - ref_st["naccept"]) <= 1 and st[0]["nreject"] == ref_st["nreject"], (st, ref_st)
+    assert abs(st[0]["dt_last"] - ref_st["dt_last"]) <= 0.25 * ref_st["dt_last"]
+    assert calls[0] == calls[1] == 2 + st[0]["naccept"] + st[0]["nreject"]
+    assert_parity(got, ref, "lock-step shards vs unsharded", rtol=1e-4)
+
+    ind, st_i, _ = run(False)
+    assert st_i[0]["dt_last"] != st_i[1]["dt_last"]                   # the coupling the lock-step removes
+    assert_parity(ind, ref, "independent shards vs unsharded", rtol=5e-3)   # still within solver tolerance
+
+    # switching the callback off again restores independent solves; fixed-dt never calls it
+    ic = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=dict(adaptive=False, dt=1 / 16))
+    hit = []
+    ic.set_shard_reduce(lambda v: hit.append(1))
+    cnf.inference(ic, cnf.TrainMode(), xs[:, :64].copy(), flat, {}, eps=eps[:, :64].copy())
+    assert not hit
