@@ -1,0 +1,194 @@
+"""CPU oracle for the gradient of the training loss w.r.t. the flat parameter vector
+(SURVEY.md section 8(f) row f3).
+
+TEST INFRASTRUCTURE ONLY -- see the header of cnf_oracle.py; the same rules apply.
+PARITY UNPINNED against the Julia package (it cannot run here); pinned instead by reverse-mode
+autograd of the SAME discrete computation (torch, float64) and by finite differences
+(tests/test_grad_oracle.py).
+
+What the reference does: ``MLJModelInterface.fit`` (src/exts/mlj_ext/core_icnf.jl:59-73) hands
+``loss(icnf, TrainMode(), xs, ps, st)`` (src/icnf.jl:481-490) to Optimization.jl with
+``AutoEnzyme``; the derivative goes through ``solve`` by SciMLSensitivity's adjoint
+(Project.toml:31; third party, not vendored).  Restated here as the DISCRETE adjoint of the Tsit5
+steps actually taken (step sizes are constants of the differentiation, as in every ODE adjoint):
+it is the exact gradient of the number ``loss`` returns, so it can be checked to rounding.
+
+Per step  u+ = u + h sum_i b_i k_i,  k_i = f(U_i),  U_i = u + h sum_{j<i} a_ij k_j  (k_1 = f(u):
+FSAL only saves the evaluation, the function of u is the same):
+    for i = 6..1:  kbar_i = h (b_i lam + sum_{m>i} a_mi w_m);   (w_i, g_i) = vjp of f at U_i with kbar_i
+    lam <- lam + sum_i w_i;   grad += sum_i g_i
+
+vjp of the augmented right-hand side (src/icnf.jl:318-350).  Only the z rows of u enter f, so with
+the cotangent (a, c_l, c_E, c_n) of (zdot, ldot, Edot, ndot) the scalar to differentiate is
+    Phi(z, theta) = ahat' nn(z) + omega' J(z) tau
+    VJP mode:  ahat = a + c_E zdot/|zdot|,  omega = eps,  tau = -c_l eps + c_n eJ/|eJ|   (eJ = J' eps)
+    JVP mode:  ahat as above,  omega = -c_l eps + c_n Je/|Je|,  tau = eps                  (Je = J eps)
+(the unit vectors are evaluated at the point: first-order chain rule).  For the MLP
+h_l = s(a_l), a_l = W_l h_{l-1} + b_l, tangent t_l = s'(a_l) .* (W_l t_{l-1}), t_0 = tau:
+    Phi = ahat' h_L + omega' t_L
+    hbar_L = ahat, tbar_L = omega;  for l = L..1 with p_l = W_l t_{l-1}:
+        abar_l = hbar_l .* s'(a_l) + tbar_l .* s''(a_l) .* p_l
+        pbar_l = tbar_l .* s'(a_l)
+        Wbar_l += abar_l h_{l-1}' + pbar_l t_{l-1}';   bbar_l += abar_l
+        hbar_{l-1} = W_l' abar_l;   tbar_{l-1} = W_l' pbar_l
+    zbar = hbar_0 (rows of z).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import cnf_oracle as O
+
+
+def act_d2(kind: int, a: np.ndarray):
+    """Second derivative of the activation w.r.t. its pre-activation."""
+    one = a.dtype.type(1)
+    if kind in (O.ACT_IDENTITY, O.ACT_RELU):
+        return np.zeros_like(a)
+    if kind == O.ACT_TANH:
+        h = np.tanh(a)
+        return -2 * h * (one - h * h)
+    if kind == O.ACT_SIGMOID:
+        s = O._sigmoid(a)
+        return s * (one - s) * (one - 2 * s)
+    if kind == O.ACT_SOFTPLUS:
+        s = O._sigmoid(a)
+        return s * (one - s)
+    if kind == O.ACT_SWISH:
+        s = O._sigmoid(a)
+        ds = s * (one - s)
+        return 2 * ds + a * ds * (one - 2 * s)
+    if kind == O.ACT_ELU:
+        return np.where(a > 0, np.zeros_like(a), np.exp(np.minimum(a, 0)))
+    raise ValueError(kind)
+
+
+def _unit(v):
+    n = np.sqrt(np.sum(v * v, axis=0, keepdims=True))
+    return np.divide(v, n, out=np.zeros_like(v), where=n > 0)
+
+
+def flatten_grads(net: O.Net, gWs, gbs):
+    parts = []
+    for gW, gb in zip(gWs, gbs):
+        parts.append(np.asarray(gW).T.reshape(-1))      # out x in, column-major
+        parts.append(np.asarray(gb).reshape(-1))
+    return np.concatenate(parts)
+
+
+def rhs_vjp(net: O.Net, flat, z, eps, cot, norm_z: bool, norm_j: bool, use_jvp=False, ys=None):
+    """Pullback of augmented_f (TrainMode) at z.  ``cot``: D x B cotangent of du = [zdot; ldot; Edot;
+    ndot].  Returns (zbar [n_in x B], grad [n_params]) -- grad summed over the columns."""
+    n_in = z.shape[0]
+    Ws, bs = O.unflatten_params(net, flat)
+    x0 = z if ys is None else np.vstack([z, ys])
+    # forward with pre-activations
+    hs, as_ = [x0], []
+    h = x0
+    for W, b in zip(Ws, bs):
+        a = W @ h + b[:, None]
+        as_.append(a)
+        h = O.act_apply(net.acts[len(as_) - 1], a)[0]
+        hs.append(h)
+    d1 = [O.act_apply(k, a)[1] for k, a in zip(net.acts, as_)]
+    d2 = [act_d2(k, a) for k, a in zip(net.acts, as_)]
+    zdot = hs[-1]
+    a_z, c_l, c_E, c_n = cot[:n_in], cot[n_in:n_in + 1], cot[n_in + 1:n_in + 2], cot[n_in + 2:n_in + 3]
+    ahat = a_z + (c_E * _unit(zdot) if norm_z else 0)
+    if use_jvp:
+        _, Je = O.mlp_jvp(net, flat, z, eps, ys)
+        omega = -c_l * eps + (c_n * _unit(Je) if norm_j else 0)
+        tau = eps
+    else:
+        _, eJ = O.mlp_vjp(net, flat, z, eps, ys)
+        omega = eps
+        tau = -c_l * eps + (c_n * _unit(eJ) if norm_j else 0)
+    # forward tangent sweep
+    t = tau if ys is None else np.vstack([tau, np.zeros_like(ys)])
+    ts, ps = [t], []
+    for W, d in zip(Ws, d1):
+        p = W @ t
+        ps.append(p)
+        t = d * p
+        ts.append(t)
+    # reverse sweep
+    hbar, tbar = ahat, omega
+    gWs, gbs = [None] * len(Ws), [None] * len(Ws)
+    for l in reversed(range(len(Ws))):
+        abar = hbar * d1[l] + tbar * d2[l] * ps[l]
+        pbar = tbar * d1[l]
+        gWs[l] = abar @ hs[l].T + pbar @ ts[l].T
+        gbs[l] = abar.sum(axis=1)
+        hbar = Ws[l].T @ abar
+        tbar = Ws[l].T @ pbar
+    return hbar[:n_in], flatten_grads(net, gWs, gbs)
+
+
+def forward_record(f, u0, t0, t1, dts):
+    """Replays the accepted steps ``dts`` (absolute sizes) and returns the states [u_0 .. u_N]."""
+    T = u0.dtype.type
+    tdir = T(1) if t1 >= t0 else T(-1)
+    us = [u0.copy()]
+    u, k1 = u0, f(u0)
+    for h in dts:
+        u, k1, _ = O.tsit5_step(f, u, k1, tdir * T(h))
+        us.append(u)
+    return us
+
+
+def final_cotangent(cfg: O.Cfg, fsol):
+    """d loss / d fsol for loss = mean_b(-logpx + lam1 E + lam2 n + lam3 A) (src/icnf.jl:481-490 with
+    inference_sol src/base_icnf.jl:167-189): -logpx = |z|^2/2 + const + dlogp."""
+    n_in, B = cfg.n_in, fsol.shape[1]
+    lam = np.zeros_like(fsol)
+    z = fsol[:n_in]
+    lam[:n_in] = z
+    if cfg.lam3 != 0 and cfg.naugs > 0:
+        lam[cfg.nvars:n_in] += cfg.lam3 * _unit(z[cfg.nvars:])
+    lam[n_in] = 1
+    lam[n_in + 1] = cfg.lam1
+    lam[n_in + 2] = cfg.lam2
+    return lam / B
+
+
+def loss_and_grad(cfg: O.Cfg, flat, xs, eps, ys=None, **solve_kw):
+    """(loss, d loss / d flat, stats) of the TrainMode loss through the Tsit5 solve."""
+    flat = np.asarray(flat)
+    u0 = O.inference_u0(cfg, xs, True)
+    f = cfg.rhs(flat, eps, True, ys)
+    fsol, st = O.tsit5_solve(f, u0, cfg.tspan[0], cfg.tspan[1], **solve_kw)
+    us = forward_record(f, u0, cfg.tspan[0], cfg.tspan[1], st.dts)
+    assert np.array_equal(us[-1], fsol)
+    logpx, regs = O.inference_sol(cfg, fsol, True)
+    val = O.loss(cfg, logpx, regs, True)
+    T = u0.dtype.type
+    tdir = 1.0 if cfg.tspan[1] >= cfg.tspan[0] else -1.0
+    n_in = cfg.n_in
+    lam = final_cotangent(cfg, fsol)
+    grad = np.zeros(flat.size, dtype=flat.dtype)
+    A, Bc = O.TSIT5_A, O.TSIT5_B
+    nz, nj = cfg.lam1 != 0, cfg.lam2 != 0
+    for n in reversed(range(len(st.dts))):
+        h = T(tdir * st.dts[n])
+        u = us[n]
+        ks, Us = [], []
+        for s in range(6):
+            acc = np.zeros_like(u)
+            for j in range(s):
+                acc = acc + T(A[s][j]) * ks[j]
+            U = u + h * acc
+            Us.append(U)
+            ks.append(f(U))
+        ws = [None] * 6
+        for i in reversed(range(6)):
+            kbar = T(Bc[i]) * lam
+            for m in range(i + 1, 6):
+                kbar[:n_in] += T(A[m][i]) * ws[m]
+            kbar = h * kbar
+            zbar, g = rhs_vjp(cfg.net, flat, Us[i][:n_in], eps, kbar, nz, nj, cfg.use_jvp, ys)
+            ws[i] = zbar
+            grad += g
+        lam = lam.copy()
+        for i in range(6):
+            lam[:n_in] += ws[i]
+    return val, grad, st
