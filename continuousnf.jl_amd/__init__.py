@@ -6,7 +6,7 @@ from . import _lib
 from ._lib import CNFError, build
 from .base_icnf import (ICNF, ODEProblem, base_sol, construct, generate, generate_prob, generate_sol,
                         inference, inference_prob,
-                        inference_sol, loss, loss_from_sums, loss_sums, n_augment,
+                        inference_sol, loss, loss_and_grad, loss_from_sums, loss_sums, n_augment,
                         n_augment_input, steer_tspan)
 from .dist import CondICNFDist, ICNFDist, logpdf, pdf, rand
 from .icnf import augmented_f

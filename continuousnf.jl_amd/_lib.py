@@ -69,6 +69,11 @@ _SIGNATURES = {
     "cnf_loss_from_sums": (C.c_int, [C.c_void_p, C.c_int, _fp, C.POINTER(C.c_float)]),
     "cnf_status_string": (C.c_char_p, [C.c_int]),
     "cnf_last_error": (C.c_char_p, [C.c_void_p]),
+    "cnf_loss_grad": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.POINTER(cnf_solve_opts),
+                                C.POINTER(C.c_float), _fp, C.POINTER(cnf_solve_stats), C.c_void_p]),
+    "cnf_loss_grad_host": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.POINTER(cnf_solve_opts),
+                                     C.POINTER(C.c_float), _fp, C.POINTER(cnf_solve_stats)]),
+    "cnf_grad_steps": (C.c_int, [C.c_void_p, _fp, C.c_int]),
     "cnf_abi_version": (C.c_int, []),
     "cnf_state_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "cnf_kernel_for": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

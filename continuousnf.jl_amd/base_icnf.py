@@ -475,6 +475,47 @@ def loss(icnf: ICNF, mode, xs, *args, eps=None):
     return loss_from_sums(icnf, mode, sums)
 
 
+def loss_and_grad(icnf: ICNF, mode, xs, *args, eps=None):
+    """``(loss, d loss / d ps)``: the pair ``MLJModelInterface.fit`` gets from Enzyme on
+    ``loss(icnf, TrainMode(), xs, ps, st)`` (src/exts/mlj_ext/core_icnf.jl:59-73, src/icnf.jl:481-490),
+    here from the discrete adjoint of the solve (cnf_loss_grad).  The gradient has the layout of
+    ``ps`` and lives where ``xs`` lives (torch.cuda tensor or numpy array).  Conditional models:
+    ``(xs, ys, ps, st)`` as everywhere else.  Steering draws t1 exactly as ``loss`` does."""
+    if _mode_id(mode) != _lib.MODE_TRAIN:
+        raise NotImplementedError("gradients are implemented for TrainMode (the mode the reference trains in)")
+    ys, ps, st = _split_cond_args(icnf, args)
+    xb = _as_colmajor(xs, icnf.nvars, "xs")
+    B = xb.B
+    icnf.set_params(ps)
+    icnf.set_cond(ys, B)
+    if eps is not None:
+        eb = _as_colmajor(eps, icnf.nvars + n_augment_input(icnf), "eps")
+        if eb.B != B:
+            raise ValueError("eps must have one column per sample")
+    else:
+        eb = draw_eps(icnf, xb, B)
+    opts = _solve_opts(icnf, steer_tspan(icnf, mode))
+    stats = _lib.cnf_solve_stats()
+    val = C.c_float()
+    l, h = _lib.lib(), icnf.handle()
+    n_params = icnf.nn.n_params
+    if xb.torch is not None:
+        t = xb.torch
+        grad = t.empty(n_params, dtype=t.float32, device=xb.arr.device)
+        _lib.check(l.cnf_loss_grad(h, xb.ptr, eb.ptr, B, C.byref(opts), C.byref(val), grad.data_ptr(),
+                                   C.byref(stats), _stream(xb)), h)
+    else:
+        grad = np.empty(n_params, dtype=np.float32)
+        _lib.check(l.cnf_loss_grad_host(h, xb.ptr, eb.ptr, B, C.byref(opts), C.byref(val), grad.ctypes.data,
+                                        C.byref(stats)), h)
+    icnf.last_stats = stats.as_dict()
+    n = l.cnf_grad_steps(h, None, 0)
+    hs = np.empty(max(n, 1), dtype=np.float32)
+    l.cnf_grad_steps(h, hs.ctypes.data, n)
+    icnf.last_steps = hs[:n]             # signed step sizes the gradient was taken through
+    return float(val.value), grad
+
+
 def loss_sums(icnf: ICNF, logpx, regs):
     """(sum logpx, sum E, sum n, sum A, B) -- the only cross-shard quantity.  Device
     inputs are reduced on the device (cnf_loss_sums) and stay there."""

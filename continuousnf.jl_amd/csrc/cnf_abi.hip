@@ -4,6 +4,8 @@
 #include "cnf_dev.h"
 #include "cnf_kernels.h"
 #include "cnf_mfma.h"
+#include "cnf_grad.h"
+#include <vector>
 
 #include <cmath>
 #include <cstdio>
@@ -41,6 +43,20 @@ struct cnf_ctx {
     // lock-step sharded solves: host callback summing 3 floats over the shards (null: off)
     cnf_shard_reduce_fn shard_reduce = nullptr;
     void* shard_user = nullptr;
+    // gradient path (cnf_loss_grad): transposed weights, per-step trajectory, adjoint scratch
+    float* d_PT = nullptr;
+    bool pt_valid = false;
+    std::vector<float*> traj_blocks;   // TRAJ_BLOCK state slots each, slot = (n_in + 3) * grad_cap_B floats
+    size_t grad_cap_B = 0;
+    float* grad_arena = nullptr;
+    float* g_US[5] = {};          // stage states 2..6
+    float* g_W[6] = {};           // zbar per stage
+    float* g_lam = nullptr;
+    float *g_HS = nullptr, *g_TS = nullptr, *g_AB = nullptr, *g_PB = nullptr;
+    float* g_part = nullptr;      // GRAD_MAX_KSPLIT x n_params
+    float* g_grad = nullptr;      // n_params (host-pointer variant)
+    std::vector<float> last_hs;   // signed step sizes of the last cnf_loss_grad solve
+    float* d_ys = nullptr;        // conditional models: copy of ys (n_cond x cond_B), kept for the weight gradient
     float* d_sums = nullptr;      // 3 floats
     float* h_sums = nullptr;      // pinned, 3 floats
     std::string err;
@@ -144,7 +160,7 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     if (e == hipSuccess) e = hipMalloc(&h->d_state, 2 * sizeof(StepState));
     if (e == hipSuccess) e = hipMalloc(&h->partials, 4 * MAX_PARTIALS * sizeof(float));
     if (e == hipSuccess) e = hipHostMalloc(&h->h_state, 3 * sizeof(StepState), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc(&h->d_sums, 4 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&h->d_sums, 8 * sizeof(float));
     if (e == hipSuccess) e = hipHostMalloc(&h->h_sums, 4 * sizeof(float), hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[1], hipEventDisableTiming);
@@ -163,6 +179,10 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     mfma_plan_free(h->mfma);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_cond) (void)hipFree(h->d_cond);
+    if (h->d_ys) (void)hipFree(h->d_ys);
+    if (h->d_PT) (void)hipFree(h->d_PT);
+    if (h->grad_arena) (void)hipFree(h->grad_arena);
+    for (float* b : h->traj_blocks) (void)hipFree(b);
     if (h->arena) (void)hipFree(h->arena);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->partials) (void)hipFree(h->partials);
@@ -185,6 +205,7 @@ extern "C" cnf_status cnf_set_params(cnf_handle h, const float* flat_dev, size_t
     if (ms != CNF_OK) return fail(h, ms, "MFMA weight packing failed");
     HIPCHK(h, hipStreamSynchronize(s));
     h->have_params = true;
+    h->pt_valid = false;
     h->cond_B = 0;       // the conditioning bias depends on W1 and b1
     return CNF_OK;
 }
@@ -198,6 +219,7 @@ extern "C" cnf_status cnf_set_params_host(cnf_handle h, const float* flat, size_
     if (ms != CNF_OK) return fail(h, ms, "MFMA weight packing failed");
     HIPCHK(h, hipDeviceSynchronize());
     h->have_params = true;
+    h->pt_valid = false;
     h->cond_B = 0;
     return CNF_OK;
 }
@@ -247,10 +269,15 @@ extern "C" cnf_status cnf_set_cond(cnf_handle h, const float* ys, int B, void* s
     if (h->cond_B != B || h->cbs != cbs) {
         HIPCHK(h, hipDeviceSynchronize());
         if (h->d_cond) { (void)hipFree(h->d_cond); h->d_cond = nullptr; }
+        if (h->d_ys) { (void)hipFree(h->d_ys); h->d_ys = nullptr; }
         h->cond_B = 0;
         HIPCHK(h, hipMalloc(&h->d_cond, (size_t)B * cbs * sizeof(float)));
+        HIPCHK(h, hipMalloc(&h->d_ys, (size_t)B * h->nd.n_cond * sizeof(float)));
         h->cbs = cbs;
     }
+    // the gradient path needs ys itself (d loss / d W1[:, n_in:] = sum_b abar_1 ys')
+    HIPCHK(h, hipMemcpyAsync(h->d_ys, ys, (size_t)B * h->nd.n_cond * sizeof(float), hipMemcpyDeviceToDevice,
+                             (hipStream_t)stream));
     launch_cond_bias(h->nd, h->d_params, ys, h->d_cond, cbs, B, (hipStream_t)stream);
     HIPCHK(h, hipGetLastError());
     h->cond_B = B;
@@ -416,10 +443,35 @@ static cnf_status lockstep_controller(cnf_handle h, StepState* state, const floa
     return CNF_OK;
 }
 
+// Trajectory store of the gradient path: state after every accepted step + the step sizes.
+static const int TRAJ_BLOCK = 16;
+struct Recorder {
+    std::vector<float> hs;        // signed step of accepted step n (u_n -> u_{n+1})
+    int n = 0;                    // accepted steps recorded; slot n holds u_n
+};
+static cnf_status traj_slot(cnf_handle h, int n, float** out) {
+    const size_t slot = ((size_t)h->nd.n_in + 3) * h->grad_cap_B;
+    while ((size_t)n >= h->traj_blocks.size() * TRAJ_BLOCK) {
+        float* b = nullptr;
+        HIPCHK(h, hipMalloc(&b, slot * TRAJ_BLOCK * sizeof(float)));
+        h->traj_blocks.push_back(b);
+    }
+    *out = h->traj_blocks[n / TRAJ_BLOCK] + (size_t)(n % TRAJ_BLOCK) * slot;
+    return CNF_OK;
+}
+
+static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const float* eps, float* u_out, int B,
+                             const cnf_solve_opts* opts, cnf_solve_stats* stats, void* stream, Recorder* rec);
+
 extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
                                       const float* eps, float* u_out, int B,
                                       const cnf_solve_opts* opts, cnf_solve_stats* stats,
                                       void* stream) {
+    return solve_core(h, mode, u0, eps, u_out, B, opts, stats, stream, nullptr);
+}
+
+static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const float* eps, float* u_out, int B,
+                             const cnf_solve_opts* opts, cnf_solve_stats* stats, void* stream, Recorder* rec) {
     cnf_status s = check_call(h, mode, B);
     if (s != CNF_OK) return s;
     if (!u0 || !u_out || !opts) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
@@ -533,10 +585,22 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
     }
     StepState* cur_state = h->d_state;   // slot holding the live integrator state
     int pp = 0;                          // partials buffer the NEXT launch reads
-    if (lockstep) {
-        // one attempt at a time: every shard must see the same global error norm before the next
-        // attempt is sized, so there is nothing to queue ahead
+    if (lockstep || rec) {
+        // one attempt at a time.  Lock-step: every shard must see the same global error norm before
+        // the next attempt is sized.  Recording (gradient path): the host files the state after
+        // every accepted step.
         StepState* snap = &h->h_state[0];
+        float h_attempt = 0.f;
+        int seen_accept = 0;
+        if (rec) {
+            float* slot0;
+            if ((s = traj_slot(h, 0, &slot0)) != CNF_OK) return s;
+            HIPCHK(h, hipMemcpyAsync(slot0, h->U[0], n * sizeof(float), hipMemcpyDeviceToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(snap, h->d_state, sizeof(StepState), hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            h_attempt = snap->h;
+            rec->hs.clear(); rec->n = 0;
+        }
         for (long it = 0;; ++it) {
             if (it >= (long)opts->maxiters) return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
             if (use_mfma) {
@@ -548,10 +612,24 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
                 enqueue_attempt_generic(h, train, eps, B, nblk, st, false);
                 launches += 7;
             }
-            if ((s = lockstep_controller(h, h->d_state, h->partials, 2, (float)n, st)) != CNF_OK) return s;
-            launches += 2;
+            if (lockstep) {
+                if ((s = lockstep_controller(h, h->d_state, h->partials, 2, (float)n, st)) != CNF_OK) return s;
+                launches += 2;
+            } else {
+                launch_controller(h->d_state, h->partials, 2, (float)n, st);
+                launches += 1;
+            }
             HIPCHK(h, hipMemcpyAsync(snap, h->d_state, sizeof(StepState), hipMemcpyDeviceToHost, st));
             HIPCHK(h, hipStreamSynchronize(st));
+            if (rec && snap->naccept > seen_accept) {
+                seen_accept = snap->naccept;
+                float* slot;
+                if ((s = traj_slot(h, seen_accept, &slot)) != CNF_OK) return s;
+                HIPCHK(h, hipMemcpyAsync(slot, h->U[snap->cur], n * sizeof(float), hipMemcpyDeviceToDevice, st));
+                rec->hs.push_back(h_attempt);
+                rec->n = seen_accept;
+            }
+            h_attempt = snap->h;
             if (snap->done) break;
         }
         launch_copy_final(h->d_state, h->U[0], h->U[1], u_out, n, st);
@@ -801,4 +879,165 @@ extern "C" cnf_status cnf_loss_from_sums(cnf_handle h, int mode, const float* su
     else                             // src/base_icnf.jl:496
         *loss = (float)(-(double)sums5[0] / cnt);
     return CNF_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Gradient of the TrainMode loss w.r.t. the parameters.
+// Reference: MLJModelInterface.fit differentiates loss(icnf, TrainMode(), xs, ps, st) with Enzyme
+// through the solve (src/exts/mlj_ext/core_icnf.jl:59-73, src/icnf.jl:481-490).
+// ---------------------------------------------------------------------------------------
+static cnf_status ensure_grad_capacity(cnf_handle h, int B) {
+    HIPCHK(h, hipSetDevice(h->device));
+    const GradLayout g = grad_layout(h->nd);
+    if (!h->d_PT) HIPCHK(h, hipMalloc(&h->d_PT, h->n_params * sizeof(float)));
+    if ((size_t)B <= h->grad_cap_B) return CNF_OK;
+    HIPCHK(h, hipDeviceSynchronize());
+    if (h->grad_arena) { (void)hipFree(h->grad_arena); h->grad_arena = nullptr; }
+    for (float* b : h->traj_blocks) (void)hipFree(b);
+    h->traj_blocks.clear();
+    h->grad_cap_B = 0;
+    const size_t cap = ((size_t)B + 63) & ~(size_t)63;
+    const size_t D = (size_t)h->nd.n_in + 3, n_in = h->nd.n_in;
+    const size_t total = 5 * D * cap + 7 * n_in * cap + 2 * (size_t)g.sum_in * cap + 2 * (size_t)g.sum_out * cap +
+                         ((size_t)GRAD_MAX_KSPLIT + 1) * h->n_params;
+    HIPCHK(h, hipMalloc(&h->grad_arena, total * sizeof(float)));
+    float* p = h->grad_arena;
+    for (int i = 0; i < 5; ++i) { h->g_US[i] = p; p += D * cap; }
+    for (int i = 0; i < 6; ++i) { h->g_W[i] = p; p += n_in * cap; }
+    h->g_lam = p; p += n_in * cap;
+    h->g_HS = p; p += (size_t)g.sum_in * cap;
+    h->g_TS = p; p += (size_t)g.sum_in * cap;
+    h->g_AB = p; p += (size_t)g.sum_out * cap;
+    h->g_PB = p; p += (size_t)g.sum_out * cap;
+    h->g_part = p; p += (size_t)GRAD_MAX_KSPLIT * h->n_params;
+    h->g_grad = p;
+    h->grad_cap_B = cap;
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* eps, int B,
+                                    const cnf_solve_opts* opts, float* loss_out, float* grad,
+                                    cnf_solve_stats* stats, void* stream) {
+    const int mode = CNF_MODE_TRAIN;
+    cnf_status s = check_call(h, mode, B);
+    if (s != CNF_OK) return s;
+    if (!xs || !eps || !opts || !loss_out || !grad) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    if (B < 1) return fail(h, CNF_ERR_BAD_SHAPE, "the loss is a mean over the batch: B must be >= 1");
+    const GradLayout gl = grad_layout(h->nd);
+    if (!grad_supported(h->nd, gl)) return fail(h, CNF_ERR_UNSUPPORTED, "network too wide for the gradient kernels");
+    if ((s = ensure_capacity(h, B)) != CNF_OK) return s;
+    if ((s = ensure_grad_capacity(h, B)) != CNF_OK) return s;
+    hipStream_t st = (hipStream_t)stream;
+    const NetDesc& nd = h->nd;
+    const int n_in = nd.n_in, D = n_in + 3;
+    const size_t n = (size_t)D * B;
+    if (!h->pt_valid) {
+        HIPCHK(h, launch_transpose_params(nd, h->d_params, h->d_PT, st));
+        h->pt_valid = true;
+    }
+
+    // ---- forward: u0, recorded solve, loss ------------------------------------------------------
+    float* u0 = h->g_US[0];
+    launch_build_u0(xs, u0, nd.nvars, D, B, st);
+    Recorder rec;
+    cnf_solve_stats sst{};
+    float* fsol = h->g_US[1];
+    if ((s = solve_core(h, mode, u0, eps, fsol, B, opts, &sst, stream, &rec)) != CNF_OK) return s;
+    h->last_hs = rec.hs;
+    launch_post(nd, 1, fsol, h->tmp_logpx, h->tmp_regs, B, st);
+    launch_loss_sums(h->tmp_logpx, h->tmp_regs, B, h->d_sums, st);     // 5 floats; d_sums holds 8
+    float sums[5];
+    HIPCHK(h, hipMemcpyAsync(sums, h->d_sums, 5 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    if ((s = cnf_loss_from_sums(h, mode, sums, loss_out)) != CNF_OK) return s;
+
+    // ---- backward: discrete adjoint of the recorded steps ---------------------------------------
+    int ksplit, chunk;
+    grad_ksplit(nd, gl, B, &ksplit, &chunk);
+    HIPCHK(h, hipMemsetAsync(h->g_part, 0, (size_t)ksplit * h->n_params * sizeof(float), st));
+    HIPCHK(h, launch_final_cotangent(nd, h->lam[2], fsol, h->g_lam, B, st));
+    const float invB = 1.0f / (float)B;
+    const float lam_l = invB, lam_E = h->lam[0] * invB, lam_n = h->lam[1] * invB;   // constant scalar rows
+    static const float A[6][5] = {
+        {0, 0, 0, 0, 0},
+        {TS_A21, 0, 0, 0, 0},
+        {TS_A31, TS_A32, 0, 0, 0},
+        {TS_A41, TS_A42, TS_A43, 0, 0},
+        {TS_A51, TS_A52, TS_A53, TS_A54, 0},
+        {TS_A61, TS_A62, TS_A63, TS_A64, TS_A65}};
+    static const float Bw[6] = {TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76};
+    int k_rhs;
+    if ((s = resolve_kernel(h, mode, B, opts->kernel, &k_rhs)) != CNF_OK) return s;
+    for (int step = rec.n - 1; step >= 0; --step) {
+        float* un;
+        if ((s = traj_slot(h, step, &un)) != CNF_OK) return s;
+        const float hs = rec.hs[step];
+        // stage states U_1 = u_n, U_2..U_6, with k_1..k_5 in K1[0], Ks[0..3]
+        const float* US[6] = {un, h->g_US[0], h->g_US[1], h->g_US[2], h->g_US[3], h->g_US[4]};
+        float* KK[5] = {h->K1[0], h->Ks[0], h->Ks[1], h->Ks[2], h->Ks[3]};
+        for (int i = 0; i < 5; ++i) {
+            if ((s = cnf_rhs(h, mode, k_rhs, US[i], eps, KK[i], B, stream)) != CNF_OK) return s;
+            StageK sk{};
+            sk.nk = i + 1;
+            for (int j = 0; j <= i; ++j) { sk.k[j] = KK[j]; sk.coef[j] = A[i + 1][j]; }
+            HIPCHK(h, launch_stage_combine(un, sk, hs, const_cast<float*>(US[i + 1]), n, st));
+        }
+        for (int i = 5; i >= 0; --i) {
+            AdjArgs a{};
+            a.P = h->d_params; a.PT = h->d_PT; a.ustage = US[i]; a.eps = eps;
+            a.ys = nd.n_cond > 0 ? h->d_ys : nullptr;
+            a.lam = h->g_lam;
+            a.nw = 0;
+            for (int m = i + 1; m < 6; ++m) { a.w[a.nw] = h->g_W[m]; a.wc[a.nw] = A[m][i]; ++a.nw; }
+            a.cb = Bw[i]; a.hstep = hs;
+            a.c_l = hs * Bw[i] * lam_l; a.c_E = hs * Bw[i] * lam_E; a.c_n = hs * Bw[i] * lam_n;
+            a.w_out = h->g_W[i];
+            a.HS = h->g_HS; a.TS = h->g_TS; a.AB = h->g_AB; a.PB = h->g_PB;
+            a.B = B;
+            HIPCHK(h, launch_adj(nd, gl, a, st));
+            HIPCHK(h, launch_wgrad(nd, gl, h->g_AB, h->g_PB, h->g_HS, h->g_TS, h->g_part, (int)h->n_params, B,
+                                   ksplit, chunk, st));
+        }
+        StageK ws{};
+        ws.nk = 6;
+        for (int i = 0; i < 6; ++i) ws.k[i] = h->g_W[i];
+        HIPCHK(h, launch_lambda_update(h->g_lam, ws, (size_t)n_in * B, st));
+    }
+    HIPCHK(h, launch_grad_reduce(h->g_part, grad, (int)h->n_params, ksplit, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    if (stats) *stats = sst;
+    return CNF_OK;
+}
+
+extern "C" int cnf_grad_steps(cnf_handle h, float* hs, int cap) {
+    if (!h) return -1;
+    const int n = (int)h->last_hs.size();
+    if (hs) for (int i = 0; i < n && i < cap; ++i) hs[i] = h->last_hs[i];
+    return n;
+}
+
+extern "C" cnf_status cnf_loss_grad_host(cnf_handle h, const float* xs, const float* eps, int B,
+                                         const cnf_solve_opts* opts, float* loss_out, float* grad,
+                                         cnf_solve_stats* stats) {
+    cnf_status s = check_call(h, CNF_MODE_TRAIN, B);
+    if (s != CNF_OK) return s;
+    if (!xs || !eps || !grad) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    if (B < 1) return fail(h, CNF_ERR_BAD_SHAPE, "the loss is a mean over the batch: B must be >= 1");
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((s = ensure_grad_capacity(h, B)) != CNF_OK) return s;
+    const size_t nx = (size_t)h->nd.nvars * B, ne = (size_t)h->nd.n_in * B;
+    float *x_d = nullptr, *e_d = nullptr;
+    HIPCHK(h, hipMalloc(&x_d, nx * sizeof(float)));
+    hipError_t e = hipMalloc(&e_d, ne * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(x_d, xs, nx * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(e_d, eps, ne * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
+    if (s == CNF_OK) s = cnf_loss_grad(h, x_d, e_d, B, opts, loss_out, h->g_grad, stats, nullptr);
+    if (s == CNF_OK) {
+        e = hipMemcpy(grad, h->g_grad, h->n_params * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(x_d);
+    if (e_d) (void)hipFree(e_d);
+    return s;
 }

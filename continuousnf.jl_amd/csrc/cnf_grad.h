@@ -1,0 +1,53 @@
+// Argument blocks and launch wrappers of the gradient path (cnf_grad.hip), used by the C ABI.
+#pragma once
+#include "cnf_dev.h"
+
+#define GRAD_MAX_KSPLIT 64
+
+// Row layouts of the [sample][feature] arrays exchanged between k_adj and k_wgrad.
+struct GradLayout {
+    int in0;                        // n_in + n_cond: input rows of the first layer
+    int in_off[CNF_MAX_LAYERS];     // offset of layer l's INPUT (h_{l-1}, t_{l-1}) in an HS/TS row
+    int out_off[CNF_MAX_LAYERS];    // offset of layer l's OUTPUT side (abar_l, pbar_l) in an AB/PB row
+    int sum_in, sum_out;            // row lengths
+    int out_last;                   // dims[L]
+    int max_dim;
+};
+
+struct AdjArgs {
+    const float* P;                 // flat parameters (Lux layout)
+    const float* PT;                // per-layer transposed weights, same offsets
+    const float* ustage;            // [B][n_in + 3] stage state (rows of z are read)
+    const float* eps;               // [B][n_in]
+    const float* ys;                // [B][n_cond] or null
+    const float* lam;               // [B][n_in]  cotangent of the z rows of u_{n+1}
+    const float* w[5];              // zbar of the later stages
+    float wc[5];                    // a_{m,i}
+    int nw;
+    float cb;                       // b_i
+    float hstep;                    // signed step size
+    float c_l, c_E, c_n;            // h * b_i * (cotangents of the three scalar rows)
+    float* w_out;                   // [B][n_in]
+    float* HS; float* TS;           // [B][sum_in]
+    float* AB; float* PB;           // [B][sum_out]
+    int B;
+};
+
+struct StageK {
+    const float* k[6];
+    float coef[6];
+    int nk;
+};
+
+GradLayout grad_layout(const NetDesc& nd);
+bool grad_supported(const NetDesc& nd, const GradLayout& g);
+void grad_ksplit(const NetDesc& nd, const GradLayout& g, int B, int* ksplit, int* chunk);
+hipError_t launch_adj(const NetDesc& nd, const GradLayout& g, const AdjArgs& a, hipStream_t s);
+hipError_t launch_wgrad(const NetDesc& nd, const GradLayout& g, const float* AB, const float* PB, const float* HS,
+                        const float* TS, float* gpart, int n_params, int B, int ksplit, int chunk, hipStream_t s);
+hipError_t launch_grad_reduce(const float* gpart, float* grad, int n_params, int ksplit, hipStream_t s);
+hipError_t launch_transpose_params(const NetDesc& nd, const float* P, float* PT, hipStream_t s);
+hipError_t launch_stage_combine(const float* u, const StageK& ks, float h, float* out, size_t n, hipStream_t s);
+hipError_t launch_lambda_update(float* lam, const StageK& ws, size_t n, hipStream_t s);
+hipError_t launch_final_cotangent(const NetDesc& nd, float lambda3, const float* fsol, float* lam, int B,
+                                  hipStream_t s);

@@ -1,0 +1,586 @@
+// Gradient of the training loss w.r.t. the flat parameter vector.
+//
+// Reference: MLJModelInterface.fit (src/exts/mlj_ext/core_icnf.jl:59-73) differentiates
+// loss(icnf, TrainMode(), xs, ps, st) (src/icnf.jl:481-490) with Enzyme through the ODE solve
+// (SciMLSensitivity; third party).  Here: the discrete adjoint of the Tsit5 steps actually taken,
+// i.e. the exact gradient of the number `loss` returns (oracle/cnf_grad_oracle.py has the algebra).
+//
+// Kernels in this file:
+//   k_adj<TS>     pullback of ONE augmented_f evaluation (src/icnf.jl:318-350, :384-420) at a stage
+//                 state: a workgroup owns TS samples, a thread owns one feature of every layer; the
+//                 four sweeps (forward, reverse of eps, forward tangent, reverse of the cotangent)
+//                 are matrix-vector products against the weights (read through L2, coalesced: W for
+//                 the forward sweeps, a transposed copy for the reverse ones) with the activations of
+//                 the TS samples in LDS.  Emits zbar and, per layer, the four factors of the weight
+//                 gradient in [sample][feature] arrays.
+//   k_wgrad       Wbar_l += ABAR_l^T H_{l-1} + PBAR_l^T T_{l-1}, bbar_l += sum_b ABAR_l: a batch-
+//                 contraction GEMM, 64x64 output tiles x K-splits; every (tile, split) workgroup owns
+//                 its slice of a partial buffer (no atomics: bit-reproducible), summed at the end.
+//   small elementwise kernels: stage combination, lambda update, final cotangent, partial reduce,
+//   weight transpose.
+// First implementation: VALU kernels.  The MFMA versions (same tiling as cnf_mfma.hip) are the next
+// optimisation step; DESIGN.md section 8.
+#include "cnf_grad.h"
+
+// ---- second derivative of the activations ----------------------------------------------------
+__device__ __forceinline__ void cnf_act2(int kind, float a, float& h, float& d1, float& d2) {
+    switch (kind) {
+        case 0: h = a; d1 = 1.0f; d2 = 0.0f; break;
+        case 1: h = cnf_tanh(a); d1 = fmaf(-h, h, 1.0f); d2 = -2.0f * h * d1; break;
+        case 2: { float s = cnf_sigmoid(a); h = s; d1 = s * (1.0f - s); d2 = d1 * (1.0f - 2.0f * s); } break;
+        case 3: { float s = cnf_sigmoid(a); h = (a > 15.0f) ? a : log1pf(__expf(a)); d1 = s; d2 = s * (1.0f - s); } break;
+        case 4: h = fmaxf(a, 0.0f); d1 = (a > 0.0f) ? 1.0f : 0.0f; d2 = 0.0f; break;
+        case 5: {
+            float s = cnf_sigmoid(a), ds = s * (1.0f - s);
+            h = a * s; d1 = s * (1.0f + a * (1.0f - s)); d2 = 2.0f * ds + a * ds * (1.0f - 2.0f * s);
+        } break;
+        default: {
+            float e = __expf(fminf(a, 0.0f));
+            h = (a > 0.0f) ? a : e - 1.0f; d1 = (a > 0.0f) ? 1.0f : e; d2 = (a > 0.0f) ? 0.0f : e;
+        } break;
+    }
+}
+
+// deterministic per-sample block sums: wave shuffle tree, then a fixed-order sum over the waves
+template <int TS>
+__device__ __forceinline__ void block_sum_ts(float (&v)[TS], float* scratch /* [nwaves][TS] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        float x = v[s];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) scratch[wave * TS + s] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        float x = 0.f;
+        for (int w = 0; w < nw; ++w) x += scratch[w * TS + s];
+        v[s] = x;
+    }
+    __syncthreads();
+}
+
+// out[s] = sum_i M[row + i*ld] * x[s][i]   (row = this thread's feature; M column-major with leading dim ld)
+template <int TS>
+__device__ __forceinline__ void gemv(const float* __restrict__ M, int ld, int n, const float* x, int xs,
+                                     float (&acc)[TS]) {
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const float w0 = M[(size_t)i * ld], w1 = M[(size_t)(i + 1) * ld], w2 = M[(size_t)(i + 2) * ld],
+                    w3 = M[(size_t)(i + 3) * ld];
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            const float* xv = x + s * xs + i;
+            acc[s] = fmaf(w0, xv[0], acc[s]);
+            acc[s] = fmaf(w1, xv[1], acc[s]);
+            acc[s] = fmaf(w2, xv[2], acc[s]);
+            acc[s] = fmaf(w3, xv[3], acc[s]);
+        }
+    }
+    for (; i < n; ++i) {
+        const float w = M[(size_t)i * ld];
+#pragma unroll
+        for (int s = 0; s < TS; ++s) acc[s] = fmaf(w, x[s * xs + i], acc[s]);
+    }
+}
+
+// LDS carve-up per sample (floats): H | T | D1 | D2Q | TB | HB0 | HB1 | EPS
+struct AdjLds {
+    int H, T, D1, D2, TB, HB0, HB1, EPS, per_sample;
+    __host__ __device__ static AdjLds make(const GradLayout& g, int n_in) {
+        AdjLds l;
+        int p = 0;
+        l.H = p; p += g.sum_in + g.out_last;
+        l.T = p; p += g.sum_in + g.out_last;
+        l.D1 = p; p += g.sum_out;
+        l.D2 = p; p += g.sum_out;
+        l.TB = p; p += g.sum_out;
+        l.HB0 = p; p += g.max_dim;
+        l.HB1 = p; p += g.max_dim;
+        l.EPS = p; p += n_in;
+        l.per_sample = p;
+        return l;
+    }
+};
+
+template <int TS>
+__global__ void k_adj(NetDesc nd, GradLayout gl, AdjArgs a) {
+    extern __shared__ float lds[];
+    const AdjLds L = AdjLds::make(gl, nd.n_in);
+    const int PS = L.per_sample;
+    float* red = lds + (size_t)TS * PS;                  // [nwaves][TS]
+    const int f = threadIdx.x;
+    const int b0 = blockIdx.x * TS;
+    const int n_in = nd.n_in, D = n_in + 3, NL = nd.n_layers;
+    const int in0 = gl.in0;
+
+    // ---- stage inputs: z (and ys), eps, cotangent of zdot -------------------------------------
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        const int b = b0 + s;
+        float* S = lds + (size_t)s * PS;
+        if (f < in0) {
+            float v = 0.f;
+            if (b < a.B) v = f < n_in ? a.ustage[(size_t)b * D + f] : a.ys[(size_t)b * nd.n_cond + (f - n_in)];
+            S[L.H + f] = v;
+        }
+        if (f < n_in) S[L.EPS + f] = b < a.B ? a.eps[(size_t)b * n_in + f] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- forward sweep: h_l, sigma', sigma'' ---------------------------------------------------
+    for (int l = 0; l < NL; ++l) {
+        const int in = l == 0 ? in0 : nd.dims[l], out = nd.dims[l + 1];
+        const int hin = gl.in_off[l], hout = l + 1 < NL ? gl.in_off[l + 1] : gl.sum_in;
+        if (f < out) {
+            float acc[TS];
+            const float bias = a.P[nd.b_off[l] + f];
+#pragma unroll
+            for (int s = 0; s < TS; ++s) acc[s] = bias;
+            gemv<TS>(a.P + nd.w_off[l] + f, out, in, lds + L.H + hin, PS, acc);
+#pragma unroll
+            for (int s = 0; s < TS; ++s) {
+                float h, d1, d2;
+                cnf_act2(nd.acts[l], acc[s], h, d1, d2);
+                float* S = lds + (size_t)s * PS;
+                S[L.H + hout + f] = h;
+                S[L.D1 + gl.out_off[l] + f] = d1;
+                S[L.D2 + gl.out_off[l] + f] = d2;
+            }
+        }
+        __syncthreads();
+    }
+    const int hL = gl.sum_in;                               // offset of h_L (= zdot) in H
+    const int outL = nd.dims[NL];                           // == n_in
+
+    // ---- ahat = kbar_z + c_E zdot/|zdot| -> HB0 ------------------------------------------------
+    float nz[TS];
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        const float v = f < outL ? lds[(size_t)s * PS + L.H + hL + f] : 0.f;
+        nz[s] = v * v;
+    }
+    if (nd.norm_z) block_sum_ts<TS>(nz, red);
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        const int b = b0 + s;
+        if (f < outL) {
+            float kb = 0.f;
+            if (b < a.B) {
+                kb = a.cb * a.lam[(size_t)b * n_in + f];
+                for (int m = 0; m < a.nw; ++m) kb = fmaf(a.wc[m], a.w[m][(size_t)b * n_in + f], kb);
+                kb *= a.hstep;
+            }
+            float v = kb;
+            if (nd.norm_z) {
+                const float nrm = sqrtf(nz[s]);
+                if (nrm > 0.f) v = fmaf(a.c_E, lds[(size_t)s * PS + L.H + hL + f] / nrm, v);
+            }
+            lds[(size_t)s * PS + L.HB0 + f] = v;
+        }
+    }
+    __syncthreads();
+
+    // two chains run over the layers: the tangent chain (forward) and the tbar chain (reverse).
+    // VJP mode: omega = eps  -> tbar chain first (gives eJ), then tau, then the tangent chain.
+    // JVP mode: tau = eps    -> tangent chain first (gives J eps), then omega, then the tbar chain.
+    auto tangent_chain = [&]() {
+        for (int l = 0; l < NL; ++l) {
+            const int in = l == 0 ? in0 : nd.dims[l], out = nd.dims[l + 1];
+            const int hin = gl.in_off[l], hout = l + 1 < NL ? gl.in_off[l + 1] : gl.sum_in;
+            if (f < out) {
+                float acc[TS];
+#pragma unroll
+                for (int s = 0; s < TS; ++s) acc[s] = 0.f;
+                gemv<TS>(a.P + nd.w_off[l] + f, out, in, lds + L.T + hin, PS, acc);
+#pragma unroll
+                for (int s = 0; s < TS; ++s) {
+                    float* S = lds + (size_t)s * PS;
+                    const int o = gl.out_off[l] + f;
+                    S[L.T + hout + f] = S[L.D1 + o] * acc[s];      // t_l = sigma' .* p_l
+                    S[L.D2 + o] = S[L.D2 + o] * acc[s];            // q_l = sigma'' .* p_l
+                }
+            }
+            __syncthreads();
+        }
+    };
+    auto tbar_chain = [&]() {                                    // TB[l] holds tbar_{l+1} (layer l's output side)
+        for (int l = NL - 1; l >= 0; --l) {
+            const int in = l == 0 ? in0 : nd.dims[l], out = nd.dims[l + 1];
+            // pbar_l = tbar_l .* sigma'_l   (kept in HB1, written out for the weight gradient)
+            if (f < out) {
+#pragma unroll
+                for (int s = 0; s < TS; ++s) {
+                    float* S = lds + (size_t)s * PS;
+                    const int o = gl.out_off[l] + f;
+                    const float pb = S[L.TB + o] * S[L.D1 + o];
+                    S[L.HB1 + f] = pb;
+                    if (b0 + s < a.B) a.PB[(size_t)(b0 + s) * gl.sum_out + o] = pb;
+                }
+            }
+            __syncthreads();
+            if (l > 0) {
+                if (f < in) {
+                    float acc[TS];
+#pragma unroll
+                    for (int s = 0; s < TS; ++s) acc[s] = 0.f;
+                    gemv<TS>(a.PT + nd.w_off[l] + f, in, out, lds + L.HB1, PS, acc);
+#pragma unroll
+                    for (int s = 0; s < TS; ++s) lds[(size_t)s * PS + L.TB + gl.out_off[l - 1] + f] = acc[s];
+                }
+            } else if (f < n_in) {                               // tbar_0 rows of z: eJ (VJP mode) -> HB1 is busy, use T's h_0 slot later
+                float acc[TS];
+#pragma unroll
+                for (int s = 0; s < TS; ++s) acc[s] = 0.f;
+                gemv<TS>(a.PT + nd.w_off[0] + f, in0, out, lds + L.HB1, PS, acc);
+#pragma unroll
+                for (int s = 0; s < TS; ++s) lds[(size_t)s * PS + L.T + f] = acc[s];   // parked in T_0
+            }
+            __syncthreads();
+        }
+    };
+
+    const int oL = gl.out_off[NL - 1];
+    if (!nd.jvp) {
+        // tbar_L = eps
+        if (f < outL) {
+#pragma unroll
+            for (int s = 0; s < TS; ++s) lds[(size_t)s * PS + L.TB + oL + f] = lds[(size_t)s * PS + L.EPS + f];
+        }
+        __syncthreads();
+        tbar_chain();                                            // T_0[0..n_in) = eJ
+        float nj[TS];
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            const float v = f < n_in ? lds[(size_t)s * PS + L.T + f] : 0.f;
+            nj[s] = v * v;
+        }
+        if (nd.norm_j) block_sum_ts<TS>(nj, red);
+        // tau = -c_l eps + c_n eJ/|eJ|   (rows of ys carry a zero tangent)
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            if (f < in0) {
+                float* S = lds + (size_t)s * PS;
+                float v = 0.f;
+                if (f < n_in) {
+                    v = -a.c_l * S[L.EPS + f];
+                    if (nd.norm_j) {
+                        const float nrm = sqrtf(nj[s]);
+                        if (nrm > 0.f) v = fmaf(a.c_n, S[L.T + f] / nrm, v);
+                    }
+                }
+                S[L.T + f] = v;
+            }
+        }
+        __syncthreads();
+        tangent_chain();
+    } else {
+        // tau = eps
+#pragma unroll
+        for (int s = 0; s < TS; ++s)
+            if (f < in0) lds[(size_t)s * PS + L.T + f] = f < n_in ? lds[(size_t)s * PS + L.EPS + f] : 0.f;
+        __syncthreads();
+        tangent_chain();                                         // T_L = J eps
+        float nj[TS];
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            const float v = f < outL ? lds[(size_t)s * PS + L.T + hL + f] : 0.f;
+            nj[s] = v * v;
+        }
+        if (nd.norm_j) block_sum_ts<TS>(nj, red);
+        // omega = -c_l eps + c_n Je/|Je|
+        if (f < outL) {
+#pragma unroll
+            for (int s = 0; s < TS; ++s) {
+                float* S = lds + (size_t)s * PS;
+                float v = -a.c_l * S[L.EPS + f];
+                if (nd.norm_j) {
+                    const float nrm = sqrtf(nj[s]);
+                    if (nrm > 0.f) v = fmaf(a.c_n, S[L.T + hL + f] / nrm, v);
+                }
+                S[L.TB + oL + f] = v;
+            }
+        }
+        __syncthreads();
+        // the tbar chain parks tbar_0 in T_0, which the weight gradient still needs as t_0 = eps:
+        // save and restore it around the chain
+        float keep[TS];
+#pragma unroll
+        for (int s = 0; s < TS; ++s) keep[s] = f < n_in ? lds[(size_t)s * PS + L.T + f] : 0.f;
+        tbar_chain();
+#pragma unroll
+        for (int s = 0; s < TS; ++s)
+            if (f < n_in) lds[(size_t)s * PS + L.T + f] = keep[s];
+        __syncthreads();
+    }
+
+    // ---- hbar chain: abar_l = hbar_l sigma' + tbar_l q_l ; hbar_{l-1} = W_l' abar_l --------------
+    int cur = L.HB0, nxt = L.HB1;
+    for (int l = NL - 1; l >= 0; --l) {
+        const int in = l == 0 ? in0 : nd.dims[l], out = nd.dims[l + 1];
+        if (f < out) {
+#pragma unroll
+            for (int s = 0; s < TS; ++s) {
+                float* S = lds + (size_t)s * PS;
+                const int o = gl.out_off[l] + f;
+                const float ab = fmaf(S[cur + f], S[L.D1 + o], S[L.TB + o] * S[L.D2 + o]);
+                S[cur + f] = ab;
+                if (b0 + s < a.B) a.AB[(size_t)(b0 + s) * gl.sum_out + o] = ab;
+            }
+        }
+        __syncthreads();
+        const int rows = l == 0 ? n_in : in;
+        if (f < rows) {
+            float acc[TS];
+#pragma unroll
+            for (int s = 0; s < TS; ++s) acc[s] = 0.f;
+            gemv<TS>(a.PT + nd.w_off[l] + f, in, out, lds + cur, PS, acc);
+#pragma unroll
+            for (int s = 0; s < TS; ++s) lds[(size_t)s * PS + nxt + f] = acc[s];
+        }
+        __syncthreads();
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+    // ---- outputs: zbar and the layer inputs / tangents for the weight gradient ------------------
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        const int b = b0 + s;
+        if (b >= a.B) continue;
+        const float* S = lds + (size_t)s * PS;
+        if (f < n_in) a.w_out[(size_t)b * n_in + f] = S[cur + f];
+        for (int i = f; i < gl.sum_in; i += blockDim.x) {
+            a.HS[(size_t)b * gl.sum_in + i] = S[L.H + i];
+            a.TS[(size_t)b * gl.sum_in + i] = S[L.T + i];
+        }
+    }
+}
+
+// ---- weight gradient: 64x64 tiles x K-splits ---------------------------------------------------
+#define WG_T 64
+#define WG_K 16
+__global__ void __launch_bounds__(256)
+k_wgrad(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const float* __restrict__ PB,
+        const float* __restrict__ HS, const float* __restrict__ TSb, float* __restrict__ gpart,
+        int n_params, int B, int chunk) {
+    __shared__ float sA[WG_K][WG_T + 4], sP[WG_K][WG_T + 4], sH[WG_K][WG_T + 4], sT[WG_K][WG_T + 4];
+    // locate this workgroup's tile
+    int tile = blockIdx.x, l = 0, to = 0, ti = 0;
+    for (; l < nd.n_layers; ++l) {
+        const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
+        const int no = (out + WG_T - 1) / WG_T, ni = (in + WG_T - 1) / WG_T;
+        if (tile < no * ni) { to = tile / ni; ti = tile % ni; break; }
+        tile -= no * ni;
+    }
+    if (l == nd.n_layers) return;
+    const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
+    const int o0 = to * WG_T, i0 = ti * WG_T;
+    const int oo = gl.out_off[l], io = gl.in_off[l];
+    const int k0 = blockIdx.y * chunk, k1 = min(B, k0 + chunk);
+    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+    float acc[4][4] = {};
+    float bsum[4] = {};
+    for (int kb = k0; kb < k1; kb += WG_K) {
+        for (int e = t; e < WG_K * WG_T; e += 256) {
+            const int r = e / WG_T, c = e % WG_T, b = kb + r;
+            const bool vb = b < k1;
+            const bool vo = vb && o0 + c < out, vi = vb && i0 + c < in;
+            sA[r][c] = vo ? AB[(size_t)b * gl.sum_out + oo + o0 + c] : 0.f;
+            sP[r][c] = vo ? PB[(size_t)b * gl.sum_out + oo + o0 + c] : 0.f;
+            sH[r][c] = vi ? HS[(size_t)b * gl.sum_in + io + i0 + c] : 0.f;
+            sT[r][c] = vi ? TSb[(size_t)b * gl.sum_in + io + i0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < WG_K; ++r) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&sA[r][4 * ty]);
+            const float4 p4 = *reinterpret_cast<const float4*>(&sP[r][4 * ty]);
+            const float4 h4 = *reinterpret_cast<const float4*>(&sH[r][4 * tx]);
+            const float4 t4 = *reinterpret_cast<const float4*>(&sT[r][4 * tx]);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, pv[4] = {p4.x, p4.y, p4.z, p4.w};
+            const float hv[4] = {h4.x, h4.y, h4.z, h4.w}, tv[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                bsum[x] += av[x];
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] = fmaf(av[x], hv[y], fmaf(pv[x], tv[y], acc[x][y]));
+            }
+        }
+        __syncthreads();
+    }
+    float* g = gpart + (size_t)blockIdx.y * n_params;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int o = o0 + 4 * ty + x;
+        if (o >= out) continue;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int i = i0 + 4 * tx + y;
+            if (i < in) g[nd.w_off[l] + o + (size_t)i * out] += acc[x][y];     // Lux layout: out x in, column-major
+        }
+        if (ti == 0 && tx == 0) g[nd.b_off[l] + o] += bsum[x];
+    }
+}
+
+// grad[p] = sum over the K-splits, in a fixed order
+__global__ void k_grad_reduce(const float* __restrict__ gpart, float* __restrict__ grad, int n_params, int ksplit) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_params) return;
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += gpart[(size_t)k * n_params + p];
+    grad[p] = s;
+}
+
+// WT_l[i + o*in] = W_l[o + i*out]  (same offsets as the flat vector; biases are not copied)
+__global__ void k_transpose_params(NetDesc nd, int in0, const float* __restrict__ P, float* __restrict__ PT) {
+    const int l = blockIdx.y;
+    const int in = l == 0 ? in0 : nd.dims[l], out = nd.dims[l + 1];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= in * out) return;
+    const int i = e % in, o = e / in;
+    PT[nd.w_off[l] + e] = P[nd.w_off[l] + o + (size_t)i * out];
+}
+
+// Uout = u + h * sum_j coef[j] * k_j    over all D*B entries
+__global__ void k_stage_combine(const float* __restrict__ u, StageK ks, float h, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int j = 0; j < ks.nk; ++j) acc = fmaf(ks.coef[j], ks.k[j][i], acc);
+    out[i] = fmaf(h, acc, u[i]);
+}
+
+// lam_z += sum_i w_i
+__global__ void k_lambda_update(float* __restrict__ lam, StageK ws, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = lam[i];
+    for (int j = 0; j < ws.nk; ++j) acc += ws.k[j][i];
+    lam[i] = acc;
+}
+
+// d loss / d z(t1) for loss = mean_b(-logpx + l1 E + l2 n + l3 A): z/B (+ l3 unit(z_aug)/B on the
+// augmented rows)    src/icnf.jl:481-490, src/base_icnf.jl:167-189
+__global__ void k_final_cotangent(NetDesc nd, float lambda3, const float* __restrict__ fsol,
+                                  float* __restrict__ lam, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n_in = nd.n_in, D = n_in + 3;
+    const float* c = fsol + (size_t)b * D;
+    const float inv = 1.0f / (float)B;
+    float sa = 0.f;
+    const bool aug = nd.norm_z_aug && nd.naugs > 0;
+    if (aug) for (int i = nd.nvars; i < n_in; ++i) sa = fmaf(c[i], c[i], sa);
+    const float nrm = sqrtf(sa);
+    for (int i = 0; i < n_in; ++i) {
+        float v = c[i];
+        if (aug && i >= nd.nvars && nrm > 0.f) v = fmaf(lambda3, c[i] / nrm, v);
+        lam[(size_t)b * n_in + i] = v * inv;
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------
+GradLayout grad_layout(const NetDesc& nd) {
+    GradLayout g{};
+    g.in0 = nd.n_in + nd.n_cond;
+    int io = 0, oo = 0, mx = g.in0;
+    for (int l = 0; l < nd.n_layers; ++l) {
+        g.in_off[l] = io;
+        io += l == 0 ? g.in0 : nd.dims[l];
+        g.out_off[l] = oo;
+        oo += nd.dims[l + 1];
+        if (nd.dims[l + 1] > mx) mx = nd.dims[l + 1];
+    }
+    g.sum_in = io; g.sum_out = oo; g.out_last = nd.dims[nd.n_layers]; g.max_dim = mx;
+    return g;
+}
+
+int grad_adj_threads(const GradLayout& g) { return (g.max_dim + 63) & ~63; }
+
+size_t grad_adj_lds_bytes(const NetDesc& nd, const GradLayout& g, int ts) {
+    const AdjLds L = AdjLds::make(g, nd.n_in);
+    const int nw = grad_adj_threads(g) / 64;
+    return ((size_t)ts * L.per_sample + (size_t)nw * ts) * sizeof(float);
+}
+
+bool grad_supported(const NetDesc& nd, const GradLayout& g) {
+    return grad_adj_threads(g) <= 1024 && grad_adj_lds_bytes(nd, g, 1) <= 160 * 1024;
+}
+
+template <int TS>
+static hipError_t launch_adj_ts(const NetDesc& nd, const GradLayout& g, const AdjArgs& a, hipStream_t s) {
+    const size_t lds = grad_adj_lds_bytes(nd, g, TS);
+    hipError_t e = hipFuncSetAttribute((const void*)k_adj<TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_adj<TS>, dim3((a.B + TS - 1) / TS), dim3(grad_adj_threads(g)), lds, s, nd, g, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_adj(const NetDesc& nd, const GradLayout& g, const AdjArgs& a, hipStream_t s) {
+    // 4 samples per workgroup amortise the weight reads once there are enough workgroups to fill
+    // the chip; small batches keep one sample per workgroup for parallelism
+    if (a.B >= 2048 && grad_adj_lds_bytes(nd, g, 4) <= 64 * 1024) return launch_adj_ts<4>(nd, g, a, s);
+    if (a.B >= 512 && grad_adj_lds_bytes(nd, g, 2) <= 64 * 1024) return launch_adj_ts<2>(nd, g, a, s);
+    return launch_adj_ts<1>(nd, g, a, s);
+}
+
+int grad_wgrad_tiles(const NetDesc& nd, const GradLayout& g) {
+    int n = 0;
+    for (int l = 0; l < nd.n_layers; ++l) {
+        const int in = l == 0 ? g.in0 : nd.dims[l], out = nd.dims[l + 1];
+        n += ((out + WG_T - 1) / WG_T) * ((in + WG_T - 1) / WG_T);
+    }
+    return n;
+}
+
+void grad_ksplit(const NetDesc& nd, const GradLayout& g, int B, int* ksplit, int* chunk) {
+    const int tiles = grad_wgrad_tiles(nd, g);
+    int ks = (1024 + tiles - 1) / tiles;                 // aim at ~1024 workgroups
+    const int maxks = (B + 63) / 64;                     // at least 64 samples per split
+    if (ks > maxks) ks = maxks;
+    if (ks > GRAD_MAX_KSPLIT) ks = GRAD_MAX_KSPLIT;
+    if (ks < 1) ks = 1;
+    int ch = (B + ks - 1) / ks;
+    ch = (ch + WG_K - 1) / WG_K * WG_K;
+    ks = (B + ch - 1) / ch;
+    *ksplit = ks; *chunk = ch;
+}
+
+hipError_t launch_wgrad(const NetDesc& nd, const GradLayout& g, const float* AB, const float* PB, const float* HS,
+                        const float* TS, float* gpart, int n_params, int B, int ksplit, int chunk, hipStream_t s) {
+    hipLaunchKernelGGL(k_wgrad, dim3(grad_wgrad_tiles(nd, g), ksplit), dim3(256), 0, s, nd, g, AB, PB, HS, TS, gpart,
+                       n_params, B, chunk);
+    return hipGetLastError();
+}
+
+hipError_t launch_grad_reduce(const float* gpart, float* grad, int n_params, int ksplit, hipStream_t s) {
+    hipLaunchKernelGGL(k_grad_reduce, dim3((n_params + 255) / 256), dim3(256), 0, s, gpart, grad, n_params, ksplit);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose_params(const NetDesc& nd, const float* P, float* PT, hipStream_t s) {
+    const GradLayout g = grad_layout(nd);
+    int mx = 0;
+    for (int l = 0; l < nd.n_layers; ++l) {
+        const int in = l == 0 ? g.in0 : nd.dims[l];
+        if (in * nd.dims[l + 1] > mx) mx = in * nd.dims[l + 1];
+    }
+    hipLaunchKernelGGL(k_transpose_params, dim3((mx + 255) / 256, nd.n_layers), dim3(256), 0, s, nd, g.in0, P, PT);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_combine(const float* u, const StageK& ks, float h, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_stage_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, ks, h, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_lambda_update(float* lam, const StageK& ws, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_lambda_update, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lam, ws, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_final_cotangent(const NetDesc& nd, float lambda3, const float* fsol, float* lam, int B,
+                                  hipStream_t s) {
+    hipLaunchKernelGGL(k_final_cotangent, dim3((B + 255) / 256), dim3(256), 0, s, nd, lambda3, fsol, lam, B);
+    return hipGetLastError();
+}

@@ -185,6 +185,28 @@ cnf_status cnf_loss_sums(cnf_handle h, const float* logpx, const float* regs, in
                          float* sums5, void* stream);
 cnf_status cnf_loss_from_sums(cnf_handle h, int mode, const float* sums5_host, float* loss);
 
+/* ---- training ------------------------------------------------ */
+
+/* loss(icnf, TrainMode(), xs, ps, st) (src/icnf.jl:481-490) AND its gradient w.r.t. the flat
+ * parameter vector -- what MLJModelInterface.fit (src/exts/mlj_ext/core_icnf.jl:59-73) obtains
+ * from Enzyme + SciMLSensitivity through `solve`.  Computed as the discrete adjoint of the Tsit5
+ * steps the forward solve took (step sizes are constants of the differentiation): the exact
+ * gradient of the returned loss value.  xs: nvars x B, eps: n_in x B (drawn by the caller, as in
+ * inference_prob src/base_icnf.jl:277-278); *loss_out is a HOST float; grad: n_params floats in the
+ * layout of cnf_set_params (device pointer; host pointer in the _host variant).  Both are means
+ * over the B columns given; a caller that shards the batch combines (loss, grad) weighted by B.
+ * Conditional models: call cnf_set_cond first, as for any other solve.  TrainMode only (the
+ * reference trains in TrainMode: core_icnf.jl:60). */
+cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* eps, int B,
+                         const cnf_solve_opts* opts, float* loss_out, float* grad,
+                         cnf_solve_stats* stats, void* stream);
+cnf_status cnf_loss_grad_host(cnf_handle h, const float* xs, const float* eps, int B,
+                              const cnf_solve_opts* opts, float* loss_out, float* grad,
+                              cnf_solve_stats* stats);
+/* The signed sizes of the steps the last cnf_loss_grad on this handle accepted (the discrete map
+ * it differentiated): writes min(n, cap) floats to hs (may be NULL) and returns n. */
+int cnf_grad_steps(cnf_handle h, float* hs, int cap);
+
 /* ---- introspection --------------------------------------------------------------- */
 const char* cnf_status_string(cnf_status s);
 const char* cnf_last_error(cnf_handle h);   /* detail for the last non-OK status       */

@@ -151,14 +151,21 @@ def final_cotangent(cfg: O.Cfg, fsol):
     return lam / B
 
 
-def loss_and_grad(cfg: O.Cfg, flat, xs, eps, ys=None, **solve_kw):
-    """(loss, d loss / d flat, stats) of the TrainMode loss through the Tsit5 solve."""
+def loss_and_grad(cfg: O.Cfg, flat, xs, eps, ys=None, dts=None, **solve_kw):
+    """(loss, d loss / d flat, stats) of the TrainMode loss through the Tsit5 solve.  ``dts``: replay
+    these accepted step sizes instead of solving (to differentiate exactly the discrete map another
+    implementation took)."""
     flat = np.asarray(flat)
     u0 = O.inference_u0(cfg, xs, True)
     f = cfg.rhs(flat, eps, True, ys)
-    fsol, st = O.tsit5_solve(f, u0, cfg.tspan[0], cfg.tspan[1], **solve_kw)
-    us = forward_record(f, u0, cfg.tspan[0], cfg.tspan[1], st.dts)
-    assert np.array_equal(us[-1], fsol)
+    if dts is None:
+        fsol, st = O.tsit5_solve(f, u0, cfg.tspan[0], cfg.tspan[1], **solve_kw)
+        us = forward_record(f, u0, cfg.tspan[0], cfg.tspan[1], st.dts)
+        assert np.array_equal(us[-1], fsol)
+    else:
+        st = O.SolveStats(naccept=len(dts), dts=[abs(float(d)) for d in dts])
+        us = forward_record(f, u0, cfg.tspan[0], cfg.tspan[1], st.dts)
+        fsol = us[-1]
     logpx, regs = O.inference_sol(cfg, fsol, True)
     val = O.loss(cfg, logpx, regs, True)
     T = u0.dtype.type

@@ -9,6 +9,7 @@ import continuousnf.jl_amd as cnf
 from continuousnf.jl_amd import _lib
 from oracle import c_oracle as CO
 from oracle import cnf_oracle as O
+from tests import helpers
 from tests.helpers import GOLDEN_CASES, assert_parity, load_golden, make_icnf
 
 pytestmark = pytest.mark.gpu
@@ -564,3 +565,123 @@ def test_lockstep_shards_follow_the_unsharded_solve(kernel):
     ic.set_shard_reduce(lambda v: hit.append(1))
     cnf.inference(ic, cnf.TrainMode(), xs[:, :64].copy(), flat, {}, eps=eps[:, :64].copy())
     assert not hit
+
+
+# ---------------------------------------------------------------------------------------
+# Row f3: gradient of the training loss w.r.t. the parameters (cnf_loss_grad)
+# ---------------------------------------------------------------------------------------
+def _grad_case(cfg, B, seed, kernel, sol_kw, ora_kw, jvp=False, n_cond=0, scale=0.2, host=False):
+    from oracle import cnf_grad_oracle as G
+    rng = np.random.default_rng(seed)
+    net = cfg.net
+    if n_cond:
+        net = O.Net((cfg.net.dims[0] + n_cond,) + tuple(cfg.net.dims[1:]), cfg.net.acts)
+    flat = O.glorot_params(net, rng, np.float32, scale)
+    xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+    eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+    ys = rng.standard_normal((n_cond, B)).astype(np.float32) if n_cond else None
+    if n_cond:
+        layers = [cnf.Dense(a, b, helpers.ACT_NAME[k]) for a, b, k in zip(net.dims[:-1], net.dims[1:], net.acts)]
+        cm = cnf.HIPJacVecMatrixMode(kernel) if jvp else cnf.HIPVecJacMatrixMode(kernel)
+        icnf = cnf.construct(cnf.CondRNODE, cnf.Chain(*layers), cfg.nvars, cfg.naugs, compute_mode=cm, tspan=cfg.tspan,
+                             lambda1=cfg.lam1, lambda2=cfg.lam2, lambda3=cfg.lam3, sol_kwargs=sol_kw)
+    else:
+        icnf = make_icnf(cnf, cfg, jvp=jvp, kernel=kernel, sol_kwargs=sol_kw)
+    args = (ys, flat, {}) if n_cond else (flat, {})
+    conv = (lambda a: a) if host else _dev
+    cargs = tuple(conv(a) if isinstance(a, np.ndarray) and a is not flat else a for a in args)
+    val, grad = cnf.loss_and_grad(icnf, cnf.TrainMode(), conv(xs), *cargs, eps=conv(eps))
+    grad = grad.cpu().numpy() if hasattr(grad, "cpu") else grad
+    c64 = O.Cfg(net, cfg.nvars, cfg.naugs, cfg.lam1, cfg.lam2, cfg.lam3, use_jvp=jvp, tspan=cfg.tspan)
+    if ora_kw == "replay":            # differentiate exactly the steps the device took
+        ora_kw = dict(dts=[float(d) for d in icnf.last_steps])
+    rval, rgrad, st = G.loss_and_grad(c64, flat.astype(np.float64), xs.astype(np.float64), eps.astype(np.float64),
+                                      None if ys is None else ys.astype(np.float64), **ora_kw)
+    return val, grad, rval, rgrad, icnf.last_stats, st
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("i", [1, 2, 3])
+def test_loss_grad_fixed_dt_matches_oracle(i, kernel):
+    """Fixed dt: the discrete adjoint on the device vs the float64 oracle (itself pinned by torch
+    autograd, tests/test_grad_oracle.py).  Tolerance: 1e-4 of the gradient's scale."""
+    cfg, _, _ = O.baseline_cfg(i)
+    cfg.tspan = (0.0, 1.0)
+    B = 96
+    val, grad, rval, rgrad, st, _ = _grad_case(cfg, B, 300 + i, kernel, dict(adaptive=False, dt=1 / 8),
+                                               dict(adaptive=False, dt=1 / 8))
+    assert st["naccept"] == 8
+    assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+    assert np.isfinite(grad).all()
+    scale = np.sqrt(np.mean(rgrad ** 2))
+    assert np.abs(grad - rgrad).max() <= 1e-4 * (np.abs(rgrad).max() + scale), (np.abs(grad - rgrad).max(), scale)
+
+
+def _assert_grad(grad, rgrad, what, rtol=1e-4):
+    assert np.isfinite(grad).all(), what
+    scale = np.sqrt(np.mean(rgrad ** 2))
+    err = np.abs(grad - rgrad).max()
+    assert err <= rtol * (np.abs(rgrad).max() + scale), (what, err, np.abs(rgrad).max(), scale)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_loss_grad_adaptive_jvp_cond_and_host(kernel):
+    """Adaptive solve, JVP compute mode, a conditional model, host arrays, ragged batches."""
+    from oracle import cnf_grad_oracle as G
+    cfg, _, _ = O.baseline_cfg(2)
+    cfg.tspan = (0.0, 1.0)
+    tol = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+    # adaptive: float32 and float64 controllers take different steps at these tolerances (the error
+    # estimate of the rows that start at 0 is rounding noise against abstol = eps), so the oracle
+    # replays the steps the device took (cnf_grad_steps) and differentiates the same discrete map
+    val, grad, rval, rgrad, st, ost = _grad_case(cfg, 77, 311, kernel, dict(tol), "replay")
+    assert st["naccept"] == ost.naccept and st["naccept"] > 4 and st["nf"] == 2 + 6 * (st["naccept"] + st["nreject"])
+    assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+    _assert_grad(grad, rgrad, "adaptive")
+    # JVP compute mode (n-dot = |J eps|), fixed dt
+    val, grad, rval, rgrad, _, _ = _grad_case(cfg, 50, 312, kernel, dict(adaptive=False, dt=1 / 6),
+                                              dict(adaptive=False, dt=1 / 6), jvp=True)
+    assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+    _assert_grad(grad, rgrad, "jvp")
+    # conditional model: gradient also w.r.t. the conditioning columns of W1
+    val, grad, rval, rgrad, _, _ = _grad_case(cfg, 40, 313, kernel, dict(adaptive=False, dt=1 / 6),
+                                              dict(adaptive=False, dt=1 / 6), n_cond=5)
+    assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+    _assert_grad(grad, rgrad, "conditional")
+    # host arrays in, host gradient out
+    val, grad, rval, rgrad, _, _ = _grad_case(cfg, 33, 314, kernel, dict(adaptive=False, dt=1 / 6),
+                                              dict(adaptive=False, dt=1 / 6), host=True)
+    assert isinstance(grad, np.ndarray)
+    _assert_grad(grad, rgrad, "host")
+
+
+def test_loss_grad_larger_batches_and_backward_time():
+    """The 2- and 4-samples-per-workgroup variants of the pullback kernel (B >= 512, B >= 2048), the
+    K-split of the weight-gradient GEMM, and a solve in reverse time."""
+    cfg, _, _ = O.baseline_cfg(2)
+    for B, tspan in ((600, (0.0, 1.0)), (2100, (0.0, 0.5)), (70, (1.0, 0.0))):
+        cfg.tspan = tspan
+        val, grad, rval, rgrad, _, _ = _grad_case(cfg, B, 320 + B, "auto", dict(adaptive=False, dt=1 / 4),
+                                                  dict(adaptive=False, dt=1 / 4))
+        assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+        _assert_grad(grad, rgrad, f"B={B} tspan={tspan}")
+
+
+def test_loss_grad_is_reproducible_and_descends():
+    """Bit-reproducible (no atomics), and a small step along -grad lowers the loss."""
+    cfg, _, _ = O.baseline_cfg(3)
+    rng = np.random.default_rng(9)
+    B = 256
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    xs, eps = _dev(rng.standard_normal((cfg.nvars, B))), _dev(rng.standard_normal((cfg.n_in, B)))
+    icnf = make_icnf(cnf, cfg, sol_kwargs=dict(adaptive=False, dt=1 / 8))
+    l0, g0 = cnf.loss_and_grad(icnf, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    l1, g1 = cnf.loss_and_grad(icnf, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    assert l0 == l1 and torch.equal(g0, g1)
+    assert abs(l0 - cnf.loss(icnf, cnf.TrainMode(), xs, flat, {}, eps=eps)) <= 1e-6 * abs(l0)
+    g = g0.cpu().numpy()
+    step = 1e-2 / np.linalg.norm(g)
+    l2 = cnf.loss(icnf, cnf.TrainMode(), xs, (flat - step * g).astype(np.float32), {}, eps=eps)
+    assert l2 < l0 and abs((l0 - l2) - step * np.dot(g, g)) <= 0.05 * step * np.dot(g, g)
+    with pytest.raises(NotImplementedError):
+        cnf.loss_and_grad(icnf, cnf.TestMode(), xs, flat, {})
