@@ -13,6 +13,7 @@ from .icnf import augmented_f
 from .layers import Chain, CondLayer, Dense, setup
 from .types import (FFJORD, RNODE, CondFFJORD, CondPlanar, CondRNODE, HIPJacVecMatrixMode,
                     HIPMatrixMode, HIPVecJacMatrixMode, Planar, TestMode, TrainMode)
-from . import parallel
+from . import mlj, parallel
+from .mlj import Adam, ICNFModel, Lion, fit, fitted_params, load_params, save_params, transform
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -45,6 +45,7 @@ struct cnf_ctx {
     void* shard_user = nullptr;
     // gradient path (cnf_loss_grad): transposed weights, per-step trajectory, adjoint scratch
     float* d_PT = nullptr;
+    float* d_adj_img = nullptr;   // padded forward/reverse weight images of the MFMA pullback kernel
     bool pt_valid = false;
     std::vector<float*> traj_blocks;   // TRAJ_BLOCK state slots each, slot = (n_in + 3) * grad_cap_B floats
     size_t grad_cap_B = 0;
@@ -181,6 +182,7 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (h->d_cond) (void)hipFree(h->d_cond);
     if (h->d_ys) (void)hipFree(h->d_ys);
     if (h->d_PT) (void)hipFree(h->d_PT);
+    if (h->d_adj_img) (void)hipFree(h->d_adj_img);
     if (h->grad_arena) (void)hipFree(h->grad_arena);
     for (float* b : h->traj_blocks) (void)hipFree(b);
     if (h->arena) (void)hipFree(h->arena);
@@ -890,6 +892,10 @@ static cnf_status ensure_grad_capacity(cnf_handle h, int B) {
     HIPCHK(h, hipSetDevice(h->device));
     const GradLayout g = grad_layout(h->nd);
     if (!h->d_PT) HIPCHK(h, hipMalloc(&h->d_PT, h->n_params * sizeof(float)));
+    if (!h->d_adj_img) {
+        const AdjMfmaLayout m = adj_mfma_layout(h->nd, g);
+        HIPCHK(h, hipMalloc(&h->d_adj_img, (size_t)m.img_floats * sizeof(float)));
+    }
     if ((size_t)B <= h->grad_cap_B) return CNF_OK;
     HIPCHK(h, hipDeviceSynchronize());
     if (h->grad_arena) { (void)hipFree(h->grad_arena); h->grad_arena = nullptr; }
@@ -931,8 +937,12 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
     const NetDesc& nd = h->nd;
     const int n_in = nd.n_in, D = n_in + 3;
     const size_t n = (size_t)D * B;
+    const AdjMfmaLayout am = adj_mfma_layout(nd, gl);
+    // the pullback kernel follows the kernel choice of the solve: GENERIC -> VALU, otherwise MFMA when it fits
+    const bool adj_mfma = opts->kernel != CNF_KERNEL_GENERIC && adj_mfma_supported(nd, am);
     if (!h->pt_valid) {
         HIPCHK(h, launch_transpose_params(nd, h->d_params, h->d_PT, st));
+        HIPCHK(h, launch_pack_adj_images(nd, gl, am, h->d_params, h->d_adj_img, st));
         h->pt_valid = true;
     }
 
@@ -994,7 +1004,8 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
             a.w_out = h->g_W[i];
             a.HS = h->g_HS; a.TS = h->g_TS; a.AB = h->g_AB; a.PB = h->g_PB;
             a.B = B;
-            HIPCHK(h, launch_adj(nd, gl, a, st));
+            if (adj_mfma) HIPCHK(h, launch_adj_mfma(nd, gl, am, h->d_adj_img, a, st));
+            else HIPCHK(h, launch_adj(nd, gl, a, st));
             HIPCHK(h, launch_wgrad(nd, gl, h->g_AB, h->g_PB, h->g_HS, h->g_TS, h->g_part, (int)h->n_params, B,
                                    ksplit, chunk, st));
         }

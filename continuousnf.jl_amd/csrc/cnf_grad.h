@@ -51,3 +51,26 @@ hipError_t launch_stage_combine(const float* u, const StageK& ks, float h, float
 hipError_t launch_lambda_update(float* lam, const StageK& ws, size_t n, hipStream_t s);
 hipError_t launch_final_cotangent(const NetDesc& nd, float lambda3, const float* fsol, float* lam, int B,
                                   hipStream_t s);
+
+// ---- MFMA pullback kernel (k_adj_mfma): padded weight images + LDS carve-up -----------------------
+struct AdjMfmaLayout {
+    int L;
+    int dp[CNF_MAX_LAYERS + 1];     // dims padded to 16; dp[0] = pad16(n_in + n_cond)
+    int f_off[CNF_MAX_LAYERS];      // forward image  F_l [dp[l+1]][dp[l]]   (row-major, k contiguous)
+    int r_off[CNF_MAX_LAYERS];      // reverse image  R_l [dp[l]][dp[l+1]]
+    int b_off[CNF_MAX_LAYERS];      // padded bias
+    int o_off[CNF_MAX_LAYERS];      // offset of layer l's output side in the D1/D2/TB rows
+    int sum_o;                      // padded row length of D1/D2/TB
+    int maxd;                       // max dp
+    int nin_p;                      // pad16(n_in)
+    int img_floats;
+    // per-sample LDS offsets (floats) and stride
+    int D1, D2, TB, S0, S1, E, AH, PS;
+    int vec4;                       // global rows are 16-byte aligned: vector stores in the epilogues
+};
+AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g);
+bool adj_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
+hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* P,
+                                  float* img, hipStream_t s);
+hipError_t launch_adj_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                           const AdjArgs& a, hipStream_t s);

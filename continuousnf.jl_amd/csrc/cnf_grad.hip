@@ -21,6 +21,9 @@
 // First implementation: VALU kernels.  The MFMA versions (same tiling as cnf_mfma.hip) are the next
 // optimisation step; DESIGN.md section 8.
 #include "cnf_grad.h"
+#include <cstdlib>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- second derivative of the activations ----------------------------------------------------
 __device__ __forceinline__ void cnf_act2(int kind, float a, float& h, float& d1, float& d2) {
@@ -422,6 +425,86 @@ k_wgrad(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const float* __
     }
 }
 
+// The same contraction on v_mfma_f32_16x16x4_f32: the K index of the MFMA is the sample.  A workgroup
+// (4 waves) owns a 64x64 output tile for one K-split; wave w the 16-column strip w (4 accumulator
+// tiles).  Per 16 samples the four operand tiles go through LDS; an MFMA k-step takes samples
+// 4c..4c+3: lane (x = l & 15, q = l >> 4) feeds A = abar[4c+q][o0+16to+x], B = h[4c+q][i0+16w+x].
+#define WM_LD (WG_T + 16)          // row stride: 16 q + x covers all 64 banks
+__global__ void __launch_bounds__(256)
+k_wgrad_mfma(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const float* __restrict__ PB,
+             const float* __restrict__ HS, const float* __restrict__ TSb, float* __restrict__ gpart,
+             int n_params, int B, int chunk) {
+    __shared__ float sA[WG_K][WM_LD], sP[WG_K][WM_LD], sH[WG_K][WM_LD], sT[WG_K][WM_LD];
+    int tile = blockIdx.x, l = 0, to_ = 0, ti = 0;
+    for (; l < nd.n_layers; ++l) {
+        const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
+        const int no = (out + WG_T - 1) / WG_T, ni = (in + WG_T - 1) / WG_T;
+        if (tile < no * ni) { to_ = tile / ni; ti = tile % ni; break; }
+        tile -= no * ni;
+    }
+    if (l == nd.n_layers) return;
+    const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
+    const int o0 = to_ * WG_T, i0 = ti * WG_T;
+    const int oo = gl.out_off[l], io = gl.in_off[l];
+    const int k0 = blockIdx.y * chunk, k1 = min(B, k0 + chunk);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, x = lane & 15, q = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    // software pipeline: the next 16 samples travel global -> registers while the MFMAs run on the
+    // current ones in LDS (a K-split has only a handful of chunks; without this the loop is latency-bound)
+    const int lc = t & 63, lr = t >> 6;                     // this thread loads column lc of rows lr, lr+4, lr+8, lr+12
+    const bool co = o0 + lc < out, ci = i0 + lc < in;
+    float ra[4], rp[4], rh[4], rt[4];
+    auto fetch = [&](int kb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = kb + lr + 4 * j;
+            const bool vb = b < k1;
+            ra[j] = (vb && co) ? AB[(size_t)b * gl.sum_out + oo + o0 + lc] : 0.f;
+            rp[j] = (vb && co) ? PB[(size_t)b * gl.sum_out + oo + o0 + lc] : 0.f;
+            rh[j] = (vb && ci) ? HS[(size_t)b * gl.sum_in + io + i0 + lc] : 0.f;
+            rt[j] = (vb && ci) ? TSb[(size_t)b * gl.sum_in + io + i0 + lc] : 0.f;
+        }
+    };
+    fetch(k0);
+    for (int kb = k0; kb < k1; kb += WG_K) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sA[lr + 4 * j][lc] = ra[j]; sP[lr + 4 * j][lc] = rp[j];
+            sH[lr + 4 * j][lc] = rh[j]; sT[lr + 4 * j][lc] = rt[j];
+        }
+        __syncthreads();
+        if (kb + WG_K < k1) fetch(kb + WG_K);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float bh = sH[4 * c + q][16 * w + x], bt = sT[4 * c + q][16 * w + x];
+#pragma unroll
+            for (int to = 0; to < 4; ++to) {
+                acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(sA[4 * c + q][16 * to + x], bh, acc[to], 0, 0, 0);
+                acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(sP[4 * c + q][16 * to + x], bt, acc[to], 0, 0, 0);
+            }
+        }
+        if (ti == 0 && t < WG_T) {
+#pragma unroll
+            for (int r = 0; r < WG_K; ++r) bsum += sA[r][t];
+        }
+        __syncthreads();
+    }
+    float* g = gpart + (size_t)blockIdx.y * n_params;
+    const int i = i0 + 16 * w + x;
+#pragma unroll
+    for (int to = 0; to < 4; ++to) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = o0 + 16 * to + 4 * q + j;
+            if (o < out && i < in) g[nd.w_off[l] + o + (size_t)i * out] += acc[to][j];
+        }
+    }
+    if (ti == 0 && t < WG_T && o0 + t < out) g[nd.b_off[l] + o0 + t] += bsum;
+}
+
 // grad[p] = sum over the K-splits, in a fixed order
 __global__ void k_grad_reduce(const float* __restrict__ gpart, float* __restrict__ grad, int n_params, int ksplit) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -548,8 +631,13 @@ void grad_ksplit(const NetDesc& nd, const GradLayout& g, int B, int* ksplit, int
 
 hipError_t launch_wgrad(const NetDesc& nd, const GradLayout& g, const float* AB, const float* PB, const float* HS,
                         const float* TS, float* gpart, int n_params, int B, int ksplit, int chunk, hipStream_t s) {
-    hipLaunchKernelGGL(k_wgrad, dim3(grad_wgrad_tiles(nd, g), ksplit), dim3(256), 0, s, nd, g, AB, PB, HS, TS, gpart,
-                       n_params, B, chunk);
+    static const bool valu = getenv("CNF_WGRAD_VALU") != nullptr;     // A/B switch; default: MFMA
+    if (valu)
+        hipLaunchKernelGGL(k_wgrad, dim3(grad_wgrad_tiles(nd, g), ksplit), dim3(256), 0, s, nd, g, AB, PB, HS, TS, gpart,
+                           n_params, B, chunk);
+    else
+        hipLaunchKernelGGL(k_wgrad_mfma, dim3(grad_wgrad_tiles(nd, g), ksplit), dim3(256), 0, s, nd, g, AB, PB, HS, TS,
+                           gpart, n_params, B, chunk);
     return hipGetLastError();
 }
 
@@ -582,5 +670,286 @@ hipError_t launch_lambda_update(float* lam, const StageK& ws, size_t n, hipStrea
 hipError_t launch_final_cotangent(const NetDesc& nd, float lambda3, const float* fsol, float* lam, int B,
                                   hipStream_t s) {
     hipLaunchKernelGGL(k_final_cotangent, dim3((B + 255) / 256), dim3(256), 0, s, nd, lambda3, fsol, lam, B);
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// MFMA pullback kernel.  Same algebra as k_adj; every sweep is a GEMM on v_mfma_f32_16x16x4_f32:
+//   a workgroup = 4 waves owns 16 samples (one MFMA column tile); wave w takes the 16-row output
+//   tiles w, w+4, ...; A = a 16x16 fragment of the padded row-major weight image (forward sweeps:
+//   W, reverse sweeps: W^T), read from global/L2 as one b128 per lane; B = the samples' activations
+//   in LDS, [sample][feature], one ds_read_b128 per lane; the accumulator (lane = sample, 4
+//   consecutive rows) goes back to LDS as one ds_write_b128 -- the conventions of cnf_mfma.hip.
+// VJP compute mode only (JVP handles run k_adj).
+// =================================================================================================
+#define AM_NS 16
+#define AM_WAVES 4
+#define AM_THREADS (AM_WAVES * 64)
+
+static inline int pad16(int x) { return (x + 15) & ~15; }
+
+AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g) {
+    AdjMfmaLayout m{};
+    m.L = nd.n_layers;
+    m.dp[0] = pad16(g.in0);
+    for (int l = 1; l <= m.L; ++l) m.dp[l] = pad16(nd.dims[l]);
+    int off = 0, oo = 0, mx = m.dp[0];
+    for (int l = 0; l < m.L; ++l) {
+        m.f_off[l] = off; off += m.dp[l + 1] * m.dp[l];
+        m.r_off[l] = off; off += m.dp[l] * m.dp[l + 1];
+        m.b_off[l] = off; off += m.dp[l + 1];
+        m.o_off[l] = oo; oo += m.dp[l + 1];
+        if (m.dp[l + 1] > mx) mx = m.dp[l + 1];
+    }
+    m.img_floats = off;
+    m.sum_o = oo; m.maxd = mx; m.nin_p = pad16(nd.n_in);
+    int p = 0;
+    m.D1 = p; p += oo;
+    m.D2 = p; p += oo;
+    m.TB = p; p += oo;
+    m.S0 = p; p += mx;
+    m.S1 = p; p += mx;
+    m.E = p; p += m.nin_p;
+    m.AH = p; p += m.nin_p;
+    m.PS = ((p + 15) & ~15) + 8;          // stride = 8 mod 16 floats: conflict-free b128 columns
+    m.vec4 = (g.sum_in & 3) == 0;         // rows of HS/TS start 16-byte aligned ...
+    for (int l = 0; l < m.L; ++l) if (g.in_off[l] & 3) m.vec4 = 0;   // ... and so does every layer's block
+    return m;
+}
+
+static size_t adj_mfma_lds_bytes(const AdjMfmaLayout& m) {
+    return ((size_t)AM_NS * m.PS + 2 * 16 * AM_NS) * sizeof(float);
+}
+
+bool adj_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m) {
+    return !nd.jvp && nd.dims[nd.n_layers] == nd.n_in && adj_mfma_lds_bytes(m) <= 160 * 1024;
+}
+
+__global__ void k_pack_adj_images(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ P,
+                                  float* __restrict__ img) {
+    const int l = blockIdx.y;
+    const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
+    const int inp = m.dp[l], outp = m.dp[l + 1];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < outp * inp) {
+        {   // forward image [o][k]
+            const int o = e / inp, k = e % inp;
+            img[m.f_off[l] + e] = (o < out && k < in) ? P[nd.w_off[l] + o + (size_t)k * out] : 0.f;
+        }
+        {   // reverse image [i][o]
+            const int i = e / outp, o = e % outp;
+            img[m.r_off[l] + e] = (o < out && i < in) ? P[nd.w_off[l] + o + (size_t)i * out] : 0.f;
+        }
+    }
+    if (e < outp) img[m.b_off[l] + e] = e < out ? P[nd.b_off[l] + e] : 0.f;
+}
+
+// Out tile(s) of one sweep: rows_p x k_p image against the [sample][feature] operand X in LDS.
+template <class Epi>
+__device__ __forceinline__ void am_gemm(const float* __restrict__ img, int rows_p, int k_p, const float* X, int PS,
+                                        Epi&& epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    const float* xrow = X + s * PS + 4 * q;
+    const int nu = k_p >> 4;
+    for (int t = wave; t < (rows_p >> 4); t += AM_WAVES) {
+        const float* arow = img + (size_t)(16 * t + s) * k_p + 4 * q;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // pairs of k-blocks; the A fragments of the next pair are in flight while this pair's MFMAs run
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(arow);
+        f32x4 a1 = nu > 1 ? *reinterpret_cast<const f32x4*>(arow + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < nu; u += 2) {
+            const f32x4 c0 = a0, c1 = a1;
+            if (u + 2 < nu) a0 = *reinterpret_cast<const f32x4*>(arow + 16 * (u + 2));
+            if (u + 3 < nu) a1 = *reinterpret_cast<const f32x4*>(arow + 16 * (u + 3));
+            else a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(xrow + 16 * u);
+            const f32x4 b1 = u + 1 < nu ? *reinterpret_cast<const f32x4*>(xrow + 16 * u + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[c], b0[c], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[c], b1[c], acc1, 0, 0, 0);
+            }
+        }
+        acc0 += acc1;
+        epi(16 * t + 4 * q, s, acc0);      // acc0[j] = Out[row 16t + 4q + j][sample s]
+    }
+}
+
+// per-sample sum of squares of X[s][0..n): every thread returns the value of sample (threadIdx.x >> 4)
+__device__ __forceinline__ float am_colnorm2(const float* X, int PS, int n, float* red) {
+    const int s = threadIdx.x >> 4, part = threadIdx.x & 15;          // 16 parts
+    float v = 0.f;
+    for (int r = part; r < n; r += 16) { const float x = X[s * PS + r]; v = fmaf(x, x, v); }
+    red[part * AM_NS + s] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int p = 0; p < 16; ++p) t += red[p * AM_NS + s];
+    __syncthreads();
+    return t;
+}
+
+__global__ void __launch_bounds__(AM_THREADS)
+k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, AdjArgs a) {
+    extern __shared__ float lds[];
+    const int PS = m.PS, NL = m.L;
+    float* red = lds + (size_t)AM_NS * PS;
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * AM_NS;
+    const int n_in = nd.n_in, D = n_in + 3, in0 = gl.in0;
+    const int es = tid >> 4, ec = tid & 15;                // elementwise passes: sample es, features ec, ec+16, ... (coalesced)
+    const int eb = b0 + es;
+    const bool ev = eb < a.B;
+
+    // ---- inputs: [z; ys; 0] -> S0, eps -> E; h_0 also goes out for the weight gradient ---------
+    for (int r = ec; r < m.dp[0]; r += 16) {
+        float v = 0.f;
+        if (ev && r < in0) v = r < n_in ? a.ustage[(size_t)eb * D + r] : a.ys[(size_t)eb * nd.n_cond + (r - n_in)];
+        lds[es * PS + m.S0 + r] = v;
+        if (ev && r < in0) a.HS[(size_t)eb * gl.sum_in + r] = v;
+    }
+    for (int r = ec; r < m.nin_p; r += 16) lds[es * PS + m.E + r] = (ev && r < n_in) ? a.eps[(size_t)eb * n_in + r] : 0.f;
+    __syncthreads();
+
+    int cur = m.S0, nxt = m.S1;
+    // ---- sweep 1: forward ------------------------------------------------------------------------
+    for (int l = 0; l < NL; ++l) {
+        const int out = nd.dims[l + 1], act = nd.acts[l];
+        const float* bias = img + m.b_off[l];
+        const int oo = m.o_off[l];
+        const int hs_off = l + 1 < NL ? gl.in_off[l + 1] : -1;
+        am_gemm(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PS, [&](int r0, int s, f32x4 acc) {
+            f32x4 h, d1, d2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float hh, dd1, dd2;
+                cnf_act2(act, acc[j] + bias[r0 + j], hh, dd1, dd2);
+                const bool live = r0 + j < out;            // padded rows stay exactly zero
+                h[j] = live ? hh : 0.f; d1[j] = live ? dd1 : 0.f; d2[j] = live ? dd2 : 0.f;
+            }
+            float* S = lds + s * PS;
+            *reinterpret_cast<f32x4*>(S + nxt + r0) = h;
+            *reinterpret_cast<f32x4*>(S + m.D1 + oo + r0) = d1;
+            *reinterpret_cast<f32x4*>(S + m.D2 + oo + r0) = d2;
+            if (hs_off >= 0 && b0 + s < a.B) {
+                float* g = a.HS + (size_t)(b0 + s) * gl.sum_in + hs_off + r0;
+                if (m.vec4 && r0 + 3 < out) *reinterpret_cast<f32x4*>(g) = h;
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (r0 + j < out) g[j] = h[j];
+                }
+            }
+        });
+        __syncthreads();
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+    // zdot in S[cur].  ahat = kbar_z + c_E zdot/|zdot| -> AH
+    {
+        float nz = 0.f;
+        if (nd.norm_z) nz = am_colnorm2(lds + cur, PS, n_in, red);
+        const float inv = (nd.norm_z && nz > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz) : 0.f;
+        for (int r = ec; r < m.nin_p; r += 16) {
+            float v = 0.f;
+            if (ev && r < n_in) {
+                float kb = a.cb * a.lam[(size_t)eb * n_in + r];
+                for (int w = 0; w < a.nw; ++w) kb = fmaf(a.wc[w], a.w[w][(size_t)eb * n_in + r], kb);
+                v = fmaf(inv, lds[es * PS + cur + r], kb * a.hstep);
+            }
+            lds[es * PS + m.AH + r] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- sweep 2: tbar chain (omega = eps) ---------------------------------------------------------
+    for (int r = ec; r < m.dp[NL]; r += 16) lds[es * PS + m.TB + m.o_off[NL - 1] + r] = r < m.nin_p ? lds[es * PS + m.E + r] : 0.f;
+    __syncthreads();
+    for (int l = NL - 1; l >= 0; --l) {
+        const int out = nd.dims[l + 1], oo = m.o_off[l];
+        for (int r = ec; r < m.dp[l + 1]; r += 16) {
+            const float pb = lds[es * PS + m.TB + oo + r] * lds[es * PS + m.D1 + oo + r];
+            lds[es * PS + cur + r] = pb;
+            if (ev && r < out) a.PB[(size_t)eb * gl.sum_out + gl.out_off[l] + r] = pb;
+        }
+        __syncthreads();
+        const int dst = l > 0 ? m.TB + m.o_off[l - 1] : nxt;              // tbar_0 = eJ parks in the other scratch
+        am_gemm(img + m.r_off[l], m.dp[l], m.dp[l + 1], lds + cur, PS, [&](int r0, int s, f32x4 acc) {
+            *reinterpret_cast<f32x4*>(lds + s * PS + dst + r0) = acc;
+        });
+        __syncthreads();
+    }
+    // eJ in S[nxt].  tau = -c_l eps + c_n eJ/|eJ|  -> S[cur] as t_0 (rows of ys and padding: 0)
+    {
+        float nj = 0.f;
+        if (nd.norm_j) nj = am_colnorm2(lds + nxt, PS, n_in, red);
+        const float inv = (nd.norm_j && nj > 0.f) ? a.c_n * __builtin_amdgcn_rsqf(nj) : 0.f;
+        for (int r = ec; r < m.dp[0]; r += 16) {
+            float v = 0.f;
+            if (r < n_in) v = fmaf(inv, lds[es * PS + nxt + r], -a.c_l * lds[es * PS + m.E + r]);
+            lds[es * PS + cur + r] = v;
+            if (ev && r < in0) a.TS[(size_t)eb * gl.sum_in + r] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- sweep 3: tangent chain --------------------------------------------------------------------
+    for (int l = 0; l < NL; ++l) {
+        const int out = nd.dims[l + 1], oo = m.o_off[l];
+        const int ts_off = l + 1 < NL ? gl.in_off[l + 1] : -1;
+        am_gemm(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PS, [&](int r0, int s, f32x4 acc) {
+            float* S = lds + s * PS;
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(S + m.D1 + oo + r0);
+            const f32x4 d2 = *reinterpret_cast<const f32x4*>(S + m.D2 + oo + r0);
+            const f32x4 t = d1 * acc;
+            *reinterpret_cast<f32x4*>(S + nxt + r0) = t;
+            *reinterpret_cast<f32x4*>(S + m.D2 + oo + r0) = d2 * acc;         // q_l = sigma'' .* p_l
+            if (ts_off >= 0 && b0 + s < a.B) {
+                float* g = a.TS + (size_t)(b0 + s) * gl.sum_in + ts_off + r0;
+                if (m.vec4 && r0 + 3 < out) *reinterpret_cast<f32x4*>(g) = t;
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (r0 + j < out) g[j] = t[j];
+                }
+            }
+        });
+        __syncthreads();
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+
+    // ---- sweep 4: hbar chain -----------------------------------------------------------------------
+    for (int r = ec; r < m.dp[NL]; r += 16) lds[es * PS + nxt + r] = r < m.nin_p ? lds[es * PS + m.AH + r] : 0.f;
+    __syncthreads();
+    for (int l = NL - 1; l >= 0; --l) {
+        const int out = nd.dims[l + 1], oo = m.o_off[l];
+        // abar_l = hbar_l sigma' + tbar_l q_l : hbar_l sits in S[nxt], abar_l goes to S[cur]
+        for (int r = ec; r < m.dp[l + 1]; r += 16) {
+            const float ab = fmaf(lds[es * PS + nxt + r], lds[es * PS + m.D1 + oo + r],
+                                  lds[es * PS + m.TB + oo + r] * lds[es * PS + m.D2 + oo + r]);
+            lds[es * PS + cur + r] = ab;
+            if (ev && r < out) a.AB[(size_t)eb * gl.sum_out + gl.out_off[l] + r] = ab;
+        }
+        __syncthreads();
+        am_gemm(img + m.r_off[l], m.dp[l], m.dp[l + 1], lds + cur, PS, [&](int r0, int s, f32x4 acc) {
+            *reinterpret_cast<f32x4*>(lds + s * PS + nxt + r0) = acc;          // hbar_{l-1}
+        });
+        __syncthreads();
+    }
+    for (int r = ec; r < n_in; r += 16)
+        if (ev) a.w_out[(size_t)eb * n_in + r] = lds[es * PS + nxt + r];
+}
+
+hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* P,
+                                  float* img, hipStream_t s) {
+    int mx = 0;
+    for (int l = 0; l < m.L; ++l) if (m.dp[l] * m.dp[l + 1] > mx) mx = m.dp[l] * m.dp[l + 1];
+    hipLaunchKernelGGL(k_pack_adj_images, dim3((mx + 255) / 256, m.L), dim3(256), 0, s, nd, g, m, P, img);
+    return hipGetLastError();
+}
+
+hipError_t launch_adj_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                           const AdjArgs& a, hipStream_t s) {
+    const size_t lds = adj_mfma_lds_bytes(m);
+    hipError_t e = hipFuncSetAttribute((const void*)k_adj_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_adj_mfma, dim3((a.B + AM_NS - 1) / AM_NS), dim3(AM_THREADS), lds, s, nd, g, m, img, a);
     return hipGetLastError();
 }

@@ -1,0 +1,193 @@
+"""Training front end: the host-side mirror of the reference's MLJ adapter for this path
+(src/exts/mlj_ext/core_icnf.jl: ``ICNFModel`` :1-29, ``fit`` :31-94, ``transform`` :96-123,
+``fitted_params`` core.jl:1-4).  ``fit`` runs the reference's loop -- shuffled mini-batches,
+``loss(icnf, TrainMode(), xs, ps, st)`` and its gradient per batch, one optimiser after the other
+for ``n_epochs`` epochs each -- with the gradient coming from the device (cnf_loss_grad) instead of
+Enzyme.  The optimisers are the two the reference names (Optimisers.jl ``Lion`` -- its default --
+and ``Adam``), restated from their published update rules; they run on the device through torch
+(plumbing: n_params-sized elementwise updates).
+
+No MLJ machinery here (tables, machines): ``X`` is an ``n x nvars`` array, one observation per row,
+as ``MLJModelInterface.matrix(X)`` yields (core_icnf.jl:32)."""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Any, Callable, Tuple
+
+import numpy as np
+
+from .base_icnf import ICNF, inference, loss_and_grad
+from .layers import setup
+from .types import TestMode, TrainMode
+
+
+@dataclass
+class Lion:
+    """Optimisers.Lion(eta = 0.001, beta = (0.9, 0.999)): x -= eta * sign(b1 m + (1 - b1) g);
+    m = b2 m + (1 - b2) g  (Chen et al. 2023)."""
+    eta: float = 1e-3
+    beta: Tuple[float, float] = (0.9, 0.999)
+
+    def init(self, ps):
+        return {"m": ps.new_zeros(ps.shape)}
+
+    def apply(self, state, ps, g):
+        import torch
+        b1, b2 = self.beta
+        ps.sub_(torch.sign(state["m"] * b1 + g * (1 - b1)), alpha=self.eta)
+        state["m"].mul_(b2).add_(g, alpha=1 - b2)
+
+
+@dataclass
+class Adam:
+    """Optimisers.Adam(eta = 0.001, beta = (0.9, 0.999), epsilon = 1e-8)."""
+    eta: float = 1e-3
+    beta: Tuple[float, float] = (0.9, 0.999)
+    epsilon: float = 1e-8
+
+    def init(self, ps):
+        return {"m": ps.new_zeros(ps.shape), "v": ps.new_zeros(ps.shape), "t": 0}
+
+    def apply(self, state, ps, g):
+        b1, b2 = self.beta
+        state["t"] += 1
+        state["m"].mul_(b1).add_(g, alpha=1 - b1)
+        state["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
+        mhat = state["m"] / (1 - b1 ** state["t"])
+        vhat = state["v"] / (1 - b2 ** state["t"])
+        ps.sub_(mhat / (vhat.sqrt() + self.epsilon), alpha=self.eta)
+
+
+@dataclass
+class ICNFModel:
+    """src/exts/mlj_ext/core_icnf.jl:1-29 (same field names and defaults; ``adtype`` has no meaning
+    here -- the derivative is the device adjoint)."""
+    m: ICNF
+    optimizers: tuple = field(default_factory=lambda: (Lion(),))
+    n_epochs: int = 300
+    use_batch: bool = True
+    batch_size: int = 32
+    sol_kwargs: dict = field(default_factory=dict)
+    callback: Callable[[int, float], Any] | None = None     # (iteration, loss) per batch; not in the reference
+
+
+def _device_matrix(icnf: ICNF, X):
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X visible: the HIP backend has no CPU fallback")
+    x = np.ascontiguousarray(np.asarray(X, dtype=np.float32).T)      # nvars x n (core_icnf.jl:32)
+    if x.shape[0] != icnf.nvars:
+        raise ValueError(f"X has {x.shape[0]} columns, the model has nvars = {icnf.nvars}")
+    return torch.from_numpy(x).to(torch.device("cuda", icnf.device))
+
+
+def fit(model: ICNFModel, verbosity: int, X, ys=None):
+    """``MLJModelInterface.fit(model, verbosity, X)`` (core_icnf.jl:31-94).  Returns
+    ``(fitresult, cache, report)`` with ``fitresult = (ps, st)``; ``ps`` is the flat Float32 vector as
+    a numpy array.  ``ys`` (n x n_cond) for the conditional models (core_cond_icnf.jl)."""
+    import torch
+    icnf = model.m
+    x = _device_matrix(icnf, X)
+    n = x.shape[1]
+    y = None
+    if icnf.cond:
+        if ys is None:
+            raise ValueError("conditional model: ys is required")
+        y = torch.from_numpy(np.ascontiguousarray(np.asarray(ys, dtype=np.float32).T)).to(x.device)
+    ps_host, st = setup(icnf.rng, icnf.nn)                            # core_icnf.jl:37-38
+    ps = torch.from_numpy(ps_host).to(x.device)
+    bs = model.batch_size if model.use_batch else n                   # core_icnf.jl:47-53
+    it = 0
+    t0 = time.perf_counter()
+    losses = []
+    for opt in model.optimizers:                                      # core_icnf.jl:64-73
+        state = opt.init(ps)
+        for _epoch in range(model.n_epochs):
+            perm = torch.from_numpy(icnf.rng.permutation(n)).to(x.device)     # shuffle = true
+            for lo in range(0, n, bs):                                # partial = true
+                idx = perm[lo:lo + bs]
+                xb = x[:, idx]
+                args = (xb, y[:, idx], ps, st) if y is not None else (xb, ps, st)
+                val, g = loss_and_grad(icnf, TrainMode(), *args)
+                opt.apply(state, ps, g)
+                losses.append(val)
+                it += 1
+                if model.callback is not None:
+                    model.callback(it, val)
+            if verbosity > 0:
+                k = max(1, (n + bs - 1) // bs)
+                print(f"epoch {_epoch + 1}/{model.n_epochs}: mean loss {np.mean(losses[-k:]):.5f}", flush=True)
+    torch.cuda.synchronize(x.device)
+    report = {"stats": {"time": time.perf_counter() - t0, "iterations": it}, "losses": np.asarray(losses)}
+    return (ps.cpu().numpy(), st), None, report
+
+
+def transform(model: ICNFModel, fitresult, Xnew, ys=None):
+    """core_icnf.jl:96-123: ``logp_x`` of every row of ``Xnew`` in TestMode (exact trace)."""
+    icnf = model.m
+    ps, st = fitresult
+    x = _device_matrix(icnf, Xnew)
+    if icnf.cond:
+        import torch
+        y = torch.from_numpy(np.ascontiguousarray(np.asarray(ys, dtype=np.float32).T)).to(x.device)
+        logpx, _ = inference(icnf, TestMode(), x, y, ps, st)
+    else:
+        logpx, _ = inference(icnf, TestMode(), x, ps, st)
+    return logpx.cpu().numpy()
+
+
+def fitted_params(_model, fitresult):
+    """src/exts/mlj_ext/core.jl:1-4."""
+    ps, st = fitresult
+    return {"learned_parameters": ps, "states": st}
+
+
+# ---------------------------------------------------------------------------------------
+# Parameter files.  The reference stores ``ps`` with JLD2 (README.md:92-95),
+# an HDF5 dialect this build cannot write; the flat vector is all the C ABI needs, so it is stored
+# with the shape information that makes it self-checking:
+#   bytes 0..3   "CNFP"      | u32 version = 1 | u32 n_layers | u32 dims[n_layers + 1] (dims[0] =
+#   columns of the first weight = n_in + n_cond) | u32 acts[n_layers] (cnfhip.h codes) | u32 nvars |
+#   u32 naugs | u32 n_cond | u64 n_params | f32 ps[n_params] (Lux order: per layer weight out x in
+#   column-major, then bias).  Little endian throughout.
+# ---------------------------------------------------------------------------------------
+_MAGIC = b"CNFP"
+
+
+def save_params(path, icnf: ICNF, ps):
+    import struct
+    ps = ps.detach().cpu().numpy() if hasattr(ps, "detach") else np.asarray(ps)
+    ps = np.ascontiguousarray(ps, dtype="<f4")
+    dims, acts = icnf.nn.dims, icnf.nn.acts
+    if ps.size != icnf.nn.n_params:
+        raise ValueError("ps does not match the network")
+    with open(path, "wb") as f:
+        f.write(_MAGIC + struct.pack("<II", 1, len(acts)))
+        f.write(struct.pack(f"<{len(dims)}I", *dims) + struct.pack(f"<{len(acts)}I", *acts))
+        f.write(struct.pack("<IIIQ", icnf.nvars, icnf.naugmented, icnf.n_cond, ps.size))
+        f.write(ps.tobytes())
+
+
+def load_params(path, icnf: ICNF | None = None):
+    """Returns the flat Float32 vector; with ``icnf`` given, checks that the file was written for the
+    same network and variable split."""
+    import struct
+    with open(path, "rb") as f:
+        raw = f.read()
+    if raw[:4] != _MAGIC:
+        raise ValueError("not a CNFP parameter file")
+    ver, L = struct.unpack_from("<II", raw, 4)
+    if ver != 1:
+        raise ValueError(f"unsupported CNFP version {ver}")
+    off = 12
+    dims = struct.unpack_from(f"<{L + 1}I", raw, off); off += 4 * (L + 1)
+    acts = struct.unpack_from(f"<{L}I", raw, off); off += 4 * L
+    nvars, naugs, n_cond, n = struct.unpack_from("<IIIQ", raw, off); off += 20
+    ps = np.frombuffer(raw, dtype="<f4", count=n, offset=off).astype(np.float32)
+    if n != sum(i * o + o for i, o in zip(dims[:-1], dims[1:])) or len(raw) != off + 4 * n:
+        raise ValueError("corrupt CNFP file: sizes do not add up")
+    if icnf is not None and (tuple(dims) != tuple(icnf.nn.dims) or tuple(acts) != tuple(icnf.nn.acts) or
+                             (nvars, naugs, n_cond) != (icnf.nvars, icnf.naugmented, icnf.n_cond)):
+        raise ValueError("parameter file was written for a different model")
+    return ps

@@ -79,3 +79,40 @@ def distributed_loss(icnf, mode, xs_local, ps, st=None, *, eps=None, group=None)
     logpx, regs = inference(icnf, mode, xs_local, ps, st, eps=eps)
     sums = allreduce_sums(loss_sums(icnf, logpx, regs), group)
     return loss_from_sums(icnf, mode, sums)
+
+
+def allreduce_mean_weighted(value: float, grad, count: int, group=None):
+    """Combine per-shard (mean loss, mean gradient, column count) into the mean over ALL columns:
+    one all-reduce of ``n_params + 2`` floats (RCCL ncclSum with the nccl backend).  ``grad`` is a torch
+    tensor (CUDA or CPU) or a numpy array; the result has the same kind."""
+    import torch
+    import torch.distributed as dist
+    is_np = not isinstance(grad, torch.Tensor)
+    g = torch.as_tensor(np.asarray(grad, dtype=np.float32)) if is_np else grad
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return value, grad
+    backend = dist.get_backend(group)
+    dev = g.device
+    buf = torch.empty(g.numel() + 2, dtype=torch.float32, device=dev)
+    buf[:-2] = g * float(count)
+    buf[-2] = value * float(count)
+    buf[-1] = float(count)
+    if backend == "nccl" and not buf.is_cuda:
+        buf = buf.cuda()
+    if backend == "gloo" and buf.is_cuda:
+        buf = buf.cpu()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    buf = buf.to(dev)
+    total = float(buf[-1])
+    out = buf[:-2] / total
+    return float(buf[-2]) / total, (out.numpy() if is_np else out)
+
+
+def distributed_loss_and_grad(icnf, mode, xs_local, *args, eps=None, group=None):
+    """Data-parallel ``loss_and_grad``: every rank differentiates the loss of its own columns
+    (``base_icnf.loss_and_grad``), then one all-reduce gives the loss and gradient of the whole batch --
+    identical on all ranks, so identical optimiser steps keep the replicas in sync."""
+    from .base_icnf import loss_and_grad
+    val, grad = loss_and_grad(icnf, mode, xs_local, *args, eps=eps)
+    B = xs_local.shape[1]
+    return allreduce_mean_weighted(val, grad, B, group)

@@ -154,4 +154,39 @@ function base_sol(icnf::ICNF{T, <:HIPMatrixMode, INPLACE},
     fsol
 end
 
+# ---- training: loss and its gradient w.r.t. ps in one C call (cnf_loss_grad) ---------------------
+# What MLJModelInterface.fit (src/exts/mlj_ext/core_icnf.jl:59-73) asks Enzyme for.  Plug it in as the
+# analytic gradient of the OptimizationFunction instead of `model.adtype`:
+#     optfunc = SciMLBase.OptimizationFunction(make_opt_loss(model.m, TrainMode(), st, model.loss);
+#                   grad = (G, u, data) -> (G .= last(loss_and_grad(model.m, first(data), u, st))))
+function loss_and_grad(icnf::ICNF{T, <:HIPMatrixMode}, xs::AbstractMatrix{<:Real}, ps, st) where {T}
+    h = handle(icnf)
+    set_params!(h, ps)
+    x = Matrix{Float32}(xs)
+    B = size(x, 2)
+    n_in = icnf.nvars + icnf.naugmented
+    ϵ = Matrix{Float32}(rand(icnf.rng, icnf.epsdist, B))          # src/base_icnf.jl:277-278
+    t0, t1 = CNF.steer_tspan(icnf, TrainMode())                    # src/base_icnf.jl:108-121
+    kw = icnf.sol_kwargs
+    opts = CnfSolveOpts(t0, t1, get(kw, :abstol, 1.0f-6), get(kw, :reltol, 1.0f-3), get(kw, :dt, 0.0f0),
+                        get(kw, :adaptive, true) ? 1 : 0, min(get(kw, :maxiters, 100_000), typemax(Int32)), 0)
+    stats = CnfSolveStats()
+    val = Ref{Float32}(0)
+    grad = Vector{Float32}(undef, length(ps))
+    check(@ccall(libcnfhip.cnf_loss_grad_host(h::Ptr{Cvoid}, x::Ptr{Float32}, ϵ::Ptr{Float32}, B::Cint,
+                                              Ref(opts)::Ptr{CnfSolveOpts}, val::Ref{Float32}, grad::Ptr{Float32},
+                                              stats::Ref{CnfSolveStats})::Cint), h)
+    val[], grad
+end
+
+# ---- parameter files (CNFP, written/read by continuousnf.jl_amd.mlj.save_params/load_params) ----
+function save_params(path, icnf::ICNF, nn_dims::Vector{Int}, acts::Vector{Int}, ps; n_cond = 0)
+    open(path, "w") do io
+        write(io, "CNFP"); write(io, UInt32(1)); write(io, UInt32(length(acts)))
+        foreach(d -> write(io, UInt32(d)), nn_dims); foreach(a -> write(io, UInt32(a)), acts)
+        write(io, UInt32(icnf.nvars)); write(io, UInt32(icnf.naugmented)); write(io, UInt32(n_cond))
+        write(io, UInt64(length(ps))); write(io, Vector{Float32}(ps))
+    end
+end
+
 end # module

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from continuousnf.jl_amd.parallel import allreduce_sums, loss_from_global_sums, make_shard_reduce, shard_range
+from continuousnf.jl_amd.parallel import allreduce_mean_weighted, allreduce_sums, loss_from_global_sums, make_shard_reduce, shard_range
 from oracle import cnf_oracle as O
 
 
@@ -49,6 +49,11 @@ def _worker(rank, world, port, q):
         v = np.array([1.5 + rank, 0.0, 100.0 * (rank + 1)], dtype=np.float32)
         make_shard_reduce()(v)
         out["lockstep"] = v.tolist()
+        # data-parallel gradient (row f3 over shards): local mean loss/gradient (oracle) -> global mean
+        from oracle import cnf_grad_oracle as G
+        lv, lg, _ = G.loss_and_grad(cfg, flat, xs[:, lo:hi], eps[:, lo:hi], adaptive=False, dt=1 / 4)
+        gv, gg = allreduce_mean_weighted(lv, lg.astype(np.float32), hi - lo)
+        out["grad"] = (gv, gg.tolist())
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -76,6 +81,11 @@ def test_sharded_loss_matches_unsharded_gloo_ws2():
             assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (got, ref)
     assert res[0] == res[1]      # every rank holds the same mean
     assert res[0]["lockstep"] == [4.0, 0.0, 300.0]
+    from oracle import cnf_grad_oracle as G
+    rv, rg, _ = G.loss_and_grad(cfg, flat, xs, eps, adaptive=False, dt=1 / 4)
+    gv, gg = res[0]["grad"]
+    assert abs(gv - rv) <= 1e-5 * max(1.0, abs(rv))
+    assert np.abs(np.asarray(gg) - rg).max() <= 1e-5 * np.abs(rg).max()
 
 
 def test_allreduce_is_identity_without_process_group():

@@ -132,3 +132,35 @@ def test_conditional_construct():
     assert f.cond and f.n_cond == 3 and f.lambda1 == 0
     with pytest.raises(TypeError):
         cnf.inference_prob(c, cnf.TrainMode(), np.zeros((2, 3), np.float32), np.zeros(nn.n_params, np.float32))
+
+
+def test_param_file_roundtrip_and_optimisers(tmp_path):
+    """CNFP parameter files (row f4) and the two optimiser update rules of the training front end."""
+    import torch
+    nn = cnf.Chain(cnf.Dense(5, 7, "tanh"), cnf.Dense(7, 3, "softplus"))
+    icnf = cnf.construct(cnf.CondRNODE, nn, 2, 1, compute_mode=cnf.HIPVecJacMatrixMode())
+    assert icnf.n_cond == 2
+    ps, _ = cnf.setup(3, nn)
+    f = tmp_path / "fitted.cnfp"
+    cnf.save_params(f, icnf, ps)
+    assert np.array_equal(cnf.load_params(f, icnf), ps)
+    other = cnf.construct(cnf.RNODE, cnf.Chain(cnf.Dense(5, 7, "tanh"), cnf.Dense(7, 5, "tanh")), 3, 2,
+                          compute_mode=cnf.HIPVecJacMatrixMode())
+    with pytest.raises(ValueError):
+        cnf.load_params(f, other)
+    raw = f.read_bytes()
+    (tmp_path / "cut.cnfp").write_bytes(raw[:-4])
+    with pytest.raises(ValueError):
+        cnf.load_params(tmp_path / "cut.cnfp")
+    # Lion: sign update with the interpolated momentum; Adam: bias-corrected first step = eta * sign(g)
+    x = torch.tensor([1.0, -2.0, 0.5])
+    g = torch.tensor([0.3, -0.1, 0.0])
+    o = cnf.Lion(eta=0.1)
+    stt = o.init(x)
+    o.apply(stt, x, g)
+    assert torch.allclose(x, torch.tensor([0.9, -1.9, 0.5])) and torch.allclose(stt["m"], 0.001 * g)
+    x = torch.tensor([1.0, -2.0])
+    o = cnf.Adam(eta=0.1)
+    stt = o.init(x)
+    o.apply(stt, x, torch.tensor([0.3, -0.1]))
+    assert torch.allclose(x, torch.tensor([0.9, -1.9]), atol=1e-6)

@@ -1,0 +1,44 @@
+"""Times loss_and_grad (row f3) against the forward loss on the BASELINE shapes.
+    python tools/prof_grad.py [cfg B reps] ...     default: a table over a few (cfg, B) pairs"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def run(i, B, reps=5):
+    import torch
+    import continuousnf.jl_amd as cnf
+    from oracle import cnf_oracle as O
+    from tests.helpers import make_icnf
+    cfg, _, _ = O.baseline_cfg(i)
+    rng = np.random.default_rng(i)
+    flat = torch.from_numpy(O.glorot_params(cfg.net, rng, np.float32, 0.05)).cuda()
+    xs = torch.from_numpy(rng.standard_normal((cfg.nvars, B)).astype(np.float32)).cuda()
+    eps = torch.from_numpy(rng.standard_normal((cfg.n_in, B)).astype(np.float32)).cuda()
+    e32 = float(np.finfo(np.float32).eps)
+    icnf = make_icnf(cnf, cfg, sol_kwargs=dict(reltol=float(np.sqrt(e32)), abstol=e32))
+    out = {}
+    for name, fn in (("loss", lambda: cnf.loss(icnf, cnf.TrainMode(), xs, flat, {}, eps=eps)),
+                     ("loss_and_grad", lambda: cnf.loss_and_grad(icnf, cnf.TrainMode(), xs, flat, {}, eps=eps))):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / reps * 1e3
+    st = icnf.last_stats
+    print(f"cfg{i} B={B}: loss {out['loss']:.2f} ms, loss_and_grad {out['loss_and_grad']:.2f} ms "
+          f"({out['loss_and_grad'] / out['loss']:.1f}x), steps {st['naccept']}+{st['nreject']}", flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 5)
+    else:
+        for i, B in ((1, 32), (2, 32), (2, 4096), (3, 32), (3, 8192), (5, 2048)):
+            run(i, B)
