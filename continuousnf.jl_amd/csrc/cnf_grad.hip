@@ -6,20 +6,20 @@
 // i.e. the exact gradient of the number `loss` returns (oracle/cnf_grad_oracle.py has the algebra).
 //
 // Kernels in this file:
-//   k_adj<TS>     pullback of ONE augmented_f evaluation (src/icnf.jl:318-350, :384-420) at a stage
+//   k_adj_mfma    the pullback on MFMA (default; second half of this file)
+//   k_adj<TS>     VALU fallback: pullback of ONE augmented_f evaluation (src/icnf.jl:318-350, :384-420) at a stage
 //                 state: a workgroup owns TS samples, a thread owns one feature of every layer; the
 //                 four sweeps (forward, reverse of eps, forward tangent, reverse of the cotangent)
 //                 are matrix-vector products against the weights (read through L2, coalesced: W for
 //                 the forward sweeps, a transposed copy for the reverse ones) with the activations of
 //                 the TS samples in LDS.  Emits zbar and, per layer, the four factors of the weight
 //                 gradient in [sample][feature] arrays.
-//   k_wgrad       Wbar_l += ABAR_l^T H_{l-1} + PBAR_l^T T_{l-1}, bbar_l += sum_b ABAR_l: a batch-
+//   k_wgrad[_mfma] Wbar_l += ABAR_l^T H_{l-1} + PBAR_l^T T_{l-1}, bbar_l += sum_b ABAR_l: a batch-
 //                 contraction GEMM, 64x64 output tiles x K-splits; every (tile, split) workgroup owns
 //                 its slice of a partial buffer (no atomics: bit-reproducible), summed at the end.
 //   small elementwise kernels: stage combination, lambda update, final cotangent, partial reduce,
 //   weight transpose.
-// First implementation: VALU kernels.  The MFMA versions (same tiling as cnf_mfma.hip) are the next
-// optimisation step; DESIGN.md section 8.
+// DESIGN.md section 4.4 has the measurements.
 #include "cnf_grad.h"
 #include <cstdlib>
 

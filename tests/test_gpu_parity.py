@@ -1,6 +1,7 @@
 """Parity of the HIP path with the oracle, through the C ABI (via the host mirror), on a
 real MI355X.  Bar: 1e-4 relative in fp32 (tests/helpers.py:RTOL)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -685,3 +686,29 @@ def test_loss_grad_is_reproducible_and_descends():
     assert l2 < l0 and abs((l0 - l2) - step * np.dot(g, g)) <= 0.05 * step * np.dot(g, g)
     with pytest.raises(NotImplementedError):
         cnf.loss_and_grad(icnf, cnf.TestMode(), xs, flat, {})
+
+
+def test_fit_transform_front_end():
+    """The training loop of the reference's MLJ adapter (src/exts/mlj_ext/core_icnf.jl:31-123) on the
+    README model without augmentation: a few epochs lower the mean batch loss towards the entropy of the
+    data distribution, `transform` returns TestMode log-densities, parameters survive a file round trip."""
+    import tempfile
+    nn = cnf.Chain(cnf.Dense(1, 3, "tanh"), cnf.Dense(3, 1, "tanh"))
+    e32 = float(np.finfo(np.float32).eps)
+    icnf = cnf.construct(cnf.RNODE, nn, 1, 0, compute_mode=cnf.HIPVecJacMatrixMode(), tspan=(0.0, 13.0), steer_rate=0.1,
+                         lambda1=1e-2, lambda2=1e-2, lambda3=1e-2, sol_kwargs=dict(reltol=float(np.sqrt(e32)), abstol=e32),
+                         rng=1)
+    r = np.random.default_rng(1).beta(2.0, 4.0, size=(256, 1)).astype(np.float32)
+    model = cnf.ICNFModel(icnf, optimizers=(cnf.Lion(eta=1e-2),), n_epochs=12, batch_size=32)
+    fitresult, cache, report = cnf.fit(model, 0, r)
+    losses = report["losses"]
+    assert report["stats"]["iterations"] == 12 * 8 and cache is None
+    assert np.mean(losses[-8:]) < np.mean(losses[:8]) - 1.0          # 4.x at initialisation
+    assert np.mean(losses[-8:]) > -0.6                                # h(Beta(2,4)) = -0.362 bounds the NLL below
+    logpx = cnf.transform(model, fitresult, r)
+    assert logpx.shape == (256,) and np.isfinite(logpx).all()
+    assert abs(-logpx.mean() - np.mean(losses[-8:])) < 0.5            # exact-trace NLL ~ the training loss
+    ps = cnf.fitted_params(model, fitresult)["learned_parameters"]
+    with tempfile.TemporaryDirectory() as d:
+        cnf.save_params(os.path.join(d, "p.cnfp"), icnf, ps)
+        assert np.array_equal(cnf.load_params(os.path.join(d, "p.cnfp"), icnf), ps)

@@ -15,3 +15,5 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 echo "write rc=$?"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_sq -- python3 tools/prof_rhs.py step 16 > $OUT/pmc_sq.log 2>&1
 echo "sq rc=$?"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/grad -- python3 tools/prof_grad.py 3 8192 3 > $OUT/grad.log 2>&1
+echo "grad rc=$?"

@@ -69,3 +69,14 @@ if fetch and write:
                    "loads are 4 B/lane, a width the guide calls uncalibrated, so the read side is an upper bound")
 json.dump(out, open(os.path.join(DST, f"{tag}_step_kernel_pmc.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+# gradient path (row f3): kernel split of loss + loss_and_grad at config 3, B = 8192
+gs = first("grad/**/*kernel_stats.csv")
+if gs:
+    rows = list(csv.DictReader(open(gs)))
+    with open(os.path.join(DST, f"{tag}_grad_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows[:12]:
+            w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                        r["MinNs"], r["MaxNs"]])
