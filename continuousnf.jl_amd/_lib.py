@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcnfhip.so")
+LIB_PATH = os.environ.get("CNFHIP_LIB") or os.path.join(_HERE, "libcnfhip.so")   # CNFHIP_LIB: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
 # enums (include/cnfhip.h)

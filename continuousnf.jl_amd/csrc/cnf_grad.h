@@ -66,7 +66,7 @@ struct AdjMfmaLayout {
     int img_floats;
     // per-sample LDS offsets (floats) and stride
     int D1, D2, TB, S0, S1, E, AH, PS;
-    int vec4;                       // global rows are 16-byte aligned: vector stores in the epilogues
+    int vec4, vec4o;                // HS/TS resp. AB/PB rows are 16-byte aligned: vector stores in the epilogues
 };
 AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g);
 bool adj_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);

@@ -675,15 +675,19 @@ hipError_t launch_final_cotangent(const NetDesc& nd, float lambda3, const float*
 
 // =================================================================================================
 // MFMA pullback kernel.  Same algebra as k_adj; every sweep is a GEMM on v_mfma_f32_16x16x4_f32:
-//   a workgroup = 4 waves owns 16 samples (one MFMA column tile); wave w takes the 16-row output
-//   tiles w, w+4, ...; A = a 16x16 fragment of the padded row-major weight image (forward sweeps:
+//   a workgroup = AM_WAVES waves owns 16 samples (one MFMA column tile); wave w takes the 16-row output
+//   tiles w, w+AM_WAVES, ...; A = a 16x16 fragment of the padded row-major weight image (forward sweeps:
 //   W, reverse sweeps: W^T), read from global/L2 as one b128 per lane; B = the samples' activations
 //   in LDS, [sample][feature], one ds_read_b128 per lane; the accumulator (lane = sample, 4
 //   consecutive rows) goes back to LDS as one ds_write_b128 -- the conventions of cnf_mfma.hip.
 // VJP compute mode only (JVP handles run k_adj).
 // =================================================================================================
 #define AM_NS 16
-#define AM_WAVES 4
+#ifndef AM_WAVES
+#define AM_WAVES 8            // measured at config 3, B = 8192: (waves, chunk) = (8, 2) 11.1 ms per gradient,
+#endif                        // (8, 4) 11.6, (4, 8) 12.3
+
+#define AM_EC (AM_WAVES * 4)          // feature lanes of an elementwise pass: AM_THREADS / 16 samples
 #define AM_THREADS (AM_WAVES * 64)
 
 static inline int pad16(int x) { return (x + 15) & ~15; }
@@ -714,11 +718,13 @@ AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g) {
     m.PS = ((p + 15) & ~15) + 8;          // stride = 8 mod 16 floats: conflict-free b128 columns
     m.vec4 = (g.sum_in & 3) == 0;         // rows of HS/TS start 16-byte aligned ...
     for (int l = 0; l < m.L; ++l) if (g.in_off[l] & 3) m.vec4 = 0;   // ... and so does every layer's block
+    m.vec4o = (g.sum_out & 3) == 0;
+    for (int l = 0; l < m.L; ++l) if (g.out_off[l] & 3) m.vec4o = 0;
     return m;
 }
 
 static size_t adj_mfma_lds_bytes(const AdjMfmaLayout& m) {
-    return ((size_t)AM_NS * m.PS + 2 * 16 * AM_NS) * sizeof(float);
+    return ((size_t)AM_NS * m.PS + (size_t)AM_EC * AM_NS) * sizeof(float);
 }
 
 bool adj_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m) {
@@ -744,51 +750,141 @@ __global__ void k_pack_adj_images(NetDesc nd, GradLayout gl, AdjMfmaLayout m, co
     if (e < outp) img[m.b_off[l] + e] = e < out ? P[nd.b_off[l] + e] : 0.f;
 }
 
+// Workgroup barrier that waits for LDS traffic only: __syncthreads() also drains the vector-memory
+// counter, which would stall on the weight fragments prefetched for the next sweep (and on the
+// stores of the factor arrays, which nobody reads in this kernel).
+__device__ __forceinline__ void am_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// A-operand stream.  The weight fragments come from L2 (~1-2k cycles away), far longer than the few
+// MFMAs of one k-block, so a wave keeps a whole CHUNK of fragments (AM_CH k-blocks of one output tile)
+// in registers and has the NEXT chunk in flight while it multiplies: the next chunk of the same tile,
+// else the first chunk of its next tile, else the first chunk of the NEXT sweep's image -- that one is
+// issued before the barrier and the elementwise pass between the sweeps.
+#ifndef AM_CH
+#define AM_CH 2
+#endif
+struct AFrag { f32x4 a[AM_CH]; };
+
+// Straight-line loads only: a branch around a load makes the compiler copy the loaded registers into
+// the loop-carried ones right away (waiting for every load in turn).  So the ADDRESS is selected, the
+// loads are unconditional; k-blocks past the end re-read the last valid fragment and are never used.
+__device__ __forceinline__ void am_load(AFrag& f, const float* __restrict__ p, int last) {
+#pragma unroll
+    for (int i = 0; i < AM_CH; ++i) f.a[i] = *reinterpret_cast<const f32x4*>(p + 16 * min(i, last));
+}
+__device__ __forceinline__ const float* am_addr(const float* __restrict__ img, int k_p, int tile, int u0) {
+    const int lane = threadIdx.x & 63;
+    return img + (size_t)(16 * tile + (lane & 15)) * k_p + 4 * (lane >> 4) + 16 * u0;
+}
+__device__ __forceinline__ void am_first(AFrag& f, const float* __restrict__ img, int rows_p, int k_p) {
+    const int wave = threadIdx.x >> 6;
+    const int tile = min(wave, (rows_p >> 4) - 1);       // waves without a tile fetch a valid one (unused)
+    am_load(f, am_addr(img, k_p, tile, 0), (k_p >> 4) - 1);
+}
+
 // Out tile(s) of one sweep: rows_p x k_p image against the [sample][feature] operand X in LDS.
+// `pf` holds am_first() of this image on entry and am_first() of (nimg, nrows_p, nk_p) on exit (nimg
+// may be null).  `pre`: optional per-row vector (bias) fetched before the MFMAs.
 template <class Epi>
 __device__ __forceinline__ void am_gemm(const float* __restrict__ img, int rows_p, int k_p, const float* X, int PS,
-                                        Epi&& epi) {
+                                        AFrag& pf, const float* __restrict__ nimg, int nrows_p, int nk_p,
+                                        const float* __restrict__ pre, Epi&& epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
     const float* xrow = X + s * PS + 4 * q;
-    const int nu = k_p >> 4;
-    for (int t = wave; t < (rows_p >> 4); t += AM_WAVES) {
-        const float* arow = img + (size_t)(16 * t + s) * k_p + 4 * q;
+    const int nu = k_p >> 4, nt = rows_p >> 4;
+    // where the next sweep's first chunk lives (a valid address even when there is no next sweep)
+    const float* nfirst = nimg ? am_addr(nimg, nk_p, min(wave, (nrows_p >> 4) - 1), 0) : am_addr(img, k_p, 0, 0);
+    const int nfirst_last = nimg ? (nk_p >> 4) - 1 : 0;
+    if (wave >= nt) {                                    // no tile in this sweep: only hand the prefetch on
+        if (nimg) am_load(pf, nfirst, nfirst_last);
+        return;
+    }
+    for (int t = wave; t < nt; t += AM_WAVES) {
+        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+        if (pre) pv = *reinterpret_cast<const f32x4*>(pre + 16 * t + 4 * q);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        // pairs of k-blocks; the A fragments of the next pair are in flight while this pair's MFMAs run
-        f32x4 a0 = *reinterpret_cast<const f32x4*>(arow);
-        f32x4 a1 = nu > 1 ? *reinterpret_cast<const f32x4*>(arow + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int u = 0; u < nu; u += 2) {
-            const f32x4 c0 = a0, c1 = a1;
-            if (u + 2 < nu) a0 = *reinterpret_cast<const f32x4*>(arow + 16 * (u + 2));
-            if (u + 3 < nu) a1 = *reinterpret_cast<const f32x4*>(arow + 16 * (u + 3));
-            else a1 = f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(xrow + 16 * u);
-            const f32x4 b1 = u + 1 < nu ? *reinterpret_cast<const f32x4*>(xrow + 16 * u + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u0 = 0; u0 < nu; u0 += AM_CH) {
+            const AFrag cur = pf;
+            const float* np;
+            int nl;
+            if (u0 + AM_CH < nu) { np = am_addr(img, k_p, t, u0 + AM_CH); nl = nu - u0 - AM_CH - 1; }
+            else if (t + AM_WAVES < nt) { np = am_addr(img, k_p, t + AM_WAVES, 0); nl = nu - 1; }
+            else { np = nfirst; nl = nfirst_last; }
+#ifndef AM_ABL_NOALOAD
+            am_load(pf, np, nl);
+#endif
+            const int n = min(AM_CH, nu - u0);
+            // all B fragments of the chunk first (LDS latency paid once, not per k-block), then the
+            // MFMAs; k-blocks i and i+1 use different accumulators so their chains interleave
+            f32x4 b[AM_CH];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[c], b0[c], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[c], b1[c], acc1, 0, 0, 0);
+            for (int i = 0; i < AM_CH; ++i) b[i] = *reinterpret_cast<const f32x4*>(xrow + 16 * (u0 + min(i, n - 1)));
+            if (n == AM_CH) {
+#pragma unroll
+                for (int i = 0; i < AM_CH; i += 2) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[i][c], b[i][c], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[i + 1][c], b[i + 1][c], acc1, 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < AM_CH; ++i) {
+                    if (i < n) {
+                        if (i & 1) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[i][c], b[i][c], acc1, 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[i][c], b[i][c], acc0, 0, 0, 0);
+                        }
+                    }
+                }
             }
         }
         acc0 += acc1;
-        epi(16 * t + 4 * q, s, acc0);      // acc0[j] = Out[row 16t + 4q + j][sample s]
+        epi(16 * t + 4 * q, s, acc0, pv);      // acc0[j] = Out[row 16t + 4q + j][sample s]
     }
 }
 
 // per-sample sum of squares of X[s][0..n): every thread returns the value of sample (threadIdx.x >> 4)
 __device__ __forceinline__ float am_colnorm2(const float* X, int PS, int n, float* red) {
-    const int s = threadIdx.x >> 4, part = threadIdx.x & 15;          // 16 parts
+    const int s = (threadIdx.x >> 4) & 15, part = (threadIdx.x & 15) | ((threadIdx.x >> 8) << 4);   // AM_EC parts
     float v = 0.f;
-    for (int r = part; r < n; r += 16) { const float x = X[s * PS + r]; v = fmaf(x, x, v); }
+    for (int r = part; r < n; r += AM_EC) { const float x = X[s * PS + r]; v = fmaf(x, x, v); }
     red[part * AM_NS + s] = v;
-    __syncthreads();
+    am_barrier();
     float t = 0.f;
-    for (int p = 0; p < 16; ++p) t += red[p * AM_NS + s];
-    __syncthreads();
+    for (int p = 0; p < AM_EC; ++p) t += red[p * AM_NS + s];
+    am_barrier();
     return t;
 }
 
+#ifdef AM_STAMPS
+__device__ unsigned long long am_stamps[64];
+#define AM_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) am_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int cnf_debug_adj_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(am_stamps), sizeof(unsigned long long) * (n < 64 ? n : 64));
+}
+#else
+#define AM_STAMP(i)
+#endif
+// 4 values of a global [sample][feature] row: one 16-byte store when the row layout allows it
+__device__ __forceinline__ void am_store4(float* g, f32x4 v, int r0, int n_valid, bool vec) {
+#ifndef AM_ABL_NOSTORE
+    if (vec && r0 + 3 < n_valid) *reinterpret_cast<f32x4*>(g) = v;
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (r0 + j < n_valid) g[j] = v[j];
+    }
+#endif
+}
+
+template <bool ALL_TANH>
 __global__ void __launch_bounds__(AM_THREADS)
 k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, AdjArgs a) {
     extern __shared__ float lds[];
@@ -797,33 +893,44 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * AM_NS;
     const int n_in = nd.n_in, D = n_in + 3, in0 = gl.in0;
-    const int es = tid >> 4, ec = tid & 15;                // elementwise passes: sample es, features ec, ec+16, ... (coalesced)
+    // elementwise passes: sample es, features ec, ec + AM_EC, ... (16 consecutive lanes = 64 contiguous bytes)
+    const int es = (tid >> 4) & 15, ec = (tid & 15) | ((tid >> 8) << 4);
     const int eb = b0 + es;
     const bool ev = eb < a.B;
+    const int oL = m.o_off[NL - 1];
 
+    AM_STAMP(0);
+    AFrag pf;
+    am_first(pf, img + m.f_off[0], m.dp[1], m.dp[0]);
     // ---- inputs: [z; ys; 0] -> S0, eps -> E; h_0 also goes out for the weight gradient ---------
-    for (int r = ec; r < m.dp[0]; r += 16) {
+    for (int r = ec; r < m.dp[0]; r += AM_EC) {
         float v = 0.f;
         if (ev && r < in0) v = r < n_in ? a.ustage[(size_t)eb * D + r] : a.ys[(size_t)eb * nd.n_cond + (r - n_in)];
         lds[es * PS + m.S0 + r] = v;
         if (ev && r < in0) a.HS[(size_t)eb * gl.sum_in + r] = v;
     }
-    for (int r = ec; r < m.nin_p; r += 16) lds[es * PS + m.E + r] = (ev && r < n_in) ? a.eps[(size_t)eb * n_in + r] : 0.f;
-    __syncthreads();
+    for (int r = ec; r < m.nin_p; r += AM_EC) lds[es * PS + m.E + r] = (ev && r < n_in) ? a.eps[(size_t)eb * n_in + r] : 0.f;
+    am_barrier();
+    AM_STAMP(1);
 
     int cur = m.S0, nxt = m.S1;
-    // ---- sweep 1: forward ------------------------------------------------------------------------
+    // ---- sweep 1: forward.  The last layer's epilogue also forms pbar_L = eps .* sigma'_L (the first
+    //      operand of the tbar chain, tbar_L = omega = eps), parked in the tbar_L slot of TB ------------
     for (int l = 0; l < NL; ++l) {
         const int out = nd.dims[l + 1], act = nd.acts[l];
-        const float* bias = img + m.b_off[l];
         const int oo = m.o_off[l];
-        const int hs_off = l + 1 < NL ? gl.in_off[l + 1] : -1;
-        am_gemm(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PS, [&](int r0, int s, f32x4 acc) {
+        const bool last = l + 1 == NL;
+        const int hs_off = last ? -1 : gl.in_off[l + 1];
+        am_gemm(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PS, pf,
+                img + (last ? m.r_off[NL - 1] : m.f_off[l + 1]), last ? m.dp[NL - 1] : m.dp[l + 2],
+                last ? m.dp[NL] : m.dp[l + 1], img + m.b_off[l],
+                [&](int r0, int s, f32x4 acc, f32x4 bias) {
             f32x4 h, d1, d2;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float hh, dd1, dd2;
-                cnf_act2(act, acc[j] + bias[r0 + j], hh, dd1, dd2);
+                if (ALL_TANH) { hh = cnf_tanh(acc[j] + bias[j]); dd1 = fmaf(-hh, hh, 1.0f); dd2 = -2.0f * hh * dd1; }
+                else cnf_act2(act, acc[j] + bias[j], hh, dd1, dd2);
                 const bool live = r0 + j < out;            // padded rows stay exactly zero
                 h[j] = live ? hh : 0.f; d1[j] = live ? dd1 : 0.f; d2[j] = live ? dd2 : 0.f;
             }
@@ -831,16 +938,17 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
             *reinterpret_cast<f32x4*>(S + nxt + r0) = h;
             *reinterpret_cast<f32x4*>(S + m.D1 + oo + r0) = d1;
             *reinterpret_cast<f32x4*>(S + m.D2 + oo + r0) = d2;
-            if (hs_off >= 0 && b0 + s < a.B) {
-                float* g = a.HS + (size_t)(b0 + s) * gl.sum_in + hs_off + r0;
-                if (m.vec4 && r0 + 3 < out) *reinterpret_cast<f32x4*>(g) = h;
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (r0 + j < out) g[j] = h[j];
-                }
+            const bool sv = b0 + s < a.B;
+            if (!last) {
+                if (sv) am_store4(a.HS + (size_t)(b0 + s) * gl.sum_in + hs_off + r0, h, r0, out, m.vec4);
+            } else {
+                const f32x4 pb = *reinterpret_cast<const f32x4*>(S + m.E + r0) * d1;      // out_L == n_in
+                *reinterpret_cast<f32x4*>(S + m.TB + oL + r0) = pb;
+                if (sv) am_store4(a.PB + (size_t)(b0 + s) * gl.sum_out + gl.out_off[l] + r0, pb, r0, out, m.vec4o);
             }
         });
-        __syncthreads();
+        am_barrier();
+        AM_STAMP(2 + l);
         const int t_ = cur; cur = nxt; nxt = t_;
     }
     // zdot in S[cur].  ahat = kbar_z + c_E zdot/|zdot| -> AH
@@ -848,7 +956,7 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
         float nz = 0.f;
         if (nd.norm_z) nz = am_colnorm2(lds + cur, PS, n_in, red);
         const float inv = (nd.norm_z && nz > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz) : 0.f;
-        for (int r = ec; r < m.nin_p; r += 16) {
+        for (int r = ec; r < m.nin_p; r += AM_EC) {
             float v = 0.f;
             if (ev && r < n_in) {
                 float kb = a.cb * a.lam[(size_t)eb * n_in + r];
@@ -858,83 +966,104 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
             lds[es * PS + m.AH + r] = v;
         }
     }
-    __syncthreads();
+    am_barrier();
+    AM_STAMP(5);
 
-    // ---- sweep 2: tbar chain (omega = eps) ---------------------------------------------------------
-    for (int r = ec; r < m.dp[NL]; r += 16) lds[es * PS + m.TB + m.o_off[NL - 1] + r] = r < m.nin_p ? lds[es * PS + m.E + r] : 0.f;
-    __syncthreads();
+    // ---- sweep 2: tbar chain (omega = eps).  Layer l's GEMM turns pbar_l into tbar_{l-1}; its epilogue
+    //      keeps tbar_{l-1} (sweep 4 needs it) and forms pbar_{l-1} = tbar_{l-1} .* sigma'_{l-1} -----------
     for (int l = NL - 1; l >= 0; --l) {
-        const int out = nd.dims[l + 1], oo = m.o_off[l];
-        for (int r = ec; r < m.dp[l + 1]; r += 16) {
-            const float pb = lds[es * PS + m.TB + oo + r] * lds[es * PS + m.D1 + oo + r];
-            lds[es * PS + cur + r] = pb;
-            if (ev && r < out) a.PB[(size_t)eb * gl.sum_out + gl.out_off[l] + r] = pb;
-        }
-        __syncthreads();
-        const int dst = l > 0 ? m.TB + m.o_off[l - 1] : nxt;              // tbar_0 = eJ parks in the other scratch
-        am_gemm(img + m.r_off[l], m.dp[l], m.dp[l + 1], lds + cur, PS, [&](int r0, int s, f32x4 acc) {
-            *reinterpret_cast<f32x4*>(lds + s * PS + dst + r0) = acc;
+        const float* X = l == NL - 1 ? lds + m.TB + oL : lds + cur;
+        const int oprev = l > 0 ? m.o_off[l - 1] : 0, outp = l > 0 ? nd.dims[l] : 0;
+        const int gprev = l > 0 ? gl.out_off[l - 1] : 0;
+        am_gemm(img + m.r_off[l], m.dp[l], m.dp[l + 1], X, PS, pf,
+                img + (l > 0 ? m.r_off[l - 1] : m.f_off[0]), l > 0 ? m.dp[l - 1] : m.dp[1], l > 0 ? m.dp[l] : m.dp[0],
+                nullptr, [&](int r0, int s, f32x4 acc, f32x4) {
+            float* S = lds + s * PS;
+            if (l > 0) {
+                *reinterpret_cast<f32x4*>(S + m.TB + oprev + r0) = acc;
+                const f32x4 pb = acc * *reinterpret_cast<const f32x4*>(S + m.D1 + oprev + r0);
+                *reinterpret_cast<f32x4*>(S + nxt + r0) = pb;
+                if (b0 + s < a.B) am_store4(a.PB + (size_t)(b0 + s) * gl.sum_out + gprev + r0, pb, r0, outp, m.vec4o);
+            } else {
+                *reinterpret_cast<f32x4*>(S + nxt + r0) = acc;                 // tbar_0 = eJ
+            }
         });
-        __syncthreads();
+        am_barrier();
+        AM_STAMP(7 + (NL - 1 - l));
+        const int t_ = cur; cur = nxt; nxt = t_;
     }
-    // eJ in S[nxt].  tau = -c_l eps + c_n eJ/|eJ|  -> S[cur] as t_0 (rows of ys and padding: 0)
+    // eJ in S[cur].  tau = -c_l eps + c_n eJ/|eJ|  -> S[nxt] as t_0 (rows of ys and padding: 0)
     {
         float nj = 0.f;
-        if (nd.norm_j) nj = am_colnorm2(lds + nxt, PS, n_in, red);
+        if (nd.norm_j) nj = am_colnorm2(lds + cur, PS, n_in, red);
         const float inv = (nd.norm_j && nj > 0.f) ? a.c_n * __builtin_amdgcn_rsqf(nj) : 0.f;
-        for (int r = ec; r < m.dp[0]; r += 16) {
+        for (int r = ec; r < m.dp[0]; r += AM_EC) {
             float v = 0.f;
-            if (r < n_in) v = fmaf(inv, lds[es * PS + nxt + r], -a.c_l * lds[es * PS + m.E + r]);
-            lds[es * PS + cur + r] = v;
+            if (r < n_in) v = fmaf(inv, lds[es * PS + cur + r], -a.c_l * lds[es * PS + m.E + r]);
+            lds[es * PS + nxt + r] = v;
             if (ev && r < in0) a.TS[(size_t)eb * gl.sum_in + r] = v;
         }
     }
-    __syncthreads();
+    am_barrier();
+    AM_STAMP(13);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
 
-    // ---- sweep 3: tangent chain --------------------------------------------------------------------
+    // ---- sweep 3: tangent chain.  The last layer's epilogue forms abar_L = ahat sigma' + eps q_L instead
+    //      of t_L (nobody reads t_L) -------------------------------------------------------------------------
     for (int l = 0; l < NL; ++l) {
         const int out = nd.dims[l + 1], oo = m.o_off[l];
-        const int ts_off = l + 1 < NL ? gl.in_off[l + 1] : -1;
-        am_gemm(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PS, [&](int r0, int s, f32x4 acc) {
+        const bool last = l + 1 == NL;
+        const int ts_off = last ? -1 : gl.in_off[l + 1];
+        am_gemm(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PS, pf,
+                img + (last ? m.r_off[NL - 1] : m.f_off[l + 1]), last ? m.dp[NL - 1] : m.dp[l + 2],
+                last ? m.dp[NL] : m.dp[l + 1], nullptr,
+                [&](int r0, int s, f32x4 acc, f32x4) {
             float* S = lds + s * PS;
             const f32x4 d1 = *reinterpret_cast<const f32x4*>(S + m.D1 + oo + r0);
-            const f32x4 d2 = *reinterpret_cast<const f32x4*>(S + m.D2 + oo + r0);
-            const f32x4 t = d1 * acc;
-            *reinterpret_cast<f32x4*>(S + nxt + r0) = t;
-            *reinterpret_cast<f32x4*>(S + m.D2 + oo + r0) = d2 * acc;         // q_l = sigma'' .* p_l
-            if (ts_off >= 0 && b0 + s < a.B) {
-                float* g = a.TS + (size_t)(b0 + s) * gl.sum_in + ts_off + r0;
-                if (m.vec4 && r0 + 3 < out) *reinterpret_cast<f32x4*>(g) = t;
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (r0 + j < out) g[j] = t[j];
-                }
+            const f32x4 q = *reinterpret_cast<const f32x4*>(S + m.D2 + oo + r0) * acc;   // q_l = sigma'' .* p_l
+            *reinterpret_cast<f32x4*>(S + m.D2 + oo + r0) = q;
+            const bool sv = b0 + s < a.B;
+            if (!last) {
+                const f32x4 t = d1 * acc;
+                *reinterpret_cast<f32x4*>(S + nxt + r0) = t;
+                if (sv) am_store4(a.TS + (size_t)(b0 + s) * gl.sum_in + ts_off + r0, t, r0, out, m.vec4);
+            } else {
+                const f32x4 ab = *reinterpret_cast<const f32x4*>(S + m.AH + r0) * d1 +
+                                 *reinterpret_cast<const f32x4*>(S + m.E + r0) * q;
+                *reinterpret_cast<f32x4*>(S + nxt + r0) = ab;
+                if (sv) am_store4(a.AB + (size_t)(b0 + s) * gl.sum_out + gl.out_off[l] + r0, ab, r0, out, m.vec4o);
             }
         });
-        __syncthreads();
+        am_barrier();
+        AM_STAMP(14 + l);
         const int t_ = cur; cur = nxt; nxt = t_;
     }
 
-    // ---- sweep 4: hbar chain -----------------------------------------------------------------------
-    for (int r = ec; r < m.dp[NL]; r += 16) lds[es * PS + nxt + r] = r < m.nin_p ? lds[es * PS + m.AH + r] : 0.f;
-    __syncthreads();
+    // ---- sweep 4: hbar chain.  Layer l's GEMM turns abar_l into hbar_{l-1}; its epilogue forms
+    //      abar_{l-1} = hbar_{l-1} sigma' + tbar_{l-1} q_{l-1}; the last one is zbar -------------------------
     for (int l = NL - 1; l >= 0; --l) {
-        const int out = nd.dims[l + 1], oo = m.o_off[l];
-        // abar_l = hbar_l sigma' + tbar_l q_l : hbar_l sits in S[nxt], abar_l goes to S[cur]
-        for (int r = ec; r < m.dp[l + 1]; r += 16) {
-            const float ab = fmaf(lds[es * PS + nxt + r], lds[es * PS + m.D1 + oo + r],
-                                  lds[es * PS + m.TB + oo + r] * lds[es * PS + m.D2 + oo + r]);
-            lds[es * PS + cur + r] = ab;
-            if (ev && r < out) a.AB[(size_t)eb * gl.sum_out + gl.out_off[l] + r] = ab;
-        }
-        __syncthreads();
-        am_gemm(img + m.r_off[l], m.dp[l], m.dp[l + 1], lds + cur, PS, [&](int r0, int s, f32x4 acc) {
-            *reinterpret_cast<f32x4*>(lds + s * PS + nxt + r0) = acc;          // hbar_{l-1}
+        const int oprev = l > 0 ? m.o_off[l - 1] : 0, outp = l > 0 ? nd.dims[l] : 0;
+        const int gprev = l > 0 ? gl.out_off[l - 1] : 0;
+        am_gemm(img + m.r_off[l], m.dp[l], m.dp[l + 1], lds + cur, PS, pf,
+                l > 0 ? img + m.r_off[l - 1] : nullptr, l > 0 ? m.dp[l - 1] : 0, l > 0 ? m.dp[l] : 0,
+                nullptr, [&](int r0, int s, f32x4 acc, f32x4) {
+            float* S = lds + s * PS;
+            const bool sv = b0 + s < a.B;
+            if (l > 0) {
+                const f32x4 ab = acc * *reinterpret_cast<const f32x4*>(S + m.D1 + oprev + r0) +
+                                 *reinterpret_cast<const f32x4*>(S + m.TB + oprev + r0) *
+                                 *reinterpret_cast<const f32x4*>(S + m.D2 + oprev + r0);
+                *reinterpret_cast<f32x4*>(S + nxt + r0) = ab;
+                if (sv) am_store4(a.AB + (size_t)(b0 + s) * gl.sum_out + gprev + r0, ab, r0, outp, m.vec4o);
+            } else if (sv) {
+                am_store4(a.w_out + (size_t)(b0 + s) * n_in + r0, acc, r0, n_in, (n_in & 3) == 0);   // zbar
+            }
         });
-        __syncthreads();
+        if (l > 0) am_barrier();
+        AM_STAMP(18 + (NL - 1 - l));
+        const int t_ = cur; cur = nxt; nxt = t_;
     }
-    for (int r = ec; r < n_in; r += 16)
-        if (ev) a.w_out[(size_t)eb * n_in + r] = lds[es * PS + nxt + r];
+    AM_STAMP(24);
 }
 
 hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* P,
@@ -948,8 +1077,14 @@ hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const 
 hipError_t launch_adj_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                            const AdjArgs& a, hipStream_t s) {
     const size_t lds = adj_mfma_lds_bytes(m);
-    hipError_t e = hipFuncSetAttribute((const void*)k_adj_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    bool all_tanh = true;
+    for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
+    const void* fn = all_tanh ? (const void*)k_adj_mfma<true> : (const void*)k_adj_mfma<false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_adj_mfma, dim3((a.B + AM_NS - 1) / AM_NS), dim3(AM_THREADS), lds, s, nd, g, m, img, a);
+    if (all_tanh)
+        hipLaunchKernelGGL(k_adj_mfma<true>, dim3((a.B + AM_NS - 1) / AM_NS), dim3(AM_THREADS), lds, s, nd, g, m, img, a);
+    else
+        hipLaunchKernelGGL(k_adj_mfma<false>, dim3((a.B + AM_NS - 1) / AM_NS), dim3(AM_THREADS), lds, s, nd, g, m, img, a);
     return hipGetLastError();
 }
