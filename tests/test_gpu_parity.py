@@ -712,3 +712,15 @@ def test_fit_transform_front_end():
     with tempfile.TemporaryDirectory() as d:
         cnf.save_params(os.path.join(d, "p.cnfp"), icnf, ps)
         assert np.array_equal(cnf.load_params(os.path.join(d, "p.cnfp"), icnf), ps)
+
+
+def test_loss_grad_tiny_batches():
+    """One sample and 17 samples (one full + one nearly empty MFMA column tile)."""
+    cfg, _, _ = O.baseline_cfg(3)
+    cfg.tspan = (0.0, 0.5)
+    for B in (1, 17):
+        for kernel in KERNELS:
+            val, grad, rval, rgrad, _, _ = _grad_case(cfg, B, 400 + B, kernel, dict(adaptive=False, dt=1 / 4),
+                                                      dict(adaptive=False, dt=1 / 4))
+            assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+            _assert_grad(grad, rgrad, f"B={B} {kernel}")

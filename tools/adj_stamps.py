@@ -1,3 +1,7 @@
+"""In-kernel phase stamps of the MFMA pullback kernel (diagnostic build only):
+    hipcc ... -DAM_STAMPS -c cnf_grad.hip ; link as build_abl/libcnf_STAMPS.so ;
+    CNFHIP_LIB=$PWD/build_abl/libcnf_STAMPS.so python tools/adj_stamps.py [B]
+Prints the s_memtime deltas between the barriers of workgroup 0 (ids in cnf_grad.hip: AM_STAMP)."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
