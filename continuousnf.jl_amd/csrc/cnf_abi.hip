@@ -5,6 +5,7 @@
 #include "cnf_kernels.h"
 #include "cnf_mfma.h"
 #include "cnf_grad.h"
+#include "cnf_trace.h"
 #include <vector>
 
 #include <cmath>
@@ -47,6 +48,8 @@ struct cnf_ctx {
     float* d_PT = nullptr;
     float* d_adj_img = nullptr;   // padded forward/reverse weight images of the MFMA pullback kernel
     bool pt_valid = false;
+    bool img_valid = false;       // d_adj_img holds the images of the current parameters
+    bool trace_on = false;        // this call evaluates TestMode with the MFMA exact-trace kernel
     std::vector<float*> traj_blocks;   // TRAJ_BLOCK state slots each, slot = (n_in + 3) * grad_cap_B floats
     size_t grad_cap_B = 0;
     float* grad_arena = nullptr;
@@ -208,6 +211,7 @@ extern "C" cnf_status cnf_set_params(cnf_handle h, const float* flat_dev, size_t
     HIPCHK(h, hipStreamSynchronize(s));
     h->have_params = true;
     h->pt_valid = false;
+    h->img_valid = false;
     h->cond_B = 0;       // the conditioning bias depends on W1 and b1
     return CNF_OK;
 }
@@ -222,6 +226,7 @@ extern "C" cnf_status cnf_set_params_host(cnf_handle h, const float* flat, size_
     HIPCHK(h, hipDeviceSynchronize());
     h->have_params = true;
     h->pt_valid = false;
+    h->img_valid = false;
     h->cond_B = 0;
     return CNF_OK;
 }
@@ -300,14 +305,47 @@ extern "C" cnf_status cnf_set_cond_host(cnf_handle h, const float* ys, int B) {
     return s;
 }
 
+static bool trace_ok(cnf_handle h);
 extern "C" int cnf_kernel_for(cnf_handle h, int mode, int B) {
     if (!h) return -1;
-    return mfma_supported(h->mfma, h->nd, mode == CNF_MODE_TRAIN, B) ? CNF_KERNEL_MFMA
-                                                                     : CNF_KERNEL_GENERIC;
+    if (mfma_supported(h->mfma, h->nd, mode == CNF_MODE_TRAIN, B)) return CNF_KERNEL_MFMA;
+    return (mode == CNF_MODE_TEST && trace_ok(h)) ? CNF_KERNEL_MFMA : CNF_KERNEL_GENERIC;
+}
+
+// padded forward/reverse weight images shared by the pullback and the exact-trace kernels
+static cnf_status ensure_adj_images(cnf_handle h, hipStream_t st) {
+    const GradLayout g = grad_layout(h->nd);
+    const AdjMfmaLayout m = adj_mfma_layout(h->nd, g);
+    if (!h->d_adj_img) HIPCHK(h, hipMalloc(&h->d_adj_img, (size_t)m.img_floats * sizeof(float)));
+    if (!h->img_valid) {
+        HIPCHK(h, launch_pack_adj_images(h->nd, g, m, h->d_params, h->d_adj_img, st));
+        h->img_valid = true;
+    }
+    return CNF_OK;
+}
+
+static bool trace_ok(cnf_handle h) {
+    const GradLayout g = grad_layout(h->nd);
+    return trace_mfma_supported(h->nd, adj_mfma_layout(h->nd, g));
+}
+
+// one TestMode evaluation with the exact-trace kernel: u -> du (or k7 when du_is_k7)
+static cnf_status launch_trace(cnf_handle h, const float* u, float* du, bool in_solve, bool du_is_k7, int B, hipStream_t st) {
+    const GradLayout g = grad_layout(h->nd);
+    const AdjMfmaLayout m = adj_mfma_layout(h->nd, g);
+    TraceArgs a{};
+    a.u = u; a.du = du; a.ys = h->nd.n_cond > 0 ? h->d_ys : nullptr;
+    a.st = in_solve ? h->d_state : nullptr;
+    a.K1[0] = h->K1[0]; a.K1[1] = h->K1[1];
+    a.du_is_k7 = du_is_k7 ? 1 : 0;
+    a.B = B;
+    HIPCHK(h, launch_trace_mfma(h->nd, g, m, h->d_adj_img, a, st));
+    return CNF_OK;
 }
 
 static cnf_status resolve_kernel(cnf_handle h, int mode, int B, int requested, int* out) {
-    const bool ok = mfma_supported(h->mfma, h->nd, mode == CNF_MODE_TRAIN, B);
+    const bool ok = mfma_supported(h->mfma, h->nd, mode == CNF_MODE_TRAIN, B) ||
+                    (mode == CNF_MODE_TEST && trace_ok(h));
     if (requested == CNF_KERNEL_AUTO) { *out = ok ? CNF_KERNEL_MFMA : CNF_KERNEL_GENERIC; return CNF_OK; }
     if (requested == CNF_KERNEL_GENERIC) { *out = CNF_KERNEL_GENERIC; return CNF_OK; }
     if (requested == CNF_KERNEL_MFMA) {
@@ -355,7 +393,11 @@ extern "C" cnf_status cnf_rhs(cnf_handle h, int mode, int kernel, const float* u
     if ((s = resolve_kernel(h, mode, B, kernel, &k)) != CNF_OK) return s;
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    if (k == CNF_KERNEL_MFMA) {
+    if (k == CNF_KERNEL_MFMA && !mfma_supported(h->mfma, h->nd, mode == CNF_MODE_TRAIN, B)) {
+        // TestMode, three or more layers: exact trace on MFMA (cnf_trace.hip)
+        if ((s = ensure_adj_images(h, st)) != CNF_OK) return s;
+        if ((s = launch_trace(h, u, du, false, false, B, st)) != CNF_OK) return s;
+    } else if (k == CNF_KERNEL_MFMA) {
         s = mfma_rhs(h->mfma, h->nd, mode == CNF_MODE_TRAIN, u, eps, du, B, st);
         if (s != CNF_OK) return fail(h, s, "MFMA RHS launch failed");
     } else {
@@ -406,7 +448,14 @@ static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, i
     a.cond = h->mfma.cond; a.cbs = h->cbs;
     for (int i = 0; i < 2; ++i) { a.U[i] = h->U[i]; a.K1[i] = h->K1[i]; }
     for (int i = 0; i < 5; ++i) a.Ks[i] = h->Ks[i];
-    for (int stage = 1; stage <= 6; ++stage) {      // computes k_{stage+1}
+    for (int stage = 1; stage <= 6 && h->trace_on; ++stage) {     // stage state, then the exact-trace kernel
+        float coef[6];
+        tsit5_row(stage, coef);
+        (void)launch_stage_state(h->d_state, h->U, h->K1, h->Ks, stage, coef, h->ws, stage == 6,
+                                 (size_t)rows_of(h, train) * B, s);
+        (void)launch_trace(h, h->ws, stage < 6 ? h->Ks[stage - 1] : nullptr, true, stage == 6, B, s);
+    }
+    for (int stage = 1; stage <= 6 && !h->trace_on; ++stage) {      // computes k_{stage+1}
         a.nk = stage;
         tsit5_row(stage, a.coef);
         a.ustage = nullptr;
@@ -497,7 +546,9 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     const size_t n = (size_t)D * B;
     int launches = 0;
 
-    const bool use_mfma = k == CNF_KERNEL_MFMA;
+    const bool use_mfma = k == CNF_KERNEL_MFMA && mfma_supported(h->mfma, h->nd, train, B);
+    h->trace_on = k == CNF_KERNEL_MFMA && !use_mfma;       // TestMode, >= 3 layers: generic driver + trace kernel
+    if (h->trace_on && (s = ensure_adj_images(h, (hipStream_t)stream)) != CNF_OK) return s;
     // lock-step over shards only matters when the controller decides something
     const bool lockstep = h->shard_reduce != nullptr && opts->adaptive;
     // number of error partials = blocks of whichever kernel writes them
@@ -528,6 +579,8 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     if (use_mfma) {
         s = mfma_rhs(h->mfma, h->nd, train, h->U[0], eps, h->K1[0], B, st);
         if (s != CNF_OK) return fail(h, s, "MFMA RHS launch failed");
+    } else if (h->trace_on) {
+        if ((s = launch_trace(h, h->U[0], h->K1[0], false, false, B, st)) != CNF_OK) return s;
     } else {
         RhsArgs a{};
         a.B = B; a.S = h->cap_B; a.train = train; a.ws = h->ws; a.eps = eps;
@@ -556,6 +609,10 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         if (use_mfma) {
             s = mfma_rhs_stage(h->mfma, h->nd, train, h->d_state, h->U, h->K1, h->Ks, eps, 1, B, st);
             if (s != CNF_OK) return fail(h, s, "MFMA RHS launch failed");
+        } else if (h->trace_on) {
+            const float one = 1.f;
+            HIPCHK(h, launch_stage_state(h->d_state, h->U, h->K1, h->Ks, 1, &one, h->ws, 0, n, st));
+            if ((s = launch_trace(h, h->ws, h->Ks[0], true, false, B, st)) != CNF_OK) return s;
         } else {
             RhsArgs a{};
             a.st = h->d_state; a.B = B; a.S = h->cap_B; a.train = train; a.ws = h->ws; a.eps = eps;

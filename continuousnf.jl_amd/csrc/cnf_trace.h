@@ -1,0 +1,31 @@
+// Exact trace (TestMode, src/icnf.jl:148-184 with jacobian_batched src/utils.jl:1-36) on MFMA for
+// networks with three or more layers -- launch wrappers of cnf_trace.hip.
+#pragma once
+#include "cnf_grad.h"
+
+struct TraceArgs {
+    const float* u;         // [B][n_in + 1] state (rows of z are read)
+    const float* ys;        // [B][n_cond] or null
+    float* du;              // [B][n_in + 1]
+    const StepState* st;    // solver: skip when done; null for a plain evaluation
+    float* K1[2];           // solver, stage 7: du goes to K1[1 - st->cur]
+    int du_is_k7;
+    int B;
+};
+
+struct TraceLayout {
+    int nct;                // column tiles of 16 tangent columns per group
+    int gs;                 // samples per group = 16 nct / nin_p
+    int PD;                 // per-sample stride of the sigma' rows
+    int PT;                 // per-column stride of the tangent buffers
+    int off_T0, off_T1, off_red;   // float offsets after the 16 sigma' rows
+    int total_floats;
+};
+
+bool trace_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
+TraceLayout trace_layout(const NetDesc& nd, const AdjMfmaLayout& m);
+hipError_t launch_trace_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                             const TraceArgs& a, hipStream_t s);
+// u_stage = U[cur] + h * sum_j coef[j] k_j (k_1 = K1[cur], k_{j>1} = Ks[j-2]), h and cur from the device state
+hipError_t launch_stage_state(const StepState* st, float* const U[2], float* const K1[2], float* const Ks[5], int nk,
+                              const float* coef, float* out, int also_unew, size_t n, hipStream_t s);

@@ -1,0 +1,232 @@
+// Exact trace on MFMA for networks with three or more layers (TestMode: src/icnf.jl:148-184 with
+// jacobian_batched src/utils.jl:1-36).  The reference runs n_in AD sweeps and materialises an
+// n_in x n_in x B tensor; here   tr J = sum_i [D_L W_L T_{L-1}]_ii,   T_l = D_l W_l T_{l-1},  T_0 = I,
+// with D_l = diag(sigma'_l) per sample: the first layer is a row scaling of W_1, the last one only
+// needs its diagonal, and the middle layers are GEMMs  W_l (out x in) x T_{l-1} (in x n_in) per sample.
+// A workgroup (AM_WAVES waves) owns 16 samples: one forward pass for all of them (sigma' of every
+// layer stays in LDS), then groups of `gs` samples whose tangent columns (gs * n_in of them, up to 8
+// MFMA column tiles) share every weight fragment fetched from L2.  The diagonal of the last layer is
+// folded into the epilogue of the last middle GEMM; J is never formed.  Two-layer networks use the
+// closed form in cnf_mfma.hip instead.
+#include "cnf_trace.h"
+#include "cnf_am.h"
+
+#define TR_NCMAX 8
+
+static inline int pad8m16(int x) { return ((x + 15) & ~15) + 8; }
+__device__ __forceinline__ int pad8m16_dev(int x) { return ((x + 15) & ~15) + 8; }
+
+TraceLayout trace_layout(const NetDesc& nd, const AdjMfmaLayout& m) {
+    TraceLayout t{};
+    const int L = m.L;
+    int midmax = 16;                                   // widest operand of a middle GEMM
+    for (int l = 1; l <= L - 1; ++l) if (m.dp[l] > midmax) midmax = m.dp[l];
+    t.PD = pad8m16(m.sum_o);
+    t.PT = pad8m16(midmax);
+    const int PSf = pad8m16(m.maxd);
+    const int nbuf = L >= 4 ? 2 : 1;
+    // as many column tiles per group as fit next to a second workgroup on the CU (<= 80 KB), at least one sample
+    const int per_sample_tiles = m.nin_p / 16;                          // 1, 2, 4 or 8 (trace_mfma_supported)
+    int nct = TR_NCMAX;
+    for (;;) {
+        const size_t fl = (size_t)AM_NS * t.PD + (size_t)nbuf * 16 * nct * t.PT + (size_t)AM_NS * AM_WAVES;
+        if (fl * 4 <= 80 * 1024 || nct <= per_sample_tiles) break;
+        nct /= 2;
+    }
+    t.nct = nct;
+    t.gs = 16 * nct / m.nin_p;
+    t.off_T0 = AM_NS * t.PD;
+    size_t region = (size_t)nbuf * 16 * nct * t.PT;
+    if (region < (size_t)2 * AM_NS * PSf) region = (size_t)2 * AM_NS * PSf;     // the forward ping-pong aliases it
+    t.off_T1 = t.off_T0 + 16 * nct * t.PT;
+    t.off_red = t.off_T0 + (int)region;
+    t.total_floats = t.off_red + AM_NS * AM_WAVES;
+    return t;
+}
+
+bool trace_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m) {
+    if (nd.n_layers < 3 || nd.dims[nd.n_layers] != nd.n_in) return false;
+    const int tps = m.nin_p / 16;
+    if (tps != 1 && tps != 2 && tps != 4 && tps != 8) return false;
+    const TraceLayout t = trace_layout(nd, m);
+    return (size_t)t.total_floats * 4 <= 160 * 1024;
+}
+
+template <bool ALL_TANH, int NCT>
+__global__ void __launch_bounds__(AM_THREADS)
+k_trace_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const float* __restrict__ img, TraceArgs a) {
+    if (a.st && a.st->done) return;
+    extern __shared__ float lds[];
+    const int NL = m.L, PD = tl.PD, PT = tl.PT;
+    const int PSf = pad8m16_dev(m.maxd);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x * AM_NS;
+    const int n_in = nd.n_in, D = n_in + 1, in0 = gl.in0;
+    const int es = (tid >> 4) & 15, ec = (tid & 15) | ((tid >> 8) << 4);
+    const int eb = b0 + es;
+    const bool ev = eb < a.B;
+    float* du = a.du;
+    if (a.st && a.du_is_k7) du = a.K1[1 - a.st->cur];
+    float* red = lds + tl.off_red;
+
+    AFrag pf;
+    am_first(pf, img + m.f_off[0], m.dp[1], m.dp[0]);
+    int cur = tl.off_T0, nxt = tl.off_T0 + AM_NS * PSf;
+    for (int r = ec; r < m.dp[0]; r += AM_EC) {
+        float v = 0.f;
+        if (ev && r < in0) v = r < n_in ? a.u[(size_t)eb * D + r] : a.ys[(size_t)eb * nd.n_cond + (r - n_in)];
+        lds[cur + es * PSf + r] = v;
+    }
+    am_barrier();
+
+    // ---- forward: zdot out, sigma' of every layer kept ------------------------------------------------
+    for (int l = 0; l < NL; ++l) {
+        const int out = nd.dims[l + 1], act = nd.acts[l], oo = m.o_off[l];
+        const bool last = l + 1 == NL;
+        am_gemm(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PSf, pf,
+                img + (last ? m.f_off[1] : m.f_off[l + 1]), last ? m.dp[2] : m.dp[l + 2], last ? m.dp[1] : m.dp[l + 1],
+                img + m.b_off[l], [&](int r0, int s, f32x4 acc, f32x4 bias) {
+            f32x4 h, d1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float hh, dd1, dd2;
+                if (ALL_TANH) { hh = cnf_tanh(acc[j] + bias[j]); dd1 = fmaf(-hh, hh, 1.0f); }
+                else cnf_act2(act, acc[j] + bias[j], hh, dd1, dd2);
+                const bool live = r0 + j < out;
+                h[j] = live ? hh : 0.f; d1[j] = live ? dd1 : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(lds + s * PD + oo + r0) = d1;
+            if (!last) *reinterpret_cast<f32x4*>(lds + nxt + s * PSf + r0) = h;
+            else if (b0 + s < a.B) {
+                float* g = du + (size_t)(b0 + s) * D + r0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (r0 + j < out) g[j] = h[j];                 // zdot rows
+            }
+        });
+        am_barrier();
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+
+    // ---- trace: groups of gs samples -------------------------------------------------------------------
+    constexpr int nct = NCT;
+    const int gs = tl.gs, tps = m.nin_p >> 4;                         // column tiles per sample
+    const int d1w = m.dp[1];                                          // features of T_1
+    const float* R0 = img + m.r_off[0];                               // W_1^T image [i][k]
+    const float* WL = img + m.f_off[NL - 1];                          // W_L image [i][j], k_p = dp[NL-1]
+    const int kL = m.dp[NL - 1];
+    const int oLast = m.o_off[NL - 1];
+    for (int g0 = 0; g0 < AM_NS; g0 += gs) {
+        if (b0 + g0 >= a.B) break;                                    // uniform: no samples left in this workgroup
+        // T_1[col][k] = sigma'_1[sample][k] * W_1[k][i]   (columns i >= n_in: zero)
+        const int ncols = 16 * nct, nq = d1w >> 2;
+        for (int e = tid; e < ncols * nq; e += AM_THREADS) {
+            const int col = e / nq, k4 = (e % nq) << 2;
+            const int sl = col / m.nin_p, i = col % m.nin_p;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < n_in)
+                v = *reinterpret_cast<const f32x4*>(lds + (g0 + sl) * PD + m.o_off[0] + k4) *
+                    *reinterpret_cast<const f32x4*>(R0 + (size_t)i * d1w + k4);
+            *reinterpret_cast<f32x4*>(lds + tl.off_T0 + col * PT + k4) = v;
+        }
+        am_barrier();
+        int tc = tl.off_T0, tn = tl.off_T1;
+        float p[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) p[c] = 0.f;
+        for (int l = 1; l <= NL - 2; ++l) {
+            const bool lastmid = l == NL - 2;
+            const int oo = m.o_off[l];
+            const float* nimg = lastmid ? img + m.f_off[1] : img + m.f_off[l + 1];
+            const int nr = lastmid ? m.dp[2] : m.dp[l + 2], nk = lastmid ? m.dp[1] : m.dp[l + 1];
+            am_gemm_multi<NCT>(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + tc, PT, pf, nimg, nr, nk,
+                               [&](int r0, int s, f32x4 (&acc)[NCT]) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) {
+                    {
+                        const int sample = g0 + c / tps, i = 16 * (c % tps) + s;
+                        const f32x4 t = acc[c] * *reinterpret_cast<const f32x4*>(lds + sample * PD + oo + r0);
+                        if (!lastmid) {
+                            *reinterpret_cast<f32x4*>(lds + tn + (16 * c + s) * PT + r0) = t;
+                        } else {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(WL + (size_t)i * kL + r0);
+                            p[c] = fmaf(t[0], w[0], fmaf(t[1], w[1], fmaf(t[2], w[2], fmaf(t[3], w[3], p[c]))));
+                        }
+                    }
+                }
+            });
+            if (!lastmid) { am_barrier(); const int t_ = tc; tc = tn; tn = t_; }
+        }
+        // tr_sample = sum_i sigma'_L[i] * (sum over rows) ; lanes hold (column i, a quarter of the rows)
+#pragma unroll
+        for (int sl = 0; sl < NCT; ++sl) {
+            if (sl < gs) {
+                float v = 0.f;
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    if (c / tps == sl)
+                        v = fmaf(p[c], lds[(g0 + sl) * PD + oLast + 16 * (c % tps) + (lane & 15)], v);
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if (lane == 0) red[(g0 + sl) * AM_WAVES + wave] = v;
+            }
+        }
+        am_barrier();                                                  // T buffers free for the next group
+    }
+    am_barrier();
+    if (tid < AM_NS && b0 + tid < a.B) {
+        float tr = 0.f;
+        for (int w = 0; w < AM_WAVES; ++w) tr += red[tid * AM_WAVES + w];
+        du[(size_t)(b0 + tid) * D + n_in] = -tr;                       // src/icnf.jl:162
+    }
+}
+
+// u_stage = U[cur] + h * sum_j coef[j] k_j
+__global__ void k_stage_state(const StepState* st, float* U0, float* U1, float* K10, float* K11, float* Ks0, float* Ks1,
+                              float* Ks2, float* Ks3, float* Ks4, int nk, float c0, float c1, float c2, float c3, float c4,
+                              float c5, float* __restrict__ out, int also_unew, size_t n) {
+    if (st->done) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cur = st->cur;
+    const float* u = cur ? U1 : U0;
+    const float* k1 = cur ? K11 : K10;
+    const float* ks[5] = {Ks0, Ks1, Ks2, Ks3, Ks4};
+    const float cf[6] = {c0, c1, c2, c3, c4, c5};
+    float acc = nk > 0 ? cf[0] * k1[i] : 0.f;
+    for (int j = 1; j < nk; ++j) acc = fmaf(cf[j], ks[j - 1][i], acc);
+    const float v = fmaf(st->h, acc, u[i]);
+    out[i] = v;
+    if (also_unew) (cur ? U0 : U1)[i] = v;
+}
+
+hipError_t launch_stage_state(const StepState* st, float* const U[2], float* const K1[2], float* const Ks[5], int nk,
+                              const float* coef, float* out, int also_unew, size_t n, hipStream_t s) {
+    float c[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < nk && j < 6; ++j) c[j] = coef[j];
+    hipLaunchKernelGGL(k_stage_state, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, U[0], U[1], K1[0], K1[1],
+                       Ks[0], Ks[1], Ks[2], Ks[3], Ks[4], nk, c[0], c[1], c[2], c[3], c[4], c[5], out, also_unew, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                             const TraceArgs& a, hipStream_t s) {
+    const TraceLayout tl = trace_layout(nd, m);
+    const size_t lds = (size_t)tl.total_floats * sizeof(float);
+    bool all_tanh = true;
+    for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
+    const dim3 grid((a.B + AM_NS - 1) / AM_NS), block(AM_THREADS);
+#define TR_LAUNCH(T, N)                                                                                             \
+    do {                                                                                                            \
+        hipError_t e = hipFuncSetAttribute((const void*)k_trace_mfma<T, N>,                                         \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+        if (e != hipSuccess) return e;                                                                              \
+        hipLaunchKernelGGL((k_trace_mfma<T, N>), grid, block, lds, s, nd, g, m, tl, img, a);                        \
+    } while (0)
+    switch (tl.nct) {
+        case 1: if (all_tanh) TR_LAUNCH(true, 1); else TR_LAUNCH(false, 1); break;
+        case 2: if (all_tanh) TR_LAUNCH(true, 2); else TR_LAUNCH(false, 2); break;
+        case 4: if (all_tanh) TR_LAUNCH(true, 4); else TR_LAUNCH(false, 4); break;
+        default: if (all_tanh) TR_LAUNCH(true, 8); else TR_LAUNCH(false, 8); break;
+    }
+#undef TR_LAUNCH
+    return hipGetLastError();
+}

@@ -724,3 +724,49 @@ def test_loss_grad_tiny_batches():
                                                       dict(adaptive=False, dt=1 / 4))
             assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
             _assert_grad(grad, rgrad, f"B={B} {kernel}")
+
+
+def test_exact_trace_mfma_deep_networks():
+    """TestMode for networks with three or more layers runs the MFMA exact-trace kernel
+    (cnf_trace.hip: tr J = sum_i [D_L W_L T_{L-1}]_ii with the tangent columns of a group of samples sharing
+    every weight fragment).  Checked against the oracle's jacobian_batched: config 3 (3 layers), a 4-layer
+    network (tangent ping-pong), mixed activations, a conditional model, ragged batches; then a solve."""
+    l = _lib.lib()
+    cases = [
+        (O.baseline_cfg(3)[0], 0, 77),
+        (O.Cfg(O.Net((16, 64, 48, 32, 16), (O.ACT_TANH,) * 4), 12, 4), 0, 50),
+        (O.Cfg(O.Net((32, 96, 64, 32), (O.ACT_SOFTPLUS, O.ACT_TANH, O.ACT_IDENTITY)), 32, 0), 0, 33),
+        (O.Cfg(O.Net((10, 40, 24, 10), (O.ACT_TANH, O.ACT_SIGMOID, O.ACT_TANH)), 8, 2), 0, 19),   # unaligned widths
+        (O.Cfg(O.Net((32, 64, 64, 32), (O.ACT_TANH,) * 3), 32, 0), 5, 40),                          # conditional
+    ]
+    for k, (cfg, n_cond, B) in enumerate(cases):
+        rng = np.random.default_rng(500 + k)
+        net = cfg.net if not n_cond else O.Net((cfg.net.dims[0] + n_cond,) + tuple(cfg.net.dims[1:]), cfg.net.acts)
+        flat = O.glorot_params(net, rng, np.float32, 0.2)
+        u = rng.standard_normal((cfg.n_in + 1, B)).astype(np.float32)
+        ys = rng.standard_normal((n_cond, B)).astype(np.float32) if n_cond else None
+        layers = [cnf.Dense(a, b, helpers.ACT_NAME[c]) for a, b, c in zip(net.dims[:-1], net.dims[1:], net.acts)]
+        tag = cnf.CondRNODE if n_cond else cnf.RNODE
+        icnf = cnf.construct(tag, cnf.Chain(*layers), cfg.nvars, cfg.naugs, compute_mode=cnf.HIPVecJacMatrixMode("mfma"))
+        nn = cnf.CondLayer(icnf.nn, _dev(ys)) if n_cond else icnf.nn
+        if n_cond:
+            icnf.set_params(flat)
+            icnf.set_cond(_dev(ys), B)
+        assert l.cnf_kernel_for(icnf.handle(), _lib.MODE_TEST, B) == _lib.KERNEL_MFMA, k
+        du = cnf.augmented_f(_dev(u), flat, 0.0, icnf, cnf.TestMode(), nn, {}, None).cpu().numpy()
+        c64 = O.Cfg(net, cfg.nvars, cfg.naugs)
+        ref = O.augmented_f_test(net, flat.astype(np.float64), u.astype(np.float64), False,
+                                 None if ys is None else ys.astype(np.float64))
+        assert_parity(du, ref, f"exact trace case {k}")
+    # a full adaptive TestMode inference on config 3 (what pdf(ICNFDist(TestMode)) runs) vs the float64 oracle
+    cfg, _, _ = O.baseline_cfg(3)
+    rng = np.random.default_rng(9)
+    B = 200
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+    kw = dict(reltol=1e-5, abstol=1e-6)
+    ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=kw)
+    logpx, _ = cnf.inference(ic, cnf.TestMode(), _dev(xs), flat, {})
+    assert ic.last_stats["kernel_used"] == _lib.KERNEL_MFMA
+    _, ref_lp, _, _ = O.inference(cfg, flat.astype(np.float64), xs.astype(np.float64), None, False, reltol=1e-9, abstol=1e-9)
+    assert_parity(logpx.cpu().numpy(), ref_lp, "config 3 TestMode logpx", rtol=2e-4)

@@ -1,0 +1,27 @@
+"""Times the TestMode (exact trace) right-hand side and a full TestMode inference on config 3
+(three layers: the MFMA exact-trace kernel of cnf_trace.hip).   python tools/prof_testmode.py [B]"""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import continuousnf.jl_amd as cnf
+from oracle import cnf_oracle as O
+from tests.helpers import make_icnf
+cfg, B, _ = O.baseline_cfg(3)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else B
+rng = np.random.default_rng(1)
+flat = O.glorot_params(cfg.net, rng, np.float32, 0.05)
+u = torch.from_numpy(rng.standard_normal((cfg.n_in + 1, B)).astype(np.float32)).cuda()
+icnf = make_icnf(cnf, cfg)
+f = lambda: cnf.augmented_f(u, flat, 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)
+f(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(5): f()
+torch.cuda.synchronize()
+print(f"cfg3 TestMode RHS B={B}: {(time.perf_counter()-t0)/5*1e3:.3f} ms")
+xs = torch.from_numpy(rng.standard_normal((cfg.nvars, B)).astype(np.float32)).cuda()
+e32 = float(np.finfo(np.float32).eps)
+ic = make_icnf(cnf, cfg, sol_kwargs=dict(reltol=float(np.sqrt(e32)), abstol=e32))
+g = lambda: cnf.inference(ic, cnf.TestMode(), xs, flat, {})
+g(); torch.cuda.synchronize()
+t0 = time.perf_counter(); g(); torch.cuda.synchronize()
+print(f"cfg3 TestMode inference B={B}: {(time.perf_counter()-t0)*1e3:.2f} ms", ic.last_stats)
