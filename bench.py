@@ -28,11 +28,13 @@ PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 PEAK_HBM_GBS = 8000.0       # spec
 
 
-def cpu_baseline(cfg, B, flat, xs, eps, kw, budget_s=12.0):
+def cpu_baseline(B, flat, xs, eps, kw, budget_s=12.0):
     """The float32 C restatement of the reference path (oracle/cnf_oracle.c, OpenMP over
-    all host cores) on the same workload; bounded to ~budget_s of CPU time."""
+    all host cores) on the same workload; bounded to ~budget_s of CPU time.  The only place
+    bench.py touches oracle/."""
     from oracle import c_oracle as CO
     from oracle import cnf_oracle as O
+    cfg, _, _ = O.baseline_cfg(3)
     u0 = O.inference_u0(cfg, xs, True)
     CO.solve(cfg, flat, u0, eps, True, **kw)            # warm-up (page-in, thread pool)
     nf, t0, n = 0, time.perf_counter(), 0
@@ -66,8 +68,7 @@ def main():
     import continuousnf.jl_amd as cnf
     from continuousnf.jl_amd import _lib
     from continuousnf.jl_amd.parallel import allreduce_sums
-    from oracle import cnf_oracle as O           # only for the config table, inputs and cpu_baseline
-    from tests.helpers import make_icnf
+    from continuousnf.jl_amd import configs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -84,17 +85,15 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    cfg, _, _ = O.baseline_cfg(3)
+    wl = configs.BASELINE[3]
     B = args.batch
-    rng = np.random.default_rng(1 + rank)               # seeds 1..
-    flat = O.glorot_params(cfg.net, np.random.default_rng(12345), np.float32)
-    xs_h = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
-    eps_h = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+    flat = configs.glorot_params(wl.dims, 12345)
+    xs_h, eps_h = configs.synthetic_inputs(wl, B, 1 + rank)     # seeds 1..
     if args.fixed_dt > 0:
         kw = dict(adaptive=False, dt=args.fixed_dt)
     else:
-        kw = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
-    icnf = make_icnf(cnf, cfg, kernel=args.kernel, sol_kwargs=kw, tag=cnf.RNODE)
+        kw = dict(configs.README_TOLERANCES)
+    icnf = configs.build(wl, kernel=args.kernel, sol_kwargs=kw)
     icnf.device = dev_index
     # resident in HBM in the reference's own layout (Julia column-major: a sample's rows contiguous)
     xs = torch.from_numpy(np.ascontiguousarray(xs_h.T)).to(dev).t()
@@ -148,8 +147,8 @@ def main():
             nsteps = 64
             opts = _lib.cnf_solve_opts(0.0, 1.0, 0.0, 0.0, 1.0 / nsteps, 0, 1 << 20, _lib.KERNEL_MFMA)
             stats = _lib.cnf_solve_stats()
-            D = cfg.D(True)
-            u0 = torch.zeros(B * D, device=dev); u0.view(B, D)[:, :cfg.nvars] = xs.t()
+            D = wl.n_in + 3
+            u0 = torch.zeros(B * D, device=dev); u0.view(B, D)[:, :wl.nvars] = xs.t()
             out = torch.empty_like(u0)
             run = lambda: _lib.check(l.cnf_solve_tsit5(h, 1, u0.data_ptr(), eps.data_ptr(), out.data_ptr(), B,
                                                        C.byref(opts), C.byref(stats), sp), h)
@@ -159,7 +158,7 @@ def main():
             per_launch_s = e0.elapsed_time(e1) * 1e-3 / nsteps
             units, kname = 6.0, "fused Tsit5 step kernel (6 RHS evaluations per launch)"
         else:
-            D = cfg.D(True)
+            D = wl.n_in + 3
             u = torch.randn(B * D, device=dev); du = torch.empty_like(u)
             n = 50
             for _ in range(5):
@@ -206,7 +205,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, B, flat, xs_h, eps_h,
+            out["cpu_baseline"] = cpu_baseline(B, flat, xs_h, eps_h,
                                                dict(dt=args.fixed_dt, adaptive=False) if args.fixed_dt > 0 else kw)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))

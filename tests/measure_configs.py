@@ -1,8 +1,8 @@
 """Runs every BASELINE.json configuration at its full size on cuda:0 and prints one JSON line
 per configuration: which kernel ran, RHS evaluations per second of an adaptive solve (README
 tolerances) and of a fixed-dt solve, plain-RHS launch time, and the parity error of the RHS
-against the float32 C oracle on a column sample.  Not part of the product; used to fill the
-tables of DESIGN.md / README.md.    python tools/measure_configs.py [cfg ...]"""
+against the float32 C oracle on a column sample.  A checker script (it uses the oracle, so it lives under tests/); fills the
+tables of DESIGN.md / README.md.    python tests/measure_configs.py [cfg ...]"""
 import ctypes as C
 import json
 import os

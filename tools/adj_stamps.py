@@ -7,15 +7,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np, torch
 import continuousnf.jl_amd as cnf
 from continuousnf.jl_amd import _lib
-from oracle import cnf_oracle as O
-from tests.helpers import make_icnf
-cfg, _, _ = O.baseline_cfg(3)
+from continuousnf.jl_amd import configs
+wl = configs.BASELINE[3]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-rng = np.random.default_rng(1)
-flat = torch.from_numpy(O.glorot_params(cfg.net, rng, np.float32, 0.05)).cuda()
-xs = torch.from_numpy(rng.standard_normal((cfg.nvars, B)).astype(np.float32)).cuda()
-eps = torch.from_numpy(rng.standard_normal((cfg.n_in, B)).astype(np.float32)).cuda()
-icnf = make_icnf(cnf, cfg, sol_kwargs=dict(adaptive=False, dt=0.25))
+flat = torch.from_numpy(configs.glorot_params(wl.dims, 1, 0.05)).cuda()
+xs_h, eps_h = configs.synthetic_inputs(wl, B, 1)
+xs, eps = torch.from_numpy(xs_h).cuda(), torch.from_numpy(eps_h).cuda()
+icnf = configs.build(wl, sol_kwargs=dict(adaptive=False, dt=0.25))
 for _ in range(2):
     cnf.loss_and_grad(icnf, cnf.TrainMode(), xs, flat, {}, eps=eps)
 torch.cuda.synchronize()

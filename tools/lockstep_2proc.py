@@ -18,20 +18,17 @@ def _worker(rank, world, port, q):
     try:
         import continuousnf.jl_amd as cnf
         from continuousnf.jl_amd.parallel import lockstep, shard_range
-        from oracle import cnf_oracle as O
-        from tests.helpers import make_icnf
-        cfg, _, _ = O.baseline_cfg(3)
+        from continuousnf.jl_amd import configs
+        cfg = configs.BASELINE[3]
         B = 1000
-        rng = np.random.default_rng(5)
-        flat = O.glorot_params(cfg.net, rng, np.float32, 0.2)
-        xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+        flat = configs.glorot_params(cfg.dims, 5, 0.2)
+        xs, eps = configs.synthetic_inputs(cfg, B, 5)
         xs[:, B // 2:] *= 2.0
-        eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
-        kw = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+        kw = dict(configs.README_TOLERANCES)
         lo, hi = shard_range(B, world, rank)
         res = {}
         for lock in (True, False):
-            icnf = make_icnf(cnf, cfg, kernel="auto", sol_kwargs=kw)
+            icnf = configs.build(cfg, kernel="auto", sol_kwargs=kw)
             if lock:
                 lockstep(icnf)
             p = cnf.inference_prob(icnf, cnf.TrainMode(), np.ascontiguousarray(xs[:, lo:hi]), flat, {},
@@ -39,7 +36,7 @@ def _worker(rank, world, port, q):
             res[lock] = (cnf.base_sol(icnf, p).view().copy(), dict(p.stats))
         full = None
         if rank == 0:
-            icnf = make_icnf(cnf, cfg, kernel="auto", sol_kwargs=kw)
+            icnf = configs.build(cfg, kernel="auto", sol_kwargs=kw)
             p = cnf.inference_prob(icnf, cnf.TrainMode(), xs, flat, {}, eps=eps)
             full = (cnf.base_sol(icnf, p).view().copy(), dict(p.stats))
         q.put((rank, res, full))

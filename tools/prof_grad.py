@@ -12,15 +12,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 def run(i, B, reps=5):
     import torch
     import continuousnf.jl_amd as cnf
-    from oracle import cnf_oracle as O
-    from tests.helpers import make_icnf
-    cfg, _, _ = O.baseline_cfg(i)
-    rng = np.random.default_rng(i)
-    flat = torch.from_numpy(O.glorot_params(cfg.net, rng, np.float32, 0.05)).cuda()
-    xs = torch.from_numpy(rng.standard_normal((cfg.nvars, B)).astype(np.float32)).cuda()
-    eps = torch.from_numpy(rng.standard_normal((cfg.n_in, B)).astype(np.float32)).cuda()
-    e32 = float(np.finfo(np.float32).eps)
-    icnf = make_icnf(cnf, cfg, sol_kwargs=dict(reltol=float(np.sqrt(e32)), abstol=e32))
+    from continuousnf.jl_amd import configs
+    wl = configs.BASELINE[i]
+    flat = torch.from_numpy(configs.glorot_params(wl.dims, i, 0.05)).cuda()
+    xs_h, eps_h = configs.synthetic_inputs(wl, B, i)
+    xs, eps = torch.from_numpy(xs_h).cuda(), torch.from_numpy(eps_h).cuda()
+    icnf = configs.build(wl, sol_kwargs=configs.README_TOLERANCES)
     out = {}
     for name, fn in (("loss", lambda: cnf.loss(icnf, cnf.TrainMode(), xs, flat, {}, eps=eps)),
                      ("loss_and_grad", lambda: cnf.loss_and_grad(icnf, cnf.TrainMode(), xs, flat, {}, eps=eps))):

@@ -12,26 +12,22 @@ import torch
 
 import continuousnf.jl_amd as cnf
 from continuousnf.jl_amd import _lib
-from oracle import cnf_oracle as O
-from tests.helpers import make_icnf
+from continuousnf.jl_amd import configs
 
 what = sys.argv[1] if len(sys.argv) > 1 else "step"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 kernel = sys.argv[3] if len(sys.argv) > 3 else "mfma"
 cfgi = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-cfg, B, _ = O.baseline_cfg(cfgi)
-B = int(os.environ.get("PROF_B", B))
-if cfgi == 5:
-    cfg.lam3 = 1e-2
-rng = np.random.default_rng(0)
-flat = O.glorot_params(cfg.net, rng, np.float32)
+cfg = configs.BASELINE[cfgi]
+B = int(os.environ.get("PROF_B", cfg.batch))
+flat = configs.glorot_params(cfg.dims, 0)
 ZERO = os.environ.get("PROF_ZERO") == "1"
 if ZERO:
     flat = flat * 0
-icnf = make_icnf(cnf, cfg, kernel=kernel)
+icnf = configs.build(cfg, kernel=kernel)
 icnf.set_params(flat)
 l, h = _lib.lib(), icnf.handle()
-D = cfg.D(True)
+D = cfg.n_in + 3
 dev = torch.device("cuda", 0)
 u = torch.randn(B * D, device=dev)
 eps = torch.randn(B * cfg.n_in, device=dev)

@@ -4,23 +4,21 @@ import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 import continuousnf.jl_amd as cnf
-from oracle import cnf_oracle as O
-from tests.helpers import make_icnf
-cfg, B, _ = O.baseline_cfg(3)
-B = int(sys.argv[1]) if len(sys.argv) > 1 else B
+from continuousnf.jl_amd import configs
+wl = configs.BASELINE[3]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else wl.batch
 rng = np.random.default_rng(1)
-flat = O.glorot_params(cfg.net, rng, np.float32, 0.05)
-u = torch.from_numpy(rng.standard_normal((cfg.n_in + 1, B)).astype(np.float32)).cuda()
-icnf = make_icnf(cnf, cfg)
+flat = configs.glorot_params(wl.dims, 1, 0.05)
+u = torch.from_numpy(rng.standard_normal((wl.n_in + 1, B)).astype(np.float32)).cuda()
+icnf = configs.build(wl)
 f = lambda: cnf.augmented_f(u, flat, 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)
 f(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(5): f()
 torch.cuda.synchronize()
 print(f"cfg3 TestMode RHS B={B}: {(time.perf_counter()-t0)/5*1e3:.3f} ms")
-xs = torch.from_numpy(rng.standard_normal((cfg.nvars, B)).astype(np.float32)).cuda()
-e32 = float(np.finfo(np.float32).eps)
-ic = make_icnf(cnf, cfg, sol_kwargs=dict(reltol=float(np.sqrt(e32)), abstol=e32))
+xs = torch.from_numpy(rng.standard_normal((wl.nvars, B)).astype(np.float32)).cuda()
+ic = configs.build(wl, sol_kwargs=configs.README_TOLERANCES)
 g = lambda: cnf.inference(ic, cnf.TestMode(), xs, flat, {})
 g(); torch.cuda.synchronize()
 t0 = time.perf_counter(); g(); torch.cuda.synchronize()
