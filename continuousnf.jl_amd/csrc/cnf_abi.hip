@@ -52,6 +52,7 @@ struct cnf_ctx {
     bool trace_on = false;        // this call evaluates TestMode with the MFMA exact-trace kernel
     std::vector<float*> traj_blocks;   // TRAJ_BLOCK state slots each, slot = (n_in + 3) * grad_cap_B floats
     size_t grad_cap_B = 0;
+    int grad_fsteps = 1;          // steps whose factor arrays are kept before one batch contraction
     float* grad_arena = nullptr;
     float* g_US[5] = {};          // stage states 2..6
     float* g_W[6] = {};           // zbar per stage
@@ -961,17 +962,24 @@ static cnf_status ensure_grad_capacity(cnf_handle h, int B) {
     h->grad_cap_B = 0;
     const size_t cap = ((size_t)B + 63) & ~(size_t)63;
     const size_t D = (size_t)h->nd.n_in + 3, n_in = h->nd.n_in;
-    const size_t total = 5 * D * cap + 7 * n_in * cap + 2 * (size_t)g.sum_in * cap + 2 * (size_t)g.sum_out * cap +
+    // the four factor arrays hold the 6 stages of `fsteps` steps: one batch contraction per fsteps steps
+    // (K = 6 fsteps B); as many steps as fit a 1 GiB budget, at most 32
+    const size_t per_step = 12 * ((size_t)g.sum_in + g.sum_out) * cap;       // floats
+    size_t fsteps = ((size_t)1 << 28) / per_step;
+    if (fsteps < 1) fsteps = 1;
+    if (fsteps > 32) fsteps = 32;
+    h->grad_fsteps = (int)fsteps;
+    const size_t total = 5 * D * cap + 7 * n_in * cap + fsteps * per_step +
                          ((size_t)GRAD_MAX_KSPLIT + 1) * h->n_params;
     HIPCHK(h, hipMalloc(&h->grad_arena, total * sizeof(float)));
     float* p = h->grad_arena;
     for (int i = 0; i < 5; ++i) { h->g_US[i] = p; p += D * cap; }
     for (int i = 0; i < 6; ++i) { h->g_W[i] = p; p += n_in * cap; }
     h->g_lam = p; p += n_in * cap;
-    h->g_HS = p; p += (size_t)g.sum_in * cap;
-    h->g_TS = p; p += (size_t)g.sum_in * cap;
-    h->g_AB = p; p += (size_t)g.sum_out * cap;
-    h->g_PB = p; p += (size_t)g.sum_out * cap;
+    h->g_HS = p; p += fsteps * 6 * (size_t)g.sum_in * cap;
+    h->g_TS = p; p += fsteps * 6 * (size_t)g.sum_in * cap;
+    h->g_AB = p; p += fsteps * 6 * (size_t)g.sum_out * cap;
+    h->g_PB = p; p += fsteps * 6 * (size_t)g.sum_out * cap;
     h->g_part = p; p += (size_t)GRAD_MAX_KSPLIT * h->n_params;
     h->g_grad = p;
     h->grad_cap_B = cap;
@@ -1019,9 +1027,10 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
     if ((s = cnf_loss_from_sums(h, mode, sums, loss_out)) != CNF_OK) return s;
 
     // ---- backward: discrete adjoint of the recorded steps ---------------------------------------
-    int ksplit, chunk;
-    grad_ksplit(nd, gl, B, &ksplit, &chunk);
-    HIPCHK(h, hipMemsetAsync(h->g_part, 0, (size_t)ksplit * h->n_params * sizeof(float), st));
+    // capacity is in samples of cap_B; with B <= cap_B at least grad_fsteps steps fit
+    const int fsteps = (int)std::min<size_t>(32, (size_t)h->grad_fsteps * h->grad_cap_B / (size_t)B);
+    int ksplit = 1, chunk = 0, filed = 0;
+    HIPCHK(h, hipMemsetAsync(h->g_part, 0, (size_t)GRAD_MAX_KSPLIT * h->n_params * sizeof(float), st));
     HIPCHK(h, launch_final_cotangent(nd, h->lam[2], fsol, h->g_lam, B, st));
     const float invB = 1.0f / (float)B;
     const float lam_l = invB, lam_E = h->lam[0] * invB, lam_n = h->lam[1] * invB;   // constant scalar rows
@@ -1059,12 +1068,22 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
             a.cb = Bw[i]; a.hstep = hs;
             a.c_l = hs * Bw[i] * lam_l; a.c_E = hs * Bw[i] * lam_E; a.c_n = hs * Bw[i] * lam_n;
             a.w_out = h->g_W[i];
-            a.HS = h->g_HS; a.TS = h->g_TS; a.AB = h->g_AB; a.PB = h->g_PB;
+            // every stage evaluation files its factors behind the earlier ones: rows [slot B, (slot + 1) B)
+            const size_t slot = (size_t)filed * 6 + i;
+            a.HS = h->g_HS + slot * B * gl.sum_in; a.TS = h->g_TS + slot * B * gl.sum_in;
+            a.AB = h->g_AB + slot * B * gl.sum_out; a.PB = h->g_PB + slot * B * gl.sum_out;
             a.B = B;
             if (adj_mfma) HIPCHK(h, launch_adj_mfma(nd, gl, am, h->d_adj_img, a, st));
             else HIPCHK(h, launch_adj(nd, gl, a, st));
-            HIPCHK(h, launch_wgrad(nd, gl, h->g_AB, h->g_PB, h->g_HS, h->g_TS, h->g_part, (int)h->n_params, B,
-                                   ksplit, chunk, st));
+        }
+        // Wbar += sum over the filed stage evaluations and their samples: one contraction with K = 6 filed B
+        if (++filed == fsteps || step == 0) {
+            int ks, ch;
+            grad_ksplit(nd, gl, 6 * filed * B, &ks, &ch);
+            if (ks > ksplit) ksplit = ks;
+            HIPCHK(h, launch_wgrad(nd, gl, h->g_AB, h->g_PB, h->g_HS, h->g_TS, h->g_part, (int)h->n_params,
+                                   6 * filed * B, ks, ch, st));
+            filed = 0;
         }
         StageK ws{};
         ws.nk = 6;
