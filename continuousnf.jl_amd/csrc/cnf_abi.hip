@@ -443,7 +443,8 @@ extern "C" cnf_status cnf_rhs_host(cnf_handle h, int mode, int kernel, const flo
 // Tsit5 driver (a7: base_sol, src/base_icnf.jl:137-143)
 // ---------------------------------------------------------------------------------------
 static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, int B,
-                                    int nblk, hipStream_t s, bool with_controller = true) {
+                                    int nblk, hipStream_t s, bool with_controller = true,
+                                    float* dump = nullptr, size_t dump_stride = 0) {
     RhsArgs a{};
     a.st = h->d_state; a.B = B; a.S = h->cap_B; a.train = train; a.ws = h->ws; a.eps = eps;
     a.cond = h->mfma.cond; a.cbs = h->cbs;
@@ -459,7 +460,7 @@ static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, i
     for (int stage = 1; stage <= 6 && !h->trace_on; ++stage) {      // computes k_{stage+1}
         a.nk = stage;
         tsit5_row(stage, a.coef);
-        a.ustage = nullptr;
+        a.ustage = (dump && stage < 6) ? dump + (size_t)(stage - 1) * dump_stride : nullptr;   // stage states 2..6
         a.ustage_is_unew = stage == 6;
         a.du_is_k7 = stage == 6;
         a.du = stage < 6 ? h->Ks[stage - 1] : nullptr;
@@ -502,7 +503,7 @@ struct Recorder {
     int n = 0;                    // accepted steps recorded; slot n holds u_n
 };
 static cnf_status traj_slot(cnf_handle h, int n, float** out) {
-    const size_t slot = ((size_t)h->nd.n_in + 3) * h->grad_cap_B;
+    const size_t slot = 6 * ((size_t)h->nd.n_in + 3) * h->grad_cap_B;   // u_n, then the stage states 2..6 of step n
     while ((size_t)n >= h->traj_blocks.size() * TRAJ_BLOCK) {
         float* b = nullptr;
         HIPCHK(h, hipMalloc(&b, slot * TRAJ_BLOCK * sizeof(float)));
@@ -663,13 +664,19 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         }
         for (long it = 0;; ++it) {
             if (it >= (long)opts->maxiters) return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
+            float* dump = nullptr;
+            if (rec) {                                   // stage states of the attempt from u_{seen_accept}
+                float* slot;
+                if ((s = traj_slot(h, seen_accept, &slot)) != CNF_OK) return s;
+                dump = slot + n;
+            }
             if (use_mfma) {
                 s = mfma_step(h->mfma, h->nd, train, h->d_state, h->d_state + 1, h->U, h->K1, h->Ks, eps,
-                              h->partials, h->partials, false, false, B, st);
+                              h->partials, h->partials, false, false, B, st, dump, n);
                 if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
                 launches += 1;
             } else {
-                enqueue_attempt_generic(h, train, eps, B, nblk, st, false);
+                enqueue_attempt_generic(h, train, eps, B, nblk, st, false, dump, n);
                 launches += 7;
             }
             if (lockstep) {
@@ -1042,22 +1049,13 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
         {TS_A51, TS_A52, TS_A53, TS_A54, 0},
         {TS_A61, TS_A62, TS_A63, TS_A64, TS_A65}};
     static const float Bw[6] = {TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76};
-    int k_rhs;
-    if ((s = resolve_kernel(h, mode, B, opts->kernel, &k_rhs)) != CNF_OK) return s;
     for (int step = rec.n - 1; step >= 0; --step) {
         float* un;
         if ((s = traj_slot(h, step, &un)) != CNF_OK) return s;
         const float hs = rec.hs[step];
-        // stage states U_1 = u_n, U_2..U_6, with k_1..k_5 in K1[0], Ks[0..3]
-        const float* US[6] = {un, h->g_US[0], h->g_US[1], h->g_US[2], h->g_US[3], h->g_US[4]};
-        float* KK[5] = {h->K1[0], h->Ks[0], h->Ks[1], h->Ks[2], h->Ks[3]};
-        for (int i = 0; i < 5; ++i) {
-            if ((s = cnf_rhs(h, mode, k_rhs, US[i], eps, KK[i], B, stream)) != CNF_OK) return s;
-            StageK sk{};
-            sk.nk = i + 1;
-            for (int j = 0; j <= i; ++j) { sk.k[j] = KK[j]; sk.coef[j] = A[i + 1][j]; }
-            HIPCHK(h, launch_stage_combine(un, sk, hs, const_cast<float*>(US[i + 1]), n, st));
-        }
+        // stage states: U_1 = u_n, U_2..U_6 were filed behind it by the forward pass
+        const float* US[6];
+        for (int i = 0; i < 6; ++i) US[i] = un + (size_t)i * n;
         for (int i = 5; i >= 0; --i) {
             AdjArgs a{};
             a.P = h->d_params; a.PT = h->d_PT; a.ustage = US[i]; a.eps = eps;

@@ -69,6 +69,8 @@ struct MfmaArgs {
     float* K1[2];
     float* Ks0;               // mode 1 output
     float* partials;          // mode 2: 2 floats per workgroup
+    float* dump;              // mode 2, gradient path: z rows of the stage states U_2..U_6 go to dump + (stage - 2) * dump_stride
+    size_t dump_stride;       //   ([B][D] arrays like the state), else null
 };
 
 // ---- layouts -------------------------------------------------------------------------------
@@ -914,15 +916,19 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         f32x4 un0 = uz0, un1 = uz1;
         // state of stage `stg` (z rows) -> region_0; the last stage's state is u_new (a7 = b)
         auto put_stage = [&](int stg) {
+            // evaluation stg (1..6) runs at the Runge-Kutta stage state U_{stg+1}; U_2..U_6 are filed, U_7 = u_new is not
+            float* dmp = (mode == 2 && a.dump && stg <= 5 && live) ? a.dump + (size_t)(stg - 1) * a.dump_stride + gcol : nullptr;
             if (own0) {
                 if (mode == 1) un0 = uz0 + hstep * kz0[0];
                 else if (mode == 2) un0 = uz0 + hstep * stage_acc4_rt(stg, kz0);
                 *(f32x4*)(lds + ly.x_off(0) + row * ly.SX(0) + r00) = un0;
+                if (dmp) st4(dmp + r00, un0, nv0);
             }
             if (own1) {
                 if (mode == 1) un1 = uz1 + hstep * kz1[0];
                 else if (mode == 2) un1 = uz1 + hstep * stage_acc4_rt(stg, kz1);
                 *(f32x4*)(lds + ly.x_off(0) + row * ly.SX(0) + r01) = un1;
+                if (dmp) st4(dmp + r01, un1, nv1);
             }
         };
         auto read_scalars = [&]() {
@@ -2161,7 +2167,7 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
         if (a.mode == 2) hipLaunchKernelGGL((k_mfma<RtLayout, true>), grid, block, shm, s, ly, a);
         else hipLaunchKernelGGL((k_mfma<RtLayout, false>), grid, block, shm, s, ly, a);
     }
-    else if (p.variant >= 2 && p.variant <= 4 && p.schedule > 0 && !a.cond) {
+    else if (p.variant >= 2 && p.variant <= 4 && p.schedule > 0 && !a.cond && !a.dump) {   // the experimental schedules do not dump stage states
         if (p.variant == 2) launch_fused<FsCfg3>(p, a, grid, s);
         else if (p.variant == 3) launch_fused<FsCfg2>(p, a, grid, s);
         else launch_fused<FsCfg1>(p, a, grid, s);
@@ -2201,7 +2207,7 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, con
 cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st_in,
                      StepState* st_out, float* const U[2], float* const K1[2], float* const Ks[5],
                      const float* eps, const float* partials_in, float* partials_out, bool apply_ctrl,
-                     bool finalize, int B, hipStream_t s) {
+                     bool finalize, int B, hipStream_t s, float* dump, size_t dump_stride) {
     if (!mfma_supported(p, nd, train, B)) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
     a.test = train ? 0 : 1;
@@ -2210,6 +2216,7 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
     a.n_total = (float)((size_t)(nd.n_in + (train ? 3 : 1)) * B);
     a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1]; a.Ks0 = Ks[0];
     a.partials = partials_out;
+    a.dump = dump; a.dump_stride = dump_stride;
     cnf_status r = launch(p, a, s);
     if (r != CNF_OK) return r;
     if (finalize) {
