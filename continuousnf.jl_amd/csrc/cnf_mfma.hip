@@ -69,6 +69,9 @@ struct MfmaArgs {
     float* K1[2];
     float* Ks0;               // mode 1 output
     float* partials;          // mode 2: 2 floats per workgroup
+    unsigned* gbar;           // persistent solve: grid-barrier counter (zeroed before the launch)
+    float* partials_b;        // persistent solve: second error-partials buffer (attempts alternate)
+    int max_attempts;         // persistent solve: attempts this launch may make
     float* dump;              // mode 2, gradient path: z rows of the stage states U_2..U_6 go to dump + (stage - 2) * dump_stride
     size_t dump_stride;       //   ([B][D] arrays like the state), else null
 };
@@ -778,7 +781,15 @@ __device__ __forceinline__ void err_acc(float& errsum, float& badcnt, const f32x
 // partials one barrier later, off the critical path.
 // STEP = true: one Tsit5 step attempt (mode 2); STEP = false: one RHS evaluation (modes 0, 1).
 // Two instantiations so that profiles name the step kernel and the plain RHS kernel apart.
-template <class LY, bool STEP>
+// PERSIST = true (STEP only): ONE launch makes all attempts of an adaptive solve.  Every workgroup
+// keeps its tile, the weight image stays in LDS, and between attempts the workgroups meet at a grid
+// barrier (all are co-resident: the host launches cooperatively, one workgroup per CU), sum the error
+// partials in the same order and take the same controller decision -- the per-launch controller of the
+// queued-launch path, without relaunching, refilling LDS or speculative launches past the end.
+// Cross-workgroup traffic (error partials + arrival tags) uses agent-scope atomic loads/stores only:
+// release/acquire fences at agent scope write back / invalidate the XCD's whole L2 once per wave
+// (measured: 136 us per attempt instead of 57), a shared arrival counter serialises 256 atomics.
+template <class LY, bool STEP, bool PERSIST = false>
 __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StepState* st = a.st;
@@ -823,6 +834,68 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
 
     int cur = 0;
     float hstep = 0.f, abstol = 0.f, reltol = 0.f;
+    unsigned gen = 0, ground = 0;
+    // Runge-Kutta state of this lane's z rows (accumulator layout); declared out here so that a
+    // persistent solve carries it from one attempt to the next in registers
+    f32x4 uz0 = {0.f, 0.f, 0.f, 0.f}, uz1 = uz0, kz0[7], kz1[7], un0 = uz0, un1 = uz0, uns_keep = uz0;
+    int prev_cur = 0;
+    // persistent solve: the evolving part of the integrator state lives in 10 of the 12 spare LDS words
+    // behind the team counters (t, dt, qold, h, eest, cur, done, naccept, nreject, nonfinite); the rest
+    // of *st is constant during the launch
+    float* pst = lds + ly.bar_off() + 4;
+    auto pst_load = [&](StepState& z) {
+        z = *st;
+        z.t = pst[0]; z.dt = pst[1]; z.qold = pst[2]; z.h = pst[3]; z.eest = pst[4];
+        z.cur = __float_as_int(pst[5]); z.done = __float_as_int(pst[6]); z.naccept = __float_as_int(pst[7]);
+        z.nreject = __float_as_int(pst[8]); z.nonfinite = __float_as_int(pst[9]);
+    };
+    auto pst_store = [&](const StepState& z) {
+        pst[0] = z.t; pst[1] = z.dt; pst[2] = z.qold; pst[3] = z.h; pst[4] = z.eest;
+        pst[5] = __int_as_float(z.cur); pst[6] = __int_as_float(z.done); pst[7] = __int_as_float(z.naccept);
+        pst[8] = __int_as_float(z.nreject); pst[9] = __int_as_float(z.nonfinite);
+    };
+    if (PERSIST) {
+        __syncthreads();                          // zero fill done before the scratch is used
+        if (tid == 0) { StepState z = *st; pst_store(z); }
+    }
+  for (int attempt = 0;; ++attempt) {             // one pass unless PERSIST
+    if (PERSIST) {
+        if (attempt > 0) {
+            // Grid barrier and partial exchange in one: workgroup i published (error sum, bad count, tag =
+            // attempt) in slot i of the buffer of the previous attempt; thread i of every workgroup waits
+            // for slot i.  No read-modify-write on a shared counter (256 serialised atomics cost more than
+            // the relaunch they replace), no cache flushes: agent-scope loads/stores only.
+            const float* pin = ((attempt - 1) & 1) ? a.partials_b : a.partials;
+            float q0 = 0.f, q1 = 0.f;
+            if (tid < (int)gridDim.x) {
+                const float want = (float)attempt;
+                while (__hip_atomic_load(pin + 4 * tid + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want)
+                    __builtin_amdgcn_s_sleep(1);
+                q0 = __hip_atomic_load(pin + 4 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q1 = __hip_atomic_load(pin + 4 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (int off = 32; off > 0; off >>= 1) { q0 += __shfl_down(q0, off, 64); q1 += __shfl_down(q1, off, 64); }
+            float* red = lds + ly.red_off();
+            if (lane == 0) { red[wave] = q0; red[16 + wave] = q1; }
+            __syncthreads();
+            if (tid == 0) {
+                float p0 = 0.f, p1 = 0.f;
+                for (int w = 0; w < MF_KTHREADS / 64; ++w) { p0 += red[w]; p1 += red[16 + w]; }
+                StepState z;
+                pst_load(z);
+                ctrl_after_step(&z, p0, p1, a.n_total);
+                pst_store(z);
+            }
+        }
+        __syncthreads();
+        cur = __float_as_int(pst[5]); hstep = pst[3]; abstol = st->abstol; reltol = st->reltol;
+        const bool stop = __float_as_int(pst[6]) != 0 || attempt >= a.max_attempts;
+        if (stop) {
+            if (blockIdx.x == 0 && tid == 0) { StepState z; pst_load(z); *a.st_out = z; }
+            return;
+        }
+        __syncthreads();                          // scratch (RED) is free again
+    } else
     if (STEP && a.apply_ctrl) {
         // In-kernel step controller: every workgroup reduces the same partials in the same
         // order and takes the same accept/reject decision; block 0 publishes the new state
@@ -863,7 +936,6 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
     const float* K1in = mode == 0 ? nullptr : a.K1[cur];
     float errsum = 0.f, badcnt = 0.f;
     unsigned* bar = (unsigned*)(lds + ly.bar_off()) + team;
-    unsigned gen = 0;
 #ifdef MF_STAMPS
     unsigned long long stamps[48] = {0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
@@ -894,26 +966,33 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         }
         // state: z rows in the accumulator layout, scalar rows in the fg == 0, q == 0 lanes
         // (the scalar rows' u, k1..k7 live in LDS: only 16 lanes per team touch them, once per stage)
-        f32x4 uz0 = {0.f, 0.f, 0.f, 0.f}, uz1 = uz0, kz0[7], kz1[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) { kz0[i] = uz0; kz1[i] = uz0; }
         float* sc = lds + ly.sc_off() + row * 24;
         auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
         auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
-        if (sown) {
-            sc_set(0, live ? ld4(Uin + gcol + n_in, nsc) : uz0);
-            sc_set(1, (live && K1in) ? ld4(K1in + gcol + n_in, nsc) : uz0);
-        }
-        if (live) {
-            if (own0 && nv0 > 0) uz0 = ld4(Uin + gcol + r00, nv0);
-            if (own1 && nv1 > 0) uz1 = ld4(Uin + gcol + r01, nv1);
-            if (K1in) {
-                if (own0 && nv0 > 0) kz0[0] = ld4(K1in + gcol + r00, nv0);
-                if (own1 && nv1 > 0) kz1[0] = ld4(K1in + gcol + r01, nv1);
+        if (!PERSIST || attempt == 0) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            uz0 = zero; uz1 = zero;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { kz0[i] = zero; kz1[i] = zero; }
+            if (sown) {
+                sc_set(0, live ? ld4(Uin + gcol + n_in, nsc) : zero);
+                sc_set(1, (live && K1in) ? ld4(K1in + gcol + n_in, nsc) : zero);
             }
+            if (live) {
+                if (own0 && nv0 > 0) uz0 = ld4(Uin + gcol + r00, nv0);
+                if (own1 && nv1 > 0) uz1 = ld4(Uin + gcol + r01, nv1);
+                if (K1in) {
+                    if (own0 && nv0 > 0) kz0[0] = ld4(K1in + gcol + r00, nv0);
+                    if (own1 && nv1 > 0) kz1[0] = ld4(K1in + gcol + r01, nv1);
+                }
+            }
+        } else if (cur != prev_cur) {        // persistent solve, previous attempt accepted: u <- u_new, k1 <- k7 (FSAL)
+            uz0 = un0; uz1 = un1; kz0[0] = kz0[6]; kz1[0] = kz1[6];
+            if (sown) { sc_set(1, sc_get(7)); sc_set(0, uns_keep); }
         }
+        prev_cur = cur;
         const int nstage = mode == 2 ? 6 : 1;
-        f32x4 un0 = uz0, un1 = uz1;
+        un0 = uz0; un1 = uz1;
         // state of stage `stg` (z rows) -> region_0; the last stage's state is u_new (a7 = b)
         auto put_stage = [&](int stg) {
             // evaluation stg (1..6) runs at the Runge-Kutta stage state U_{stg+1}; U_2..U_6 are filed, U_7 = u_new is not
@@ -988,6 +1067,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                     for (int j = 0; j < 7; ++j) ks[j] = sc_get(1 + j);
                     const f32x4 us = sc_get(0);
                     const f32x4 uns = us + hstep * stage_acc4<6>(ks);
+                    uns_keep = uns;
                     st4(Un + n_in, uns, nsc); st4(K7 + n_in, ks[6], nsc);
                     err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, nsc);
                 }
@@ -1017,10 +1097,21 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         if (tid == 0) {
             float e = 0.f, b = 0.f;
             for (int w = 0; w < MF_KTHREADS / 64; ++w) { e += lds[ly.red_off() + w]; b += lds[ly.red_off() + 16 + w]; }
-            a.partials[2 * blockIdx.x] = e;
-            a.partials[2 * blockIdx.x + 1] = b;
+            float* pout = (PERSIST && (attempt & 1)) ? a.partials_b : a.partials;
+            if (PERSIST) {
+                __hip_atomic_store(pout + 4 * blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pout + 4 * blockIdx.x + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // values first, then the tag that releases them
+                __hip_atomic_store(pout + 4 * blockIdx.x + 2, (float)(attempt + 1), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                pout[2 * blockIdx.x] = e;
+                pout[2 * blockIdx.x + 1] = b;
+            }
         }
     }
+    if (!PERSIST) break;
+  }
 }
 
 // =================================================================================================
@@ -2088,6 +2179,8 @@ static hipError_t set_attr() {
     hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        MF_LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_mfma<LY, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_mfma<LY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                MF_LDS_BYTES);
 }
@@ -2182,6 +2275,59 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
         else hipLaunchKernelGGL((k_mfma<RtLayout, false>), grid, block, shm, s, ly, a);
     }
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+// ---- persistent adaptive solve: all attempts in one cooperative launch ---------------------------
+template <class LY>
+static hipError_t launch_persistent_ly(LY ly, const MfmaArgs& a, dim3 grid, size_t shm, hipStream_t s) {
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mfma<LY, true, true>, MF_KTHREADS, shm);
+    if (e != hipSuccess) return e;
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if ((long)per_cu * cus < (long)grid.x) return hipErrorCooperativeLaunchTooLarge;
+    MfmaArgs args = a;
+    void* params[2] = {(void*)&ly, (void*)&args};
+    return hipLaunchCooperativeKernel((const void*)k_mfma<LY, true, true>, grid, dim3(MF_KTHREADS), params,
+                                      (unsigned)shm, s);
+}
+
+template <class LY>
+static hipError_t launch_persistent_static(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStream_t s) {
+    LY ly;
+    ly.n_in_ = p.ly.n_in; ly.norm_z_ = p.ly.norm_z; ly.norm_j_ = p.ly.norm_j;
+    return launch_persistent_ly(ly, a, grid, (size_t)LY::total_floats() * sizeof(float), s);
+}
+
+// All attempts of a TrainMode solve from the state in *st (after the initial-dt phase) until t1 or
+// max_attempts; *st is updated in place.  CNF_ERR_UNSUPPORTED: not launchable cooperatively (more
+// tiles than co-resident workgroups) -- the caller falls back to queued launches.
+cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st, float* const U[2],
+                                 float* const K1[2], const float* eps, float* partials_a, float* partials_b,
+                                 unsigned* gbar, int max_attempts, int B, hipStream_t s) {
+    if (!train || !mfma_supported(p, nd, train, B)) return CNF_ERR_UNSUPPORTED;
+    const int ntile = (B + MF_NB - 1) / MF_NB;
+    if (ntile != mfma_grid_for(B)) return CNF_ERR_UNSUPPORTED;        // one tile per workgroup only
+    MfmaArgs a{};
+    a.mode = 2; a.B = B; a.img = p.d_img; a.eps = eps; a.st = st; a.st_out = st;
+    a.n_total = (float)((size_t)(nd.n_in + 3) * B);
+    a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1];
+    a.partials = partials_a; a.partials_b = partials_b; a.gbar = gbar; a.max_attempts = max_attempts;
+    a.cond = p.cond; a.cbs = p.cbs;
+    if (ntile > MF_KTHREADS || 4 * ntile > 2 * 1024) return CNF_ERR_UNSUPPORTED;      // one slot per thread, 4 floats each
+    if (hipMemsetAsync(partials_a, 0, 4 * ntile * sizeof(float), s) != hipSuccess ||
+        hipMemsetAsync(partials_b, 0, 4 * ntile * sizeof(float), s) != hipSuccess) return CNF_ERR_HIP;
+    (void)gbar;
+    const dim3 grid(ntile);
+    hipError_t e;
+    if (p.variant == 2) e = launch_persistent_static<LyCfg3>(p, a, grid, s);
+    else if (p.variant == 3) e = launch_persistent_static<LyCfg2>(p, a, grid, s);
+    else if (p.variant == 4) e = launch_persistent_static<LyCfg1>(p, a, grid, s);
+    else if (p.variant == 5) e = launch_persistent_static<LyCfg5>(p, a, grid, s);
+    else { RtLayout ly{p.ly}; e = launch_persistent_ly(ly, a, grid, (size_t)p.ly.total_floats * sizeof(float), s); }
+    if (e == hipErrorCooperativeLaunchTooLarge) return CNF_ERR_UNSUPPORTED;
+    return e == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 
 cnf_status mfma_rhs(const MfmaPlan& p, const NetDesc& nd_, bool train, const float* u,

@@ -770,3 +770,26 @@ def test_exact_trace_mfma_deep_networks():
     assert ic.last_stats["kernel_used"] == _lib.KERNEL_MFMA
     _, ref_lp, _, _ = O.inference(cfg, flat.astype(np.float64), xs.astype(np.float64), None, False, reltol=1e-9, abstol=1e-9)
     assert_parity(logpx.cpu().numpy(), ref_lp, "config 3 TestMode logpx", rtol=2e-4)
+
+
+def test_persistent_solve_matches_queued_launches(monkeypatch):
+    """CNF_PERSISTENT=1: every attempt of an adaptive solve in one cooperative launch (grid barrier through
+    tagged partials, controller in the kernel, state in registers).  Same control law, same reduction
+    order: the step sequence and the result are bit-identical to the queued-launch path."""
+    for i, B in ((3, 500), (2, 700), (1, 333)):
+        cfg, _, _ = O.baseline_cfg(i)
+        rng = np.random.default_rng(600 + i)
+        flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+        xs, eps = _dev(rng.standard_normal((cfg.nvars, B))), _dev(rng.standard_normal((cfg.n_in, B)))
+        kw = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("CNF_PERSISTENT", mode)
+            ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=kw)
+            prob = cnf.inference_prob(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+            out[mode] = (cnf.base_sol(ic, prob).view().clone(), dict(prob.stats))
+        (a, sa), (b, sb) = out["0"], out["1"]
+        assert sb["launches"] < sa["launches"] and sb["kernel_used"] == _lib.KERNEL_MFMA
+        assert (sa["nf"], sa["naccept"], sa["nreject"], sa["dt_last"]) == (sb["nf"], sb["naccept"], sb["nreject"], sb["dt_last"])
+        assert torch.equal(a, b), i
+    monkeypatch.delenv("CNF_PERSISTENT")
