@@ -460,6 +460,33 @@ def generate(icnf: ICNF, mode, ps, st=None, n: int = 1, *, ys=None, z0=None, eps
 
 def inference(icnf: ICNF, mode, xs, *args, eps=None):
     """src/base_icnf.jl:407-415 / :417-426 (conditional: ``inference(icnf, mode, xs, ys, ps, st)``)."""
+    if _is_torch(xs):
+        # device tensors: the whole of inference_prob -> base_sol -> inference_sol in ONE C call (cnf_inference)
+        ys, ps, st = _split_cond_args(icnf, args)
+        m = _mode_id(mode)
+        xb = _as_colmajor(xs, icnf.nvars, "xs")
+        B = xb.B
+        icnf.set_params(ps)
+        icnf.set_cond(ys, B)
+        if eps is not None:
+            eb = _as_colmajor(eps, icnf.nvars + n_augment_input(icnf), "eps")
+            if eb.B != B:
+                raise ValueError("eps must have one column per sample")
+        elif m == _lib.MODE_TRAIN:
+            eb = draw_eps(icnf, xb, B)
+        else:
+            eb = None                           # TestMode: exact trace, no probes
+        t = xb.torch
+        logpx = t.empty(B, dtype=t.float32, device=xb.arr.device)
+        regs = t.empty(3 * B, dtype=t.float32, device=xb.arr.device)
+        opts = _solve_opts(icnf, steer_tspan(icnf, mode))
+        stats = _lib.cnf_solve_stats()
+        l, h = _lib.lib(), icnf.handle()
+        _lib.check(l.cnf_inference(h, m, xb.ptr, eb.ptr if eb is not None else None, logpx.data_ptr(), regs.data_ptr(), None, B,
+                                   C.byref(opts), C.byref(stats), _stream(xb)), h)
+        icnf.last_stats = stats.as_dict()
+        r = regs.view(3, B)
+        return logpx, (r[0], r[1], r[2])
     prob = inference_prob(icnf, mode, xs, *args, eps=eps)
     res = inference_sol(icnf, mode, prob)
     icnf.last_stats = prob.stats

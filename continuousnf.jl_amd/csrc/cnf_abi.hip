@@ -894,24 +894,14 @@ extern "C" cnf_status cnf_inference(cnf_handle h, int mode, const float* xs, con
     if (stats) memset(stats, 0, sizeof *stats);
     if (B == 0) return CNF_OK;
     HIPCHK(h, hipSetDevice(h->device));
-    const size_t D = rows_of(h, mode);
-    float* buf = u_final;
-    float* owned = nullptr;
-    if (!buf) {
-        HIPCHK(h, hipMalloc(&owned, 2 * D * B * sizeof(float)));
-        buf = owned;
-    }
-    float* u0 = nullptr;
-    float* u0_owned = nullptr;
-    if (owned) u0 = owned + D * B;
-    else { HIPCHK(h, hipMalloc(&u0_owned, D * B * sizeof(float))); u0 = u0_owned; }
+    if ((s = ensure_capacity(h, B)) != CNF_OK) return s;
+    // no allocations on this path: u0 is assembled in a stage buffer the solve only uses once it has
+    // copied u0 away, and (without u_final) the final state lands in the same buffer afterwards
+    float* u0 = h->Ks[4];
+    float* buf = u_final ? u_final : h->Ks[4];
     s = cnf_build_u0(h, mode, xs, u0, B, stream);
     if (s == CNF_OK) s = cnf_solve_tsit5(h, mode, u0, eps, buf, B, opts, stats, stream);
-    if (s == CNF_OK) s = cnf_inference_post(h, mode, buf, logpx, regs, B, stream);
-    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
-    if (owned) (void)hipFree(owned);
-    if (u0_owned) (void)hipFree(u0_owned);
-    if (s == CNF_OK && e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
+    if (s == CNF_OK) s = cnf_inference_post(h, mode, buf, logpx, regs, B, stream);     // stream-ordered
     return s;
 }
 

@@ -168,7 +168,9 @@ cnf_status cnf_build_u0(cnf_handle h, int mode, const float* xs, float* u0, int 
 cnf_status cnf_inference_post(cnf_handle h, int mode, const float* u_final, float* logpx,
                               float* regs, int B, void* stream);
 
-/* inference (src/base_icnf.jl:407-415) = build_u0 + solve + post, all on device. */
+/* inference (src/base_icnf.jl:407-415) = build_u0 + solve + post, all on device, no allocations.
+ * logpx / regs (and u_final) are written stream-ordered: valid for later work on `stream`, or after
+ * a stream synchronisation for the host. */
 cnf_status cnf_inference(cnf_handle h, int mode, const float* xs, const float* eps,
                          float* logpx, float* regs, float* u_final /* may be NULL */,
                          int B, const cnf_solve_opts* opts, cnf_solve_stats* stats,
