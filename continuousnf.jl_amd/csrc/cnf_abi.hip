@@ -50,7 +50,9 @@ struct cnf_ctx {
     float* d_adj_img = nullptr;   // padded forward/reverse weight images of the MFMA pullback kernel
     bool pt_valid = false;
     bool img_valid = false;       // d_adj_img holds the images of the current parameters
-    bool trace_on = false;        // this call evaluates TestMode with the MFMA exact-trace kernel
+    bool trace_on = false;        // this call evaluates through an auxiliary MFMA kernel (cnf_trace.hip) behind the generic driver
+    bool aux_train = false;       //   false: TestMode exact trace; true: TrainMode JVP
+    const float* aux_eps = nullptr;
     std::vector<float*> traj_blocks;   // TRAJ_BLOCK state slots each, slot = (n_in + 3) * grad_cap_B floats
     size_t grad_cap_B = 0;
     int grad_fsteps = 1;          // steps whose factor arrays are kept before one batch contraction
@@ -308,10 +310,12 @@ extern "C" cnf_status cnf_set_cond_host(cnf_handle h, const float* ys, int B) {
 }
 
 static bool trace_ok(cnf_handle h);
+static bool jvp_aux_ok(cnf_handle h);
 extern "C" int cnf_kernel_for(cnf_handle h, int mode, int B) {
     if (!h) return -1;
     if (mfma_supported(h->mfma, h->nd, mode == CNF_MODE_TRAIN, B)) return CNF_KERNEL_MFMA;
-    return (mode == CNF_MODE_TEST && trace_ok(h)) ? CNF_KERNEL_MFMA : CNF_KERNEL_GENERIC;
+    if (mode == CNF_MODE_TRAIN) return jvp_aux_ok(h) ? CNF_KERNEL_MFMA : CNF_KERNEL_GENERIC;
+    return trace_ok(h) ? CNF_KERNEL_MFMA : CNF_KERNEL_GENERIC;
 }
 
 // padded forward/reverse weight images shared by the pullback and the exact-trace kernels
@@ -330,8 +334,13 @@ static bool trace_ok(cnf_handle h) {
     const GradLayout g = grad_layout(h->nd);
     return trace_mfma_supported(h->nd, adj_mfma_layout(h->nd, g));
 }
+// TrainMode with the JVP compute mode on a network the fused step kernel cannot hold
+static bool jvp_aux_ok(cnf_handle h) {
+    const GradLayout g = grad_layout(h->nd);
+    return jvp_mfma_supported(h->nd, adj_mfma_layout(h->nd, g));
+}
 
-// one TestMode evaluation with the exact-trace kernel: u -> du (or k7 when du_is_k7)
+// one evaluation with an auxiliary MFMA kernel (TestMode: exact trace; TrainMode: JVP): u -> du (or k7)
 static cnf_status launch_trace(cnf_handle h, const float* u, float* du, bool in_solve, bool du_is_k7, int B, hipStream_t st) {
     const GradLayout g = grad_layout(h->nd);
     const AdjMfmaLayout m = adj_mfma_layout(h->nd, g);
@@ -341,13 +350,14 @@ static cnf_status launch_trace(cnf_handle h, const float* u, float* du, bool in_
     a.K1[0] = h->K1[0]; a.K1[1] = h->K1[1];
     a.du_is_k7 = du_is_k7 ? 1 : 0;
     a.B = B;
-    HIPCHK(h, launch_trace_mfma(h->nd, g, m, h->d_adj_img, a, st));
+    if (h->aux_train) HIPCHK(h, launch_jvp_mfma(h->nd, g, m, h->d_adj_img, a, h->aux_eps, st));
+    else HIPCHK(h, launch_trace_mfma(h->nd, g, m, h->d_adj_img, a, st));
     return CNF_OK;
 }
 
 static cnf_status resolve_kernel(cnf_handle h, int mode, int B, int requested, int* out) {
     const bool ok = mfma_supported(h->mfma, h->nd, mode == CNF_MODE_TRAIN, B) ||
-                    (mode == CNF_MODE_TEST && trace_ok(h));
+                    (mode == CNF_MODE_TEST && trace_ok(h)) || (mode == CNF_MODE_TRAIN && jvp_aux_ok(h));
     if (requested == CNF_KERNEL_AUTO) { *out = ok ? CNF_KERNEL_MFMA : CNF_KERNEL_GENERIC; return CNF_OK; }
     if (requested == CNF_KERNEL_GENERIC) { *out = CNF_KERNEL_GENERIC; return CNF_OK; }
     if (requested == CNF_KERNEL_MFMA) {
@@ -396,8 +406,9 @@ extern "C" cnf_status cnf_rhs(cnf_handle h, int mode, int kernel, const float* u
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     if (k == CNF_KERNEL_MFMA && !mfma_supported(h->mfma, h->nd, mode == CNF_MODE_TRAIN, B)) {
-        // TestMode, three or more layers: exact trace on MFMA (cnf_trace.hip)
+        // TestMode, three or more layers: exact trace on MFMA; TrainMode/JVP beyond LDS (cnf_trace.hip)
         if ((s = ensure_adj_images(h, st)) != CNF_OK) return s;
+        h->aux_train = mode == CNF_MODE_TRAIN; h->aux_eps = eps;
         if ((s = launch_trace(h, u, du, false, false, B, st)) != CNF_OK) return s;
     } else if (k == CNF_KERNEL_MFMA) {
         s = mfma_rhs(h->mfma, h->nd, mode == CNF_MODE_TRAIN, u, eps, du, B, st);
@@ -550,7 +561,8 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     int launches = 0;
 
     const bool use_mfma = k == CNF_KERNEL_MFMA && mfma_supported(h->mfma, h->nd, train, B);
-    h->trace_on = k == CNF_KERNEL_MFMA && !use_mfma;       // TestMode, >= 3 layers: generic driver + trace kernel
+    h->trace_on = k == CNF_KERNEL_MFMA && !use_mfma;       // generic driver + an auxiliary MFMA kernel per stage
+    h->aux_train = train != 0; h->aux_eps = eps;
     if (h->trace_on && (s = ensure_adj_images(h, (hipStream_t)stream)) != CNF_OK) return s;
     // lock-step over shards only matters when the controller decides something
     const bool lockstep = h->shard_reduce != nullptr && opts->adaptive;

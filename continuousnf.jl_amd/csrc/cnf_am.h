@@ -170,7 +170,7 @@ __device__ __forceinline__ void am_store4(float* g, f32x4 v, int r0, int n_valid
 template <int NCT, class Epi>
 __device__ __forceinline__ void am_gemm_multi(const float* __restrict__ img, int rows_p, int k_p, const float* X, int PX,
                                               AFrag& pf, const float* __restrict__ nimg, int nrows_p, int nk_p,
-                                              Epi&& epi) {
+                                              Epi&& epi, const float* __restrict__ pre = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
     const float* xrow = X + s * PX + 4 * q;
@@ -185,6 +185,7 @@ __device__ __forceinline__ void am_gemm_multi(const float* __restrict__ img, int
         f32x4 acc[NCT];
 #pragma unroll
         for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (pre) acc[0] = *reinterpret_cast<const f32x4*>(pre + 16 * t + 4 * q);     // column tile 0 starts from the bias
         for (int u0 = 0; u0 < nu; u0 += AM_CH) {
             const AFrag cur = pf;
             const float* np;

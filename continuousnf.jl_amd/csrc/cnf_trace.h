@@ -26,6 +26,9 @@ bool trace_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
 TraceLayout trace_layout(const NetDesc& nd, const AdjMfmaLayout& m);
 hipError_t launch_trace_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                              const TraceArgs& a, hipStream_t s);
+bool jvp_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
+hipError_t launch_jvp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                           const TraceArgs& a, const float* eps, hipStream_t s);
 // u_stage = U[cur] + h * sum_j coef[j] k_j (k_1 = K1[cur], k_{j>1} = Ks[j-2]), h and cur from the device state
 hipError_t launch_stage_state(const StepState* st, float* const U[2], float* const K1[2], float* const Ks[5], int nk,
                               const float* coef, float* out, int also_unew, size_t n, hipStream_t s);

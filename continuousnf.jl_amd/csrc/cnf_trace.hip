@@ -179,6 +179,123 @@ k_trace_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const f
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// TrainMode, JVP compute mode (src/icnf.jl:384-420) for networks whose weights + tangent images do not
+// fit the fused step kernel's LDS plan: (zdot, J eps) by one forward sweep in which the activations and
+// the tangents of the 16 samples are two column tiles sharing every weight fragment;
+//   ldot = -eps' (J eps),  Edot = |zdot|,  ndot = |J eps|.
+// ---------------------------------------------------------------------------------------------------
+struct JvpLayout { int PX, off_E, off_red, total_floats; };
+
+static JvpLayout jvp_layout(const NetDesc&, const AdjMfmaLayout& m) {
+    JvpLayout j{};
+    j.PX = pad8m16(m.maxd);
+    j.off_E = 2 * 32 * j.PX;                       // two ping-pong buffers of 32 columns (16 h + 16 t)
+    j.off_red = j.off_E + AM_NS * (m.nin_p + 8);
+    j.total_floats = j.off_red + 3 * AM_EC * AM_NS;
+    return j;
+}
+
+bool jvp_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m) {
+    if (!nd.jvp || nd.dims[nd.n_layers] != nd.n_in) return false;
+    return (size_t)jvp_layout(nd, m).total_floats * 4 <= 160 * 1024;
+}
+
+template <bool ALL_TANH>
+__global__ void __launch_bounds__(AM_THREADS)
+k_jvp_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, JvpLayout jl, const float* __restrict__ img, TraceArgs a,
+           const float* __restrict__ eps) {
+    if (a.st && a.st->done) return;
+    extern __shared__ float lds[];
+    const int NL = m.L, PX = jl.PX, PE = m.nin_p + 8;
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * AM_NS;
+    const int n_in = nd.n_in, D = n_in + 3, in0 = gl.in0;
+    const int es = (tid >> 4) & 15, ec = (tid & 15) | ((tid >> 8) << 4);
+    const int eb = b0 + es;
+    const bool ev = eb < a.B;
+    float* du = a.du;
+    if (a.st && a.du_is_k7) du = a.K1[1 - a.st->cur];
+    float* red = lds + jl.off_red;
+
+    AFrag pf;
+    am_first(pf, img + m.f_off[0], m.dp[1], m.dp[0]);
+    int cur = 0, nxt = 32 * PX;
+    for (int r = ec; r < m.dp[0]; r += AM_EC) {
+        float v = 0.f, e = 0.f;
+        if (ev && r < in0) v = r < n_in ? a.u[(size_t)eb * D + r] : a.ys[(size_t)eb * nd.n_cond + (r - n_in)];
+        if (ev && r < n_in) e = eps[(size_t)eb * n_in + r];
+        lds[cur + es * PX + r] = v;                       // h_0 = [z; ys]
+        lds[cur + (16 + es) * PX + r] = e;                // t_0 = [eps; 0]
+        if (r < m.nin_p) lds[jl.off_E + es * PE + r] = e;
+    }
+    am_barrier();
+    for (int l = 0; l < NL; ++l) {
+        const int out = nd.dims[l + 1], act = nd.acts[l];
+        const bool last = l + 1 == NL;
+        am_gemm_multi<2>(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PX, pf,
+                         last ? nullptr : img + m.f_off[l + 1], last ? 0 : m.dp[l + 2], last ? 0 : m.dp[l + 1],
+                         [&](int r0, int s, f32x4 (&acc)[2]) {
+            f32x4 h, t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float hh, dd1, dd2;
+                if (ALL_TANH) { hh = cnf_tanh(acc[0][j]); dd1 = fmaf(-hh, hh, 1.0f); }
+                else cnf_act2(act, acc[0][j], hh, dd1, dd2);
+                const bool live = r0 + j < out;
+                h[j] = live ? hh : 0.f; t[j] = live ? dd1 * acc[1][j] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(lds + nxt + s * PX + r0) = h;
+            *reinterpret_cast<f32x4*>(lds + nxt + (16 + s) * PX + r0) = t;
+            if (last && b0 + s < a.B) {
+                float* g = du + (size_t)(b0 + s) * D + r0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (r0 + j < out) g[j] = h[j];             // zdot rows
+            }
+        }, img + m.b_off[l]);
+        am_barrier();
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+    // scalar rows: zdot in columns 0..15, J eps in columns 16..31 of S[cur]
+    {
+        float e2 = 0.f, n2 = 0.f, dot = 0.f;
+        for (int r = ec; r < n_in; r += AM_EC) {
+            const float z = lds[cur + es * PX + r], je = lds[cur + (16 + es) * PX + r];
+            e2 = fmaf(z, z, e2); n2 = fmaf(je, je, n2); dot = fmaf(je, lds[jl.off_E + es * PE + r], dot);
+        }
+        red[(0 * AM_EC + ec) * AM_NS + es] = e2;
+        red[(1 * AM_EC + ec) * AM_NS + es] = n2;
+        red[(2 * AM_EC + ec) * AM_NS + es] = dot;
+    }
+    am_barrier();
+    if (tid < AM_NS && b0 + tid < a.B) {
+        float e2 = 0.f, n2 = 0.f, dot = 0.f;
+        for (int p = 0; p < AM_EC; ++p) {
+            e2 += red[(0 * AM_EC + p) * AM_NS + tid]; n2 += red[(1 * AM_EC + p) * AM_NS + tid];
+            dot += red[(2 * AM_EC + p) * AM_NS + tid];
+        }
+        float* g = du + (size_t)(b0 + tid) * D + n_in;
+        g[0] = -dot;                                            // src/icnf.jl:404
+        g[1] = nd.norm_z ? sqrtf(e2) : 0.f;                     // :405-411
+        g[2] = nd.norm_j ? sqrtf(n2) : 0.f;                     // :412-413
+    }
+}
+
+hipError_t launch_jvp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                           const TraceArgs& a, const float* eps, hipStream_t s) {
+    const JvpLayout jl = jvp_layout(nd, m);
+    const size_t lds = (size_t)jl.total_floats * sizeof(float);
+    bool all_tanh = true;
+    for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
+    const void* fn = all_tanh ? (const void*)k_jvp_mfma<true> : (const void*)k_jvp_mfma<false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const dim3 grid((a.B + AM_NS - 1) / AM_NS), block(AM_THREADS);
+    if (all_tanh) hipLaunchKernelGGL(k_jvp_mfma<true>, grid, block, lds, s, nd, g, m, jl, img, a, eps);
+    else hipLaunchKernelGGL(k_jvp_mfma<false>, grid, block, lds, s, nd, g, m, jl, img, a, eps);
+    return hipGetLastError();
+}
+
 // u_stage = U[cur] + h * sum_j coef[j] k_j
 __global__ void k_stage_state(const StepState* st, float* U0, float* U1, float* K10, float* K11, float* Ks0, float* Ks1,
                               float* Ks2, float* Ks3, float* Ks4, int nk, float c0, float c1, float c2, float c3, float c4,

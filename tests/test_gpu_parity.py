@@ -793,3 +793,31 @@ def test_persistent_solve_matches_queued_launches(monkeypatch):
         assert (sa["nf"], sa["naccept"], sa["nreject"], sa["dt_last"]) == (sb["nf"], sb["naccept"], sb["nreject"], sb["dt_last"])
         assert torch.equal(a, b), i
     monkeypatch.delenv("CNF_PERSISTENT")
+
+
+def test_jvp_mode_large_network_on_mfma():
+    """TrainMode with the JVP compute mode (src/icnf.jl:384-420) on config 5's 128-384-128 network, whose
+    tangent images do not fit beside the weights in the fused step kernel: the forward sweep with the
+    tangents as a second column tile (cnf_trace.hip: k_jvp_mfma) behind the generic Tsit5 driver."""
+    cfg, _, _ = O.baseline_cfg(5)
+    B = 150
+    rng = np.random.default_rng(700)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    u = rng.standard_normal((cfg.D(True), B)).astype(np.float32)
+    eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+    icnf = make_icnf(cnf, cfg, jvp=True, kernel="mfma")
+    assert _lib.lib().cnf_kernel_for(icnf.handle(), _lib.MODE_TRAIN, B) == _lib.KERNEL_MFMA
+    du = cnf.augmented_f(_dev(u), flat, 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, _dev(eps)).cpu().numpy()
+    ref = O.augmented_f_train(cfg.net, flat.astype(np.float64), u.astype(np.float64), eps.astype(np.float64),
+                              cfg.lam1 != 0, cfg.lam2 != 0, use_jvp=True)
+    assert_parity(du, ref, "cfg5 JVP RHS")
+    # and through a fixed-dt solve
+    ic = make_icnf(cnf, cfg, jvp=True, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
+    xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+    logpx, regs = cnf.inference(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+    assert ic.last_stats["kernel_used"] == _lib.KERNEL_MFMA
+    c64 = O.Cfg(cfg.net, cfg.nvars, cfg.naugs, cfg.lam1, cfg.lam2, cfg.lam3, use_jvp=True)
+    _, ref_lp, ref_regs, _ = O.inference(c64, flat.astype(np.float64), xs.astype(np.float64), eps.astype(np.float64),
+                                         True, dt=1 / 8, adaptive=False)
+    assert_parity(logpx.cpu().numpy(), ref_lp, "cfg5 JVP logpx")
+    assert_parity(regs[1].cpu().numpy(), ref_regs[1], "cfg5 JVP n-dot integral")
