@@ -687,7 +687,7 @@ AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g) {
     m.S0 = p; p += mx;
     m.S1 = p; p += mx;
     m.E = p; p += m.nin_p;
-    m.AH = p; p += m.nin_p;
+    m.AH = m.TB + m.o_off[m.L - 1];       // ahat reuses the tbar_L slot (free after the first reverse GEMM)
     m.PS = ((p + 15) & ~15) + 8;          // stride = 8 mod 16 floats: conflict-free b128 columns
     m.vec4 = (g.sum_in & 3) == 0;         // rows of HS/TS start 16-byte aligned ...
     for (int l = 0; l < m.L; ++l) if (g.in_off[l] & 3) m.vec4 = 0;   // ... and so does every layer's block
@@ -799,23 +799,7 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
         AM_STAMP(2 + l);
         const int t_ = cur; cur = nxt; nxt = t_;
     }
-    // zdot in S[cur].  ahat = kbar_z + c_E zdot/|zdot| -> AH
-    {
-        float nz = 0.f;
-        if (nd.norm_z) nz = am_colnorm2(lds + cur, PS, n_in, red);
-        const float inv = (nd.norm_z && nz > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz) : 0.f;
-        for (int r = ec; r < m.nin_p; r += AM_EC) {
-            float v = 0.f;
-            if (ev && r < n_in) {
-                float kb = a.cb * a.lam[(size_t)eb * n_in + r];
-                for (int w = 0; w < a.nw; ++w) kb = fmaf(a.wc[w], a.w[w][(size_t)eb * n_in + r], kb);
-                v = fmaf(inv, lds[es * PS + cur + r], kb * a.hstep);
-            }
-            lds[es * PS + m.AH + r] = v;
-        }
-    }
-    am_barrier();
-    AM_STAMP(5);
+    const int zd = cur;                                     // zdot stays in S[zd] until AH is formed (inside sweep 2)
 
     // ---- sweep 2: tbar chain (omega = eps).  Layer l's GEMM turns pbar_l into tbar_{l-1}; its epilogue
     //      keeps tbar_{l-1} (sweep 4 needs it) and forms pbar_{l-1} = tbar_{l-1} .* sigma'_{l-1} -----------
@@ -839,6 +823,23 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
         am_barrier();
         AM_STAMP(7 + (NL - 1 - l));
         const int t_ = cur; cur = nxt; nxt = t_;
+        if (l == NL - 1) {
+            // zdot still sits in S[zd]: ahat = kbar_z + c_E zdot/|zdot| -> AH.  AH shares the tbar_L slot of TB,
+            // free now that pbar_L (parked there by sweep 1) has been consumed by this GEMM.
+            float nz = 0.f;
+            if (nd.norm_z) nz = am_colnorm2(lds + zd, PS, n_in, red);
+            const float inv = (nd.norm_z && nz > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz) : 0.f;
+            for (int r = ec; r < m.nin_p; r += AM_EC) {
+                float v = 0.f;
+                if (ev && r < n_in) {
+                    float kb = a.cb * a.lam[(size_t)eb * n_in + r];
+                    for (int w = 0; w < a.nw; ++w) kb = fmaf(a.wc[w], a.w[w][(size_t)eb * n_in + r], kb);
+                    v = fmaf(inv, lds[es * PS + zd + r], kb * a.hstep);
+                }
+                lds[es * PS + m.AH + r] = v;
+            }
+            am_barrier();                                   // zdot's buffer is the next epilogue's target
+        }
     }
     // eJ in S[cur].  tau = -c_l eps + c_n eJ/|eJ|  -> S[nxt] as t_0 (rows of ys and padding: 0)
     {

@@ -1111,6 +1111,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         }
     }
     if (!PERSIST) break;
+    __syncthreads();        // thread 0 has read the RED scratch before the next attempt's controller reuses it
   }
 }
 

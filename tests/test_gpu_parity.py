@@ -821,3 +821,15 @@ def test_jvp_mode_large_network_on_mfma():
                                          True, dt=1 / 8, adaptive=False)
     assert_parity(logpx.cpu().numpy(), ref_lp, "cfg5 JVP logpx")
     assert_parity(regs[1].cpu().numpy(), ref_regs[1], "cfg5 JVP n-dot integral")
+
+
+def test_loss_grad_config5_network():
+    """The gradient on config 5's 128-384-128 network (weights streamed from L2 in the forward kernel, MFMA
+    pullback with ahat sharing the tbar_L slot to fit 160 KB of LDS)."""
+    cfg, _, _ = O.baseline_cfg(5)
+    cfg.tspan = (0.0, 0.5)
+    for kernel in KERNELS:
+        val, grad, rval, rgrad, _, _ = _grad_case(cfg, 40, 810, kernel, dict(adaptive=False, dt=1 / 4),
+                                                  dict(adaptive=False, dt=1 / 4), scale=0.1)
+        assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+        _assert_grad(grad, rgrad, f"config 5 {kernel}")
