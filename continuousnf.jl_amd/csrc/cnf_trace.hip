@@ -281,6 +281,146 @@ k_jvp_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, JvpLayout jl, const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// TrainMode, VJP compute mode (src/icnf.jl:318-350) as a stand-alone evaluation for networks whose weights
+// do not fit in LDS: there the fused step kernel streams the weights through 64 busy CUs at B = 2048,
+// while 16-sample workgroups give twice as many and share nothing but L2.  Forward sweep (sigma' kept),
+// then the reverse chain g_{l-1} = W_l' (g_l .* sigma'_l) from g_L = eps:  eJ = J' eps,
+//   ldot = -eJ' eps,  Edot = |zdot|,  ndot = |eJ|.
+// ---------------------------------------------------------------------------------------------------
+struct VjpLayout { int PD, PX, off_S, off_E, off_red, total_floats; };
+
+static VjpLayout vjp_layout(const NetDesc&, const AdjMfmaLayout& m) {
+    VjpLayout v{};
+    v.PD = pad8m16(m.sum_o);
+    v.PX = pad8m16(m.maxd);
+    v.off_S = AM_NS * v.PD;
+    v.off_E = v.off_S + 2 * AM_NS * v.PX;
+    v.off_red = v.off_E + AM_NS * (m.nin_p + 8);
+    v.total_floats = v.off_red + 3 * AM_EC * AM_NS;
+    return v;
+}
+
+bool vjp_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m) {
+    if (nd.jvp || nd.dims[nd.n_layers] != nd.n_in) return false;
+    return (size_t)vjp_layout(nd, m).total_floats * 4 <= 160 * 1024;
+}
+
+template <bool ALL_TANH>
+__global__ void __launch_bounds__(AM_THREADS)
+k_vjp_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, VjpLayout vl, const float* __restrict__ img, TraceArgs a,
+           const float* __restrict__ eps) {
+    if (a.st && a.st->done) return;
+    extern __shared__ float lds[];
+    const int NL = m.L, PD = vl.PD, PX = vl.PX, PE = m.nin_p + 8;
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * AM_NS;
+    const int n_in = nd.n_in, D = n_in + 3, in0 = gl.in0;
+    const int es = (tid >> 4) & 15, ec = (tid & 15) | ((tid >> 8) << 4);
+    const int eb = b0 + es;
+    const bool ev = eb < a.B;
+    float* du = a.du;
+    if (a.st && a.du_is_k7) du = a.K1[1 - a.st->cur];
+    float* red = lds + vl.off_red;
+
+    AFrag pf;
+    am_first(pf, img + m.f_off[0], m.dp[1], m.dp[0]);
+    int cur = vl.off_S, nxt = vl.off_S + AM_NS * PX;
+    for (int r = ec; r < m.dp[0]; r += AM_EC) {
+        float v = 0.f;
+        if (ev && r < in0) v = r < n_in ? a.u[(size_t)eb * D + r] : a.ys[(size_t)eb * nd.n_cond + (r - n_in)];
+        lds[cur + es * PX + r] = v;
+        if (r < m.nin_p) lds[vl.off_E + es * PE + r] = (ev && r < n_in) ? eps[(size_t)eb * n_in + r] : 0.f;
+    }
+    am_barrier();
+    // forward; the last layer's epilogue also forms g_L .* sigma'_L = eps .* sigma'_L, the first reverse operand
+    for (int l = 0; l < NL; ++l) {
+        const int out = nd.dims[l + 1], act = nd.acts[l], oo = m.o_off[l];
+        const bool last = l + 1 == NL;
+        am_gemm(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PX, pf,
+                img + (last ? m.r_off[NL - 1] : m.f_off[l + 1]), last ? m.dp[NL - 1] : m.dp[l + 2],
+                last ? m.dp[NL] : m.dp[l + 1], img + m.b_off[l], [&](int r0, int s, f32x4 acc, f32x4 bias) {
+            f32x4 h, d1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float hh, dd1, dd2;
+                if (ALL_TANH) { hh = cnf_tanh(acc[j] + bias[j]); dd1 = fmaf(-hh, hh, 1.0f); }
+                else cnf_act2(act, acc[j] + bias[j], hh, dd1, dd2);
+                const bool live = r0 + j < out;
+                h[j] = live ? hh : 0.f; d1[j] = live ? dd1 : 0.f;
+            }
+            if (!last) {
+                *reinterpret_cast<f32x4*>(lds + s * PD + oo + r0) = d1;
+                *reinterpret_cast<f32x4*>(lds + nxt + s * PX + r0) = h;
+            } else {
+                // zdot stays in the sigma'_L slot (its norm is needed below), eps .* sigma'_L is the operand
+                *reinterpret_cast<f32x4*>(lds + s * PD + oo + r0) = h;
+                *reinterpret_cast<f32x4*>(lds + nxt + s * PX + r0) =
+                    d1 * *reinterpret_cast<const f32x4*>(lds + vl.off_E + s * PE + r0);
+                if (b0 + s < a.B) {
+                    float* g = du + (size_t)(b0 + s) * D + r0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (r0 + j < out) g[j] = h[j];
+                }
+            }
+        });
+        am_barrier();
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+    // reverse chain
+    for (int l = NL - 1; l >= 0; --l) {
+        const int oprev = l > 0 ? m.o_off[l - 1] : 0;
+        am_gemm(img + m.r_off[l], m.dp[l], m.dp[l + 1], lds + cur, PX, pf,
+                l > 0 ? img + m.r_off[l - 1] : nullptr, l > 0 ? m.dp[l - 1] : 0, l > 0 ? m.dp[l] : 0, nullptr,
+                [&](int r0, int s, f32x4 acc, f32x4) {
+            f32x4 v = acc;
+            if (l > 0) v = acc * *reinterpret_cast<const f32x4*>(lds + s * PD + oprev + r0);
+            *reinterpret_cast<f32x4*>(lds + nxt + s * PX + r0) = v;
+        });
+        am_barrier();
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+    // eJ in S[cur] (rows < n_in), zdot in the sigma'_L slot
+    {
+        const int oL = m.o_off[NL - 1];
+        float e2 = 0.f, n2 = 0.f, dot = 0.f;
+        for (int r = ec; r < n_in; r += AM_EC) {
+            const float z = lds[es * PD + oL + r], ej = lds[cur + es * PX + r];
+            e2 = fmaf(z, z, e2); n2 = fmaf(ej, ej, n2); dot = fmaf(ej, lds[vl.off_E + es * PE + r], dot);
+        }
+        red[(0 * AM_EC + ec) * AM_NS + es] = e2;
+        red[(1 * AM_EC + ec) * AM_NS + es] = n2;
+        red[(2 * AM_EC + ec) * AM_NS + es] = dot;
+    }
+    am_barrier();
+    if (tid < AM_NS && b0 + tid < a.B) {
+        float e2 = 0.f, n2 = 0.f, dot = 0.f;
+        for (int p = 0; p < AM_EC; ++p) {
+            e2 += red[(0 * AM_EC + p) * AM_NS + tid]; n2 += red[(1 * AM_EC + p) * AM_NS + tid];
+            dot += red[(2 * AM_EC + p) * AM_NS + tid];
+        }
+        float* g = du + (size_t)(b0 + tid) * D + n_in;
+        g[0] = -dot;                                            // src/icnf.jl:334
+        g[1] = nd.norm_z ? sqrtf(e2) : 0.f;                     // :335-341
+        g[2] = nd.norm_j ? sqrtf(n2) : 0.f;                     // :342-348
+    }
+}
+
+hipError_t launch_vjp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                           const TraceArgs& a, const float* eps, hipStream_t s) {
+    const VjpLayout vl = vjp_layout(nd, m);
+    const size_t lds = (size_t)vl.total_floats * sizeof(float);
+    bool all_tanh = true;
+    for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
+    const void* fn = all_tanh ? (const void*)k_vjp_mfma<true> : (const void*)k_vjp_mfma<false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const dim3 grid((a.B + AM_NS - 1) / AM_NS), block(AM_THREADS);
+    if (all_tanh) hipLaunchKernelGGL(k_vjp_mfma<true>, grid, block, lds, s, nd, g, m, vl, img, a, eps);
+    else hipLaunchKernelGGL(k_vjp_mfma<false>, grid, block, lds, s, nd, g, m, vl, img, a, eps);
+    return hipGetLastError();
+}
+
 hipError_t launch_jvp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                            const TraceArgs& a, const float* eps, hipStream_t s) {
     const JvpLayout jl = jvp_layout(nd, m);

@@ -833,3 +833,29 @@ def test_loss_grad_config5_network():
                                                   dict(adaptive=False, dt=1 / 4), scale=0.1)
         assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
         _assert_grad(grad, rgrad, f"config 5 {kernel}")
+
+
+def test_auto_uses_standalone_vjp_kernel_for_streamed_weights():
+    """kernel = auto on config 5's network (weights streamed from L2) at a batch below one wave of 16-sample
+    workgroups: TrainMode/VJP runs the stand-alone k_vjp_mfma (cnf_trace.hip) behind the generic driver;
+    an explicit kernel = mfma keeps the fused step kernel.  Both against the oracle."""
+    cfg, _, _ = O.baseline_cfg(5)
+    B = 120
+    rng = np.random.default_rng(900)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    u = rng.standard_normal((cfg.D(True), B)).astype(np.float32)
+    xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+    eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+    ref = cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True)(u.astype(np.float64))
+    _, ref_lp, _, _ = O.inference(cfg, flat.astype(np.float64), xs.astype(np.float64), eps.astype(np.float64), True,
+                                  dt=1 / 8, adaptive=False)
+    launches = {}
+    for kernel in ("auto", "mfma"):
+        ic = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=dict(adaptive=False, dt=1 / 8))
+        du = cnf.augmented_f(_dev(u), flat, 0.0, ic, cnf.TrainMode(), ic.nn, {}, _dev(eps)).cpu().numpy()
+        assert_parity(du, ref, f"cfg5 VJP RHS, kernel={kernel}")
+        logpx, _ = cnf.inference(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+        assert_parity(logpx.cpu().numpy(), ref_lp, f"cfg5 VJP logpx, kernel={kernel}")
+        assert ic.last_stats["kernel_used"] == _lib.KERNEL_MFMA
+        launches[kernel] = ic.last_stats["launches"]
+    assert launches["auto"] > 4 * launches["mfma"]          # one launch per stage instead of one per step
