@@ -102,8 +102,9 @@ def main():
     mode = cnf.TrainMode()
 
     def step():
-        logpx, regs = cnf.inference(icnf, mode, xs, ps, {}, eps=eps)
-        sums = allreduce_sums(cnf.loss_sums(icnf, logpx, regs))
+        # one rank's share of `loss`: solve + post-processing + the 5 local sums in one C call, then the all-reduce
+        _, _, local = cnf.inference(icnf, mode, xs, ps, {}, eps=eps, with_sums=True)
+        sums = allreduce_sums(local)
         return icnf.last_stats, sums
 
     def sync():

@@ -63,6 +63,8 @@ _SIGNATURES = {
     "cnf_inference_post": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int, C.c_void_p]),
     "cnf_inference": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int,
                                 C.POINTER(cnf_solve_opts), C.POINTER(cnf_solve_stats), C.c_void_p]),
+    "cnf_inference_sums": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int,
+                                     C.POINTER(cnf_solve_opts), C.POINTER(cnf_solve_stats), C.c_void_p]),
     "cnf_inference_host": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int,
                                      C.POINTER(cnf_solve_opts), C.POINTER(cnf_solve_stats)]),
     "cnf_loss_sums": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, _fp, C.c_void_p]),

@@ -458,8 +458,12 @@ def generate(icnf: ICNF, mode, ps, st=None, n: int = 1, *, ys=None, z0=None, eps
     return generate_sol(icnf, mode, generate_prob(icnf, mode, ps, st, n, ys=ys, z0=z0, eps=eps))
 
 
-def inference(icnf: ICNF, mode, xs, *args, eps=None):
-    """src/base_icnf.jl:407-415 / :417-426 (conditional: ``inference(icnf, mode, xs, ys, ps, st)``)."""
+def inference(icnf: ICNF, mode, xs, *args, eps=None, with_sums=False):
+    """src/base_icnf.jl:407-415 / :417-426 (conditional: ``inference(icnf, mode, xs, ys, ps, st)``).
+    ``with_sums`` (device tensors only): also return the 5 local loss sums of ``loss_sums``, computed in
+    the same C call (cnf_inference_sums) -- what a rank needs before its all-reduce."""
+    if with_sums and not _is_torch(xs):
+        raise ValueError("with_sums needs device tensors")
     if _is_torch(xs):
         # device tensors: the whole of inference_prob -> base_sol -> inference_sol in ONE C call (cnf_inference)
         ys, ps, st = _split_cond_args(icnf, args)
@@ -482,10 +486,18 @@ def inference(icnf: ICNF, mode, xs, *args, eps=None):
         opts = _solve_opts(icnf, steer_tspan(icnf, mode))
         stats = _lib.cnf_solve_stats()
         l, h = _lib.lib(), icnf.handle()
-        _lib.check(l.cnf_inference(h, m, xb.ptr, eb.ptr if eb is not None else None, logpx.data_ptr(), regs.data_ptr(), None, B,
-                                   C.byref(opts), C.byref(stats), _stream(xb)), h)
+        ep = eb.ptr if eb is not None else None
+        if with_sums:
+            sums = t.empty(5, dtype=t.float32, device=xb.arr.device)
+            _lib.check(l.cnf_inference_sums(h, m, xb.ptr, ep, logpx.data_ptr(), regs.data_ptr(), sums.data_ptr(), B,
+                                            C.byref(opts), C.byref(stats), _stream(xb)), h)
+        else:
+            _lib.check(l.cnf_inference(h, m, xb.ptr, ep, logpx.data_ptr(), regs.data_ptr(), None, B,
+                                       C.byref(opts), C.byref(stats), _stream(xb)), h)
         icnf.last_stats = stats.as_dict()
         r = regs.view(3, B)
+        if with_sums:
+            return logpx, (r[0], r[1], r[2]), sums
         return logpx, (r[0], r[1], r[2])
     prob = inference_prob(icnf, mode, xs, *args, eps=eps)
     res = inference_sol(icnf, mode, prob)

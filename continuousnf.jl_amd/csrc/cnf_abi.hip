@@ -538,7 +538,8 @@ static cnf_status traj_slot(cnf_handle h, int n, float** out) {
 }
 
 static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const float* eps, float* u_out, int B,
-                             const cnf_solve_opts* opts, cnf_solve_stats* stats, void* stream, Recorder* rec);
+                             const cnf_solve_opts* opts, cnf_solve_stats* stats, void* stream, Recorder* rec,
+                             bool final_sync = true);
 
 extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
                                       const float* eps, float* u_out, int B,
@@ -548,7 +549,8 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
 }
 
 static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const float* eps, float* u_out, int B,
-                             const cnf_solve_opts* opts, cnf_solve_stats* stats, void* stream, Recorder* rec) {
+                             const cnf_solve_opts* opts, cnf_solve_stats* stats, void* stream, Recorder* rec,
+                             bool final_sync) {
     cnf_status s = check_call(h, mode, B);
     if (s != CNF_OK) return s;
     if (!u0 || !u_out || !opts) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
@@ -775,9 +777,11 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     }
     while (!done) {
         bool can = nq < 2 && enq < (long)opts->maxiters && est_left != 0;
-        if (est_left < 0 && nq > 0) can = false;          // learn t and dt from the first chunk
         if (can) {
-            long todo = chunk;
+            // t and dt are unknown until the first chunk's mirror arrives: meanwhile half a chunk goes in
+            // behind it on speculation (a solve shorter than 12 attempts pays a few 5 us early exits; all
+            // others no longer wait for the host between the first two chunks)
+            long todo = (est_left < 0 && nq > 0) ? chunk / 2 : chunk;
             if (est_left > 0 && est_left < todo) todo = est_left;
             if (enq + todo > (long)opts->maxiters) todo = (long)opts->maxiters - enq;
             for (long i = 0; i < todo; ++i) {
@@ -805,7 +809,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             HIPCHK(h, hipEventRecord(h->ev[slot], st));
             slot_busy[slot] = true;
             q[nq].slot = slot; q[nq].enq_at = enq; ++nq;
-            if (nq < 2 && est_left >= chunk) continue;     // far from t1: keep a second chunk in flight
+            if (nq < 2 && (est_left >= chunk || est_left < 0)) continue;   // far from t1 (or unknown): keep a second chunk in flight
         }
         if (nq == 0) {
             HIPCHK(h, hipStreamSynchronize(st));
@@ -840,7 +844,9 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     launch_copy_final(cur_state, h->U[0], h->U[1], u_out, n, st);
     launches += 1;
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(st));
+    // the step count is already known from the last mirror; the copy is stream-ordered work.  Callers that
+    // hand u_out to the host wait here, cnf_inference goes straight on to the post-processing kernel.
+    if (final_sync) HIPCHK(h, hipStreamSynchronize(st));
     nf += 6 * (fin.naccept + fin.nreject);
     if (stats) {
         stats->nf = nf;
@@ -925,8 +931,17 @@ extern "C" cnf_status cnf_inference(cnf_handle h, int mode, const float* xs, con
     float* u0 = h->Ks[4];
     float* buf = u_final ? u_final : h->Ks[4];
     s = cnf_build_u0(h, mode, xs, u0, B, stream);
-    if (s == CNF_OK) s = cnf_solve_tsit5(h, mode, u0, eps, buf, B, opts, stats, stream);
+    if (s == CNF_OK) s = solve_core(h, mode, u0, eps, buf, B, opts, stats, stream, nullptr, false);
     if (s == CNF_OK) s = cnf_inference_post(h, mode, buf, logpx, regs, B, stream);     // stream-ordered
+    return s;
+}
+
+extern "C" cnf_status cnf_inference_sums(cnf_handle h, int mode, const float* xs, const float* eps, float* logpx,
+                                         float* regs, float* sums5, int B, const cnf_solve_opts* opts,
+                                         cnf_solve_stats* stats, void* stream) {
+    if (!sums5) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    cnf_status s = cnf_inference(h, mode, xs, eps, logpx, regs, nullptr, B, opts, stats, stream);
+    if (s == CNF_OK) s = cnf_loss_sums(h, logpx, regs, B, sums5, stream);
     return s;
 }
 

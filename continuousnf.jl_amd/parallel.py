@@ -75,9 +75,13 @@ def loss_from_global_sums(sums, mode_train: bool, lambdas):
 def distributed_loss(icnf, mode, xs_local, ps, st=None, *, eps=None, group=None):
     """``loss`` over a batch sharded by columns: local inference on this rank's columns,
     then the 5-float all-reduce, then the mean."""
-    from .base_icnf import inference, loss_from_sums, loss_sums
-    logpx, regs = inference(icnf, mode, xs_local, ps, st, eps=eps)
-    sums = allreduce_sums(loss_sums(icnf, logpx, regs), group)
+    from .base_icnf import _is_torch, inference, loss_from_sums, loss_sums
+    if _is_torch(xs_local):
+        _, _, local = inference(icnf, mode, xs_local, ps, st, eps=eps, with_sums=True)
+    else:
+        logpx, regs = inference(icnf, mode, xs_local, ps, st, eps=eps)
+        local = loss_sums(icnf, logpx, regs)
+    sums = allreduce_sums(local, group)
     return loss_from_sums(icnf, mode, sums)
 
 

@@ -175,6 +175,11 @@ cnf_status cnf_inference(cnf_handle h, int mode, const float* xs, const float* e
                          float* logpx, float* regs, float* u_final /* may be NULL */,
                          int B, const cnf_solve_opts* opts, cnf_solve_stats* stats,
                          void* stream);
+/* cnf_inference followed by cnf_loss_sums in one call (no host round trip in between): what one rank of a
+ * sharded `loss` evaluation needs before its 5-float all-reduce. */
+cnf_status cnf_inference_sums(cnf_handle h, int mode, const float* xs, const float* eps, float* logpx,
+                              float* regs, float* sums5, int B, const cnf_solve_opts* opts,
+                              cnf_solve_stats* stats, void* stream);
 cnf_status cnf_inference_host(cnf_handle h, int mode, const float* xs, const float* eps,
                               float* logpx, float* regs, float* u_final, int B,
                               const cnf_solve_opts* opts, cnf_solve_stats* stats);
