@@ -42,6 +42,13 @@ struct cnf_ctx {
     StepState* d_state = nullptr;   // two slots: [0] canonical, [1] ping-pong partner of the fused MFMA path
     StepState* h_state = nullptr; // pinned, two slots for pipelined polling + one init slot
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // streamed solve: the step kernel mirrors the state into pinned, host-coherent memory after every
+    // controller run and publishes its launch index in the word behind it; the host polls that word
+    struct HostMirror { StepState s; unsigned seq; };
+    HostMirror* h_mirror = nullptr;        // host address
+    HostMirror* d_mirror = nullptr;        // the same memory as the device sees it
+    unsigned mirror_base = 0;              // launch indices are monotonic over the handle's life: late launches of
+                                           // an earlier solve can never look like news of the current one
     // lock-step sharded solves: host callback summing 3 floats over the shards (null: off)
     cnf_shard_reduce_fn shard_reduce = nullptr;
     void* shard_user = nullptr;
@@ -170,6 +177,8 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     if (e == hipSuccess) e = hipHostMalloc(&h->h_state, 3 * sizeof(StepState), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(&h->d_sums, 8 * sizeof(float));
     if (e == hipSuccess) e = hipHostMalloc(&h->h_sums, 4 * sizeof(float), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&h->h_mirror, sizeof(*h->h_mirror), hipHostMallocCoherent | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_mirror, h->h_mirror, 0);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[1], hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -196,6 +205,7 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->partials) (void)hipFree(h->partials);
     if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->h_mirror) (void)hipHostFree(h->h_mirror);
     if (h->d_sums) (void)hipFree(h->d_sums);
     if (h->h_sums) (void)hipHostFree(h->h_sums);
     if (h->ev[0]) (void)hipEventDestroy(h->ev[0]);
@@ -773,6 +783,58 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             done = true;
         } else if (s != CNF_ERR_UNSUPPORTED) {
             return fail(h, s, "persistent solve launch failed");
+        }
+    }
+    // Default for the fused step kernel: a stream of launches kept a few ahead of the last state the host has
+    // seen.  Launch i applies the controller of attempt i-1 and block 0 mirrors the new state to pinned host
+    // memory; the host polls the launch index behind it -- no events, no copy kernels, no stand-alone
+    // controller, no chunk boundaries.  Launches queued past the end find `done` and exit at once.
+    const char* ps_ = getenv("CNF_CHUNKED");
+    if (use_mfma && !done && !(ps_ && ps_[0] == '1')) {
+        const int AHEAD = 4;
+        volatile cnf_ctx::HostMirror* hm = h->h_mirror;
+        const unsigned base = h->mirror_base;
+        long sent = 0, seen = 0;                    // launches enqueued; index of the newest mirror read
+        const long max_launches = (long)opts->maxiters + 1;
+        for (;;) {
+            while (sent < max_launches && sent - seen < AHEAD && !done) {
+                const bool apply = sent > 0;
+                StepState* st_next = cur_state == h->d_state ? h->d_state + 1 : h->d_state;
+                s = mfma_step(h->mfma, h->nd, train, cur_state, st_next, h->U, h->K1, h->Ks, eps,
+                              h->partials + 2 * MAX_PARTIALS * pp, h->partials + 2 * MAX_PARTIALS * (pp ^ 1), apply,
+                              false, B, st, nullptr, 0, &h->d_mirror->s, &h->d_mirror->seq, base + (unsigned)sent);
+                if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
+                if (apply) cur_state = st_next;
+                pp ^= 1;
+                ++sent; ++launches;
+            }
+            h->mirror_base = base + (unsigned)sent;
+            if (done) break;
+            if (seen + 1 >= max_launches) {
+                HIPCHK(h, hipStreamSynchronize(st));
+                return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
+            }
+            // wait for a mirror newer than the last one read (launch 0 writes none: it has no controller to run)
+            unsigned sq;
+            long spins = 0;
+            while ((int)((sq = hm->seq) - base) <= (int)seen) {
+                if (++spins % 200000 == 0) {                       // a faulted kernel would never publish
+                    hipError_t qe = hipStreamQuery(st);
+                    if (qe != hipSuccess && qe != hipErrorNotReady) HIPCHK(h, qe);
+                    if (qe == hipSuccess && (int)(hm->seq - base) <= (int)seen)
+                        return fail(h, CNF_ERR_HIP, "step kernels finished without publishing a state");
+                }
+            }
+            // the state was written before the index (system-scope release); re-read until it is stable
+            StepState snap;
+            for (;;) {
+                memcpy(&snap, const_cast<const StepState*>(&hm->s), sizeof snap);
+                const unsigned sq2 = hm->seq;
+                if (sq2 == sq) break;
+                sq = sq2;
+            }
+            seen = (long)(sq - base);
+            if (snap.done) { fin = snap; done = true; }
         }
     }
     while (!done) {

@@ -67,5 +67,6 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
                      StepState* st_out, float* const U[2], float* const K1[2], float* const Ks[5],
                      const float* eps, const float* partials_in, float* partials_out, bool apply_ctrl,
                      bool finalize, int B, hipStream_t s, float* dump = nullptr,
-                     size_t dump_stride = 0);
+                     size_t dump_stride = 0, StepState* mirror = nullptr, unsigned* mirror_seq = nullptr,
+                     unsigned seq = 0);
 int mfma_grid_for(int B);

@@ -69,6 +69,9 @@ struct MfmaArgs {
     float* K1[2];
     float* Ks0;               // mode 1 output
     float* partials;          // mode 2: 2 floats per workgroup
+    StepState* mirror;        // streamed solve: pinned host copy of the state after each controller run ...
+    unsigned* mirror_seq;     //   ... published by storing this launch's index here (after the state)
+    unsigned seq;
     unsigned* gbar;           // persistent solve: grid-barrier counter (zeroed before the launch)
     float* partials_b;        // persistent solve: second error-partials buffer (attempts alternate)
     int max_attempts;         // persistent solve: attempts this launch may make
@@ -786,6 +789,22 @@ __device__ __forceinline__ void err_acc(float& errsum, float& badcnt, const f32x
 // barrier (all are co-resident: the host launches cooperatively, one workgroup per CU), sum the error
 // partials in the same order and take the same controller decision -- the per-launch controller of the
 // queued-launch path, without relaunching, refilling LDS or speculative launches past the end.
+// Streamed solve: block 0 copies the integrator state to pinned host memory after every controller run and
+// then publishes the launch index; the host polls that word instead of waiting on events and copies.
+__device__ __forceinline__ void publish_mirror(const MfmaArgs& a, const StepState& z) {
+    if (!a.mirror) return;
+    // system-scope stores word by word (write-through to the host), wait for them, then the index: no
+    // release fence -- that would write back this XCD's whole L2 on every launch
+    static_assert(sizeof(StepState) % 4 == 0, "copied as 32-bit words");
+    const unsigned* src = reinterpret_cast<const unsigned*>(&z);
+    unsigned* dst = reinterpret_cast<unsigned*>(a.mirror);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(StepState) / 4); ++i)
+        __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(a.mirror_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Cross-workgroup traffic (error partials + arrival tags) uses agent-scope atomic loads/stores only:
 // release/acquire fences at agent scope write back / invalidate the XCD's whole L2 once per wave
 // (measured: 136 us per attempt instead of 57), a shared arrival counter serialises 256 atomics.
@@ -799,7 +818,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
     const int mode = STEP ? 2 : a.mode;
     if (st && st->done) {
         // keep the state chain intact for the launches queued behind this one
-        if (STEP && a.apply_ctrl && blockIdx.x == 0 && tid == 0) *a.st_out = *st;
+        if (STEP && a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
         return;
     }
     // error partials of the previous attempt: requested first, consumed after the image fill
@@ -911,7 +930,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
             for (int w = 0; w < MF_KTHREADS / 64; ++w) { p0 += red[w]; p1 += red[16 + w]; }
             StepState ns = *st;
             ctrl_after_step(&ns, p0, p1, a.n_total);
-            if (blockIdx.x == 0) *a.st_out = ns;
+            if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
             sc[0] = __int_as_float(ns.cur); sc[1] = ns.h; sc[2] = ns.abstol; sc[3] = ns.reltol;
             sc[4] = __int_as_float(ns.done);
         }
@@ -1189,7 +1208,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_fused(FS ly, MfmaArgs a) {
     const int n_in = ly.n_in(), D = n_in + 3;
     const int mode = STEP ? 2 : a.mode;
     if (st && st->done) {
-        if (STEP && a.apply_ctrl && blockIdx.x == 0 && tid == 0) *a.st_out = *st;
+        if (STEP && a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
         return;
     }
     float cp0 = 0.f, cp1 = 0.f;
@@ -1228,7 +1247,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_fused(FS ly, MfmaArgs a) {
             for (int w = 0; w < MF_THREADS / 64; ++w) { p0 += red[w]; p1 += red[8 + w]; }
             StepState ns = *st;
             ctrl_after_step(&ns, p0, p1, a.n_total);
-            if (blockIdx.x == 0) *a.st_out = ns;
+            if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
             sc[0] = __int_as_float(ns.cur); sc[1] = ns.h; sc[2] = ns.abstol; sc[3] = ns.reltol;
             sc[4] = __int_as_float(ns.done);
         }
@@ -1599,7 +1618,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_pp(FS ly, MfmaArgs a) {
     const int n_in = ly.n_in(), D = n_in + 3;
     const int mode = STEP ? 2 : a.mode;
     if (st && st->done) {
-        if (STEP && a.apply_ctrl && blockIdx.x == 0 && tid == 0) *a.st_out = *st;
+        if (STEP && a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
         return;
     }
     float cp0 = 0.f, cp1 = 0.f;
@@ -1638,7 +1657,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_pp(FS ly, MfmaArgs a) {
             for (int w = 0; w < MF_THREADS / 64; ++w) { p0 += red[w]; p1 += red[8 + w]; }
             StepState ns = *st;
             ctrl_after_step(&ns, p0, p1, a.n_total);
-            if (blockIdx.x == 0) *a.st_out = ns;
+            if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
             sc[0] = __int_as_float(ns.cur); sc[1] = ns.h; sc[2] = ns.abstol; sc[3] = ns.reltol;
             sc[4] = __int_as_float(ns.done);
         }
@@ -2354,7 +2373,8 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, con
 cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st_in,
                      StepState* st_out, float* const U[2], float* const K1[2], float* const Ks[5],
                      const float* eps, const float* partials_in, float* partials_out, bool apply_ctrl,
-                     bool finalize, int B, hipStream_t s, float* dump, size_t dump_stride) {
+                     bool finalize, int B, hipStream_t s, float* dump, size_t dump_stride, StepState* mirror,
+                     unsigned* mirror_seq, unsigned seq) {
     if (!mfma_supported(p, nd, train, B)) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
     a.test = train ? 0 : 1;
@@ -2364,6 +2384,7 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
     a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1]; a.Ks0 = Ks[0];
     a.partials = partials_out;
     a.dump = dump; a.dump_stride = dump_stride;
+    a.mirror = mirror; a.mirror_seq = mirror_seq; a.seq = seq;
     cnf_status r = launch(p, a, s);
     if (r != CNF_OK) return r;
     if (finalize) {
