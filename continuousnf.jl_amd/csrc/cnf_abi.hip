@@ -39,6 +39,7 @@ struct cnf_ctx {
     float* tmp_logpx = nullptr;
     float* tmp_regs = nullptr;
     float* partials = nullptr;    // 2 * MAX_PARTIALS floats
+    StepState* last_state = nullptr; // device slot holding the state at the end of the last solve
     StepState* d_state = nullptr;   // two slots: [0] canonical, [1] ping-pong partner of the fused MFMA path
     StepState* h_state = nullptr; // pinned, two slots for pipelined polling + one init slot
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -175,7 +176,8 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     if (e == hipSuccess) e = hipMalloc(&h->d_state, 2 * sizeof(StepState));
     if (e == hipSuccess) e = hipMalloc(&h->partials, 4 * MAX_PARTIALS * sizeof(float));
     if (e == hipSuccess) e = hipHostMalloc(&h->h_state, 3 * sizeof(StepState), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc(&h->d_sums, 8 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&h->d_sums, 16 * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->d_sums, 0, 16 * sizeof(float));      // words 8.. are device tickets: zero between launches
     if (e == hipSuccess) e = hipHostMalloc(&h->h_sums, 4 * sizeof(float), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(&h->h_mirror, sizeof(*h->h_mirror), hipHostMallocCoherent | hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_mirror, h->h_mirror, 0);
@@ -505,8 +507,10 @@ static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, i
     for (int i = 0; i < 2; ++i) { n.U[i] = h->U[i]; n.K1[i] = h->K1[i]; }
     for (int i = 0; i < 5; ++i) n.Ks[i] = h->Ks[i];
     n.partials = h->partials;
+    if (with_controller) {      // error norm + controller in one launch
+        n.ticket = reinterpret_cast<unsigned*>(h->d_sums + 8); n.st_mut = h->d_state; n.ctrl_phase = 2; n.n_total = (float)n.n;
+    }
     launch_norm_partials(n, nblk, s);
-    if (with_controller) launch_controller(h->d_state, h->partials, 2, (float)n.n, s);
 }
 
 extern "C" cnf_status cnf_set_shard_reduce(cnf_handle h, cnf_shard_reduce_fn fn, void* user) {
@@ -555,6 +559,7 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
                                       const float* eps, float* u_out, int B,
                                       const cnf_solve_opts* opts, cnf_solve_stats* stats,
                                       void* stream) {
+    if (h && !u_out) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
     return solve_core(h, mode, u0, eps, u_out, B, opts, stats, stream, nullptr);
 }
 
@@ -563,7 +568,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                              bool final_sync) {
     cnf_status s = check_call(h, mode, B);
     if (s != CNF_OK) return s;
-    if (!u0 || !u_out || !opts) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    if (!u0 || !opts) return fail(h, CNF_ERR_BAD_ARG, "null pointer");      // u_out may be null: the state stays in U[cur]
     const int train = mode == CNF_MODE_TRAIN;
     if (train && !eps) return fail(h, CNF_ERR_BAD_ARG, "eps is required in TrainMode");
     if (!(opts->t0 == opts->t0) || !(opts->t1 == opts->t1) || opts->t0 == opts->t1)
@@ -613,7 +618,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         init->h = init->tdir * hh;
     }
     HIPCHK(h, hipMemcpyAsync(h->d_state, init, sizeof(StepState), hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (u0 != h->U[0]) HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
 
     // k1 = f(u0)
     if (use_mfma) {
@@ -639,11 +644,13 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     if (opts->adaptive && opts->dt == 0.f) {
         // automatic initial dt (Hairer; OrdinaryDiffEq's ode_determine_initdt, third party)
         na.kind = 0;
-        launch_norm_partials(na, nblk, st);
         if (lockstep) {
+            launch_norm_partials(na, nblk, st);
             if ((s = lockstep_controller(h, h->d_state, h->partials, 0, (float)n, st)) != CNF_OK) return s;
-        } else {
-            launch_controller(h->d_state, h->partials, 0, (float)n, st);
+        } else {        // norm + controller in one launch (the last block to finish runs the controller)
+            na.ticket = reinterpret_cast<unsigned*>(h->d_sums + 8); na.st_mut = h->d_state; na.ctrl_phase = 0; na.n_total = (float)n;
+            launch_norm_partials(na, nblk, st);
+            na.ticket = nullptr;
         }
         // f1 = f(u0 + h*f0) -> Ks[0]
         if (use_mfma) {
@@ -663,13 +670,15 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             launch_rhs_generic(h->nd, h->d_params, a, st);
         }
         na.kind = 1;
-        launch_norm_partials(na, nblk, st);
         if (lockstep) {
+            launch_norm_partials(na, nblk, st);
             if ((s = lockstep_controller(h, h->d_state, h->partials, 1, (float)n, st)) != CNF_OK) return s;
         } else {
-            launch_controller(h->d_state, h->partials, 1, (float)n, st);
+            na.ticket = reinterpret_cast<unsigned*>(h->d_sums + 8); na.st_mut = h->d_state; na.ctrl_phase = 1; na.n_total = (float)n;
+            launch_norm_partials(na, nblk, st);
+            na.ticket = nullptr;
         }
-        launches += 5;
+        launches += lockstep ? 5 : 3;
         nf += 1;
     }
     HIPCHK(h, hipGetLastError());
@@ -737,8 +746,11 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             h_attempt = snap->h;
             if (snap->done) break;
         }
-        launch_copy_final(h->d_state, h->U[0], h->U[1], u_out, n, st);
-        launches += 1;
+        h->last_state = h->d_state;
+        if (u_out) {
+            launch_copy_final(h->d_state, h->U[0], h->U[1], u_out, n, st);
+            launches += 1;
+        }
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipStreamSynchronize(st));
         if (stats) {
@@ -791,7 +803,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     // controller, no chunk boundaries.  Launches queued past the end find `done` and exit at once.
     const char* ps_ = getenv("CNF_CHUNKED");
     if (use_mfma && !done && !(ps_ && ps_[0] == '1')) {
-        const int AHEAD = 4;
+        const int AHEAD = 3;
         volatile cnf_ctx::HostMirror* hm = h->h_mirror;
         const unsigned base = h->mirror_base;
         long sent = 0, seen = 0;                    // launches enqueued; index of the newest mirror read
@@ -903,8 +915,11 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         fin = h->h_state[q[0].slot];
         q[0] = q[1]; --nq;
     }
-    launch_copy_final(cur_state, h->U[0], h->U[1], u_out, n, st);
-    launches += 1;
+    h->last_state = cur_state;
+    if (u_out) {
+        launch_copy_final(cur_state, h->U[0], h->U[1], u_out, n, st);
+        launches += 1;
+    }
     HIPCHK(h, hipGetLastError());
     // the step count is already known from the last mirror; the copy is stream-ordered work.  Callers that
     // hand u_out to the host wait here, cnf_inference goes straight on to the post-processing kernel.
@@ -988,13 +1003,15 @@ extern "C" cnf_status cnf_inference(cnf_handle h, int mode, const float* xs, con
     if (B == 0) return CNF_OK;
     HIPCHK(h, hipSetDevice(h->device));
     if ((s = ensure_capacity(h, B)) != CNF_OK) return s;
-    // no allocations on this path: u0 is assembled in a stage buffer the solve only uses once it has
-    // copied u0 away, and (without u_final) the final state lands in the same buffer afterwards
-    float* u0 = h->Ks[4];
-    float* buf = u_final ? u_final : h->Ks[4];
-    s = cnf_build_u0(h, mode, xs, u0, B, stream);
-    if (s == CNF_OK) s = solve_core(h, mode, u0, eps, buf, B, opts, stats, stream, nullptr, false);
-    if (s == CNF_OK) s = cnf_inference_post(h, mode, buf, logpx, regs, B, stream);     // stream-ordered
+    // no allocations and no copies on this path: u0 is assembled in the integrator's own state buffer, and the
+    // post-processing reads the final state from wherever the integrator left it
+    s = cnf_build_u0(h, mode, xs, h->U[0], B, stream);
+    if (s == CNF_OK) s = solve_core(h, mode, h->U[0], eps, u_final, B, opts, stats, stream, nullptr, false);
+    if (s == CNF_OK) {
+        launch_post_state(h->nd, mode == CNF_MODE_TRAIN, h->last_state, h->U[0], h->U[1], logpx, regs, B,
+                          (hipStream_t)stream);                                           // stream-ordered
+        HIPCHK(h, hipGetLastError());
+    }
     return s;
 }
 

@@ -265,6 +265,27 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
 //                    sc = abstol + max(|u|,|u_new|) reltol;  p1 = nonfinite count
 // partials[2*blockIdx.x + {0,1}]
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void ctrl_phase(StepState* st, int phase, float p0, float p1, float n_total) {
+    const float span = fabsf(st->t1 - st->t0);
+    if (phase == 0) {
+        float d0 = sqrtf(p0 / n_total), d1 = sqrtf(p1 / n_total);
+        float dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+        dt0 = fminf(dt0, span);
+        st->d0 = dt0;   // keep dt0
+        st->d1 = d1;
+        st->h = st->tdir * dt0;
+    } else if (phase == 1) {
+        float dt0 = st->d0, d1 = st->d1;
+        float d2 = sqrtf(p0 / n_total) / dt0;
+        float m = fmaxf(d1, d2);
+        float dt1 = (m <= 1e-15f) ? fmaxf(1e-6f, dt0 * 1e-3f) : powf(0.01f / m, 0.2f);
+        st->dt = fminf(fminf(100.f * dt0, dt1), span);
+        ctrl_set_attempt_h(st);
+    } else {
+        ctrl_after_step(st, p0, p1, n_total);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_norm_partials(NormArgs a) {
     __shared__ float sm[8];
@@ -310,10 +331,34 @@ k_norm_partials(NormArgs a) {
     }
     float s0 = block_sum(p0, sm);
     float s1 = block_sum(p1, sm);
-    if (threadIdx.x == 0) {
-        a.partials[2 * blockIdx.x] = s0;
-        a.partials[2 * blockIdx.x + 1] = s1;
+    if (!a.ticket) {
+        if (threadIdx.x == 0) {
+            a.partials[2 * blockIdx.x] = s0;
+            a.partials[2 * blockIdx.x + 1] = s1;
+        }
+        return;
     }
+    // fused controller: partials and ticket go through agent-scope atomics (no cache flushes); the block
+    // that draws the last ticket sums the partials in the fixed order of k_controller and runs the phase
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.partials + 2 * blockIdx.x, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.partials + 2 * blockIdx.x + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.x - 1;
+        if (last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last || st->done) return;
+    float q0 = 0.f, q1 = 0.f;
+    for (int i = threadIdx.x; i < st->n_partials; i += blockDim.x) {
+        q0 += __hip_atomic_load(a.partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q1 += __hip_atomic_load(a.partials + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    q0 = block_sum(q0, sm);
+    q1 = block_sum(q1, sm);
+    if (threadIdx.x == 0) ctrl_phase(a.st_mut, a.ctrl_phase, q0, q1, a.n_total);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -321,27 +366,6 @@ k_norm_partials(NormArgs a) {
 // Control law: OrdinaryDiffEq-style PI controller for Tsit5 (third
 // party in the reference, restated from the published scheme, mirrored by the oracle).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void ctrl_phase(StepState* st, int phase, float p0, float p1, float n_total) {
-    const float span = fabsf(st->t1 - st->t0);
-    if (phase == 0) {
-        float d0 = sqrtf(p0 / n_total), d1 = sqrtf(p1 / n_total);
-        float dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
-        dt0 = fminf(dt0, span);
-        st->d0 = dt0;   // keep dt0
-        st->d1 = d1;
-        st->h = st->tdir * dt0;
-    } else if (phase == 1) {
-        float dt0 = st->d0, d1 = st->d1;
-        float d2 = sqrtf(p0 / n_total) / dt0;
-        float m = fmaxf(d1, d2);
-        float dt1 = (m <= 1e-15f) ? fmaxf(1e-6f, dt0 * 1e-3f) : powf(0.01f / m, 0.2f);
-        st->dt = fminf(fminf(100.f * dt0, dt1), span);
-        ctrl_set_attempt_h(st);
-    } else {
-        ctrl_after_step(st, p0, p1, n_total);
-    }
-}
-
 __global__ void __launch_bounds__(256)
 k_controller(StepState* st, const float* __restrict__ partials, int phase, float n_total) {
     __shared__ float sm[8];
@@ -405,6 +429,28 @@ __global__ void k_copy_final(const StepState* st, const float* U0, const float* 
 // inference_sol (src/base_icnf.jl:167-189), one lane per column
 __global__ void k_post(NetDesc nd, int train, const float* __restrict__ fsol,
                        float* __restrict__ logpx, float* __restrict__ regs, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n_in = nd.n_in;
+    const int D = n_in + 1 + (train ? 2 : 0);
+    const float* c = fsol + (size_t)b * D;
+    float ss = 0.f, sa = 0.f;
+    for (int i = 0; i < n_in; ++i) {
+        float v = c[i];
+        ss = fmaf(v, v, ss);
+        if (i >= nd.nvars) sa = fmaf(v, v, sa);
+    }
+    const float log2pi = 1.8378770664093453f;
+    float logpz = -0.5f * fmaf((float)n_in, log2pi, ss);      // base_icnf.jl:177
+    logpx[b] = logpz - c[n_in];                                // base_icnf.jl:178
+    regs[b] = train ? c[n_in + 1] : 0.f;
+    regs[(size_t)B + b] = train ? c[n_in + 2] : 0.f;
+    regs[2 * (size_t)B + b] = (nd.norm_z_aug && nd.naugs > 0) ? sqrtf(sa) : 0.f;  // :179-187
+}
+
+__global__ void k_post_state(NetDesc nd, int train, const StepState* st, const float* U0, const float* U1,
+                             float* __restrict__ logpx, float* __restrict__ regs, int B) {
+    const float* fsol = st->cur ? U1 : U0;
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int n_in = nd.n_in;
@@ -504,6 +550,10 @@ void launch_post(const NetDesc& nd, int train, const float* fsol, float* logpx, 
                  int B, hipStream_t s) {
     hipLaunchKernelGGL(k_post, dim3((B + 255) / 256), dim3(256), 0, s, nd, train, fsol, logpx,
                        regs, B);
+}
+void launch_post_state(const NetDesc& nd, int train, const StepState* st, const float* U0, const float* U1,
+                       float* logpx, float* regs, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_post_state, dim3((B + 255) / 256), dim3(256), 0, s, nd, train, st, U0, U1, logpx, regs, B);
 }
 void launch_cond_bias(const NetDesc& nd, const float* P, const float* ys, float* cond, int cbs, int B,
                       hipStream_t s) {

@@ -33,6 +33,11 @@ struct NormArgs {
     float* K1[2];
     float* Ks[5];
     float* partials;        // 2 floats per block
+    // fused controller (optional): the last block to finish reduces the partials and runs this phase
+    unsigned* ticket;       // device counter, zero between launches; null: partials only
+    StepState* st_mut;
+    int ctrl_phase;
+    float n_total;
 };
 
 void launch_rhs_generic(const NetDesc& nd, const float* P, const RhsArgs& a, hipStream_t s);
@@ -47,6 +52,9 @@ void launch_copy_final(const StepState* st, const float* U0, const float* U1, fl
                        size_t n, hipStream_t s);
 void launch_post(const NetDesc& nd, int train, const float* fsol, float* logpx, float* regs,
                  int B, hipStream_t s);
+// same, reading the final state straight from the integrator's buffer U[st->cur]
+void launch_post_state(const NetDesc& nd, int train, const StepState* st, const float* U0, const float* U1,
+                       float* logpx, float* regs, int B, hipStream_t s);
 void launch_cond_bias(const NetDesc& nd, const float* P, const float* ys, float* cond, int cbs, int B,
                       hipStream_t s);
 void launch_loss_sums(const float* logpx, const float* regs, int B, float* sums5,
