@@ -54,8 +54,8 @@ def cpu_baseline(B, flat, xs, eps, kw, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "mfma"])
     ap.add_argument("--batch", type=int, default=8192, help="columns per GPU")
     ap.add_argument("--fixed-dt", type=float, default=0.0, help="use fixed steps instead of adaptive")

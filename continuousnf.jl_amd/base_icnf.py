@@ -48,9 +48,17 @@ class _Buf:
             return self.arr.data_ptr()
         return self.arr.ctypes.data
 
+    def flat2d(self):
+        """(B, rows) row-major view of the storage (torch buffers)"""
+        if self.arr.dim() == 2:
+            return self.arr.t()
+        return self.arr.view(self.B, self.rows)
+
     def view(self):
         """logical (rows, B) view without copying"""
         if self.torch is not None:
+            if self.arr.dim() == 2:
+                return self.arr                  # a column-major (rows, B) tensor taken as it came
             return self.arr.view(self.B, self.rows).t()
         return self.arr.reshape(self.B, self.rows).T
 
@@ -65,6 +73,8 @@ def _as_colmajor(x, rows=None, name="array"):
             raise ValueError(f"{name} has {x.shape[0]} rows, expected {rows}")
         if not x.is_cuda:
             raise ValueError(f"{name}: torch tensors must live on the GPU (pass numpy for host data)")
+        if x.dtype == torch.float32 and x.stride(0) == 1 and x.stride(1) == x.shape[0]:
+            return _Buf(x, x.shape[0], x.shape[1], torch)    # already column-major: use the storage as it is
         t = x.t().contiguous().to(torch.float32).reshape(-1)   # (B, rows) row-major == col-major
         return _Buf(t, x.shape[0], x.shape[1], torch)
     a = np.asarray(x)
@@ -347,6 +357,16 @@ def inference_prob(icnf: ICNF, mode, xs, *args, eps=None) -> ODEProblem:
 
 
 def _solve_opts(icnf: ICNF, tspan):
+    key = (tspan, id(icnf.sol_kwargs), len(icnf.sol_kwargs), icnf.compute_mode.kernel)
+    hit = getattr(icnf, "_opts_cache", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    opts = _solve_opts_build(icnf, tspan)
+    icnf._opts_cache = (key, opts)
+    return opts
+
+
+def _solve_opts_build(icnf: ICNF, tspan):
     kw = dict(icnf.sol_kwargs)
     kernel = _KERNEL[icnf.compute_mode.kernel]
     adaptive = bool(kw.pop("adaptive", True))
@@ -440,7 +460,7 @@ def generate_prob(icnf: ICNF, mode, ps, st, n: int, *, ys=None, z0=None, eps=Non
         eb = _as_colmajor(eps, n_in, "eps")
     u0 = _empty_like(zb, D, n)
     v = u0.arr.view(n, D) if u0.torch is not None else u0.arr.reshape(n, D)
-    src = zb.arr.view(n, n_in) if zb.torch is not None else zb.arr.reshape(n, n_in)
+    src = zb.flat2d() if zb.torch is not None else zb.arr.reshape(n, n_in)
     v[:, :n_in] = src
     v[:, n_in:] = 0.0                                   # zrs = zeros(n_aug + 1, n)  (:367-368)
     t0, t1 = steer_tspan(icnf, mode)
