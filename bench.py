@@ -145,7 +145,7 @@ def main():
         if kernel_used == _lib.KERNEL_MFMA:
             # dominant kernel = the fused Tsit5 step kernel (6 RHS evaluations per launch):
             # time a fixed-dt solve of n steps = n launches of that kernel.
-            nsteps = 64
+            nsteps = 256                  # long enough that the initial-dt phase and the finishing launch vanish in the mean
             opts = _lib.cnf_solve_opts(0.0, 1.0, 0.0, 0.0, 1.0 / nsteps, 0, 1 << 20, _lib.KERNEL_MFMA)
             stats = _lib.cnf_solve_stats()
             D = wl.n_in + 3
