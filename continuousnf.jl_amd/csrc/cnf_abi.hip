@@ -620,8 +620,19 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     HIPCHK(h, hipMemcpyAsync(h->d_state, init, sizeof(StepState), hipMemcpyHostToDevice, st));
     if (u0 != h->U[0]) HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
 
-    // k1 = f(u0)
-    if (use_mfma) {
+    // k1 = f(u0).  With the automatic initial dt on the fused path, the two norms and their controller phases
+    // ride in the RHS launches themselves (the last workgroup to finish runs the phase): 2 launches, not 4.
+    const bool hairer = opts->adaptive && opts->dt == 0.f;
+    unsigned* ticket = reinterpret_cast<unsigned*>(h->d_sums + 8);
+    bool fused_init = false;
+    const char* nf_ = getenv("CNF_NO_FUSED_INIT");
+    if (use_mfma && hairer && !lockstep && !(nf_ && nf_[0] == '1')) {
+        s = mfma_rhs_init0(h->mfma, h->nd, train, h->d_state, h->U[0], eps, h->K1[0], h->partials, ticket, B, st);
+        if (s == CNF_OK) fused_init = true;
+        else if (s != CNF_ERR_UNSUPPORTED) return fail(h, s, "MFMA RHS launch failed");
+    }
+    if (fused_init) {
+    } else if (use_mfma) {
         s = mfma_rhs(h->mfma, h->nd, train, h->U[0], eps, h->K1[0], B, st);
         if (s != CNF_OK) return fail(h, s, "MFMA RHS launch failed");
     } else if (h->trace_on) {
@@ -641,7 +652,14 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     for (int i = 0; i < 2; ++i) { na.U[i] = h->U[i]; na.K1[i] = h->K1[i]; }
     for (int i = 0; i < 5; ++i) na.Ks[i] = h->Ks[i];
 
-    if (opts->adaptive && opts->dt == 0.f) {
+    if (hairer && fused_init) {
+        // f1 = f(u0 + h*f0) -> Ks[0], with the second norm and the controller phase that sets dt
+        s = mfma_rhs_stage(h->mfma, h->nd, train, h->d_state, h->U, h->K1, h->Ks, eps, 1, B, st, h->d_state,
+                           h->partials, ticket);
+        if (s != CNF_OK) return fail(h, s, "MFMA RHS launch failed");
+        launches += 1;
+        nf += 1;
+    } else if (hairer) {
         // automatic initial dt (Hairer; OrdinaryDiffEq's ode_determine_initdt, third party)
         na.kind = 0;
         if (lockstep) {

@@ -128,6 +128,29 @@ __device__ __forceinline__ void ctrl_after_step(StepState* st, float p0, float p
     if (!st->done) ctrl_set_attempt_h(st);
 }
 
+// phases of the device controller: 0/1 = the two norms of the automatic initial dt (Hairer; OrdinaryDiffEq's
+// ode_determine_initdt, third party), 2 = after a step attempt
+__device__ __forceinline__ void ctrl_phase(StepState* st, int phase, float p0, float p1, float n_total) {
+    const float span = fabsf(st->t1 - st->t0);
+    if (phase == 0) {
+        float d0 = sqrtf(p0 / n_total), d1 = sqrtf(p1 / n_total);
+        float dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+        dt0 = fminf(dt0, span);
+        st->d0 = dt0;   // keep dt0
+        st->d1 = d1;
+        st->h = st->tdir * dt0;
+    } else if (phase == 1) {
+        float dt0 = st->d0, d1 = st->d1;
+        float d2 = sqrtf(p0 / n_total) / dt0;
+        float m = fmaxf(d1, d2);
+        float dt1 = (m <= 1e-15f) ? fmaxf(1e-6f, dt0 * 1e-3f) : powf(0.01f / m, 0.2f);
+        st->dt = fminf(fminf(100.f * dt0, dt1), span);
+        ctrl_set_attempt_h(st);
+    } else {
+        ctrl_after_step(st, p0, p1, n_total);
+    }
+}
+
 // ---- activations: value and derivative w.r.t. the pre-activation ------------------------
 __device__ __forceinline__ float cnf_sigmoid(float a) { return 1.0f / (1.0f + __expf(-a)); }
 

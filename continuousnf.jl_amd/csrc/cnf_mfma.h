@@ -51,9 +51,12 @@ bool mfma_supported(const MfmaPlan& p, const NetDesc& nd, bool train, int B);
 cnf_status mfma_rhs(const MfmaPlan& p, const NetDesc& nd, bool train, const float* u,
                     const float* eps, float* du, int B, hipStream_t s);
 // f(u + h*k1) -> Ks[0]  (initial-dt probe; h and the buffer set come from *st)
+cnf_status mfma_rhs_init0(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st, const float* u,
+                          const float* eps, float* du, float* partials, unsigned* ticket, int B, hipStream_t s);
 cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st,
                           float* const U[2], float* const K1[2], float* const Ks[5],
-                          const float* eps, int nk, int B, hipStream_t s);
+                          const float* eps, int nk, int B, hipStream_t s, StepState* st_init = nullptr,
+                          float* partials = nullptr, unsigned* ticket = nullptr);
 // one full Tsit5 step attempt: 6 RHS evaluations + error partials in ONE launch.
 //  apply_ctrl: the launch first applies the step controller to (st_in, partials_in) -- the
 //              outcome of the previous attempt -- redundantly in every workgroup, block 0

@@ -69,6 +69,8 @@ struct MfmaArgs {
     float* K1[2];
     float* Ks0;               // mode 1 output
     float* partials;          // mode 2: 2 floats per workgroup
+    int init_phase;           // modes 0/1 inside a solve: also produce the norm partials of initial-dt phase 0/1 and let
+    unsigned* ticket;         //   the last workgroup to finish run that controller phase on *st_out (-1: off)
     StepState* mirror;        // streamed solve: pinned host copy of the state after each controller run ...
     unsigned* mirror_seq;     //   ... published by storing this launch's index here (after the state)
     unsigned seq;
@@ -1069,6 +1071,26 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                 if (own0) st4(out + r00, kz0[1], nv0);
                 if (own1) st4(out + r01, kz1[1], nv1);
                 if (sown) st4(out + n_in, sc_get(2), nsc);
+                if (a.init_phase >= 0) {       // norms of the automatic initial dt, over the rows this lane owns
+                    auto acc = [&](const f32x4& u4, const f32x4& f0, const f32x4& f1, int nvalid) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (c < nvalid) {
+                                const float sk = fmaf(fabsf(u4[c]), reltol, abstol);
+                                if (a.init_phase == 0) {
+                                    const float x = u4[c] / sk, y = f1[c] / sk;
+                                    errsum = fmaf(x, x, errsum); badcnt = fmaf(y, y, badcnt);
+                                } else {
+                                    const float x = (f1[c] - f0[c]) / sk;
+                                    errsum = fmaf(x, x, errsum);
+                                }
+                            }
+                        }
+                    };
+                    if (own0) acc(uz0, kz0[0], kz0[1], nv0);
+                    if (own1) acc(uz1, kz1[0], kz1[1], nv1);
+                    if (sown) acc(sc_get(0), sc_get(1), sc_get(2), nsc);
+                }
             } else {
                 float* Un = a.U[1 - cur] + gcol;
                 float* K7 = a.K1[1 - cur] + gcol;
@@ -1104,7 +1126,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                stamps[37], stamps[32], stamps[33], stamps[34]);
     }
 #endif
-    if (mode == 2) {
+    if (mode == 2 || a.init_phase >= 0) {
         // deterministic block reduction of the error partial (fixed tree, fixed order)
         __syncthreads();
         for (int off = 32; off > 0; off >>= 1) {
@@ -1117,6 +1139,16 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
             float e = 0.f, b = 0.f;
             for (int w = 0; w < MF_KTHREADS / 64; ++w) { e += lds[ly.red_off() + w]; b += lds[ly.red_off() + 16 + w]; }
             float* pout = (PERSIST && (attempt & 1)) ? a.partials_b : a.partials;
+            if (mode != 2) {
+                // initial-dt phase: partials through agent-scope atomics, then a ticket; whoever draws the last
+                // one sums all partials (fixed order) and runs the controller phase -- no separate launches
+                __hip_atomic_store(pout + 2 * blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pout + 2 * blockIdx.x + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lds[ly.red_off() + 40] = (tk == gridDim.x - 1) ? 1.f : 0.f;
+                if (tk == gridDim.x - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else
             if (PERSIST) {
                 __hip_atomic_store(pout + 4 * blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(pout + 4 * blockIdx.x + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1126,6 +1158,25 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
             } else {
                 pout[2 * blockIdx.x] = e;
                 pout[2 * blockIdx.x + 1] = b;
+            }
+        }
+    }
+    if (mode != 2 && a.init_phase >= 0) {
+        __syncthreads();
+        if (lds[ly.red_off() + 40] != 0.f) {         // this workgroup drew the last ticket: all its threads reduce
+            const float* pin = a.partials;
+            float q0 = 0.f, q1 = 0.f;
+            for (int i = tid; i < (int)gridDim.x; i += MF_KTHREADS) {
+                q0 += __hip_atomic_load(pin + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q1 += __hip_atomic_load(pin + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (int off = 32; off > 0; off >>= 1) { q0 += __shfl_down(q0, off, 64); q1 += __shfl_down(q1, off, 64); }
+            if (lane == 0) { lds[ly.red_off() + wave] = q0; lds[ly.red_off() + 16 + wave] = q1; }
+            __syncthreads();
+            if (tid == 0) {
+                float p0 = 0.f, p1 = 0.f;
+                for (int w = 0; w < MF_KTHREADS / 64; ++w) { p0 += lds[ly.red_off() + w]; p1 += lds[ly.red_off() + 16 + w]; }
+                ctrl_phase(a.st_out, a.init_phase, p0, p1, a.n_total);
             }
         }
     }
@@ -2330,6 +2381,7 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     const int ntile = (B + MF_NB - 1) / MF_NB;
     if (ntile != mfma_grid_for(B)) return CNF_ERR_UNSUPPORTED;        // one tile per workgroup only
     MfmaArgs a{};
+    a.init_phase = -1;
     a.mode = 2; a.B = B; a.img = p.d_img; a.eps = eps; a.st = st; a.st_out = st;
     a.n_total = (float)((size_t)(nd.n_in + 3) * B);
     a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1];
@@ -2354,19 +2406,40 @@ cnf_status mfma_rhs(const MfmaPlan& p, const NetDesc& nd_, bool train, const flo
                     const float* eps, float* du, int B, hipStream_t s) {
     if (!mfma_supported(p, nd_, train, B)) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
+    a.init_phase = -1;
     a.test = train ? 0 : 1;
     a.mode = 0; a.B = B; a.img = p.d_img; a.eps = eps; a.u = u; a.du = du;
     return launch(p, a, s);
 }
 
+// k1 = f(u0) at the start of a solve, with the first norm of the automatic initial dt (d0, d1) and its
+// controller phase folded into the same launch
+cnf_status mfma_rhs_init0(const MfmaPlan& p, const NetDesc& nd_, bool train, StepState* st, const float* u,
+                          const float* eps, float* du, float* partials, unsigned* ticket, int B, hipStream_t s) {
+    if (!mfma_supported(p, nd_, train, B) || p.schedule != 0) return CNF_ERR_UNSUPPORTED;
+    MfmaArgs a{};
+    a.test = train ? 0 : 1;
+    a.mode = 0; a.B = B; a.img = p.d_img; a.eps = eps; a.u = u; a.du = du;
+    a.st = st; a.st_out = st; a.init_phase = 0; a.partials = partials; a.ticket = ticket;
+    a.n_total = (float)((size_t)(nd_.n_in + (train ? 3 : 1)) * B);
+    return launch(p, a, s);
+}
+
 cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, const StepState* st,
                           float* const U[2], float* const K1[2], float* const Ks[5],
-                          const float* eps, int nk, int B, hipStream_t s) {
+                          const float* eps, int nk, int B, hipStream_t s, StepState* st_init, float* partials,
+                          unsigned* ticket) {
     if (!mfma_supported(p, nd_, train, B) || nk != 1) return CNF_ERR_UNSUPPORTED;
+    if (st_init && p.schedule != 0) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
+    a.init_phase = -1;
     a.test = train ? 0 : 1;
     a.mode = 1; a.B = B; a.img = p.d_img; a.eps = eps; a.st = st;
     a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1]; a.Ks0 = Ks[0];
+    if (st_init) {       // second norm of the automatic initial dt + its controller phase in this launch
+        a.st_out = st_init; a.init_phase = 1; a.partials = partials; a.ticket = ticket;
+        a.n_total = (float)((size_t)(nd_.n_in + (train ? 3 : 1)) * B);
+    }
     return launch(p, a, s);
 }
 
@@ -2377,6 +2450,7 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
                      unsigned* mirror_seq, unsigned seq) {
     if (!mfma_supported(p, nd, train, B)) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
+    a.init_phase = -1;
     a.test = train ? 0 : 1;
     a.mode = 2; a.B = B; a.img = p.d_img; a.eps = eps; a.st = st_in; a.st_out = st_out;
     a.partials_in = partials_in; a.apply_ctrl = apply_ctrl ? 1 : 0;
