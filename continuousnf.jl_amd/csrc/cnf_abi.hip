@@ -1184,7 +1184,7 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
     // ---- backward: discrete adjoint of the recorded steps ---------------------------------------
     // capacity is in samples of cap_B; with B <= cap_B at least grad_fsteps steps fit
     const int fsteps = (int)std::min<size_t>(32, (size_t)h->grad_fsteps * h->grad_cap_B / (size_t)B);
-    int ksplit = 1, chunk = 0, filed = 0;
+    int ksplit = 1, filed = 0;
     HIPCHK(h, hipMemsetAsync(h->g_part, 0, (size_t)GRAD_MAX_KSPLIT * h->n_params * sizeof(float), st));
     HIPCHK(h, launch_final_cotangent(nd, h->lam[2], fsol, h->g_lam, B, st));
     const float invB = 1.0f / (float)B;

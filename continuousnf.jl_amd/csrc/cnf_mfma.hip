@@ -855,7 +855,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
 
     int cur = 0;
     float hstep = 0.f, abstol = 0.f, reltol = 0.f;
-    unsigned gen = 0, ground = 0;
+    unsigned gen = 0;
     // Runge-Kutta state of this lane's z rows (accumulator layout); declared out here so that a
     // persistent solve carries it from one attempt to the next in registers
     f32x4 uz0 = {0.f, 0.f, 0.f, 0.f}, uz1 = uz0, kz0[7], kz1[7], un0 = uz0, un1 = uz0, uns_keep = uz0;
@@ -944,8 +944,8 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol;
     }
 
-    constexpr int TT = MF_KTHREADS / 2, TNB = MF_NB / 2;
-    const int team = wave / MF_WPT, tt = tid & (TT - 1);
+    constexpr int TNB = MF_NB / 2;
+    const int team = wave / MF_WPT;
     const int s = lane & 15, q = lane >> 4, fg = (wave + (MF_WPT / 2) * team) % MF_WPT;
     const int nt0 = ly.P(0) >> 4;
     const bool own0 = fg < nt0, own1 = nt0 > MF_WPT && fg + MF_WPT < nt0;   // z-row tiles fg, fg+MF_WPT
