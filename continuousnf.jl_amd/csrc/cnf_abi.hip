@@ -1204,6 +1204,7 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
         // stage states: U_1 = u_n, U_2..U_6 were filed behind it by the forward pass
         const float* US[6];
         for (int i = 0; i < 6; ++i) US[i] = un + (size_t)i * n;
+        AdjStepArgs S{};
         for (int i = 5; i >= 0; --i) {
             AdjArgs a{};
             a.P = h->d_params; a.PT = h->d_PT; a.ustage = US[i]; a.eps = eps;
@@ -1219,8 +1220,17 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
             a.HS = h->g_HS + slot * B * gl.sum_in; a.TS = h->g_TS + slot * B * gl.sum_in;
             a.AB = h->g_AB + slot * B * gl.sum_out; a.PB = h->g_PB + slot * B * gl.sum_out;
             a.B = B;
-            if (adj_mfma) HIPCHK(h, launch_adj_mfma(nd, gl, am, h->d_adj_img, a, st));
+            if (adj_mfma) S.st[i] = a;
             else HIPCHK(h, launch_adj(nd, gl, a, st));
+        }
+        if (adj_mfma) {        // the six stage pullbacks and the lambda update of this step in ONE launch
+            S.first = 5; S.last = 0; S.B = B; S.lam_update = 1; S.lam_out = h->g_lam;
+            HIPCHK(h, launch_adj_mfma_step(nd, gl, am, h->d_adj_img, S, st));
+        } else {
+            StageK ws{};
+            ws.nk = 6;
+            for (int i = 0; i < 6; ++i) ws.k[i] = h->g_W[i];
+            HIPCHK(h, launch_lambda_update(h->g_lam, ws, (size_t)n_in * B, st));
         }
         // Wbar += sum over the filed stage evaluations and their samples: one contraction with K = 6 filed B
         if (++filed == fsteps || step == 0) {
@@ -1231,10 +1241,6 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
                                    6 * filed * B, ks, ch, st));
             filed = 0;
         }
-        StageK ws{};
-        ws.nk = 6;
-        for (int i = 0; i < 6; ++i) ws.k[i] = h->g_W[i];
-        HIPCHK(h, launch_lambda_update(h->g_lam, ws, (size_t)n_in * B, st));
     }
     HIPCHK(h, launch_grad_reduce(h->g_part, grad, (int)h->n_params, ksplit, st));
     HIPCHK(h, hipStreamSynchronize(st));

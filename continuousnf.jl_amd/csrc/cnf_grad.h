@@ -33,6 +33,16 @@ struct AdjArgs {
     int B;
 };
 
+// the six stage pullbacks of one Runge-Kutta step in one launch (MFMA pullback): stages first .. last, then
+// lambda <- lambda + sum of their zbar
+struct AdjStepArgs {
+    AdjArgs st[6];
+    int first, last;
+    int B;
+    int lam_update;
+    float* lam_out;
+};
+
 struct StageK {
     const float* k[6];
     float coef[6];
@@ -74,3 +84,5 @@ hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const 
                                   float* img, hipStream_t s);
 hipError_t launch_adj_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                            const AdjArgs& a, hipStream_t s);
+hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                                const AdjStepArgs& S, hipStream_t s);

@@ -734,7 +734,7 @@ extern "C" int cnf_debug_adj_stamps(unsigned long long* out, int n) {
 #endif
 template <bool ALL_TANH>
 __global__ void __launch_bounds__(AM_THREADS)
-k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, AdjArgs a) {
+k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, AdjStepArgs S) {
     extern __shared__ float lds[];
     const int PS = m.PS, NL = m.L;
     float* red = lds + (size_t)AM_NS * PS;
@@ -744,9 +744,11 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
     // elementwise passes: sample es, features ec, ec + AM_EC, ... (16 consecutive lanes = 64 contiguous bytes)
     const int es = (tid >> 4) & 15, ec = (tid & 15) | ((tid >> 8) << 4);
     const int eb = b0 + es;
-    const bool ev = eb < a.B;
+    const bool ev = eb < S.B;
     const int oL = m.o_off[NL - 1];
 
+  for (int stg = S.first; stg >= S.last; --stg) {      // the stages of one Runge-Kutta step, last to first
+    const AdjArgs& a = S.st[stg];
     AM_STAMP(0);
     AFrag pf;
     am_first(pf, img + m.f_off[0], m.dp[1], m.dp[0]);
@@ -913,6 +915,19 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
         const int t_ = cur; cur = nxt; nxt = t_;
     }
     AM_STAMP(24);
+    // zbar of this stage is input to the earlier stages (and to the lambda update): stores first, then everyone
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    am_barrier();
+  }
+  if (S.lam_update) {        // lambda <- lambda + sum over the stages of zbar   (rows of this workgroup's samples)
+    for (int r = ec; r < n_in; r += AM_EC) {
+        if (ev) {
+            float acc = S.st[0].lam[(size_t)eb * n_in + r];
+            for (int k = S.last; k <= S.first; ++k) acc += S.st[k].w_out[(size_t)eb * n_in + r];
+            S.lam_out[(size_t)eb * n_in + r] = acc;
+        }
+    }
+  }
 }
 
 hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* P,
@@ -923,8 +938,8 @@ hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const 
     return hipGetLastError();
 }
 
-hipError_t launch_adj_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
-                           const AdjArgs& a, hipStream_t s) {
+hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                                const AdjStepArgs& S, hipStream_t s) {
     const size_t lds = adj_mfma_lds_bytes(m);
     bool all_tanh = true;
     for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
@@ -932,8 +947,16 @@ hipError_t launch_adj_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfma
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (all_tanh)
-        hipLaunchKernelGGL(k_adj_mfma<true>, dim3((a.B + AM_NS - 1) / AM_NS), dim3(AM_THREADS), lds, s, nd, g, m, img, a);
+        hipLaunchKernelGGL(k_adj_mfma<true>, dim3((S.B + AM_NS - 1) / AM_NS), dim3(AM_THREADS), lds, s, nd, g, m, img, S);
     else
-        hipLaunchKernelGGL(k_adj_mfma<false>, dim3((a.B + AM_NS - 1) / AM_NS), dim3(AM_THREADS), lds, s, nd, g, m, img, a);
+        hipLaunchKernelGGL(k_adj_mfma<false>, dim3((S.B + AM_NS - 1) / AM_NS), dim3(AM_THREADS), lds, s, nd, g, m, img, S);
     return hipGetLastError();
+}
+
+// one stage only (kept for callers that drive the stages themselves)
+hipError_t launch_adj_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                           const AdjArgs& a, hipStream_t s) {
+    AdjStepArgs S{};
+    S.st[0] = a; S.first = 0; S.last = 0; S.B = a.B; S.lam_update = 0; S.lam_out = nullptr;
+    return launch_adj_mfma_step(nd, g, m, img, S, s);
 }
