@@ -61,7 +61,9 @@ struct cnf_ctx {
     bool trace_on = false;        // this call evaluates through an auxiliary MFMA kernel (cnf_trace.hip) behind the generic driver
     bool aux_train = false;       //   false: TestMode exact trace; true: TrainMode JVP
     const float* aux_eps = nullptr;
-    std::vector<float*> traj_blocks;   // TRAJ_BLOCK state slots each, slot = (n_in + 3) * grad_cap_B floats
+    float* traj = nullptr;             // trajectory store: traj_cap slots of 6 (n_in + 3) grad_cap_B floats (u_n, U_2..U_6)
+    float* traj_hs = nullptr;          // device: signed size of accepted step n (written by the step kernel)
+    int traj_cap = 0;
     size_t grad_cap_B = 0;
     int grad_fsteps = 1;          // steps whose factor arrays are kept before one batch contraction
     float* grad_arena = nullptr;
@@ -202,7 +204,8 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (h->d_PT) (void)hipFree(h->d_PT);
     if (h->d_adj_img) (void)hipFree(h->d_adj_img);
     if (h->grad_arena) (void)hipFree(h->grad_arena);
-    for (float* b : h->traj_blocks) (void)hipFree(b);
+    if (h->traj) (void)hipFree(h->traj);
+    if (h->traj_hs) (void)hipFree(h->traj_hs);
     if (h->arena) (void)hipFree(h->arena);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->partials) (void)hipFree(h->partials);
@@ -535,19 +538,34 @@ static cnf_status lockstep_controller(cnf_handle h, StepState* state, const floa
 }
 
 // Trajectory store of the gradient path: state after every accepted step + the step sizes.
-static const int TRAJ_BLOCK = 16;
 struct Recorder {
     std::vector<float> hs;        // signed step of accepted step n (u_n -> u_{n+1})
-    int n = 0;                    // accepted steps recorded; slot n holds u_n
+    int n = 0;                    // accepted steps recorded; slot n holds u_n and the stage states of step n
+    bool overflow = false;        // the solve took more steps than the store holds: grow it and solve again
 };
-static cnf_status traj_slot(cnf_handle h, int n, float** out) {
-    const size_t slot = 6 * ((size_t)h->nd.n_in + 3) * h->grad_cap_B;   // u_n, then the stage states 2..6 of step n
-    while ((size_t)n >= h->traj_blocks.size() * TRAJ_BLOCK) {
-        float* b = nullptr;
-        HIPCHK(h, hipMalloc(&b, slot * TRAJ_BLOCK * sizeof(float)));
-        h->traj_blocks.push_back(b);
+static size_t traj_slot_floats(cnf_handle h) { return 6 * ((size_t)h->nd.n_in + 3) * h->grad_cap_B; }
+// make room for `steps` slots (contiguous: the step kernel indexes it by the accepted-step counter)
+static cnf_status traj_reserve(cnf_handle h, int steps) {
+    if (steps <= h->traj_cap) return CNF_OK;
+    int cap = h->traj_cap ? h->traj_cap : 32;
+    while (cap < steps) cap *= 2;
+    const size_t slot = traj_slot_floats(h);
+    float *nt = nullptr, *nh = nullptr;
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMalloc(&nt, slot * cap * sizeof(float)));
+    HIPCHK(h, hipMalloc(&nh, (size_t)cap * sizeof(float)));
+    if (h->traj) {
+        HIPCHK(h, hipMemcpy(nt, h->traj, slot * h->traj_cap * sizeof(float), hipMemcpyDeviceToDevice));
+        HIPCHK(h, hipMemcpy(nh, h->traj_hs, (size_t)h->traj_cap * sizeof(float), hipMemcpyDeviceToDevice));
+        (void)hipFree(h->traj); (void)hipFree(h->traj_hs);
     }
-    *out = h->traj_blocks[n / TRAJ_BLOCK] + (size_t)(n % TRAJ_BLOCK) * slot;
+    h->traj = nt; h->traj_hs = nh; h->traj_cap = cap;
+    return CNF_OK;
+}
+static cnf_status traj_slot(cnf_handle h, int n, float** out) {
+    cnf_status s = traj_reserve(h, n + 1);
+    if (s != CNF_OK) return s;
+    *out = h->traj + (size_t)n * traj_slot_floats(h);
     return CNF_OK;
 }
 
@@ -711,7 +729,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     }
     StepState* cur_state = h->d_state;   // slot holding the live integrator state
     int pp = 0;                          // partials buffer the NEXT launch reads
-    if (lockstep || rec) {
+    if (lockstep || (rec && !use_mfma)) {
         // one attempt at a time.  Lock-step: every shard must see the same global error norm before
         // the next attempt is sized.  Recording (gradient path): the host files the state after
         // every accepted step.
@@ -826,13 +844,22 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         const unsigned base = h->mirror_base;
         long sent = 0, seen = 0;                    // launches enqueued; index of the newest mirror read
         const long max_launches = (long)opts->maxiters + 1;
+        // gradient path: every attempt files u_n and its stage states in the slot of step `naccept`, indexed on
+        // the device; the store is sized beforehand and the solve repeated if it took more steps than fit
+        float* dump = nullptr; size_t slot = 0; int dcap = 0;
+        if (rec) {
+            if ((s = traj_reserve(h, 64)) != CNF_OK) return s;
+            slot = traj_slot_floats(h); dcap = h->traj_cap;
+            dump = h->traj + n;                      // stage area of slot 0; u_n sits one array before
+        }
         for (;;) {
             while (sent < max_launches && sent - seen < AHEAD && !done) {
                 const bool apply = sent > 0;
                 StepState* st_next = cur_state == h->d_state ? h->d_state + 1 : h->d_state;
                 s = mfma_step(h->mfma, h->nd, train, cur_state, st_next, h->U, h->K1, h->Ks, eps,
                               h->partials + 2 * MAX_PARTIALS * pp, h->partials + 2 * MAX_PARTIALS * (pp ^ 1), apply,
-                              false, B, st, nullptr, 0, &h->d_mirror->s, &h->d_mirror->seq, base + (unsigned)sent);
+                              false, B, st, dump, n, &h->d_mirror->s, &h->d_mirror->seq, base + (unsigned)sent, slot, dcap,
+                              h->traj_hs);
                 if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
                 if (apply) cur_state = st_next;
                 pp ^= 1;
@@ -934,6 +961,15 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         q[0] = q[1]; --nq;
     }
     h->last_state = cur_state;
+    if (rec) {            // streamed recording: step sizes back from the device
+        rec->n = fin.naccept;
+        rec->overflow = fin.naccept > h->traj_cap;
+        rec->hs.assign((size_t)(rec->overflow ? 0 : fin.naccept), 0.f);
+        if (!rec->overflow && fin.naccept > 0)
+            HIPCHK(h, hipMemcpyAsync(rec->hs.data(), h->traj_hs, (size_t)fin.naccept * sizeof(float),
+                                     hipMemcpyDeviceToHost, st));
+        final_sync = true;
+    }
     if (u_out) {
         launch_copy_final(cur_state, h->U[0], h->U[1], u_out, n, st);
         launches += 1;
@@ -1112,8 +1148,7 @@ static cnf_status ensure_grad_capacity(cnf_handle h, int B) {
     if ((size_t)B <= h->grad_cap_B) return CNF_OK;
     HIPCHK(h, hipDeviceSynchronize());
     if (h->grad_arena) { (void)hipFree(h->grad_arena); h->grad_arena = nullptr; }
-    for (float* b : h->traj_blocks) (void)hipFree(b);
-    h->traj_blocks.clear();
+    if (h->traj) { (void)hipFree(h->traj); (void)hipFree(h->traj_hs); h->traj = nullptr; h->traj_hs = nullptr; h->traj_cap = 0; }
     h->grad_cap_B = 0;
     const size_t cap = ((size_t)B + 63) & ~(size_t)63;
     const size_t D = (size_t)h->nd.n_in + 3, n_in = h->nd.n_in;
@@ -1172,7 +1207,11 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
     Recorder rec;
     cnf_solve_stats sst{};
     float* fsol = h->g_US[1];
-    if ((s = solve_core(h, mode, u0, eps, fsol, B, opts, &sst, stream, &rec)) != CNF_OK) return s;
+    for (;;) {
+        if ((s = solve_core(h, mode, u0, eps, fsol, B, opts, &sst, stream, &rec)) != CNF_OK) return s;
+        if (!rec.overflow) break;
+        if ((s = traj_reserve(h, rec.n + 8)) != CNF_OK) return s;       // more steps than slots: grow, solve again
+    }
     h->last_hs = rec.hs;
     launch_post(nd, 1, fsol, h->tmp_logpx, h->tmp_regs, B, st);
     launch_loss_sums(h->tmp_logpx, h->tmp_regs, B, h->d_sums, st);     // 5 floats; d_sums holds 8

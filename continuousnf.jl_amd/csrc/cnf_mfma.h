@@ -71,5 +71,5 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
                      const float* eps, const float* partials_in, float* partials_out, bool apply_ctrl,
                      bool finalize, int B, hipStream_t s, float* dump = nullptr,
                      size_t dump_stride = 0, StepState* mirror = nullptr, unsigned* mirror_seq = nullptr,
-                     unsigned seq = 0);
+                     unsigned seq = 0, size_t dump_step_stride = 0, int dump_cap = 0, float* hs_out = nullptr);
 int mfma_grid_for(int B);

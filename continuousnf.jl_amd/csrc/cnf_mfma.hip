@@ -79,6 +79,9 @@ struct MfmaArgs {
     int max_attempts;         // persistent solve: attempts this launch may make
     float* dump;              // mode 2, gradient path: z rows of the stage states U_2..U_6 go to dump + (stage - 2) * dump_stride
     size_t dump_stride;       //   ([B][D] arrays like the state), else null
+    size_t dump_step_stride;  // != 0: trajectory store indexed on the device -- this attempt files into the slot of step
+    int dump_cap;             //   `naccept` (u_n one array before `dump`, then U_2..U_6), if naccept < dump_cap, and its
+    float* hs_out;            //   signed step size into hs_out[naccept]
 };
 
 // ---- layouts -------------------------------------------------------------------------------
@@ -853,7 +856,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
             *(f32x4*)(lds + z) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    int cur = 0;
+    int cur = 0, nacc = 0;
     float hstep = 0.f, abstol = 0.f, reltol = 0.f;
     unsigned gen = 0;
     // Runge-Kutta state of this lane's z rows (accumulator layout); declared out here so that a
@@ -934,14 +937,21 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
             ctrl_after_step(&ns, p0, p1, a.n_total);
             if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
             sc[0] = __int_as_float(ns.cur); sc[1] = ns.h; sc[2] = ns.abstol; sc[3] = ns.reltol;
-            sc[4] = __int_as_float(ns.done);
+            sc[4] = __int_as_float(ns.done); sc[5] = __int_as_float(ns.naccept);
         }
         __syncthreads();
         cur = __float_as_int(sc[0]); hstep = sc[1]; abstol = sc[2]; reltol = sc[3];
+        nacc = __float_as_int(sc[5]);
         if (__float_as_int(sc[4])) return;        // the controller just finished the solve
         __syncthreads();                          // scratch (RED) is free again
     } else if (st) {
-        cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol;
+        cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol; nacc = st->naccept;
+    }
+    // where this attempt files its stage states (gradient path), if anywhere
+    float* dumpb = a.dump;
+    if (a.dump && a.dump_step_stride) {
+        dumpb = nacc < a.dump_cap ? a.dump + (size_t)nacc * a.dump_step_stride : nullptr;
+        if (dumpb && blockIdx.x == 0 && tid == 0) a.hs_out[nacc] = hstep;
     }
 
     constexpr int TNB = MF_NB / 2;
@@ -1007,6 +1017,11 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                     if (own1 && nv1 > 0) kz1[0] = ld4(K1in + gcol + r01, nv1);
                 }
             }
+            if (mode == 2 && dumpb && a.dump_step_stride && live) {      // u_n of this step, one array before its stage states
+                float* un_slot = dumpb - a.dump_stride + gcol;
+                if (own0) st4(un_slot + r00, uz0, nv0);
+                if (own1) st4(un_slot + r01, uz1, nv1);
+            }
         } else if (cur != prev_cur) {        // persistent solve, previous attempt accepted: u <- u_new, k1 <- k7 (FSAL)
             uz0 = un0; uz1 = un1; kz0[0] = kz0[6]; kz1[0] = kz1[6];
             if (sown) { sc_set(1, sc_get(7)); sc_set(0, uns_keep); }
@@ -1017,7 +1032,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         // state of stage `stg` (z rows) -> region_0; the last stage's state is u_new (a7 = b)
         auto put_stage = [&](int stg) {
             // evaluation stg (1..6) runs at the Runge-Kutta stage state U_{stg+1}; U_2..U_6 are filed, U_7 = u_new is not
-            float* dmp = (mode == 2 && a.dump && stg <= 5 && live) ? a.dump + (size_t)(stg - 1) * a.dump_stride + gcol : nullptr;
+            float* dmp = (mode == 2 && dumpb && stg <= 5 && live) ? dumpb + (size_t)(stg - 1) * a.dump_stride + gcol : nullptr;
             if (own0) {
                 if (mode == 1) un0 = uz0 + hstep * kz0[0];
                 else if (mode == 2) un0 = uz0 + hstep * stage_acc4_rt(stg, kz0);
@@ -2447,7 +2462,7 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
                      StepState* st_out, float* const U[2], float* const K1[2], float* const Ks[5],
                      const float* eps, const float* partials_in, float* partials_out, bool apply_ctrl,
                      bool finalize, int B, hipStream_t s, float* dump, size_t dump_stride, StepState* mirror,
-                     unsigned* mirror_seq, unsigned seq) {
+                     unsigned* mirror_seq, unsigned seq, size_t dump_step_stride, int dump_cap, float* hs_out) {
     if (!mfma_supported(p, nd, train, B)) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
     a.init_phase = -1;
@@ -2458,6 +2473,7 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
     a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1]; a.Ks0 = Ks[0];
     a.partials = partials_out;
     a.dump = dump; a.dump_stride = dump_stride;
+    a.dump_step_stride = dump_step_stride; a.dump_cap = dump_cap; a.hs_out = hs_out;
     a.mirror = mirror; a.mirror_seq = mirror_seq; a.seq = seq;
     cnf_status r = launch(p, a, s);
     if (r != CNF_OK) return r;

@@ -859,3 +859,15 @@ def test_auto_uses_standalone_vjp_kernel_for_streamed_weights():
         assert ic.last_stats["kernel_used"] == _lib.KERNEL_MFMA
         launches[kernel] = ic.last_stats["launches"]
     assert launches["auto"] > 4 * launches["mfma"]          # one launch per stage instead of one per step
+
+
+def test_loss_grad_more_steps_than_the_trajectory_store():
+    """100 fixed steps: more than the 64 slots the trajectory store starts with -- the recorded forward notices,
+    grows the store and solves again; the gradient still matches the oracle."""
+    cfg, _, _ = O.baseline_cfg(2)
+    cfg.tspan = (0.0, 1.0)
+    val, grad, rval, rgrad, st, _ = _grad_case(cfg, 24, 950, "mfma", dict(adaptive=False, dt=1 / 100),
+                                               dict(adaptive=False, dt=1 / 100))
+    assert st["naccept"] == 100
+    assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+    _assert_grad(grad, rgrad, "100 steps")
