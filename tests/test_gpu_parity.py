@@ -871,3 +871,27 @@ def test_loss_grad_more_steps_than_the_trajectory_store():
     assert st["naccept"] == 100
     assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
     _assert_grad(grad, rgrad, "100 steps")
+
+
+def test_config4_full_batch_on_one_gpu():
+    """BASELINE config 4 unsharded: FFJORD, 65536 columns on one GPU (2048 tiles over 512 workgroups: several
+    tiles per workgroup, 512 error partials).  Sampled columns of a fixed-dt solve against the oracle; the
+    adaptive solve of the whole batch finishes with consistent counters."""
+    cfg, B, _ = O.baseline_cfg(4)
+    rng = np.random.default_rng(44)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.05)
+    xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+    eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+    ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
+    logpx, regs = cnf.inference(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+    assert torch.isfinite(logpx).all() and float(regs[0].abs().max()) == 0.0      # FFJORD: E and n rows are zero
+    idx = rng.choice(B, 48, replace=False)
+    _, ref_lp, _, _ = O.inference(cfg, flat.astype(np.float64), xs[:, idx].astype(np.float64),
+                                  eps[:, idx].astype(np.float64), True, dt=1 / 8, adaptive=False)
+    assert_parity(logpx[torch.from_numpy(idx).cuda()].cpu().numpy(), ref_lp, "cfg4 full batch, sampled columns")
+    kw = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+    ica = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=kw)
+    lp_all, _ = cnf.inference(ica, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+    st = ica.last_stats
+    assert st["nf"] == 2 + 6 * (st["naccept"] + st["nreject"]) and st["t_final"] == 1.0
+    assert torch.isfinite(lp_all).all()
