@@ -759,6 +759,18 @@ __device__ __forceinline__ f32x4 ld4(const float* p, int nvalid4) {   // rows be
     const float v0 = p[0], v1 = p[i1], v2 = p[i2], v3 = p[i3];
     return f32x4{nvalid4 > 0 ? v0 : 0.f, nvalid4 > 1 ? v1 : 0.f, nvalid4 > 2 ? v2 : 0.f, nvalid4 > 3 ? v3 : 0.f};
 }
+// Branch-free variant for the kernel prologue: `ld4_issue` only issues the four loads (always from valid
+// addresses: `safe` stands in when there is nothing to read), `ld4_mask` zeroes what was not asked for.
+// A branch around a load makes the compiler wait for it at once; issuing all prologue loads first and
+// masking afterwards keeps ~30 loads in flight instead of 8 serial groups of 4.
+__device__ __forceinline__ f32x4 ld4_issue(const float* p, int nvalid4, const float* safe) {
+    const float* q = nvalid4 > 0 ? p : safe;
+    const int i1 = nvalid4 > 1 ? 1 : 0, i2 = nvalid4 > 2 ? 2 : 0, i3 = nvalid4 > 3 ? 3 : 0;
+    return f32x4{q[0], q[i1], q[i2], q[i3]};
+}
+__device__ __forceinline__ f32x4 ld4_mask(const f32x4& v, int nvalid4) {
+    return f32x4{nvalid4 > 0 ? v.x : 0.f, nvalid4 > 1 ? v.y : 0.f, nvalid4 > 2 ? v.z : 0.f, nvalid4 > 3 ? v.w : 0.f};
+}
 __device__ __forceinline__ void st4(float* p, const f32x4& v, int nvalid4) {
     if (nvalid4 > 0) p[0] = v.x;
     if (nvalid4 > 1) p[1] = v.y;
@@ -988,41 +1000,39 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         // eps tile -> EPS[sample][feature]: the lanes that own the state rows also fetch the eps
         // rows (same addresses pattern; previous readers are this team's waves, ordered by the
         // last team barrier of the previous tile)
-        {
-            const float* ep = a.eps ? a.eps + (size_t)(b0 + s) * n_in : nullptr;
-            if (own0) *(f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r00) =
-                (ep && live && nv0 > 0) ? ld4(ep + r00, nv0) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (own1) *(f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r01) =
-                (ep && live && nv1 > 0) ? ld4(ep + r01, nv1) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        // state: z rows in the accumulator layout, scalar rows in the fg == 0, q == 0 lanes
-        // (the scalar rows' u, k1..k7 live in LDS: only 16 lanes per team touch them, once per stage)
         float* sc = lds + ly.sc_off() + row * 24;
         auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
         auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
-        if (!PERSIST || attempt == 0) {
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            uz0 = zero; uz1 = zero;
+        {
+            // every global read of the prologue is issued before any of them is consumed
+            const float* safe = a.img;
+            const bool fresh = !PERSIST || attempt == 0;
+            const float* ep = a.eps ? a.eps + (size_t)(b0 + s) * n_in : nullptr;
+            const int ce0 = (own0 && ep && live) ? nv0 : 0, ce1 = (own1 && ep && live) ? nv1 : 0;
+            const int cu0 = (fresh && own0 && live) ? nv0 : 0, cu1 = (fresh && own1 && live) ? nv1 : 0;
+            const int ck0 = K1in ? cu0 : 0, ck1 = K1in ? cu1 : 0;
+            const int cs0 = (fresh && sown && live) ? nsc : 0, cs1 = K1in ? cs0 : 0;
+            const f32x4 re0 = ld4_issue(ep + r00, ce0, safe), re1 = ld4_issue(ep + r01, ce1, safe);
+            const f32x4 ru0 = ld4_issue(Uin + gcol + r00, cu0, safe), ru1 = ld4_issue(Uin + gcol + r01, cu1, safe);
+            const f32x4 rk0 = ld4_issue(K1in + gcol + r00, ck0, safe), rk1 = ld4_issue(K1in + gcol + r01, ck1, safe);
+            const f32x4 rs0 = ld4_issue(Uin + gcol + n_in, cs0, safe), rs1 = ld4_issue(K1in + gcol + n_in, cs1, safe);
+            if (own0) *(f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r00) = ld4_mask(re0, ce0);
+            if (own1) *(f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r01) = ld4_mask(re1, ce1);
+            if (fresh) {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 7; ++i) { kz0[i] = zero; kz1[i] = zero; }
-            if (sown) {
-                sc_set(0, live ? ld4(Uin + gcol + n_in, nsc) : zero);
-                sc_set(1, (live && K1in) ? ld4(K1in + gcol + n_in, nsc) : zero);
-            }
-            if (live) {
-                if (own0 && nv0 > 0) uz0 = ld4(Uin + gcol + r00, nv0);
-                if (own1 && nv1 > 0) uz1 = ld4(Uin + gcol + r01, nv1);
-                if (K1in) {
-                    if (own0 && nv0 > 0) kz0[0] = ld4(K1in + gcol + r00, nv0);
-                    if (own1 && nv1 > 0) kz1[0] = ld4(K1in + gcol + r01, nv1);
+                for (int i = 0; i < 7; ++i) { kz0[i] = zero; kz1[i] = zero; }
+                uz0 = ld4_mask(ru0, cu0); uz1 = ld4_mask(ru1, cu1);
+                kz0[0] = ld4_mask(rk0, ck0); kz1[0] = ld4_mask(rk1, ck1);
+                if (sown) { sc_set(0, ld4_mask(rs0, cs0)); sc_set(1, ld4_mask(rs1, cs1)); }
+                if (mode == 2 && dumpb && a.dump_step_stride && live) {      // u_n of this step, one array before its stage states
+                    float* un_slot = dumpb - a.dump_stride + gcol;
+                    if (own0) st4(un_slot + r00, uz0, nv0);
+                    if (own1) st4(un_slot + r01, uz1, nv1);
                 }
             }
-            if (mode == 2 && dumpb && a.dump_step_stride && live) {      // u_n of this step, one array before its stage states
-                float* un_slot = dumpb - a.dump_stride + gcol;
-                if (own0) st4(un_slot + r00, uz0, nv0);
-                if (own1) st4(un_slot + r01, uz1, nv1);
-            }
-        } else if (cur != prev_cur) {        // persistent solve, previous attempt accepted: u <- u_new, k1 <- k7 (FSAL)
+        }
+        if (PERSIST && attempt > 0 && cur != prev_cur) {        // persistent solve, previous attempt accepted: u <- u_new, k1 <- k7 (FSAL)
             uz0 = un0; uz1 = un1; kz0[0] = kz0[6]; kz1[0] = kz1[6];
             if (sown) { sc_set(1, sc_get(7)); sc_set(0, uns_keep); }
         }
