@@ -26,13 +26,16 @@ TraceLayout trace_layout(const NetDesc& nd, const AdjMfmaLayout& m) {
     const int PSf = pad8m16(m.maxd);
     const int nbuf = L >= 4 ? 2 : 1;
     // as many column tiles per group as fit next to a second workgroup on the CU (<= 80 KB), at least one sample
-    const int per_sample_tiles = m.nin_p / 16;                          // 1, 2, 4 or 8 (trace_mfma_supported)
-    int nct = TR_NCMAX;
-    for (;;) {
-        const size_t fl = (size_t)AM_NS * t.PD + (size_t)nbuf * 16 * nct * t.PT + (size_t)AM_NS * AM_WAVES;
-        if (fl * 4 <= 80 * 1024 || nct <= per_sample_tiles) break;
-        nct /= 2;
+    const int per_sample_tiles = m.nin_p / 16;                          // 1 .. 8 (trace_mfma_supported)
+    // samples per group: a divisor of 16 (groups tile the workgroup's samples), as many as fit 8 column tiles and
+    // leave room for a second workgroup on the CU (<= 80 KB), at least one
+    int gs = 1;
+    for (int g = 16; g >= 1; g /= 2) {
+        const int c = g * per_sample_tiles;
+        const size_t fl = (size_t)AM_NS * t.PD + (size_t)nbuf * 16 * c * t.PT + (size_t)AM_NS * AM_WAVES;
+        if (c <= TR_NCMAX && (fl * 4 <= 80 * 1024 || g == 1)) { gs = g; break; }
     }
+    int nct = gs * per_sample_tiles;
     t.nct = nct;
     t.gs = 16 * nct / m.nin_p;
     t.off_T0 = AM_NS * t.PD;
@@ -46,8 +49,7 @@ TraceLayout trace_layout(const NetDesc& nd, const AdjMfmaLayout& m) {
 
 bool trace_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m) {
     if (nd.n_layers < 3 || nd.dims[nd.n_layers] != nd.n_in) return false;
-    const int tps = m.nin_p / 16;
-    if (tps != 1 && tps != 2 && tps != 4 && tps != 8) return false;
+    if (m.nin_p / 16 > TR_NCMAX) return false;
     const TraceLayout t = trace_layout(nd, m);
     return (size_t)t.total_floats * 4 <= 160 * 1024;
 }
@@ -481,7 +483,11 @@ hipError_t launch_trace_mfma(const NetDesc& nd, const GradLayout& g, const AdjMf
     switch (tl.nct) {
         case 1: if (all_tanh) TR_LAUNCH(true, 1); else TR_LAUNCH(false, 1); break;
         case 2: if (all_tanh) TR_LAUNCH(true, 2); else TR_LAUNCH(false, 2); break;
+        case 3: if (all_tanh) TR_LAUNCH(true, 3); else TR_LAUNCH(false, 3); break;
         case 4: if (all_tanh) TR_LAUNCH(true, 4); else TR_LAUNCH(false, 4); break;
+        case 5: if (all_tanh) TR_LAUNCH(true, 5); else TR_LAUNCH(false, 5); break;
+        case 6: if (all_tanh) TR_LAUNCH(true, 6); else TR_LAUNCH(false, 6); break;
+        case 7: if (all_tanh) TR_LAUNCH(true, 7); else TR_LAUNCH(false, 7); break;
         default: if (all_tanh) TR_LAUNCH(true, 8); else TR_LAUNCH(false, 8); break;
     }
 #undef TR_LAUNCH

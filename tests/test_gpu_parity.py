@@ -738,6 +738,9 @@ def test_exact_trace_mfma_deep_networks():
         (O.Cfg(O.Net((32, 96, 64, 32), (O.ACT_SOFTPLUS, O.ACT_TANH, O.ACT_IDENTITY)), 32, 0), 0, 33),
         (O.Cfg(O.Net((10, 40, 24, 10), (O.ACT_TANH, O.ACT_SIGMOID, O.ACT_TANH)), 8, 2), 0, 19),   # unaligned widths
         (O.Cfg(O.Net((32, 64, 64, 32), (O.ACT_TANH,) * 3), 32, 0), 5, 40),                          # conditional
+        (O.Cfg(O.Net((40, 64, 64, 40), (O.ACT_TANH,) * 3), 40, 0), 0, 21),      # 3 column tiles per sample
+        (O.Cfg(O.Net((72, 96, 80, 72), (O.ACT_TANH,) * 3), 60, 12), 0, 18),     # 5 column tiles per sample
+        (O.Cfg(O.Net((100, 64, 64, 100), (O.ACT_TANH,) * 3), 100, 0), 0, 17),   # 7 column tiles per sample
     ]
     for k, (cfg, n_cond, B) in enumerate(cases):
         rng = np.random.default_rng(500 + k)
