@@ -523,8 +523,8 @@ __device__ __forceinline__ void bwd_epilogue(const LY& ly, float* lds, int l, in
 template <class LY, class F>
 __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* wimg, int lane, int wave,
                                          unsigned* bar, unsigned& gen, f32x4& zd0, f32x4& zd1,
-                                         F&& after_zdot, const float* cimg = nullptr, int SWC = 0,
-                                         const float* cbrow = nullptr STAMP_ARGS) {
+                                         F&& after_zdot, const float* cimg, int SWC,
+                                         const float* cbrow STAMP_ARGS) {
     // wimg: where the weight image is read from -- the LDS copy, or (networks too large for
     // LDS) the HBM/L2-resident image, with a row-major transposed copy for the reverse sweep
     // team = column tile; the feature-group index is rotated by 2 for team 1 so that the
