@@ -818,7 +818,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     // launches at config 3 (the per-attempt critical path is the same; the refill and the launch gaps it
     // saves are about what the barrier costs), so the queued path stays the default.
     const char* pe = getenv("CNF_PERSISTENT");
-    if (use_mfma && train && pe && pe[0] == '1') {
+    if (use_mfma && train && !rec && pe && pe[0] == '1') {       // (a recording solve always streams)
         unsigned* gbar = reinterpret_cast<unsigned*>(h->d_sums + 4);
         s = mfma_solve_persistent(h->mfma, h->nd, true, h->d_state, h->U, h->K1, eps, h->partials,
                                   h->partials + 2 * MAX_PARTIALS, gbar, opts->maxiters, B, st);
@@ -838,7 +838,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     // memory; the host polls the launch index behind it -- no events, no copy kernels, no stand-alone
     // controller, no chunk boundaries.  Launches queued past the end find `done` and exit at once.
     const char* ps_ = getenv("CNF_CHUNKED");
-    if (use_mfma && !done && !(ps_ && ps_[0] == '1')) {
+    if (use_mfma && !done && (rec || !(ps_ && ps_[0] == '1'))) {
         const int AHEAD = 3;
         volatile cnf_ctx::HostMirror* hm = h->h_mirror;
         const unsigned base = h->mirror_base;
