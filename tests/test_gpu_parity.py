@@ -899,3 +899,25 @@ def test_config4_full_batch_on_one_gpu():
     st = ica.last_stats
     assert st["nf"] == 2 + 6 * (st["naccept"] + st["nreject"]) and st["t_final"] == 1.0
     assert torch.isfinite(lp_all).all()
+
+
+def test_inference_with_sums_and_distributed_loss_single_process():
+    """cnf_inference_sums (solve + post-processing + local loss sums in one call) agrees with the separate
+    calls, and parallel.distributed_loss without a process group is the plain loss."""
+    from continuousnf.jl_amd.parallel import distributed_loss
+    cfg, _, _ = O.baseline_cfg(2)
+    rng = np.random.default_rng(31)
+    B = 300
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    xs, eps = _dev(rng.standard_normal((cfg.nvars, B))), _dev(rng.standard_normal((cfg.n_in, B)))
+    ic = make_icnf(cnf, cfg, sol_kwargs=dict(adaptive=False, dt=1 / 16))
+    for mode in (cnf.TrainMode(), cnf.TestMode()):
+        logpx, regs, sums = cnf.inference(ic, mode, xs, flat, {}, eps=eps, with_sums=True)
+        lp2, regs2 = cnf.inference(ic, mode, xs, flat, {}, eps=eps)
+        assert torch.equal(logpx, lp2) and all(torch.equal(a, b) for a, b in zip(regs, regs2))
+        ref = cnf.loss_sums(ic, lp2, regs2)
+        assert torch.allclose(sums, ref, rtol=1e-6, atol=0) and float(sums[4]) == B
+        val = distributed_loss(ic, mode, xs, flat, {}, eps=eps)
+        assert abs(val - cnf.loss(ic, mode, xs, flat, {}, eps=eps)) <= 1e-6 * max(1.0, abs(val))
+    with pytest.raises(ValueError):
+        cnf.inference(ic, cnf.TrainMode(), xs.cpu().numpy(), flat, {}, eps=eps.cpu().numpy(), with_sums=True)
