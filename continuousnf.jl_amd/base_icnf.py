@@ -6,7 +6,9 @@ are ``D x B``) and may be numpy arrays (copied through the *_host entry points) 
 CUDA tensors (used in place, on torch's current stream)."""
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 from dataclasses import dataclass, field
 from typing import Any
 
@@ -22,6 +24,27 @@ _KERNEL = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "mfma": _li
 
 def _is_torch(x):
     return type(x).__module__.startswith("torch")
+
+
+# Handles still open at interpreter exit are destroyed here, while the HIP runtime (and a profiler's
+# tool library) are still alive: atexit hooks run before library destructors, and this one is
+# registered after torch's, so it runs before torch tears its context down.  __del__ at interpreter
+# teardown gives no such ordering.
+_OPEN = {}
+
+
+def _close_all():
+    for ref in list(_OPEN.values()):
+        ic = ref()
+        if ic is not None:
+            try:
+                ic.close()
+            except Exception:
+                pass
+    _OPEN.clear()
+
+
+atexit.register(_close_all)
 
 
 def _mode_id(mode) -> int:
@@ -101,7 +124,7 @@ def _stream(buf: _Buf):
 # ---------------------------------------------------------------------------------------
 # ICNF (src/icnf.jl:69-104) + construct (src/base_icnf.jl:1-77)
 # ---------------------------------------------------------------------------------------
-@dataclass
+@dataclass(eq=False)
 class ICNF:
     tag: type
     nn: Chain
@@ -146,6 +169,7 @@ class ICNF:
             h = C.c_void_p()
             _lib.check(l.cnf_create(C.byref(h), C.byref(cfg)))
             self._handle = h
+            _OPEN[id(self)] = weakref.ref(self)
         return self._handle
 
     def close(self):
@@ -154,6 +178,7 @@ class ICNF:
             self._handle = None
             self._params_id = None
             self._cond_id = None
+            _OPEN.pop(id(self), None)
 
     def __del__(self):
         try:
@@ -166,9 +191,12 @@ class ICNF:
         h = self.handle()
         l = _lib.lib()
         if _is_torch(ps):
-            key = ("t", ps.data_ptr(), ps._version, ps.numel())
-            if key == self._params_id:
+            # identity of a tensor this object keeps alive (+ its in-place version counter): an address
+            # can be handed to a new tensor by the caching allocator, an object held here cannot
+            prev = self._params_id
+            if prev is not None and prev[0] == "t" and prev[1] is ps and prev[2] == ps._version:
                 return
+            key = ("t", ps, ps._version)
             import torch
             p = ps.detach().to(torch.float32).contiguous().reshape(-1)
             if p.is_cuda:
@@ -179,7 +207,7 @@ class ICNF:
         else:
             p = np.ascontiguousarray(np.asarray(ps), dtype=np.float32).reshape(-1)
             key = ("n", p.tobytes())
-            if key == self._params_id:
+            if self._params_id is not None and self._params_id[0] == "n" and key == self._params_id:
                 return
             _lib.check(l.cnf_set_params_host(h, p.ctypes.data, p.size), h)
         self._params_id = key
@@ -217,9 +245,15 @@ class ICNF:
         yb = _as_colmajor(ys, self.n_cond, "ys")
         if yb.B != B:
             raise ValueError("ys must have one column per sample")
-        key = ("t", yb.arr.data_ptr(), yb.arr._version, B) if yb.torch is not None else ("n", yb.arr.tobytes(), B)
-        if key == self._cond_id:
-            return
+        if yb.torch is not None:
+            prev = self._cond_id
+            if prev is not None and prev[0] == "t" and prev[1] is ys and prev[2] == ys._version and prev[3] == B:
+                return
+            key = ("t", ys, ys._version, B)          # the caller's tensor, held: identity, not address
+        else:
+            key = ("n", yb.arr.tobytes(), B)
+            if self._cond_id is not None and self._cond_id[0] == "n" and key == self._cond_id:
+                return
         l, h = _lib.lib(), self.handle()
         if yb.torch is not None:
             _lib.check(l.cnf_set_cond(h, yb.ptr, B, _stream(yb)), h)
@@ -357,7 +391,7 @@ def inference_prob(icnf: ICNF, mode, xs, *args, eps=None) -> ODEProblem:
 
 
 def _solve_opts(icnf: ICNF, tspan):
-    key = (tspan, id(icnf.sol_kwargs), len(icnf.sol_kwargs), icnf.compute_mode.kernel)
+    key = (tspan, tuple(sorted(icnf.sol_kwargs.items())), icnf.compute_mode.kernel)
     hit = getattr(icnf, "_opts_cache", None)
     if hit is not None and hit[0] == key:
         return hit[1]

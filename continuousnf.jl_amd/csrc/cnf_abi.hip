@@ -813,26 +813,6 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     bool slot_busy[2] = {false, false};
     bool done = false;
     StepState fin{};
-    // Optional (CNF_PERSISTENT=1): ONE cooperative launch makes every attempt (tag barrier + in-kernel
-    // controller between attempts, state carried in registers).  Measured 1 % faster than the queued
-    // launches at config 3 (the per-attempt critical path is the same; the refill and the launch gaps it
-    // saves are about what the barrier costs), so the queued path stays the default.
-    const char* pe = getenv("CNF_PERSISTENT");
-    if (use_mfma && train && !rec && pe && pe[0] == '1') {       // (a recording solve always streams)
-        unsigned* gbar = reinterpret_cast<unsigned*>(h->d_sums + 4);
-        s = mfma_solve_persistent(h->mfma, h->nd, true, h->d_state, h->U, h->K1, eps, h->partials,
-                                  h->partials + 2 * MAX_PARTIALS, gbar, opts->maxiters, B, st);
-        if (s == CNF_OK) {
-            HIPCHK(h, hipMemcpyAsync(&h->h_state[0], h->d_state, sizeof(StepState), hipMemcpyDeviceToHost, st));
-            HIPCHK(h, hipStreamSynchronize(st));
-            fin = h->h_state[0];
-            launches += 1;
-            if (!fin.done) return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
-            done = true;
-        } else if (s != CNF_ERR_UNSUPPORTED) {
-            return fail(h, s, "persistent solve launch failed");
-        }
-    }
     // Default for the fused step kernel: a stream of launches kept a few ahead of the last state the host has
     // seen.  Launch i applies the controller of attempt i-1 and block 0 mirrors the new state to pinned host
     // memory; the host polls the launch index behind it -- no events, no copy kernels, no stand-alone

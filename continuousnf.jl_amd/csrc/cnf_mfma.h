@@ -36,8 +36,6 @@ struct MfmaLayout {
 
 struct MfmaPlan {
     int variant = 0;                // 0: shape not supported by the MFMA path
-    int schedule = 0;               // static shapes: 0 phase-per-layer (default, fastest measured),
-                                    // 1 fused narrow layers, 2 fused + ping-pong teams (CNF_MFMA_SCHEDULE)
     MfmaLayout ly{};
     float* d_img = nullptr;         // weight+bias image in HBM (LDS order), refreshed by pack
     const float* cond = nullptr;    // conditional models: per-sample first-layer bias [B][cbs] (owned by the handle)
@@ -63,9 +61,6 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd, bool train, cons
 //              stores the new state to st_out; otherwise the launch runs from st_in as is.
 //  finalize  : follow the launch by the one-block controller kernel (in place on the state
 //              slot the launch ran from), so that the host can poll an up-to-date state.
-cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st, float* const U[2],
-                                 float* const K1[2], const float* eps, float* partials_a, float* partials_b,
-                                 unsigned* gbar, int max_attempts, int B, hipStream_t s);
 cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st_in,
                      StepState* st_out, float* const U[2], float* const K1[2], float* const Ks[5],
                      const float* eps, const float* partials_in, float* partials_out, bool apply_ctrl,

@@ -41,11 +41,9 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// k_mfma geometry: 2 teams (one per 16-sample column tile) of MF_WPT waves.  4 -> 512 lanes,
-// 2 waves per SIMD, <= 256 VGPRs; 8 -> 1024 lanes, 4 waves per SIMD, <= 128 VGPRs.
-#ifndef MF_WPT
+// k_mfma geometry: 2 teams (one per 16-sample column tile) of MF_WPT = 4 waves: 512 lanes,
+// 2 waves per SIMD, <= 256 VGPRs.
 #define MF_WPT 4
-#endif
 #define MF_KTHREADS (MF_WPT * 128)
 
 struct MfmaArgs {
@@ -74,9 +72,6 @@ struct MfmaArgs {
     StepState* mirror;        // streamed solve: pinned host copy of the state after each controller run ...
     unsigned* mirror_seq;     //   ... published by storing this launch's index here (after the state)
     unsigned seq;
-    unsigned* gbar;           // persistent solve: grid-barrier counter (zeroed before the launch)
-    float* partials_b;        // persistent solve: second error-partials buffer (attempts alternate)
-    int max_attempts;         // persistent solve: attempts this launch may make
     float* dump;              // mode 2, gradient path: z rows of the stage states U_2..U_6 go to dump + (stage - 2) * dump_stride
     size_t dump_stride;       //   ([B][D] arrays like the state), else null
     size_t dump_step_stride;  // != 0: trajectory store indexed on the device -- this attempt files into the slot of step
@@ -413,31 +408,13 @@ __device__ __forceinline__ void gemm_bwd(f32x4& acc0, f32x4& acc1, int U, int SW
     }
 }
 
-// Team barrier.  The 8 waves form two teams of 4 (team = wave >> 2), one per 16-sample
-// column tile, and a SIMD hosts one wave of each team.  All synchronisation inside the
-// stage loop is team-local -- a monotonic arrival counter in LDS -- so the two teams drift
-// out of phase and one team's MFMA chains run while the other team sits in an epilogue, an
-// LDS round trip or a barrier.  (s_barrier would force both waves of every SIMD into the
-// same phase and leave the matrix pipe idle in every non-MFMA phase.)
-#ifndef MF_TEAM_SYNC
-#define MF_TEAM_SYNC 0   // 0: s_barrier (faster as measured); 1: team-local LDS barriers
-#endif
-__device__ __forceinline__ void team_barrier(unsigned* cnt, unsigned& gen, int lane) {
+// Phase barrier of the workgroup (both teams).  Team-local LDS barriers and a ping-pong of the two
+// teams were measured slower and are gone.
+__device__ __forceinline__ void team_barrier(unsigned*, unsigned&, int) {
 #ifdef MF_ABL_NOBAR
     return;
 #endif
-#if !MF_TEAM_SYNC
     __syncthreads();
-    return;
-#endif
-    gen += MF_WPT;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // my LDS writes are done
-    if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    int spins = 0;
-    while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - gen) < 0) {
-        if (++spins > (1 << 22)) break;                             // bounded: never hang the GPU
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 __device__ __forceinline__ float quad_sum(float v) {     // sum over the 4 lanes l, l^16, l^32, l^48
@@ -801,11 +778,6 @@ __device__ __forceinline__ void err_acc(float& errsum, float& badcnt, const f32x
 // partials one barrier later, off the critical path.
 // STEP = true: one Tsit5 step attempt (mode 2); STEP = false: one RHS evaluation (modes 0, 1).
 // Two instantiations so that profiles name the step kernel and the plain RHS kernel apart.
-// PERSIST = true (STEP only): ONE launch makes all attempts of an adaptive solve.  Every workgroup
-// keeps its tile, the weight image stays in LDS, and between attempts the workgroups meet at a grid
-// barrier (all are co-resident: the host launches cooperatively, one workgroup per CU), sum the error
-// partials in the same order and take the same controller decision -- the per-launch controller of the
-// queued-launch path, without relaunching, refilling LDS or speculative launches past the end.
 // Streamed solve: block 0 copies the integrator state to pinned host memory after every controller run and
 // then publishes the launch index; the host polls that word instead of waiting on events and copies.
 __device__ __forceinline__ void publish_mirror(const MfmaArgs& a, const StepState& z) {
@@ -822,10 +794,7 @@ __device__ __forceinline__ void publish_mirror(const MfmaArgs& a, const StepStat
     __hip_atomic_store(a.mirror_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Cross-workgroup traffic (error partials + arrival tags) uses agent-scope atomic loads/stores only:
-// release/acquire fences at agent scope write back / invalidate the XCD's whole L2 once per wave
-// (measured: 136 us per attempt instead of 57), a shared arrival counter serialises 256 atomics.
-template <class LY, bool STEP, bool PERSIST = false>
+template <class LY, bool STEP>
 __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StepState* st = a.st;
@@ -871,67 +840,8 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
     int cur = 0, nacc = 0;
     float hstep = 0.f, abstol = 0.f, reltol = 0.f;
     unsigned gen = 0;
-    // Runge-Kutta state of this lane's z rows (accumulator layout); declared out here so that a
-    // persistent solve carries it from one attempt to the next in registers
-    f32x4 uz0 = {0.f, 0.f, 0.f, 0.f}, uz1 = uz0, kz0[7], kz1[7], un0 = uz0, un1 = uz0, uns_keep = uz0;
-    int prev_cur = 0;
-    // persistent solve: the evolving part of the integrator state lives in 10 of the 12 spare LDS words
-    // behind the team counters (t, dt, qold, h, eest, cur, done, naccept, nreject, nonfinite); the rest
-    // of *st is constant during the launch
-    float* pst = lds + ly.bar_off() + 4;
-    auto pst_load = [&](StepState& z) {
-        z = *st;
-        z.t = pst[0]; z.dt = pst[1]; z.qold = pst[2]; z.h = pst[3]; z.eest = pst[4];
-        z.cur = __float_as_int(pst[5]); z.done = __float_as_int(pst[6]); z.naccept = __float_as_int(pst[7]);
-        z.nreject = __float_as_int(pst[8]); z.nonfinite = __float_as_int(pst[9]);
-    };
-    auto pst_store = [&](const StepState& z) {
-        pst[0] = z.t; pst[1] = z.dt; pst[2] = z.qold; pst[3] = z.h; pst[4] = z.eest;
-        pst[5] = __int_as_float(z.cur); pst[6] = __int_as_float(z.done); pst[7] = __int_as_float(z.naccept);
-        pst[8] = __int_as_float(z.nreject); pst[9] = __int_as_float(z.nonfinite);
-    };
-    if (PERSIST) {
-        __syncthreads();                          // zero fill done before the scratch is used
-        if (tid == 0) { StepState z = *st; pst_store(z); }
-    }
-  for (int attempt = 0;; ++attempt) {             // one pass unless PERSIST
-    if (PERSIST) {
-        if (attempt > 0) {
-            // Grid barrier and partial exchange in one: workgroup i published (error sum, bad count, tag =
-            // attempt) in slot i of the buffer of the previous attempt; thread i of every workgroup waits
-            // for slot i.  No read-modify-write on a shared counter (256 serialised atomics cost more than
-            // the relaunch they replace), no cache flushes: agent-scope loads/stores only.
-            const float* pin = ((attempt - 1) & 1) ? a.partials_b : a.partials;
-            float q0 = 0.f, q1 = 0.f;
-            if (tid < (int)gridDim.x) {
-                const float want = (float)attempt;
-                while (__hip_atomic_load(pin + 4 * tid + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want)
-                    __builtin_amdgcn_s_sleep(1);
-                q0 = __hip_atomic_load(pin + 4 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                q1 = __hip_atomic_load(pin + 4 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            for (int off = 32; off > 0; off >>= 1) { q0 += __shfl_down(q0, off, 64); q1 += __shfl_down(q1, off, 64); }
-            float* red = lds + ly.red_off();
-            if (lane == 0) { red[wave] = q0; red[16 + wave] = q1; }
-            __syncthreads();
-            if (tid == 0) {
-                float p0 = 0.f, p1 = 0.f;
-                for (int w = 0; w < MF_KTHREADS / 64; ++w) { p0 += red[w]; p1 += red[16 + w]; }
-                StepState z;
-                pst_load(z);
-                ctrl_after_step(&z, p0, p1, a.n_total);
-                pst_store(z);
-            }
-        }
-        __syncthreads();
-        cur = __float_as_int(pst[5]); hstep = pst[3]; abstol = st->abstol; reltol = st->reltol;
-        const bool stop = __float_as_int(pst[6]) != 0 || attempt >= a.max_attempts;
-        if (stop) {
-            if (blockIdx.x == 0 && tid == 0) { StepState z; pst_load(z); *a.st_out = z; }
-            return;
-        }
-        __syncthreads();                          // scratch (RED) is free again
-    } else
+    // Runge-Kutta state of this lane's z rows (accumulator layout)
+    f32x4 uz0 = {0.f, 0.f, 0.f, 0.f}, uz1 = uz0, kz0[7], kz1[7], un0 = uz0, un1 = uz0;
     if (STEP && a.apply_ctrl) {
         // In-kernel step controller: every workgroup reduces the same partials in the same
         // order and takes the same accept/reject decision; block 0 publishes the new state
@@ -986,9 +896,6 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
 #endif
     __syncthreads();       // image filled, counters zeroed
     STAMP(15);
-#if MF_TEAM_SYNC
-    if (team == 0) __builtin_amdgcn_s_setprio(2);
-#endif
 
     const int ntile = (a.B + MF_NB - 1) / MF_NB;
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -1006,19 +913,18 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         {
             // every global read of the prologue is issued before any of them is consumed
             const float* safe = a.img;
-            const bool fresh = !PERSIST || attempt == 0;
             const float* ep = a.eps ? a.eps + (size_t)(b0 + s) * n_in : nullptr;
             const int ce0 = (own0 && ep && live) ? nv0 : 0, ce1 = (own1 && ep && live) ? nv1 : 0;
-            const int cu0 = (fresh && own0 && live) ? nv0 : 0, cu1 = (fresh && own1 && live) ? nv1 : 0;
+            const int cu0 = (own0 && live) ? nv0 : 0, cu1 = (own1 && live) ? nv1 : 0;
             const int ck0 = K1in ? cu0 : 0, ck1 = K1in ? cu1 : 0;
-            const int cs0 = (fresh && sown && live) ? nsc : 0, cs1 = K1in ? cs0 : 0;
+            const int cs0 = (sown && live) ? nsc : 0, cs1 = K1in ? cs0 : 0;
             const f32x4 re0 = ld4_issue(ep + r00, ce0, safe), re1 = ld4_issue(ep + r01, ce1, safe);
             const f32x4 ru0 = ld4_issue(Uin + gcol + r00, cu0, safe), ru1 = ld4_issue(Uin + gcol + r01, cu1, safe);
             const f32x4 rk0 = ld4_issue(K1in + gcol + r00, ck0, safe), rk1 = ld4_issue(K1in + gcol + r01, ck1, safe);
             const f32x4 rs0 = ld4_issue(Uin + gcol + n_in, cs0, safe), rs1 = ld4_issue(K1in + gcol + n_in, cs1, safe);
             if (own0) *(f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r00) = ld4_mask(re0, ce0);
             if (own1) *(f32x4*)(lds + ly.eps_off() + row * ly.SX(0) + r01) = ld4_mask(re1, ce1);
-            if (fresh) {
+            {
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < 7; ++i) { kz0[i] = zero; kz1[i] = zero; }
@@ -1032,11 +938,6 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                 }
             }
         }
-        if (PERSIST && attempt > 0 && cur != prev_cur) {        // persistent solve, previous attempt accepted: u <- u_new, k1 <- k7 (FSAL)
-            uz0 = un0; uz1 = un1; kz0[0] = kz0[6]; kz1[0] = kz1[6];
-            if (sown) { sc_set(1, sc_get(7)); sc_set(0, uns_keep); }
-        }
-        prev_cur = cur;
         const int nstage = mode == 2 ? 6 : 1;
         un0 = uz0; un1 = uz1;
         // state of stage `stg` (z rows) -> region_0; the last stage's state is u_new (a7 = b)
@@ -1133,7 +1034,6 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                     for (int j = 0; j < 7; ++j) ks[j] = sc_get(1 + j);
                     const f32x4 us = sc_get(0);
                     const f32x4 uns = us + hstep * stage_acc4<6>(ks);
-                    uns_keep = uns;
                     st4(Un + n_in, uns, nsc); st4(K7 + n_in, ks[6], nsc);
                     err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, nsc);
                 }
@@ -1163,7 +1063,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         if (tid == 0) {
             float e = 0.f, b = 0.f;
             for (int w = 0; w < MF_KTHREADS / 64; ++w) { e += lds[ly.red_off() + w]; b += lds[ly.red_off() + 16 + w]; }
-            float* pout = (PERSIST && (attempt & 1)) ? a.partials_b : a.partials;
+            float* pout = a.partials;
             if (mode != 2) {
                 // initial-dt phase: partials through agent-scope atomics, then a ticket; whoever draws the last
                 // one sums all partials (fixed order) and runs the controller phase -- no separate launches
@@ -1173,13 +1073,6 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                 const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 lds[ly.red_off() + 40] = (tk == gridDim.x - 1) ? 1.f : 0.f;
                 if (tk == gridDim.x - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else
-            if (PERSIST) {
-                __hip_atomic_store(pout + 4 * blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pout + 4 * blockIdx.x + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // values first, then the tag that releases them
-                __hip_atomic_store(pout + 4 * blockIdx.x + 2, (float)(attempt + 1), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 pout[2 * blockIdx.x] = e;
                 pout[2 * blockIdx.x + 1] = b;
@@ -1205,936 +1098,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
             }
         }
     }
-    if (!PERSIST) break;
-    __syncthreads();        // thread 0 has read the RED scratch before the next attempt's controller reuses it
-  }
 }
-
-// =================================================================================================
-// Fused-phase kernel for compile-time layouts with n_in <= 32 (one or two 16-row state tiles).
-//
-// The narrow GEMMs at both ends of the network (last layer forward: n_in outputs; first layer
-// reverse: n_in outputs) keep only 1-2 of a team's 4 waves busy when they run as phases of
-// their own, and every phase costs a barrier, an LDS round trip and an epilogue.  Here they
-// are folded into their wide neighbours as split-K partial products taken straight from
-// registers (an accumulator tile IS the B operand of the next product over its rows):
-//   P1      h_1 = act(W_1 z)                       [... hidden layers ...]
-//   P(L-1)  h_{L-1} = act(W_{L-1} h_{L-2});  partial zdot_w = W_L[:, own rows] h_{L-1}[own rows]  -> scratch
-//   Pmid    every wave sums the 4 partials: zdot, g_L = eps .* sigma'_L (registers);
-//           g_{L-1} = (W_L^T g_L) .* sigma'  straight from those registers
-//   ...     reverse hidden layers ...
-//   Plast   g_1 (registers);  partial eJ_w = W_1^T[:, own rows] g_1[own rows]          -> scratch
-//   (the eJ partials are summed by otherwise idle waves at the start of the next evaluation)
-// Config 3: 4 barriers per evaluation instead of 7, every wave busy in every phase.
-template <int ACT, int... PD>
-struct FsLayout {
-    static constexpr bool kStatic = true;
-    static constexpr int kL = sizeof...(PD) - 1;
-    int n_in_, norm_z_, norm_j_;
-    __host__ __device__ static constexpr int pd(int l) { constexpr int a[] = {PD...}; return a[l]; }
-    __host__ __device__ static constexpr int L() { return kL; }
-    __host__ __device__ static constexpr int P(int l) { return pd(l); }
-    __host__ __device__ static constexpr int act(int) { return ACT; }
-    __host__ __device__ static constexpr int SW(int l) { return sw_of(pd(l)); }
-    __host__ __device__ static constexpr int SX(int l) { return sx_of(pd(l)); }
-    __host__ __device__ static constexpr int w_off(int l) {
-        int off = 0;
-        for (int i = 0; i < l; ++i) off += pd(i + 1) * sw_of(pd(i));
-        return off;
-    }
-    __host__ __device__ static constexpr int b_off(int l) {
-        int off = w_off(kL);
-        for (int i = 0; i < l; ++i) off += pd(i + 1);
-        return off;
-    }
-    __host__ __device__ static constexpr int img_floats() { return (b_off(kL) + 3) & ~3; }
-    __host__ __device__ static constexpr int x_off(int l) {          // regions 0 .. L-1 only
-        int off = img_floats();
-        for (int i = 0; i < l; ++i) off += MF_NB * sx_of(pd(i));
-        return off;
-    }
-    static constexpr int kNT0 = pd(0) / 16;
-    __host__ __device__ static constexpr int scr_off() { return x_off(kL); }   // zdot partials [team][wave][tile][16][16]
-    // eJ partials: with L >= 3 a barrier separates their last reader (phase 1) from the next
-    // zdot-partial writer (phase L-1), so they share the area; with L == 2 they need their own
-    __host__ __device__ static constexpr int scr2_off() { return scr_off() + (kL >= 3 ? 0 : 2 * 4 * kNT0 * 256); }
-    __host__ __device__ static constexpr int red_off() { return scr2_off() + 2 * 4 * kNT0 * 256; }
-    __host__ __device__ static constexpr int bar_off() { return red_off() + (3 * kNT0 * MF_NB < 16 ? 16 : 3 * kNT0 * MF_NB); }
-    __host__ __device__ static constexpr int total_floats() { return bar_off() + 16; }
-    __device__ __forceinline__ int n_in() const { return n_in_; }
-    __device__ __forceinline__ int norm_z() const { return norm_z_; }
-    __device__ __forceinline__ int norm_j() const { return norm_j_; }
-    static constexpr bool kOK = kL >= 2 && pd(0) <= 32 && pd(0) == pd(kL);
-};
-
-// 4 MFMAs: acc += A-block (row fragment a) x B (a register tile b)
-__device__ __forceinline__ f32x4 mfma_ab(const f32x4& a, const f32x4& b, f32x4 acc) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], acc, 0, 0, 0);
-    return acc;
-}
-
-template <class FS, bool STEP>
-__global__ void __launch_bounds__(MF_THREADS, 2) k_fused(FS ly, MfmaArgs a) {
-    static_assert(FS::kOK, "layout not fusable");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int L = FS::kL, NT0 = FS::kNT0;
-    const StepState* st = a.st;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_in = ly.n_in(), D = n_in + 3;
-    const int mode = STEP ? 2 : a.mode;
-    if (st && st->done) {
-        if (STEP && a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
-        return;
-    }
-    float cp0 = 0.f, cp1 = 0.f;
-    if (STEP && a.apply_ctrl) {
-        const int np = st->n_partials;
-        for (int i = tid; i < np; i += MF_THREADS) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
-    }
-    {   // weights + biases -> LDS, rest zeroed
-        constexpr int n = FS::img_floats();
-        int i = tid * 4;
-        for (; i + 3 * MF_THREADS * 4 < n; i += 4 * MF_THREADS * 4) {
-            const f32x4 v0 = *(const f32x4*)(a.img + i);
-            const f32x4 v1 = *(const f32x4*)(a.img + i + MF_THREADS * 4);
-            const f32x4 v2 = *(const f32x4*)(a.img + i + 2 * MF_THREADS * 4);
-            const f32x4 v3 = *(const f32x4*)(a.img + i + 3 * MF_THREADS * 4);
-            *(f32x4*)(lds + i) = v0;
-            *(f32x4*)(lds + i + MF_THREADS * 4) = v1;
-            *(f32x4*)(lds + i + 2 * MF_THREADS * 4) = v2;
-            *(f32x4*)(lds + i + 3 * MF_THREADS * 4) = v3;
-        }
-        for (; i < n; i += MF_THREADS * 4) *(f32x4*)(lds + i) = *(const f32x4*)(a.img + i);
-        for (int z = n + tid * 4; z < FS::total_floats(); z += MF_THREADS * 4)
-            *(f32x4*)(lds + z) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    int cur = 0;
-    float hstep = 0.f, abstol = 0.f, reltol = 0.f;
-    if (STEP && a.apply_ctrl) {
-        float* sc = lds + FS::bar_off() + 4;
-        __syncthreads();
-        for (int off = 32; off > 0; off >>= 1) { cp0 += __shfl_down(cp0, off, 64); cp1 += __shfl_down(cp1, off, 64); }
-        float* red = lds + FS::red_off();
-        if (lane == 0) { red[wave] = cp0; red[8 + wave] = cp1; }
-        __syncthreads();
-        if (tid == 0) {
-            float p0 = 0.f, p1 = 0.f;
-            for (int w = 0; w < MF_THREADS / 64; ++w) { p0 += red[w]; p1 += red[8 + w]; }
-            StepState ns = *st;
-            ctrl_after_step(&ns, p0, p1, a.n_total);
-            if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
-            sc[0] = __int_as_float(ns.cur); sc[1] = ns.h; sc[2] = ns.abstol; sc[3] = ns.reltol;
-            sc[4] = __int_as_float(ns.done);
-        }
-        __syncthreads();
-        cur = __float_as_int(sc[0]); hstep = sc[1]; abstol = sc[2]; reltol = sc[3];
-        if (__float_as_int(sc[4])) return;
-        __syncthreads();
-    } else if (st) {
-        cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol;
-    }
-
-    constexpr int TNB = MF_NB / 2;
-    const int team = wave >> 2, fg = (wave + 2 * team) & 3;
-    const int s = lane & 15, q = lane >> 4;
-    const int row = TNB * team + s;
-    const bool own = fg < NT0;                       // owns z-row tile fg
-    const bool sown = fg == 0 && q == 0;             // owns the scalar rows of sample s
-    const int r0 = 16 * fg + 4 * q;
-    const int nv = own ? n_in - r0 : 0;
-    const float* Uin = mode == 0 ? a.u : a.U[cur];
-    const float* K1in = mode == 0 ? nullptr : a.K1[cur];
-    float errsum = 0.f, badcnt = 0.f;
-    float* scr = lds + FS::scr_off() + team * (4 * NT0 * 256);
-    float* scr2 = lds + FS::scr2_off() + team * (4 * NT0 * 256);
-    float* red = lds + FS::red_off();
-#ifdef MF_STAMPS
-    unsigned long long stamps[48] = {0};
-    unsigned long long tlast = __builtin_amdgcn_s_memtime();
-    const unsigned long long tstart = tlast;
-#endif
-    __syncthreads();
-    STAMP(0);
-
-    const int ntile = (a.B + MF_NB - 1) / MF_NB;
-    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const int b0 = tile * MF_NB + TNB * team;
-        const int nvalid = max(0, min(TNB, a.B - b0));
-        const bool live = s < nvalid;
-        const size_t gcol = (size_t)(b0 + s) * D;
-        // eps of this lane's sample, all NT0 row tiles, accumulator layout
-        f32x4 ev[NT0];
-#pragma unroll
-        for (int t = 0; t < NT0; ++t)
-            ev[t] = live ? ld4(a.eps + (size_t)(b0 + s) * n_in + 16 * t + 4 * q, n_in - (16 * t + 4 * q))
-                         : f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 uz = {0.f, 0.f, 0.f, 0.f}, kz[7], us = uz, ks[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) { kz[i] = uz; ks[i] = uz; }
-        if (live) {
-            if (own) uz = ld4(Uin + gcol + r0, nv);
-            if (sown) us = ld4(Uin + gcol + n_in, 3);
-            if (K1in) {
-                if (own) kz[0] = ld4(K1in + gcol + r0, nv);
-                if (sown) ks[0] = ld4(K1in + gcol + n_in, 3);
-            }
-        }
-        const int nstage = mode == 2 ? 6 : 1;
-        f32x4 un = uz;
-        auto put_stage = [&](int stg) {
-            if (own) {
-                if (mode == 1) un = uz + hstep * kz[0];
-                else if (mode == 2) un = uz + hstep * stage_acc4_rt(stg, kz);
-                *(f32x4*)(lds + FS::x_off(0) + row * FS::SX(0) + r0) = un;
-            }
-        };
-        // sum of the eJ partials of the previous evaluation -> trace / norm partials in RED
-        auto reduce_eJ = [&]() {
-#pragma unroll
-            for (int kt = 0; kt < NT0; ++kt) {
-                if (fg == 3 - kt) {
-                    constexpr int NW = FS::P(1) / 16 < 4 ? FS::P(1) / 16 : 4;
-                    f32x4 e = *(const f32x4*)(scr2 + ((0 * NT0 + kt) * 16 + s) * 16 + 4 * q);
-#pragma unroll
-                    for (int w = 1; w < NW; ++w) e += *(const f32x4*)(scr2 + ((w * NT0 + kt) * 16 + s) * 16 + 4 * q);
-                    float ld = -(e.x * ev[kt].x + e.y * ev[kt].y + e.z * ev[kt].z + e.w * ev[kt].w);
-                    float n2 = e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
-                    ld = quad_sum(ld);
-                    n2 = quad_sum(n2);
-                    if (q == 0) { red[(NT0 + kt) * MF_NB + row] = ld; red[(2 * NT0 + kt) * MF_NB + row] = n2; }
-                }
-            }
-        };
-        float e2s = 0.f;                       // scalar owner: |zdot|^2 of the previous evaluation
-        auto read_E = [&]() { e2s = 0.f; for (int t = 0; t < NT0; ++t) e2s += red[t * MF_NB + row]; };
-        auto read_ln = [&]() {
-            float ld = 0.f, n2 = 0.f;
-            for (int t = 0; t < NT0; ++t) { ld += red[(NT0 + t) * MF_NB + row]; n2 += red[(2 * NT0 + t) * MF_NB + row]; }
-            return f32x4{ld, ly.norm_z() ? __builtin_sqrtf(e2s) : 0.f, ly.norm_j() ? __builtin_sqrtf(n2) : 0.f, 0.f};
-        };
-        put_stage(1);
-        __syncthreads();
-        STAMP(1);
-
-        for (int stg = 1; stg <= nstage; ++stg) {
-            f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;     // this wave's tiles of the current layer (registers)
-            // A fragments (weights: independent of any barrier) requested one phase early
-            f32x4 ra0[NT0], ra1[NT0];                     // W_L^T columns for the reverse of the last layer
-            // ---------------- forward hidden layers 0 .. L-2 ----------------
-            static_for_up<0, L - 1>([&](auto lc) {
-                constexpr int l = decltype(lc)::value;
-                constexpr int ntiles = FS::P(l + 1) / 16, U = FS::P(l) / 16, SW = FS::SW(l);
-                static_assert(ntiles <= 8, "one pass per layer");
-                if (l == 0 && stg > 1) {
-                    if (sown) read_E();
-                    reduce_eJ();
-                }
-                const float* xb = lds + FS::x_off(l) + row * FS::SX(l) + 4 * q;
-                const float* W = lds + FS::w_off(l);
-                const int t0 = fg, t1 = fg + 4;
-                const bool has = t0 < ntiles, two = t1 < ntiles;
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-                f32x4 pa0[NT0], pa1[NT0];                 // W_L row fragments for the split-K partial
-                if (l == L - 2 && has) {
-                    constexpr int SWL = FS::SW(L - 1);
-                    const float* WL = lds + FS::w_off(L - 1);
-#pragma unroll
-                    for (int ot = 0; ot < NT0; ++ot) {
-                        pa0[ot] = *(const f32x4*)(WL + (16 * ot + s) * SWL + 16 * t0 + 4 * q);
-                        if (two) pa1[ot] = *(const f32x4*)(WL + (16 * ot + s) * SWL + 16 * t1 + 4 * q);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (has) {
-                    const float* wa0 = W + (16 * t0 + s) * SW + 4 * q;
-                    const float* wa1 = W + (16 * t1 + s) * SW + 4 * q;
-                    STAMP(41);
-                    if (two) fwd_body<U, 2>(acc0, acc1, xb, wa0, wa1);
-                    else { fwd_body<U, 1>(acc0, acc1, xb, wa0, wa1); acc0 += acc1; }
-                    STAMP(42 + (l == L - 2 ? 1 : 0));
-                    const f32x4 bv0 = *(const f32x4*)(lds + FS::b_off(l) + 16 * t0 + 4 * q);
-                    f32x4 dd_;
-                    act4(FS::act(l), acc0 + bv0, h0, dd_);
-                    *(f32x4*)(lds + FS::x_off(l + 1) + row * FS::SX(l + 1) + 16 * t0 + 4 * q) = h0;
-                    if (two) {
-                        const f32x4 bv1 = *(const f32x4*)(lds + FS::b_off(l) + 16 * t1 + 4 * q);
-                        act4(FS::act(l), acc1 + bv1, h1, dd_);
-                        *(f32x4*)(lds + FS::x_off(l + 1) + row * FS::SX(l + 1) + 16 * t1 + 4 * q) = h1;
-                    }
-                }
-                STAMP(4 + 4 * l);
-                if (l == L - 2) {
-                    // split-K partial of the last layer from the register tiles:
-                    // zdot_w[ot] = W_L[ot, own rows] h[own rows]; NT0 independent chains, interleaved
-                    if (has) {
-                        f32x4 pz[NT0];
-#pragma unroll
-                        for (int ot = 0; ot < NT0; ++ot) pz[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-#pragma unroll
-                            for (int ot = 0; ot < NT0; ++ot)
-                                pz[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa0[ot][c], h0[c], pz[ot], 0, 0, 0);
-                        if (two) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                                for (int ot = 0; ot < NT0; ++ot)
-                                    pz[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa1[ot][c], h1[c], pz[ot], 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int ot = 0; ot < NT0; ++ot)
-                            *(f32x4*)(scr + ((fg * NT0 + ot) * 16 + s) * 16 + 4 * q) = pz[ot];
-                    }
-                    // weights for the reverse of the last layer: requested before the barrier
-                    {
-                        constexpr int SWr = FS::SW(L - 1);
-                        const float* Wr = lds + FS::w_off(L - 1);
-                        constexpr int ntr = FS::P(L - 1) / 16;
-                        if (fg < ntr) {
-#pragma unroll
-                            for (int u = 0; u < NT0; ++u) {
-                                const float* p0 = Wr + (16 * u + 4 * q) * SWr + 16 * fg + s;
-                                ra0[u] = f32x4{p0[0], p0[SWr], p0[2 * SWr], p0[3 * SWr]};
-                                if (fg + 4 < ntr) {
-                                    const float* p1 = p0 + 64;
-                                    ra1[u] = f32x4{p1[0], p1[SWr], p1[2 * SWr], p1[3 * SWr]};
-                                }
-                            }
-                        }
-                    }
-                }
-                STAMP(5 + 4 * l);
-                __syncthreads();
-                STAMP(6 + 4 * l);
-                if (l == 0 && stg > 1 && sown) set_k(ks, stg - 1, read_ln());
-            });
-            // ---------------- middle: zdot, g_L; reverse of the last layer from registers ----------------
-            f32x4 gL[NT0];
-            {
-                constexpr int NW = FS::P(L - 1) / 16 < 4 ? FS::P(L - 1) / 16 : 4;
-                f32x4 zp[NT0][NW], bvv[NT0];
-#pragma unroll
-                for (int ot = 0; ot < NT0; ++ot) {
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) zp[ot][w] = *(const f32x4*)(scr + ((w * NT0 + ot) * 16 + s) * 16 + 4 * q);
-                    bvv[ot] = *(const f32x4*)(lds + FS::b_off(L - 1) + 16 * ot + 4 * q);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ot = 0; ot < NT0; ++ot) {
-                    f32x4 z = zp[ot][0];
-#pragma unroll
-                    for (int w = 1; w < NW; ++w) z += zp[ot][w];
-                    const f32x4 bv = bvv[ot];
-                    f32x4 zd, dd;
-                    act4(FS::act(L - 1), z + bv, zd, dd);
-                    gL[ot] = ev[ot] * dd;           // eps is zero on padding rows -> g_L too
-                    if (fg == ot) {
-                        const int rr = 16 * ot + 4 * q;
-                        zd = f32x4{rr + 0 < n_in ? zd.x : 0.f, rr + 1 < n_in ? zd.y : 0.f,
-                                   rr + 2 < n_in ? zd.z : 0.f, rr + 3 < n_in ? zd.w : 0.f};
-                        const float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
-                        if (q == 0) red[ot * MF_NB + row] = e2;
-                        if (mode == 2) { set_k(kz, stg, zd); if (stg < nstage) put_stage(stg + 1); }
-                        else kz[1] = zd;
-                    }
-                }
-            }
-            STAMP(20);
-            // reverse sweep, layers L-1 .. 1; output tiles of layer l's input (P(l) rows)
-            static_for_down<L - 1>([&](auto lc) {
-                constexpr int l = decltype(lc)::value;
-                if constexpr (l >= 1) {
-                    constexpr int ntiles = FS::P(l) / 16, SW = FS::SW(l);
-                    static_assert(ntiles <= 8, "one pass per layer");
-                    const float* W = lds + FS::w_off(l);
-                    const int t0 = fg, t1 = fg + 4;
-                    const bool has = t0 < ntiles, two = t1 < ntiles;
-                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-                    f32x4 g0 = acc0, g1 = acc0;
-                    f32x4 ea0[NT0], ea1[NT0];             // W_1^T fragments for the split-K partial of eJ
-                    if (l == 1 && has) {
-                        constexpr int SW0 = FS::SW(0);
-                        const float* W0 = lds + FS::w_off(0);
-#pragma unroll
-                        for (int kt = 0; kt < NT0; ++kt) {
-                            const float* p0 = W0 + (16 * t0 + 4 * q) * SW0 + 16 * kt + s;
-                            ea0[kt] = f32x4{p0[0], p0[SW0], p0[2 * SW0], p0[3 * SW0]};
-                            if (two) {
-                                const float* p1 = W0 + (16 * t1 + 4 * q) * SW0 + 16 * kt + s;
-                                ea1[kt] = f32x4{p1[0], p1[SW0], p1[2 * SW0], p1[3 * SW0]};
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (has) {
-                        const float* wc0 = W + (4 * q) * SW + 16 * t0 + s;
-                        const float* wc1 = W + (4 * q) * SW + 16 * t1 + s;
-                        if constexpr (l == L - 1) {
-                            // B operand = g_L register tiles, A = fragments requested before the barrier
-#pragma unroll
-                            for (int u = 0; u < NT0; ++u)
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) {
-                                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[u][c], gL[u][c], acc0, 0, 0, 0);
-                                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[u][c], gL[u][c], acc1, 0, 0, 0);
-                                }
-                        } else {
-                            constexpr int U = FS::P(l + 1) / 16;
-                            const float* gb = lds + FS::x_off(l + 1) + row * FS::SX(l + 1) + 4 * q;
-                            if (two) bwd_body<U, 2>(acc0, acc1, SW, gb, wc0, wc1);
-                            else { bwd_body<U, 1>(acc0, acc1, SW, gb, wc0, wc1); acc0 += acc1; }
-                        }
-                        // g_l = acc .* sigma'(h_l), h_l read back from region_l at this lane's own position
-                        float* o0 = lds + FS::x_off(l) + row * FS::SX(l) + 16 * t0 + 4 * q;
-                        const f32x4 hv0 = *(const f32x4*)o0;
-                        g0 = f32x4{acc0.x * d_from_h(FS::act(l - 1), hv0.x), acc0.y * d_from_h(FS::act(l - 1), hv0.y),
-                                   acc0.z * d_from_h(FS::act(l - 1), hv0.z), acc0.w * d_from_h(FS::act(l - 1), hv0.w)};
-                        if (l > 1) *(f32x4*)o0 = g0;
-                        if (two) {
-                            float* o1 = lds + FS::x_off(l) + row * FS::SX(l) + 16 * t1 + 4 * q;
-                            const f32x4 hv1 = *(const f32x4*)o1;
-                            g1 = f32x4{acc1.x * d_from_h(FS::act(l - 1), hv1.x), acc1.y * d_from_h(FS::act(l - 1), hv1.y),
-                                       acc1.z * d_from_h(FS::act(l - 1), hv1.z), acc1.w * d_from_h(FS::act(l - 1), hv1.w)};
-                            if (l > 1) *(f32x4*)o1 = g1;
-                        }
-                        STAMP(24 + 4 * l);
-                        if constexpr (l == 1) {
-                            // split-K partial of eJ = W_1^T g_1 from the register tiles (NT0 chains)
-                            f32x4 pe[NT0];
-#pragma unroll
-                            for (int kt = 0; kt < NT0; ++kt) pe[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                                for (int kt = 0; kt < NT0; ++kt)
-                                    pe[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0[kt][c], g0[c], pe[kt], 0, 0, 0);
-                            if (two) {
-#pragma unroll
-                                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                                    for (int kt = 0; kt < NT0; ++kt)
-                                        pe[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1[kt][c], g1[c], pe[kt], 0, 0, 0);
-                            }
-#pragma unroll
-                            for (int kt = 0; kt < NT0; ++kt)
-                                *(f32x4*)(scr2 + ((fg * NT0 + kt) * 16 + s) * 16 + 4 * q) = pe[kt];
-                        }
-                    }
-                    STAMP(25 + 4 * l);
-                    __syncthreads();
-                    STAMP(26 + 4 * l);
-                }
-            });
-        }
-        // last evaluation: eJ partials -> RED, then the scalar rows
-        if (sown) read_E();
-        reduce_eJ();
-        __syncthreads();
-        if (sown) {
-            const f32x4 v = read_ln();
-            if (mode == 2) ks[6] = v; else ks[1] = v;
-        }
-        // ---- outputs ----
-        if (live) {
-            if (mode == 0 || mode == 1) {
-                float* out = (mode == 0 ? a.du : a.Ks0) + gcol;
-                if (own) st4(out + r0, kz[1], nv);
-                if (sown) st4(out + n_in, ks[1], 3);
-            } else {
-                float* Un = a.U[1 - cur] + gcol;
-                float* K7 = a.K1[1 - cur] + gcol;
-                if (own) {
-                    st4(Un + r0, un, nv); st4(K7 + r0, kz[6], nv);
-                    err_acc(errsum, badcnt, kz, uz, un, hstep, abstol, reltol, nv);
-                }
-                if (sown) {
-                    const f32x4 uns = us + hstep * stage_acc4<6>(ks);
-                    st4(Un + n_in, uns, 3); st4(K7 + n_in, ks[6], 3);
-                    err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
-                }
-            }
-        }
-        __syncthreads();      // RED / scratch reads of this tile precede the next tile's writes
-    }
-#ifdef MF_STAMPS
-    STAMP(40);
-    if (blockIdx.x == 0 && lane == 0 && mode == 2) {
-        printf("wave %d total %llu fill %llu pre %llu tail %llu | P1 g+e %llu wait %llu | P2 g+e %llu part %llu wait %llu | mid %llu | B3(l=2) g+e %llu wait %llu | B2(l=1) g+e %llu part %llu wait %llu || pre-gemm %llu gemmP1 %llu gemmP2 %llu\n",
-               wave, tlast - tstart, stamps[0], stamps[1], stamps[40], stamps[4] + stamps[5], stamps[6], stamps[8], stamps[9], stamps[10],
-               stamps[20], stamps[32] + stamps[33], stamps[34], stamps[28], stamps[29], stamps[30], stamps[41], stamps[42], stamps[43]);
-    }
-#endif
-    if (mode == 2) {
-        for (int off = 32; off > 0; off >>= 1) {
-            errsum += __shfl_down(errsum, off, 64);
-            badcnt += __shfl_down(badcnt, off, 64);
-        }
-        if (lane == 0) { red[wave] = errsum; red[8 + wave] = badcnt; }
-        __syncthreads();
-        if (tid == 0) {
-            float e = 0.f, b = 0.f;
-            for (int w = 0; w < MF_THREADS / 64; ++w) { e += red[w]; b += red[8 + w]; }
-            a.partials[2 * blockIdx.x] = e;
-            a.partials[2 * blockIdx.x + 1] = b;
-        }
-    }
-}
-
-// Ping-pong variant of k_fused (same layout, same arithmetic, different schedule).
-template <class FS, bool STEP>
-__global__ void __launch_bounds__(MF_THREADS, 2) k_pp(FS ly, MfmaArgs a) {
-    static_assert(FS::kOK, "layout not fusable");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int L = FS::kL, NT0 = FS::kNT0;
-    const StepState* st = a.st;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_in = ly.n_in(), D = n_in + 3;
-    const int mode = STEP ? 2 : a.mode;
-    if (st && st->done) {
-        if (STEP && a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
-        return;
-    }
-    float cp0 = 0.f, cp1 = 0.f;
-    if (STEP && a.apply_ctrl) {
-        const int np = st->n_partials;
-        for (int i = tid; i < np; i += MF_THREADS) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
-    }
-    {   // weights + biases -> LDS, rest zeroed
-        constexpr int n = FS::img_floats();
-        int i = tid * 4;
-        for (; i + 3 * MF_THREADS * 4 < n; i += 4 * MF_THREADS * 4) {
-            const f32x4 v0 = *(const f32x4*)(a.img + i);
-            const f32x4 v1 = *(const f32x4*)(a.img + i + MF_THREADS * 4);
-            const f32x4 v2 = *(const f32x4*)(a.img + i + 2 * MF_THREADS * 4);
-            const f32x4 v3 = *(const f32x4*)(a.img + i + 3 * MF_THREADS * 4);
-            *(f32x4*)(lds + i) = v0;
-            *(f32x4*)(lds + i + MF_THREADS * 4) = v1;
-            *(f32x4*)(lds + i + 2 * MF_THREADS * 4) = v2;
-            *(f32x4*)(lds + i + 3 * MF_THREADS * 4) = v3;
-        }
-        for (; i < n; i += MF_THREADS * 4) *(f32x4*)(lds + i) = *(const f32x4*)(a.img + i);
-        for (int z = n + tid * 4; z < FS::total_floats(); z += MF_THREADS * 4)
-            *(f32x4*)(lds + z) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    int cur = 0;
-    float hstep = 0.f, abstol = 0.f, reltol = 0.f;
-    if (STEP && a.apply_ctrl) {
-        float* sc = lds + FS::bar_off() + 4;
-        __syncthreads();
-        for (int off = 32; off > 0; off >>= 1) { cp0 += __shfl_down(cp0, off, 64); cp1 += __shfl_down(cp1, off, 64); }
-        float* red = lds + FS::red_off();
-        if (lane == 0) { red[wave] = cp0; red[8 + wave] = cp1; }
-        __syncthreads();
-        if (tid == 0) {
-            float p0 = 0.f, p1 = 0.f;
-            for (int w = 0; w < MF_THREADS / 64; ++w) { p0 += red[w]; p1 += red[8 + w]; }
-            StepState ns = *st;
-            ctrl_after_step(&ns, p0, p1, a.n_total);
-            if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
-            sc[0] = __int_as_float(ns.cur); sc[1] = ns.h; sc[2] = ns.abstol; sc[3] = ns.reltol;
-            sc[4] = __int_as_float(ns.done);
-        }
-        __syncthreads();
-        cur = __float_as_int(sc[0]); hstep = sc[1]; abstol = sc[2]; reltol = sc[3];
-        if (__float_as_int(sc[4])) return;
-        __syncthreads();
-    } else if (st) {
-        cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol;
-    }
-
-    constexpr int TNB = MF_NB / 2;
-    const int team = wave >> 2, fg = (wave + 2 * team) & 3;
-    const int s = lane & 15, q = lane >> 4;
-    const int row = TNB * team + s;
-    const bool own = fg < NT0;                       // owns z-row tile fg
-    const bool sown = fg == 0 && q == 0;             // owns the scalar rows of sample s
-    const int r0 = 16 * fg + 4 * q;
-    const int nv = own ? n_in - r0 : 0;
-    const float* Uin = mode == 0 ? a.u : a.U[cur];
-    const float* K1in = mode == 0 ? nullptr : a.K1[cur];
-    float errsum = 0.f, badcnt = 0.f;
-    float* scr = lds + FS::scr_off() + team * (4 * NT0 * 256);
-    float* scr2 = lds + FS::scr2_off() + team * (4 * NT0 * 256);
-    float* red = lds + FS::red_off();
-    __syncthreads();
-
-    const int ntile = (a.B + MF_NB - 1) / MF_NB;
-    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const int b0 = tile * MF_NB + TNB * team;
-        const int nvalid = max(0, min(TNB, a.B - b0));
-        const bool live = s < nvalid;
-        const size_t gcol = (size_t)(b0 + s) * D;
-        // eps of this lane's sample, all NT0 row tiles, accumulator layout
-        f32x4 ev[NT0];
-#pragma unroll
-        for (int t = 0; t < NT0; ++t)
-            ev[t] = live ? ld4(a.eps + (size_t)(b0 + s) * n_in + 16 * t + 4 * q, n_in - (16 * t + 4 * q))
-                         : f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 uz = {0.f, 0.f, 0.f, 0.f}, kz[7], us = uz, ks[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) { kz[i] = uz; ks[i] = uz; }
-        if (live) {
-            if (own) uz = ld4(Uin + gcol + r0, nv);
-            if (sown) us = ld4(Uin + gcol + n_in, 3);
-            if (K1in) {
-                if (own) kz[0] = ld4(K1in + gcol + r0, nv);
-                if (sown) ks[0] = ld4(K1in + gcol + n_in, 3);
-            }
-        }
-        const int nstage = mode == 2 ? 6 : 1;
-        f32x4 un = uz;
-        auto put_stage = [&](int stg) {
-            if (own) {
-                if (mode == 1) un = uz + hstep * kz[0];
-                else if (mode == 2) un = uz + hstep * stage_acc4_rt(stg, kz);
-                *(f32x4*)(lds + FS::x_off(0) + row * FS::SX(0) + r0) = un;
-            }
-        };
-        // sum of the eJ partials of the previous evaluation -> trace / norm partials in RED
-        auto reduce_eJ = [&]() {
-#pragma unroll
-            for (int kt = 0; kt < NT0; ++kt) {
-                if (fg == 3 - kt) {
-                    constexpr int NW = FS::P(1) / 16 < 4 ? FS::P(1) / 16 : 4;
-                    f32x4 e = *(const f32x4*)(scr2 + ((0 * NT0 + kt) * 16 + s) * 16 + 4 * q);
-#pragma unroll
-                    for (int w = 1; w < NW; ++w) e += *(const f32x4*)(scr2 + ((w * NT0 + kt) * 16 + s) * 16 + 4 * q);
-                    float ld = -(e.x * ev[kt].x + e.y * ev[kt].y + e.z * ev[kt].z + e.w * ev[kt].w);
-                    float n2 = e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
-                    ld = quad_sum(ld);
-                    n2 = quad_sum(n2);
-                    if (q == 0) { red[(NT0 + kt) * MF_NB + row] = ld; red[(2 * NT0 + kt) * MF_NB + row] = n2; }
-                }
-            }
-        };
-        float e2s = 0.f;                       // scalar owner: |zdot|^2 of the previous evaluation
-        auto read_E = [&]() { e2s = 0.f; for (int t = 0; t < NT0; ++t) e2s += red[t * MF_NB + row]; };
-        auto read_ln = [&]() {
-            float ld = 0.f, n2 = 0.f;
-            for (int t = 0; t < NT0; ++t) { ld += red[(NT0 + t) * MF_NB + row]; n2 += red[(2 * NT0 + t) * MF_NB + row]; }
-            return f32x4{ld, ly.norm_z() ? __builtin_sqrtf(e2s) : 0.f, ly.norm_j() ? __builtin_sqrtf(n2) : 0.f, 0.f};
-        };
-        put_stage(1);
-        __syncthreads();
-
-        // ------------------------------------------------------------------------------------------
-        // Ping-pong schedule.  Every phase of an evaluation is cut into a G sub-step (LDS operand
-        // reads + the MFMA chain) and an E sub-step (activation epilogue, LDS writes, the small
-        // split-K products).  Team 1 runs one sub-step behind team 0, so in every barrier
-        // interval one team of a SIMD's two waves is in a G sub-step and the other in an E
-        // sub-step: the matrix pipe sees one MFMA chain at a time, back to back, instead of two
-        // chains together followed by two epilogues together.
-        //   sub-steps: fwd layer l: G 2l, E 2l+1 (l = 0..L-2) | last layer reverse from registers:
-        //   G 2(L-1), E 2(L-1)+1 | reverse layers l = L-2..1: G, E
-        // ------------------------------------------------------------------------------------------
-        constexpr int NSUB = 4 * (L - 1);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;     // carried from a G sub-step to its E sub-step
-        f32x4 pa0[NT0], pa1[NT0], ra0[NT0], ra1[NT0], ea0[NT0], ea1[NT0];
-#pragma unroll
-        for (int t = 0; t < NT0; ++t) { pa0[t] = acc0; pa1[t] = acc0; ra0[t] = acc0; ra1[t] = acc0; ea0[t] = acc0; ea1[t] = acc0; }
-        int stg = 1;
-
-        // ---- forward hidden layer l: G ----
-        auto fwdG = [&](auto lc) {
-            constexpr int l = decltype(lc)::value;
-            constexpr int ntiles = FS::P(l + 1) / 16, U = FS::P(l) / 16, SW = FS::SW(l);
-            static_assert(ntiles <= 8, "one pass per layer");
-            if (l == 0 && stg > 1) {
-                if (sown) read_E();
-                reduce_eJ();
-            }
-            const float* xb = lds + FS::x_off(l) + row * FS::SX(l) + 4 * q;
-            const float* W = lds + FS::w_off(l);
-            const int t0 = fg, t1 = fg + 4;
-            const bool has = t0 < ntiles, two = t1 < ntiles;
-            acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0;
-            if (l == L - 2 && has) {
-                constexpr int SWL = FS::SW(L - 1);
-                const float* WL = lds + FS::w_off(L - 1);
-#pragma unroll
-                for (int ot = 0; ot < NT0; ++ot) {
-                    pa0[ot] = *(const f32x4*)(WL + (16 * ot + s) * SWL + 16 * t0 + 4 * q);
-                    if (two) pa1[ot] = *(const f32x4*)(WL + (16 * ot + s) * SWL + 16 * t1 + 4 * q);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (has) {
-                const float* wa0 = W + (16 * t0 + s) * SW + 4 * q;
-                const float* wa1 = W + (16 * t1 + s) * SW + 4 * q;
-                if (two) fwd_body<U, 2>(acc0, acc1, xb, wa0, wa1);
-                else { fwd_body<U, 1>(acc0, acc1, xb, wa0, wa1); acc0 += acc1; }
-            }
-        };
-        // ---- forward hidden layer l: E ----
-        auto fwdE = [&](auto lc) {
-            constexpr int l = decltype(lc)::value;
-            constexpr int ntiles = FS::P(l + 1) / 16;
-            if (l == 0 && stg > 1 && sown) set_k(ks, stg - 1, read_ln());
-            const int t0 = fg, t1 = fg + 4;
-            const bool has = t0 < ntiles, two = t1 < ntiles;
-            f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0, dd_;
-            if (has) {
-                const f32x4 bv0 = *(const f32x4*)(lds + FS::b_off(l) + 16 * t0 + 4 * q);
-                act4(FS::act(l), acc0 + bv0, h0, dd_);
-                *(f32x4*)(lds + FS::x_off(l + 1) + row * FS::SX(l + 1) + 16 * t0 + 4 * q) = h0;
-                if (two) {
-                    const f32x4 bv1 = *(const f32x4*)(lds + FS::b_off(l) + 16 * t1 + 4 * q);
-                    act4(FS::act(l), acc1 + bv1, h1, dd_);
-                    *(f32x4*)(lds + FS::x_off(l + 1) + row * FS::SX(l + 1) + 16 * t1 + 4 * q) = h1;
-                }
-            }
-            if (l == L - 2) {
-                if (has) {
-                    f32x4 pz[NT0];
-#pragma unroll
-                    for (int ot = 0; ot < NT0; ++ot) pz[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int ot = 0; ot < NT0; ++ot)
-                            pz[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa0[ot][c], h0[c], pz[ot], 0, 0, 0);
-                    if (two) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-#pragma unroll
-                            for (int ot = 0; ot < NT0; ++ot)
-                                pz[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa1[ot][c], h1[c], pz[ot], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int ot = 0; ot < NT0; ++ot)
-                        *(f32x4*)(scr + ((fg * NT0 + ot) * 16 + s) * 16 + 4 * q) = pz[ot];
-                }
-                constexpr int SWr = FS::SW(L - 1);
-                const float* Wr = lds + FS::w_off(L - 1);
-                constexpr int ntr = FS::P(L - 1) / 16;
-                if (fg < ntr) {
-#pragma unroll
-                    for (int u = 0; u < NT0; ++u) {
-                        const float* p0 = Wr + (16 * u + 4 * q) * SWr + 16 * fg + s;
-                        ra0[u] = f32x4{p0[0], p0[SWr], p0[2 * SWr], p0[3 * SWr]};
-                        if (fg + 4 < ntr) {
-                            const float* p1 = p0 + 64;
-                            ra1[u] = f32x4{p1[0], p1[SWr], p1[2 * SWr], p1[3 * SWr]};
-                        }
-                    }
-                }
-            }
-        };
-        // ---- reverse layer l (input side P(l) rows): prefetch of the eJ-partial fragments ----
-        auto load_ea = [&](int t0, int t1, bool two) {
-            constexpr int SW0 = FS::SW(0);
-            const float* W0 = lds + FS::w_off(0);
-#pragma unroll
-            for (int kt = 0; kt < NT0; ++kt) {
-                const float* p0 = W0 + (16 * t0 + 4 * q) * SW0 + 16 * kt + s;
-                ea0[kt] = f32x4{p0[0], p0[SW0], p0[2 * SW0], p0[3 * SW0]};
-                if (two) {
-                    const float* p1 = W0 + (16 * t1 + 4 * q) * SW0 + 16 * kt + s;
-                    ea1[kt] = f32x4{p1[0], p1[SW0], p1[2 * SW0], p1[3 * SW0]};
-                }
-            }
-        };
-        // ---- middle G: zdot, g_L, next stage state; reverse of the last layer from registers ----
-        auto midG = [&]() {
-            constexpr int NW = FS::P(L - 1) / 16 < 4 ? FS::P(L - 1) / 16 : 4;
-            constexpr int l = L - 1;
-            constexpr int ntiles = FS::P(l) / 16;
-            const int t0 = fg, t1 = fg + 4;
-            const bool has = t0 < ntiles, two = t1 < ntiles;
-            f32x4 zp[NT0][NW], bvv[NT0], gL[NT0];
-#pragma unroll
-            for (int ot = 0; ot < NT0; ++ot) {
-#pragma unroll
-                for (int w = 0; w < NW; ++w) zp[ot][w] = *(const f32x4*)(scr + ((w * NT0 + ot) * 16 + s) * 16 + 4 * q);
-                bvv[ot] = *(const f32x4*)(lds + FS::b_off(L - 1) + 16 * ot + 4 * q);
-            }
-            if (l == 1 && has) load_ea(t0, t1, two);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ot = 0; ot < NT0; ++ot) {
-                f32x4 z = zp[ot][0];
-#pragma unroll
-                for (int w = 1; w < NW; ++w) z += zp[ot][w];
-                f32x4 zd, dd;
-                act4(FS::act(L - 1), z + bvv[ot], zd, dd);
-                gL[ot] = ev[ot] * dd;
-                if (fg == ot) {
-                    const int rr = 16 * ot + 4 * q;
-                    zd = f32x4{rr + 0 < n_in ? zd.x : 0.f, rr + 1 < n_in ? zd.y : 0.f,
-                               rr + 2 < n_in ? zd.z : 0.f, rr + 3 < n_in ? zd.w : 0.f};
-                    const float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
-                    if (q == 0) red[ot * MF_NB + row] = e2;
-                    if (mode == 2) { set_k(kz, stg, zd); if (stg < nstage) put_stage(stg + 1); }
-                    else kz[1] = zd;
-                }
-            }
-            acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0;
-            if (has) {
-#pragma unroll
-                for (int u = 0; u < NT0; ++u)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[u][c], gL[u][c], acc0, 0, 0, 0);
-                        if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[u][c], gL[u][c], acc1, 0, 0, 0);
-                    }
-            }
-        };
-        // ---- reverse layer l: G (B operand from LDS) ----
-        auto bwdG = [&](auto lc) {
-            constexpr int l = decltype(lc)::value;
-            constexpr int ntiles = FS::P(l) / 16, SW = FS::SW(l), U = FS::P(l + 1) / 16;
-            static_assert(ntiles <= 8, "one pass per layer");
-            const float* W = lds + FS::w_off(l);
-            const int t0 = fg, t1 = fg + 4;
-            const bool has = t0 < ntiles, two = t1 < ntiles;
-            acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0;
-            if (l == 1 && has) { load_ea(t0, t1, two); __builtin_amdgcn_sched_barrier(0); }
-            if (has) {
-                const float* wc0 = W + (4 * q) * SW + 16 * t0 + s;
-                const float* wc1 = W + (4 * q) * SW + 16 * t1 + s;
-                const float* gb = lds + FS::x_off(l + 1) + row * FS::SX(l + 1) + 4 * q;
-                if (two) bwd_body<U, 2>(acc0, acc1, SW, gb, wc0, wc1);
-                else { bwd_body<U, 1>(acc0, acc1, SW, gb, wc0, wc1); acc0 += acc1; }
-            }
-        };
-        // ---- reverse layer l: E (scale by sigma'(h_l); layer 1 also forms the eJ partial) ----
-        auto bwdE = [&](auto lc) {
-            constexpr int l = decltype(lc)::value;
-            constexpr int ntiles = FS::P(l) / 16;
-            const int t0 = fg, t1 = fg + 4;
-            const bool has = t0 < ntiles, two = t1 < ntiles;
-            if (has) {
-                f32x4 g0, g1 = {0.f, 0.f, 0.f, 0.f};
-                float* o0 = lds + FS::x_off(l) + row * FS::SX(l) + 16 * t0 + 4 * q;
-                const f32x4 hv0 = *(const f32x4*)o0;
-                g0 = f32x4{acc0.x * d_from_h(FS::act(l - 1), hv0.x), acc0.y * d_from_h(FS::act(l - 1), hv0.y),
-                           acc0.z * d_from_h(FS::act(l - 1), hv0.z), acc0.w * d_from_h(FS::act(l - 1), hv0.w)};
-                if (l > 1) *(f32x4*)o0 = g0;
-                if (two) {
-                    float* o1 = lds + FS::x_off(l) + row * FS::SX(l) + 16 * t1 + 4 * q;
-                    const f32x4 hv1 = *(const f32x4*)o1;
-                    g1 = f32x4{acc1.x * d_from_h(FS::act(l - 1), hv1.x), acc1.y * d_from_h(FS::act(l - 1), hv1.y),
-                               acc1.z * d_from_h(FS::act(l - 1), hv1.z), acc1.w * d_from_h(FS::act(l - 1), hv1.w)};
-                    if (l > 1) *(f32x4*)o1 = g1;
-                }
-                if constexpr (l == 1) {
-                    f32x4 pe[NT0];
-#pragma unroll
-                    for (int kt = 0; kt < NT0; ++kt) pe[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int kt = 0; kt < NT0; ++kt)
-                            pe[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0[kt][c], g0[c], pe[kt], 0, 0, 0);
-                    if (two) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-#pragma unroll
-                            for (int kt = 0; kt < NT0; ++kt)
-                                pe[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1[kt][c], g1[c], pe[kt], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int kt = 0; kt < NT0; ++kt)
-                        *(f32x4*)(scr2 + ((fg * NT0 + kt) * 16 + s) * 16 + 4 * q) = pe[kt];
-                }
-            }
-        };
-        // sub-step dispatch (compile-time layer indices behind a wave-uniform switch)
-        auto run_sub = [&](int sub) {
-            static_assert(L == 2 || L == 3 || L == 4, "sub-step table written for 2..4 layers");
-            if constexpr (L == 2) {
-                switch (sub) {
-                    case 0: fwdG(std::integral_constant<int, 0>{}); break;
-                    case 1: fwdE(std::integral_constant<int, 0>{}); break;
-                    case 2: midG(); break;
-                    default: bwdE(std::integral_constant<int, 1>{}); break;
-                }
-            } else if constexpr (L == 3) {
-                switch (sub) {
-                    case 0: fwdG(std::integral_constant<int, 0>{}); break;
-                    case 1: fwdE(std::integral_constant<int, 0>{}); break;
-                    case 2: fwdG(std::integral_constant<int, 1>{}); break;
-                    case 3: fwdE(std::integral_constant<int, 1>{}); break;
-                    case 4: midG(); break;
-                    case 5: bwdE(std::integral_constant<int, 2>{}); break;
-                    case 6: bwdG(std::integral_constant<int, 1>{}); break;
-                    default: bwdE(std::integral_constant<int, 1>{}); break;
-                }
-            } else {
-                switch (sub) {
-                    case 0: fwdG(std::integral_constant<int, 0>{}); break;
-                    case 1: fwdE(std::integral_constant<int, 0>{}); break;
-                    case 2: fwdG(std::integral_constant<int, 1>{}); break;
-                    case 3: fwdE(std::integral_constant<int, 1>{}); break;
-                    case 4: fwdG(std::integral_constant<int, 2>{}); break;
-                    case 5: fwdE(std::integral_constant<int, 2>{}); break;
-                    case 6: midG(); break;
-                    case 7: bwdE(std::integral_constant<int, 3>{}); break;
-                    case 8: bwdG(std::integral_constant<int, 2>{}); break;
-                    case 9: bwdE(std::integral_constant<int, 2>{}); break;
-                    case 10: bwdG(std::integral_constant<int, 1>{}); break;
-                    default: bwdE(std::integral_constant<int, 1>{}); break;
-                }
-            }
-        };
-        const int total = NSUB * nstage;
-        for (int i = 0; i <= total; ++i) {
-            const int j = i - team;                       // team 1 runs one sub-step behind
-            if (j >= 0 && j < total) {
-                stg = j / NSUB + 1;
-                run_sub(j - (stg - 1) * NSUB);
-            }
-            __syncthreads();
-        }
-        // last evaluation: eJ partials -> RED, then the scalar rows
-        if (sown) read_E();
-        reduce_eJ();
-        __syncthreads();
-        if (sown) {
-            const f32x4 v = read_ln();
-            if (mode == 2) ks[6] = v; else ks[1] = v;
-        }
-        // ---- outputs ----
-        if (live) {
-            if (mode == 0 || mode == 1) {
-                float* out = (mode == 0 ? a.du : a.Ks0) + gcol;
-                if (own) st4(out + r0, kz[1], nv);
-                if (sown) st4(out + n_in, ks[1], 3);
-            } else {
-                float* Un = a.U[1 - cur] + gcol;
-                float* K7 = a.K1[1 - cur] + gcol;
-                if (own) {
-                    st4(Un + r0, un, nv); st4(K7 + r0, kz[6], nv);
-                    err_acc(errsum, badcnt, kz, uz, un, hstep, abstol, reltol, nv);
-                }
-                if (sown) {
-                    const f32x4 uns = us + hstep * stage_acc4<6>(ks);
-                    st4(Un + n_in, uns, 3); st4(K7 + n_in, ks[6], 3);
-                    err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
-                }
-            }
-        }
-        __syncthreads();      // RED / scratch reads of this tile precede the next tile's writes
-    }
-    if (mode == 2) {
-        for (int off = 32; off > 0; off >>= 1) {
-            errsum += __shfl_down(errsum, off, 64);
-            badcnt += __shfl_down(badcnt, off, 64);
-        }
-        if (lane == 0) { red[wave] = errsum; red[8 + wave] = badcnt; }
-        __syncthreads();
-        if (tid == 0) {
-            float e = 0.f, b = 0.f;
-            for (int w = 0; w < MF_THREADS / 64; ++w) { e += red[w]; b += red[8 + w]; }
-            a.partials[2 * blockIdx.x] = e;
-            a.partials[2 * blockIdx.x + 1] = b;
-        }
-    }
-}
-
 
 // ---- weight image packing -------------------------------------------------------------------
 __global__ void k_pack_image(MfmaLayout ly, NetDesc nd, const float* __restrict__ P,
@@ -2172,9 +1136,6 @@ using LyCfg3 = StLayout<CNF_ACT_TANH, 32, 128, 128, 32>;   // BASELINE configs 3
 using LyCfg2 = StLayout<CNF_ACT_TANH, 16, 48, 16>;         // BASELINE config 2
 using LyCfg1 = StLayout<CNF_ACT_TANH, 16, 16, 16>;         // BASELINE config 1 (2->6->2 padded)
 using LyCfg5 = StLayoutX<false, CNF_ACT_TANH, 128, 384, 128>;   // BASELINE config 5: weights stay in HBM/L2
-using FsCfg3 = FsLayout<CNF_ACT_TANH, 32, 128, 128, 32>;   // same shapes, fused-phase layout
-using FsCfg2 = FsLayout<CNF_ACT_TANH, 16, 48, 16>;
-using FsCfg1 = FsLayout<CNF_ACT_TANH, 16, 16, 16>;
 
 template <class LY>
 static bool matches(const MfmaLayout& m) {
@@ -2255,10 +1216,6 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     if (ly.P[0] > 128) return;                                             // state tiles fg, fg+4 only
     p.variant = 1;
     if (nd.jvp) return;                  // forward-mode sweep: run-time-layout kernel only
-    // experimental schedules for the static shapes (kept for A/B measurements)
-    const char* sch = getenv("CNF_MFMA_SCHEDULE");
-    p.schedule = sch ? atoi(sch) : 0;
-    if (p.schedule < 0 || p.schedule > 2) p.schedule = 0;
     if (matches<LyCfg3>(ly)) p.variant = 2;
     else if (matches<LyCfg2>(ly)) p.variant = 3;
     else if (matches<LyCfg1>(ly)) p.variant = 4;
@@ -2275,22 +1232,8 @@ static hipError_t set_attr() {
     hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        MF_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_mfma<LY, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
-    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_mfma<LY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                MF_LDS_BYTES);
-}
-
-template <class FS>
-static hipError_t set_attr_fused() {
-    hipError_t e = hipFuncSetAttribute((const void*)k_fused<FS, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       MF_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_fused<FS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_pp<FS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_pp<FS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
 }
 
 cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params, hipStream_t s) {
@@ -2302,9 +1245,6 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
         if (e == hipSuccess) e = set_attr<LyCfg2>();
         if (e == hipSuccess) e = set_attr<LyCfg1>();
         if (e == hipSuccess) e = set_attr<LyCfg5>();
-        if (e == hipSuccess) e = set_attr_fused<FsCfg3>();
-        if (e == hipSuccess) e = set_attr_fused<FsCfg2>();
-        if (e == hipSuccess) e = set_attr_fused<FsCfg1>();
         if (e != hipSuccess) return CNF_ERR_HIP;
     }
     hipLaunchKernelGGL(k_pack_image, dim3((p.ly.img_floats + 255) / 256), dim3(256), 0, s, p.ly, nd,
@@ -2330,20 +1270,6 @@ static void launch_static(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipSt
     if (a.mode == 2) hipLaunchKernelGGL((k_mfma<LY, true>), grid, dim3(MF_KTHREADS), shm, s, ly, a);
     else hipLaunchKernelGGL((k_mfma<LY, false>), grid, dim3(MF_KTHREADS), shm, s, ly, a);
 }
-template <class FS>
-static void launch_fused(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStream_t s) {
-    FS ly;
-    ly.n_in_ = p.ly.n_in; ly.norm_z_ = p.ly.norm_z; ly.norm_j_ = p.ly.norm_j;
-    const size_t shm = (size_t)FS::total_floats() * sizeof(float);
-    if (p.schedule == 2) {     // fused narrow layers + ping-pong teams
-        if (a.mode == 2) hipLaunchKernelGGL((k_pp<FS, true>), grid, dim3(MF_THREADS), shm, s, ly, a);
-        else hipLaunchKernelGGL((k_pp<FS, false>), grid, dim3(MF_THREADS), shm, s, ly, a);
-    } else {                   // fused narrow layers, both teams in the same phase
-        if (a.mode == 2) hipLaunchKernelGGL((k_fused<FS, true>), grid, dim3(MF_THREADS), shm, s, ly, a);
-        else hipLaunchKernelGGL((k_fused<FS, false>), grid, dim3(MF_THREADS), shm, s, ly, a);
-    }
-}
-
 static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
     MfmaArgs a = a0;
     if (a.test) { a.cimg = p.d_img + p.ly.c_off; a.SWC = p.ly.SWC; }
@@ -2356,11 +1282,6 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
         if (a.mode == 2) hipLaunchKernelGGL((k_mfma<RtLayout, true>), grid, block, shm, s, ly, a);
         else hipLaunchKernelGGL((k_mfma<RtLayout, false>), grid, block, shm, s, ly, a);
     }
-    else if (p.variant >= 2 && p.variant <= 4 && p.schedule > 0 && !a.cond && !a.dump) {   // the experimental schedules do not dump stage states
-        if (p.variant == 2) launch_fused<FsCfg3>(p, a, grid, s);
-        else if (p.variant == 3) launch_fused<FsCfg2>(p, a, grid, s);
-        else launch_fused<FsCfg1>(p, a, grid, s);
-    }
     else if (p.variant == 2) launch_static<LyCfg3>(p, a, grid, s);
     else if (p.variant == 3) launch_static<LyCfg2>(p, a, grid, s);
     else if (p.variant == 4) launch_static<LyCfg1>(p, a, grid, s);
@@ -2371,60 +1292,6 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
         else hipLaunchKernelGGL((k_mfma<RtLayout, false>), grid, block, shm, s, ly, a);
     }
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
-}
-
-// ---- persistent adaptive solve: all attempts in one cooperative launch ---------------------------
-template <class LY>
-static hipError_t launch_persistent_ly(LY ly, const MfmaArgs& a, dim3 grid, size_t shm, hipStream_t s) {
-    int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mfma<LY, true, true>, MF_KTHREADS, shm);
-    if (e != hipSuccess) return e;
-    int dev = 0, cus = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if ((long)per_cu * cus < (long)grid.x) return hipErrorCooperativeLaunchTooLarge;
-    MfmaArgs args = a;
-    void* params[2] = {(void*)&ly, (void*)&args};
-    return hipLaunchCooperativeKernel((const void*)k_mfma<LY, true, true>, grid, dim3(MF_KTHREADS), params,
-                                      (unsigned)shm, s);
-}
-
-template <class LY>
-static hipError_t launch_persistent_static(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStream_t s) {
-    LY ly;
-    ly.n_in_ = p.ly.n_in; ly.norm_z_ = p.ly.norm_z; ly.norm_j_ = p.ly.norm_j;
-    return launch_persistent_ly(ly, a, grid, (size_t)LY::total_floats() * sizeof(float), s);
-}
-
-// All attempts of a TrainMode solve from the state in *st (after the initial-dt phase) until t1 or
-// max_attempts; *st is updated in place.  CNF_ERR_UNSUPPORTED: not launchable cooperatively (more
-// tiles than co-resident workgroups) -- the caller falls back to queued launches.
-cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st, float* const U[2],
-                                 float* const K1[2], const float* eps, float* partials_a, float* partials_b,
-                                 unsigned* gbar, int max_attempts, int B, hipStream_t s) {
-    if (!train || !mfma_supported(p, nd, train, B)) return CNF_ERR_UNSUPPORTED;
-    const int ntile = (B + MF_NB - 1) / MF_NB;
-    if (ntile != mfma_grid_for(B)) return CNF_ERR_UNSUPPORTED;        // one tile per workgroup only
-    MfmaArgs a{};
-    a.init_phase = -1;
-    a.mode = 2; a.B = B; a.img = p.d_img; a.eps = eps; a.st = st; a.st_out = st;
-    a.n_total = (float)((size_t)(nd.n_in + 3) * B);
-    a.U[0] = U[0]; a.U[1] = U[1]; a.K1[0] = K1[0]; a.K1[1] = K1[1];
-    a.partials = partials_a; a.partials_b = partials_b; a.gbar = gbar; a.max_attempts = max_attempts;
-    a.cond = p.cond; a.cbs = p.cbs;
-    if (ntile > MF_KTHREADS || 4 * ntile > 2 * 1024) return CNF_ERR_UNSUPPORTED;      // one slot per thread, 4 floats each
-    if (hipMemsetAsync(partials_a, 0, 4 * ntile * sizeof(float), s) != hipSuccess ||
-        hipMemsetAsync(partials_b, 0, 4 * ntile * sizeof(float), s) != hipSuccess) return CNF_ERR_HIP;
-    (void)gbar;
-    const dim3 grid(ntile);
-    hipError_t e;
-    if (p.variant == 2) e = launch_persistent_static<LyCfg3>(p, a, grid, s);
-    else if (p.variant == 3) e = launch_persistent_static<LyCfg2>(p, a, grid, s);
-    else if (p.variant == 4) e = launch_persistent_static<LyCfg1>(p, a, grid, s);
-    else if (p.variant == 5) e = launch_persistent_static<LyCfg5>(p, a, grid, s);
-    else { RtLayout ly{p.ly}; e = launch_persistent_ly(ly, a, grid, (size_t)p.ly.total_floats * sizeof(float), s); }
-    if (e == hipErrorCooperativeLaunchTooLarge) return CNF_ERR_UNSUPPORTED;
-    return e == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 
 cnf_status mfma_rhs(const MfmaPlan& p, const NetDesc& nd_, bool train, const float* u,
@@ -2441,7 +1308,7 @@ cnf_status mfma_rhs(const MfmaPlan& p, const NetDesc& nd_, bool train, const flo
 // controller phase folded into the same launch
 cnf_status mfma_rhs_init0(const MfmaPlan& p, const NetDesc& nd_, bool train, StepState* st, const float* u,
                           const float* eps, float* du, float* partials, unsigned* ticket, int B, hipStream_t s) {
-    if (!mfma_supported(p, nd_, train, B) || p.schedule != 0) return CNF_ERR_UNSUPPORTED;
+    if (!mfma_supported(p, nd_, train, B)) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
     a.test = train ? 0 : 1;
     a.mode = 0; a.B = B; a.img = p.d_img; a.eps = eps; a.u = u; a.du = du;
@@ -2455,7 +1322,6 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, con
                           const float* eps, int nk, int B, hipStream_t s, StepState* st_init, float* partials,
                           unsigned* ticket) {
     if (!mfma_supported(p, nd_, train, B) || nk != 1) return CNF_ERR_UNSUPPORTED;
-    if (st_init && p.schedule != 0) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
     a.init_phase = -1;
     a.test = train ? 0 : 1;

@@ -347,21 +347,6 @@ def test_rhs_work_model():
     assert fl.value == B * (4 * M + 6 * 32) and by.value == 4 * B * (32 + 32 + 35) + 4 * P
 
 
-@pytest.mark.parametrize("schedule", ["1", "2"])
-def test_experimental_mfma_schedules_keep_parity(schedule, monkeypatch):
-    """CNF_MFMA_SCHEDULE=1 (narrow layers fused as split-K partials) and =2 (that plus the
-    ping-pong team schedule) are alternative orderings of the same arithmetic."""
-    monkeypatch.setenv("CNF_MFMA_SCHEDULE", schedule)
-    for name in ("cfg3_headline_small", "cfg2_regression", "cfg1_readme"):
-        g, cfg = load_golden(name)
-        icnf = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=float(g["dt"])))
-        du = cnf.augmented_f(g["u_train"], g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, g["eps"])
-        assert_parity(du, g["du_train_vjp"], f"{name} schedule {schedule} rhs")
-        logpx, _ = cnf.inference(icnf, cnf.TrainMode(), g["xs"], g["flat"], {}, eps=g["eps"])
-        assert_parity(logpx, g["logpx_train_vjp"], f"{name} schedule {schedule} logpx")
-        icnf.close()
-
-
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_generate_matches_backward_oracle_and_inverts_inference(kernel):
     """`generate` = the same RHS over reverse(tspan) from a base-distribution
@@ -773,30 +758,6 @@ def test_exact_trace_mfma_deep_networks():
     assert ic.last_stats["kernel_used"] == _lib.KERNEL_MFMA
     _, ref_lp, _, _ = O.inference(cfg, flat.astype(np.float64), xs.astype(np.float64), None, False, reltol=1e-9, abstol=1e-9)
     assert_parity(logpx.cpu().numpy(), ref_lp, "config 3 TestMode logpx", rtol=2e-4)
-
-
-def test_persistent_solve_matches_queued_launches(monkeypatch):
-    """CNF_PERSISTENT=1: every attempt of an adaptive solve in one cooperative launch (grid barrier through
-    tagged partials, controller in the kernel, state in registers).  Same control law, same reduction
-    order: the same step sequence as the queued-launch path; values agree to rounding (the two kernels are
-    separate template instantiations, so the compiler's FMA contractions may differ in the last bit)."""
-    for i, B in ((3, 500), (2, 700), (1, 333)):
-        cfg, _, _ = O.baseline_cfg(i)
-        rng = np.random.default_rng(600 + i)
-        flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
-        xs, eps = _dev(rng.standard_normal((cfg.nvars, B))), _dev(rng.standard_normal((cfg.n_in, B)))
-        kw = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
-        out = {}
-        for mode in ("0", "1"):
-            monkeypatch.setenv("CNF_PERSISTENT", mode)
-            ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=kw)
-            prob = cnf.inference_prob(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
-            out[mode] = (cnf.base_sol(ic, prob).view().clone(), dict(prob.stats))
-        (a, sa), (b, sb) = out["0"], out["1"]
-        assert sb["launches"] < sa["launches"] and sb["kernel_used"] == _lib.KERNEL_MFMA
-        assert (sa["nf"], sa["naccept"], sa["nreject"]) == (sb["nf"], sb["naccept"], sb["nreject"])
-        assert_parity(b.cpu().numpy(), a.cpu().numpy(), f"persistent vs queued, config {i}")
-    monkeypatch.delenv("CNF_PERSISTENT")
 
 
 def test_jvp_mode_large_network_on_mfma():
