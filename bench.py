@@ -9,13 +9,21 @@ nvars=32, naugs=0, MLP 32->128->128->32 (tanh), batch 8192 per GPU, TrainMode
 A "step" is one whole log-density inference (u0 assembly + adaptive Tsit5 solve + logpdf
 post-processing + loss sums) over one synthetic Gaussian batch that is already resident in
 HBM.  metric = RHS evaluations per second (the integrator's `nf` counter / wall time).
-With N GPUs the batch axis is sharded (8192 columns per rank, weak scaling): every rank
-solves its own shard, the only collective is the 5-float all-reduce behind the mean
-log-likelihood, and `value` sums the shard-RHS-evaluations of all ranks.
+
+N GPUs: one process per GPU, the batch axis sharded (8192 columns per rank, weak scaling).
+Every rank solves its own shard; the only collective is the 5-float all-reduce behind the mean
+log-likelihood (RCCL over xGMI, through the C ABI's cnf_loss_allreduce), and `value` sums the
+shard-RHS-evaluations of all ranks.  Two ways in:
+  * under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`):
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment;
+  * bare `python bench.py --gpus N`: this process starts the N rank processes itself, BEFORE it
+    touches the GPU (it never re-executes a process that has initialised HIP), and waits for them.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,32 +34,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 PEAK_HBM_GBS = 8000.0       # spec
+PMC_FILE = os.path.join("profiles", "round2_step_kernel_pmc.json")   # tools/collect_profiles.sh + summarize_profiles.py
 
 
-def cpu_baseline(B, flat, xs, eps, kw, budget_s=12.0):
-    """The float32 C restatement of the reference path (oracle/cnf_oracle.c, OpenMP over
-    all host cores) on the same workload; bounded to ~budget_s of CPU time.  The only place
-    bench.py touches oracle/."""
-    from oracle import c_oracle as CO
-    from oracle import cnf_oracle as O
-    cfg, _, _ = O.baseline_cfg(3)
-    u0 = O.inference_u0(cfg, xs, True)
-    CO.solve(cfg, flat, u0, eps, True, **kw)            # warm-up (page-in, thread pool)
-    nf, t0, n = 0, time.perf_counter(), 0
-    while True:
-        _, st = CO.solve(cfg, flat, u0, eps, True, **kw)
-        nf += st["nf"]
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 50:
-            break
-    return {"value": nf / el, "unit": "RHS-evals/s", "cores": CO.threads(), "kind": "port",
-            "sample": f"{n} adaptive Tsit5 solves of the same workload (B={B}, nf={st['nf']} each), "
-                      f"C/OpenMP restatement of the reference path (the Julia package cannot run here)",
-            "seconds": el}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -60,30 +46,128 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="columns per GPU")
     ap.add_argument("--fixed-dt", type=float, default=0.0, help="use fixed steps instead of adaptive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per device) and wait.
+    Nothing in this process has touched the GPU: torch.cuda.device_count() does not initialise it."""
+    import torch
+    backend = os.environ.get("CNF_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and args.gpus > ndev:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {ndev} device(s) visible (one rank per GPU; "
+                 f"CNF_BENCH_BACKEND=gloo rehearses several ranks on one card)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def _timed_solves(fn, budget_s, max_n=50):
+    fn()                                              # warm-up (page-in, thread pools)
+    nf, n, t0 = 0, 0, time.perf_counter()
+    while True:
+        st = fn()
+        nf += st["nf"]
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= max_n:
+            return nf, n, el, st
+
+
+def cpu_baseline(B, flat, xs, eps, kw, budget_s=9.0):
+    """CPU numbers beside the GPU number (the only place bench.py touches oracle/), both on a bounded
+    sample of the same workload and both restatements -- the Julia package itself cannot run here:
+      cpu_baseline: float32 sgemm over the whole n x B matrices + vectorised tanh on all host cores
+                    (oracle/cnf_blas.py, torch-CPU) -- the class of computation the reference's Lux/BLAS
+                    path performs (src/icnf.jl:331-332);
+      cpu_port:     the scalar-loop C/OpenMP restatement (oracle/cnf_oracle.c), the second checker of the
+                    parity tests."""
+    from oracle import c_oracle as CO
+    from oracle import cnf_blas as BL
+    from oracle import cnf_oracle as O
+    cfg, _, _ = O.baseline_cfg(3)
+    u0 = O.inference_u0(cfg, xs, True)
+    nf, n, el, st = _timed_solves(lambda: BL.solve(cfg, flat, u0, eps, **kw)[1], budget_s)
+    blas = {"value": nf / el, "unit": "RHS-evals/s", "cores": BL.threads(), "kind": "port",
+            "impl": "float32 sgemm over the full n x B matrices + tanh, torch-CPU on all host cores; "
+                    "Tsit5 driver in numpy (oracle/cnf_blas.py)",
+            "sample": f"{n} adaptive Tsit5 solves of the same workload (B={B}, nf={st['nf']} each); restatement "
+                      f"of the reference path (the Julia package cannot run here)",
+            "seconds": el}
+    nf, n, el, st = _timed_solves(lambda: CO.solve(cfg, flat, u0, eps, True, **kw)[1], budget_s)
+    port = {"value": nf / el, "unit": "RHS-evals/s", "cores": CO.threads(), "kind": "port",
+            "impl": "scalar loops over 16-sample blocks, C/OpenMP (oracle/cnf_oracle.c)",
+            "sample": f"{n} adaptive Tsit5 solves (B={B}, nf={st['nf']} each)", "seconds": el}
+    return blas, port
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
     import continuousnf.jl_amd as cnf
-    from continuousnf.jl_amd import _lib
-    from continuousnf.jl_amd.parallel import allreduce_sums
-    from continuousnf.jl_amd import configs
+    from continuousnf.jl_amd import _lib, configs
+    from continuousnf.jl_amd.parallel import RcclComm, allreduce_sums
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # one rank per GPU; CNF_BENCH_BACKEND=gloo lets several ranks share one card for a rehearsal
     backend = os.environ.get("CNF_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(1, torch.cuda.device_count())
+    if os.environ.get("CNF_BENCH_DRYRUN") == "1":
+        # rehearsal of the launch logic alone (tests/test_dist_gloo.py, no GPU): rendezvous, count the ranks, stop
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        n = torch.ones(1)
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.all_reduce(n)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "ranks_seen": int(n), "local_rank": local_rank}), flush=True)
+        return
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no GPU visible (the HIP backend has no CPU fallback)")
+    if backend == "nccl" and world > 1 and local_rank >= ndev:
+        sys.exit(f"bench.py: local rank {local_rank} has no device of its own ({ndev} visible)")
+    dev_index = local_rank % ndev
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    comm, collective = None, "none (1 rank)"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        collective = f"torch.distributed all_reduce ({backend})"
+        if backend == "nccl":
+            # the path's own collective: an RCCL communicator owned through the C ABI (what a torch-less
+            # caller uses); every rank must succeed, otherwise all fall back to torch's communicator
+            ok = 1
+            try:
+                comm = RcclComm.from_torch_group(dev_index)
+                ok = int(comm.size() == world)
+            except Exception as e:                                    # noqa: BLE001
+                print(f"[rank {rank}] cnf_comm_init failed: {e}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag) == 1:
+                collective = "cnf_loss_allreduce (RCCL ncclAllReduce via the C ABI)"
+            else:
+                comm = None
 
     wl = configs.BASELINE[3]
     B = args.batch
@@ -101,11 +185,15 @@ def main():
     ps = torch.from_numpy(flat).to(dev)
     mode = cnf.TrainMode()
 
+    def reduce_sums(local):
+        if comm is not None:
+            return comm.allreduce_sums(icnf, local)
+        return allreduce_sums(local)
+
     def step():
         # one rank's share of `loss`: solve + post-processing + the 5 local sums in one C call, then the all-reduce
         _, _, local = cnf.inference(icnf, mode, xs, ps, {}, eps=eps, with_sums=True)
-        sums = allreduce_sums(local)
-        return icnf.last_stats, sums
+        return icnf.last_stats, reduce_sums(local)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -123,20 +211,38 @@ def main():
         nf_total += st["nf"]
     sync()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     loss = cnf.loss_from_sums(icnf, mode, sums)
-    t = torch.tensor([elapsed, float(nf_total)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+
+    ranks_seen, per_rank_ms, allreduce_us = 1, [elapsed / args.steps * 1e3], None
     if world > 1:
+        tdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed, float(nf_total), 1.0], dtype=torch.float64, device=tdev)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed, nf_all = float(tmax[0]), float(tsum[1])
+        elapsed, nf_all, ranks_seen = float(tmax[0]), float(tsum[1]), int(round(float(tsum[2])))
+        gathered = [torch.zeros(1, dtype=torch.float64, device=tdev) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([local_elapsed / args.steps * 1e3], dtype=torch.float64, device=tdev))
+        per_rank_ms = [float(g) for g in gathered]
+        # the collective by itself: 5 floats, latency-bound
+        probe = torch.ones(5, dtype=torch.float32, device=dev)
+        for _ in range(5):
+            reduce_sums(probe.clone())
+        sync()
+        n_ar = 50
+        ta = time.perf_counter()
+        for _ in range(n_ar):
+            probe = reduce_sums(probe * (1.0 / world))
+        torch.cuda.synchronize(dev)
+        allreduce_us = (time.perf_counter() - ta) / n_ar * 1e6
     else:
         nf_all = float(nf_total)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
     roof = None
     if rank == 0:
-        l, h = _lib.lib(), icnf.handle()
         import ctypes as C
+        l, h = _lib.lib(), icnf.handle()
         fl, by = C.c_double(), C.c_double()
         _lib.check(l.cnf_rhs_work(h, 1, B, C.byref(fl), C.byref(by)))
         stream = torch.cuda.current_stream(dev)
@@ -171,17 +277,20 @@ def main():
             e1.record(stream); e1.synchronize()
             per_launch_s = e0.elapsed_time(e1) * 1e-3 / n
             units, kname = 1.0, "k_rhs_generic (1 RHS evaluation per launch)"
-        # HBM bytes per launch of that kernel from the PMC counters: collected in separate
-        # rocprofv3 --pmc passes (tools/collect_profiles.sh; FETCH_SIZE and WRITE_SIZE cannot
-        # share a pass) and committed under profiles/; bench.py cannot profile itself.
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "round1_step_kernel_pmc.json")
+        # HBM bytes per launch of that kernel come from PMC counters, which need their own rocprofv3 --pmc
+        # passes (FETCH_SIZE and WRITE_SIZE cannot share one; bench.py cannot profile itself): the figure is
+        # REPLAYED from the committed summary of tools/collect_profiles.sh, and says so.
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, PMC_FILE)
         if kernel_used == _lib.KERNEL_MFMA and os.path.exists(pmc) and B == 8192:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc))
+            traffic = rec.get("hbm_bytes_per_launch")
+            traffic_source = (f"{PMC_FILE} (rocprofv3 --pmc passes of tools/collect_profiles.sh, full-step launches "
+                              f"only; built from commit {rec.get('commit', '?')}); not measured in this run")
         tf = units * fl.value / per_launch_s / 1e12
         gbs = units * by.value / per_launch_s / 1e9
         roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / PEAK_F32_TFLOPS, "traffic": traffic, "kernel": kname,
+                "frac": tf / PEAK_F32_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "kernel": kname,
                 "launch_us": per_launch_s * 1e6,
                 "algorithmic_flops_per_launch": units * fl.value,
                 "algorithmic_bytes_per_launch": units * by.value,
@@ -200,18 +309,30 @@ def main():
                                       "adaptive reltol=sqrt(eps32) abstol=eps32"),
                        "global_batch": B * world, "parallelism": f"columns sharded x{world}",
                        "kernel": {1: "generic", 2: "mfma"}.get(st["kernel_used"], "?")},
+            "ranks_seen": ranks_seen, "backend": backend if world > 1 else None, "collective": collective,
+            "per_rank_ms_per_step": per_rank_ms, "allreduce_us": allreduce_us,
             "sample_evals_per_s": nf_all / elapsed * B,
             "nf_per_solve": st["nf"], "naccept": st["naccept"], "nreject": st["nreject"],
             "launches_per_solve": st["launches"], "loss": loss,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, flat, xs_h, eps_h,
-                                               dict(dt=args.fixed_dt, adaptive=False) if args.fixed_dt > 0 else kw)
+            kwb = dict(dt=args.fixed_dt, adaptive=False) if args.fixed_dt > 0 else kw
+            out["cpu_baseline"], out["cpu_port"] = cpu_baseline(B, flat, xs_h, eps_h, kwb)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
+    icnf.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 # enums (include/cnfhip.h)
 OK, ERR_BAD_ARG, ERR_BAD_SHAPE, ERR_HIP, ERR_NO_DEVICE, ERR_MAXITERS, ERR_UNSUPPORTED, \
-    ERR_NO_PARAMS, ERR_NONFINITE = range(9)
+    ERR_NO_PARAMS, ERR_NONFINITE, ERR_RCCL = range(10)
 MODE_TEST, MODE_TRAIN = 0, 1
 AD_VJP, AD_JVP = 0, 1
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
@@ -80,7 +80,17 @@ _SIGNATURES = {
     "cnf_state_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "cnf_kernel_for": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "cnf_rhs_work": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "cnf_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "cnf_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "cnf_comm_destroy": (C.c_int, [C.c_void_p]),
+    "cnf_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "cnf_comm_allreduce": (C.c_int, [C.c_void_p, _fp, C.c_size_t, C.c_void_p]),
+    "cnf_comm_last_error": (C.c_char_p, []),
+    "cnf_comm_library": (C.c_char_p, []),
+    "cnf_loss_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, _fp, C.c_void_p]),
+    "cnf_set_shard_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
+COMM_ID_BYTES = 128
 EXPORTS = tuple(_SIGNATURES)
 
 _lib = None

@@ -53,6 +53,7 @@ struct cnf_ctx {
     // lock-step sharded solves: host callback summing 3 floats over the shards (null: off)
     cnf_shard_reduce_fn shard_reduce = nullptr;
     void* shard_user = nullptr;
+    cnf_comm shard_comm = nullptr;         // ... or an RCCL communicator: reduced on the stream, no host round trip
     // gradient path (cnf_loss_grad): transposed weights, per-step trajectory, adjoint scratch
     float* d_PT = nullptr;
     float* d_adj_img = nullptr;   // padded forward/reverse weight images of the MFMA pullback kernel
@@ -114,6 +115,7 @@ extern "C" const char* cnf_status_string(cnf_status s) {
         case CNF_ERR_UNSUPPORTED: return "unsupported configuration";
         case CNF_ERR_NO_PARAMS: return "parameters not set";
         case CNF_ERR_NONFINITE: return "non-finite solver state";
+        case CNF_ERR_RCCL: return "RCCL error";
     }
     return "unknown status";
 }
@@ -528,6 +530,11 @@ extern "C" cnf_status cnf_set_shard_reduce(cnf_handle h, cnf_shard_reduce_fn fn,
 static cnf_status lockstep_controller(cnf_handle h, StepState* state, const float* partials, int phase,
                                       float n_local, hipStream_t st) {
     launch_reduce_partials(state, partials, h->d_sums, n_local, st);
+    if (h->shard_comm) {                 // RCCL: the three floats never leave the device
+        if (cnf_comm_allreduce(h->shard_comm, h->d_sums, 3, st) != CNF_OK) return fail(h, CNF_ERR_RCCL, cnf_comm_last_error());
+        launch_controller_sums(state, h->d_sums, phase, st);
+        return CNF_OK;
+    }
     HIPCHK(h, hipMemcpyAsync(h->h_sums, h->d_sums, 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     if (h->shard_reduce(h->h_sums, 3, h->shard_user) != 0)
@@ -613,7 +620,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     h->aux_train = train != 0; h->aux_eps = eps;
     if (h->trace_on && (s = ensure_adj_images(h, (hipStream_t)stream)) != CNF_OK) return s;
     // lock-step over shards only matters when the controller decides something
-    const bool lockstep = h->shard_reduce != nullptr && opts->adaptive;
+    const bool lockstep = (h->shard_reduce != nullptr || h->shard_comm != nullptr) && opts->adaptive;
     // number of error partials = blocks of whichever kernel writes them
     int nblk = (int)((n + 255) / 256);
     if (nblk > 256) nblk = 256;
@@ -1097,6 +1104,19 @@ extern "C" cnf_status cnf_loss_sums(cnf_handle h, const float* logpx, const floa
     HIPCHK(h, hipSetDevice(h->device));
     launch_loss_sums(logpx, regs, B, sums5, (hipStream_t)stream);
     HIPCHK(h, hipGetLastError());
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_loss_allreduce(cnf_handle h, cnf_comm comm, float* sums5, void* stream) {
+    if (!h || !comm || !sums5) return CNF_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (cnf_comm_allreduce(comm, sums5, 5, stream) != CNF_OK) return fail(h, CNF_ERR_RCCL, cnf_comm_last_error());
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_set_shard_comm(cnf_handle h, cnf_comm comm) {
+    if (!h) return CNF_ERR_BAD_ARG;
+    h->shard_comm = comm;
     return CNF_OK;
 }
 

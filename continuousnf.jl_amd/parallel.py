@@ -36,6 +36,93 @@ def allreduce_sums(sums, group=None):
     return sums
 
 
+class RcclComm:
+    """An RCCL communicator owned through the C ABI (cnf_comm_* in include/cnfhip.h): what a caller
+    without torch.distributed (the Julia shim) uses for the 5-float all-reduce behind ``loss``
+    (src/icnf.jl:489).  ``handle`` is an ``ncclComm_t``."""
+
+    def __init__(self, world_size: int, rank: int, unique_id: bytes, device: int):
+        from . import _lib
+        import ctypes as C
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes of RcclComm.unique_id()")
+        l = _lib.lib()
+        h = C.c_void_p()
+        st = l.cnf_comm_init(C.byref(h), world_size, rank, unique_id, device)
+        if st != _lib.OK:
+            raise _lib.CNFError(st, l.cnf_comm_last_error().decode())
+        self.handle, self.world_size, self.rank, self.device = h, world_size, rank, device
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """ncclGetUniqueId: call on ONE rank and hand the bytes to the others."""
+        from . import _lib
+        import ctypes as C
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        l = _lib.lib()
+        st = l.cnf_comm_unique_id(buf)
+        if st != _lib.OK:
+            raise _lib.CNFError(st, l.cnf_comm_last_error().decode())
+        return buf.raw
+
+    @classmethod
+    def from_torch_group(cls, device: int, group=None):
+        """Bootstrap over an initialised torch.distributed group (any backend): rank 0 draws the id,
+        the group broadcasts the 128 bytes."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(world, rank, box[0], device)
+
+    def size(self) -> int:
+        from . import _lib
+        import ctypes as C
+        n = C.c_int()
+        st = _lib.lib().cnf_comm_size(self.handle, C.byref(n))
+        if st != _lib.OK:
+            raise _lib.CNFError(st, _lib.lib().cnf_comm_last_error().decode())
+        return n.value
+
+    def allreduce_sums(self, icnf, sums):
+        """cnf_loss_allreduce: in-place RCCL sum of the 5 device floats on torch's current stream."""
+        from . import _lib
+        import ctypes as C
+        import torch
+        if not (isinstance(sums, torch.Tensor) and sums.is_cuda and sums.dtype == torch.float32 and sums.numel() == 5
+                and sums.is_contiguous()):
+            raise ValueError("sums must be a contiguous float32 CUDA tensor of 5 elements")
+        st = C.c_void_p(torch.cuda.current_stream(sums.device).cuda_stream)
+        _lib.check(_lib.lib().cnf_loss_allreduce(icnf.handle(), self.handle, sums.data_ptr(), st), icnf.handle())
+        return sums
+
+    def allreduce(self, t):
+        """cnf_comm_allreduce: in-place sum of a contiguous float32 CUDA tensor."""
+        from . import _lib
+        import ctypes as C
+        import torch
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("need a contiguous float32 CUDA tensor")
+        st = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        rc = _lib.lib().cnf_comm_allreduce(self.handle, t.data_ptr(), t.numel(), st)
+        if rc != _lib.OK:
+            raise _lib.CNFError(rc, _lib.lib().cnf_comm_last_error().decode())
+        return t
+
+    def lockstep(self, icnf, enable=True):
+        """cnf_set_shard_comm: the adaptive controller of ``icnf`` reduces its three floats through this
+        communicator on the solve's stream (no host callback)."""
+        from . import _lib
+        _lib.check(_lib.lib().cnf_set_shard_comm(icnf.handle(), self.handle if enable else None), icnf.handle())
+        return icnf
+
+    def close(self):
+        if self.handle is not None:
+            from . import _lib
+            _lib.lib().cnf_comm_destroy(self.handle)
+            self.handle = None
+
+
 def make_shard_reduce(group=None):
     """Callback for ``ICNF.set_shard_reduce``: sums the controller's three floats over the ranks of
     ``group`` (gloo: on the host buffer itself; nccl = RCCL: through a 3-float device tensor)."""

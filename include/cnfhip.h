@@ -42,7 +42,8 @@ typedef enum {
     CNF_ERR_MAXITERS = 5,     /* solver hit maxiters before reaching t1               */
     CNF_ERR_UNSUPPORTED = 6,  /* valid request this build has no kernel for           */
     CNF_ERR_NO_PARAMS = 7,    /* cnf_set_params has not been called                   */
-    CNF_ERR_NONFINITE = 8     /* solver state became NaN/Inf                          */
+    CNF_ERR_NONFINITE = 8,    /* solver state became NaN/Inf                          */
+    CNF_ERR_RCCL = 9          /* librccl missing or an RCCL call failed (see cnf_comm_last_error) */
 } cnf_status;
 
 /* Mode (src/types.jl:1-3). */
@@ -191,6 +192,40 @@ cnf_status cnf_inference_host(cnf_handle h, int mode, const float* xs, const flo
 cnf_status cnf_loss_sums(cnf_handle h, const float* logpx, const float* regs, int B,
                          float* sums5, void* stream);
 cnf_status cnf_loss_from_sums(cnf_handle h, int mode, const float* sums5_host, float* loss);
+
+/* ---- multi-GPU: the one collective of the path (b') ------------------------
+ *
+ * The reference has no collective: it is single-process and `mean` at src/icnf.jl:489 /
+ * src/base_icnf.jl:496 runs over all columns.  With the columns sharded over GPUs (one process per
+ * GPU) that mean is an RCCL all-reduce (ncclSum, ncclFloat32, over xGMI) of the five floats of
+ * cnf_loss_sums.  These entry points let a caller without torch.distributed (the Julia shim) do
+ * it: rank 0 draws an id (cnf_comm_unique_id), hands the 128 bytes to the other ranks by any means
+ * it has (a file, a socket, MPI), every rank calls cnf_comm_init, then cnf_loss_allreduce after
+ * cnf_loss_sums / cnf_inference_sums.  A cnf_comm IS an ncclComm_t: a communicator the caller
+ * already owns (NCCL.jl, torch) can be passed to cnf_loss_allreduce as it is.  librccl is loaded on
+ * first use (dlopen; CNFHIP_RCCL_LIB overrides the search), so single-GPU use needs no RCCL. */
+#define CNF_COMM_ID_BYTES 128
+typedef void* cnf_comm;                                  /* ncclComm_t */
+cnf_status cnf_comm_unique_id(char* id /* CNF_COMM_ID_BYTES */);          /* ncclGetUniqueId   */
+cnf_status cnf_comm_init(cnf_comm* out, int world_size, int rank,
+                         const char* id /* CNF_COMM_ID_BYTES */, int device);  /* ncclCommInitRank on `device`
+                                                      (< 0: on the device the caller has already selected) */
+cnf_status cnf_comm_destroy(cnf_comm comm);
+cnf_status cnf_comm_size(cnf_comm comm, int* world_size);                     /* ncclCommCount */
+/* In-place sum over the ranks of n DEVICE floats, stream-ordered (ncclAllReduce). */
+cnf_status cnf_comm_allreduce(cnf_comm comm, float* buf_dev, size_t n, void* stream);
+const char* cnf_comm_last_error(void);    /* detail for the last CNF_ERR_RCCL on this thread */
+const char* cnf_comm_library(void);       /* which librccl was resolved ("" if none)          */
+
+/* `mean` of loss over ALL shards (src/icnf.jl:489): all-reduce sums5 (device, from cnf_loss_sums /
+ * cnf_inference_sums) in place on `stream`; afterwards every rank holds the global sums and
+ * cnf_loss_from_sums gives the loss of the whole batch.  One 20-byte ncclAllReduce: latency-bound
+ * (SURVEY section 5), no data-path traffic. */
+cnf_status cnf_loss_allreduce(cnf_handle h, cnf_comm comm, float* sums5, void* stream);
+/* Lock-step sharded solves through RCCL instead of a host callback (see cnf_set_shard_reduce): the
+ * three controller floats are all-reduced on the solve's stream, no host round trip.  comm = NULL
+ * switches it off.  Every rank must call the solve collectively. */
+cnf_status cnf_set_shard_comm(cnf_handle h, cnf_comm comm);
 
 /* ---- training ------------------------------------------------ */
 

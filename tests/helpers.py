@@ -8,30 +8,57 @@ from oracle import cnf_oracle as O
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
 
-# Parity bar (BASELINE.json north_star): 1e-4 relative in fp32.  Entries of a row that
-# nearly cancel (the trace row sums n_in signed terms) carry fp32 noise proportional to the
-# row's magnitude, not their own, so the error of an entry is measured against
-# |ref| + rms(row):  |got - ref| <= RTOL * (|ref| + rms_row).
+# Parity bar (BASELINE.json north_star; SURVEY.md 8 d-metric): 1e-4 relative in fp32 with an absolute floor of
+# 1e-6 for entries near zero:   |got - ref| <= RTOL * |ref| + ATOL.
+# One exception, the dlogp / trace row of a state matrix (row n_in of `du` / `fsol`): it is a sum of n_in signed
+# terms eps_i (J^T eps)_i of O(1) size that can cancel to ~0 for a sample, so its fp32 rounding noise scales
+# with the ROW's magnitude, not the entry's.  That row alone is measured against |ref| + rms(row).
 RTOL = 1e-4
+ATOL = 1e-6
+
+# every assert_parity call files its numbers here; the GPU suite writes them to parity_report.json at exit
+REPORT = []
 
 
-def parity_err(got, ref):
+def _bars(ref, rtol, atol, trace_row):
+    """Allowed |got - ref| per entry."""
+    bar = rtol * np.abs(ref) + atol
+    if trace_row is not None and ref.ndim == 2 and 0 <= trace_row < ref.shape[0]:
+        row = ref[trace_row]
+        bar[trace_row] = rtol * (np.abs(row) + np.sqrt(np.mean(row * row))) + atol
+    return bar
+
+
+def parity_err(got, ref, rtol=RTOL, atol=None, trace_row=None):
+    """max over entries of |got - ref| / bar  (<= 1 passes)."""
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (got.shape, ref.shape)
     if ref.size == 0:
         return 0.0
-    if ref.ndim == 1:
-        scale = np.sqrt(np.mean(ref * ref))
-    else:
-        scale = np.sqrt(np.mean(ref * ref, axis=-1, keepdims=True))
-    return float(np.max(np.abs(got - ref) / (np.abs(ref) + scale + 1e-30)))
+    if atol is None:
+        atol = ATOL * (rtol / RTOL)
+    return float(np.max(np.abs(got - ref) / _bars(ref, rtol, atol, trace_row)))
 
 
-def assert_parity(got, ref, what="", rtol=RTOL):
-    assert np.all(np.isfinite(np.asarray(got, dtype=np.float64))), f"{what}: non-finite output"
-    e = parity_err(got, ref)
-    assert e <= rtol, f"{what}: parity error {e:.3e} > {rtol:g}"
+def assert_parity(got, ref, what="", rtol=RTOL, atol=None, trace_row=None):
+    """``trace_row``: index of the dlogp row when ``got`` is a D x B state matrix (see above)."""
+    g64 = np.asarray(got, dtype=np.float64)
+    r64 = np.asarray(ref, dtype=np.float64)
+    assert np.all(np.isfinite(g64)), f"{what}: non-finite output"
+    e = parity_err(g64, r64, rtol, atol, trace_row)
+    if r64.size:
+        d = np.abs(g64 - r64)
+        rel = d / (np.abs(r64) + 1e-2 * (np.sqrt(np.mean(r64 * r64)) + 1e-30))
+        rec = {"what": what, "shape": list(r64.shape), "rtol": rtol, "err_over_bar": e,
+               "max_abs_err": float(d.max()), "max_rel_err": float(rel.max()), "mean_rel_err": float(rel.mean())}
+        if r64.ndim == 2 and trace_row is not None:
+            rows = {"z": slice(0, trace_row), "dlogp": slice(trace_row, trace_row + 1),
+                    "E_n": slice(trace_row + 1, r64.shape[0])}
+            rec["rows"] = {k: {"max_rel_err": float(rel[v].max()), "mean_rel_err": float(rel[v].mean())}
+                           for k, v in rows.items() if rel[v].size}
+        REPORT.append(rec)
+    assert e <= 1.0, f"{what}: parity error {e:.3f} x the bar (rtol {rtol:g})"
     return e
 
 

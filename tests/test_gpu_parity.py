@@ -51,13 +51,13 @@ def test_rhs_matches_golden(name, kernel):
         tag = "jvp" if jvp else "vjp"
         # host arrays -> cnf_rhs_host; device tensors -> cnf_rhs
         du = cnf.augmented_f(g["u_train"], g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, g["eps"])
-        assert_parity(du, g[f"du_train_{tag}"], f"{name} train {tag} host")
+        assert_parity(du, g[f"du_train_{tag}"], f"{name} train {tag} host", trace_row=cfg.n_in)
         du_d = cnf.augmented_f(_dev(g["u_train"]), g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, _dev(g["eps"]))
         assert du_d.shape == g["u_train"].shape
-        assert_parity(du_d.cpu().numpy(), g[f"du_train_{tag}"], f"{name} train {tag} device")
+        assert_parity(du_d.cpu().numpy(), g[f"du_train_{tag}"], f"{name} train {tag} device", trace_row=cfg.n_in)
         if _supported(icnf, cnf.TestMode(), g["u_train"].shape[1]):
             dt = cnf.augmented_f(g["u_train"][: cfg.n_in + 1], g["flat"], 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)
-            assert_parity(dt, g["du_test"], f"{name} test")
+            assert_parity(dt, g["du_test"], f"{name} test", trace_row=cfg.n_in)
         else:   # an explicit request for a kernel that does not exist fails loudly
             with pytest.raises(cnf.CNFError) as e:
                 cnf.augmented_f(g["u_train"][: cfg.n_in + 1], g["flat"], 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)
@@ -74,7 +74,7 @@ def test_rhs_inplace_form(kernel):
     du = torch.full_like(u, float("nan"))
     r = cnf.augmented_f(du, u, g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, eps)   # icnf.jl:352-382
     assert r is None
-    assert_parity(du.cpu().numpy(), g["du_train_vjp"], "in-place")
+    assert_parity(du.cpu().numpy(), g["du_train_vjp"], "in-place", trace_row=cfg.n_in)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -89,7 +89,7 @@ def test_rhs_ragged_batches(B, kernel):
     _skip_if_unsupported(icnf, cnf.TrainMode(), B)
     du = cnf.augmented_f(u, flat, 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, eps)
     ref = cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True)(u.astype(np.float64))
-    assert_parity(du, ref, f"B={B}")
+    assert_parity(du, ref, f"B={B}", trace_row=cfg.n_in)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -110,8 +110,8 @@ def test_rhs_baseline_configs_vs_c_oracle(i, kernel):
             continue
         du = cnf.augmented_f(u, flat, 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, eps)
         ref = cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True)(u.astype(np.float64))
-        assert_parity(du, ref, f"cfg{i} train jvp={jvp}")
-        assert_parity(du, CO.rhs(cfg, flat, u, eps, True), f"cfg{i} vs C oracle")
+        assert_parity(du, ref, f"cfg{i} train jvp={jvp}", trace_row=cfg.n_in)
+        assert_parity(du, CO.rhs(cfg, flat, u, eps, True), f"cfg{i} vs C oracle", trace_row=cfg.n_in)
         icnf.close()
     cfg.use_jvp = False
     icnf = make_icnf(cnf, cfg, kernel=kernel)
@@ -119,7 +119,7 @@ def test_rhs_baseline_configs_vs_c_oracle(i, kernel):
     if not _supported(icnf, cnf.TestMode(), Bt):
         return
     dt = cnf.augmented_f(u[: cfg.n_in + 1, :Bt], flat, 0.0, icnf, cnf.TestMode(), icnf.nn, {}, None)
-    assert_parity(dt, CO.rhs(cfg, flat, u[: cfg.n_in + 1, :Bt], None, False), f"cfg{i} test")
+    assert_parity(dt, CO.rhs(cfg, flat, u[: cfg.n_in + 1, :Bt], None, False), f"cfg{i} test", trace_row=cfg.n_in)
 
 
 # ---------------------------------------------------------------------------------------
@@ -139,7 +139,7 @@ def test_fixed_dt_inference_matches_golden(name, kernel):
         prob = cnf.inference_prob(icnf, cnf.TrainMode(), _dev(g["xs"]), g["flat"], {}, eps=_dev(g["eps"]))
         fsol = cnf.base_sol(icnf, prob)
         assert prob.stats["nf"] == int(g[f"nf_train_{tag}"])
-        assert_parity(fsol.view().cpu().numpy(), g[f"fsol_train_{tag}"], f"{name} fsol {tag}")
+        assert_parity(fsol.view().cpu().numpy(), g[f"fsol_train_{tag}"], f"{name} fsol {tag}", trace_row=cfg.n_in)
         logpx, (E, n, A) = cnf.inference(icnf, cnf.TrainMode(), _dev(g["xs"]), g["flat"], {}, eps=_dev(g["eps"]))
         assert_parity(logpx.cpu().numpy(), g[f"logpx_train_{tag}"], f"{name} logpx {tag}")
         assert_parity(torch.stack([E, n, A]).cpu().numpy(), g[f"regs_train_{tag}"], f"{name} regs {tag}")
@@ -184,8 +184,8 @@ def test_adaptive_solve_vs_oracles(i, kernel):
     assert abs(st["t_final"] - cfg.tspan[1]) < 1e-6
     ref64, _ = O.tsit5_solve(cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True),
                              u0.astype(np.float64), *cfg.tspan, reltol=1e-10, abstol=1e-10)
-    assert_parity(fsol, ref64, f"cfg{i} adaptive vs float64", rtol=5e-3)
-    assert_parity(fsol, cref, f"cfg{i} adaptive vs C oracle", rtol=2e-3)
+    assert_parity(fsol, ref64, f"cfg{i} adaptive vs float64", rtol=5e-3, trace_row=cfg.n_in)
+    assert_parity(fsol, cref, f"cfg{i} adaptive vs C oracle", rtol=2e-3, trace_row=cfg.n_in)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -241,7 +241,7 @@ def test_full_size_cfg3_properties(kernel):
     assert torch.allclose(du[cfg.n_in + 1], du[: cfg.n_in].norm(dim=0), rtol=1e-5)
     idx = rng.choice(B, 256, replace=False)
     ref = cfg.rhs(flat.astype(np.float64), eps[:, idx].astype(np.float64), True)(u[:, idx].astype(np.float64))
-    assert_parity(du[:, torch.from_numpy(idx).cuda()].cpu().numpy(), ref, "cfg3 sampled columns")
+    assert_parity(du[:, torch.from_numpy(idx).cuda()].cpu().numpy(), ref, "cfg3 sampled columns", trace_row=cfg.n_in)
     # FFJORD switches (lambda = 0): regulariser rows are exactly zero (icnf.jl:337-340, 344-347)
     cfg4, _, _ = O.baseline_cfg(4)
     ic4 = make_icnf(cnf, cfg4, kernel=kernel)
@@ -410,13 +410,13 @@ def test_conditional_models(kernel, dims, nvars, naugs):
         cfg = O.Cfg(net, nvars, naugs, 1e-2, 1e-2, 1e-2 if naugs else 0.0, jvp)
         nnc = cnf.CondLayer(icnf.nn, ys)
         du = cnf.augmented_f(u, flat, 0.0, icnf, cnf.TrainMode(), nnc, {}, eps)
-        assert_parity(du, cfg.rhs(f64(flat), f64(eps), True, f64(ys))(f64(u)), f"cond train jvp={jvp}")
+        assert_parity(du, cfg.rhs(f64(flat), f64(eps), True, f64(ys))(f64(u)), f"cond train jvp={jvp}", trace_row=n_in)
         # device arrays
         du_d = cnf.augmented_f(_dev(u), flat, 0.0, icnf, cnf.TrainMode(), cnf.CondLayer(icnf.nn, _dev(ys)), {}, _dev(eps))
-        assert_parity(du_d.cpu().numpy(), du, "cond device == host", rtol=1e-6)
+        assert_parity(du_d.cpu().numpy(), du, "cond device == host", rtol=1e-6, trace_row=n_in)
         if _supported(icnf, cnf.TestMode(), B):
             dt = cnf.augmented_f(u[: n_in + 1], flat, 0.0, icnf, cnf.TestMode(), nnc, {}, None)
-            assert_parity(dt, cfg.rhs(f64(flat), None, False, f64(ys))(f64(u[: n_in + 1])), "cond test")
+            assert_parity(dt, cfg.rhs(f64(flat), None, False, f64(ys))(f64(u[: n_in + 1])), "cond test", trace_row=n_in)
         logpx, (E, n, A) = cnf.inference(icnf, cnf.TrainMode(), xs, ys, flat, {}, eps=eps)
         _, ref_lp, (rE, rn, rA), st = O.inference(cfg, f64(flat), f64(xs), f64(eps), True, f64(ys), dt=1 / 16, adaptive=False)
         assert_parity(logpx, ref_lp, f"cond logpx jvp={jvp}")
@@ -461,9 +461,9 @@ def test_full_size_cfg5_properties():
     assert abs(d.mean()) < 5 * d.std() / np.sqrt(B)
     idx = rng.choice(B, 64, replace=False)
     ref_te = cfg.rhs(flat.astype(np.float64), None, False)(u[: cfg.n_in + 1, idx].astype(np.float64))
-    assert_parity(te[:, torch.from_numpy(idx).cuda()].cpu().numpy(), ref_te, "cfg5 exact trace, sampled columns")
+    assert_parity(te[:, torch.from_numpy(idx).cuda()].cpu().numpy(), ref_te, "cfg5 exact trace, sampled columns", trace_row=cfg.n_in)
     ref_tr = cfg.rhs(flat.astype(np.float64), eps[:, idx].astype(np.float64), True)(u[:, idx].astype(np.float64))
-    assert_parity(tr[:, torch.from_numpy(idx).cuda()].cpu().numpy(), ref_tr, "cfg5 Hutchinson, sampled columns")
+    assert_parity(tr[:, torch.from_numpy(idx).cuda()].cpu().numpy(), ref_tr, "cfg5 Hutchinson, sampled columns", trace_row=cfg.n_in)
     # exact logpdf (README usage: ICNFDist(icnf, TestMode(), ps, st)) vs a float64 solve on a few columns
     ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
     xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
@@ -539,11 +539,11 @@ def test_lockstep_shards_follow_the_unsharded_solve(kernel):
     assert abs(st[0]["naccept"] - ref_st["naccept"]) <= 1 and st[0]["nreject"] == ref_st["nreject"], (st, ref_st)
     assert abs(st[0]["dt_last"] - ref_st["dt_last"]) <= 0.25 * ref_st["dt_last"]
     assert calls[0] == calls[1] == 2 + st[0]["naccept"] + st[0]["nreject"]
-    assert_parity(got, ref, "lock-step shards vs unsharded", rtol=1e-4)
+    assert_parity(got, ref, "lock-step shards vs unsharded", rtol=1e-4, trace_row=cfg.n_in)
 
     ind, st_i, _ = run(False)
     assert st_i[0]["dt_last"] != st_i[1]["dt_last"]                   # the coupling the lock-step removes
-    assert_parity(ind, ref, "independent shards vs unsharded", rtol=5e-3)   # still within solver tolerance
+    assert_parity(ind, ref, "independent shards vs unsharded", rtol=5e-3, trace_row=cfg.n_in)   # still within solver tolerance
 
     # switching the callback off again restores independent solves; fixed-dt never calls it
     ic = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=dict(adaptive=False, dt=1 / 16))
@@ -745,7 +745,7 @@ def test_exact_trace_mfma_deep_networks():
         c64 = O.Cfg(net, cfg.nvars, cfg.naugs)
         ref = O.augmented_f_test(net, flat.astype(np.float64), u.astype(np.float64), False,
                                  None if ys is None else ys.astype(np.float64))
-        assert_parity(du, ref, f"exact trace case {k}")
+        assert_parity(du, ref, f"exact trace case {k}", trace_row=cfg.n_in)
     # a full adaptive TestMode inference on config 3 (what pdf(ICNFDist(TestMode)) runs) vs the float64 oracle
     cfg, _, _ = O.baseline_cfg(3)
     rng = np.random.default_rng(9)
@@ -775,7 +775,7 @@ def test_jvp_mode_large_network_on_mfma():
     du = cnf.augmented_f(_dev(u), flat, 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, _dev(eps)).cpu().numpy()
     ref = O.augmented_f_train(cfg.net, flat.astype(np.float64), u.astype(np.float64), eps.astype(np.float64),
                               cfg.lam1 != 0, cfg.lam2 != 0, use_jvp=True)
-    assert_parity(du, ref, "cfg5 JVP RHS")
+    assert_parity(du, ref, "cfg5 JVP RHS", trace_row=cfg.n_in)
     # and through a fixed-dt solve
     ic = make_icnf(cnf, cfg, jvp=True, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
     xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
@@ -818,7 +818,7 @@ def test_auto_uses_standalone_vjp_kernel_for_streamed_weights():
     for kernel in ("auto", "mfma"):
         ic = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=dict(adaptive=False, dt=1 / 8))
         du = cnf.augmented_f(_dev(u), flat, 0.0, ic, cnf.TrainMode(), ic.nn, {}, _dev(eps)).cpu().numpy()
-        assert_parity(du, ref, f"cfg5 VJP RHS, kernel={kernel}")
+        assert_parity(du, ref, f"cfg5 VJP RHS, kernel={kernel}", trace_row=cfg.n_in)
         logpx, _ = cnf.inference(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
         assert_parity(logpx.cpu().numpy(), ref_lp, f"cfg5 VJP logpx, kernel={kernel}")
         assert ic.last_stats["kernel_used"] == _lib.KERNEL_MFMA
@@ -882,3 +882,58 @@ def test_inference_with_sums_and_distributed_loss_single_process():
         assert abs(val - cnf.loss(ic, mode, xs, flat, {}, eps=eps)) <= 1e-6 * max(1.0, abs(val))
     with pytest.raises(ValueError):
         cnf.inference(ic, cnf.TrainMode(), xs.cpu().numpy(), flat, {}, eps=eps.cpu().numpy(), with_sums=True)
+
+
+def test_upload_cache_is_keyed_on_the_object_not_its_address():
+    """Two temporaries of equal size in a row: the caching allocator may hand the second one the address of the
+    first, so an address-keyed upload cache would silently keep the old weights (round-1 advisor finding)."""
+    g, cfg = load_golden("cfg2_regression")
+    icnf = make_icnf(cnf, cfg, sol_kwargs=dict(adaptive=False, dt=float(g["dt"])))
+    xs, eps = _dev(g["xs"]), _dev(g["eps"])
+
+    def run(scale):
+        return cnf.inference(icnf, cnf.TrainMode(), xs, torch.from_numpy(g["flat"] * scale).cuda(), {}, eps=eps)[0].clone()
+
+    a, b = run(1.0), run(0.5)
+    assert not torch.allclose(a, b)
+    assert_parity(a.cpu().numpy(), g["logpx_train_vjp"], "temporary params 1")
+    # in-place update of a tensor the caller keeps: the version counter invalidates the cache
+    ps = torch.from_numpy(g["flat"].copy()).cuda()
+    a2 = cnf.inference(icnf, cnf.TrainMode(), xs, ps, {}, eps=eps)[0].clone()
+    ps.mul_(0.5)
+    b2 = cnf.inference(icnf, cnf.TrainMode(), xs, ps, {}, eps=eps)[0].clone()
+    assert torch.equal(a2, a) and torch.equal(b2, b)
+    # sol_kwargs changed in place are seen too
+    icnf.sol_kwargs["dt"] = float(g["dt"]) / 2
+    c = cnf.inference(icnf, cnf.TrainMode(), xs, ps, {}, eps=eps)[0]
+    assert icnf.last_stats["naccept"] == 2 * round(1.0 / float(g["dt"])) and not torch.equal(c, b2)
+    icnf.close()
+
+
+def test_loss_allreduce_through_the_c_abi_on_real_rccl():
+    """cnf_comm_* / cnf_loss_allreduce against the real librccl: a one-rank communicator on this GPU (two ranks
+    cannot share a device under RCCL; the two-process path is covered on CPU with the test double and by
+    bench.py --gpus N on a multi-GPU node)."""
+    from continuousnf.jl_amd.parallel import RcclComm
+    g, cfg = load_golden("cfg2_regression")
+    icnf = make_icnf(cnf, cfg, sol_kwargs=dict(adaptive=False, dt=float(g["dt"])))
+    comm = RcclComm(1, 0, RcclComm.unique_id(), 0)
+    assert comm.size() == 1 and _lib.lib().cnf_comm_library()
+    _, _, sums = cnf.inference(icnf, cnf.TrainMode(), _dev(g["xs"]), g["flat"], {}, eps=_dev(g["eps"]), with_sums=True)
+    before = sums.clone()
+    out = comm.allreduce_sums(icnf, sums)
+    torch.cuda.synchronize()
+    assert torch.equal(out, before) and float(out[4]) == g["xs"].shape[1]
+    t = torch.arange(1000, dtype=torch.float32, device="cuda")
+    assert torch.equal(comm.allreduce(t.clone()), t)
+    # lock-step through the communicator: with one rank the adaptive solve is the plain adaptive solve
+    kw = dict(reltol=1e-4, abstol=1e-6)
+    ic2 = make_icnf(cnf, cfg, sol_kwargs=kw)
+    ref = cnf.inference(ic2, cnf.TrainMode(), _dev(g["xs"]), g["flat"], {}, eps=_dev(g["eps"]))[0].clone()
+    ref_st = dict(ic2.last_stats)
+    comm.lockstep(ic2)
+    got = cnf.inference(ic2, cnf.TrainMode(), _dev(g["xs"]), g["flat"], {}, eps=_dev(g["eps"]))[0]
+    assert (ic2.last_stats["naccept"], ic2.last_stats["nreject"]) == (ref_st["naccept"], ref_st["nreject"])
+    assert_parity(got.cpu().numpy(), ref.cpu().numpy(), "RCCL lock-step, 1 rank", rtol=1e-5)
+    comm.lockstep(ic2, enable=False)
+    comm.close(); icnf.close(); ic2.close()
