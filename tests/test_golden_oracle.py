@@ -32,20 +32,20 @@ def test_c_oracle_matches_golden(name):
         cfg.use_jvp = jvp
         tag = "jvp" if jvp else "vjp"
         du = CO.rhs(cfg, g["flat"], g["u_train"], g["eps"], True)
-        assert_parity(du, g[f"du_train_{tag}"], f"{name} du train {tag}")
+        assert_parity(du, g[f"du_train_{tag}"], f"{name} du train {tag}", trace_row=cfg.n_in)
         u0 = O.inference_u0(cfg, g["xs"], True)
         fsol, st = CO.solve(cfg, g["flat"], u0, g["eps"], True, dt=float(g["dt"]), adaptive=False)
         assert st["nf"] == int(g[f"nf_train_{tag}"])
-        assert_parity(fsol, g[f"fsol_train_{tag}"], f"{name} fsol train {tag}")
+        assert_parity(fsol, g[f"fsol_train_{tag}"], f"{name} fsol train {tag}", trace_row=cfg.n_in)
         logpx, regs = CO.post(cfg, fsol, True)
         assert_parity(logpx, g[f"logpx_train_{tag}"], f"{name} logpx {tag}")
         assert_parity(regs, g[f"regs_train_{tag}"], f"{name} regs {tag}")
     cfg.use_jvp = False
     du = CO.rhs(cfg, g["flat"], g["u_train"][: cfg.n_in + 1], None, False)
-    assert_parity(du, g["du_test"], f"{name} du test")
+    assert_parity(du, g["du_test"], f"{name} du test", trace_row=cfg.n_in)
     u0 = O.inference_u0(cfg, g["xs"], False)
     fsol, _ = CO.solve(cfg, g["flat"], u0, None, False, dt=float(g["dt"]), adaptive=False)
-    assert_parity(fsol, g["fsol_test"], f"{name} fsol test")
+    assert_parity(fsol, g["fsol_test"], f"{name} fsol test", trace_row=cfg.n_in)
 
 
 def test_c_oracle_adaptive_matches_float32_numpy_stepping():
@@ -62,5 +62,5 @@ def test_c_oracle_adaptive_matches_float32_numpy_stepping():
     ref64, _ = O.tsit5_solve(cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True),
                              u0.astype(np.float64), 0.0, 1.0, reltol=1e-10, abstol=1e-10)
     # at reltol 3.45e-4 the solver error itself bounds agreement
-    assert_parity(got, ref64, "adaptive vs tight float64", rtol=5e-3)
-    assert_parity(got, ref, "adaptive C vs numpy float32", rtol=5e-3)
+    assert_parity(got, ref64, "adaptive vs tight float64", rtol=5e-3, trace_row=cfg.n_in)
+    assert_parity(got, ref, "adaptive C vs numpy float32", rtol=5e-3, trace_row=cfg.n_in)

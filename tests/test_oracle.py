@@ -238,3 +238,25 @@ def test_conditional_layer_matches_autograd():
     Ws, bs = O.unflatten_params(net, flat)
     a1 = Ws[0][:, :n_in] @ z + (Ws[0][:, n_in:] @ ys + bs[0][:, None])
     assert np.allclose(O.mlp_forward(net, flat, z, ys)[1][1], np.tanh(a1), atol=1e-14)
+
+
+def test_blas_baseline_matches_the_oracle():
+    """oracle/cnf_blas.py (bench.py's cpu_baseline: sgemm over the whole n x B matrices on torch-CPU) computes the
+    same RHS and the same solve as the numpy oracle."""
+    from oracle import cnf_blas as BL
+    from tests.helpers import assert_parity
+    for i in (2, 3):
+        cfg, _, _ = O.baseline_cfg(i)
+        rng = np.random.default_rng(40 + i)
+        flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+        B = 96
+        xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+        eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+        u0 = O.inference_u0(cfg, xs, True)
+        ref = cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True)(u0.astype(np.float64))
+        assert_parity(BL.make_rhs(cfg, flat, eps)(u0), ref, f"blas rhs cfg{i}", trace_row=cfg.n_in)
+        got, st = BL.solve(cfg, flat, u0, eps, dt=1 / 8, adaptive=False)
+        want, st2 = O.tsit5_solve(cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True), u0.astype(np.float64),
+                                  0.0, 1.0, dt=1 / 8, adaptive=False)
+        assert st["nf"] == st2.nf
+        assert_parity(got, want, f"blas solve cfg{i}", trace_row=cfg.n_in)
