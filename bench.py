@@ -93,13 +93,16 @@ def cpu_baseline(B, flat, xs, eps, kw, budget_s=9.0):
                     path performs (src/icnf.jl:331-332);
       cpu_port:     the scalar-loop C/OpenMP restatement (oracle/cnf_oracle.c), the second checker of the
                     parity tests."""
-    from oracle import c_oracle as CO
     from oracle import cnf_blas as BL
+    os.environ.setdefault("OMP_NUM_THREADS", str(BL.available_cores()))     # before the OpenMP port is loaded
+    from oracle import c_oracle as CO
     from oracle import cnf_oracle as O
     cfg, _, _ = O.baseline_cfg(3)
     u0 = O.inference_u0(cfg, xs, True)
+    nthr, _ = BL.tune_threads(cfg, flat, u0, eps)         # the fastest thread count on this host (stated as `cores`)
     nf, n, el, st = _timed_solves(lambda: BL.solve(cfg, flat, u0, eps, **kw)[1], budget_s)
-    blas = {"value": nf / el, "unit": "RHS-evals/s", "cores": BL.threads(), "kind": "port",
+    blas = {"value": nf / el, "unit": "RHS-evals/s", "cores": nthr, "host_cores": BL.os_cpu_count(),
+            "available_cores": BL.available_cores(), "kind": "port",
             "impl": "float32 sgemm over the full n x B matrices + tanh, torch-CPU on all host cores; "
                     "Tsit5 driver in numpy (oracle/cnf_blas.py)",
             "sample": f"{n} adaptive Tsit5 solves of the same workload (B={B}, nf={st['nf']} each); restatement "

@@ -38,6 +38,7 @@ struct MfmaPlan {
     int variant = 0;                // 0: shape not supported by the MFMA path
     MfmaLayout ly{};
     float* d_img = nullptr;         // weight+bias image in HBM (LDS order), refreshed by pack
+    float* d_img3 = nullptr;        // variant 2: register-fragment image of k_step3, refreshed by pack
     const float* cond = nullptr;    // conditional models: per-sample first-layer bias [B][cbs] (owned by the handle)
     int cbs = 0;
 };

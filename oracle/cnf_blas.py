@@ -20,6 +20,47 @@ def threads() -> int:
     return torch.get_num_threads()
 
 
+def available_cores() -> int:
+    """Cores this process may really use: the affinity mask, capped by a cgroup CPU quota (a GPU box hands a
+    container a share of the host's cores; torch would otherwise start one thread per host core)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def tune_threads(cfg, flat, u0, eps, reps=3):
+    """Pick the torch thread count that evaluates the RHS fastest (candidates around the available cores) and
+    leave torch set to it.  Returns (threads, rhs_per_s)."""
+    import time
+    import torch
+    avail = available_cores()
+    cands = sorted({max(1, avail // 2), avail, min(2 * avail, os_cpu_count()), os_cpu_count()})
+    f = make_rhs(cfg, flat, eps)
+    best = (0.0, avail)
+    for n in cands:
+        torch.set_num_threads(n)
+        f(u0)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f(u0)
+        rate = reps / (time.perf_counter() - t0)
+        if rate > best[0]:
+            best = (rate, n)
+    torch.set_num_threads(best[1])
+    return best[1], best[0]
+
+
+def os_cpu_count() -> int:
+    import os
+    return os.cpu_count() or 1
+
+
 def make_rhs(cfg: O.Cfg, flat, eps):
     """Returns f(u) -> du for TrainMode/VJP on numpy float32 ``(D, B)`` arrays; all matrix work in torch-CPU."""
     import torch
