@@ -31,6 +31,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # kernel arguments in device memory (see continuousnf.jl_amd/__init__.py)
 
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 PEAK_HBM_GBS = 8000.0       # spec

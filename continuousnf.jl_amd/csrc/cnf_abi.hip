@@ -6,6 +6,9 @@
 #include "cnf_mfma.h"
 #include "cnf_grad.h"
 #include "cnf_trace.h"
+#include "cnf_mirror.h"
+#include <immintrin.h>
+#include <sched.h>
 #include <vector>
 
 #include <cmath>
@@ -44,11 +47,11 @@ struct cnf_ctx {
     StepState* h_state = nullptr; // pinned, two slots for pipelined polling + one init slot
     hipEvent_t ev[2] = {nullptr, nullptr};
     // streamed solve: the step kernel mirrors the state into pinned, host-coherent memory after every
-    // controller run and publishes its launch index in the word behind it; the host polls that word
-    struct HostMirror { StepState s; unsigned seq; };
+    // controller run as tagged granules (cnf_mirror.h); the host polls them
+    typedef CnfMirrorT<StepState> HostMirror;
     HostMirror* h_mirror = nullptr;        // host address
     HostMirror* d_mirror = nullptr;        // the same memory as the device sees it
-    unsigned mirror_base = 0;              // launch indices are monotonic over the handle's life: late launches of
+    unsigned mirror_base = 1;              // launch indices are monotonic over the handle's life: late launches of
                                            // an earlier solve can never look like news of the current one
     // lock-step sharded solves: host callback summing 3 floats over the shards (null: off)
     cnf_shard_reduce_fn shard_reduce = nullptr;
@@ -185,6 +188,7 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     if (e == hipSuccess) e = hipHostMalloc(&h->h_sums, 4 * sizeof(float), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(&h->h_mirror, sizeof(*h->h_mirror), hipHostMallocCoherent | hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_mirror, h->h_mirror, 0);
+    if (e == hipSuccess) memset(h->h_mirror, 0, sizeof(*h->h_mirror));     // tag 0 is never a launch index (mirror_base starts at 1)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[1], hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -827,7 +831,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     const char* ps_ = getenv("CNF_CHUNKED");
     if (use_mfma && !done && (rec || !(ps_ && ps_[0] == '1'))) {
         const int AHEAD = 3;
-        volatile cnf_ctx::HostMirror* hm = h->h_mirror;
+        const volatile cnf_ctx::HostMirror* hm = h->h_mirror;
         const unsigned base = h->mirror_base;
         long sent = 0, seen = 0;                    // launches enqueued; index of the newest mirror read
         const long max_launches = (long)opts->maxiters + 1;
@@ -845,8 +849,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                 StepState* st_next = cur_state == h->d_state ? h->d_state + 1 : h->d_state;
                 s = mfma_step(h->mfma, h->nd, train, cur_state, st_next, h->U, h->K1, h->Ks, eps,
                               h->partials + 2 * MAX_PARTIALS * pp, h->partials + 2 * MAX_PARTIALS * (pp ^ 1), apply,
-                              false, B, st, dump, n, &h->d_mirror->s, &h->d_mirror->seq, base + (unsigned)sent, slot, dcap,
-                              h->traj_hs);
+                              false, B, st, dump, n, h->d_mirror, base + (unsigned)sent, slot, dcap, h->traj_hs);
                 if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
                 if (apply) cur_state = st_next;
                 pp ^= 1;
@@ -858,24 +861,21 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                 HIPCHK(h, hipStreamSynchronize(st));
                 return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
             }
-            // wait for a mirror newer than the last one read (launch 0 writes none: it has no controller to run)
-            unsigned sq;
-            long spins = 0;
-            while ((int)((sq = hm->seq) - base) <= (int)seen) {
-                if (++spins % 200000 == 0) {                       // a faulted kernel would never publish
+            // wait for a consistent snapshot newer than the last one read (launch 0 writes none: it has no controller
+            // to run).  The spin backs off: pause first, yield the core once the wait outlasts a few launches.
+            unsigned sq = 0;
+            StepState snap;
+            for (long spins = 0;; ++spins) {
+                if (cnf_mirror_read(hm, &snap, &sq) && (int)(sq - base) > (int)seen) break;
+                if (spins < 4096) _mm_pause();
+                else sched_yield();
+                if (spins % 100000 == 99999) {                     // a faulted kernel would never publish
                     hipError_t qe = hipStreamQuery(st);
                     if (qe != hipSuccess && qe != hipErrorNotReady) HIPCHK(h, qe);
-                    if (qe == hipSuccess && (int)(hm->seq - base) <= (int)seen)
+                    if (qe == hipSuccess && !(cnf_mirror_read(hm, &snap, &sq) && (int)(sq - base) > (int)seen))
                         return fail(h, CNF_ERR_HIP, "step kernels finished without publishing a state");
+                    if (qe == hipSuccess) break;
                 }
-            }
-            // the state was written before the index (system-scope release); re-read until it is stable
-            StepState snap;
-            for (;;) {
-                memcpy(&snap, const_cast<const StepState*>(&hm->s), sizeof snap);
-                const unsigned sq2 = hm->seq;
-                if (sq2 == sq) break;
-                sq = sq2;
             }
             seen = (long)(sq - base);
             if (snap.done) { fin = snap; done = true; }

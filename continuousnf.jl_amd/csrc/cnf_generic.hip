@@ -89,15 +89,15 @@ k_rhs_generic(NetDesc nd, const float* __restrict__ P, RhsArgs a) {
     float hstep = 0.f;
     if (st) {
         const int cur = st->cur;
-        u = a.U[cur];
-        kb[0] = a.K1[cur];
+        u = (cur ? a.U[1] : a.U[0]);
+        kb[0] = (cur ? a.K1[1] : a.K1[0]);
         for (int j = 1; j < 6; ++j) kb[j] = a.Ks[j - 1];
         hstep = st->h;
     } else {
         u = a.u;
     }
     float* ust = a.ustage;
-    if (st && a.ustage_is_unew) ust = a.U[1 - st->cur];
+    if (st && a.ustage_is_unew) ust = (st->cur ? a.U[0] : a.U[1]);
     for (int r = 0; r < D; ++r) {
         float v = u[(size_t)b * D + r];
         if (a.nk > 0) {
@@ -133,7 +133,7 @@ k_rhs_generic(NetDesc nd, const float* __restrict__ P, RhsArgs a) {
     const int hoffL = hoff;
 
     float* du = a.du;
-    if (st && a.du_is_k7) du = a.K1[1 - st->cur];
+    if (st && a.du_is_k7) du = (st->cur ? a.K1[0] : a.K1[1]);
     float* dub = du + (size_t)b * D;
 
     float ldot = 0.f, nsq = 0.f, esq = 0.f;
@@ -273,8 +273,8 @@ k_norm_partials(NormArgs a) {
     float p0 = 0.f, p1 = 0.f;
     if (!st->done) {
         const int cur = st->cur;
-        const float* u = a.U[cur];
-        const float* k1 = a.K1[cur];
+        const float* u = (cur ? a.U[1] : a.U[0]);
+        const float* k1 = (cur ? a.K1[1] : a.K1[0]);
         const float abstol = st->abstol, reltol = st->reltol;
         const size_t n = a.n;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -291,8 +291,8 @@ k_norm_partials(NormArgs a) {
                 float x = (a.Ks[0][i] - k1[i]) / sk;
                 p0 = fmaf(x, x, p0);
             } else {
-                const float* un = a.U[1 - cur];
-                const float* k7 = a.K1[1 - cur];
+                const float* un = (cur ? a.U[0] : a.U[1]);
+                const float* k7 = (cur ? a.K1[0] : a.K1[1]);
                 float e = TS_BT1 * k1[i];
                 e = fmaf(TS_BT2, a.Ks[0][i], e);
                 e = fmaf(TS_BT3, a.Ks[1][i], e);

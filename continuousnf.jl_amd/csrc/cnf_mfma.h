@@ -66,6 +66,6 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
                      StepState* st_out, float* const U[2], float* const K1[2], float* const Ks[5],
                      const float* eps, const float* partials_in, float* partials_out, bool apply_ctrl,
                      bool finalize, int B, hipStream_t s, float* dump = nullptr,
-                     size_t dump_stride = 0, StepState* mirror = nullptr, unsigned* mirror_seq = nullptr,
+                     size_t dump_stride = 0, void* mirror = nullptr,
                      unsigned seq = 0, size_t dump_step_stride = 0, int dump_cap = 0, float* hs_out = nullptr);
 int mfma_grid_for(int B);

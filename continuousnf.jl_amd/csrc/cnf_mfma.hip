@@ -33,51 +33,18 @@
 // value: any network whose images fit in LDS) and StLayout<...> (sizes and activations
 // are compile-time constants: LDS offsets become instruction immediates, layer loops
 // unroll, no integer address arithmetic is left in the GEMM phases).
-#include "cnf_mfma.h"
-#include "cnf_kernels.h"
+#include "cnf_mfma_dev.h"
+#include "cnf_step3.h"
 
 #include <cstdlib>
 #include <type_traits>
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // k_mfma geometry: 2 teams (one per 16-sample column tile) of MF_WPT = 4 waves: 512 lanes,
 // 2 waves per SIMD, <= 256 VGPRs.
 #define MF_WPT 4
 #define MF_KTHREADS (MF_WPT * 128)
 
-struct MfmaArgs {
-    int mode;                 // 0: plain RHS (u -> du), 1: probe f(u + h k1) -> Ks[0], 2: Tsit5 step
-    int B;
-    const float* img;         // weight+bias image
-    const float* eps;         // n_in x B
-    const float* u;           // mode 0
-    float* du;                // mode 0
-    const StepState* st;      // mode 1, 2: state to run from (mode 2 + apply_ctrl: state BEFORE the controller)
-    StepState* st_out;        // mode 2 + apply_ctrl: where block 0 stores the state after the controller
-    const float* partials_in; // mode 2 + apply_ctrl: error partials of the previous attempt
-    int apply_ctrl;
-    float n_total;            // D * B
-    const float* cond;        // conditional models: per-sample first-layer bias [B][cbs], else null
-    int cbs;
-    int test;                 // TestMode: exact trace (2-layer closed form), state rows = n_in + 1
-    const float* cimg;        // TestMode: row-major image of C = W_1 .* W_2^T  (P1 x SWC)
-    int SWC;
-    float* U[2];
-    float* K1[2];
-    float* Ks0;               // mode 1 output
-    float* partials;          // mode 2: 2 floats per workgroup
-    int init_phase;           // modes 0/1 inside a solve: also produce the norm partials of initial-dt phase 0/1 and let
-    unsigned* ticket;         //   the last workgroup to finish run that controller phase on *st_out (-1: off)
-    StepState* mirror;        // streamed solve: pinned host copy of the state after each controller run ...
-    unsigned* mirror_seq;     //   ... published by storing this launch's index here (after the state)
-    unsigned seq;
-    float* dump;              // mode 2, gradient path: z rows of the stage states U_2..U_6 go to dump + (stage - 2) * dump_stride
-    size_t dump_stride;       //   ([B][D] arrays like the state), else null
-    size_t dump_step_stride;  // != 0: trajectory store indexed on the device -- this attempt files into the slot of step
-    int dump_cap;             //   `naccept` (u_n one array before `dump`, then U_2..U_6), if naccept < dump_cap, and its
-    float* hs_out;            //   signed step size into hs_out[naccept]
-};
 
 // ---- layouts -------------------------------------------------------------------------------
 __host__ __device__ constexpr int pad_to(int x, int residue, int modulus) {  // smallest y >= x, y % modulus == residue
@@ -192,13 +159,6 @@ __device__ __forceinline__ void for_layers_down(const LY& ly, F&& f) {
 }
 
 // ---- activation helpers ------------------------------------------------------------------
-// tanh(a) = 1 - 2/(exp(2a) + 1): v_mul, v_exp, v_add, v_rcp, v_fma.  Absolute error
-// <= 2e-7 (one rounding of values near 1), which is what every other fp32 activation value
-// carries; measured against the parity metric it is indistinguishable from libm's tanh.
-__device__ __forceinline__ float tanh_fast(float a) {
-    const float t = __builtin_amdgcn_exp2f(a * 2.8853900817779268f);
-    return fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
-}
 __device__ __forceinline__ void act_fast(int kind, float a, float& h, float& d) {
 #ifdef MF_ABL_NOACT
     h = a; d = 1.0f; return;
@@ -417,11 +377,6 @@ __device__ __forceinline__ void team_barrier(unsigned*, unsigned&, int) {
     __syncthreads();
 }
 
-__device__ __forceinline__ float quad_sum(float v) {     // sum over the 4 lanes l, l^16, l^32, l^48
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
 
 // ---- epilogues ---------------------------------------------------------------------------------
 // forward tile: bias + activation; hidden layers store h.  The last layer keeps zdot in
@@ -696,79 +651,6 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
     });
 }
 
-// Tsit5 stage combination sum_j a_{S+1,j} k_j (S = 1..6) on 4 rows at once
-template <int S>
-__device__ __forceinline__ f32x4 stage_acc4(const f32x4 (&k)[7]) {
-    constexpr float A[7][6] = {
-        {0, 0, 0, 0, 0, 0},
-        {TS_A21, 0, 0, 0, 0, 0},
-        {TS_A31, TS_A32, 0, 0, 0, 0},
-        {TS_A41, TS_A42, TS_A43, 0, 0, 0},
-        {TS_A51, TS_A52, TS_A53, TS_A54, 0, 0},
-        {TS_A61, TS_A62, TS_A63, TS_A64, TS_A65, 0},
-        {TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76}};
-    f32x4 acc = A[S][0] * k[0];
-#pragma unroll
-    for (int j = 1; j < S; ++j) acc += A[S][j] * k[j];
-    return acc;
-}
-__device__ __forceinline__ f32x4 stage_acc4_rt(int stg, const f32x4 (&k)[7]) {
-    switch (stg) {
-        case 1: return stage_acc4<1>(k);
-        case 2: return stage_acc4<2>(k);
-        case 3: return stage_acc4<3>(k);
-        case 4: return stage_acc4<4>(k);
-        case 5: return stage_acc4<5>(k);
-        default: return stage_acc4<6>(k);
-    }
-}
-__device__ __forceinline__ void set_k(f32x4 (&k)[7], int idx, const f32x4& v) {
-    // select per slot: keeps every k[i] in registers (a switch turns into an indexed store
-    // and sends the array to scratch)
-#pragma unroll
-    for (int i = 1; i < 7; ++i) k[i] = idx == i ? v : k[i];
-}
-__device__ __forceinline__ f32x4 ld4(const float* p, int nvalid4) {   // rows beyond n_in read as 0
-    // one branch for "nothing valid" (never touches memory then); otherwise branch-free:
-    // out-of-range elements re-read element 0 and are zeroed, so the four loads issue back to back
-    if (nvalid4 <= 0) return f32x4{0.f, 0.f, 0.f, 0.f};
-    const int i1 = nvalid4 > 1 ? 1 : 0, i2 = nvalid4 > 2 ? 2 : 0, i3 = nvalid4 > 3 ? 3 : 0;
-    const float v0 = p[0], v1 = p[i1], v2 = p[i2], v3 = p[i3];
-    return f32x4{nvalid4 > 0 ? v0 : 0.f, nvalid4 > 1 ? v1 : 0.f, nvalid4 > 2 ? v2 : 0.f, nvalid4 > 3 ? v3 : 0.f};
-}
-// Branch-free variant for the kernel prologue: `ld4_issue` only issues the four loads (always from valid
-// addresses: `safe` stands in when there is nothing to read), `ld4_mask` zeroes what was not asked for.
-// A branch around a load makes the compiler wait for it at once; issuing all prologue loads first and
-// masking afterwards keeps ~30 loads in flight instead of 8 serial groups of 4.
-__device__ __forceinline__ f32x4 ld4_issue(const float* p, int nvalid4, const float* safe) {
-    const float* q = nvalid4 > 0 ? p : safe;
-    const int i1 = nvalid4 > 1 ? 1 : 0, i2 = nvalid4 > 2 ? 2 : 0, i3 = nvalid4 > 3 ? 3 : 0;
-    return f32x4{q[0], q[i1], q[i2], q[i3]};
-}
-__device__ __forceinline__ f32x4 ld4_mask(const f32x4& v, int nvalid4) {
-    return f32x4{nvalid4 > 0 ? v.x : 0.f, nvalid4 > 1 ? v.y : 0.f, nvalid4 > 2 ? v.z : 0.f, nvalid4 > 3 ? v.w : 0.f};
-}
-__device__ __forceinline__ void st4(float* p, const f32x4& v, int nvalid4) {
-    if (nvalid4 > 0) p[0] = v.x;
-    if (nvalid4 > 1) p[1] = v.y;
-    if (nvalid4 > 2) p[2] = v.z;
-    if (nvalid4 > 3) p[3] = v.w;
-}
-__device__ __forceinline__ void err_acc(float& errsum, float& badcnt, const f32x4 (&k)[7], const f32x4& u,
-                                        const f32x4& un, float h, float abstol, float reltol, int nvalid4) {
-    f32x4 e = TS_BT1 * k[0] + TS_BT2 * k[1] + TS_BT3 * k[2] + TS_BT4 * k[3] + TS_BT5 * k[4] + TS_BT6 * k[5] +
-              TS_BT7 * k[6];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if (c < nvalid4) {
-            const float sc = fmaf(fmaxf(fabsf(u[c]), fabsf(un[c])), reltol, abstol);
-            const float x = h * e[c] / sc;
-            errsum = fmaf(x, x, errsum);
-            if (!(fabsf(un[c]) <= 3.0e38f)) badcnt += 1.f;
-        }
-    }
-}
-
 // One workgroup = one 32-sample tile (two teams of 16 samples).  The Runge-Kutta state is
 // kept in registers in the MFMA accumulator layout: the lane that produces rows 4q..4q+3
 // of zdot for sample s (wave fg owns the 16-row tiles fg and fg+4 of the n_in rows) holds
@@ -780,19 +662,6 @@ __device__ __forceinline__ void err_acc(float& errsum, float& badcnt, const f32x
 // Two instantiations so that profiles name the step kernel and the plain RHS kernel apart.
 // Streamed solve: block 0 copies the integrator state to pinned host memory after every controller run and
 // then publishes the launch index; the host polls that word instead of waiting on events and copies.
-__device__ __forceinline__ void publish_mirror(const MfmaArgs& a, const StepState& z) {
-    if (!a.mirror) return;
-    // system-scope stores word by word (write-through to the host), wait for them, then the index: no
-    // release fence -- that would write back this XCD's whole L2 on every launch
-    static_assert(sizeof(StepState) % 4 == 0, "copied as 32-bit words");
-    const unsigned* src = reinterpret_cast<const unsigned*>(&z);
-    unsigned* dst = reinterpret_cast<unsigned*>(a.mirror);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(StepState) / 4); ++i)
-        __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(a.mirror_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 template <class LY, bool STEP>
 __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, MfmaArgs a) {
@@ -885,8 +754,10 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
     const int r00 = 16 * fg + 4 * q, r01 = r00 + 16 * MF_WPT;   // first owned row of each tile
     const int nv0 = own0 ? n_in - r00 : 0, nv1 = own1 ? n_in - r01 : 0;   // valid rows (may be <= 0 or > 4)
     const int row = TNB * team + s;
-    const float* Uin = mode == 0 ? a.u : a.U[cur];
-    const float* K1in = mode == 0 ? nullptr : a.K1[cur];
+    // (explicit selects: indexing the kernel-argument arrays with a run-time value makes the compiler fetch the
+    // pointer from the argument segment through a vector load -- a memory round trip in front of the state loads)
+    const float* Uin = mode == 0 ? a.u : (cur ? a.U[1] : a.U[0]);
+    const float* K1in = mode == 0 ? nullptr : (cur ? a.K1[1] : a.K1[0]);
     float errsum = 0.f, badcnt = 0.f;
     unsigned* bar = (unsigned*)(lds + ly.bar_off()) + team;
 #ifdef MF_STAMPS
@@ -1018,8 +889,8 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                     if (sown) acc(sc_get(0), sc_get(1), sc_get(2), nsc);
                 }
             } else {
-                float* Un = a.U[1 - cur] + gcol;
-                float* K7 = a.K1[1 - cur] + gcol;
+                float* Un = (cur ? a.U[0] : a.U[1]) + gcol;
+                float* K7 = (cur ? a.K1[0] : a.K1[1]) + gcol;
                 if (own0) {
                     st4(Un + r00, un0, nv0); st4(K7 + r00, kz0[6], nv0);
                     err_acc(errsum, badcnt, kz0, uz0, un0, hstep, abstol, reltol, nv0);
@@ -1098,357 +969,6 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
             }
         }
     }
-}
-
-// =================================================================================================
-// k_step3 -- the Tsit5 step kernel of the headline shape 32 -> 128 -> 128 -> 32, tanh (BASELINE configs 3
-// and 4; any net that pads to it), second generation.  Same arithmetic as k_mfma<LyCfg3, true>, same
-// interface (MfmaArgs, mode 2), different schedule:
-//
-//  * WEIGHTS LIVE IN REGISTERS for the whole launch.  Wave w owns output rows 16w..16w+15 of both wide
-//    layers in both sweeps: its A operands (16 rows of W1, of W2, of W3^T, of W2^T: 8 + 32 + 8 + 32 VGPRs)
-//    never change, so they are loaded once from a fragment-ordered image (one coalesced 1 KiB load per
-//    fragment) and no weight passes through LDS again -- the reverse sweep's 4 x ds_read_b32 column walks
-//    and their bank conflicts are gone, and LDS holds activations only (49 KB instead of 160 KB).
-//    The two narrow products (W3 h2: 2 row tiles, and W1^T g1: 2 row tiles) run on 4 waves each, one per
-//    SIMD (waves 0-3 / waves 4-7), whose fragments share one more set of 32 VGPRs.
-//  * THE TWO 16-SAMPLE HALVES OF THE TILE ARE PIPELINED AGAINST EACH OTHER.  Every wave computes half A,
-//    then half B while the epilogue of A (bias, tanh, store) retires under B's MFMAs; the barrier that
-//    publishes A's activations falls between "MFMAs of B" and "epilogue of B", and the next layer's half A
-//    starts behind it while B's epilogue retires -- so the epilogues of the wide layers leave the
-//    critical path (in k_mfma both halves ran concurrently in different waves and every phase ended with
-//    all epilogues exposed in front of its barrier).
-//  * The Runge-Kutta state of the z rows sits in the lanes that produce zdot (waves 0-3), the three scalar
-//    rows in LDS, as before; the next stage state is formed in the epilogue of the last forward layer.
-// LDS images are [sample][feature] with row strides == 8 (mod 16) floats: conflict-free ds_read_b128 B
-// operands; an accumulator tile is stored with one ds_write_b128 per lane (lane = sample, 4 rows).
-// =================================================================================================
-namespace s3 {
-constexpr int NB = 32, P0 = 32, PH = 128;
-constexpr int SX0 = 40, SXH = 136;
-constexpr int X0 = 0;                          // stage state z            [32][40]
-constexpr int H1 = X0 + NB * SX0;              // h1                       [32][136]
-constexpr int H2 = H1 + NB * SXH;              // h2, then g2 in place     [32][136]
-constexpr int G1 = H2 + NB * SXH;              // g1                       [32][136]
-constexpr int G3 = G1 + NB * SXH;              // g3 = eps .* sigma'(h3)   [32][40]
-constexpr int RED = G3 + NB * SX0;             // partials [e2 t0, e2 t1, ld t0, ld t1, n2 t0, n2 t1][32]
-constexpr int SC = RED + 256;                  // scalar-row Runge-Kutta state [32][8][3]
-constexpr int MISC = SC + NB * 24;             // controller scratch, block reductions (64 words)
-constexpr int TOTAL = MISC + 64;
-constexpr int NFRAG = 28;                      // register fragments per wave: WF1 2, WF2 8, WB3 2, WB2 8, narrow 8
-constexpr int IMG_W = 8 * NFRAG * 256;
-constexpr int IMG_B1 = IMG_W, IMG_B2 = IMG_B1 + PH, IMG_B3 = IMG_B2 + PH;
-constexpr int IMG_FLOATS = IMG_B3 + P0;
-}  // namespace s3
-
-// One 16-row x 16-sample output tile: NU k-blocks of 16 features, A from registers, B from the
-// [sample][feature] image (xb = image + sample * stride + 4q).  Two accumulation chains (even / odd k-steps)
-// so that a wave alone on its SIMD can issue back to back (dependent latency 40 cycles > issue 32).
-template <int NU>
-__device__ __forceinline__ f32x4 s3_gemm(const f32x4 (&wf)[NU], const float* xb) {
-    f32x4 b[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) b[u] = *(const f32x4*)(xb + 16 * u);
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].x, b[u].x, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].y, b[u].y, a1, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].z, b[u].z, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].w, b[u].w, a1, 0, 0, 0);
-    }
-    return a0 + a1;
-}
-__device__ __forceinline__ f32x4 s3_tanh4(const f32x4& a) {
-    return f32x4{tanh_fast(a.x), tanh_fast(a.y), tanh_fast(a.z), tanh_fast(a.w)};
-}
-__device__ __forceinline__ f32x4 s3_dtanh4(const f32x4& h) {       // sigma' from h
-    return f32x4{fmaf(-h.x, h.x, 1.f), fmaf(-h.y, h.y, 1.f), fmaf(-h.z, h.z, 1.f), fmaf(-h.w, h.w, 1.f)};
-}
-
-#ifdef S3_STAMPS
-#define S3T(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
-                    s3acc[i] += t_ - s3last; s3last = t_; } while (0)
-#else
-#define S3T(i) do {} while (0)
-#endif
-__global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __restrict__ img3, int n_in, int norm_z,
-                                                  int norm_j) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const StepState* st = a.st;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int D = n_in + 3;
-    if (st->done) {
-        if (a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
-        return;
-    }
-#ifdef S3_STAMPS
-    unsigned long long s3acc[24] = {0};
-    unsigned long long s3last = __builtin_amdgcn_s_memtime();
-    const unsigned long long s3start = s3last;
-#endif
-    // error partials of the previous attempt: requested first, consumed by the controller below
-    float cp0 = 0.f, cp1 = 0.f;
-    if (a.apply_ctrl) {
-        const int np = st->n_partials;
-        for (int i = tid; i < np; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
-    }
-    // weight fragments -> registers (28 coalesced 1 KiB loads per wave, all in flight together)
-    const int s = lane & 15, q = lane >> 4;
-    f32x4 wF1[2], wF2[8], wB3[2], wB2[8], wN[8];
-    {
-        const f32x4* wp = reinterpret_cast<const f32x4*>(img3) + (size_t)wave * s3::NFRAG * 64 + lane;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) wF1[u] = wp[u * 64];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) wF2[u] = wp[(2 + u) * 64];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) wN[u] = wp[(20 + u) * 64];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) wB3[u] = wp[(10 + u) * 64];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) wB2[u] = wp[(12 + u) * 64];
-    }
-    const int t = wave & 1, hf = (wave >> 1) & 1;         // narrow phases: row tile and sample half of this wave
-    const f32x4 bF1 = *(const f32x4*)(img3 + s3::IMG_B1 + 16 * wave + 4 * q);
-    const f32x4 bF2 = *(const f32x4*)(img3 + s3::IMG_B2 + 16 * wave + 4 * q);
-    const f32x4 bF3 = *(const f32x4*)(img3 + s3::IMG_B3 + 16 * t + 4 * q);
-
-    int cur = 0;
-    float hstep = 0.f, abstol = 0.f, reltol = 0.f;
-    float* msc = lds + s3::MISC;
-    if (a.apply_ctrl) {
-        // In-kernel step controller (as in k_mfma): every workgroup reduces the same partials in the same order
-        // and takes the same decision; block 0 publishes the new state for the next launch and the host mirror.
-        for (int off = 32; off > 0; off >>= 1) { cp0 += __shfl_down(cp0, off, 64); cp1 += __shfl_down(cp1, off, 64); }
-        if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; }
-        __syncthreads();
-        if (tid == 0) {
-            float p0 = 0.f, p1 = 0.f;
-            for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
-            StepState ns = *st;
-            ctrl_after_step(&ns, p0, p1, a.n_total);
-            if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
-            msc[32] = __int_as_float(ns.cur); msc[33] = ns.h; msc[34] = ns.abstol; msc[35] = ns.reltol;
-            msc[36] = __int_as_float(ns.done);
-        }
-        __syncthreads();
-        cur = __float_as_int(msc[32]); hstep = msc[33]; abstol = msc[34]; reltol = msc[35];
-        if (__float_as_int(msc[36])) return;        // the controller just finished the solve
-        __syncthreads();                            // scratch is free again
-    } else {
-        cur = st->cur; hstep = st->h; abstol = st->abstol; reltol = st->reltol;
-    }
-
-    const bool zown = wave < 4;                           // waves 0-3 produce zdot: they hold the z rows of the state
-    const bool sown = zown && t == 0 && q == 0;           // waves 0, 2: lane s holds the scalar rows of sample 16 hf + s
-    const int smp = 16 * hf + s;                          // sample of this lane in the narrow phases
-    const int r0 = 16 * t + 4 * q;                        // first of its 4 rows there
-    const int nv = n_in - r0;                             // valid rows among them (may be <= 0 or > 4)
-    const float* Uin = a.U[cur];
-    const float* K1in = a.K1[cur];
-    float errsum = 0.f, badcnt = 0.f;
-    float* sc = lds + s3::SC + smp * 24;
-    auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
-    auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
-    auto read_scalars = [&]() {
-        const float* r = lds + s3::RED + smp;
-        const float e2 = r[0] + r[32], ld = r[64] + r[96], n2 = r[128] + r[160];
-        return f32x4{ld, norm_z ? __builtin_sqrtf(e2) : 0.f, norm_j ? __builtin_sqrtf(n2) : 0.f, 0.f};
-    };
-    // operand / result addresses of the wide phases (lane = sample s of half A / B, 4 rows 16 wave + 4q ..)
-    const float* x0A = lds + s3::X0 + s * s3::SX0 + 4 * q;
-    const float* x0B = x0A + 16 * s3::SX0;
-    const float* g3A = lds + s3::G3 + s * s3::SX0 + 4 * q;
-    const float* g3B = g3A + 16 * s3::SX0;
-    const float* h1rA = lds + s3::H1 + s * s3::SXH + 4 * q;
-    const float* h1rB = h1rA + 16 * s3::SXH;
-    const float* h2rA = lds + s3::H2 + s * s3::SXH + 4 * q;
-    const float* h2rB = h2rA + 16 * s3::SXH;
-    float* h1wA = lds + s3::H1 + s * s3::SXH + 16 * wave + 4 * q;
-    float* h1wB = h1wA + 16 * s3::SXH;
-    float* h2wA = lds + s3::H2 + s * s3::SXH + 16 * wave + 4 * q;
-    float* h2wB = h2wA + 16 * s3::SXH;
-    float* g1wA = lds + s3::G1 + s * s3::SXH + 16 * wave + 4 * q;
-    float* g1wB = g1wA + 16 * s3::SXH;
-    const float* nrH2 = lds + s3::H2 + smp * s3::SXH + 4 * q;       // narrow phases: B operands of this wave's half
-    const float* nrG1 = lds + s3::G1 + smp * s3::SXH + 4 * q;
-    float* x0w = lds + s3::X0 + smp * s3::SX0 + r0;
-    float* g3w = lds + s3::G3 + smp * s3::SX0 + r0;
-
-    const int ntile = (a.B + s3::NB - 1) / s3::NB;
-    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const int b0 = tile * s3::NB + 16 * hf;
-        const int nvalid = max(0, min(16, a.B - b0));
-        const bool live = s < nvalid;
-        const size_t gcol = (size_t)(b0 + s) * D;
-        f32x4 eps4, uz, kz[7], un;
-        {
-            const float* safe = img3;
-            const float* ep = a.eps + (size_t)(b0 + s) * n_in;
-            const int ce = live ? nv : 0, cu = (zown && live) ? nv : 0, cs = (sown && live) ? 3 : 0;
-            const f32x4 re = ld4_issue(ep + r0, ce, safe);
-            const f32x4 ru = ld4_issue(Uin + gcol + r0, cu, safe), rk = ld4_issue(K1in + gcol + r0, cu, safe);
-            const f32x4 rs0 = ld4_issue(Uin + gcol + n_in, cs, safe), rs1 = ld4_issue(K1in + gcol + n_in, cs, safe);
-            eps4 = ld4_mask(re, ce);
-            uz = ld4_mask(ru, cu);
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 7; ++i) kz[i] = zero;
-            kz[0] = ld4_mask(rk, cu);
-            if (sown) { sc_set(0, ld4_mask(rs0, cs)); sc_set(1, ld4_mask(rs1, cs)); }
-        }
-        un = uz + (hstep * TS_A21) * kz[0];               // state of evaluation 1: U_2 = u + h a21 k1
-        if (zown) *(f32x4*)x0w = un;
-        __syncthreads();
-        S3T(20);
-
-        for (int stg = 1; stg <= 6; ++stg) {
-            // ---- forward ----
-            const f32x4 a1A = s3_gemm<2>(wF1, x0A);
-            const f32x4 a1B = s3_gemm<2>(wF1, x0B);
-            *(f32x4*)h1wA = s3_tanh4(a1A + bF1);
-            S3T(0);
-            __syncthreads();                                                   // h1(A) visible
-            S3T(1);
-            const f32x4 a2A = s3_gemm<8>(wF2, h1rA);
-            *(f32x4*)h1wB = s3_tanh4(a1B + bF1);
-            // scalar rows of the PREVIOUS evaluation from its RED partials: complete since the barrier above,
-            // rewritten from this evaluation's last forward epilogue on
-            if (stg > 1 && sown) sc_set(stg, read_scalars());                  // slot j holds k_j
-            S3T(2);
-            __syncthreads();                                                   // h1(B) visible
-            S3T(3);
-            const f32x4 a2B = s3_gemm<8>(wF2, h1rB);
-            *(f32x4*)h2wA = s3_tanh4(a2A + bF2);
-            S3T(4);
-            __syncthreads();                                                   // h2(A) visible
-            S3T(5);
-            *(f32x4*)h2wB = s3_tanh4(a2B + bF2);
-            S3T(6);
-            __syncthreads();                                                   // h2 complete
-            S3T(7);
-            if (zown) {
-                // last layer on waves 0-3 (one per SIMD): zdot rows r0..r0+3 of sample smp
-                const f32x4 zd = s3_tanh4(s3_gemm<8>(wN, nrH2) + bF3);         // padded rows: zero weights and bias -> 0
-                set_k(kz, stg, zd);
-                const float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
-                if (q == 0) lds[s3::RED + t * 32 + smp] = e2;
-                *(f32x4*)g3w = eps4 * s3_dtanh4(zd);                           // g3 = eps .* sigma'_3
-                if (stg < 6) {                                                 // state of the next evaluation
-                    un = uz + hstep * stage_acc4_rt(stg + 1, kz);
-                    *(f32x4*)x0w = un;
-                }
-            }
-            S3T(8);
-            __syncthreads();                                                   // g3 (and the next stage state) visible
-            S3T(9);
-            // ---- reverse ----
-            const f32x4 hv2A = *(const f32x4*)h2wA;
-            const f32x4 c3A = s3_gemm<2>(wB3, g3A);
-            const f32x4 c3B = s3_gemm<2>(wB3, g3B);
-            *(f32x4*)h2wA = c3A * s3_dtanh4(hv2A);                             // g2 over h2, in place
-            S3T(10);
-            __syncthreads();                                                   // g2(A) visible
-            S3T(11);
-            const f32x4 hv2B = *(const f32x4*)h2wB;
-            const f32x4 c2A = s3_gemm<8>(wB2, h2rA);
-            *(f32x4*)h2wB = c3B * s3_dtanh4(hv2B);
-            S3T(12);
-            __syncthreads();                                                   // g2(B) visible
-            S3T(13);
-            const f32x4 hv1A = *(const f32x4*)h1wA;
-            const f32x4 c2B = s3_gemm<8>(wB2, h2rB);
-            *(f32x4*)g1wA = c2A * s3_dtanh4(hv1A);
-            S3T(14);
-            __syncthreads();                                                   // g1(A) visible
-            S3T(15);
-            const f32x4 hv1B = *(const f32x4*)h1wB;
-            *(f32x4*)g1wB = c2B * s3_dtanh4(hv1B);
-            S3T(16);
-            __syncthreads();                                                   // g1 complete
-            S3T(17);
-            if (!zown) {
-                // eJ = W1^T g1 on waves 4-7 (one per SIMD): trace and norm partials (src/icnf.jl:334, :343)
-                const f32x4 ej = s3_gemm<8>(wN, nrG1);
-                const float ld = quad_sum(-(ej.x * eps4.x + ej.y * eps4.y + ej.z * eps4.z + ej.w * eps4.w));
-                const float n2 = quad_sum(ej.x * ej.x + ej.y * ej.y + ej.z * ej.z + ej.w * ej.w);
-                if (q == 0) { lds[s3::RED + (2 + t) * 32 + smp] = ld; lds[s3::RED + (4 + t) * 32 + smp] = n2; }
-            }
-            S3T(18);
-            // no barrier here: the next evaluation's first layer reads X0 (written two barriers ago) and writes H1,
-            // which the product above does not touch
-        }
-        __syncthreads();                                   // RED of the last evaluation complete
-        S3T(19);
-        if (sown) sc_set(7, read_scalars());
-        // ---- outputs: u_new (= the state evaluation 6 ran at) and k7 ----
-        if (live) {
-            float* Un = a.U[1 - cur] + gcol;
-            float* K7 = a.K1[1 - cur] + gcol;
-            if (zown) {
-                st4(Un + r0, un, nv); st4(K7 + r0, kz[6], nv);
-                err_acc(errsum, badcnt, kz, uz, un, hstep, abstol, reltol, nv);
-            }
-            if (sown) {
-                f32x4 ks[7];
-#pragma unroll
-                for (int j = 0; j < 7; ++j) ks[j] = sc_get(1 + j);
-                const f32x4 us = sc_get(0);
-                const f32x4 uns = us + hstep * stage_acc4<6>(ks);
-                st4(Un + n_in, uns, 3); st4(K7 + n_in, ks[6], 3);
-                err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
-            }
-        }
-        __syncthreads();                                   // this tile's RED / SC / X0 reads precede the next tile's writes
-    }
-    // deterministic block reduction of the error partial (fixed tree, fixed order)
-    for (int off = 32; off > 0; off >>= 1) {
-        errsum += __shfl_down(errsum, off, 64);
-        badcnt += __shfl_down(badcnt, off, 64);
-    }
-    if (lane == 0) { msc[wave] = errsum; msc[16 + wave] = badcnt; }
-    __syncthreads();
-    if (tid == 0) {
-        float e = 0.f, b = 0.f;
-        for (int w = 0; w < 8; ++w) { e += msc[w]; b += msc[16 + w]; }
-        a.partials[2 * blockIdx.x] = e;
-        a.partials[2 * blockIdx.x + 1] = b;
-    }
-#ifdef S3_STAMPS
-    S3T(21);
-    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 1 || wave == 4 || wave == 5))
-        printf("wave %d total %llu pre %llu tail %llu | F1 %llu+%llu F2A %llu+%llu F2B %llu+%llu epi %llu+%llu F3 %llu+%llu | "
-               "B3 %llu+%llu B2A %llu+%llu B2B %llu+%llu epi %llu+%llu B1 %llu fin %llu\n",
-               wave, s3last - s3start, s3acc[20], s3acc[21], s3acc[0], s3acc[1], s3acc[2], s3acc[3], s3acc[4], s3acc[5], s3acc[6],
-               s3acc[7], s3acc[8], s3acc[9], s3acc[10], s3acc[11], s3acc[12], s3acc[13], s3acc[14], s3acc[15], s3acc[16],
-               s3acc[17], s3acc[18], s3acc[19]);
-#endif
-}
-
-// register-fragment image of k_step3 (see the kernel for the fragment order)
-__global__ void k_pack_step3(NetDesc nd, const float* __restrict__ P, float* __restrict__ img) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s3::IMG_FLOATS) return;
-    float v = 0.f;
-    if (i < s3::IMG_W) {
-        const int w = i / (s3::NFRAG * 256), rem = i % (s3::NFRAG * 256);
-        const int j = rem / 256, lane = (rem % 256) / 4, c = rem % 4, s = lane & 15, q = lane >> 4;
-        int l, o, k;
-        if (j < 2)       { l = 0; o = 16 * w + s; k = 16 * j + 4 * q + c; }                 // W1 rows        (forward 1)
-        else if (j < 10) { l = 1; o = 16 * w + s; k = 16 * (j - 2) + 4 * q + c; }           // W2 rows        (forward 2)
-        else if (j < 12) { l = 2; o = 16 * (j - 10) + 4 * q + c; k = 16 * w + s; }          // W3^T rows      (reverse 3)
-        else if (j < 20) { l = 1; o = 16 * (j - 12) + 4 * q + c; k = 16 * w + s; }          // W2^T rows      (reverse 2)
-        else if (w < 4)  { l = 2; o = 16 * (w & 1) + s; k = 16 * (j - 20) + 4 * q + c; }    // W3 rows        (forward 3, waves 0-3)
-        else             { l = 0; o = 16 * (j - 20) + 4 * q + c; k = 16 * (w & 1) + s; }    // W1^T rows      (reverse 1, waves 4-7)
-        if (o < nd.dims[l + 1] && k < nd.dims[l]) v = P[nd.w_off[l] + o + (size_t)k * nd.dims[l + 1]];
-    } else {
-        const int r = i - s3::IMG_W;
-        const int l = r < s3::PH ? 0 : (r < 2 * s3::PH ? 1 : 2);
-        const int o = r - (l == 0 ? 0 : (l == 1 ? s3::PH : 2 * s3::PH));
-        if (o < nd.dims[l + 1]) v = P[nd.b_off[l] + o];
-    }
-    img[i] = v;
 }
 
 // ---- weight image packing -------------------------------------------------------------------
@@ -1603,8 +1123,8 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
     hipLaunchKernelGGL(k_pack_image, dim3((p.ly.img_floats + 255) / 256), dim3(256), 0, s, p.ly, nd,
                        d_params, p.d_img);
     if (p.variant == 2) {       // headline shape: register-fragment image of k_step3
-        if (!p.d_img3 && hipMalloc(&p.d_img3, (size_t)s3::IMG_FLOATS * sizeof(float)) != hipSuccess) return CNF_ERR_HIP;
-        hipLaunchKernelGGL(k_pack_step3, dim3((s3::IMG_FLOATS + 255) / 256), dim3(256), 0, s, nd, d_params, p.d_img3);
+        if (!p.d_img3 && hipMalloc(&p.d_img3, step3_img_floats() * sizeof(float)) != hipSuccess) return CNF_ERR_HIP;
+        step3_pack(nd, d_params, p.d_img3, s);
     }
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
@@ -1646,8 +1166,7 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
         else hipLaunchKernelGGL((k_mfma<RtLayout, false>), grid, block, shm, s, ly, a);
     }
     else if (p.variant == 2 && a.mode == 2 && !a.test && !a.cond && !a.dump && p.d_img3 && !step_v1())
-        hipLaunchKernelGGL(k_step3, grid, dim3(512), (size_t)s3::TOTAL * sizeof(float), s, a, p.d_img3, p.ly.n_in,
-                           p.ly.norm_z, p.ly.norm_j);
+        step3_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s);
     else if (p.variant == 2) launch_static<LyCfg3>(p, a, grid, s);
     else if (p.variant == 3) launch_static<LyCfg2>(p, a, grid, s);
     else if (p.variant == 4) launch_static<LyCfg1>(p, a, grid, s);
@@ -1703,8 +1222,8 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, con
 cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st_in,
                      StepState* st_out, float* const U[2], float* const K1[2], float* const Ks[5],
                      const float* eps, const float* partials_in, float* partials_out, bool apply_ctrl,
-                     bool finalize, int B, hipStream_t s, float* dump, size_t dump_stride, StepState* mirror,
-                     unsigned* mirror_seq, unsigned seq, size_t dump_step_stride, int dump_cap, float* hs_out) {
+                     bool finalize, int B, hipStream_t s, float* dump, size_t dump_stride, void* mirror,
+                     unsigned seq, size_t dump_step_stride, int dump_cap, float* hs_out) {
     if (!mfma_supported(p, nd, train, B)) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
     a.init_phase = -1;
@@ -1716,7 +1235,7 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
     a.partials = partials_out;
     a.dump = dump; a.dump_stride = dump_stride;
     a.dump_step_stride = dump_step_stride; a.dump_cap = dump_cap; a.hs_out = hs_out;
-    a.mirror = mirror; a.mirror_seq = mirror_seq; a.seq = seq;
+    a.mirror = mirror; a.seq = seq;
     cnf_status r = launch(p, a, s);
     if (r != CNF_OK) return r;
     if (finalize) {

@@ -1,0 +1,599 @@
+// k_step3 -- the Tsit5 step kernel of the headline shape 32 -> 128 -> 128 -> 32, tanh (BASELINE configs 3 and
+// 4; any net that pads to it): one launch = one step attempt = 6 evaluations of augmented_f
+// (src/icnf.jl:318-350: Dense+tanh forward, reverse sweep of eps, trace and norm rows) + the stage
+// combinations + the embedded error estimate + the controller of the previous attempt.  Same arithmetic and
+// interface as k_mfma<LyCfg3, true> (cnf_mfma.hip), different schedule:
+//
+//  * WEIGHTS LIVE IN REGISTERS for the whole launch.  Wave w owns output rows 16w..16w+15 of both wide layers in
+//    both sweeps; its A operands (16 rows of W2, of W3^T, of W2^T: 32 + 8 + 32 VGPRs, plus W1 rows on waves 0-3)
+//    never change, so they are loaded once from a fragment-ordered image (one coalesced 1 KiB load per
+//    fragment) and no weight passes through LDS: no column walks (4 x ds_read_b32) in the reverse sweep, no
+//    bank conflicts, and LDS holds activations only.
+//  * THE TWO 16-SAMPLE HALVES OF THE TILE ARE PIPELINED AGAINST EACH OTHER.  Every wave computes half A, then
+//    half B while A's epilogue (bias, tanh, store) retires under B's MFMAs; the barrier that publishes A's
+//    activations sits between "MFMAs of B" and "epilogue of B", and the next layer's half A starts behind it.
+//    Each wide product keeps its last two k-blocks for AFTER the next barrier: the wave first requests the
+//    operands that barrier has just published, then issues those 8 MFMAs while the requests are in flight, so
+//    the LDS round trip behind a barrier is covered by MFMA work that did not depend on it.
+//  * The narrow products run one wave per SIMD: W3 h2 (zdot) on waves 0-3; W1^T g1 (eps^T J) on waves 4-7,
+//    concurrently with the first layer of the NEXT evaluation on waves 0-3 (it only needs the new stage state).
+//  * Runge-Kutta state of the z rows: u, k1 and the running stage sum in the lanes that produce zdot (waves
+//    0-3), k2..k7 in LDS (written and read back by the same lane); the three scalar rows in LDS.
+// LDS images are [sample][feature] with row strides == 8 (mod 16) floats: conflict-free ds_read_b128 B operands;
+// an accumulator tile is stored with one ds_write_b128 per lane (lane = sample, 4 rows).
+#include "cnf_step3.h"
+
+namespace s3 {
+constexpr int NB = 32, P0 = 32, PH = 128;
+constexpr int SX0 = 40, SXH = 136, SKZ = 264, SW2 = 132;
+// LDS plan (floats).  Permanent: the two K = 128 weight images of the narrow products; then the activation area,
+// which the W2 staging image aliases during the prologue.
+constexpr int W1T = 0;                         // rows k of W1^T (k < 32), 128 outs            [32][136]
+constexpr int W3R = W1T + P0 * SXH;            // rows o of W3 (o < 32), 128 ins               [32][136]
+constexpr int X0 = W3R + P0 * SXH;             // stage state z                                [32][40]
+constexpr int H1 = X0 + NB * SX0;              // h1                                           [32][136]
+constexpr int H2 = H1 + NB * SXH;              // h2, then g2 in place                         [32][136]
+constexpr int G1 = H2 + NB * SXH;              // g1                                           [32][136]
+constexpr int G3 = G1 + NB * SXH;              // g3 = eps .* sigma'(h3)                       [32][40]
+constexpr int KZ = G3 + NB * SX0;              // z rows: u, k1, k2..k7                        [32][8*32 (+8)]
+constexpr int RED = KZ + NB * SKZ;             // partials [e2 | ld | n2][32 samples][8 = 2 row tiles x 4 q]
+constexpr int SC = RED + 3 * NB * 8;           // scalar-row Runge-Kutta state [32][8][3]
+constexpr int EPS = SC + NB * 24;              // the probe rows eps                           [32][40]
+constexpr int BIAS = EPS + NB * SX0;           // b1 (128), b2 (128), b3 (32)
+constexpr int MISC = BIAS + 2 * PH + P0;       // controller scratch, block reductions (64 words)
+constexpr int TOTAL = MISC + 64;
+constexpr int STG = X0;                        // prologue only: W2 row-major, stride 132     [128][132]
+static_assert(STG + PH * SW2 <= RED, "the W2 staging image must not reach the scratch that the prologue uses");
+// global image (floats): the LDS images as they are stored, then the register fragments read straight from memory
+constexpr int IMG_W2 = 0;                      // [128][132]
+constexpr int IMG_W1T = IMG_W2 + PH * SW2;     // [32][136]   (W1T and W3R are contiguous: one copy loop)
+constexpr int IMG_W3R = IMG_W1T + P0 * SXH;    // [32][136]
+constexpr int IMG_B1 = IMG_W3R + P0 * SXH, IMG_B2 = IMG_B1 + PH, IMG_B3 = IMG_B2 + PH;
+constexpr int IMG_FR1 = IMG_B3 + P0;           // W1 row fragments, waves 0-3: 4 per wave (tile w: k-blocks 0,1; tile w+4: 0,1)
+constexpr int IMG_FR3 = IMG_FR1 + 4 * 4 * 256; // W3^T row fragments, waves 0-7: 2 per wave
+constexpr int IMG_FLOATS = IMG_FR3 + 8 * 2 * 256;
+}  // namespace s3
+
+// Tsit5 rows a_{s+1, 1..6} (s = 1..6) as data: the stage sums take their coefficients by scalar loads
+__constant__ float S3_A[7][8] = {
+    {0, 0, 0, 0, 0, 0, 0, 0},
+    {TS_A21, 0, 0, 0, 0, 0, 0, 0},
+    {TS_A31, TS_A32, 0, 0, 0, 0, 0, 0},
+    {TS_A41, TS_A42, TS_A43, 0, 0, 0, 0, 0},
+    {TS_A51, TS_A52, TS_A53, TS_A54, 0, 0, 0, 0},
+    {TS_A61, TS_A62, TS_A63, TS_A64, TS_A65, 0, 0, 0},
+    {TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76, 0, 0}};
+
+__constant__ float S3_BT[8] = {TS_BT1, TS_BT2, TS_BT3, TS_BT4, TS_BT5, TS_BT6, TS_BT7, 0};
+
+#define S3_SB() __builtin_amdgcn_sched_barrier(0)
+// workgroup barrier for LDS traffic only: does not drain global loads / stores in flight
+// (the scheduling fences keep register-only instructions -- MFMAs -- in the interval the source puts them in)
+__device__ __forceinline__ void s3_bar() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NU, int NB_>
+__device__ __forceinline__ void s3_load(f32x4 (&b)[NB_], const float* xb, int boff = 0) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) b[boff + u] = *(const f32x4*)(xb + 16 * u);
+}
+// k-blocks [U0, U1) of one 16x16 output tile: A from registers, B from registers; two accumulation chains (even /
+// odd k-steps) so that a wave alone on its SIMD can issue back to back (dependent latency 40 cycles > issue 32)
+template <int U0, int U1, int NW, int NB_>
+__device__ __forceinline__ void s3_mm(f32x4& a0, f32x4& a1, const f32x4 (&wf)[NW], const f32x4 (&b)[NB_], int woff = 0,
+                                      int boff = 0) {
+#pragma unroll
+    for (int u = U0; u < U1; ++u) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[woff + u].x, b[boff + u].x, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[woff + u].y, b[boff + u].y, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[woff + u].z, b[boff + u].z, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[woff + u].w, b[boff + u].w, a1, 0, 0, 0);
+    }
+}
+// Behind a barrier: the 8 operand requests of the next product, issued in the shadow of 4 MFMAs that are ready to go
+// (operands in registers): MFMA, two requests, MFMA, two requests, ...  An in-order wave that issued the requests
+// first would leave the matrix pipe idle for their issue time on both waves of the SIMD at once.
+template <int UW, int UB, int NW, int NB_>
+__device__ __forceinline__ void s3_mm_load(f32x4& a0, f32x4& a1, const f32x4 (&wf)[NW], const f32x4 (&b)[NB_], f32x4 (&nb)[8],
+                                           const float* xb) {
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[UW].x, b[UB].x, a0, 0, 0, 0);
+    nb[0] = *(const f32x4*)(xb); nb[1] = *(const f32x4*)(xb + 16);
+    S3_SB();
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[UW].y, b[UB].y, a1, 0, 0, 0);
+    nb[2] = *(const f32x4*)(xb + 32); nb[3] = *(const f32x4*)(xb + 48);
+    S3_SB();
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[UW].z, b[UB].z, a0, 0, 0, 0);
+    nb[4] = *(const f32x4*)(xb + 64); nb[5] = *(const f32x4*)(xb + 80);
+    S3_SB();
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[UW].w, b[UB].w, a1, 0, 0, 0);
+    nb[6] = *(const f32x4*)(xb + 96); nb[7] = *(const f32x4*)(xb + 112);
+    S3_SB();
+}
+__device__ __forceinline__ f32x4 s3_tanh4(const f32x4& a) {
+    return f32x4{tanh_fast(a.x), tanh_fast(a.y), tanh_fast(a.z), tanh_fast(a.w)};
+}
+__device__ __forceinline__ f32x4 s3_dtanh4(const f32x4& h) {       // sigma' from h
+    return f32x4{fmaf(-h.x, h.x, 1.f), fmaf(-h.y, h.y, 1.f), fmaf(-h.z, h.z, 1.f), fmaf(-h.w, h.w, 1.f)};
+}
+__device__ __forceinline__ float s3_dot4(const f32x4& a, const f32x4& b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+#ifdef S3_STAMPS
+#define S3T(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+                    s3acc[i] += t_ - s3last; s3last = t_; } while (0)
+#else
+#define S3T(i) do {} while (0)
+#endif
+
+__global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __restrict__ img3, int n_in, int norm_z,
+                                                  int norm_j) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const StepState* st = a.st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = n_in + 3;
+    const int s = lane & 15, q = lane >> 4;
+    const int t = wave & 1, hf = (wave >> 1) & 1;         // narrow phases: row tile and sample half of this wave
+    const bool zown = wave < 4;                           // waves 0-3 produce zdot: they hold the z rows of the state
+    const bool sown = !zown && t == 0 && q == 0;          // waves 4, 6: lane s holds the scalar rows of sample 16 hf + s
+    const int smp = 16 * hf + s;                          // sample of this lane in the narrow phases
+    const int r0 = 16 * t + 4 * q;                        // first of its 4 rows there
+    const int nv = n_in - r0;                             // valid rows among them (may be <= 0 or > 4)
+#ifdef S3_STAMPS
+    unsigned long long s3acc[36] = {0};
+    unsigned long long s3last = __builtin_amdgcn_s_memtime();
+    const unsigned long long s3start = s3last;
+    const unsigned long long s3rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- everything the launch needs from memory is requested up front, in one round trip: the integrator state,
+    // the error partials of the previous attempt (one pair per workgroup of the same grid), the weight fragments,
+    // and this workgroup's first tile from BOTH buffer sets (which one is current is the controller's decision)
+    StepState st0;                                         // the controller thread's copy (one round trip, with the rest)
+    if (tid == 0) st0 = *st;
+    const int st_done = st->done, st_cur = st->cur;
+    const float st_h = st->h, st_abstol = st->abstol, st_reltol = st->reltol;
+    float cp0 = 0.f, cp1 = 0.f;
+    if (a.apply_ctrl)
+        for (int i = tid; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
+    const int ntile = (a.B + s3::NB - 1) / s3::NB;
+    f32x4 ru[2], rk[2];
+    int ce = 0, cu = 0, cs = 0;
+    float* sc = lds + s3::SC + smp * 24;
+    auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
+    auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
+    {
+        f32x4 rs[2][2];
+        const int b0 = blockIdx.x * s3::NB + 16 * hf;
+        const bool live = s < max(0, min(16, a.B - b0));
+        const size_t gcol = (size_t)(b0 + s) * D;
+        ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
+        const f32x4 re = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            ru[c] = ld4_issue(a.U[c] + gcol + r0, cu, img3);
+            rk[c] = ld4_issue(a.K1[c] + gcol + r0, cu, img3);
+            rs[c][0] = ld4_issue(a.U[c] + gcol + n_in, cs, img3);
+            rs[c][1] = ld4_issue(a.K1[c] + gcol + n_in, cs, img3);
+        }
+        // scalar rows of both candidates wait in LDS (slots 2..5 of the scalar-row state) for the controller's choice
+        if (sown) {
+            sc_set(2, ld4_mask(rs[0][0], cs)); sc_set(3, ld4_mask(rs[0][1], cs));
+            sc_set(4, ld4_mask(rs[1][0], cs)); sc_set(5, ld4_mask(rs[1][1], cs));
+        }
+        // the probe rows go straight to their LDS image (waves 0-3 need them for g3, waves 4-7 for the trace row)
+        *(f32x4*)(lds + s3::EPS + smp * s3::SX0 + r0) = ld4_mask(re, ce);
+    }
+    S3T(32);
+    if (st_done) {       // launches queued past the end of the solve: keep the state chain intact and leave
+        if (a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
+        return;
+    }
+    // Weights.  W2 is needed twice per wave (16 of its rows forward, 16 of its columns in reverse): it is read from
+    // memory ONCE per workgroup into an LDS staging image (which aliases the activation area, idle until the first
+    // stage) and the 8 waves cut their two register fragments out of it.  The K = 128 images of the narrow products
+    // (W3 rows, W1^T rows) stay in LDS for the whole launch; the K = 32 fragments (W1 rows, W3^T rows: 6 per wave)
+    // come straight from memory.  135 KB per workgroup from L2 instead of 240 KB for all-register fragments.
+    // The images travel by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, LDS destination = wave-uniform
+    // base + 16 lane, no registers in between); the copies are contiguous because memory holds the LDS layout.
+    constexpr int NC2 = s3::PH * s3::SW2 / 4, NCN = 2 * s3::P0 * s3::SXH / 4, NCB = (2 * s3::PH + s3::P0) / 4;
+    static_assert(NC2 % 64 == 0 && NCN % 64 == 0, "whole wave instructions");
+    {
+        typedef __attribute__((address_space(3))) float* lds_f;
+        typedef const __attribute__((address_space(1))) float* glb_f;
+#pragma unroll
+        for (int i = 0; i < (NC2 + 511) / 512; ++i) {
+            const int c = 512 * i + 64 * wave;                 // wave-uniform chunk (16 B) index
+            if (c < NC2)
+                __builtin_amdgcn_global_load_lds((glb_f)(img3 + s3::IMG_W2 + 4 * (c + lane)), (lds_f)(lds + s3::STG + 4 * c), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < (NCN + 511) / 512; ++i) {
+            const int c = 512 * i + 64 * wave;
+            if (c < NCN)
+                __builtin_amdgcn_global_load_lds((glb_f)(img3 + s3::IMG_W1T + 4 * (c + lane)), (lds_f)(lds + s3::W1T + 4 * c), 16, 0, 0);
+        }
+    }
+    const f32x4 sgb = reinterpret_cast<const f32x4*>(img3 + s3::IMG_B1)[min(tid, NCB - 1)];
+    f32x4 wF1[4], wF2[8], wB3[2], wB2[8];
+    // the K = 32 fragments (6 per wave) straight from memory: on their way with the images
+    if (zown) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(img3 + s3::IMG_FR1) + (size_t)wave * 4 * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wF1[u] = wp[u * 64];
+    }
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(img3 + s3::IMG_FR3) + (size_t)wave * 2 * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) wB3[u] = wp[u * 64];
+    }
+    float* msc = lds + s3::MISC;
+    S3T(33);
+    if (a.apply_ctrl) {
+        for (int off = 32; off > 0; off >>= 1) { cp0 += __shfl_down(cp0, off, 64); cp1 += __shfl_down(cp1, off, 64); }
+        if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; }
+    }
+    S3T(34);
+    if (tid < NCB) reinterpret_cast<f32x4*>(lds + s3::BIAS)[tid] = sgb;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA pieces have landed (then the barrier)
+    S3T(24);
+    s3_bar();                                              // staging image and partial sums complete
+    S3T(25);
+    int cur = st_cur;
+    float hstep = st_h, abstol = st_abstol, reltol = st_reltol;
+    if (a.apply_ctrl && tid == 0) {
+        // In-kernel step controller (as in k_mfma): every workgroup reduces the same partials in the same order
+        // and takes the same decision; block 0 publishes the new state for the next launch and the host mirror.
+        float p0 = 0.f, p1 = 0.f;
+        for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
+        StepState ns = st0;
+        ctrl_after_step(&ns, p0, p1, a.n_total);
+        if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
+        msc[32] = __int_as_float(ns.cur); msc[33] = ns.h; msc[34] = ns.abstol; msc[35] = ns.reltol;
+        msc[36] = __int_as_float(ns.done);
+    }
+    {   // this wave's fragments of W2: rows 16w + s (b128 along the row), columns 16w + s (4 x b32 down the column)
+        const float* rw = lds + s3::STG + (16 * wave + s) * s3::SW2 + 4 * q;
+        const float* cw = lds + s3::STG + (4 * q) * s3::SW2 + 16 * wave + s;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            wF2[u] = *(const f32x4*)(rw + 16 * u);
+            const float* c_ = cw + 16 * u * s3::SW2;
+            wB2[u] = f32x4{c_[0], c_[s3::SW2], c_[2 * s3::SW2], c_[3 * s3::SW2]};
+        }
+    }
+    S3T(26);
+    s3_bar();                                              // controller done; the staging area is free
+    S3T(27);
+    if (a.apply_ctrl) {
+        cur = __float_as_int(msc[32]); hstep = msc[33]; abstol = msc[34]; reltol = msc[35];
+        if (__float_as_int(msc[36])) return;        // the controller just finished the solve
+    }
+    // (explicit selects: indexing the kernel-argument arrays with a run-time value makes the compiler fetch the
+    // pointer from the argument segment through a vector load -- a memory round trip in front of the state loads)
+    const float* Uin = cur ? a.U[1] : a.U[0];
+    const float* K1in = cur ? a.K1[1] : a.K1[0];
+    float* Uout = cur ? a.U[0] : a.U[1];
+    float* K1out = cur ? a.K1[0] : a.K1[1];
+
+    float errsum = 0.f, badcnt = 0.f;
+    // the 8 partials (2 row tiles x 4 lanes) of one sample and one kind sit side by side: two b128 reads each
+    auto red8 = [&](int kind) {
+        const float* r = lds + s3::RED + (kind * s3::NB + smp) * 8;
+        const f32x4 a_ = *(const f32x4*)r, b_ = *(const f32x4*)(r + 4);
+        return ((a_.x + a_.y) + (a_.z + a_.w)) + ((b_.x + b_.y) + (b_.z + b_.w));
+    };
+    auto read_scalars = [&]() {
+        const float e2 = red8(0), ld = red8(1), n2 = red8(2);
+        return f32x4{ld, norm_z ? __builtin_sqrtf(e2) : 0.f, norm_j ? __builtin_sqrtf(n2) : 0.f, 0.f};
+    };
+    float* redw = lds + s3::RED + smp * 8 + 4 * t + q;                 // this lane's slot of kind 0 (+ 256 per kind)
+    // operand / result addresses of the wide phases (lane = sample s of half A, 4 rows 16 wave + 4q ..; half B = +16 rows)
+    const float* x0r = lds + s3::X0 + s * s3::SX0 + 4 * q;
+    const float* g3r = lds + s3::G3 + s * s3::SX0 + 4 * q;
+    const float* h1r = lds + s3::H1 + s * s3::SXH + 4 * q;
+    const float* h2r = lds + s3::H2 + s * s3::SXH + 4 * q;
+    float* h1w = lds + s3::H1 + s * s3::SXH + 16 * wave + 4 * q;
+    float* h2w = lds + s3::H2 + s * s3::SXH + 16 * wave + 4 * q;
+    float* g1w = lds + s3::G1 + s * s3::SXH + 16 * wave + 4 * q;
+    constexpr int HB = 16 * s3::SXH, XB = 16 * s3::SX0;              // half B = 16 samples on
+    const float* nrH2 = lds + s3::H2 + smp * s3::SXH + 4 * q;         // narrow phases: B operands of this wave's half
+    const float* nrG1 = lds + s3::G1 + smp * s3::SXH + 4 * q;
+    // ... and their A operands: row 16t + s of W3 (waves 0-3) / of W1^T (waves 4-7)
+    const float* nrW = lds + (zown ? s3::W3R : s3::W1T) + (16 * t + s) * s3::SXH + 4 * q;
+    float* x0w = lds + s3::X0 + smp * s3::SX0 + r0;
+    float* g3w = lds + s3::G3 + smp * s3::SX0 + r0;
+    // Runge-Kutta state of the z rows r0..r0+3 of sample smp, written and read by this lane only:
+    float* rkw = lds + s3::KZ + smp * s3::SKZ + r0;                   // u at rkw, k1 at rkw + 32,
+    float* kzw = rkw + 64;                                            // k_{j+2} at kzw + 32 j (j = 0..5)
+    float* epw = lds + s3::EPS + smp * s3::SX0 + r0;                  // the probe rows eps
+    const float* bias = lds + s3::BIAS;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int b0 = tile * s3::NB + 16 * hf;
+        const bool live = s < max(0, min(16, a.B - b0));
+        const size_t gcol = (size_t)(b0 + s) * D;
+        f32x4 uz, k1z;
+        if (tile == blockIdx.x) {                              // requested at kernel entry
+            uz = ld4_mask(cur ? ru[1] : ru[0], cu);
+            k1z = ld4_mask(cur ? rk[1] : rk[0], cu);
+            if (sown) { sc_set(0, sc_get(cur ? 4 : 2)); sc_set(1, sc_get(cur ? 5 : 3)); }
+        } else {
+            ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
+            const f32x4 e_ = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+            const f32x4 u_ = ld4_issue(Uin + gcol + r0, cu, img3), k_ = ld4_issue(K1in + gcol + r0, cu, img3);
+            const f32x4 s0 = ld4_issue(Uin + gcol + n_in, cs, img3), s1 = ld4_issue(K1in + gcol + n_in, cs, img3);
+            *(f32x4*)epw = ld4_mask(e_, ce); uz = ld4_mask(u_, cu); k1z = ld4_mask(k_, cu);
+            if (sown) { sc_set(0, ld4_mask(s0, cs)); sc_set(1, ld4_mask(s1, cs)); }
+        }
+        if (zown) {
+            *(f32x4*)x0w = uz + (hstep * TS_A21) * k1z;   // state of evaluation 1: U_2 = u + h a21 k1
+            *(f32x4*)rkw = uz;
+            *(f32x4*)(rkw + 32) = k1z;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;       // k2..k7: not produced yet
+        }
+        S3T(28);
+        s3_bar();
+        S3T(20);
+
+        // eJ = W1^T g1 on waves 4-7 (one per SIMD): trace and norm partials (src/icnf.jl:334, :343)
+        f32x4 aN[8];                                       // A operands of the narrow products, fetched one interval ahead
+        auto reverse_first = [&]() {
+            f32x4 bN[8];
+            s3_load<8>(bN, nrG1);
+            S3_SB();
+            f32x4 j0 = zero4, j1 = zero4;
+            s3_mm<0, 8>(j0, j1, aN, bN);
+            const f32x4 ej = j0 + j1;
+            redw[s3::NB * 8] = -s3_dot4(ej, *(const f32x4*)epw);
+            redw[2 * s3::NB * 8] = s3_dot4(ej, ej);
+        };
+
+        for (int stg = 1; stg <= 6; ++stg) {
+            f32x4 bA[8], bB[8];
+            f32x4 p0, p1, r0_, r1_;
+            // ---- interval 0: first layer (waves 0-3: tiles w and w+4, both halves) || eJ of the previous evaluation (4-7)
+            if (zown) {
+                s3_load<2>(bA, x0r, 0);
+                s3_load<2>(bB, x0r + XB, 0);                                   // half B: used behind the barrier
+                const f32x4 bv0 = *(const f32x4*)(bias + 16 * wave + 4 * q), bv1 = *(const f32x4*)(bias + 16 * wave + 64 + 4 * q);
+                S3_SB();
+                f32x4 c0 = zero4, c1 = zero4, d0 = zero4, d1 = zero4;
+                s3_mm<0, 2>(c0, c1, wF1, bA, 0, 0);                            // half A, tile w
+                s3_mm<0, 2>(d0, d1, wF1, bA, 2, 0);                            // half A, tile w+4
+                *(f32x4*)h1w = s3_tanh4(c0 + c1 + bv0);
+                *(f32x4*)(h1w + 64) = s3_tanh4(d0 + d1 + bv1);
+            } else if (stg > 1) {
+                reverse_first();
+            }
+            S3T(0);
+            s3_bar();                                                          // h1(A) visible
+            S3T(1);
+            // ---- interval 1: half A of the second layer requested; under its flight waves 0-3 do half B of the first
+            // layer (operands already in registers); then second layer, half A, k-blocks 0..5
+            s3_load<8>(bA, h1r);
+            S3_SB();
+            if (zown) {
+                const f32x4 bv0 = *(const f32x4*)(bias + 16 * wave + 4 * q), bv1 = *(const f32x4*)(bias + 16 * wave + 64 + 4 * q);
+                p0 = zero4; p1 = zero4; r0_ = zero4; r1_ = zero4;
+                s3_mm<0, 2>(p0, p1, wF1, bB, 0, 0);                            // half B, tile w
+                s3_mm<0, 2>(r0_, r1_, wF1, bB, 2, 0);                          // half B, tile w+4
+                *(f32x4*)(h1w + HB) = s3_tanh4(p0 + p1 + bv0);
+                *(f32x4*)(h1w + HB + 64) = s3_tanh4(r0_ + r1_ + bv1);
+            }
+            f32x4 a0 = zero4, a1 = zero4;
+            s3_mm<0, 6>(a0, a1, wF2, bA);
+            // scalar rows of the PREVIOUS evaluation from its RED partials: complete since the barrier above,
+            // rewritten from this evaluation's last forward epilogue on
+            if (stg > 1 && sown) sc_set(stg, read_scalars());                  // slot j holds k_j
+            S3T(2);
+            s3_bar();                                                          // h1(B) visible
+            S3T(3);
+            // ---- interval 2: half B requested, half A finished under its flight, half B k-blocks 0..5 || epilogue A
+            s3_mm_load<6, 6>(a0, a1, wF2, bA, bB, h1r + HB);
+            s3_mm<7, 8>(a0, a1, wF2, bA);
+            f32x4 e0 = zero4, e1 = zero4;
+            s3_mm<0, 6>(e0, e1, wF2, bB);
+            const f32x4 bv2 = *(const f32x4*)(bias + s3::PH + 16 * wave + 4 * q);
+            *(f32x4*)h2w = s3_tanh4(a0 + a1 + bv2);
+            S3T(4);
+            s3_bar();                                                          // h2(A) visible
+            S3T(5);
+            // ---- interval 3: rest of half B and its epilogue (waves 0-3: the W3 rows of the next interval on their way)
+            if (zown) s3_load<8>(aN, nrW);
+            s3_mm<6, 8>(e0, e1, wF2, bB);
+            *(f32x4*)(h2w + HB) = s3_tanh4(e0 + e1 + bv2);
+            S3T(6);
+            s3_bar();                                                          // h2 complete
+            S3T(7);
+            // ---- interval 4: last layer on waves 0-3 (one per SIMD): zdot rows r0..r0+3 of sample smp
+            if (zown) {
+                s3_load<8>(bA, nrH2);
+                const f32x4 bv3 = *(const f32x4*)(bias + 2 * s3::PH + r0);
+                S3_SB();
+                f32x4 z0 = zero4, z1 = zero4;
+                s3_mm<0, 8>(z0, z1, aN, bA);
+#ifdef S3_STAMPS
+                S3_SB(); S3T(29); S3_SB();
+#endif
+                // stage sum without the k this evaluation will produce: pre = u + h sum_{j<stg} a_{stg+1,j} k_j
+                // (straight-line: the coefficients of k's not yet produced are zero in the table, their slots hold zeros)
+                const float* A = S3_A[stg < 6 ? stg + 1 : 6];
+                f32x4 pre = *(const f32x4*)rkw + (hstep * A[0]) * *(const f32x4*)(rkw + 32);
+#pragma unroll
+                for (int j = 1; j < 5; ++j) pre += (hstep * A[j]) * *(const f32x4*)(kzw + 32 * (j - 1));
+                const f32x4 ev = *(const f32x4*)epw;
+                const f32x4 zd = s3_tanh4(z0 + z1 + bv3);                      // padded rows: zero weights and bias -> 0
+                *(f32x4*)g3w = ev * s3_dtanh4(zd);                             // g3 = eps .* sigma'_3
+                if (stg < 6) *(f32x4*)x0w = pre + (hstep * A[stg]) * zd;       // state of the next evaluation
+                *(f32x4*)(kzw + 32 * (stg - 1)) = zd;                          // k_{stg+1}
+                redw[0] = s3_dot4(zd, zd);
+            }
+            S3T(8);
+            s3_bar();                                                          // g3 (and the next stage state) visible
+            S3T(9);
+            // ---- interval 5: reverse of the last layer, both halves; g2(A) over h2(A)
+            s3_load<2>(bA, g3r, 0);
+            s3_load<2>(bB, g3r + XB, 0);                                       // half B: used behind the barrier
+            const f32x4 hv2A = *(const f32x4*)h2w;
+            S3_SB();
+            f32x4 c0 = zero4, c1 = zero4, d0 = zero4, d1 = zero4;
+            s3_mm<0, 2>(c0, c1, wB3, bA, 0, 0);
+            *(f32x4*)h2w = (c0 + c1) * s3_dtanh4(hv2A);
+            S3T(10);
+            s3_bar();                                                          // g2(A) visible
+            S3T(11);
+            // ---- interval 6: half A of the reverse second layer requested; under its flight the reverse last layer of
+            // half B; then reverse second layer, half A, k-blocks 0..5
+            s3_mm_load<0, 0>(d0, d1, wB3, bB, bA, h2r);
+            const f32x4 hv2B = *(const f32x4*)(h2w + HB);
+            s3_mm<1, 2>(d0, d1, wB3, bB, 0, 0);
+            *(f32x4*)(h2w + HB) = (d0 + d1) * s3_dtanh4(hv2B);
+            a0 = zero4; a1 = zero4;
+            s3_mm<0, 6>(a0, a1, wB2, bA);
+            S3T(12);
+            s3_bar();                                                          // g2(B) visible
+            S3T(13);
+            // ---- interval 7: half B requested, half A finished, half B k-blocks 0..5 || g1(A)
+            s3_mm_load<6, 6>(a0, a1, wB2, bA, bB, h2r + HB);
+            const f32x4 hv1A = *(const f32x4*)h1w;
+            s3_mm<7, 8>(a0, a1, wB2, bA);
+            e0 = zero4; e1 = zero4;
+            s3_mm<0, 6>(e0, e1, wB2, bB);
+            *(f32x4*)g1w = (a0 + a1) * s3_dtanh4(hv1A);
+            S3T(14);
+            s3_bar();                                                          // g1(A) visible
+            S3T(15);
+            // ---- interval 8: rest of half B, g1(B) (waves 4-7: the W1^T rows of their next product on their way)
+            if (!zown) s3_load<8>(aN, nrW);
+            const f32x4 hv1B = *(const f32x4*)(h1w + HB);
+            s3_mm<6, 8>(e0, e1, wB2, bB);
+            *(f32x4*)(g1w + HB) = (e0 + e1) * s3_dtanh4(hv1B);
+            S3T(16);
+            s3_bar();                                                          // g1 complete
+            S3T(17);
+        }
+        if (!zown) reverse_first();                        // eJ of the last evaluation
+        S3T(18);
+        s3_bar();                                          // RED of the last evaluation complete
+        S3T(19);
+        // ---- error estimate and outputs: u_new (= the state evaluation 6 ran at) and k7 ----
+        if (live && zown) {
+            const f32x4 k7z = *(const f32x4*)(kzw + 32 * 5), uz_ = *(const f32x4*)rkw;
+            const f32x4 un = *(const f32x4*)x0w;           // U_7 = u_new: the state the last evaluation ran at
+            f32x4 ez = TS_BT1 * *(const f32x4*)(rkw + 32) + TS_BT7 * k7z;
+            ez += TS_BT2 * *(const f32x4*)(kzw) + TS_BT3 * *(const f32x4*)(kzw + 32) + TS_BT4 * *(const f32x4*)(kzw + 64) +
+                  TS_BT5 * *(const f32x4*)(kzw + 96) + TS_BT6 * *(const f32x4*)(kzw + 128);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                  // rows beyond n_in: u = k = 0 -> contribute exactly 0
+                const float scl = fmaf(fmaxf(fabsf(uz_[c]), fabsf(un[c])), reltol, abstol);
+                const float x = c < nv ? hstep * ez[c] / scl : 0.f;
+                errsum = fmaf(x, x, errsum);
+                badcnt += (c < nv && !(fabsf(un[c]) <= 3.0e38f)) ? 1.f : 0.f;
+            }
+            const size_t gc = (size_t)(tile * s3::NB + 16 * hf + s) * D;
+            float* Un = Uout + gc + r0;
+            float* K7 = K1out + gc + r0;
+            if (nv >= 4) {
+                Un[0] = un.x; Un[1] = un.y; Un[2] = un.z; Un[3] = un.w;
+                K7[0] = k7z.x; K7[1] = k7z.y; K7[2] = k7z.z; K7[3] = k7z.w;
+            } else { st4(Un, un, nv); st4(K7, k7z, nv); }
+        }
+        if (live && sown) {
+            f32x4 ks[7];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ks[j] = sc_get(1 + j);
+            const f32x4 us = sc_get(0);
+            ks[6] = read_scalars();                        // k7 of the scalar rows, straight from the partials
+            const f32x4 uns = us + hstep * stage_acc4<6>(ks);
+            err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
+            const size_t gc = (size_t)(tile * s3::NB + 16 * hf + s) * D;
+            float* Un = Uout + gc + n_in;
+            float* K7 = K1out + gc + n_in;
+            Un[0] = uns.x; Un[1] = uns.y; Un[2] = uns.z;
+            K7[0] = ks[6].x; K7[1] = ks[6].y; K7[2] = ks[6].z;
+        }
+        S3T(30);
+        S3T(31);
+        s3_bar();                                          // this tile's RED / SC / KZ reads precede the next tile's writes
+    }
+    // deterministic block reduction of the error partial (fixed tree, fixed order)
+    for (int off = 32; off > 0; off >>= 1) {
+        errsum += __shfl_down(errsum, off, 64);
+        badcnt += __shfl_down(badcnt, off, 64);
+    }
+    if (lane == 0) { msc[wave] = errsum; msc[16 + wave] = badcnt; }
+    s3_bar();
+    if (tid == 0) {
+        float e = 0.f, b = 0.f;
+        for (int w = 0; w < 8; ++w) { e += msc[w]; b += msc[16 + w]; }
+        a.partials[2 * blockIdx.x] = e;
+        a.partials[2 * blockIdx.x + 1] = b;
+    }
+#ifdef S3_STAMPS
+    S3T(21);
+    const unsigned long long s3rt1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 1 || wave == 4 || wave == 5))
+        printf("wave %d total %llu pre %llu tail %llu | F1 %llu+%llu F2A %llu+%llu F2B %llu+%llu F2t %llu+%llu F3 %llu+%llu | "
+               "B3 %llu+%llu B2A %llu+%llu B2B %llu+%llu B2t %llu+%llu B1 %llu fin %llu\n",
+               wave, s3last - s3start, s3acc[20], s3acc[21], s3acc[0], s3acc[1], s3acc[2], s3acc[3], s3acc[4], s3acc[5], s3acc[6],
+               s3acc[7], s3acc[8], s3acc[9], s3acc[10], s3acc[11], s3acc[12], s3acc[13], s3acc[14], s3acc[15], s3acc[16],
+               s3acc[17], s3acc[18], s3acc[19]);
+    if (blockIdx.x == 7 && lane == 0 && wave == 0) {
+        const unsigned long long rt = s3rt1 - s3rt0;
+        printf("  clock: %llu shader cycles in %llu x 10 ns -> %.0f MHz\n", s3last - s3start, rt, (double)(s3last - s3start) / (double)rt * 100.0);
+    }
+    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 4))
+        printf("  wave %d prologue: scalars %llu issue %llu partials %llu staged(in ctrl bar) | to ctrl bar %llu wait %llu ctrl %llu wait %llu tileprep %llu wait(in pre) | F3 loads+mfma %llu (rest in F3) | tail: err %llu stores %llu fin %llu\n",
+               wave, s3acc[32], s3acc[33], s3acc[34], s3acc[24], s3acc[25], s3acc[26], s3acc[27], s3acc[28], s3acc[29], s3acc[30], s3acc[31], s3acc[21]);
+#endif
+}
+
+// Weight image of k_step3 (layout: namespace s3).  Fragment element (wave w, fragment j, lane = 16q + s, c):
+//   FR1 (waves 0-3): W1 rows: tile w + 4 (j >> 1), k-block j & 1:  W1[16 (w + 4 (j >> 1)) + s][16 (j & 1) + 4q + c]
+//   FR3 (all waves): W3^T rows:                                   W3[16 j + 4q + c][16 w + s]
+__global__ void k_pack_step3(NetDesc nd, const float* __restrict__ P, float* __restrict__ img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s3::IMG_FLOATS) return;
+    float v = 0.f;
+    int l = -1, o = 0, k = 0;
+    if (i < s3::IMG_W1T) { l = 1; o = i / s3::SW2; k = i % s3::SW2; }                                        // W2[o][k]
+    else if (i < s3::IMG_W3R) { const int r = i - s3::IMG_W1T; l = 0; k = r / s3::SXH; o = r % s3::SXH; }     // W1T[k][o]
+    else if (i < s3::IMG_B1) { const int r = i - s3::IMG_W3R; l = 2; o = r / s3::SXH; k = r % s3::SXH; }      // W3R[o][k]
+    else if (i < s3::IMG_FR1) {
+        const int r = i - s3::IMG_B1;
+        const int lb = r < s3::PH ? 0 : (r < 2 * s3::PH ? 1 : 2);
+        const int ob = r - (lb == 0 ? 0 : (lb == 1 ? s3::PH : 2 * s3::PH));
+        if (ob < nd.dims[lb + 1]) v = P[nd.b_off[lb] + ob];
+    } else {
+        const bool f1 = i < s3::IMG_FR3;
+        const int r = i - (f1 ? s3::IMG_FR1 : s3::IMG_FR3);
+        const int nf = f1 ? 4 : 2;
+        const int w = r / (nf * 256), rem = r % (nf * 256);
+        const int j = rem / 256, lane = (rem % 256) / 4, c = rem % 4, s = lane & 15, q = lane >> 4;
+        if (f1) { l = 0; o = 16 * (w + 4 * (j >> 1)) + s; k = 16 * (j & 1) + 4 * q + c; }
+        else    { l = 2; o = 16 * j + 4 * q + c; k = 16 * w + s; }
+    }
+    if (l >= 0 && o < nd.dims[l + 1] && k < nd.dims[l]) v = P[nd.w_off[l] + o + (size_t)k * nd.dims[l + 1]];
+    img[i] = v;
+}
+
+size_t step3_img_floats() { return (size_t)s3::IMG_FLOATS; }
+
+void step3_pack(const NetDesc& nd, const float* d_params, float* d_img3, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_step3, dim3((s3::IMG_FLOATS + 255) / 256), dim3(256), 0, s, nd, d_params, d_img3);
+}
+
+void step3_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_step3, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(s3::TOTAL * sizeof(float)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_step3, grid, dim3(512), (size_t)s3::TOTAL * sizeof(float), s, a, d_img3, n_in, norm_z, norm_j);
+}

@@ -68,7 +68,7 @@ k_trace_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const f
     const int eb = b0 + es;
     const bool ev = eb < a.B;
     float* du = a.du;
-    if (a.st && a.du_is_k7) du = a.K1[1 - a.st->cur];
+    if (a.st && a.du_is_k7) du = (a.st->cur ? a.K1[0] : a.K1[1]);
     float* red = lds + tl.off_red;
 
     AFrag pf;
@@ -217,7 +217,7 @@ k_jvp_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, JvpLayout jl, const float
     const int eb = b0 + es;
     const bool ev = eb < a.B;
     float* du = a.du;
-    if (a.st && a.du_is_k7) du = a.K1[1 - a.st->cur];
+    if (a.st && a.du_is_k7) du = (a.st->cur ? a.K1[0] : a.K1[1]);
     float* red = lds + jl.off_red;
 
     AFrag pf;
@@ -322,7 +322,7 @@ k_vjp_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, VjpLayout vl, const float
     const int eb = b0 + es;
     const bool ev = eb < a.B;
     float* du = a.du;
-    if (a.st && a.du_is_k7) du = a.K1[1 - a.st->cur];
+    if (a.st && a.du_is_k7) du = (a.st->cur ? a.K1[0] : a.K1[1]);
     float* red = lds + vl.off_red;
 
     AFrag pf;

@@ -3,6 +3,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # before torch initialises HIP (see continuousnf.jl_amd/__init__.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
