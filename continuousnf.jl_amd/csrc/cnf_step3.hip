@@ -54,17 +54,19 @@ constexpr int IMG_FR3 = IMG_FR1 + 4 * 4 * 256; // W3^T row fragments, waves 0-7:
 constexpr int IMG_FLOATS = IMG_FR3 + 8 * 2 * 256;
 }  // namespace s3
 
-// Tsit5 rows a_{s+1, 1..6} (s = 1..6) as data: the stage sums take their coefficients by scalar loads
-__constant__ float S3_A[7][8] = {
+// Tsit5 rows a_{s+1, 1..6} (s = 1..6), passed BY VALUE as a kernel argument: the stage sums then take their coefficients
+// by scalar loads from the argument segment, which every wave has just read (scalar-cache hits).  A __constant__ table
+// costs a scalar-cache miss -- a memory round trip -- in front of the first stage of every launch, and select chains
+// over immediates put the 21 literals into vector registers.
+struct S3Tab { float a[7][8]; };
+static const S3Tab kS3Tab = {{
     {0, 0, 0, 0, 0, 0, 0, 0},
     {TS_A21, 0, 0, 0, 0, 0, 0, 0},
     {TS_A31, TS_A32, 0, 0, 0, 0, 0, 0},
     {TS_A41, TS_A42, TS_A43, 0, 0, 0, 0, 0},
     {TS_A51, TS_A52, TS_A53, TS_A54, 0, 0, 0, 0},
     {TS_A61, TS_A62, TS_A63, TS_A64, TS_A65, 0, 0, 0},
-    {TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76, 0, 0}};
-
-__constant__ float S3_BT[8] = {TS_BT1, TS_BT2, TS_BT3, TS_BT4, TS_BT5, TS_BT6, TS_BT7, 0};
+    {TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76, 0, 0}}};
 
 #define S3_SB() __builtin_amdgcn_sched_barrier(0)
 // workgroup barrier for LDS traffic only: does not drain global loads / stores in flight
@@ -130,7 +132,7 @@ __device__ __forceinline__ float s3_dot4(const f32x4& a, const f32x4& b) {
 #endif
 
 __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __restrict__ img3, int n_in, int norm_z,
-                                                  int norm_j) {
+                                                  int norm_j, const S3Tab tab) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StepState* st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,8 +155,11 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
     // and this workgroup's first tile from BOTH buffer sets (which one is current is the controller's decision)
     StepState st0;                                         // the controller thread's copy (one round trip, with the rest)
     if (tid == 0) st0 = *st;
-    const int st_done = st->done, st_cur = st->cur;
-    const float st_h = st->h, st_abstol = st->abstol, st_reltol = st->reltol;
+    // (wave-uniform values into scalar registers: the buffer pointers selected from `cur` stay out of the vector file)
+    const int st_done = __builtin_amdgcn_readfirstlane(st->done), st_cur = __builtin_amdgcn_readfirstlane(st->cur);
+    const float st_h = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(st->h)));
+    const float st_abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(st->abstol)));
+    const float st_reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(st->reltol)));
     float cp0 = 0.f, cp1 = 0.f;
     if (a.apply_ctrl)
         for (int i = tid; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
@@ -268,7 +273,10 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
     s3_bar();                                              // controller done; the staging area is free
     S3T(27);
     if (a.apply_ctrl) {
-        cur = __float_as_int(msc[32]); hstep = msc[33]; abstol = msc[34]; reltol = msc[35];
+        cur = __builtin_amdgcn_readfirstlane(__float_as_int(msc[32]));
+        hstep = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[33])));
+        abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[34])));
+        reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[35])));
         if (__float_as_int(msc[36])) return;        // the controller just finished the solve
     }
     // (explicit selects: indexing the kernel-argument arrays with a run-time value makes the compiler fetch the
@@ -422,7 +430,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
 #endif
                 // stage sum without the k this evaluation will produce: pre = u + h sum_{j<stg} a_{stg+1,j} k_j
                 // (straight-line: the coefficients of k's not yet produced are zero in the table, their slots hold zeros)
-                const float* A = S3_A[stg < 6 ? stg + 1 : 6];
+                const float* A = tab.a[stg < 6 ? stg + 1 : 6];
                 f32x4 pre = *(const f32x4*)rkw + (hstep * A[0]) * *(const f32x4*)(rkw + 32);
 #pragma unroll
                 for (int j = 1; j < 5; ++j) pre += (hstep * A[j]) * *(const f32x4*)(kzw + 32 * (j - 1));
@@ -595,5 +603,5 @@ void step3_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, 
                                   (int)(s3::TOTAL * sizeof(float)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_step3, grid, dim3(512), (size_t)s3::TOTAL * sizeof(float), s, a, d_img3, n_in, norm_z, norm_j);
+    hipLaunchKernelGGL(k_step3, grid, dim3(512), (size_t)s3::TOTAL * sizeof(float), s, a, d_img3, n_in, norm_z, norm_j, kS3Tab);
 }
