@@ -1,18 +1,30 @@
-"""Turns gpurun_out/profiles_r1 (written by tools/collect_profiles.sh on the GPU box) into the
-committed summaries under profiles/."""
+"""Turns gpurun_out/profiles_<tag> (written by tools/collect_profiles.sh on the GPU box) into the committed summaries
+under profiles/.     python tools/summarize_profiles.py [tag=r2] [name=round2]
+
+Launches of the step kernel that exit at once (queued past the end of a solve, or behind a controller that has just
+finished it) are dropped before any counter is averaged: they are identified by their duration in the kernel trace
+of the same pass (joined on the dispatch id), so the per-launch figures are those of FULL steps."""
 import collections
 import csv
 import glob
 import json
 import os
-import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "profiles_r1")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+name = sys.argv[2] if len(sys.argv) > 2 else "round2"
+SRC = os.path.join(ROOT, "gpurun_out", f"profiles_{tag}")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
 os.makedirs(DST, exist_ok=True)
+STEP = ("k_step3", "k_mfma")          # the step kernel of the headline shape (second / first generation)
+FULL_US = 15.0                        # anything shorter did not do a step
+
+
+def is_step(kname):
+    # k_step3(...) or the STEP = true instantiation k_mfma<Layout, true>(...) -- not the plain RHS kernel k_mfma<Layout, false>
+    return kname.startswith("k_step3") or ("k_mfma<" in kname and ", true>(" in kname)
 
 
 def first(pattern):
@@ -20,10 +32,17 @@ def first(pattern):
     return max(g, key=os.path.getmtime) if g else None      # newest run
 
 
+def commit():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        return "?"
+
+
 st = first("bench/**/*kernel_stats.csv")
 if st:
     rows = list(csv.DictReader(open(st)))
-    with open(os.path.join(DST, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as f:
+    with open(os.path.join(DST, f"{name}_bench_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows[:12]:
@@ -32,49 +51,62 @@ if st:
     log = os.path.join(SRC, "bench_under_rocprof.log")
     for line in open(log):
         if line.startswith("{"):
-            open(os.path.join(DST, f"{tag}_bench_under_rocprof.json"), "w").write(line)
-    # duration histogram of the step kernel (full steps vs early exits)
+            open(os.path.join(DST, f"{name}_bench_under_rocprof.json"), "w").write(line)
+    # duration split of the step kernel (full steps vs early exits)
     tr = first("bench/**/*kernel_trace.csv")
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(tr))
-         if "k_mfma" in r["Kernel_Name"] and "true" in r["Kernel_Name"]]
-    full = [x for x in d if x > 20]
-    with open(os.path.join(DST, f"{tag}_step_kernel_durations.txt"), "w") as f:
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(tr)) if is_step(r["Kernel_Name"])]
+    full = [x for x in d if x > FULL_US]
+    with open(os.path.join(DST, f"{name}_step_kernel_durations.txt"), "w") as f:
         f.write(f"fused step kernel launches: {len(d)}; doing a full step: {len(full)}; "
                 f"early exits (solve already finished): {len(d) - len(full)}\n")
         if full:
             f.write(f"full-step launches: mean {sum(full) / len(full):.2f} us, min {min(full):.2f}, max {max(full):.2f}\n")
 
 
-def pmc(dirname, want):
+def pmc(dirname):
+    """mean counter values over the FULL-step launches of this pass"""
     f = first(f"{dirname}/**/*counter_collection.csv")
+    t = first(f"{dirname}/**/*kernel_trace.csv")
     if not f:
-        return {}
-    agg = collections.defaultdict(list)
+        return {}, 0, 0
+    dur = {}
+    if t:
+        for r in csv.DictReader(open(t)):
+            dur[r.get("Dispatch_Id")] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    agg, seen, kept = collections.defaultdict(list), set(), set()
     for r in csv.DictReader(open(f)):
-        if "k_mfma" in r["Kernel_Name"] and "true" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items() if k in want or not want}
+        if not is_step(r["Kernel_Name"]):
+            continue
+        did = r.get("Dispatch_Id")
+        seen.add(did)
+        if did in dur and dur[did] < FULL_US:
+            continue
+        kept.add(did)
+        agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}, len(seen), len(kept)
 
 
-fetch = pmc("pmc_fetch", {"FETCH_SIZE"})
-write = pmc("pmc_write", {"WRITE_SIZE"})
-sq = pmc("pmc_sq", set())
-out = {"kernel": "k_mfma<StLayout<1,32,128,128,32>, true> (fused Tsit5 step, B=8192)",
-       "per_launch": {**fetch, **write, **sq}}
-if fetch and write:
-    # MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
-    # reports half the bytes of wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE exact.
-    out["hbm_bytes_per_launch"] = 2 * fetch["FETCH_SIZE"] * 1024 + write["WRITE_SIZE"] * 1024
-    out["note"] = ("traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read-side correction); the state "
-                   "loads are 4 B/lane, a width the guide calls uncalibrated, so the read side is an upper bound")
-json.dump(out, open(os.path.join(DST, f"{tag}_step_kernel_pmc.json"), "w"), indent=1)
+out = {"kernel": "k_step3 (fused Tsit5 step of the headline shape, B = 8192)", "commit": commit(), "per_launch": {}, "launches": {}}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_wait"):
+    vals, n, k = pmc(d)
+    out["per_launch"].update(vals)
+    out["launches"][d] = {"step_launches": n, "full_steps_averaged": k}
+pl = out["per_launch"]
+if "FETCH_SIZE" in pl and "WRITE_SIZE" in pl:
+    # MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes
+    # of wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE exact.
+    out["hbm_bytes_per_launch"] = 2 * pl["FETCH_SIZE"] * 1024 + pl["WRITE_SIZE"] * 1024
+    out["note"] = ("traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read-side correction); the state loads are "
+                   "4 B/lane, a width the guide calls uncalibrated, so the read side is an upper bound; early-exit "
+                   "launches (< 15 us) are excluded from every mean")
+json.dump(out, open(os.path.join(DST, f"{name}_step_kernel_pmc.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 
 # gradient path (row f3): kernel split of loss + loss_and_grad at config 3, B = 8192
 gs = first("grad/**/*kernel_stats.csv")
 if gs:
     rows = list(csv.DictReader(open(gs)))
-    with open(os.path.join(DST, f"{tag}_grad_kernel_stats.csv"), "w", newline="") as f:
+    with open(os.path.join(DST, f"{name}_grad_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows[:12]:
