@@ -79,6 +79,8 @@ struct cnf_ctx {
     float* g_grad = nullptr;      // n_params (host-pointer variant)
     std::vector<float> last_hs;   // signed step sizes of the last cnf_loss_grad solve
     float* d_ys = nullptr;        // conditional models: copy of ys (n_cond x cond_B), kept for the weight gradient
+    float* stage = nullptr;       // device staging area of the *_host entry points, owned by the handle, grown on demand
+    size_t stage_cap = 0;         //   (floats): no allocation per call, nothing to free on an error path
     float* d_sums = nullptr;      // 3 floats
     float* h_sums = nullptr;      // pinned, 3 floats
     std::string err;
@@ -217,6 +219,7 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (h->partials) (void)hipFree(h->partials);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_mirror) (void)hipHostFree(h->h_mirror);
+    if (h->stage) (void)hipFree(h->stage);
     if (h->d_sums) (void)hipFree(h->d_sums);
     if (h->h_sums) (void)hipHostFree(h->h_sums);
     if (h->ev[0]) (void)hipEventDestroy(h->ev[0]);
@@ -279,6 +282,17 @@ static cnf_status ensure_capacity(cnf_handle h, int B) {
     return CNF_OK;
 }
 
+// staging area for host-pointer calls: at least `nfloats` floats of device memory owned by the handle
+static cnf_status ensure_stage(cnf_handle h, size_t nfloats) {
+    if (nfloats <= h->stage_cap) return CNF_OK;
+    HIPCHK(h, hipDeviceSynchronize());
+    if (h->stage) { (void)hipFree(h->stage); h->stage = nullptr; h->stage_cap = 0; }
+    const size_t cap = (nfloats + 4095) & ~(size_t)4095;
+    HIPCHK(h, hipMalloc(&h->stage, cap * sizeof(float)));
+    h->stage_cap = cap;
+    return CNF_OK;
+}
+
 static cnf_status check_call(cnf_handle h, int mode, int B) {
     if (!h) return CNF_ERR_BAD_ARG;
     if (mode != CNF_MODE_TEST && mode != CNF_MODE_TRAIN) return fail(h, CNF_ERR_BAD_ARG, "unknown mode");
@@ -320,12 +334,12 @@ extern "C" cnf_status cnf_set_cond_host(cnf_handle h, const float* ys, int B) {
     if (!h) return CNF_ERR_BAD_ARG;
     if (!ys || B < 1 || h->nd.n_cond == 0) return fail(h, CNF_ERR_BAD_ARG, "bad conditioning input");
     HIPCHK(h, hipSetDevice(h->device));
-    float* d = nullptr;
-    HIPCHK(h, hipMalloc(&d, (size_t)B * h->nd.n_cond * sizeof(float)));
+    cnf_status s = ensure_stage(h, (size_t)B * h->nd.n_cond);
+    if (s != CNF_OK) return s;
+    float* d = h->stage;
     HIPCHK(h, hipMemcpy(d, ys, (size_t)B * h->nd.n_cond * sizeof(float), hipMemcpyHostToDevice));
-    cnf_status s = cnf_set_cond(h, d, B, nullptr);
-    hipError_t e = hipDeviceSynchronize();
-    (void)hipFree(d);
+    s = cnf_set_cond(h, d, B, nullptr);
+    hipError_t e = hipDeviceSynchronize();      // cnf_set_cond keeps its own copy of ys: the staging area is free again
     if (s == CNF_OK && e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
     return s;
 }
@@ -466,21 +480,17 @@ extern "C" cnf_status cnf_rhs_host(cnf_handle h, int mode, int kernel, const flo
     if (B == 0) return CNF_OK;
     HIPCHK(h, hipSetDevice(h->device));
     const size_t D = rows_of(h, mode), n_in = h->nd.n_in;
-    float *du_d = nullptr, *u_d = nullptr, *e_d = nullptr;
-    HIPCHK(h, hipMalloc(&u_d, D * B * sizeof(float)));
-    HIPCHK(h, hipMalloc(&du_d, D * B * sizeof(float)));
+    if ((s = ensure_stage(h, (2 * D + n_in) * B)) != CNF_OK) return s;
+    float* u_d = h->stage;
+    float* du_d = u_d + D * B;
+    float* e_d = eps ? du_d + D * B : nullptr;
     HIPCHK(h, hipMemcpy(u_d, u, D * B * sizeof(float), hipMemcpyHostToDevice));
-    if (eps) {
-        HIPCHK(h, hipMalloc(&e_d, n_in * B * sizeof(float)));
-        HIPCHK(h, hipMemcpy(e_d, eps, n_in * B * sizeof(float), hipMemcpyHostToDevice));
-    }
+    if (eps) HIPCHK(h, hipMemcpy(e_d, eps, n_in * B * sizeof(float), hipMemcpyHostToDevice));
     s = cnf_rhs(h, mode, kernel, u_d, e_d, du_d, B, nullptr);
     if (s == CNF_OK) {
         hipError_t e = hipMemcpy(du, du_d, D * B * sizeof(float), hipMemcpyDeviceToHost);
         if (e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
     }
-    (void)hipFree(u_d); (void)hipFree(du_d);
-    if (e_d) (void)hipFree(e_d);
     return s;
 }
 
@@ -564,10 +574,17 @@ static cnf_status traj_reserve(cnf_handle h, int steps) {
     float *nt = nullptr, *nh = nullptr;
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMalloc(&nt, slot * cap * sizeof(float)));
-    HIPCHK(h, hipMalloc(&nh, (size_t)cap * sizeof(float)));
+    if (hipMalloc(&nh, (size_t)cap * sizeof(float)) != hipSuccess) {
+        (void)hipFree(nt);
+        return fail(h, CNF_ERR_HIP, "hipMalloc of the trajectory step-size array failed");
+    }
     if (h->traj) {
-        HIPCHK(h, hipMemcpy(nt, h->traj, slot * h->traj_cap * sizeof(float), hipMemcpyDeviceToDevice));
-        HIPCHK(h, hipMemcpy(nh, h->traj_hs, (size_t)h->traj_cap * sizeof(float), hipMemcpyDeviceToDevice));
+        hipError_t ce = hipMemcpy(nt, h->traj, slot * h->traj_cap * sizeof(float), hipMemcpyDeviceToDevice);
+        if (ce == hipSuccess) ce = hipMemcpy(nh, h->traj_hs, (size_t)h->traj_cap * sizeof(float), hipMemcpyDeviceToDevice);
+        if (ce != hipSuccess) {
+            (void)hipFree(nt); (void)hipFree(nh);
+            return fail(h, CNF_ERR_HIP, hipGetErrorString(ce));
+        }
         (void)hipFree(h->traj); (void)hipFree(h->traj_hs);
     }
     h->traj = nt; h->traj_hs = nh; h->traj_cap = cap;
@@ -988,21 +1005,17 @@ extern "C" cnf_status cnf_solve_tsit5_host(cnf_handle h, int mode, const float* 
     if (B == 0) { if (stats) memset(stats, 0, sizeof *stats); return CNF_OK; }
     HIPCHK(h, hipSetDevice(h->device));
     const size_t D = rows_of(h, mode), n_in = h->nd.n_in;
-    float *u_d = nullptr, *o_d = nullptr, *e_d = nullptr;
-    HIPCHK(h, hipMalloc(&u_d, D * B * sizeof(float)));
-    HIPCHK(h, hipMalloc(&o_d, D * B * sizeof(float)));
+    if ((s = ensure_stage(h, (2 * D + n_in) * B)) != CNF_OK) return s;
+    float* u_d = h->stage;
+    float* o_d = u_d + D * B;
+    float* e_d = eps ? o_d + D * B : nullptr;
     HIPCHK(h, hipMemcpy(u_d, u0, D * B * sizeof(float), hipMemcpyHostToDevice));
-    if (eps) {
-        HIPCHK(h, hipMalloc(&e_d, n_in * B * sizeof(float)));
-        HIPCHK(h, hipMemcpy(e_d, eps, n_in * B * sizeof(float), hipMemcpyHostToDevice));
-    }
+    if (eps) HIPCHK(h, hipMemcpy(e_d, eps, n_in * B * sizeof(float), hipMemcpyHostToDevice));
     s = cnf_solve_tsit5(h, mode, u_d, e_d, o_d, B, opts, stats, nullptr);
     if (s == CNF_OK) {
         hipError_t e = hipMemcpy(u_out, o_d, D * B * sizeof(float), hipMemcpyDeviceToHost);
         if (e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
     }
-    (void)hipFree(u_d); (void)hipFree(o_d);
-    if (e_d) (void)hipFree(e_d);
     return s;
 }
 
@@ -1075,15 +1088,13 @@ extern "C" cnf_status cnf_inference_host(cnf_handle h, int mode, const float* xs
     if (B == 0) { if (stats) memset(stats, 0, sizeof *stats); return CNF_OK; }
     HIPCHK(h, hipSetDevice(h->device));
     const size_t D = rows_of(h, mode), n_in = h->nd.n_in, nv = h->nd.nvars;
-    float *xs_d = nullptr, *e_d = nullptr, *out_d = nullptr;
     const size_t out_f = (size_t)B * (4 + D);
-    HIPCHK(h, hipMalloc(&xs_d, nv * B * sizeof(float)));
-    HIPCHK(h, hipMalloc(&out_d, out_f * sizeof(float)));
+    if ((s = ensure_stage(h, (nv + n_in) * B + out_f)) != CNF_OK) return s;
+    float* xs_d = h->stage;
+    float* out_d = xs_d + nv * B;
+    float* e_d = eps ? out_d + out_f : nullptr;
     HIPCHK(h, hipMemcpy(xs_d, xs, nv * B * sizeof(float), hipMemcpyHostToDevice));
-    if (eps) {
-        HIPCHK(h, hipMalloc(&e_d, n_in * B * sizeof(float)));
-        HIPCHK(h, hipMemcpy(e_d, eps, n_in * B * sizeof(float), hipMemcpyHostToDevice));
-    }
+    if (eps) HIPCHK(h, hipMemcpy(e_d, eps, n_in * B * sizeof(float), hipMemcpyHostToDevice));
     float* lp = out_d; float* rg = out_d + B; float* uf = out_d + 4 * (size_t)B;
     s = cnf_inference(h, mode, xs_d, e_d, lp, rg, uf, B, opts, stats, nullptr);
     if (s == CNF_OK) {
@@ -1092,8 +1103,6 @@ extern "C" cnf_status cnf_inference_host(cnf_handle h, int mode, const float* xs
         if (e == hipSuccess && u_final) e = hipMemcpy(u_final, uf, D * B * sizeof(float), hipMemcpyDeviceToHost);
         if (e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
     }
-    (void)hipFree(xs_d); (void)hipFree(out_d);
-    if (e_d) (void)hipFree(e_d);
     return s;
 }
 
@@ -1304,10 +1313,10 @@ extern "C" cnf_status cnf_loss_grad_host(cnf_handle h, const float* xs, const fl
     HIPCHK(h, hipSetDevice(h->device));
     if ((s = ensure_grad_capacity(h, B)) != CNF_OK) return s;
     const size_t nx = (size_t)h->nd.nvars * B, ne = (size_t)h->nd.n_in * B;
-    float *x_d = nullptr, *e_d = nullptr;
-    HIPCHK(h, hipMalloc(&x_d, nx * sizeof(float)));
-    hipError_t e = hipMalloc(&e_d, ne * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(x_d, xs, nx * sizeof(float), hipMemcpyHostToDevice);
+    if ((s = ensure_stage(h, nx + ne)) != CNF_OK) return s;
+    float* x_d = h->stage;
+    float* e_d = x_d + nx;
+    hipError_t e = hipMemcpy(x_d, xs, nx * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(e_d, eps, ne * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
     if (s == CNF_OK) s = cnf_loss_grad(h, x_d, e_d, B, opts, loss_out, h->g_grad, stats, nullptr);
@@ -1315,7 +1324,5 @@ extern "C" cnf_status cnf_loss_grad_host(cnf_handle h, const float* xs, const fl
         e = hipMemcpy(grad, h->g_grad, h->n_params * sizeof(float), hipMemcpyDeviceToHost);
         if (e != hipSuccess) s = fail(h, CNF_ERR_HIP, hipGetErrorString(e));
     }
-    (void)hipFree(x_d);
-    if (e_d) (void)hipFree(e_d);
     return s;
 }
