@@ -1,7 +1,7 @@
 # ContinuousNormalizingFlowsHIPExt.jl -- the Julia side of the MI355X backend.
 #
 # UNTESTED: Julia is not installed in the build container, so this file has never been
-# parsed or run.  It shows, concretely, the methods a maintainer adds next to the
+# parsed or run (julia/make_fixtures.jl, beside it, produces the fixtures that would test it).  It shows, concretely, the methods a maintainer adds next to the
 # reference's own dispatch points; the C ABI it binds (include/cnfhip.h) is what the
 # repository tests through Python/ctypes.
 #
@@ -14,11 +14,31 @@
 module ContinuousNormalizingFlowsHIPExt
 
 import ContinuousNormalizingFlows as CNF
-import ContinuousNormalizingFlows: ICNF, MatrixMode, TrainMode, TestMode, Mode, n_augment,
-    n_augment_input, augmented_f, base_sol
-import LuxCore, SciMLBase
+import ContinuousNormalizingFlows: ICNF, AbstractICNF, MatrixMode, TrainMode, TestMode, Mode, n_augment,
+    n_augment_input, augmented_f, base_sol, rng_AT, base_AT
+import ComputationalResources, LuxCore, NNlib, Random, SciMLBase
 
 const libcnfhip = get(ENV, "CNFHIP_LIB", "libcnfhip.so")
+
+function __init__()
+    # kernel arguments in device memory: saves a PCIe read (~2.5 us) at the start of every step kernel; the HIP runtime
+    # reads the switch when it initialises, so it has to be set before the first HIP call of the process
+    haskey(ENV, "HIP_FORCE_DEV_KERNARG") || (ENV["HIP_FORCE_DEV_KERNARG"] = "1")
+end
+
+# ---- resource hooks (pattern: ext/ContinuousNormalizingFlowsCUDAExt/ContinuousNormalizingFlowsCUDAExt.jl:5-15) ------
+# ComputationalResources has no ROCm resource, so the backend defines its own.  With it, `construct(...; resource =
+# ROCmLibs())` selects where inference_prob allocates the probe (src/base_icnf.jl:277) and which RNG fills it (:278).
+# The C ABI takes host OR device pointers, so the default keeps host arrays (no AMDGPU.jl dependency); with AMDGPU.jl
+# loaded, `base_AT` may return `AMDGPU.ROCArray{T}(undef, dims...)` and the device-pointer entry points
+# (cnf_rhs / cnf_solve_tsit5 / cnf_inference) take `pointer(x)` directly: see INTEGRATION.md.
+struct ROCmLibs <: ComputationalResources.AbstractResource end
+
+@inline rng_AT(::ROCmLibs) = Random.default_rng()
+
+@inline function base_AT(::ROCmLibs, ::AbstractICNF{T}, dims...) where {T <: AbstractFloat}
+    Array{T}(undef, dims...)
+end
 
 # ---- compute modes (src/types.jl:17-23 pattern) ------------------------------------------
 abstract type HIPMatrixMode{ADBack} <: MatrixMode{ADBack} end
@@ -55,7 +75,15 @@ check(st::Cint, h) = st == 0 ? nothing :
     error("libcnfhip: ", unsafe_string(@ccall libcnfhip.cnf_status_string(st::Cint)::Cstring), " -- ",
           unsafe_string(@ccall libcnfhip.cnf_last_error(h::Ptr{Cvoid})::Cstring))
 
-const ACT = Dict(identity => 0, tanh => 1)   # extend with the activations of include/cnfhip.h
+# Dense activations of include/cnfhip.h (CNF_ACT_*).  Lux swaps some of them for NNlib's fast variants when it
+# builds the layer, so both spellings are listed.
+const ACT = IdDict{Any, Int32}(identity => 0,
+    tanh => 1, NNlib.tanh_fast => 1,
+    NNlib.sigmoid => 2, NNlib.sigmoid_fast => 2,
+    NNlib.softplus => 3, NNlib.relu => 4, NNlib.swish => 5, NNlib.elu => 6)
+act_code(f) = get(ACT, f) do
+    error("libcnfhip has no kernel for activation $f (supported: identity tanh sigmoid softplus relu swish elu)")
+end
 mode_flag(::TrainMode) = Cint(1)
 mode_flag(::Mode) = Cint(0)
 
@@ -66,7 +94,7 @@ function handle(icnf::ICNF{T, <:HIPMatrixMode}) where {T}
     get!(HANDLES, icnf) do
         layers = icnf.nn.layers                       # Lux.Chain of Lux.Dense
         dims = Int32[first(layers).in_dims; [l.out_dims for l in layers]...]
-        acts = Int32[ACT[l.activation] for l in layers]
+        acts = Int32[act_code(l.activation) for l in layers]
         h = Ref{Ptr{Cvoid}}(C_NULL)
         GC.@preserve dims acts begin
             cfg = CnfConfig(length(layers), pointer(dims), pointer(acts), icnf.nvars,
@@ -79,8 +107,18 @@ function handle(icnf::ICNF{T, <:HIPMatrixMode}) where {T}
     end
 end
 
-set_params!(h, p) = (v = Vector{Float32}(p);   # ComponentArray -> flat vector: weight, bias per layer
-    check(@ccall(libcnfhip.cnf_set_params_host(h::Ptr{Cvoid}, v::Ptr{Float32}, length(v)::Csize_t)::Cint), h))
+# Upload `p` (ComponentArray -> flat vector: per layer weight, column-major, then bias) unless the handle already holds
+# it.  The integrator calls augmented_f 6 times per step with the SAME `p` object: the upload is keyed on the identity of
+# that object plus a hash of its contents (an optimiser that updates `p` in place changes the hash).
+const UPLOADED = Dict{Ptr{Cvoid}, Tuple{UInt, UInt}}()
+function set_params!(h, p)
+    key = (objectid(p), hash(p))
+    get(UPLOADED, h, nothing) == key && return nothing
+    v = Vector{Float32}(p)
+    check(@ccall(libcnfhip.cnf_set_params_host(h::Ptr{Cvoid}, v::Ptr{Float32}, length(v)::Csize_t)::Cint), h)
+    UPLOADED[h] = key
+    nothing
+end
 
 # ---- augmented_f (src/icnf.jl:318-350 / :352-382 and the TestMode pair :148-184) ------------
 function augmented_f(u::Any, p::Any, ::Any, icnf::ICNF{T, <:HIPMatrixMode, false}, mode::Mode,
@@ -127,6 +165,25 @@ function lockstep!(icnf::ICNF{T, <:HIPMatrixMode}, reduce!) where {T}
                                                 pointer_from_objref(ref)::Ptr{Cvoid})::Cint), h)
     icnf
 end
+
+# ---- the mean of `loss` over shards (src/icnf.jl:489): RCCL all-reduce without MPI.jl / NCCL.jl ----------------------
+# One process per GPU.  Rank 0 draws an id and hands the 128 bytes to the other ranks by any channel it has (a file, a
+# socket, MPI.bcast); every rank then builds the communicator and reduces the five sums of cnf_loss_sums in place.
+comm_unique_id() = (id = Vector{UInt8}(undef, 128);
+    check(@ccall(libcnfhip.cnf_comm_unique_id(id::Ptr{UInt8})::Cint), C_NULL); id)
+function comm_init(world_size::Integer, rank::Integer, id::Vector{UInt8}, device::Integer)
+    c = Ref{Ptr{Cvoid}}(C_NULL)
+    check(@ccall(libcnfhip.cnf_comm_init(c::Ptr{Ptr{Cvoid}}, world_size::Cint, rank::Cint, id::Ptr{UInt8},
+                                         device::Cint)::Cint), C_NULL)
+    c[]
+end
+# sums5: DEVICE pointer to the 5 floats written by cnf_loss_sums / cnf_inference_sums; reduced in place on `stream`
+loss_allreduce!(icnf, comm::Ptr{Cvoid}, sums5::Ptr{Float32}, stream::Ptr{Cvoid} = C_NULL) =
+    check(@ccall(libcnfhip.cnf_loss_allreduce(handle(icnf)::Ptr{Cvoid}, comm::Ptr{Cvoid}, sums5::Ptr{Float32},
+                                              stream::Ptr{Cvoid})::Cint), handle(icnf))
+# lock-step adaptive solves through the same communicator (no host callback): cnf_set_shard_comm
+lockstep!(icnf::ICNF{T, <:HIPMatrixMode}, comm::Ptr{Cvoid}) where {T} =
+    check(@ccall(libcnfhip.cnf_set_shard_comm(handle(icnf)::Ptr{Cvoid}, comm::Ptr{Cvoid})::Cint), handle(icnf))
 
 # ---- base_sol (src/base_icnf.jl:137-143): the whole solve in one C call ------------------------
 # Returns the final D x B matrix directly, which is what inference_sol slices
