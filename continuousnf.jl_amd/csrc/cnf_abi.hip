@@ -372,6 +372,8 @@ static bool trace_ok(cnf_handle h) {
 // TrainMode/VJP on a network whose weights the fused step kernel must stream from L2: below one wave of
 // 16-sample workgroups the stand-alone kernel (cnf_trace.hip: k_vjp_mfma) keeps twice as many CUs busy
 static bool vjp_aux_preferred(cnf_handle h, int B) {
+    static const bool on = [] { const char* e = getenv("CNF_VJP_AUX"); return e && e[0] == '1'; }();
+    if (!on) return false;
     if (h->nd.jvp || h->mfma.variant == 0 || h->mfma.ly.wlds) return false;
     const GradLayout g = grad_layout(h->nd);
     if (!vjp_mfma_supported(h->nd, adj_mfma_layout(h->nd, g))) return false;
@@ -645,7 +647,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     // number of error partials = blocks of whichever kernel writes them
     int nblk = (int)((n + 255) / 256);
     if (nblk > 256) nblk = 256;
-    if (use_mfma) nblk = mfma_grid_for(B);
+    if (use_mfma) nblk = mfma_grid_for(h->mfma, B);
 
     // initial state
     StepState* init = &h->h_state[2];

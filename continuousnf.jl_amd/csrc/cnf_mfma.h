@@ -68,4 +68,4 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
                      bool finalize, int B, hipStream_t s, float* dump = nullptr,
                      size_t dump_stride = 0, void* mirror = nullptr,
                      unsigned seq = 0, size_t dump_step_stride = 0, int dump_cap = 0, float* hs_out = nullptr);
-int mfma_grid_for(int B);
+int mfma_grid_for(const MfmaPlan& p, int B);

@@ -43,6 +43,7 @@
 // k_mfma geometry: 2 teams (one per 16-sample column tile) of MF_WPT = 4 waves: 512 lanes,
 // 2 waves per SIMD, <= 256 VGPRs.
 #define MF_WPT 4
+#define MF_WPT_NARROW 8       // one team of 8 waves = 16-sample workgroups (networks that stream their weights from L2)
 #define MF_KTHREADS (MF_WPT * 128)
 
 
@@ -452,7 +453,7 @@ __device__ __forceinline__ void bwd_epilogue(const LY& ly, float* lds, int l, in
 #define STAMP_ARGS
 #define STAMP_PASS
 #endif
-template <class LY, class F>
+template <int WPT, class LY, class F>
 __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* wimg, int lane, int wave,
                                          unsigned* bar, unsigned& gen, f32x4& zd0, f32x4& zd1,
                                          F&& after_zdot, const float* cimg, int SWC,
@@ -461,7 +462,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
     // LDS) the HBM/L2-resident image, with a row-major transposed copy for the reverse sweep
     // team = column tile; the feature-group index is rotated by 2 for team 1 so that the
     // narrow layers (fewer than 4 output tiles) of the two teams land on different SIMDs
-    const int s = lane & 15, q = lane >> 4, team = wave / MF_WPT, fg = (wave + (MF_WPT / 2) * team) % MF_WPT;
+    const int s = lane & 15, q = lane >> 4, team = wave / WPT, fg = (wave + (WPT / 2) * team) % WPT;
     const int row = 16 * team + s;
     if constexpr (!LY::kStatic) {
         if (ly.jvp() && !cimg) {
@@ -476,9 +477,9 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
                 const float* W = wimg + ly.w_off(l);
                 const bool last = l == L - 1;
                 const int act = ly.act(l);
-                for (int t0 = fg; t0 < ntiles; t0 += 2 * MF_WPT) {
-                    const int t1 = t0 + MF_WPT;
-                    const bool two = ntiles > MF_WPT && t1 < ntiles;   // constant false for layers of <= MF_WPT tiles
+                for (int t0 = fg; t0 < ntiles; t0 += 2 * WPT) {
+                    const int t1 = t0 + WPT;
+                    const bool two = ntiles > WPT && t1 < ntiles;   // constant false for layers of <= WPT tiles
                     f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = ah0, at0 = ah0, at1 = ah0;
                     const float* wa0 = W + (16 * t0 + s) * SW + 4 * q;
                     const float* wa1 = W + (16 * t1 + s) * SW + 4 * q;
@@ -531,9 +532,9 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
         const float* xb = lds + ly.x_off(l) + row * ly.SX(l) + 4 * q;
         const float* W = wimg + ly.w_off(l);
         const bool last = l == ly.L() - 1;
-        for (int t0 = fg; t0 < ntiles; t0 += 2 * MF_WPT) {
-            const int t1 = t0 + MF_WPT;
-            const bool two = ntiles > MF_WPT && t1 < ntiles;   // constant false for layers of <= MF_WPT tiles
+        for (int t0 = fg; t0 < ntiles; t0 += 2 * WPT) {
+            const int t1 = t0 + WPT;
+            const bool two = ntiles > WPT && t1 < ntiles;   // constant false for layers of <= WPT tiles
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* wa0 = W + (16 * t0 + s) * SW + 4 * q;
             const float* wa1 = W + (16 * t1 + s) * SW + 4 * q;
@@ -577,9 +578,9 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
         const float* gb = lds + ly.x_off(2) + row * ly.SX(2) + 4 * q;
         const int pact = ly.act(0);
         float trp = 0.f;
-        for (int t0 = fg; t0 < ntiles; t0 += 2 * MF_WPT) {
-            const int t1 = t0 + MF_WPT;
-            const bool two = ntiles > MF_WPT && t1 < ntiles;   // constant false for layers of <= MF_WPT tiles
+        for (int t0 = fg; t0 < ntiles; t0 += 2 * WPT) {
+            const int t1 = t0 + WPT;
+            const bool two = ntiles > WPT && t1 < ntiles;   // constant false for layers of <= WPT tiles
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* ra = cimg + (16 * t0 + s) * SWC + 4 * q;
             const float* rb = cimg + (16 * t1 + s) * SWC + 4 * q;
@@ -604,9 +605,9 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
         const int ntiles = ly.P(l) >> 4, SW = ly.SW(l);
         const float* gb = lds + ly.x_off(l + 1) + row * ly.SX(l + 1) + 4 * q;
         const float* W = wimg + ly.w_off(l);
-        for (int t0 = fg; t0 < ntiles; t0 += 2 * MF_WPT) {
-            const int t1 = t0 + MF_WPT;
-            const bool two = ntiles > MF_WPT && t1 < ntiles;   // constant false for layers of <= MF_WPT tiles
+        for (int t0 = fg; t0 < ntiles; t0 += 2 * WPT) {
+            const int t1 = t0 + WPT;
+            const bool two = ntiles > WPT && t1 < ntiles;   // constant false for layers of <= WPT tiles
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* wc0 = W + (4 * q) * SW + 16 * t0 + s;
             const float* wc1 = W + (4 * q) * SW + 16 * t1 + s;
@@ -651,6 +652,183 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
     });
 }
 
+// ---- weight stream (static layouts whose weights stay in L2) --------------------------------------------
+// Every wave's sequence of weight fragments is known at compile time and does not depend on data: tiles fg,
+// fg+WPT, ... of every sweep, sweep after sweep, evaluation after evaluation.  So the fragments are fetched as ONE
+// stream that runs MF_AH k-blocks ahead of the MFMAs ACROSS tile, sweep and evaluation boundaries: the last k-blocks
+// of a tile request the first fragments of the wave's next tile (or of the next sweep's image), which then travel
+// while the epilogue and the barrier run.  Without that every tile start exposes a full L2 round trip -- six per
+// evaluation on BASELINE config 5.
+#ifndef MF_AH
+#define MF_AH 4
+#endif
+struct WPre { f32x4 a0[MF_AH], a1[MF_AH]; };
+
+template <bool TWO>
+__device__ __forceinline__ void wpre_load(WPre& p, const float* w0, const float* w1) {
+#pragma unroll
+    for (int j = 0; j < MF_AH; ++j) {
+        p.a0[j] = *(const f32x4*)(w0 + 16 * j);
+        if (TWO) p.a1[j] = *(const f32x4*)(w1 + 16 * j);
+    }
+}
+
+// one tile (NTL == 1) or two tiles sharing the B operand (NTL == 2) of NU k-blocks; `pre` holds the first MF_AH
+// fragments on entry and those of the next body (rows nw0 / nw1) on exit
+template <int NU, int NTL, bool NEXT_TWO>
+__device__ __forceinline__ void chain_body(f32x4& acc0, f32x4& acc1, const float* xb, const float* wa0,
+                                           const float* wa1, WPre& pre, const float* nw0, const float* nw1) {
+    static_assert(NU >= MF_AH, "a body must be at least as long as the prefetch distance");
+    constexpr int R = MF_AH + 1;
+    f32x4 a0[R], a1[R], b[3];
+#pragma unroll
+    for (int j = 0; j < MF_AH; ++j) { a0[j] = pre.a0[j]; if (NTL == 2) a1[j] = pre.a1[j]; }
+    b[0] = *(const f32x4*)xb;
+    if (NU > 1) b[1] = *(const f32x4*)(xb + 16);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block<NTL>(acc0, acc1, b[u % 3], a0[u % R], a1[u % R]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + MF_AH < NU) {
+            a0[(u + MF_AH) % R] = *(const f32x4*)(wa0 + 16 * (u + MF_AH));
+            if (NTL == 2) a1[(u + MF_AH) % R] = *(const f32x4*)(wa1 + 16 * (u + MF_AH));
+        } else {
+            const int j = u + MF_AH - NU;
+            pre.a0[j] = *(const f32x4*)(nw0 + 16 * j);
+            if (NEXT_TWO) pre.a1[j] = *(const f32x4*)(nw1 + 16 * j);
+        }
+        if (u + 2 < NU) b[(u + 2) % 3] = *(const f32x4*)(xb + 16 * (u + 2));
+    }
+}
+
+// one sweep: this wave's NT tiles (fg, fg + WPT, ...) of a row-major image with NU k-blocks per row.
+// pro(t) -> per-tile vector fetched BEFORE the MFMAs (bias); epi(t, acc, pro value).
+template <int WPT, int NU, int NT, bool NEXT_TWO, class Pro, class Epi>
+__device__ __forceinline__ void stream_sweep(const float* img, int SW, const float* xb, int fg, int s, int q,
+                                             WPre& pre, const float* nw0, const float* nw1, Pro&& pro, Epi&& epi) {
+    auto rowp = [&](int t) { return img + (16 * t + s) * SW + 4 * q; };
+    static_for_up<0, (NT + 1) / 2>([&](auto bi) {
+        constexpr int b = decltype(bi)::value;
+        constexpr bool two = 2 * b + 1 < NT, has_next = 2 * b + 2 < NT, next_two_in = 2 * b + 3 < NT;
+        const int t0 = fg + 2 * b * WPT, t1 = t0 + WPT;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 p0 = pro(t0), p1 = two ? pro(t1) : zero;
+        f32x4 acc0 = zero, acc1 = zero;
+        if constexpr (has_next)
+            chain_body<NU, two ? 2 : 1, next_two_in>(acc0, acc1, xb, rowp(t0), rowp(t1), pre, rowp(t0 + 2 * WPT),
+                                                     rowp(t0 + 3 * WPT));
+        else
+            chain_body<NU, two ? 2 : 1, NEXT_TWO>(acc0, acc1, xb, rowp(t0), rowp(t1), pre, nw0, nw1);
+        if (!two) acc0 += acc1;
+        epi(t0, acc0, p0);
+        if (two) epi(t1, acc1, p1);
+    });
+}
+
+template <class LY, int WPT>
+constexpr bool stream_ok() {
+    if constexpr (!LY::kStatic) return false;
+    else {
+        if (LY::wlds()) return false;
+        for (int l = 0; l <= LY::kL; ++l) if ((LY::P(l) / 16) % WPT) return false;
+        for (int l = 0; l <= LY::kL; ++l) if (LY::P(l) / 16 < MF_AH) return false;
+        return LY::P(LY::kL) / 16 <= 2 * WPT;
+    }
+}
+
+// LDS-only workgroup barrier: __syncthreads() would also drain the weight fragments in flight
+__device__ __forceinline__ void stream_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// rhs_tile for the streamed layouts (same contract; `pre` carries the stream from call to call)
+template <int WPT, class LY, class F>
+__device__ __forceinline__ void rhs_tile_stream(const LY& ly, float* lds, const float* wimg, int lane, int wave,
+                                                f32x4& zd0, f32x4& zd1, F&& after_zdot, const float* cimg, int SWC,
+                                                const float* cbrow, WPre& pre) {
+    constexpr int L = LY::kL;
+    const int s = lane & 15, q = lane >> 4, team = wave / WPT, fg = (wave + (WPT / 2) * team) % WPT;
+    const int row = 16 * team + s;
+    const bool test = cimg != nullptr;
+    // first rows of this wave in an image (tile fg and tile fg + WPT)
+    auto first0 = [&](const float* img, int SW) { return img + (16 * fg + s) * SW + 4 * q; };
+    auto first1 = [&](const float* img, int SW) { return img + (16 * (fg + WPT) + s) * SW + 4 * q; };
+    // ---- forward ----
+    static_for_up<0, L>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr bool last = l == L - 1;
+        constexpr int NU = LY::P(l) / 16, NT = LY::P(l + 1) / 16 / WPT;
+        // what follows this sweep: the next forward layer, or the first reverse sweep / the trace image
+        constexpr int NT_next = last ? LY::P(L - 1) / 16 / WPT : LY::P(l + 2 > L ? L : l + 2) / 16 / WPT;
+        const float* nimg = last ? (test ? cimg : wimg + LY::wt_off(L - 1)) : wimg + LY::w_off(last ? l : l + 1);
+        const int nSW = last ? (test ? SWC : LY::SWT(L - 1)) : LY::SW(last ? l : l + 1);
+        const float* xb = lds + LY::x_off(l) + row * LY::SX(l) + 4 * q;
+        stream_sweep<WPT, NU, NT, (NT_next >= 2)>(wimg + LY::w_off(l), LY::SW(l), xb, fg, s, q, pre,
+                                                  first0(nimg, nSW), first1(nimg, nSW),
+            [&](int t) {
+                const int r0 = 16 * t + 4 * q;
+                return (l == 0 && cbrow) ? *(const f32x4*)(cbrow + r0) : *(const f32x4*)(wimg + LY::b_off(l) + r0);
+            },
+            [&](int t, const f32x4& acc, const f32x4& bv) {
+                const int r0 = 16 * t + 4 * q;
+                f32x4 h, d;
+                act4(LY::act(l), acc + bv, h, d);
+                float* out = lds + LY::x_off(l + 1) + row * LY::SX(l + 1) + r0;
+                if constexpr (!last) *(f32x4*)out = h;
+                else {
+                    const int n_in = ly.n_in();
+                    const f32x4 ev = *(const f32x4*)(lds + LY::eps_off() + row * LY::SX(0) + r0);
+                    const f32x4 zd = {r0 + 0 < n_in ? h.x : 0.f, r0 + 1 < n_in ? h.y : 0.f, r0 + 2 < n_in ? h.z : 0.f,
+                                      r0 + 3 < n_in ? h.w : 0.f};
+                    if (t == fg) zd0 = zd; else zd1 = zd;
+                    *(f32x4*)out = test ? f32x4{r0 + 0 < n_in ? d.x : 0.f, r0 + 1 < n_in ? d.y : 0.f,
+                                                r0 + 2 < n_in ? d.z : 0.f, r0 + 3 < n_in ? d.w : 0.f}
+                                        : ev * d;
+                    const float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
+                    if (q == 0) lds[LY::red_off() + t * MF_NB + row] = e2;
+                }
+            });
+        if (last) after_zdot();
+        stream_barrier();
+    });
+    const float* w0first0 = first0(wimg + LY::w_off(0), LY::SW(0));
+    const float* w0first1 = first1(wimg + LY::w_off(0), LY::SW(0));
+    constexpr bool F0_TWO = LY::P(1) / 16 / WPT >= 2;
+    if (test) {
+        // ---- exact trace of a 2-layer net: tr J = sum_k sigma'_1[k] (C sigma'_2)[k], C = W_1 .* W_2^T (rows in L2)
+        if constexpr (L == 2) {
+            constexpr int NU = LY::P(2) / 16, NT = LY::P(1) / 16 / WPT;
+            const float* gb = lds + LY::x_off(2) + row * LY::SX(2) + 4 * q;
+            float trp = 0.f;
+            stream_sweep<WPT, NU, NT, F0_TWO>(cimg, SWC, gb, fg, s, q, pre, w0first0, w0first1,
+                [&](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
+                [&](int t, const f32x4& acc, const f32x4&) {
+                    const f32x4 h = *(const f32x4*)(lds + LY::x_off(1) + row * LY::SX(1) + 16 * t + 4 * q);
+                    trp += acc.x * d_from_h(LY::act(0), h.x) + acc.y * d_from_h(LY::act(0), h.y) +
+                           acc.z * d_from_h(LY::act(0), h.z) + acc.w * d_from_h(LY::act(0), h.w);
+                });
+            trp = quad_sum(trp);
+            if (q == 0) lds[LY::red_off() + fg * MF_NB + row] = -trp;
+        }
+        stream_barrier();
+        return;
+    }
+    // ---- reverse (VJP): rows of the transposed images ----
+    static_for_down<L - 1>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int NU = LY::P(l + 1) / 16, NT = LY::P(l) / 16 / WPT;
+        constexpr int NT_next = l > 0 ? LY::P(l > 0 ? l - 1 : 0) / 16 / WPT : LY::P(1) / 16 / WPT;
+        const float* nw0 = l > 0 ? first0(wimg + LY::wt_off(l > 0 ? l - 1 : 0), LY::SWT(l > 0 ? l - 1 : 0)) : w0first0;
+        const float* nw1 = l > 0 ? first1(wimg + LY::wt_off(l > 0 ? l - 1 : 0), LY::SWT(l > 0 ? l - 1 : 0)) : w0first1;
+        const float* gb = lds + LY::x_off(l + 1) + row * LY::SX(l + 1) + 4 * q;
+        stream_sweep<WPT, NU, (NT < 1 ? 1 : NT), (NT_next >= 2)>(wimg + LY::wt_off(l), LY::SWT(l), gb, fg, s, q, pre, nw0, nw1,
+            [&](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
+            [&](int t, const f32x4& acc, const f32x4&) { bwd_epilogue(ly, lds, l, t, acc, row, q); });
+        stream_barrier();
+    });
+}
+
 // One workgroup = one 32-sample tile (two teams of 16 samples).  The Runge-Kutta state is
 // kept in registers in the MFMA accumulator layout: the lane that produces rows 4q..4q+3
 // of zdot for sample s (wave fg owns the 16-row tiles fg and fg+4 of the n_in rows) holds
@@ -663,7 +841,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
 // Streamed solve: block 0 copies the integrator state to pinned host memory after every controller run and
 // then publishes the launch index; the host polls that word instead of waiting on events and copies.
 
-template <class LY, bool STEP>
+template <class LY, bool STEP, int WPT = MF_WPT>
 __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StepState* st = a.st;
@@ -675,6 +853,14 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         // keep the state chain intact for the launches queued behind this one
         if (STEP && a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
         return;
+    }
+    // streamed layouts: the first weight fragments of this wave set off before anything else
+    constexpr bool STREAM = stream_ok<LY, WPT>();
+    WPre pre;
+    if constexpr (STREAM) {
+        const int tm = wave / WPT, fgs = (wave + (WPT / 2) * tm) % WPT;
+        const float* w0 = a.img + LY::w_off(0) + (16 * fgs + (lane & 15)) * LY::SW(0) + 4 * (lane >> 4);
+        wpre_load<(LY::P(1) / 16 / WPT >= 2)>(pre, w0, w0 + 16 * WPT * LY::SW(0));
     }
     // error partials of the previous attempt: requested first, consumed after the image fill
     float cp0 = 0.f, cp1 = 0.f;
@@ -745,13 +931,13 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         if (dumpb && blockIdx.x == 0 && tid == 0) a.hs_out[nacc] = hstep;
     }
 
-    constexpr int TNB = MF_NB / 2;
-    const int team = wave / MF_WPT;
-    const int s = lane & 15, q = lane >> 4, fg = (wave + (MF_WPT / 2) * team) % MF_WPT;
+    constexpr int TNB = 16, NBT = 16 * (MF_KTHREADS / 64 / WPT);   // samples per team / per workgroup tile
+    const int team = wave / WPT;
+    const int s = lane & 15, q = lane >> 4, fg = (wave + (WPT / 2) * team) % WPT;
     const int nt0 = ly.P(0) >> 4;
-    const bool own0 = fg < nt0, own1 = nt0 > MF_WPT && fg + MF_WPT < nt0;   // z-row tiles fg, fg+MF_WPT
+    const bool own0 = fg < nt0, own1 = nt0 > WPT && fg + WPT < nt0;   // z-row tiles fg, fg+WPT
     const bool sown = fg == 0 && q == 0;                  // scalar rows of sample s
-    const int r00 = 16 * fg + 4 * q, r01 = r00 + 16 * MF_WPT;   // first owned row of each tile
+    const int r00 = 16 * fg + 4 * q, r01 = r00 + 16 * WPT;   // first owned row of each tile
     const int nv0 = own0 ? n_in - r00 : 0, nv1 = own1 ? n_in - r01 : 0;   // valid rows (may be <= 0 or > 4)
     const int row = TNB * team + s;
     // (explicit selects: indexing the kernel-argument arrays with a run-time value makes the compiler fetch the
@@ -768,9 +954,9 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
     __syncthreads();       // image filled, counters zeroed
     STAMP(15);
 
-    const int ntile = (a.B + MF_NB - 1) / MF_NB;
+    const int ntile = (a.B + NBT - 1) / NBT;
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const int b0 = tile * MF_NB + TNB * team;                 // first sample of this team
+        const int b0 = tile * NBT + TNB * team;                 // first sample of this team
         const int nvalid = max(0, min(TNB, a.B - b0));
         const bool live = s < nvalid;                             // this lane's sample exists
         const size_t gcol = (size_t)(b0 + s) * D;
@@ -831,7 +1017,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
         auto read_scalars = [&]() {
             if (a.test) {       // exact trace: 4 per-wave partials of -tr J
                 float ld = 0.f;
-                for (int w = 0; w < MF_WPT; ++w) ld += lds[ly.red_off() + w * MF_NB + row];
+                for (int w = 0; w < WPT; ++w) ld += lds[ly.red_off() + w * MF_NB + row];
                 return f32x4{ld, 0.f, 0.f, 0.f};
             }
             float ld = 0.f, e2 = 0.f, n2 = 0.f;
@@ -850,12 +1036,18 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
             // rewritten only in this evaluation's last forward epilogue, two barriers on)
             if (stg > 1 && sown) sc_set(stg, read_scalars());        // slot j holds k_j
             f32x4 zd0 = {0.f, 0.f, 0.f, 0.f}, zd1 = zd0;
-            rhs_tile(ly, lds, wimg, lane, wave, bar, gen, zd0, zd1, [&]() {
+            auto after_zdot = [&]() {
                 if (mode == 2) {
                     set_k(kz0, stg, zd0); set_k(kz1, stg, zd1);
                     if (stg < nstage) put_stage(stg + 1);
                 } else { kz0[1] = zd0; kz1[1] = zd1; }
-            }, a.test ? a.cimg : nullptr, a.SWC, cbrow STAMP_PASS);
+            };
+            if constexpr (STREAM)
+                rhs_tile_stream<WPT>(ly, lds, wimg, lane, wave, zd0, zd1, after_zdot, a.test ? a.cimg : nullptr, a.SWC,
+                                     cbrow, pre);
+            else
+                rhs_tile<WPT>(ly, lds, wimg, lane, wave, bar, gen, zd0, zd1, after_zdot, a.test ? a.cimg : nullptr, a.SWC,
+                              cbrow STAMP_PASS);
         }
         // scalar rows of the last evaluation (rhs_tile ended with a barrier)
         if (sown) {
@@ -1100,12 +1292,12 @@ void mfma_plan_free(MfmaPlan& p) {
     p.d_img3 = nullptr;
 }
 
-template <class LY>
+template <class LY, int WPT = MF_WPT>
 static hipError_t set_attr() {
-    hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LY, true, WPT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        MF_LDS_BYTES);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_mfma<LY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    return hipFuncSetAttribute((const void*)k_mfma<LY, false, WPT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                MF_LDS_BYTES);
 }
 
@@ -1118,6 +1310,8 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
         if (e == hipSuccess) e = set_attr<LyCfg2>();
         if (e == hipSuccess) e = set_attr<LyCfg1>();
         if (e == hipSuccess) e = set_attr<LyCfg5>();
+        if (e == hipSuccess) e = set_attr<LyCfg5, MF_WPT_NARROW>();
+        if (e == hipSuccess) e = set_attr<RtLayout, MF_WPT_NARROW>();
         if (e != hipSuccess) return CNF_ERR_HIP;
     }
     hipLaunchKernelGGL(k_pack_image, dim3((p.ly.img_floats + 255) / 256), dim3(256), 0, s, p.ly, nd,
@@ -1134,18 +1328,28 @@ bool mfma_supported(const MfmaPlan& p, const NetDesc&, bool train, int) {
     return train || p.ly.c_off >= 0;     // TestMode: exact trace in closed form for 2-layer nets
 }
 
-int mfma_grid_for(int B) {
-    int nt = (B + MF_NB - 1) / MF_NB;
+// Networks whose weights stream from L2 run 16-sample workgroups (one team of 8 waves): the two teams of a
+// 32-sample tile share nothing there (each fetches its own fragments), so the narrow tile costs no extra traffic
+// and puts twice as many CUs to work at small batches (BASELINE config 5: 2048 columns = 128 workgroups, not 64).
+// CNF_WIDE_TILES=1 keeps the 32-sample tile (A/B measurements only).
+static bool narrow_tiles(const MfmaPlan& p) {
+    static const bool wide = [] { const char* e = getenv("CNF_WIDE_TILES"); return e && e[0] == '1'; }();
+    return p.variant != 0 && !p.ly.wlds && !wide;
+}
+
+int mfma_grid_for(const MfmaPlan& p, int B) {
+    const int nb = narrow_tiles(p) ? 16 : MF_NB;
+    int nt = (B + nb - 1) / nb;
     return nt < 512 ? (nt < 1 ? 1 : nt) : 512;
 }
 
-template <class LY>
+template <class LY, int WPT = MF_WPT>
 static void launch_static(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipStream_t s) {
     LY ly;
     ly.n_in_ = p.ly.n_in; ly.norm_z_ = p.ly.norm_z; ly.norm_j_ = p.ly.norm_j;
     const size_t shm = (size_t)LY::total_floats() * sizeof(float);
-    if (a.mode == 2) hipLaunchKernelGGL((k_mfma<LY, true>), grid, dim3(MF_KTHREADS), shm, s, ly, a);
-    else hipLaunchKernelGGL((k_mfma<LY, false>), grid, dim3(MF_KTHREADS), shm, s, ly, a);
+    if (a.mode == 2) hipLaunchKernelGGL((k_mfma<LY, true, WPT>), grid, dim3(MF_KTHREADS), shm, s, ly, a);
+    else hipLaunchKernelGGL((k_mfma<LY, false, WPT>), grid, dim3(MF_KTHREADS), shm, s, ly, a);
 }
 // CNF_STEP_V1=1: the first-generation step kernel (k_mfma) for the headline shape too -- A/B measurements only
 static bool step_v1() {
@@ -1157,9 +1361,16 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
     MfmaArgs a = a0;
     if (a.test) { a.cimg = p.d_img + p.ly.c_off; a.SWC = p.ly.SWC; }
     a.cond = p.cond; a.cbs = p.cbs;
-    const dim3 grid(mfma_grid_for(a.B)), block(MF_KTHREADS);
+    const dim3 grid(mfma_grid_for(p, a.B)), block(MF_KTHREADS);
     const size_t shm = (size_t)p.ly.total_floats * sizeof(float);
-    if (a.test && p.variant != 5) {
+    const bool narrow = narrow_tiles(p);
+    if (narrow && p.variant != 5) {
+        RtLayout ly{p.ly};
+        if (a.mode == 2) hipLaunchKernelGGL((k_mfma<RtLayout, true, MF_WPT_NARROW>), grid, block, shm, s, ly, a);
+        else hipLaunchKernelGGL((k_mfma<RtLayout, false, MF_WPT_NARROW>), grid, block, shm, s, ly, a);
+    }
+    else if (narrow) launch_static<LyCfg5, MF_WPT_NARROW>(p, a, grid, s);
+    else if (a.test && p.variant != 5) {
         // exact trace: the run-time-layout kernel (the static BASELINE shapes 1-3 are TrainMode kernels)
         RtLayout ly{p.ly};
         if (a.mode == 2) hipLaunchKernelGGL((k_mfma<RtLayout, true>), grid, block, shm, s, ly, a);
