@@ -369,18 +369,6 @@ static bool trace_ok(cnf_handle h) {
     const GradLayout g = grad_layout(h->nd);
     return trace_mfma_supported(h->nd, adj_mfma_layout(h->nd, g));
 }
-// TrainMode/VJP on a network whose weights the fused step kernel must stream from L2: below one wave of
-// 16-sample workgroups the stand-alone kernel (cnf_trace.hip: k_vjp_mfma) keeps twice as many CUs busy
-static bool vjp_aux_preferred(cnf_handle h, int B) {
-    static const bool on = [] { const char* e = getenv("CNF_VJP_AUX"); return e && e[0] == '1'; }();
-    if (!on) return false;
-    if (h->nd.jvp || h->mfma.variant == 0 || h->mfma.ly.wlds) return false;
-    const GradLayout g = grad_layout(h->nd);
-    if (!vjp_mfma_supported(h->nd, adj_mfma_layout(h->nd, g))) return false;
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) return false;
-    return (B + 15) / 16 <= cus;
-}
 // TrainMode with the JVP compute mode on a network the fused step kernel cannot hold
 static bool jvp_aux_ok(cnf_handle h) {
     const GradLayout g = grad_layout(h->nd);
@@ -398,7 +386,6 @@ static cnf_status launch_trace(cnf_handle h, const float* u, float* du, bool in_
     a.du_is_k7 = du_is_k7 ? 1 : 0;
     a.B = B;
     if (h->aux_train && h->nd.jvp) HIPCHK(h, launch_jvp_mfma(h->nd, g, m, h->d_adj_img, a, h->aux_eps, st));
-    else if (h->aux_train) HIPCHK(h, launch_vjp_mfma(h->nd, g, m, h->d_adj_img, a, h->aux_eps, st));
     else HIPCHK(h, launch_trace_mfma(h->nd, g, m, h->d_adj_img, a, st));
     return CNF_OK;
 }
@@ -453,8 +440,7 @@ extern "C" cnf_status cnf_rhs(cnf_handle h, int mode, int kernel, const float* u
     if ((s = resolve_kernel(h, mode, B, kernel, &k)) != CNF_OK) return s;
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    if (k == CNF_KERNEL_MFMA && (!mfma_supported(h->mfma, h->nd, mode == CNF_MODE_TRAIN, B) ||
-                                 (mode == CNF_MODE_TRAIN && kernel == CNF_KERNEL_AUTO && vjp_aux_preferred(h, B)))) {
+    if (k == CNF_KERNEL_MFMA && !mfma_supported(h->mfma, h->nd, mode == CNF_MODE_TRAIN, B)) {
         // TestMode, three or more layers: exact trace on MFMA; TrainMode/JVP beyond LDS (cnf_trace.hip)
         if ((s = ensure_adj_images(h, st)) != CNF_OK) return s;
         h->aux_train = mode == CNF_MODE_TRAIN; h->aux_eps = eps;
@@ -637,8 +623,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     const size_t n = (size_t)D * B;
     int launches = 0;
 
-    const bool use_mfma = k == CNF_KERNEL_MFMA && mfma_supported(h->mfma, h->nd, train, B) &&
-                          !(train && !rec && opts->kernel == CNF_KERNEL_AUTO && vjp_aux_preferred(h, B));
+    const bool use_mfma = k == CNF_KERNEL_MFMA && mfma_supported(h->mfma, h->nd, train, B);
     h->trace_on = k == CNF_KERNEL_MFMA && !use_mfma;       // generic driver + an auxiliary MFMA kernel per stage
     h->aux_train = train != 0; h->aux_eps = eps;
     if (h->trace_on && (s = ensure_adj_images(h, (hipStream_t)stream)) != CNF_OK) return s;

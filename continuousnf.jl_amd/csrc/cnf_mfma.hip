@@ -88,6 +88,7 @@ template <bool WLDS, int ACT, int... PD>
 struct StLayoutX {
     static constexpr bool kStatic = true;
     static constexpr int kL = sizeof...(PD) - 1;
+    static constexpr int kNB = WLDS ? MF_NB : 16;      // samples per workgroup tile (mfma_plan_init: place_lds)
     int n_in_, norm_z_, norm_j_;
     __host__ __device__ static constexpr int pd(int l) { constexpr int a[] = {PD...}; return a[l]; }
     __host__ __device__ static constexpr int L() { return kL; }
@@ -119,12 +120,12 @@ struct StLayoutX {
     }
     __host__ __device__ static constexpr int x_off(int l) {
         int off = WLDS ? img_floats() : 0;
-        for (int i = 0; i < l; ++i) off += MF_NB * sx_of(pd(i));
+        for (int i = 0; i < l; ++i) off += kNB * sx_of(pd(i));
         return off;
     }
     __host__ __device__ static constexpr int eps_off() { return x_off(kL + 1); }
-    __host__ __device__ static constexpr int du_off() { return eps_off() + MF_NB * sx_of(pd(0)); }
-    __host__ __device__ static constexpr int red_off() { return du_off() + MF_NB * sx_of(pd(0)); }
+    __host__ __device__ static constexpr int du_off() { return eps_off() + kNB * sx_of(pd(0)); }
+    __host__ __device__ static constexpr int red_off() { return du_off() + kNB * sx_of(pd(0)); }
     __host__ __device__ static constexpr int red_floats() {
         return 3 * (pd(0) / 16) * MF_NB < 256 ? 256 : 3 * (pd(0) / 16) * MF_NB;
     }
@@ -1232,17 +1233,18 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     ly.img_floats = (off + 3) & ~3;
     ly.wlds = 1;
     ly.jvp = nd.jvp;
-    auto place_lds = [&](int start) {
+    // nb = samples per workgroup tile: 32 (two teams) with the weights in LDS, 16 (one team of 8 waves) without
+    auto place_lds = [&](int start, int nb) {
         int o = start;
         for (int l = 0; l <= nd.n_layers; ++l) {
             ly.SX[l] = sx_of(ly.P[l]);
             ly.x_off[l] = o;
-            o += MF_NB * ly.SX[l];
+            o += nb * ly.SX[l];
         }
-        ly.eps_off = o; o += MF_NB * ly.SX[0];
-        ly.du_off = o;  o += MF_NB * ly.SX[0];
+        ly.eps_off = o; o += nb * ly.SX[0];
+        ly.du_off = o;  o += nb * ly.SX[0];
         if (ly.jvp)
-            for (int l = 1; l < nd.n_layers; ++l) { ly.tx_off[l] = o; o += MF_NB * ly.SX[l]; }
+            for (int l = 1; l < nd.n_layers; ++l) { ly.tx_off[l] = o; o += nb * ly.SX[l]; }
         ly.red_off = o;
         int red = 3 * (ly.P[0] >> 4) * MF_NB;
         o += red < 256 ? 256 : red;
@@ -1250,7 +1252,7 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
         o += 16;                      // team-barrier counters / controller scratch
         ly.total_floats = o;
     };
-    place_lds(ly.img_floats);
+    place_lds(ly.img_floats, MF_NB);
     if ((size_t)ly.total_floats * sizeof(float) > MF_LDS_BYTES) {
         // weights do not fit in LDS next to the activation images: leave them in HBM/L2 and add
         // a row-major transposed copy per layer for the reverse sweep
@@ -1262,7 +1264,7 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
             o += ly.P[l] * ly.SWT[l];
         }
         ly.img_floats = (o + 3) & ~3;
-        place_lds(0);
+        place_lds(0, 16);
     }
     ly.core_img = ly.img_floats;
     ly.c_off = -1; ly.SWC = 0;
@@ -1309,7 +1311,6 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
         if (e == hipSuccess) e = set_attr<LyCfg3>();
         if (e == hipSuccess) e = set_attr<LyCfg2>();
         if (e == hipSuccess) e = set_attr<LyCfg1>();
-        if (e == hipSuccess) e = set_attr<LyCfg5>();
         if (e == hipSuccess) e = set_attr<LyCfg5, MF_WPT_NARROW>();
         if (e == hipSuccess) e = set_attr<RtLayout, MF_WPT_NARROW>();
         if (e != hipSuccess) return CNF_ERR_HIP;
@@ -1331,11 +1332,8 @@ bool mfma_supported(const MfmaPlan& p, const NetDesc&, bool train, int) {
 // Networks whose weights stream from L2 run 16-sample workgroups (one team of 8 waves): the two teams of a
 // 32-sample tile share nothing there (each fetches its own fragments), so the narrow tile costs no extra traffic
 // and puts twice as many CUs to work at small batches (BASELINE config 5: 2048 columns = 128 workgroups, not 64).
-// CNF_WIDE_TILES=1 keeps the 32-sample tile (A/B measurements only).
-static bool narrow_tiles(const MfmaPlan& p) {
-    static const bool wide = [] { const char* e = getenv("CNF_WIDE_TILES"); return e && e[0] == '1'; }();
-    return p.variant != 0 && !p.ly.wlds && !wide;
-}
+// Measured on config 5, same box: 32-sample tiles 41.8 us per RHS, 16-sample tiles 25.9, with the fragment stream 21.7.
+static bool narrow_tiles(const MfmaPlan& p) { return p.variant != 0 && !p.ly.wlds; }
 
 int mfma_grid_for(const MfmaPlan& p, int B) {
     const int nb = narrow_tiles(p) ? 16 : MF_NB;
@@ -1381,7 +1379,6 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
     else if (p.variant == 2) launch_static<LyCfg3>(p, a, grid, s);
     else if (p.variant == 3) launch_static<LyCfg2>(p, a, grid, s);
     else if (p.variant == 4) launch_static<LyCfg1>(p, a, grid, s);
-    else if (p.variant == 5) launch_static<LyCfg5>(p, a, grid, s);
     else {
         RtLayout ly{p.ly};
         if (a.mode == 2) hipLaunchKernelGGL((k_mfma<RtLayout, true>), grid, block, shm, s, ly, a);

@@ -26,9 +26,6 @@ bool trace_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
 TraceLayout trace_layout(const NetDesc& nd, const AdjMfmaLayout& m);
 hipError_t launch_trace_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                              const TraceArgs& a, hipStream_t s);
-bool vjp_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
-hipError_t launch_vjp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
-                           const TraceArgs& a, const float* eps, hipStream_t s);
 bool jvp_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
 hipError_t launch_jvp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                            const TraceArgs& a, const float* eps, hipStream_t s);

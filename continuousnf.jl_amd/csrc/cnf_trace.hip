@@ -8,6 +8,7 @@
 // MFMA column tiles) share every weight fragment fetched from L2.  The diagonal of the last layer is
 // folded into the epilogue of the last middle GEMM; J is never formed.  Two-layer networks use the
 // closed form in cnf_mfma.hip instead.
+#include <cstdlib>
 #include "cnf_trace.h"
 #include "cnf_am.h"
 
@@ -182,6 +183,240 @@ k_trace_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const f
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Three-layer networks whose middle weight matrix fits the register file (BASELINE configs 3/4: 32-128-128-32):
+//   tr J = sum_i d3_i sum_j W3[i][j] d2_j X[j][i],     X = (W2 diag(d1)) W1   per sample,
+// as MFMA products with EVERY operand fragment resident in registers for the whole kernel: wave w keeps its 16-row
+// tile of W2 (A), all of W1^T (B) and its slice of W3.  The per-sample part is one v_mul per two MFMAs (the A
+// fragment scaled by sigma'_1, fetched from LDS as a broadcast); no tangent image is built in LDS, no weight is
+// re-read, and after the forward pass the waves do not meet again until the final sum.  Two samples advance together:
+// four independent accumulator chains.
+// ---------------------------------------------------------------------------------------------------
+template <bool ALL_TANH, int NIP, int H1, int H2>
+__global__ void __launch_bounds__(AM_THREADS)
+k_trace3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const float* __restrict__ img, TraceArgs a) {
+    extern __shared__ float lds[];
+    // no branch before the loads: the integrator state is read through a pointer that is always valid and every
+    // request of the prologue (state words, the 16 samples, the resident fragments) is in flight before `done` is tested
+    const StepState* stp = a.st ? a.st : reinterpret_cast<const StepState*>(img);
+    const int st_done = stp->done, st_cur = stp->cur;
+    constexpr int TI = NIP / 16, KB = H1 / 16, K0 = NIP / 16;
+    static_assert(H2 / 16 == AM_WAVES && H1 / 16 == AM_WAVES, "one row tile of W1 and of W2 per wave");
+#ifdef TR_STAMPS
+    const unsigned long long te = __builtin_amdgcn_s_memtime();
+#endif
+    const int PD = tl.PD;
+    const int PSf = pad8m16_dev(m.maxd);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    const int b0 = blockIdx.x * AM_NS;
+    const int n_in = nd.n_in, D = n_in + 1, in0 = gl.in0;
+    float* du = (a.st && a.du_is_k7) ? (st_cur ? a.K1[0] : a.K1[1]) : a.du;
+
+    // state of the 16 samples first (its consumer, the LDS image, must not queue behind the weight fragments)
+    const int es = tid >> 5, er = tid & 31;                            // (sample, input row): NIP == 32 rows
+    float xin = 0.f;
+    if (b0 + es < a.B && er < in0)
+        xin = er < n_in ? a.u[(size_t)(b0 + es) * D + er] : a.ys[(size_t)(b0 + es) * nd.n_cond + (er - n_in)];
+    // resident fragments: W1 row tile (forward), W2 row tile (forward AND trace), all of W1^T (trace), the W3 slice
+    // (trace epilogue AND this wave's k-block of the last forward layer)
+    f32x4 w1a[K0], wa[KB], wb[TI][KB], w3[TI], bias1, bias2;
+    {
+        const float* W1 = img + m.f_off[0] + (size_t)(16 * wave + s) * NIP + 4 * q;       // [j][i]
+        const float* W2 = img + m.f_off[1] + (size_t)(16 * wave + s) * H1 + 4 * q;        // [j][k]
+        const float* WL = img + m.f_off[2] + 16 * wave + 4 * q;                            // W3 [i][j]
+#pragma unroll
+        for (int u = 0; u < K0; ++u) w1a[u] = *reinterpret_cast<const f32x4*>(W1 + 16 * u);
+        bias1 = *reinterpret_cast<const f32x4*>(img + m.b_off[0] + 16 * wave + 4 * q);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) wa[u] = *reinterpret_cast<const f32x4*>(W2 + 16 * u);
+        bias2 = *reinterpret_cast<const f32x4*>(img + m.b_off[1] + 16 * wave + 4 * q);
+#pragma unroll
+        for (int c = 0; c < TI; ++c) w3[c] = *reinterpret_cast<const f32x4*>(WL + (size_t)(16 * c + s) * H2);
+    }
+    // W1^T is the same for all eight waves: one coalesced copy through LDS instead of eight scattered ones from L2
+    // (the prologue is bound by the bytes the waves pull through the L1, not by latency)
+    constexpr int WTS = H1 + 8, WT_PER = NIP * H1 / 4 / AM_THREADS;   // row stride of the staging image; float4s per thread
+    f32x4 wt[WT_PER];
+#pragma unroll
+    for (int j = 0; j < WT_PER; ++j) {
+        const int idx = tid + AM_THREADS * j, row = idx / (H1 / 4), c4 = idx % (H1 / 4);
+        wt[j] = *reinterpret_cast<const f32x4*>(img + m.r_off[0] + (size_t)row * H1 + 4 * c4);
+        if (row >= n_in) wt[j] = f32x4{0.f, 0.f, 0.f, 0.f};       // columns n_in.. of W1 are the conditioning inputs
+    }
+    const float bias3 = er < nd.dims[3] ? img[m.b_off[2] + er] : 0.f;
+
+    float* S0 = lds + tl.off_T0;                    // [sample][feature], stride PSf: state, then h2
+    float* S1 = S0 + AM_NS * PSf;                   // h1
+    float* Z = S1 + AM_NS * PSf;                    // per-wave partial sums of the last layer [wave][sample][ZS]
+    constexpr int ZS = NIP + 4;
+    float* WT = Z + AM_WAVES * AM_NS * ZS;          // staging image of W1^T [i][k], stride WTS (never aliased)
+    if (a.st && st_done) return;
+#pragma unroll
+    for (int j = 0; j < WT_PER; ++j) {
+        const int idx = tid + AM_THREADS * j, row = idx / (H1 / 4), c4 = idx % (H1 / 4);
+        *reinterpret_cast<f32x4*>(WT + row * WTS + 4 * c4) = wt[j];
+    }
+    S0[es * PSf + er] = xin;
+    am_barrier();
+#ifdef TR_STAMPS
+    const unsigned long long tf = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+    for (int c = 0; c < TI; ++c)
+#pragma unroll
+        for (int u = 0; u < KB; ++u) wb[c][u] = *reinterpret_cast<const f32x4*>(WT + (16 * c + s) * WTS + 16 * u + 4 * q);
+    // ---- forward, every weight already in registers: sigma' of every layer to LDS, zdot out ----
+    auto act4v = [&](int l, const f32x4& x, f32x4& h, f32x4& d) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float hh, dd1, dd2;
+            if (ALL_TANH) { hh = cnf_tanh(x[j]); dd1 = fmaf(-hh, hh, 1.0f); }
+            else cnf_act2(nd.acts[l], x[j], hh, dd1, dd2);
+            h[j] = hh; d[j] = dd1;
+        }
+    };
+    {   // layer 1: rows 16 wave .. +15 of H1
+        f32x4 acc = bias1;
+#pragma unroll
+        for (int u = 0; u < K0; ++u) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(S0 + s * PSf + 16 * u + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a[u][k], b[k], acc, 0, 0, 0);
+        }
+        f32x4 h, d;
+        act4v(0, acc, h, d);
+        const int r0 = 16 * wave + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (r0 + j >= nd.dims[1]) { h[j] = 0.f; d[j] = 0.f; }
+        *reinterpret_cast<f32x4*>(S1 + s * PSf + r0) = h;
+        *reinterpret_cast<f32x4*>(lds + s * PD + m.o_off[0] + r0) = d;
+    }
+    am_barrier();
+    {   // layer 2: rows 16 wave .. +15 of H2, A = the resident W2 tile
+        f32x4 acc0 = bias2, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < KB; u += 2) {
+            const f32x4 b0v = *reinterpret_cast<const f32x4*>(S1 + s * PSf + 16 * u + 4 * q);
+            const f32x4 b1v = *reinterpret_cast<const f32x4*>(S1 + s * PSf + 16 * (u + 1) + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u][k], b0v[k], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u + 1][k], b1v[k], acc1, 0, 0, 0);
+            }
+        }
+        f32x4 h, d;
+        act4v(1, acc0 + acc1, h, d);
+        const int r0 = 16 * wave + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (r0 + j >= nd.dims[2]) { h[j] = 0.f; d[j] = 0.f; }
+        *reinterpret_cast<f32x4*>(S0 + s * PSf + r0) = h;             // the state image was last read before the barrier
+        *reinterpret_cast<f32x4*>(lds + s * PD + m.o_off[1] + r0) = d;
+    }
+    am_barrier();
+    {   // layer 3: this wave's k-block (16 wave .. +15) of both output tiles; A = the resident W3 slice
+        const f32x4 b = *reinterpret_cast<const f32x4*>(S0 + s * PSf + 16 * wave + 4 * q);
+#pragma unroll
+        for (int c = 0; c < TI; ++c) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[c][k], b[k], acc, 0, 0, 0);
+            *reinterpret_cast<f32x4*>(Z + (wave * AM_NS + s) * ZS + 16 * c + 4 * q) = acc;
+        }
+    }
+    am_barrier();
+    {   // sum over the k-blocks, bias, activation: zdot out, sigma'_3 kept
+        float z = bias3;
+#pragma unroll
+        for (int w = 0; w < AM_WAVES; ++w) z += Z[(w * AM_NS + es) * ZS + er];
+        float hh, dd1, dd2;
+        if (ALL_TANH) { hh = cnf_tanh(z); dd1 = fmaf(-hh, hh, 1.0f); }
+        else cnf_act2(nd.acts[2], z, hh, dd1, dd2);
+        const bool live = er < nd.dims[3];
+        lds[es * PD + m.o_off[2] + er] = live ? dd1 : 0.f;
+        if (live && b0 + es < a.B) du[(size_t)(b0 + es) * D + er] = hh;                    // zdot rows
+    }
+    am_barrier();
+
+    // ---- trace: pairs of samples, no workgroup barrier ----
+    // per-lane partials go to LDS as they are (the forward ping-pong buffers are free now); one reduction at the end
+    float* part = lds + tl.off_T0;                                   // [sample][512 lanes]
+#ifdef TR_STAMPS
+    const unsigned long long tc0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int o1 = m.o_off[0] + 4 * q, o2 = m.o_off[1] + 16 * wave + 4 * q, o3 = m.o_off[2] + s;
+    f32x4 d1a = *reinterpret_cast<const f32x4*>(lds + o1), d1b = *reinterpret_cast<const f32x4*>(lds + PD + o1);
+#ifdef TR_ABL_NOTRACE
+    for (int s0 = 0; s0 < 0; s0 += 2) {
+#else
+    for (int s0 = 0; s0 < AM_NS; s0 += 2) {
+#endif
+        const float* da = lds + s0 * PD;
+        const float* db = da + PD;
+        const float* dnext = lds + (s0 + 2 < AM_NS ? s0 + 2 : 0) * PD;      // the next pair's first k-block
+        f32x4 acc[2][TI];
+#pragma unroll
+        for (int c = 0; c < TI; ++c) { acc[0][c] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][c] = acc[0][c]; }
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const f32x4 xa = wa[u] * d1a, xb = wa[u] * d1b;           // rows of W2 diag(sigma'_1), this k-block
+            // sigma'_1 of the next k-block (of the next pair at the end) is requested before this block's MFMAs
+            if (u + 1 < KB) {
+                d1a = *reinterpret_cast<const f32x4*>(da + o1 + 16 * (u + 1));
+                d1b = *reinterpret_cast<const f32x4*>(db + o1 + 16 * (u + 1));
+            } else {
+                d1a = *reinterpret_cast<const f32x4*>(dnext + o1);
+                d1b = *reinterpret_cast<const f32x4*>(dnext + PD + o1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int c = 0; c < TI; ++c) {
+                    acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[k], wb[c][u][k], acc[0][c], 0, 0, 0);
+                    acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[k], wb[c][u][k], acc[1][c], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // acc[.][c][j] = X[16 wave + 4q + j][16c + s]
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float* dn = n ? db : da;
+            const f32x4 d2 = *reinterpret_cast<const f32x4*>(dn + o2);
+            float p = 0.f;
+#pragma unroll
+            for (int c = 0; c < TI; ++c) {
+                const f32x4 t = acc[n][c] * d2 * w3[c];
+                p = fmaf((t[0] + t[1]) + (t[2] + t[3]), dn[o3 + 16 * c], p);
+            }
+            part[(s0 + n) * AM_THREADS + tid] = p;
+        }
+    }
+#ifdef TR_STAMPS
+    {
+        const unsigned long long tc1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+        if ((blockIdx.x == 3 || blockIdx.x == 300) && lane == 0 && (wave == 0 || wave == 5))
+            printf("blk %d wave %d: prologue %llu forward %llu trace loop %llu cycles, %llu ticks of 100 MHz -> %.0f MHz\n", blockIdx.x, wave,
+                   tf - te, tc0 - tf, tc1 - tc0, tr1 - tr0, (double)(tc1 - tc0) / (double)(tr1 - tr0) * 100.0);
+    }
+#endif
+    am_barrier();
+    {   // 32 lanes per sample: 16 partials each, then a 5-step butterfly
+        const int smp = tid >> 5, j = tid & 31;
+        float tr = 0.f;
+#pragma unroll
+        for (int i = 0; i < AM_THREADS / 32; ++i) tr += part[smp * AM_THREADS + j + 32 * i];
+        for (int off = 16; off > 0; off >>= 1) tr += __shfl_xor(tr, off, 64);
+        if (j == 0 && b0 + smp < a.B) du[(size_t)(b0 + smp) * D + n_in] = -tr;      // src/icnf.jl:162
+    }
+}
+
+static bool trace3_shape(const NetDesc& nd, const AdjMfmaLayout& m) {
+    return nd.n_layers == 3 && m.nin_p == 32 && m.dp[0] == 32 && m.dp[1] == 128 && m.dp[2] == 128 && m.dp[3] == 32 &&
+           AM_WAVES == 8;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // TrainMode, JVP compute mode (src/icnf.jl:384-420) for networks whose weights + tangent images do not
 // fit the fused step kernel's LDS plan: (zdot, J eps) by one forward sweep in which the activations and
 // the tangents of the 16 samples are two column tiles sharing every weight fragment;
@@ -283,146 +518,6 @@ k_jvp_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, JvpLayout jl, const float
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// TrainMode, VJP compute mode (src/icnf.jl:318-350) as a stand-alone evaluation for networks whose weights
-// do not fit in LDS: there the fused step kernel streams the weights through 64 busy CUs at B = 2048,
-// while 16-sample workgroups give twice as many and share nothing but L2.  Forward sweep (sigma' kept),
-// then the reverse chain g_{l-1} = W_l' (g_l .* sigma'_l) from g_L = eps:  eJ = J' eps,
-//   ldot = -eJ' eps,  Edot = |zdot|,  ndot = |eJ|.
-// ---------------------------------------------------------------------------------------------------
-struct VjpLayout { int PD, PX, off_S, off_E, off_red, total_floats; };
-
-static VjpLayout vjp_layout(const NetDesc&, const AdjMfmaLayout& m) {
-    VjpLayout v{};
-    v.PD = pad8m16(m.sum_o);
-    v.PX = pad8m16(m.maxd);
-    v.off_S = AM_NS * v.PD;
-    v.off_E = v.off_S + 2 * AM_NS * v.PX;
-    v.off_red = v.off_E + AM_NS * (m.nin_p + 8);
-    v.total_floats = v.off_red + 3 * AM_EC * AM_NS;
-    return v;
-}
-
-bool vjp_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m) {
-    if (nd.jvp || nd.dims[nd.n_layers] != nd.n_in) return false;
-    return (size_t)vjp_layout(nd, m).total_floats * 4 <= 160 * 1024;
-}
-
-template <bool ALL_TANH>
-__global__ void __launch_bounds__(AM_THREADS)
-k_vjp_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, VjpLayout vl, const float* __restrict__ img, TraceArgs a,
-           const float* __restrict__ eps) {
-    if (a.st && a.st->done) return;
-    extern __shared__ float lds[];
-    const int NL = m.L, PD = vl.PD, PX = vl.PX, PE = m.nin_p + 8;
-    const int tid = threadIdx.x;
-    const int b0 = blockIdx.x * AM_NS;
-    const int n_in = nd.n_in, D = n_in + 3, in0 = gl.in0;
-    const int es = (tid >> 4) & 15, ec = (tid & 15) | ((tid >> 8) << 4);
-    const int eb = b0 + es;
-    const bool ev = eb < a.B;
-    float* du = a.du;
-    if (a.st && a.du_is_k7) du = (a.st->cur ? a.K1[0] : a.K1[1]);
-    float* red = lds + vl.off_red;
-
-    AFrag pf;
-    am_first(pf, img + m.f_off[0], m.dp[1], m.dp[0]);
-    int cur = vl.off_S, nxt = vl.off_S + AM_NS * PX;
-    for (int r = ec; r < m.dp[0]; r += AM_EC) {
-        float v = 0.f;
-        if (ev && r < in0) v = r < n_in ? a.u[(size_t)eb * D + r] : a.ys[(size_t)eb * nd.n_cond + (r - n_in)];
-        lds[cur + es * PX + r] = v;
-        if (r < m.nin_p) lds[vl.off_E + es * PE + r] = (ev && r < n_in) ? eps[(size_t)eb * n_in + r] : 0.f;
-    }
-    am_barrier();
-    // forward; the last layer's epilogue also forms g_L .* sigma'_L = eps .* sigma'_L, the first reverse operand
-    for (int l = 0; l < NL; ++l) {
-        const int out = nd.dims[l + 1], act = nd.acts[l], oo = m.o_off[l];
-        const bool last = l + 1 == NL;
-        am_gemm(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PX, pf,
-                img + (last ? m.r_off[NL - 1] : m.f_off[l + 1]), last ? m.dp[NL - 1] : m.dp[l + 2],
-                last ? m.dp[NL] : m.dp[l + 1], img + m.b_off[l], [&](int r0, int s, f32x4 acc, f32x4 bias) {
-            f32x4 h, d1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float hh, dd1, dd2;
-                if (ALL_TANH) { hh = cnf_tanh(acc[j] + bias[j]); dd1 = fmaf(-hh, hh, 1.0f); }
-                else cnf_act2(act, acc[j] + bias[j], hh, dd1, dd2);
-                const bool live = r0 + j < out;
-                h[j] = live ? hh : 0.f; d1[j] = live ? dd1 : 0.f;
-            }
-            if (!last) {
-                *reinterpret_cast<f32x4*>(lds + s * PD + oo + r0) = d1;
-                *reinterpret_cast<f32x4*>(lds + nxt + s * PX + r0) = h;
-            } else {
-                // zdot stays in the sigma'_L slot (its norm is needed below), eps .* sigma'_L is the operand
-                *reinterpret_cast<f32x4*>(lds + s * PD + oo + r0) = h;
-                *reinterpret_cast<f32x4*>(lds + nxt + s * PX + r0) =
-                    d1 * *reinterpret_cast<const f32x4*>(lds + vl.off_E + s * PE + r0);
-                if (b0 + s < a.B) {
-                    float* g = du + (size_t)(b0 + s) * D + r0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (r0 + j < out) g[j] = h[j];
-                }
-            }
-        });
-        am_barrier();
-        const int t_ = cur; cur = nxt; nxt = t_;
-    }
-    // reverse chain
-    for (int l = NL - 1; l >= 0; --l) {
-        const int oprev = l > 0 ? m.o_off[l - 1] : 0;
-        am_gemm(img + m.r_off[l], m.dp[l], m.dp[l + 1], lds + cur, PX, pf,
-                l > 0 ? img + m.r_off[l - 1] : nullptr, l > 0 ? m.dp[l - 1] : 0, l > 0 ? m.dp[l] : 0, nullptr,
-                [&](int r0, int s, f32x4 acc, f32x4) {
-            f32x4 v = acc;
-            if (l > 0) v = acc * *reinterpret_cast<const f32x4*>(lds + s * PD + oprev + r0);
-            *reinterpret_cast<f32x4*>(lds + nxt + s * PX + r0) = v;
-        });
-        am_barrier();
-        const int t_ = cur; cur = nxt; nxt = t_;
-    }
-    // eJ in S[cur] (rows < n_in), zdot in the sigma'_L slot
-    {
-        const int oL = m.o_off[NL - 1];
-        float e2 = 0.f, n2 = 0.f, dot = 0.f;
-        for (int r = ec; r < n_in; r += AM_EC) {
-            const float z = lds[es * PD + oL + r], ej = lds[cur + es * PX + r];
-            e2 = fmaf(z, z, e2); n2 = fmaf(ej, ej, n2); dot = fmaf(ej, lds[vl.off_E + es * PE + r], dot);
-        }
-        red[(0 * AM_EC + ec) * AM_NS + es] = e2;
-        red[(1 * AM_EC + ec) * AM_NS + es] = n2;
-        red[(2 * AM_EC + ec) * AM_NS + es] = dot;
-    }
-    am_barrier();
-    if (tid < AM_NS && b0 + tid < a.B) {
-        float e2 = 0.f, n2 = 0.f, dot = 0.f;
-        for (int p = 0; p < AM_EC; ++p) {
-            e2 += red[(0 * AM_EC + p) * AM_NS + tid]; n2 += red[(1 * AM_EC + p) * AM_NS + tid];
-            dot += red[(2 * AM_EC + p) * AM_NS + tid];
-        }
-        float* g = du + (size_t)(b0 + tid) * D + n_in;
-        g[0] = -dot;                                            // src/icnf.jl:334
-        g[1] = nd.norm_z ? sqrtf(e2) : 0.f;                     // :335-341
-        g[2] = nd.norm_j ? sqrtf(n2) : 0.f;                     // :342-348
-    }
-}
-
-hipError_t launch_vjp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
-                           const TraceArgs& a, const float* eps, hipStream_t s) {
-    const VjpLayout vl = vjp_layout(nd, m);
-    const size_t lds = (size_t)vl.total_floats * sizeof(float);
-    bool all_tanh = true;
-    for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
-    const void* fn = all_tanh ? (const void*)k_vjp_mfma<true> : (const void*)k_vjp_mfma<false>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    const dim3 grid((a.B + AM_NS - 1) / AM_NS), block(AM_THREADS);
-    if (all_tanh) hipLaunchKernelGGL(k_vjp_mfma<true>, grid, block, lds, s, nd, g, m, vl, img, a, eps);
-    else hipLaunchKernelGGL(k_vjp_mfma<false>, grid, block, lds, s, nd, g, m, vl, img, a, eps);
-    return hipGetLastError();
-}
-
 hipError_t launch_jvp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                            const TraceArgs& a, const float* eps, hipStream_t s) {
     const JvpLayout jl = jvp_layout(nd, m);
@@ -469,10 +564,25 @@ hipError_t launch_stage_state(const StepState* st, float* const U[2], float* con
 hipError_t launch_trace_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                              const TraceArgs& a, hipStream_t s) {
     const TraceLayout tl = trace_layout(nd, m);
-    const size_t lds = (size_t)tl.total_floats * sizeof(float);
+    const size_t lds_generic = (size_t)tl.total_floats * sizeof(float), lds = lds_generic;
     bool all_tanh = true;
     for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
     const dim3 grid((a.B + AM_NS - 1) / AM_NS), block(AM_THREADS);
+    static const bool generic_only = [] { const char* e = getenv("CNF_TRACE_GENERIC"); return e && e[0] == '1'; }();
+    if (trace3_shape(nd, m) && !generic_only) {          // resident-fragment kernel (A/B switch: CNF_TRACE_GENERIC=1)
+        // forward images + per-wave partials of the last layer; later the per-lane trace partials (same area)
+        const int PSf = pad8m16(m.maxd), fwd = 2 * AM_NS * PSf + AM_WAVES * AM_NS * (32 + 4) + 32 * (128 + 8),
+                  tr = AM_NS * AM_THREADS;
+        const size_t need = (size_t)(tl.off_T0 + (fwd > tr ? fwd : tr)) * sizeof(float);
+        const size_t lds = lds_generic > need ? lds_generic : need;
+        hipError_t e = hipFuncSetAttribute(all_tanh ? (const void*)k_trace3<true, 32, 128, 128>
+                                                    : (const void*)k_trace3<false, 32, 128, 128>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (all_tanh) hipLaunchKernelGGL((k_trace3<true, 32, 128, 128>), grid, block, lds, s, nd, g, m, tl, img, a);
+        else hipLaunchKernelGGL((k_trace3<false, 32, 128, 128>), grid, block, lds, s, nd, g, m, tl, img, a);
+        return hipGetLastError();
+    }
 #define TR_LAUNCH(T, N)                                                                                             \
     do {                                                                                                            \
         hipError_t e = hipFuncSetAttribute((const void*)k_trace_mfma<T, N>,                                         \

@@ -800,30 +800,32 @@ def test_loss_grad_config5_network():
         _assert_grad(grad, rgrad, f"config 5 {kernel}")
 
 
-def test_auto_uses_standalone_vjp_kernel_for_streamed_weights():
-    """kernel = auto on config 5's network (weights streamed from L2) at a batch below one wave of 16-sample
-    workgroups: TrainMode/VJP runs the stand-alone k_vjp_mfma (cnf_trace.hip) behind the generic driver;
-    an explicit kernel = mfma keeps the fused step kernel.  Both against the oracle."""
+def test_streamed_weights_run_the_fused_step_kernel_on_16_sample_tiles():
+    """Config 5's network (weights streamed from L2) at ragged batches that leave the last 16-sample workgroup
+    partly empty: kernel = auto and kernel = mfma are the same fused step kernel (one launch per step, 16-sample
+    tiles, fragment stream across sweeps), TrainMode/VJP and TestMode, RHS and a fixed-dt inference against the oracle."""
     cfg, _, _ = O.baseline_cfg(5)
-    B = 120
-    rng = np.random.default_rng(900)
-    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
-    u = rng.standard_normal((cfg.D(True), B)).astype(np.float32)
-    xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
-    eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
-    ref = cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True)(u.astype(np.float64))
-    _, ref_lp, _, _ = O.inference(cfg, flat.astype(np.float64), xs.astype(np.float64), eps.astype(np.float64), True,
-                                  dt=1 / 8, adaptive=False)
-    launches = {}
-    for kernel in ("auto", "mfma"):
-        ic = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=dict(adaptive=False, dt=1 / 8))
-        du = cnf.augmented_f(_dev(u), flat, 0.0, ic, cnf.TrainMode(), ic.nn, {}, _dev(eps)).cpu().numpy()
-        assert_parity(du, ref, f"cfg5 VJP RHS, kernel={kernel}", trace_row=cfg.n_in)
-        logpx, _ = cnf.inference(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
-        assert_parity(logpx.cpu().numpy(), ref_lp, f"cfg5 VJP logpx, kernel={kernel}")
-        assert ic.last_stats["kernel_used"] == _lib.KERNEL_MFMA
-        launches[kernel] = ic.last_stats["launches"]
-    assert launches["auto"] > 4 * launches["mfma"]          # one launch per stage instead of one per step
+    for B, seed in ((120, 900), (16, 901), (33, 902)):
+        rng = np.random.default_rng(seed)
+        flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+        xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+        eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+        for train in (True, False):
+            mode = cnf.TrainMode() if train else cnf.TestMode()
+            u = rng.standard_normal((cfg.D(train), B)).astype(np.float32)
+            ref = cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), train)(u.astype(np.float64))
+            _, ref_lp, _, _ = O.inference(cfg, flat.astype(np.float64), xs.astype(np.float64), eps.astype(np.float64),
+                                          train, dt=1 / 8, adaptive=False)
+            launches = {}
+            for kernel in ("auto", "mfma"):
+                ic = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=dict(adaptive=False, dt=1 / 8))
+                du = cnf.augmented_f(_dev(u), flat, 0.0, ic, mode, ic.nn, {}, _dev(eps)).cpu().numpy()
+                assert_parity(du, ref, f"cfg5 RHS B={B} train={train} kernel={kernel}", trace_row=cfg.n_in)
+                logpx, _ = cnf.inference(ic, mode, _dev(xs), flat, {}, eps=_dev(eps))
+                assert_parity(logpx.cpu().numpy(), ref_lp, f"cfg5 logpx B={B} train={train} kernel={kernel}")
+                assert ic.last_stats["kernel_used"] == _lib.KERNEL_MFMA
+                launches[kernel] = ic.last_stats["launches"]
+            assert launches["auto"] == launches["mfma"] <= 8 + 4, launches      # 8 steps: one launch each (+ k1, copy)
 
 
 def test_loss_grad_more_steps_than_the_trajectory_store():
