@@ -45,7 +45,6 @@ struct cnf_ctx {
     StepState* last_state = nullptr; // device slot holding the state at the end of the last solve
     StepState* d_state = nullptr;   // two slots: [0] canonical, [1] ping-pong partner of the fused MFMA path
     StepState* h_state = nullptr; // pinned, two slots for pipelined polling + one init slot
-    hipEvent_t ev[2] = {nullptr, nullptr};
     // streamed solve: the step kernel mirrors the state into pinned, host-coherent memory after every
     // controller run as tagged granules (cnf_mirror.h); the host polls them
     typedef CnfMirrorT<StepState> HostMirror;
@@ -191,8 +190,6 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     if (e == hipSuccess) e = hipHostMalloc(&h->h_mirror, sizeof(*h->h_mirror), hipHostMallocCoherent | hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_mirror, h->h_mirror, 0);
     if (e == hipSuccess) memset(h->h_mirror, 0, sizeof(*h->h_mirror));     // tag 0 is never a launch index (mirror_base starts at 1)
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[0], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev[1], hipEventDisableTiming);
     if (e != hipSuccess) {
         cnf_destroy(h);
         return CNF_ERR_HIP;
@@ -222,8 +219,6 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->d_sums) (void)hipFree(h->d_sums);
     if (h->h_sums) (void)hipHostFree(h->h_sums);
-    if (h->ev[0]) (void)hipEventDestroy(h->ev[0]);
-    if (h->ev[1]) (void)hipEventDestroy(h->ev[1]);
     delete h;
     return CNF_OK;
 }
@@ -376,7 +371,10 @@ static bool jvp_aux_ok(cnf_handle h) {
 }
 
 // one evaluation with an auxiliary MFMA kernel (TestMode: exact trace; TrainMode: JVP): u -> du (or k7)
-static cnf_status launch_trace(cnf_handle h, const float* u, float* du, bool in_solve, bool du_is_k7, int B, hipStream_t st) {
+// nk > 0 (inside a solve): the kernel forms the Runge-Kutta stage state from nk stage derivatives itself (and, for
+// stage 6, stores it as the new solution); otherwise it evaluates at `u`
+static cnf_status launch_trace(cnf_handle h, const float* u, float* du, bool in_solve, bool du_is_k7, int B, hipStream_t st,
+                               int nk = 0, const float* coef = nullptr, bool also_unew = false) {
     const GradLayout g = grad_layout(h->nd);
     const AdjMfmaLayout m = adj_mfma_layout(h->nd, g);
     TraceArgs a{};
@@ -385,6 +383,11 @@ static cnf_status launch_trace(cnf_handle h, const float* u, float* du, bool in_
     a.K1[0] = h->K1[0]; a.K1[1] = h->K1[1];
     a.du_is_k7 = du_is_k7 ? 1 : 0;
     a.B = B;
+    a.nk = in_solve ? nk : 0;
+    for (int i = 0; i < 2; ++i) a.U[i] = h->U[i];
+    for (int i = 0; i < 5; ++i) a.Ks[i] = h->Ks[i];
+    for (int i = 0; i < a.nk && i < 6; ++i) a.coef[i] = coef[i];
+    a.also_unew = also_unew ? 1 : 0;
     if (h->aux_train && h->nd.jvp) HIPCHK(h, launch_jvp_mfma(h->nd, g, m, h->d_adj_img, a, h->aux_eps, st));
     else HIPCHK(h, launch_trace_mfma(h->nd, g, m, h->d_adj_img, a, st));
     return CNF_OK;
@@ -487,18 +490,17 @@ extern "C" cnf_status cnf_rhs_host(cnf_handle h, int mode, int kernel, const flo
 // ---------------------------------------------------------------------------------------
 static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, int B,
                                     int nblk, hipStream_t s, bool with_controller = true,
-                                    float* dump = nullptr, size_t dump_stride = 0) {
+                                    float* dump = nullptr, size_t dump_stride = 0, void* mirror = nullptr,
+                                    unsigned seq = 0) {
     RhsArgs a{};
     a.st = h->d_state; a.B = B; a.S = h->cap_B; a.train = train; a.ws = h->ws; a.eps = eps;
     a.cond = h->mfma.cond; a.cbs = h->cbs;
     for (int i = 0; i < 2; ++i) { a.U[i] = h->U[i]; a.K1[i] = h->K1[i]; }
     for (int i = 0; i < 5; ++i) a.Ks[i] = h->Ks[i];
-    for (int stage = 1; stage <= 6 && h->trace_on; ++stage) {     // stage state, then the exact-trace kernel
+    for (int stage = 1; stage <= 6 && h->trace_on; ++stage) {     // the auxiliary kernel forms its stage state itself
         float coef[6];
         tsit5_row(stage, coef);
-        (void)launch_stage_state(h->d_state, h->U, h->K1, h->Ks, stage, coef, h->ws, stage == 6,
-                                 (size_t)rows_of(h, train) * B, s);
-        (void)launch_trace(h, h->ws, stage < 6 ? h->Ks[stage - 1] : nullptr, true, stage == 6, B, s);
+        (void)launch_trace(h, nullptr, stage < 6 ? h->Ks[stage - 1] : nullptr, true, stage == 6, B, s, stage, coef, stage == 6);
     }
     for (int stage = 1; stage <= 6 && !h->trace_on; ++stage) {      // computes k_{stage+1}
         a.nk = stage;
@@ -516,6 +518,7 @@ static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, i
     n.partials = h->partials;
     if (with_controller) {      // error norm + controller in one launch
         n.ticket = reinterpret_cast<unsigned*>(h->d_sums + 8); n.st_mut = h->d_state; n.ctrl_phase = 2; n.n_total = (float)n.n;
+        n.mirror = mirror; n.seq = seq;
     }
     launch_norm_partials(n, nblk, s);
 }
@@ -709,8 +712,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             if (s != CNF_OK) return fail(h, s, "MFMA RHS launch failed");
         } else if (h->trace_on) {
             const float one = 1.f;
-            HIPCHK(h, launch_stage_state(h->d_state, h->U, h->K1, h->Ks, 1, &one, h->ws, 0, n, st));
-            if ((s = launch_trace(h, h->ws, h->Ks[0], true, false, B, st)) != CNF_OK) return s;
+            if ((s = launch_trace(h, nullptr, h->Ks[0], true, false, B, st, 1, &one)) != CNF_OK) return s;
         } else {
             RhsArgs a{};
             a.st = h->d_state; a.B = B; a.S = h->cap_B; a.train = train; a.ws = h->ws; a.eps = eps;
@@ -734,14 +736,6 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     }
     HIPCHK(h, hipGetLastError());
 
-    // attempts, enqueued in chunks; the device-side controller decides accept/reject and
-    // the next dt, the host only polls `done` one chunk behind the GPU.
-    long expected = opts->maxiters;
-    if (!opts->adaptive) {
-        double ns = std::ceil(std::fabs((double)opts->t1 - (double)opts->t0) / (double)opts->dt - 1e-6);
-        expected = (long)ns;
-        if (expected < 1) expected = 1;
-    }
     StepState* cur_state = h->d_state;   // slot holding the live integrator state
     int pp = 0;                          // partials buffer the NEXT launch reads
     if (lockstep || (rec && !use_mfma)) {
@@ -816,29 +810,19 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         if (snap->nonfinite) return fail(h, CNF_ERR_NONFINITE, "solver state became NaN/Inf");
         return CNF_OK;
     }
-    // Attempts are queued in chunks, at most two chunks in flight.  After every chunk the state
-    // is copied to a pinned mirror; the host reads the mirrors one chunk behind the GPU and
-    // sizes the next chunk by the attempts still needed, (t1 - t)/dt, so that the queue
-    // neither drains (GPU idle) nor runs far past t1 (launches that exit at once).
-    const int chunk = opts->adaptive ? 8 : 64;
-    long enq = 0;                        // attempts enqueued so far
-    long est_left = opts->adaptive ? -1 : expected;   // attempts still to enqueue; -1 = unknown
-    struct Pend { int slot; long enq_at; } q[2];
-    int nq = 0;
-    bool slot_busy[2] = {false, false};
+    // Streamed solve: launches are kept a few attempts ahead of the last state the host has seen.  The controller of an
+    // attempt runs on the device -- inside the NEXT launch of the fused step kernel, or in the last block of the error-norm
+    // kernel on the per-stage paths -- and whoever ran it mirrors the new state to pinned host memory under the launch
+    // index; the host polls that index: no events, no copies, no stand-alone controller, no chunk boundaries.
+    // Launches queued past the end find `done` and exit at once.
     bool done = false;
     StepState fin{};
-    // Default for the fused step kernel: a stream of launches kept a few ahead of the last state the host has
-    // seen.  Launch i applies the controller of attempt i-1 and block 0 mirrors the new state to pinned host
-    // memory; the host polls the launch index behind it -- no events, no copy kernels, no stand-alone
-    // controller, no chunk boundaries.  Launches queued past the end find `done` and exit at once.
-    const char* ps_ = getenv("CNF_CHUNKED");
-    if (use_mfma && !done && (rec || !(ps_ && ps_[0] == '1'))) {
+    {
         const int AHEAD = 3;
         const volatile cnf_ctx::HostMirror* hm = h->h_mirror;
         const unsigned base = h->mirror_base;
-        long sent = 0, seen = 0;                    // launches enqueued; index of the newest mirror read
-        const long max_launches = (long)opts->maxiters + 1;
+        long sent = 0, seen = 0;       // launches (fused) / attempts (per-stage) enqueued; newest mirror index read
+        const long max_sent = (long)opts->maxiters + (use_mfma ? 1 : 0);   // fused: one more launch runs the last controller
         // gradient path: every attempt files u_n and its stage states in the slot of step `naccept`, indexed on
         // the device; the store is sized beforehand and the solve repeated if it took more steps than fit
         float* dump = nullptr; size_t slot = 0; int dcap = 0;
@@ -848,25 +832,34 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             dump = h->traj + n;                      // stage area of slot 0; u_n sits one array before
         }
         for (;;) {
-            while (sent < max_launches && sent - seen < AHEAD && !done) {
-                const bool apply = sent > 0;
-                StepState* st_next = cur_state == h->d_state ? h->d_state + 1 : h->d_state;
-                s = mfma_step(h->mfma, h->nd, train, cur_state, st_next, h->U, h->K1, h->Ks, eps,
-                              h->partials + 2 * MAX_PARTIALS * pp, h->partials + 2 * MAX_PARTIALS * (pp ^ 1), apply,
-                              false, B, st, dump, n, h->d_mirror, base + (unsigned)sent, slot, dcap, h->traj_hs);
-                if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
-                if (apply) cur_state = st_next;
-                pp ^= 1;
-                ++sent; ++launches;
+            while (sent < max_sent && sent - seen < AHEAD && !done) {
+                if (use_mfma) {
+                    // launch i applies the controller of attempt i-1 and publishes under index i
+                    const bool apply = sent > 0;
+                    StepState* st_next = cur_state == h->d_state ? h->d_state + 1 : h->d_state;
+                    s = mfma_step(h->mfma, h->nd, train, cur_state, st_next, h->U, h->K1, h->Ks, eps,
+                                  h->partials + 2 * MAX_PARTIALS * pp, h->partials + 2 * MAX_PARTIALS * (pp ^ 1), apply,
+                                  false, B, st, dump, n, h->d_mirror, base + (unsigned)sent, slot, dcap, h->traj_hs);
+                    if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
+                    if (apply) cur_state = st_next;
+                    pp ^= 1;
+                    ++launches;
+                } else {
+                    // attempt i ends with its own controller and publishes under index i + 1
+                    enqueue_attempt_generic(h, train, eps, B, nblk, st, true, nullptr, 0, h->d_mirror,
+                                            base + (unsigned)sent + 1);
+                    launches += 7;      // 6 stage evaluations + error norm with the controller
+                }
+                ++sent;
             }
-            h->mirror_base = base + (unsigned)sent;
+            h->mirror_base = base + (unsigned)sent + 1;
             if (done) break;
-            if (seen + 1 >= max_launches) {
+            if (seen >= (long)opts->maxiters) {
                 HIPCHK(h, hipStreamSynchronize(st));
                 return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
             }
-            // wait for a consistent snapshot newer than the last one read (launch 0 writes none: it has no controller
-            // to run).  The spin backs off: pause first, yield the core once the wait outlasts a few launches.
+            // wait for a consistent snapshot newer than the last one read.  The spin backs off: pause first, yield the
+            // core once the wait outlasts a few launches.
             unsigned sq = 0;
             StepState snap;
             for (long spins = 0;; ++spins) {
@@ -884,72 +877,6 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             seen = (long)(sq - base);
             if (snap.done) { fin = snap; done = true; }
         }
-    }
-    while (!done) {
-        bool can = nq < 2 && enq < (long)opts->maxiters && est_left != 0;
-        if (can) {
-            // t and dt are unknown until the first chunk's mirror arrives: meanwhile half a chunk goes in
-            // behind it on speculation (a solve shorter than 12 attempts pays a few 5 us early exits; all
-            // others no longer wait for the host between the first two chunks)
-            long todo = (est_left < 0 && nq > 0) ? chunk / 2 : chunk;
-            if (est_left > 0 && est_left < todo) todo = est_left;
-            if (enq + todo > (long)opts->maxiters) todo = (long)opts->maxiters - enq;
-            for (long i = 0; i < todo; ++i) {
-                if (use_mfma) {
-                    // fused path: the controller of attempt i-1 runs inside launch i; only the
-                    // last launch of a chunk is followed by the stand-alone controller
-                    const bool apply = i > 0, fin_ = i == todo - 1;
-                    StepState* st_next = cur_state == h->d_state ? h->d_state + 1 : h->d_state;
-                    s = mfma_step(h->mfma, h->nd, train, cur_state, st_next, h->U, h->K1, h->Ks, eps,
-                                  h->partials + 2 * MAX_PARTIALS * pp, h->partials + 2 * MAX_PARTIALS * (pp ^ 1),
-                                  apply, fin_, B, st);
-                    if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
-                    if (apply) cur_state = st_next;
-                    pp ^= 1;
-                    launches += fin_ ? 2 : 1;
-                } else {
-                    enqueue_attempt_generic(h, train, eps, B, nblk, st);
-                    launches += 8;
-                }
-            }
-            enq += todo;
-            if (est_left > 0) est_left -= todo;
-            const int slot = slot_busy[0] ? 1 : 0;
-            HIPCHK(h, hipMemcpyAsync(&h->h_state[slot], cur_state, sizeof(StepState), hipMemcpyDeviceToHost, st));
-            HIPCHK(h, hipEventRecord(h->ev[slot], st));
-            slot_busy[slot] = true;
-            q[nq].slot = slot; q[nq].enq_at = enq; ++nq;
-            if (nq < 2 && (est_left >= chunk || est_left < 0)) continue;   // far from t1 (or unknown): keep a second chunk in flight
-        }
-        if (nq == 0) {
-            HIPCHK(h, hipStreamSynchronize(st));
-            return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
-        }
-        // read the oldest pending mirror
-        const Pend pd = q[0];
-        q[0] = q[1]; --nq;
-        HIPCHK(h, hipEventSynchronize(h->ev[pd.slot]));
-        slot_busy[pd.slot] = false;
-        fin = h->h_state[pd.slot];
-        done = fin.done != 0;
-        if (!done) {
-            long need = 1;
-            if (fin.dt > 0.f) need = (long)std::ceil(std::fabs((double)fin.t1 - (double)fin.t) / (double)fin.dt);
-            if (need < 1) need = 1;
-            est_left = need - (enq - pd.enq_at);           // minus what is already queued behind this snapshot
-            if (est_left < 0) est_left = 0;
-            if (est_left == 0 && nq == 0) est_left = 1;    // the estimate fell short: one more
-            if (enq >= (long)opts->maxiters && nq == 0) {
-                HIPCHK(h, hipStreamSynchronize(st));
-                return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
-            }
-        }
-    }
-    // drain chunks still in flight (their launches exit at once: the state says done)
-    while (nq > 0) {
-        HIPCHK(h, hipEventSynchronize(h->ev[q[0].slot]));
-        fin = h->h_state[q[0].slot];
-        q[0] = q[1]; --nq;
     }
     h->last_state = cur_state;
     if (rec) {            // streamed recording: step sizes back from the device

@@ -39,6 +39,21 @@ struct StepState {
     int n_partials;         // entries of the error-partials array
 };
 
+#ifdef __HIPCC__
+// Integrator state -> pinned host mirror: one 8-byte system-scope store per state word, {tag = launch index, word}
+// (protocol and reader: cnf_mirror.h).  No wait, no fence: the reader validates the tags, and a release fence would
+// write back this XCD's whole L2 on every launch.
+__device__ __forceinline__ void mirror_store(void* mirror, unsigned seq, const StepState& z) {
+    if (!mirror) return;
+    static_assert(sizeof(StepState) % 4 == 0, "copied as 32-bit words");
+    const unsigned* src = reinterpret_cast<const unsigned*>(&z);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(mirror);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(StepState) / 4); ++i)
+        __hip_atomic_store(dst + i, ((unsigned long long)seq << 32) | src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+
 // Tsit5 (Tsitouras 2011); same digits as oracle/cnf_oracle.py.
 #define TS_A21 0.161f
 #define TS_A31 -0.008480655492356989f

@@ -330,7 +330,11 @@ k_norm_partials(NormArgs a) {
         if (last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (!last || st->done) return;
+    if (!last) return;
+    if (st->done) {                       // queued past the end: keep the host's view current
+        if (threadIdx.x == 0) mirror_store(a.mirror, a.seq, *st);
+        return;
+    }
     float q0 = 0.f, q1 = 0.f;
     for (int i = threadIdx.x; i < st->n_partials; i += blockDim.x) {
         q0 += __hip_atomic_load(a.partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -338,7 +342,10 @@ k_norm_partials(NormArgs a) {
     }
     q0 = block_sum(q0, sm);
     q1 = block_sum(q1, sm);
-    if (threadIdx.x == 0) ctrl_phase(a.st_mut, a.ctrl_phase, q0, q1, a.n_total);
+    if (threadIdx.x == 0) {
+        ctrl_phase(a.st_mut, a.ctrl_phase, q0, q1, a.n_total);
+        mirror_store(a.mirror, a.seq, *a.st_mut);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

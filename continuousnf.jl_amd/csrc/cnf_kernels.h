@@ -38,6 +38,8 @@ struct NormArgs {
     StepState* st_mut;
     int ctrl_phase;
     float n_total;
+    void* mirror;           // pinned host mirror of the state (streamed solve) or null; written after the controller
+    unsigned seq;           //   with this tag
 };
 
 void launch_rhs_generic(const NetDesc& nd, const float* P, const RhsArgs& a, hipStream_t s);

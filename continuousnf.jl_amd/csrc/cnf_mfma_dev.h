@@ -125,14 +125,4 @@ __device__ __forceinline__ void err_acc(float& errsum, float& badcnt, const f32x
     }
 }
 
-__device__ __forceinline__ void publish_mirror(const MfmaArgs& a, const StepState& z) {
-    if (!a.mirror) return;
-    // one 8-byte system-scope store per state word: {tag = this launch's index, word} (protocol: cnf_mirror.h).  No wait,
-    // no fence: the reader validates the tags, and a release fence would write back this XCD's whole L2 on every launch.
-    static_assert(sizeof(StepState) % 4 == 0, "copied as 32-bit words");
-    const unsigned* src = reinterpret_cast<const unsigned*>(&z);
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.mirror);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(StepState) / 4); ++i)
-        __hip_atomic_store(dst + i, ((unsigned long long)a.seq << 32) | src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+__device__ __forceinline__ void publish_mirror(const MfmaArgs& a, const StepState& z) { mirror_store(a.mirror, a.seq, z); }

@@ -11,6 +11,14 @@ struct TraceArgs {
     float* K1[2];           // solver, stage 7: du goes to K1[1 - st->cur]
     int du_is_k7;
     int B;
+    // Runge-Kutta stage state formed by the kernel itself (nk > 0; `u` is ignored then):
+    //   u = U[cur] + h * sum_j coef[j] k_{j+1},   k_1 = K1[cur], k_2.. = Ks[0..],   h and cur from the device state;
+    // also_unew: the stage state is the new solution (stage 6) and is stored to U[1 - cur], all D rows
+    float* U[2];
+    const float* Ks[5];
+    int nk;
+    float coef[6];
+    int also_unew;
 };
 
 struct TraceLayout {
@@ -29,6 +37,3 @@ hipError_t launch_trace_mfma(const NetDesc& nd, const GradLayout& g, const AdjMf
 bool jvp_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
 hipError_t launch_jvp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                            const TraceArgs& a, const float* eps, hipStream_t s);
-// u_stage = U[cur] + h * sum_j coef[j] k_j (k_1 = K1[cur], k_{j>1} = Ks[j-2]), h and cur from the device state
-hipError_t launch_stage_state(const StepState* st, float* const U[2], float* const K1[2], float* const Ks[5], int nk,
-                              const float* coef, float* out, int also_unew, size_t n, hipStream_t s);

@@ -14,6 +14,24 @@
 
 #define TR_NCMAX 8
 
+// entry `idx` of the state the evaluation runs at: given (plain evaluation) or formed from the Runge-Kutta stages.
+// Explicit selects: run-time indexing of kernel-argument arrays would go through memory.
+__device__ __forceinline__ float trace_in(const TraceArgs& a, int cur, float hstep, size_t idx) {
+    if (a.nk == 0) return a.u[idx];
+    float acc = a.coef[0] * (cur ? a.K1[1] : a.K1[0])[idx];
+    if (a.nk > 1) acc = fmaf(a.coef[1], a.Ks[0][idx], acc);
+    if (a.nk > 2) acc = fmaf(a.coef[2], a.Ks[1][idx], acc);
+    if (a.nk > 3) acc = fmaf(a.coef[3], a.Ks[2][idx], acc);
+    if (a.nk > 4) acc = fmaf(a.coef[4], a.Ks[3][idx], acc);
+    if (a.nk > 5) acc = fmaf(a.coef[5], a.Ks[4][idx], acc);
+    return fmaf(hstep, acc, (cur ? a.U[1] : a.U[0])[idx]);
+}
+// stage 6: rows n_in .. D-1 of the new solution (the network never reads them); one thread per sample
+__device__ __forceinline__ void trace_unew_tail(const TraceArgs& a, int cur, float hstep, int b, int n_in, int D) {
+    float* un = cur ? a.U[0] : a.U[1];
+    for (int r = n_in; r < D; ++r) un[(size_t)b * D + r] = trace_in(a, cur, hstep, (size_t)b * D + r);
+}
+
 static inline int pad8m16(int x) { return ((x + 15) & ~15) + 8; }
 __device__ __forceinline__ int pad8m16_dev(int x) { return ((x + 15) & ~15) + 8; }
 
@@ -60,6 +78,8 @@ __global__ void __launch_bounds__(AM_THREADS)
 k_trace_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const float* __restrict__ img, TraceArgs a) {
     if (a.st && a.st->done) return;
     extern __shared__ float lds[];
+    const int st_cur = a.st ? a.st->cur : 0;
+    const float st_h = a.st ? a.st->h : 0.f;
     const int NL = m.L, PD = tl.PD, PT = tl.PT;
     const int PSf = pad8m16_dev(m.maxd);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -77,9 +97,13 @@ k_trace_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const f
     int cur = tl.off_T0, nxt = tl.off_T0 + AM_NS * PSf;
     for (int r = ec; r < m.dp[0]; r += AM_EC) {
         float v = 0.f;
-        if (ev && r < in0) v = r < n_in ? a.u[(size_t)eb * D + r] : a.ys[(size_t)eb * nd.n_cond + (r - n_in)];
+        if (ev && r < in0) {
+            v = r < n_in ? trace_in(a, st_cur, st_h, (size_t)eb * D + r) : a.ys[(size_t)eb * nd.n_cond + (r - n_in)];
+            if (a.also_unew && r < n_in) (st_cur ? a.U[0] : a.U[1])[(size_t)eb * D + r] = v;
+        }
         lds[cur + es * PSf + r] = v;
     }
+    if (a.also_unew && ev && ec == 0) trace_unew_tail(a, st_cur, st_h, eb, n_in, D);
     am_barrier();
 
     // ---- forward: zdot out, sigma' of every layer kept ------------------------------------------------
@@ -199,6 +223,7 @@ k_trace3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const float
     // request of the prologue (state words, the 16 samples, the resident fragments) is in flight before `done` is tested
     const StepState* stp = a.st ? a.st : reinterpret_cast<const StepState*>(img);
     const int st_done = stp->done, st_cur = stp->cur;
+    const float st_h = stp->h;
     constexpr int TI = NIP / 16, KB = H1 / 16, K0 = NIP / 16;
     static_assert(H2 / 16 == AM_WAVES && H1 / 16 == AM_WAVES, "one row tile of W1 and of W2 per wave");
 #ifdef TR_STAMPS
@@ -216,7 +241,8 @@ k_trace3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const float
     const int es = tid >> 5, er = tid & 31;                            // (sample, input row): NIP == 32 rows
     float xin = 0.f;
     if (b0 + es < a.B && er < in0)
-        xin = er < n_in ? a.u[(size_t)(b0 + es) * D + er] : a.ys[(size_t)(b0 + es) * nd.n_cond + (er - n_in)];
+        xin = er < n_in ? trace_in(a, st_cur, st_h, (size_t)(b0 + es) * D + er)
+                        : a.ys[(size_t)(b0 + es) * nd.n_cond + (er - n_in)];
     // resident fragments: W1 row tile (forward), W2 row tile (forward AND trace), all of W1^T (trace), the W3 slice
     // (trace epilogue AND this wave's k-block of the last forward layer)
     f32x4 w1a[K0], wa[KB], wb[TI][KB], w3[TI], bias1, bias2;
@@ -251,6 +277,10 @@ k_trace3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const float
     constexpr int ZS = NIP + 4;
     float* WT = Z + AM_WAVES * AM_NS * ZS;          // staging image of W1^T [i][k], stride WTS (never aliased)
     if (a.st && st_done) return;
+    if (a.also_unew && b0 + es < a.B) {              // stage 6: the state this evaluation runs at is the new solution
+        if (er < n_in) (st_cur ? a.U[0] : a.U[1])[(size_t)(b0 + es) * D + er] = xin;
+        if (er == 0) trace_unew_tail(a, st_cur, st_h, b0 + es, n_in, D);
+    }
 #pragma unroll
     for (int j = 0; j < WT_PER; ++j) {
         const int idx = tid + AM_THREADS * j, row = idx / (H1 / 4), c4 = idx % (H1 / 4);
@@ -444,6 +474,8 @@ k_jvp_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, JvpLayout jl, const float
            const float* __restrict__ eps) {
     if (a.st && a.st->done) return;
     extern __shared__ float lds[];
+    const int st_cur = a.st ? a.st->cur : 0;
+    const float st_h = a.st ? a.st->h : 0.f;
     const int NL = m.L, PX = jl.PX, PE = m.nin_p + 8;
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * AM_NS;
@@ -460,12 +492,16 @@ k_jvp_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, JvpLayout jl, const float
     int cur = 0, nxt = 32 * PX;
     for (int r = ec; r < m.dp[0]; r += AM_EC) {
         float v = 0.f, e = 0.f;
-        if (ev && r < in0) v = r < n_in ? a.u[(size_t)eb * D + r] : a.ys[(size_t)eb * nd.n_cond + (r - n_in)];
+        if (ev && r < in0) {
+            v = r < n_in ? trace_in(a, st_cur, st_h, (size_t)eb * D + r) : a.ys[(size_t)eb * nd.n_cond + (r - n_in)];
+            if (a.also_unew && r < n_in) (st_cur ? a.U[0] : a.U[1])[(size_t)eb * D + r] = v;
+        }
         if (ev && r < n_in) e = eps[(size_t)eb * n_in + r];
         lds[cur + es * PX + r] = v;                       // h_0 = [z; ys]
         lds[cur + (16 + es) * PX + r] = e;                // t_0 = [eps; 0]
         if (r < m.nin_p) lds[jl.off_E + es * PE + r] = e;
     }
+    if (a.also_unew && ev && ec == 0) trace_unew_tail(a, st_cur, st_h, eb, n_in, D);
     am_barrier();
     for (int l = 0; l < NL; ++l) {
         const int out = nd.dims[l + 1], act = nd.acts[l];
@@ -530,34 +566,6 @@ hipError_t launch_jvp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfma
     const dim3 grid((a.B + AM_NS - 1) / AM_NS), block(AM_THREADS);
     if (all_tanh) hipLaunchKernelGGL(k_jvp_mfma<true>, grid, block, lds, s, nd, g, m, jl, img, a, eps);
     else hipLaunchKernelGGL(k_jvp_mfma<false>, grid, block, lds, s, nd, g, m, jl, img, a, eps);
-    return hipGetLastError();
-}
-
-// u_stage = U[cur] + h * sum_j coef[j] k_j
-__global__ void k_stage_state(const StepState* st, float* U0, float* U1, float* K10, float* K11, float* Ks0, float* Ks1,
-                              float* Ks2, float* Ks3, float* Ks4, int nk, float c0, float c1, float c2, float c3, float c4,
-                              float c5, float* __restrict__ out, int also_unew, size_t n) {
-    if (st->done) return;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int cur = st->cur;
-    const float* u = cur ? U1 : U0;
-    const float* k1 = cur ? K11 : K10;
-    const float* ks[5] = {Ks0, Ks1, Ks2, Ks3, Ks4};
-    const float cf[6] = {c0, c1, c2, c3, c4, c5};
-    float acc = nk > 0 ? cf[0] * k1[i] : 0.f;
-    for (int j = 1; j < nk; ++j) acc = fmaf(cf[j], ks[j - 1][i], acc);
-    const float v = fmaf(st->h, acc, u[i]);
-    out[i] = v;
-    if (also_unew) (cur ? U0 : U1)[i] = v;
-}
-
-hipError_t launch_stage_state(const StepState* st, float* const U[2], float* const K1[2], float* const Ks[5], int nk,
-                              const float* coef, float* out, int also_unew, size_t n, hipStream_t s) {
-    float c[6] = {0, 0, 0, 0, 0, 0};
-    for (int j = 0; j < nk && j < 6; ++j) c[j] = coef[j];
-    hipLaunchKernelGGL(k_stage_state, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, U[0], U[1], K1[0], K1[1],
-                       Ks[0], Ks[1], Ks[2], Ks[3], Ks[4], nk, c[0], c[1], c[2], c[3], c[4], c[5], out, also_unew, n);
     return hipGetLastError();
 }
 
