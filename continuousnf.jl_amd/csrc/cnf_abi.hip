@@ -1174,6 +1174,7 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
             a.lam = h->g_lam;
             a.nw = 0;
             for (int m = i + 1; m < 6; ++m) { a.w[a.nw] = h->g_W[m]; a.wc[a.nw] = A[m][i]; ++a.nw; }
+            for (int k = a.nw; k < 5; ++k) { a.w[k] = h->g_lam; a.wc[k] = 0.f; }     // unused slots: a readable array, weight 0
             a.cb = Bw[i]; a.hstep = hs;
             a.c_l = hs * Bw[i] * lam_l; a.c_E = hs * Bw[i] * lam_E; a.c_n = hs * Bw[i] * lam_n;
             a.w_out = h->g_W[i];

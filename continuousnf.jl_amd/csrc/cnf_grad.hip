@@ -930,6 +930,403 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same pullback for the headline shape 32-128-128-32 (BASELINE configs 3/4): 32 samples per workgroup (two
+// MFMA column tiles that share every A fragment) and every weight fragment resident in registers for all six
+// stages of the launch -- wave w keeps its 16-row tile of W1, W2, W3^T and W2^T, waves 0..3 also a 16-row tile of
+// W3 and W1^T (out tile w & 1, column tile w >> 1: the 32-row sweeps run on one wave per SIMD).  A sweep is then
+// B operand from LDS -> MFMAs -> epilogue -> LDS with no weight traffic at all; k_adj_mfma re-streams 200 KB of
+// fragments from L2 per stage and 16 samples, and waits for them in each of its 12 sweeps.  Epilogues, LDS rows
+// and factor arrays are those of k_adj_mfma.
+// ---------------------------------------------------------------------------------------------------
+#define A3_NS 32
+// two column tiles against one A tile; B operands run two k-blocks ahead of the MFMAs (ring of 3)
+template <int KB>
+__device__ __forceinline__ void adj3_tile2(const f32x4 (&A)[KB], const float* X, int PS, int s, int q, const f32x4& init,
+                                           f32x4& out0, f32x4& out1) {
+    const float* x0 = X + s * PS + 4 * q;
+    const float* x1 = x0 + 16 * PS;
+    f32x4 b0[2], b1[2];                    // B operands one k-block (8 MFMAs) ahead
+    b0[0] = *reinterpret_cast<const f32x4*>(x0);
+    b1[0] = *reinterpret_cast<const f32x4*>(x1);
+    f32x4 a00 = init, a10 = init, a01 = {0.f, 0.f, 0.f, 0.f}, a11 = a01;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+        if (u + 1 < KB) {
+            b0[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(x0 + 16 * (u + 1));
+            b1[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(x1 + 16 * (u + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (u & 1) {
+                a01 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][k], b0[u & 1][k], a01, 0, 0, 0);
+                a11 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][k], b1[u & 1][k], a11, 0, 0, 0);
+            } else {
+                a00 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][k], b0[u & 1][k], a00, 0, 0, 0);
+                a10 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][k], b1[u & 1][k], a10, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    out0 = a00 + a01; out1 = a10 + a11;
+}
+// one column tile (rows of X start at the tile's first sample)
+template <int KB>
+__device__ __forceinline__ f32x4 adj3_tile1(const f32x4 (&A)[KB], const float* X, int PS, int s, int q, const f32x4& init) {
+    const float* x0 = X + s * PS + 4 * q;
+    f32x4 b[3];
+#pragma unroll
+    for (int u = 0; u < 2 && u < KB; ++u) b[u] = *reinterpret_cast<const f32x4*>(x0 + 16 * u);
+    f32x4 a0 = init, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {       // two chains, alternating: a dependent MFMA would wait for its predecessor
+            if (k & 1) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][k], b[u % 3][k], a1, 0, 0, 0);
+            else a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][k], b[u % 3][k], a0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 2 < KB) b[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(x0 + 16 * (u + 2));
+    }
+    return a0 + a1;
+}
+// Stage inputs of one (sample, row) element, RAW (nothing is combined here, so nothing waits for the loads): state row
+// (or conditioning input), eps, lambda and the zbar of the four oldest later stages.  Unused a.w[] slots point at
+// lambda with coefficient 0 (cnf_abi.hip), so every request is unconditional and its pointer a scalar load.
+struct Adj3In { float x, e, lam, w[4]; };
+__device__ __forceinline__ void adj3_fetch(const AdjArgs& a, const NetDesc& nd, int eb, bool ev, int r, int n_in, int in0,
+                                           int D, Adj3In& o) {
+    o.x = 0.f; o.e = 0.f; o.lam = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) o.w[w] = 0.f;
+    // both base pointers as scalars first: a per-lane choice between two pointer FIELDS makes the compiler fetch the
+    // chosen field with a vector load and wait for it (and for every request in front of it)
+    const float* pu = a.ustage;
+    const float* py = a.ys ? a.ys : a.ustage;
+    asm volatile("" ::"s"(pu), "s"(py));
+    if (ev && r < in0) o.x = *(r < n_in ? pu + (size_t)eb * D + r : py + (size_t)eb * nd.n_cond + (r - n_in));
+    if (ev && r < n_in) {
+        const size_t ix = (size_t)eb * n_in + r;
+        o.e = a.eps[ix];
+        o.lam = a.lam[ix];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o.w[w] = a.w[w + 1][ix];
+    }
+}
+
+static size_t adj3_lds_bytes(const AdjMfmaLayout& m) { return ((size_t)A3_NS * m.PS + (size_t)AM_EC * A3_NS) * sizeof(float); }
+
+template <bool ALL_TANH>
+__global__ void __launch_bounds__(AM_THREADS)
+k_adj3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, AdjStepArgs S) {
+    extern __shared__ float lds[];
+    constexpr int NL = 3, H = 128, NI = 32;               // dp = {32, 128, 128, 32}
+    static_assert(AM_WAVES == 8, "one 16-row tile of the 128-wide layers per wave");
+    const int PS = m.PS;
+    float* red = lds + (size_t)A3_NS * PS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    const int b0 = blockIdx.x * A3_NS;
+    const int n_in = nd.n_in, D = n_in + 3, in0 = gl.in0;
+    const int es = (tid >> 4) & 15, ec = (tid & 15) | ((tid >> 8) << 4);
+    const int oL = m.o_off[NL - 1];
+    const bool narrow = wave < 4;                          // 32-row sweeps: out tile nt, column tile nc, one wave per SIMD
+    const int nt = wave & 1, nc = (wave >> 1) & 1;
+
+    // resident fragments: A operand (rows 16 tile + s, k = 16u + 4q ..) of each image
+    // (the two tiles of the 32-row sweeps, W3 and W1^T, share ONE register buffer `na`: each is fetched from L2 a whole
+    // sweep before its use -- keeping both resident as well would spill)
+    f32x4 f1[NI / 16], f2[H / 16], r3[NI / 16], r2[H / 16], na[H / 16], bias1, bias2, bias3;
+    const float* F3 = img + m.f_off[2] + (size_t)(16 * nt + s) * H + 4 * q;             // W3   [32][128]
+    const float* R1 = img + m.r_off[0] + (size_t)(16 * nt + s) * H + 4 * q;             // W1^T [32][128]
+    auto fetch_na = [&](const float* base) {
+        if (narrow) {
+#pragma unroll
+            for (int u = 0; u < H / 16; ++u) na[u] = *reinterpret_cast<const f32x4*>(base + 16 * u);
+        }
+    };
+    {
+        const float* F1 = img + m.f_off[0] + (size_t)(16 * wave + s) * NI + 4 * q;      // W1   [128][32]
+        const float* F2 = img + m.f_off[1] + (size_t)(16 * wave + s) * H + 4 * q;       // W2   [128][128]
+        const float* R3 = img + m.r_off[2] + (size_t)(16 * wave + s) * NI + 4 * q;      // W3^T [128][32]
+        const float* R2 = img + m.r_off[1] + (size_t)(16 * wave + s) * H + 4 * q;       // W2^T [128][128]
+#pragma unroll
+        for (int u = 0; u < NI / 16; ++u) { f1[u] = *reinterpret_cast<const f32x4*>(F1 + 16 * u); r3[u] = *reinterpret_cast<const f32x4*>(R3 + 16 * u); }
+#pragma unroll
+        for (int u = 0; u < H / 16; ++u) {
+            f2[u] = *reinterpret_cast<const f32x4*>(F2 + 16 * u); r2[u] = *reinterpret_cast<const f32x4*>(R2 + 16 * u);
+        }
+        bias1 = *reinterpret_cast<const f32x4*>(img + m.b_off[0] + 16 * wave + 4 * q);
+        bias2 = *reinterpret_cast<const f32x4*>(img + m.b_off[1] + 16 * wave + 4 * q);
+        bias3 = *reinterpret_cast<const f32x4*>(img + m.b_off[2] + 16 * nt + 4 * q);
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int r0w = 16 * wave + 4 * q, r0n = 16 * nt + 4 * q;       // first row of this lane in a wide / narrow tile
+
+    Adj3In pf[2];                                         // inputs of the coming stage (see below)
+
+  for (int stg = S.first; stg >= S.last; --stg) {      // the stages of one Runge-Kutta step, last to first
+    // opaque zero: keeps the compiler from hoisting the per-sample global addresses of all six array families out of
+    // the stage loop into 64-bit register pairs (they pushed the kernel into scratch)
+    int zopq = 0;
+    asm volatile("" : "+v"(zopq));
+    const int b0v = b0 + zopq;
+    const AdjArgs& a = S.st[stg];
+    AM_STAMP(14 + (stg == S.last ? 0 : 1));
+    // the argument block of the NEXT stage is pulled into the scalar cache together with this stage's (one miss per
+    // stage instead of two: the prefetch below would otherwise stall on it in the middle of the stage)
+    {
+        const AdjArgs& an = S.st[stg > S.last ? stg - 1 : stg];
+        const int t0 = __float_as_int(an.cb), t1 = an.nw, t2 = an.B;
+        const float* t3 = an.ustage;
+        const float* t4 = an.w[2];
+        asm volatile("" ::"s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4));
+    }
+    // ---- inputs: [z; ys; 0] -> S0, eps -> E; h_0 also goes out for the weight gradient ---------
+    // Everything a stage reads from global memory except the zbar of the stage just finished (a.w[0]) is known a
+    // stage ahead: it is fetched during the previous stage (`pf_*`, filled after its second sweep), so that only one
+    // request stands between the end-of-stage barrier and the first sweep.  The thread's element: row ec of samples
+    // es and es + 16.
+    static_assert(AM_EC == NI, "one row of the 32 per thread in the elementwise passes");
+    float kbv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+        const int e2 = es + 16 * hs, eb = b0v + e2;
+        const bool ev = eb < S.B;
+        if (stg == S.first) adj3_fetch(a, nd, eb, ev, ec, n_in, in0, D, pf[hs]);
+        if (ev && ec < n_in) {
+            float kb = a.cb * pf[hs].lam;
+            kb = fmaf(a.wc[0], a.w[0][(size_t)eb * n_in + ec], kb);       // the stage just finished
+#pragma unroll
+            for (int w = 0; w < 4; ++w) kb = fmaf(a.wc[w + 1], pf[hs].w[w], kb);
+            kbv[hs] = kb * a.hstep;
+        }
+        lds[e2 * PS + m.S0 + ec] = pf[hs].x;
+        if (ev && ec < in0) a.HS[(size_t)eb * gl.sum_in + ec] = pf[hs].x;
+        lds[e2 * PS + m.E + ec] = pf[hs].e;
+    }
+    am_barrier();
+    AM_STAMP(0);
+
+    int cur = m.S0, nxt = m.S1;
+    // ---- sweep 1: forward (h, sigma', sigma''); the last layer also forms pbar_L = eps .* sigma'_L ----
+    auto fwd_epi = [&](int l, int r0, int ct, const f32x4& x) {
+        float* Sw = lds + (16 * ct + s) * PS;
+        const size_t gb = (size_t)(b0v + 16 * ct + s);
+        const bool sv = b0v + 16 * ct + s < a.B;
+        const int out = nd.dims[l + 1], act = nd.acts[l], oo = m.o_off[l];
+        const bool last = l + 1 == NL;
+        f32x4 h, d1, d2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float hh, dd1, dd2;
+            if (ALL_TANH) { hh = tanh_fast(x[j]); dd1 = fmaf(-hh, hh, 1.0f); dd2 = -2.0f * hh * dd1; }   // as the step kernels
+            else cnf_act2(act, x[j], hh, dd1, dd2);
+            const bool live = r0 + j < out;            // padded rows stay exactly zero
+            h[j] = live ? hh : 0.f; d1[j] = live ? dd1 : 0.f; d2[j] = live ? dd2 : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(Sw + nxt + r0) = h;
+        *reinterpret_cast<f32x4*>(Sw + m.D1 + oo + r0) = d1;
+        *reinterpret_cast<f32x4*>(Sw + m.D2 + oo + r0) = d2;
+        if (!last) {
+            if (sv) am_store4(a.HS + gb * gl.sum_in + gl.in_off[l + 1] + r0, h, r0, out, m.vec4);
+        } else {
+            const f32x4 pb = *reinterpret_cast<const f32x4*>(Sw + m.E + r0) * d1;      // out_L == n_in
+            *reinterpret_cast<f32x4*>(Sw + m.TB + oL + r0) = pb;
+            if (sv) am_store4(a.PB + gb * gl.sum_out + gl.out_off[l] + r0, pb, r0, out, m.vec4o);
+            // |zdot|^2 of this lane's 4 rows: one of the sample's 8 partials (2 tiles x 4 row groups)
+            red[(16 * ct + s) * 8 + 4 * nt + q] = (h[0] * h[0] + h[1] * h[1]) + (h[2] * h[2] + h[3] * h[3]);
+        }
+    };
+    f32x4 o0, o1;
+    adj3_tile2(f1, lds + cur, PS, s, q, bias1, o0, o1);
+    fwd_epi(0, r0w, 0, o0); fwd_epi(0, r0w, 1, o1);
+    am_barrier();
+    AM_STAMP(1);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+    fetch_na(F3);
+    adj3_tile2(f2, lds + cur, PS, s, q, bias2, o0, o1);
+    fwd_epi(1, r0w, 0, o0); fwd_epi(1, r0w, 1, o1);
+    am_barrier();
+    AM_STAMP(2);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+    if (narrow) fwd_epi(2, r0n, nc, adj3_tile1(na, lds + cur + 16 * nc * PS, PS, s, q, bias3));
+    am_barrier();
+    AM_STAMP(3);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+    const int zd = cur;                                     // zdot stays in S[zd] until AH is formed (inside sweep 2)
+
+    // ---- sweep 2: tbar chain (omega = eps): layer l's product turns pbar_l into tbar_{l-1} ----
+    auto tb_epi = [&](int l, int r0, int ct, const f32x4& acc) {      // l = the layer whose transposed image was applied
+        float* Sw = lds + (16 * ct + s) * PS;
+        if (l > 0) {
+            const int oprev = m.o_off[l - 1];
+            *reinterpret_cast<f32x4*>(Sw + m.TB + oprev + r0) = acc;
+            const f32x4 pb = acc * *reinterpret_cast<const f32x4*>(Sw + m.D1 + oprev + r0);
+            *reinterpret_cast<f32x4*>(Sw + nxt + r0) = pb;
+            if (b0v + 16 * ct + s < a.B)
+                am_store4(a.PB + (size_t)(b0v + 16 * ct + s) * gl.sum_out + gl.out_off[l - 1] + r0, pb, r0, nd.dims[l], m.vec4o);
+        } else {
+            *reinterpret_cast<f32x4*>(Sw + nxt + r0) = acc;                 // tbar_0 = eJ
+            float p2 = 0.f;                                                 // |eJ|^2 partial (rows of z only)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (r0 + j < n_in) p2 = fmaf(acc[j], acc[j], p2);
+            red[256 + (16 * ct + s) * 8 + 4 * nt + q] = p2;
+        }
+    };
+    fetch_na(R1);
+    adj3_tile2(r3, lds + m.TB + oL, PS, s, q, zero4, o0, o1);
+    tb_epi(2, r0w, 0, o0); tb_epi(2, r0w, 1, o1);
+    am_barrier();
+    AM_STAMP(4);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+    {
+        // zdot still sits in S[zd]: ahat = kbar_z + c_E zdot/|zdot| -> AH (shares the tbar_L slot of TB, free now)
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+            const int e2 = es + 16 * hs, eb = b0v + e2;
+            const bool ev = eb < S.B;
+            float nzs = 0.f;
+#pragma unroll
+            for (int p8 = 0; p8 < 8; ++p8) nzs += red[e2 * 8 + p8];
+            const float nz[2] = {nzs, nzs};
+            const float inv = (nd.norm_z && nz[hs] > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz[hs]) : 0.f;
+            lds[e2 * PS + m.AH + ec] = (ev && ec < n_in) ? fmaf(inv, lds[e2 * PS + zd + ec], kbv[hs]) : 0.f;
+        }
+        am_barrier();                                   // zdot's buffer is the next epilogue's target
+    }
+    adj3_tile2(r2, lds + cur, PS, s, q, zero4, o0, o1);
+    tb_epi(1, r0w, 0, o0); tb_epi(1, r0w, 1, o1);
+    am_barrier();
+    AM_STAMP(5);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+    if (narrow) tb_epi(0, r0n, nc, adj3_tile1(na, lds + cur + 16 * nc * PS, PS, s, q, zero4));
+    am_barrier();
+    AM_STAMP(6);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+    // eJ in S[cur].  tau = -c_l eps + c_n eJ/|eJ|  -> S[nxt] as t_0 (rows of ys and padding: 0)
+    {
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+            const int e2 = es + 16 * hs, eb = b0v + e2;
+            const bool ev = eb < S.B;
+            float njs = 0.f;
+#pragma unroll
+            for (int p8 = 0; p8 < 8; ++p8) njs += red[256 + e2 * 8 + p8];
+            const float nj[2] = {njs, njs};
+            const float inv = (nd.norm_j && nj[hs] > 0.f) ? a.c_n * __builtin_amdgcn_rsqf(nj[hs]) : 0.f;
+            for (int r = ec; r < NI; r += AM_EC) {
+                float v = 0.f;
+                if (r < n_in) v = fmaf(inv, lds[e2 * PS + cur + r], -a.c_l * lds[e2 * PS + m.E + r]);
+                lds[e2 * PS + nxt + r] = v;
+                if (ev && r < in0) a.TS[(size_t)eb * gl.sum_in + r] = v;
+            }
+        }
+    }
+    am_barrier();
+    AM_STAMP(7);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+
+    if (stg > S.last) {                                   // inputs of the next stage: in flight during sweeps 3 and 4
+        const AdjArgs& an = S.st[stg - 1];
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+            const int eb = b0v + es + 16 * hs;
+            adj3_fetch(an, nd, eb, eb < S.B, ec, n_in, in0, D, pf[hs]);
+        }
+    }
+    // ---- sweep 3: tangent chain; the last layer forms abar_L = ahat sigma' + eps q_L instead of t_L ----
+    auto tan_epi = [&](int l, int r0, int ct, const f32x4& acc) {
+        float* Sw = lds + (16 * ct + s) * PS;
+        const size_t gb = (size_t)(b0v + 16 * ct + s);
+        const bool sv = b0v + 16 * ct + s < a.B;
+        const int out = nd.dims[l + 1], oo = m.o_off[l];
+        const bool last = l + 1 == NL;
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(Sw + m.D1 + oo + r0);
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(Sw + m.D2 + oo + r0) * acc;   // q_l = sigma'' .* p_l
+        *reinterpret_cast<f32x4*>(Sw + m.D2 + oo + r0) = qv;
+        if (!last) {
+            const f32x4 t = d1 * acc;
+            *reinterpret_cast<f32x4*>(Sw + nxt + r0) = t;
+            if (sv) am_store4(a.TS + gb * gl.sum_in + gl.in_off[l + 1] + r0, t, r0, out, m.vec4);
+        } else {
+            const f32x4 ab = *reinterpret_cast<const f32x4*>(Sw + m.AH + r0) * d1 +
+                             *reinterpret_cast<const f32x4*>(Sw + m.E + r0) * qv;
+            *reinterpret_cast<f32x4*>(Sw + nxt + r0) = ab;
+            if (sv) am_store4(a.AB + gb * gl.sum_out + gl.out_off[l] + r0, ab, r0, out, m.vec4o);
+        }
+    };
+    fetch_na(F3);
+    adj3_tile2(f1, lds + cur, PS, s, q, zero4, o0, o1);
+    tan_epi(0, r0w, 0, o0); tan_epi(0, r0w, 1, o1);
+    am_barrier();
+    AM_STAMP(8);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+    adj3_tile2(f2, lds + cur, PS, s, q, zero4, o0, o1);
+    tan_epi(1, r0w, 0, o0); tan_epi(1, r0w, 1, o1);
+    am_barrier();
+    AM_STAMP(9);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+    if (narrow) tan_epi(2, r0n, nc, adj3_tile1(na, lds + cur + 16 * nc * PS, PS, s, q, zero4));
+    am_barrier();
+    AM_STAMP(10);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+
+    // ---- sweep 4: hbar chain; abar_{l-1} = hbar_{l-1} sigma' + tbar_{l-1} q_{l-1}; the last one is zbar ----
+    auto hb_epi = [&](int l, int r0, int ct, const f32x4& acc) {
+        float* Sw = lds + (16 * ct + s) * PS;
+        const size_t gb = (size_t)(b0v + 16 * ct + s);
+        const bool sv = b0v + 16 * ct + s < a.B;
+        if (l > 0) {
+            const int oprev = m.o_off[l - 1];
+            const f32x4 ab = acc * *reinterpret_cast<const f32x4*>(Sw + m.D1 + oprev + r0) +
+                             *reinterpret_cast<const f32x4*>(Sw + m.TB + oprev + r0) *
+                             *reinterpret_cast<const f32x4*>(Sw + m.D2 + oprev + r0);
+            *reinterpret_cast<f32x4*>(Sw + nxt + r0) = ab;
+            if (sv) am_store4(a.AB + gb * gl.sum_out + gl.out_off[l - 1] + r0, ab, r0, nd.dims[l], m.vec4o);
+        } else if (sv) {
+            am_store4(a.w_out + gb * n_in + r0, acc, r0, n_in, (n_in & 3) == 0);   // zbar
+        }
+    };
+    fetch_na(R1);
+    adj3_tile2(r3, lds + cur, PS, s, q, zero4, o0, o1);
+    hb_epi(2, r0w, 0, o0); hb_epi(2, r0w, 1, o1);
+    am_barrier();
+    AM_STAMP(11);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+    adj3_tile2(r2, lds + cur, PS, s, q, zero4, o0, o1);
+    hb_epi(1, r0w, 0, o0); hb_epi(1, r0w, 1, o1);
+    am_barrier();
+    AM_STAMP(12);
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+    if (narrow) hb_epi(0, r0n, nc, adj3_tile1(na, lds + cur + 16 * nc * PS, PS, s, q, zero4));
+    // zbar of this stage is input to the earlier stages (and to the lambda update): stores first, then everyone
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    am_barrier();
+    AM_STAMP(13);
+  }
+  if (S.lam_update) {        // lambda <- lambda + sum over the stages of zbar   (rows of this workgroup's samples)
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+        const int eb = b0 + es + 16 * hs;
+        for (int r = ec; r < n_in; r += AM_EC) {
+            if (eb < S.B) {
+                float acc = S.st[0].lam[(size_t)eb * n_in + r];
+                for (int k = S.last; k <= S.first; ++k) acc += S.st[k].w_out[(size_t)eb * n_in + r];
+                S.lam_out[(size_t)eb * n_in + r] = acc;
+            }
+        }
+    }
+  }
+}
+
+static bool adj3_shape(const NetDesc& nd, const AdjMfmaLayout& m) {
+    return nd.n_layers == 3 && m.dp[0] == 32 && m.dp[1] == 128 && m.dp[2] == 128 && m.dp[3] == 32 && m.nin_p == 32 &&
+           AM_WAVES == 8 && adj3_lds_bytes(m) <= 160 * 1024;
+}
+
 hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* P,
                                   float* img, hipStream_t s) {
     int mx = 0;
@@ -943,6 +1340,17 @@ hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const Ad
     const size_t lds = adj_mfma_lds_bytes(m);
     bool all_tanh = true;
     for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
+    static const bool generic_only = [] { const char* e = getenv("CNF_ADJ_GENERIC"); return e && e[0] == '1'; }();
+    if (adj3_shape(nd, m) && !generic_only) {          // resident-fragment pullback (A/B switch: CNF_ADJ_GENERIC=1)
+        const void* f3 = all_tanh ? (const void*)k_adj3<true> : (const void*)k_adj3<false>;
+        const size_t lds3 = adj3_lds_bytes(m);
+        hipError_t e3 = hipFuncSetAttribute(f3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        if (e3 != hipSuccess) return e3;
+        const dim3 grid3((S.B + A3_NS - 1) / A3_NS);
+        if (all_tanh) hipLaunchKernelGGL(k_adj3<true>, grid3, dim3(AM_THREADS), lds3, s, nd, g, m, img, S);
+        else hipLaunchKernelGGL(k_adj3<false>, grid3, dim3(AM_THREADS), lds3, s, nd, g, m, img, S);
+        return hipGetLastError();
+    }
     const void* fn = all_tanh ? (const void*)k_adj_mfma<true> : (const void*)k_adj_mfma<false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

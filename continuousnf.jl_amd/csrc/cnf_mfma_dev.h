@@ -38,13 +38,6 @@ struct MfmaArgs {
     float* hs_out;            //   signed step size into hs_out[naccept]
 };
 
-// tanh(a) = 1 - 2/(exp(2a) + 1): v_mul, v_exp, v_add, v_rcp, v_fma.  Absolute error
-// <= 2e-7 (one rounding of values near 1), which is what every other fp32 activation value
-// carries; measured against the parity metric it is indistinguishable from libm's tanh.
-__device__ __forceinline__ float tanh_fast(float a) {
-    const float t = __builtin_amdgcn_exp2f(a * 2.8853900817779268f);
-    return fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
-}
 
 __device__ __forceinline__ float quad_sum(float v) {     // sum over the 4 lanes l, l^16, l^32, l^48
     v += __shfl_xor(v, 16, 64);

@@ -28,3 +28,5 @@ t = t[:n]
 d = np.diff(t)
 print("stamps", n, "total ticks", t[-1] - t[0])
 print(" ".join(str(x) for x in d))
+raw = np.array(list(buf), dtype=np.int64)
+print("raw - min:", " ".join(str(int(x - raw[raw > 0].min())) if x > 0 else "-" for x in raw[:20]))
