@@ -23,7 +23,7 @@ def pytest_sessionfinish(session, exitstatus):
     the GPU box leaves its measured errors behind as an artifact (repo root and gpurun_out/)."""
     import json
     from tests import helpers
-    if not helpers.REPORT:
+    if not helpers.REPORT or os.environ.get("CNF_NO_PARITY_REPORT") == "1":
         return
     try:
         import torch
@@ -38,7 +38,7 @@ def pytest_sessionfinish(session, exitstatus):
             worst[k] = r
     out = {"bar": "|got-ref| <= 1e-4*|ref| + 1e-6 (dlogp row: 1e-4*(|ref| + rms(row)) + 1e-6); looser rtol where stated",
            "n_comparisons": len(helpers.REPORT), "max_err_over_bar": max(r["err_over_bar"] for r in helpers.REPORT),
-           "max_rel_err": max(r["max_rel_err"] for r in helpers.REPORT if r["rtol"] <= 1e-4),
+           "max_rel_err": max([r["max_rel_err"] for r in helpers.REPORT if r["rtol"] <= 1e-4] or [0.0]),
            "comparisons": sorted(worst.values(), key=lambda r: -r["err_over_bar"])}
     for path in (os.path.join(ROOT, "parity_report.json"), os.path.join(ROOT, "gpurun_out", "parity_report.json")):
         try:

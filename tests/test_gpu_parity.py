@@ -185,7 +185,10 @@ def test_adaptive_solve_vs_oracles(i, kernel):
     ref64, _ = O.tsit5_solve(cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True),
                              u0.astype(np.float64), *cfg.tspan, reltol=1e-10, abstol=1e-10)
     assert_parity(fsol, ref64, f"cfg{i} adaptive vs float64", rtol=5e-3, trace_row=cfg.n_in)
-    assert_parity(fsol, cref, f"cfg{i} adaptive vs C oracle", rtol=2e-3, trace_row=cfg.n_in)
+    # two float32 adaptive solves that round differently take slightly different steps: each is within the solver
+    # tolerance of the true solution, so their mutual distance gets the same bar as the distance to the float64 solve
+    # (measured: 2e-3 relative at config 1, t in (0, 13); 1e-4..6e-4 elsewhere)
+    assert_parity(fsol, cref, f"cfg{i} adaptive vs C oracle", rtol=5e-3, trace_row=cfg.n_in)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -641,6 +644,40 @@ def test_loss_grad_adaptive_jvp_cond_and_host(kernel):
     _assert_grad(grad, rgrad, "host")
 
 
+def test_loss_grad_headline_shape_variants():
+    """The resident-fragment pullback k_adj3 (shapes that pad to 32-128-128-32, 32 samples per workgroup): other
+    activations, a conditional model, widths below the padding, ragged and tiny batches, FFJORD (no norm rows)."""
+    cases = [
+        (O.Cfg(O.Net((32, 128, 128, 32), (O.ACT_SOFTPLUS, O.ACT_SIGMOID, O.ACT_TANH)), 32, 0, 0.01, 0.01), 0, 45),
+        (O.Cfg(O.Net((28, 128, 128, 28), (O.ACT_TANH,) * 3), 28, 0, 0.01, 0.01), 4, 70),
+        (O.Cfg(O.Net((30, 120, 116, 30), (O.ACT_TANH, O.ACT_ELU, O.ACT_TANH)), 20, 10, 0.01, 0.01, 0.01), 0, 33),
+        (O.Cfg(O.Net((32, 128, 128, 32), (O.ACT_TANH,) * 3), 32, 0), 0, 1),
+        (O.Cfg(O.Net((32, 128, 128, 32), (O.ACT_TANH,) * 3), 32, 0, 0.01, 0.01), 0, 300),
+    ]
+    for k, (cfg, n_cond, B) in enumerate(cases):
+        cfg.tspan = (0.0, 0.5)
+        val, grad, rval, rgrad, _, _ = _grad_case(cfg, B, 340 + k, "mfma", dict(adaptive=False, dt=1 / 4),
+                                                  dict(adaptive=False, dt=1 / 4), n_cond=n_cond, scale=0.1)
+        assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval)), k
+        _assert_grad(grad, rgrad, f"headline-shape case {k}")
+
+
+def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
+    """CNF_STEP_V1 / CNF_TRACE_GENERIC / CNF_ADJ_GENERIC (read once per process) route the headline shape to the
+    first-generation kernels; each route runs its parity tests in a child process."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for var, sel in (("CNF_STEP_V1", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve"),
+                     ("CNF_TRACE_GENERIC", "test_exact_trace_mfma_deep_networks"),
+                     ("CNF_ADJ_GENERIC", "test_loss_grad_fixed_dt_matches_oracle and 3-mfma or test_loss_grad_headline")):
+        env = dict(os.environ, **{var: "1", "CNF_NO_PARITY_REPORT": "1"})
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x",
+                            "-m", "gpu", "-p", "no:cacheprovider", "-k", sel], env=env, cwd=root, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, (var, r.stdout[-2000:], r.stderr[-1000:])
+        assert " passed" in r.stdout and "failed" not in r.stdout, (var, r.stdout[-500:])
+
+
 def test_loss_grad_larger_batches_and_backward_time():
     """The 2- and 4-samples-per-workgroup variants of the pullback kernel (B >= 512, B >= 2048), the
     K-split of the weight-gradient GEMM, and a solve in reverse time."""
@@ -726,6 +763,12 @@ def test_exact_trace_mfma_deep_networks():
         (O.Cfg(O.Net((40, 64, 64, 40), (O.ACT_TANH,) * 3), 40, 0), 0, 21),      # 3 column tiles per sample
         (O.Cfg(O.Net((72, 96, 80, 72), (O.ACT_TANH,) * 3), 60, 12), 0, 18),     # 5 column tiles per sample
         (O.Cfg(O.Net((100, 64, 64, 100), (O.ACT_TANH,) * 3), 100, 0), 0, 17),   # 7 column tiles per sample
+        # the shape of the resident-fragment kernel k_trace3 (pads to 32-128-128-32): other activations, a conditional
+        # model (28 + 4 input rows), widths below the padding, one sample, a ragged last workgroup
+        (O.Cfg(O.Net((32, 128, 128, 32), (O.ACT_SOFTPLUS, O.ACT_SIGMOID, O.ACT_TANH)), 32, 0), 0, 45),
+        (O.Cfg(O.Net((28, 128, 128, 28), (O.ACT_TANH,) * 3), 28, 0), 4, 35),
+        (O.Cfg(O.Net((30, 120, 116, 30), (O.ACT_TANH, O.ACT_ELU, O.ACT_TANH)), 20, 10), 0, 1),
+        (O.baseline_cfg(3)[0], 0, 1000),
     ]
     for k, (cfg, n_cond, B) in enumerate(cases):
         rng = np.random.default_rng(500 + k)

@@ -98,7 +98,7 @@ def _check_oracle(path):
         nf, nacc, nrej = (int(x) for x in r[f"stats_adapt_{tag}"])
         # THE check of the controller law restated from memory
         assert (sa.nf, sa.naccept, sa.nreject) == (nf, nacc, nrej), "adaptive step sequence differs from OrdinaryDiffEq's"
-        assert_parity(fa, r[f"fsol_adapt_{tag}"], f"ref adaptive fsol {tag}", rtol=2e-3, trace_row=cfg.n_in)
+        assert_parity(fa, r[f"fsol_adapt_{tag}"], f"ref adaptive fsol {tag}", rtol=5e-3, trace_row=cfg.n_in)
 
 
 def test_the_checks_themselves_on_a_synthetic_fixture(tmp_path):
@@ -159,5 +159,5 @@ def test_hip_path_against_reference_fixtures(path):
     fa = cnf.base_sol(ica, prob).view()
     nf, nacc, nrej = (int(x) for x in r["stats_adapt_train"])
     assert (prob.stats["nf"], prob.stats["naccept"], prob.stats["nreject"]) == (nf, nacc, nrej)
-    assert_parity(fa, r["fsol_adapt_train"], "HIP vs reference adaptive fsol", rtol=2e-3, trace_row=cfg.n_in)
+    assert_parity(fa, r["fsol_adapt_train"], "HIP vs reference adaptive fsol", rtol=5e-3, trace_row=cfg.n_in)
     icnf.close(); ica.close()
