@@ -201,7 +201,8 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
 
 extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (!h) return CNF_ERR_BAD_ARG;
-    (void)hipSetDevice(h->device);
+    // called from a finaliser after the HIP runtime has shut down (process exit): nothing left to free on the device
+    if (hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); delete h; return CNF_OK; }
     mfma_plan_free(h->mfma);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_cond) (void)hipFree(h->d_cond);
@@ -661,8 +662,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     const bool hairer = opts->adaptive && opts->dt == 0.f;
     unsigned* ticket = reinterpret_cast<unsigned*>(h->d_sums + 8);
     bool fused_init = false;
-    const char* nf_ = getenv("CNF_NO_FUSED_INIT");
-    if (use_mfma && hairer && !lockstep && !(nf_ && nf_[0] == '1')) {
+    if (use_mfma && hairer && !lockstep) {
         s = mfma_rhs_init0(h->mfma, h->nd, train, h->d_state, h->U[0], eps, h->K1[0], h->partials, ticket, B, st);
         if (s == CNF_OK) fused_init = true;
         else if (s != CNF_ERR_UNSUPPORTED) return fail(h, s, "MFMA RHS launch failed");

@@ -58,7 +58,7 @@ for i in which:
         ns = min(B, 128 if (i == 5 and not tr) else 512)
         got = du.view(B, D)[:ns].cpu().numpy().T
         ref = CO.rhs(cfg, flat, u_h[:, :ns], eps_h[:, :ns], tr)
-        perr = parity_err(got, ref)
+        perr = parity_err(got, ref, trace_row=cfg.n_in)
         fl, by = C.c_double(), C.c_double()
         l.cnf_rhs_work(h, m, B, C.byref(fl), C.byref(by))
         out = {"cfg": i, "mode": mname, "B": B, "kernel": {1: "generic", 2: "mfma"}[kern], "rhs_us": round(rhs_us, 1),

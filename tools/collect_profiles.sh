@@ -22,3 +22,10 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 echo "wait rc=$?"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/grad -- python3 tools/prof_grad.py 3 8192 3 > $OUT/grad.log 2>&1
 echo "grad rc=$?"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/testmode -- python3 tools/prof_testmode.py > $OUT/testmode.log 2>&1
+echo "testmode rc=$?"
+# every BASELINE configuration at full size (uses the oracle as the checker: tests/measure_configs.py)
+timeout -k 10 500 python3 tests/measure_configs.py > $OUT/all_configs.log 2>&1
+echo "all_configs rc=$?"
+grep "^{" $OUT/all_configs.log > $OUT/all_configs.jsonl
+timeout -k 10 200 python3 tools/prof_testmode.py >> $OUT/testmode_plain.log 2>&1

@@ -112,3 +112,18 @@ if gs:
         for r in rows[:12]:
             w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                         r["MinNs"], r["MaxNs"]])
+
+# TestMode of the headline network (exact trace): kernel split of tools/prof_testmode.py
+ts = first("testmode/**/*kernel_stats.csv")
+if ts:
+    rows = list(csv.DictReader(open(ts)))
+    with open(os.path.join(DST, f"{name}_testmode_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows[:8]:
+            w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                        r["MinNs"], r["MaxNs"]])
+for src, dst in (("all_configs.jsonl", f"{name}_all_configs.jsonl"), ("testmode_plain.log", f"{name}_testmode.txt")):
+    pth = os.path.join(SRC, src)
+    if os.path.exists(pth):
+        open(os.path.join(DST, dst), "w").write("".join(l for l in open(pth) if l.startswith(("{", "cfg"))))
