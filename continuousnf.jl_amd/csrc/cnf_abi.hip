@@ -831,8 +831,12 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             slot = traj_slot_floats(h); dcap = h->traj_cap;
             dump = h->traj + n;                      // stage area of slot 0; u_n sits one array before
         }
+        // attempts the newest snapshot says are still needed, (t1 - t)/dt rounded up (the controller rarely shrinks dt
+        // near the end); -1 = no snapshot yet.  Launches beyond that would only find `done` and exit.
+        long need = -1;
         for (;;) {
-            while (sent < max_sent && sent - seen < AHEAD && !done) {
+            while (sent < max_sent && sent - seen < AHEAD && !done &&
+                   (need < 0 || sent - seen < need + (use_mfma ? 1 : 0))) {      // fused: + the launch that runs the last controller
                 if (use_mfma) {
                     // launch i applies the controller of attempt i-1 and publishes under index i
                     const bool apply = sent > 0;
@@ -876,6 +880,12 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             }
             seen = (long)(sq - base);
             if (snap.done) { fin = snap; done = true; }
+            need = 1;
+            if (snap.dt > 0.f) {
+                const double left = std::fabs((double)snap.t1 - (double)snap.t) / (double)snap.dt;
+                need = left > 1e6 ? 1000000 : (long)std::ceil(left - 1e-6);
+                if (need < 1) need = 1;
+            }
         }
     }
     h->last_state = cur_state;

@@ -150,52 +150,18 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
     const unsigned long long s3start = s3last;
     const unsigned long long s3rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    // ---- everything the launch needs from memory is requested up front, in one round trip: the integrator state,
-    // the error partials of the previous attempt (one pair per workgroup of the same grid), the weight fragments,
-    // and this workgroup's first tile from BOTH buffer sets (which one is current is the controller's decision)
-    StepState st0;                                         // the controller thread's copy (one round trip, with the rest)
+    // ---- everything the launch needs from memory is requested up front, in ONE round trip, and nothing is consumed
+    // before all of it is in flight.  Order of issue = order of return: the integrator state words first (the `done`
+    // test and the controller need them soonest), then the error partials, the weight stream (135 KB per workgroup:
+    // it bounds the prologue, so it must not queue behind anything that waits), then this workgroup's first tile from
+    // BOTH buffer sets (which one is current is the controller's decision).
+    StepState st0;                                         // the controller thread's copy
     if (tid == 0) st0 = *st;
-    // (wave-uniform values into scalar registers: the buffer pointers selected from `cur` stay out of the vector file)
-    const int st_done = __builtin_amdgcn_readfirstlane(st->done), st_cur = __builtin_amdgcn_readfirstlane(st->cur);
-    const float st_h = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(st->h)));
-    const float st_abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(st->abstol)));
-    const float st_reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(st->reltol)));
+    const int v_done = st->done, v_cur = st->cur;
+    const float v_h = st->h, v_abstol = st->abstol, v_reltol = st->reltol;
     float cp0 = 0.f, cp1 = 0.f;
     if (a.apply_ctrl)
         for (int i = tid; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
-    const int ntile = (a.B + s3::NB - 1) / s3::NB;
-    f32x4 ru[2], rk[2];
-    int ce = 0, cu = 0, cs = 0;
-    float* sc = lds + s3::SC + smp * 24;
-    auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
-    auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
-    {
-        f32x4 rs[2][2];
-        const int b0 = blockIdx.x * s3::NB + 16 * hf;
-        const bool live = s < max(0, min(16, a.B - b0));
-        const size_t gcol = (size_t)(b0 + s) * D;
-        ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
-        const f32x4 re = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            ru[c] = ld4_issue(a.U[c] + gcol + r0, cu, img3);
-            rk[c] = ld4_issue(a.K1[c] + gcol + r0, cu, img3);
-            rs[c][0] = ld4_issue(a.U[c] + gcol + n_in, cs, img3);
-            rs[c][1] = ld4_issue(a.K1[c] + gcol + n_in, cs, img3);
-        }
-        // scalar rows of both candidates wait in LDS (slots 2..5 of the scalar-row state) for the controller's choice
-        if (sown) {
-            sc_set(2, ld4_mask(rs[0][0], cs)); sc_set(3, ld4_mask(rs[0][1], cs));
-            sc_set(4, ld4_mask(rs[1][0], cs)); sc_set(5, ld4_mask(rs[1][1], cs));
-        }
-        // the probe rows go straight to their LDS image (waves 0-3 need them for g3, waves 4-7 for the trace row)
-        *(f32x4*)(lds + s3::EPS + smp * s3::SX0 + r0) = ld4_mask(re, ce);
-    }
-    S3T(32);
-    if (st_done) {       // launches queued past the end of the solve: keep the state chain intact and leave
-        if (a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
-        return;
-    }
     // Weights.  W2 is needed twice per wave (16 of its rows forward, 16 of its columns in reverse): it is read from
     // memory ONCE per workgroup into an LDS staging image (which aliases the activation area, idle until the first
     // stage) and the 8 waves cut their two register fragments out of it.  The K = 128 images of the narrow products
@@ -234,6 +200,45 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
 #pragma unroll
         for (int u = 0; u < 2; ++u) wB3[u] = wp[u * 64];
     }
+    const int ntile = (a.B + s3::NB - 1) / s3::NB;
+    f32x4 ru[2], rk[2], re, rs[2][2];
+    int ce = 0, cu = 0, cs = 0;
+    float* sc = lds + s3::SC + smp * 24;
+    auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
+    auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
+    {
+        const int b0 = blockIdx.x * s3::NB + 16 * hf;
+        const bool live = s < max(0, min(16, a.B - b0));
+        const size_t gcol = (size_t)(b0 + s) * D;
+        ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
+        re = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            ru[c] = ld4_issue(a.U[c] + gcol + r0, cu, img3);
+            rk[c] = ld4_issue(a.K1[c] + gcol + r0, cu, img3);
+            rs[c][0] = ld4_issue(a.U[c] + gcol + n_in, cs, img3);
+            rs[c][1] = ld4_issue(a.K1[c] + gcol + n_in, cs, img3);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);                     // nothing above is consumed before all of it is requested
+    // (wave-uniform values into scalar registers: the buffer pointers selected from `cur` stay out of the vector file)
+    const int st_done = __builtin_amdgcn_readfirstlane(v_done), st_cur = __builtin_amdgcn_readfirstlane(v_cur);
+    const float st_h = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_h)));
+    const float st_abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_abstol)));
+    const float st_reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_reltol)));
+    S3T(32);
+    if (st_done) {       // launches queued past the end of the solve: keep the state chain intact and leave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the LDS-DMA pieces must have landed before the wave ends)
+        if (a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
+        return;
+    }
+    // scalar rows of both candidates wait in LDS (slots 2..5 of the scalar-row state) for the controller's choice
+    if (sown) {
+        sc_set(2, ld4_mask(rs[0][0], cs)); sc_set(3, ld4_mask(rs[0][1], cs));
+        sc_set(4, ld4_mask(rs[1][0], cs)); sc_set(5, ld4_mask(rs[1][1], cs));
+    }
+    // the probe rows go straight to their LDS image (waves 0-3 need them for g3, waves 4-7 for the trace row)
+    *(f32x4*)(lds + s3::EPS + smp * s3::SX0 + r0) = ld4_mask(re, ce);
     float* msc = lds + s3::MISC;
     S3T(33);
     if (a.apply_ctrl) {
