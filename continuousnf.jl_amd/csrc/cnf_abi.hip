@@ -636,7 +636,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     // number of error partials = blocks of whichever kernel writes them
     int nblk = (int)((n + 255) / 256);
     if (nblk > 256) nblk = 256;
-    if (use_mfma) nblk = mfma_grid_for(h->mfma, B);
+    if (use_mfma) nblk = mfma_grid_for(h->mfma, B, rec != nullptr, train != 0);
 
     // initial state
     StepState* init = &h->h_state[2];

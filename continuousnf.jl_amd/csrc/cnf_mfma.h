@@ -38,7 +38,8 @@ struct MfmaPlan {
     int variant = 0;                // 0: shape not supported by the MFMA path
     MfmaLayout ly{};
     float* d_img = nullptr;         // weight+bias image in HBM (LDS order), refreshed by pack
-    float* d_img3 = nullptr;        // variant 2: register-fragment image of k_step3, refreshed by pack
+    float* d_img3 = nullptr;        // headline shape: register-fragment image of k_step3 / k_step3j, refreshed by pack
+    bool shape3 = false;            // the network pads to 32-128-128-32, all tanh (either compute mode)
     const float* cond = nullptr;    // conditional models: per-sample first-layer bias [B][cbs] (owned by the handle)
     int cbs = 0;
 };
@@ -68,4 +69,5 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
                      bool finalize, int B, hipStream_t s, float* dump = nullptr,
                      size_t dump_stride = 0, void* mirror = nullptr,
                      unsigned seq = 0, size_t dump_step_stride = 0, int dump_cap = 0, float* hs_out = nullptr);
-int mfma_grid_for(const MfmaPlan& p, int B);
+// workgroups (= error partials) of a step launch; `recording`: the solve files its stage states (gradient path)
+int mfma_grid_for(const MfmaPlan& p, int B, bool recording = false, bool train = true);

@@ -1214,6 +1214,7 @@ static bool matches(const MfmaLayout& m) {
 
 void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     p.variant = 0;
+    p.shape3 = false;
     MfmaLayout& ly = p.ly;
     ly = MfmaLayout{};
     ly.L = nd.n_layers;
@@ -1280,7 +1281,9 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     if ((size_t)ly.total_floats * sizeof(float) > MF_LDS_BYTES) return;   // activations alone exceed LDS
     if (ly.P[0] > 128) return;                                             // state tiles fg, fg+4 only
     p.variant = 1;
-    if (nd.jvp) return;                  // forward-mode sweep: run-time-layout kernel only
+    p.shape3 = ly.L == 3 && ly.P[0] == 32 && ly.P[1] == 128 && ly.P[2] == 128 && ly.P[3] == 32 &&
+               ly.acts[0] == CNF_ACT_TANH && ly.acts[1] == CNF_ACT_TANH && ly.acts[2] == CNF_ACT_TANH;
+    if (nd.jvp) return;                  // forward-mode sweep: k_step3j for the headline shape, else the run-time-layout kernel
     if (matches<LyCfg3>(ly)) p.variant = 2;
     else if (matches<LyCfg2>(ly)) p.variant = 3;
     else if (matches<LyCfg1>(ly)) p.variant = 4;
@@ -1317,7 +1320,7 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
     }
     hipLaunchKernelGGL(k_pack_image, dim3((p.ly.img_floats + 255) / 256), dim3(256), 0, s, p.ly, nd,
                        d_params, p.d_img);
-    if (p.variant == 2) {       // headline shape: register-fragment image of k_step3
+    if (p.variant == 2 || p.shape3) {       // headline shape: register-fragment image of k_step3 / k_step3j
         if (!p.d_img3 && hipMalloc(&p.d_img3, step3_img_floats() * sizeof(float)) != hipSuccess) return CNF_ERR_HIP;
         step3_pack(nd, d_params, p.d_img3, s);
     }
@@ -1329,16 +1332,34 @@ bool mfma_supported(const MfmaPlan& p, const NetDesc&, bool train, int) {
     return train || p.ly.c_off >= 0;     // TestMode: exact trace in closed form for 2-layer nets
 }
 
+// CNF_STEP_V1=1: the first-generation step kernel (k_mfma) for the headline shape too -- A/B measurements only
+static bool step_v1() {
+    static const bool v = [] { const char* e = getenv("CNF_STEP_V1"); return e && e[0] == '1'; }();
+    return v;
+}
+
 // Networks whose weights stream from L2 run 16-sample workgroups (one team of 8 waves): the two teams of a
 // 32-sample tile share nothing there (each fetches its own fragments), so the narrow tile costs no extra traffic
 // and puts twice as many CUs to work at small batches (BASELINE config 5: 2048 columns = 128 workgroups, not 64).
 // Measured on config 5, same box: 32-sample tiles 41.8 us per RHS, 16-sample tiles 25.9, with the fragment stream 21.7.
 static bool narrow_tiles(const MfmaPlan& p) { return p.variant != 0 && !p.ly.wlds; }
 
-int mfma_grid_for(const MfmaPlan& p, int B) {
+static int step3_grid_for(int B) {
+    const int nt = (B + 31) / 32;
+    return nt < 512 ? (nt < 1 ? 1 : nt) : 512;
+}
+
+// does a step attempt of this solve run on k_step3j?  (same test on the host side -- number of error partials -- and in launch())
+static bool step3j_route(const MfmaPlan& p, bool train, bool recording) {
+    return p.shape3 && p.ly.jvp && train && !p.cond && !recording && p.d_img3 && !step_v1();
+}
+static int base_grid_for(const MfmaPlan& p, int B) {
     const int nb = narrow_tiles(p) ? 16 : MF_NB;
     int nt = (B + nb - 1) / nb;
     return nt < 512 ? (nt < 1 ? 1 : nt) : 512;
+}
+int mfma_grid_for(const MfmaPlan& p, int B, bool recording, bool train) {
+    return step3j_route(p, train, recording) ? step3_grid_for(B) : base_grid_for(p, B);
 }
 
 template <class LY, int WPT = MF_WPT>
@@ -1349,20 +1370,24 @@ static void launch_static(const MfmaPlan& p, const MfmaArgs& a, dim3 grid, hipSt
     if (a.mode == 2) hipLaunchKernelGGL((k_mfma<LY, true, WPT>), grid, dim3(MF_KTHREADS), shm, s, ly, a);
     else hipLaunchKernelGGL((k_mfma<LY, false, WPT>), grid, dim3(MF_KTHREADS), shm, s, ly, a);
 }
-// CNF_STEP_V1=1: the first-generation step kernel (k_mfma) for the headline shape too -- A/B measurements only
-static bool step_v1() {
-    static const bool v = [] { const char* e = getenv("CNF_STEP_V1"); return e && e[0] == '1'; }();
-    return v;
-}
 
 static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
     MfmaArgs a = a0;
     if (a.test) { a.cimg = p.d_img + p.ly.c_off; a.SWC = p.ly.SWC; }
     a.cond = p.cond; a.cbs = p.cbs;
-    const dim3 grid(mfma_grid_for(p, a.B)), block(MF_KTHREADS);
+    // k_step3j: JVP handles of the headline shape -- and VJP handles WITHOUT the |eps^T J| row (FFJORD): zdot and
+    // ldot = -eps.(J eps) = -(eps^T J).eps do not depend on the mode, and one forward sweep of two column tiles is the
+    // shorter schedule (3 barrier intervals per evaluation instead of 9)
+    const bool j3 = a.mode == 2 && (step3j_route(p, !a.test, a.dump != nullptr) ||
+                                    (p.variant == 2 && !p.ly.norm_j && !a.test && !a.cond && !a.dump && p.d_img3 && !step_v1()));
+    const dim3 grid(j3 ? step3_grid_for(a.B) : base_grid_for(p, a.B)), block(MF_KTHREADS);
     const size_t shm = (size_t)p.ly.total_floats * sizeof(float);
     const bool narrow = narrow_tiles(p);
-    if (narrow && p.variant != 5) {
+    if (j3) {
+        // JVP compute mode on the headline shape: 32-sample tiles whatever the run-time layout chose
+        step3j_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s);
+    }
+    else if (narrow && p.variant != 5) {
         RtLayout ly{p.ly};
         if (a.mode == 2) hipLaunchKernelGGL((k_mfma<RtLayout, true, MF_WPT_NARROW>), grid, block, shm, s, ly, a);
         else hipLaunchKernelGGL((k_mfma<RtLayout, false, MF_WPT_NARROW>), grid, block, shm, s, ly, a);

@@ -566,6 +566,368 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
 #endif
 }
 
+// k_step3j -- the same step for the JVP compute mode (DIJacVecMatrixMode, src/icnf.jl:384-420): per evaluation ONE
+// forward sweep of the state columns h_l and the tangent columns tau_l = sigma'_l .* (W_l tau_{l-1}), tau_0 = eps, as two
+// column tiles per sample half that share every weight fragment; ldot = -eps.(J eps), Edot = |zdot|, ndot = |J eps|.
+// Three dependent products instead of six: 3 barrier intervals per evaluation, no reverse fragments, no W2 staging.
+// Prologue, controller, Runge-Kutta bookkeeping and outputs are those of k_step3.
+__global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __restrict__ img3, int n_in, int norm_z,
+                                                  int norm_j, const S3Tab tab) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const StepState* st = a.st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = n_in + 3;
+    const int s = lane & 15, q = lane >> 4;
+    const int t = wave & 1, hf = (wave >> 1) & 1;         // narrow phases: row tile and sample half of this wave
+    const bool zown = wave < 4;                           // waves 0-3 produce zdot: they hold the z rows of the state
+    const bool sown = !zown && t == 0 && q == 0;          // waves 4, 6: lane s holds the scalar rows of sample 16 hf + s
+    const int smp = 16 * hf + s;                          // sample of this lane in the narrow phases
+    const int r0 = 16 * t + 4 * q;                        // first of its 4 rows there
+    const int nv = n_in - r0;                             // valid rows among them (may be <= 0 or > 4)
+#ifdef S3_STAMPS
+    unsigned long long s3acc[36] = {0};
+    unsigned long long s3last = __builtin_amdgcn_s_memtime();
+    const unsigned long long s3start = s3last;
+    const unsigned long long s3rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- everything the launch needs from memory is requested up front, in ONE round trip, and nothing is consumed
+    // before all of it is in flight.  Order of issue = order of return: the integrator state words first (the `done`
+    // test and the controller need them soonest), then the error partials, the weight stream (135 KB per workgroup:
+    // it bounds the prologue, so it must not queue behind anything that waits), then this workgroup's first tile from
+    // BOTH buffer sets (which one is current is the controller's decision).
+    StepState st0;                                         // the controller thread's copy
+    if (tid == 0) st0 = *st;
+    const int v_done = st->done, v_cur = st->cur;
+    const float v_h = st->h, v_abstol = st->abstol, v_reltol = st->reltol;
+    float cp0 = 0.f, cp1 = 0.f;
+    if (a.apply_ctrl)
+        for (int i = tid; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
+    // Weights: forward orientation only.  W3 rows (the K = 128 operand of the last layer) into their LDS image by
+    // LDS-DMA; this wave's 16-row tiles of W1 (2 fragments) and of W2 (8 fragments, straight from the row-major image).
+    constexpr int NCN = s3::P0 * s3::SXH / 4, NCB = (2 * s3::PH + s3::P0) / 4;
+    static_assert(NCN % 64 == 0, "whole wave instructions");
+    {
+        typedef __attribute__((address_space(3))) float* lds_f;
+        typedef const __attribute__((address_space(1))) float* glb_f;
+#pragma unroll
+        for (int i = 0; i < (NCN + 511) / 512; ++i) {
+            const int c = 512 * i + 64 * wave;
+            if (c < NCN)
+                __builtin_amdgcn_global_load_lds((glb_f)(img3 + s3::IMG_W3R + 4 * (c + lane)), (lds_f)(lds + s3::W3R + 4 * c), 16, 0, 0);
+        }
+    }
+    const f32x4 sgb = reinterpret_cast<const f32x4*>(img3 + s3::IMG_B1)[min(tid, NCB - 1)];
+    f32x4 wF1[2], wF2[8];
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(img3 + s3::IMG_FR1) + (size_t)((wave & 3) * 4 + 2 * (wave >> 2)) * 64 + lane;
+        wF1[0] = wp[0]; wF1[1] = wp[64];
+        const float* rw = img3 + s3::IMG_W2 + (16 * wave + s) * s3::SW2 + 4 * q;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wF2[u] = *(const f32x4*)(rw + 16 * u);
+    }
+    const int ntile = (a.B + s3::NB - 1) / s3::NB;
+    f32x4 ru[2], rk[2], re, rs[2][2];
+    int ce = 0, cu = 0, cs = 0;
+    float* sc = lds + s3::SC + smp * 24;
+    auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
+    auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
+    {
+        const int b0 = blockIdx.x * s3::NB + 16 * hf;
+        const bool live = s < max(0, min(16, a.B - b0));
+        const size_t gcol = (size_t)(b0 + s) * D;
+        ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
+        re = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            ru[c] = ld4_issue(a.U[c] + gcol + r0, cu, img3);
+            rk[c] = ld4_issue(a.K1[c] + gcol + r0, cu, img3);
+            rs[c][0] = ld4_issue(a.U[c] + gcol + n_in, cs, img3);
+            rs[c][1] = ld4_issue(a.K1[c] + gcol + n_in, cs, img3);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);                     // nothing above is consumed before all of it is requested
+    // (wave-uniform values into scalar registers: the buffer pointers selected from `cur` stay out of the vector file)
+    const int st_done = __builtin_amdgcn_readfirstlane(v_done), st_cur = __builtin_amdgcn_readfirstlane(v_cur);
+    const float st_h = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_h)));
+    const float st_abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_abstol)));
+    const float st_reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_reltol)));
+    S3T(32);
+    if (st_done) {       // launches queued past the end of the solve: keep the state chain intact and leave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the LDS-DMA pieces must have landed before the wave ends)
+        if (a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
+        return;
+    }
+    // scalar rows of both candidates wait in LDS (slots 2..5 of the scalar-row state) for the controller's choice
+    if (sown) {
+        sc_set(2, ld4_mask(rs[0][0], cs)); sc_set(3, ld4_mask(rs[0][1], cs));
+        sc_set(4, ld4_mask(rs[1][0], cs)); sc_set(5, ld4_mask(rs[1][1], cs));
+    }
+    // the probe rows go straight to their LDS image (waves 0-3 need them for g3, waves 4-7 for the trace row)
+    *(f32x4*)(lds + s3::EPS + smp * s3::SX0 + r0) = ld4_mask(re, ce);
+    float* msc = lds + s3::MISC;
+    S3T(33);
+    if (a.apply_ctrl) {
+        for (int off = 32; off > 0; off >>= 1) { cp0 += __shfl_down(cp0, off, 64); cp1 += __shfl_down(cp1, off, 64); }
+        if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; }
+    }
+    S3T(34);
+    if (tid < NCB) reinterpret_cast<f32x4*>(lds + s3::BIAS)[tid] = sgb;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA pieces have landed (then the barrier)
+    S3T(24);
+    s3_bar();                                              // staging image and partial sums complete
+    S3T(25);
+    int cur = st_cur;
+    float hstep = st_h, abstol = st_abstol, reltol = st_reltol;
+    if (a.apply_ctrl && tid == 0) {
+        // In-kernel step controller (as in k_mfma): every workgroup reduces the same partials in the same order
+        // and takes the same decision; block 0 publishes the new state for the next launch and the host mirror.
+        float p0 = 0.f, p1 = 0.f;
+        for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
+        StepState ns = st0;
+        ctrl_after_step(&ns, p0, p1, a.n_total);
+        if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
+        msc[32] = __int_as_float(ns.cur); msc[33] = ns.h; msc[34] = ns.abstol; msc[35] = ns.reltol;
+        msc[36] = __int_as_float(ns.done);
+    }
+    S3T(26);
+    s3_bar();                                              // controller done; the staging area is free
+    S3T(27);
+    if (a.apply_ctrl) {
+        cur = __builtin_amdgcn_readfirstlane(__float_as_int(msc[32]));
+        hstep = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[33])));
+        abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[34])));
+        reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[35])));
+        if (__float_as_int(msc[36])) return;        // the controller just finished the solve
+    }
+    // (explicit selects: indexing the kernel-argument arrays with a run-time value makes the compiler fetch the
+    // pointer from the argument segment through a vector load -- a memory round trip in front of the state loads)
+    const float* Uin = cur ? a.U[1] : a.U[0];
+    const float* K1in = cur ? a.K1[1] : a.K1[0];
+    float* Uout = cur ? a.U[0] : a.U[1];
+    float* K1out = cur ? a.K1[0] : a.K1[1];
+
+    float errsum = 0.f, badcnt = 0.f;
+    // the 8 partials (2 row tiles x 4 lanes) of one sample and one kind sit side by side: two b128 reads each
+    auto red8 = [&](int kind) {
+        const float* r = lds + s3::RED + (kind * s3::NB + smp) * 8;
+        const f32x4 a_ = *(const f32x4*)r, b_ = *(const f32x4*)(r + 4);
+        return ((a_.x + a_.y) + (a_.z + a_.w)) + ((b_.x + b_.y) + (b_.z + b_.w));
+    };
+    auto read_scalars = [&]() {
+        const float e2 = red8(0), ld = red8(1), n2 = red8(2);
+        return f32x4{ld, norm_z ? __builtin_sqrtf(e2) : 0.f, norm_j ? __builtin_sqrtf(n2) : 0.f, 0.f};
+    };
+    float* redw = lds + s3::RED + smp * 8 + 4 * t + q;                 // this lane's slot of kind 0 (+ 256 per kind)
+    // LDS images of the tangent columns: T1 where k_step3 keeps g1, T2 where it keeps W1^T (not loaded here), sigma'_3 in G3
+    constexpr int T1 = s3::G1, T2 = s3::W1T;
+    const float* x0r = lds + s3::X0 + s * s3::SX0 + 4 * q;            // lane = sample s of half A; half B = +16 rows
+    const float* e0r = lds + s3::EPS + s * s3::SX0 + 4 * q;           // tau_0 = eps
+    const float* h1r = lds + s3::H1 + s * s3::SXH + 4 * q;
+    const float* t1r = lds + T1 + s * s3::SXH + 4 * q;
+    float* h1w = lds + s3::H1 + s * s3::SXH + 16 * wave + 4 * q;
+    float* t1w = lds + T1 + s * s3::SXH + 16 * wave + 4 * q;
+    float* h2w = lds + s3::H2 + s * s3::SXH + 16 * wave + 4 * q;
+    float* t2w = lds + T2 + s * s3::SXH + 16 * wave + 4 * q;
+    constexpr int HB = 16 * s3::SXH, XB = 16 * s3::SX0;              // half B = 16 samples on
+    // last layer: wave -> (row tile t, sample half hf, kind): waves 0-3 the state columns (zdot), 4-7 the tangent columns
+    const float* nr3 = lds + (zown ? s3::H2 : T2) + smp * s3::SXH + 4 * q;
+    const float* nrW = lds + s3::W3R + (16 * t + s) * s3::SXH + 4 * q;
+    float* x0w = lds + s3::X0 + smp * s3::SX0 + r0;
+    float* g3w = lds + s3::G3 + smp * s3::SX0 + r0;
+    // Runge-Kutta state of the z rows r0..r0+3 of sample smp, written and read by this lane only:
+    float* rkw = lds + s3::KZ + smp * s3::SKZ + r0;                   // u at rkw, k1 at rkw + 32,
+    float* kzw = rkw + 64;                                            // k_{j+2} at kzw + 32 j (j = 0..5)
+    float* epw = lds + s3::EPS + smp * s3::SX0 + r0;                  // the probe rows eps
+    const float* bias = lds + s3::BIAS;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int b0 = tile * s3::NB + 16 * hf;
+        const bool live = s < max(0, min(16, a.B - b0));
+        const size_t gcol = (size_t)(b0 + s) * D;
+        f32x4 uz, k1z;
+        if (tile == blockIdx.x) {                              // requested at kernel entry
+            uz = ld4_mask(cur ? ru[1] : ru[0], cu);
+            k1z = ld4_mask(cur ? rk[1] : rk[0], cu);
+            if (sown) { sc_set(0, sc_get(cur ? 4 : 2)); sc_set(1, sc_get(cur ? 5 : 3)); }
+        } else {
+            ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
+            const f32x4 e_ = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+            const f32x4 u_ = ld4_issue(Uin + gcol + r0, cu, img3), k_ = ld4_issue(K1in + gcol + r0, cu, img3);
+            const f32x4 s0 = ld4_issue(Uin + gcol + n_in, cs, img3), s1 = ld4_issue(K1in + gcol + n_in, cs, img3);
+            *(f32x4*)epw = ld4_mask(e_, ce); uz = ld4_mask(u_, cu); k1z = ld4_mask(k_, cu);
+            if (sown) { sc_set(0, ld4_mask(s0, cs)); sc_set(1, ld4_mask(s1, cs)); }
+        }
+        if (zown) {
+            *(f32x4*)x0w = uz + (hstep * TS_A21) * k1z;   // state of evaluation 1: U_2 = u + h a21 k1
+            *(f32x4*)rkw = uz;
+            *(f32x4*)(rkw + 32) = k1z;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;       // k2..k7: not produced yet
+        }
+        S3T(28);
+        s3_bar();
+        S3T(20);
+
+        // tau_3 = sigma'_3 .* (W3 tau_2) on waves 4-7: trace and norm partials (src/icnf.jl:404, :413).  The product is
+        // formed in interval 2; sigma'_3 comes from the wave that formed zdot of the same rows, one barrier later.
+        f32x4 aN[8], tacc = zero4;
+        auto finish_tau = [&]() {
+            const f32x4 tj = tacc * *(const f32x4*)g3w;
+            redw[s3::NB * 8] = -s3_dot4(tj, *(const f32x4*)epw);
+            redw[2 * s3::NB * 8] = s3_dot4(tj, tj);
+        };
+
+        for (int stg = 1; stg <= 6; ++stg) {
+            // ---- interval 0: first layer, tile `wave`, both halves, state and tangent columns (K = 32)
+            {
+                f32x4 bh[4], bt[4];
+                s3_load<2>(bh, x0r, 0); s3_load<2>(bh, x0r + XB, 2);
+                s3_load<2>(bt, e0r, 0); s3_load<2>(bt, e0r + XB, 2);
+                const f32x4 bv1 = *(const f32x4*)(bias + 16 * wave + 4 * q);
+                if (!zown && stg > 1) finish_tau();                            // of the previous evaluation
+                S3_SB();
+                f32x4 c0 = zero4, c1 = zero4, d0 = zero4, d1 = zero4, e0 = zero4, e1 = zero4, f0 = zero4, f1 = zero4;
+                s3_mm<0, 2>(c0, c1, wF1, bh, 0, 0);
+                s3_mm<0, 2>(d0, d1, wF1, bh, 0, 2);
+                s3_mm<0, 2>(e0, e1, wF1, bt, 0, 0);
+                s3_mm<0, 2>(f0, f1, wF1, bt, 0, 2);
+                const f32x4 hA = s3_tanh4(c0 + c1 + bv1), hB = s3_tanh4(d0 + d1 + bv1);
+                *(f32x4*)h1w = hA;
+                *(f32x4*)t1w = s3_dtanh4(hA) * (e0 + e1);
+                *(f32x4*)(h1w + HB) = hB;
+                *(f32x4*)(t1w + HB) = s3_dtanh4(hB) * (f0 + f1);
+            }
+            S3T(0);
+            s3_bar();                                                          // h1, t1 visible
+            S3T(1);
+            // ---- interval 1: second layer, tile `wave`, both halves, state and tangent columns: operands one k-block
+            // ahead of the MFMAs (ring of 2), 16 MFMAs per k-block on 8 chains
+            {
+                f32x4 rb[2][4];
+                rb[0][0] = *(const f32x4*)h1r; rb[0][1] = *(const f32x4*)t1r;
+                rb[0][2] = *(const f32x4*)(h1r + HB); rb[0][3] = *(const f32x4*)(t1r + HB);
+                f32x4 acc[4][2];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) { acc[n][0] = zero4; acc[n][1] = zero4; }
+                const f32x4 bv2 = *(const f32x4*)(bias + s3::PH + 16 * wave + 4 * q);
+                // scalar rows of the PREVIOUS evaluation from its RED partials (complete since the barrier above)
+                if (stg > 1 && sown) sc_set(stg, read_scalars());              // slot j holds k_j
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (u + 1 < 8) {
+                        rb[(u + 1) & 1][0] = *(const f32x4*)(h1r + 16 * (u + 1));
+                        rb[(u + 1) & 1][1] = *(const f32x4*)(t1r + 16 * (u + 1));
+                        rb[(u + 1) & 1][2] = *(const f32x4*)(h1r + HB + 16 * (u + 1));
+                        rb[(u + 1) & 1][3] = *(const f32x4*)(t1r + HB + 16 * (u + 1));
+                    } else {
+                        s3_load<8>(aN, nrW);                                   // W3 rows of the next interval on their way
+                    }
+                    S3_SB();
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[n][c & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wF2[u][c], rb[u & 1][n][c], acc[n][c & 1], 0, 0, 0);
+                    }
+                    S3_SB();
+                }
+                const f32x4 hA = s3_tanh4(acc[0][0] + acc[0][1] + bv2), hB = s3_tanh4(acc[2][0] + acc[2][1] + bv2);
+                *(f32x4*)h2w = hA;
+                *(f32x4*)t2w = s3_dtanh4(hA) * (acc[1][0] + acc[1][1]);
+                *(f32x4*)(h2w + HB) = hB;
+                *(f32x4*)(t2w + HB) = s3_dtanh4(hB) * (acc[3][0] + acc[3][1]);
+            }
+            S3T(2);
+            s3_bar();                                                          // h2, t2 visible
+            S3T(3);
+            // ---- interval 2: last layer, one product per wave: rows r0..r0+3 of sample smp, state (0-3) / tangent (4-7)
+            {
+                f32x4 bA[8];
+                s3_load<8>(bA, nr3);
+                const f32x4 bv3 = *(const f32x4*)(bias + 2 * s3::PH + r0);
+                S3_SB();
+                f32x4 z0 = zero4, z1 = zero4;
+                s3_mm<0, 8>(z0, z1, aN, bA);
+                if (zown) {
+                    // stage sum without the k this evaluation will produce: pre = u + h sum_{j<stg} a_{stg+1,j} k_j
+                    const float* A = tab.a[stg < 6 ? stg + 1 : 6];
+                    f32x4 pre = *(const f32x4*)rkw + (hstep * A[0]) * *(const f32x4*)(rkw + 32);
+#pragma unroll
+                    for (int jj = 1; jj < 5; ++jj) pre += (hstep * A[jj]) * *(const f32x4*)(kzw + 32 * (jj - 1));
+                    const f32x4 zd = s3_tanh4(z0 + z1 + bv3);                  // padded rows: zero weights and bias -> 0
+                    *(f32x4*)g3w = s3_dtanh4(zd);                              // sigma'_3 for the tangent rows
+                    if (stg < 6) *(f32x4*)x0w = pre + (hstep * A[stg]) * zd;   // state of the next evaluation
+                    *(f32x4*)(kzw + 32 * (stg - 1)) = zd;                      // k_{stg+1}
+                    redw[0] = s3_dot4(zd, zd);
+                } else {
+                    tacc = z0 + z1;
+                }
+            }
+            S3T(4);
+            s3_bar();                                                          // sigma'_3 (and the next stage state) visible
+            S3T(5);
+        }
+        if (!zown) finish_tau();                           // of the last evaluation
+        S3T(18);
+        s3_bar();                                          // RED of the last evaluation complete
+        S3T(19);
+        // ---- error estimate and outputs: u_new (= the state evaluation 6 ran at) and k7 ----
+        if (live && zown) {
+            const f32x4 k7z = *(const f32x4*)(kzw + 32 * 5), uz_ = *(const f32x4*)rkw;
+            const f32x4 un = *(const f32x4*)x0w;           // U_7 = u_new: the state the last evaluation ran at
+            f32x4 ez = TS_BT1 * *(const f32x4*)(rkw + 32) + TS_BT7 * k7z;
+            ez += TS_BT2 * *(const f32x4*)(kzw) + TS_BT3 * *(const f32x4*)(kzw + 32) + TS_BT4 * *(const f32x4*)(kzw + 64) +
+                  TS_BT5 * *(const f32x4*)(kzw + 96) + TS_BT6 * *(const f32x4*)(kzw + 128);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                  // rows beyond n_in: u = k = 0 -> contribute exactly 0
+                const float scl = fmaf(fmaxf(fabsf(uz_[c]), fabsf(un[c])), reltol, abstol);
+                const float x = c < nv ? hstep * ez[c] / scl : 0.f;
+                errsum = fmaf(x, x, errsum);
+                badcnt += (c < nv && !(fabsf(un[c]) <= 3.0e38f)) ? 1.f : 0.f;
+            }
+            const size_t gc = (size_t)(tile * s3::NB + 16 * hf + s) * D;
+            float* Un = Uout + gc + r0;
+            float* K7 = K1out + gc + r0;
+            if (nv >= 4) {
+                Un[0] = un.x; Un[1] = un.y; Un[2] = un.z; Un[3] = un.w;
+                K7[0] = k7z.x; K7[1] = k7z.y; K7[2] = k7z.z; K7[3] = k7z.w;
+            } else { st4(Un, un, nv); st4(K7, k7z, nv); }
+        }
+        if (live && sown) {
+            f32x4 ks[7];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ks[j] = sc_get(1 + j);
+            const f32x4 us = sc_get(0);
+            ks[6] = read_scalars();                        // k7 of the scalar rows, straight from the partials
+            const f32x4 uns = us + hstep * stage_acc4<6>(ks);
+            err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
+            const size_t gc = (size_t)(tile * s3::NB + 16 * hf + s) * D;
+            float* Un = Uout + gc + n_in;
+            float* K7 = K1out + gc + n_in;
+            Un[0] = uns.x; Un[1] = uns.y; Un[2] = uns.z;
+            K7[0] = ks[6].x; K7[1] = ks[6].y; K7[2] = ks[6].z;
+        }
+        S3T(30);
+        S3T(31);
+        s3_bar();                                          // this tile's RED / SC / KZ reads precede the next tile's writes
+    }
+    // deterministic block reduction of the error partial (fixed tree, fixed order)
+    for (int off = 32; off > 0; off >>= 1) {
+        errsum += __shfl_down(errsum, off, 64);
+        badcnt += __shfl_down(badcnt, off, 64);
+    }
+    if (lane == 0) { msc[wave] = errsum; msc[16 + wave] = badcnt; }
+    s3_bar();
+    if (tid == 0) {
+        float e = 0.f, b = 0.f;
+        for (int w = 0; w < 8; ++w) { e += msc[w]; b += msc[16 + w]; }
+        a.partials[2 * blockIdx.x] = e;
+        a.partials[2 * blockIdx.x + 1] = b;
+    }
+}
+
+
 // Weight image of k_step3 (layout: namespace s3).  Fragment element (wave w, fragment j, lane = 16q + s, c):
 //   FR1 (waves 0-3): W1 rows: tile w + 4 (j >> 1), k-block j & 1:  W1[16 (w + 4 (j >> 1)) + s][16 (j & 1) + 4q + c]
 //   FR3 (all waves): W3^T rows:                                   W3[16 j + 4q + c][16 w + s]
@@ -609,4 +971,13 @@ void step3_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, 
         attr_set = true;
     }
     hipLaunchKernelGGL(k_step3, grid, dim3(512), (size_t)s3::TOTAL * sizeof(float), s, a, d_img3, n_in, norm_z, norm_j, kS3Tab);
+}
+
+void step3j_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_step3j, hipFuncAttributeMaxDynamicSharedMemorySize, s3::TOTAL * (int)sizeof(float));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_step3j, grid, dim3(512), s3::TOTAL * sizeof(float), s, a, d_img3, n_in, norm_z, norm_j, kS3Tab);
 }

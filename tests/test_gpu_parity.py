@@ -803,6 +803,34 @@ def test_exact_trace_mfma_deep_networks():
     assert_parity(logpx.cpu().numpy(), ref_lp, "config 3 TestMode logpx", rtol=2e-4)
 
 
+def test_jvp_mode_headline_shape_step_kernel():
+    """JVP compute mode on the headline network runs the fused step kernel k_step3j (one forward sweep of state and
+    tangent columns per evaluation): fixed-dt and adaptive solves against the oracles, ragged and multi-tile batches,
+    RNODE (all three scalar rows) and FFJORD (no norm rows)."""
+    for i, B in ((3, 77), (3, 1000), (4, 40)):
+        cfg, _, _ = O.baseline_cfg(i)
+        cfg.use_jvp = True
+        rng = np.random.default_rng(720 + B)
+        flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+        xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+        eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+        ic = make_icnf(cnf, cfg, jvp=True, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
+        prob = cnf.inference_prob(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+        fsol = cnf.base_sol(ic, prob).view().cpu().numpy()
+        assert prob.stats["kernel_used"] == _lib.KERNEL_MFMA and prob.stats["launches"] <= 8 + 4
+        u0 = O.inference_u0(cfg, xs, True)
+        ref, _ = O.tsit5_solve(cfg.rhs(flat.astype(np.float64), eps.astype(np.float64), True), u0.astype(np.float64),
+                               *cfg.tspan, dt=1 / 8, adaptive=False)
+        assert_parity(fsol, ref, f"cfg{i} JVP fixed-dt fsol B={B}", trace_row=cfg.n_in)
+        kw = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+        ia = make_icnf(cnf, cfg, jvp=True, kernel="mfma", sol_kwargs=kw)
+        pa = cnf.inference_prob(ia, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+        fa = cnf.base_sol(ia, pa).view().cpu().numpy()
+        cref, cst = CO.solve(cfg, flat, u0, eps, True, **kw)
+        assert abs(pa.stats["naccept"] - cst["naccept"]) <= 2, (pa.stats, cst)
+        assert_parity(fa, cref, f"cfg{i} JVP adaptive vs C oracle B={B}", rtol=5e-3, trace_row=cfg.n_in)
+
+
 def test_jvp_mode_large_network_on_mfma():
     """TrainMode with the JVP compute mode (src/icnf.jl:384-420) on config 5's 128-384-128 network, whose
     tangent images do not fit beside the weights in the fused step kernel: the forward sweep with the
