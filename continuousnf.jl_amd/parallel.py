@@ -71,8 +71,16 @@ class RcclComm:
         the group broadcasts the 128 bytes."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        uid, err = None, None
+        if rank == 0:
+            try:
+                uid = cls.unique_id()
+            except Exception as e:                      # noqa: BLE001 -- rank 0 must still reach the broadcast:
+                err = e                                 # the other ranks are waiting in it
+        box = [uid]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if box[0] is None:                              # every rank fails together
+            raise RuntimeError(f"rank 0 could not draw an RCCL id: {err}" if rank == 0 else "rank 0 could not draw an RCCL id")
         return cls(world, rank, box[0], device)
 
     def size(self) -> int:
