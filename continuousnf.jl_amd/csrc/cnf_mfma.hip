@@ -162,9 +162,6 @@ __device__ __forceinline__ void for_layers_down(const LY& ly, F&& f) {
 
 // ---- activation helpers ------------------------------------------------------------------
 __device__ __forceinline__ void act_fast(int kind, float a, float& h, float& d) {
-#ifdef MF_ABL_NOACT
-    h = a; d = 1.0f; return;
-#endif
     if (kind == 1) { h = tanh_fast(a); d = fmaf(-h, h, 1.0f); }
     else cnf_act(kind, a, h, d);
 }
@@ -204,56 +201,6 @@ __device__ __forceinline__ f32x4 mfma4(const f32x4& a, const f32x4& b, f32x4 c) 
 template <int NTL>
 __device__ __forceinline__ void mfma_block(f32x4& acc0, f32x4& acc1, const f32x4& b, const f32x4& a0,
                                            const f32x4& a1) {
-#ifdef MF_ABL_NOMFMA
-    acc0 += a0 * b; if (NTL == 2) acc1 += a1 * b; return;
-#endif
-#ifdef MF_ABL_SAMEREG
-    {   // MFMAs depend on the loaded B operand only (A = B register): isolates operand-fetch effects
-        asm volatile("" ::"v"(a0));
-        if (NTL == 2) asm volatile("" ::"v"(a1));
-        for (int i = 0; i < 4; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i], b[i], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i], b[i], acc1, 0, 0, 0);
-        }
-        return;
-    }
-#endif
-#ifdef MF_ABL_AONLY
-    {   // MFMAs depend on the loaded A operands only
-        asm volatile("" ::"v"(b));
-        for (int i = 0; i < 4; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], a0[i], acc0, 0, 0, 0);
-            if (NTL == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], a1[i], acc1, 0, 0, 0);
-            else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], a0[i], acc1, 0, 0, 0);
-        }
-        return;
-    }
-#endif
-#ifdef MF_ABL_TWOCONST
-    {   // loads stay live, MFMAs run on two different constant register sets
-        asm volatile("" ::"v"(a0), "v"(b));
-        if (NTL == 2) asm volatile("" ::"v"(a1));
-        f32x4 ca = {1.f, 2.f, 3.f, 4.f}, cb = {5.f, 6.f, 7.f, 8.f};
-        asm volatile("" : "+v"(ca), "+v"(cb));
-        for (int i = 0; i < 4; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[i], cb[i], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[i], cb[i], acc1, 0, 0, 0);
-        }
-        return;
-    }
-#endif
-#ifdef MF_ABL_NODEP
-    {   // loads stay live (asm sink) but the MFMAs run on constants
-        asm volatile("" ::"v"(a0), "v"(b));
-        if (NTL == 2) asm volatile("" ::"v"(a1));
-        const f32x4 c = {1.f, 2.f, 3.f, 4.f};
-        for (int i = 0; i < 4; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c[i], c[i], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c[i], c[i], acc1, 0, 0, 0);
-        }
-        return;
-    }
-#endif
     if (NTL == 2) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -299,11 +246,6 @@ __device__ __forceinline__ void fwd_body(f32x4& acc0, f32x4& acc1, const float* 
 template <int NU, int NTL>
 __device__ __forceinline__ void bwd_body(f32x4& acc0, f32x4& acc1, int SW, const float* gb,
                                          const float* wc0, const float* wc1) {
-#ifdef MF_ABL_NOLOAD
-    { f32x4 c = {1.f, 2.f, 3.f, 4.f};
-      for (int u = 0; u < NU; ++u) mfma_block<NTL>(acc0, acc1, c, c, c);
-      return; }
-#endif
     f32x4 b[3], a0[3], a1[3];
 #pragma unroll
     for (int u = 0; u < 2 && u < NU; ++u) {
@@ -370,14 +312,8 @@ __device__ __forceinline__ void gemm_bwd(f32x4& acc0, f32x4& acc1, int U, int SW
     }
 }
 
-// Phase barrier of the workgroup (both teams).  Team-local LDS barriers and a ping-pong of the two
-// teams were measured slower and are gone.
-__device__ __forceinline__ void team_barrier(unsigned*, unsigned&, int) {
-#ifdef MF_ABL_NOBAR
-    return;
-#endif
-    __syncthreads();
-}
+// Phase barrier of the workgroup (both teams).
+__device__ __forceinline__ void phase_barrier() { __syncthreads(); }
 
 
 // ---- epilogues ---------------------------------------------------------------------------------
@@ -456,7 +392,7 @@ __device__ __forceinline__ void bwd_epilogue(const LY& ly, float* lds, int l, in
 #endif
 template <int WPT, class LY, class F>
 __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* wimg, int lane, int wave,
-                                         unsigned* bar, unsigned& gen, f32x4& zd0, f32x4& zd1,
+                                         f32x4& zd0, f32x4& zd1,
                                          F&& after_zdot, const float* cimg, int SWC,
                                          const float* cbrow STAMP_ARGS) {
     // wimg: where the weight image is read from -- the LDS copy, or (networks too large for
@@ -522,7 +458,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
                     }
                 }
                 if (last) after_zdot();
-                team_barrier(bar, gen, lane);
+                phase_barrier();
             }
             return;
         }
@@ -568,7 +504,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
         // one barrier off the critical path of every stage
         if (last) after_zdot();
         STAMP(17 + 3 * (int)l);
-        team_barrier(bar, gen, lane);
+        phase_barrier();
         STAMP(18 + 3 * (int)l);
     });
     if (cimg) {
@@ -598,7 +534,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
         }
         trp = quad_sum(trp);
         if (q == 0) lds[ly.red_off() + fg * MF_NB + row] = -trp;      // one partial per wave of the team
-        team_barrier(bar, gen, lane);
+        phase_barrier();
         return;
     }
     // ---- reverse (VJP): g_l = (W_{l+1}^T g_{l+1}) .* sigma'_l, in place over h_l ----
@@ -648,7 +584,7 @@ __device__ __forceinline__ void rhs_tile(const LY& ly, float* lds, const float* 
             if (two) bwd_epilogue(ly, lds, l, t1, acc1, row, q);
         }
         STAMP(33 + 3 * (int)l);
-        team_barrier(bar, gen, lane);
+        phase_barrier();
         STAMP(34 + 3 * (int)l);
     });
 }
@@ -895,7 +831,6 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
 
     int cur = 0, nacc = 0;
     float hstep = 0.f, abstol = 0.f, reltol = 0.f;
-    unsigned gen = 0;
     // Runge-Kutta state of this lane's z rows (accumulator layout)
     f32x4 uz0 = {0.f, 0.f, 0.f, 0.f}, uz1 = uz0, kz0[7], kz1[7], un0 = uz0, un1 = uz0;
     if (STEP && a.apply_ctrl) {
@@ -946,7 +881,6 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
     const float* Uin = mode == 0 ? a.u : (cur ? a.U[1] : a.U[0]);
     const float* K1in = mode == 0 ? nullptr : (cur ? a.K1[1] : a.K1[0]);
     float errsum = 0.f, badcnt = 0.f;
-    unsigned* bar = (unsigned*)(lds + ly.bar_off()) + team;
 #ifdef MF_STAMPS
     unsigned long long stamps[48] = {0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
@@ -1030,7 +964,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
             return f32x4{ld, ly.norm_z() ? __builtin_sqrtf(e2) : 0.f, ly.norm_j() ? __builtin_sqrtf(n2) : 0.f, 0.f};
         };
         put_stage(1);
-        team_barrier(bar, gen, lane);
+        phase_barrier();
         STAMP(0);
         for (int stg = 1; stg <= nstage; ++stg) {
             // scalar rows of the PREVIOUS evaluation, from its RED partials (RED[0] is
@@ -1047,7 +981,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                 rhs_tile_stream<WPT>(ly, lds, wimg, lane, wave, zd0, zd1, after_zdot, a.test ? a.cimg : nullptr, a.SWC,
                                      cbrow, pre);
             else
-                rhs_tile<WPT>(ly, lds, wimg, lane, wave, bar, gen, zd0, zd1, after_zdot, a.test ? a.cimg : nullptr, a.SWC,
+                rhs_tile<WPT>(ly, lds, wimg, lane, wave, zd0, zd1, after_zdot, a.test ? a.cimg : nullptr, a.SWC,
                               cbrow STAMP_PASS);
         }
         // scalar rows of the last evaluation (rhs_tile ended with a barrier)
@@ -1104,7 +1038,7 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
             }
         }
         // this team's RED / EPS reads of this tile precede its next-tile writes
-        team_barrier(bar, gen, lane);
+        phase_barrier();
     }
 #ifdef MF_STAMPS
     STAMP(14);
@@ -1375,17 +1309,25 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
     MfmaArgs a = a0;
     if (a.test) { a.cimg = p.d_img + p.ly.c_off; a.SWC = p.ly.SWC; }
     a.cond = p.cond; a.cbs = p.cbs;
-    // k_step3j: JVP handles of the headline shape -- and VJP handles WITHOUT the |eps^T J| row (FFJORD): zdot and
-    // ldot = -eps.(J eps) = -(eps^T J).eps do not depend on the mode, and one forward sweep of two column tiles is the
-    // shorter schedule (3 barrier intervals per evaluation instead of 9)
-    const bool j3 = a.mode == 2 && (step3j_route(p, !a.test, a.dump != nullptr) ||
-                                    (p.variant == 2 && !p.ly.norm_j && !a.test && !a.cond && !a.dump && p.d_img3 && !step_v1()));
-    const dim3 grid(j3 ? step3_grid_for(a.B) : base_grid_for(p, a.B)), block(MF_KTHREADS);
+    // Resident-fragment kernels of the headline shape (cnf_step3.hip).  k_step3j: JVP handles -- and VJP handles WITHOUT the
+    // |eps^T J| row (FFJORD): zdot and ldot = -eps.(J eps) = -(eps^T J).eps do not depend on the mode, and one forward sweep
+    // of two column tiles is the shorter schedule.  k_step3: VJP handles with that row.  They take the step attempts
+    // (mode 2) and the two single evaluations of the automatic initial dt (modes 0 / 1 with an init phase).
+    const bool s3ok = !a.test && !a.cond && !a.dump && p.d_img3 && !step_v1();
+    const bool use_j = s3ok && ((p.shape3 && p.ly.jvp) || (p.variant == 2 && !p.ly.norm_j));
+    const bool use_v = s3ok && !use_j && p.variant == 2;
+    const int single = a.mode == 2 ? 0 : ((a.st && a.init_phase >= 0) ? a.mode + 1 : -1);     // -1: not theirs
+    const bool s3 = (use_j || use_v) && single >= 0;
+    const dim3 grid(s3 ? step3_grid_for(a.B) : base_grid_for(p, a.B)), block(MF_KTHREADS);
     const size_t shm = (size_t)p.ly.total_floats * sizeof(float);
     const bool narrow = narrow_tiles(p);
-    if (j3) {
-        // JVP compute mode on the headline shape: 32-sample tiles whatever the run-time layout chose
-        step3j_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s);
+    if (s3) {
+        if (a.mode == 0) {      // f(u): the kernel reads its state through the buffer-set pointers (k1 is masked out)
+            a.U[0] = a.U[1] = const_cast<float*>(a.u);
+            a.K1[0] = a.K1[1] = a.du;
+        }
+        if (use_j) step3j_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, single);
+        else step3_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, single);
     }
     else if (narrow && p.variant != 5) {
         RtLayout ly{p.ly};
@@ -1399,8 +1341,6 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
         if (a.mode == 2) hipLaunchKernelGGL((k_mfma<RtLayout, true>), grid, block, shm, s, ly, a);
         else hipLaunchKernelGGL((k_mfma<RtLayout, false>), grid, block, shm, s, ly, a);
     }
-    else if (p.variant == 2 && a.mode == 2 && !a.test && !a.cond && !a.dump && p.d_img3 && !step_v1())
-        step3_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s);
     else if (p.variant == 2) launch_static<LyCfg3>(p, a, grid, s);
     else if (p.variant == 3) launch_static<LyCfg2>(p, a, grid, s);
     else if (p.variant == 4) launch_static<LyCfg1>(p, a, grid, s);

@@ -6,7 +6,10 @@ size_t step3_img_floats();
 // register-fragment weight image from the flat parameter vector
 void step3_pack(const NetDesc& nd, const float* d_params, float* d_img3, hipStream_t s);
 // one step attempt (MfmaArgs as for k_mfma mode 2; no cond, no dump, TrainMode)
-void step3_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s);
+// single: 0 = a step attempt; 1 / 2 = ONE evaluation, the first / second launch of the automatic initial dt
+// (f(u) -> a.du with the norms of phase 0; f(u + h k1) -> a.Ks0 with the norm of phase 1; a.st, a.st_out, a.partials,
+// a.ticket, a.n_total as for k_mfma's modes 0 / 1 with init_phase 0 / 1)
+void step3_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single = 0);
 // the same for the JVP compute mode (k_step3j); also exact for VJP handles without the |eps^T J| row (norm_j == 0):
 // ldot = -eps.(J eps) = -(eps^T J).eps and zdot do not depend on the mode
-void step3j_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s);
+void step3j_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single = 0);

@@ -132,7 +132,7 @@ __device__ __forceinline__ float s3_dot4(const f32x4& a, const f32x4& b) {
 #endif
 
 __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __restrict__ img3, int n_in, int norm_z,
-                                                  int norm_j, const S3Tab tab) {
+                                                  int norm_j, const S3Tab tab, int single) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StepState* st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -286,6 +286,11 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
     }
     // (explicit selects: indexing the kernel-argument arrays with a run-time value makes the compiler fetch the
     // pointer from the argument segment through a vector load -- a memory round trip in front of the state loads)
+    // single != 0: ONE evaluation instead of a step attempt -- the two launches of the automatic initial dt
+    // (1: f(u) -> a.du with the norms of phase 0; 2: f(u + h k1) -> a.Ks0 with the norm of phase 1), same prologue,
+    // same evaluation code; the last workgroup to finish runs the controller phase (as k_mfma does for them)
+    const int nstg = single ? 1 : 6;
+    const float c21 = single == 1 ? 0.f : (single == 2 ? 1.f : TS_A21);
     const float* Uin = cur ? a.U[1] : a.U[0];
     const float* K1in = cur ? a.K1[1] : a.K1[0];
     float* Uout = cur ? a.U[0] : a.U[1];
@@ -334,6 +339,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
             uz = ld4_mask(cur ? ru[1] : ru[0], cu);
             k1z = ld4_mask(cur ? rk[1] : rk[0], cu);
             if (sown) { sc_set(0, sc_get(cur ? 4 : 2)); sc_set(1, sc_get(cur ? 5 : 3)); }
+            if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }     // there is no k1 yet
         } else {
             ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
             const f32x4 e_ = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
@@ -341,9 +347,10 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
             const f32x4 s0 = ld4_issue(Uin + gcol + n_in, cs, img3), s1 = ld4_issue(K1in + gcol + n_in, cs, img3);
             *(f32x4*)epw = ld4_mask(e_, ce); uz = ld4_mask(u_, cu); k1z = ld4_mask(k_, cu);
             if (sown) { sc_set(0, ld4_mask(s0, cs)); sc_set(1, ld4_mask(s1, cs)); }
+            if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }
         }
         if (zown) {
-            *(f32x4*)x0w = uz + (hstep * TS_A21) * k1z;   // state of evaluation 1: U_2 = u + h a21 k1
+            *(f32x4*)x0w = uz + (hstep * c21) * k1z;      // state of evaluation 1: U_2 = u + h a21 k1
             *(f32x4*)rkw = uz;
             *(f32x4*)(rkw + 32) = k1z;
 #pragma unroll
@@ -366,7 +373,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
             redw[2 * s3::NB * 8] = s3_dot4(ej, ej);
         };
 
-        for (int stg = 1; stg <= 6; ++stg) {
+        for (int stg = 1; stg <= nstg; ++stg) {
             f32x4 bA[8], bB[8];
             f32x4 p0, p1, r0_, r1_;
             // ---- interval 0: first layer (waves 0-3: tiles w and w+4, both halves) || eJ of the previous evaluation (4-7)
@@ -494,8 +501,37 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
         S3T(18);
         s3_bar();                                          // RED of the last evaluation complete
         S3T(19);
+        if (single) {
+            // ---- one evaluation: f -> out, and the norms of the initial-dt phase over the rows this lane owns ----
+            float* out = (single == 1 ? a.du : a.Ks0) + (size_t)(tile * s3::NB + 16 * hf + s) * D;
+            auto norms = [&](const f32x4& u4, const f32x4& f0, const f32x4& f1, int nvalid) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < nvalid) {
+                        const float sk = fmaf(fabsf(u4[c]), reltol, abstol);
+                        if (single == 1) {
+                            const float x = u4[c] / sk, y = f1[c] / sk;
+                            errsum = fmaf(x, x, errsum); badcnt = fmaf(y, y, badcnt);
+                        } else {
+                            const float x = (f1[c] - f0[c]) / sk;
+                            errsum = fmaf(x, x, errsum);
+                        }
+                    }
+                }
+            };
+            if (live && zown) {
+                const f32x4 f1 = *(const f32x4*)kzw;                    // k2 slot = this evaluation's zdot
+                st4(out + r0, f1, nv);
+                norms(*(const f32x4*)rkw, *(const f32x4*)(rkw + 32), f1, nv);
+            }
+            if (live && sown) {
+                const f32x4 f1 = read_scalars();
+                out[n_in] = f1.x; out[n_in + 1] = f1.y; out[n_in + 2] = f1.z;
+                norms(sc_get(0), sc_get(1), f1, 3);
+            }
+        }
         // ---- error estimate and outputs: u_new (= the state evaluation 6 ran at) and k7 ----
-        if (live && zown) {
+        if (!single && live && zown) {
             const f32x4 k7z = *(const f32x4*)(kzw + 32 * 5), uz_ = *(const f32x4*)rkw;
             const f32x4 un = *(const f32x4*)x0w;           // U_7 = u_new: the state the last evaluation ran at
             f32x4 ez = TS_BT1 * *(const f32x4*)(rkw + 32) + TS_BT7 * k7z;
@@ -516,7 +552,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
                 K7[0] = k7z.x; K7[1] = k7z.y; K7[2] = k7z.z; K7[3] = k7z.w;
             } else { st4(Un, un, nv); st4(K7, k7z, nv); }
         }
-        if (live && sown) {
+        if (!single && live && sown) {
             f32x4 ks[7];
 #pragma unroll
             for (int j = 0; j < 6; ++j) ks[j] = sc_get(1 + j);
@@ -544,8 +580,37 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
     if (tid == 0) {
         float e = 0.f, b = 0.f;
         for (int w = 0; w < 8; ++w) { e += msc[w]; b += msc[16 + w]; }
-        a.partials[2 * blockIdx.x] = e;
-        a.partials[2 * blockIdx.x + 1] = b;
+        if (!single) {
+            a.partials[2 * blockIdx.x] = e;
+            a.partials[2 * blockIdx.x + 1] = b;
+        } else {
+            // initial-dt phase: partials through agent-scope atomics, then a ticket; whoever draws the last one sums all
+            // partials (fixed order) and runs the controller phase -- no separate launches
+            __hip_atomic_store(a.partials + 2 * blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.partials + 2 * blockIdx.x + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            msc[40] = (tk == gridDim.x - 1) ? 1.f : 0.f;
+            if (tk == gridDim.x - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (single) {
+        s3_bar();
+        if (msc[40] != 0.f) {                        // this workgroup drew the last ticket: all its threads reduce
+            float q0 = 0.f, q1 = 0.f;
+            for (int i = tid; i < (int)gridDim.x; i += 512) {
+                q0 += __hip_atomic_load(a.partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q1 += __hip_atomic_load(a.partials + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (int off = 32; off > 0; off >>= 1) { q0 += __shfl_down(q0, off, 64); q1 += __shfl_down(q1, off, 64); }
+            if (lane == 0) { msc[wave] = q0; msc[16 + wave] = q1; }
+            s3_bar();
+            if (tid == 0) {
+                float p0 = 0.f, p1 = 0.f;
+                for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
+                ctrl_phase(a.st_out, single - 1, p0, p1, a.n_total);
+            }
+        }
     }
 #ifdef S3_STAMPS
     S3T(21);
@@ -572,7 +637,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
 // Three dependent products instead of six: 3 barrier intervals per evaluation, no reverse fragments, no W2 staging.
 // Prologue, controller, Runge-Kutta bookkeeping and outputs are those of k_step3.
 __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __restrict__ img3, int n_in, int norm_z,
-                                                  int norm_j, const S3Tab tab) {
+                                                  int norm_j, const S3Tab tab, int single) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StepState* st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -701,6 +766,11 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
     }
     // (explicit selects: indexing the kernel-argument arrays with a run-time value makes the compiler fetch the
     // pointer from the argument segment through a vector load -- a memory round trip in front of the state loads)
+    // single != 0: ONE evaluation instead of a step attempt -- the two launches of the automatic initial dt
+    // (1: f(u) -> a.du with the norms of phase 0; 2: f(u + h k1) -> a.Ks0 with the norm of phase 1), same prologue,
+    // same evaluation code; the last workgroup to finish runs the controller phase (as k_mfma does for them)
+    const int nstg = single ? 1 : 6;
+    const float c21 = single == 1 ? 0.f : (single == 2 ? 1.f : TS_A21);
     const float* Uin = cur ? a.U[1] : a.U[0];
     const float* K1in = cur ? a.K1[1] : a.K1[0];
     float* Uout = cur ? a.U[0] : a.U[1];
@@ -750,6 +820,7 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
             uz = ld4_mask(cur ? ru[1] : ru[0], cu);
             k1z = ld4_mask(cur ? rk[1] : rk[0], cu);
             if (sown) { sc_set(0, sc_get(cur ? 4 : 2)); sc_set(1, sc_get(cur ? 5 : 3)); }
+            if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }     // there is no k1 yet
         } else {
             ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
             const f32x4 e_ = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
@@ -757,9 +828,10 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
             const f32x4 s0 = ld4_issue(Uin + gcol + n_in, cs, img3), s1 = ld4_issue(K1in + gcol + n_in, cs, img3);
             *(f32x4*)epw = ld4_mask(e_, ce); uz = ld4_mask(u_, cu); k1z = ld4_mask(k_, cu);
             if (sown) { sc_set(0, ld4_mask(s0, cs)); sc_set(1, ld4_mask(s1, cs)); }
+            if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }
         }
         if (zown) {
-            *(f32x4*)x0w = uz + (hstep * TS_A21) * k1z;   // state of evaluation 1: U_2 = u + h a21 k1
+            *(f32x4*)x0w = uz + (hstep * c21) * k1z;      // state of evaluation 1: U_2 = u + h a21 k1
             *(f32x4*)rkw = uz;
             *(f32x4*)(rkw + 32) = k1z;
 #pragma unroll
@@ -778,7 +850,7 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
             redw[2 * s3::NB * 8] = s3_dot4(tj, tj);
         };
 
-        for (int stg = 1; stg <= 6; ++stg) {
+        for (int stg = 1; stg <= nstg; ++stg) {
             // ---- interval 0: first layer, tile `wave`, both halves, state and tangent columns (K = 32)
             {
                 f32x4 bh[4], bt[4];
@@ -872,8 +944,37 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
         S3T(18);
         s3_bar();                                          // RED of the last evaluation complete
         S3T(19);
+        if (single) {
+            // ---- one evaluation: f -> out, and the norms of the initial-dt phase over the rows this lane owns ----
+            float* out = (single == 1 ? a.du : a.Ks0) + (size_t)(tile * s3::NB + 16 * hf + s) * D;
+            auto norms = [&](const f32x4& u4, const f32x4& f0, const f32x4& f1, int nvalid) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < nvalid) {
+                        const float sk = fmaf(fabsf(u4[c]), reltol, abstol);
+                        if (single == 1) {
+                            const float x = u4[c] / sk, y = f1[c] / sk;
+                            errsum = fmaf(x, x, errsum); badcnt = fmaf(y, y, badcnt);
+                        } else {
+                            const float x = (f1[c] - f0[c]) / sk;
+                            errsum = fmaf(x, x, errsum);
+                        }
+                    }
+                }
+            };
+            if (live && zown) {
+                const f32x4 f1 = *(const f32x4*)kzw;                    // k2 slot = this evaluation's zdot
+                st4(out + r0, f1, nv);
+                norms(*(const f32x4*)rkw, *(const f32x4*)(rkw + 32), f1, nv);
+            }
+            if (live && sown) {
+                const f32x4 f1 = read_scalars();
+                out[n_in] = f1.x; out[n_in + 1] = f1.y; out[n_in + 2] = f1.z;
+                norms(sc_get(0), sc_get(1), f1, 3);
+            }
+        }
         // ---- error estimate and outputs: u_new (= the state evaluation 6 ran at) and k7 ----
-        if (live && zown) {
+        if (!single && live && zown) {
             const f32x4 k7z = *(const f32x4*)(kzw + 32 * 5), uz_ = *(const f32x4*)rkw;
             const f32x4 un = *(const f32x4*)x0w;           // U_7 = u_new: the state the last evaluation ran at
             f32x4 ez = TS_BT1 * *(const f32x4*)(rkw + 32) + TS_BT7 * k7z;
@@ -894,7 +995,7 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
                 K7[0] = k7z.x; K7[1] = k7z.y; K7[2] = k7z.z; K7[3] = k7z.w;
             } else { st4(Un, un, nv); st4(K7, k7z, nv); }
         }
-        if (live && sown) {
+        if (!single && live && sown) {
             f32x4 ks[7];
 #pragma unroll
             for (int j = 0; j < 6; ++j) ks[j] = sc_get(1 + j);
@@ -922,8 +1023,37 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
     if (tid == 0) {
         float e = 0.f, b = 0.f;
         for (int w = 0; w < 8; ++w) { e += msc[w]; b += msc[16 + w]; }
-        a.partials[2 * blockIdx.x] = e;
-        a.partials[2 * blockIdx.x + 1] = b;
+        if (!single) {
+            a.partials[2 * blockIdx.x] = e;
+            a.partials[2 * blockIdx.x + 1] = b;
+        } else {
+            // initial-dt phase: partials through agent-scope atomics, then a ticket; whoever draws the last one sums all
+            // partials (fixed order) and runs the controller phase -- no separate launches
+            __hip_atomic_store(a.partials + 2 * blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.partials + 2 * blockIdx.x + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            msc[40] = (tk == gridDim.x - 1) ? 1.f : 0.f;
+            if (tk == gridDim.x - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (single) {
+        s3_bar();
+        if (msc[40] != 0.f) {                        // this workgroup drew the last ticket: all its threads reduce
+            float q0 = 0.f, q1 = 0.f;
+            for (int i = tid; i < (int)gridDim.x; i += 512) {
+                q0 += __hip_atomic_load(a.partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q1 += __hip_atomic_load(a.partials + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (int off = 32; off > 0; off >>= 1) { q0 += __shfl_down(q0, off, 64); q1 += __shfl_down(q1, off, 64); }
+            if (lane == 0) { msc[wave] = q0; msc[16 + wave] = q1; }
+            s3_bar();
+            if (tid == 0) {
+                float p0 = 0.f, p1 = 0.f;
+                for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
+                ctrl_phase(a.st_out, single - 1, p0, p1, a.n_total);
+            }
+        }
     }
 }
 
@@ -963,21 +1093,21 @@ void step3_pack(const NetDesc& nd, const float* d_params, float* d_img3, hipStre
     hipLaunchKernelGGL(k_pack_step3, dim3((s3::IMG_FLOATS + 255) / 256), dim3(256), 0, s, nd, d_params, d_img3);
 }
 
-void step3_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s) {
+void step3_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_step3, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(s3::TOTAL * sizeof(float)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_step3, grid, dim3(512), (size_t)s3::TOTAL * sizeof(float), s, a, d_img3, n_in, norm_z, norm_j, kS3Tab);
+    hipLaunchKernelGGL(k_step3, grid, dim3(512), (size_t)s3::TOTAL * sizeof(float), s, a, d_img3, n_in, norm_z, norm_j, kS3Tab, single);
 }
 
-void step3j_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s) {
+void step3j_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)k_step3j, hipFuncAttributeMaxDynamicSharedMemorySize, s3::TOTAL * (int)sizeof(float));
         attr = true;
     }
-    hipLaunchKernelGGL(k_step3j, grid, dim3(512), s3::TOTAL * sizeof(float), s, a, d_img3, n_in, norm_z, norm_j, kS3Tab);
+    hipLaunchKernelGGL(k_step3j, grid, dim3(512), s3::TOTAL * sizeof(float), s, a, d_img3, n_in, norm_z, norm_j, kS3Tab, single);
 }
