@@ -1227,6 +1227,8 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
 void mfma_plan_free(MfmaPlan& p) {
     if (p.d_img) (void)hipFree(p.d_img);
     if (p.d_img3) (void)hipFree(p.d_img3);
+    if (p.d_idle) (void)hipFree(p.d_idle);
+    p.d_idle = nullptr;
     p.d_img = nullptr;
     p.d_img3 = nullptr;
 }
@@ -1256,6 +1258,10 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
                        d_params, p.d_img);
     if (p.variant == 2 || p.shape3) {       // headline shape: register-fragment image of k_step3 / k_step3j
         if (!p.d_img3 && hipMalloc(&p.d_img3, step3_img_floats() * sizeof(float)) != hipSuccess) return CNF_ERR_HIP;
+        if (!p.d_idle) {
+            if (hipMalloc(&p.d_idle, sizeof(StepState)) != hipSuccess) return CNF_ERR_HIP;
+            if (hipMemsetAsync(p.d_idle, 0, sizeof(StepState), s) != hipSuccess) return CNF_ERR_HIP;
+        }
         step3_pack(nd, d_params, p.d_img3, s);
     }
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
@@ -1316,7 +1322,11 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
     const bool s3ok = !a.test && !a.cond && !a.dump && p.d_img3 && !step_v1();
     const bool use_j = s3ok && ((p.shape3 && p.ly.jvp) || (p.variant == 2 && !p.ly.norm_j));
     const bool use_v = s3ok && !use_j && p.variant == 2;
-    const int single = a.mode == 2 ? 0 : ((a.st && a.init_phase >= 0) ? a.mode + 1 : -1);     // -1: not theirs
+    // single evaluations: the two launches of the automatic initial dt (modes 0 / 1 with an init phase) and, for JVP
+    // handles, the plain evaluation of cnf_rhs (mode 0 without an integrator state: it reads a zeroed one).  The plain
+    // VJP evaluation stays on k_mfma: measured 14.9 us there against 16.5 us here (the heavier prologue), JVP 50 against 14.6.
+    int single = a.mode == 2 ? 0 : ((a.st && a.init_phase >= 0) ? a.mode + 1 : -1);            // -1: not theirs
+    if (a.mode == 0 && !a.st && a.init_phase < 0 && p.d_idle && p.ly.jvp) { single = 1; a.st = p.d_idle; }
     const bool s3 = (use_j || use_v) && single >= 0;
     const dim3 grid(s3 ? step3_grid_for(a.B) : base_grid_for(p, a.B)), block(MF_KTHREADS);
     const size_t shm = (size_t)p.ly.total_floats * sizeof(float);

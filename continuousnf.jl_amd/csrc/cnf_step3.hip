@@ -522,12 +522,12 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
             if (live && zown) {
                 const f32x4 f1 = *(const f32x4*)kzw;                    // k2 slot = this evaluation's zdot
                 st4(out + r0, f1, nv);
-                norms(*(const f32x4*)rkw, *(const f32x4*)(rkw + 32), f1, nv);
+                if (a.init_phase >= 0) norms(*(const f32x4*)rkw, *(const f32x4*)(rkw + 32), f1, nv);
             }
             if (live && sown) {
                 const f32x4 f1 = read_scalars();
                 out[n_in] = f1.x; out[n_in + 1] = f1.y; out[n_in + 2] = f1.z;
-                norms(sc_get(0), sc_get(1), f1, 3);
+                if (a.init_phase >= 0) norms(sc_get(0), sc_get(1), f1, 3);
             }
         }
         // ---- error estimate and outputs: u_new (= the state evaluation 6 ran at) and k7 ----
@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
         if (!single) {
             a.partials[2 * blockIdx.x] = e;
             a.partials[2 * blockIdx.x + 1] = b;
-        } else {
+        } else if (a.init_phase >= 0) {
             // initial-dt phase: partials through agent-scope atomics, then a ticket; whoever draws the last one sums all
             // partials (fixed order) and runs the controller phase -- no separate launches
             __hip_atomic_store(a.partials + 2 * blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -594,7 +594,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
             if (tk == gridDim.x - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (single) {
+    if (single && a.init_phase >= 0) {
         s3_bar();
         if (msc[40] != 0.f) {                        // this workgroup drew the last ticket: all its threads reduce
             float q0 = 0.f, q1 = 0.f;
@@ -965,12 +965,12 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
             if (live && zown) {
                 const f32x4 f1 = *(const f32x4*)kzw;                    // k2 slot = this evaluation's zdot
                 st4(out + r0, f1, nv);
-                norms(*(const f32x4*)rkw, *(const f32x4*)(rkw + 32), f1, nv);
+                if (a.init_phase >= 0) norms(*(const f32x4*)rkw, *(const f32x4*)(rkw + 32), f1, nv);
             }
             if (live && sown) {
                 const f32x4 f1 = read_scalars();
                 out[n_in] = f1.x; out[n_in + 1] = f1.y; out[n_in + 2] = f1.z;
-                norms(sc_get(0), sc_get(1), f1, 3);
+                if (a.init_phase >= 0) norms(sc_get(0), sc_get(1), f1, 3);
             }
         }
         // ---- error estimate and outputs: u_new (= the state evaluation 6 ran at) and k7 ----
@@ -1026,7 +1026,7 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
         if (!single) {
             a.partials[2 * blockIdx.x] = e;
             a.partials[2 * blockIdx.x + 1] = b;
-        } else {
+        } else if (a.init_phase >= 0) {
             // initial-dt phase: partials through agent-scope atomics, then a ticket; whoever draws the last one sums all
             // partials (fixed order) and runs the controller phase -- no separate launches
             __hip_atomic_store(a.partials + 2 * blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1037,7 +1037,7 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
             if (tk == gridDim.x - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (single) {
+    if (single && a.init_phase >= 0) {
         s3_bar();
         if (msc[40] != 0.f) {                        // this workgroup drew the last ticket: all its threads reduce
             float q0 = 0.f, q1 = 0.f;
