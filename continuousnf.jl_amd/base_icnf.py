@@ -535,14 +535,15 @@ def inference(icnf: ICNF, mode, xs, *args, eps=None, with_sums=False):
         else:
             eb = None                           # TestMode: exact trace, no probes
         t = xb.torch
-        logpx = t.empty(B, dtype=t.float32, device=xb.arr.device)
-        regs = t.empty(3 * B, dtype=t.float32, device=xb.arr.device)
+        # one allocation for the three outputs (logpx | regs | sums): the allocator call is the slowest line of this path
+        buf = t.empty(4 * B + 8, dtype=t.float32, device=xb.arr.device)
+        logpx, regs = buf[:B], buf[B:4 * B]
         opts = _solve_opts(icnf, steer_tspan(icnf, mode))
         stats = _lib.cnf_solve_stats()
         l, h = _lib.lib(), icnf.handle()
         ep = eb.ptr if eb is not None else None
         if with_sums:
-            sums = t.empty(5, dtype=t.float32, device=xb.arr.device)
+            sums = buf[4 * B:4 * B + 5]
             _lib.check(l.cnf_inference_sums(h, m, xb.ptr, ep, logpx.data_ptr(), regs.data_ptr(), sums.data_ptr(), B,
                                             C.byref(opts), C.byref(stats), _stream(xb)), h)
         else:

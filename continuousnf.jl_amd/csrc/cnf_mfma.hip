@@ -140,6 +140,22 @@ struct StLayoutX {
 template <int ACT, int... PD>
 using StLayout = StLayoutX<true, ACT, PD...>;
 
+// streamed weights + tangent images (JVP compute mode): same formulas as mfma_plan_init with jvp = 1, wlds = 0
+template <int ACT, int... PD>
+struct StLayoutJ : StLayoutX<false, ACT, PD...> {
+    using B_ = StLayoutX<false, ACT, PD...>;
+    __host__ __device__ static constexpr bool jvp() { return true; }
+    __host__ __device__ static constexpr int tx_off(int l) {           // tau_l, l = 1 .. L-1 (tau_0 is the eps image)
+        int off = B_::du_off() + B_::kNB * sx_of(B_::pd(0));
+        for (int i = 1; i < l; ++i) off += B_::kNB * sx_of(B_::pd(i));
+        return off;
+    }
+    __host__ __device__ static constexpr int red_off() { return tx_off(B_::kL); }
+    __host__ __device__ static constexpr int sc_off() { return red_off() + B_::red_floats(); }
+    __host__ __device__ static constexpr int bar_off() { return sc_off() + MF_NB * 24; }
+    __host__ __device__ static constexpr int total_floats() { return bar_off() + 16; }
+};
+
 // layer loops: unrolled with compile-time indices for static layouts, plain loops otherwise
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for_up(F&& f) {
@@ -663,6 +679,124 @@ __device__ __forceinline__ void stream_sweep(const float* img, int SW, const flo
     });
 }
 
+// LDS-only workgroup barrier: __syncthreads() would also drain the weight fragments in flight
+__device__ __forceinline__ void stream_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// the same stream with TWO B operands per sample tile (state and tangent columns, JVP compute mode): 4 products per
+// k-block when the wave has two tiles in flight
+template <int NU, int NTL, bool NEXT_TWO>
+__device__ __forceinline__ void chain_body2(f32x4 (&acc)[4], const float* xh, const float* xt, const float* wa0,
+                                            const float* wa1, WPre& pre, const float* nw0, const float* nw1) {
+    static_assert(NU >= MF_AH, "a body must be at least as long as the prefetch distance");
+    constexpr int R = MF_AH + 1;
+    f32x4 a0[R], a1[R], bh[3], bt[3];
+#pragma unroll
+    for (int j = 0; j < MF_AH; ++j) { a0[j] = pre.a0[j]; if (NTL == 2) a1[j] = pre.a1[j]; }
+    bh[0] = *(const f32x4*)xh; bt[0] = *(const f32x4*)xt;
+    if (NU > 1) { bh[1] = *(const f32x4*)(xh + 16); bt[1] = *(const f32x4*)(xt + 16); }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u % R][c], bh[u % 3][c], acc[0], 0, 0, 0);     // tile 0, state
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u % R][c], bt[u % 3][c], acc[1], 0, 0, 0);     // tile 0, tangent
+            if (NTL == 2) {
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u % R][c], bh[u % 3][c], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u % R][c], bt[u % 3][c], acc[3], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + MF_AH < NU) {
+            a0[(u + MF_AH) % R] = *(const f32x4*)(wa0 + 16 * (u + MF_AH));
+            if (NTL == 2) a1[(u + MF_AH) % R] = *(const f32x4*)(wa1 + 16 * (u + MF_AH));
+        } else {
+            const int j = u + MF_AH - NU;
+            pre.a0[j] = *(const f32x4*)(nw0 + 16 * j);
+            if (NEXT_TWO) pre.a1[j] = *(const f32x4*)(nw1 + 16 * j);
+        }
+        if (u + 2 < NU) { bh[(u + 2) % 3] = *(const f32x4*)(xh + 16 * (u + 2)); bt[(u + 2) % 3] = *(const f32x4*)(xt + 16 * (u + 2)); }
+    }
+}
+
+// rhs_tile for the streamed layouts in the JVP compute mode (DIJacVecMatrixMode, src/icnf.jl:384-420): one forward sweep of
+// h_l and tau_l = sigma'_l .* (W_l tau_{l-1}), tau_0 = eps; ldot = -eps.tau_L, ndot^2 = |tau_L|^2.  Same contract as rhs_tile.
+template <int WPT, class LY, class F>
+__device__ __forceinline__ void rhs_tile_stream_jvp(const LY& ly, float* lds, const float* wimg, int lane, int wave,
+                                                    f32x4& zd0, f32x4& zd1, F&& after_zdot, const float* cbrow, WPre& pre) {
+    constexpr int L = LY::kL;
+    const int s = lane & 15, q = lane >> 4, team = wave / WPT, fg = (wave + (WPT / 2) * team) % WPT;
+    const int row = 16 * team + s;
+    const int n_in = ly.n_in(), nt0 = LY::P(0) >> 4;
+    auto rowp = [&](const float* img, int SW, int t) { return img + (16 * t + s) * SW + 4 * q; };
+    static_for_up<0, L>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr bool last = l == L - 1;
+        constexpr int NU = LY::P(l) / 16, NT = LY::P(l + 1) / 16 / WPT;
+        constexpr int ln = last ? 0 : l + 1;                               // the sweep that follows (next evaluation's first)
+        constexpr bool NEXT_TWO = LY::P(ln + 1) / 16 / WPT >= 2;
+        const float* img = wimg + LY::w_off(l);
+        const float* nimg = wimg + LY::w_off(ln);
+        const float* xh = lds + LY::x_off(l) + row * LY::SX(l) + 4 * q;
+        const float* xt = lds + (l == 0 ? LY::eps_off() : LY::tx_off(l)) + row * LY::SX(l) + 4 * q;
+        static_for_up<0, (NT + 1) / 2>([&](auto bi) {
+            constexpr int b = decltype(bi)::value;
+            constexpr bool two = 2 * b + 1 < NT, has_next = 2 * b + 2 < NT, next_two_in = 2 * b + 3 < NT;
+            const int t0 = fg + 2 * b * WPT, t1 = t0 + WPT;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            auto biasv = [&](int t) {
+                const int r0 = 16 * t + 4 * q;
+                return (l == 0 && cbrow) ? *(const f32x4*)(cbrow + r0) : *(const f32x4*)(wimg + LY::b_off(l) + r0);
+            };
+            const f32x4 bv0 = biasv(t0), bv1 = two ? biasv(t1) : zero;
+            f32x4 acc[4] = {zero, zero, zero, zero};
+            if constexpr (has_next)
+                chain_body2<NU, two ? 2 : 1, next_two_in>(acc, xh, xt, rowp(img, LY::SW(l), t0), rowp(img, LY::SW(l), t1), pre,
+                                                          rowp(img, LY::SW(l), t0 + 2 * WPT), rowp(img, LY::SW(l), t0 + 3 * WPT));
+            else
+                chain_body2<NU, two ? 2 : 1, NEXT_TWO>(acc, xh, xt, rowp(img, LY::SW(l), t0), rowp(img, LY::SW(l), t1), pre,
+                                                       rowp(nimg, LY::SW(ln), fg), rowp(nimg, LY::SW(ln), fg + WPT));
+            auto epi = [&](int t, const f32x4& ah, const f32x4& at, const f32x4& bv) {
+                const int r0 = 16 * t + 4 * q;
+                f32x4 h, d;
+                act4(LY::act(l), ah + bv, h, d);
+                const f32x4 tau = d * at;
+                if constexpr (!last) {
+                    *(f32x4*)(lds + LY::x_off(l + 1) + row * LY::SX(l + 1) + r0) = h;
+                    *(f32x4*)(lds + LY::tx_off(l + 1) + row * LY::SX(l + 1) + r0) = tau;
+                } else {
+                    const f32x4 ev = *(const f32x4*)(lds + LY::eps_off() + row * LY::SX(0) + r0);
+                    const f32x4 zd = {r0 + 0 < n_in ? h.x : 0.f, r0 + 1 < n_in ? h.y : 0.f, r0 + 2 < n_in ? h.z : 0.f,
+                                      r0 + 3 < n_in ? h.w : 0.f};
+                    const f32x4 tm = {r0 + 0 < n_in ? tau.x : 0.f, r0 + 1 < n_in ? tau.y : 0.f, r0 + 2 < n_in ? tau.z : 0.f,
+                                      r0 + 3 < n_in ? tau.w : 0.f};
+                    if (t == fg) zd0 = zd; else zd1 = zd;
+                    const float e2 = quad_sum(zd.x * zd.x + zd.y * zd.y + zd.z * zd.z + zd.w * zd.w);
+                    const float ld = quad_sum(-(ev.x * tm.x + ev.y * tm.y + ev.z * tm.z + ev.w * tm.w));   // icnf.jl:404
+                    const float n2 = quad_sum(tm.x * tm.x + tm.y * tm.y + tm.z * tm.z + tm.w * tm.w);      // icnf.jl:413
+                    if (q == 0) {
+                        lds[LY::red_off() + t * MF_NB + row] = e2;
+                        lds[LY::red_off() + (nt0 + t) * MF_NB + row] = ld;
+                        lds[LY::red_off() + (2 * nt0 + t) * MF_NB + row] = n2;
+                    }
+                }
+            };
+            epi(t0, acc[0], acc[1], bv0);
+            if (two) epi(t1, acc[2], acc[3], bv1);
+        });
+        if (last) after_zdot();
+        stream_barrier();
+    });
+}
+
+template <class LY>
+constexpr bool static_jvp() {
+    if constexpr (LY::kStatic) return LY::jvp();
+    else return false;
+}
+
 template <class LY, int WPT>
 constexpr bool stream_ok() {
     if constexpr (!LY::kStatic) return false;
@@ -674,10 +808,6 @@ constexpr bool stream_ok() {
     }
 }
 
-// LDS-only workgroup barrier: __syncthreads() would also drain the weight fragments in flight
-__device__ __forceinline__ void stream_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // rhs_tile for the streamed layouts (same contract; `pre` carries the stream from call to call)
 template <int WPT, class LY, class F>
@@ -977,7 +1107,9 @@ __global__ void __launch_bounds__(MF_KTHREADS, MF_KTHREADS / 256) k_mfma(LY ly, 
                     if (stg < nstage) put_stage(stg + 1);
                 } else { kz0[1] = zd0; kz1[1] = zd1; }
             };
-            if constexpr (STREAM)
+            if constexpr (STREAM && static_jvp<LY>())
+                rhs_tile_stream_jvp<WPT>(ly, lds, wimg, lane, wave, zd0, zd1, after_zdot, cbrow, pre);
+            else if constexpr (STREAM)
                 rhs_tile_stream<WPT>(ly, lds, wimg, lane, wave, zd0, zd1, after_zdot, a.test ? a.cimg : nullptr, a.SWC,
                                      cbrow, pre);
             else
@@ -1134,6 +1266,7 @@ using LyCfg3 = StLayout<CNF_ACT_TANH, 32, 128, 128, 32>;   // BASELINE configs 3
 using LyCfg2 = StLayout<CNF_ACT_TANH, 16, 48, 16>;         // BASELINE config 2
 using LyCfg1 = StLayout<CNF_ACT_TANH, 16, 16, 16>;         // BASELINE config 1 (2->6->2 padded)
 using LyCfg5 = StLayoutX<false, CNF_ACT_TANH, 128, 384, 128>;   // BASELINE config 5: weights stay in HBM/L2
+using LyCfg5J = StLayoutJ<CNF_ACT_TANH, 128, 384, 128>;         // the same in the JVP compute mode (tangent images)
 
 template <class LY>
 static bool matches(const MfmaLayout& m) {
@@ -1217,7 +1350,10 @@ void mfma_plan_init(MfmaPlan& p, const NetDesc& nd) {
     p.variant = 1;
     p.shape3 = ly.L == 3 && ly.P[0] == 32 && ly.P[1] == 128 && ly.P[2] == 128 && ly.P[3] == 32 &&
                ly.acts[0] == CNF_ACT_TANH && ly.acts[1] == CNF_ACT_TANH && ly.acts[2] == CNF_ACT_TANH;
-    if (nd.jvp) return;                  // forward-mode sweep: k_step3j for the headline shape, else the run-time-layout kernel
+    if (nd.jvp) {                        // forward-mode sweep: k_step3j for the headline shape, the JVP fragment stream for
+        if (matches<LyCfg5J>(ly)) p.variant = 6;     // config 5's, else the run-time-layout kernel
+        return;
+    }
     if (matches<LyCfg3>(ly)) p.variant = 2;
     else if (matches<LyCfg2>(ly)) p.variant = 3;
     else if (matches<LyCfg1>(ly)) p.variant = 4;
@@ -1251,6 +1387,7 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
         if (e == hipSuccess) e = set_attr<LyCfg2>();
         if (e == hipSuccess) e = set_attr<LyCfg1>();
         if (e == hipSuccess) e = set_attr<LyCfg5, MF_WPT_NARROW>();
+        if (e == hipSuccess) e = set_attr<LyCfg5J, MF_WPT_NARROW>();
         if (e == hipSuccess) e = set_attr<RtLayout, MF_WPT_NARROW>();
         if (e != hipSuccess) return CNF_ERR_HIP;
     }
@@ -1339,6 +1476,8 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
         if (use_j) step3j_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, single);
         else step3_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, single);
     }
+    else if (narrow && p.variant == 6 && !a.test) launch_static<LyCfg5J, MF_WPT_NARROW>(p, a, grid, s);
+    else if (narrow && p.variant == 6) launch_static<LyCfg5, MF_WPT_NARROW>(p, a, grid, s);       // TestMode: no tangent images
     else if (narrow && p.variant != 5) {
         RtLayout ly{p.ly};
         if (a.mode == 2) hipLaunchKernelGGL((k_mfma<RtLayout, true, MF_WPT_NARROW>), grid, block, shm, s, ly, a);
