@@ -1456,9 +1456,9 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
     // |eps^T J| row (FFJORD): zdot and ldot = -eps.(J eps) = -(eps^T J).eps do not depend on the mode, and one forward sweep
     // of two column tiles is the shorter schedule.  k_step3: VJP handles with that row.  They take the step attempts
     // (mode 2) and the two single evaluations of the automatic initial dt (modes 0 / 1 with an init phase).
-    const bool s3ok = !a.test && !a.cond && p.d_img3 && !step_v1();
-    const bool use_j = s3ok && !a.dump && ((p.shape3 && p.ly.jvp) || (p.variant == 2 && !p.ly.norm_j));
-    const bool use_v = s3ok && !use_j && p.variant == 2 && !p.ly.jvp;      // (recording solves file their stage states here too)
+    const bool s3ok = !a.test && !a.cond && !a.dump && p.d_img3 && !step_v1();
+    const bool use_j = s3ok && ((p.shape3 && p.ly.jvp) || (p.variant == 2 && !p.ly.norm_j));
+    const bool use_v = s3ok && !use_j && p.variant == 2;
     // single evaluations: the two launches of the automatic initial dt (modes 0 / 1 with an init phase) and, for JVP
     // handles, the plain evaluation of cnf_rhs (mode 0 without an integrator state: it reads a zeroed one).  The plain
     // VJP evaluation stays on k_mfma: measured 14.9 us there against 16.5 us here (the heavier prologue), JVP 50 against 14.6.

@@ -131,8 +131,6 @@ __device__ __forceinline__ float s3_dot4(const f32x4& a, const f32x4& b) {
 #define S3T(i) do {} while (0)
 #endif
 
-// DUMP: the recording instantiation (gradient path) files the stage states; the plain one carries none of that code
-template <bool DUMP>
 __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __restrict__ img3, int n_in, int norm_z,
                                                   int norm_j, const S3Tab tab, int single) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -253,9 +251,8 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
     S3T(24);
     s3_bar();                                              // staging image and partial sums complete
     S3T(25);
-    int cur = st_cur, nacc = 0;
+    int cur = st_cur;
     float hstep = st_h, abstol = st_abstol, reltol = st_reltol;
-    if (DUMP && a.dump) nacc = __builtin_amdgcn_readfirstlane(st->naccept);
     if (a.apply_ctrl && tid == 0) {
         // In-kernel step controller (as in k_mfma): every workgroup reduces the same partials in the same order
         // and takes the same decision; block 0 publishes the new state for the next launch and the host mirror.
@@ -266,7 +263,6 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
         if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
         msc[32] = __int_as_float(ns.cur); msc[33] = ns.h; msc[34] = ns.abstol; msc[35] = ns.reltol;
         msc[36] = __int_as_float(ns.done);
-        msc[37] = __int_as_float(ns.naccept);
     }
     {   // this wave's fragments of W2: rows 16w + s (b128 along the row), columns 16w + s (4 x b32 down the column)
         const float* rw = lds + s3::STG + (16 * wave + s) * s3::SW2 + 4 * q;
@@ -287,14 +283,6 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
         abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[34])));
         reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[35])));
         if (__float_as_int(msc[36])) return;        // the controller just finished the solve
-        if (DUMP) nacc = __builtin_amdgcn_readfirstlane(__float_as_int(msc[37]));
-    }
-    // gradient path: this attempt files u_n and its stage states U_2..U_6 (z rows) in the slot of step `naccept`
-    // (a rejected attempt is overwritten by the retry); slot layout as k_mfma writes it (cnf_abi.hip: traj_*)
-    float* dumpb = nullptr;
-    if (DUMP && a.dump) {
-        dumpb = a.dump_step_stride ? (nacc < a.dump_cap ? a.dump + (size_t)nacc * a.dump_step_stride : nullptr) : a.dump;
-        if (dumpb && a.dump_step_stride && blockIdx.x == 0 && tid == 0) a.hs_out[nacc] = hstep;
     }
     // (explicit selects: indexing the kernel-argument arrays with a run-time value makes the compiler fetch the
     // pointer from the argument segment through a vector load -- a memory round trip in front of the state loads)
@@ -361,12 +349,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
             if (sown) { sc_set(0, ld4_mask(s0, cs)); sc_set(1, ld4_mask(s1, cs)); }
             if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }
         }
-        float* dcol = (DUMP && dumpb && live && zown) ? dumpb + gcol + r0 : nullptr;     // this lane's rows of the stage-state arrays
         if (zown) {
-            if (DUMP && dcol) {
-                if (a.dump_step_stride) st4(dcol - a.dump_stride, uz, nv);         // u_n: one array before the stage states
-                st4(dcol, uz + (hstep * c21) * k1z, nv);                           // U_2
-            }
             *(f32x4*)x0w = uz + (hstep * c21) * k1z;      // state of evaluation 1: U_2 = u + h a21 k1
             *(f32x4*)rkw = uz;
             *(f32x4*)(rkw + 32) = k1z;
@@ -467,7 +450,6 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
                 const f32x4 zd = s3_tanh4(z0 + z1 + bv3);                      // padded rows: zero weights and bias -> 0
                 *(f32x4*)g3w = ev * s3_dtanh4(zd);                             // g3 = eps .* sigma'_3
                 if (stg < 6) *(f32x4*)x0w = pre + (hstep * A[stg]) * zd;       // state of the next evaluation
-                if (DUMP && dcol && stg < 5) st4(dcol + (size_t)stg * a.dump_stride, pre + (hstep * A[stg]) * zd, nv);   // U_{stg+2}
                 *(f32x4*)(kzw + 32 * (stg - 1)) = zd;                          // k_{stg+1}
                 redw[0] = s3_dot4(zd, zd);
             }
@@ -1114,16 +1096,11 @@ void step3_pack(const NetDesc& nd, const float* d_params, float* d_img3, hipStre
 void step3_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_step3<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(s3::TOTAL * sizeof(float)));
-        (void)hipFuncSetAttribute((const void*)k_step3<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_step3, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(s3::TOTAL * sizeof(float)));
         attr_set = true;
     }
-    if (a.dump)
-        hipLaunchKernelGGL(k_step3<true>, grid, dim3(512), (size_t)s3::TOTAL * sizeof(float), s, a, d_img3, n_in, norm_z, norm_j, kS3Tab, single);
-    else
-        hipLaunchKernelGGL(k_step3<false>, grid, dim3(512), (size_t)s3::TOTAL * sizeof(float), s, a, d_img3, n_in, norm_z, norm_j, kS3Tab, single);
+    hipLaunchKernelGGL(k_step3, grid, dim3(512), (size_t)s3::TOTAL * sizeof(float), s, a, d_img3, n_in, norm_z, norm_j, kS3Tab, single);
 }
 
 void step3j_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single) {

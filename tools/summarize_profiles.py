@@ -24,7 +24,7 @@ FULL_US = 15.0                        # anything shorter did not do a step
 
 def is_step(kname):
     # k_step3(...) or the STEP = true instantiation k_mfma<Layout, true>(...) -- not the plain RHS kernel k_mfma<Layout, false>
-    return "k_step3<" in kname or kname.startswith("k_step3(") or ("k_mfma<" in kname and ", true>(" in kname)
+    return kname.startswith("k_step3") or ("k_mfma<" in kname and ", true>(" in kname)
 
 
 def first(pattern):
