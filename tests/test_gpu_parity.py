@@ -660,6 +660,15 @@ def test_loss_grad_headline_shape_variants():
                                                   dict(adaptive=False, dt=1 / 4), n_cond=n_cond, scale=0.1)
         assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval)), k
         _assert_grad(grad, rgrad, f"headline-shape case {k}")
+    # JVP handle of the same shape: the forward steps of the recorded solve leave k_step3j (it files no stage states) for
+    # the run-time-layout kernel, whose grid differs -- the partial count of the controller must follow
+    cfg = O.Cfg(O.Net((32, 128, 128, 32), (O.ACT_TANH,) * 3), 32, 0, 0.01, 0.01)
+    cfg.tspan = (0.0, 0.5)
+    tol = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+    val, grad, rval, rgrad, st, ost = _grad_case(cfg, 90, 349, "mfma", dict(tol), "replay", jvp=True, scale=0.1)
+    assert st["naccept"] == ost.naccept
+    assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+    _assert_grad(grad, rgrad, "headline shape, JVP handle, adaptive")
 
 
 def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
