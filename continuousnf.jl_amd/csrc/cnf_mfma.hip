@@ -25,14 +25,18 @@
 //     image per layer serves both sweeps;
 //   - weights live in LDS for the whole launch when they fit (one padded row-major copy per
 //     layer: read as b128 along rows forward, as 4 x b32 down columns in reverse); larger
-//     networks read row fragments straight from HBM/L2 (plus a transposed copy for reverse);
+//     networks read row fragments straight from L2 (plus a transposed copy for reverse) on
+//     16-sample workgroups (one team of 8 waves), static layouts as ONE fragment stream per wave
+//     that runs ahead across tile, sweep and evaluation boundaries (rhs_tile_stream[_jvp]);
 //   - the Runge-Kutta state of the z rows sits in registers in the accumulator layout of the
 //     lanes that produce zdot; the three scalar rows sit in LDS.
 //
 // Two layout flavours drive the same kernel template: RtLayout (every size a run-time
-// value: any network whose images fit in LDS) and StLayout<...> (sizes and activations
-// are compile-time constants: LDS offsets become instruction immediates, layer loops
+// value: any network whose images fit in LDS) and StLayoutX<...> / StLayoutJ<...> (sizes and
+// activations are compile-time constants: LDS offsets become instruction immediates, layer loops
 // unroll, no integer address arithmetic is left in the GEMM phases).
+// The headline shape 32-128-128-32 has kernels of its own with the weight fragments resident in
+// registers (cnf_step3.hip: k_step3, k_step3j); launch() below routes to them.
 #include "cnf_mfma_dev.h"
 #include "cnf_step3.h"
 
