@@ -123,6 +123,18 @@ __device__ __forceinline__ f32x4 s3_dtanh4(const f32x4& h) {       // sigma' fro
 __device__ __forceinline__ float s3_dot4(const f32x4& a, const f32x4& b) {
     return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
+// Sum over the 64 lanes of the wave, fixed tree, on the VALU: four DPP butterflies inside each row of 16 lanes (quad
+// swaps, half-row mirror, row mirror: every lane ends with its row's total), then the four row totals through
+// v_readlane.  The __shfl_down ladder does the same through the LDS crossbar: six dependent round trips per value.
+__device__ __forceinline__ float s3_wave_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    const int i = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
+}
 
 #ifdef S3_STAMPS
 #define S3T(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
@@ -242,7 +254,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
     float* msc = lds + s3::MISC;
     S3T(33);
     if (a.apply_ctrl) {
-        for (int off = 32; off > 0; off >>= 1) { cp0 += __shfl_down(cp0, off, 64); cp1 += __shfl_down(cp1, off, 64); }
+        cp0 = s3_wave_sum(cp0); cp1 = s3_wave_sum(cp1);
         if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; }
     }
     S3T(34);
@@ -571,10 +583,8 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
         s3_bar();                                          // this tile's RED / SC / KZ reads precede the next tile's writes
     }
     // deterministic block reduction of the error partial (fixed tree, fixed order)
-    for (int off = 32; off > 0; off >>= 1) {
-        errsum += __shfl_down(errsum, off, 64);
-        badcnt += __shfl_down(badcnt, off, 64);
-    }
+    errsum = s3_wave_sum(errsum);
+    badcnt = s3_wave_sum(badcnt);
     if (lane == 0) { msc[wave] = errsum; msc[16 + wave] = badcnt; }
     s3_bar();
     if (tid == 0) {
@@ -602,7 +612,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
                 q0 += __hip_atomic_load(a.partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 q1 += __hip_atomic_load(a.partials + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            for (int off = 32; off > 0; off >>= 1) { q0 += __shfl_down(q0, off, 64); q1 += __shfl_down(q1, off, 64); }
+            q0 = s3_wave_sum(q0); q1 = s3_wave_sum(q1);
             if (lane == 0) { msc[wave] = q0; msc[16 + wave] = q1; }
             s3_bar();
             if (tid == 0) {
@@ -732,7 +742,7 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
     float* msc = lds + s3::MISC;
     S3T(33);
     if (a.apply_ctrl) {
-        for (int off = 32; off > 0; off >>= 1) { cp0 += __shfl_down(cp0, off, 64); cp1 += __shfl_down(cp1, off, 64); }
+        cp0 = s3_wave_sum(cp0); cp1 = s3_wave_sum(cp1);
         if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; }
     }
     S3T(34);
@@ -1014,10 +1024,8 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
         s3_bar();                                          // this tile's RED / SC / KZ reads precede the next tile's writes
     }
     // deterministic block reduction of the error partial (fixed tree, fixed order)
-    for (int off = 32; off > 0; off >>= 1) {
-        errsum += __shfl_down(errsum, off, 64);
-        badcnt += __shfl_down(badcnt, off, 64);
-    }
+    errsum = s3_wave_sum(errsum);
+    badcnt = s3_wave_sum(badcnt);
     if (lane == 0) { msc[wave] = errsum; msc[16 + wave] = badcnt; }
     s3_bar();
     if (tid == 0) {
@@ -1045,7 +1053,7 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
                 q0 += __hip_atomic_load(a.partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 q1 += __hip_atomic_load(a.partials + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            for (int off = 32; off > 0; off >>= 1) { q0 += __shfl_down(q0, off, 64); q1 += __shfl_down(q1, off, 64); }
+            q0 = s3_wave_sum(q0); q1 = s3_wave_sum(q1);
             if (lane == 0) { msc[wave] = q0; msc[16 + wave] = q1; }
             s3_bar();
             if (tid == 0) {
