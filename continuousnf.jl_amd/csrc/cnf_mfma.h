@@ -40,6 +40,7 @@ struct MfmaPlan {
     float* d_img = nullptr;         // weight+bias image in HBM (LDS order), refreshed by pack
     float* d_img3 = nullptr;        // headline shape: register-fragment image of k_step3 / k_step3j, refreshed by pack
     bool shape3 = false;            // the network pads to 32-128-128-32, all tanh (either compute mode)
+    void* d_img3b = nullptr;        // headline shape: split-bf16 fragment image of k_step3jb
     StepState* d_idle = nullptr;    // a zeroed integrator state for plain evaluations on the step kernels (they read one)
     const float* cond = nullptr;    // conditional models: per-sample first-layer bias [B][cbs] (owned by the handle)
     int cbs = 0;

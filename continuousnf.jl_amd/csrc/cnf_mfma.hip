@@ -1368,7 +1368,9 @@ void mfma_plan_free(MfmaPlan& p) {
     if (p.d_img) (void)hipFree(p.d_img);
     if (p.d_img3) (void)hipFree(p.d_img3);
     if (p.d_idle) (void)hipFree(p.d_idle);
+    if (p.d_img3b) (void)hipFree(p.d_img3b);
     p.d_idle = nullptr;
+    p.d_img3b = nullptr;
     p.d_img = nullptr;
     p.d_img3 = nullptr;
 }
@@ -1404,6 +1406,8 @@ cnf_status mfma_plan_pack(MfmaPlan& p, const NetDesc& nd, const float* d_params,
             if (hipMemsetAsync(p.d_idle, 0, sizeof(StepState), s) != hipSuccess) return CNF_ERR_HIP;
         }
         step3_pack(nd, d_params, p.d_img3, s);
+        if (!p.d_img3b && hipMalloc(&p.d_img3b, step3b_img_bytes()) != hipSuccess) return CNF_ERR_HIP;
+        step3b_pack(nd, d_params, p.d_img3b, s);
     }
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
@@ -1477,7 +1481,11 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
             a.U[0] = a.U[1] = const_cast<float*>(a.u);
             a.K1[0] = a.K1[1] = a.du;
         }
-        if (use_j) step3j_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, single);
+        // k_step3jb: the same schedule with every fp32 product formed from six bf16 MFMA terms on exactly split operands
+        // (CNF_STEP_FP32=1 keeps the fp32 MFMA kernel k_step3j: A/B measurements)
+        static const bool fp32_only = [] { const char* e = getenv("CNF_STEP_FP32"); return e && e[0] == '1'; }();
+        if (use_j && p.d_img3b && !fp32_only) step3jb_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, single);
+        else if (use_j) step3j_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, single);
         else step3_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, single);
     }
     else if (narrow && p.variant == 6 && !a.test) launch_static<LyCfg5J, MF_WPT_NARROW>(p, a, grid, s);

@@ -13,3 +13,7 @@ void step3_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, 
 // the same for the JVP compute mode (k_step3j); also exact for VJP handles without the |eps^T J| row (norm_j == 0):
 // ldot = -eps.(J eps) = -(eps^T J).eps and zdot do not depend on the mode
 void step3j_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single = 0);
+// k_step3jb: k_step3j with every product formed from six bf16 MFMA terms on exactly split operands
+size_t step3b_img_bytes();
+void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStream_t s);
+void step3jb_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single = 0);

@@ -1066,6 +1066,464 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_step3jb -- k_step3j with every fp32 product formed from SIX bf16 MFMA terms: each operand is split into three bf16
+// pieces (8 + 8 + 8 mantissa bits: the split is exact), v_mfma_f32_16x16x32_bf16 accumulates the six products above
+// 2^-24 of the result in fp32.  Measured on a K = 128 tile (tools/ubench/bf16_split.hip): the same error as
+// v_mfma_f32_16x16x4_f32 (6.7e-8 against 7.6e-8 of sum|a b|) at 2.3x its rate.  Weight fragments arrive pre-split
+// (k_pack_step3b); activations are split in the epilogues and live in LDS as three bf16 images [sample][feature].
+// The Runge-Kutta rows of z live in registers here (the images take their LDS).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+namespace s3b {
+// fp32 regions (float offsets), then the bf16 images (byte offsets)
+constexpr int G3 = 0, EPS = G3 + 32 * 40, RED = EPS + 32 * 40, SC = RED + 3 * 32 * 8, BIAS = SC + 32 * 24;
+constexpr int MISC = BIAS + 2 * 128 + 32, FP_END = MISC + 64;
+constexpr int WS = 288, WP = 32 * WS, WI = 3 * WP;        // wide image: row stride (144 bf16), piece, image (hi | mid | lo)
+constexpr int NS = 96, NP = 32 * NS, NI = 3 * NP;         // narrow image (K = 32): row stride (48 bf16)
+constexpr int H1B = FP_END * 4, T1B = H1B + WI, H2B = T1B + WI, T2B = H2B + WI, X0B = T2B + WI, T0B = X0B + NI;
+constexpr int TOTAL_BYTES = T0B + NI;
+static_assert(H1B % 16 == 0 && TOTAL_BYTES <= 160 * 1024, "LDS plan");
+// global image (bytes): fragment-ordered split weights, one 16-byte load per lane and piece
+constexpr int FR1 = 0;                                     // W1: [tile 8][piece 3][lane 64] x 16 B
+constexpr int FR2 = FR1 + 8 * 3 * 1024;                    // W2: [tile 8][k-block 4][piece 3][lane 64] x 16 B
+constexpr int FR3 = FR2 + 8 * 4 * 3 * 1024;                // W3: [tile 2][k-block 4][piece 3][lane 64] x 16 B
+constexpr int BIASB = FR3 + 2 * 4 * 3 * 1024;              // b1 (128), b2 (128), b3 (32) fp32
+constexpr int IMG_BYTES = BIASB + (2 * 128 + 32) * 4;
+}  // namespace s3b
+
+__device__ __forceinline__ void s3b_split(float v, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+// 4 rows of one sample -> the three images (8 bytes each)
+__device__ __forceinline__ void s3b_store4(char* img, int piece_bytes, const f32x4& v) {
+    bf16x4 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { __bf16 a, b, c; s3b_split(v[j], a, b, c); h[j] = a; m[j] = b; l[j] = c; }
+    *(bf16x4*)img = h; *(bf16x4*)(img + piece_bytes) = m; *(bf16x4*)(img + 2 * piece_bytes) = l;
+}
+struct S3bOp { bf16x8 h, m, l; };
+__device__ __forceinline__ S3bOp s3b_load(const char* img, int piece_bytes) {
+    S3bOp o;
+    o.h = *(const bf16x8*)img; o.m = *(const bf16x8*)(img + piece_bytes); o.l = *(const bf16x8*)(img + 2 * piece_bytes);
+    return o;
+}
+// term T (0..5, smallest first) of the product a x b into acc
+template <int T>
+__device__ __forceinline__ f32x4 s3b_term(const S3bOp& a, const S3bOp& b, const f32x4& acc) {
+    if (T == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, acc, 0, 0, 0);
+    if (T == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, acc, 0, 0, 0);
+    if (T == 2) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, acc, 0, 0, 0);
+    if (T == 3) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, acc, 0, 0, 0);
+    if (T == 4) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0);
+}
+// NC independent products that share the A operand: term-major order, so that the six terms of one accumulator are NC
+// MFMAs apart
+template <int NC>
+__device__ __forceinline__ void s3b_mm(f32x4 (&acc)[NC], const S3bOp& a, const S3bOp (&b)[NC]) {
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[n] = s3b_term<0>(a, b[n], acc[n]);
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[n] = s3b_term<1>(a, b[n], acc[n]);
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[n] = s3b_term<2>(a, b[n], acc[n]);
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[n] = s3b_term<3>(a, b[n], acc[n]);
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[n] = s3b_term<4>(a, b[n], acc[n]);
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[n] = s3b_term<5>(a, b[n], acc[n]);
+}
+
+__global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __restrict__ imgb, int n_in, int norm_z,
+                                                   int norm_j, const S3Tab tab, int single) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* ldsb = reinterpret_cast<char*>(lds);
+    const float* img3 = reinterpret_cast<const float*>(imgb);      // (a valid address for masked loads)
+    const StepState* st = a.st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = n_in + 3;
+    const int s = lane & 15, q = lane >> 4;
+    const int t = wave & 1, hf = (wave >> 1) & 1;         // last layer: row tile and sample half of this wave
+    const bool zown = wave < 4;                           // waves 0-3 produce zdot: they hold the z rows of the state
+    const bool sown = !zown && t == 0 && q == 0;          // waves 4, 6: lane s holds the scalar rows of sample 16 hf + s
+    const int smp = 16 * hf + s;
+    const int r0 = 16 * t + 4 * q;
+    const int nv = n_in - r0;
+    // ---- requests of the prologue (order of issue = order of return; nothing consumed before all are in flight) ----
+    StepState st0;
+    if (tid == 0) st0 = *st;
+    const int v_done = st->done, v_cur = st->cur;
+    const float v_h = st->h, v_abstol = st->abstol, v_reltol = st->reltol;
+    float cp0 = 0.f, cp1 = 0.f;
+    if (a.apply_ctrl)
+        for (int i = tid; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
+    // resident split fragments: W1 tile `wave` (K = 32), W2 tile `wave` (4 k-blocks), W3 tile t (4 k-blocks)
+    S3bOp wF1, wF2[4], w3[4];
+    {
+        const char* f1 = imgb + s3b::FR1 + (size_t)wave * 3 * 1024 + 16 * lane;
+        wF1 = s3b_load(f1, 1024);
+        const char* f2 = imgb + s3b::FR2 + (size_t)wave * 4 * 3 * 1024 + 16 * lane;
+        const char* f3 = imgb + s3b::FR3 + (size_t)t * 4 * 3 * 1024 + 16 * lane;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { wF2[b] = s3b_load(f2 + b * 3 * 1024, 1024); w3[b] = s3b_load(f3 + b * 3 * 1024, 1024); }
+    }
+    constexpr int NCB = (2 * 128 + 32) / 4;
+    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3b::BIASB)[min(tid, NCB - 1)];
+    const int ntile = (a.B + 31) / 32;
+    f32x4 ru[2], rk[2], re, rs[2][2];
+    int ce = 0, cu = 0, cs = 0;
+    float* sc = lds + s3b::SC + smp * 24;
+    auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
+    auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
+    {
+        const int b0 = blockIdx.x * 32 + 16 * hf;
+        const bool live = s < max(0, min(16, a.B - b0));
+        const size_t gcol = (size_t)(b0 + s) * D;
+        ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
+        re = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            ru[c] = ld4_issue(a.U[c] + gcol + r0, cu, img3);
+            rk[c] = ld4_issue(a.K1[c] + gcol + r0, cu, img3);
+            rs[c][0] = ld4_issue(a.U[c] + gcol + n_in, cs, img3);
+            rs[c][1] = ld4_issue(a.K1[c] + gcol + n_in, cs, img3);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int st_done = __builtin_amdgcn_readfirstlane(v_done), st_cur = __builtin_amdgcn_readfirstlane(v_cur);
+    const float st_h = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_h)));
+    const float st_abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_abstol)));
+    const float st_reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_reltol)));
+    if (st_done) {       // launches queued past the end of the solve: keep the state chain intact and leave
+        if (a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
+        return;
+    }
+    if (sown) {
+        sc_set(2, ld4_mask(rs[0][0], cs)); sc_set(3, ld4_mask(rs[0][1], cs));
+        sc_set(4, ld4_mask(rs[1][0], cs)); sc_set(5, ld4_mask(rs[1][1], cs));
+    }
+    // the probe rows: fp32 for the trace row, split as tau_0 (the tangent operand of the first layer)
+    float* epw = lds + s3b::EPS + smp * 40 + r0;
+    char* x0w = ldsb + s3b::X0B + smp * s3b::NS + 2 * r0;            // this lane's 4 rows of the state image
+    {
+        const f32x4 ev = ld4_mask(re, ce);
+        *(f32x4*)epw = ev;
+        s3b_store4(ldsb + s3b::T0B + smp * s3b::NS + 2 * r0, s3b::NP, ev);
+    }
+    float* msc = lds + s3b::MISC;
+    if (a.apply_ctrl) {
+        cp0 = s3_wave_sum(cp0); cp1 = s3_wave_sum(cp1);
+        if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; }
+    }
+    if (tid < NCB) reinterpret_cast<f32x4*>(lds + s3b::BIAS)[tid] = sgb;
+    s3_bar();                                              // partial sums, biases and probe images complete
+    int cur = st_cur;
+    float hstep = st_h, abstol = st_abstol, reltol = st_reltol;
+    if (a.apply_ctrl && tid == 0) {
+        float p0 = 0.f, p1 = 0.f;
+        for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
+        StepState ns = st0;
+        ctrl_after_step(&ns, p0, p1, a.n_total);
+        if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
+        msc[32] = __int_as_float(ns.cur); msc[33] = ns.h; msc[34] = ns.abstol; msc[35] = ns.reltol;
+        msc[36] = __int_as_float(ns.done);
+    }
+    s3_bar();                                              // controller done
+    if (a.apply_ctrl) {
+        cur = __builtin_amdgcn_readfirstlane(__float_as_int(msc[32]));
+        hstep = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[33])));
+        abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[34])));
+        reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[35])));
+        if (__float_as_int(msc[36])) return;        // the controller just finished the solve
+    }
+    const int nstg = single ? 1 : 6;
+    const float c21 = single == 1 ? 0.f : (single == 2 ? 1.f : TS_A21);
+    const float* Uin = cur ? a.U[1] : a.U[0];
+    const float* K1in = cur ? a.K1[1] : a.K1[0];
+    float* Uout = cur ? a.U[0] : a.U[1];
+    float* K1out = cur ? a.K1[0] : a.K1[1];
+
+    float errsum = 0.f, badcnt = 0.f;
+    auto red8 = [&](int kind) {
+        const float* r = lds + s3b::RED + (kind * 32 + smp) * 8;
+        const f32x4 a_ = *(const f32x4*)r, b_ = *(const f32x4*)(r + 4);
+        return ((a_.x + a_.y) + (a_.z + a_.w)) + ((b_.x + b_.y) + (b_.z + b_.w));
+    };
+    auto read_scalars = [&]() {
+        const float e2 = red8(0), ld = red8(1), n2 = red8(2);
+        return f32x4{ld, norm_z ? __builtin_sqrtf(e2) : 0.f, norm_j ? __builtin_sqrtf(n2) : 0.f, 0.f};
+    };
+    float* redw = lds + s3b::RED + smp * 8 + 4 * t + q;
+    float* g3w = lds + s3b::G3 + smp * 40 + r0;
+    const float* bias = lds + s3b::BIAS;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // B operands: lane (sample s of half A, k = 8q ..): byte offsets into an image; half B = 16 rows on
+    const int nb_rd = s * s3b::NS + 16 * q, wb_rd = s * s3b::WS + 16 * q;
+    // results: lane (sample s, rows 16 wave + 4q ..) of the wide images
+    const int wb_wr = s * s3b::WS + 2 * (16 * wave + 4 * q);
+    constexpr int HBW = 16 * s3b::WS, HBN = 16 * s3b::NS;
+
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int b0 = tile * 32 + 16 * hf;
+        const bool live = s < max(0, min(16, a.B - b0));
+        const size_t gcol = (size_t)(b0 + s) * D;
+        f32x4 uz, kz[7], un = zero4;                       // Runge-Kutta rows of z (waves 0-3): u, k1..k7, u_new
+#pragma unroll
+        for (int j = 0; j < 7; ++j) kz[j] = zero4;
+        if (tile == blockIdx.x) {                              // requested at kernel entry
+            uz = ld4_mask(cur ? ru[1] : ru[0], cu);
+            kz[0] = ld4_mask(cur ? rk[1] : rk[0], cu);
+            if (sown) { sc_set(0, sc_get(cur ? 4 : 2)); sc_set(1, sc_get(cur ? 5 : 3)); }
+        } else {
+            ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
+            const f32x4 e_ = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+            const f32x4 u_ = ld4_issue(Uin + gcol + r0, cu, img3), k_ = ld4_issue(K1in + gcol + r0, cu, img3);
+            const f32x4 s0 = ld4_issue(Uin + gcol + n_in, cs, img3), s1 = ld4_issue(K1in + gcol + n_in, cs, img3);
+            const f32x4 ev = ld4_mask(e_, ce);
+            *(f32x4*)epw = ev;
+            s3b_store4(ldsb + s3b::T0B + smp * s3b::NS + 2 * r0, s3b::NP, ev);
+            uz = ld4_mask(u_, cu); kz[0] = ld4_mask(k_, cu);
+            if (sown) { sc_set(0, ld4_mask(s0, cs)); sc_set(1, ld4_mask(s1, cs)); }
+        }
+        if (single == 1) { kz[0] = zero4; if (sown) sc_set(1, zero4); }      // there is no k1 yet
+        if (zown) {
+            un = uz + (hstep * c21) * kz[0];               // state of evaluation 1: U_2 = u + h a21 k1
+            s3b_store4(x0w, s3b::NP, un);
+        }
+        s3_bar();
+
+        // tau_3 = sigma'_3 .* (W3 tau_2) on waves 4-7: the product is formed in interval 2; sigma'_3 comes from the wave
+        // that formed zdot of the same rows, one barrier later
+        f32x4 tacc = zero4;
+        auto finish_tau = [&]() {
+            const f32x4 tj = tacc * *(const f32x4*)g3w;
+            redw[32 * 8] = -s3_dot4(tj, *(const f32x4*)epw);
+            redw[2 * 32 * 8] = s3_dot4(tj, tj);
+        };
+
+        for (int stg = 1; stg <= nstg; ++stg) {
+            // ---- interval 0: first layer, tile `wave`, both halves, state and tangent columns (one k-block)
+            {
+                const f32x4 bv1 = *(const f32x4*)(bias + 16 * wave + 4 * q);
+                if (!zown && stg > 1) finish_tau();                            // of the previous evaluation
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    S3bOp b[2];
+                    b[0] = s3b_load(ldsb + s3b::X0B + nb_rd + half * HBN, s3b::NP);
+                    b[1] = s3b_load(ldsb + s3b::T0B + nb_rd + half * HBN, s3b::NP);
+                    S3_SB();
+                    f32x4 acc[2] = {zero4, zero4};
+                    s3b_mm<2>(acc, wF1, b);
+                    const f32x4 h1 = s3_tanh4(acc[0] + bv1);
+                    s3b_store4(ldsb + s3b::H1B + wb_wr + half * HBW, s3b::WP, h1);
+                    s3b_store4(ldsb + s3b::T1B + wb_wr + half * HBW, s3b::WP, s3_dtanh4(h1) * acc[1]);
+                }
+            }
+            s3_bar();                                                          // h1, t1 visible
+            // ---- interval 1: second layer, tile `wave`: half A (state, tangent), then half B; operands one k-block ahead
+            {
+                const f32x4 bv2 = *(const f32x4*)(bias + 128 + 16 * wave + 4 * q);
+                if (stg > 1 && sown) sc_set(stg, read_scalars());              // scalar rows of the PREVIOUS evaluation
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const char* hb = ldsb + s3b::H1B + wb_rd + half * HBW;
+                    const char* tb = ldsb + s3b::T1B + wb_rd + half * HBW;
+                    f32x4 acc[2] = {zero4, zero4};
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {       // (the other wave of the SIMD covers the LDS latency)
+                        S3bOp rb[2];
+                        rb[0] = s3b_load(hb + 64 * kb, s3b::WP); rb[1] = s3b_load(tb + 64 * kb, s3b::WP);
+                        S3_SB();
+                        s3b_mm<2>(acc, wF2[kb], rb);
+                        S3_SB();
+                    }
+                    const f32x4 h2 = s3_tanh4(acc[0] + bv2);
+                    s3b_store4(ldsb + s3b::H2B + wb_wr + half * HBW, s3b::WP, h2);
+                    s3b_store4(ldsb + s3b::T2B + wb_wr + half * HBW, s3b::WP, s3_dtanh4(h2) * acc[1]);
+                }
+            }
+            s3_bar();                                                          // h2, t2 visible
+            // ---- interval 2: last layer, one product per wave: rows r0..r0+3 of sample smp, state (0-3) / tangent (4-7)
+            {
+                const char* xb = ldsb + (zown ? s3b::H2B : s3b::T2B) + smp * s3b::WS + 16 * q;
+                const f32x4 bv3 = *(const f32x4*)(bias + 256 + r0);
+                // two accumulation chains (terms 0-2 / 3-5): a wave alone on its product would otherwise wait on itself
+                f32x4 z0 = zero4, z1 = zero4;
+                S3bOp b = s3b_load(xb, s3b::WP);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const S3bOp bn = s3b_load(xb + 64 * (kb + 1 < 4 ? kb + 1 : kb), s3b::WP);
+                    S3_SB();
+                    z0 = s3b_term<0>(w3[kb], b, z0); z1 = s3b_term<3>(w3[kb], b, z1);
+                    z0 = s3b_term<1>(w3[kb], b, z0); z1 = s3b_term<4>(w3[kb], b, z1);
+                    z0 = s3b_term<2>(w3[kb], b, z0); z1 = s3b_term<5>(w3[kb], b, z1);
+                    S3_SB();
+                    b = bn;
+                }
+                if (zown) {
+                    // stage sum without the k this evaluation produces: pre = u + h sum_{j<stg} a_{stg+1,j} k_j
+                    const float* A = tab.a[stg < 6 ? stg + 1 : 6];
+                    f32x4 pre = uz + (hstep * A[0]) * kz[0];
+#pragma unroll
+                    for (int jj = 1; jj < 5; ++jj) pre += (hstep * A[jj]) * kz[jj];      // k's not yet produced are zero
+                    const f32x4 zd = s3_tanh4(z0 + z1 + bv3);                  // padded rows: zero weights and bias -> 0
+                    *(f32x4*)g3w = s3_dtanh4(zd);                              // sigma'_3 for the tangent rows
+                    if (stg < 6) { un = pre + (hstep * A[stg]) * zd; s3b_store4(x0w, s3b::NP, un); }   // next stage state
+                    set_k(kz, stg, zd);                                        // k_{stg+1}
+                    redw[0] = s3_dot4(zd, zd);
+                } else {
+                    tacc = z0 + z1;
+                }
+            }
+            s3_bar();                                                          // sigma'_3 (and the next stage state) visible
+        }
+        if (!zown) finish_tau();                           // of the last evaluation
+        s3_bar();                                          // RED of the last evaluation complete
+        if (single) {
+            float* out = (single == 1 ? a.du : a.Ks0) + (size_t)(tile * 32 + 16 * hf + s) * D;
+            auto norms = [&](const f32x4& u4, const f32x4& f0, const f32x4& f1, int nvalid) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < nvalid) {
+                        const float sk = fmaf(fabsf(u4[c]), reltol, abstol);
+                        if (single == 1) {
+                            const float x = u4[c] / sk, y = f1[c] / sk;
+                            errsum = fmaf(x, x, errsum); badcnt = fmaf(y, y, badcnt);
+                        } else {
+                            const float x = (f1[c] - f0[c]) / sk;
+                            errsum = fmaf(x, x, errsum);
+                        }
+                    }
+                }
+            };
+            if (live && zown) {
+                st4(out + r0, kz[1], nv);                                      // k2 slot = this evaluation's zdot
+                if (a.init_phase >= 0) norms(uz, kz[0], kz[1], nv);
+            }
+            if (live && sown) {
+                const f32x4 f1 = read_scalars();
+                out[n_in] = f1.x; out[n_in + 1] = f1.y; out[n_in + 2] = f1.z;
+                if (a.init_phase >= 0) norms(sc_get(0), sc_get(1), f1, 3);
+            }
+        }
+        // ---- error estimate and outputs: u_new (= the state evaluation 6 ran at) and k7 ----
+        if (!single && live && zown) {
+            const f32x4 ez = TS_BT1 * kz[0] + TS_BT2 * kz[1] + TS_BT3 * kz[2] + TS_BT4 * kz[3] + TS_BT5 * kz[4] +
+                             TS_BT6 * kz[5] + TS_BT7 * kz[6];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                  // rows beyond n_in: u = k = 0 -> contribute exactly 0
+                const float scl = fmaf(fmaxf(fabsf(uz[c]), fabsf(un[c])), reltol, abstol);
+                const float x = c < nv ? hstep * ez[c] / scl : 0.f;
+                errsum = fmaf(x, x, errsum);
+                badcnt += (c < nv && !(fabsf(un[c]) <= 3.0e38f)) ? 1.f : 0.f;
+            }
+            const size_t gc = (size_t)(tile * 32 + 16 * hf + s) * D;
+            st4(Uout + gc + r0, un, nv); st4(K1out + gc + r0, kz[6], nv);
+        }
+        if (!single && live && sown) {
+            f32x4 ks[7];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ks[j] = sc_get(1 + j);
+            const f32x4 us = sc_get(0);
+            ks[6] = read_scalars();                        // k7 of the scalar rows, straight from the partials
+            const f32x4 uns = us + hstep * stage_acc4<6>(ks);
+            err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
+            const size_t gc = (size_t)(tile * 32 + 16 * hf + s) * D;
+            float* Un = Uout + gc + n_in;
+            float* K7 = K1out + gc + n_in;
+            Un[0] = uns.x; Un[1] = uns.y; Un[2] = uns.z;
+            K7[0] = ks[6].x; K7[1] = ks[6].y; K7[2] = ks[6].z;
+        }
+        s3_bar();                                          // this tile's RED / SC reads precede the next tile's writes
+    }
+    // deterministic block reduction of the error partial (fixed tree, fixed order)
+    errsum = s3_wave_sum(errsum);
+    badcnt = s3_wave_sum(badcnt);
+    if (lane == 0) { msc[wave] = errsum; msc[16 + wave] = badcnt; }
+    s3_bar();
+    if (tid == 0) {
+        float e = 0.f, b = 0.f;
+        for (int w = 0; w < 8; ++w) { e += msc[w]; b += msc[16 + w]; }
+        if (!single) {
+            a.partials[2 * blockIdx.x] = e;
+            a.partials[2 * blockIdx.x + 1] = b;
+        } else if (a.init_phase >= 0) {
+            __hip_atomic_store(a.partials + 2 * blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.partials + 2 * blockIdx.x + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            msc[40] = (tk == gridDim.x - 1) ? 1.f : 0.f;
+            if (tk == gridDim.x - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (single && a.init_phase >= 0) {
+        s3_bar();
+        if (msc[40] != 0.f) {                        // this workgroup drew the last ticket: all its threads reduce
+            float q0 = 0.f, q1 = 0.f;
+            for (int i = tid; i < (int)gridDim.x; i += 512) {
+                q0 += __hip_atomic_load(a.partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q1 += __hip_atomic_load(a.partials + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            q0 = s3_wave_sum(q0); q1 = s3_wave_sum(q1);
+            if (lane == 0) { msc[wave] = q0; msc[16 + wave] = q1; }
+            s3_bar();
+            if (tid == 0) {
+                float p0 = 0.f, p1 = 0.f;
+                for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
+                ctrl_phase(a.st_out, single - 1, p0, p1, a.n_total);
+            }
+        }
+    }
+}
+
+// split fragment image of k_step3jb: fragment f (W1 tiles 0..7 | W2 tile x k-block | W3 tile x k-block), lane = 16q + x:
+// the 8 weights W[16 tile + x][32 kblock + 8q .. +7] as three bf16 pieces
+__global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __restrict__ img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int NF = 8 + 32 + 8;
+    if (i < (2 * 128 + 32)) {
+        const int l = i < 128 ? 0 : (i < 256 ? 1 : 2), o = i < 128 ? i : (i < 256 ? i - 128 : i - 256);
+        reinterpret_cast<float*>(img + s3b::BIASB)[i] = o < nd.dims[l + 1] ? P[nd.b_off[l] + o] : 0.f;
+    }
+    if (i >= NF * 64) return;
+    const int f = i >> 6, lane = i & 63, x = lane & 15, q = lane >> 4;
+    int l, tile, kb;
+    char* dst;
+    if (f < 8) { l = 0; tile = f; kb = 0; dst = img + s3b::FR1 + (size_t)f * 3 * 1024; }
+    else if (f < 40) { l = 1; tile = (f - 8) >> 2; kb = (f - 8) & 3; dst = img + s3b::FR2 + (size_t)(f - 8) * 3 * 1024; }
+    else { l = 2; tile = (f - 40) >> 2; kb = (f - 40) & 3; dst = img + s3b::FR3 + (size_t)(f - 40) * 3 * 1024; }
+    bf16x8 h, m, lo;
+    const int o = 16 * tile + x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 32 * kb + 8 * q + j;
+        const float v = (o < nd.dims[l + 1] && k < nd.dims[l]) ? P[nd.w_off[l] + o + (size_t)k * nd.dims[l + 1]] : 0.f;
+        __bf16 a, b, c;
+        s3b_split(v, a, b, c);
+        h[j] = a; m[j] = b; lo[j] = c;
+    }
+    *(bf16x8*)(dst + 16 * lane) = h; *(bf16x8*)(dst + 1024 + 16 * lane) = m; *(bf16x8*)(dst + 2048 + 16 * lane) = lo;
+}
+
+size_t step3b_img_bytes() { return (size_t)s3b::IMG_BYTES; }
+void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_step3b, dim3((48 * 64 + 255) / 256), dim3(256), 0, s, nd, d_params, (char*)d_imgb);
+}
+void step3jb_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_step3jb, hipFuncAttributeMaxDynamicSharedMemorySize, s3b::TOTAL_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_step3jb, grid, dim3(512), s3b::TOTAL_BYTES, s, a, (const char*)d_imgb, n_in, norm_z, norm_j, kS3Tab, single);
+}
+
 // Weight image of k_step3 (layout: namespace s3).  Fragment element (wave w, fragment j, lane = 16q + s, c):
 //   FR1 (waves 0-3): W1 rows: tile w + 4 (j >> 1), k-block j & 1:  W1[16 (w + 4 (j >> 1)) + s][16 (j & 1) + 4q + c]
 //   FR3 (all waves): W3^T rows:                                   W3[16 j + 4q + c][16 w + s]
