@@ -1486,6 +1486,7 @@ static cnf_status launch(const MfmaPlan& p, const MfmaArgs& a0, hipStream_t s) {
         static const bool fp32_only = [] { const char* e = getenv("CNF_STEP_FP32"); return e && e[0] == '1'; }();
         if (use_j && p.d_img3b && !fp32_only) step3jb_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, single);
         else if (use_j) step3j_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, single);
+        else if (p.d_img3b && !fp32_only && !a.dump) step3b_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, single);
         else step3_launch(a, p.d_img3, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, single);
     }
     else if (narrow && p.variant == 6 && !a.test) launch_static<LyCfg5J, MF_WPT_NARROW>(p, a, grid, s);

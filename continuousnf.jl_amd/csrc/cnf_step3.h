@@ -17,3 +17,5 @@ void step3j_launch(const MfmaArgs& a, const float* d_img3, int n_in, int norm_z,
 size_t step3b_img_bytes();
 void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStream_t s);
 void step3jb_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single = 0);
+// k_step3b: the VJP step kernel (k_step3) on six-term bf16 products
+void step3b_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single = 0);

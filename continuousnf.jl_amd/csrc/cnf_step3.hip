@@ -1482,38 +1482,510 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
     }
 }
 
-// split fragment image of k_step3jb: fragment f (W1 tiles 0..7 | W2 tile x k-block | W3 tile x k-block), lane = 16q + x:
-// the 8 weights W[16 tile + x][32 kblock + 8q .. +7] as three bf16 pieces
+// ---------------------------------------------------------------------------------------------------------------
+// k_step3b -- the VJP step kernel (k_step3) on six-term bf16 products.  What differs from k_step3jb: both orientations of
+// W2 and W3^T / W1 tiles resident as split fragments (120 VGPRs), the K = 128 operands of the two narrow products (W3,
+// W1^T) as split images in LDS, g2 / g1 written IN PLACE over h2 / h1 (sigma' is taken from the three pieces' exact sum),
+// the K = 32 operands (state, g3) kept in fp32 and split on the way into the MFMA, the probe rows in registers.
+// Six barrier intervals per evaluation, both sample halves inside each (they share the A fragments).
+// ---------------------------------------------------------------------------------------------------------------
+namespace s3v {
+constexpr int SKZ = 264;
+constexpr int X0 = 0, G3 = X0 + 32 * 40, KZ = G3 + 32 * 40, RED = KZ + 32 * SKZ, SC = RED + 3 * 32 * 8, BIAS = SC + 32 * 24;
+constexpr int MISC = BIAS + 2 * 128 + 32, FP_END = MISC + 64;
+constexpr int WS = 272, WP = 32 * WS, WI = 3 * WP;        // split image [piece][32 rows][128 bf16 + 8]: 17 x 16 B per row
+constexpr int H1G = FP_END * 4, H2G = H1G + WI, W3I = H2G + WI, W1TI = W3I + WI;
+constexpr int TOTAL_BYTES = W1TI + WI;
+static_assert(H1G % 16 == 0 && TOTAL_BYTES <= 160 * 1024, "LDS plan");
+// global image, behind the one of k_step3jb: W2^T and W3^T fragments, then the two LDS images as they are stored
+constexpr int G_FRB2 = (s3b::IMG_BYTES + 15) & ~15;        // W2^T: [tile 8][k-block 4][piece 3][lane 64] x 16 B
+constexpr int G_FRB3 = G_FRB2 + 8 * 4 * 3 * 1024;          // W3^T: [tile 8][piece 3][lane 64] x 16 B
+constexpr int G_W3I = G_FRB3 + 8 * 3 * 1024;               // W3 rows, then W1^T rows: 2 x WI bytes, LDS layout
+constexpr int IMG_BYTES = G_W3I + 2 * WI;
+}  // namespace s3v
+
+// 8 consecutive fp32 values -> a split operand (K = 32 products whose B operand stays in fp32 in LDS)
+__device__ __forceinline__ S3bOp s3b_load_f32(const float* p) {
+    const f32x4 lo4 = *(const f32x4*)p, hi4 = *(const f32x4*)(p + 4);
+    S3bOp o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 a, b, c;
+        s3b_split(j < 4 ? lo4[j] : hi4[j - 4], a, b, c);
+        o.h[j] = a; o.m[j] = b; o.l[j] = c;
+    }
+    return o;
+}
+// 4 rows of one sample back from the three images: the pieces sum to the fp32 value exactly
+__device__ __forceinline__ f32x4 s3b_load4(const char* img, int piece_bytes) {
+    const bf16x4 h = *(const bf16x4*)img, m = *(const bf16x4*)(img + piece_bytes), l = *(const bf16x4*)(img + 2 * piece_bytes);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (float)h[j] + ((float)m[j] + (float)l[j]);
+    return v;
+}
+
+__global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __restrict__ imgb, int n_in, int norm_z,
+                                                   int norm_j, const S3Tab tab, int single) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* ldsb = reinterpret_cast<char*>(lds);
+    const float* img3 = reinterpret_cast<const float*>(imgb);      // (a valid address for masked loads)
+    const StepState* st = a.st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = n_in + 3;
+    const int s = lane & 15, q = lane >> 4;
+    const int t = wave & 1, hf = (wave >> 1) & 1;         // narrow phases: row tile and sample half of this wave
+    const bool zown = wave < 4;                           // waves 0-3 produce zdot: they hold the z rows of the state
+    const bool sown = !zown && t == 0 && q == 0;          // waves 4, 6: lane s holds the scalar rows of sample 16 hf + s
+    const int smp = 16 * hf + s;                          // sample of this lane in the narrow phases
+    const int r0 = 16 * t + 4 * q;                        // first of its 4 rows there
+    const int nv = n_in - r0;                             // valid rows among them (may be <= 0 or > 4)
+    // ---- everything the launch needs from memory is requested up front, in ONE round trip, and nothing is consumed
+    // before all of it is in flight.  Order of issue = order of return: the integrator state words first (the `done`
+    // test and the controller need them soonest), then the error partials, the weight stream (135 KB per workgroup:
+    // it bounds the prologue, so it must not queue behind anything that waits), then this workgroup's first tile from
+    // BOTH buffer sets (which one is current is the controller's decision).
+    StepState st0;                                         // the controller thread's copy
+    if (tid == 0) st0 = *st;
+    const int v_done = st->done, v_cur = st->cur;
+    const float v_h = st->h, v_abstol = st->abstol, v_reltol = st->reltol;
+    float cp0 = 0.f, cp1 = 0.f;
+    if (a.apply_ctrl)
+        for (int i = tid; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
+    // Weights, pre-split into three bf16 pieces (k_pack_step3b).  Resident fragments of this wave: its 16-row tile of W1
+    // and of W3^T (K = 32: one k-block), of W2 and of W2^T (four k-blocks).  The K = 128 operands of the narrow products
+    // (rows of W3, rows of W1^T) stay in LDS as split images, copied as they are stored (LDS-DMA).
+    constexpr int NCI = 2 * s3v::WI / 16, NCB = (2 * 128 + 32) / 4;
+    static_assert(NCI % 64 == 0, "whole wave instructions");
+    {
+        typedef __attribute__((address_space(3))) char* lds_c;
+        typedef const __attribute__((address_space(1))) char* glb_c;
+#pragma unroll
+        for (int i = 0; i < (NCI + 511) / 512; ++i) {
+            const int c = 512 * i + 64 * wave;                 // wave-uniform chunk (16 B) index
+            if (c < NCI)
+                __builtin_amdgcn_global_load_lds((glb_c)(imgb + s3v::G_W3I + 16 * (c + lane)), (lds_c)(ldsb + s3v::W3I + 16 * c), 16, 0, 0);
+        }
+    }
+    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3b::BIASB)[min(tid, NCB - 1)];
+    S3bOp wF1, wF2[4], wB3, wB2[4];
+    {
+        wF1 = s3b_load(imgb + s3b::FR1 + (size_t)wave * 3 * 1024 + 16 * lane, 1024);
+        wB3 = s3b_load(imgb + s3v::G_FRB3 + (size_t)wave * 3 * 1024 + 16 * lane, 1024);
+        const char* f2 = imgb + s3b::FR2 + (size_t)wave * 4 * 3 * 1024 + 16 * lane;
+        const char* r2 = imgb + s3v::G_FRB2 + (size_t)wave * 4 * 3 * 1024 + 16 * lane;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { wF2[b] = s3b_load(f2 + b * 3 * 1024, 1024); wB2[b] = s3b_load(r2 + b * 3 * 1024, 1024); }
+    }
+    const int ntile = (a.B + 32 - 1) / 32;
+    f32x4 ru[2], rk[2], re, rs[2][2];
+    int ce = 0, cu = 0, cs = 0;
+    float* sc = lds + s3v::SC + smp * 24;
+    auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
+    auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
+    {
+        const int b0 = blockIdx.x * 32 + 16 * hf;
+        const bool live = s < max(0, min(16, a.B - b0));
+        const size_t gcol = (size_t)(b0 + s) * D;
+        ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
+        re = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            ru[c] = ld4_issue(a.U[c] + gcol + r0, cu, img3);
+            rk[c] = ld4_issue(a.K1[c] + gcol + r0, cu, img3);
+            rs[c][0] = ld4_issue(a.U[c] + gcol + n_in, cs, img3);
+            rs[c][1] = ld4_issue(a.K1[c] + gcol + n_in, cs, img3);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);                     // nothing above is consumed before all of it is requested
+    // (wave-uniform values into scalar registers: the buffer pointers selected from `cur` stay out of the vector file)
+    const int st_done = __builtin_amdgcn_readfirstlane(v_done), st_cur = __builtin_amdgcn_readfirstlane(v_cur);
+    const float st_h = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_h)));
+    const float st_abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_abstol)));
+    const float st_reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_reltol)));
+    if (st_done) {       // launches queued past the end of the solve: keep the state chain intact and leave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the LDS-DMA pieces must have landed before the wave ends)
+        if (a.apply_ctrl && blockIdx.x == 0 && tid == 0) { *a.st_out = *st; publish_mirror(a, *st); }
+        return;
+    }
+    // scalar rows of both candidates wait in LDS (slots 2..5 of the scalar-row state) for the controller's choice
+    if (sown) {
+        sc_set(2, ld4_mask(rs[0][0], cs)); sc_set(3, ld4_mask(rs[0][1], cs));
+        sc_set(4, ld4_mask(rs[1][0], cs)); sc_set(5, ld4_mask(rs[1][1], cs));
+    }
+    // the probe rows go straight to their LDS image (waves 0-3 need them for g3, waves 4-7 for the trace row)
+    f32x4 epsr = ld4_mask(re, ce);                         // this lane's 4 probe rows of sample smp (g3 on waves 0-3, trace row on 4-7)
+    float* msc = lds + s3v::MISC;
+    if (a.apply_ctrl) {
+        cp0 = s3_wave_sum(cp0); cp1 = s3_wave_sum(cp1);
+        if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; }
+    }
+    if (tid < NCB) reinterpret_cast<f32x4*>(lds + s3v::BIAS)[tid] = sgb;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA pieces have landed (then the barrier)
+    s3_bar();                                              // staging image and partial sums complete
+    int cur = st_cur;
+    float hstep = st_h, abstol = st_abstol, reltol = st_reltol;
+    if (a.apply_ctrl && tid == 0) {
+        // In-kernel step controller (as in k_mfma): every workgroup reduces the same partials in the same order
+        // and takes the same decision; block 0 publishes the new state for the next launch and the host mirror.
+        float p0 = 0.f, p1 = 0.f;
+        for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
+        StepState ns = st0;
+        ctrl_after_step(&ns, p0, p1, a.n_total);
+        if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
+        msc[32] = __int_as_float(ns.cur); msc[33] = ns.h; msc[34] = ns.abstol; msc[35] = ns.reltol;
+        msc[36] = __int_as_float(ns.done);
+    }
+    s3_bar();                                              // controller done; the staging area is free
+    if (a.apply_ctrl) {
+        cur = __builtin_amdgcn_readfirstlane(__float_as_int(msc[32]));
+        hstep = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[33])));
+        abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[34])));
+        reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[35])));
+        if (__float_as_int(msc[36])) return;        // the controller just finished the solve
+    }
+    // (explicit selects: indexing the kernel-argument arrays with a run-time value makes the compiler fetch the
+    // pointer from the argument segment through a vector load -- a memory round trip in front of the state loads)
+    // single != 0: ONE evaluation instead of a step attempt -- the two launches of the automatic initial dt
+    // (1: f(u) -> a.du with the norms of phase 0; 2: f(u + h k1) -> a.Ks0 with the norm of phase 1), same prologue,
+    // same evaluation code; the last workgroup to finish runs the controller phase (as k_mfma does for them)
+    const int nstg = single ? 1 : 6;
+    const float c21 = single == 1 ? 0.f : (single == 2 ? 1.f : TS_A21);
+    const float* Uin = cur ? a.U[1] : a.U[0];
+    const float* K1in = cur ? a.K1[1] : a.K1[0];
+    float* Uout = cur ? a.U[0] : a.U[1];
+    float* K1out = cur ? a.K1[0] : a.K1[1];
+
+    float errsum = 0.f, badcnt = 0.f;
+    // the 8 partials (2 row tiles x 4 lanes) of one sample and one kind sit side by side: two b128 reads each
+    auto red8 = [&](int kind) {
+        const float* r = lds + s3v::RED + (kind * 32 + smp) * 8;
+        const f32x4 a_ = *(const f32x4*)r, b_ = *(const f32x4*)(r + 4);
+        return ((a_.x + a_.y) + (a_.z + a_.w)) + ((b_.x + b_.y) + (b_.z + b_.w));
+    };
+    auto read_scalars = [&]() {
+        const float e2 = red8(0), ld = red8(1), n2 = red8(2);
+        return f32x4{ld, norm_z ? __builtin_sqrtf(e2) : 0.f, norm_j ? __builtin_sqrtf(n2) : 0.f, 0.f};
+    };
+    float* redw = lds + s3v::RED + smp * 8 + 4 * t + q;                 // this lane's slot of kind 0 (+ 256 per kind)
+    // B operands from a split image: lane (sample s of half A, k = 8q ..); half B = 16 rows on.  Results: lane (sample s,
+    // rows 16 wave + 4q ..) of the wide images
+    const int wb_rd = s * s3v::WS + 16 * q, wb_wr = s * s3v::WS + 2 * (16 * wave + 4 * q);
+    constexpr int HBW = 16 * s3v::WS;
+    // narrow products: A = rows 16t + s of W3 (waves 0-3) / of W1^T (waves 4-7), B = this wave's half of h2 / g1
+    const char* nrA = ldsb + (zown ? s3v::W3I : s3v::W1TI) + (16 * t + s) * s3v::WS + 16 * q;
+    const char* nrB = ldsb + (zown ? s3v::H2G : s3v::H1G) + smp * s3v::WS + 16 * q;
+    float* x0w = lds + s3v::X0 + smp * 40 + r0;
+    float* g3w = lds + s3v::G3 + smp * 40 + r0;
+    // Runge-Kutta state of the z rows r0..r0+3 of sample smp, written and read by this lane only:
+    float* rkw = lds + s3v::KZ + smp * s3v::SKZ + r0;                   // u at rkw, k1 at rkw + 32,
+    float* kzw = rkw + 64;                                            // k_{j+2} at kzw + 32 j (j = 0..5)
+    const float* bias = lds + s3v::BIAS;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int b0 = tile * 32 + 16 * hf;
+        const bool live = s < max(0, min(16, a.B - b0));
+        const size_t gcol = (size_t)(b0 + s) * D;
+        f32x4 uz, k1z;
+        if (tile == blockIdx.x) {                              // requested at kernel entry
+            uz = ld4_mask(cur ? ru[1] : ru[0], cu);
+            k1z = ld4_mask(cur ? rk[1] : rk[0], cu);
+            if (sown) { sc_set(0, sc_get(cur ? 4 : 2)); sc_set(1, sc_get(cur ? 5 : 3)); }
+            if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }     // there is no k1 yet
+        } else {
+            ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
+            const f32x4 e_ = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+            const f32x4 u_ = ld4_issue(Uin + gcol + r0, cu, img3), k_ = ld4_issue(K1in + gcol + r0, cu, img3);
+            const f32x4 s0 = ld4_issue(Uin + gcol + n_in, cs, img3), s1 = ld4_issue(K1in + gcol + n_in, cs, img3);
+            epsr = ld4_mask(e_, ce); uz = ld4_mask(u_, cu); k1z = ld4_mask(k_, cu);
+            if (sown) { sc_set(0, ld4_mask(s0, cs)); sc_set(1, ld4_mask(s1, cs)); }
+            if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }
+        }
+        if (zown) {
+            *(f32x4*)x0w = uz + (hstep * c21) * k1z;      // state of evaluation 1: U_2 = u + h a21 k1
+            *(f32x4*)rkw = uz;
+            *(f32x4*)(rkw + 32) = k1z;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;       // k2..k7: not produced yet
+        }
+        s3_bar();
+
+        for (int stg = 1; stg <= nstg; ++stg) {
+            // ---- interval 0: first layer, tile `wave`, both halves (K = 32: one k-block; the fp32 state is split on the way in)
+            {
+                const f32x4 bv1 = *(const f32x4*)(bias + 16 * wave + 4 * q);
+                S3bOp b[2];
+                b[0] = s3b_load_f32(lds + s3v::X0 + s * 40 + 8 * q);
+                b[1] = s3b_load_f32(lds + s3v::X0 + (16 + s) * 40 + 8 * q);
+                S3_SB();
+                f32x4 acc[2] = {zero4, zero4};
+                s3b_mm<2>(acc, wF1, b);
+                s3b_store4(ldsb + s3v::H1G + wb_wr, s3v::WP, s3_tanh4(acc[0] + bv1));
+                s3b_store4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP, s3_tanh4(acc[1] + bv1));
+            }
+            s3_bar();                                                          // h1 visible
+            // ---- interval 1: second layer, tile `wave`, both halves share the A fragments
+            {
+                const f32x4 bv2 = *(const f32x4*)(bias + 128 + 16 * wave + 4 * q);
+                // scalar rows of the PREVIOUS evaluation from its RED partials (complete since the last barrier of it)
+                if (stg > 1 && sown) sc_set(stg, read_scalars());              // slot j holds k_j
+                f32x4 acc[2] = {zero4, zero4};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    S3bOp b[2];
+                    b[0] = s3b_load(ldsb + s3v::H1G + wb_rd + 64 * kb, s3v::WP);
+                    b[1] = s3b_load(ldsb + s3v::H1G + wb_rd + HBW + 64 * kb, s3v::WP);
+                    S3_SB();
+                    s3b_mm<2>(acc, wF2[kb], b);
+                    S3_SB();
+                }
+                s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, s3_tanh4(acc[0] + bv2));
+                s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, s3_tanh4(acc[1] + bv2));
+            }
+            s3_bar();                                                          // h2 visible
+            // ---- interval 2: last layer on waves 0-3 (one per SIMD): zdot rows r0..r0+3 of sample smp
+            if (zown) {
+                const f32x4 bv3 = *(const f32x4*)(bias + 256 + r0);
+                f32x4 z0 = zero4, z1 = zero4;                                  // two chains (terms 0-2 / 3-5)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const S3bOp av = s3b_load(nrA + 64 * kb, s3v::WP), bvv = s3b_load(nrB + 64 * kb, s3v::WP);
+                    S3_SB();
+                    z0 = s3b_term<0>(av, bvv, z0); z1 = s3b_term<3>(av, bvv, z1);
+                    z0 = s3b_term<1>(av, bvv, z0); z1 = s3b_term<4>(av, bvv, z1);
+                    z0 = s3b_term<2>(av, bvv, z0); z1 = s3b_term<5>(av, bvv, z1);
+                    S3_SB();
+                }
+                // stage sum without the k this evaluation will produce: pre = u + h sum_{j<stg} a_{stg+1,j} k_j
+                const float* A = tab.a[stg < 6 ? stg + 1 : 6];
+                f32x4 pre = *(const f32x4*)rkw + (hstep * A[0]) * *(const f32x4*)(rkw + 32);
+#pragma unroll
+                for (int j = 1; j < 5; ++j) pre += (hstep * A[j]) * *(const f32x4*)(kzw + 32 * (j - 1));
+                const f32x4 zd = s3_tanh4(z0 + z1 + bv3);                      // padded rows: zero weights and bias -> 0
+                *(f32x4*)g3w = epsr * s3_dtanh4(zd);                           // g3 = eps .* sigma'_3
+                if (stg < 6) *(f32x4*)x0w = pre + (hstep * A[stg]) * zd;       // state of the next evaluation
+                *(f32x4*)(kzw + 32 * (stg - 1)) = zd;                          // k_{stg+1}
+                redw[0] = s3_dot4(zd, zd);
+            }
+            s3_bar();                                                          // g3 (and the next stage state) visible
+            // ---- interval 3: reverse of the last layer, tile `wave` of W3^T, both halves (K = 32); g2 over h2 in place
+            {
+                S3bOp b[2];
+                b[0] = s3b_load_f32(lds + s3v::G3 + s * 40 + 8 * q);
+                b[1] = s3b_load_f32(lds + s3v::G3 + (16 + s) * 40 + 8 * q);
+                const f32x4 h2a = s3b_load4(ldsb + s3v::H2G + wb_wr, s3v::WP), h2b = s3b_load4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP);
+                S3_SB();
+                f32x4 acc[2] = {zero4, zero4};
+                s3b_mm<2>(acc, wB3, b);
+                s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, acc[0] * s3_dtanh4(h2a));
+                s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, acc[1] * s3_dtanh4(h2b));
+            }
+            s3_bar();                                                          // g2 visible
+            // ---- interval 4: reverse of the second layer, tile `wave` of W2^T; g1 over h1 in place
+            {
+                const f32x4 h1a = s3b_load4(ldsb + s3v::H1G + wb_wr, s3v::WP), h1b = s3b_load4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP);
+                f32x4 acc[2] = {zero4, zero4};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    S3bOp b[2];
+                    b[0] = s3b_load(ldsb + s3v::H2G + wb_rd + 64 * kb, s3v::WP);
+                    b[1] = s3b_load(ldsb + s3v::H2G + wb_rd + HBW + 64 * kb, s3v::WP);
+                    S3_SB();
+                    s3b_mm<2>(acc, wB2[kb], b);
+                    S3_SB();
+                }
+                s3b_store4(ldsb + s3v::H1G + wb_wr, s3v::WP, acc[0] * s3_dtanh4(h1a));
+                s3b_store4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP, acc[1] * s3_dtanh4(h1b));
+            }
+            s3_bar();                                                          // g1 visible
+            // ---- interval 5: eJ = W1^T g1 on waves 4-7 (one per SIMD): trace and norm partials (src/icnf.jl:334, :343)
+            if (!zown) {
+                f32x4 j0 = zero4, j1 = zero4;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const S3bOp av = s3b_load(nrA + 64 * kb, s3v::WP), bvv = s3b_load(nrB + 64 * kb, s3v::WP);
+                    S3_SB();
+                    j0 = s3b_term<0>(av, bvv, j0); j1 = s3b_term<3>(av, bvv, j1);
+                    j0 = s3b_term<1>(av, bvv, j0); j1 = s3b_term<4>(av, bvv, j1);
+                    j0 = s3b_term<2>(av, bvv, j0); j1 = s3b_term<5>(av, bvv, j1);
+                    S3_SB();
+                }
+                const f32x4 ej = j0 + j1;
+                redw[32 * 8] = -s3_dot4(ej, epsr);
+                redw[2 * 32 * 8] = s3_dot4(ej, ej);
+            }
+            s3_bar();                                                          // RED complete; h1 / g1 free for the next evaluation
+        }
+        if (single) {
+            // ---- one evaluation: f -> out, and the norms of the initial-dt phase over the rows this lane owns ----
+            float* out = (single == 1 ? a.du : a.Ks0) + (size_t)(tile * 32 + 16 * hf + s) * D;
+            auto norms = [&](const f32x4& u4, const f32x4& f0, const f32x4& f1, int nvalid) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < nvalid) {
+                        const float sk = fmaf(fabsf(u4[c]), reltol, abstol);
+                        if (single == 1) {
+                            const float x = u4[c] / sk, y = f1[c] / sk;
+                            errsum = fmaf(x, x, errsum); badcnt = fmaf(y, y, badcnt);
+                        } else {
+                            const float x = (f1[c] - f0[c]) / sk;
+                            errsum = fmaf(x, x, errsum);
+                        }
+                    }
+                }
+            };
+            if (live && zown) {
+                const f32x4 f1 = *(const f32x4*)kzw;                    // k2 slot = this evaluation's zdot
+                st4(out + r0, f1, nv);
+                if (a.init_phase >= 0) norms(*(const f32x4*)rkw, *(const f32x4*)(rkw + 32), f1, nv);
+            }
+            if (live && sown) {
+                const f32x4 f1 = read_scalars();
+                out[n_in] = f1.x; out[n_in + 1] = f1.y; out[n_in + 2] = f1.z;
+                if (a.init_phase >= 0) norms(sc_get(0), sc_get(1), f1, 3);
+            }
+        }
+        // ---- error estimate and outputs: u_new (= the state evaluation 6 ran at) and k7 ----
+        if (!single && live && zown) {
+            const f32x4 k7z = *(const f32x4*)(kzw + 32 * 5), uz_ = *(const f32x4*)rkw;
+            const f32x4 un = *(const f32x4*)x0w;           // U_7 = u_new: the state the last evaluation ran at
+            f32x4 ez = TS_BT1 * *(const f32x4*)(rkw + 32) + TS_BT7 * k7z;
+            ez += TS_BT2 * *(const f32x4*)(kzw) + TS_BT3 * *(const f32x4*)(kzw + 32) + TS_BT4 * *(const f32x4*)(kzw + 64) +
+                  TS_BT5 * *(const f32x4*)(kzw + 96) + TS_BT6 * *(const f32x4*)(kzw + 128);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                  // rows beyond n_in: u = k = 0 -> contribute exactly 0
+                const float scl = fmaf(fmaxf(fabsf(uz_[c]), fabsf(un[c])), reltol, abstol);
+                const float x = c < nv ? hstep * ez[c] / scl : 0.f;
+                errsum = fmaf(x, x, errsum);
+                badcnt += (c < nv && !(fabsf(un[c]) <= 3.0e38f)) ? 1.f : 0.f;
+            }
+            const size_t gc = (size_t)(tile * 32 + 16 * hf + s) * D;
+            float* Un = Uout + gc + r0;
+            float* K7 = K1out + gc + r0;
+            if (nv >= 4) {
+                Un[0] = un.x; Un[1] = un.y; Un[2] = un.z; Un[3] = un.w;
+                K7[0] = k7z.x; K7[1] = k7z.y; K7[2] = k7z.z; K7[3] = k7z.w;
+            } else { st4(Un, un, nv); st4(K7, k7z, nv); }
+        }
+        if (!single && live && sown) {
+            f32x4 ks[7];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ks[j] = sc_get(1 + j);
+            const f32x4 us = sc_get(0);
+            ks[6] = read_scalars();                        // k7 of the scalar rows, straight from the partials
+            const f32x4 uns = us + hstep * stage_acc4<6>(ks);
+            err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
+            const size_t gc = (size_t)(tile * 32 + 16 * hf + s) * D;
+            float* Un = Uout + gc + n_in;
+            float* K7 = K1out + gc + n_in;
+            Un[0] = uns.x; Un[1] = uns.y; Un[2] = uns.z;
+            K7[0] = ks[6].x; K7[1] = ks[6].y; K7[2] = ks[6].z;
+        }
+        s3_bar();                                          // this tile's RED / SC / KZ reads precede the next tile's writes
+    }
+    // deterministic block reduction of the error partial (fixed tree, fixed order)
+    errsum = s3_wave_sum(errsum);
+    badcnt = s3_wave_sum(badcnt);
+    if (lane == 0) { msc[wave] = errsum; msc[16 + wave] = badcnt; }
+    s3_bar();
+    if (tid == 0) {
+        float e = 0.f, b = 0.f;
+        for (int w = 0; w < 8; ++w) { e += msc[w]; b += msc[16 + w]; }
+        if (!single) {
+            a.partials[2 * blockIdx.x] = e;
+            a.partials[2 * blockIdx.x + 1] = b;
+        } else if (a.init_phase >= 0) {
+            // initial-dt phase: partials through agent-scope atomics, then a ticket; whoever draws the last one sums all
+            // partials (fixed order) and runs the controller phase -- no separate launches
+            __hip_atomic_store(a.partials + 2 * blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.partials + 2 * blockIdx.x + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            msc[40] = (tk == gridDim.x - 1) ? 1.f : 0.f;
+            if (tk == gridDim.x - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (single && a.init_phase >= 0) {
+        s3_bar();
+        if (msc[40] != 0.f) {                        // this workgroup drew the last ticket: all its threads reduce
+            float q0 = 0.f, q1 = 0.f;
+            for (int i = tid; i < (int)gridDim.x; i += 512) {
+                q0 += __hip_atomic_load(a.partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q1 += __hip_atomic_load(a.partials + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            q0 = s3_wave_sum(q0); q1 = s3_wave_sum(q1);
+            if (lane == 0) { msc[wave] = q0; msc[16 + wave] = q1; }
+            s3_bar();
+            if (tid == 0) {
+                float p0 = 0.f, p1 = 0.f;
+                for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
+                ctrl_phase(a.st_out, single - 1, p0, p1, a.n_total);
+            }
+        }
+    }
+}
+
+// Split weight image of k_step3jb / k_step3b.  Fragment f, lane = 16q + x: the 8 weights M[16 tile + x][32 kblock + 8q .. +7]
+// of M = W1 | W2 | W3 (k_step3jb, k_step3b) | W2^T | W3^T (k_step3b) as three bf16 pieces; then the two LDS images of
+// k_step3b (rows of W3, rows of W1^T) in their LDS layout; biases in fp32.
 __global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __restrict__ img) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int NF = 8 + 32 + 8;
+    constexpr int NF = 8 + 32 + 8 + 32 + 8, NIMG = 2 * 32 * 17;
     if (i < (2 * 128 + 32)) {
         const int l = i < 128 ? 0 : (i < 256 ? 1 : 2), o = i < 128 ? i : (i < 256 ? i - 128 : i - 256);
         reinterpret_cast<float*>(img + s3b::BIASB)[i] = o < nd.dims[l + 1] ? P[nd.b_off[l] + o] : 0.f;
     }
-    if (i >= NF * 64) return;
-    const int f = i >> 6, lane = i & 63, x = lane & 15, q = lane >> 4;
-    int l, tile, kb;
-    char* dst;
-    if (f < 8) { l = 0; tile = f; kb = 0; dst = img + s3b::FR1 + (size_t)f * 3 * 1024; }
-    else if (f < 40) { l = 1; tile = (f - 8) >> 2; kb = (f - 8) & 3; dst = img + s3b::FR2 + (size_t)(f - 8) * 3 * 1024; }
-    else { l = 2; tile = (f - 40) >> 2; kb = (f - 40) & 3; dst = img + s3b::FR3 + (size_t)(f - 40) * 3 * 1024; }
+    // W_l[o][k] with zero padding
+    auto W = [&](int l, int o, int k) {
+        return (o < nd.dims[l + 1] && k < nd.dims[l]) ? P[nd.w_off[l] + o + (size_t)k * nd.dims[l + 1]] : 0.f;
+    };
     bf16x8 h, m, lo;
-    const int o = 16 * tile + x;
+    char* dst = nullptr;
+    if (i < NF * 64) {
+        const int f = i >> 6, lane = i & 63, x = lane & 15, q = lane >> 4;
+        int l, tile, kb, tr = 0;                   // tr: the fragment is a tile of the TRANSPOSED matrix
+        if (f < 8) { l = 0; tile = f; kb = 0; dst = img + s3b::FR1 + (size_t)f * 3 * 1024; }
+        else if (f < 40) { l = 1; tile = (f - 8) >> 2; kb = (f - 8) & 3; dst = img + s3b::FR2 + (size_t)(f - 8) * 3 * 1024; }
+        else if (f < 48) { l = 2; tile = (f - 40) >> 2; kb = (f - 40) & 3; dst = img + s3b::FR3 + (size_t)(f - 40) * 3 * 1024; }
+        else if (f < 80) { l = 1; tr = 1; tile = (f - 48) >> 2; kb = (f - 48) & 3; dst = img + s3v::G_FRB2 + (size_t)(f - 48) * 3 * 1024; }
+        else { l = 2; tr = 1; tile = f - 80; kb = 0; dst = img + s3v::G_FRB3 + (size_t)(f - 80) * 3 * 1024; }
+        dst += 16 * lane;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 32 * kb + 8 * q + j;
-        const float v = (o < nd.dims[l + 1] && k < nd.dims[l]) ? P[nd.w_off[l] + o + (size_t)k * nd.dims[l + 1]] : 0.f;
-        __bf16 a, b, c;
-        s3b_split(v, a, b, c);
-        h[j] = a; m[j] = b; lo[j] = c;
+        for (int j = 0; j < 8; ++j) {
+            const int r = 16 * tile + x, k = 32 * kb + 8 * q + j;
+            __bf16 a, b, c;
+            s3b_split(tr ? W(l, k, r) : W(l, r, k), a, b, c);
+            h[j] = a; m[j] = b; lo[j] = c;
+        }
+        *(bf16x8*)dst = h; *(bf16x8*)(dst + 1024) = m; *(bf16x8*)(dst + 2048) = lo;
+    } else if (i < NF * 64 + NIMG) {
+        const int e = i - NF * 64, which = e / (32 * 17), r = (e / 17) % 32, g = e % 17;     // 17 groups of 8 bf16 per row
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * g + j;
+            const float v = k < 128 ? (which == 0 ? W(2, r, k) : W(0, k, r)) : 0.f;      // W3[r][k] | W1^T[r][k] = W1[k][r]
+            __bf16 a, b, c;
+            s3b_split(v, a, b, c);
+            h[j] = a; m[j] = b; lo[j] = c;
+        }
+        dst = img + s3v::G_W3I + (size_t)which * s3v::WI + r * s3v::WS + 16 * g;
+        *(bf16x8*)dst = h; *(bf16x8*)(dst + s3v::WP) = m; *(bf16x8*)(dst + 2 * s3v::WP) = lo;
     }
-    *(bf16x8*)(dst + 16 * lane) = h; *(bf16x8*)(dst + 1024 + 16 * lane) = m; *(bf16x8*)(dst + 2048 + 16 * lane) = lo;
 }
 
-size_t step3b_img_bytes() { return (size_t)s3b::IMG_BYTES; }
+size_t step3b_img_bytes() { return (size_t)s3v::IMG_BYTES; }
 void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStream_t s) {
-    hipLaunchKernelGGL(k_pack_step3b, dim3((48 * 64 + 255) / 256), dim3(256), 0, s, nd, d_params, (char*)d_imgb);
+    constexpr int NT = (8 + 32 + 8 + 32 + 8) * 64 + 2 * 32 * 17;
+    hipLaunchKernelGGL(k_pack_step3b, dim3((NT + 255) / 256), dim3(256), 0, s, nd, d_params, (char*)d_imgb);
+}
+void step3b_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_step3b, hipFuncAttributeMaxDynamicSharedMemorySize, s3v::TOTAL_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_step3b, grid, dim3(512), s3v::TOTAL_BYTES, s, a, (const char*)d_imgb, n_in, norm_z, norm_j, kS3Tab, single);
 }
 void step3jb_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single) {
     static bool attr = false;
