@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # kernel arguments in device memory (see continuousnf.jl_amd/__init__.py)
 
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0       # spec
 PMC_FILE = os.path.join("profiles", "round2_step_kernel_pmc.json")   # tools/collect_profiles.sh + summarize_profiles.py
 
@@ -293,8 +294,18 @@ def run_rank(args):
                               f"only; built from commit {rec.get('commit', '?')}); not measured in this run")
         tf = units * fl.value / per_launch_s / 1e12
         gbs = units * by.value / per_launch_s / 1e9
+        # The step kernel of the headline shape forms every fp32 product from six bf16 MFMA terms on operands split EXACTLY
+        # into three bf16 pieces (CNF_STEP_FP32=1 selects the fp32-MFMA kernel).  `achieved` stays what the contract
+        # defines -- algorithmic fp32 flops per launch over the launch time -- and is priced against the fp32 MFMA peak;
+        # `executed` prices the bf16 flops actually issued (6 per fp32 product) against the bf16 peak.
+        split = kernel_used == _lib.KERNEL_MFMA and os.environ.get("CNF_STEP_FP32") != "1"
         roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                 "frac": tf / PEAK_F32_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "kernel": kname,
+                "arithmetic": ("fp32 result of every product = six v_mfma_f32_16x16x32_bf16 terms on operands split exactly "
+                               "into three bf16 pieces, fp32 accumulate; measured as accurate as v_mfma_f32_16x16x4_f32 "
+                               "(tools/ubench/bf16_split.hip, parity suite unchanged)") if split else "v_mfma_f32_16x16x4_f32",
+                "executed": ({"unit": "TFLOP/s bf16", "achieved": 6.0 * tf, "peak": PEAK_BF16_TFLOPS,
+                              "frac": 6.0 * tf / PEAK_BF16_TFLOPS} if split else None),
                 "launch_us": per_launch_s * 1e6,
                 "algorithmic_flops_per_launch": units * fl.value,
                 "algorithmic_bytes_per_launch": units * by.value,
@@ -306,7 +317,9 @@ def run_rank(args):
             "value": nf_all / elapsed, "unit": "RHS-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if os.environ.get("CNF_STEP_FP32") == "1" else "f32 (products as six bf16 MFMA terms of exactly split operands, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: RNODE nvars=32 naugs=0, MLP 32-128-128-32 tanh, "
                                    f"batch {B} per GPU, TrainMode Hutchinson VJP, Tsit5 tspan (0,1), "
                                    + (f"fixed dt={args.fixed_dt}" if args.fixed_dt > 0 else

@@ -1093,11 +1093,17 @@ constexpr int BIASB = FR3 + 2 * 4 * 3 * 1024;              // b1 (128), b2 (128)
 constexpr int IMG_BYTES = BIASB + (2 * 128 + 32) * 4;
 }  // namespace s3b
 
+// v = h + m + l exactly: pieces by TRUNCATION (one AND each: the upper 16 bits of an fp32 are a bf16), residuals by exact
+// subtractions; the last residual has at most 8 significant bits, so its upper half is all of it.  (Round-to-nearest
+// pieces cost a convert and a widen each and buy nothing: the three products left out are below 2^-24 either way.)
 __device__ __forceinline__ void s3b_split(float v, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)v;
-    const float r1 = v - (float)h;
-    m = (__bf16)r1;
-    l = (__bf16)(r1 - (float)m);
+    const unsigned hb = __float_as_uint(v) & 0xFFFF0000u;
+    const float r1 = v - __uint_as_float(hb);
+    const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(mb);
+    h = __builtin_bit_cast(__bf16, (unsigned short)(hb >> 16));
+    m = __builtin_bit_cast(__bf16, (unsigned short)(mb >> 16));
+    l = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(r2) >> 16));
 }
 // 4 rows of one sample -> the three images (8 bytes each)
 __device__ __forceinline__ void s3b_store4(char* img, int piece_bytes, const f32x4& v) {
@@ -1540,6 +1546,11 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     const int smp = 16 * hf + s;                          // sample of this lane in the narrow phases
     const int r0 = 16 * t + 4 * q;                        // first of its 4 rows there
     const int nv = n_in - r0;                             // valid rows among them (may be <= 0 or > 4)
+#ifdef S3_STAMPS
+    unsigned long long s3acc[36] = {0};
+    unsigned long long s3last = __builtin_amdgcn_s_memtime();
+    const unsigned long long s3start = s3last;
+#endif
     // ---- everything the launch needs from memory is requested up front, in ONE round trip, and nothing is consumed
     // before all of it is in flight.  Order of issue = order of return: the integrator state words first (the `done`
     // test and the controller need them soonest), then the error partials, the weight stream (135 KB per workgroup:
@@ -1683,6 +1694,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     const float* bias = lds + s3v::BIAS;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    S3T(20);
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const int b0 = tile * 32 + 16 * hf;
         const bool live = s < max(0, min(16, a.B - b0));
@@ -1710,6 +1722,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
             for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;       // k2..k7: not produced yet
         }
         s3_bar();
+        S3T(21);
 
         for (int stg = 1; stg <= nstg; ++stg) {
             // ---- interval 0: first layer, tile `wave`, both halves (K = 32: one k-block; the fp32 state is split on the way in)
@@ -1724,7 +1737,9 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
                 s3b_store4(ldsb + s3v::H1G + wb_wr, s3v::WP, s3_tanh4(acc[0] + bv1));
                 s3b_store4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP, s3_tanh4(acc[1] + bv1));
             }
-            s3_bar();                                                          // h1 visible
+            S3T(0);
+            s3_bar();
+            S3T(1);                                                          // h1 visible
             // ---- interval 1: second layer, tile `wave`, both halves share the A fragments
             {
                 const f32x4 bv2 = *(const f32x4*)(bias + 128 + 16 * wave + 4 * q);
@@ -1743,7 +1758,9 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
                 s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, s3_tanh4(acc[0] + bv2));
                 s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, s3_tanh4(acc[1] + bv2));
             }
-            s3_bar();                                                          // h2 visible
+            S3T(2);
+            s3_bar();
+            S3T(3);                                                          // h2 visible
             // ---- interval 2: last layer on waves 0-3 (one per SIMD): zdot rows r0..r0+3 of sample smp
             if (zown) {
                 const f32x4 bv3 = *(const f32x4*)(bias + 256 + r0);
@@ -1768,7 +1785,9 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
                 *(f32x4*)(kzw + 32 * (stg - 1)) = zd;                          // k_{stg+1}
                 redw[0] = s3_dot4(zd, zd);
             }
-            s3_bar();                                                          // g3 (and the next stage state) visible
+            S3T(4);
+            s3_bar();
+            S3T(5);                                                          // g3 (and the next stage state) visible
             // ---- interval 3: reverse of the last layer, tile `wave` of W3^T, both halves (K = 32); g2 over h2 in place
             {
                 S3bOp b[2];
@@ -1781,7 +1800,9 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
                 s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, acc[0] * s3_dtanh4(h2a));
                 s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, acc[1] * s3_dtanh4(h2b));
             }
-            s3_bar();                                                          // g2 visible
+            S3T(6);
+            s3_bar();
+            S3T(7);                                                          // g2 visible
             // ---- interval 4: reverse of the second layer, tile `wave` of W2^T; g1 over h1 in place
             {
                 const f32x4 h1a = s3b_load4(ldsb + s3v::H1G + wb_wr, s3v::WP), h1b = s3b_load4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP);
@@ -1798,7 +1819,9 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
                 s3b_store4(ldsb + s3v::H1G + wb_wr, s3v::WP, acc[0] * s3_dtanh4(h1a));
                 s3b_store4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP, acc[1] * s3_dtanh4(h1b));
             }
-            s3_bar();                                                          // g1 visible
+            S3T(8);
+            s3_bar();
+            S3T(9);                                                          // g1 visible
             // ---- interval 5: eJ = W1^T g1 on waves 4-7 (one per SIMD): trace and norm partials (src/icnf.jl:334, :343)
             if (!zown) {
                 f32x4 j0 = zero4, j1 = zero4;
@@ -1815,7 +1838,9 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
                 redw[32 * 8] = -s3_dot4(ej, epsr);
                 redw[2 * 32 * 8] = s3_dot4(ej, ej);
             }
-            s3_bar();                                                          // RED complete; h1 / g1 free for the next evaluation
+            S3T(10);
+            s3_bar();
+            S3T(11);                                                          // RED complete; h1 / g1 free for the next evaluation
         }
         if (single) {
             // ---- one evaluation: f -> out, and the norms of the initial-dt phase over the rows this lane owns ----
@@ -1924,6 +1949,13 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
             }
         }
     }
+#ifdef S3_STAMPS
+    S3T(22);
+    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 5))
+        printf("k_step3b wave %d total %llu | prologue %llu tileprep %llu tail %llu | F1 %llu+%llu F2 %llu+%llu F3 %llu+%llu B3 %llu+%llu B2 %llu+%llu B1 %llu+%llu\n",
+               wave, s3last - s3start, s3acc[20], s3acc[21], s3acc[22], s3acc[0], s3acc[1], s3acc[2], s3acc[3], s3acc[4], s3acc[5],
+               s3acc[6], s3acc[7], s3acc[8], s3acc[9], s3acc[10], s3acc[11]);
+#endif
 }
 
 // Split weight image of k_step3jb / k_step3b.  Fragment f, lane = 16q + x: the 8 weights M[16 tile + x][32 kblock + 8q .. +7]

@@ -26,7 +26,7 @@ FULL_US = 30.0                        # anything shorter did not do a full step:
 def is_step(kname):
     # k_step3(...) or the STEP = true instantiation k_mfma<Layout, true>(...) -- not the plain RHS kernel k_mfma<Layout, false>
     # (k_step3j is the JVP / FFJORD step kernel: not the kernel the headline bench runs)
-    return kname.startswith("k_step3(") or "k_step3<" in kname or ("k_mfma<" in kname and ", true>(" in kname)
+    return kname.startswith(("k_step3(", "k_step3b(")) or "k_step3<" in kname or ("k_mfma<" in kname and ", true>(" in kname)
 
 
 def first(pattern):
@@ -89,7 +89,7 @@ def pmc(dirname):
     return {k: sum(v) / len(v) for k, v in agg.items()}, len(seen), len(kept)
 
 
-out = {"kernel": "k_step3 (fused Tsit5 step of the headline shape, B = 8192)", "commit": commit(), "per_launch": {}, "launches": {}}
+out = {"kernel": "k_step3b (fused Tsit5 step of the headline shape on six-term bf16 products, B = 8192)", "commit": commit(), "per_launch": {}, "launches": {}}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_wait"):
     vals, n, k = pmc(d)
     out["per_launch"].update(vals)

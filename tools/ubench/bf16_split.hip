@@ -11,11 +11,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)x[j];
-        const float r1 = x[j] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;
-        hi[j] = h; mid[j] = m; lo[j] = (__bf16)r2;
+        // pieces by truncation (the upper half of an fp32 is a bf16), residuals by exact subtractions: as the kernels do
+        const unsigned hb = __float_as_uint(x[j]) & 0xFFFF0000u;
+        const float r1 = x[j] - __uint_as_float(hb);
+        const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+        const float r2 = r1 - __uint_as_float(mb);
+        hi[j] = __builtin_bit_cast(__bf16, (unsigned short)(hb >> 16));
+        mid[j] = __builtin_bit_cast(__bf16, (unsigned short)(mb >> 16));
+        lo[j] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(r2) >> 16));
     }
 }
 
