@@ -1497,11 +1497,12 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
 // ---------------------------------------------------------------------------------------------------------------
 namespace s3v {
 constexpr int SKZ = 264;
-constexpr int X0 = 0, G3 = X0 + 32 * 40, KZ = G3 + 32 * 40, RED = KZ + 32 * SKZ, SC = RED + 3 * 32 * 8, BIAS = SC + 32 * 24;
+constexpr int KZ = 0, RED = KZ + 32 * SKZ, SC = RED + 3 * 32 * 8, BIAS = SC + 32 * 24;
 constexpr int MISC = BIAS + 2 * 128 + 32, FP_END = MISC + 64;
 constexpr int WS = 272, WP = 32 * WS, WI = 3 * WP;        // split image [piece][32 rows][128 bf16 + 8]: 17 x 16 B per row
-constexpr int H1G = FP_END * 4, H2G = H1G + WI, W3I = H2G + WI, W1TI = W3I + WI;
-constexpr int TOTAL_BYTES = W1TI + WI;
+constexpr int NS = 80, NP = 32 * NS, NI = 3 * NP;         // K = 32 images (state, g3): [piece][32 rows][32 bf16 + 8]
+constexpr int H1G = FP_END * 4, H2G = H1G + WI, W3I = H2G + WI, W1TI = W3I + WI, X0S = W1TI + WI, G3S = X0S + NI;
+constexpr int TOTAL_BYTES = G3S + NI;
 static_assert(H1G % 16 == 0 && TOTAL_BYTES <= 160 * 1024, "LDS plan");
 // global image, behind the one of k_step3jb: W2^T and W3^T fragments, then the two LDS images as they are stored
 constexpr int G_FRB2 = (s3b::IMG_BYTES + 15) & ~15;        // W2^T: [tile 8][k-block 4][piece 3][lane 64] x 16 B
@@ -1686,8 +1687,10 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     // narrow products: A = rows 16t + s of W3 (waves 0-3) / of W1^T (waves 4-7), B = this wave's half of h2 / g1
     const char* nrA = ldsb + (zown ? s3v::W3I : s3v::W1TI) + (16 * t + s) * s3v::WS + 16 * q;
     const char* nrB = ldsb + (zown ? s3v::H2G : s3v::H1G) + smp * s3v::WS + 16 * q;
-    float* x0w = lds + s3v::X0 + smp * 40 + r0;
-    float* g3w = lds + s3v::G3 + smp * 40 + r0;
+    char* x0w = ldsb + s3v::X0S + smp * s3v::NS + 2 * r0;               // this lane's 4 rows of the state / g3 images
+    char* g3w = ldsb + s3v::G3S + smp * s3v::NS + 2 * r0;
+    const int nb_rd = s * s3v::NS + 16 * q;                             // their B operands: lane (sample s of half A, k = 8q ..)
+    constexpr int HBN = 16 * s3v::NS;
     // Runge-Kutta state of the z rows r0..r0+3 of sample smp, written and read by this lane only:
     float* rkw = lds + s3v::KZ + smp * s3v::SKZ + r0;                   // u at rkw, k1 at rkw + 32,
     float* kzw = rkw + 64;                                            // k_{j+2} at kzw + 32 j (j = 0..5)
@@ -1715,7 +1718,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
             if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }
         }
         if (zown) {
-            *(f32x4*)x0w = uz + (hstep * c21) * k1z;      // state of evaluation 1: U_2 = u + h a21 k1
+            s3b_store4(x0w, s3v::NP, uz + (hstep * c21) * k1z);      // state of evaluation 1: U_2 = u + h a21 k1
             *(f32x4*)rkw = uz;
             *(f32x4*)(rkw + 32) = k1z;
 #pragma unroll
@@ -1729,8 +1732,8 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
             {
                 const f32x4 bv1 = *(const f32x4*)(bias + 16 * wave + 4 * q);
                 S3bOp b[2];
-                b[0] = s3b_load_f32(lds + s3v::X0 + s * 40 + 8 * q);
-                b[1] = s3b_load_f32(lds + s3v::X0 + (16 + s) * 40 + 8 * q);
+                b[0] = s3b_load(ldsb + s3v::X0S + nb_rd, s3v::NP);
+                b[1] = s3b_load(ldsb + s3v::X0S + nb_rd + HBN, s3v::NP);
                 S3_SB();
                 f32x4 acc[2] = {zero4, zero4};
                 s3b_mm<2>(acc, wF1, b);
@@ -1780,8 +1783,8 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 #pragma unroll
                 for (int j = 1; j < 5; ++j) pre += (hstep * A[j]) * *(const f32x4*)(kzw + 32 * (j - 1));
                 const f32x4 zd = s3_tanh4(z0 + z1 + bv3);                      // padded rows: zero weights and bias -> 0
-                *(f32x4*)g3w = epsr * s3_dtanh4(zd);                           // g3 = eps .* sigma'_3
-                if (stg < 6) *(f32x4*)x0w = pre + (hstep * A[stg]) * zd;       // state of the next evaluation
+                s3b_store4(g3w, s3v::NP, epsr * s3_dtanh4(zd));               // g3 = eps .* sigma'_3
+                if (stg < 6) s3b_store4(x0w, s3v::NP, pre + (hstep * A[stg]) * zd);     // state of the next evaluation
                 *(f32x4*)(kzw + 32 * (stg - 1)) = zd;                          // k_{stg+1}
                 redw[0] = s3_dot4(zd, zd);
             }
@@ -1791,8 +1794,8 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
             // ---- interval 3: reverse of the last layer, tile `wave` of W3^T, both halves (K = 32); g2 over h2 in place
             {
                 S3bOp b[2];
-                b[0] = s3b_load_f32(lds + s3v::G3 + s * 40 + 8 * q);
-                b[1] = s3b_load_f32(lds + s3v::G3 + (16 + s) * 40 + 8 * q);
+                b[0] = s3b_load(ldsb + s3v::G3S + nb_rd, s3v::NP);
+                b[1] = s3b_load(ldsb + s3v::G3S + nb_rd + HBN, s3v::NP);
                 const f32x4 h2a = s3b_load4(ldsb + s3v::H2G + wb_wr, s3v::WP), h2b = s3b_load4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP);
                 S3_SB();
                 f32x4 acc[2] = {zero4, zero4};
@@ -1874,7 +1877,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
         // ---- error estimate and outputs: u_new (= the state evaluation 6 ran at) and k7 ----
         if (!single && live && zown) {
             const f32x4 k7z = *(const f32x4*)(kzw + 32 * 5), uz_ = *(const f32x4*)rkw;
-            const f32x4 un = *(const f32x4*)x0w;           // U_7 = u_new: the state the last evaluation ran at
+            const f32x4 un = s3b_load4(x0w, s3v::NP);     // U_7 = u_new: the state the last evaluation ran at (the pieces sum exactly)
             f32x4 ez = TS_BT1 * *(const f32x4*)(rkw + 32) + TS_BT7 * k7z;
             ez += TS_BT2 * *(const f32x4*)(kzw) + TS_BT3 * *(const f32x4*)(kzw + 32) + TS_BT4 * *(const f32x4*)(kzw + 64) +
                   TS_BT5 * *(const f32x4*)(kzw + 96) + TS_BT6 * *(const f32x4*)(kzw + 128);
