@@ -171,9 +171,9 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
     if (tid == 0) st0 = *st;
     const int v_done = st->done, v_cur = st->cur;
     const float v_h = st->h, v_abstol = st->abstol, v_reltol = st->reltol;
-    float cp0 = 0.f, cp1 = 0.f;
-    if (a.apply_ctrl)
-        for (int i = tid; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
+    // (one unconditional load per thread: a loop here would wait for its data before anything below is even requested)
+    const float* ppin = a.apply_ctrl ? a.partials_in : img3;
+    const float2 pp = *reinterpret_cast<const float2*>(ppin + 2 * min(tid, (int)gridDim.x - 1));
     // Weights.  W2 is needed twice per wave (16 of its rows forward, 16 of its columns in reverse): it is read from
     // memory ONCE per workgroup into an LDS staging image (which aliases the activation area, idle until the first
     // stage) and the 8 waves cut their two register fragments out of it.  The K = 128 images of the narrow products
@@ -254,6 +254,8 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
     float* msc = lds + s3::MISC;
     S3T(33);
     if (a.apply_ctrl) {
+        float cp0 = tid < (int)gridDim.x ? pp.x : 0.f, cp1 = tid < (int)gridDim.x ? pp.y : 0.f;
+        for (int i = tid + 512; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
         cp0 = s3_wave_sum(cp0); cp1 = s3_wave_sum(cp1);
         if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; }
     }
@@ -674,9 +676,9 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
     if (tid == 0) st0 = *st;
     const int v_done = st->done, v_cur = st->cur;
     const float v_h = st->h, v_abstol = st->abstol, v_reltol = st->reltol;
-    float cp0 = 0.f, cp1 = 0.f;
-    if (a.apply_ctrl)
-        for (int i = tid; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
+    // (one unconditional load per thread: a loop here would wait for its data before anything below is even requested)
+    const float* ppin = a.apply_ctrl ? a.partials_in : img3;
+    const float2 pp = *reinterpret_cast<const float2*>(ppin + 2 * min(tid, (int)gridDim.x - 1));
     // Weights: forward orientation only.  W3 rows (the K = 128 operand of the last layer) into their LDS image by
     // LDS-DMA; this wave's 16-row tiles of W1 (2 fragments) and of W2 (8 fragments, straight from the row-major image).
     constexpr int NCN = s3::P0 * s3::SXH / 4, NCB = (2 * s3::PH + s3::P0) / 4;
@@ -742,6 +744,8 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
     float* msc = lds + s3::MISC;
     S3T(33);
     if (a.apply_ctrl) {
+        float cp0 = tid < (int)gridDim.x ? pp.x : 0.f, cp1 = tid < (int)gridDim.x ? pp.y : 0.f;
+        for (int i = tid + 512; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
         cp0 = s3_wave_sum(cp0); cp1 = s3_wave_sum(cp1);
         if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; }
     }
@@ -1166,9 +1170,9 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
     if (tid == 0) st0 = *st;
     const int v_done = st->done, v_cur = st->cur;
     const float v_h = st->h, v_abstol = st->abstol, v_reltol = st->reltol;
-    float cp0 = 0.f, cp1 = 0.f;
-    if (a.apply_ctrl)
-        for (int i = tid; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
+    // (one unconditional load per thread: a loop here would wait for its data before anything below is even requested)
+    const float* ppin = a.apply_ctrl ? a.partials_in : img3;
+    const float2 pp = *reinterpret_cast<const float2*>(ppin + 2 * min(tid, (int)gridDim.x - 1));
     // resident split fragments: W1 tile `wave` (K = 32), W2 tile `wave` (4 k-blocks), W3 tile t (4 k-blocks)
     S3bOp wF1, wF2[4], w3[4];
     {
@@ -1224,6 +1228,8 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
     }
     float* msc = lds + s3b::MISC;
     if (a.apply_ctrl) {
+        float cp0 = tid < (int)gridDim.x ? pp.x : 0.f, cp1 = tid < (int)gridDim.x ? pp.y : 0.f;
+        for (int i = tid + 512; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
         cp0 = s3_wave_sum(cp0); cp1 = s3_wave_sum(cp1);
         if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; }
     }
@@ -1553,48 +1559,23 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     const unsigned long long s3start = s3last;
 #endif
     // ---- everything the launch needs from memory is requested up front, in ONE round trip, and nothing is consumed
-    // before all of it is in flight.  Order of issue = order of return: the integrator state words first (the `done`
-    // test and the controller need them soonest), then the error partials, the weight stream (135 KB per workgroup:
-    // it bounds the prologue, so it must not queue behind anything that waits), then this workgroup's first tile from
-    // BOTH buffer sets (which one is current is the controller's decision).
+    // before all of it is in flight: the integrator state words first (the `done` test and the controller need them
+    // soonest), then the error partials, then the two groups below.
     StepState st0;                                         // the controller thread's copy
     if (tid == 0) st0 = *st;
     const int v_done = st->done, v_cur = st->cur;
     const float v_h = st->h, v_abstol = st->abstol, v_reltol = st->reltol;
-    float cp0 = 0.f, cp1 = 0.f;
-    if (a.apply_ctrl)
-        for (int i = tid; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
-    // Weights, pre-split into three bf16 pieces (k_pack_step3b).  Resident fragments of this wave: its 16-row tile of W1
-    // and of W3^T (K = 32: one k-block), of W2 and of W2^T (four k-blocks).  The K = 128 operands of the narrow products
-    // (rows of W3, rows of W1^T) stay in LDS as split images, copied as they are stored (LDS-DMA).
-    constexpr int NCI = 2 * s3v::WI / 16, NCB = (2 * 128 + 32) / 4;
-    static_assert(NCI % 64 == 0, "whole wave instructions");
-    {
-        typedef __attribute__((address_space(3))) char* lds_c;
-        typedef const __attribute__((address_space(1))) char* glb_c;
-#pragma unroll
-        for (int i = 0; i < (NCI + 511) / 512; ++i) {
-            const int c = 512 * i + 64 * wave;                 // wave-uniform chunk (16 B) index
-            if (c < NCI)
-                __builtin_amdgcn_global_load_lds((glb_c)(imgb + s3v::G_W3I + 16 * (c + lane)), (lds_c)(ldsb + s3v::W3I + 16 * c), 16, 0, 0);
-        }
-    }
-    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3b::BIASB)[min(tid, NCB - 1)];
-    S3bOp wF1, wF2[4], wB3, wB2[4];
-    {
-        wF1 = s3b_load(imgb + s3b::FR1 + (size_t)wave * 3 * 1024 + 16 * lane, 1024);
-        wB3 = s3b_load(imgb + s3v::G_FRB3 + (size_t)wave * 3 * 1024 + 16 * lane, 1024);
-        const char* f2 = imgb + s3b::FR2 + (size_t)wave * 4 * 3 * 1024 + 16 * lane;
-        const char* r2 = imgb + s3v::G_FRB2 + (size_t)wave * 4 * 3 * 1024 + 16 * lane;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { wF2[b] = s3b_load(f2 + b * 3 * 1024, 1024); wB2[b] = s3b_load(r2 + b * 3 * 1024, 1024); }
-    }
+    // (one unconditional load per thread: a loop here would wait for its data before anything below is even requested)
+    const float* ppin = a.apply_ctrl ? a.partials_in : img3;
+    const float2 pp = *reinterpret_cast<const float2*>(ppin + 2 * min(tid, (int)gridDim.x - 1));
+    // Issue order = return order.  Group 1 is what the controller and the FORWARD half of the first evaluation need: this
+    // workgroup's first tile from BOTH buffer sets (which one is current is the controller's decision), the two LDS images
+    // (every LDS-DMA piece sits in group 1: the compiler makes LDS accesses wait for outstanding ones), the biases, the
+    // W1 / W2 fragments.  Group 2 (the W3^T / W2^T fragments: 120 of the 292 KB) is first needed three intervals later and
+    // streams in behind the first forward sweep.
     const int ntile = (a.B + 32 - 1) / 32;
     f32x4 ru[2], rk[2], re, rs[2][2];
     int ce = 0, cu = 0, cs = 0;
-    float* sc = lds + s3v::SC + smp * 24;
-    auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
-    auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
     {
         const int b0 = blockIdx.x * 32 + 16 * hf;
         const bool live = s < max(0, min(16, a.B - b0));
@@ -1609,7 +1590,45 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
             rs[c][1] = ld4_issue(a.K1[c] + gcol + n_in, cs, img3);
         }
     }
+    // Weights, pre-split into three bf16 pieces (k_pack_step3b).  Resident fragments of this wave: its 16-row tile of W1
+    // and of W3^T (K = 32: one k-block), of W2 and of W2^T (four k-blocks).  The K = 128 operands of the narrow products
+    // (rows of W3, rows of W1^T) stay in LDS as split images, copied as they are stored (LDS-DMA).
+    constexpr int NCI = 2 * s3v::WI / 16, NCB = (2 * 128 + 32) / 4;
+    constexpr int G2 = 3 + 12;                                 // vector-memory instructions of group 2 (per wave)
+    static_assert(NCI % 64 == 0, "whole wave instructions");
+    typedef __attribute__((address_space(3))) char* lds_c;
+    typedef const __attribute__((address_space(1))) char* glb_c;
+#pragma unroll
+    for (int i = 0; i < (NCI + 511) / 512; ++i) {
+        const int c = 512 * i + 64 * wave;                     // wave-uniform chunk (16 B) index
+        if (c < NCI)
+            __builtin_amdgcn_global_load_lds((glb_c)(imgb + s3v::G_W3I + 16 * (c + lane)), (lds_c)(ldsb + s3v::W3I + 16 * c), 16, 0, 0);
+    }
+    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3b::BIASB)[min(tid, NCB - 1)];
+    S3bOp wF1, wF2[4], wB3, wB2[4];
+    wF1 = s3b_load(imgb + s3b::FR1 + (size_t)wave * 3 * 1024 + 16 * lane, 1024);
+    {
+        const char* f2 = imgb + s3b::FR2 + (size_t)wave * 4 * 3 * 1024 + 16 * lane;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) wF2[b] = s3b_load(f2 + b * 3 * 1024, 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);                     // ---- group 2: everything below is issued after everything above
+    wB3 = s3b_load(imgb + s3v::G_FRB3 + (size_t)wave * 3 * 1024 + 16 * lane, 1024);
+    {
+        const char* r2 = imgb + s3v::G_FRB2 + (size_t)wave * 4 * 3 * 1024 + 16 * lane;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) wB2[b] = s3b_load(r2 + b * 3 * 1024, 1024);
+    }
+    float* sc = lds + s3v::SC + smp * 24;
+    auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
+    auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
     __builtin_amdgcn_sched_barrier(0);                     // nothing above is consumed before all of it is requested
+    // Group 1 has landed once no more than group 2's instructions are outstanding (in-order return): this wave's pieces
+    // of the LDS images are in place.  (The builtin, not inline assembly, and in front of the first LDS access: the
+    // compiler's own wait insertion reads it and stops guarding LDS accesses against the LDS-DMA with vmcnt(0).)
+    static_assert(G2 < 16, "s_waitcnt encoding below");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | G2);               // vmcnt(G2), nothing else
+    __builtin_amdgcn_sched_barrier(0);
     // (wave-uniform values into scalar registers: the buffer pointers selected from `cur` stay out of the vector file)
     const int st_done = __builtin_amdgcn_readfirstlane(v_done), st_cur = __builtin_amdgcn_readfirstlane(v_cur);
     const float st_h = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_h)));
@@ -1629,12 +1648,13 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     f32x4 epsr = ld4_mask(re, ce);                         // this lane's 4 probe rows of sample smp (g3 on waves 0-3, trace row on 4-7)
     float* msc = lds + s3v::MISC;
     if (a.apply_ctrl) {
+        float cp0 = tid < (int)gridDim.x ? pp.x : 0.f, cp1 = tid < (int)gridDim.x ? pp.y : 0.f;
+        for (int i = tid + 512; i < (int)gridDim.x; i += 512) { cp0 += a.partials_in[2 * i]; cp1 += a.partials_in[2 * i + 1]; }
         cp0 = s3_wave_sum(cp0); cp1 = s3_wave_sum(cp1);
         if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; }
     }
     if (tid < NCB) reinterpret_cast<f32x4*>(lds + s3v::BIAS)[tid] = sgb;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA pieces have landed (then the barrier)
-    s3_bar();                                              // staging image and partial sums complete
+    s3_bar();                                              // LDS images and partial sums complete
     int cur = st_cur;
     float hstep = st_h, abstol = st_abstol, reltol = st_reltol;
     if (a.apply_ctrl && tid == 0) {
@@ -1698,37 +1718,39 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     S3T(20);
+    // a tile's z rows into the Runge-Kutta state and the state image of its first evaluation
+    auto tile_in = [&](const f32x4& uz, f32x4 k1z) {
+        if (single == 1) { k1z = zero4; if (sown) sc_set(1, k1z); }          // there is no k1 yet
+        if (zown) {
+            s3b_store4(x0w, s3v::NP, uz + (hstep * c21) * k1z);              // state of evaluation 1: U_2 = u + h a21 k1
+            *(f32x4*)rkw = uz;
+            *(f32x4*)(rkw + 32) = k1z;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;     // k2..k7: not produced yet
+        }
+    };
+    // the first tile was requested at kernel entry; it goes to LDS here, so that none of it is carried into the loop
+    if (sown) { sc_set(0, sc_get(cur ? 4 : 2)); sc_set(1, sc_get(cur ? 5 : 3)); }
+    tile_in(ld4_mask(cur ? ru[1] : ru[0], cu), ld4_mask(cur ? rk[1] : rk[0], cu));
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const int b0 = tile * 32 + 16 * hf;
         const bool live = s < max(0, min(16, a.B - b0));
         const size_t gcol = (size_t)(b0 + s) * D;
-        f32x4 uz, k1z;
-        if (tile == blockIdx.x) {                              // requested at kernel entry
-            uz = ld4_mask(cur ? ru[1] : ru[0], cu);
-            k1z = ld4_mask(cur ? rk[1] : rk[0], cu);
-            if (sown) { sc_set(0, sc_get(cur ? 4 : 2)); sc_set(1, sc_get(cur ? 5 : 3)); }
-            if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }     // there is no k1 yet
-        } else {
+        if (tile != (int)blockIdx.x) {
             ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
             const f32x4 e_ = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
             const f32x4 u_ = ld4_issue(Uin + gcol + r0, cu, img3), k_ = ld4_issue(K1in + gcol + r0, cu, img3);
             const f32x4 s0 = ld4_issue(Uin + gcol + n_in, cs, img3), s1 = ld4_issue(K1in + gcol + n_in, cs, img3);
-            epsr = ld4_mask(e_, ce); uz = ld4_mask(u_, cu); k1z = ld4_mask(k_, cu);
+            epsr = ld4_mask(e_, ce);
             if (sown) { sc_set(0, ld4_mask(s0, cs)); sc_set(1, ld4_mask(s1, cs)); }
-            if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }
-        }
-        if (zown) {
-            s3b_store4(x0w, s3v::NP, uz + (hstep * c21) * k1z);      // state of evaluation 1: U_2 = u + h a21 k1
-            *(f32x4*)rkw = uz;
-            *(f32x4*)(rkw + 32) = k1z;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;       // k2..k7: not produced yet
+            tile_in(ld4_mask(u_, cu), ld4_mask(k_, cu));
         }
         s3_bar();
         S3T(21);
 
         for (int stg = 1; stg <= nstg; ++stg) {
-            // ---- interval 0: first layer, tile `wave`, both halves (K = 32: one k-block; the fp32 state is split on the way in)
+            f32x4 d2a, d2b;                                                  // sigma'_2 at this lane's h2 entries (interval 1 -> 3)
+            // ---- interval 0: first layer, tile `wave`, both halves (K = 32: one k-block)
             {
                 const f32x4 bv1 = *(const f32x4*)(bias + 16 * wave + 4 * q);
                 S3bOp b[2];
@@ -1758,8 +1780,10 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
                     s3b_mm<2>(acc, wF2[kb], b);
                     S3_SB();
                 }
-                s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, s3_tanh4(acc[0] + bv2));
-                s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, s3_tanh4(acc[1] + bv2));
+                const f32x4 h2a = s3_tanh4(acc[0] + bv2), h2b = s3_tanh4(acc[1] + bv2);
+                d2a = s3_dtanh4(h2a); d2b = s3_dtanh4(h2b);
+                s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, h2a);
+                s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, h2b);
             }
             S3T(2);
             s3_bar();
@@ -1796,12 +1820,11 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
                 S3bOp b[2];
                 b[0] = s3b_load(ldsb + s3v::G3S + nb_rd, s3v::NP);
                 b[1] = s3b_load(ldsb + s3v::G3S + nb_rd + HBN, s3v::NP);
-                const f32x4 h2a = s3b_load4(ldsb + s3v::H2G + wb_wr, s3v::WP), h2b = s3b_load4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP);
                 S3_SB();
                 f32x4 acc[2] = {zero4, zero4};
                 s3b_mm<2>(acc, wB3, b);
-                s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, acc[0] * s3_dtanh4(h2a));
-                s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, acc[1] * s3_dtanh4(h2b));
+                s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, acc[0] * d2a);
+                s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, acc[1] * d2b);
             }
             S3T(6);
             s3_bar();
