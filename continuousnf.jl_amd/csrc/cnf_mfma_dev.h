@@ -94,6 +94,21 @@ __device__ __forceinline__ f32x4 ld4_issue(const float* p, int nvalid4, const fl
     const int i1 = nvalid4 > 1 ? 1 : 0, i2 = nvalid4 > 2 ? 2 : 0, i3 = nvalid4 > 3 ? 3 : 0;
     return f32x4{q[0], q[i1], q[i2], q[i3]};
 }
+// One instruction instead of four when every lane's count is <= 0 or >= 4 (`wide`, wave-uniform: the rows come in whole
+// groups of four) -- the sample rows are only 4-byte aligned (D = n_in + 3 floats apart), which global memory allows.
+// The texture-address path handles a wave's 64 lane addresses per instruction at a fixed rate whatever the width, so the
+// prologue's ~36 dword gathers per wave cost it four times the cycles of 9 wide ones.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+__device__ __forceinline__ f32x4 ld4_issue_w(const float* p, int nvalid4, const float* safe, bool wide) {
+    if (wide) return *reinterpret_cast<const f32x4u*>(nvalid4 > 0 ? p : safe);
+    return ld4_issue(p, nvalid4, safe);
+}
+__device__ __forceinline__ f32x4 ld3_issue(const float* p, int nvalid, const float* safe) {   // nvalid is 0 or 3
+    const f32x3u v = *reinterpret_cast<const f32x3u*>(nvalid > 0 ? p : safe);
+    return f32x4{v.x, v.y, v.z, 0.f};
+}
+__device__ __forceinline__ void st4_wide(float* p, const f32x4& v) { *reinterpret_cast<f32x4u*>(p) = v; }
 __device__ __forceinline__ f32x4 ld4_mask(const f32x4& v, int nvalid4) {
     return f32x4{nvalid4 > 0 ? v.x : 0.f, nvalid4 > 1 ? v.y : 0.f, nvalid4 > 2 ? v.z : 0.f, nvalid4 > 3 ? v.w : 0.f};
 }

@@ -143,9 +143,23 @@ __device__ __forceinline__ float s3_wave_sum(float v) {
 #define S3T(i) do {} while (0)
 #endif
 
+// Kernel entry, shared by the four step kernels.  Every memory round trip in front of the weight stream is exposed (the
+// caches start cold), and the compiler fetches kernel arguments lazily, each batch behind its own wait: all arguments the
+// prologue uses are demanded at once (one batch, one wait), and the integrator state words are read with VECTOR loads (an
+// opaque zero in the address), which queue with the other requests instead of stalling the wave as scalar loads do.
+#define S3_ARGS_UP_FRONT(a, img)                                                                                        \
+    asm volatile("" ::"s"(a.st), "s"(a.partials_in), "s"(a.eps), "s"(a.U[0]), "s"(a.U[1]), "s"(a.K1[0]), "s"(a.K1[1]),   \
+                 "s"(a.B), "s"(a.apply_ctrl), "s"(img), "s"((int)gridDim.x))
+__device__ __forceinline__ const StepState* s3_state_words(const StepState* st) {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return st + z;
+}
+
 __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __restrict__ img3, int n_in, int norm_z,
                                                   int norm_j, const S3Tab tab, int single) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    S3_ARGS_UP_FRONT(a, img3);
     const StepState* st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = n_in + 3;
@@ -167,10 +181,9 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
     // test and the controller need them soonest), then the error partials, the weight stream (135 KB per workgroup:
     // it bounds the prologue, so it must not queue behind anything that waits), then this workgroup's first tile from
     // BOTH buffer sets (which one is current is the controller's decision).
-    StepState st0;                                         // the controller thread's copy
-    if (tid == 0) st0 = *st;
-    const int v_done = st->done, v_cur = st->cur;
-    const float v_h = st->h, v_abstol = st->abstol, v_reltol = st->reltol;
+    const StepState* stw = s3_state_words(st);
+    const int v_done = stw->done, v_cur = stw->cur;
+    const float v_h = stw->h, v_abstol = stw->abstol, v_reltol = stw->reltol;
     // (one unconditional load per thread: a loop here would wait for its data before anything below is even requested)
     const float* ppin = a.apply_ctrl ? a.partials_in : img3;
     const float2 pp = *reinterpret_cast<const float2*>(ppin + 2 * min(tid, (int)gridDim.x - 1));
@@ -272,7 +285,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
         // and takes the same decision; block 0 publishes the new state for the next launch and the host mirror.
         float p0 = 0.f, p1 = 0.f;
         for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
-        StepState ns = st0;
+        StepState ns = *st;                                // (cached by now: the state words above came from these lines)
         ctrl_after_step(&ns, p0, p1, a.n_total);
         if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
         msc[32] = __int_as_float(ns.cur); msc[33] = ns.h; msc[34] = ns.abstol; msc[35] = ns.reltol;
@@ -651,6 +664,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
 __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __restrict__ img3, int n_in, int norm_z,
                                                   int norm_j, const S3Tab tab, int single) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    S3_ARGS_UP_FRONT(a, img3);
     const StepState* st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = n_in + 3;
@@ -672,10 +686,9 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
     // test and the controller need them soonest), then the error partials, the weight stream (135 KB per workgroup:
     // it bounds the prologue, so it must not queue behind anything that waits), then this workgroup's first tile from
     // BOTH buffer sets (which one is current is the controller's decision).
-    StepState st0;                                         // the controller thread's copy
-    if (tid == 0) st0 = *st;
-    const int v_done = st->done, v_cur = st->cur;
-    const float v_h = st->h, v_abstol = st->abstol, v_reltol = st->reltol;
+    const StepState* stw = s3_state_words(st);
+    const int v_done = stw->done, v_cur = stw->cur;
+    const float v_h = stw->h, v_abstol = stw->abstol, v_reltol = stw->reltol;
     // (one unconditional load per thread: a loop here would wait for its data before anything below is even requested)
     const float* ppin = a.apply_ctrl ? a.partials_in : img3;
     const float2 pp = *reinterpret_cast<const float2*>(ppin + 2 * min(tid, (int)gridDim.x - 1));
@@ -762,7 +775,7 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
         // and takes the same decision; block 0 publishes the new state for the next launch and the host mirror.
         float p0 = 0.f, p1 = 0.f;
         for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
-        StepState ns = st0;
+        StepState ns = *st;                                // (cached by now: the state words above came from these lines)
         ctrl_after_step(&ns, p0, p1, a.n_total);
         if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
         msc[32] = __int_as_float(ns.cur); msc[33] = ns.h; msc[34] = ns.abstol; msc[35] = ns.reltol;
@@ -1155,6 +1168,7 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* ldsb = reinterpret_cast<char*>(lds);
     const float* img3 = reinterpret_cast<const float*>(imgb);      // (a valid address for masked loads)
+    S3_ARGS_UP_FRONT(a, imgb);
     const StepState* st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = n_in + 3;
@@ -1166,10 +1180,9 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
     const int r0 = 16 * t + 4 * q;
     const int nv = n_in - r0;
     // ---- requests of the prologue (order of issue = order of return; nothing consumed before all are in flight) ----
-    StepState st0;
-    if (tid == 0) st0 = *st;
-    const int v_done = st->done, v_cur = st->cur;
-    const float v_h = st->h, v_abstol = st->abstol, v_reltol = st->reltol;
+    const StepState* stw = s3_state_words(st);
+    const int v_done = stw->done, v_cur = stw->cur;
+    const float v_h = stw->h, v_abstol = stw->abstol, v_reltol = stw->reltol;
     // (one unconditional load per thread: a loop here would wait for its data before anything below is even requested)
     const float* ppin = a.apply_ctrl ? a.partials_in : img3;
     const float2 pp = *reinterpret_cast<const float2*>(ppin + 2 * min(tid, (int)gridDim.x - 1));
@@ -1240,7 +1253,7 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
     if (a.apply_ctrl && tid == 0) {
         float p0 = 0.f, p1 = 0.f;
         for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
-        StepState ns = st0;
+        StepState ns = *st;                                // (cached by now: the state words above came from these lines)
         ctrl_after_step(&ns, p0, p1, a.n_total);
         if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
         msc[32] = __int_as_float(ns.cur); msc[33] = ns.h; msc[34] = ns.abstol; msc[35] = ns.reltol;
@@ -1514,12 +1527,12 @@ static_assert(H1G % 16 == 0 && TOTAL_BYTES <= 160 * 1024, "LDS plan");
 constexpr int G_FRB2 = (s3b::IMG_BYTES + 15) & ~15;        // W2^T: [tile 8][k-block 4][piece 3][lane 64] x 16 B
 constexpr int G_FRB3 = G_FRB2 + 8 * 4 * 3 * 1024;          // W3^T: [tile 8][piece 3][lane 64] x 16 B
 constexpr int G_W3I = G_FRB3 + 8 * 3 * 1024;               // W3 rows, then W1^T rows: 2 x WI bytes, LDS layout
-constexpr int IMG_BYTES = G_W3I + 2 * WI;
+constexpr int G_F32 = (G_W3I + 2 * WI + 15) & ~15;         // the resident fragments of k_step3b in fp32 (split on arrival: 2/3 of
+constexpr int IMG_BYTES = G_F32 + 8 * 10 * 2048;           // the bytes): [wave 8][W1 | W2 x4 | W3^T | W2^T x4][half 2][lane 64] x 16 B
 }  // namespace s3v
 
 // 8 consecutive fp32 values -> a split operand (K = 32 products whose B operand stays in fp32 in LDS)
-__device__ __forceinline__ S3bOp s3b_load_f32(const float* p) {
-    const f32x4 lo4 = *(const f32x4*)p, hi4 = *(const f32x4*)(p + 4);
+__device__ __forceinline__ S3bOp s3b_split8(const f32x4& lo4, const f32x4& hi4) {
     S3bOp o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1528,6 +1541,13 @@ __device__ __forceinline__ S3bOp s3b_load_f32(const float* p) {
         o.h[j] = a; o.m[j] = b; o.l[j] = c;
     }
     return o;
+}
+// an ordered no-op that consumes and redefines the operand: pins its computation in program order
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void s3b_pin(S3bOp& o) {
+    u32x4 a = __builtin_bit_cast(u32x4, o.h), b = __builtin_bit_cast(u32x4, o.m), c = __builtin_bit_cast(u32x4, o.l);
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+    o.h = __builtin_bit_cast(bf16x8, a); o.m = __builtin_bit_cast(bf16x8, b); o.l = __builtin_bit_cast(bf16x8, c);
 }
 // 4 rows of one sample back from the three images: the pieces sum to the fp32 value exactly
 __device__ __forceinline__ f32x4 s3b_load4(const char* img, int piece_bytes) {
@@ -1543,6 +1563,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* ldsb = reinterpret_cast<char*>(lds);
     const float* img3 = reinterpret_cast<const float*>(imgb);      // (a valid address for masked loads)
+    S3_ARGS_UP_FRONT(a, imgb);
     const StepState* st = a.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = n_in + 3;
@@ -1561,10 +1582,9 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     // ---- everything the launch needs from memory is requested up front, in ONE round trip, and nothing is consumed
     // before all of it is in flight: the integrator state words first (the `done` test and the controller need them
     // soonest), then the error partials, then the two groups below.
-    StepState st0;                                         // the controller thread's copy
-    if (tid == 0) st0 = *st;
-    const int v_done = st->done, v_cur = st->cur;
-    const float v_h = st->h, v_abstol = st->abstol, v_reltol = st->reltol;
+    const StepState* stw = s3_state_words(st);
+    const int v_done = stw->done, v_cur = stw->cur;
+    const float v_h = stw->h, v_abstol = stw->abstol, v_reltol = stw->reltol;
     // (one unconditional load per thread: a loop here would wait for its data before anything below is even requested)
     const float* ppin = a.apply_ctrl ? a.partials_in : img3;
     const float2 pp = *reinterpret_cast<const float2*>(ppin + 2 * min(tid, (int)gridDim.x - 1));
@@ -1574,6 +1594,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     // W1 / W2 fragments.  Group 2 (the W3^T / W2^T fragments: 120 of the 292 KB) is first needed three intervals later and
     // streams in behind the first forward sweep.
     const int ntile = (a.B + 32 - 1) / 32;
+    const bool wide = (n_in & 3) == 0;                     // every lane's four rows are all valid or all padding
     f32x4 ru[2], rk[2], re, rs[2][2];
     int ce = 0, cu = 0, cs = 0;
     {
@@ -1581,54 +1602,59 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
         const bool live = s < max(0, min(16, a.B - b0));
         const size_t gcol = (size_t)(b0 + s) * D;
         ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
-        re = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+        re = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            ru[c] = ld4_issue(a.U[c] + gcol + r0, cu, img3);
-            rk[c] = ld4_issue(a.K1[c] + gcol + r0, cu, img3);
-            rs[c][0] = ld4_issue(a.U[c] + gcol + n_in, cs, img3);
-            rs[c][1] = ld4_issue(a.K1[c] + gcol + n_in, cs, img3);
+            ru[c] = ld4_issue_w(a.U[c] + gcol + r0, cu, img3, wide);
+            rk[c] = ld4_issue_w(a.K1[c] + gcol + r0, cu, img3, wide);
+            rs[c][0] = ld3_issue(a.U[c] + gcol + n_in, cs, img3);
+            rs[c][1] = ld3_issue(a.K1[c] + gcol + n_in, cs, img3);
         }
     }
     // Weights, pre-split into three bf16 pieces (k_pack_step3b).  Resident fragments of this wave: its 16-row tile of W1
     // and of W3^T (K = 32: one k-block), of W2 and of W2^T (four k-blocks).  The K = 128 operands of the narrow products
     // (rows of W3, rows of W1^T) stay in LDS as split images, copied as they are stored (LDS-DMA).
     constexpr int NCI = 2 * s3v::WI / 16, NCB = (2 * 128 + 32) / 4;
-    constexpr int G2 = 3 + 12;                                 // vector-memory instructions of group 2 (per wave)
     static_assert(NCI % 64 == 0, "whole wave instructions");
     typedef __attribute__((address_space(3))) char* lds_c;
     typedef const __attribute__((address_space(1))) char* glb_c;
+    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3b::BIASB)[min(tid, NCB - 1)];
+    // the resident fragments arrive in fp32 and are split here, in arrival order, while the rest of the stream is in flight
+    S3bOp wF1, wF2[4], wB3, wB2[4];
+    {
+        const char* fw = imgb + s3v::G_F32 + (size_t)wave * 10 * 2048 + 16 * lane;
+        constexpr int AH = 5;                                  // fragments requested ahead of the one being split
+        f32x4 raw[10][2];
+#pragma unroll
+        for (int f = 0; f < AH; ++f) { raw[f][0] = *(const f32x4*)(fw + f * 2048); raw[f][1] = *(const f32x4*)(fw + f * 2048 + 1024); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 10; ++f) {
+            if (f + AH < 10) {
+                raw[f + AH][0] = *(const f32x4*)(fw + (f + AH) * 2048);
+                raw[f + AH][1] = *(const f32x4*)(fw + (f + AH) * 2048 + 1024);
+            }
+            S3bOp o = s3b_split8(raw[f][0], raw[f][1]);
+            s3b_pin(o);                                        // (the split stays here, between the two scheduling barriers)
+            if (f == 0) wF1 = o; else if (f < 5) wF2[f - 1] = o; else if (f == 5) wB3 = o; else wB2[f - 6] = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the two LDS images last: while LDS-DMA pieces are outstanding the compiler waits with vmcnt(0) for ANY loaded register
 #pragma unroll
     for (int i = 0; i < (NCI + 511) / 512; ++i) {
         const int c = 512 * i + 64 * wave;                     // wave-uniform chunk (16 B) index
         if (c < NCI)
             __builtin_amdgcn_global_load_lds((glb_c)(imgb + s3v::G_W3I + 16 * (c + lane)), (lds_c)(ldsb + s3v::W3I + 16 * c), 16, 0, 0);
     }
-    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3b::BIASB)[min(tid, NCB - 1)];
-    S3bOp wF1, wF2[4], wB3, wB2[4];
-    wF1 = s3b_load(imgb + s3b::FR1 + (size_t)wave * 3 * 1024 + 16 * lane, 1024);
-    {
-        const char* f2 = imgb + s3b::FR2 + (size_t)wave * 4 * 3 * 1024 + 16 * lane;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) wF2[b] = s3b_load(f2 + b * 3 * 1024, 1024);
-    }
-    __builtin_amdgcn_sched_barrier(0);                     // ---- group 2: everything below is issued after everything above
-    wB3 = s3b_load(imgb + s3v::G_FRB3 + (size_t)wave * 3 * 1024 + 16 * lane, 1024);
-    {
-        const char* r2 = imgb + s3v::G_FRB2 + (size_t)wave * 4 * 3 * 1024 + 16 * lane;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) wB2[b] = s3b_load(r2 + b * 3 * 1024, 1024);
-    }
     float* sc = lds + s3v::SC + smp * 24;
     auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
     auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
     __builtin_amdgcn_sched_barrier(0);                     // nothing above is consumed before all of it is requested
-    // Group 1 has landed once no more than group 2's instructions are outstanding (in-order return): this wave's pieces
-    // of the LDS images are in place.  (The builtin, not inline assembly, and in front of the first LDS access: the
-    // compiler's own wait insertion reads it and stops guarding LDS accesses against the LDS-DMA with vmcnt(0).)
-    static_assert(G2 < 16, "s_waitcnt encoding below");
-    __builtin_amdgcn_s_waitcnt(0x0F70 | G2);               // vmcnt(G2), nothing else
+    S3T(23);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's LDS-DMA pieces have landed
     __builtin_amdgcn_sched_barrier(0);
+    S3T(24);
     // (wave-uniform values into scalar registers: the buffer pointers selected from `cur` stay out of the vector file)
     const int st_done = __builtin_amdgcn_readfirstlane(v_done), st_cur = __builtin_amdgcn_readfirstlane(v_cur);
     const float st_h = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_h)));
@@ -1655,6 +1681,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     }
     if (tid < NCB) reinterpret_cast<f32x4*>(lds + s3v::BIAS)[tid] = sgb;
     s3_bar();                                              // LDS images and partial sums complete
+    S3T(25);
     int cur = st_cur;
     float hstep = st_h, abstol = st_abstol, reltol = st_reltol;
     if (a.apply_ctrl && tid == 0) {
@@ -1662,13 +1689,15 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
         // and takes the same decision; block 0 publishes the new state for the next launch and the host mirror.
         float p0 = 0.f, p1 = 0.f;
         for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
-        StepState ns = st0;
+        StepState ns = *st;                                // (cached by now: the state words above came from these lines)
         ctrl_after_step(&ns, p0, p1, a.n_total);
         if (blockIdx.x == 0) { *a.st_out = ns; publish_mirror(a, ns); }
         msc[32] = __int_as_float(ns.cur); msc[33] = ns.h; msc[34] = ns.abstol; msc[35] = ns.reltol;
         msc[36] = __int_as_float(ns.done);
     }
+    S3T(26);
     s3_bar();                                              // controller done; the staging area is free
+    S3T(27);
     if (a.apply_ctrl) {
         cur = __builtin_amdgcn_readfirstlane(__float_as_int(msc[32]));
         hstep = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[33])));
@@ -1738,9 +1767,9 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
         const size_t gcol = (size_t)(b0 + s) * D;
         if (tile != (int)blockIdx.x) {
             ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
-            const f32x4 e_ = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
-            const f32x4 u_ = ld4_issue(Uin + gcol + r0, cu, img3), k_ = ld4_issue(K1in + gcol + r0, cu, img3);
-            const f32x4 s0 = ld4_issue(Uin + gcol + n_in, cs, img3), s1 = ld4_issue(K1in + gcol + n_in, cs, img3);
+            const f32x4 e_ = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
+            const f32x4 u_ = ld4_issue_w(Uin + gcol + r0, cu, img3, wide), k_ = ld4_issue_w(K1in + gcol + r0, cu, img3, wide);
+            const f32x4 s0 = ld3_issue(Uin + gcol + n_in, cs, img3), s1 = ld3_issue(K1in + gcol + n_in, cs, img3);
             epsr = ld4_mask(e_, ce);
             if (sown) { sc_set(0, ld4_mask(s0, cs)); sc_set(1, ld4_mask(s1, cs)); }
             tile_in(ld4_mask(u_, cu), ld4_mask(k_, cu));
@@ -1914,10 +1943,8 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
             const size_t gc = (size_t)(tile * 32 + 16 * hf + s) * D;
             float* Un = Uout + gc + r0;
             float* K7 = K1out + gc + r0;
-            if (nv >= 4) {
-                Un[0] = un.x; Un[1] = un.y; Un[2] = un.z; Un[3] = un.w;
-                K7[0] = k7z.x; K7[1] = k7z.y; K7[2] = k7z.z; K7[3] = k7z.w;
-            } else { st4(Un, un, nv); st4(K7, k7z, nv); }
+            if (nv >= 4) { st4_wide(Un, un); st4_wide(K7, k7z); }
+            else { st4(Un, un, nv); st4(K7, k7z, nv); }
         }
         if (!single && live && sown) {
             f32x4 ks[7];
@@ -1978,8 +2005,8 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 #ifdef S3_STAMPS
     S3T(22);
     if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 5))
-        printf("k_step3b wave %d total %llu | prologue %llu tileprep %llu tail %llu | F1 %llu+%llu F2 %llu+%llu F3 %llu+%llu B3 %llu+%llu B2 %llu+%llu B1 %llu+%llu\n",
-               wave, s3last - s3start, s3acc[20], s3acc[21], s3acc[22], s3acc[0], s3acc[1], s3acc[2], s3acc[3], s3acc[4], s3acc[5],
+        printf("k_step3b wave %d total %llu | issue %llu landed %llu bar %llu ctrl %llu bar %llu rest %llu tileprep %llu tail %llu | F1 %llu+%llu F2 %llu+%llu F3 %llu+%llu B3 %llu+%llu B2 %llu+%llu B1 %llu+%llu\n",
+               wave, s3last - s3start, s3acc[23], s3acc[24], s3acc[25], s3acc[26], s3acc[27], s3acc[20], s3acc[21], s3acc[22], s3acc[0], s3acc[1], s3acc[2], s3acc[3], s3acc[4], s3acc[5],
                s3acc[6], s3acc[7], s3acc[8], s3acc[9], s3acc[10], s3acc[11]);
 #endif
 }
@@ -1987,9 +2014,24 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 // Split weight image of k_step3jb / k_step3b.  Fragment f, lane = 16q + x: the 8 weights M[16 tile + x][32 kblock + 8q .. +7]
 // of M = W1 | W2 | W3 (k_step3jb, k_step3b) | W2^T | W3^T (k_step3b) as three bf16 pieces; then the two LDS images of
 // k_step3b (rows of W3, rows of W1^T) in their LDS layout; biases in fp32.
+__device__ __forceinline__ bool o_in(const NetDesc& nd, int l, int o, int k) { return o < nd.dims[l + 1] && k < nd.dims[l]; }
 __global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __restrict__ img) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     constexpr int NF = 8 + 32 + 8 + 32 + 8, NIMG = 2 * 32 * 17;
+    if (i >= NF * 64 + NIMG && i < NF * 64 + NIMG + 80 * 64) {      // fp32 fragments of k_step3b
+        const int e = i - NF * 64 - NIMG, w = e / 640, f = (e / 64) % 10, lane = e & 63, x = lane & 15, q = lane >> 4;
+        const int l = f == 0 ? 0 : (f == 5 ? 2 : 1), tr = f >= 5, kb = f == 0 || f == 5 ? 0 : (f < 5 ? f - 1 : f - 6);
+        float v[8];
+        for (int j = 0; j < 8; ++j) {
+            const int r = 16 * w + x, k = 32 * kb + 8 * q + j;
+            v[j] = tr ? (o_in(nd, l, k, r) ? P[nd.w_off[l] + k + (size_t)r * nd.dims[l + 1]] : 0.f)
+                      : (o_in(nd, l, r, k) ? P[nd.w_off[l] + r + (size_t)k * nd.dims[l + 1]] : 0.f);
+        }
+        char* d = img + s3v::G_F32 + (size_t)(w * 10 + f) * 2048 + 16 * lane;
+        *(f32x4*)d = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(d + 1024) = f32x4{v[4], v[5], v[6], v[7]};
+        return;
+    }
     if (i < (2 * 128 + 32)) {
         const int l = i < 128 ? 0 : (i < 256 ? 1 : 2), o = i < 128 ? i : (i < 256 ? i - 128 : i - 256);
         reinterpret_cast<float*>(img + s3b::BIASB)[i] = o < nd.dims[l + 1] ? P[nd.b_off[l] + o] : 0.f;
@@ -2034,7 +2076,7 @@ __global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __r
 
 size_t step3b_img_bytes() { return (size_t)s3v::IMG_BYTES; }
 void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStream_t s) {
-    constexpr int NT = (8 + 32 + 8 + 32 + 8) * 64 + 2 * 32 * 17;
+    constexpr int NT = (8 + 32 + 8 + 32 + 8) * 64 + 2 * 32 * 17 + 80 * 64;
     hipLaunchKernelGGL(k_pack_step3b, dim3((NT + 255) / 256), dim3(256), 0, s, nd, d_params, (char*)d_imgb);
 }
 void step3b_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single) {
