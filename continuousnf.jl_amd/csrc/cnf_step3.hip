@@ -226,6 +226,7 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
         for (int u = 0; u < 2; ++u) wB3[u] = wp[u * 64];
     }
     const int ntile = (a.B + s3::NB - 1) / s3::NB;
+    const bool wide = (n_in & 3) == 0;                     // every lane's four rows are all valid or all padding
     f32x4 ru[2], rk[2], re, rs[2][2];
     int ce = 0, cu = 0, cs = 0;
     float* sc = lds + s3::SC + smp * 24;
@@ -236,13 +237,13 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
         const bool live = s < max(0, min(16, a.B - b0));
         const size_t gcol = (size_t)(b0 + s) * D;
         ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
-        re = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+        re = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            ru[c] = ld4_issue(a.U[c] + gcol + r0, cu, img3);
-            rk[c] = ld4_issue(a.K1[c] + gcol + r0, cu, img3);
-            rs[c][0] = ld4_issue(a.U[c] + gcol + n_in, cs, img3);
-            rs[c][1] = ld4_issue(a.K1[c] + gcol + n_in, cs, img3);
+            ru[c] = ld4_issue_w(a.U[c] + gcol + r0, cu, img3, wide);
+            rk[c] = ld4_issue_w(a.K1[c] + gcol + r0, cu, img3, wide);
+            rs[c][0] = ld3_issue(a.U[c] + gcol + n_in, cs, img3);
+            rs[c][1] = ld3_issue(a.K1[c] + gcol + n_in, cs, img3);
         }
     }
     __builtin_amdgcn_sched_barrier(0);                     // nothing above is consumed before all of it is requested
@@ -369,9 +370,9 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
             if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }     // there is no k1 yet
         } else {
             ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
-            const f32x4 e_ = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
-            const f32x4 u_ = ld4_issue(Uin + gcol + r0, cu, img3), k_ = ld4_issue(K1in + gcol + r0, cu, img3);
-            const f32x4 s0 = ld4_issue(Uin + gcol + n_in, cs, img3), s1 = ld4_issue(K1in + gcol + n_in, cs, img3);
+            const f32x4 e_ = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
+            const f32x4 u_ = ld4_issue_w(Uin + gcol + r0, cu, img3, wide), k_ = ld4_issue_w(K1in + gcol + r0, cu, img3, wide);
+            const f32x4 s0 = ld3_issue(Uin + gcol + n_in, cs, img3), s1 = ld3_issue(K1in + gcol + n_in, cs, img3);
             *(f32x4*)epw = ld4_mask(e_, ce); uz = ld4_mask(u_, cu); k1z = ld4_mask(k_, cu);
             if (sown) { sc_set(0, ld4_mask(s0, cs)); sc_set(1, ld4_mask(s1, cs)); }
             if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }
@@ -574,10 +575,8 @@ __global__ void __launch_bounds__(512, 2) k_step3(MfmaArgs a, const float* __res
             const size_t gc = (size_t)(tile * s3::NB + 16 * hf + s) * D;
             float* Un = Uout + gc + r0;
             float* K7 = K1out + gc + r0;
-            if (nv >= 4) {
-                Un[0] = un.x; Un[1] = un.y; Un[2] = un.z; Un[3] = un.w;
-                K7[0] = k7z.x; K7[1] = k7z.y; K7[2] = k7z.z; K7[3] = k7z.w;
-            } else { st4(Un, un, nv); st4(K7, k7z, nv); }
+            if (nv >= 4) { st4_wide(Un, un); st4_wide(K7, k7z); }
+            else { st4(Un, un, nv); st4(K7, k7z, nv); }
         }
         if (!single && live && sown) {
             f32x4 ks[7];
@@ -716,6 +715,7 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
         for (int u = 0; u < 8; ++u) wF2[u] = *(const f32x4*)(rw + 16 * u);
     }
     const int ntile = (a.B + s3::NB - 1) / s3::NB;
+    const bool wide = (n_in & 3) == 0;                     // every lane's four rows are all valid or all padding
     f32x4 ru[2], rk[2], re, rs[2][2];
     int ce = 0, cu = 0, cs = 0;
     float* sc = lds + s3::SC + smp * 24;
@@ -726,13 +726,13 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
         const bool live = s < max(0, min(16, a.B - b0));
         const size_t gcol = (size_t)(b0 + s) * D;
         ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
-        re = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+        re = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            ru[c] = ld4_issue(a.U[c] + gcol + r0, cu, img3);
-            rk[c] = ld4_issue(a.K1[c] + gcol + r0, cu, img3);
-            rs[c][0] = ld4_issue(a.U[c] + gcol + n_in, cs, img3);
-            rs[c][1] = ld4_issue(a.K1[c] + gcol + n_in, cs, img3);
+            ru[c] = ld4_issue_w(a.U[c] + gcol + r0, cu, img3, wide);
+            rk[c] = ld4_issue_w(a.K1[c] + gcol + r0, cu, img3, wide);
+            rs[c][0] = ld3_issue(a.U[c] + gcol + n_in, cs, img3);
+            rs[c][1] = ld3_issue(a.K1[c] + gcol + n_in, cs, img3);
         }
     }
     __builtin_amdgcn_sched_barrier(0);                     // nothing above is consumed before all of it is requested
@@ -850,9 +850,9 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
             if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }     // there is no k1 yet
         } else {
             ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
-            const f32x4 e_ = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
-            const f32x4 u_ = ld4_issue(Uin + gcol + r0, cu, img3), k_ = ld4_issue(K1in + gcol + r0, cu, img3);
-            const f32x4 s0 = ld4_issue(Uin + gcol + n_in, cs, img3), s1 = ld4_issue(K1in + gcol + n_in, cs, img3);
+            const f32x4 e_ = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
+            const f32x4 u_ = ld4_issue_w(Uin + gcol + r0, cu, img3, wide), k_ = ld4_issue_w(K1in + gcol + r0, cu, img3, wide);
+            const f32x4 s0 = ld3_issue(Uin + gcol + n_in, cs, img3), s1 = ld3_issue(K1in + gcol + n_in, cs, img3);
             *(f32x4*)epw = ld4_mask(e_, ce); uz = ld4_mask(u_, cu); k1z = ld4_mask(k_, cu);
             if (sown) { sc_set(0, ld4_mask(s0, cs)); sc_set(1, ld4_mask(s1, cs)); }
             if (single == 1) { k1z = f32x4{0.f, 0.f, 0.f, 0.f}; if (sown) sc_set(1, k1z); }
@@ -1017,10 +1017,8 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
             const size_t gc = (size_t)(tile * s3::NB + 16 * hf + s) * D;
             float* Un = Uout + gc + r0;
             float* K7 = K1out + gc + r0;
-            if (nv >= 4) {
-                Un[0] = un.x; Un[1] = un.y; Un[2] = un.z; Un[3] = un.w;
-                K7[0] = k7z.x; K7[1] = k7z.y; K7[2] = k7z.z; K7[3] = k7z.w;
-            } else { st4(Un, un, nv); st4(K7, k7z, nv); }
+            if (nv >= 4) { st4_wide(Un, un); st4_wide(K7, k7z); }
+            else { st4(Un, un, nv); st4(K7, k7z, nv); }
         }
         if (!single && live && sown) {
             f32x4 ks[7];
@@ -1102,13 +1100,19 @@ constexpr int NS = 96, NP = 32 * NS, NI = 3 * NP;         // narrow image (K = 3
 constexpr int H1B = FP_END * 4, T1B = H1B + WI, H2B = T1B + WI, T2B = H2B + WI, X0B = T2B + WI, T0B = X0B + NI;
 constexpr int TOTAL_BYTES = T0B + NI;
 static_assert(H1B % 16 == 0 && TOTAL_BYTES <= 160 * 1024, "LDS plan");
-// global image (bytes): fragment-ordered split weights, one 16-byte load per lane and piece
-constexpr int FR1 = 0;                                     // W1: [tile 8][piece 3][lane 64] x 16 B
-constexpr int FR2 = FR1 + 8 * 3 * 1024;                    // W2: [tile 8][k-block 4][piece 3][lane 64] x 16 B
-constexpr int FR3 = FR2 + 8 * 4 * 3 * 1024;                // W3: [tile 2][k-block 4][piece 3][lane 64] x 16 B
-constexpr int BIASB = FR3 + 2 * 4 * 3 * 1024;              // b1 (128), b2 (128), b3 (32) fp32
-constexpr int IMG_BYTES = BIASB + (2 * 128 + 32) * 4;
 }  // namespace s3b
+// Global image of the two split kernels (bytes).  The register-resident fragments travel in fp32 and are split on arrival
+// (2/3 of the bytes of three bf16 pieces; the split runs while the rest of the stream is in flight).  Fragment = the 8
+// weights M[16 tile + x][32 k-block + 8q .. +7] of lane 16q + x, as two 16-byte halves: [half 2][lane 64] x 16 B.
+namespace s3g {
+constexpr int BIASB = 0;                                   // b1 (128), b2 (128), b3 (32) fp32
+constexpr int F32 = (2 * 128 + 32) * 4;                    // [wave 8][W1 | W2 x4 | W3^T | W2^T x4], then W3: [tile 2][k-block 4]
+constexpr int NFR = 8 * 10 + 2 * 4;
+constexpr int W3I = F32 + NFR * 2048;                      // k_step3b's LDS images (three bf16 pieces, LDS layout): W3 rows, W1^T rows
+constexpr int WI = 3 * 32 * 272;
+constexpr int IMG_BYTES = W3I + 2 * WI;
+static_assert(F32 % 16 == 0 && W3I % 16 == 0, "16-byte loads");
+}  // namespace s3g
 
 // v = h + m + l exactly: pieces by TRUNCATION (one AND each: the upper 16 bits of an fp32 are a bf16), residuals by exact
 // subtractions; the last residual has at most 8 significant bits, so its upper half is all of it.  (Round-to-nearest
@@ -1134,6 +1138,24 @@ __device__ __forceinline__ S3bOp s3b_load(const char* img, int piece_bytes) {
     S3bOp o;
     o.h = *(const bf16x8*)img; o.m = *(const bf16x8*)(img + piece_bytes); o.l = *(const bf16x8*)(img + 2 * piece_bytes);
     return o;
+}
+// 8 consecutive fp32 values -> a split operand
+__device__ __forceinline__ S3bOp s3b_split8(const f32x4& lo4, const f32x4& hi4) {
+    S3bOp o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 a, b, c;
+        s3b_split(j < 4 ? lo4[j] : hi4[j - 4], a, b, c);
+        o.h[j] = a; o.m[j] = b; o.l[j] = c;
+    }
+    return o;
+}
+// an ordered no-op that consumes and redefines the operand: pins its computation in program order
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void s3b_pin(S3bOp& o) {
+    u32x4 a = __builtin_bit_cast(u32x4, o.h), b = __builtin_bit_cast(u32x4, o.m), c = __builtin_bit_cast(u32x4, o.l);
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+    o.h = __builtin_bit_cast(bf16x8, a); o.m = __builtin_bit_cast(bf16x8, b); o.l = __builtin_bit_cast(bf16x8, c);
 }
 // term T (0..5, smallest first) of the product a x b into acc
 template <int T>
@@ -1187,18 +1209,30 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
     const float* ppin = a.apply_ctrl ? a.partials_in : img3;
     const float2 pp = *reinterpret_cast<const float2*>(ppin + 2 * min(tid, (int)gridDim.x - 1));
     // resident split fragments: W1 tile `wave` (K = 32), W2 tile `wave` (4 k-blocks), W3 tile t (4 k-blocks)
+    // (they arrive in fp32 and are split here, in arrival order, while the rest of the stream is in flight)
     S3bOp wF1, wF2[4], w3[4];
     {
-        const char* f1 = imgb + s3b::FR1 + (size_t)wave * 3 * 1024 + 16 * lane;
-        wF1 = s3b_load(f1, 1024);
-        const char* f2 = imgb + s3b::FR2 + (size_t)wave * 4 * 3 * 1024 + 16 * lane;
-        const char* f3 = imgb + s3b::FR3 + (size_t)t * 4 * 3 * 1024 + 16 * lane;
+        const char* fw = imgb + s3g::F32 + (size_t)wave * 10 * 2048 + 16 * lane;
+        const char* f3 = imgb + s3g::F32 + (size_t)(80 + 4 * t) * 2048 + 16 * lane;
+        auto src = [&](int f) { return f < 5 ? fw + f * 2048 : f3 + (f - 5) * 2048; };
+        constexpr int AH = 5;                                  // fragments requested ahead of the one being split
+        f32x4 raw[9][2];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) { wF2[b] = s3b_load(f2 + b * 3 * 1024, 1024); w3[b] = s3b_load(f3 + b * 3 * 1024, 1024); }
+        for (int f = 0; f < AH; ++f) { raw[f][0] = *(const f32x4*)src(f); raw[f][1] = *(const f32x4*)(src(f) + 1024); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 9; ++f) {
+            if (f + AH < 9) { raw[f + AH][0] = *(const f32x4*)src(f + AH); raw[f + AH][1] = *(const f32x4*)(src(f + AH) + 1024); }
+            S3bOp o = s3b_split8(raw[f][0], raw[f][1]);
+            s3b_pin(o);                                        // (the split stays here, between the two scheduling barriers)
+            if (f == 0) wF1 = o; else if (f < 5) wF2[f - 1] = o; else w3[f - 5] = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     constexpr int NCB = (2 * 128 + 32) / 4;
-    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3b::BIASB)[min(tid, NCB - 1)];
+    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3g::BIASB)[min(tid, NCB - 1)];
     const int ntile = (a.B + 31) / 32;
+    const bool wide = (n_in & 3) == 0;                     // every lane's four rows are all valid or all padding
     f32x4 ru[2], rk[2], re, rs[2][2];
     int ce = 0, cu = 0, cs = 0;
     float* sc = lds + s3b::SC + smp * 24;
@@ -1209,13 +1243,13 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
         const bool live = s < max(0, min(16, a.B - b0));
         const size_t gcol = (size_t)(b0 + s) * D;
         ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
-        re = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
+        re = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            ru[c] = ld4_issue(a.U[c] + gcol + r0, cu, img3);
-            rk[c] = ld4_issue(a.K1[c] + gcol + r0, cu, img3);
-            rs[c][0] = ld4_issue(a.U[c] + gcol + n_in, cs, img3);
-            rs[c][1] = ld4_issue(a.K1[c] + gcol + n_in, cs, img3);
+            ru[c] = ld4_issue_w(a.U[c] + gcol + r0, cu, img3, wide);
+            rk[c] = ld4_issue_w(a.K1[c] + gcol + r0, cu, img3, wide);
+            rs[c][0] = ld3_issue(a.U[c] + gcol + n_in, cs, img3);
+            rs[c][1] = ld3_issue(a.K1[c] + gcol + n_in, cs, img3);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1307,9 +1341,9 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
             if (sown) { sc_set(0, sc_get(cur ? 4 : 2)); sc_set(1, sc_get(cur ? 5 : 3)); }
         } else {
             ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
-            const f32x4 e_ = ld4_issue(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3);
-            const f32x4 u_ = ld4_issue(Uin + gcol + r0, cu, img3), k_ = ld4_issue(K1in + gcol + r0, cu, img3);
-            const f32x4 s0 = ld4_issue(Uin + gcol + n_in, cs, img3), s1 = ld4_issue(K1in + gcol + n_in, cs, img3);
+            const f32x4 e_ = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
+            const f32x4 u_ = ld4_issue_w(Uin + gcol + r0, cu, img3, wide), k_ = ld4_issue_w(K1in + gcol + r0, cu, img3, wide);
+            const f32x4 s0 = ld3_issue(Uin + gcol + n_in, cs, img3), s1 = ld3_issue(K1in + gcol + n_in, cs, img3);
             const f32x4 ev = ld4_mask(e_, ce);
             *(f32x4*)epw = ev;
             s3b_store4(ldsb + s3b::T0B + smp * s3b::NS + 2 * r0, s3b::NP, ev);
@@ -1449,7 +1483,8 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
                 badcnt += (c < nv && !(fabsf(un[c]) <= 3.0e38f)) ? 1.f : 0.f;
             }
             const size_t gc = (size_t)(tile * 32 + 16 * hf + s) * D;
-            st4(Uout + gc + r0, un, nv); st4(K1out + gc + r0, kz[6], nv);
+            if (nv >= 4) { st4_wide(Uout + gc + r0, un); st4_wide(K1out + gc + r0, kz[6]); }
+            else { st4(Uout + gc + r0, un, nv); st4(K1out + gc + r0, kz[6], nv); }
         }
         if (!single && live && sown) {
             f32x4 ks[7];
@@ -1523,32 +1558,9 @@ constexpr int NS = 80, NP = 32 * NS, NI = 3 * NP;         // K = 32 images (stat
 constexpr int H1G = FP_END * 4, H2G = H1G + WI, W3I = H2G + WI, W1TI = W3I + WI, X0S = W1TI + WI, G3S = X0S + NI;
 constexpr int TOTAL_BYTES = G3S + NI;
 static_assert(H1G % 16 == 0 && TOTAL_BYTES <= 160 * 1024, "LDS plan");
-// global image, behind the one of k_step3jb: W2^T and W3^T fragments, then the two LDS images as they are stored
-constexpr int G_FRB2 = (s3b::IMG_BYTES + 15) & ~15;        // W2^T: [tile 8][k-block 4][piece 3][lane 64] x 16 B
-constexpr int G_FRB3 = G_FRB2 + 8 * 4 * 3 * 1024;          // W3^T: [tile 8][piece 3][lane 64] x 16 B
-constexpr int G_W3I = G_FRB3 + 8 * 3 * 1024;               // W3 rows, then W1^T rows: 2 x WI bytes, LDS layout
-constexpr int G_F32 = (G_W3I + 2 * WI + 15) & ~15;         // the resident fragments of k_step3b in fp32 (split on arrival: 2/3 of
-constexpr int IMG_BYTES = G_F32 + 8 * 10 * 2048;           // the bytes): [wave 8][W1 | W2 x4 | W3^T | W2^T x4][half 2][lane 64] x 16 B
+static_assert(WI == s3g::WI, "global image");
 }  // namespace s3v
 
-// 8 consecutive fp32 values -> a split operand (K = 32 products whose B operand stays in fp32 in LDS)
-__device__ __forceinline__ S3bOp s3b_split8(const f32x4& lo4, const f32x4& hi4) {
-    S3bOp o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        __bf16 a, b, c;
-        s3b_split(j < 4 ? lo4[j] : hi4[j - 4], a, b, c);
-        o.h[j] = a; o.m[j] = b; o.l[j] = c;
-    }
-    return o;
-}
-// an ordered no-op that consumes and redefines the operand: pins its computation in program order
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void s3b_pin(S3bOp& o) {
-    u32x4 a = __builtin_bit_cast(u32x4, o.h), b = __builtin_bit_cast(u32x4, o.m), c = __builtin_bit_cast(u32x4, o.l);
-    asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
-    o.h = __builtin_bit_cast(bf16x8, a); o.m = __builtin_bit_cast(bf16x8, b); o.l = __builtin_bit_cast(bf16x8, c);
-}
 // 4 rows of one sample back from the three images: the pieces sum to the fp32 value exactly
 __device__ __forceinline__ f32x4 s3b_load4(const char* img, int piece_bytes) {
     const bf16x4 h = *(const bf16x4*)img, m = *(const bf16x4*)(img + piece_bytes), l = *(const bf16x4*)(img + 2 * piece_bytes);
@@ -1618,11 +1630,11 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     static_assert(NCI % 64 == 0, "whole wave instructions");
     typedef __attribute__((address_space(3))) char* lds_c;
     typedef const __attribute__((address_space(1))) char* glb_c;
-    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3b::BIASB)[min(tid, NCB - 1)];
+    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3g::BIASB)[min(tid, NCB - 1)];
     // the resident fragments arrive in fp32 and are split here, in arrival order, while the rest of the stream is in flight
     S3bOp wF1, wF2[4], wB3, wB2[4];
     {
-        const char* fw = imgb + s3v::G_F32 + (size_t)wave * 10 * 2048 + 16 * lane;
+        const char* fw = imgb + s3g::F32 + (size_t)wave * 10 * 2048 + 16 * lane;
         constexpr int AH = 5;                                  // fragments requested ahead of the one being split
         f32x4 raw[10][2];
 #pragma unroll
@@ -1645,7 +1657,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     for (int i = 0; i < (NCI + 511) / 512; ++i) {
         const int c = 512 * i + 64 * wave;                     // wave-uniform chunk (16 B) index
         if (c < NCI)
-            __builtin_amdgcn_global_load_lds((glb_c)(imgb + s3v::G_W3I + 16 * (c + lane)), (lds_c)(ldsb + s3v::W3I + 16 * c), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_c)(imgb + s3g::W3I + 16 * (c + lane)), (lds_c)(ldsb + s3v::W3I + 16 * c), 16, 0, 0);
     }
     float* sc = lds + s3v::SC + smp * 24;
     auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
@@ -2011,56 +2023,38 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 #endif
 }
 
-// Split weight image of k_step3jb / k_step3b.  Fragment f, lane = 16q + x: the 8 weights M[16 tile + x][32 kblock + 8q .. +7]
-// of M = W1 | W2 | W3 (k_step3jb, k_step3b) | W2^T | W3^T (k_step3b) as three bf16 pieces; then the two LDS images of
-// k_step3b (rows of W3, rows of W1^T) in their LDS layout; biases in fp32.
-__device__ __forceinline__ bool o_in(const NetDesc& nd, int l, int o, int k) { return o < nd.dims[l + 1] && k < nd.dims[l]; }
+// Image of k_step3jb / k_step3b (layout: namespace s3g): biases, the fp32 fragments, the two split LDS images of k_step3b.
 __global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __restrict__ img) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int NF = 8 + 32 + 8 + 32 + 8, NIMG = 2 * 32 * 17;
-    if (i >= NF * 64 + NIMG && i < NF * 64 + NIMG + 80 * 64) {      // fp32 fragments of k_step3b
-        const int e = i - NF * 64 - NIMG, w = e / 640, f = (e / 64) % 10, lane = e & 63, x = lane & 15, q = lane >> 4;
-        const int l = f == 0 ? 0 : (f == 5 ? 2 : 1), tr = f >= 5, kb = f == 0 || f == 5 ? 0 : (f < 5 ? f - 1 : f - 6);
-        float v[8];
-        for (int j = 0; j < 8; ++j) {
-            const int r = 16 * w + x, k = 32 * kb + 8 * q + j;
-            v[j] = tr ? (o_in(nd, l, k, r) ? P[nd.w_off[l] + k + (size_t)r * nd.dims[l + 1]] : 0.f)
-                      : (o_in(nd, l, r, k) ? P[nd.w_off[l] + r + (size_t)k * nd.dims[l + 1]] : 0.f);
-        }
-        char* d = img + s3v::G_F32 + (size_t)(w * 10 + f) * 2048 + 16 * lane;
-        *(f32x4*)d = f32x4{v[0], v[1], v[2], v[3]};
-        *(f32x4*)(d + 1024) = f32x4{v[4], v[5], v[6], v[7]};
-        return;
-    }
-    if (i < (2 * 128 + 32)) {
-        const int l = i < 128 ? 0 : (i < 256 ? 1 : 2), o = i < 128 ? i : (i < 256 ? i - 128 : i - 256);
-        reinterpret_cast<float*>(img + s3b::BIASB)[i] = o < nd.dims[l + 1] ? P[nd.b_off[l] + o] : 0.f;
-    }
+    constexpr int NIMG = 2 * 32 * 17;
     // W_l[o][k] with zero padding
     auto W = [&](int l, int o, int k) {
         return (o < nd.dims[l + 1] && k < nd.dims[l]) ? P[nd.w_off[l] + o + (size_t)k * nd.dims[l + 1]] : 0.f;
     };
-    bf16x8 h, m, lo;
-    char* dst = nullptr;
-    if (i < NF * 64) {
+    if (i < (2 * 128 + 32)) {
+        const int l = i < 128 ? 0 : (i < 256 ? 1 : 2), o = i < 128 ? i : (i < 256 ? i - 128 : i - 256);
+        reinterpret_cast<float*>(img + s3g::BIASB)[i] = o < nd.dims[l + 1] ? P[nd.b_off[l] + o] : 0.f;
+    }
+    if (i < s3g::NFR * 64) {
         const int f = i >> 6, lane = i & 63, x = lane & 15, q = lane >> 4;
         int l, tile, kb, tr = 0;                   // tr: the fragment is a tile of the TRANSPOSED matrix
-        if (f < 8) { l = 0; tile = f; kb = 0; dst = img + s3b::FR1 + (size_t)f * 3 * 1024; }
-        else if (f < 40) { l = 1; tile = (f - 8) >> 2; kb = (f - 8) & 3; dst = img + s3b::FR2 + (size_t)(f - 8) * 3 * 1024; }
-        else if (f < 48) { l = 2; tile = (f - 40) >> 2; kb = (f - 40) & 3; dst = img + s3b::FR3 + (size_t)(f - 40) * 3 * 1024; }
-        else if (f < 80) { l = 1; tr = 1; tile = (f - 48) >> 2; kb = (f - 48) & 3; dst = img + s3v::G_FRB2 + (size_t)(f - 48) * 3 * 1024; }
-        else { l = 2; tr = 1; tile = f - 80; kb = 0; dst = img + s3v::G_FRB3 + (size_t)(f - 80) * 3 * 1024; }
-        dst += 16 * lane;
+        if (f < 80) {                              // wave w: W1 | W2 x4 | W3^T | W2^T x4
+            const int g = f % 10;
+            tile = f / 10;
+            l = g == 0 ? 0 : (g == 5 ? 2 : 1); tr = g >= 5; kb = (g == 0 || g == 5) ? 0 : (g < 5 ? g - 1 : g - 6);
+        } else { l = 2; tile = (f - 80) >> 2; kb = (f - 80) & 3; }      // W3 tiles (k_step3jb)
+        float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = 16 * tile + x, k = 32 * kb + 8 * q + j;
-            __bf16 a, b, c;
-            s3b_split(tr ? W(l, k, r) : W(l, r, k), a, b, c);
-            h[j] = a; m[j] = b; lo[j] = c;
+            v[j] = tr ? W(l, k, r) : W(l, r, k);
         }
-        *(bf16x8*)dst = h; *(bf16x8*)(dst + 1024) = m; *(bf16x8*)(dst + 2048) = lo;
-    } else if (i < NF * 64 + NIMG) {
-        const int e = i - NF * 64, which = e / (32 * 17), r = (e / 17) % 32, g = e % 17;     // 17 groups of 8 bf16 per row
+        char* d = img + s3g::F32 + (size_t)f * 2048 + 16 * lane;
+        *(f32x4*)d = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(d + 1024) = f32x4{v[4], v[5], v[6], v[7]};
+    } else if (i < s3g::NFR * 64 + NIMG) {
+        const int e = i - s3g::NFR * 64, which = e / (32 * 17), r = (e / 17) % 32, g = e % 17;     // 17 groups of 8 bf16 per row
+        bf16x8 h, m, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 8 * g + j;
@@ -2069,14 +2063,13 @@ __global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __r
             s3b_split(v, a, b, c);
             h[j] = a; m[j] = b; lo[j] = c;
         }
-        dst = img + s3v::G_W3I + (size_t)which * s3v::WI + r * s3v::WS + 16 * g;
+        char* dst = img + s3g::W3I + (size_t)which * s3v::WI + r * s3v::WS + 16 * g;
         *(bf16x8*)dst = h; *(bf16x8*)(dst + s3v::WP) = m; *(bf16x8*)(dst + 2 * s3v::WP) = lo;
     }
 }
-
-size_t step3b_img_bytes() { return (size_t)s3v::IMG_BYTES; }
+size_t step3b_img_bytes() { return (size_t)s3g::IMG_BYTES; }
 void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStream_t s) {
-    constexpr int NT = (8 + 32 + 8 + 32 + 8) * 64 + 2 * 32 * 17 + 80 * 64;
+    constexpr int NT = s3g::NFR * 64 + 2 * 32 * 17;
     hipLaunchKernelGGL(k_pack_step3b, dim3((NT + 255) / 256), dim3(256), 0, s, nd, d_params, (char*)d_imgb);
 }
 void step3b_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single) {
