@@ -672,11 +672,14 @@ def test_loss_grad_headline_shape_variants():
 
 
 def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
-    """CNF_STEP_V1 / CNF_TRACE_GENERIC / CNF_ADJ_GENERIC (read once per process) route the headline shape to the
-    first-generation kernels; each route runs its parity tests in a child process."""
+    """CNF_STEP_FP32 (the fp32-MFMA step kernels k_step3 / k_step3j instead of the split-bf16 ones), CNF_STEP_V1 /
+    CNF_TRACE_GENERIC / CNF_ADJ_GENERIC (the first-generation kernels): read once per process; each route runs its parity
+    tests in a child process."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for var, sel in (("CNF_STEP_V1", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve"),
+    for var, sel in (("CNF_STEP_FP32", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve or "
+                                       "test_jvp_mode_headline_shape_step_kernel or ragged"),
+                     ("CNF_STEP_V1", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve"),
                      ("CNF_TRACE_GENERIC", "test_exact_trace_mfma_deep_networks"),
                      ("CNF_ADJ_GENERIC", "test_loss_grad_fixed_dt_matches_oracle and 3-mfma or test_loss_grad_headline")):
         env = dict(os.environ, **{var: "1", "CNF_NO_PARITY_REPORT": "1"})
