@@ -41,6 +41,7 @@ struct cnf_ctx {
     int cond_B = 0, cbs = 0;
     float* tmp_logpx = nullptr;
     float* tmp_regs = nullptr;
+    float* post_part = nullptr;   // loss-sum partials of the post-processing kernel: 4 floats per 64 columns
     float* partials = nullptr;    // 2 * MAX_PARTIALS floats
     StepState* last_state = nullptr; // device slot holding the state at the end of the last solve
     StepState* d_state = nullptr;   // two slots: [0] canonical, [1] ping-pong partner of the fused MFMA path
@@ -265,7 +266,7 @@ static cnf_status ensure_capacity(cnf_handle h, int B) {
     const size_t Dmax = (size_t)h->nd.n_in + 3;
     const size_t ws_f = ((size_t)2 * h->nd.sum_dims + (size_t)2 * h->nd.max_dim) * cap;
     const size_t st_f = Dmax * cap;
-    const size_t total = ws_f + 9 * st_f + 4 * cap;
+    const size_t total = ws_f + 9 * st_f + 4 * cap + cap / 16;
     HIPCHK(h, hipMalloc(&h->arena, total * sizeof(float)));
     float* p = h->arena;
     h->ws = p; p += ws_f;
@@ -274,6 +275,7 @@ static cnf_status ensure_capacity(cnf_handle h, int B) {
     for (int i = 0; i < 5; ++i) { h->Ks[i] = p; p += st_f; }
     h->tmp_logpx = p; p += cap;
     h->tmp_regs = p; p += 3 * cap;
+    h->post_part = p; p += cap / 16;
     h->cap_B = cap;
     return CNF_OK;
 }
@@ -589,9 +591,21 @@ static cnf_status traj_slot(cnf_handle h, int n, float** out) {
     return CNF_OK;
 }
 
+// Post-processing (and loss sums) the caller wants behind the solve.  The streamed driver enqueues it itself, right behind
+// the attempt its step estimate says is the last one -- the kernel checks `done` and does nothing if the estimate was
+// short -- so that it does not wait for the host to notice the end of the solve; `launched` tells the caller it ran.
+struct PostHook {
+    float* logpx; float* regs; float* sums5;
+    bool launched = false;
+};
+static void enqueue_post(cnf_handle h, int train, const StepState* state, const PostHook& ph, int B, bool need_done,
+                         hipStream_t st) {
+    launch_post_state(h->nd, train, state, h->U[0], h->U[1], ph.logpx, ph.regs, B, st, need_done, ph.sums5, h->post_part,
+                      reinterpret_cast<unsigned*>(h->d_sums + 9));
+}
 static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const float* eps, float* u_out, int B,
                              const cnf_solve_opts* opts, cnf_solve_stats* stats, void* stream, Recorder* rec,
-                             bool final_sync = true);
+                             bool final_sync = true, PostHook* post = nullptr);
 
 extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
                                       const float* eps, float* u_out, int B,
@@ -603,7 +617,7 @@ extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
 
 static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const float* eps, float* u_out, int B,
                              const cnf_solve_opts* opts, cnf_solve_stats* stats, void* stream, Recorder* rec,
-                             bool final_sync) {
+                             bool final_sync, PostHook* post) {
     cnf_status s = check_call(h, mode, B);
     if (s != CNF_OK) return s;
     if (!u0 || !opts) return fail(h, CNF_ERR_BAD_ARG, "null pointer");      // u_out may be null: the state stays in U[cur]
@@ -654,7 +668,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         float hh = init->dt < rem ? init->dt : rem;
         init->h = init->tdir * hh;
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_state, init, sizeof(StepState), hipMemcpyHostToDevice, st));
+    launch_set_state(h->d_state, *init, st);
     if (u0 != h->U[0]) HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
 
     // k1 = f(u0).  With the automatic initial dt on the fused path, the two norms and their controller phases
@@ -817,6 +831,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     // Launches queued past the end find `done` and exit at once.
     bool done = false;
     StepState fin{};
+    long post_at = -1, seen_done = -1;  // launches enqueued when the post-processing was last enqueued; the launch that published `done`
     {
         const int AHEAD = 3;
         const volatile cnf_ctx::HostMirror* hm = h->h_mirror;
@@ -857,6 +872,13 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                 ++sent;
             }
             h->mirror_base = base + (unsigned)sent + 1;
+            // everything the estimate asks for is in the queue: the post-processing goes right behind it (fused path: the
+            // state slot the newest launch writes is the one a `done` would be published in)
+            if (post && !rec && use_mfma && !done && need >= 0 && sent - seen >= need + 1 && post_at != sent) {
+                enqueue_post(h, train, cur_state, *post, B, true, st);
+                post_at = sent;
+                ++launches;
+            }
             if (done) break;
             if (seen >= (long)opts->maxiters) {
                 HIPCHK(h, hipStreamSynchronize(st));
@@ -879,7 +901,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                 }
             }
             seen = (long)(sq - base);
-            if (snap.done) { fin = snap; done = true; }
+            if (snap.done) { fin = snap; done = true; seen_done = seen; }
             need = 1;
             if (snap.dt > 0.f) {
                 const double left = std::fabs((double)snap.t1 - (double)snap.t) / (double)snap.dt;
@@ -889,6 +911,12 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         }
     }
     h->last_state = cur_state;
+    if (post) {
+        // the speculative launch counts if it was enqueued behind the launch that published `done` (mirror index
+        // `seen`, i.e. launch number seen on the fused path: the launches are numbered from 0)
+        if (!(post_at > seen_done)) { enqueue_post(h, train, cur_state, *post, B, false, st); ++launches; }
+        post->launched = true;
+    }
     if (rec) {            // streamed recording: step sizes back from the device
         rec->n = fin.naccept;
         rec->overflow = fin.naccept > h->traj_cap;
@@ -970,36 +998,44 @@ extern "C" cnf_status cnf_inference_post(cnf_handle h, int mode, const float* u_
     return CNF_OK;
 }
 
-extern "C" cnf_status cnf_inference(cnf_handle h, int mode, const float* xs, const float* eps,
-                                    float* logpx, float* regs, float* u_final, int B,
-                                    const cnf_solve_opts* opts, cnf_solve_stats* stats,
-                                    void* stream) {
+static cnf_status inference_impl(cnf_handle h, int mode, const float* xs, const float* eps,
+                                 float* logpx, float* regs, float* u_final, float* sums5, int B,
+                                 const cnf_solve_opts* opts, cnf_solve_stats* stats, void* stream) {
     cnf_status s = check_call(h, mode, B);
     if (s != CNF_OK) return s;
     if (!xs || !logpx || !regs || !opts) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
     if (stats) memset(stats, 0, sizeof *stats);
-    if (B == 0) return CNF_OK;
+    if (B == 0) {
+        if (sums5) HIPCHK(h, hipMemsetAsync(sums5, 0, 5 * sizeof(float), (hipStream_t)stream));
+        return CNF_OK;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     if ((s = ensure_capacity(h, B)) != CNF_OK) return s;
     // no allocations and no copies on this path: u0 is assembled in the integrator's own state buffer, and the
     // post-processing reads the final state from wherever the integrator left it
     s = cnf_build_u0(h, mode, xs, h->U[0], B, stream);
-    if (s == CNF_OK) s = solve_core(h, mode, h->U[0], eps, u_final, B, opts, stats, stream, nullptr, false);
-    if (s == CNF_OK) {
-        launch_post_state(h->nd, mode == CNF_MODE_TRAIN, h->last_state, h->U[0], h->U[1], logpx, regs, B,
-                          (hipStream_t)stream);                                           // stream-ordered
+    PostHook ph{logpx, regs, sums5};
+    if (s == CNF_OK) s = solve_core(h, mode, h->U[0], eps, u_final, B, opts, stats, stream, nullptr, false, &ph);
+    if (s == CNF_OK && !ph.launched) {                      // (the one-attempt-at-a-time drivers leave it to the caller)
+        enqueue_post(h, mode == CNF_MODE_TRAIN, h->last_state, ph, B, false, (hipStream_t)stream);   // stream-ordered
         HIPCHK(h, hipGetLastError());
     }
     return s;
 }
 
+extern "C" cnf_status cnf_inference(cnf_handle h, int mode, const float* xs, const float* eps,
+                                    float* logpx, float* regs, float* u_final, int B,
+                                    const cnf_solve_opts* opts, cnf_solve_stats* stats,
+                                    void* stream) {
+    return inference_impl(h, mode, xs, eps, logpx, regs, u_final, nullptr, B, opts, stats, stream);
+}
+
 extern "C" cnf_status cnf_inference_sums(cnf_handle h, int mode, const float* xs, const float* eps, float* logpx,
                                          float* regs, float* sums5, int B, const cnf_solve_opts* opts,
                                          cnf_solve_stats* stats, void* stream) {
-    if (!sums5) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
-    cnf_status s = cnf_inference(h, mode, xs, eps, logpx, regs, nullptr, B, opts, stats, stream);
-    if (s == CNF_OK) s = cnf_loss_sums(h, logpx, regs, B, sums5, stream);
-    return s;
+    if (h && !sums5) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    // the sums ride in the post-processing launch (block partials, the last block adds them in block order)
+    return inference_impl(h, mode, xs, eps, logpx, regs, nullptr, sums5, B, opts, stats, stream);
 }
 
 extern "C" cnf_status cnf_inference_host(cnf_handle h, int mode, const float* xs,

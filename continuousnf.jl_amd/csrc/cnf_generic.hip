@@ -435,27 +435,75 @@ __global__ void k_post(NetDesc nd, int train, const float* __restrict__ fsol,
     regs[2 * (size_t)B + b] = (nd.norm_z_aug && nd.naugs > 0) ? sqrtf(sa) : 0.f;  // :179-187
 }
 
-__global__ void k_post_state(NetDesc nd, int train, const StepState* st, const float* U0, const float* U1,
-                             float* __restrict__ logpx, float* __restrict__ regs, int B) {
+// Post-processing straight from the integrator's buffer U[st->cur], optionally with the five loss sums of src/icnf.jl:489
+// in the same launch.  Four lanes share a sample (their loads of one row are neighbours; one lane per sample would touch
+// 64 rows, 140 bytes apart, with every load).  Sums: fixed tree inside the block, block partials through agent-scope
+// atomics, the block that draws the last ticket adds them in block order -- the result does not depend on which one it is.
+// need_done: the launch was enqueued on the strength of the host's step estimate, right behind the attempt expected to
+// be the last; if that attempt did not finish the solve it does nothing and the host enqueues it again.
+__global__ void __launch_bounds__(256)
+k_post_state(NetDesc nd, int train, const StepState* st, const float* U0, const float* U1,
+             float* __restrict__ logpx, float* __restrict__ regs, int B, int need_done, float* __restrict__ sums5,
+             float* part, unsigned* ticket) {
+    if (need_done && !st->done) return;
     const float* fsol = st->cur ? U1 : U0;
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    const int tid = threadIdx.x, p = tid & 3;
+    const int b = blockIdx.x * 64 + (tid >> 2);
     const int n_in = nd.n_in;
     const int D = n_in + 1 + (train ? 2 : 0);
-    const float* c = fsol + (size_t)b * D;
+    const float* c = fsol + (size_t)min(b, B - 1) * D;
     float ss = 0.f, sa = 0.f;
-    for (int i = 0; i < n_in; ++i) {
-        float v = c[i];
+    for (int i = p; i < n_in; i += 4) {
+        const float v = c[i];
         ss = fmaf(v, v, ss);
         if (i >= nd.nvars) sa = fmaf(v, v, sa);
     }
-    const float log2pi = 1.8378770664093453f;
-    float logpz = -0.5f * fmaf((float)n_in, log2pi, ss);      // base_icnf.jl:177
-    logpx[b] = logpz - c[n_in];                                // base_icnf.jl:178
-    regs[b] = train ? c[n_in + 1] : 0.f;
-    regs[(size_t)B + b] = train ? c[n_in + 2] : 0.f;
-    regs[2 * (size_t)B + b] = (nd.norm_z_aug && nd.naugs > 0) ? sqrtf(sa) : 0.f;  // :179-187
+    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
+    sa += __shfl_xor(sa, 1, 64); sa += __shfl_xor(sa, 2, 64);
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (b < B && p == 0) {
+        const float log2pi = 1.8378770664093453f;
+        const float logpz = -0.5f * fmaf((float)n_in, log2pi, ss);      // base_icnf.jl:177
+        v4[0] = logpz - c[n_in];                                        // base_icnf.jl:178
+        v4[1] = train ? c[n_in + 1] : 0.f;
+        v4[2] = train ? c[n_in + 2] : 0.f;
+        v4[3] = (nd.norm_z_aug && nd.naugs > 0) ? sqrtf(sa) : 0.f;      // :179-187
+        logpx[b] = v4[0];
+        regs[b] = v4[1];
+        regs[(size_t)B + b] = v4[2];
+        regs[2 * (size_t)B + b] = v4[3];
+    }
+    if (!sums5) return;
+    __shared__ float sm[4][4];
+    __shared__ int last;
+    const int w = tid >> 6, l = tid & 63;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float r = wave_sum(v4[j]);
+        if (l == 0) sm[j][w] = r;
+    }
+    __syncthreads();
+    if (tid < 4)
+        __hip_atomic_store(part + 4 * blockIdx.x + tid, (sm[tid][0] + sm[tid][1]) + (sm[tid][2] + sm[tid][3]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {                              // (the four stores above are this wave's: one wait covers them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = t == gridDim.x - 1;
+            if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!last || tid >= 4) return;
+    float r = 0.f;
+    for (unsigned i = 0; i < gridDim.x; ++i) r += __hip_atomic_load(part + 4 * i + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sums5[tid] = r;
+    if (tid == 0) sums5[4] = (float)B;
 }
+
+// the integrator's initial state by value (a 76-byte host-to-device copy is a 5 us staging kernel of the runtime)
+__global__ void k_set_state(StepState* dst, StepState v) { *dst = v; }
 
 // conditional models: cond[b][o] = b1[o] + sum_c W1[o, n_in + c] * ys[c, b]   (padded to cbs with 0)
 __global__ void k_cond_bias(NetDesc nd, const float* __restrict__ P, const float* __restrict__ ys,
@@ -539,8 +587,13 @@ void launch_post(const NetDesc& nd, int train, const float* fsol, float* logpx, 
                        regs, B);
 }
 void launch_post_state(const NetDesc& nd, int train, const StepState* st, const float* U0, const float* U1,
-                       float* logpx, float* regs, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_post_state, dim3((B + 255) / 256), dim3(256), 0, s, nd, train, st, U0, U1, logpx, regs, B);
+                       float* logpx, float* regs, int B, hipStream_t s, bool need_done, float* sums5, float* part,
+                       unsigned* ticket) {
+    hipLaunchKernelGGL(k_post_state, dim3((B + 63) / 64), dim3(256), 0, s, nd, train, st, U0, U1, logpx, regs, B,
+                       need_done ? 1 : 0, sums5, part, ticket);
+}
+void launch_set_state(StepState* dst, const StepState& v, hipStream_t s) {
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, s, dst, v);
 }
 void launch_cond_bias(const NetDesc& nd, const float* P, const float* ys, float* cond, int cbs, int B,
                       hipStream_t s) {

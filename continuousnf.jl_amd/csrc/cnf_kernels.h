@@ -55,8 +55,11 @@ void launch_copy_final(const StepState* st, const float* U0, const float* U1, fl
 void launch_post(const NetDesc& nd, int train, const float* fsol, float* logpx, float* regs,
                  int B, hipStream_t s);
 // same, reading the final state straight from the integrator's buffer U[st->cur]
+// (need_done: do nothing unless st->done; sums5: also the five loss sums, through `part` (4 floats per 64 samples) and `ticket`)
 void launch_post_state(const NetDesc& nd, int train, const StepState* st, const float* U0, const float* U1,
-                       float* logpx, float* regs, int B, hipStream_t s);
+                       float* logpx, float* regs, int B, hipStream_t s, bool need_done = false, float* sums5 = nullptr,
+                       float* part = nullptr, unsigned* ticket = nullptr);
+void launch_set_state(StepState* dst, const StepState& v, hipStream_t s);
 void launch_cond_bias(const NetDesc& nd, const float* P, const float* ys, float* cond, int cbs, int B,
                       hipStream_t s);
 void launch_loss_sums(const float* logpx, const float* regs, int B, float* sums5,
