@@ -596,6 +596,7 @@ static cnf_status traj_slot(cnf_handle h, int n, float** out) {
 // short -- so that it does not wait for the host to notice the end of the solve; `launched` tells the caller it ran.
 struct PostHook {
     float* logpx; float* regs; float* sums5;
+    const float* xs = nullptr;     // also assemble u0 from these columns, in the launch that sets the initial state
     bool launched = false;
 };
 static void enqueue_post(cnf_handle h, int train, const StepState* state, const PostHook& ph, int B, bool need_done,
@@ -668,7 +669,8 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         float hh = init->dt < rem ? init->dt : rem;
         init->h = init->tdir * hh;
     }
-    launch_set_state(h->d_state, *init, st);
+    if (post && post->xs) launch_build_u0(post->xs, h->U[0], h->nd.nvars, D, B, st, h->d_state, init);   // (u0 == h->U[0])
+    else launch_set_state(h->d_state, *init, st);
     if (u0 != h->U[0]) HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
 
     // k1 = f(u0).  With the automatic initial dt on the fused path, the two norms and their controller phases
@@ -1013,8 +1015,7 @@ static cnf_status inference_impl(cnf_handle h, int mode, const float* xs, const 
     if ((s = ensure_capacity(h, B)) != CNF_OK) return s;
     // no allocations and no copies on this path: u0 is assembled in the integrator's own state buffer, and the
     // post-processing reads the final state from wherever the integrator left it
-    s = cnf_build_u0(h, mode, xs, h->U[0], B, stream);
-    PostHook ph{logpx, regs, sums5};
+    PostHook ph{logpx, regs, sums5, xs};
     if (s == CNF_OK) s = solve_core(h, mode, h->U[0], eps, u_final, B, opts, stats, stream, nullptr, false, &ph);
     if (s == CNF_OK && !ph.launched) {                      // (the one-attempt-at-a-time drivers leave it to the caller)
         enqueue_post(h, mode == CNF_MODE_TRAIN, h->last_state, ph, B, false, (hipStream_t)stream);   // stream-ordered

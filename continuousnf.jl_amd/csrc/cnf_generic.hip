@@ -396,8 +396,11 @@ __global__ void k_controller_sums(StepState* st, const float* __restrict__ sums3
 // small elementwise kernels
 // ---------------------------------------------------------------------------------------
 // u0 = vcat(xs, zeros(naugs + n_aug + 1, B))      src/base_icnf.jl:275-276, 282
+// (st_dst: the launch also sets the integrator's initial state, handed over by value -- one launch less at the start of a
+// solve, where the stream is empty and every launch is a host round trip)
 __global__ void k_build_u0(const float* __restrict__ xs, float* __restrict__ u0, int nvars,
-                           int D, int B) {
+                           int D, int B, StepState* st_dst, StepState st_val) {
+    if (st_dst && blockIdx.x == 0 && threadIdx.x == 0) *st_dst = st_val;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)D * B) return;
     int r = (int)(i % D);
@@ -495,10 +498,12 @@ k_post_state(NetDesc nd, int train, const StepState* st, const float* U0, const 
         }
     }
     __syncthreads();
-    if (!last || tid >= 4) return;
+    if (!last) return;
+    // wave j adds sum j: lane l the blocks l, l + 64, ... in that order, then the fixed tree over the lanes
     float r = 0.f;
-    for (unsigned i = 0; i < gridDim.x; ++i) r += __hip_atomic_load(part + 4 * i + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sums5[tid] = r;
+    for (unsigned i = l; i < gridDim.x; i += 64) r += __hip_atomic_load(part + 4 * i + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r = wave_sum(r);
+    if (l == 0) sums5[w] = r;
     if (tid == 0) sums5[4] = (float)B;
 }
 
@@ -570,10 +575,12 @@ void launch_reduce_partials(const StepState* st, const float* partials, float* o
 void launch_controller_sums(StepState* st, const float* sums3, int phase, hipStream_t s) {
     hipLaunchKernelGGL(k_controller_sums, dim3(1), dim3(1), 0, s, st, sums3, phase);
 }
-void launch_build_u0(const float* xs, float* u0, int nvars, int D, int B, hipStream_t s) {
-    size_t n = (size_t)D * B;
-    hipLaunchKernelGGL(k_build_u0, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xs, u0,
-                       nvars, D, B);
+void launch_build_u0(const float* xs, float* u0, int nvars, int D, int B, hipStream_t s, StepState* st_dst,
+                     const StepState* st_val) {
+    const size_t n = (size_t)D * B;
+    StepState v{};
+    if (st_dst) v = *st_val;
+    hipLaunchKernelGGL(k_build_u0, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xs, u0, nvars, D, B, st_dst, v);
 }
 void launch_copy_final(const StepState* st, const float* U0, const float* U1, float* out,
                        size_t n, hipStream_t s) {

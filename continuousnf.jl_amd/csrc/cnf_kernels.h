@@ -49,7 +49,8 @@ void launch_controller(StepState* st, const float* partials, int phase, float n_
 void launch_reduce_partials(const StepState* st, const float* partials, float* out3, float n_local,
                             hipStream_t s);
 void launch_controller_sums(StepState* st, const float* sums3, int phase, hipStream_t s);
-void launch_build_u0(const float* xs, float* u0, int nvars, int D, int B, hipStream_t s);
+void launch_build_u0(const float* xs, float* u0, int nvars, int D, int B, hipStream_t s, StepState* st_dst = nullptr,
+                     const StepState* st_val = nullptr);
 void launch_copy_final(const StepState* st, const float* U0, const float* U1, float* out,
                        size_t n, hipStream_t s);
 void launch_post(const NetDesc& nd, int train, const float* fsol, float* logpx, float* regs,
