@@ -209,6 +209,10 @@ def run_rank(args):
     for _ in range(args.warmup):
         step()
     sync()
+    # the one-launch solve adds up its own durations on the device (100 MHz real-time clock, workgroup 0, entry to exit)
+    # while the timed region runs: nothing is added to the region, the total is read after it
+    import ctypes as C
+    _lib.check(_lib.lib().cnf_solve_kernel_time(icnf.handle(), 1, None, None), icnf.handle())
     t0 = time.perf_counter()
     nf_total = 0
     for _ in range(args.steps):
@@ -217,6 +221,8 @@ def run_rank(args):
     sync()
     elapsed = time.perf_counter() - t0
     local_elapsed = elapsed
+    k_mean_us, k_launches = C.c_float(), C.c_int()
+    _lib.check(_lib.lib().cnf_solve_kernel_time(icnf.handle(), 0, C.byref(k_mean_us), C.byref(k_launches)), icnf.handle())
     loss = cnf.loss_from_sums(icnf, mode, sums)
 
     ranks_seen, per_rank_ms, allreduce_us = 1, [elapsed / args.steps * 1e3], None
@@ -264,11 +270,21 @@ def run_rank(args):
             out = torch.empty_like(u0)
             run = lambda: _lib.check(l.cnf_solve_tsit5(h, 1, u0.data_ptr(), eps.data_ptr(), out.data_ptr(), B,
                                                        C.byref(opts), C.byref(stats), sp), h)
-            run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream); run(); e1.record(stream); e1.synchronize()
-            per_launch_s = e0.elapsed_time(e1) * 1e-3 / nsteps
-            units, kname = 6.0, "fused Tsit5 step kernel (6 RHS evaluations per launch)"
+            if k_launches.value == args.steps:
+                # the one-launch solve (k_solve3b) took every solve of the timed region: the dominant kernel IS the solve the
+                # headline times.  Its launch = one adaptive solve of this workload; its duration = the mean the kernel
+                # itself measured over the timed region (what rocprofv3 --kernel-trace reports for it); nf from the stats
+                per_launch_s = k_mean_us.value * 1e-6
+                units = float(st["nf"])
+                kname = (f"k_solve3b: the whole Tsit5 solve in one launch ({st['nf']} RHS evaluations, "
+                         f"{st['naccept'] + st['nreject']} step attempts; mean over the {k_launches.value} launches of the timed "
+                         f"region, in-kernel 100 MHz clock)")
+            else:
+                run()
+                e0.record(stream); run(); e1.record(stream); e1.synchronize()
+                per_launch_s = e0.elapsed_time(e1) * 1e-3 / nsteps
+                units, kname = 6.0, "fused Tsit5 step kernel (6 RHS evaluations per launch)"
         else:
             D = wl.n_in + 3
             u = torch.randn(B * D, device=dev); du = torch.empty_like(u)

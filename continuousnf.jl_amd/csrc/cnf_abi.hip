@@ -42,6 +42,8 @@ struct cnf_ctx {
     float* tmp_logpx = nullptr;
     float* tmp_regs = nullptr;
     float* post_part = nullptr;   // loss-sum partials of the post-processing kernel: 4 floats per 64 columns
+    unsigned persist_base = 0;    // meetings the one-launch solves have held on the partials buffer so far
+    bool time_kernel = false;     // cnf_solve_kernel_time: the one-launch solve kernel adds up its own durations
     float* partials = nullptr;    // 2 * MAX_PARTIALS floats
     StepState* last_state = nullptr; // device slot holding the state at the end of the last solve
     StepState* d_state = nullptr;   // two slots: [0] canonical, [1] ping-pong partner of the fused MFMA path
@@ -183,10 +185,11 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     hipError_t e = hipSetDevice(h->device);
     if (e == hipSuccess) e = hipMalloc(&h->d_params, h->n_params * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&h->d_state, 2 * sizeof(StepState));
-    if (e == hipSuccess) e = hipMalloc(&h->partials, 4 * MAX_PARTIALS * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&h->partials, 4 * MAX_PARTIALS * sizeof(float));      // (the one-launch solve: 2 x 1024 8-byte words)
+    if (e == hipSuccess) e = hipMemset(h->partials, 0, 4 * MAX_PARTIALS * sizeof(float));
     if (e == hipSuccess) e = hipHostMalloc(&h->h_state, 3 * sizeof(StepState), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc(&h->d_sums, 16 * sizeof(float));
-    if (e == hipSuccess) e = hipMemset(h->d_sums, 0, 16 * sizeof(float));      // words 8.. are device tickets: zero between launches
+    if (e == hipSuccess) e = hipMalloc(&h->d_sums, 24 * sizeof(float));      // 8 floats of sums, tickets, the kernel clock words
+    if (e == hipSuccess) e = hipMemset(h->d_sums, 0, 24 * sizeof(float));      // words 8.. are device tickets: zero between launches
     if (e == hipSuccess) e = hipHostMalloc(&h->h_sums, 4 * sizeof(float), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(&h->h_mirror, sizeof(*h->h_mirror), hipHostMallocCoherent | hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_mirror, h->h_mirror, 0);
@@ -407,6 +410,19 @@ static cnf_status resolve_kernel(cnf_handle h, int mode, int B, int requested, i
         return CNF_OK;
     }
     return fail(h, CNF_ERR_BAD_ARG, "unknown kernel selector");
+}
+
+extern "C" cnf_status cnf_solve_kernel_time(cnf_handle h, int enable, float* mean_us, int* launches) {
+    if (!h) return CNF_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    unsigned long long w[3] = {0, 0, 0};
+    HIPCHK(h, hipMemcpy(w, h->d_sums + 12, sizeof w, hipMemcpyDeviceToHost));
+    if (mean_us) *mean_us = w[2] ? (float)((double)w[1] * 0.01 / (double)w[2]) : 0.f;       // s_memrealtime: 100 MHz
+    if (launches) *launches = (int)w[2];
+    HIPCHK(h, hipMemset(h->d_sums + 12, 0, sizeof w));
+    h->time_kernel = enable != 0;
+    return CNF_OK;
 }
 
 extern "C" cnf_status cnf_rhs_work(cnf_handle h, int mode, int B, double* flops, double* bytes) {
@@ -673,9 +689,67 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     else launch_set_state(h->d_state, *init, st);
     if (u0 != h->U[0]) HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
 
+    const bool hairer = opts->adaptive && opts->dt == 0.f;
+    // The whole solve in one cooperative launch where the handle and the batch allow it (k_solve3b): the weights and the
+    // Runge-Kutta rows stay on the CUs for all attempts, the workgroups exchange two floats per attempt.
+    if (use_mfma && !rec && !lockstep) {
+        const unsigned base = h->mirror_base;
+        s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror, base, h->partials,
+                                  reinterpret_cast<unsigned*>(h->d_sums + 10), h->persist_base,
+                                  reinterpret_cast<int*>(h->d_sums + 11), (int)opts->maxiters, hairer,
+                                  h->time_kernel ? reinterpret_cast<unsigned long long*>(h->d_sums + 12) : nullptr);
+        if (s == CNF_OK) {
+            ++launches;
+            h->mirror_base = base + 1;
+            h->last_state = h->d_state;
+            if (post) { enqueue_post(h, train, h->d_state, *post, B, false, st); ++launches; post->launched = true; }
+            if (u_out) { launch_copy_final(h->d_state, h->U[0], h->U[1], u_out, n, st); ++launches; }
+            HIPCHK(h, hipGetLastError());
+            // the final state arrives through the host mirror, as in the streamed solve
+            const volatile cnf_ctx::HostMirror* hm = h->h_mirror;
+            StepState fin{};
+            unsigned sq = 0;
+            for (long spins = 0;; ++spins) {
+                if (cnf_mirror_read(hm, &fin, &sq) && sq == base) break;
+                if (spins < 4096) _mm_pause();
+                else sched_yield();
+                if (spins % 100000 == 99999) {
+                    hipError_t qe = hipStreamQuery(st);
+                    if (qe != hipSuccess && qe != hipErrorNotReady) HIPCHK(h, qe);
+                    if (qe == hipSuccess && !(cnf_mirror_read(hm, &fin, &sq) && sq == base))
+                        return fail(h, CNF_ERR_HIP, "the solve kernel finished without publishing a state");
+                }
+            }
+            const int attempts = fin.naccept + fin.nreject;
+            h->persist_base += (unsigned)((hairer ? 2 : 0) + attempts);
+            if (final_sync) HIPCHK(h, hipStreamSynchronize(st));
+            if (stats) {
+                stats->nf = (hairer ? 2 : 1) + 6 * attempts;
+                stats->naccept = fin.naccept;
+                stats->nreject = fin.nreject;
+                stats->t_final = fin.t;
+                stats->dt_last = fin.dt;
+                stats->kernel_used = k;
+                stats->launches = launches;
+            }
+            if (fin.nonfinite) return fail(h, CNF_ERR_NONFINITE, "solver state became NaN/Inf");
+            if (!fin.done) {
+                // maxiters, or a wait inside the kernel ran out (abort word): start the ticket count afresh either way
+                HIPCHK(h, hipStreamSynchronize(st));
+                int aborted = 0;
+                HIPCHK(h, hipMemcpy(&aborted, h->d_sums + 11, sizeof(int), hipMemcpyDeviceToHost));
+                HIPCHK(h, hipMemset(h->d_sums + 10, 0, 2 * sizeof(float)));
+                HIPCHK(h, hipMemset(h->partials, 0, 4 * MAX_PARTIALS * sizeof(float)));      // (stale meeting indices)
+                h->persist_base = 0;
+                return aborted ? fail(h, CNF_ERR_HIP, "one-launch solve: a workgroup did not arrive (set CNF_PERSISTENT=0)")
+                               : fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
+            }
+            return CNF_OK;
+        }
+        if (s != CNF_ERR_UNSUPPORTED) return fail(h, s, "one-launch solve failed to start");
+    }
     // k1 = f(u0).  With the automatic initial dt on the fused path, the two norms and their controller phases
     // ride in the RHS launches themselves (the last workgroup to finish runs the phase): 2 launches, not 4.
-    const bool hairer = opts->adaptive && opts->dt == 0.f;
     unsigned* ticket = reinterpret_cast<unsigned*>(h->d_sums + 8);
     bool fused_init = false;
     if (use_mfma && hairer && !lockstep) {

@@ -71,5 +71,12 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
                      bool finalize, int B, hipStream_t s, float* dump = nullptr,
                      size_t dump_stride = 0, void* mirror = nullptr,
                      unsigned seq = 0, size_t dump_step_stride = 0, int dump_cap = 0, float* hs_out = nullptr);
+// the whole solve in one cooperative launch (headline shape, VJP with the |eps^T J| row, B <= 32 x CUs); CNF_ERR_UNSUPPORTED
+// otherwise.  `st`: the initial state in, the final state out (cur = 0: the final columns are in U[0]); part: 2 x 1024
+// floats; counter / base: ticket word (never reset) and its value at launch; abort_flag: set by the kernel when a wait ran out
+cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st, float* const U[2],
+                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, float* part,
+                                 unsigned* counter, unsigned base, int* abort_flag, int maxiters, bool hairer,
+                                 unsigned long long* t_out = nullptr);
 // workgroups (= error partials) of a step launch; `recording`: the solve files its stage states (gradient path)
 int mfma_grid_for(const MfmaPlan& p, int B, bool recording = false, bool train = true);

@@ -1554,6 +1554,34 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, con
     return launch(p, a, s);
 }
 
+// The whole solve of the headline shape in one cooperative launch (k_solve3b, cnf_step3.hip): VJP handles with the
+// |eps^T J| row whose batch is at most one 32-column tile per CU.  CNF_ERR_UNSUPPORTED: not this handle / batch, or the
+// device cannot place the grid right now -- the caller streams step launches instead.  CNF_PERSISTENT=0 switches it off.
+cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st, float* const U[2],
+                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, float* part,
+                                 unsigned* counter, unsigned base, int* abort_flag, int maxiters, bool hairer,
+                                 unsigned long long* t_out) {
+    static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); return e && e[0] == '0'; }();
+    static const bool fp32_only = [] { const char* e = getenv("CNF_STEP_FP32"); return e && e[0] == '1'; }();
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n;
+    }();
+    if (off || fp32_only || step_v1() || !train || p.cond || !p.d_img3b || p.variant != 2 || p.ly.jvp || !p.ly.norm_j)
+        return CNF_ERR_UNSUPPORTED;
+    const int ntile = (B + 31) / 32;
+    if (ntile < 1 || ntile > n_cu || ntile > 512) return CNF_ERR_UNSUPPORTED;
+    MfmaArgs a{};
+    a.init_phase = -1;
+    a.mode = 2; a.B = B; a.eps = eps; a.st = st; a.st_out = st;
+    a.n_total = (float)((size_t)(nd.n_in + 3) * B);
+    a.U[0] = U[0]; a.U[1] = U[1];
+    a.mirror = mirror; a.seq = seq;
+    return step3b_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, ntile, s, part, counter, base, abort_flag,
+                               maxiters, hairer, t_out);
+}
+
 cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st_in,
                      StepState* st_out, float* const U[2], float* const K1[2], float* const Ks[5],
                      const float* eps, const float* partials_in, float* partials_out, bool apply_ctrl,

@@ -19,3 +19,7 @@ void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStre
 void step3jb_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single = 0);
 // k_step3b: the VJP step kernel (k_step3) on six-term bf16 products
 void step3b_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single = 0);
+// the whole solve of one shard in ONE cooperative launch (k_solve3b): grid = tiles of 32 columns, all resident
+cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, int grid, hipStream_t s,
+                               float* part, unsigned* counter, unsigned base, int* abort_flag, int maxiters, bool hairer,
+                               unsigned long long* t_out = nullptr);

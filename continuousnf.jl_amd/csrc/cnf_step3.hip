@@ -2023,6 +2023,433 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_solve3b -- the WHOLE adaptive solve of one shard in one launch: k_step3b's evaluation code inside the step loop.  What
+// a launch per attempt pays every time -- the 212 KB weight stream, the state round trip through HBM, the error partials
+// of the previous launch, kernel start and drain -- is paid once: weights, Runge-Kutta rows and probe rows stay in
+// registers / LDS for all attempts, and the workgroups meet once per attempt to exchange their error partials (two floats
+// each) through agent-scope atomics: a partial store, a ticket, a poll of the ticket, then every workgroup adds the same
+// partials in the same order and runs the same controller, as the launches of the streamed driver do.  No cache is
+// flushed: nothing else crosses workgroups.  Needs every workgroup resident (one 32-sample tile per workgroup, one
+// workgroup per CU: B <= 32 x CUs, cooperative launch); every wait is bounded, so a lost workgroup ends the launch with
+// an error word instead of hanging it.  Results are bit-identical to the streamed solve (same sums, same order).
+// ---------------------------------------------------------------------------------------------------------------
+struct Solve3Args {
+    float* part;          // error partials: two buffers (meeting index parity) of 2 x 512 words {meeting index, float}
+    unsigned* counter;    // (unused)
+    unsigned base;        // meetings held by earlier launches on this buffer: the indices go on from there
+    int* abort_flag;      // set when a wait ran out
+    unsigned long long* t_out;   // null, or {entry stamp, sum of durations, launches}: workgroup 0's 100 MHz real-time clock
+    int maxiters;
+    int hairer;           // automatic initial dt: the norms of f(u0), a second evaluation and its norm first
+};
+__global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __restrict__ imgb, int n_in, int norm_z,
+                                                    int norm_j, const S3Tab tab, Solve3Args sv) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* ldsb = reinterpret_cast<char*>(lds);
+    const float* img3 = reinterpret_cast<const float*>(imgb);      // (a valid address for masked loads)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = n_in + 3;
+    const int s = lane & 15, q = lane >> 4;
+    const int t = wave & 1, hf = (wave >> 1) & 1;
+    const bool zown = wave < 4;
+    const bool sown = !zown && t == 0 && q == 0;
+    const int smp = 16 * hf + s;
+    const int r0 = 16 * t + 4 * q;
+    const int nv = n_in - r0;
+    const bool wide = (n_in & 3) == 0;
+    const int b0 = blockIdx.x * 32 + 16 * hf;
+    const bool live = s < max(0, min(16, a.B - b0));
+    const size_t gcol = (size_t)(b0 + s) * D;
+    const int ce = live ? nv : 0, cu = (zown && live) ? nv : 0, cs = (sown && live) ? 3 : 0;
+    if (sv.t_out && blockIdx.x == 0 && tid == 0) sv.t_out[0] = __builtin_amdgcn_s_memrealtime();
+    // ---- one round trip: this tile's state and probe rows, the weights ----
+    const f32x4 re = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
+    const f32x4 ru = ld4_issue_w(a.U[0] + gcol + r0, cu, img3, wide);
+    const f32x4 rs = ld3_issue(a.U[0] + gcol + n_in, cs, img3);
+    constexpr int NCI = 2 * s3v::WI / 16, NCB = (2 * 128 + 32) / 4;
+    typedef __attribute__((address_space(3))) char* lds_c;
+    typedef const __attribute__((address_space(1))) char* glb_c;
+    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3g::BIASB)[min(tid, NCB - 1)];
+    // the resident fragments arrive in fp32 and are split here, in arrival order, while the rest of the stream is in flight
+    S3bOp wF1, wF2[4], wB3, wB2[4];
+    {
+        const char* fw = imgb + s3g::F32 + (size_t)wave * 10 * 2048 + 16 * lane;
+        constexpr int AH = 5;                                  // fragments requested ahead of the one being split
+        f32x4 raw[10][2];
+#pragma unroll
+        for (int f = 0; f < AH; ++f) { raw[f][0] = *(const f32x4*)(fw + f * 2048); raw[f][1] = *(const f32x4*)(fw + f * 2048 + 1024); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 10; ++f) {
+            if (f + AH < 10) {
+                raw[f + AH][0] = *(const f32x4*)(fw + (f + AH) * 2048);
+                raw[f + AH][1] = *(const f32x4*)(fw + (f + AH) * 2048 + 1024);
+            }
+            S3bOp o = s3b_split8(raw[f][0], raw[f][1]);
+            s3b_pin(o);                                        // (the split stays here, between the two scheduling barriers)
+            if (f == 0) wF1 = o; else if (f < 5) wF2[f - 1] = o; else if (f == 5) wB3 = o; else wB2[f - 6] = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the two LDS images last: while LDS-DMA pieces are outstanding the compiler waits with vmcnt(0) for ANY loaded register
+#pragma unroll
+    for (int i = 0; i < (NCI + 511) / 512; ++i) {
+        const int c = 512 * i + 64 * wave;                     // wave-uniform chunk (16 B) index
+        if (c < NCI)
+            __builtin_amdgcn_global_load_lds((glb_c)(imgb + s3g::W3I + 16 * (c + lane)), (lds_c)(ldsb + s3v::W3I + 16 * c), 16, 0, 0);
+    }
+    float* sc = lds + s3v::SC + smp * 24;
+    auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
+    auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's LDS-DMA pieces have landed
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 epsr = ld4_mask(re, ce);
+    float* msc = lds + s3v::MISC;
+    StepState* ns = reinterpret_cast<StepState*>(msc + 44);            // the integrator state (thread 0 runs the controller on it)
+    static_assert(sizeof(StepState) <= 20 * sizeof(float), "fits the scratch words");
+    if (tid == 0) *ns = *a.st;
+    if (tid < NCB) reinterpret_cast<f32x4*>(lds + s3v::BIAS)[tid] = sgb;
+    const int single = 0;                                              // (the evaluation code is k_step3b's)
+    (void)single;
+    float errsum = 0.f, badcnt = 0.f;
+    // the 8 partials (2 row tiles x 4 lanes) of one sample and one kind sit side by side: two b128 reads each
+    auto red8 = [&](int kind) {
+        const float* r = lds + s3v::RED + (kind * 32 + smp) * 8;
+        const f32x4 a_ = *(const f32x4*)r, b_ = *(const f32x4*)(r + 4);
+        return ((a_.x + a_.y) + (a_.z + a_.w)) + ((b_.x + b_.y) + (b_.z + b_.w));
+    };
+    auto read_scalars = [&]() {
+        const float e2 = red8(0), ld = red8(1), n2 = red8(2);
+        return f32x4{ld, norm_z ? __builtin_sqrtf(e2) : 0.f, norm_j ? __builtin_sqrtf(n2) : 0.f, 0.f};
+    };
+    float* redw = lds + s3v::RED + smp * 8 + 4 * t + q;                 // this lane's slot of kind 0 (+ 256 per kind)
+    // B operands from a split image: lane (sample s of half A, k = 8q ..); half B = 16 rows on.  Results: lane (sample s,
+    // rows 16 wave + 4q ..) of the wide images
+    const int wb_rd = s * s3v::WS + 16 * q, wb_wr = s * s3v::WS + 2 * (16 * wave + 4 * q);
+    constexpr int HBW = 16 * s3v::WS;
+    // narrow products: A = rows 16t + s of W3 (waves 0-3) / of W1^T (waves 4-7), B = this wave's half of h2 / g1
+    const char* nrA = ldsb + (zown ? s3v::W3I : s3v::W1TI) + (16 * t + s) * s3v::WS + 16 * q;
+    const char* nrB = ldsb + (zown ? s3v::H2G : s3v::H1G) + smp * s3v::WS + 16 * q;
+    char* x0w = ldsb + s3v::X0S + smp * s3v::NS + 2 * r0;               // this lane's 4 rows of the state / g3 images
+    char* g3w = ldsb + s3v::G3S + smp * s3v::NS + 2 * r0;
+    const int nb_rd = s * s3v::NS + 16 * q;                             // their B operands: lane (sample s of half A, k = 8q ..)
+    constexpr int HBN = 16 * s3v::NS;
+    // Runge-Kutta state of the z rows r0..r0+3 of sample smp, written and read by this lane only:
+    float* rkw = lds + s3v::KZ + smp * s3v::SKZ + r0;                   // u at rkw, k1 at rkw + 32,
+    float* kzw = rkw + 64;                                            // k_{j+2} at kzw + 32 j (j = 0..5)
+    const float* bias = lds + s3v::BIAS;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // this tile's rows
+    if (zown) { *(f32x4*)rkw = ld4_mask(ru, cu); *(f32x4*)(rkw + 32) = zero4; }
+    if (sown) { sc_set(0, ld4_mask(rs, cs)); sc_set(1, zero4); }
+    s3_bar();                                              // LDS images, biases, state
+    float hstep = ns->h, abstol = ns->abstol, reltol = ns->reltol;
+    hstep = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hstep)));
+    abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(abstol)));
+    reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(reltol)));
+    int nsync = 0;                                         // meetings so far (the same count in every workgroup)
+    // The workgroups' partials (e, b) -> the sums of all of them, in msc[32], msc[33] for thread 0 (what the prologue of a
+    // step launch computes from the previous launch's partials, in the same order).  Returns false when a wait ran out.
+    auto meet = [&](float e_lane, float b_lane) -> bool {
+        float e = s3_wave_sum(e_lane), b = s3_wave_sum(b_lane);
+        if (lane == 0) { msc[wave] = e; msc[16 + wave] = b; }
+        s3_bar();
+        // Every partial travels with the index of the meeting it belongs to in the same 8-byte word: a reader needs no
+        // ticket -- thread i polls workgroup i's two words until both carry this meeting's index -- so a meeting costs one
+        // store and one load round trip.  Two buffers by parity: a workgroup can be one meeting ahead of a reader, not two.
+        unsigned long long* pb = reinterpret_cast<unsigned long long*>(sv.part) + (nsync & 1) * 1024;
+        const unsigned tag = sv.base + (unsigned)nsync + 1u;
+        if (tid == 0) {
+            float e8 = 0.f, b8 = 0.f;
+            for (int w = 0; w < 8; ++w) { e8 += msc[w]; b8 += msc[16 + w]; }
+            __hip_atomic_store(pb + 2 * blockIdx.x, ((unsigned long long)tag << 32) | __float_as_uint(e8), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pb + 2 * blockIdx.x + 1, ((unsigned long long)tag << 32) | __float_as_uint(b8), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float cp0 = 0.f, cp1 = 0.f;
+        int ok = 1;
+        if (tid < (int)gridDim.x) {
+            ok = 0;
+            for (int spin = 0; spin < (1 << 21); ++spin) {
+                const unsigned long long w0 = __hip_atomic_load(pb + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long w1 = __hip_atomic_load(pb + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag) {
+                    cp0 = __uint_as_float((unsigned)w0); cp1 = __uint_as_float((unsigned)w1); ok = 1;
+                    break;
+                }
+                if ((spin & 255) == 255 && __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok) __hip_atomic_store(sv.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cp0 = s3_wave_sum(cp0); cp1 = s3_wave_sum(cp1);
+        const float bad = s3_wave_sum(ok ? 0.f : 1.f);
+        s3_bar();                                          // (msc[0..7], [16..23] were read by thread 0 above)
+        if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; msc[24 + wave] = bad; }
+        s3_bar();
+        float nbad = 0.f;
+        for (int w = 0; w < 8; ++w) nbad += msc[24 + w];
+        if (tid == 0) {
+            float p0 = 0.f, p1 = 0.f;
+            for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
+            msc[32] = p0; msc[33] = p1;
+        }
+        ++nsync;
+        return nbad == 0.f;
+    };
+    // thread 0 ran a controller phase on *ns: the new step and tolerances to everyone
+    auto share = [&]() {
+        s3_bar();
+        hstep = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[36])));
+        abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[37])));
+        reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[38])));
+        const int fl = __builtin_amdgcn_readfirstlane(__float_as_int(msc[39]));
+        s3_bar();                                          // (the words are rewritten by the next phase)
+        return fl;                                         // bit 0: done, bit 1: the attempt was accepted
+    };
+    auto post_ctrl = [&](int accepted) {                   // thread 0, after a controller phase
+        msc[36] = ns->h; msc[37] = ns->abstol; msc[38] = ns->reltol;
+        msc[39] = __int_as_float((ns->done ? 1 : 0) | (accepted ? 2 : 0));
+    };
+    // one evaluation at the state image in place; zdot -> the k2 slot, scalar rows from the RED partials
+    int nstg = 1;
+    float c21 = 0.f;
+    auto evals = [&]() {
+        for (int stg = 1; stg <= nstg; ++stg) {
+            f32x4 d2a, d2b;                                                  // sigma'_2 at this lane's h2 entries (interval 1 -> 3)
+            // ---- interval 0: first layer, tile `wave`, both halves (K = 32: one k-block)
+            {
+                const f32x4 bv1 = *(const f32x4*)(bias + 16 * wave + 4 * q);
+                S3bOp b[2];
+                b[0] = s3b_load(ldsb + s3v::X0S + nb_rd, s3v::NP);
+                b[1] = s3b_load(ldsb + s3v::X0S + nb_rd + HBN, s3v::NP);
+                S3_SB();
+                f32x4 acc[2] = {zero4, zero4};
+                s3b_mm<2>(acc, wF1, b);
+                s3b_store4(ldsb + s3v::H1G + wb_wr, s3v::WP, s3_tanh4(acc[0] + bv1));
+                s3b_store4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP, s3_tanh4(acc[1] + bv1));
+            }
+            s3_bar();
+            // ---- interval 1: second layer, tile `wave`, both halves share the A fragments
+            {
+                const f32x4 bv2 = *(const f32x4*)(bias + 128 + 16 * wave + 4 * q);
+                // scalar rows of the PREVIOUS evaluation from its RED partials (complete since the last barrier of it)
+                if (stg > 1 && sown) sc_set(stg, read_scalars());              // slot j holds k_j
+                f32x4 acc[2] = {zero4, zero4};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    S3bOp b[2];
+                    b[0] = s3b_load(ldsb + s3v::H1G + wb_rd + 64 * kb, s3v::WP);
+                    b[1] = s3b_load(ldsb + s3v::H1G + wb_rd + HBW + 64 * kb, s3v::WP);
+                    S3_SB();
+                    s3b_mm<2>(acc, wF2[kb], b);
+                    S3_SB();
+                }
+                const f32x4 h2a = s3_tanh4(acc[0] + bv2), h2b = s3_tanh4(acc[1] + bv2);
+                d2a = s3_dtanh4(h2a); d2b = s3_dtanh4(h2b);
+                s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, h2a);
+                s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, h2b);
+            }
+            s3_bar();
+            // ---- interval 2: last layer on waves 0-3 (one per SIMD): zdot rows r0..r0+3 of sample smp
+            if (zown) {
+                const f32x4 bv3 = *(const f32x4*)(bias + 256 + r0);
+                f32x4 z0 = zero4, z1 = zero4;                                  // two chains (terms 0-2 / 3-5)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const S3bOp av = s3b_load(nrA + 64 * kb, s3v::WP), bvv = s3b_load(nrB + 64 * kb, s3v::WP);
+                    S3_SB();
+                    z0 = s3b_term<0>(av, bvv, z0); z1 = s3b_term<3>(av, bvv, z1);
+                    z0 = s3b_term<1>(av, bvv, z0); z1 = s3b_term<4>(av, bvv, z1);
+                    z0 = s3b_term<2>(av, bvv, z0); z1 = s3b_term<5>(av, bvv, z1);
+                    S3_SB();
+                }
+                // stage sum without the k this evaluation will produce: pre = u + h sum_{j<stg} a_{stg+1,j} k_j
+                const float* A = tab.a[stg < 6 ? stg + 1 : 6];
+                f32x4 pre = *(const f32x4*)rkw + (hstep * A[0]) * *(const f32x4*)(rkw + 32);
+#pragma unroll
+                for (int j = 1; j < 5; ++j) pre += (hstep * A[j]) * *(const f32x4*)(kzw + 32 * (j - 1));
+                const f32x4 zd = s3_tanh4(z0 + z1 + bv3);                      // padded rows: zero weights and bias -> 0
+                s3b_store4(g3w, s3v::NP, epsr * s3_dtanh4(zd));               // g3 = eps .* sigma'_3
+                if (stg < 6) s3b_store4(x0w, s3v::NP, pre + (hstep * A[stg]) * zd);     // state of the next evaluation
+                *(f32x4*)(kzw + 32 * (stg - 1)) = zd;                          // k_{stg+1}
+                redw[0] = s3_dot4(zd, zd);
+            }
+            s3_bar();
+            // ---- interval 3: reverse of the last layer, tile `wave` of W3^T, both halves (K = 32); g2 over h2 in place
+            {
+                S3bOp b[2];
+                b[0] = s3b_load(ldsb + s3v::G3S + nb_rd, s3v::NP);
+                b[1] = s3b_load(ldsb + s3v::G3S + nb_rd + HBN, s3v::NP);
+                S3_SB();
+                f32x4 acc[2] = {zero4, zero4};
+                s3b_mm<2>(acc, wB3, b);
+                s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, acc[0] * d2a);
+                s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, acc[1] * d2b);
+            }
+            s3_bar();
+            // ---- interval 4: reverse of the second layer, tile `wave` of W2^T; g1 over h1 in place
+            {
+                const f32x4 h1a = s3b_load4(ldsb + s3v::H1G + wb_wr, s3v::WP), h1b = s3b_load4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP);
+                f32x4 acc[2] = {zero4, zero4};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    S3bOp b[2];
+                    b[0] = s3b_load(ldsb + s3v::H2G + wb_rd + 64 * kb, s3v::WP);
+                    b[1] = s3b_load(ldsb + s3v::H2G + wb_rd + HBW + 64 * kb, s3v::WP);
+                    S3_SB();
+                    s3b_mm<2>(acc, wB2[kb], b);
+                    S3_SB();
+                }
+                s3b_store4(ldsb + s3v::H1G + wb_wr, s3v::WP, acc[0] * s3_dtanh4(h1a));
+                s3b_store4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP, acc[1] * s3_dtanh4(h1b));
+            }
+            s3_bar();
+            // ---- interval 5: eJ = W1^T g1 on waves 4-7 (one per SIMD): trace and norm partials (src/icnf.jl:334, :343)
+            if (!zown) {
+                f32x4 j0 = zero4, j1 = zero4;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const S3bOp av = s3b_load(nrA + 64 * kb, s3v::WP), bvv = s3b_load(nrB + 64 * kb, s3v::WP);
+                    S3_SB();
+                    j0 = s3b_term<0>(av, bvv, j0); j1 = s3b_term<3>(av, bvv, j1);
+                    j0 = s3b_term<1>(av, bvv, j0); j1 = s3b_term<4>(av, bvv, j1);
+                    j0 = s3b_term<2>(av, bvv, j0); j1 = s3b_term<5>(av, bvv, j1);
+                    S3_SB();
+                }
+                const f32x4 ej = j0 + j1;
+                redw[32 * 8] = -s3_dot4(ej, epsr);
+                redw[2 * 32 * 8] = s3_dot4(ej, ej);
+            }
+            s3_bar();
+        }
+    };
+    // (x / sk)^2 onto acc, sk = atol + rtol |u|: the expressions of the single-evaluation launches, digit for digit
+    auto add_norm = [&](float& acc, float u, float x) {
+        const float sk = fmaf(fabsf(u), reltol, abstol);
+        const float y = x / sk;
+        acc = fmaf(y, y, acc);
+    };
+    bool alive = true;
+    {
+        // ---- k1 = f(u0); with the automatic initial dt (Hairer; the two single evaluations of the streamed driver) also
+        // its norms, f(u0 + h0 f0) and that norm ----
+        if (zown) {
+            s3b_store4(x0w, s3v::NP, *(const f32x4*)rkw);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;
+        }
+        s3_bar();
+        nstg = 1; evals();
+        float e = 0.f, b = 0.f;
+        if (live && zown) {
+            const f32x4 u4 = *(const f32x4*)rkw, f0 = *(const f32x4*)kzw;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < nv) { add_norm(e, u4[c], u4[c]); add_norm(b, u4[c], f0[c]); }
+            *(f32x4*)(rkw + 32) = f0;                                      // k1 = f(u0)
+        }
+        if (live && sown) {
+            const f32x4 u4 = sc_get(0), f0 = read_scalars();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { add_norm(e, u4[c], u4[c]); add_norm(b, u4[c], f0[c]); }
+            sc_set(1, f0);
+        }
+        if (sv.hairer) alive = meet(e, b);
+        if (sv.hairer && alive) {
+            if (tid == 0) { ctrl_phase(ns, 0, msc[32], msc[33], a.n_total); post_ctrl(0); }
+            share();
+            if (zown) {
+                s3b_store4(x0w, s3v::NP, *(const f32x4*)rkw + hstep * *(const f32x4*)(rkw + 32));   // f(u0 + h0 f0)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;
+            }
+            s3_bar();
+            nstg = 1; evals();
+            e = 0.f; b = 0.f;
+            if (live && zown) {
+                const f32x4 u4 = *(const f32x4*)rkw, f0 = *(const f32x4*)(rkw + 32), f1 = *(const f32x4*)kzw;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < nv) add_norm(e, u4[c], f1[c] - f0[c]);
+            }
+            if (live && sown) {
+                const f32x4 u4 = sc_get(0), f0 = sc_get(1), f1 = read_scalars();
+#pragma unroll
+                for (int c = 0; c < 3; ++c) add_norm(e, u4[c], f1[c] - f0[c]);
+            }
+            alive = meet(e, b);
+            if (alive) {
+                if (tid == 0) { ctrl_phase(ns, 1, msc[32], msc[33], a.n_total); post_ctrl(0); }
+                share();
+            }
+        }
+    }
+    // ---- step attempts ----
+    int done = 0;
+    for (int it = 0; alive && !done && it < sv.maxiters; ++it) {
+        if (zown) {
+            s3b_store4(x0w, s3v::NP, *(const f32x4*)rkw + (hstep * TS_A21) * *(const f32x4*)(rkw + 32));   // U_2 = u + h a21 k1
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;
+        }
+        s3_bar();
+        nstg = 6; evals();
+        float errsum = 0.f, badcnt = 0.f;
+        if (live && zown) {
+            const f32x4 k7z = *(const f32x4*)(kzw + 32 * 5), uz_ = *(const f32x4*)rkw;
+            const f32x4 un = s3b_load4(x0w, s3v::NP);
+            f32x4 ez = TS_BT1 * *(const f32x4*)(rkw + 32) + TS_BT7 * k7z;
+            ez += TS_BT2 * *(const f32x4*)(kzw) + TS_BT3 * *(const f32x4*)(kzw + 32) + TS_BT4 * *(const f32x4*)(kzw + 64) +
+                  TS_BT5 * *(const f32x4*)(kzw + 96) + TS_BT6 * *(const f32x4*)(kzw + 128);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float scl = fmaf(fmaxf(fabsf(uz_[c]), fabsf(un[c])), reltol, abstol);
+                const float x = c < nv ? hstep * ez[c] / scl : 0.f;
+                errsum = fmaf(x, x, errsum);
+                badcnt += (c < nv && !(fabsf(un[c]) <= 3.0e38f)) ? 1.f : 0.f;
+            }
+        }
+        if (live && sown) {
+            f32x4 ks[7];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ks[j] = sc_get(1 + j);
+            const f32x4 us = sc_get(0);
+            ks[6] = read_scalars();
+            const f32x4 uns = us + hstep * stage_acc4<6>(ks);
+            err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
+            sc_set(7, uns);                                                // kept for an accepted attempt
+        }
+        alive = meet(errsum, badcnt);
+        if (!alive) break;
+        if (tid == 0) {
+            const int acc0 = ns->naccept;
+            ctrl_after_step(ns, msc[32], msc[33], a.n_total);
+            post_ctrl(ns->naccept != acc0);
+        }
+        const int fl = share();
+        done = fl & 1;
+        if (fl & 2) {                                                      // accepted: u <- u_new, k1 <- k7 (FSAL)
+            if (zown) {
+                *(f32x4*)rkw = s3b_load4(x0w, s3v::NP);
+                *(f32x4*)(rkw + 32) = *(const f32x4*)(kzw + 32 * 5);
+            }
+            if (sown) { const f32x4 k7s = read_scalars(); sc_set(0, sc_get(7)); sc_set(1, k7s); }
+        }
+    }
+    // ---- the final state to the integrator's buffer set 0 ----
+    if (live && zown) { if (nv >= 4) st4_wide(a.U[0] + gcol + r0, *(const f32x4*)rkw); else st4(a.U[0] + gcol + r0, *(const f32x4*)rkw, nv); }
+    if (live && sown) { const f32x4 us = sc_get(0); float* o = a.U[0] + gcol + n_in; o[0] = us.x; o[1] = us.y; o[2] = us.z; }
+    if (blockIdx.x == 0 && tid == 0) {
+        ns->cur = 0;
+        *a.st_out = *ns;
+        if (sv.t_out) { sv.t_out[1] += __builtin_amdgcn_s_memrealtime() - sv.t_out[0]; sv.t_out[2] += 1; }
+        publish_mirror(a, *ns);
+    }
+}
+
 // Image of k_step3jb / k_step3b (layout: namespace s3g): biases, the fp32 fragments, the two split LDS images of k_step3b.
 __global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __restrict__ img) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2071,6 +2498,30 @@ size_t step3b_img_bytes() { return (size_t)s3g::IMG_BYTES; }
 void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStream_t s) {
     constexpr int NT = s3g::NFR * 64 + 2 * 32 * 17;
     hipLaunchKernelGGL(k_pack_step3b, dim3((NT + 255) / 256), dim3(256), 0, s, nd, d_params, (char*)d_imgb);
+}
+cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, int grid, hipStream_t s,
+                               float* part, unsigned* counter, unsigned base, int* abort_flag, int maxiters, bool hairer,
+                               unsigned long long* t_out) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)k_solve3b, hipFuncAttributeMaxDynamicSharedMemorySize, s3v::TOTAL_BYTES) != hipSuccess)
+            return CNF_ERR_HIP;
+        attr = true;
+    }
+    MfmaArgs a_ = a;
+    const char* img = (const char*)d_imgb;
+    S3Tab tab = kS3Tab;
+    Solve3Args sv{part, counter, base, abort_flag, t_out, maxiters, hairer ? 1 : 0};
+    void* args[] = {&a_, &img, &n_in, &norm_z, &norm_j, &tab, &sv};
+    // every workgroup must be resident for the whole launch: the cooperative launch refuses what it cannot place (and the
+    // runtime keeps cooperative kernels of one process apart).  CNF_PERSISTENT=2: a plain launch -- no such guarantee, only
+    // the bounded waits inside the kernel; for measurements on a GPU that runs nothing else.
+    static const bool plain = [] { const char* e = getenv("CNF_PERSISTENT"); return e && e[0] == '2'; }();
+    hipError_t e;
+    if (plain) e = hipLaunchKernel((const void*)k_solve3b, dim3(grid), dim3(512), args, s3v::TOTAL_BYTES, s);
+    else e = hipLaunchCooperativeKernel((const void*)k_solve3b, dim3(grid), dim3(512), args, s3v::TOTAL_BYTES, s);
+    if (e != hipSuccess) { (void)hipGetLastError(); return CNF_ERR_UNSUPPORTED; }
+    return CNF_OK;
 }
 void step3b_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single) {
     static bool attr = false;

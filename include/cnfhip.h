@@ -261,6 +261,11 @@ int cnf_kernel_for(cnf_handle h, int mode, int B);
  * bytes = 4*B*(n_in + [train] n_in + D) + 4*P; flops = B*(4M + 6 n_in) (Train);
  * Test: B*3M for 2-layer nets (closed-form trace), else B*(2M + n_in*2M). */
 cnf_status cnf_rhs_work(cnf_handle h, int mode, int B, double* flops, double* bytes);
+/* Measurement aid (bench.py).  While enabled, the kernel of the one-launch solve reads the 100 MHz real-time clock at
+ * its entry and exit (workgroup 0) and adds the interval to a device-side total: no event, no extra synchronisation
+ * inside the timed region.  The call returns the mean interval (microseconds) and the number of such launches since the
+ * previous call, zeroes both, and sets the switch; pointers may be null.  0 launches: the solves streamed step launches. */
+cnf_status cnf_solve_kernel_time(cnf_handle h, int enable, float* mean_us, int* launches);
 
 #ifdef __cplusplus
 }

@@ -672,22 +672,65 @@ def test_loss_grad_headline_shape_variants():
 
 
 def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
-    """CNF_STEP_FP32 (the fp32-MFMA step kernels k_step3 / k_step3j instead of the split-bf16 ones), CNF_STEP_V1 /
+    """CNF_PERSISTENT=0 (the streamed step launches instead of the one-launch solve), CNF_STEP_FP32 (the fp32-MFMA step
+    kernels k_step3 / k_step3j instead of the split-bf16 ones), CNF_STEP_V1 /
     CNF_TRACE_GENERIC / CNF_ADJ_GENERIC (the first-generation kernels): read once per process; each route runs its parity
     tests in a child process."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for var, sel in (("CNF_STEP_FP32", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve or "
+    for var, sel in (("CNF_PERSISTENT=0", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3 or "
+                                          "test_one_launch_solve"),
+                     ("CNF_STEP_FP32", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve or "
                                        "test_jvp_mode_headline_shape_step_kernel or ragged"),
                      ("CNF_STEP_V1", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve"),
                      ("CNF_TRACE_GENERIC", "test_exact_trace_mfma_deep_networks"),
                      ("CNF_ADJ_GENERIC", "test_loss_grad_fixed_dt_matches_oracle and 3-mfma or test_loss_grad_headline")):
-        env = dict(os.environ, **{var: "1", "CNF_NO_PARITY_REPORT": "1"})
+        name, _, val = var.partition("=")
+        env = dict(os.environ, **{name: val or "1", "CNF_NO_PARITY_REPORT": "1"})
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x",
                             "-m", "gpu", "-p", "no:cacheprovider", "-k", sel], env=env, cwd=root, capture_output=True,
                            text=True, timeout=900)
         assert r.returncode == 0, (var, r.stdout[-2000:], r.stderr[-1000:])
         assert " passed" in r.stdout and "failed" not in r.stdout, (var, r.stdout[-500:])
+
+
+def test_one_launch_solve_takes_the_headline_shape_and_agrees_with_the_streamed_launches():
+    """k_solve3b: the adaptive solve of the headline shape (VJP, |eps^T J| row, at most one 32-column tile per CU) is ONE
+    cooperative launch; larger batches stream step launches.  Same arithmetic, separately compiled: agreement to the
+    solver tolerance, identical step counts on this well-conditioned case; fixed steps, ragged tiles, backward time and
+    maxiters go through the same launch."""
+    cfg, _, _ = O.baseline_cfg(3)
+    rng = np.random.default_rng(77)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    persistent = os.environ.get("CNF_PERSISTENT") != "0" and os.environ.get("CNF_STEP_FP32") != "1" \
+        and os.environ.get("CNF_STEP_V1") != "1"
+    res = {}
+    for B in (8192, 1000, 8224):
+        xs, eps = _dev(rng.standard_normal((cfg.nvars, B))), _dev(rng.standard_normal((cfg.n_in, B)))
+        for name, kw in (("adaptive", dict(reltol=3.45e-4, abstol=1.19e-7)), ("fixed", dict(adaptive=False, dt=1 / 8))):
+            ic = make_icnf(cnf, cfg, sol_kwargs=kw)
+            logpx, regs = cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+            stt = ic.last_stats
+            one = persistent and B <= 8192
+            assert (stt["launches"] <= 3) == one, (B, name, stt)
+            assert stt["nf"] == (2 if name == "adaptive" else 1) + 6 * (stt["naccept"] + stt["nreject"])
+            # the columns do not interact: a sub-batch through the other driver gives the same columns (to the tolerance
+            # of the solve when the step sequences differ: the error norm is over the batch)
+            sub = slice(0, 512)
+            lp2, _ = cnf.inference(make_icnf(cnf, cfg, sol_kwargs=kw), cnf.TrainMode(), xs[:, sub].contiguous(), flat, {},
+                                   eps=eps[:, sub].contiguous())
+            tol = 2e-3 if name == "adaptive" else 2e-5
+            assert torch.allclose(logpx[sub], lp2, rtol=tol, atol=tol), (B, name, float((logpx[sub] - lp2).abs().max()))
+            res[(B, name)] = logpx
+    # maxiters inside the launch
+    ic = make_icnf(cnf, cfg, sol_kwargs=dict(reltol=3.45e-4, abstol=1.19e-7, maxiters=3))
+    xs, eps = _dev(rng.standard_normal((cfg.nvars, 256))), _dev(rng.standard_normal((cfg.n_in, 256)))
+    with pytest.raises(_lib.CNFError):
+        cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    # and the handle still works afterwards
+    ic2 = make_icnf(cnf, cfg, sol_kwargs=dict(reltol=3.45e-4, abstol=1.19e-7))
+    lp, _ = cnf.inference(ic2, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    assert torch.isfinite(lp).all()
 
 
 def test_loss_grad_larger_batches_and_backward_time():

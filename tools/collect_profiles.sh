@@ -1,8 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (inside gpurun): rocprofv3 summaries for profiles/.
 #  1. kernel trace + stats of the default bench command
-#  2. counters of the fused step kernel in separate --pmc passes (each with --kernel-trace only: FETCH_SIZE and WRITE_SIZE
-#     cannot share a pass), on tools/prof_rhs.py (fixed-dt solve = step launches only)
+#  2. counters of the headline kernel in separate --pmc passes (each with --kernel-trace only: FETCH_SIZE and WRITE_SIZE
+#     cannot share a pass), on tools/prof_rhs.py bench (the adaptive solves bench.py times: with the one-launch solve
+#     k_solve3b a launch IS such a solve; CNF_PERSISTENT=0: the step launches of the streamed solve)
 #  3. kernel split of the gradient path
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -12,13 +13,13 @@ OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
 echo "bench rc=$?"
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/prof_rhs.py step 16 > $OUT/pmc_fetch.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/prof_rhs.py bench 16 > $OUT/pmc_fetch.log 2>&1
 echo "fetch rc=$?"
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/prof_rhs.py step 16 > $OUT/pmc_write.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/prof_rhs.py bench 16 > $OUT/pmc_write.log 2>&1
 echo "write rc=$?"
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_sq -- python3 tools/prof_rhs.py step 16 > $OUT/pmc_sq.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_sq -- python3 tools/prof_rhs.py bench 16 > $OUT/pmc_sq.log 2>&1
 echo "sq rc=$?"
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_wait -- python3 tools/prof_rhs.py step 16 > $OUT/pmc_wait.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_wait -- python3 tools/prof_rhs.py bench 16 > $OUT/pmc_wait.log 2>&1
 echo "wait rc=$?"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/grad -- python3 tools/prof_grad.py 3 8192 3 > $OUT/grad.log 2>&1
 echo "grad rc=$?"

@@ -1,6 +1,6 @@
 """Profiling driver: runs N plain RHS launches and/or N fused Tsit5 steps on BASELINE cfg3
 (B = 8192) so that rocprofv3 sees only the kernels of interest.
-usage: python3 tools/prof_rhs.py [rhs|step] [n] [kernel]"""
+usage: python3 tools/prof_rhs.py [rhs|step|adaptive|bench] [n] [kernel]"""
 import ctypes as C
 import os
 import sys
@@ -45,6 +45,27 @@ if what == "rhs":
         _lib.check(l.cnf_rhs(h, 1, k, u.data_ptr(), eps.data_ptr(), du.data_ptr(), B, sp), h)
     e1.record(); e1.synchronize()
     print(f"rhs: {e0.elapsed_time(e1) * 1e3 / n:.2f} us per launch")
+elif what == "bench":
+    # the launches bench.py times: adaptive solves of ITS inputs (seeds of SURVEY 8d-inputs) at the README tolerances
+    wl = cfg
+    flat_b = configs.glorot_params(wl.dims, 12345)
+    xs_h, eps_h = configs.synthetic_inputs(wl, B, 1)
+    icnf.set_params(flat_b)
+    ub = torch.zeros(B * D, device=dev)
+    ub.view(B, D)[:, :wl.nvars] = torch.from_numpy(np.ascontiguousarray(xs_h.T)).to(dev)
+    eb = torch.from_numpy(np.ascontiguousarray(eps_h.T)).to(dev).contiguous()
+    tol = configs.README_TOLERANCES
+    opts = _lib.cnf_solve_opts(0.0, 1.0, tol["abstol"], tol["reltol"], 0.0, 1, 1 << 20, k)
+    stats = _lib.cnf_solve_stats()
+    run = lambda: _lib.check(l.cnf_solve_tsit5(h, 1, ub.data_ptr(), eb.data_ptr(), du.data_ptr(), B,
+                                               C.byref(opts), C.byref(stats), sp), h)
+    run(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        run()
+    e1.record(); e1.synchronize()
+    print(f"bench solve: {e0.elapsed_time(e1) * 1e3 / n:.1f} us per solve, nf={stats.nf} naccept={stats.naccept} "
+          f"nreject={stats.nreject} launches={stats.launches}")
 elif what == "adaptive":
     import time
     opts = _lib.cnf_solve_opts(0.0, 1.0, 1.1920929e-7, 3.4526698e-4, 0.0, 1, 1 << 20, k)

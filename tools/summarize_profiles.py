@@ -23,7 +23,16 @@ FULL_US = 30.0                        # anything shorter did not do a full step:
                                       # single-evaluation launches of the automatic initial dt 19 us, a step 50 us
 
 
+SOLVE = "k_solve3b("                  # the one-launch solve: when it ran, IT is the headline kernel (a launch = a whole solve)
+
+
 def is_step(kname):
+    if HAVE_SOLVE:
+        return kname.startswith(SOLVE)
+    return is_step_launch(kname)
+
+
+def is_step_launch(kname):
     # k_step3(...) or the STEP = true instantiation k_mfma<Layout, true>(...) -- not the plain RHS kernel k_mfma<Layout, false>
     # (k_step3j is the JVP / FFJORD step kernel: not the kernel the headline bench runs)
     return kname.startswith(("k_step3(", "k_step3b(")) or "k_step3<" in kname or ("k_mfma<" in kname and ", true>(" in kname)
@@ -41,6 +50,12 @@ def commit():
         return "?"
 
 
+HAVE_SOLVE = False
+_tr0 = None
+for _g in glob.glob(os.path.join(SRC, "bench/**/*kernel_trace.csv"), recursive=True):
+    _tr0 = _g if _tr0 is None or os.path.getmtime(_g) > os.path.getmtime(_tr0) else _tr0
+if _tr0:
+    HAVE_SOLVE = any(r["Kernel_Name"].startswith(SOLVE) for r in csv.DictReader(open(_tr0)))
 st = first("bench/**/*kernel_stats.csv")
 if st:
     rows = list(csv.DictReader(open(st)))
@@ -59,11 +74,16 @@ if st:
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(tr)) if is_step(r["Kernel_Name"])]
     full = [x for x in d if x > FULL_US]
     with open(os.path.join(DST, f"{name}_step_kernel_durations.txt"), "w") as f:
-        f.write(f"fused step kernel launches: {len(d)}; doing a full step: {len(full)}; "
-                f"others (early exits of launches queued past the end, single-evaluation launches of the automatic "
-                f"initial dt): {len(d) - len(full)}\n")
-        if full:
-            f.write(f"full-step launches: mean {sum(full) / len(full):.2f} us, min {min(full):.2f}, max {max(full):.2f}\n")
+        if HAVE_SOLVE:
+            f.write(f"k_solve3b launches (one adaptive solve of the bench workload each): {len(d)}\n")
+            if d:
+                f.write(f"per launch: mean {sum(d) / len(d):.2f} us, min {min(d):.2f}, max {max(d):.2f}\n")
+        else:
+            f.write(f"fused step kernel launches: {len(d)}; doing a full step: {len(full)}; "
+                    f"others (early exits of launches queued past the end, single-evaluation launches of the automatic "
+                    f"initial dt): {len(d) - len(full)}\n")
+            if full:
+                f.write(f"full-step launches: mean {sum(full) / len(full):.2f} us, min {min(full):.2f}, max {max(full):.2f}\n")
 
 
 def pmc(dirname):
@@ -89,7 +109,9 @@ def pmc(dirname):
     return {k: sum(v) / len(v) for k, v in agg.items()}, len(seen), len(kept)
 
 
-out = {"kernel": "k_step3b (fused Tsit5 step of the headline shape on six-term bf16 products, B = 8192)", "commit": commit(), "per_launch": {}, "launches": {}}
+out = {"kernel": ("k_solve3b (one adaptive Tsit5 solve of the bench workload per launch, six-term bf16 products, B = 8192)" if HAVE_SOLVE else
+                  "k_step3b (fused Tsit5 step of the headline shape on six-term bf16 products, B = 8192)"),
+       "commit": commit(), "per_launch": {}, "launches": {}}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_wait"):
     vals, n, k = pmc(d)
     out["per_launch"].update(vals)
