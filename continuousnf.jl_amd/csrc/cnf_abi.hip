@@ -185,8 +185,9 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     hipError_t e = hipSetDevice(h->device);
     if (e == hipSuccess) e = hipMalloc(&h->d_params, h->n_params * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&h->d_state, 2 * sizeof(StepState));
-    if (e == hipSuccess) e = hipMalloc(&h->partials, 4 * MAX_PARTIALS * sizeof(float));      // (the one-launch solve: 2 x 1024 8-byte words)
-    if (e == hipSuccess) e = hipMemset(h->partials, 0, 4 * MAX_PARTIALS * sizeof(float));
+    // (the one-launch solve uses it as 8-byte words: 2 x 1024 of the meetings, 2048 of the loss-sum partials)
+    if (e == hipSuccess) e = hipMalloc(&h->partials, 8 * MAX_PARTIALS * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->partials, 0, 8 * MAX_PARTIALS * sizeof(float));
     if (e == hipSuccess) e = hipHostMalloc(&h->h_state, 3 * sizeof(StepState), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(&h->d_sums, 24 * sizeof(float));      // 8 floats of sums, tickets, the kernel clock words
     if (e == hipSuccess) e = hipMemset(h->d_sums, 0, 24 * sizeof(float));      // words 8.. are device tickets: zero between launches
@@ -685,24 +686,25 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         float hh = init->dt < rem ? init->dt : rem;
         init->h = init->tdir * hh;
     }
-    if (post && post->xs) launch_build_u0(post->xs, h->U[0], h->nd.nvars, D, B, st, h->d_state, init);   // (u0 == h->U[0])
-    else launch_set_state(h->d_state, *init, st);
-    if (u0 != h->U[0]) HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-
     const bool hairer = opts->adaptive && opts->dt == 0.f;
     // The whole solve in one cooperative launch where the handle and the batch allow it (k_solve3b): the weights and the
     // Runge-Kutta rows stay on the CUs for all attempts, the workgroups exchange two floats per attempt.
     if (use_mfma && !rec && !lockstep) {
         const unsigned base = h->mirror_base;
-        s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror, base, h->partials,
-                                  reinterpret_cast<unsigned*>(h->d_sums + 10), h->persist_base,
-                                  reinterpret_cast<int*>(h->d_sums + 11), (int)opts->maxiters, hairer,
-                                  h->time_kernel ? reinterpret_cast<unsigned long long*>(h->d_sums + 12) : nullptr);
+        Solve3Args sv{};
+        sv.part = h->partials; sv.base = h->persist_base; sv.abort_flag = reinterpret_cast<int*>(h->d_sums + 11);
+        sv.t_out = h->time_kernel ? reinterpret_cast<unsigned long long*>(h->d_sums + 12) : nullptr;
+        sv.maxiters = (int)opts->maxiters; sv.hairer = hairer ? 1 : 0; sv.init = *init;
+        const bool fused_io = post && post->xs;            // inference: u0 from the data columns and the post-processing in the launch
+        if (fused_io) { sv.xs = post->xs; sv.logpx = post->logpx; sv.regs = post->regs; sv.sums5 = post->sums5; }
+        else if (u0 != h->U[0]) HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror, base, sv);
         if (s == CNF_OK) {
             ++launches;
             h->mirror_base = base + 1;
             h->last_state = h->d_state;
-            if (post) { enqueue_post(h, train, h->d_state, *post, B, false, st); ++launches; post->launched = true; }
+            if (fused_io) post->launched = true;
+            else if (post) { enqueue_post(h, train, h->d_state, *post, B, false, st); ++launches; post->launched = true; }
             if (u_out) { launch_copy_final(h->d_state, h->U[0], h->U[1], u_out, n, st); ++launches; }
             HIPCHK(h, hipGetLastError());
             // the final state arrives through the host mirror, as in the streamed solve
@@ -721,7 +723,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                 }
             }
             const int attempts = fin.naccept + fin.nreject;
-            h->persist_base += (unsigned)((hairer ? 2 : 0) + attempts);
+            h->persist_base += (unsigned)((hairer ? 2 : 0) + attempts + (fused_io && post->sums5 ? 1 : 0));
             if (final_sync) HIPCHK(h, hipStreamSynchronize(st));
             if (stats) {
                 stats->nf = (hairer ? 2 : 1) + 6 * attempts;
@@ -739,7 +741,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                 int aborted = 0;
                 HIPCHK(h, hipMemcpy(&aborted, h->d_sums + 11, sizeof(int), hipMemcpyDeviceToHost));
                 HIPCHK(h, hipMemset(h->d_sums + 10, 0, 2 * sizeof(float)));
-                HIPCHK(h, hipMemset(h->partials, 0, 4 * MAX_PARTIALS * sizeof(float)));      // (stale meeting indices)
+                HIPCHK(h, hipMemset(h->partials, 0, 8 * MAX_PARTIALS * sizeof(float)));      // (stale meeting indices)
                 h->persist_base = 0;
                 return aborted ? fail(h, CNF_ERR_HIP, "one-launch solve: a workgroup did not arrive (set CNF_PERSISTENT=0)")
                                : fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
@@ -748,6 +750,10 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         }
         if (s != CNF_ERR_UNSUPPORTED) return fail(h, s, "one-launch solve failed to start");
     }
+    if (post && post->xs) launch_build_u0(post->xs, h->U[0], h->nd.nvars, D, B, st, h->d_state, init);   // (u0 == h->U[0])
+    else launch_set_state(h->d_state, *init, st);
+    if (u0 != h->U[0]) HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+
     // k1 = f(u0).  With the automatic initial dt on the fused path, the two norms and their controller phases
     // ride in the RHS launches themselves (the last workgroup to finish runs the phase): 2 launches, not 4.
     unsigned* ticket = reinterpret_cast<unsigned*>(h->d_sums + 8);

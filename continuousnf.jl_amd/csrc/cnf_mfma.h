@@ -71,12 +71,28 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
                      bool finalize, int B, hipStream_t s, float* dump = nullptr,
                      size_t dump_stride = 0, void* mirror = nullptr,
                      unsigned seq = 0, size_t dump_step_stride = 0, int dump_cap = 0, float* hs_out = nullptr);
+// arguments of the one-launch solve (k_solve3b, cnf_step3.hip) beyond those of a step launch
+struct Solve3Args {
+    float* part;          // error partials: two buffers (meeting index parity) of 2 x 512 words {meeting index, float}
+    unsigned* counter;    // (unused)
+    unsigned base;        // meetings held by earlier launches on this buffer: the indices go on from there
+    int* abort_flag;      // set when a wait ran out
+    unsigned long long* t_out;   // null, or {entry stamp, sum of durations, launches}: workgroup 0's 100 MHz real-time clock
+    int maxiters;
+    int hairer;           // automatic initial dt: the norms of f(u0), a second evaluation and its norm first
+    StepState init;       // the integrator's initial state (by value: no launch, no copy in front of this one)
+    // inference in the same launch (all null / 0: a bare solve from the columns in a.U[0]):
+    const float* xs;      // the data columns [B][nvars]: u0 = (xs, 0) is assembled here       (src/base_icnf.jl:266-286)
+    float* logpx;         // post-processing of the final state                               (src/base_icnf.jl:173-187)
+    float* regs;
+    float* sums5;         // and the five loss sums                                           (src/icnf.jl:489)
+    int nvars, naugs, norm_z_aug;
+};
 // the whole solve in one cooperative launch (headline shape, VJP with the |eps^T J| row, B <= 32 x CUs); CNF_ERR_UNSUPPORTED
-// otherwise.  `st`: the initial state in, the final state out (cur = 0: the final columns are in U[0]); part: 2 x 1024
-// floats; counter / base: ticket word (never reset) and its value at launch; abort_flag: set by the kernel when a wait ran out
-cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st, float* const U[2],
-                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, float* part,
-                                 unsigned* counter, unsigned base, int* abort_flag, int maxiters, bool hairer,
-                                 unsigned long long* t_out = nullptr);
+// otherwise.  sv (cnf_step3.h): the initial state by value, the meeting buffer and its index base, optionally the data
+// columns to assemble u0 from and the outputs of the post-processing; st_out: the final state (cur = 0: the final columns
+// are in U[0])
+cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st_out, float* const U[2],
+                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv);
 // workgroups (= error partials) of a step launch; `recording`: the solve files its stage states (gradient path)
 int mfma_grid_for(const MfmaPlan& p, int B, bool recording = false, bool train = true);

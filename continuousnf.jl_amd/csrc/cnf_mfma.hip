@@ -1557,10 +1557,8 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, con
 // The whole solve of the headline shape in one cooperative launch (k_solve3b, cnf_step3.hip): VJP handles with the
 // |eps^T J| row whose batch is at most one 32-column tile per CU.  CNF_ERR_UNSUPPORTED: not this handle / batch, or the
 // device cannot place the grid right now -- the caller streams step launches instead.  CNF_PERSISTENT=0 switches it off.
-cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st, float* const U[2],
-                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, float* part,
-                                 unsigned* counter, unsigned base, int* abort_flag, int maxiters, bool hairer,
-                                 unsigned long long* t_out) {
+cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st_out, float* const U[2],
+                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv) {
     static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); return e && e[0] == '0'; }();
     static const bool fp32_only = [] { const char* e = getenv("CNF_STEP_FP32"); return e && e[0] == '1'; }();
     static const int n_cu = [] {
@@ -1574,12 +1572,12 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     if (ntile < 1 || ntile > n_cu || ntile > 512) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
     a.init_phase = -1;
-    a.mode = 2; a.B = B; a.eps = eps; a.st = st; a.st_out = st;
+    a.mode = 2; a.B = B; a.eps = eps; a.st = st_out; a.st_out = st_out;
     a.n_total = (float)((size_t)(nd.n_in + 3) * B);
     a.U[0] = U[0]; a.U[1] = U[1];
     a.mirror = mirror; a.seq = seq;
-    return step3b_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, ntile, s, part, counter, base, abort_flag,
-                               maxiters, hairer, t_out);
+    sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
+    return step3b_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, ntile, s, sv);
 }
 
 cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st_in,

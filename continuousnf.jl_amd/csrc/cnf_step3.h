@@ -20,6 +20,6 @@ void step3jb_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z,
 // k_step3b: the VJP step kernel (k_step3) on six-term bf16 products
 void step3b_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single = 0);
 // the whole solve of one shard in ONE cooperative launch (k_solve3b): grid = tiles of 32 columns, all resident
+// (Solve3Args: cnf_mfma.h)
 cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, int grid, hipStream_t s,
-                               float* part, unsigned* counter, unsigned base, int* abort_flag, int maxiters, bool hairer,
-                               unsigned long long* t_out = nullptr);
+                               const Solve3Args& sv);

@@ -2034,15 +2034,6 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 // workgroup per CU: B <= 32 x CUs, cooperative launch); every wait is bounded, so a lost workgroup ends the launch with
 // an error word instead of hanging it.  Results are bit-identical to the streamed solve (same sums, same order).
 // ---------------------------------------------------------------------------------------------------------------
-struct Solve3Args {
-    float* part;          // error partials: two buffers (meeting index parity) of 2 x 512 words {meeting index, float}
-    unsigned* counter;    // (unused)
-    unsigned base;        // meetings held by earlier launches on this buffer: the indices go on from there
-    int* abort_flag;      // set when a wait ran out
-    unsigned long long* t_out;   // null, or {entry stamp, sum of durations, launches}: workgroup 0's 100 MHz real-time clock
-    int maxiters;
-    int hairer;           // automatic initial dt: the norms of f(u0), a second evaluation and its norm first
-};
 __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __restrict__ imgb, int n_in, int norm_z,
                                                     int norm_j, const S3Tab tab, Solve3Args sv) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2065,8 +2056,16 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     if (sv.t_out && blockIdx.x == 0 && tid == 0) sv.t_out[0] = __builtin_amdgcn_s_memrealtime();
     // ---- one round trip: this tile's state and probe rows, the weights ----
     const f32x4 re = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
-    const f32x4 ru = ld4_issue_w(a.U[0] + gcol + r0, cu, img3, wide);
-    const f32x4 rs = ld3_issue(a.U[0] + gcol + n_in, cs, img3);
+    f32x4 ru, rs;
+    if (sv.xs) {                                           // u0 = (xs; zeros for the augmented and the scalar rows)
+        const float* xc = sv.xs + (size_t)(b0 + s) * sv.nvars;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ru[j] = (cu > j && r0 + j < sv.nvars) ? xc[r0 + j] : 0.f;
+        rs = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        ru = ld4_issue_w(a.U[0] + gcol + r0, cu, img3, wide);
+        rs = ld3_issue(a.U[0] + gcol + n_in, cs, img3);
+    }
     constexpr int NCI = 2 * s3v::WI / 16, NCB = (2 * 128 + 32) / 4;
     typedef __attribute__((address_space(3))) char* lds_c;
     typedef const __attribute__((address_space(1))) char* glb_c;
@@ -2109,7 +2108,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     float* msc = lds + s3v::MISC;
     StepState* ns = reinterpret_cast<StepState*>(msc + 44);            // the integrator state (thread 0 runs the controller on it)
     static_assert(sizeof(StepState) <= 20 * sizeof(float), "fits the scratch words");
-    if (tid == 0) *ns = *a.st;
+    if (tid == 0) *ns = sv.init;
     if (tid < NCB) reinterpret_cast<f32x4*>(lds + s3v::BIAS)[tid] = sgb;
     const int single = 0;                                              // (the evaluation code is k_step3b's)
     (void)single;
@@ -2442,6 +2441,67 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     // ---- the final state to the integrator's buffer set 0 ----
     if (live && zown) { if (nv >= 4) st4_wide(a.U[0] + gcol + r0, *(const f32x4*)rkw); else st4(a.U[0] + gcol + r0, *(const f32x4*)rkw, nv); }
     if (live && sown) { const f32x4 us = sc_get(0); float* o = a.U[0] + gcol + n_in; o[0] = us.x; o[1] = us.y; o[2] = us.z; }
+    if (sv.logpx && alive) {
+        // ---- post-processing of this tile: logp(z) - dlogp, the regulariser rows; then the loss sums of the batch ----
+        if (zown) {
+            const f32x4 u4 = *(const f32x4*)rkw;
+            float ss = 0.f, sa = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < nv) { ss = fmaf(u4[c], u4[c], ss); if (r0 + c >= sv.nvars) sa = fmaf(u4[c], u4[c], sa); }
+            redw[0] = ss; redw[32 * 8] = sa;
+        }
+        s3_bar();
+        float v4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live && sown) {
+            const float ss = red8(0), sa = red8(1);
+            const f32x4 us = sc_get(0);
+            const float log2pi = 1.8378770664093453f;
+            v4[0] = -0.5f * fmaf((float)n_in, log2pi, ss) - us.x;         // base_icnf.jl:177-178
+            v4[1] = us.y; v4[2] = us.z;
+            v4[3] = (sv.norm_z_aug && sv.naugs > 0) ? sqrtf(sa) : 0.f;    // :179-187
+            const size_t b = (size_t)(b0 + s), Bz = (size_t)a.B;
+            sv.logpx[b] = v4[0]; sv.regs[b] = v4[1]; sv.regs[Bz + b] = v4[2]; sv.regs[2 * Bz + b] = v4[3];
+        }
+        if (sv.sums5) {
+            // workgroup partials (waves 4 and 6 hold them) -> tagged words, one more meeting index; workgroup 0 adds them in
+            // workgroup order
+            unsigned long long* qb = reinterpret_cast<unsigned long long*>(sv.part) + 2048;
+            const unsigned tag = sv.base + (unsigned)nsync + 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v4[j] = s3_wave_sum(v4[j]);
+            s3_bar();                                      // (red8 above read RED; msc below)
+            if (lane == 0 && (wave == 4 || wave == 6)) for (int j = 0; j < 4; ++j) msc[(wave == 4 ? 0 : 8) + j] = v4[j];
+            s3_bar();
+            if (tid < 4)
+                __hip_atomic_store(qb + 4 * blockIdx.x + tid, ((unsigned long long)tag << 32) | __float_as_uint(msc[tid] + msc[8 + tid]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0) {
+                float c4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (tid < (int)gridDim.x) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        for (int spin = 0; spin < (1 << 21); ++spin) {
+                            const unsigned long long w = __hip_atomic_load(qb + 4 * tid + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((unsigned)(w >> 32) == tag) { c4[j] = __uint_as_float((unsigned)w); break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c4[j] = s3_wave_sum(c4[j]);
+                s3_bar();
+                if (lane == 0) for (int j = 0; j < 4; ++j) msc[4 * wave + j] = c4[j];
+                s3_bar();
+                if (tid < 4) {
+                    float r = 0.f;
+                    for (int w = 0; w < 8; ++w) r += msc[4 * w + tid];
+                    sv.sums5[tid] = r;
+                }
+                if (tid == 0) sv.sums5[4] = (float)a.B;
+            }
+        }
+    }
     if (blockIdx.x == 0 && tid == 0) {
         ns->cur = 0;
         *a.st_out = *ns;
@@ -2500,8 +2560,7 @@ void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStre
     hipLaunchKernelGGL(k_pack_step3b, dim3((NT + 255) / 256), dim3(256), 0, s, nd, d_params, (char*)d_imgb);
 }
 cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, int grid, hipStream_t s,
-                               float* part, unsigned* counter, unsigned base, int* abort_flag, int maxiters, bool hairer,
-                               unsigned long long* t_out) {
+                               const Solve3Args& sv_) {
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)k_solve3b, hipFuncAttributeMaxDynamicSharedMemorySize, s3v::TOTAL_BYTES) != hipSuccess)
@@ -2511,7 +2570,7 @@ cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, 
     MfmaArgs a_ = a;
     const char* img = (const char*)d_imgb;
     S3Tab tab = kS3Tab;
-    Solve3Args sv{part, counter, base, abort_flag, t_out, maxiters, hairer ? 1 : 0};
+    Solve3Args sv = sv_;
     void* args[] = {&a_, &img, &n_in, &norm_z, &norm_j, &tab, &sv};
     // every workgroup must be resident for the whole launch: the cooperative launch refuses what it cannot place (and the
     // runtime keeps cooperative kernels of one process apart).  CNF_PERSISTENT=2: a plain launch -- no such guarantee, only
