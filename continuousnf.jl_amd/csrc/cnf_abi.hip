@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -690,6 +691,9 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     // The whole solve in one cooperative launch where the handle and the batch allow it (k_solve3b): the weights and the
     // Runge-Kutta rows stay on the CUs for all attempts, the workgroups exchange two floats per attempt.
     if (use_mfma && !rec && !lockstep) {
+        // one such kernel at a time in this process: two of them would each hold CUs the other is waiting for
+        static std::mutex persist_mu;
+        std::unique_lock<std::mutex> persist_lock(persist_mu);
         const unsigned base = h->mirror_base;
         Solve3Args sv{};
         sv.part = h->partials; sv.base = h->persist_base; sv.abort_flag = reinterpret_cast<int*>(h->d_sums + 11);
@@ -749,6 +753,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             return CNF_OK;
         }
         if (s != CNF_ERR_UNSUPPORTED) return fail(h, s, "one-launch solve failed to start");
+        persist_lock.unlock();
     }
     if (post && post->xs) launch_build_u0(post->xs, h->U[0], h->nd.nvars, D, B, st, h->d_state, init);   // (u0 == h->U[0])
     else launch_set_state(h->d_state, *init, st);

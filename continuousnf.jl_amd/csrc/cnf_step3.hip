@@ -2572,12 +2572,14 @@ cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, 
     S3Tab tab = kS3Tab;
     Solve3Args sv = sv_;
     void* args[] = {&a_, &img, &n_in, &norm_z, &norm_j, &tab, &sv};
-    // every workgroup must be resident for the whole launch: the cooperative launch refuses what it cannot place (and the
-    // runtime keeps cooperative kernels of one process apart).  CNF_PERSISTENT=2: a plain launch -- no such guarantee, only
-    // the bounded waits inside the kernel; for measurements on a GPU that runs nothing else.
-    static const bool plain = [] { const char* e = getenv("CNF_PERSISTENT"); return e && e[0] == '2'; }();
+    // Every workgroup must be resident for the whole launch.  The grid is at most one workgroup per CU (the caller checks)
+    // and 157 KB of LDS keep a second one off a CU, so an ordinary launch places all of them as soon as the CUs are free;
+    // the caller keeps the one-launch solves of this process apart (a mutex), and every wait inside the kernel is
+    // bounded.  CNF_PERSISTENT=2 goes through hipLaunchCooperativeKernel instead: the same placement, checked by the
+    // runtime, at 10-15 us more per launch (its barrier packets around the kernel).
+    static const bool coop = [] { const char* e = getenv("CNF_PERSISTENT"); return e && e[0] == '2'; }();
     hipError_t e;
-    if (plain) e = hipLaunchKernel((const void*)k_solve3b, dim3(grid), dim3(512), args, s3v::TOTAL_BYTES, s);
+    if (!coop) e = hipLaunchKernel((const void*)k_solve3b, dim3(grid), dim3(512), args, s3v::TOTAL_BYTES, s);
     else e = hipLaunchCooperativeKernel((const void*)k_solve3b, dim3(grid), dim3(512), args, s3v::TOTAL_BYTES, s);
     if (e != hipSuccess) { (void)hipGetLastError(); return CNF_ERR_UNSUPPORTED; }
     return CNF_OK;
