@@ -1109,7 +1109,7 @@ constexpr int BIASB = 0;                                   // b1 (128), b2 (128)
 constexpr int F32 = (2 * 128 + 32) * 4;                    // [wave 8][W1 | W2 x4 | W3^T | W2^T x4], then W3: [tile 2][k-block 4]
 constexpr int NFR = 8 * 10 + 2 * 4;
 constexpr int W3I = F32 + NFR * 2048;                      // k_step3b's LDS images (three bf16 pieces, LDS layout): W3 rows, W1^T rows
-constexpr int WI = 3 * 32 * 272;
+constexpr int WI = 3 * 32 * 256;
 constexpr int IMG_BYTES = W3I + 2 * WI;
 static_assert(F32 % 16 == 0 && W3I % 16 == 0, "16-byte loads");
 }  // namespace s3g
@@ -1553,8 +1553,13 @@ namespace s3v {
 constexpr int SKZ = 264;
 constexpr int KZ = 0, RED = KZ + 32 * SKZ, SC = RED + 3 * 32 * 8, BIAS = SC + 32 * 24;
 constexpr int MISC = BIAS + 2 * 128 + 32, FP_END = MISC + 64;
-constexpr int WS = 272, WP = 32 * WS, WI = 3 * WP;        // split image [piece][32 rows][128 bf16 + 8]: 17 x 16 B per row
-constexpr int NS = 80, NP = 32 * NS, NI = 3 * NP;         // K = 32 images (state, g3): [piece][32 rows][32 bf16 + 8]
+// Split images [piece][32 rows][K bf16], rows WITHOUT padding, the 16-byte chunks of a row XOR-swizzled by the row: chunk c
+// of row r sits at chunk position c ^ (r & 15) (K = 128: 16 chunks) / c ^ ((-(r >> 2)) & 3) (K = 32: 4 chunks).  An operand
+// read (lane (q, s): chunk q + 4 kb of row s, ds_read_b128) then has no bank conflict in any of the instruction's four
+// 16-lane groups; padded rows cannot do that together with 16-byte alignment (272-byte rows: two-way, i.e. the LDS pipe as
+// busy as the matrix pipe in the wide products).  The 8-byte epilogue stores stay two-way.
+constexpr int WS = 256, WP = 32 * WS, WI = 3 * WP;
+constexpr int NS = 64, NP = 32 * NS, NI = 3 * NP;
 constexpr int H1G = FP_END * 4, H2G = H1G + WI, W3I = H2G + WI, W1TI = W3I + WI, X0S = W1TI + WI, G3S = X0S + NI;
 constexpr int TOTAL_BYTES = G3S + NI;
 static_assert(H1G % 16 == 0 && TOTAL_BYTES <= 160 * 1024, "LDS plan");
@@ -1743,14 +1748,18 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
     float* redw = lds + s3v::RED + smp * 8 + 4 * t + q;                 // this lane's slot of kind 0 (+ 256 per kind)
     // B operands from a split image: lane (sample s of half A, k = 8q ..); half B = 16 rows on.  Results: lane (sample s,
     // rows 16 wave + 4q ..) of the wide images
-    const int wb_rd = s * s3v::WS + 16 * q, wb_wr = s * s3v::WS + 2 * (16 * wave + 4 * q);
+    // (swizzled rows: k-block kb of a row is reached by XOR 64 kb on the byte offset, not by adding to it)
+    const int wb_rd = s * s3v::WS + 16 * (q ^ s);
+    const int wb_wr = s * s3v::WS + 16 * ((2 * wave + (q >> 1)) ^ s) + 8 * (q & 1);
     constexpr int HBW = 16 * s3v::WS;
     // narrow products: A = rows 16t + s of W3 (waves 0-3) / of W1^T (waves 4-7), B = this wave's half of h2 / g1
-    const char* nrA = ldsb + (zown ? s3v::W3I : s3v::W1TI) + (16 * t + s) * s3v::WS + 16 * q;
-    const char* nrB = ldsb + (zown ? s3v::H2G : s3v::H1G) + smp * s3v::WS + 16 * q;
-    char* x0w = ldsb + s3v::X0S + smp * s3v::NS + 2 * r0;               // this lane's 4 rows of the state / g3 images
-    char* g3w = ldsb + s3v::G3S + smp * s3v::NS + 2 * r0;
-    const int nb_rd = s * s3v::NS + 16 * q;                             // their B operands: lane (sample s of half A, k = 8q ..)
+    const char* nrA = ldsb + (zown ? s3v::W3I : s3v::W1TI) + 16 * t * s3v::WS;      // + (wb_rd ^ 64 kb): row 16t + s
+    const char* nrB = ldsb + (zown ? s3v::H2G : s3v::H1G) + 16 * hf * s3v::WS;      // + (wb_rd ^ 64 kb): row smp
+    const int nsw = (-(s >> 2)) & 3;                                    // chunk swizzle of the K = 32 images (rows s, 16 + s)
+    const int nw = smp * s3v::NS + 16 * ((2 * t + (q >> 1)) ^ nsw) + 8 * (q & 1);
+    char* x0w = ldsb + s3v::X0S + nw;                                   // this lane's 4 rows of the state / g3 images
+    char* g3w = ldsb + s3v::G3S + nw;
+    const int nb_rd = s * s3v::NS + 16 * (q ^ nsw);                     // their B operands: lane (sample s of half A, k = 8q ..)
     constexpr int HBN = 16 * s3v::NS;
     // Runge-Kutta state of the z rows r0..r0+3 of sample smp, written and read by this lane only:
     float* rkw = lds + s3v::KZ + smp * s3v::SKZ + r0;                   // u at rkw, k1 at rkw + 32,
@@ -1815,8 +1824,8 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
                     S3bOp b[2];
-                    b[0] = s3b_load(ldsb + s3v::H1G + wb_rd + 64 * kb, s3v::WP);
-                    b[1] = s3b_load(ldsb + s3v::H1G + wb_rd + HBW + 64 * kb, s3v::WP);
+                    b[0] = s3b_load(ldsb + s3v::H1G + (wb_rd ^ (64 * kb)), s3v::WP);
+                    b[1] = s3b_load(ldsb + s3v::H1G + HBW + (wb_rd ^ (64 * kb)), s3v::WP);
                     S3_SB();
                     s3b_mm<2>(acc, wF2[kb], b);
                     S3_SB();
@@ -1835,7 +1844,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
                 f32x4 z0 = zero4, z1 = zero4;                                  // two chains (terms 0-2 / 3-5)
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
-                    const S3bOp av = s3b_load(nrA + 64 * kb, s3v::WP), bvv = s3b_load(nrB + 64 * kb, s3v::WP);
+                    const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), s3v::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), s3v::WP);
                     S3_SB();
                     z0 = s3b_term<0>(av, bvv, z0); z1 = s3b_term<3>(av, bvv, z1);
                     z0 = s3b_term<1>(av, bvv, z0); z1 = s3b_term<4>(av, bvv, z1);
@@ -1877,8 +1886,8 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
                     S3bOp b[2];
-                    b[0] = s3b_load(ldsb + s3v::H2G + wb_rd + 64 * kb, s3v::WP);
-                    b[1] = s3b_load(ldsb + s3v::H2G + wb_rd + HBW + 64 * kb, s3v::WP);
+                    b[0] = s3b_load(ldsb + s3v::H2G + (wb_rd ^ (64 * kb)), s3v::WP);
+                    b[1] = s3b_load(ldsb + s3v::H2G + HBW + (wb_rd ^ (64 * kb)), s3v::WP);
                     S3_SB();
                     s3b_mm<2>(acc, wB2[kb], b);
                     S3_SB();
@@ -1894,7 +1903,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
                 f32x4 j0 = zero4, j1 = zero4;
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
-                    const S3bOp av = s3b_load(nrA + 64 * kb, s3v::WP), bvv = s3b_load(nrB + 64 * kb, s3v::WP);
+                    const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), s3v::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), s3v::WP);
                     S3_SB();
                     j0 = s3b_term<0>(av, bvv, j0); j1 = s3b_term<3>(av, bvv, j1);
                     j0 = s3b_term<1>(av, bvv, j0); j1 = s3b_term<4>(av, bvv, j1);
@@ -2126,14 +2135,18 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     float* redw = lds + s3v::RED + smp * 8 + 4 * t + q;                 // this lane's slot of kind 0 (+ 256 per kind)
     // B operands from a split image: lane (sample s of half A, k = 8q ..); half B = 16 rows on.  Results: lane (sample s,
     // rows 16 wave + 4q ..) of the wide images
-    const int wb_rd = s * s3v::WS + 16 * q, wb_wr = s * s3v::WS + 2 * (16 * wave + 4 * q);
+    // (swizzled rows: k-block kb of a row is reached by XOR 64 kb on the byte offset, not by adding to it)
+    const int wb_rd = s * s3v::WS + 16 * (q ^ s);
+    const int wb_wr = s * s3v::WS + 16 * ((2 * wave + (q >> 1)) ^ s) + 8 * (q & 1);
     constexpr int HBW = 16 * s3v::WS;
     // narrow products: A = rows 16t + s of W3 (waves 0-3) / of W1^T (waves 4-7), B = this wave's half of h2 / g1
-    const char* nrA = ldsb + (zown ? s3v::W3I : s3v::W1TI) + (16 * t + s) * s3v::WS + 16 * q;
-    const char* nrB = ldsb + (zown ? s3v::H2G : s3v::H1G) + smp * s3v::WS + 16 * q;
-    char* x0w = ldsb + s3v::X0S + smp * s3v::NS + 2 * r0;               // this lane's 4 rows of the state / g3 images
-    char* g3w = ldsb + s3v::G3S + smp * s3v::NS + 2 * r0;
-    const int nb_rd = s * s3v::NS + 16 * q;                             // their B operands: lane (sample s of half A, k = 8q ..)
+    const char* nrA = ldsb + (zown ? s3v::W3I : s3v::W1TI) + 16 * t * s3v::WS;      // + (wb_rd ^ 64 kb): row 16t + s
+    const char* nrB = ldsb + (zown ? s3v::H2G : s3v::H1G) + 16 * hf * s3v::WS;      // + (wb_rd ^ 64 kb): row smp
+    const int nsw = (-(s >> 2)) & 3;                                    // chunk swizzle of the K = 32 images (rows s, 16 + s)
+    const int nw = smp * s3v::NS + 16 * ((2 * t + (q >> 1)) ^ nsw) + 8 * (q & 1);
+    char* x0w = ldsb + s3v::X0S + nw;                                   // this lane's 4 rows of the state / g3 images
+    char* g3w = ldsb + s3v::G3S + nw;
+    const int nb_rd = s * s3v::NS + 16 * (q ^ nsw);                     // their B operands: lane (sample s of half A, k = 8q ..)
     constexpr int HBN = 16 * s3v::NS;
     // Runge-Kutta state of the z rows r0..r0+3 of sample smp, written and read by this lane only:
     float* rkw = lds + s3v::KZ + smp * s3v::SKZ + r0;                   // u at rkw, k1 at rkw + 32,
@@ -2242,8 +2255,8 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
                     S3bOp b[2];
-                    b[0] = s3b_load(ldsb + s3v::H1G + wb_rd + 64 * kb, s3v::WP);
-                    b[1] = s3b_load(ldsb + s3v::H1G + wb_rd + HBW + 64 * kb, s3v::WP);
+                    b[0] = s3b_load(ldsb + s3v::H1G + (wb_rd ^ (64 * kb)), s3v::WP);
+                    b[1] = s3b_load(ldsb + s3v::H1G + HBW + (wb_rd ^ (64 * kb)), s3v::WP);
                     S3_SB();
                     s3b_mm<2>(acc, wF2[kb], b);
                     S3_SB();
@@ -2260,7 +2273,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
                 f32x4 z0 = zero4, z1 = zero4;                                  // two chains (terms 0-2 / 3-5)
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
-                    const S3bOp av = s3b_load(nrA + 64 * kb, s3v::WP), bvv = s3b_load(nrB + 64 * kb, s3v::WP);
+                    const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), s3v::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), s3v::WP);
                     S3_SB();
                     z0 = s3b_term<0>(av, bvv, z0); z1 = s3b_term<3>(av, bvv, z1);
                     z0 = s3b_term<1>(av, bvv, z0); z1 = s3b_term<4>(av, bvv, z1);
@@ -2298,8 +2311,8 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
                     S3bOp b[2];
-                    b[0] = s3b_load(ldsb + s3v::H2G + wb_rd + 64 * kb, s3v::WP);
-                    b[1] = s3b_load(ldsb + s3v::H2G + wb_rd + HBW + 64 * kb, s3v::WP);
+                    b[0] = s3b_load(ldsb + s3v::H2G + (wb_rd ^ (64 * kb)), s3v::WP);
+                    b[1] = s3b_load(ldsb + s3v::H2G + HBW + (wb_rd ^ (64 * kb)), s3v::WP);
                     S3_SB();
                     s3b_mm<2>(acc, wB2[kb], b);
                     S3_SB();
@@ -2313,7 +2326,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
                 f32x4 j0 = zero4, j1 = zero4;
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
-                    const S3bOp av = s3b_load(nrA + 64 * kb, s3v::WP), bvv = s3b_load(nrB + 64 * kb, s3v::WP);
+                    const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), s3v::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), s3v::WP);
                     S3_SB();
                     j0 = s3b_term<0>(av, bvv, j0); j1 = s3b_term<3>(av, bvv, j1);
                     j0 = s3b_term<1>(av, bvv, j0); j1 = s3b_term<4>(av, bvv, j1);
@@ -2513,7 +2526,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
 // Image of k_step3jb / k_step3b (layout: namespace s3g): biases, the fp32 fragments, the two split LDS images of k_step3b.
 __global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __restrict__ img) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int NIMG = 2 * 32 * 17;
+    constexpr int NIMG = 2 * 32 * 16;
     // W_l[o][k] with zero padding
     auto W = [&](int l, int o, int k) {
         return (o < nd.dims[l + 1] && k < nd.dims[l]) ? P[nd.w_off[l] + o + (size_t)k * nd.dims[l + 1]] : 0.f;
@@ -2540,7 +2553,7 @@ __global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __r
         *(f32x4*)d = f32x4{v[0], v[1], v[2], v[3]};
         *(f32x4*)(d + 1024) = f32x4{v[4], v[5], v[6], v[7]};
     } else if (i < s3g::NFR * 64 + NIMG) {
-        const int e = i - s3g::NFR * 64, which = e / (32 * 17), r = (e / 17) % 32, g = e % 17;     // 17 groups of 8 bf16 per row
+        const int e = i - s3g::NFR * 64, which = e / (32 * 16), r = (e / 16) % 32, g = e % 16;     // 16 chunks of 8 bf16 per row
         bf16x8 h, m, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -2550,13 +2563,13 @@ __global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __r
             s3b_split(v, a, b, c);
             h[j] = a; m[j] = b; lo[j] = c;
         }
-        char* dst = img + s3g::W3I + (size_t)which * s3v::WI + r * s3v::WS + 16 * g;
+        char* dst = img + s3g::W3I + (size_t)which * s3v::WI + r * s3v::WS + 16 * (g ^ (r & 15));      // (swizzled rows: s3v)
         *(bf16x8*)dst = h; *(bf16x8*)(dst + s3v::WP) = m; *(bf16x8*)(dst + 2 * s3v::WP) = lo;
     }
 }
 size_t step3b_img_bytes() { return (size_t)s3g::IMG_BYTES; }
 void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStream_t s) {
-    constexpr int NT = s3g::NFR * 64 + 2 * 32 * 17;
+    constexpr int NT = s3g::NFR * 64 + 2 * 32 * 16;
     hipLaunchKernelGGL(k_pack_step3b, dim3((NT + 255) / 256), dim3(256), 0, s, nd, d_params, (char*)d_imgb);
 }
 cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, int grid, hipStream_t s,
