@@ -1095,8 +1095,9 @@ namespace s3b {
 // fp32 regions (float offsets), then the bf16 images (byte offsets)
 constexpr int G3 = 0, EPS = G3 + 32 * 40, RED = EPS + 32 * 40, SC = RED + 3 * 32 * 8, BIAS = SC + 32 * 24;
 constexpr int MISC = BIAS + 2 * 128 + 32, FP_END = MISC + 64;
-constexpr int WS = 288, WP = 32 * WS, WI = 3 * WP;        // wide image: row stride (144 bf16), piece, image (hi | mid | lo)
-constexpr int NS = 96, NP = 32 * NS, NI = 3 * NP;         // narrow image (K = 32): row stride (48 bf16)
+// images [piece hi | mid | lo][32 rows][K bf16]: rows without padding, 16-byte chunks XOR-swizzled by the row (as s3v below)
+constexpr int WS = 256, WP = 32 * WS, WI = 3 * WP;        // K = 128
+constexpr int NS = 64, NP = 32 * NS, NI = 3 * NP;         // K = 32
 constexpr int H1B = FP_END * 4, T1B = H1B + WI, H2B = T1B + WI, T2B = H2B + WI, X0B = T2B + WI, T0B = X0B + NI;
 constexpr int TOTAL_BYTES = T0B + NI;
 static_assert(H1B % 16 == 0 && TOTAL_BYTES <= 160 * 1024, "LDS plan");
@@ -1267,11 +1268,13 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
     }
     // the probe rows: fp32 for the trace row, split as tau_0 (the tangent operand of the first layer)
     float* epw = lds + s3b::EPS + smp * 40 + r0;
-    char* x0w = ldsb + s3b::X0B + smp * s3b::NS + 2 * r0;            // this lane's 4 rows of the state image
+    const int nsw = (-(s >> 2)) & 3;                                 // chunk swizzle of the K = 32 images (rows s, 16 + s)
+    const int nw = smp * s3b::NS + 16 * ((2 * t + (q >> 1)) ^ nsw) + 8 * (q & 1);      // this lane's 4 rows there
+    char* x0w = ldsb + s3b::X0B + nw;
     {
         const f32x4 ev = ld4_mask(re, ce);
         *(f32x4*)epw = ev;
-        s3b_store4(ldsb + s3b::T0B + smp * s3b::NS + 2 * r0, s3b::NP, ev);
+        s3b_store4(ldsb + s3b::T0B + nw, s3b::NP, ev);
     }
     float* msc = lds + s3b::MISC;
     if (a.apply_ctrl) {
@@ -1323,9 +1326,10 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
     const float* bias = lds + s3b::BIAS;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // B operands: lane (sample s of half A, k = 8q ..): byte offsets into an image; half B = 16 rows on
-    const int nb_rd = s * s3b::NS + 16 * q, wb_rd = s * s3b::WS + 16 * q;
+    // (swizzled rows: k-block kb of a row is reached by XOR 64 kb on the byte offset)
+    const int nb_rd = s * s3b::NS + 16 * (q ^ nsw), wb_rd = s * s3b::WS + 16 * (q ^ s);
     // results: lane (sample s, rows 16 wave + 4q ..) of the wide images
-    const int wb_wr = s * s3b::WS + 2 * (16 * wave + 4 * q);
+    const int wb_wr = s * s3b::WS + 16 * ((2 * wave + (q >> 1)) ^ s) + 8 * (q & 1);
     constexpr int HBW = 16 * s3b::WS, HBN = 16 * s3b::NS;
 
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -1346,7 +1350,7 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
             const f32x4 s0 = ld3_issue(Uin + gcol + n_in, cs, img3), s1 = ld3_issue(K1in + gcol + n_in, cs, img3);
             const f32x4 ev = ld4_mask(e_, ce);
             *(f32x4*)epw = ev;
-            s3b_store4(ldsb + s3b::T0B + smp * s3b::NS + 2 * r0, s3b::NP, ev);
+            s3b_store4(ldsb + s3b::T0B + nw, s3b::NP, ev);
             uz = ld4_mask(u_, cu); kz[0] = ld4_mask(k_, cu);
             if (sown) { sc_set(0, ld4_mask(s0, cs)); sc_set(1, ld4_mask(s1, cs)); }
         }
@@ -1391,13 +1395,13 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
                 if (stg > 1 && sown) sc_set(stg, read_scalars());              // scalar rows of the PREVIOUS evaluation
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    const char* hb = ldsb + s3b::H1B + wb_rd + half * HBW;
-                    const char* tb = ldsb + s3b::T1B + wb_rd + half * HBW;
+                    const char* hb = ldsb + s3b::H1B + half * HBW;
+                    const char* tb = ldsb + s3b::T1B + half * HBW;
                     f32x4 acc[2] = {zero4, zero4};
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) {       // (the other wave of the SIMD covers the LDS latency)
                         S3bOp rb[2];
-                        rb[0] = s3b_load(hb + 64 * kb, s3b::WP); rb[1] = s3b_load(tb + 64 * kb, s3b::WP);
+                        rb[0] = s3b_load(hb + (wb_rd ^ (64 * kb)), s3b::WP); rb[1] = s3b_load(tb + (wb_rd ^ (64 * kb)), s3b::WP);
                         S3_SB();
                         s3b_mm<2>(acc, wF2[kb], rb);
                         S3_SB();
@@ -1410,14 +1414,14 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
             s3_bar();                                                          // h2, t2 visible
             // ---- interval 2: last layer, one product per wave: rows r0..r0+3 of sample smp, state (0-3) / tangent (4-7)
             {
-                const char* xb = ldsb + (zown ? s3b::H2B : s3b::T2B) + smp * s3b::WS + 16 * q;
+                const char* xb = ldsb + (zown ? s3b::H2B : s3b::T2B) + 16 * hf * s3b::WS;      // + (wb_rd ^ 64 kb): row smp
                 const f32x4 bv3 = *(const f32x4*)(bias + 256 + r0);
                 // two accumulation chains (terms 0-2 / 3-5): a wave alone on its product would otherwise wait on itself
                 f32x4 z0 = zero4, z1 = zero4;
-                S3bOp b = s3b_load(xb, s3b::WP);
+                S3bOp b = s3b_load(xb + wb_rd, s3b::WP);
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
-                    const S3bOp bn = s3b_load(xb + 64 * (kb + 1 < 4 ? kb + 1 : kb), s3b::WP);
+                    const S3bOp bn = s3b_load(xb + (wb_rd ^ (64 * (kb + 1 < 4 ? kb + 1 : kb))), s3b::WP);
                     S3_SB();
                     z0 = s3b_term<0>(w3[kb], b, z0); z1 = s3b_term<3>(w3[kb], b, z1);
                     z0 = s3b_term<1>(w3[kb], b, z0); z1 = s3b_term<4>(w3[kb], b, z1);
