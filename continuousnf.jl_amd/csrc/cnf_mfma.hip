@@ -1554,8 +1554,8 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, con
     return launch(p, a, s);
 }
 
-// The whole solve of the headline shape in one cooperative launch (k_solve3b, cnf_step3.hip): VJP handles with the
-// |eps^T J| row whose batch is at most one 32-column tile per CU.  CNF_ERR_UNSUPPORTED: not this handle / batch, or the
+// The whole solve of the headline shape in one launch (k_solve3b, cnf_step3.hip): VJP handles whose batch is at most one
+// 32-column tile per CU.  CNF_ERR_UNSUPPORTED: not this handle / batch, or the
 // device cannot place the grid right now -- the caller streams step launches instead.  CNF_PERSISTENT=0 switches it off.
 cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st_out, float* const U[2],
                                  const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv) {
@@ -1566,7 +1566,9 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
         return n;
     }();
-    if (off || fp32_only || step_v1() || !train || p.cond || !p.d_img3b || p.variant != 2 || p.ly.jvp || !p.ly.norm_j)
+    // (VJP handles without the |eps^T J| row -- FFJORD -- stream their steps on the JVP kernel, the shorter schedule per
+    // launch; as ONE launch the VJP kernel wins, and it simply leaves that row zero)
+    if (off || fp32_only || step_v1() || !train || p.cond || !p.d_img3b || p.variant != 2 || p.ly.jvp)
         return CNF_ERR_UNSUPPORTED;
     const int ntile = (B + 31) / 32;
     if (ntile < 1 || ntile > n_cu || ntile > 512) return CNF_ERR_UNSUPPORTED;
