@@ -147,6 +147,10 @@ def run_rank(args):
     if backend == "nccl" and world > 1 and local_rank >= ndev:
         sys.exit(f"bench.py: local rank {local_rank} has no device of its own ({ndev} visible)")
     dev_index = local_rank % ndev
+    if world > ndev:
+        # rehearsal with several ranks on one GPU (gloo): the one-launch solve needs every CU for itself; two processes'
+        # launches would each hold CUs the other waits for -- stream step launches instead
+        os.environ.setdefault("CNF_PERSISTENT", "0")
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     comm, collective = None, "none (1 rank)"

@@ -1602,18 +1602,15 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 #endif
     // ---- everything the launch needs from memory is requested up front, in ONE round trip, and nothing is consumed
     // before all of it is in flight: the integrator state words first (the `done` test and the controller need them
-    // soonest), then the error partials, then the two groups below.
+    // soonest), then the error partials, then the tile and the weights.
     const StepState* stw = s3_state_words(st);
     const int v_done = stw->done, v_cur = stw->cur;
     const float v_h = stw->h, v_abstol = stw->abstol, v_reltol = stw->reltol;
     // (one unconditional load per thread: a loop here would wait for its data before anything below is even requested)
     const float* ppin = a.apply_ctrl ? a.partials_in : img3;
     const float2 pp = *reinterpret_cast<const float2*>(ppin + 2 * min(tid, (int)gridDim.x - 1));
-    // Issue order = return order.  Group 1 is what the controller and the FORWARD half of the first evaluation need: this
-    // workgroup's first tile from BOTH buffer sets (which one is current is the controller's decision), the two LDS images
-    // (every LDS-DMA piece sits in group 1: the compiler makes LDS accesses wait for outstanding ones), the biases, the
-    // W1 / W2 fragments.  Group 2 (the W3^T / W2^T fragments: 120 of the 292 KB) is first needed three intervals later and
-    // streams in behind the first forward sweep.
+    // Issue order = return order: this workgroup's first tile from BOTH buffer sets (which one is current is the
+    // controller's decision), the biases, the resident fragments (fp32, split as they arrive), the two LDS images last.
     const int ntile = (a.B + 32 - 1) / 32;
     const bool wide = (n_in & 3) == 0;                     // every lane's four rows are all valid or all padding
     f32x4 ru[2], rk[2], re, rs[2][2];
@@ -1632,9 +1629,9 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
             rs[c][1] = ld3_issue(a.K1[c] + gcol + n_in, cs, img3);
         }
     }
-    // Weights, pre-split into three bf16 pieces (k_pack_step3b).  Resident fragments of this wave: its 16-row tile of W1
-    // and of W3^T (K = 32: one k-block), of W2 and of W2^T (four k-blocks).  The K = 128 operands of the narrow products
-    // (rows of W3, rows of W1^T) stay in LDS as split images, copied as they are stored (LDS-DMA).
+    // Weights (k_pack_step3b).  Resident fragments of this wave: its 16-row tile of W1 and of W3^T (K = 32: one k-block),
+    // of W2 and of W2^T (four k-blocks).  The K = 128 operands of the narrow products (rows of W3, rows of W1^T) stay in
+    // LDS as split images, copied as they are stored (LDS-DMA).
     constexpr int NCI = 2 * s3v::WI / 16, NCB = (2 * 128 + 32) / 4;
     static_assert(NCI % 64 == 0, "whole wave instructions");
     typedef __attribute__((address_space(3))) char* lds_c;
