@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("CNF_PERSISTENT", "0")      # two processes on one GPU: no one-launch solves (they need every CU)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import continuousnf.jl_amd as cnf
