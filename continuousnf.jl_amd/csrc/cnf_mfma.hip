@@ -1566,9 +1566,11 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
         return n;
     }();
-    // (VJP handles without the |eps^T J| row -- FFJORD -- stream their steps on the JVP kernel, the shorter schedule per
-    // launch; as ONE launch the VJP kernel wins, and it simply leaves that row zero)
-    if (off || fp32_only || step_v1() || !train || p.cond || !p.d_img3b || p.variant != 2 || p.ly.jvp)
+    // k_solve3jb (one forward sweep of state and tangent columns): JVP handles, and VJP handles without the |eps^T J| row
+    // (FFJORD: zdot and ldot do not depend on the mode); k_solve3b: VJP handles with that row
+    const bool vjp_ok = p.variant == 2 && !p.ly.jvp;
+    const bool jvp = (p.shape3 && p.ly.jvp) || (vjp_ok && !p.ly.norm_j);
+    if (off || fp32_only || step_v1() || !train || p.cond || !p.d_img3b || !(jvp || vjp_ok))
         return CNF_ERR_UNSUPPORTED;
     const int ntile = (B + 31) / 32;
     if (ntile < 1 || ntile > n_cu || ntile > 512) return CNF_ERR_UNSUPPORTED;
@@ -1579,7 +1581,7 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     a.U[0] = U[0]; a.U[1] = U[1];
     a.mirror = mirror; a.seq = seq;
     sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
-    return step3b_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, ntile, s, sv);
+    return step3b_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, ntile, s, sv, jvp);
 }
 
 cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st_in,

@@ -21,5 +21,6 @@ void step3jb_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z,
 void step3b_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single = 0);
 // the whole solve of one shard in ONE cooperative launch (k_solve3b): grid = tiles of 32 columns, all resident
 // (Solve3Args: cnf_mfma.h)
+// (jvp: k_solve3jb, the JVP compute mode)
 cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, int grid, hipStream_t s,
-                               const Solve3Args& sv);
+                               const Solve3Args& sv, bool jvp = false);

@@ -2524,6 +2524,431 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_solve3jb -- the one-launch solve (k_solve3b) around k_step3jb's evaluation code: the JVP compute mode of the headline
+// shape.  Same meetings, same controller, same fused assembly of u0 / post-processing / loss sums; the Runge-Kutta rows of
+// z stay in registers (as in k_step3jb), the scalar rows in LDS.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __restrict__ imgb, int n_in, int norm_z,
+                                                     int norm_j, const S3Tab tab, Solve3Args sv) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* ldsb = reinterpret_cast<char*>(lds);
+    const float* img3 = reinterpret_cast<const float*>(imgb);      // (a valid address for masked loads)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = n_in + 3;
+    const int s = lane & 15, q = lane >> 4;
+    const int t = wave & 1, hf = (wave >> 1) & 1;
+    const bool zown = wave < 4;
+    const bool sown = !zown && t == 0 && q == 0;
+    const int smp = 16 * hf + s;
+    const int r0 = 16 * t + 4 * q;
+    const int nv = n_in - r0;
+    const bool wide = (n_in & 3) == 0;
+    const int b0 = blockIdx.x * 32 + 16 * hf;
+    const bool live = s < max(0, min(16, a.B - b0));
+    const size_t gcol = (size_t)(b0 + s) * D;
+    const int ce = live ? nv : 0, cu = (zown && live) ? nv : 0, cs = (sown && live) ? 3 : 0;
+    if (sv.t_out && blockIdx.x == 0 && tid == 0) sv.t_out[0] = __builtin_amdgcn_s_memrealtime();
+    const f32x4 re = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
+    f32x4 ru, rs;
+    if (sv.xs) {                                           // u0 = (xs; zeros for the augmented and the scalar rows)
+        const float* xc = sv.xs + (size_t)(b0 + s) * sv.nvars;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ru[j] = (cu > j && r0 + j < sv.nvars) ? xc[r0 + j] : 0.f;
+        rs = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        ru = ld4_issue_w(a.U[0] + gcol + r0, cu, img3, wide);
+        rs = ld3_issue(a.U[0] + gcol + n_in, cs, img3);
+    }
+    // (they arrive in fp32 and are split here, in arrival order, while the rest of the stream is in flight)
+    S3bOp wF1, wF2[4], w3[4];
+    {
+        const char* fw = imgb + s3g::F32 + (size_t)wave * 10 * 2048 + 16 * lane;
+        const char* f3 = imgb + s3g::F32 + (size_t)(80 + 4 * t) * 2048 + 16 * lane;
+        auto src = [&](int f) { return f < 5 ? fw + f * 2048 : f3 + (f - 5) * 2048; };
+        constexpr int AH = 5;                                  // fragments requested ahead of the one being split
+        f32x4 raw[9][2];
+#pragma unroll
+        for (int f = 0; f < AH; ++f) { raw[f][0] = *(const f32x4*)src(f); raw[f][1] = *(const f32x4*)(src(f) + 1024); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 9; ++f) {
+            if (f + AH < 9) { raw[f + AH][0] = *(const f32x4*)src(f + AH); raw[f + AH][1] = *(const f32x4*)(src(f + AH) + 1024); }
+            S3bOp o = s3b_split8(raw[f][0], raw[f][1]);
+            s3b_pin(o);                                        // (the split stays here, between the two scheduling barriers)
+            if (f == 0) wF1 = o; else if (f < 5) wF2[f - 1] = o; else w3[f - 5] = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    constexpr int NCB = (2 * 128 + 32) / 4;
+    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3g::BIASB)[min(tid, NCB - 1)];
+    float* sc = lds + s3b::SC + smp * 24;
+    auto sc_get = [&](int j) { return f32x4{sc[3 * j], sc[3 * j + 1], sc[3 * j + 2], 0.f}; };
+    auto sc_set = [&](int j, const f32x4& v) { sc[3 * j] = v.x; sc[3 * j + 1] = v.y; sc[3 * j + 2] = v.z; };
+    __builtin_amdgcn_sched_barrier(0);
+    // the probe rows: fp32 for the trace row, split as tau_0 (the tangent operand of the first layer)
+    float* epw = lds + s3b::EPS + smp * 40 + r0;
+    const int nsw = (-(s >> 2)) & 3;                                 // chunk swizzle of the K = 32 images (rows s, 16 + s)
+    const int nw = smp * s3b::NS + 16 * ((2 * t + (q >> 1)) ^ nsw) + 8 * (q & 1);      // this lane's 4 rows there
+    char* x0w = ldsb + s3b::X0B + nw;
+    {
+        const f32x4 ev = ld4_mask(re, ce);
+        *(f32x4*)epw = ev;
+        s3b_store4(ldsb + s3b::T0B + nw, s3b::NP, ev);
+    }
+    float* msc = lds + s3b::MISC;
+    StepState* ns = reinterpret_cast<StepState*>(msc + 44);            // the integrator state (thread 0 runs the controller on it)
+    if (tid == 0) *ns = sv.init;
+    if (tid < NCB) reinterpret_cast<f32x4*>(lds + s3b::BIAS)[tid] = sgb;
+    const int single = 0;
+    (void)single;
+    float errsum = 0.f, badcnt = 0.f;
+    auto red8 = [&](int kind) {
+        const float* r = lds + s3b::RED + (kind * 32 + smp) * 8;
+        const f32x4 a_ = *(const f32x4*)r, b_ = *(const f32x4*)(r + 4);
+        return ((a_.x + a_.y) + (a_.z + a_.w)) + ((b_.x + b_.y) + (b_.z + b_.w));
+    };
+    auto read_scalars = [&]() {
+        const float e2 = red8(0), ld = red8(1), n2 = red8(2);
+        return f32x4{ld, norm_z ? __builtin_sqrtf(e2) : 0.f, norm_j ? __builtin_sqrtf(n2) : 0.f, 0.f};
+    };
+    float* redw = lds + s3b::RED + smp * 8 + 4 * t + q;
+    float* g3w = lds + s3b::G3 + smp * 40 + r0;
+    const float* bias = lds + s3b::BIAS;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // B operands: lane (sample s of half A, k = 8q ..): byte offsets into an image; half B = 16 rows on
+    // (swizzled rows: k-block kb of a row is reached by XOR 64 kb on the byte offset)
+    const int nb_rd = s * s3b::NS + 16 * (q ^ nsw), wb_rd = s * s3b::WS + 16 * (q ^ s);
+    // results: lane (sample s, rows 16 wave + 4q ..) of the wide images
+    const int wb_wr = s * s3b::WS + 16 * ((2 * wave + (q >> 1)) ^ s) + 8 * (q & 1);
+    constexpr int HBW = 16 * s3b::WS, HBN = 16 * s3b::NS;
+
+    f32x4 uz = ld4_mask(ru, cu), kz[7], un = zero4;        // Runge-Kutta rows of z (waves 0-3): u, k1..k7, u_new
+#pragma unroll
+    for (int j = 0; j < 7; ++j) kz[j] = zero4;
+    if (sown) { sc_set(0, ld4_mask(rs, cs)); sc_set(1, zero4); }
+    s3_bar();                                              // biases, probe images, state
+    float hstep = ns->h, abstol = ns->abstol, reltol = ns->reltol;
+    hstep = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hstep)));
+    abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(abstol)));
+    reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(reltol)));
+    int nsync = 0;                                         // meetings so far (the same count in every workgroup)
+    // The workgroups' partials (e, b) -> the sums of all of them, in msc[32], msc[33] for thread 0 (what the prologue of a
+    // step launch computes from the previous launch's partials, in the same order).  Returns false when a wait ran out.
+    auto meet = [&](float e_lane, float b_lane) -> bool {
+        float e = s3_wave_sum(e_lane), b = s3_wave_sum(b_lane);
+        if (lane == 0) { msc[wave] = e; msc[16 + wave] = b; }
+        s3_bar();
+        // Every partial travels with the index of the meeting it belongs to in the same 8-byte word: a reader needs no
+        // ticket -- thread i polls workgroup i's two words until both carry this meeting's index -- so a meeting costs one
+        // store and one load round trip.  Two buffers by parity: a workgroup can be one meeting ahead of a reader, not two.
+        unsigned long long* pb = reinterpret_cast<unsigned long long*>(sv.part) + (nsync & 1) * 1024;
+        const unsigned tag = sv.base + (unsigned)nsync + 1u;
+        if (tid == 0) {
+            float e8 = 0.f, b8 = 0.f;
+            for (int w = 0; w < 8; ++w) { e8 += msc[w]; b8 += msc[16 + w]; }
+            __hip_atomic_store(pb + 2 * blockIdx.x, ((unsigned long long)tag << 32) | __float_as_uint(e8), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pb + 2 * blockIdx.x + 1, ((unsigned long long)tag << 32) | __float_as_uint(b8), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float cp0 = 0.f, cp1 = 0.f;
+        int ok = 1;
+        if (tid < (int)gridDim.x) {
+            ok = 0;
+            for (int spin = 0; spin < (1 << 21); ++spin) {
+                const unsigned long long w0 = __hip_atomic_load(pb + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long w1 = __hip_atomic_load(pb + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag) {
+                    cp0 = __uint_as_float((unsigned)w0); cp1 = __uint_as_float((unsigned)w1); ok = 1;
+                    break;
+                }
+                if ((spin & 255) == 255 && __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok) __hip_atomic_store(sv.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cp0 = s3_wave_sum(cp0); cp1 = s3_wave_sum(cp1);
+        const float bad = s3_wave_sum(ok ? 0.f : 1.f);
+        s3_bar();                                          // (msc[0..7], [16..23] were read by thread 0 above)
+        if (lane == 0) { msc[wave] = cp0; msc[16 + wave] = cp1; msc[24 + wave] = bad; }
+        s3_bar();
+        float nbad = 0.f;
+        for (int w = 0; w < 8; ++w) nbad += msc[24 + w];
+        if (tid == 0) {
+            float p0 = 0.f, p1 = 0.f;
+            for (int w = 0; w < 8; ++w) { p0 += msc[w]; p1 += msc[16 + w]; }
+            msc[32] = p0; msc[33] = p1;
+        }
+        ++nsync;
+        return nbad == 0.f;
+    };
+    // thread 0 ran a controller phase on *ns: the new step and tolerances to everyone
+    auto share = [&]() {
+        s3_bar();
+        hstep = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[36])));
+        abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[37])));
+        reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(msc[38])));
+        const int fl = __builtin_amdgcn_readfirstlane(__float_as_int(msc[39]));
+        s3_bar();                                          // (the words are rewritten by the next phase)
+        return fl;                                         // bit 0: done, bit 1: the attempt was accepted
+    };
+    auto post_ctrl = [&](int accepted) {                   // thread 0, after a controller phase
+        msc[36] = ns->h; msc[37] = ns->abstol; msc[38] = ns->reltol;
+        msc[39] = __int_as_float((ns->done ? 1 : 0) | (accepted ? 2 : 0));
+    };
+    // the evaluations of one attempt (nstg = 6) or one evaluation (nstg = 1) at the state image in place
+    int nstg = 1;
+    f32x4 tacc = zero4;
+    auto finish_tau = [&]() {
+        const f32x4 tj = tacc * *(const f32x4*)g3w;
+        redw[32 * 8] = -s3_dot4(tj, *(const f32x4*)epw);
+        redw[2 * 32 * 8] = s3_dot4(tj, tj);
+    };
+    auto evals = [&]() {
+        for (int stg = 1; stg <= nstg; ++stg) {
+            // ---- interval 0: first layer, tile `wave`, both halves, state and tangent columns (one k-block)
+            {
+                const f32x4 bv1 = *(const f32x4*)(bias + 16 * wave + 4 * q);
+                if (!zown && stg > 1) finish_tau();                            // of the previous evaluation
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    S3bOp b[2];
+                    b[0] = s3b_load(ldsb + s3b::X0B + nb_rd + half * HBN, s3b::NP);
+                    b[1] = s3b_load(ldsb + s3b::T0B + nb_rd + half * HBN, s3b::NP);
+                    S3_SB();
+                    f32x4 acc[2] = {zero4, zero4};
+                    s3b_mm<2>(acc, wF1, b);
+                    const f32x4 h1 = s3_tanh4(acc[0] + bv1);
+                    s3b_store4(ldsb + s3b::H1B + wb_wr + half * HBW, s3b::WP, h1);
+                    s3b_store4(ldsb + s3b::T1B + wb_wr + half * HBW, s3b::WP, s3_dtanh4(h1) * acc[1]);
+                }
+            }
+            s3_bar();                                                          // h1, t1 visible
+            // ---- interval 1: second layer, tile `wave`: half A (state, tangent), then half B; operands one k-block ahead
+            {
+                const f32x4 bv2 = *(const f32x4*)(bias + 128 + 16 * wave + 4 * q);
+                if (stg > 1 && sown) sc_set(stg, read_scalars());              // scalar rows of the PREVIOUS evaluation
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const char* hb = ldsb + s3b::H1B + half * HBW;
+                    const char* tb = ldsb + s3b::T1B + half * HBW;
+                    f32x4 acc[2] = {zero4, zero4};
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {       // (the other wave of the SIMD covers the LDS latency)
+                        S3bOp rb[2];
+                        rb[0] = s3b_load(hb + (wb_rd ^ (64 * kb)), s3b::WP); rb[1] = s3b_load(tb + (wb_rd ^ (64 * kb)), s3b::WP);
+                        S3_SB();
+                        s3b_mm<2>(acc, wF2[kb], rb);
+                        S3_SB();
+                    }
+                    const f32x4 h2 = s3_tanh4(acc[0] + bv2);
+                    s3b_store4(ldsb + s3b::H2B + wb_wr + half * HBW, s3b::WP, h2);
+                    s3b_store4(ldsb + s3b::T2B + wb_wr + half * HBW, s3b::WP, s3_dtanh4(h2) * acc[1]);
+                }
+            }
+            s3_bar();                                                          // h2, t2 visible
+            // ---- interval 2: last layer, one product per wave: rows r0..r0+3 of sample smp, state (0-3) / tangent (4-7)
+            {
+                const char* xb = ldsb + (zown ? s3b::H2B : s3b::T2B) + 16 * hf * s3b::WS;      // + (wb_rd ^ 64 kb): row smp
+                const f32x4 bv3 = *(const f32x4*)(bias + 256 + r0);
+                // two accumulation chains (terms 0-2 / 3-5): a wave alone on its product would otherwise wait on itself
+                f32x4 z0 = zero4, z1 = zero4;
+                S3bOp b = s3b_load(xb + wb_rd, s3b::WP);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const S3bOp bn = s3b_load(xb + (wb_rd ^ (64 * (kb + 1 < 4 ? kb + 1 : kb))), s3b::WP);
+                    S3_SB();
+                    z0 = s3b_term<0>(w3[kb], b, z0); z1 = s3b_term<3>(w3[kb], b, z1);
+                    z0 = s3b_term<1>(w3[kb], b, z0); z1 = s3b_term<4>(w3[kb], b, z1);
+                    z0 = s3b_term<2>(w3[kb], b, z0); z1 = s3b_term<5>(w3[kb], b, z1);
+                    S3_SB();
+                    b = bn;
+                }
+                if (zown) {
+                    // stage sum without the k this evaluation produces: pre = u + h sum_{j<stg} a_{stg+1,j} k_j
+                    const float* A = tab.a[stg < 6 ? stg + 1 : 6];
+                    f32x4 pre = uz + (hstep * A[0]) * kz[0];
+#pragma unroll
+                    for (int jj = 1; jj < 5; ++jj) pre += (hstep * A[jj]) * kz[jj];      // k's not yet produced are zero
+                    const f32x4 zd = s3_tanh4(z0 + z1 + bv3);                  // padded rows: zero weights and bias -> 0
+                    *(f32x4*)g3w = s3_dtanh4(zd);                              // sigma'_3 for the tangent rows
+                    if (stg < 6) { un = pre + (hstep * A[stg]) * zd; s3b_store4(x0w, s3b::NP, un); }   // next stage state
+                    set_k(kz, stg, zd);                                        // k_{stg+1}
+                    redw[0] = s3_dot4(zd, zd);
+                } else {
+                    tacc = z0 + z1;
+                }
+            }
+            s3_bar();                                                          // sigma'_3 (and the next stage state) visible
+        }
+        if (!zown) finish_tau();                           // of the last evaluation
+        s3_bar();                                          // RED of the last evaluation complete
+    };
+    auto add_norm = [&](float& acc, float u, float x) {
+        const float sk = fmaf(fabsf(u), reltol, abstol);
+        const float y = x / sk;
+        acc = fmaf(y, y, acc);
+    };
+    bool alive = true;
+    {
+        // ---- k1 = f(u0); with the automatic initial dt also its norms, f(u0 + h0 f0) and that norm ----
+        if (zown) { un = uz; s3b_store4(x0w, s3b::NP, un); }
+        s3_bar();
+        nstg = 1; evals();
+        float e = 0.f, b = 0.f;
+        if (live && zown) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < nv) { add_norm(e, uz[c], uz[c]); add_norm(b, uz[c], kz[1][c]); }
+        }
+        if (zown) kz[0] = kz[1];                                           // k1 = f(u0)
+        if (live && sown) {
+            const f32x4 u4 = sc_get(0), f0 = read_scalars();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { add_norm(e, u4[c], u4[c]); add_norm(b, u4[c], f0[c]); }
+            sc_set(1, f0);
+        } else if (sown) sc_set(1, read_scalars());
+        if (sv.hairer) alive = meet(e, b);
+        if (sv.hairer && alive) {
+            if (tid == 0) { ctrl_phase(ns, 0, msc[32], msc[33], a.n_total); post_ctrl(0); }
+            share();
+            if (zown) { un = uz + hstep * kz[0]; s3b_store4(x0w, s3b::NP, un); }
+            s3_bar();
+            nstg = 1; evals();
+            e = 0.f; b = 0.f;
+            if (live && zown) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < nv) add_norm(e, uz[c], kz[1][c] - kz[0][c]);
+            }
+            if (live && sown) {
+                const f32x4 u4 = sc_get(0), f0 = sc_get(1), f1 = read_scalars();
+#pragma unroll
+                for (int c = 0; c < 3; ++c) add_norm(e, u4[c], f1[c] - f0[c]);
+            }
+            alive = meet(e, b);
+            if (alive) {
+                if (tid == 0) { ctrl_phase(ns, 1, msc[32], msc[33], a.n_total); post_ctrl(0); }
+                share();
+            }
+        }
+    }
+    // ---- step attempts ----
+    int done = 0;
+    for (int it = 0; alive && !done && it < sv.maxiters; ++it) {
+#pragma unroll
+        for (int j = 1; j < 7; ++j) kz[j] = zero4;
+        if (zown) { un = uz + (hstep * TS_A21) * kz[0]; s3b_store4(x0w, s3b::NP, un); }      // U_2 = u + h a21 k1
+        s3_bar();
+        nstg = 6; evals();
+        float errsum = 0.f, badcnt = 0.f;
+        if (live && zown) {
+            const f32x4 ez = TS_BT1 * kz[0] + TS_BT2 * kz[1] + TS_BT3 * kz[2] + TS_BT4 * kz[3] + TS_BT5 * kz[4] +
+                             TS_BT6 * kz[5] + TS_BT7 * kz[6];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float scl = fmaf(fmaxf(fabsf(uz[c]), fabsf(un[c])), reltol, abstol);
+                const float x = c < nv ? hstep * ez[c] / scl : 0.f;
+                errsum = fmaf(x, x, errsum);
+                badcnt += (c < nv && !(fabsf(un[c]) <= 3.0e38f)) ? 1.f : 0.f;
+            }
+        }
+        if (live && sown) {
+            f32x4 ks[7];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ks[j] = sc_get(1 + j);
+            const f32x4 us = sc_get(0);
+            ks[6] = read_scalars();
+            const f32x4 uns = us + hstep * stage_acc4<6>(ks);
+            err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
+            sc_set(7, uns);                                                // kept for an accepted attempt
+        }
+        alive = meet(errsum, badcnt);
+        if (!alive) break;
+        if (tid == 0) {
+            const int acc0 = ns->naccept;
+            ctrl_after_step(ns, msc[32], msc[33], a.n_total);
+            post_ctrl(ns->naccept != acc0);
+        }
+        const int fl = share();
+        done = fl & 1;
+        if (fl & 2) {                                                      // accepted: u <- u_new, k1 <- k7 (FSAL)
+            if (zown) { uz = un; kz[0] = kz[6]; }
+            if (sown) { const f32x4 k7s = read_scalars(); sc_set(0, sc_get(7)); sc_set(1, k7s); }
+        }
+    }
+    // ---- the final state to the integrator's buffer set 0 ----
+    if (live && zown) { if (nv >= 4) st4_wide(a.U[0] + gcol + r0, uz); else st4(a.U[0] + gcol + r0, uz, nv); }
+    if (live && sown) { const f32x4 us = sc_get(0); float* o = a.U[0] + gcol + n_in; o[0] = us.x; o[1] = us.y; o[2] = us.z; }
+    if (sv.logpx && alive) {
+        // ---- post-processing of this tile: logp(z) - dlogp, the regulariser rows; then the loss sums of the batch ----
+        if (zown) {
+            const f32x4 u4 = uz;
+            float ss = 0.f, sa = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < nv) { ss = fmaf(u4[c], u4[c], ss); if (r0 + c >= sv.nvars) sa = fmaf(u4[c], u4[c], sa); }
+            redw[0] = ss; redw[32 * 8] = sa;
+        }
+        s3_bar();
+        float v4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live && sown) {
+            const float ss = red8(0), sa = red8(1);
+            const f32x4 us = sc_get(0);
+            const float log2pi = 1.8378770664093453f;
+            v4[0] = -0.5f * fmaf((float)n_in, log2pi, ss) - us.x;         // base_icnf.jl:177-178
+            v4[1] = us.y; v4[2] = us.z;
+            v4[3] = (sv.norm_z_aug && sv.naugs > 0) ? sqrtf(sa) : 0.f;    // :179-187
+            const size_t b = (size_t)(b0 + s), Bz = (size_t)a.B;
+            sv.logpx[b] = v4[0]; sv.regs[b] = v4[1]; sv.regs[Bz + b] = v4[2]; sv.regs[2 * Bz + b] = v4[3];
+        }
+        if (sv.sums5) {
+            // workgroup partials (waves 4 and 6 hold them) -> tagged words, one more meeting index; workgroup 0 adds them in
+            // workgroup order
+            unsigned long long* qb = reinterpret_cast<unsigned long long*>(sv.part) + 2048;
+            const unsigned tag = sv.base + (unsigned)nsync + 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v4[j] = s3_wave_sum(v4[j]);
+            s3_bar();                                      // (red8 above read RED; msc below)
+            if (lane == 0 && (wave == 4 || wave == 6)) for (int j = 0; j < 4; ++j) msc[(wave == 4 ? 0 : 8) + j] = v4[j];
+            s3_bar();
+            if (tid < 4)
+                __hip_atomic_store(qb + 4 * blockIdx.x + tid, ((unsigned long long)tag << 32) | __float_as_uint(msc[tid] + msc[8 + tid]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0) {
+                float c4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (tid < (int)gridDim.x) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        for (int spin = 0; spin < (1 << 21); ++spin) {
+                            const unsigned long long w = __hip_atomic_load(qb + 4 * tid + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((unsigned)(w >> 32) == tag) { c4[j] = __uint_as_float((unsigned)w); break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c4[j] = s3_wave_sum(c4[j]);
+                s3_bar();
+                if (lane == 0) for (int j = 0; j < 4; ++j) msc[4 * wave + j] = c4[j];
+                s3_bar();
+                if (tid < 4) {
+                    float r = 0.f;
+                    for (int w = 0; w < 8; ++w) r += msc[4 * w + tid];
+                    sv.sums5[tid] = r;
+                }
+                if (tid == 0) sv.sums5[4] = (float)a.B;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        ns->cur = 0;
+        *a.st_out = *ns;
+        if (sv.t_out) { sv.t_out[1] += __builtin_amdgcn_s_memrealtime() - sv.t_out[0]; sv.t_out[2] += 1; }
+        publish_mirror(a, *ns);
+    }
+}
+
+
 // Image of k_step3jb / k_step3b (layout: namespace s3g): biases, the fp32 fragments, the two split LDS images of k_step3b.
 __global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __restrict__ img) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2574,13 +2999,16 @@ void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStre
     hipLaunchKernelGGL(k_pack_step3b, dim3((NT + 255) / 256), dim3(256), 0, s, nd, d_params, (char*)d_imgb);
 }
 cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, int grid, hipStream_t s,
-                               const Solve3Args& sv_) {
+                               const Solve3Args& sv_, bool jvp) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_solve3b, hipFuncAttributeMaxDynamicSharedMemorySize, s3v::TOTAL_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_solve3b, hipFuncAttributeMaxDynamicSharedMemorySize, s3v::TOTAL_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_solve3jb, hipFuncAttributeMaxDynamicSharedMemorySize, s3b::TOTAL_BYTES) != hipSuccess)
             return CNF_ERR_HIP;
         attr = true;
     }
+    const void* fn = jvp ? (const void*)k_solve3jb : (const void*)k_solve3b;
+    const size_t shm = jvp ? s3b::TOTAL_BYTES : s3v::TOTAL_BYTES;
     MfmaArgs a_ = a;
     const char* img = (const char*)d_imgb;
     S3Tab tab = kS3Tab;
@@ -2593,8 +3021,8 @@ cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, 
     // runtime, at 10-15 us more per launch (its barrier packets around the kernel).
     static const bool coop = [] { const char* e = getenv("CNF_PERSISTENT"); return e && e[0] == '2'; }();
     hipError_t e;
-    if (!coop) e = hipLaunchKernel((const void*)k_solve3b, dim3(grid), dim3(512), args, s3v::TOTAL_BYTES, s);
-    else e = hipLaunchCooperativeKernel((const void*)k_solve3b, dim3(grid), dim3(512), args, s3v::TOTAL_BYTES, s);
+    if (!coop) e = hipLaunchKernel(fn, dim3(grid), dim3(512), args, shm, s);
+    else e = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(512), args, shm, s);
     if (e != hipSuccess) { (void)hipGetLastError(); return CNF_ERR_UNSUPPORTED; }
     return CNF_OK;
 }

@@ -722,6 +722,20 @@ def test_one_launch_solve_takes_the_headline_shape_and_agrees_with_the_streamed_
             tol = 2e-3 if name == "adaptive" else 2e-5
             assert torch.allclose(logpx[sub], lp2, rtol=tol, atol=tol), (B, name, float((logpx[sub] - lp2).abs().max()))
             res[(B, name)] = logpx
+    # the JVP compute mode and handles without the |eps^T J| row (FFJORD) take k_solve3jb; same agreement with the
+    # C oracle as the streamed launches (they share the bar of test_adaptive_solve_vs_oracles)
+    cfg4, _, _ = O.baseline_cfg(4)
+    for c, jvp in ((cfg, True), (cfg4, False)):
+        B = 2048
+        xs, eps = _dev(rng.standard_normal((c.nvars, B))), _dev(rng.standard_normal((c.n_in, B)))
+        fl = O.glorot_params(c.net, rng, np.float32, 0.1)
+        ic = make_icnf(cnf, c, jvp=jvp, sol_kwargs=dict(adaptive=False, dt=1 / 8))
+        logpx, regs = cnf.inference(ic, cnf.TrainMode(), xs, fl, {}, eps=eps)
+        assert (ic.last_stats["launches"] <= 3) == persistent, (jvp, ic.last_stats)
+        sub = slice(100, 164)
+        lp2, _ = cnf.inference(make_icnf(cnf, c, jvp=jvp, kernel="generic", sol_kwargs=dict(adaptive=False, dt=1 / 8)),
+                               cnf.TrainMode(), xs[:, sub].contiguous(), fl, {}, eps=eps[:, sub].contiguous())
+        assert torch.allclose(logpx[sub], lp2, rtol=2e-5, atol=2e-5), (jvp, float((logpx[sub] - lp2).abs().max()))
     # maxiters inside the launch
     ic = make_icnf(cnf, cfg, sol_kwargs=dict(reltol=3.45e-4, abstol=1.19e-7, maxiters=3))
     xs, eps = _dev(rng.standard_normal((cfg.nvars, 256))), _dev(rng.standard_normal((cfg.n_in, 256)))
