@@ -2188,14 +2188,17 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
         if (tid < (int)gridDim.x) {
             ok = 0;
             for (int spin = 0; spin < (1 << 21); ++spin) {
-                const unsigned long long w0 = __hip_atomic_load(pb + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long w1 = __hip_atomic_load(pb + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // both words of workgroup `tid` with ONE 16-byte load past the caches (each half carries its own index, so a
+                // torn pair is simply not accepted): half the polling traffic of two 8-byte atomic loads
+                u32x4 wq;
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(wq) : "v"(pb + 2 * tid) : "memory");
+                const unsigned long long w0 = ((unsigned long long)wq.y << 32) | wq.x, w1 = ((unsigned long long)wq.w << 32) | wq.z;
                 if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag) {
                     cp0 = __uint_as_float((unsigned)w0); cp1 = __uint_as_float((unsigned)w1); ok = 1;
                     break;
                 }
                 if ((spin & 255) == 255 && __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(4);
             }
             if (!ok) __hip_atomic_store(sv.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -2657,14 +2660,17 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         if (tid < (int)gridDim.x) {
             ok = 0;
             for (int spin = 0; spin < (1 << 21); ++spin) {
-                const unsigned long long w0 = __hip_atomic_load(pb + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long w1 = __hip_atomic_load(pb + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // both words of workgroup `tid` with ONE 16-byte load past the caches (each half carries its own index, so a
+                // torn pair is simply not accepted): half the polling traffic of two 8-byte atomic loads
+                u32x4 wq;
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(wq) : "v"(pb + 2 * tid) : "memory");
+                const unsigned long long w0 = ((unsigned long long)wq.y << 32) | wq.x, w1 = ((unsigned long long)wq.w << 32) | wq.z;
                 if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag) {
                     cp0 = __uint_as_float((unsigned)w0); cp1 = __uint_as_float((unsigned)w1); ok = 1;
                     break;
                 }
                 if ((spin & 255) == 255 && __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(4);
             }
             if (!ok) __hip_atomic_store(sv.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
