@@ -29,4 +29,4 @@ echo "testmode rc=$?"
 timeout -k 10 500 python3 tests/measure_configs.py > $OUT/all_configs.log 2>&1
 echo "all_configs rc=$?"
 grep "^{" $OUT/all_configs.log > $OUT/all_configs.jsonl
-timeout -k 10 200 python3 tools/prof_testmode.py >> $OUT/testmode_plain.log 2>&1
+timeout -k 10 200 python3 tools/prof_testmode.py > $OUT/testmode_plain.log 2>&1
