@@ -1370,84 +1370,7 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
             redw[2 * 32 * 8] = s3_dot4(tj, tj);
         };
 
-        for (int stg = 1; stg <= nstg; ++stg) {
-            // ---- interval 0: first layer, tile `wave`, both halves, state and tangent columns (one k-block)
-            {
-                const f32x4 bv1 = *(const f32x4*)(bias + 16 * wave + 4 * q);
-                if (!zown && stg > 1) finish_tau();                            // of the previous evaluation
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    S3bOp b[2];
-                    b[0] = s3b_load(ldsb + s3b::X0B + nb_rd + half * HBN, s3b::NP);
-                    b[1] = s3b_load(ldsb + s3b::T0B + nb_rd + half * HBN, s3b::NP);
-                    S3_SB();
-                    f32x4 acc[2] = {zero4, zero4};
-                    s3b_mm<2>(acc, wF1, b);
-                    const f32x4 h1 = s3_tanh4(acc[0] + bv1);
-                    s3b_store4(ldsb + s3b::H1B + wb_wr + half * HBW, s3b::WP, h1);
-                    s3b_store4(ldsb + s3b::T1B + wb_wr + half * HBW, s3b::WP, s3_dtanh4(h1) * acc[1]);
-                }
-            }
-            s3_bar();                                                          // h1, t1 visible
-            // ---- interval 1: second layer, tile `wave`: half A (state, tangent), then half B; operands one k-block ahead
-            {
-                const f32x4 bv2 = *(const f32x4*)(bias + 128 + 16 * wave + 4 * q);
-                if (stg > 1 && sown) sc_set(stg, read_scalars());              // scalar rows of the PREVIOUS evaluation
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const char* hb = ldsb + s3b::H1B + half * HBW;
-                    const char* tb = ldsb + s3b::T1B + half * HBW;
-                    f32x4 acc[2] = {zero4, zero4};
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) {       // (the other wave of the SIMD covers the LDS latency)
-                        S3bOp rb[2];
-                        rb[0] = s3b_load(hb + (wb_rd ^ (64 * kb)), s3b::WP); rb[1] = s3b_load(tb + (wb_rd ^ (64 * kb)), s3b::WP);
-                        S3_SB();
-                        s3b_mm<2>(acc, wF2[kb], rb);
-                        S3_SB();
-                    }
-                    const f32x4 h2 = s3_tanh4(acc[0] + bv2);
-                    s3b_store4(ldsb + s3b::H2B + wb_wr + half * HBW, s3b::WP, h2);
-                    s3b_store4(ldsb + s3b::T2B + wb_wr + half * HBW, s3b::WP, s3_dtanh4(h2) * acc[1]);
-                }
-            }
-            s3_bar();                                                          // h2, t2 visible
-            // ---- interval 2: last layer, one product per wave: rows r0..r0+3 of sample smp, state (0-3) / tangent (4-7)
-            {
-                const char* xb = ldsb + (zown ? s3b::H2B : s3b::T2B) + 16 * hf * s3b::WS;      // + (wb_rd ^ 64 kb): row smp
-                const f32x4 bv3 = *(const f32x4*)(bias + 256 + r0);
-                // two accumulation chains (terms 0-2 / 3-5): a wave alone on its product would otherwise wait on itself
-                f32x4 z0 = zero4, z1 = zero4;
-                S3bOp b = s3b_load(xb + wb_rd, s3b::WP);
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    const S3bOp bn = s3b_load(xb + (wb_rd ^ (64 * (kb + 1 < 4 ? kb + 1 : kb))), s3b::WP);
-                    S3_SB();
-                    z0 = s3b_term<0>(w3[kb], b, z0); z1 = s3b_term<3>(w3[kb], b, z1);
-                    z0 = s3b_term<1>(w3[kb], b, z0); z1 = s3b_term<4>(w3[kb], b, z1);
-                    z0 = s3b_term<2>(w3[kb], b, z0); z1 = s3b_term<5>(w3[kb], b, z1);
-                    S3_SB();
-                    b = bn;
-                }
-                if (zown) {
-                    // stage sum without the k this evaluation produces: pre = u + h sum_{j<stg} a_{stg+1,j} k_j
-                    const float* A = tab.a[stg < 6 ? stg + 1 : 6];
-                    f32x4 pre = uz + (hstep * A[0]) * kz[0];
-#pragma unroll
-                    for (int jj = 1; jj < 5; ++jj) pre += (hstep * A[jj]) * kz[jj];      // k's not yet produced are zero
-                    const f32x4 zd = s3_tanh4(z0 + z1 + bv3);                  // padded rows: zero weights and bias -> 0
-                    *(f32x4*)g3w = s3_dtanh4(zd);                              // sigma'_3 for the tangent rows
-                    if (stg < 6) { un = pre + (hstep * A[stg]) * zd; s3b_store4(x0w, s3b::NP, un); }   // next stage state
-                    set_k(kz, stg, zd);                                        // k_{stg+1}
-                    redw[0] = s3_dot4(zd, zd);
-                } else {
-                    tacc = z0 + z1;
-                }
-            }
-            s3_bar();                                                          // sigma'_3 (and the next stage state) visible
-        }
-        if (!zown) finish_tau();                           // of the last evaluation
-        s3_bar();                                          // RED of the last evaluation complete
+#include "cnf_step3jb_eval.inc"
         if (single) {
             float* out = (single == 1 ? a.du : a.Ks0) + (size_t)(tile * 32 + 16 * hf + s) * D;
             auto norms = [&](const f32x4& u4, const f32x4& f0, const f32x4& f1, int nvalid) {
@@ -1799,126 +1722,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
         s3_bar();
         S3T(21);
 
-        for (int stg = 1; stg <= nstg; ++stg) {
-            f32x4 d2a, d2b;                                                  // sigma'_2 at this lane's h2 entries (interval 1 -> 3)
-            // ---- interval 0: first layer, tile `wave`, both halves (K = 32: one k-block)
-            {
-                const f32x4 bv1 = *(const f32x4*)(bias + 16 * wave + 4 * q);
-                S3bOp b[2];
-                b[0] = s3b_load(ldsb + s3v::X0S + nb_rd, s3v::NP);
-                b[1] = s3b_load(ldsb + s3v::X0S + nb_rd + HBN, s3v::NP);
-                S3_SB();
-                f32x4 acc[2] = {zero4, zero4};
-                s3b_mm<2>(acc, wF1, b);
-                s3b_store4(ldsb + s3v::H1G + wb_wr, s3v::WP, s3_tanh4(acc[0] + bv1));
-                s3b_store4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP, s3_tanh4(acc[1] + bv1));
-            }
-            S3T(0);
-            s3_bar();
-            S3T(1);                                                          // h1 visible
-            // ---- interval 1: second layer, tile `wave`, both halves share the A fragments
-            {
-                const f32x4 bv2 = *(const f32x4*)(bias + 128 + 16 * wave + 4 * q);
-                // scalar rows of the PREVIOUS evaluation from its RED partials (complete since the last barrier of it)
-                if (stg > 1 && sown) sc_set(stg, read_scalars());              // slot j holds k_j
-                f32x4 acc[2] = {zero4, zero4};
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    S3bOp b[2];
-                    b[0] = s3b_load(ldsb + s3v::H1G + (wb_rd ^ (64 * kb)), s3v::WP);
-                    b[1] = s3b_load(ldsb + s3v::H1G + HBW + (wb_rd ^ (64 * kb)), s3v::WP);
-                    S3_SB();
-                    s3b_mm<2>(acc, wF2[kb], b);
-                    S3_SB();
-                }
-                const f32x4 h2a = s3_tanh4(acc[0] + bv2), h2b = s3_tanh4(acc[1] + bv2);
-                d2a = s3_dtanh4(h2a); d2b = s3_dtanh4(h2b);
-                s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, h2a);
-                s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, h2b);
-            }
-            S3T(2);
-            s3_bar();
-            S3T(3);                                                          // h2 visible
-            // ---- interval 2: last layer on waves 0-3 (one per SIMD): zdot rows r0..r0+3 of sample smp
-            if (zown) {
-                const f32x4 bv3 = *(const f32x4*)(bias + 256 + r0);
-                f32x4 z0 = zero4, z1 = zero4;                                  // two chains (terms 0-2 / 3-5)
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), s3v::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), s3v::WP);
-                    S3_SB();
-                    z0 = s3b_term<0>(av, bvv, z0); z1 = s3b_term<3>(av, bvv, z1);
-                    z0 = s3b_term<1>(av, bvv, z0); z1 = s3b_term<4>(av, bvv, z1);
-                    z0 = s3b_term<2>(av, bvv, z0); z1 = s3b_term<5>(av, bvv, z1);
-                    S3_SB();
-                }
-                // stage sum without the k this evaluation will produce: pre = u + h sum_{j<stg} a_{stg+1,j} k_j
-                const float* A = tab.a[stg < 6 ? stg + 1 : 6];
-                f32x4 pre = *(const f32x4*)rkw + (hstep * A[0]) * *(const f32x4*)(rkw + 32);
-#pragma unroll
-                for (int j = 1; j < 5; ++j) pre += (hstep * A[j]) * *(const f32x4*)(kzw + 32 * (j - 1));
-                const f32x4 zd = s3_tanh4(z0 + z1 + bv3);                      // padded rows: zero weights and bias -> 0
-                s3b_store4(g3w, s3v::NP, epsr * s3_dtanh4(zd));               // g3 = eps .* sigma'_3
-                if (stg < 6) s3b_store4(x0w, s3v::NP, pre + (hstep * A[stg]) * zd);     // state of the next evaluation
-                *(f32x4*)(kzw + 32 * (stg - 1)) = zd;                          // k_{stg+1}
-                redw[0] = s3_dot4(zd, zd);
-            }
-            S3T(4);
-            s3_bar();
-            S3T(5);                                                          // g3 (and the next stage state) visible
-            // ---- interval 3: reverse of the last layer, tile `wave` of W3^T, both halves (K = 32); g2 over h2 in place
-            {
-                S3bOp b[2];
-                b[0] = s3b_load(ldsb + s3v::G3S + nb_rd, s3v::NP);
-                b[1] = s3b_load(ldsb + s3v::G3S + nb_rd + HBN, s3v::NP);
-                S3_SB();
-                f32x4 acc[2] = {zero4, zero4};
-                s3b_mm<2>(acc, wB3, b);
-                s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, acc[0] * d2a);
-                s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, acc[1] * d2b);
-            }
-            S3T(6);
-            s3_bar();
-            S3T(7);                                                          // g2 visible
-            // ---- interval 4: reverse of the second layer, tile `wave` of W2^T; g1 over h1 in place
-            {
-                const f32x4 h1a = s3b_load4(ldsb + s3v::H1G + wb_wr, s3v::WP), h1b = s3b_load4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP);
-                f32x4 acc[2] = {zero4, zero4};
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    S3bOp b[2];
-                    b[0] = s3b_load(ldsb + s3v::H2G + (wb_rd ^ (64 * kb)), s3v::WP);
-                    b[1] = s3b_load(ldsb + s3v::H2G + HBW + (wb_rd ^ (64 * kb)), s3v::WP);
-                    S3_SB();
-                    s3b_mm<2>(acc, wB2[kb], b);
-                    S3_SB();
-                }
-                s3b_store4(ldsb + s3v::H1G + wb_wr, s3v::WP, acc[0] * s3_dtanh4(h1a));
-                s3b_store4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP, acc[1] * s3_dtanh4(h1b));
-            }
-            S3T(8);
-            s3_bar();
-            S3T(9);                                                          // g1 visible
-            // ---- interval 5: eJ = W1^T g1 on waves 4-7 (one per SIMD): trace and norm partials (src/icnf.jl:334, :343)
-            if (!zown) {
-                f32x4 j0 = zero4, j1 = zero4;
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), s3v::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), s3v::WP);
-                    S3_SB();
-                    j0 = s3b_term<0>(av, bvv, j0); j1 = s3b_term<3>(av, bvv, j1);
-                    j0 = s3b_term<1>(av, bvv, j0); j1 = s3b_term<4>(av, bvv, j1);
-                    j0 = s3b_term<2>(av, bvv, j0); j1 = s3b_term<5>(av, bvv, j1);
-                    S3_SB();
-                }
-                const f32x4 ej = j0 + j1;
-                redw[32 * 8] = -s3_dot4(ej, epsr);
-                redw[2 * 32 * 8] = s3_dot4(ej, ej);
-            }
-            S3T(10);
-            s3_bar();
-            S3T(11);                                                          // RED complete; h1 / g1 free for the next evaluation
-        }
+#include "cnf_step3b_eval.inc"
         if (single) {
             // ---- one evaluation: f -> out, and the norms of the initial-dt phase over the rows this lane owns ----
             float* out = (single == 1 ? a.du : a.Ks0) + (size_t)(tile * 32 + 16 * hf + s) * D;
@@ -2122,6 +1926,10 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     if (tid < NCB) reinterpret_cast<f32x4*>(lds + s3v::BIAS)[tid] = sgb;
     const int single = 0;                                              // (the evaluation code is k_step3b's)
     (void)single;
+#ifdef S3_STAMPS
+    unsigned long long s3acc[36] = {0};
+    unsigned long long s3last = __builtin_amdgcn_s_memtime();
+#endif
     float errsum = 0.f, badcnt = 0.f;
     // the 8 partials (2 row tiles x 4 lanes) of one sample and one kind sit side by side: two b128 reads each
     auto red8 = [&](int kind) {
@@ -2235,114 +2043,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     int nstg = 1;
     float c21 = 0.f;
     auto evals = [&]() {
-        for (int stg = 1; stg <= nstg; ++stg) {
-            f32x4 d2a, d2b;                                                  // sigma'_2 at this lane's h2 entries (interval 1 -> 3)
-            // ---- interval 0: first layer, tile `wave`, both halves (K = 32: one k-block)
-            {
-                const f32x4 bv1 = *(const f32x4*)(bias + 16 * wave + 4 * q);
-                S3bOp b[2];
-                b[0] = s3b_load(ldsb + s3v::X0S + nb_rd, s3v::NP);
-                b[1] = s3b_load(ldsb + s3v::X0S + nb_rd + HBN, s3v::NP);
-                S3_SB();
-                f32x4 acc[2] = {zero4, zero4};
-                s3b_mm<2>(acc, wF1, b);
-                s3b_store4(ldsb + s3v::H1G + wb_wr, s3v::WP, s3_tanh4(acc[0] + bv1));
-                s3b_store4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP, s3_tanh4(acc[1] + bv1));
-            }
-            s3_bar();
-            // ---- interval 1: second layer, tile `wave`, both halves share the A fragments
-            {
-                const f32x4 bv2 = *(const f32x4*)(bias + 128 + 16 * wave + 4 * q);
-                // scalar rows of the PREVIOUS evaluation from its RED partials (complete since the last barrier of it)
-                if (stg > 1 && sown) sc_set(stg, read_scalars());              // slot j holds k_j
-                f32x4 acc[2] = {zero4, zero4};
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    S3bOp b[2];
-                    b[0] = s3b_load(ldsb + s3v::H1G + (wb_rd ^ (64 * kb)), s3v::WP);
-                    b[1] = s3b_load(ldsb + s3v::H1G + HBW + (wb_rd ^ (64 * kb)), s3v::WP);
-                    S3_SB();
-                    s3b_mm<2>(acc, wF2[kb], b);
-                    S3_SB();
-                }
-                const f32x4 h2a = s3_tanh4(acc[0] + bv2), h2b = s3_tanh4(acc[1] + bv2);
-                d2a = s3_dtanh4(h2a); d2b = s3_dtanh4(h2b);
-                s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, h2a);
-                s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, h2b);
-            }
-            s3_bar();
-            // ---- interval 2: last layer on waves 0-3 (one per SIMD): zdot rows r0..r0+3 of sample smp
-            if (zown) {
-                const f32x4 bv3 = *(const f32x4*)(bias + 256 + r0);
-                f32x4 z0 = zero4, z1 = zero4;                                  // two chains (terms 0-2 / 3-5)
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), s3v::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), s3v::WP);
-                    S3_SB();
-                    z0 = s3b_term<0>(av, bvv, z0); z1 = s3b_term<3>(av, bvv, z1);
-                    z0 = s3b_term<1>(av, bvv, z0); z1 = s3b_term<4>(av, bvv, z1);
-                    z0 = s3b_term<2>(av, bvv, z0); z1 = s3b_term<5>(av, bvv, z1);
-                    S3_SB();
-                }
-                // stage sum without the k this evaluation will produce: pre = u + h sum_{j<stg} a_{stg+1,j} k_j
-                const float* A = tab.a[stg < 6 ? stg + 1 : 6];
-                f32x4 pre = *(const f32x4*)rkw + (hstep * A[0]) * *(const f32x4*)(rkw + 32);
-#pragma unroll
-                for (int j = 1; j < 5; ++j) pre += (hstep * A[j]) * *(const f32x4*)(kzw + 32 * (j - 1));
-                const f32x4 zd = s3_tanh4(z0 + z1 + bv3);                      // padded rows: zero weights and bias -> 0
-                s3b_store4(g3w, s3v::NP, epsr * s3_dtanh4(zd));               // g3 = eps .* sigma'_3
-                if (stg < 6) s3b_store4(x0w, s3v::NP, pre + (hstep * A[stg]) * zd);     // state of the next evaluation
-                *(f32x4*)(kzw + 32 * (stg - 1)) = zd;                          // k_{stg+1}
-                redw[0] = s3_dot4(zd, zd);
-            }
-            s3_bar();
-            // ---- interval 3: reverse of the last layer, tile `wave` of W3^T, both halves (K = 32); g2 over h2 in place
-            {
-                S3bOp b[2];
-                b[0] = s3b_load(ldsb + s3v::G3S + nb_rd, s3v::NP);
-                b[1] = s3b_load(ldsb + s3v::G3S + nb_rd + HBN, s3v::NP);
-                S3_SB();
-                f32x4 acc[2] = {zero4, zero4};
-                s3b_mm<2>(acc, wB3, b);
-                s3b_store4(ldsb + s3v::H2G + wb_wr, s3v::WP, acc[0] * d2a);
-                s3b_store4(ldsb + s3v::H2G + wb_wr + HBW, s3v::WP, acc[1] * d2b);
-            }
-            s3_bar();
-            // ---- interval 4: reverse of the second layer, tile `wave` of W2^T; g1 over h1 in place
-            {
-                const f32x4 h1a = s3b_load4(ldsb + s3v::H1G + wb_wr, s3v::WP), h1b = s3b_load4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP);
-                f32x4 acc[2] = {zero4, zero4};
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    S3bOp b[2];
-                    b[0] = s3b_load(ldsb + s3v::H2G + (wb_rd ^ (64 * kb)), s3v::WP);
-                    b[1] = s3b_load(ldsb + s3v::H2G + HBW + (wb_rd ^ (64 * kb)), s3v::WP);
-                    S3_SB();
-                    s3b_mm<2>(acc, wB2[kb], b);
-                    S3_SB();
-                }
-                s3b_store4(ldsb + s3v::H1G + wb_wr, s3v::WP, acc[0] * s3_dtanh4(h1a));
-                s3b_store4(ldsb + s3v::H1G + wb_wr + HBW, s3v::WP, acc[1] * s3_dtanh4(h1b));
-            }
-            s3_bar();
-            // ---- interval 5: eJ = W1^T g1 on waves 4-7 (one per SIMD): trace and norm partials (src/icnf.jl:334, :343)
-            if (!zown) {
-                f32x4 j0 = zero4, j1 = zero4;
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), s3v::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), s3v::WP);
-                    S3_SB();
-                    j0 = s3b_term<0>(av, bvv, j0); j1 = s3b_term<3>(av, bvv, j1);
-                    j0 = s3b_term<1>(av, bvv, j0); j1 = s3b_term<4>(av, bvv, j1);
-                    j0 = s3b_term<2>(av, bvv, j0); j1 = s3b_term<5>(av, bvv, j1);
-                    S3_SB();
-                }
-                const f32x4 ej = j0 + j1;
-                redw[32 * 8] = -s3_dot4(ej, epsr);
-                redw[2 * 32 * 8] = s3_dot4(ej, ej);
-            }
-            s3_bar();
-        }
+#include "cnf_step3b_eval.inc"
     };
     // (x / sk)^2 onto acc, sk = atol + rtol |u|: the expressions of the single-evaluation launches, digit for digit
     auto add_norm = [&](float& acc, float u, float x) {
@@ -2712,84 +2413,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         redw[2 * 32 * 8] = s3_dot4(tj, tj);
     };
     auto evals = [&]() {
-        for (int stg = 1; stg <= nstg; ++stg) {
-            // ---- interval 0: first layer, tile `wave`, both halves, state and tangent columns (one k-block)
-            {
-                const f32x4 bv1 = *(const f32x4*)(bias + 16 * wave + 4 * q);
-                if (!zown && stg > 1) finish_tau();                            // of the previous evaluation
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    S3bOp b[2];
-                    b[0] = s3b_load(ldsb + s3b::X0B + nb_rd + half * HBN, s3b::NP);
-                    b[1] = s3b_load(ldsb + s3b::T0B + nb_rd + half * HBN, s3b::NP);
-                    S3_SB();
-                    f32x4 acc[2] = {zero4, zero4};
-                    s3b_mm<2>(acc, wF1, b);
-                    const f32x4 h1 = s3_tanh4(acc[0] + bv1);
-                    s3b_store4(ldsb + s3b::H1B + wb_wr + half * HBW, s3b::WP, h1);
-                    s3b_store4(ldsb + s3b::T1B + wb_wr + half * HBW, s3b::WP, s3_dtanh4(h1) * acc[1]);
-                }
-            }
-            s3_bar();                                                          // h1, t1 visible
-            // ---- interval 1: second layer, tile `wave`: half A (state, tangent), then half B; operands one k-block ahead
-            {
-                const f32x4 bv2 = *(const f32x4*)(bias + 128 + 16 * wave + 4 * q);
-                if (stg > 1 && sown) sc_set(stg, read_scalars());              // scalar rows of the PREVIOUS evaluation
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const char* hb = ldsb + s3b::H1B + half * HBW;
-                    const char* tb = ldsb + s3b::T1B + half * HBW;
-                    f32x4 acc[2] = {zero4, zero4};
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) {       // (the other wave of the SIMD covers the LDS latency)
-                        S3bOp rb[2];
-                        rb[0] = s3b_load(hb + (wb_rd ^ (64 * kb)), s3b::WP); rb[1] = s3b_load(tb + (wb_rd ^ (64 * kb)), s3b::WP);
-                        S3_SB();
-                        s3b_mm<2>(acc, wF2[kb], rb);
-                        S3_SB();
-                    }
-                    const f32x4 h2 = s3_tanh4(acc[0] + bv2);
-                    s3b_store4(ldsb + s3b::H2B + wb_wr + half * HBW, s3b::WP, h2);
-                    s3b_store4(ldsb + s3b::T2B + wb_wr + half * HBW, s3b::WP, s3_dtanh4(h2) * acc[1]);
-                }
-            }
-            s3_bar();                                                          // h2, t2 visible
-            // ---- interval 2: last layer, one product per wave: rows r0..r0+3 of sample smp, state (0-3) / tangent (4-7)
-            {
-                const char* xb = ldsb + (zown ? s3b::H2B : s3b::T2B) + 16 * hf * s3b::WS;      // + (wb_rd ^ 64 kb): row smp
-                const f32x4 bv3 = *(const f32x4*)(bias + 256 + r0);
-                // two accumulation chains (terms 0-2 / 3-5): a wave alone on its product would otherwise wait on itself
-                f32x4 z0 = zero4, z1 = zero4;
-                S3bOp b = s3b_load(xb + wb_rd, s3b::WP);
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    const S3bOp bn = s3b_load(xb + (wb_rd ^ (64 * (kb + 1 < 4 ? kb + 1 : kb))), s3b::WP);
-                    S3_SB();
-                    z0 = s3b_term<0>(w3[kb], b, z0); z1 = s3b_term<3>(w3[kb], b, z1);
-                    z0 = s3b_term<1>(w3[kb], b, z0); z1 = s3b_term<4>(w3[kb], b, z1);
-                    z0 = s3b_term<2>(w3[kb], b, z0); z1 = s3b_term<5>(w3[kb], b, z1);
-                    S3_SB();
-                    b = bn;
-                }
-                if (zown) {
-                    // stage sum without the k this evaluation produces: pre = u + h sum_{j<stg} a_{stg+1,j} k_j
-                    const float* A = tab.a[stg < 6 ? stg + 1 : 6];
-                    f32x4 pre = uz + (hstep * A[0]) * kz[0];
-#pragma unroll
-                    for (int jj = 1; jj < 5; ++jj) pre += (hstep * A[jj]) * kz[jj];      // k's not yet produced are zero
-                    const f32x4 zd = s3_tanh4(z0 + z1 + bv3);                  // padded rows: zero weights and bias -> 0
-                    *(f32x4*)g3w = s3_dtanh4(zd);                              // sigma'_3 for the tangent rows
-                    if (stg < 6) { un = pre + (hstep * A[stg]) * zd; s3b_store4(x0w, s3b::NP, un); }   // next stage state
-                    set_k(kz, stg, zd);                                        // k_{stg+1}
-                    redw[0] = s3_dot4(zd, zd);
-                } else {
-                    tacc = z0 + z1;
-                }
-            }
-            s3_bar();                                                          // sigma'_3 (and the next stage state) visible
-        }
-        if (!zown) finish_tau();                           // of the last evaluation
-        s3_bar();                                          // RED of the last evaluation complete
+#include "cnf_step3jb_eval.inc"
     };
     auto add_norm = [&](float& acc, float u, float x) {
         const float sk = fmaf(fabsf(u), reltol, abstol);
