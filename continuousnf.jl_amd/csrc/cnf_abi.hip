@@ -690,7 +690,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     const bool hairer = opts->adaptive && opts->dt == 0.f;
     // The whole solve in one cooperative launch where the handle and the batch allow it (k_solve3b): the weights and the
     // Runge-Kutta rows stay on the CUs for all attempts, the workgroups exchange two floats per attempt.
-    if (use_mfma && !rec && !lockstep) {
+    if (use_mfma && !lockstep) {
         // one such kernel at a time in this process: two of them would each hold CUs the other is waiting for
         static std::mutex persist_mu;
         std::unique_lock<std::mutex> persist_lock(persist_mu);
@@ -702,7 +702,16 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         const bool fused_io = post && post->xs;            // inference: u0 from the data columns and the post-processing in the launch
         if (fused_io) { sv.xs = post->xs; sv.logpx = post->logpx; sv.regs = post->regs; sv.sums5 = post->sums5; }
         else if (u0 != h->U[0]) HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-        s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror, base, sv);
+        // gradient path: every attempt files u_n and its stage states in the slot of step `naccept` (as the streamed
+        // recording does); the store is sized beforehand and the solve repeated if it took more steps than fit
+        float* dump = nullptr; size_t slot = 0; int dcap = 0;
+        if (rec) {
+            if ((s = traj_reserve(h, 64)) != CNF_OK) return s;
+            slot = traj_slot_floats(h); dcap = h->traj_cap;
+            dump = h->traj + n;                      // stage area of slot 0; u_n sits one array before
+        }
+        s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror, base, sv,
+                                  dump, n, slot, dcap, h->traj_hs);
         if (s == CNF_OK) {
             ++launches;
             h->mirror_base = base + 1;
@@ -725,6 +734,15 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                     if (qe == hipSuccess && !(cnf_mirror_read(hm, &fin, &sq) && sq == base))
                         return fail(h, CNF_ERR_HIP, "the solve kernel finished without publishing a state");
                 }
+            }
+            if (rec) {                               // step sizes back from the device
+                rec->n = fin.naccept;
+                rec->overflow = fin.naccept > h->traj_cap;
+                rec->hs.assign((size_t)(rec->overflow ? 0 : fin.naccept), 0.f);
+                if (!rec->overflow && fin.naccept > 0)
+                    HIPCHK(h, hipMemcpyAsync(rec->hs.data(), h->traj_hs, (size_t)fin.naccept * sizeof(float),
+                                             hipMemcpyDeviceToHost, st));
+                final_sync = true;
             }
             const int attempts = fin.naccept + fin.nreject;
             h->persist_base += (unsigned)((hairer ? 2 : 0) + attempts + (fused_io && post->sums5 ? 1 : 0));

@@ -93,6 +93,8 @@ struct Solve3Args {
 // columns to assemble u0 from and the outputs of the post-processing; st_out: the final state (cur = 0: the final columns
 // are in U[0])
 cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st_out, float* const U[2],
-                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv);
+                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv,
+                                 float* dump = nullptr, size_t dump_stride = 0, size_t dump_step_stride = 0, int dump_cap = 0,
+                                 float* hs_out = nullptr);     // dump ...: the trajectory store of the gradient path (as mfma_step)
 // workgroups (= error partials) of a step launch; `recording`: the solve files its stage states (gradient path)
 int mfma_grid_for(const MfmaPlan& p, int B, bool recording = false, bool train = true);

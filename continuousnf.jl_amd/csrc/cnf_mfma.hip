@@ -1558,7 +1558,8 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, con
 // 32-column tile per CU.  CNF_ERR_UNSUPPORTED: not this handle / batch, or the
 // device cannot place the grid right now -- the caller streams step launches instead.  CNF_PERSISTENT=0 switches it off.
 cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st_out, float* const U[2],
-                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv) {
+                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv,
+                                 float* dump, size_t dump_stride, size_t dump_step_stride, int dump_cap, float* hs_out) {
     static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); return e && e[0] == '0'; }();
     static const bool fp32_only = [] { const char* e = getenv("CNF_STEP_FP32"); return e && e[0] == '1'; }();
     static const int n_cu = [] {
@@ -1569,7 +1570,8 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     // k_solve3jb (one forward sweep of state and tangent columns): JVP handles, and VJP handles without the |eps^T J| row
     // (FFJORD: zdot and ldot do not depend on the mode); k_solve3b: VJP handles with that row
     const bool vjp_ok = p.variant == 2 && !p.ly.jvp;
-    const bool jvp = (p.shape3 && p.ly.jvp) || (vjp_ok && !p.ly.norm_j);
+    const bool jvp = (p.shape3 && p.ly.jvp) || (vjp_ok && !p.ly.norm_j && !dump);
+    if (dump && !vjp_ok) return CNF_ERR_UNSUPPORTED;       // recording (gradient path): the VJP kernel only
     if (off || fp32_only || step_v1() || !train || p.cond || !p.d_img3b || !(jvp || vjp_ok))
         return CNF_ERR_UNSUPPORTED;
     const int ntile = (B + 31) / 32;
@@ -1580,6 +1582,7 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     a.n_total = (float)((size_t)(nd.n_in + 3) * B);
     a.U[0] = U[0]; a.U[1] = U[1];
     a.mirror = mirror; a.seq = seq;
+    a.dump = dump; a.dump_stride = dump_stride; a.dump_step_stride = dump_step_stride; a.dump_cap = dump_cap; a.hs_out = hs_out;
     sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
     return step3b_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, ntile, s, sv, jvp);
 }

@@ -1722,6 +1722,9 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
         s3_bar();
         S3T(21);
 
+        constexpr bool S3B_RECORDS = false;                // (recording launches stay on k_mfma)
+        float* const dmpw = nullptr; const size_t dmp_stride = 0;
+        (void)dmpw; (void)dmp_stride;
 #include "cnf_step3b_eval.inc"
         if (single) {
             // ---- one evaluation: f -> out, and the norms of the initial-dt phase over the rows this lane owns ----
@@ -1848,6 +1851,9 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 // workgroup per CU: B <= 32 x CUs, cooperative launch); every wait is bounded, so a lost workgroup ends the launch with
 // an error word instead of hanging it.  Results are bit-identical to the streamed solve (same sums, same order).
 // ---------------------------------------------------------------------------------------------------------------
+// RECORD (gradient path): every attempt files u_n and its stage states U_2..U_6 (z rows) in the trajectory slot of step
+// `naccept` (a.dump, as the recording launches of k_mfma do), its signed step size in a.hs_out.
+template <bool RECORD>
 __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __restrict__ imgb, int n_in, int norm_z,
                                                     int norm_j, const S3Tab tab, Solve3Args sv) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2042,7 +2048,10 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     // one evaluation at the state image in place; zdot -> the k2 slot, scalar rows from the RED partials
     int nstg = 1;
     float c21 = 0.f;
+    float* dmpw = nullptr;                                 // RECORD: this lane's rows of the current step's slot (null: not filed)
+    const size_t dmp_stride = a.dump_stride;
     auto evals = [&]() {
+        constexpr bool S3B_RECORDS = RECORD;
 #include "cnf_step3b_eval.inc"
     };
     // (x / sk)^2 onto acc, sk = atol + rtol |u|: the expressions of the single-evaluation launches, digit for digit
@@ -2106,12 +2115,23 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     }
     // ---- step attempts ----
     int done = 0;
+    int nacc = 0;                                          // accepted steps so far (the same count in every workgroup)
     for (int it = 0; alive && !done && it < sv.maxiters; ++it) {
         if (zown) {
-            s3b_store4(x0w, s3v::NP, *(const f32x4*)rkw + (hstep * TS_A21) * *(const f32x4*)(rkw + 32));   // U_2 = u + h a21 k1
+            const f32x4 u2 = *(const f32x4*)rkw + (hstep * TS_A21) * *(const f32x4*)(rkw + 32);
+            s3b_store4(x0w, s3v::NP, u2);                                    // U_2 = u + h a21 k1
 #pragma unroll
             for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;
+            if (RECORD) {
+                dmpw = (live && nacc < a.dump_cap) ? a.dump + (size_t)nacc * a.dump_step_stride + gcol + r0 : nullptr;
+                if (dmpw && nv > 0) {
+                    const f32x4 un_ = *(const f32x4*)rkw;
+                    if (nv >= 4) { st4_wide(dmpw - dmp_stride, un_); st4_wide(dmpw, u2); }
+                    else { st4(dmpw - dmp_stride, un_, nv); st4(dmpw, u2, nv); }
+                }
+            }
         }
+        if (RECORD && blockIdx.x == 0 && tid == 0 && nacc < a.dump_cap) a.hs_out[nacc] = hstep;
         s3_bar();
         nstg = 6; evals();
         float errsum = 0.f, badcnt = 0.f;
@@ -2149,6 +2169,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
         const int fl = share();
         done = fl & 1;
         if (fl & 2) {                                                      // accepted: u <- u_new, k1 <- k7 (FSAL)
+            ++nacc;
             if (zown) {
                 *(f32x4*)rkw = s3b_load4(x0w, s3v::NP);
                 *(f32x4*)(rkw + 32) = *(const f32x4*)(kzw + 32 * 5);
@@ -2632,12 +2653,15 @@ cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, 
                                const Solve3Args& sv_, bool jvp) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_solve3b, hipFuncAttributeMaxDynamicSharedMemorySize, s3v::TOTAL_BYTES) != hipSuccess ||
+        if (hipFuncSetAttribute((const void*)k_solve3b<false>, hipFuncAttributeMaxDynamicSharedMemorySize, s3v::TOTAL_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_solve3b<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s3v::TOTAL_BYTES) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_solve3jb, hipFuncAttributeMaxDynamicSharedMemorySize, s3b::TOTAL_BYTES) != hipSuccess)
             return CNF_ERR_HIP;
         attr = true;
     }
-    const void* fn = jvp ? (const void*)k_solve3jb : (const void*)k_solve3b;
+    const bool record = a.dump != nullptr;                 // (the JVP kernel does not record)
+    if (record && jvp) return CNF_ERR_UNSUPPORTED;
+    const void* fn = jvp ? (const void*)k_solve3jb : (record ? (const void*)k_solve3b<true> : (const void*)k_solve3b<false>);
     const size_t shm = jvp ? s3b::TOTAL_BYTES : s3v::TOTAL_BYTES;
     MfmaArgs a_ = a;
     const char* img = (const char*)d_imgb;
