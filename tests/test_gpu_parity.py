@@ -736,6 +736,21 @@ def test_one_launch_solve_takes_the_headline_shape_and_agrees_with_the_streamed_
         lp2, _ = cnf.inference(make_icnf(cnf, c, jvp=jvp, kernel="generic", sol_kwargs=dict(adaptive=False, dt=1 / 8)),
                                cnf.TrainMode(), xs[:, sub].contiguous(), fl, {}, eps=eps[:, sub].contiguous())
         assert torch.allclose(logpx[sub], lp2, rtol=2e-5, atol=2e-5), (jvp, float((logpx[sub] - lp2).abs().max()))
+    # cnf_solve_kernel_time: the kernel's own clock, summed on the device while enabled
+    import ctypes as C
+    ic = make_icnf(cnf, cfg, sol_kwargs=dict(adaptive=False, dt=1 / 8))
+    xs, eps = _dev(rng.standard_normal((cfg.nvars, 512))), _dev(rng.standard_normal((cfg.n_in, 512)))
+    cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    l, hh = _lib.lib(), ic.handle()
+    _lib.check(l.cnf_solve_kernel_time(hh, 1, None, None), hh)
+    for _ in range(3):
+        cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    us, k = C.c_float(), C.c_int()
+    _lib.check(l.cnf_solve_kernel_time(hh, 0, C.byref(us), C.byref(k)), hh)
+    assert k.value == (3 if persistent else 0) and (20.0 < us.value < 5000.0 if persistent else us.value == 0.0), (k.value, us.value)
+    cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    _lib.check(l.cnf_solve_kernel_time(hh, 0, C.byref(us), C.byref(k)), hh)
+    assert k.value == 0                                    # switched off: nothing is counted
     # maxiters inside the launch
     ic = make_icnf(cnf, cfg, sol_kwargs=dict(reltol=3.45e-4, abstol=1.19e-7, maxiters=3))
     xs, eps = _dev(rng.standard_normal((cfg.nvars, 256))), _dev(rng.standard_normal((cfg.n_in, 256)))
