@@ -23,12 +23,15 @@ FULL_US = 30.0                        # anything shorter did not do a full step:
                                       # single-evaluation launches of the automatic initial dt 19 us, a step 50 us
 
 
-SOLVE = "k_solve3b("                  # the one-launch solve: when it ran, IT is the headline kernel (a launch = a whole solve)
+def is_solve(kname):
+    # the one-launch solve (the plain instantiation, not the recording one of the gradient path): when it ran, IT is the
+    # headline kernel (a launch = a whole solve)
+    return "k_solve3b<false>(" in kname or kname.startswith("k_solve3b(")
 
 
 def is_step(kname):
     if HAVE_SOLVE:
-        return kname.startswith(SOLVE)
+        return is_solve(kname)
     return is_step_launch(kname)
 
 
@@ -55,7 +58,7 @@ _tr0 = None
 for _g in glob.glob(os.path.join(SRC, "bench/**/*kernel_trace.csv"), recursive=True):
     _tr0 = _g if _tr0 is None or os.path.getmtime(_g) > os.path.getmtime(_tr0) else _tr0
 if _tr0:
-    HAVE_SOLVE = any(r["Kernel_Name"].startswith(SOLVE) for r in csv.DictReader(open(_tr0)))
+    HAVE_SOLVE = any(is_solve(r["Kernel_Name"]) for r in csv.DictReader(open(_tr0)))
 st = first("bench/**/*kernel_stats.csv")
 if st:
     rows = list(csv.DictReader(open(st)))
