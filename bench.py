@@ -310,8 +310,10 @@ def run_rank(args):
         if kernel_used == _lib.KERNEL_MFMA and os.path.exists(pmc) and B == 8192:
             rec = json.load(open(pmc))
             traffic = rec.get("hbm_bytes_per_launch")
-            traffic_source = (f"{PMC_FILE} (rocprofv3 --pmc passes of tools/collect_profiles.sh, full-step launches "
-                              f"only; built from commit {rec.get('commit', '?')}); not measured in this run")
+            traffic_source = (f"{PMC_FILE} (rocprofv3 --pmc passes of tools/collect_profiles.sh over launches of "
+                              f"'{rec.get('kernel', '?')}'; built from commit {rec.get('commit', '?')}); not measured in this run")
+            if ("k_solve3b" in rec.get("kernel", "")) != ("k_solve3b" in kname):
+                traffic, traffic_source = None, None        # the committed counters are of the other driver's kernel
         tf = units * fl.value / per_launch_s / 1e12
         gbs = units * by.value / per_launch_s / 1e9
         # The step kernel of the headline shape forms every fp32 product from six bf16 MFMA terms on operands split EXACTLY
