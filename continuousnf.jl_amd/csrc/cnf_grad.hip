@@ -22,6 +22,7 @@
 // DESIGN.md section 4.4 has the measurements.
 #include "cnf_grad.h"
 #include "cnf_am.h"
+#include "cnf_split.h"
 #include <cstdlib>
 
 
@@ -486,6 +487,108 @@ k_wgrad_mfma(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const floa
     if (ti == 0 && t < WG_T && o0 + t < out) g[nd.b_off[l] + o0 + t] += bsum;
 }
 
+// The same contraction with every fp32 product formed from six bf16 MFMA terms on exactly split operands
+// (v_mfma_f32_16x16x32_bf16: 32 samples per instruction; accuracy of the fp32 MFMA, cnf_split.h).  A thread fetches 8
+// consecutive samples of one column of each of the four factor arrays (the next 32 samples travel while the current ones
+// are multiplied), splits them and stores the three pieces as 16-byte chunks of [piece][column][32 samples] images whose
+// chunks are XOR-swizzled by the column, so that the operand reads (lane (q, x): column 16 tile + x, chunk q) have no
+// bank conflicts.  Output tile, K-splits and the reduction over them are those of k_wgrad_mfma.
+#define WB_K 32
+__global__ void __launch_bounds__(256)
+k_wgrad_mfma_b(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const float* __restrict__ PB,
+               const float* __restrict__ HS, const float* __restrict__ TSb, float* __restrict__ gpart,
+               int n_params, int B, int chunk) {
+    constexpr int PIECE = WG_T * 64;                                   // one piece of one array: 64 columns x 64 bytes
+    __shared__ __attribute__((aligned(16))) char simg[4 * 3 * PIECE];  // A | P | H | T, three pieces each (48 KB)
+    __shared__ float sbias[4][WG_T];
+    int tile = blockIdx.x, l = 0, to_ = 0, ti = 0;
+    for (; l < nd.n_layers; ++l) {
+        const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
+        const int no = (out + WG_T - 1) / WG_T, ni = (in + WG_T - 1) / WG_T;
+        if (tile < no * ni) { to_ = tile / ni; ti = tile % ni; break; }
+        tile -= no * ni;
+    }
+    if (l == nd.n_layers) return;
+    const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
+    const int o0 = to_ * WG_T, i0 = ti * WG_T;
+    const int oo = gl.out_off[l], io = gl.in_off[l];
+    const int k0 = blockIdx.y * chunk, k1 = min(B, k0 + chunk);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, x = lane & 15, q = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const int lc = t & 63, lr = t >> 6;                     // this thread: column lc, samples 8 lr .. 8 lr + 7 of a chunk
+    const bool co = o0 + lc < out, ci = i0 + lc < in;
+    float ra[8], rp[8], rh[8], rt[8];
+    auto fetch = [&](int kb) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int b = kb + 8 * lr + j;
+            const bool vb = b < k1;
+            ra[j] = (vb && co) ? AB[(size_t)b * gl.sum_out + oo + o0 + lc] : 0.f;
+            rp[j] = (vb && co) ? PB[(size_t)b * gl.sum_out + oo + o0 + lc] : 0.f;
+            rh[j] = (vb && ci) ? HS[(size_t)b * gl.sum_in + io + i0 + lc] : 0.f;
+            rt[j] = (vb && ci) ? TSb[(size_t)b * gl.sum_in + io + i0 + lc] : 0.f;
+        }
+    };
+    // chunk c (8 samples) of column r at chunk position c ^ ((-(r >> 2)) & 3) of its 64-byte row
+    auto put = [&](int arr, const float (&v)[8]) {
+        bf16x8 h, m, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { __bf16 a_, b_, c_; s3b_split(v[j], a_, b_, c_); h[j] = a_; m[j] = b_; lo[j] = c_; }
+        char* d = simg + arr * 3 * PIECE + lc * 64 + 16 * (lr ^ ((-(lc >> 2)) & 3));
+        *(bf16x8*)d = h; *(bf16x8*)(d + PIECE) = m; *(bf16x8*)(d + 2 * PIECE) = lo;
+    };
+    struct Op { bf16x8 h, m, l; };
+    auto get = [&](int arr, int col) {                      // operand of this lane: column `col`, samples 8q .. 8q + 7
+        const char* d = simg + arr * 3 * PIECE + col * 64 + 16 * (q ^ ((-(col >> 2)) & 3));
+        Op o; o.h = *(const bf16x8*)d; o.m = *(const bf16x8*)(d + PIECE); o.l = *(const bf16x8*)(d + 2 * PIECE);
+        return o;
+    };
+    auto mm6 = [&](const Op& a, const Op& b, f32x4 c) {     // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+    };
+    fetch(k0);
+    for (int kb = k0; kb < k1; kb += WB_K) {
+        if (ti == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum += ra[j];
+        }
+        put(0, ra); put(1, rp); put(2, rh); put(3, rt);
+        __syncthreads();
+        if (kb + WB_K < k1) fetch(kb + WB_K);
+        const Op bh = get(2, 16 * w + x), bt = get(3, 16 * w + x);
+#pragma unroll
+        for (int to = 0; to < 4; ++to) {
+            const Op aa = get(0, 16 * to + x), ap = get(1, 16 * to + x);
+            acc[to] = mm6(aa, bh, acc[to]);
+            acc[to] = mm6(ap, bt, acc[to]);
+        }
+        __syncthreads();
+    }
+    float* g = gpart + (size_t)blockIdx.y * n_params;
+    const int i = i0 + 16 * w + x;
+#pragma unroll
+    for (int to = 0; to < 4; ++to) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = o0 + 16 * to + 4 * q + j;
+            if (o < out && i < in) g[nd.w_off[l] + o + (size_t)i * out] += acc[to][j];
+        }
+    }
+    if (ti == 0) {                                          // bias: the column sums of abar, four sample groups per column
+        sbias[lr][lc] = bsum;
+        __syncthreads();
+        if (t < WG_T && o0 + t < out) g[nd.b_off[l] + o0 + t] += (sbias[0][t] + sbias[1][t]) + (sbias[2][t] + sbias[3][t]);
+    }
+}
+
 // grad[p] = sum over the K-splits, in a fixed order
 __global__ void k_grad_reduce(const float* __restrict__ gpart, float* __restrict__ grad, int n_params, int ksplit) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -605,15 +708,19 @@ void grad_ksplit(const NetDesc& nd, const GradLayout& g, int B, int* ksplit, int
     if (ks > GRAD_MAX_KSPLIT) ks = GRAD_MAX_KSPLIT;
     if (ks < 1) ks = 1;
     int ch = (B + ks - 1) / ks;
-    ch = (ch + WG_K - 1) / WG_K * WG_K;
+    ch = (ch + WB_K - 1) / WB_K * WB_K;                  // whole 32-sample groups (a multiple of the fp32 kernels' 16 too)
     ks = (B + ch - 1) / ch;
     *ksplit = ks; *chunk = ch;
 }
 
 hipError_t launch_wgrad(const NetDesc& nd, const GradLayout& g, const float* AB, const float* PB, const float* HS,
                         const float* TS, float* gpart, int n_params, int B, int ksplit, int chunk, hipStream_t s) {
-    static const bool valu = getenv("CNF_WGRAD_VALU") != nullptr;     // A/B switch; default: MFMA
-    if (valu)
+    static const bool valu = getenv("CNF_WGRAD_VALU") != nullptr;     // A/B switches; default: split-bf16 MFMA
+    static const bool fp32 = getenv("CNF_WGRAD_FP32") != nullptr;
+    if (!valu && !fp32)
+        hipLaunchKernelGGL(k_wgrad_mfma_b, dim3(grad_wgrad_tiles(nd, g), ksplit), dim3(256), 0, s, nd, g, AB, PB, HS, TS,
+                           gpart, n_params, B, chunk);
+    else if (valu)
         hipLaunchKernelGGL(k_wgrad, dim3(grad_wgrad_tiles(nd, g), ksplit), dim3(256), 0, s, nd, g, AB, PB, HS, TS, gpart,
                            n_params, B, chunk);
     else

@@ -22,6 +22,7 @@
 // LDS images are [sample][feature] with row strides == 8 (mod 16) floats: conflict-free ds_read_b128 B operands;
 // an accumulator tile is stored with one ds_write_b128 per lane (lane = sample, 4 rows).
 #include "cnf_step3.h"
+#include "cnf_split.h"
 
 namespace s3 {
 constexpr int NB = 32, P0 = 32, PH = 128;
@@ -1089,8 +1090,7 @@ __global__ void __launch_bounds__(512, 2) k_step3j(MfmaArgs a, const float* __re
 // (k_pack_step3b); activations are split in the epilogues and live in LDS as three bf16 images [sample][feature].
 // The Runge-Kutta rows of z live in registers here (the images take their LDS).
 // ---------------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// (bf16x8 / bf16x4 and the three-piece split s3b_split: cnf_split.h)
 namespace s3b {
 // fp32 regions (float offsets), then the bf16 images (byte offsets)
 constexpr int G3 = 0, EPS = G3 + 32 * 40, RED = EPS + 32 * 40, SC = RED + 3 * 32 * 8, BIAS = SC + 32 * 24;
@@ -1115,18 +1115,6 @@ constexpr int IMG_BYTES = W3I + 2 * WI;
 static_assert(F32 % 16 == 0 && W3I % 16 == 0, "16-byte loads");
 }  // namespace s3g
 
-// v = h + m + l exactly: pieces by TRUNCATION (one AND each: the upper 16 bits of an fp32 are a bf16), residuals by exact
-// subtractions; the last residual has at most 8 significant bits, so its upper half is all of it.  (Round-to-nearest
-// pieces cost a convert and a widen each and buy nothing: the three products left out are below 2^-24 either way.)
-__device__ __forceinline__ void s3b_split(float v, __bf16& h, __bf16& m, __bf16& l) {
-    const unsigned hb = __float_as_uint(v) & 0xFFFF0000u;
-    const float r1 = v - __uint_as_float(hb);
-    const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(mb);
-    h = __builtin_bit_cast(__bf16, (unsigned short)(hb >> 16));
-    m = __builtin_bit_cast(__bf16, (unsigned short)(mb >> 16));
-    l = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(r2) >> 16));
-}
 // 4 rows of one sample -> the three images (8 bytes each)
 __device__ __forceinline__ void s3b_store4(char* img, int piece_bytes, const f32x4& v) {
     bf16x4 h, m, l;
