@@ -494,50 +494,62 @@ k_wgrad_mfma(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const floa
 // chunks are XOR-swizzled by the column, so that the operand reads (lane (q, x): column 16 tile + x, chunk q) have no
 // bank conflicts.  Output tile, K-splits and the reduction over them are those of k_wgrad_mfma.
 #define WB_K 32
+// TS = 16-column groups per side of the output tile (4: 64 x 64, what launch_wgrad uses; 8: 128 x 128).  Tiles narrower
+// than that skip their empty strips.
+template <int TS>
 __global__ void __launch_bounds__(256)
 k_wgrad_mfma_b(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const float* __restrict__ PB,
                const float* __restrict__ HS, const float* __restrict__ TSb, float* __restrict__ gpart,
                int n_params, int B, int chunk) {
-    constexpr int PIECE = WG_T * 64;                                   // one piece of one array: 64 columns x 64 bytes
-    __shared__ __attribute__((aligned(16))) char simg[4 * 3 * PIECE];  // A | P | H | T, three pieces each (48 KB)
-    __shared__ float sbias[4][WG_T];
+    constexpr int T = 16 * TS, CP = T / 64, NSW = TS / 4;              // tile side; columns per thread; strips per wave
+    constexpr int PIECE = T * 64;                                      // one piece of one array: T columns x 64 bytes
+    extern __shared__ __attribute__((aligned(16))) char simg[];        // A | P | H | T, three pieces each; then the bias sums
+    float* sbias = reinterpret_cast<float*>(simg + 4 * 3 * PIECE);     // [4][T]
     int tile = blockIdx.x, l = 0, to_ = 0, ti = 0;
     for (; l < nd.n_layers; ++l) {
         const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
-        const int no = (out + WG_T - 1) / WG_T, ni = (in + WG_T - 1) / WG_T;
+        const int no = (out + T - 1) / T, ni = (in + T - 1) / T;
         if (tile < no * ni) { to_ = tile / ni; ti = tile % ni; break; }
         tile -= no * ni;
     }
     if (l == nd.n_layers) return;
     const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
-    const int o0 = to_ * WG_T, i0 = ti * WG_T;
+    const int o0 = to_ * T, i0 = ti * T;
     const int oo = gl.out_off[l], io = gl.in_off[l];
     const int k0 = blockIdx.y * chunk, k1 = min(B, k0 + chunk);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, x = lane & 15, q = lane >> 4;
-    f32x4 acc[4];
+    const int nto = min(TS, (out - o0 + 15) / 16);                     // 16-row groups of the tile that exist
+    f32x4 acc[NSW][TS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-    const int lc = t & 63, lr = t >> 6;                     // this thread: column lc, samples 8 lr .. 8 lr + 7 of a chunk
-    const bool co = o0 + lc < out, ci = i0 + lc < in;
-    float ra[8], rp[8], rh[8], rt[8];
+    for (int a = 0; a < NSW; ++a)
+#pragma unroll
+        for (int i = 0; i < TS; ++i) acc[a][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) bsum[c] = 0.f;
+    const int lc = t & 63, lr = t >> 6;                     // this thread: columns lc (+ 64), samples 8 lr .. 8 lr + 7 of a chunk
+    float ra[CP][8], rp[CP][8], rh[CP][8], rt[CP][8];
     auto fetch = [&](int kb) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int b = kb + 8 * lr + j;
-            const bool vb = b < k1;
-            ra[j] = (vb && co) ? AB[(size_t)b * gl.sum_out + oo + o0 + lc] : 0.f;
-            rp[j] = (vb && co) ? PB[(size_t)b * gl.sum_out + oo + o0 + lc] : 0.f;
-            rh[j] = (vb && ci) ? HS[(size_t)b * gl.sum_in + io + i0 + lc] : 0.f;
-            rt[j] = (vb && ci) ? TSb[(size_t)b * gl.sum_in + io + i0 + lc] : 0.f;
+        for (int c = 0; c < CP; ++c) {
+            const bool co = o0 + lc + 64 * c < out, ci = i0 + lc + 64 * c < in;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int b = kb + 8 * lr + j;
+                const bool vb = b < k1;
+                ra[c][j] = (vb && co) ? AB[(size_t)b * gl.sum_out + oo + o0 + lc + 64 * c] : 0.f;
+                rp[c][j] = (vb && co) ? PB[(size_t)b * gl.sum_out + oo + o0 + lc + 64 * c] : 0.f;
+                rh[c][j] = (vb && ci) ? HS[(size_t)b * gl.sum_in + io + i0 + lc + 64 * c] : 0.f;
+                rt[c][j] = (vb && ci) ? TSb[(size_t)b * gl.sum_in + io + i0 + lc + 64 * c] : 0.f;
+            }
         }
     };
     // chunk c (8 samples) of column r at chunk position c ^ ((-(r >> 2)) & 3) of its 64-byte row
-    auto put = [&](int arr, const float (&v)[8]) {
+    auto put = [&](int arr, int col, const float (&v)[8]) {
         bf16x8 h, m, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { __bf16 a_, b_, c_; s3b_split(v[j], a_, b_, c_); h[j] = a_; m[j] = b_; lo[j] = c_; }
-        char* d = simg + arr * 3 * PIECE + lc * 64 + 16 * (lr ^ ((-(lc >> 2)) & 3));
+        char* d = simg + arr * 3 * PIECE + col * 64 + 16 * (lr ^ ((-(col >> 2)) & 3));
         *(bf16x8*)d = h; *(bf16x8*)(d + PIECE) = m; *(bf16x8*)(d + 2 * PIECE) = lo;
     };
     struct Op { bf16x8 h, m, l; };
@@ -556,36 +568,52 @@ k_wgrad_mfma_b(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const fl
     };
     fetch(k0);
     for (int kb = k0; kb < k1; kb += WB_K) {
-        if (ti == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bsum += ra[j];
+        for (int c = 0; c < CP; ++c) {
+            if (ti == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum[c] += ra[c][j];
+            }
+            put(0, lc + 64 * c, ra[c]); put(1, lc + 64 * c, rp[c]); put(2, lc + 64 * c, rh[c]); put(3, lc + 64 * c, rt[c]);
         }
-        put(0, ra); put(1, rp); put(2, rh); put(3, rt);
         __syncthreads();
         if (kb + WB_K < k1) fetch(kb + WB_K);
-        const Op bh = get(2, 16 * w + x), bt = get(3, 16 * w + x);
 #pragma unroll
-        for (int to = 0; to < 4; ++to) {
-            const Op aa = get(0, 16 * to + x), ap = get(1, 16 * to + x);
-            acc[to] = mm6(aa, bh, acc[to]);
-            acc[to] = mm6(ap, bt, acc[to]);
+        for (int a = 0; a < NSW; ++a) {
+            const int strip = w + 4 * a;                               // this wave's a-th 16-column strip of the input side
+            if (i0 + 16 * strip < in) {                                // (wave-uniform)
+                const Op bh = get(2, 16 * strip + x), bt = get(3, 16 * strip + x);
+#pragma unroll
+                for (int to = 0; to < TS; ++to) {
+                    if (to < nto) {
+                        const Op aa = get(0, 16 * to + x), ap = get(1, 16 * to + x);
+                        acc[a][to] = mm6(aa, bh, acc[a][to]);
+                        acc[a][to] = mm6(ap, bt, acc[a][to]);
+                    }
+                }
+            }
         }
         __syncthreads();
     }
     float* g = gpart + (size_t)blockIdx.y * n_params;
-    const int i = i0 + 16 * w + x;
 #pragma unroll
-    for (int to = 0; to < 4; ++to) {
+    for (int a = 0; a < NSW; ++a) {
+        const int i = i0 + 16 * (w + 4 * a) + x;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = o0 + 16 * to + 4 * q + j;
-            if (o < out && i < in) g[nd.w_off[l] + o + (size_t)i * out] += acc[to][j];
+        for (int to = 0; to < TS; ++to) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = o0 + 16 * to + 4 * q + j;
+                if (o < out && i < in) g[nd.w_off[l] + o + (size_t)i * out] += acc[a][to][j];
+            }
         }
     }
     if (ti == 0) {                                          // bias: the column sums of abar, four sample groups per column
-        sbias[lr][lc] = bsum;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) sbias[lr * T + lc + 64 * c] = bsum[c];
         __syncthreads();
-        if (t < WG_T && o0 + t < out) g[nd.b_off[l] + o0 + t] += (sbias[0][t] + sbias[1][t]) + (sbias[2][t] + sbias[3][t]);
+        for (int c = t; c < T; c += 256)
+            if (o0 + c < out) g[nd.b_off[l] + o0 + c] += (sbias[c] + sbias[T + c]) + (sbias[2 * T + c] + sbias[3 * T + c]);
     }
 }
 
@@ -717,9 +745,26 @@ hipError_t launch_wgrad(const NetDesc& nd, const GradLayout& g, const float* AB,
                         const float* TS, float* gpart, int n_params, int B, int ksplit, int chunk, hipStream_t s) {
     static const bool valu = getenv("CNF_WGRAD_VALU") != nullptr;     // A/B switches; default: split-bf16 MFMA
     static const bool fp32 = getenv("CNF_WGRAD_FP32") != nullptr;
-    if (!valu && !fp32)
-        hipLaunchKernelGGL(k_wgrad_mfma_b, dim3(grad_wgrad_tiles(nd, g), ksplit), dim3(256), 0, s, nd, g, AB, PB, HS, TS,
-                           gpart, n_params, B, chunk);
+    if (!valu && !fp32) {
+        // 64 x 64 output tiles.  (128 x 128 -- every factor column read by one workgroup per K-split, 1.11x instead of
+        // 1.56x the minimum traffic -- was measured: 96 KB of LDS leave one workgroup per CU and the launch 1.5 rounds of
+        // them; the gradient went from 4.76 to 5.59 ms.)
+        constexpr int TSB = 4, TB = 16 * TSB;
+        constexpr size_t shm = (size_t)4 * 3 * TB * 64 + 4 * TB * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)k_wgrad_mfma_b<TSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+                return hipGetLastError();
+            attr = true;
+        }
+        int tiles = 0;
+        for (int l = 0; l < nd.n_layers; ++l) {
+            const int in = l == 0 ? g.in0 : nd.dims[l], out = nd.dims[l + 1];
+            tiles += ((out + TB - 1) / TB) * ((in + TB - 1) / TB);
+        }
+        hipLaunchKernelGGL(k_wgrad_mfma_b<TSB>, dim3(tiles, ksplit), dim3(256), shm, s, nd, g, AB, PB, HS, TS, gpart, n_params,
+                           B, chunk);
+    }
     else if (valu)
         hipLaunchKernelGGL(k_wgrad, dim3(grad_wgrad_tiles(nd, g), ksplit), dim3(256), 0, s, nd, g, AB, PB, HS, TS, gpart,
                            n_params, B, chunk);
