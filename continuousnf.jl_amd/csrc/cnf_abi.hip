@@ -1288,10 +1288,9 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
     h->last_hs = rec.hs;
     launch_post(nd, 1, fsol, h->tmp_logpx, h->tmp_regs, B, st);
     launch_loss_sums(h->tmp_logpx, h->tmp_regs, B, h->d_sums, st);     // 5 floats; d_sums holds 8
-    float sums[5];
+    // (the five sums travel to the host behind the backward pass: the loss VALUE is not needed to start it)
+    float* sums = reinterpret_cast<float*>(&h->h_state[2]);             // pinned; the initial-state slot is free by now
     HIPCHK(h, hipMemcpyAsync(sums, h->d_sums, 5 * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    if ((s = cnf_loss_from_sums(h, mode, sums, loss_out)) != CNF_OK) return s;
 
     // ---- backward: discrete adjoint of the recorded steps ---------------------------------------
     // capacity is in samples of cap_B; with B <= cap_B at least grad_fsteps steps fit
@@ -1357,6 +1356,7 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
     }
     HIPCHK(h, launch_grad_reduce(h->g_part, grad, (int)h->n_params, ksplit, st));
     HIPCHK(h, hipStreamSynchronize(st));
+    if ((s = cnf_loss_from_sums(h, mode, sums, loss_out)) != CNF_OK) return s;
     if (stats) *stats = sst;
     return CNF_OK;
 }
