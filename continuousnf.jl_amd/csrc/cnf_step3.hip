@@ -1924,7 +1924,6 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     unsigned long long s3acc[36] = {0};
     unsigned long long s3last = __builtin_amdgcn_s_memtime();
 #endif
-    float errsum = 0.f, badcnt = 0.f;
     // the 8 partials (2 row tiles x 4 lanes) of one sample and one kind sit side by side: two b128 reads each
     auto red8 = [&](int kind) {
         const float* r = lds + s3v::RED + (kind * 32 + smp) * 8;
@@ -2035,7 +2034,6 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     };
     // one evaluation at the state image in place; zdot -> the k2 slot, scalar rows from the RED partials
     int nstg = 1;
-    float c21 = 0.f;
     float* dmpw = nullptr;                                 // RECORD: this lane's rows of the current step's slot (null: not filed)
     const size_t dmp_stride = a.dump_stride;
     auto evals = [&]() {
@@ -2315,7 +2313,6 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
     if (tid < NCB) reinterpret_cast<f32x4*>(lds + s3b::BIAS)[tid] = sgb;
     const int single = 0;
     (void)single;
-    float errsum = 0.f, badcnt = 0.f;
     auto red8 = [&](int kind) {
         const float* r = lds + s3b::RED + (kind * 32 + smp) * 8;
         const f32x4 a_ = *(const f32x4*)r, b_ = *(const f32x4*)(r + 4);
