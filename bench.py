@@ -102,11 +102,14 @@ def cpu_baseline(B, flat, xs, eps, kw, budget_s=9.0):
     cfg, _, _ = O.baseline_cfg(3)
     u0 = O.inference_u0(cfg, xs, True)
     nthr, _ = BL.tune_threads(cfg, flat, u0, eps)         # the fastest thread count on this host (stated as `cores`)
-    nf, n, el, st = _timed_solves(lambda: BL.solve(cfg, flat, u0, eps, **kw)[1], budget_s)
+    nf, n, el, st = _timed_solves(lambda: BL.solve_torch(cfg, flat, u0, eps, **kw)[1], budget_s)
+    M = sum(a * b for a, b in zip(cfg.net.dims[:-1], cfg.net.dims[1:]))
     blas = {"value": nf / el, "unit": "RHS-evals/s", "cores": nthr, "host_cores": BL.os_cpu_count(),
             "available_cores": BL.available_cores(), "kind": "port",
-            "impl": "float32 sgemm over the full n x B matrices + tanh, torch-CPU on all host cores; "
-                    "Tsit5 driver in numpy (oracle/cnf_blas.py)",
+            "achieved_gflops": nf / el * B * (4.0 * M + 6.0 * cfg.n_in) / 1e9,
+            "impl": "float32 sgemm over the full n x B matrices + tanh AND the Tsit5 driver (stage combinations, error "
+                    "estimate, norms) as threaded torch-CPU ops on (D, B) tensors, no numpy round trips "
+                    "(oracle/cnf_blas.py: solve_torch)",
             "sample": f"{n} adaptive Tsit5 solves of the same workload (B={B}, nf={st['nf']} each); restatement "
                       f"of the reference path (the Julia package cannot run here)",
             "seconds": el}

@@ -8,7 +8,37 @@ import os as _os
 # argument block, and with the block behind PCIe that read costs ~2.5 us per launch (measured: 56.6 ->
 # 54.0 us per fused step).  The HIP runtime reads the switch when it initialises, so it has to be in the
 # environment before the first HIP call of the process; a value the user set is left alone.
+# SIDE EFFECT, process-wide: importing this package sets HIP_FORCE_DEV_KERNARG=1 for every HIP user of the process, and
+# it has NO effect if HIP was initialised before the import (e.g. `torch.cuda.init()` ran first): the library still works,
+# each step launch just reads its arguments over PCIe.  `kernarg_in_device_memory()` tells which case holds.
+_KERNARG_SET_HERE = "HIP_FORCE_DEV_KERNARG" not in _os.environ
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+
+def kernarg_in_device_memory():
+    """True / False when it is known whether the HIP runtime saw HIP_FORCE_DEV_KERNARG=1 at initialisation, None when
+    the variable was set by this import but torch had already initialised HIP (so the runtime never read it)."""
+    if _os.environ.get("HIP_FORCE_DEV_KERNARG") != "1":
+        return False
+    if not _KERNARG_SET_HERE:
+        return True
+    try:
+        import torch
+        return None if (torch.cuda.is_initialized() and not _HIP_COLD_AT_IMPORT) else True
+    except ImportError:
+        return True
+
+
+def _hip_cold():
+    import sys as _sys
+    t = _sys.modules.get("torch")
+    try:
+        return t is None or not t.cuda.is_initialized()
+    except Exception:
+        return True
+
+
+_HIP_COLD_AT_IMPORT = _hip_cold()
 
 from . import _lib
 from ._lib import CNFError, build

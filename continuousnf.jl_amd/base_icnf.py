@@ -213,6 +213,24 @@ class ICNF:
         self._params_id = key
         self._cond_id = None        # the conditioning bias depends on the parameters
 
+    def set_step_trace(self, cap_attempts: int):
+        """Diagnostic (cnf_set_step_trace): what ``sol.stats`` / the integrator's step log would show if base_sol kept
+        ``sol`` (src/base_icnf.jl:141-142).  Returns a (cap, 4) float32 CUDA tensor that every later one-launch solve on
+        this handle fills with (t, signed h, EEst, accepted) per step attempt; ``0`` switches it off."""
+        l, h = _lib.lib(), self.handle()
+        if cap_attempts <= 0:
+            _lib.check(l.cnf_set_step_trace(h, None, 0), h)
+            self._trace = None
+            return None
+        import torch
+        self._trace = torch.zeros(cap_attempts, 4, dtype=torch.float32, device=torch.device("cuda", self.device))
+        _lib.check(l.cnf_set_step_trace(h, self._trace.data_ptr(), cap_attempts), h)
+        return self._trace
+
+    def solve_fallbacks(self) -> int:
+        """One-launch solves of this handle that ran out of a wait and were run again on the streamed driver."""
+        return int(_lib.lib().cnf_solve_fallbacks(self.handle()))
+
     def set_shard_reduce(self, fn):
         """Lock-step sharded solves (cnf_set_shard_reduce): ``fn(values)`` receives a
         writable float32 numpy view of the local sums and must replace it IN PLACE by the sum over

@@ -7,6 +7,7 @@
 #include "cnf_grad.h"
 #include "cnf_trace.h"
 #include "cnf_mirror.h"
+#include "cnf_step3.h"
 #include <immintrin.h>
 #include <sched.h>
 #include <vector>
@@ -45,6 +46,9 @@ struct cnf_ctx {
     float* post_part = nullptr;   // loss-sum partials of the post-processing kernel: 4 floats per 64 columns
     unsigned persist_base = 0;    // meetings the one-launch solves have held on the partials buffer so far
     bool time_kernel = false;     // cnf_solve_kernel_time: the one-launch solve kernel adds up its own durations
+    int fallbacks = 0;            // one-launch solves that ran out of a wait and were run again on the streamed driver
+    float* step_trace = nullptr;  // cnf_set_step_trace: caller-owned device buffer, 4 floats per step attempt
+    int step_trace_cap = 0;
     float* partials = nullptr;    // 2 * MAX_PARTIALS floats
     StepState* last_state = nullptr; // device slot holding the state at the end of the last solve
     StepState* d_state = nullptr;   // two slots: [0] canonical, [1] ping-pong partner of the fused MFMA path
@@ -427,6 +431,30 @@ extern "C" cnf_status cnf_solve_kernel_time(cnf_handle h, int enable, float* mea
     return CNF_OK;
 }
 
+extern "C" cnf_status cnf_set_step_trace(cnf_handle h, float* trace_dev, int cap_attempts) {
+    if (!h || cap_attempts < 0 || (cap_attempts > 0 && !trace_dev)) return CNF_ERR_BAD_ARG;
+    h->step_trace = cap_attempts > 0 ? trace_dev : nullptr;
+    h->step_trace_cap = cap_attempts;
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_selftest_split_product(const float* A, const float* Bt, float* C, int K) {
+    if (!A || !Bt || !C || K < 32 || K % 32 != 0 || K > 4096) return CNF_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CNF_ERR_NO_DEVICE;
+    float* d = nullptr;
+    const size_t na = (size_t)16 * K;
+    if (hipMalloc(&d, (2 * na + 256) * sizeof(float)) != hipSuccess) return CNF_ERR_HIP;
+    hipError_t e = hipMemcpy(d, A, na * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + na, Bt, na * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = split_product_test_launch(d, d + na, d + 2 * na, K, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(C, d + 2 * na, 256 * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return e == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_solve_fallbacks(cnf_handle h) { return h ? h->fallbacks : -1; }
+
 extern "C" cnf_status cnf_rhs_work(cnf_handle h, int mode, int B, double* flops, double* bytes) {
     if (!h || !flops || !bytes) return CNF_ERR_BAD_ARG;
     const NetDesc& nd = h->nd;
@@ -699,6 +727,10 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         sv.part = h->partials; sv.base = h->persist_base; sv.abort_flag = reinterpret_cast<int*>(h->d_sums + 11);
         sv.t_out = h->time_kernel ? reinterpret_cast<unsigned long long*>(h->d_sums + 12) : nullptr;
         sv.maxiters = (int)opts->maxiters; sv.hairer = hairer ? 1 : 0; sv.init = *init;
+        // polls a wait inside the kernel makes before it gives up (seconds at the default; CNF_SOLVE_POLL_LIMIT: tests)
+        static const int spin_limit = [] { const char* e = getenv("CNF_SOLVE_POLL_LIMIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 21); }();
+        sv.spin_limit = spin_limit;
+        sv.trace = h->step_trace; sv.trace_cap = h->step_trace_cap;
         const bool fused_io = post && post->xs;            // inference: u0 from the data columns and the post-processing in the launch
         if (fused_io) { sv.xs = post->xs; sv.logpx = post->logpx; sv.regs = post->regs; sv.sums5 = post->sums5; }
         else if (u0 != h->U[0]) HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -710,15 +742,12 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             slot = traj_slot_floats(h); dcap = h->traj_cap;
             dump = h->traj + n;                      // stage area of slot 0; u_n sits one array before
         }
-        s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror, base, sv,
+        s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror, base, sv, h->device,
                                   dump, n, slot, dcap, h->traj_hs);
         if (s == CNF_OK) {
             ++launches;
             h->mirror_base = base + 1;
             h->last_state = h->d_state;
-            if (fused_io) post->launched = true;
-            else if (post) { enqueue_post(h, train, h->d_state, *post, B, false, st); ++launches; post->launched = true; }
-            if (u_out) { launch_copy_final(h->d_state, h->U[0], h->U[1], u_out, n, st); ++launches; }
             HIPCHK(h, hipGetLastError());
             // the final state arrives through the host mirror, as in the streamed solve
             const volatile cnf_ctx::HostMirror* hm = h->h_mirror;
@@ -735,42 +764,54 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                         return fail(h, CNF_ERR_HIP, "the solve kernel finished without publishing a state");
                 }
             }
-            if (rec) {                               // step sizes back from the device
-                rec->n = fin.naccept;
-                rec->overflow = fin.naccept > h->traj_cap;
-                rec->hs.assign((size_t)(rec->overflow ? 0 : fin.naccept), 0.f);
-                if (!rec->overflow && fin.naccept > 0)
-                    HIPCHK(h, hipMemcpyAsync(rec->hs.data(), h->traj_hs, (size_t)fin.naccept * sizeof(float),
-                                             hipMemcpyDeviceToHost, st));
-                final_sync = true;
-            }
             const int attempts = fin.naccept + fin.nreject;
             h->persist_base += (unsigned)((hairer ? 2 : 0) + attempts + (fused_io && post->sums5 ? 1 : 0));
-            if (final_sync) HIPCHK(h, hipStreamSynchronize(st));
-            if (stats) {
-                stats->nf = (hairer ? 2 : 1) + 6 * attempts;
-                stats->naccept = fin.naccept;
-                stats->nreject = fin.nreject;
-                stats->t_final = fin.t;
-                stats->dt_last = fin.dt;
-                stats->kernel_used = k;
-                stats->launches = launches;
-            }
-            if (fin.nonfinite) return fail(h, CNF_ERR_NONFINITE, "solver state became NaN/Inf");
-            if (!fin.done) {
-                // maxiters, or a wait inside the kernel ran out (abort word): start the ticket count afresh either way
+            bool aborted = false;
+            if (!fin.done && !fin.nonfinite) {
+                // maxiters, or a wait inside the kernel ran out (abort word): start the meeting indices afresh either way
                 HIPCHK(h, hipStreamSynchronize(st));
-                int aborted = 0;
-                HIPCHK(h, hipMemcpy(&aborted, h->d_sums + 11, sizeof(int), hipMemcpyDeviceToHost));
+                int ab = 0;
+                HIPCHK(h, hipMemcpy(&ab, h->d_sums + 11, sizeof(int), hipMemcpyDeviceToHost));
                 HIPCHK(h, hipMemset(h->d_sums + 10, 0, 2 * sizeof(float)));
                 HIPCHK(h, hipMemset(h->partials, 0, 8 * MAX_PARTIALS * sizeof(float)));      // (stale meeting indices)
                 h->persist_base = 0;
-                return aborted ? fail(h, CNF_ERR_HIP, "one-launch solve: a workgroup did not arrive (set CNF_PERSISTENT=0)")
-                               : fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
+                aborted = ab != 0;
+                if (!aborted) return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
             }
-            return CNF_OK;
-        }
-        if (s != CNF_ERR_UNSUPPORTED) return fail(h, s, "one-launch solve failed to start");
+            if (!aborted) {
+                if (fused_io) post->launched = true;
+                else if (post) { enqueue_post(h, train, h->d_state, *post, B, false, st); ++launches; post->launched = true; }
+                if (u_out) { launch_copy_final(h->d_state, h->U[0], h->U[1], u_out, n, st); ++launches; }
+                HIPCHK(h, hipGetLastError());
+                if (rec) {                               // step sizes back from the device
+                    rec->n = fin.naccept;
+                    rec->overflow = fin.naccept > h->traj_cap;
+                    rec->hs.assign((size_t)(rec->overflow ? 0 : fin.naccept), 0.f);
+                    if (!rec->overflow && fin.naccept > 0)
+                        HIPCHK(h, hipMemcpyAsync(rec->hs.data(), h->traj_hs, (size_t)fin.naccept * sizeof(float),
+                                                 hipMemcpyDeviceToHost, st));
+                    final_sync = true;
+                }
+                if (final_sync) HIPCHK(h, hipStreamSynchronize(st));
+                if (stats) {
+                    stats->nf = (hairer ? 2 : 1) + 6 * attempts;
+                    stats->naccept = fin.naccept;
+                    stats->nreject = fin.nreject;
+                    stats->t_final = fin.t;
+                    stats->dt_last = fin.dt;
+                    stats->kernel_used = k;
+                    stats->launches = launches;
+                }
+                if (fin.nonfinite) return fail(h, CNF_ERR_NONFINITE, "solver state became NaN/Inf");
+                return CNF_OK;
+            }
+            // A workgroup did not arrive within the wait bound: something else holds CUs (another stream or process, a CU
+            // mask).  The launch has ended (every wait is bounded); nothing of its result is used.  The solve runs again from
+            // u0 on the streamed driver below, which needs no co-residency.
+            ++h->fallbacks;
+            if (!fused_io && u0 == h->U[0])
+                return fail(h, CNF_ERR_HIP, "one-launch solve: a workgroup did not arrive and u0 was solved in place (set CNF_PERSISTENT=0)");
+        } else if (s != CNF_ERR_UNSUPPORTED) return fail(h, s, "one-launch solve failed to start");
         persist_lock.unlock();
     }
     if (post && post->xs) launch_build_u0(post->xs, h->U[0], h->nd.nvars, D, B, st, h->d_state, init);   // (u0 == h->U[0])

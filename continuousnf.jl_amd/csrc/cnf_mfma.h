@@ -74,7 +74,9 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
 // arguments of the one-launch solve (k_solve3b, cnf_step3.hip) beyond those of a step launch
 struct Solve3Args {
     float* part;          // error partials: two buffers (meeting index parity) of 2 x 512 words {meeting index, float}
-    unsigned* counter;    // (unused)
+    int spin_limit;       // polls a wait makes before it gives up (abort word; the caller then streams step launches)
+    float* trace;         // null, or 4 floats per step attempt: (t, signed h, EEst, accepted) -- cnf_set_step_trace
+    int trace_cap;        //   attempts the buffer holds
     unsigned base;        // meetings held by earlier launches on this buffer: the indices go on from there
     int* abort_flag;      // set when a wait ran out
     unsigned long long* t_out;   // null, or {entry stamp, sum of durations, launches}: workgroup 0's 100 MHz real-time clock
@@ -88,12 +90,12 @@ struct Solve3Args {
     float* sums5;         // and the five loss sums                                           (src/icnf.jl:489)
     int nvars, naugs, norm_z_aug;
 };
-// the whole solve in one cooperative launch (headline shape, VJP with the |eps^T J| row, B <= 32 x CUs); CNF_ERR_UNSUPPORTED
-// otherwise.  sv (cnf_step3.h): the initial state by value, the meeting buffer and its index base, optionally the data
+// the whole solve in one launch (headline shape, B <= 32 x the workgroups the device can hold at once); CNF_ERR_UNSUPPORTED
+// otherwise.  `device`: the handle's device (CU count, occupancy and function attributes are kept per device).  sv (cnf_step3.h): the initial state by value, the meeting buffer and its index base, optionally the data
 // columns to assemble u0 from and the outputs of the post-processing; st_out: the final state (cur = 0: the final columns
 // are in U[0])
 cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st_out, float* const U[2],
-                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv,
+                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv, int device,
                                  float* dump = nullptr, size_t dump_stride = 0, size_t dump_step_stride = 0, int dump_cap = 0,
                                  float* hs_out = nullptr);     // dump ...: the trajectory store of the gradient path (as mfma_step)
 // workgroups (= error partials) of a step launch; `recording`: the solve files its stage states (gradient path)

@@ -1554,19 +1554,14 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, con
     return launch(p, a, s);
 }
 
-// The whole solve of the headline shape in one launch (k_solve3b, cnf_step3.hip): VJP handles whose batch is at most one
-// 32-column tile per CU.  CNF_ERR_UNSUPPORTED: not this handle / batch, or the
-// device cannot place the grid right now -- the caller streams step launches instead.  CNF_PERSISTENT=0 switches it off.
+// The whole solve of the headline shape in one launch (k_solve3b / k_solve3jb, cnf_step3.hip): at most one 32-column tile
+// per workgroup the device holds at once.  CNF_ERR_UNSUPPORTED: not this handle / batch -- the caller streams step
+// launches instead.  CNF_PERSISTENT=0 switches it off.
 cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st_out, float* const U[2],
-                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv,
+                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv, int device,
                                  float* dump, size_t dump_stride, size_t dump_step_stride, int dump_cap, float* hs_out) {
     static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); return e && e[0] == '0'; }();
     static const bool fp32_only = [] { const char* e = getenv("CNF_STEP_FP32"); return e && e[0] == '1'; }();
-    static const int n_cu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        return n;
-    }();
     // k_solve3jb (one forward sweep of state and tangent columns): JVP handles, and VJP handles without the |eps^T J| row
     // (FFJORD: zdot and ldot do not depend on the mode); k_solve3b: VJP handles with that row
     const bool vjp_ok = p.variant == 2 && !p.ly.jvp;
@@ -1575,7 +1570,7 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     if (off || fp32_only || step_v1() || !train || p.cond || !p.d_img3b || !(jvp || vjp_ok))
         return CNF_ERR_UNSUPPORTED;
     const int ntile = (B + 31) / 32;
-    if (ntile < 1 || ntile > n_cu || ntile > 512) return CNF_ERR_UNSUPPORTED;
+    if (ntile < 1 || ntile > 512 || ntile > step3b_solve_resident(jvp, dump != nullptr, device)) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
     a.init_phase = -1;
     a.mode = 2; a.B = B; a.eps = eps; a.st = st_out; a.st_out = st_out;
@@ -1584,7 +1579,7 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     a.mirror = mirror; a.seq = seq;
     a.dump = dump; a.dump_stride = dump_stride; a.dump_step_stride = dump_step_stride; a.dump_cap = dump_cap; a.hs_out = hs_out;
     sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
-    return step3b_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, ntile, s, sv, jvp);
+    return step3b_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, ntile, s, sv, jvp, device);
 }
 
 cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st_in,

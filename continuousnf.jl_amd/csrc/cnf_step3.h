@@ -19,8 +19,12 @@ void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStre
 void step3jb_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single = 0);
 // k_step3b: the VJP step kernel (k_step3) on six-term bf16 products
 void step3b_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single = 0);
-// the whole solve of one shard in ONE cooperative launch (k_solve3b): grid = tiles of 32 columns, all resident
+// the whole solve of one shard in ONE launch (k_solve3b): grid = tiles of 32 columns, all resident
 // (Solve3Args: cnf_mfma.h)
 // (jvp: k_solve3jb, the JVP compute mode)
 cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, int grid, hipStream_t s,
-                               const Solve3Args& sv, bool jvp = false);
+                               const Solve3Args& sv, bool jvp, int device);
+// workgroups of the one-launch solve kernels the device can hold at once (occupancy x CUs; 0: unknown device)
+int step3b_solve_resident(bool jvp, bool record, int device);
+// C = A Bt^T (16 x K each, K a multiple of 32) on the split-bf16 six-term product of the kernels above: arithmetic self-test
+hipError_t split_product_test_launch(const float* dA, const float* dBt, float* dC, int K, hipStream_t s);

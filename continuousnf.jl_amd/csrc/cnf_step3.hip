@@ -23,6 +23,7 @@
 // an accumulator tile is stored with one ds_write_b128 per lane (lane = sample, 4 rows).
 #include "cnf_step3.h"
 #include "cnf_split.h"
+#include <mutex>
 
 namespace s3 {
 constexpr int NB = 32, P0 = 32, PH = 128;
@@ -1832,12 +1833,17 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 // k_solve3b -- the WHOLE adaptive solve of one shard in one launch: k_step3b's evaluation code inside the step loop.  What
 // a launch per attempt pays every time -- the 212 KB weight stream, the state round trip through HBM, the error partials
 // of the previous launch, kernel start and drain -- is paid once: weights, Runge-Kutta rows and probe rows stay in
-// registers / LDS for all attempts, and the workgroups meet once per attempt to exchange their error partials (two floats
-// each) through agent-scope atomics: a partial store, a ticket, a poll of the ticket, then every workgroup adds the same
-// partials in the same order and runs the same controller, as the launches of the streamed driver do.  No cache is
-// flushed: nothing else crosses workgroups.  Needs every workgroup resident (one 32-sample tile per workgroup, one
-// workgroup per CU: B <= 32 x CUs, cooperative launch); every wait is bounded, so a lost workgroup ends the launch with
-// an error word instead of hanging it.  Results are bit-identical to the streamed solve (same sums, same order).
+// registers / LDS for all attempts, and the workgroups MEET once per attempt to exchange their error partials (two floats
+// each): every workgroup stores its two partials as 8-byte words {meeting index, float} (agent-scope relaxed atomics, two
+// buffers by index parity), thread i polls workgroup i's words until they carry this meeting's index (one 16-byte load
+// past the caches per poll), then every workgroup adds the same partials in the same order and runs the same controller,
+// as the launches of the streamed driver do.  No ticket, no fence, no cache flush: nothing else crosses workgroups.
+// Needs every workgroup resident: an ORDINARY launch whose grid the host bounds by what the device holds at once
+// (occupancy x CUs: step3b_solve_resident); every wait is bounded (sv.spin_limit polls), so a workgroup that never
+// arrives -- CUs held by another stream, process or CU mask -- ends the launch with the abort word and `done` = 0, and
+// the host runs the solve again on the streamed driver (cnf_abi.hip).  The two drivers run the same arithmetic from
+// separately compiled code: identical step counts on well-conditioned cases, results equal to the solver tolerance, not
+// bit for bit.
 // ---------------------------------------------------------------------------------------------------------------
 // RECORD (gradient path): every attempt files u_n and its stage states U_2..U_6 (z rows) in the trajectory slot of step
 // `naccept` (a.dump, as the recording launches of k_mfma do), its signed step size in a.hs_out.
@@ -1988,7 +1994,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
         int ok = 1;
         if (tid < (int)gridDim.x) {
             ok = 0;
-            for (int spin = 0; spin < (1 << 21); ++spin) {
+            for (int spin = 0; spin < sv.spin_limit; ++spin) {
                 // both words of workgroup `tid` with ONE 16-byte load past the caches (each half carries its own index, so a
                 // torn pair is simply not accepted): half the polling traffic of two 8-byte atomic loads
                 u32x4 wq;
@@ -2149,8 +2155,11 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
         if (!alive) break;
         if (tid == 0) {
             const int acc0 = ns->naccept;
+            const float t_att = ns->t, h_att = ns->h;
             ctrl_after_step(ns, msc[32], msc[33], a.n_total);
             post_ctrl(ns->naccept != acc0);
+            if (sv.trace && blockIdx.x == 0 && it < sv.trace_cap)
+                *(f32x4u*)(sv.trace + 4 * it) = f32x4{t_att, h_att, ns->eest, ns->naccept != acc0 ? 1.f : 0.f};
         }
         const int fl = share();
         done = fl & 1;
@@ -2203,27 +2212,37 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (blockIdx.x == 0) {
                 float c4[4] = {0.f, 0.f, 0.f, 0.f};
+                float late = 0.f;                              // a partial that never arrived: the abort path, as in a meeting
                 if (tid < (int)gridDim.x) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        for (int spin = 0; spin < (1 << 21); ++spin) {
+                        int got = 0;
+                        for (int spin = 0; spin < sv.spin_limit; ++spin) {
                             const unsigned long long w = __hip_atomic_load(qb + 4 * tid + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((unsigned)(w >> 32) == tag) { c4[j] = __uint_as_float((unsigned)w); break; }
+                            if ((unsigned)(w >> 32) == tag) { c4[j] = __uint_as_float((unsigned)w); got = 1; break; }
                             __builtin_amdgcn_s_sleep(1);
                         }
+                        if (!got) late = 1.f;
                     }
+                    if (late != 0.f) __hip_atomic_store(sv.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) c4[j] = s3_wave_sum(c4[j]);
+                late = s3_wave_sum(late);
                 s3_bar();
-                if (lane == 0) for (int j = 0; j < 4; ++j) msc[4 * wave + j] = c4[j];
+                if (lane == 0) { for (int j = 0; j < 4; ++j) msc[4 * wave + j] = c4[j]; msc[32 + wave] = late; }
                 s3_bar();
                 if (tid < 4) {
                     float r = 0.f;
                     for (int w = 0; w < 8; ++w) r += msc[4 * w + tid];
                     sv.sums5[tid] = r;
                 }
-                if (tid == 0) sv.sums5[4] = (float)a.B;
+                if (tid == 0) {
+                    sv.sums5[4] = (float)a.B;
+                    float nl = 0.f;
+                    for (int w = 0; w < 8; ++w) nl += msc[32 + w];
+                    if (nl != 0.f) ns->done = 0;               // the host sees the abort word and runs the solve again, streamed
+                }
             }
         }
     }
@@ -2366,7 +2385,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         int ok = 1;
         if (tid < (int)gridDim.x) {
             ok = 0;
-            for (int spin = 0; spin < (1 << 21); ++spin) {
+            for (int spin = 0; spin < sv.spin_limit; ++spin) {
                 // both words of workgroup `tid` with ONE 16-byte load past the caches (each half carries its own index, so a
                 // torn pair is simply not accepted): half the polling traffic of two 8-byte atomic loads
                 u32x4 wq;
@@ -2502,8 +2521,11 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         if (!alive) break;
         if (tid == 0) {
             const int acc0 = ns->naccept;
+            const float t_att = ns->t, h_att = ns->h;
             ctrl_after_step(ns, msc[32], msc[33], a.n_total);
             post_ctrl(ns->naccept != acc0);
+            if (sv.trace && blockIdx.x == 0 && it < sv.trace_cap)
+                *(f32x4u*)(sv.trace + 4 * it) = f32x4{t_att, h_att, ns->eest, ns->naccept != acc0 ? 1.f : 0.f};
         }
         const int fl = share();
         done = fl & 1;
@@ -2552,27 +2574,37 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (blockIdx.x == 0) {
                 float c4[4] = {0.f, 0.f, 0.f, 0.f};
+                float late = 0.f;                              // a partial that never arrived: the abort path, as in a meeting
                 if (tid < (int)gridDim.x) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        for (int spin = 0; spin < (1 << 21); ++spin) {
+                        int got = 0;
+                        for (int spin = 0; spin < sv.spin_limit; ++spin) {
                             const unsigned long long w = __hip_atomic_load(qb + 4 * tid + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((unsigned)(w >> 32) == tag) { c4[j] = __uint_as_float((unsigned)w); break; }
+                            if ((unsigned)(w >> 32) == tag) { c4[j] = __uint_as_float((unsigned)w); got = 1; break; }
                             __builtin_amdgcn_s_sleep(1);
                         }
+                        if (!got) late = 1.f;
                     }
+                    if (late != 0.f) __hip_atomic_store(sv.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) c4[j] = s3_wave_sum(c4[j]);
+                late = s3_wave_sum(late);
                 s3_bar();
-                if (lane == 0) for (int j = 0; j < 4; ++j) msc[4 * wave + j] = c4[j];
+                if (lane == 0) { for (int j = 0; j < 4; ++j) msc[4 * wave + j] = c4[j]; msc[32 + wave] = late; }
                 s3_bar();
                 if (tid < 4) {
                     float r = 0.f;
                     for (int w = 0; w < 8; ++w) r += msc[4 * w + tid];
                     sv.sums5[tid] = r;
                 }
-                if (tid == 0) sv.sums5[4] = (float)a.B;
+                if (tid == 0) {
+                    sv.sums5[4] = (float)a.B;
+                    float nl = 0.f;
+                    for (int w = 0; w < 8; ++w) nl += msc[32 + w];
+                    if (nl != 0.f) ns->done = 0;               // the host sees the abort word and runs the solve again, streamed
+                }
             }
         }
     }
@@ -2584,6 +2616,32 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Self-test of the arithmetic of the split kernels (cnf_selftest_split_product): C = A Bt^T for A, Bt of 16 x K fp32 on ONE
+// wave, with the operand split (s3b_split8) and the six-term product (s3b_mm, smallest term first, fp32 accumulate over the
+// k-blocks in order) that k_step3b / k_step3jb / k_solve3b / k_solve3jb run.  The parity suite bounds its error against
+// float64 on random, wide-dynamic-range and cancelling inputs.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_split_product_test(const float* __restrict__ A, const float* __restrict__ Bt,
+                                                           float* __restrict__ Cm, int K) {
+    const int lane = threadIdx.x, x = lane & 15, q = lane >> 4;
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int kb = 0; kb < K / 32; ++kb) {
+        const float* ap = A + (size_t)x * K + 32 * kb + 8 * q;
+        const float* bp = Bt + (size_t)x * K + 32 * kb + 8 * q;
+        const S3bOp a = s3b_split8(*(const f32x4*)ap, *(const f32x4*)(ap + 4));      // (hipMalloc base, offsets of 8 floats)
+        S3bOp b[1];
+        b[0] = s3b_split8(*(const f32x4*)bp, *(const f32x4*)(bp + 4));
+        s3b_mm<1>(acc, a, b);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Cm[(size_t)(4 * q + i) * 16 + x] = acc[0][i];       // lane (column x, rows 4q..4q+3)
+}
+hipError_t split_product_test_launch(const float* dA, const float* dBt, float* dC, int K, hipStream_t s) {
+    hipLaunchKernelGGL(k_split_product_test, dim3(1), dim3(64), 0, s, dA, dBt, dC, K);
+    return hipGetLastError();
+}
 
 // Image of k_step3jb / k_step3b (layout: namespace s3g): biases, the fp32 fragments, the two split LDS images of k_step3b.
 __global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __restrict__ img) {
@@ -2634,35 +2692,56 @@ void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStre
     constexpr int NT = s3g::NFR * 64 + 2 * 32 * 16;
     hipLaunchKernelGGL(k_pack_step3b, dim3((NT + 255) / 256), dim3(256), 0, s, nd, d_params, (char*)d_imgb);
 }
-cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, int grid, hipStream_t s,
-                               const Solve3Args& sv_, bool jvp) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_solve3b<false>, hipFuncAttributeMaxDynamicSharedMemorySize, s3v::TOTAL_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_solve3b<true>, hipFuncAttributeMaxDynamicSharedMemorySize, s3v::TOTAL_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_solve3jb, hipFuncAttributeMaxDynamicSharedMemorySize, s3b::TOTAL_BYTES) != hipSuccess)
-            return CNF_ERR_HIP;
-        attr = true;
+// Function attributes and occupancy belong to a (function, device) pair: kept per device, set on first use there.
+static const void* solve3_fn(bool jvp, bool record) {
+    return jvp ? (const void*)k_solve3jb : (record ? (const void*)k_solve3b<true> : (const void*)k_solve3b<false>);
+}
+static size_t solve3_shm(bool jvp) { return jvp ? (size_t)s3b::TOTAL_BYTES : (size_t)s3v::TOTAL_BYTES; }
+int step3b_solve_resident(bool jvp, bool record, int device) {
+    constexpr int MAXDEV = 64;
+    static std::mutex mu;
+    static int resident[MAXDEV][3];                         // 0: not asked yet, -1: unusable, else workgroups the device holds
+    if (device < 0 || device >= MAXDEV) return 0;
+    const int which = jvp ? 2 : (record ? 1 : 0);
+    std::lock_guard<std::mutex> lk(mu);
+    int& r = resident[device][which];
+    if (r == 0) {
+        r = -1;
+        int cur = -1, n_cu = 0, per_cu = 0;
+        const void* fn = solve3_fn(jvp, record);
+        const size_t shm = solve3_shm(jvp);
+        if (hipGetDevice(&cur) == hipSuccess && (cur == device || hipSetDevice(device) == hipSuccess)) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess &&
+                hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, shm) == hipSuccess && per_cu >= 1 && n_cu >= 1)
+                // (148 KB of LDS per workgroup: one per CU whatever the API says about registers -- it is known to report
+                // one block too many at some SGPR counts, MI355X_MICROARCH.md "Correctness boundaries")
+                r = n_cu * 1;
+            else (void)hipGetLastError();
+            if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+        }
     }
+    return r > 0 ? r : 0;
+}
+cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, int grid, hipStream_t s,
+                               const Solve3Args& sv_, bool jvp, int device) {
     const bool record = a.dump != nullptr;                 // (the JVP kernel does not record)
     if (record && jvp) return CNF_ERR_UNSUPPORTED;
-    const void* fn = jvp ? (const void*)k_solve3jb : (record ? (const void*)k_solve3b<true> : (const void*)k_solve3b<false>);
-    const size_t shm = jvp ? s3b::TOTAL_BYTES : s3v::TOTAL_BYTES;
+    // Every workgroup must be resident for the whole launch: the grid is bounded by what THIS device holds at once.  An
+    // ordinary launch places all of them as soon as the CUs are free; the caller keeps the one-launch solves of this process
+    // apart (a mutex); whatever else holds CUs (another stream, process, a CU mask) makes a wait run out, and the caller
+    // then streams step launches instead.
+    const int resident = step3b_solve_resident(jvp, record, device);
+    if (grid < 1 || grid > resident) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a_ = a;
     const char* img = (const char*)d_imgb;
     S3Tab tab = kS3Tab;
     Solve3Args sv = sv_;
     void* args[] = {&a_, &img, &n_in, &norm_z, &norm_j, &tab, &sv};
-    // Every workgroup must be resident for the whole launch.  The grid is at most one workgroup per CU (the caller checks)
-    // and 157 KB of LDS keep a second one off a CU, so an ordinary launch places all of them as soon as the CUs are free;
-    // the caller keeps the one-launch solves of this process apart (a mutex), and every wait inside the kernel is
-    // bounded.  CNF_PERSISTENT=2 goes through hipLaunchCooperativeKernel instead: the same placement, checked by the
-    // runtime, at 10-15 us more per launch (its barrier packets around the kernel).
-    static const bool coop = [] { const char* e = getenv("CNF_PERSISTENT"); return e && e[0] == '2'; }();
-    hipError_t e;
-    if (!coop) e = hipLaunchKernel(fn, dim3(grid), dim3(512), args, shm, s);
-    else e = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(512), args, shm, s);
-    if (e != hipSuccess) { (void)hipGetLastError(); return CNF_ERR_UNSUPPORTED; }
+    if (hipLaunchKernel(solve3_fn(jvp, record), dim3(grid), dim3(512), args, solve3_shm(jvp), s) != hipSuccess) {
+        (void)hipGetLastError();
+        return CNF_ERR_UNSUPPORTED;
+    }
     return CNF_OK;
 }
 void step3b_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, dim3 grid, hipStream_t s, int single) {

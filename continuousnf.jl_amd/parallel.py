@@ -121,12 +121,24 @@ class RcclComm:
         """cnf_set_shard_comm: the adaptive controller of ``icnf`` reduces its three floats through this
         communicator on the solve's stream (no host callback)."""
         from . import _lib
+        import weakref
         _lib.check(_lib.lib().cnf_set_shard_comm(icnf.handle(), self.handle if enable else None), icnf.handle())
+        users = self.__dict__.setdefault("_lockstep_users", {})
+        if enable:
+            users[id(icnf)] = weakref.ref(icnf)
+        else:
+            users.pop(id(icnf), None)
         return icnf
 
     def close(self):
         if self.handle is not None:
             from . import _lib
+            # handles still reducing through this communicator must not keep a dangling ncclComm_t
+            for ref in list(self.__dict__.get("_lockstep_users", {}).values()):
+                ic = ref()
+                if ic is not None and ic._handle is not None:
+                    _lib.lib().cnf_set_shard_comm(ic._handle, None)
+            self.__dict__["_lockstep_users"] = {}
             _lib.lib().cnf_comm_destroy(self.handle)
             self.handle = None
 

@@ -267,6 +267,20 @@ cnf_status cnf_rhs_work(cnf_handle h, int mode, int B, double* flops, double* by
  * previous call, zeroes both, and sets the switch; pointers may be null.  0 launches: the solves streamed step launches. */
 cnf_status cnf_solve_kernel_time(cnf_handle h, int enable, float* mean_us, int* launches);
 
+/* Diagnostic: what `sol.stats` and the integrator's step log would tell a Julia caller if base_sol kept `sol`
+ * (src/base_icnf.jl:141-142 returns only the final state).  trace_dev: caller-owned DEVICE buffer of 4 * cap_attempts
+ * floats; every later one-launch solve on this handle files (t, signed h, EEst, accepted ? 1 : 0) of step attempt i at
+ * floats 4i..4i+3 (attempts beyond the capacity are not filed).  cap_attempts = 0 switches it off. */
+cnf_status cnf_set_step_trace(cnf_handle h, float* trace_dev, int cap_attempts);
+/* One-launch solves on this handle that ran out of a wait (CUs held by someone else) and were run again, from u0, on the
+ * streamed driver; the calls returned CNF_OK with the streamed result. */
+int cnf_solve_fallbacks(cnf_handle h);
+/* Arithmetic self-test (no handle): C (16 x 16, row-major, HOST) = A Bt^T for HOST matrices A, Bt of 16 x K floats
+ * (row-major, K a multiple of 32), computed on one wavefront with the operand split and the six-term bf16 MFMA product
+ * the headline kernels use in place of the reference's sgemm (Lux Dense inside src/icnf.jl:331-332).  The parity suite
+ * bounds |C - float64| by a multiple of eps32 * sum_k |a b|. */
+cnf_status cnf_selftest_split_product(const float* A, const float* Bt, float* C, int K);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,73 @@
+# ContinuousNormalizingFlowsHIPAMDGPUExt.jl -- device residency through the reference's own resource hooks.
+#
+# UNTESTED (no Julia in the build container; AMDGPU.jl API names are from memory and marked where they matter).
+# Loaded when AMDGPU.jl is present next to ContinuousNormalizingFlowsHIPExt (a package extension with
+# `AMDGPU` as its trigger, exactly as ext/ContinuousNormalizingFlowsCUDAExt is triggered by `CUDA`).  Pattern followed:
+# ext/ContinuousNormalizingFlowsCUDAExt/ContinuousNormalizingFlowsCUDAExt.jl:5-15 -- `rng_AT` picks the device RNG and
+# `base_AT` the device array type, so that inference_prob (src/base_icnf.jl:275-282) builds `u0` and `ϵ` ON THE DEVICE and
+# every later array of the solve inherits that type.  With this file loaded nothing crosses PCIe per solve: `base_sol`
+# hands device pointers to cnf_solve_tsit5 on AMDGPU.jl's current stream, and the final `D x B` matrix it returns is a
+# ROCArray that inference_sol slices on the device (src/base_icnf.jl:173-188).
+module ContinuousNormalizingFlowsHIPAMDGPUExt
+
+import AMDGPU, SciMLBase
+import ContinuousNormalizingFlows as CNF
+import ContinuousNormalizingFlows: ICNF, AbstractICNF, TrainMode, TestMode, rng_AT, base_AT, base_sol
+import ..ContinuousNormalizingFlowsHIPExt as HIPExt
+import ..ContinuousNormalizingFlowsHIPExt: ROCmLibs, HIPMatrixMode, libcnfhip, handle, set_params!, check, mode_flag,
+    CnfSolveOpts, CnfSolveStats
+
+# resource hooks (src/base_icnf.jl:123-135; the CUDA precedent: ext/...CUDAExt.jl:5-15)
+@inline rng_AT(::ROCmLibs) = AMDGPU.rocrand_rng()                       # (AMDGPU.jl's rocRAND generator; name from memory)
+@inline function base_AT(::ROCmLibs, ::AbstractICNF{T}, dims...) where {T <: AbstractFloat}
+    AMDGPU.ROCArray{T}(undef, dims...)
+end
+
+devptr(x::AMDGPU.ROCArray{Float32}) = Base.unsafe_convert(Ptr{Float32}, x)     # device address of element 1
+raw_stream() = Base.unsafe_convert(Ptr{Cvoid}, AMDGPU.stream())                # hipStream_t of the task-local stream (from memory)
+
+# base_sol on device arrays: strictly more specific than the host method of ContinuousNormalizingFlowsHIPExt (u0's type)
+function base_sol(icnf::ICNF{T, <:HIPMatrixMode, INPLACE},
+        prob::SciMLBase.AbstractODEProblem{<:AMDGPU.ROCMatrix{Float32}, NTuple{2, T}, INPLACE}) where {T, INPLACE}
+    f = prob.f.f                       # ode_func_op / ode_func_ip (src/base_icnf.jl:517-523)
+    mode, ϵ = f.mode, f.ϵ
+    h = handle(icnf)
+    set_params!(h, prob.p; force = true)
+    u0 = prob.u0
+    B = size(u0, 2)
+    kw = icnf.sol_kwargs
+    opts = CnfSolveOpts(prob.tspan[1], prob.tspan[2], get(kw, :abstol, 1.0f-6), get(kw, :reltol, 1.0f-3),
+                        get(kw, :dt, 0.0f0), get(kw, :adaptive, true) ? 1 : 0,
+                        min(get(kw, :maxiters, 100_000), typemax(Int32)), 0)
+    stats = CnfSolveStats()
+    fsol = similar(u0)
+    ϵd = ϵ isa AMDGPU.ROCArray{Float32} ? ϵ : AMDGPU.ROCArray{Float32}(ϵ)
+    GC.@preserve u0 fsol ϵd begin
+        check(@ccall(libcnfhip.cnf_solve_tsit5(h::Ptr{Cvoid}, mode_flag(mode)::Cint, devptr(u0)::Ptr{Float32},
+                                               devptr(ϵd)::Ptr{Float32}, devptr(fsol)::Ptr{Float32}, B::Cint,
+                                               Ref(opts)::Ptr{CnfSolveOpts}, stats::Ref{CnfSolveStats},
+                                               raw_stream()::Ptr{Cvoid})::Cint), h)
+    end
+    fsol                               # (cnf_solve_tsit5 returns after the solve has finished: the step count is data dependent)
+end
+
+# the RHS on device arrays (the integrator-driven path): cnf_rhs with device pointers, stream-ordered
+function HIPExt.rhs!(du::AMDGPU.ROCMatrix{Float32}, u::AMDGPU.ROCMatrix{Float32}, p, icnf, mode, nn, ϵ)
+    h = handle(icnf)
+    set_params!(h, p)
+    B = size(u, 2)
+    ϵd = ϵ isa AMDGPU.ROCArray{Float32} ? ϵ : AMDGPU.ROCArray{Float32}(ϵ)
+    if nn isa CNF.CondLayer
+        ys = nn.ys isa AMDGPU.ROCArray{Float32} ? nn.ys : AMDGPU.ROCArray{Float32}(nn.ys)
+        GC.@preserve ys check(@ccall(libcnfhip.cnf_set_cond(h::Ptr{Cvoid}, devptr(ys)::Ptr{Float32}, B::Cint,
+                                                            raw_stream()::Ptr{Cvoid})::Cint), h)
+    end
+    GC.@preserve du u ϵd begin
+        check(@ccall(libcnfhip.cnf_rhs(h::Ptr{Cvoid}, mode_flag(mode)::Cint, 0::Cint, devptr(u)::Ptr{Float32},
+                                       devptr(ϵd)::Ptr{Float32}, devptr(du)::Ptr{Float32}, B::Cint,
+                                       raw_stream()::Ptr{Cvoid})::Cint), h)
+    end
+    nothing
+end
+
+end # module

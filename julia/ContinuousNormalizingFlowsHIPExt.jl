@@ -29,9 +29,9 @@ end
 # ---- resource hooks (pattern: ext/ContinuousNormalizingFlowsCUDAExt/ContinuousNormalizingFlowsCUDAExt.jl:5-15) ------
 # ComputationalResources has no ROCm resource, so the backend defines its own.  With it, `construct(...; resource =
 # ROCmLibs())` selects where inference_prob allocates the probe (src/base_icnf.jl:277) and which RNG fills it (:278).
-# The C ABI takes host OR device pointers, so the default keeps host arrays (no AMDGPU.jl dependency); with AMDGPU.jl
-# loaded, `base_AT` may return `AMDGPU.ROCArray{T}(undef, dims...)` and the device-pointer entry points
-# (cnf_rhs / cnf_solve_tsit5 / cnf_inference) take `pointer(x)` directly: see INTEGRATION.md.
+# The C ABI takes host OR device pointers.  This file keeps host arrays (no AMDGPU.jl dependency: the *_host entry points
+# copy explicitly); with AMDGPU.jl loaded, julia/ContinuousNormalizingFlowsHIPAMDGPUExt.jl overrides `base_AT` / `rng_AT`
+# to device arrays and `base_sol` to the device-pointer entry point (no PCIe traffic per solve): see INTEGRATION.md.
 struct ROCmLibs <: ComputationalResources.AbstractResource end
 
 @inline rng_AT(::ROCmLibs) = Random.default_rng()
@@ -108,28 +108,34 @@ function handle(icnf::ICNF{T, <:HIPMatrixMode}) where {T}
 end
 
 # Upload `p` (ComponentArray -> flat vector: per layer weight, column-major, then bias) unless the handle already holds
-# it.  The integrator calls augmented_f 6 times per step with the SAME `p` object: the upload is keyed on the identity of
-# that object plus a hash of its contents (an optimiser that updates `p` in place changes the hash).
+# it.  The integrator calls augmented_f 6 times per step with the SAME `p` object, so the RHS-level key is the identity
+# of that object plus a version counter -- no pass over the data per call.  Code that updates `p` IN PLACE between solves
+# (an optimiser) bumps the counter with `params_updated!(p)`; `base_sol` (once per solve) uploads unconditionally, which
+# costs one 100 KB copy per solve and cannot go stale.
 const UPLOADED = Dict{Ptr{Cvoid}, Tuple{UInt, UInt}}()
-function set_params!(h, p)
-    key = (objectid(p), hash(p))
-    get(UPLOADED, h, nothing) == key && return nothing
+const PARAM_VERSION = IdDict{Any, UInt}()
+params_updated!(p) = (PARAM_VERSION[p] = get(PARAM_VERSION, p, UInt(0)) + UInt(1); p)
+function set_params!(h, p; force::Bool = false)
+    key = (objectid(p), get(PARAM_VERSION, p, UInt(0)))
+    !force && get(UPLOADED, h, nothing) == key && return nothing
     v = Vector{Float32}(p)
     check(@ccall(libcnfhip.cnf_set_params_host(h::Ptr{Cvoid}, v::Ptr{Float32}, length(v)::Csize_t)::Cint), h)
     UPLOADED[h] = key
     nothing
 end
 
-# ---- augmented_f (src/icnf.jl:318-350 / :352-382 and the TestMode pair :148-184) ------------
-function augmented_f(u::Any, p::Any, ::Any, icnf::ICNF{T, <:HIPMatrixMode, false}, mode::Mode,
-        nn::LuxCore.AbstractLuxLayer, st::NamedTuple, ϵ::AbstractMatrix{T}) where {T <: AbstractFloat}
-    du = similar(u)
-    augmented_f(du, u, p, nothing, icnf, mode, nn, st, ϵ)
-    du
-end
-
-function augmented_f(du::Any, u::Any, p::Any, ::Any, icnf::ICNF{T, <:HIPMatrixMode}, mode::Mode,
-        nn::LuxCore.AbstractLuxLayer, st::NamedTuple, ϵ::AbstractMatrix{T}) where {T <: AbstractFloat}
+# ---- augmented_f -----------------------------------------------------------------------------
+# One method per (INPLACE, mode) pair, each STRICTLY more specific than the reference method it stands beside, so that
+# dispatch is unambiguous (Aqua's ambiguity test, test/quality_tests.jl:3-5):
+#   reference, TestMode:   icnf::ICNF{T, <:MatrixMode, false}, mode::TestMode   (src/icnf.jl:148-157)
+#                          icnf::ICNF{T, <:MatrixMode, true},  mode::TestMode   (src/icnf.jl:166-175)
+#     -> here ICNF{T, <:HIPMatrixMode, false|true}, mode::TestMode: same positions, a subtype in the second parameter.
+#   reference, TrainMode:  icnf::ICNF{T, <:DIVecJacMatrixMode | <:DIJacVecMatrixMode, false|true, ...}, mode::TrainMode
+#                          (src/icnf.jl:318-327, 352-362, 384-393, 422-432): those compute modes are siblings of
+#                          HIPMatrixMode under MatrixMode, so no reference method applies to a HIP handle in TrainMode.
+# (A single method on `mode::Mode` -- the round-2 form -- was ambiguous with the two TestMode methods above: more
+# specific in the compute mode, less specific in the mode.)
+function rhs!(du, u, p, icnf, mode, nn, ϵ)
     h = handle(icnf)
     set_params!(h, p)
     B = size(u, 2)
@@ -141,6 +147,27 @@ function augmented_f(du::Any, u::Any, p::Any, ::Any, icnf::ICNF{T, <:HIPMatrixMo
     check(@ccall(libcnfhip.cnf_rhs_host(h::Ptr{Cvoid}, mode_flag(mode)::Cint, 0::Cint, u::Ptr{Float32},
                                         ϵ::Ptr{Float32}, du::Ptr{Float32}, B::Cint)::Cint), h)
     nothing
+end
+
+function augmented_f(u::Any, p::Any, ::Any, icnf::ICNF{T, <:HIPMatrixMode, false}, mode::TrainMode,
+        nn::LuxCore.AbstractLuxLayer, st::NamedTuple, ϵ::AbstractMatrix{T}) where {T <: AbstractFloat}
+    du = similar(u)
+    rhs!(du, u, p, icnf, mode, nn, ϵ)
+    du
+end
+function augmented_f(u::Any, p::Any, ::Any, icnf::ICNF{T, <:HIPMatrixMode, false}, mode::TestMode,
+        nn::LuxCore.AbstractLuxLayer, st::NamedTuple, ϵ::AbstractMatrix{T}) where {T <: AbstractFloat}
+    du = similar(u)
+    rhs!(du, u, p, icnf, mode, nn, ϵ)
+    du
+end
+function augmented_f(du::Any, u::Any, p::Any, ::Any, icnf::ICNF{T, <:HIPMatrixMode, true}, mode::TrainMode,
+        nn::LuxCore.AbstractLuxLayer, st::NamedTuple, ϵ::AbstractMatrix{T}) where {T <: AbstractFloat}
+    rhs!(du, u, p, icnf, mode, nn, ϵ)
+end
+function augmented_f(du::Any, u::Any, p::Any, ::Any, icnf::ICNF{T, <:HIPMatrixMode, true}, mode::TestMode,
+        nn::LuxCore.AbstractLuxLayer, st::NamedTuple, ϵ::AbstractMatrix{T}) where {T <: AbstractFloat}
+    rhs!(du, u, p, icnf, mode, nn, ϵ)
 end
 
 # ---- lock-step sharded solves (cnf_set_shard_reduce) ------------------------------------------
@@ -194,7 +221,7 @@ function base_sol(icnf::ICNF{T, <:HIPMatrixMode, INPLACE},
     f = prob.f.f                       # ode_func_op / ode_func_ip (src/base_icnf.jl:517-523)
     mode, ϵ = f.mode, f.ϵ
     h = handle(icnf)
-    set_params!(h, prob.p)
+    set_params!(h, prob.p; force = true)          # once per solve: cannot go stale under in-place optimisers
     u0 = Matrix{Float32}(prob.u0)
     B = size(u0, 2)
     kw = icnf.sol_kwargs
@@ -218,7 +245,7 @@ end
 #                   grad = (G, u, data) -> (G .= last(loss_and_grad(model.m, first(data), u, st))))
 function loss_and_grad(icnf::ICNF{T, <:HIPMatrixMode}, xs::AbstractMatrix{<:Real}, ps, st) where {T}
     h = handle(icnf)
-    set_params!(h, ps)
+    set_params!(h, ps; force = true)
     x = Matrix{Float32}(xs)
     B = size(x, 2)
     n_in = icnf.nvars + icnf.naugmented

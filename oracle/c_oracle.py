@@ -76,8 +76,12 @@ def rhs(cfg, flat, u, eps, train):
 
 
 def solve(cfg, flat, u0, eps, train, *, dt=0.0, adaptive=True, abstol=1e-6, reltol=1e-3,
-          maxiters=100000, tspan=None):
+          maxiters=100000, tspan=None, trace=None):
+    """``trace``: a float32 array of shape (cap, 4) that receives (t, signed h, EEst, accepted) per step attempt."""
     net = make_net(cfg)
+    if trace is not None:
+        assert trace.dtype == np.float32 and trace.flags.c_contiguous and trace.shape[1] == 4
+        lib().oc_set_trace(_p(trace), C.c_int(trace.shape[0]))
     D, B = u0.shape
     t0, t1 = tspan if tspan is not None else cfg.tspan
     uf, pf = _cm(u0), np.ascontiguousarray(flat, dtype=np.float32)
@@ -88,6 +92,8 @@ def solve(cfg, flat, u0, eps, train, *, dt=0.0, adaptive=True, abstol=1e-6, relt
                               C.c_int(int(train)), C.c_float(t0), C.c_float(t1), C.c_float(abstol),
                               C.c_float(reltol), C.c_float(dt), C.c_int(int(adaptive)),
                               C.c_int(maxiters), C.byref(st))
+    if trace is not None:
+        lib().oc_set_trace(None, C.c_int(0))
     if rc:
         raise RuntimeError(f"oc_solve_tsit5 rc={rc}")
     return out.reshape(B, D).T, {"nf": st.nf, "naccept": st.naccept, "nreject": st.nreject,

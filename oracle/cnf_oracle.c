@@ -218,6 +218,11 @@ static const float BT_[7] = {-0.00178001105222577714f, -0.0008164344596567469f, 
 
 typedef struct { int nf, naccept, nreject; float t_final, dt_last; } oc_stats;
 
+/* optional log of the step attempts of the next solves: 4 floats each, (t, signed h, EEst, accepted) */
+static float* g_trace = 0;
+static int g_trace_cap = 0;
+void oc_set_trace(float* buf, int cap_attempts) { g_trace = buf; g_trace_cap = buf ? cap_attempts : 0; }
+
 static double rms2(const float* x, const float* sk, size_t n) { /* sum (x/sk)^2 */
     double s = 0;
 #pragma omp parallel for reduction(+ : s)
@@ -287,6 +292,9 @@ int oc_solve_tsit5(const oc_net* net, const float* P, const float* u0, const flo
             q11 = powf(fmaxf(eest, 1e-30f), 7.f / 50.f);
             q = q11 / powf(qold, 2.f / 25.f);
             q = fmaxf(0.1f, fminf(5.f, q / 0.9f));
+        }
+        if (g_trace && it < g_trace_cap) {
+            g_trace[4 * it] = t; g_trace[4 * it + 1] = h; g_trace[4 * it + 2] = eest; g_trace[4 * it + 3] = (float)accept;
         }
         if (accept) {
             nacc++;

@@ -260,3 +260,13 @@ def test_blas_baseline_matches_the_oracle():
                                   0.0, 1.0, dt=1 / 8, adaptive=False)
         assert st["nf"] == st2.nf
         assert_parity(got, want, f"blas solve cfg{i}", trace_row=cfg.n_in)
+        # the all-torch driver bench.py times (solve_torch): same fixed-dt result, and the same adaptive step sequence
+        # as the numpy driver around the same right-hand side
+        got_t, st_t = BL.solve_torch(cfg, flat, u0, eps, dt=1 / 8, adaptive=False)
+        assert st_t["nf"] == st2.nf
+        assert_parity(got_t, want, f"torch-driver solve cfg{i}", trace_row=cfg.n_in)
+        kw = dict(reltol=3.45e-4, abstol=1.19e-7)
+        ga, sa = BL.solve(cfg, flat, u0, eps, **kw)
+        gt, stt = BL.solve_torch(cfg, flat, u0, eps, **kw)
+        assert (sa["nf"], sa["naccept"], sa["nreject"]) == (stt["nf"], stt["naccept"], stt["nreject"])
+        assert_parity(gt, ga, f"torch-driver adaptive cfg{i}", rtol=1e-3, trace_row=cfg.n_in)
