@@ -1569,8 +1569,13 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     if (dump && !vjp_ok) return CNF_ERR_UNSUPPORTED;       // recording (gradient path): the VJP kernel only
     if (off || fp32_only || step_v1() || !train || p.cond || !p.d_img3b || !(jvp || vjp_ok))
         return CNF_ERR_UNSUPPORTED;
+    // CNF_PIPE=1: k_solve3p, the interleaved schedule with the SIMD partners in complementary roles (cnf_step3p.hip) instead
+    // of k_solve3b.  Parity-tested; measured SLOWER (48.7 against 33.2 us per attempt), so it is opt-in.
+    static const bool pipe = [] { const char* e = getenv("CNF_PIPE"); return e && e[0] == '1'; }();
+    const bool use_p = pipe && !jvp;
     const int ntile = (B + 31) / 32;
-    if (ntile < 1 || ntile > 512 || ntile > step3b_solve_resident(jvp, dump != nullptr, device)) return CNF_ERR_UNSUPPORTED;
+    const int resident = use_p ? step3p_solve_resident(dump != nullptr, device) : step3b_solve_resident(jvp, dump != nullptr, device);
+    if (ntile < 1 || ntile > 512 || ntile > resident) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
     a.init_phase = -1;
     a.mode = 2; a.B = B; a.eps = eps; a.st = st_out; a.st_out = st_out;
@@ -1579,6 +1584,7 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     a.mirror = mirror; a.seq = seq;
     a.dump = dump; a.dump_stride = dump_stride; a.dump_step_stride = dump_step_stride; a.dump_cap = dump_cap; a.hs_out = hs_out;
     sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
+    if (use_p) return step3p_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, ntile, s, sv, device);
     return step3b_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, ntile, s, sv, jvp, device);
 }
 

@@ -1145,10 +1145,11 @@ def test_split_product_error_bound():
     truncation, |m| < 2^-7 |v|, |l| < 2^-15 |v|; the three products left out (m l, l m, l l) are below 2^-21 |a b| in the
     worst case (every mantissa bit set) and ~2^-24 |a b| on random bits; the rest is fp32 accumulation.  Bounds asserted,
     relative to S = sum_k |a_k b_k| per output entry:
-      random N(0,1), K = 128 ........................ 2^-22 S   (v_mfma_f32_16x16x4_f32 measures 7.6e-8 S = 2^-23.6 S)
-      magnitudes over 40 binades, random signs ....... 2^-22 S
+      random N(0,1), K = 32 .. 512 .................. 2^-22 S   (v_mfma_f32_16x16x4_f32 measures 7.6e-8 S = 2^-23.6 S)
+      magnitudes over 40 binades, random signs ....... 2^-20 S   (one product dominates a sum: its own worst case shows)
       all-ones mantissas, one sign (worst case) ...... 2^-20 S
-      exactly cancelling K = 128 sums ................ 2^-21 S absolute (the exact result is 0)"""
+      exactly cancelling K = 128 sums ................ 2^-21 S absolute (the exact result is 0)
+    The measured figures go to parity_report.json."""
     l = _lib.lib()
     rng = np.random.default_rng(2024)
 
@@ -1171,7 +1172,7 @@ def test_split_product_error_bound():
         mag = lambda: np.exp2(rng.uniform(-20, 20, (16, 128))) * rng.choice([-1.0, 1.0], (16, 128))
         e = max(e, run(mag(), mag())[0])
     worst["40 binades"] = e
-    assert e <= 2.0 ** -22, e
+    assert e <= 2.0 ** -20, e
     ones = np.full((16, 128), np.float32(np.nextafter(np.float32(2.0), np.float32(0.0))))      # 0x3FFFFFFF: every bit set
     e = run(ones, ones)[0]
     worst["all-ones mantissas"] = e
@@ -1255,7 +1256,9 @@ def test_one_launch_solve_falls_back_when_a_workgroup_does_not_arrive():
     assert torch.isfinite(logpx).all() and float(sums[4]) == B
     assert torch.allclose(logpx[sub], ref, rtol=2e-5, atol=2e-5), float((logpx[sub] - ref).abs().max())
     assert abs(float(sums[0]) - float(logpx.double().sum())) <= 1e-5 * abs(float(sums[0]))
-    if forced:
+    if not _one_launch_expected():
+        assert fb == 0 and ic.last_stats["launches"] > 3, (fb, ic.last_stats)      # streamed anyway: nothing to fall back from
+    elif forced:
         assert fb == 1 and ic.last_stats["launches"] > 3, (fb, ic.last_stats)
     else:
         assert (fb == 0) == (ic.last_stats["launches"] <= 3), (fb, ic.last_stats)
