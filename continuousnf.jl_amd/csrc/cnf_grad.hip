@@ -546,9 +546,11 @@ k_wgrad_mfma_b(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const fl
     };
     // chunk c (8 samples) of column r at chunk position c ^ ((-(r >> 2)) & 3) of its 64-byte row
     auto put = [&](int arr, int col, const float (&v)[8]) {
-        bf16x8 h, m, lo;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { __bf16 a_, b_, c_; s3b_split(v[j], a_, b_, c_); h[j] = a_; m[j] = b_; lo[j] = c_; }
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        u32x4_ hp, mp, lp;
+        { unsigned h_, m_, l_; s3b_split2(v[0], v[1], h_, m_, l_); hp.x = h_; mp.x = m_; lp.x = l_; } { unsigned h_, m_, l_; s3b_split2(v[2], v[3], h_, m_, l_); hp.y = h_; mp.y = m_; lp.y = l_; }
+        { unsigned h_, m_, l_; s3b_split2(v[4], v[5], h_, m_, l_); hp.z = h_; mp.z = m_; lp.z = l_; } { unsigned h_, m_, l_; s3b_split2(v[6], v[7], h_, m_, l_); hp.w = h_; mp.w = m_; lp.w = l_; }
+        const bf16x8 h = __builtin_bit_cast(bf16x8, hp), m = __builtin_bit_cast(bf16x8, mp), lo = __builtin_bit_cast(bf16x8, lp);
         char* d = simg + arr * 3 * PIECE + col * 64 + 16 * (lr ^ ((-(col >> 2)) & 3));
         *(bf16x8*)d = h; *(bf16x8*)(d + PIECE) = m; *(bf16x8*)(d + 2 * PIECE) = lo;
     };

@@ -2547,15 +2547,14 @@ __global__ void k_pack_step3b(NetDesc nd, const float* __restrict__ P, char* __r
         *(f32x4*)(d + 1024) = f32x4{v[4], v[5], v[6], v[7]};
     } else if (i < s3g::NFR * 64 + NIMG) {
         const int e = i - s3g::NFR * 64, which = e / (32 * 16), r = (e / 16) % 32, g = e % 16;     // 16 chunks of 8 bf16 per row
-        bf16x8 h, m, lo;
+        float vv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 8 * g + j;
-            const float v = k < 128 ? (which == 0 ? W(2, r, k) : W(0, k, r)) : 0.f;      // W3[r][k] | W1^T[r][k] = W1[k][r]
-            __bf16 a, b, c;
-            s3b_split(v, a, b, c);
-            h[j] = a; m[j] = b; lo[j] = c;
+            vv[j] = k < 128 ? (which == 0 ? W(2, r, k) : W(0, k, r)) : 0.f;      // W3[r][k] | W1^T[r][k] = W1[k][r]
         }
+        const S3bOp sp = s3b_split8(f32x4{vv[0], vv[1], vv[2], vv[3]}, f32x4{vv[4], vv[5], vv[6], vv[7]});
+        const bf16x8 h = sp.h, m = sp.m, lo = sp.l;
         char* dst = img + s3g::W3I + (size_t)which * s3v::WI + r * s3v::WS + 16 * (g ^ (r & 15));      // (swizzled rows: s3v)
         *(bf16x8*)dst = h; *(bf16x8*)(dst + s3v::WP) = m; *(bf16x8*)(dst + 2 * s3v::WP) = lo;
     }

@@ -64,11 +64,12 @@ static_assert(F32 % 16 == 0 && W3I % 16 == 0, "16-byte loads");
 }  // namespace s3g
 
 // 4 rows of one sample -> the three images (8 bytes each)
+typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void s3b_store4(char* img, int piece_bytes, const f32x4& v) {
-    bf16x4 h, m, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { __bf16 a, b, c; s3b_split(v[j], a, b, c); h[j] = a; m[j] = b; l[j] = c; }
-    *(bf16x4*)img = h; *(bf16x4*)(img + piece_bytes) = m; *(bf16x4*)(img + 2 * piece_bytes) = l;
+    u32x2_ h, m, l;
+    { unsigned h_, m_, l_; s3b_split2(v[0], v[1], h_, m_, l_); h.x = h_; m.x = m_; l.x = l_; }
+    { unsigned h_, m_, l_; s3b_split2(v[2], v[3], h_, m_, l_); h.y = h_; m.y = m_; l.y = l_; }
+    *(u32x2_*)img = h; *(u32x2_*)(img + piece_bytes) = m; *(u32x2_*)(img + 2 * piece_bytes) = l;
 }
 struct S3bOp { bf16x8 h, m, l; };
 __device__ __forceinline__ S3bOp s3b_load(const char* img, int piece_bytes) {
@@ -77,18 +78,18 @@ __device__ __forceinline__ S3bOp s3b_load(const char* img, int piece_bytes) {
     return o;
 }
 // 8 consecutive fp32 values -> a split operand
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ S3bOp s3b_split8(const f32x4& lo4, const f32x4& hi4) {
+    u32x4 h, m, l;
+    { unsigned h_, m_, l_; s3b_split2(lo4[0], lo4[1], h_, m_, l_); h.x = h_; m.x = m_; l.x = l_; }
+    { unsigned h_, m_, l_; s3b_split2(lo4[2], lo4[3], h_, m_, l_); h.y = h_; m.y = m_; l.y = l_; }
+    { unsigned h_, m_, l_; s3b_split2(hi4[0], hi4[1], h_, m_, l_); h.z = h_; m.z = m_; l.z = l_; }
+    { unsigned h_, m_, l_; s3b_split2(hi4[2], hi4[3], h_, m_, l_); h.w = h_; m.w = m_; l.w = l_; }
     S3bOp o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        __bf16 a, b, c;
-        s3b_split(j < 4 ? lo4[j] : hi4[j - 4], a, b, c);
-        o.h[j] = a; o.m[j] = b; o.l[j] = c;
-    }
+    o.h = __builtin_bit_cast(bf16x8, h); o.m = __builtin_bit_cast(bf16x8, m); o.l = __builtin_bit_cast(bf16x8, l);
     return o;
 }
 // an ordered no-op that consumes and redefines the operand: pins its computation in program order
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void s3b_pin(S3bOp& o) {
     u32x4 a = __builtin_bit_cast(u32x4, o.h), b = __builtin_bit_cast(u32x4, o.m), c = __builtin_bit_cast(u32x4, o.l);
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c));

@@ -672,7 +672,9 @@ def test_loss_grad_headline_shape_variants():
 
 
 def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
-    """CNF_PERSISTENT=0 (the streamed step launches instead of the one-launch solve), CNF_STEP_FP32 (the fp32-MFMA step
+    """CNF_PERSISTENT=0 (the streamed step launches instead of the one-launch solve), CNF_PIPE=1 (k_solve3p: the interleaved
+    schedule of the one-launch solve), CNF_SOLVE_POLL_LIMIT=1 (every wait of the one-launch solve runs out: the streamed
+    fallback), CNF_STEP_FP32 (the fp32-MFMA step
     kernels k_step3 / k_step3j instead of the split-bf16 ones), CNF_STEP_V1 /
     CNF_TRACE_GENERIC / CNF_ADJ_GENERIC (the first-generation kernels): read once per process; each route runs its parity
     tests in a child process."""
@@ -681,6 +683,8 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
     for var, sel in (("CNF_PERSISTENT=0", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3 or "
                                           "test_one_launch_solve or test_headline_kernels_strict"),
                      ("CNF_SOLVE_POLL_LIMIT=1", "test_one_launch_solve_falls_back"),
+                     ("CNF_PIPE=1", "test_headline_kernels_strict or test_adaptive_solve_vs_oracles and 3-mfma or "
+                                    "test_loss_grad_headline or test_one_launch_solve_takes"),
                      ("CNF_STEP_FP32", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve or "
                                        "test_jvp_mode_headline_shape_step_kernel or ragged or test_headline_kernels_strict"),
                      ("CNF_STEP_V1", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve"),
@@ -1141,14 +1145,16 @@ def test_headline_kernels_strict_vs_float64_at_size(B):
 
 def test_split_product_error_bound():
     """The arithmetic of the split kernels, isolated (cnf_selftest_split_product: operand split + six-term bf16 MFMA
-    product, as k_step3b / k_solve3b run it) against float64.  An fp32 value is the exact sum of three bf16 pieces by
-    truncation, |m| < 2^-7 |v|, |l| < 2^-15 |v|; the three products left out (m l, l m, l l) are below 2^-21 |a b| in the
-    worst case (every mantissa bit set) and ~2^-24 |a b| on random bits; the rest is fp32 accumulation.  Bounds asserted,
-    relative to S = sum_k |a_k b_k| per output entry:
-      random N(0,1), K = 32 .. 512 .................. 2^-22 S   (v_mfma_f32_16x16x4_f32 measures 7.6e-8 S = 2^-23.6 S)
-      magnitudes over 40 binades, random signs ....... 2^-20 S   (one product dominates a sum: its own worst case shows)
-      all-ones mantissas, one sign (worst case) ...... 2^-20 S
-      exactly cancelling K = 128 sums ................ 2^-21 S absolute (the exact result is 0)
+    product, as k_step3b / k_solve3b run it) against float64.  An fp32 value is the exact sum of three bf16 pieces taken by
+    round-to-nearest, |m| <= 2^-8 |v|, |l| <= 2^-16 |v|, so the three products left out (m l, l m, l l) stay below
+    2^-23 |a b| for every input (truncated pieces, round 2's form: 2^-21 with every mantissa bit set -- measured 4e-7);
+    the rest is the fp32 accumulation inside and between the MFMAs.  Bounds asserted, relative to S = sum_k |a_k b_k| per
+    output entry (measured on MI355X in brackets):
+      random N(0,1), K = 32 .. 512 .................. 2^-22 S   [0.65 .. 1.3e-7; v_mfma_f32_16x16x4_f32: 7.6e-8]
+      magnitudes over 40 binades, random signs ....... 2^-20 S   [4.1e-7: the MFMA aligns the 32 products of a k-block to
+                                                                  the largest one; a property of the accumulate, not of the split]
+      all-ones mantissas, one sign ................... 2^-22 S   [1.2e-7]
+      exactly cancelling K = 128 sums ................ 2^-22 S absolute (the exact result is 0)   [7.4e-8]
     The measured figures go to parity_report.json."""
     l = _lib.lib()
     rng = np.random.default_rng(2024)
@@ -1176,13 +1182,13 @@ def test_split_product_error_bound():
     ones = np.full((16, 128), np.float32(np.nextafter(np.float32(2.0), np.float32(0.0))))      # 0x3FFFFFFF: every bit set
     e = run(ones, ones)[0]
     worst["all-ones mantissas"] = e
-    assert e <= 2.0 ** -20, e
+    assert e <= 2.0 ** -22, e
     A = rng.standard_normal((16, 128)).astype(np.float32)
     Bt = rng.standard_normal((16, 128)).astype(np.float32)
     A[:, 64:] = A[:, :64]; Bt[:, 64:] = -Bt[:, :64]            # sum_k a_k b_k = 0 exactly, term by term
     e = run(A, Bt)[0]
     worst["cancelling"] = e
-    assert e <= 2.0 ** -21, e
+    assert e <= 2.0 ** -22, e
     helpers.REPORT.append({"what": "split product |C - f64| / sum|ab|", "shape": [16, 16], "rtol": 2.0 ** -20,
                            "err_over_bar": max(worst.values()) / 2.0 ** -20, "max_abs_err": max(worst.values()),
                            "max_rel_err": max(worst.values()), "mean_rel_err": float(np.mean(list(worst.values()))),
@@ -1217,11 +1223,15 @@ def test_step_trace_follows_the_c_oracle():
     assert abs(na - nc) <= 2 and g[0, 0] == 0.0
     assert abs(float(g[g[:, 3] > 0, 1].sum()) - 1.0) < 1e-5          # accepted steps tile the span
     assert np.all(np.diff(g[g[:, 3] > 0, 0]) > 0)
+    # the first attempt starts from the same t and the same automatic dt; its error estimate is a round-off-level quantity
+    # on this well-resolved problem (1e-4: the products differ in rounding between the two), so it agrees in magnitude only;
+    # where an estimate is well above round-off the two agree to a few per cent
+    assert abs(g[0, 1] / c[0, 1] - 1.0) < 1e-3, (g[0], c[0])
+    assert 0.2 < g[0, 2] / c[0, 2] < 5.0, (g[0], c[0])
     m = min(na, nc)
-    big = (c[:m, 2] > 1e-2) & (g[:m, 2] > 1e-2)
-    same_t = np.abs(g[:m, 0] - c[:m, 0]) <= 1e-3 * np.maximum(1e-3, np.abs(c[:m, 0]))
-    sel = big & same_t
-    assert sel.sum() >= 3 and np.all(np.abs(g[:m, 2][sel] / c[:m, 2][sel] - 1.0) < 0.05), (g[:m], c[:m])
+    sel = (c[:m, 2] > 1e-2) & (g[:m, 2] > 1e-2) & (np.abs(g[:m, 0] - c[:m, 0]) <= 1e-3 * np.maximum(1e-3, np.abs(c[:m, 0])))
+    assert np.all(np.abs(g[:m, 2][sel] / c[:m, 2][sel] - 1.0) < 0.05), (g[:m], c[:m])
+    assert np.all((g[:, 2] >= 0) & (g[:, 2] <= 1.0 + 1e-6) | (g[:, 3] == 0))      # accepted attempts have EEst <= 1
     assert ic.set_step_trace(0) is None
     ic.close()
 
