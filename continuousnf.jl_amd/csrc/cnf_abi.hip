@@ -743,7 +743,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             dump = h->traj + n;                      // stage area of slot 0; u_n sits one array before
         }
         s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror, base, sv, h->device,
-                                  dump, n, slot, dcap, h->traj_hs);
+                                  dump, n, slot, dcap, h->traj_hs, h->K1);
         if (s == CNF_OK) {
             ++launches;
             h->mirror_base = base + 1;

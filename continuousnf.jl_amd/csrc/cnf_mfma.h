@@ -97,6 +97,7 @@ struct Solve3Args {
 cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st_out, float* const U[2],
                                  const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv, int device,
                                  float* dump = nullptr, size_t dump_stride = 0, size_t dump_step_stride = 0, int dump_cap = 0,
-                                 float* hs_out = nullptr);     // dump ...: the trajectory store of the gradient path (as mfma_step)
+                                 float* hs_out = nullptr,      // dump ...: the trajectory store of the gradient path (as mfma_step)
+                                 float* const* K1 = nullptr);  // the k1 / k7 buffer sets: batches of several tiles per workgroup
 // workgroups (= error partials) of a step launch; `recording`: the solve files its stage states (gradient path)
 int mfma_grid_for(const MfmaPlan& p, int B, bool recording = false, bool train = true);

@@ -1559,7 +1559,8 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, con
 // launches instead.  CNF_PERSISTENT=0 switches it off.
 cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st_out, float* const U[2],
                                  const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv, int device,
-                                 float* dump, size_t dump_stride, size_t dump_step_stride, int dump_cap, float* hs_out) {
+                                 float* dump, size_t dump_stride, size_t dump_step_stride, int dump_cap, float* hs_out,
+                                 float* const* K1) {
     static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); return e && e[0] == '0'; }();
     static const bool fp32_only = [] { const char* e = getenv("CNF_STEP_FP32"); return e && e[0] == '1'; }();
     // k_solve3jb (one forward sweep of state and tangent columns): JVP handles, and VJP handles without the |eps^T J| row
@@ -1575,17 +1576,27 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     const bool use_p = pipe && !jvp;
     const int ntile = (B + 31) / 32;
     const int resident = use_p ? step3p_solve_resident(dump != nullptr, device) : step3b_solve_resident(jvp, dump != nullptr, device);
-    if (ntile < 1 || ntile > 512 || ntile > resident) return CNF_ERR_UNSUPPORTED;
+    if (ntile < 1 || resident < 1) return CNF_ERR_UNSUPPORTED;
+    // One 32-column tile per workgroup when the device holds them all at once; larger batches run several tiles per
+    // workgroup with the state in the integrator's buffers (the tiles dealt evenly: ceil(ntile / rounds) workgroups)
+    int grid = ntile;
+    if (ntile > resident) {
+        if (use_p || dump || !K1) return CNF_ERR_UNSUPPORTED;
+        const int rounds = (ntile + resident - 1) / resident;
+        grid = (ntile + rounds - 1) / rounds;
+    }
+    if (grid > 512) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
     a.init_phase = -1;
     a.mode = 2; a.B = B; a.eps = eps; a.st = st_out; a.st_out = st_out;
     a.n_total = (float)((size_t)(nd.n_in + 3) * B);
     a.U[0] = U[0]; a.U[1] = U[1];
+    if (K1) { a.K1[0] = K1[0]; a.K1[1] = K1[1]; }
     a.mirror = mirror; a.seq = seq;
     a.dump = dump; a.dump_stride = dump_stride; a.dump_step_stride = dump_step_stride; a.dump_cap = dump_cap; a.hs_out = hs_out;
     sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
-    if (use_p) return step3p_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, ntile, s, sv, device);
-    return step3b_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, ntile, s, sv, jvp, device);
+    if (use_p) return step3p_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, sv, device);
+    return step3b_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, sv, jvp, device);
 }
 
 cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const StepState* st_in,

@@ -1720,7 +1720,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 // ---------------------------------------------------------------------------------------------------------------
 // RECORD (gradient path): every attempt files u_n and its stage states U_2..U_6 (z rows) in the trajectory slot of step
 // `naccept` (a.dump, as the recording launches of k_mfma do), its signed step size in a.hs_out.
-template <bool RECORD>
+template <bool RECORD, bool MULTI>
 __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __restrict__ imgb, int n_in, int norm_z,
                                                     int norm_j, const S3Tab tab, Solve3Args sv) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1736,10 +1736,18 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     const int r0 = 16 * t + 4 * q;
     const int nv = n_in - r0;
     const bool wide = (n_in & 3) == 0;
-    const int b0 = blockIdx.x * 32 + 16 * hf;
-    const bool live = s < max(0, min(16, a.B - b0));
-    const size_t gcol = (size_t)(b0 + s) * D;
-    const int ce = live ? nv : 0, cu = (zown && live) ? nv : 0, cs = (sown && live) ? 3 : 0;
+    const int ntile = (a.B + 31) / 32;
+    constexpr bool multi = MULTI;                          // several tiles per workgroup: the state lives in a.U / a.K1 (k_solve3jb)
+    int b0 = blockIdx.x * 32 + 16 * hf;
+    bool live = s < max(0, min(16, a.B - b0));
+    size_t gcol = (size_t)(b0 + s) * D;
+    int ce = live ? nv : 0, cu = (zown && live) ? nv : 0, cs = (sown && live) ? 3 : 0;
+    auto set_tile = [&](int tile) {
+        b0 = tile * 32 + 16 * hf;
+        live = s < max(0, min(16, a.B - b0));
+        gcol = (size_t)(b0 + s) * D;
+        ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
+    };
     if (sv.t_out && blockIdx.x == 0 && tid == 0) sv.t_out[0] = __builtin_amdgcn_s_memrealtime();
     // ---- one round trip: this tile's state and probe rows, the weights ----
     const f32x4 re = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
@@ -1791,7 +1799,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's LDS-DMA pieces have landed
     __builtin_amdgcn_sched_barrier(0);
-    const f32x4 epsr = ld4_mask(re, ce);
+    f32x4 epsr = ld4_mask(re, ce);
     float* msc = lds + s3v::MISC;
     StepState* ns = reinterpret_cast<StepState*>(msc + 44);            // the integrator state (thread 0 runs the controller on it)
     static_assert(sizeof(StepState) <= 20 * sizeof(float), "fits the scratch words");
@@ -1925,51 +1933,93 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
         const float y = x / sk;
         acc = fmaf(y, y, acc);
     };
+    // ---- several tiles per workgroup (as k_solve3jb): a tile's rows from / to the integrator's buffers ----
+    int cur = 0;                                           // the buffer set that holds (u, k1)
+    auto load_tile = [&](int tile, bool with_k1, bool from_xs) {
+        set_tile(tile);
+        const float* Uc = cur ? a.U[1] : a.U[0];
+        const float* Kc = cur ? a.K1[1] : a.K1[0];
+        const f32x4 e_ = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
+        f32x4 u_, s_;
+        if (from_xs) {
+            const float* xc = sv.xs + (size_t)(b0 + s) * sv.nvars;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u_[j] = (cu > j && r0 + j < sv.nvars) ? xc[r0 + j] : 0.f;
+            s_ = zero4;
+        } else {
+            u_ = ld4_issue_w(Uc + gcol + r0, cu, img3, wide);
+            s_ = ld3_issue(Uc + gcol + n_in, cs, img3);
+        }
+        f32x4 k_ = zero4, ks_ = zero4;
+        if (with_k1) { k_ = ld4_issue_w(Kc + gcol + r0, cu, img3, wide); ks_ = ld3_issue(Kc + gcol + n_in, cs, img3); }
+        epsr = ld4_mask(e_, ce);
+        if (zown) { *(f32x4*)rkw = ld4_mask(u_, cu); *(f32x4*)(rkw + 32) = ld4_mask(k_, cu); }
+        if (sown) { sc_set(0, ld4_mask(s_, cs)); sc_set(1, ld4_mask(ks_, cs)); }
+    };
+    auto store_rows = [&](float* dst, const f32x4& z4, const f32x4& s4) {     // one D-row column of this lane's sample
+        if (live && zown) { if (nv >= 4) st4_wide(dst + gcol + r0, z4); else st4(dst + gcol + r0, z4, nv); }
+        if (live && sown) { float* o = dst + gcol + n_in; o[0] = s4.x; o[1] = s4.y; o[2] = s4.z; }
+    };
     bool alive = true;
     {
         // ---- k1 = f(u0); with the automatic initial dt (Hairer; the two single evaluations of the streamed driver) also
         // its norms, f(u0 + h0 f0) and that norm ----
-        if (zown) {
-            s3b_store4(x0w, s3v::NP, *(const f32x4*)rkw);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;
-        }
-        s3_bar();
-        nstg = 1; evals();
         float e = 0.f, b = 0.f;
-        if (live && zown) {
-            const f32x4 u4 = *(const f32x4*)rkw, f0 = *(const f32x4*)kzw;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) if (c < nv) { add_norm(e, u4[c], u4[c]); add_norm(b, u4[c], f0[c]); }
-            *(f32x4*)(rkw + 32) = f0;                                      // k1 = f(u0)
-        }
-        if (live && sown) {
-            const f32x4 u4 = sc_get(0), f0 = read_scalars();
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { add_norm(e, u4[c], u4[c]); add_norm(b, u4[c], f0[c]); }
-            sc_set(1, f0);
-        }
-        if (sv.hairer) alive = meet(e, b);
-        if (sv.hairer && alive) {
-            if (tid == 0) { ctrl_phase(ns, 0, msc[32], msc[33], a.n_total); post_ctrl(0); }
-            share();
+        for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+            if (multi) { load_tile(tile, false, sv.xs != nullptr); }
             if (zown) {
-                s3b_store4(x0w, s3v::NP, *(const f32x4*)rkw + hstep * *(const f32x4*)(rkw + 32));   // f(u0 + h0 f0)
+                s3b_store4(x0w, s3v::NP, *(const f32x4*)rkw);
 #pragma unroll
                 for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;
             }
             s3_bar();
             nstg = 1; evals();
-            e = 0.f; b = 0.f;
+            f32x4 f0z = zero4, f0s = zero4;
+            if (zown) f0z = *(const f32x4*)kzw;
             if (live && zown) {
-                const f32x4 u4 = *(const f32x4*)rkw, f0 = *(const f32x4*)(rkw + 32), f1 = *(const f32x4*)kzw;
+                const f32x4 u4 = *(const f32x4*)rkw;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (c < nv) add_norm(e, u4[c], f1[c] - f0[c]);
+                for (int c = 0; c < 4; ++c) if (c < nv) { add_norm(e, u4[c], u4[c]); add_norm(b, u4[c], f0z[c]); }
             }
+            if (zown) *(f32x4*)(rkw + 32) = f0z;                           // k1 = f(u0)
+            if (sown) f0s = read_scalars();
             if (live && sown) {
-                const f32x4 u4 = sc_get(0), f0 = sc_get(1), f1 = read_scalars();
+                const f32x4 u4 = sc_get(0);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) add_norm(e, u4[c], f1[c] - f0[c]);
+                for (int c = 0; c < 3; ++c) { add_norm(e, u4[c], u4[c]); add_norm(b, u4[c], f0s[c]); }
+            }
+            if (sown) sc_set(1, f0s);
+            if (multi) {                                   // u0 (when it came from the data columns) and k1 to the buffers
+                if (sv.xs) store_rows(a.U[0], zown ? *(const f32x4*)rkw : zero4, sown ? sc_get(0) : zero4);
+                store_rows(a.K1[0], f0z, f0s);
+                s3_bar();                                  // (this tile's LDS rows are read before the next tile's are written)
+            }
+        }
+        if (sv.hairer) alive = meet(e, b);
+        if (sv.hairer && alive) {
+            if (tid == 0) { ctrl_phase(ns, 0, msc[32], msc[33], a.n_total); post_ctrl(0); }
+            share();
+            e = 0.f; b = 0.f;
+            for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+                if (multi) { load_tile(tile, true, false); }
+                if (zown) {
+                    s3b_store4(x0w, s3v::NP, *(const f32x4*)rkw + hstep * *(const f32x4*)(rkw + 32));   // f(u0 + h0 f0)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) *(f32x4*)(kzw + 32 * j) = zero4;
+                }
+                s3_bar();
+                nstg = 1; evals();
+                if (live && zown) {
+                    const f32x4 u4 = *(const f32x4*)rkw, f0 = *(const f32x4*)(rkw + 32), f1 = *(const f32x4*)kzw;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (c < nv) add_norm(e, u4[c], f1[c] - f0[c]);
+                }
+                if (live && sown) {
+                    const f32x4 u4 = sc_get(0), f0 = sc_get(1), f1 = read_scalars();
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) add_norm(e, u4[c], f1[c] - f0[c]);
+                }
+                if (multi) s3_bar();
             }
             alive = meet(e, b);
             if (alive) {
@@ -1982,6 +2032,9 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     int done = 0;
     int nacc = 0;                                          // accepted steps so far (the same count in every workgroup)
     for (int it = 0; alive && !done && it < sv.maxiters; ++it) {
+      float errsum = 0.f, badcnt = 0.f;
+      for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        if (multi) { load_tile(tile, true, false); }
         if (zown) {
             const f32x4 u2 = *(const f32x4*)rkw + (hstep * TS_A21) * *(const f32x4*)(rkw + 32);
             s3b_store4(x0w, s3v::NP, u2);                                    // U_2 = u + h a21 k1
@@ -1999,7 +2052,6 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
         if (RECORD && blockIdx.x == 0 && tid == 0 && nacc < a.dump_cap) a.hs_out[nacc] = hstep;
         s3_bar();
         nstg = 6; evals();
-        float errsum = 0.f, badcnt = 0.f;
         if (live && zown) {
             const f32x4 k7z = *(const f32x4*)(kzw + 32 * 5), uz_ = *(const f32x4*)rkw;
             const f32x4 un = s3b_load4(x0w, s3v::NP);
@@ -2014,16 +2066,26 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
                 badcnt += (c < nv && !(fabsf(un[c]) <= 3.0e38f)) ? 1.f : 0.f;
             }
         }
-        if (live && sown) {
+        f32x4 uns = zero4, k7s = zero4;
+        if (sown) {
             f32x4 ks[7];
 #pragma unroll
             for (int j = 0; j < 6; ++j) ks[j] = sc_get(1 + j);
             const f32x4 us = sc_get(0);
             ks[6] = read_scalars();
-            const f32x4 uns = us + hstep * stage_acc4<6>(ks);
-            err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
+            k7s = ks[6];
+            uns = us + hstep * stage_acc4<6>(ks);
+            if (live) err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
             sc_set(7, uns);                                                // kept for an accepted attempt
         }
+        if (multi) {                                       // (u_new, k7) to the other buffer set, as a step launch does
+            float* Un = cur ? a.U[0] : a.U[1];
+            float* Kn = cur ? a.K1[0] : a.K1[1];
+            store_rows(Un, zown ? s3b_load4(x0w, s3v::NP) : zero4, uns);
+            store_rows(Kn, zown ? *(const f32x4*)(kzw + 32 * 5) : zero4, k7s);
+            s3_bar();
+        }
+      }
         alive = meet(errsum, badcnt);
         if (!alive) break;
         if (tid == 0) {
@@ -2036,7 +2098,8 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
         }
         const int fl = share();
         done = fl & 1;
-        if (fl & 2) {                                                      // accepted: u <- u_new, k1 <- k7 (FSAL)
+        if (fl & 2 && multi) { ++nacc; cur ^= 1; }
+        else if (fl & 2) {                                                 // accepted: u <- u_new, k1 <- k7 (FSAL)
             ++nacc;
             if (zown) {
                 *(f32x4*)rkw = s3b_load4(x0w, s3v::NP);
@@ -2046,10 +2109,19 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
         }
     }
     // ---- the final state to the integrator's buffer set 0 ----
-    if (live && zown) { if (nv >= 4) st4_wide(a.U[0] + gcol + r0, *(const f32x4*)rkw); else st4(a.U[0] + gcol + r0, *(const f32x4*)rkw, nv); }
-    if (live && sown) { const f32x4 us = sc_get(0); float* o = a.U[0] + gcol + n_in; o[0] = us.x; o[1] = us.y; o[2] = us.z; }
+    if (!multi) store_rows(a.U[0], zown ? *(const f32x4*)rkw : zero4, sown ? sc_get(0) : zero4);
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};                   // this lane's share of the loss sums (waves 4 and 6)
     if (sv.logpx && alive) {
-        // ---- post-processing of this tile: logp(z) - dlogp, the regulariser rows; then the loss sums of the batch ----
+        // ---- post-processing of every tile: logp(z) - dlogp, the regulariser rows; then the loss sums of the batch ----
+      for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        if (multi) {
+            set_tile(tile);
+            const float* Uc = cur ? a.U[1] : a.U[0];
+            const f32x4 u_ = ld4_issue_w(Uc + gcol + r0, cu, img3, wide), s_ = ld3_issue(Uc + gcol + n_in, cs, img3);
+            s3_bar();                                      // (the tile before has read its RED / SC words)
+            if (zown) *(f32x4*)rkw = ld4_mask(u_, cu);
+            if (sown) sc_set(0, ld4_mask(s_, cs));
+        }
         if (zown) {
             const f32x4 u4 = *(const f32x4*)rkw;
             float ss = 0.f, sa = 0.f;
@@ -2059,17 +2131,17 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
             redw[0] = ss; redw[32 * 8] = sa;
         }
         s3_bar();
-        float v4[4] = {0.f, 0.f, 0.f, 0.f};
         if (live && sown) {
             const float ss = red8(0), sa = red8(1);
             const f32x4 us = sc_get(0);
             const float log2pi = 1.8378770664093453f;
-            v4[0] = -0.5f * fmaf((float)n_in, log2pi, ss) - us.x;         // base_icnf.jl:177-178
-            v4[1] = us.y; v4[2] = us.z;
-            v4[3] = (sv.norm_z_aug && sv.naugs > 0) ? sqrtf(sa) : 0.f;    // :179-187
+            const float lp = -0.5f * fmaf((float)n_in, log2pi, ss) - us.x;        // base_icnf.jl:177-178
+            const float aa = (sv.norm_z_aug && sv.naugs > 0) ? sqrtf(sa) : 0.f;   // :179-187
             const size_t b = (size_t)(b0 + s), Bz = (size_t)a.B;
-            sv.logpx[b] = v4[0]; sv.regs[b] = v4[1]; sv.regs[Bz + b] = v4[2]; sv.regs[2 * Bz + b] = v4[3];
+            sv.logpx[b] = lp; sv.regs[b] = us.y; sv.regs[Bz + b] = us.z; sv.regs[2 * Bz + b] = aa;
+            v4[0] += lp; v4[1] += us.y; v4[2] += us.z; v4[3] += aa;
         }
+      }
         if (sv.sums5) {
             // workgroup partials (waves 4 and 6 hold them) -> tagged words, one more meeting index; workgroup 0 adds them in
             // workgroup order
@@ -2120,7 +2192,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
-        ns->cur = 0;
+        ns->cur = multi ? cur : 0;
         *a.st_out = *ns;
         if (sv.t_out) { sv.t_out[1] += __builtin_amdgcn_s_memrealtime() - sv.t_out[0]; sv.t_out[2] += 1; }
         publish_mirror(a, *ns);
@@ -2129,9 +2201,18 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_solve3jb -- the one-launch solve (k_solve3b) around k_step3jb's evaluation code: the JVP compute mode of the headline
-// shape.  Same meetings, same controller, same fused assembly of u0 / post-processing / loss sums; the Runge-Kutta rows of
-// z stay in registers (as in k_step3jb), the scalar rows in LDS.
+// shape (and VJP handles without the |eps^T J| row: FFJORD).  Same meetings, same controller, same fused assembly of u0 /
+// post-processing / loss sums.
+//   One tile per workgroup (B <= 32 x the resident workgroups): the Runge-Kutta rows of z stay in registers for the whole
+//   solve (as in k_step3jb), the scalar rows in LDS; nothing but the meeting words leaves the CU between attempts.
+//   SEVERAL tiles per workgroup (larger batches: BASELINE config 4 unsharded, lock-step-free shards of any size): every
+//   attempt loops over the workgroup's tiles, taking (u, k1) and the probe rows from the integrator's buffer set `cur`
+//   and filing (u_new, k7) in the other set -- what a step launch of k_step3jb does per tile --, the workgroups meet
+//   once per attempt over the sum of their tiles' error partials, an accepted attempt flips `cur`.  Per attempt and
+//   sample that is 2 D + n_in floats read and 2 D written (45 MB at B = 65 536: microseconds), against the weight stream,
+//   prologue and launch of a step kernel per attempt that it replaces.
 // ---------------------------------------------------------------------------------------------------------------
+template <bool MULTI>
 __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __restrict__ imgb, int n_in, int norm_z,
                                                      int norm_j, const S3Tab tab, Solve3Args sv) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2147,10 +2228,19 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
     const int r0 = 16 * t + 4 * q;
     const int nv = n_in - r0;
     const bool wide = (n_in & 3) == 0;
-    const int b0 = blockIdx.x * 32 + 16 * hf;
-    const bool live = s < max(0, min(16, a.B - b0));
-    const size_t gcol = (size_t)(b0 + s) * D;
-    const int ce = live ? nv : 0, cu = (zown && live) ? nv : 0, cs = (sown && live) ? 3 : 0;
+    const int ntile = (a.B + 31) / 32;
+    constexpr bool multi = MULTI;                          // several tiles per workgroup: the state lives in a.U / a.K1
+    // the tile this workgroup is working on
+    int b0 = blockIdx.x * 32 + 16 * hf;
+    bool live = s < max(0, min(16, a.B - b0));
+    size_t gcol = (size_t)(b0 + s) * D;
+    int ce = live ? nv : 0, cu = (zown && live) ? nv : 0, cs = (sown && live) ? 3 : 0;
+    auto set_tile = [&](int tile) {
+        b0 = tile * 32 + 16 * hf;
+        live = s < max(0, min(16, a.B - b0));
+        gcol = (size_t)(b0 + s) * D;
+        ce = live ? nv : 0; cu = (zown && live) ? nv : 0; cs = (sown && live) ? 3 : 0;
+    };
     if (sv.t_out && blockIdx.x == 0 && tid == 0) sv.t_out[0] = __builtin_amdgcn_s_memrealtime();
     const f32x4 re = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
     f32x4 ru, rs;
@@ -2194,11 +2284,11 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
     const int nsw = (-(s >> 2)) & 3;                                 // chunk swizzle of the K = 32 images (rows s, 16 + s)
     const int nw = smp * s3b::NS + 16 * ((2 * t + (q >> 1)) ^ nsw) + 8 * (q & 1);      // this lane's 4 rows there
     char* x0w = ldsb + s3b::X0B + nw;
-    {
-        const f32x4 ev = ld4_mask(re, ce);
+    auto put_eps = [&](const f32x4& ev) {
         *(f32x4*)epw = ev;
         s3b_store4(ldsb + s3b::T0B + nw, s3b::NP, ev);
-    }
+    };
+    put_eps(ld4_mask(re, ce));
     float* msc = lds + s3b::MISC;
     StepState* ns = reinterpret_cast<StepState*>(msc + 44);            // the integrator state (thread 0 runs the controller on it)
     if (tid == 0) *ns = sv.init;
@@ -2318,40 +2408,83 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         const float y = x / sk;
         acc = fmaf(y, y, acc);
     };
+    // ---- several tiles per workgroup: a tile's rows from / to the integrator's buffers ----
+    int cur = 0;                                           // the buffer set that holds (u, k1)
+    // (u, k1) and the probe rows of tile `tile`; k1 only when `with_k1`; from the data columns when `from_xs`
+    auto load_tile = [&](int tile, bool with_k1, bool from_xs) {
+        set_tile(tile);
+        const float* Uc = cur ? a.U[1] : a.U[0];
+        const float* Kc = cur ? a.K1[1] : a.K1[0];
+        const f32x4 e_ = ld4_issue_w(a.eps + (size_t)(b0 + s) * n_in + r0, ce, img3, wide);
+        f32x4 u_, s_;
+        if (from_xs) {
+            const float* xc = sv.xs + (size_t)(b0 + s) * sv.nvars;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u_[j] = (cu > j && r0 + j < sv.nvars) ? xc[r0 + j] : 0.f;
+            s_ = zero4;
+        } else {
+            u_ = ld4_issue_w(Uc + gcol + r0, cu, img3, wide);
+            s_ = ld3_issue(Uc + gcol + n_in, cs, img3);
+        }
+        f32x4 k_ = zero4, ks_ = zero4;
+        if (with_k1) { k_ = ld4_issue_w(Kc + gcol + r0, cu, img3, wide); ks_ = ld3_issue(Kc + gcol + n_in, cs, img3); }
+        put_eps(ld4_mask(e_, ce));
+        uz = ld4_mask(u_, cu);
+        kz[0] = ld4_mask(k_, cu);
+        if (sown) { sc_set(0, ld4_mask(s_, cs)); sc_set(1, ld4_mask(ks_, cs)); }
+    };
+    auto store_rows = [&](float* dst, const f32x4& z4, const f32x4& s4) {     // one D-row column of this lane's sample
+        if (live && zown) { if (nv >= 4) st4_wide(dst + gcol + r0, z4); else st4(dst + gcol + r0, z4, nv); }
+        if (live && sown) { float* o = dst + gcol + n_in; o[0] = s4.x; o[1] = s4.y; o[2] = s4.z; }
+    };
     bool alive = true;
     {
         // ---- k1 = f(u0); with the automatic initial dt also its norms, f(u0 + h0 f0) and that norm ----
-        if (zown) { un = uz; s3b_store4(x0w, s3b::NP, un); }
-        s3_bar();
-        nstg = 1; evals();
         float e = 0.f, b = 0.f;
-        if (live && zown) {
+        for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+            if (multi) { load_tile(tile, false, sv.xs != nullptr); s3_bar(); }
+            if (zown) { un = uz; s3b_store4(x0w, s3b::NP, un); }
+            s3_bar();
+            nstg = 1; evals();
+            if (live && zown) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) if (c < nv) { add_norm(e, uz[c], uz[c]); add_norm(b, uz[c], kz[1][c]); }
+                for (int c = 0; c < 4; ++c) if (c < nv) { add_norm(e, uz[c], uz[c]); add_norm(b, uz[c], kz[1][c]); }
+            }
+            if (zown) kz[0] = kz[1];                                           // k1 = f(u0)
+            f32x4 f0s = zero4;
+            if (sown) f0s = read_scalars();
+            if (live && sown) {
+                const f32x4 u4 = sc_get(0);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { add_norm(e, u4[c], u4[c]); add_norm(b, u4[c], f0s[c]); }
+            }
+            if (sown) sc_set(1, f0s);
+            if (multi) {                                   // u0 (when it came from the data columns) and k1 to the buffers
+                if (sv.xs) store_rows(a.U[0], uz, sc_get(0));
+                store_rows(a.K1[0], kz[0], f0s);
+                s3_bar();                                  // (this tile's LDS words are read before the next tile's are written)
+            }
         }
-        if (zown) kz[0] = kz[1];                                           // k1 = f(u0)
-        if (live && sown) {
-            const f32x4 u4 = sc_get(0), f0 = read_scalars();
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { add_norm(e, u4[c], u4[c]); add_norm(b, u4[c], f0[c]); }
-            sc_set(1, f0);
-        } else if (sown) sc_set(1, read_scalars());
         if (sv.hairer) alive = meet(e, b);
         if (sv.hairer && alive) {
             if (tid == 0) { ctrl_phase(ns, 0, msc[32], msc[33], a.n_total); post_ctrl(0); }
             share();
-            if (zown) { un = uz + hstep * kz[0]; s3b_store4(x0w, s3b::NP, un); }
-            s3_bar();
-            nstg = 1; evals();
             e = 0.f; b = 0.f;
-            if (live && zown) {
+            for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+                if (multi) { load_tile(tile, true, false); s3_bar(); }
+                if (zown) { un = uz + hstep * kz[0]; s3b_store4(x0w, s3b::NP, un); }
+                s3_bar();
+                nstg = 1; evals();
+                if (live && zown) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (c < nv) add_norm(e, uz[c], kz[1][c] - kz[0][c]);
-            }
-            if (live && sown) {
-                const f32x4 u4 = sc_get(0), f0 = sc_get(1), f1 = read_scalars();
+                    for (int c = 0; c < 4; ++c) if (c < nv) add_norm(e, uz[c], kz[1][c] - kz[0][c]);
+                }
+                if (live && sown) {
+                    const f32x4 u4 = sc_get(0), f0 = sc_get(1), f1 = read_scalars();
 #pragma unroll
-                for (int c = 0; c < 3; ++c) add_norm(e, u4[c], f1[c] - f0[c]);
+                    for (int c = 0; c < 3; ++c) add_norm(e, u4[c], f1[c] - f0[c]);
+                }
+                if (multi) s3_bar();
             }
             alive = meet(e, b);
             if (alive) {
@@ -2363,32 +2496,44 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
     // ---- step attempts ----
     int done = 0;
     for (int it = 0; alive && !done && it < sv.maxiters; ++it) {
-#pragma unroll
-        for (int j = 1; j < 7; ++j) kz[j] = zero4;
-        if (zown) { un = uz + (hstep * TS_A21) * kz[0]; s3b_store4(x0w, s3b::NP, un); }      // U_2 = u + h a21 k1
-        s3_bar();
-        nstg = 6; evals();
         float errsum = 0.f, badcnt = 0.f;
-        if (live && zown) {
-            const f32x4 ez = TS_BT1 * kz[0] + TS_BT2 * kz[1] + TS_BT3 * kz[2] + TS_BT4 * kz[3] + TS_BT5 * kz[4] +
-                             TS_BT6 * kz[5] + TS_BT7 * kz[6];
+        for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+            if (multi) { load_tile(tile, true, false); s3_bar(); }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float scl = fmaf(fmaxf(fabsf(uz[c]), fabsf(un[c])), reltol, abstol);
-                const float x = c < nv ? hstep * ez[c] / scl : 0.f;
-                errsum = fmaf(x, x, errsum);
-                badcnt += (c < nv && !(fabsf(un[c]) <= 3.0e38f)) ? 1.f : 0.f;
+            for (int j = 1; j < 7; ++j) kz[j] = zero4;
+            if (zown) { un = uz + (hstep * TS_A21) * kz[0]; s3b_store4(x0w, s3b::NP, un); }      // U_2 = u + h a21 k1
+            s3_bar();
+            nstg = 6; evals();
+            if (live && zown) {
+                const f32x4 ez = TS_BT1 * kz[0] + TS_BT2 * kz[1] + TS_BT3 * kz[2] + TS_BT4 * kz[3] + TS_BT5 * kz[4] +
+                                 TS_BT6 * kz[5] + TS_BT7 * kz[6];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float scl = fmaf(fmaxf(fabsf(uz[c]), fabsf(un[c])), reltol, abstol);
+                    const float x = c < nv ? hstep * ez[c] / scl : 0.f;
+                    errsum = fmaf(x, x, errsum);
+                    badcnt += (c < nv && !(fabsf(un[c]) <= 3.0e38f)) ? 1.f : 0.f;
+                }
             }
-        }
-        if (live && sown) {
-            f32x4 ks[7];
+            f32x4 uns = zero4, k7s = zero4;
+            if (sown) {
+                f32x4 ks[7];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) ks[j] = sc_get(1 + j);
-            const f32x4 us = sc_get(0);
-            ks[6] = read_scalars();
-            const f32x4 uns = us + hstep * stage_acc4<6>(ks);
-            err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
-            sc_set(7, uns);                                                // kept for an accepted attempt
+                for (int j = 0; j < 6; ++j) ks[j] = sc_get(1 + j);
+                const f32x4 us = sc_get(0);
+                ks[6] = read_scalars();
+                k7s = ks[6];
+                uns = us + hstep * stage_acc4<6>(ks);
+                if (live) err_acc(errsum, badcnt, ks, us, uns, hstep, abstol, reltol, 3);
+                sc_set(7, uns);                                                // kept for an accepted attempt
+            }
+            if (multi) {                                   // (u_new, k7) to the other buffer set, as a step launch does
+                float* Un = cur ? a.U[0] : a.U[1];
+                float* Kn = cur ? a.K1[0] : a.K1[1];
+                store_rows(Un, un, uns);
+                store_rows(Kn, kz[6], k7s);
+                s3_bar();
+            }
         }
         alive = meet(errsum, badcnt);
         if (!alive) break;
@@ -2403,34 +2548,46 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         const int fl = share();
         done = fl & 1;
         if (fl & 2) {                                                      // accepted: u <- u_new, k1 <- k7 (FSAL)
-            if (zown) { uz = un; kz[0] = kz[6]; }
-            if (sown) { const f32x4 k7s = read_scalars(); sc_set(0, sc_get(7)); sc_set(1, k7s); }
+            if (multi) cur ^= 1;
+            else {
+                if (zown) { uz = un; kz[0] = kz[6]; }
+                if (sown) { const f32x4 k7s = read_scalars(); sc_set(0, sc_get(7)); sc_set(1, k7s); }
+            }
         }
     }
-    // ---- the final state to the integrator's buffer set 0 ----
-    if (live && zown) { if (nv >= 4) st4_wide(a.U[0] + gcol + r0, uz); else st4(a.U[0] + gcol + r0, uz, nv); }
-    if (live && sown) { const f32x4 us = sc_get(0); float* o = a.U[0] + gcol + n_in; o[0] = us.x; o[1] = us.y; o[2] = us.z; }
+    // ---- the final state: one tile per workgroup -> the integrator's buffer set 0; several: it is in set `cur` ----
+    if (!multi) store_rows(a.U[0], uz, sc_get(0));
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};                   // this lane's share of the loss sums (waves 4 and 6)
     if (sv.logpx && alive) {
-        // ---- post-processing of this tile: logp(z) - dlogp, the regulariser rows; then the loss sums of the batch ----
-        if (zown) {
-            const f32x4 u4 = uz;
-            float ss = 0.f, sa = 0.f;
+        // ---- post-processing of every tile: logp(z) - dlogp, the regulariser rows; then the loss sums of the batch ----
+        for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+            if (multi) {
+                set_tile(tile);
+                const float* Uc = cur ? a.U[1] : a.U[0];
+                const f32x4 u_ = ld4_issue_w(Uc + gcol + r0, cu, img3, wide), s_ = ld3_issue(Uc + gcol + n_in, cs, img3);
+                uz = ld4_mask(u_, cu);
+                s3_bar();                                  // (the tile before has read its RED / SC words)
+                if (sown) sc_set(0, ld4_mask(s_, cs));
+            }
+            if (zown) {
+                const f32x4 u4 = uz;
+                float ss = 0.f, sa = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < nv) { ss = fmaf(u4[c], u4[c], ss); if (r0 + c >= sv.nvars) sa = fmaf(u4[c], u4[c], sa); }
-            redw[0] = ss; redw[32 * 8] = sa;
-        }
-        s3_bar();
-        float v4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (live && sown) {
-            const float ss = red8(0), sa = red8(1);
-            const f32x4 us = sc_get(0);
-            const float log2pi = 1.8378770664093453f;
-            v4[0] = -0.5f * fmaf((float)n_in, log2pi, ss) - us.x;         // base_icnf.jl:177-178
-            v4[1] = us.y; v4[2] = us.z;
-            v4[3] = (sv.norm_z_aug && sv.naugs > 0) ? sqrtf(sa) : 0.f;    // :179-187
-            const size_t b = (size_t)(b0 + s), Bz = (size_t)a.B;
-            sv.logpx[b] = v4[0]; sv.regs[b] = v4[1]; sv.regs[Bz + b] = v4[2]; sv.regs[2 * Bz + b] = v4[3];
+                for (int c = 0; c < 4; ++c)
+                    if (c < nv) { ss = fmaf(u4[c], u4[c], ss); if (r0 + c >= sv.nvars) sa = fmaf(u4[c], u4[c], sa); }
+                redw[0] = ss; redw[32 * 8] = sa;
+            }
+            s3_bar();
+            if (live && sown) {
+                const float ss = red8(0), sa = red8(1);
+                const f32x4 us = sc_get(0);
+                const float log2pi = 1.8378770664093453f;
+                const float lp = -0.5f * fmaf((float)n_in, log2pi, ss) - us.x;        // base_icnf.jl:177-178
+                const float aa = (sv.norm_z_aug && sv.naugs > 0) ? sqrtf(sa) : 0.f;   // :179-187
+                const size_t b = (size_t)(b0 + s), Bz = (size_t)a.B;
+                sv.logpx[b] = lp; sv.regs[b] = us.y; sv.regs[Bz + b] = us.z; sv.regs[2 * Bz + b] = aa;
+                v4[0] += lp; v4[1] += us.y; v4[2] += us.z; v4[3] += aa;
+            }
         }
         if (sv.sums5) {
             // workgroup partials (waves 4 and 6 hold them) -> tagged words, one more meeting index; workgroup 0 adds them in
@@ -2482,13 +2639,12 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
-        ns->cur = 0;
+        ns->cur = multi ? cur : 0;
         *a.st_out = *ns;
         if (sv.t_out) { sv.t_out[1] += __builtin_amdgcn_s_memrealtime() - sv.t_out[0]; sv.t_out[2] += 1; }
         publish_mirror(a, *ns);
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // Self-test of the arithmetic of the split kernels (cnf_selftest_split_product): C = A Bt^T for A, Bt of 16 x K fp32 on ONE
@@ -2565,8 +2721,10 @@ void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStre
     hipLaunchKernelGGL(k_pack_step3b, dim3((NT + 255) / 256), dim3(256), 0, s, nd, d_params, (char*)d_imgb);
 }
 // Function attributes and occupancy belong to a (function, device) pair: kept per device, set on first use there.
-static const void* solve3_fn(bool jvp, bool record) {
-    return jvp ? (const void*)k_solve3jb : (record ? (const void*)k_solve3b<true> : (const void*)k_solve3b<false>);
+static const void* solve3_fn(bool jvp, bool record, bool multi = false) {
+    if (jvp) return multi ? (const void*)k_solve3jb<true> : (const void*)k_solve3jb<false>;
+    if (record) return (const void*)k_solve3b<true, false>;
+    return multi ? (const void*)k_solve3b<false, true> : (const void*)k_solve3b<false, false>;
 }
 static size_t solve3_shm(bool jvp) { return jvp ? (size_t)s3b::TOTAL_BYTES : (size_t)s3v::TOTAL_BYTES; }
 int step3b_solve_resident(bool jvp, bool record, int device) {
@@ -2581,9 +2739,11 @@ int step3b_solve_resident(bool jvp, bool record, int device) {
         r = -1;
         int cur = -1, n_cu = 0, per_cu = 0;
         const void* fn = solve3_fn(jvp, record);
+        const void* fn_multi = solve3_fn(jvp, record, !record);           // (the several-tiles-per-workgroup instantiation)
         const size_t shm = solve3_shm(jvp);
         if (hipGetDevice(&cur) == hipSuccess && (cur == device || hipSetDevice(device) == hipSuccess)) {
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess &&
+                hipFuncSetAttribute(fn_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess &&
                 hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, shm) == hipSuccess && per_cu >= 1 && n_cu >= 1)
                 // (148 KB of LDS per workgroup: one per CU whatever the API says about registers -- it is known to report
@@ -2610,7 +2770,9 @@ cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, 
     S3Tab tab = kS3Tab;
     Solve3Args sv = sv_;
     void* args[] = {&a_, &img, &n_in, &norm_z, &norm_j, &tab, &sv};
-    if (hipLaunchKernel(solve3_fn(jvp, record), dim3(grid), dim3(512), args, solve3_shm(jvp), s) != hipSuccess) {
+    const bool multi = (a.B + 31) / 32 > grid;             // several tiles per workgroup: the state lives in a.U / a.K1
+    if (multi && (record || !a.K1[0] || !a.K1[1])) return CNF_ERR_UNSUPPORTED;
+    if (hipLaunchKernel(solve3_fn(jvp, record, multi), dim3(grid), dim3(512), args, solve3_shm(jvp), s) != hipSuccess) {
         (void)hipGetLastError();
         return CNF_ERR_UNSUPPORTED;
     }
