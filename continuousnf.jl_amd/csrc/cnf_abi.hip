@@ -385,8 +385,18 @@ static bool jvp_aux_ok(cnf_handle h) {
 // one evaluation with an auxiliary MFMA kernel (TestMode: exact trace; TrainMode: JVP): u -> du (or k7)
 // nk > 0 (inside a solve): the kernel forms the Runge-Kutta stage state from nk stage derivatives itself (and, for
 // stage 6, stores it as the new solution); otherwise it evaluates at `u`
+struct TraceFuse {          // norms / controller / the whole attempt inside the trace launch (k_trace3s; see TraceArgs)
+    int norm_kind = -1;     // 0 / 1: norms of the automatic initial dt; 2: the error norm of an attempt
+    bool step = false;      // the six stage evaluations of an attempt in one launch
+    void* mirror = nullptr;
+    unsigned seq = 0;
+};
+static bool trace_fused_ok(cnf_handle h, int B) {
+    const GradLayout g = grad_layout(h->nd);
+    return !h->aux_train && trace_fused_supported(h->nd, adj_mfma_layout(h->nd, g), B);
+}
 static cnf_status launch_trace(cnf_handle h, const float* u, float* du, bool in_solve, bool du_is_k7, int B, hipStream_t st,
-                               int nk = 0, const float* coef = nullptr, bool also_unew = false) {
+                               int nk = 0, const float* coef = nullptr, bool also_unew = false, const TraceFuse* fuse = nullptr) {
     const GradLayout g = grad_layout(h->nd);
     const AdjMfmaLayout m = adj_mfma_layout(h->nd, g);
     TraceArgs a{};
@@ -400,6 +410,13 @@ static cnf_status launch_trace(cnf_handle h, const float* u, float* du, bool in_
     for (int i = 0; i < 5; ++i) a.Ks[i] = h->Ks[i];
     for (int i = 0; i < a.nk && i < 6; ++i) a.coef[i] = coef[i];
     a.also_unew = also_unew ? 1 : 0;
+    a.norm_kind = -1;
+    if (fuse) {
+        a.norm_kind = fuse->norm_kind; a.fused_step = fuse->step ? 1 : 0;
+        a.partials = h->partials; a.ticket = reinterpret_cast<unsigned*>(h->d_sums + 8); a.st_mut = h->d_state;
+        a.n_total = (float)((size_t)rows_of(h, CNF_MODE_TEST) * B);
+        a.mirror = fuse->mirror; a.seq = fuse->seq;
+    }
     if (h->aux_train && h->nd.jvp) HIPCHK(h, launch_jvp_mfma(h->nd, g, m, h->d_adj_img, a, h->aux_eps, st));
     else HIPCHK(h, launch_trace_mfma(h->nd, g, m, h->d_adj_img, a, st));
     return CNF_OK;
@@ -537,7 +554,7 @@ extern "C" cnf_status cnf_rhs_host(cnf_handle h, int mode, int kernel, const flo
 // ---------------------------------------------------------------------------------------
 // Tsit5 driver (a7: base_sol, src/base_icnf.jl:137-143)
 // ---------------------------------------------------------------------------------------
-static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, int B,
+static int enqueue_attempt_generic(cnf_handle h, int train, const float* eps, int B,
                                     int nblk, hipStream_t s, bool with_controller = true,
                                     float* dump = nullptr, size_t dump_stride = 0, void* mirror = nullptr,
                                     unsigned seq = 0) {
@@ -546,6 +563,12 @@ static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, i
     a.cond = h->mfma.cond; a.cbs = h->cbs;
     for (int i = 0; i < 2; ++i) { a.U[i] = h->U[i]; a.K1[i] = h->K1[i]; }
     for (int i = 0; i < 5; ++i) a.Ks[i] = h->Ks[i];
+    if (h->trace_on && with_controller && !dump && trace_fused_ok(h, B)) {
+        // TestMode on the 32-128-128-32 shape: the six stage evaluations, the error norm and the controller in ONE launch
+        TraceFuse f; f.norm_kind = 2; f.step = true; f.mirror = mirror; f.seq = seq;
+        (void)launch_trace(h, nullptr, nullptr, true, false, B, s, 0, nullptr, false, &f);
+        return 1;
+    }
     for (int stage = 1; stage <= 6 && h->trace_on; ++stage) {     // the auxiliary kernel forms its stage state itself
         float coef[6];
         tsit5_row(stage, coef);
@@ -570,6 +593,7 @@ static void enqueue_attempt_generic(cnf_handle h, int train, const float* eps, i
         n.mirror = mirror; n.seq = seq;
     }
     launch_norm_partials(n, nblk, s);
+    return 7;                            // six stage evaluations + the error norm (with the controller)
 }
 
 extern "C" cnf_status cnf_set_shard_reduce(cnf_handle h, cnf_shard_reduce_fn fn, void* user) {
@@ -698,6 +722,9 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     int nblk = (int)((n + 255) / 256);
     if (nblk > 256) nblk = 256;
     if (use_mfma) nblk = mfma_grid_for(h->mfma, B, rec != nullptr, train != 0);
+    // TestMode on k_trace3s: the trace launches write the error partials themselves (one pair per workgroup)
+    const bool trace_fused = h->trace_on && !lockstep && !rec && trace_fused_ok(h, B);
+    if (trace_fused) nblk = trace_fused_grid(B);
 
     // initial state
     StepState* init = &h->h_state[2];
@@ -831,6 +858,10 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     } else if (use_mfma) {
         s = mfma_rhs(h->mfma, h->nd, train, h->U[0], eps, h->K1[0], B, st);
         if (s != CNF_OK) return fail(h, s, "MFMA RHS launch failed");
+    } else if (h->trace_on && trace_fused && hairer) {       // k1 = f(u0) with the first norm of the automatic initial dt
+        TraceFuse f; f.norm_kind = 0;
+        if ((s = launch_trace(h, h->U[0], h->K1[0], true, false, B, st, 0, nullptr, false, &f)) != CNF_OK) return s;
+        fused_init = true;
     } else if (h->trace_on) {
         if ((s = launch_trace(h, h->U[0], h->K1[0], false, false, B, st)) != CNF_OK) return s;
     } else {
@@ -848,7 +879,14 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     for (int i = 0; i < 2; ++i) { na.U[i] = h->U[i]; na.K1[i] = h->K1[i]; }
     for (int i = 0; i < 5; ++i) na.Ks[i] = h->Ks[i];
 
-    if (hairer && fused_init) {
+    if (hairer && fused_init && h->trace_on) {
+        // f1 = f(u0 + h*f0) -> Ks[0] with the second norm and the controller phase that sets dt, in the trace launch
+        const float one = 1.f;
+        TraceFuse f; f.norm_kind = 1;
+        if ((s = launch_trace(h, nullptr, h->Ks[0], true, false, B, st, 1, &one, false, &f)) != CNF_OK) return s;
+        launches += 1;
+        nf += 1;
+    } else if (hairer && fused_init) {
         // f1 = f(u0 + h*f0) -> Ks[0], with the second norm and the controller phase that sets dt
         s = mfma_rhs_stage(h->mfma, h->nd, train, h->d_state, h->U, h->K1, h->Ks, eps, 1, B, st, h->d_state,
                            h->partials, ticket);
@@ -928,8 +966,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                 if (s != CNF_OK) return fail(h, s, "MFMA step launch failed");
                 launches += 1;
             } else {
-                enqueue_attempt_generic(h, train, eps, B, nblk, st, false, dump, n);
-                launches += 7;
+                launches += enqueue_attempt_generic(h, train, eps, B, nblk, st, false, dump, n);
             }
             if (lockstep) {
                 if ((s = lockstep_controller(h, h->d_state, h->partials, 2, (float)n, st)) != CNF_OK) return s;
@@ -1011,9 +1048,8 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                     ++launches;
                 } else {
                     // attempt i ends with its own controller and publishes under index i + 1
-                    enqueue_attempt_generic(h, train, eps, B, nblk, st, true, nullptr, 0, h->d_mirror,
-                                            base + (unsigned)sent + 1);
-                    launches += 7;      // 6 stage evaluations + error norm with the controller
+                    launches += enqueue_attempt_generic(h, train, eps, B, nblk, st, true, nullptr, 0, h->d_mirror,
+                                                        base + (unsigned)sent + 1);
                 }
                 ++sent;
             }

@@ -19,6 +19,15 @@ struct TraceArgs {
     int nk;
     float coef[6];
     int also_unew;
+    // k_trace3s only (trace_fused_supported): norms and controller in the same launch, as k_norm_partials does them
+    int norm_kind;          // -1: none; 0 / 1: the two norms of the automatic initial dt over this evaluation; 2: the error norm
+    int fused_step;         // 1: the six stage evaluations of an attempt in this launch (then norm_kind = 2)
+    float* partials;        // 2 floats per workgroup (agent-scope atomics)
+    unsigned* ticket;       // zero between launches; the workgroup that draws the last one runs the controller phase
+    StepState* st_mut;      // the state it acts on (tolerances are read from it)
+    float n_total;          // D * B
+    void* mirror;           // pinned host mirror, written after the controller
+    unsigned seq;
 };
 
 struct TraceLayout {
@@ -34,6 +43,8 @@ bool trace_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
 TraceLayout trace_layout(const NetDesc& nd, const AdjMfmaLayout& m);
 hipError_t launch_trace_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                              const TraceArgs& a, hipStream_t s);
+bool trace_fused_supported(const NetDesc& nd, const AdjMfmaLayout& m, int B);
+int trace_fused_grid(int B);          // workgroups (= error partials) of a fused launch
 bool jvp_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
 hipError_t launch_jvp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                            const TraceArgs& a, const float* eps, hipStream_t s);

@@ -14,6 +14,16 @@
 
 #define TR_NCMAX 8
 
+// Tsit5 rows a_{s+1,1..s} (s = 1..6) for the kernels that run the stages of an attempt themselves
+__device__ static const float kTsit5Row[7][6] = {
+    {0, 0, 0, 0, 0, 0},
+    {TS_A21, 0, 0, 0, 0, 0},
+    {TS_A31, TS_A32, 0, 0, 0, 0},
+    {TS_A41, TS_A42, TS_A43, 0, 0, 0},
+    {TS_A51, TS_A52, TS_A53, TS_A54, 0, 0},
+    {TS_A61, TS_A62, TS_A63, TS_A64, TS_A65, 0},
+    {TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76}};
+
 // entry `idx` of the state the evaluation runs at: given (plain evaluation) or formed from the Runge-Kutta stages.
 // Explicit selects: run-time indexing of kernel-argument arrays would go through memory.
 __device__ __forceinline__ float trace_in(const TraceArgs& a, int cur, float hstep, size_t idx) {
@@ -441,6 +451,396 @@ k_trace3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_trace3s -- the same exact trace with the per-sample product on SIX-TERM bf16 MFMAs (cnf_split.h), re-associated so
+// that the operand a sample rescales is the SMALL one and never leaves the wave that builds it:
+//   tr J = sum_{k,j} d1_k W2[j][k] (d2_j Z[k][j]),      Z = W1 (D3 W3)     per sample   (128 x 128, contraction over n_in),
+// where k_trace3 forms X = (W2 D1) W1 (contraction over 128: a 128 x 128 operand rescaled per sample).  Wave w owns the
+// 16 columns j = 16w .. 16w+15 of Z: its B operand is ITS column tile of D3 W3 D2 -- 8 values per lane, scaled and split in
+// registers (16 products, 4 pair splits per sample) -- against all eight row tiles of W1, resident as split fragments (96
+// VGPRs, split once per launch): 48 v_mfma_f32_16x16x32_bf16 per wave and sample where k_trace3 issues 64
+// v_mfma_f32_16x16x4_f32 at a sixth of the rate, with no LDS traffic for the operands and NO barrier inside the sample loop
+// (the waves drift freely).  The diagonal contraction runs on the accumulators against the wave's forward fragment of W2
+// (the very registers of the forward pass) and d1 (68 VALU operations per sample).  Forward pass, stage-state assembly and
+// outputs are k_trace3's.
+//   STEP: the six stage evaluations of one attempt in this launch -- stage s forms its state from k_1..k_s, the result goes
+//   to Ks[s-1], for s = 6 to K1[1 - cur] with the state stored as the new solution: what six launches did --, then the
+//   error norm of the attempt and, in the workgroup that finishes last, the controller (what k_norm_partials did): one
+//   launch per attempt.  norm_kind 0 / 1 fuse the two norms of the automatic initial dt into the plain launches likewise.
+// ---------------------------------------------------------------------------------------------------
+#include "cnf_split.h"
+template <bool ALL_TANH, bool STEP, int NS, int NIP, int H1, int H2>
+__global__ void __launch_bounds__(AM_THREADS, 2)
+k_trace3s(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const float* __restrict__ img, TraceArgs a) {
+    extern __shared__ float lds[];
+    const StepState* stp = a.st ? a.st : reinterpret_cast<const StepState*>(img);
+    const int st_done = stp->done, st_cur = stp->cur;
+    const float st_h = stp->h;
+    constexpr int TI = NIP / 16, KB = H1 / 16, K0 = NIP / 16;
+    static_assert(NIP == 32 && H1 == 128 && H2 == 128 && AM_WAVES == 8, "one row tile of W1 and of W2 per wave, K = n_in = one k-block");
+    const int PD = tl.PD;
+    const int PSf = pad8m16_dev(m.maxd);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    static_assert(NS == 16 || NS == 32, "samples per workgroup: one or two MFMA column tiles in the forward pass");
+    constexpr int NH = NS / 16;
+    const int b0 = blockIdx.x * NS;
+    const int n_in = nd.n_in, D = n_in + 1, in0 = gl.in0;
+#ifdef TR3S_STAMPS
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+    unsigned long long ts1 = 0, ts2 = 0, ts3 = 0;
+#endif
+    const int es = tid >> 5, er = tid & 31;                            // (sample, input row): NIP == 32 rows
+    if (a.st && st_done) {                           // queued past the end of the solve: keep the host's view current and leave
+        if (a.ticket && blockIdx.x == 0 && tid == 0) mirror_store(a.mirror, a.seq, *a.st);
+        return;
+    }
+    // ---- resident for the whole launch ----
+    // forward fragments (fp32): W1 row tile, W2 row tile (ALSO the weights of the diagonal contraction), the W3 slice of
+    // this wave's k-block of the last layer
+    f32x4 w1a[K0], wa[KB], w3[TI], bias1, bias2;
+    {
+        const float* W1 = img + m.f_off[0] + (size_t)(16 * wave + s) * NIP + 4 * q;       // [j][i]
+        const float* W2 = img + m.f_off[1] + (size_t)(16 * wave + s) * H1 + 4 * q;        // [j][k]
+        const float* WL = img + m.f_off[2] + 16 * wave + 4 * q;                            // W3 [i][j]
+#pragma unroll
+        for (int u = 0; u < K0; ++u) w1a[u] = *reinterpret_cast<const f32x4*>(W1 + 16 * u);
+        bias1 = *reinterpret_cast<const f32x4*>(img + m.b_off[0] + 16 * wave + 4 * q);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) wa[u] = *reinterpret_cast<const f32x4*>(W2 + 16 * u);
+        bias2 = *reinterpret_cast<const f32x4*>(img + m.b_off[1] + 16 * wave + 4 * q);
+#pragma unroll
+        for (int c = 0; c < TI; ++c) w3[c] = *reinterpret_cast<const f32x4*>(WL + (size_t)(16 * c + s) * H2);
+    }
+    const float bias3 = er < nd.dims[3] ? img[m.b_off[2] + er] : 0.f;
+    // trace operands: the eight row tiles of W1 as split fragments (A: row 16 t + s, inputs 8q .. 8q+7; conditioning columns
+    // zero), and W3[8q .. 8q+7][16 wave + s], the column of D3 W3 D2 this lane rescales per sample
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    bf16x8 ah[8], am_[8], al[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const float* W1r = img + m.f_off[0] + (size_t)(16 * t + s) * NIP + 8 * q;
+        f32x4 lo = *reinterpret_cast<const f32x4*>(W1r), hi = *reinterpret_cast<const f32x4*>(W1r + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { if (8 * q + j >= n_in) lo[j] = 0.f; if (8 * q + 4 + j >= n_in) hi[j] = 0.f; }
+        u32x4_ h, mm, l;
+        { unsigned x, y, z; s3b_split2(lo[0], lo[1], x, y, z); h.x = x; mm.x = y; l.x = z; }
+        { unsigned x, y, z; s3b_split2(lo[2], lo[3], x, y, z); h.y = x; mm.y = y; l.y = z; }
+        { unsigned x, y, z; s3b_split2(hi[0], hi[1], x, y, z); h.z = x; mm.z = y; l.z = z; }
+        { unsigned x, y, z; s3b_split2(hi[2], hi[3], x, y, z); h.w = x; mm.w = y; l.w = z; }
+        ah[t] = __builtin_bit_cast(bf16x8, h); am_[t] = __builtin_bit_cast(bf16x8, mm); al[t] = __builtin_bit_cast(bf16x8, l);
+    }
+    f32x4 w3lo, w3hi;
+    {
+        const float* R3 = img + m.r_off[2] + (size_t)(16 * wave + s) * NIP + 8 * q;       // reverse image [j][i] = W3[i][j]
+        w3lo = *reinterpret_cast<const f32x4*>(R3); w3hi = *reinterpret_cast<const f32x4*>(R3 + 4);
+    }
+    float* S0 = lds + NS * PD;                      // (sigma' rows first: [sample][PD]) [sample][feature], stride PSf: state, then h2
+    float* S1 = S0 + NS * PSf;                      // h1
+    float* Z = S1 + NS * PSf;                       // per-wave partial sums of the last layer [wave][sample][ZS]
+    constexpr int ZS = NIP + 4;
+    float* red = Z + AM_WAVES * NS * ZS;            // trace partials [sample][wave]; then scratch of the norms
+
+#ifdef TR3S_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts1 = __builtin_amdgcn_s_memtime();
+#endif
+  for (int stage = 1; stage <= (STEP ? 6 : 1); ++stage) {
+    // this evaluation's stage state and destination (STEP: of stage `stage`; else as the arguments say)
+    const int nk = STEP ? stage : a.nk;
+    float cf[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) cf[j] = STEP ? kTsit5Row[stage][j] : a.coef[j];
+    const bool is_k7 = STEP ? stage == 6 : (a.st && a.du_is_k7), also_unew = STEP ? stage == 6 : a.also_unew != 0;
+    float* du = is_k7 ? (st_cur ? a.K1[0] : a.K1[1])
+                      : (STEP ? const_cast<float*>(stage == 1 ? a.Ks[0] : stage == 2 ? a.Ks[1] : stage == 3 ? a.Ks[2] : stage == 4 ? a.Ks[3] : a.Ks[4])
+                              : a.du);
+    // entry `idx` of the state the evaluation runs at (trace_in with this stage's coefficients).  An opaque zero in the
+    // index, new in every stage, keeps the compiler from hoisting the 64-bit addresses of the seven arrays (two sample halves,
+    // two rows each) out of the stage loop -- 56 registers it then has to spill around the trace loop.
+    int oz = 0;
+    if (STEP) asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+    auto state_in = [&](size_t idx) {
+        idx += (size_t)oz;
+        if (nk == 0) return a.u[idx];
+        float acc = cf[0] * (st_cur ? a.K1[1] : a.K1[0])[idx];
+        if (nk > 1) acc = fmaf(cf[1], a.Ks[0][idx], acc);
+        if (nk > 2) acc = fmaf(cf[2], a.Ks[1][idx], acc);
+        if (nk > 3) acc = fmaf(cf[3], a.Ks[2][idx], acc);
+        if (nk > 4) acc = fmaf(cf[4], a.Ks[3][idx], acc);
+        if (nk > 5) acc = fmaf(cf[5], a.Ks[4][idx], acc);
+        return fmaf(st_h, acc, (st_cur ? a.U[1] : a.U[0])[idx]);
+    };
+
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {                 // thread (es, er): row er of samples es and es + 16
+        const int sm = es + 16 * hh;
+        float xin = 0.f;
+        if (b0 + sm < a.B && er < in0)
+            xin = er < n_in ? state_in((size_t)(b0 + sm) * D + er)
+                            : a.ys[(size_t)(b0 + sm) * nd.n_cond + (er - n_in)];
+        if (also_unew && b0 + sm < a.B) {            // stage 6: the state this evaluation runs at is the new solution
+            float* un = st_cur ? a.U[0] : a.U[1];
+            if (er < n_in) un[(size_t)(b0 + sm) * D + er] = xin;
+            if (er == 0) un[(size_t)(b0 + sm) * D + n_in] = state_in((size_t)(b0 + sm) * D + n_in);     // the dlogp row
+        }
+        S0[sm * PSf + er] = xin;
+    }
+    am_barrier();
+    // ---- forward (k_trace3's): sigma' of every layer to LDS, zdot out ----
+    auto act4v = [&](int l, const f32x4& x, f32x4& h, f32x4& d) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float hh, dd1, dd2;
+            if (ALL_TANH) { hh = cnf_tanh(x[j]); dd1 = fmaf(-hh, hh, 1.0f); }
+            else cnf_act2(nd.acts[l], x[j], hh, dd1, dd2);
+            h[j] = hh; d[j] = dd1;
+        }
+    };
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {   // layer 1: rows 16 wave .. +15 of H1, samples 16 hh + s
+        const int sm = s + 16 * hh;
+        f32x4 acc = bias1;
+#pragma unroll
+        for (int u = 0; u < K0; ++u) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(S0 + sm * PSf + 16 * u + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a[u][k], b[k], acc, 0, 0, 0);
+        }
+        f32x4 h, d;
+        act4v(0, acc, h, d);
+        const int r0 = 16 * wave + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (r0 + j >= nd.dims[1]) { h[j] = 0.f; d[j] = 0.f; }
+        *reinterpret_cast<f32x4*>(S1 + sm * PSf + r0) = h;
+        *reinterpret_cast<f32x4*>(lds + sm * PD + m.o_off[0] + r0) = d;
+    }
+    am_barrier();
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {   // layer 2: rows 16 wave .. +15 of H2
+        const int sm = s + 16 * hh;
+        f32x4 acc0 = bias2, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < KB; u += 2) {
+            const f32x4 b0v = *reinterpret_cast<const f32x4*>(S1 + sm * PSf + 16 * u + 4 * q);
+            const f32x4 b1v = *reinterpret_cast<const f32x4*>(S1 + sm * PSf + 16 * (u + 1) + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u][k], b0v[k], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u + 1][k], b1v[k], acc1, 0, 0, 0);
+            }
+        }
+        f32x4 h, d;
+        act4v(1, acc0 + acc1, h, d);
+        const int r0 = 16 * wave + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (r0 + j >= nd.dims[2]) { h[j] = 0.f; d[j] = 0.f; }
+        *reinterpret_cast<f32x4*>(S0 + sm * PSf + r0) = h;            // the state image was last read before the barrier
+        *reinterpret_cast<f32x4*>(lds + sm * PD + m.o_off[1] + r0) = d;
+    }
+    am_barrier();
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {   // layer 3: this wave's k-block (16 wave .. +15) of both output tiles
+        const int sm = s + 16 * hh;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(S0 + sm * PSf + 16 * wave + 4 * q);
+#pragma unroll
+        for (int c = 0; c < TI; ++c) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[c][k], b[k], acc, 0, 0, 0);
+            *reinterpret_cast<f32x4*>(Z + (wave * NS + sm) * ZS + 16 * c + 4 * q) = acc;
+        }
+    }
+    am_barrier();
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {   // sum over the k-blocks, bias, activation: zdot out, sigma'_3 kept
+        const int sm = es + 16 * hf;
+        float z = bias3;
+#pragma unroll
+        for (int w = 0; w < AM_WAVES; ++w) z += Z[(w * NS + sm) * ZS + er];
+        float hh, dd1, dd2;
+        if (ALL_TANH) { hh = cnf_tanh(z); dd1 = fmaf(-hh, hh, 1.0f); }
+        else cnf_act2(nd.acts[2], z, hh, dd1, dd2);
+        const bool live = er < nd.dims[3];
+        lds[sm * PD + m.o_off[2] + er] = live ? dd1 : 0.f;
+        if (live && b0 + sm < a.B) du[(size_t)(b0 + sm) * D + er] = hh;                    // zdot rows
+    }
+    am_barrier();                                   // sigma' rows complete
+#ifdef TR3S_STAMPS
+    ts2 = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- trace: every wave on its own columns of Z, sample after sample, no barrier ----
+    // Software pipeline inside the wave (its instruction stream is in-order; the matrix pipe runs beside it): behind the six
+    // products of tile t come one quarter of the NEXT sample's operand split and the diagonal contraction of tile t - 1,
+    // whose accumulator has had a tile's time to arrive.
+    struct Bop { bf16x8 h, m, l; };
+    auto scaled = [&](int b, f32x4& vlo, f32x4& vhi) {          // this lane's column of D3 W3 D2: inputs 8q .. 8q+7 of column 16 wave + s
+        const float* db = lds + b * PD;
+        const f32x4 dlo = *reinterpret_cast<const f32x4*>(db + m.o_off[2] + 8 * q), dhi = *reinterpret_cast<const f32x4*>(db + m.o_off[2] + 8 * q + 4);
+        const float d2 = db[m.o_off[1] + 16 * wave + s];
+        vlo = (w3lo * dlo) * d2; vhi = (w3hi * dhi) * d2;
+    };
+    u32x4_ nh, nm, nl;                               // the next sample's operand, filled a quarter at a time
+    auto split_q = [&](int qq, const f32x4& vlo, const f32x4& vhi) {
+        unsigned x, y, z;
+        if (qq == 0) { s3b_split2(vlo[0], vlo[1], x, y, z); nh.x = x; nm.x = y; nl.x = z; }
+        else if (qq == 1) { s3b_split2(vlo[2], vlo[3], x, y, z); nh.y = x; nm.y = y; nl.y = z; }
+        else if (qq == 2) { s3b_split2(vhi[0], vhi[1], x, y, z); nh.z = x; nm.z = y; nl.z = z; }
+        else { s3b_split2(vhi[2], vhi[3], x, y, z); nh.w = x; nm.w = y; nl.w = z; }
+    };
+    Bop bc;
+    {
+        f32x4 vlo, vhi;
+        scaled(0, vlo, vhi);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) split_q(qq, vlo, vhi);
+        bc.h = __builtin_bit_cast(bf16x8, nh); bc.m = __builtin_bit_cast(bf16x8, nm); bc.l = __builtin_bit_cast(bf16x8, nl);
+    }
+    for (int b = 0; b < NS; ++b) {
+        const float* db = lds + b * PD;
+        f32x4 vlo, vhi;
+        scaled(b + 1 < NS ? b + 1 : b, vlo, vhi);          // (the last iteration prepares a copy that nobody uses)
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f}, cprev = sum;
+        f32x4 d1n = *reinterpret_cast<const f32x4*>(db + m.o_off[0] + 4 * q);          // d1 of tile 0
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], bc.h, c, 0, 0, 0);       // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bc.l, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am_[t], bc.m, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am_[t], bc.h, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bc.m, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bc.h, c, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t < 4) split_q(t, vlo, vhi);
+            if (t > 0) {
+                // cprev[r] = d2[j] Z[k = 16 (t-1) + 4q + r][j = 16 wave + s]; W2[j][k] = wa[t-1][r], d1[k] = d1n[r]
+                const f32x4 wd = wa[t - 1] * d1n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] = fmaf(cprev[r], wd[r], sum[r]);
+            }
+            d1n = *reinterpret_cast<const f32x4*>(db + m.o_off[0] + 16 * t + 4 * q);
+            __builtin_amdgcn_sched_barrier(0);
+            cprev = c;
+        }
+        {
+            const f32x4 wd = wa[7] * d1n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[r] = fmaf(cprev[r], wd[r], sum[r]);
+        }
+        bc.h = __builtin_bit_cast(bf16x8, nh); bc.m = __builtin_bit_cast(bf16x8, nm); bc.l = __builtin_bit_cast(bf16x8, nl);
+        float p = (sum[0] + sum[1]) + (sum[2] + sum[3]);
+        // fixed tree over the 64 lanes (quad swaps, half-row, row mirrors, then the four row totals)
+        p += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(p), 0xB1, 0xF, 0xF, true));
+        p += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(p), 0x4E, 0xF, 0xF, true));
+        p += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(p), 0x141, 0xF, 0xF, true));
+        p += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(p), 0x140, 0xF, 0xF, true));
+        const int pi = __float_as_int(p);
+        const float tot = (__int_as_float(__builtin_amdgcn_readlane(pi, 0)) + __int_as_float(__builtin_amdgcn_readlane(pi, 16))) +
+                          (__int_as_float(__builtin_amdgcn_readlane(pi, 32)) + __int_as_float(__builtin_amdgcn_readlane(pi, 48)));
+        if (lane == 0) red[b * AM_WAVES + wave] = tot;
+    }
+#ifdef TR3S_STAMPS
+    ts3 = __builtin_amdgcn_s_memtime();
+    if ((blockIdx.x == 3 || blockIdx.x == 200) && lane == 0 && (wave == 0 || wave == 5))
+        printf("k_trace3s blk %d wave %d: resident operands %llu, state + forward %llu, trace loop %llu cycles\n", blockIdx.x, wave,
+               ts1 - ts0, ts2 - ts1, ts3 - ts2);
+#endif
+    am_barrier();
+    if (tid < NS && b0 + tid < a.B) {
+        float tr = 0.f;
+        for (int w = 0; w < AM_WAVES; ++w) tr += red[tid * AM_WAVES + w];
+        du[(size_t)(b0 + tid) * D + n_in] = -tr;                       // src/icnf.jl:162
+    }
+    // The stage derivative just written is read back by OTHER threads of this workgroup (the next stage state, the norms):
+    // the stores have to be complete before anybody loads those lines (nothing of them is in this CU's L1 yet).
+    if (STEP || a.norm_kind >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); am_barrier(); }
+  }
+    if (a.norm_kind < 0) return;
+    // ---- fused norm (k_norm_partials: kind 0 / 1 = the two norms of the automatic initial dt, 2 = the error estimate of
+    // the attempt) over this workgroup's 32 x D entries, then -- in the workgroup that draws the last ticket -- the controller
+    {
+        const StepState* sp = a.st_mut;
+        const float abstol = sp->abstol, reltol = sp->reltol;
+        const float* U = a.nk == 0 && !STEP && a.u ? a.u : (st_cur ? a.U[1] : a.U[0]);
+        const float* K1c = st_cur ? a.K1[1] : a.K1[0];
+        float p0 = 0.f, p1 = 0.f;
+        auto entry = [&](size_t i) {
+            if (a.norm_kind == 0) {                  // f0 = the evaluation just written (a.du)
+                const float uv = U[i], sk = fmaf(fabsf(uv), reltol, abstol);
+                const float x = uv / sk, y = a.du[i] / sk;
+                p0 = fmaf(x, x, p0); p1 = fmaf(y, y, p1);
+            } else if (a.norm_kind == 1) {           // f1 = the evaluation just written (Ks[0]), f0 = k1
+                const float uv = U[i], sk = fmaf(fabsf(uv), reltol, abstol);
+                const float x = (a.du[i] - K1c[i]) / sk;
+                p0 = fmaf(x, x, p0);
+            } else {
+                const float* un = st_cur ? a.U[0] : a.U[1];
+                const float* k7 = st_cur ? a.K1[0] : a.K1[1];
+                float e = TS_BT1 * K1c[i];
+                e = fmaf(TS_BT2, a.Ks[0][i], e); e = fmaf(TS_BT3, a.Ks[1][i], e); e = fmaf(TS_BT4, a.Ks[2][i], e);
+                e = fmaf(TS_BT5, a.Ks[3][i], e); e = fmaf(TS_BT6, a.Ks[4][i], e); e = fmaf(TS_BT7, k7[i], e);
+                e *= st_h;
+                const float uv = U[i], nv = un[i];
+                const float sc = fmaf(fmaxf(fabsf(uv), fabsf(nv)), reltol, abstol);
+                const float x = e / sc;
+                p0 = fmaf(x, x, p0);
+                if (!(fabsf(nv) <= 3.0e38f)) p1 += 1.f;
+            }
+        };
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+            const int sm = es + 16 * hf;
+            if (b0 + sm < a.B) {
+                if (er < n_in) entry((size_t)(b0 + sm) * D + er);
+                if (er == 0) entry((size_t)(b0 + sm) * D + n_in);
+            }
+        }
+        // fixed trees: the 64 lanes of a wave, then the eight waves
+        auto wsum = [&](float v) {
+            v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+            v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+            v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
+            v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));
+            const int i = __float_as_int(v);
+            return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
+                   (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
+        };
+        float* nr = red;
+        p0 = wsum(p0); p1 = wsum(p1);
+        if (lane == 0) { nr[wave] = p0; nr[8 + wave] = p1; }
+        am_barrier();
+        if (tid == 0) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int w = 0; w < AM_WAVES; ++w) { s0 += nr[w]; s1 += nr[8 + w]; }
+            __hip_atomic_store(a.partials + 2 * blockIdx.x, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.partials + 2 * blockIdx.x + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = tk == gridDim.x - 1;
+            if (last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nr[16] = last ? 1.f : 0.f;
+        }
+        am_barrier();
+        if (nr[16] == 0.f) return;
+        float q0 = 0.f, q1 = 0.f;                    // the last workgroup: all partials in the fixed order of k_controller
+        for (int i = tid; i < (int)gridDim.x; i += AM_THREADS) {
+            q0 += __hip_atomic_load(a.partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q1 += __hip_atomic_load(a.partials + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        q0 = wsum(q0); q1 = wsum(q1);
+        am_barrier();
+        if (lane == 0) { nr[wave] = q0; nr[8 + wave] = q1; }
+        am_barrier();
+        if (tid == 0) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int w = 0; w < AM_WAVES; ++w) { s0 += nr[w]; s1 += nr[8 + w]; }
+            ctrl_phase(a.st_mut, a.norm_kind, s0, s1, a.n_total);
+            mirror_store(a.mirror, a.seq, *a.st_mut);
+        }
+    }
+}
+
 static bool trace3_shape(const NetDesc& nd, const AdjMfmaLayout& m) {
     return nd.n_layers == 3 && m.nin_p == 32 && m.dp[0] == 32 && m.dp[1] == 128 && m.dp[2] == 128 && m.dp[3] == 32 &&
            AM_WAVES == 8;
@@ -569,14 +969,45 @@ hipError_t launch_jvp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfma
     return hipGetLastError();
 }
 
+// fused norms / the fused six-stage step exist in the split kernel of the 32-128-128-32 shape only
+bool trace_fused_supported(const NetDesc& nd, const AdjMfmaLayout& m, int B) {
+    static const bool generic_only = [] { const char* e = getenv("CNF_TRACE_GENERIC"); return e && e[0] == '1'; }();
+    static const bool trace_fp32 = [] { const char* e = getenv("CNF_TRACE_FP32"); return e && e[0] == '1'; }();
+    static const bool unfused = [] { const char* e = getenv("CNF_TRACE_UNFUSED"); return e && e[0] == '1'; }();
+    return trace3_shape(nd, m) && !generic_only && !trace_fp32 && !unfused && trace_fused_grid(B) <= 1024;
+}
+// k_trace3s: 32 samples per workgroup once that still gives every CU of an MI355X a workgroup, 16 below (measured, config 3:
+// B = 8192: 59 against 67 us per evaluation; B = 4096: 52 against 35)
+static int trace3s_ns(int B) { return B >= 32 * 256 ? 32 : 16; }
+int trace_fused_grid(int B) { const int ns = trace3s_ns(B); return (B + ns - 1) / ns; }
+
 hipError_t launch_trace_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                              const TraceArgs& a, hipStream_t s) {
     const TraceLayout tl = trace_layout(nd, m);
+    if ((a.norm_kind >= 0 || a.fused_step) && !trace_fused_supported(nd, m, a.B)) return hipErrorInvalidValue;
     const size_t lds_generic = (size_t)tl.total_floats * sizeof(float), lds = lds_generic;
     bool all_tanh = true;
     for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
     const dim3 grid((a.B + AM_NS - 1) / AM_NS), block(AM_THREADS);
     static const bool generic_only = [] { const char* e = getenv("CNF_TRACE_GENERIC"); return e && e[0] == '1'; }();
+    static const bool trace_fp32 = [] { const char* e = getenv("CNF_TRACE_FP32"); return e && e[0] == '1'; }();
+    if (trace3_shape(nd, m) && !generic_only && !trace_fp32) {      // split-bf16 products (A/B switch: CNF_TRACE_FP32=1 -> k_trace3)
+        const int PSf = pad8m16(m.maxd);
+        const int ns = trace3s_ns(a.B);                  // samples per workgroup
+        const size_t lds = (size_t)(ns * tl.PD + 2 * ns * PSf + AM_WAVES * ns * (32 + 4) + ns * AM_WAVES + 32) * sizeof(float);
+        const dim3 grid((a.B + ns - 1) / ns);
+        const bool step = a.fused_step != 0;
+        const void* fn;
+        if (ns == 32) fn = all_tanh ? (step ? (const void*)k_trace3s<true, true, 32, 32, 128, 128> : (const void*)k_trace3s<true, false, 32, 32, 128, 128>)
+                                    : (step ? (const void*)k_trace3s<false, true, 32, 32, 128, 128> : (const void*)k_trace3s<false, false, 32, 32, 128, 128>);
+        else fn = all_tanh ? (step ? (const void*)k_trace3s<true, true, 16, 32, 128, 128> : (const void*)k_trace3s<true, false, 16, 32, 128, 128>)
+                           : (step ? (const void*)k_trace3s<false, true, 16, 32, 128, 128> : (const void*)k_trace3s<false, false, 16, 32, 128, 128>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        NetDesc nd_ = nd; GradLayout g_ = g; AdjMfmaLayout m_ = m; TraceLayout tl_ = tl; TraceArgs a_ = a;
+        void* args[] = {&nd_, &g_, &m_, &tl_, &img, &a_};
+        return hipLaunchKernel(fn, grid, block, args, lds, s);
+    }
     if (trace3_shape(nd, m) && !generic_only) {          // resident-fragment kernel (A/B switch: CNF_TRACE_GENERIC=1)
         // forward images + per-wave partials of the last layer; later the per-lane trace partials (same area)
         const int PSf = pad8m16(m.maxd), fwd = 2 * AM_NS * PSf + AM_WAVES * AM_NS * (32 + 4) + 32 * (128 + 8),

@@ -689,6 +689,7 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
                                        "test_jvp_mode_headline_shape_step_kernel or ragged or test_headline_kernels_strict"),
                      ("CNF_STEP_V1", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve"),
                      ("CNF_TRACE_GENERIC", "test_exact_trace_mfma_deep_networks"),
+                     ("CNF_TRACE_FP32", "test_exact_trace_mfma_deep_networks"),
                      ("CNF_ADJ_GENERIC", "test_loss_grad_fixed_dt_matches_oracle and 3-mfma or test_loss_grad_headline")):
         name, _, val = var.partition("=")
         env = dict(os.environ, **{name: val or "1", "CNF_NO_PARITY_REPORT": "1"})
