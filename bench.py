@@ -36,7 +36,7 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # kernel arguments in de
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0       # spec
-PMC_FILE = os.path.join("profiles", "round2_step_kernel_pmc.json")   # tools/collect_profiles.sh + summarize_profiles.py
+PMC_FILE = os.path.join("profiles", "round3_step_kernel_pmc.json")   # tools/collect_profiles.sh + summarize_profiles.py
 
 
 def parse_args():

@@ -20,17 +20,24 @@ from oracle import c_oracle as CO
 from oracle import cnf_oracle as O
 from tests.helpers import make_icnf, parity_err
 
-which = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 5]
+which = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 5, 13, 14, 23]
 dev = torch.device("cuda", 0)
-for i in which:
+for case in which:
+    # 13 / 14: configs 3 / 4 at 65536 columns on ONE GPU (several tiles per workgroup of the one-launch solve);
+    # 23: config 3's network in TestMode (exact trace of a three-layer net: k_trace3s, fused attempts)
+    i = case % 10
     cfg, B, train = O.baseline_cfg(i)
-    if i == 4:
+    if case == 4:
         B = 8192                      # per-GPU shard of the 65536-column batch
+    if case in (13, 14):
+        B = 65536
     rng = np.random.default_rng(i)
     flat = O.glorot_params(cfg.net, rng, np.float32)
     modes = [("train", True)] if train else [("test", False), ("train", True)]
-    if i in (3, 5):
+    if case in (3, 5):
         modes.append(("train-jvp", True))
+    if case == 23:
+        modes = [("test", False)]
     for mname, tr in modes:
         cfg.use_jvp = mname == "train-jvp"
         icnf = make_icnf(cnf, cfg, jvp=cfg.use_jvp, kernel="auto")
@@ -61,7 +68,7 @@ for i in which:
         perr = parity_err(got, ref, trace_row=cfg.n_in)
         fl, by = C.c_double(), C.c_double()
         l.cnf_rhs_work(h, m, B, C.byref(fl), C.byref(by))
-        out = {"cfg": i, "mode": mname, "B": B, "kernel": {1: "generic", 2: "mfma"}[kern], "rhs_us": round(rhs_us, 1),
+        out = {"cfg": i, "case": case, "mode": mname, "B": B, "kernel": {1: "generic", 2: "mfma"}[kern], "rhs_us": round(rhs_us, 1),
                "rhs_TFLOPs": round(fl.value / rhs_us / 1e6, 2), "parity_err_vs_c_oracle": float(f"{perr:.2e}")}
         # solves
         u0 = u.clone()
@@ -69,6 +76,8 @@ for i in which:
         for tag, opts in (("adaptive", _lib.cnf_solve_opts(cfg.tspan[0], cfg.tspan[1], 1.1920929e-7, 3.4526698e-4, 0.0, 1, 1 << 20, 0)),
                           ("fixed", _lib.cnf_solve_opts(cfg.tspan[0], cfg.tspan[1], 0.0, 0.0, (cfg.tspan[1] - cfg.tspan[0]) / 32, 0, 1 << 20, 0))):
             if kern == 1 and i == 5 and not tr and tag == "fixed":
+                continue
+            if B > 8192 and tag == "fixed":
                 continue
             stats = _lib.cnf_solve_stats()
             run = lambda: _lib.check(l.cnf_solve_tsit5(h, m, u0.data_ptr(), eps.data_ptr(), du.data_ptr(), B,
@@ -85,5 +94,6 @@ for i in which:
             out[f"{tag}_ms"] = round(el * 1e3, 3)
             out[f"{tag}_nf"] = stats.nf
             out[f"{tag}_rhs_evals_per_s"] = round(stats.nf / el, 1)
+            out[f"{tag}_launches"] = stats.launches
         print(json.dumps(out), flush=True)
         icnf.close()

@@ -8,7 +8,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export HIP_FORCE_DEV_KERNARG=1
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1

@@ -13,8 +13,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
-name = sys.argv[2] if len(sys.argv) > 2 else "round2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+name = sys.argv[2] if len(sys.argv) > 2 else "round3"
 SRC = os.path.join(ROOT, "gpurun_out", f"profiles_{tag}")
 DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
@@ -26,7 +26,7 @@ FULL_US = 30.0                        # anything shorter did not do a full step:
 def is_solve(kname):
     # the one-launch solve (the plain instantiation, not the recording one of the gradient path): when it ran, IT is the
     # headline kernel (a launch = a whole solve)
-    return "k_solve3b<false>(" in kname or kname.startswith("k_solve3b(")
+    return "k_solve3b<false" in kname or kname.startswith("k_solve3b(")      # (<false>: round 2; <false, false>: RECORD, MULTI)
 
 
 def is_step(kname):
