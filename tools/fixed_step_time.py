@@ -5,7 +5,7 @@ import torch
 import continuousnf.jl_amd as cnf
 from continuousnf.jl_amd import _lib, configs
 cfg = configs.BASELINE[3]; B = cfg.batch
-icnf = configs.build(cfg, kernel="mfma"); icnf.set_params(configs.glorot_params(cfg.dims, 0))
+icnf = configs.build(cfg, kernel="mfma", jvp=os.environ.get("FST_JVP") == "1"); icnf.set_params(configs.glorot_params(cfg.dims, 0))
 l, h = _lib.lib(), icnf.handle()
 D = cfg.n_in + 3; dev = torch.device("cuda", 0)
 u = torch.randn(B * D, device=dev) * 0.5; u.view(B, D)[:, cfg.n_in:] = 0
