@@ -760,7 +760,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         sv.trace = h->step_trace; sv.trace_cap = h->step_trace_cap;
         const bool fused_io = post && post->xs;            // inference: u0 from the data columns and the post-processing in the launch
         if (fused_io) { sv.xs = post->xs; sv.logpx = post->logpx; sv.regs = post->regs; sv.sums5 = post->sums5; }
-        else if (u0 != h->U[0]) HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        else { sv.u0 = u0; sv.u_out = rec ? nullptr : u_out; }   // (the launcher reads u0 in place or copies it into U[0])
         // gradient path: every attempt files u_n and its stage states in the slot of step `naccept` (as the streamed
         // recording does); the store is sized beforehand and the solve repeated if it took more steps than fit
         float* dump = nullptr; size_t slot = 0; int dcap = 0;
@@ -808,7 +808,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             if (!aborted) {
                 if (fused_io) post->launched = true;
                 else if (post) { enqueue_post(h, train, h->d_state, *post, B, false, st); ++launches; post->launched = true; }
-                if (u_out) { launch_copy_final(h->d_state, h->U[0], h->U[1], u_out, n, st); ++launches; }
+                if (u_out && !sv.u_out) { launch_copy_final(h->d_state, h->U[0], h->U[1], u_out, n, st); ++launches; }
                 HIPCHK(h, hipGetLastError());
                 if (rec) {                               // step sizes back from the device
                     rec->n = fin.naccept;

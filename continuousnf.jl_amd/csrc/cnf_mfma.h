@@ -89,13 +89,18 @@ struct Solve3Args {
     float* regs;
     float* sums5;         // and the five loss sums                                           (src/icnf.jl:489)
     int nvars, naugs, norm_z_aug;
+    // a bare solve called with caller-owned columns: u0 (read where it is when every workgroup owns ONE tile, copied into
+    // U[0] by the launcher otherwise) and where the final columns go (null on return from the launcher = not written by
+    // the kernel: they are in the integrator's buffers, as st_out says)
+    const float* u0;
+    float* u_out;
 };
 // the whole solve in one launch (headline shape, B <= 32 x the workgroups the device can hold at once); CNF_ERR_UNSUPPORTED
 // otherwise.  `device`: the handle's device (CU count, occupancy and function attributes are kept per device).  sv (cnf_step3.h): the initial state by value, the meeting buffer and its index base, optionally the data
 // columns to assemble u0 from and the outputs of the post-processing; st_out: the final state (cur = 0: the final columns
 // are in U[0])
 cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st_out, float* const U[2],
-                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv, int device,
+                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args& sv, int device,
                                  float* dump = nullptr, size_t dump_stride = 0, size_t dump_step_stride = 0, int dump_cap = 0,
                                  float* hs_out = nullptr,      // dump ...: the trajectory store of the gradient path (as mfma_step)
                                  float* const* K1 = nullptr);  // the k1 / k7 buffer sets: batches of several tiles per workgroup

@@ -1558,7 +1558,7 @@ cnf_status mfma_rhs_stage(const MfmaPlan& p, const NetDesc& nd_, bool train, con
 // per workgroup the device holds at once.  CNF_ERR_UNSUPPORTED: not this handle / batch -- the caller streams step
 // launches instead.  CNF_PERSISTENT=0 switches it off.
 cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool train, StepState* st_out, float* const U[2],
-                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args sv, int device,
+                                 const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, Solve3Args& sv, int device,
                                  float* dump, size_t dump_stride, size_t dump_step_stride, int dump_cap, float* hs_out,
                                  float* const* K1) {
     static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); return e && e[0] == '0'; }();
@@ -1591,6 +1591,16 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     a.mode = 2; a.B = B; a.eps = eps; a.st = st_out; a.st_out = st_out;
     a.n_total = (float)((size_t)(nd.n_in + 3) * B);
     a.U[0] = U[0]; a.U[1] = U[1];
+    // Caller-owned columns.  One tile per workgroup: the launch reads u0 where the caller keeps it and writes the final
+    // columns where the caller wants them -- no copy launches around the solve.  Otherwise the state lives in the
+    // integrator's buffers between attempts: u0 is copied in, the caller copies the result out (sv.u_out = null says so).
+    const bool direct = grid == ntile && !use_p && !dump && sv.u_out != nullptr && !sv.xs;
+    if (!direct) sv.u_out = nullptr;
+    if (sv.u0 && sv.u0 != U[0]) {
+        if (direct) a.U[0] = const_cast<float*>(sv.u0);        // (read in the prologue only: the final store goes to sv.u_out)
+        else if (hipMemcpyAsync(U[0], sv.u0, (size_t)B * (nd.n_in + 3) * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return CNF_ERR_HIP;
+    }
     if (K1) { a.K1[0] = K1[0]; a.K1[1] = K1[1]; }
     a.mirror = mirror; a.seq = seq;
     a.dump = dump; a.dump_stride = dump_stride; a.dump_step_stride = dump_step_stride; a.dump_cap = dump_cap; a.hs_out = hs_out;

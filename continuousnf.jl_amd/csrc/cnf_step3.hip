@@ -2113,7 +2113,9 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
         }
     }
     // ---- the final state to the integrator's buffer set 0 ----
-    if (!multi) store_rows(a.U[0], zown ? *(const f32x4*)rkw : zero4, sown ? sc_get(0) : zero4);
+    // (to the caller's columns when the launcher passed them: sv.u_out; never after an abort -- the caller may be solving
+    // in place, and the streamed driver starts again from u0)
+    if (!multi && (alive || !sv.u_out)) store_rows(sv.u_out ? sv.u_out : a.U[0], zown ? *(const f32x4*)rkw : zero4, sown ? sc_get(0) : zero4);
     float v4[4] = {0.f, 0.f, 0.f, 0.f};                   // this lane's share of the loss sums (waves 4 and 6)
     if (sv.logpx && alive) {
         // ---- post-processing of every tile: logp(z) - dlogp, the regulariser rows; then the loss sums of the batch ----
@@ -2560,7 +2562,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         }
     }
     // ---- the final state: one tile per workgroup -> the integrator's buffer set 0; several: it is in set `cur` ----
-    if (!multi) store_rows(a.U[0], uz, sc_get(0));
+    if (!multi && (alive || !sv.u_out)) store_rows(sv.u_out ? sv.u_out : a.U[0], uz, sc_get(0));
     float v4[4] = {0.f, 0.f, 0.f, 0.f};                   // this lane's share of the loss sums (waves 4 and 6)
     if (sv.logpx && alive) {
         // ---- post-processing of every tile: logp(z) - dlogp, the regulariser rows; then the loss sums of the batch ----

@@ -700,6 +700,53 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
         assert " passed" in r.stdout and "failed" not in r.stdout, (var, r.stdout[-500:])
 
 
+def test_bare_solve_reads_and_writes_the_callers_columns():
+    """cnf_solve_tsit5 on caller-owned columns (src/base_icnf.jl:137-143: `base_sol` hands over `prob.u0` and takes the last
+    state): the one-launch solve reads u0 where it is and writes the final columns where they are wanted -- ONE launch,
+    no copies around it -- out of place, in place (u_out = u0), and beyond one tile per workgroup (state in the
+    integrator's buffers: a copy out); all equal to the solve through the handle's own buffers (inference on the same
+    columns is the reference)."""
+    import ctypes as C
+    cfg, _, _ = O.baseline_cfg(3)
+    rng = np.random.default_rng(5)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    persistent = os.environ.get("CNF_PERSISTENT") != "0" and os.environ.get("CNF_STEP_FP32") != "1" \
+        and os.environ.get("CNF_STEP_V1") != "1"
+    for jvp in (False, True):
+        for B in (1000, 8224):
+            D = cfg.n_in + 3
+            ic = make_icnf(cnf, cfg, jvp=jvp, sol_kwargs=dict(adaptive=False, dt=1 / 8))
+            ic.set_params(flat)
+            l, h = _lib.lib(), ic.handle()
+            u0 = _dev(rng.standard_normal((B, D))).contiguous()
+            u0[:, cfg.n_in:] = 0
+            eps = _dev(rng.standard_normal((B, cfg.n_in))).contiguous()
+            sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            opts = _lib.cnf_solve_opts(0.0, 1.0, 0.0, 0.0, 1 / 8, 0, 1 << 20, 0)
+            stats = _lib.cnf_solve_stats()
+            keep = u0.clone()
+            out = torch.full_like(u0, float("nan"))
+            _lib.check(l.cnf_solve_tsit5(h, 1, u0.data_ptr(), eps.data_ptr(), out.data_ptr(), B, C.byref(opts), C.byref(stats), sp), h)
+            torch.cuda.synchronize()
+            one = persistent and (B <= 8192 or os.environ.get("CNF_PIPE") != "1")
+            if one and os.environ.get("CNF_PIPE") != "1":
+                assert stats.launches == (1 if B <= 8192 else 2), (jvp, B, stats.launches)
+            assert torch.equal(u0, keep) and bool(torch.isfinite(out).all())
+            inpl = u0.clone()
+            _lib.check(l.cnf_solve_tsit5(h, 1, inpl.data_ptr(), eps.data_ptr(), inpl.data_ptr(), B, C.byref(opts), C.byref(stats), sp), h)
+            torch.cuda.synchronize()
+            assert torch.equal(inpl, out), (jvp, B, float((inpl - out).abs().max()))
+            # the same columns through the generic kernel's streamed solve
+            ig = make_icnf(cnf, cfg, jvp=jvp, kernel="generic", sol_kwargs=dict(adaptive=False, dt=1 / 8))
+            ig.set_params(flat)
+            sub = 96
+            og = torch.empty(sub, D, device=u0.device)
+            _lib.check(l.cnf_solve_tsit5(ig.handle(), 1, u0[:sub].contiguous().data_ptr(), eps[:sub].contiguous().data_ptr(),
+                                         og.data_ptr(), sub, C.byref(opts), C.byref(stats), sp), ig.handle())
+            torch.cuda.synchronize()
+            assert torch.allclose(out[:sub], og, rtol=2e-5, atol=2e-5), (jvp, B, float((out[:sub] - og).abs().max()))
+
+
 def test_one_launch_solve_takes_the_headline_shape_and_agrees_with_the_streamed_launches():
     """k_solve3b: the adaptive solve of the headline shape (VJP, |eps^T J| row) is ONE launch -- one 32-column tile per
     workgroup up to 8192 columns, several tiles per workgroup beyond (the state then lives in the integrator's buffers);
