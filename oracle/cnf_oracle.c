@@ -42,9 +42,25 @@ static inline void act(int kind, float a, float* h, float* d) {
     }
 }
 
-/* y[o][:] = sum_k W[o + k*out] x[k][:]  (W column-major out x in) */
+/* y[o][:] = sum_k W[o + k*out] x[k][:]  (W column-major out x in).  Four output rows share every load of x[k][:] (register
+   blocking: the one-row form is bound by its loads); each accumulator still adds its products in the order k = 0, 1, ..:
+   results are the same bit for bit. */
 static void gemm_fwd(const float* W, int out, int in, const float (*x)[NB], float (*y)[NB]) {
-    for (int o = 0; o < out; ++o) {
+    int o = 0;
+    for (; o + 4 <= out; o += 4) {
+        float a0[NB], a1[NB], a2[NB], a3[NB];
+        for (int j = 0; j < NB; ++j) { a0[j] = 0.f; a1[j] = 0.f; a2[j] = 0.f; a3[j] = 0.f; }
+        for (int k = 0; k < in; ++k) {
+            const float* w = W + o + (size_t)k * out;
+            const float w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            for (int j = 0; j < NB; ++j) {
+                const float xv = x[k][j];
+                a0[j] += w0 * xv; a1[j] += w1 * xv; a2[j] += w2 * xv; a3[j] += w3 * xv;
+            }
+        }
+        for (int j = 0; j < NB; ++j) { y[o][j] = a0[j]; y[o + 1][j] = a1[j]; y[o + 2][j] = a2[j]; y[o + 3][j] = a3[j]; }
+    }
+    for (; o < out; ++o) {
         float acc[NB];
         for (int j = 0; j < NB; ++j) acc[j] = 0.f;
         for (int k = 0; k < in; ++k) {
@@ -54,9 +70,23 @@ static void gemm_fwd(const float* W, int out, int in, const float (*x)[NB], floa
         for (int j = 0; j < NB; ++j) y[o][j] = acc[j];
     }
 }
-/* y[k][:] = sum_o W[o + k*out] g[o][:] */
+/* y[k][:] = sum_o W[o + k*out] g[o][:]  (four input columns share every load of g[o][:]) */
 static void gemm_bwd(const float* W, int out, int in, const float (*g)[NB], float (*y)[NB]) {
-    for (int k = 0; k < in; ++k) {
+    int k = 0;
+    for (; k + 4 <= in; k += 4) {
+        float a0[NB], a1[NB], a2[NB], a3[NB];
+        for (int j = 0; j < NB; ++j) { a0[j] = 0.f; a1[j] = 0.f; a2[j] = 0.f; a3[j] = 0.f; }
+        const float *c0 = W + (size_t)k * out, *c1 = c0 + out, *c2 = c1 + out, *c3 = c2 + out;
+        for (int o = 0; o < out; ++o) {
+            const float w0 = c0[o], w1 = c1[o], w2 = c2[o], w3 = c3[o];
+            for (int j = 0; j < NB; ++j) {
+                const float gv = g[o][j];
+                a0[j] += w0 * gv; a1[j] += w1 * gv; a2[j] += w2 * gv; a3[j] += w3 * gv;
+            }
+        }
+        for (int j = 0; j < NB; ++j) { y[k][j] = a0[j]; y[k + 1][j] = a1[j]; y[k + 2][j] = a2[j]; y[k + 3][j] = a3[j]; }
+    }
+    for (; k < in; ++k) {
         float acc[NB];
         for (int j = 0; j < NB; ++j) acc[j] = 0.f;
         const float* w = W + (size_t)k * out;
