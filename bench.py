@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=8192, help="columns per GPU")
     ap.add_argument("--fixed-dt", type=float, default=0.0, help="use fixed steps instead of adaptive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth", type=int, default=2, choices=[1, 2, 3],
+                    help="steps in flight: 2 = each step is submitted while the one before it runs (default); 1 = one at a time")
     return ap.parse_args()
 
 
@@ -225,11 +227,28 @@ def run_rank(args):
     # while the timed region runs: nothing is added to the region, the total is read after it
     import ctypes as C
     _lib.check(_lib.lib().cnf_solve_kernel_time(icnf.handle(), 1, None, None), icnf.handle())
+    # The K steps are SUBMITTED (cnf_inference_submit): each step's solve, post-processing, loss sums and all-reduce are
+    # enqueued on the stream while the step before is still running, and collected (status, statistics) one step behind --
+    # the GPU goes from one solve straight into the next instead of idling ~25 us per step while the host turns round.
+    # Every step is complete, collective included, before the closing synchronisation.  --depth 1: one at a time.
     t0 = time.perf_counter()
     nf_total = 0
-    for _ in range(args.steps):
-        st, sums = step()
-        nf_total += st["nf"]
+    if args.depth > 1:
+        pend = []
+        for _ in range(args.steps):
+            _, _, local = cnf.inference_submit(icnf, mode, xs, ps, {}, eps=eps, with_sums=True)
+            pend.append(reduce_sums(local))
+            if len(pend) >= args.depth:
+                nf_total += cnf.inference_collect(icnf)["nf"]
+                sums = pend.pop(0)
+        while pend:
+            nf_total += cnf.inference_collect(icnf)["nf"]
+            sums = pend.pop(0)
+        st = icnf.last_stats
+    else:
+        for _ in range(args.steps):
+            st, sums = step()
+            nf_total += st["nf"]
     sync()
     elapsed = time.perf_counter() - t0
     local_elapsed = elapsed
@@ -360,7 +379,7 @@ def run_rank(args):
             "per_rank_ms_per_step": per_rank_ms, "allreduce_us": allreduce_us,
             "sample_evals_per_s": nf_all / elapsed * B,
             "nf_per_solve": st["nf"], "naccept": st["naccept"], "nreject": st["nreject"],
-            "launches_per_solve": st["launches"], "loss": loss,
+            "launches_per_solve": st["launches"], "steps_in_flight": args.depth, "loss": loss,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

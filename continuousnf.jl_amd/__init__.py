@@ -43,7 +43,7 @@ _HIP_COLD_AT_IMPORT = _hip_cold()
 from . import _lib
 from ._lib import CNFError, build
 from .base_icnf import (ICNF, ODEProblem, base_sol, construct, generate, generate_prob, generate_sol,
-                        inference, inference_prob,
+                        inference, inference_collect, inference_prob, inference_submit,
                         inference_sol, loss, loss_and_grad, loss_from_sums, loss_sums, n_augment,
                         n_augment_input, steer_tspan)
 from .dist import CondICNFDist, ICNFDist, logpdf, pdf, rand

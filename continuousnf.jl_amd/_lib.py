@@ -67,6 +67,10 @@ _SIGNATURES = {
                                      C.POINTER(cnf_solve_opts), C.POINTER(cnf_solve_stats), C.c_void_p]),
     "cnf_inference_host": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int,
                                      C.POINTER(cnf_solve_opts), C.POINTER(cnf_solve_stats)]),
+    "cnf_inference_submit": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_int,
+                                       C.POINTER(cnf_solve_opts), C.c_void_p]),
+    "cnf_inference_collect": (C.c_int, [C.c_void_p, C.POINTER(cnf_solve_stats)]),
+    "cnf_inference_pending": (C.c_int, [C.c_void_p]),
     "cnf_loss_sums": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, _fp, C.c_void_p]),
     "cnf_loss_from_sums": (C.c_int, [C.c_void_p, C.c_int, _fp, C.POINTER(C.c_float)]),
     "cnf_status_string": (C.c_char_p, [C.c_int]),

@@ -578,6 +578,54 @@ def inference(icnf: ICNF, mode, xs, *args, eps=None, with_sums=False):
     return res
 
 
+def inference_submit(icnf: ICNF, mode, xs, *args, eps=None, with_sums=False):
+    """``inference`` on device tensors, submitted: the solve is enqueued and the call returns (cnf_inference_submit) --
+    a loop over column blocks or mini-batches keeps the GPU going from one solve straight into the next.  Returns the
+    output tensors ``(logpx, (E, n, A)[, sums])``; they are valid once ``inference_collect(icnf)`` has returned for this
+    submission (oldest first; up to three outstanding per ICNF, all on one stream)."""
+    if not _is_torch(xs):
+        raise ValueError("inference_submit needs device tensors")
+    ys, ps, st = _split_cond_args(icnf, args)
+    m = _mode_id(mode)
+    xb = _as_colmajor(xs, icnf.nvars, "xs")
+    B = xb.B
+    l, h = _lib.lib(), icnf.handle()
+    if not l.cnf_inference_pending(h):          # (parameters and conditioning are not to change under submitted work)
+        icnf.set_params(ps)
+        icnf.set_cond(ys, B)
+    if eps is not None:
+        eb = _as_colmajor(eps, icnf.nvars + n_augment_input(icnf), "eps")
+        if eb.B != B:
+            raise ValueError("eps must have one column per sample")
+    elif m == _lib.MODE_TRAIN:
+        eb = draw_eps(icnf, xb, B)
+    else:
+        eb = None
+    t = xb.torch
+    buf = t.empty(4 * B + 8, dtype=t.float32, device=xb.arr.device)
+    logpx, regs = buf[:B], buf[B:4 * B]
+    opts = _solve_opts(icnf, steer_tspan(icnf, mode))
+    sums = buf[4 * B:4 * B + 5] if with_sums else None
+    _lib.check(l.cnf_inference_submit(h, m, xb.ptr, eb.ptr if eb is not None else None, logpx.data_ptr(), regs.data_ptr(),
+                                      sums.data_ptr() if with_sums else None, B, C.byref(opts), _stream(xb)), h)
+    # (the inputs must outlive the launch: the submission keeps them)
+    icnf._submitted = getattr(icnf, "_submitted", [])
+    icnf._submitted.append((xb, eb, buf))
+    r = regs.view(3, B)
+    return (logpx, (r[0], r[1], r[2]), sums) if with_sums else (logpx, (r[0], r[1], r[2]))
+
+
+def inference_collect(icnf: ICNF):
+    """Completes the oldest submitted inference (cnf_inference_collect); its statistics become ``icnf.last_stats``."""
+    l, h = _lib.lib(), icnf.handle()
+    stats = _lib.cnf_solve_stats()
+    _lib.check(l.cnf_inference_collect(h, C.byref(stats)), h)
+    if getattr(icnf, "_submitted", None):
+        icnf._submitted.pop(0)
+    icnf.last_stats = stats.as_dict()
+    return icnf.last_stats
+
+
 def loss(icnf: ICNF, mode, xs, *args, eps=None):
     """TrainMode: mean(-logpx + l1 E + l2 n + l3 A) (src/icnf.jl:481-490); otherwise
     -mean(logpx) (src/base_icnf.jl:489-497).  Single process; the sharded form is

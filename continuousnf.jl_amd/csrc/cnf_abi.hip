@@ -18,6 +18,7 @@
 #include <cstring>
 #include <new>
 #include <mutex>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -44,7 +45,27 @@ struct cnf_ctx {
     float* tmp_logpx = nullptr;
     float* tmp_regs = nullptr;
     float* post_part = nullptr;   // loss-sum partials of the post-processing kernel: 4 floats per 64 columns
-    unsigned persist_base = 0;    // meetings the one-launch solves have held on the partials buffer so far
+    // inferences submitted and not yet collected (cnf_inference_submit / cnf_inference_collect): the one-launch solve is
+    // enqueued and the call returns; the outcome is read later from the launch's own slot of the host mirror
+    struct Submitted {
+        bool launched = false;    // a one-launch solve is in flight (else: the call completed synchronously; status / stats say how)
+        unsigned seq = 0;         // its launch index = the tag it publishes its final state with
+        int slot = 0;             // ... into this slot of the host mirror
+        bool hairer = false;
+        int mode = 0, B = 0, k = 0;
+        const float *xs = nullptr, *eps = nullptr;
+        float *logpx = nullptr, *regs = nullptr, *sums5 = nullptr;
+        cnf_solve_opts opts{};
+        hipStream_t st = nullptr;
+        cnf_solve_stats stats{};
+        cnf_status status = CNF_OK;
+    };
+    std::deque<Submitted> submitted;
+    unsigned one_launch_count = 0; // one-launch solves so far: they take the mirror slots 1, 2, 3 in turn (slot 0: the streamed solves)
+    bool submitting = false;      // inside cnf_inference_submit: a one-launch solve is recorded in `submitted`, not waited for
+    bool sub_taken = false;       //   ... and this call was
+    bool collecting = false;      // inside submit / collect: check_call does not drain the queue
+    bool no_persist = false;      // the fallback of a collected launch: straight to the streamed driver
     bool time_kernel = false;     // cnf_solve_kernel_time: the one-launch solve kernel adds up its own durations
     int fallbacks = 0;            // one-launch solves that ran out of a wait and were run again on the streamed driver
     float* step_trace = nullptr;  // cnf_set_step_trace: caller-owned device buffer, 4 floats per step attempt
@@ -197,9 +218,12 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     if (e == hipSuccess) e = hipMalloc(&h->d_sums, 24 * sizeof(float));      // 8 floats of sums, tickets, the kernel clock words
     if (e == hipSuccess) e = hipMemset(h->d_sums, 0, 24 * sizeof(float));      // words 8.. are device tickets: zero between launches
     if (e == hipSuccess) e = hipHostMalloc(&h->h_sums, 4 * sizeof(float), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc(&h->h_mirror, sizeof(*h->h_mirror), hipHostMallocCoherent | hipHostMallocMapped);
+    // (four slots: the streamed solves use slot 0; the one-launch solves take slots 1, 2, 3 in turn, so that up to three
+    // submitted launches can be in flight -- and one of them be run again on the streamed driver -- without overwriting
+    // each other's final state)
+    if (e == hipSuccess) e = hipHostMalloc(&h->h_mirror, 4 * sizeof(*h->h_mirror), hipHostMallocCoherent | hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_mirror, h->h_mirror, 0);
-    if (e == hipSuccess) memset(h->h_mirror, 0, sizeof(*h->h_mirror));     // tag 0 is never a launch index (mirror_base starts at 1)
+    if (e == hipSuccess) memset(h->h_mirror, 0, 4 * sizeof(*h->h_mirror));     // tag 0 is never a launch index (mirror_base starts at 1)
     if (e != hipSuccess) {
         cnf_destroy(h);
         return CNF_ERR_HIP;
@@ -209,10 +233,20 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     return CNF_OK;
 }
 
+// submitted launches still in flight read the handle's buffers: calls that change or free them wait for those launches
+// (the submissions stay collectable: their outcome sits in the host mirror)
+static void release_submitted(cnf_handle h);
+static void sync_submitted(cnf_handle h) {
+    for (const auto& sub : h->submitted)
+        if (sub.launched) (void)hipStreamSynchronize(sub.st);
+}
+
 extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (!h) return CNF_ERR_BAD_ARG;
     // called from a finaliser after the HIP runtime has shut down (process exit): nothing left to free on the device
     if (hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); delete h; return CNF_OK; }
+    sync_submitted(h);
+    release_submitted(h);
     mfma_plan_free(h->mfma);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_cond) (void)hipFree(h->d_cond);
@@ -239,6 +273,7 @@ extern "C" cnf_status cnf_set_params(cnf_handle h, const float* flat_dev, size_t
     if (n != h->n_params) return fail(h, CNF_ERR_BAD_SHAPE, "parameter count does not match the layer sizes");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(h, hipSetDevice(h->device));
+    sync_submitted(h);
     HIPCHK(h, hipMemcpyAsync(h->d_params, flat_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     cnf_status ms = mfma_plan_pack(h->mfma, h->nd, h->d_params, s);
     if (ms != CNF_OK) return fail(h, ms, "MFMA weight packing failed");
@@ -254,6 +289,7 @@ extern "C" cnf_status cnf_set_params_host(cnf_handle h, const float* flat, size_
     if (!h || !flat) return CNF_ERR_BAD_ARG;
     if (n != h->n_params) return fail(h, CNF_ERR_BAD_SHAPE, "parameter count does not match the layer sizes");
     HIPCHK(h, hipSetDevice(h->device));
+    sync_submitted(h);
     HIPCHK(h, hipMemcpy(h->d_params, flat, n * sizeof(float), hipMemcpyHostToDevice));
     cnf_status ms = mfma_plan_pack(h->mfma, h->nd, h->d_params, nullptr);
     if (ms != CNF_OK) return fail(h, ms, "MFMA weight packing failed");
@@ -300,6 +336,8 @@ static cnf_status ensure_stage(cnf_handle h, size_t nfloats) {
     return CNF_OK;
 }
 
+static cnf_status collect_one(cnf_handle h, cnf_solve_stats* stats);
+static void release_submitted(cnf_handle h);
 static cnf_status check_call(cnf_handle h, int mode, int B) {
     if (!h) return CNF_ERR_BAD_ARG;
     if (mode != CNF_MODE_TEST && mode != CNF_MODE_TRAIN) return fail(h, CNF_ERR_BAD_ARG, "unknown mode");
@@ -309,6 +347,11 @@ static cnf_status check_call(cnf_handle h, int mode, int B) {
         return fail(h, CNF_ERR_NO_PARAMS, "conditional model: call cnf_set_cond with the ys of this batch first");
     h->mfma.cond = h->nd.n_cond > 0 ? h->d_cond : nullptr;
     h->mfma.cbs = h->cbs;
+    // any other call on the handle first completes the inferences submitted on it (their statistics are dropped)
+    while (!h->collecting && !h->submitted.empty()) {
+        const cnf_status s = collect_one(h, nullptr);
+        if (s != CNF_OK) return s;
+    }
     return CNF_OK;
 }
 
@@ -678,6 +721,38 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                              const cnf_solve_opts* opts, cnf_solve_stats* stats, void* stream, Recorder* rec,
                              bool final_sync = true, PostHook* post = nullptr);
 
+// One-launch solves of this process: one at a time (two would each hold CUs the other is waiting for), except that
+// submitted launches may queue up behind each other on ONE stream.
+static std::mutex g_persist_mu;
+static int g_submitted_inflight = 0;               // (both under g_persist_mu)
+static hipStream_t g_submitted_stream = nullptr;
+
+// The outcome of the one-launch solve with launch index `seq`: its final state arrives in its slot of the host mirror.
+// *aborted: a wait inside the kernel ran out (the state says so itself: n_partials < 0) -- nothing of the launch is used,
+// the abort word is cleared (after the stream has drained: launches queued behind it read it too) and the caller runs
+// the solve again on the streamed driver.
+static cnf_status finish_one_launch(cnf_handle h, unsigned seq, int slot, hipStream_t st, StepState* fin, bool* aborted) {
+    const volatile cnf_ctx::HostMirror* hm = h->h_mirror + slot;
+    unsigned sq = 0;
+    for (long spins = 0;; ++spins) {
+        if (cnf_mirror_read(hm, fin, &sq) && sq == seq) break;
+        if (spins < 4096) _mm_pause();
+        else sched_yield();
+        if (spins % 100000 == 99999) {
+            hipError_t qe = hipStreamQuery(st);
+            if (qe != hipSuccess && qe != hipErrorNotReady) HIPCHK(h, qe);
+            if (qe == hipSuccess && !(cnf_mirror_read(hm, fin, &sq) && sq == seq))
+                return fail(h, CNF_ERR_HIP, "the solve kernel finished without publishing a state");
+        }
+    }
+    *aborted = fin->n_partials < 0;
+    if (*aborted) {
+        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, hipMemset(h->d_sums + 11, 0, sizeof(float)));
+    } else if (!fin->done && !fin->nonfinite) return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
+    return CNF_OK;
+}
+
 extern "C" cnf_status cnf_solve_tsit5(cnf_handle h, int mode, const float* u0,
                                       const float* eps, float* u_out, int B,
                                       const cnf_solve_opts* opts, cnf_solve_stats* stats,
@@ -745,13 +820,16 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     const bool hairer = opts->adaptive && opts->dt == 0.f;
     // The whole solve in one cooperative launch where the handle and the batch allow it (k_solve3b): the weights and the
     // Runge-Kutta rows stay on the CUs for all attempts, the workgroups exchange two floats per attempt.
-    if (use_mfma && !lockstep) {
-        // one such kernel at a time in this process: two of them would each hold CUs the other is waiting for
-        static std::mutex persist_mu;
-        std::unique_lock<std::mutex> persist_lock(persist_mu);
+    if (use_mfma && !lockstep && !h->no_persist) {
+        // one such kernel at a time in this process: two of them would each hold CUs the other is waiting for.  Launches
+        // queued on ONE stream run one after the other by themselves (submitted inferences); a launch on another stream
+        // waits for those first.
+        std::unique_lock<std::mutex> persist_lock(g_persist_mu);
+        if (g_submitted_inflight > 0 && g_submitted_stream != st) HIPCHK(h, hipStreamSynchronize(g_submitted_stream));
         const unsigned base = h->mirror_base;
+        const int mslot = 1 + (int)(h->one_launch_count % 3);
         Solve3Args sv{};
-        sv.part = h->partials; sv.base = h->persist_base; sv.abort_flag = reinterpret_cast<int*>(h->d_sums + 11);
+        sv.part = h->partials; sv.base_dev = reinterpret_cast<unsigned*>(h->d_sums + 10); sv.abort_flag = reinterpret_cast<int*>(h->d_sums + 11);
         sv.t_out = h->time_kernel ? reinterpret_cast<unsigned long long*>(h->d_sums + 12) : nullptr;
         sv.maxiters = (int)opts->maxiters; sv.hairer = hairer ? 1 : 0; sv.init = *init;
         // polls a wait inside the kernel makes before it gives up (seconds at the default; CNF_SOLVE_POLL_LIMIT: tests)
@@ -769,42 +847,30 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             slot = traj_slot_floats(h); dcap = h->traj_cap;
             dump = h->traj + n;                      // stage area of slot 0; u_n sits one array before
         }
-        s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror, base, sv, h->device,
+        s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror + mslot, base, sv, h->device,
                                   dump, n, slot, dcap, h->traj_hs, h->K1);
         if (s == CNF_OK) {
             ++launches;
             h->mirror_base = base + 1;
+            ++h->one_launch_count;
             h->last_state = h->d_state;
             HIPCHK(h, hipGetLastError());
-            // the final state arrives through the host mirror, as in the streamed solve
-            const volatile cnf_ctx::HostMirror* hm = h->h_mirror;
+            if (h->submitting && fused_io && !rec && !u_out) {
+                // submitted: the launch is on its way; cnf_inference_collect reads its outcome from its mirror slot
+                cnf_ctx::Submitted sub;
+                sub.launched = true; sub.seq = base; sub.slot = mslot; sub.hairer = hairer; sub.mode = mode; sub.B = B; sub.k = k;
+                sub.xs = post->xs; sub.eps = eps; sub.logpx = post->logpx; sub.regs = post->regs; sub.sums5 = post->sums5;
+                sub.opts = *opts; sub.st = st;
+                h->submitted.push_back(sub);
+                h->sub_taken = true;
+                ++g_submitted_inflight; g_submitted_stream = st;
+                post->launched = true;
+                return CNF_OK;
+            }
             StepState fin{};
-            unsigned sq = 0;
-            for (long spins = 0;; ++spins) {
-                if (cnf_mirror_read(hm, &fin, &sq) && sq == base) break;
-                if (spins < 4096) _mm_pause();
-                else sched_yield();
-                if (spins % 100000 == 99999) {
-                    hipError_t qe = hipStreamQuery(st);
-                    if (qe != hipSuccess && qe != hipErrorNotReady) HIPCHK(h, qe);
-                    if (qe == hipSuccess && !(cnf_mirror_read(hm, &fin, &sq) && sq == base))
-                        return fail(h, CNF_ERR_HIP, "the solve kernel finished without publishing a state");
-                }
-            }
-            const int attempts = fin.naccept + fin.nreject;
-            h->persist_base += (unsigned)((hairer ? 2 : 0) + attempts + (fused_io && post->sums5 ? 1 : 0));
             bool aborted = false;
-            if (!fin.done && !fin.nonfinite) {
-                // maxiters, or a wait inside the kernel ran out (abort word): start the meeting indices afresh either way
-                HIPCHK(h, hipStreamSynchronize(st));
-                int ab = 0;
-                HIPCHK(h, hipMemcpy(&ab, h->d_sums + 11, sizeof(int), hipMemcpyDeviceToHost));
-                HIPCHK(h, hipMemset(h->d_sums + 10, 0, 2 * sizeof(float)));
-                HIPCHK(h, hipMemset(h->partials, 0, 8 * MAX_PARTIALS * sizeof(float)));      // (stale meeting indices)
-                h->persist_base = 0;
-                aborted = ab != 0;
-                if (!aborted) return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
-            }
+            if ((s = finish_one_launch(h, base, mslot, st, &fin, &aborted)) != CNF_OK) return s;
+            const int attempts = fin.naccept + fin.nreject;
             if (!aborted) {
                 if (fused_io) post->launched = true;
                 else if (post) { enqueue_post(h, train, h->d_state, *post, B, false, st); ++launches; post->launched = true; }
@@ -1203,6 +1269,78 @@ static cnf_status inference_impl(cnf_handle h, int mode, const float* xs, const 
     }
     return s;
 }
+
+// ---- submitted inferences: enqueue now, collect later (the GPU goes from one solve straight into the next) ----
+// The oldest submitted inference: wait for its outcome; a launch that ran out of a wait is run again on the streamed driver.
+static cnf_status collect_one(cnf_handle h, cnf_solve_stats* stats) {
+    cnf_ctx::Submitted sub = h->submitted.front();
+    h->submitted.pop_front();
+    if (stats) *stats = sub.stats;
+    if (!sub.launched) return sub.status;
+    HIPCHK(h, hipSetDevice(h->device));
+    StepState fin{};
+    bool aborted = false;
+    cnf_status s;
+    {
+        std::unique_lock<std::mutex> lock(g_persist_mu);
+        s = finish_one_launch(h, sub.seq, sub.slot, sub.st, &fin, &aborted);
+        --g_submitted_inflight;
+    }
+    if (s != CNF_OK) return s;
+    if (!aborted) {
+        if (stats) {
+            const int attempts = fin.naccept + fin.nreject;
+            stats->nf = (sub.hairer ? 2 : 1) + 6 * attempts;
+            stats->naccept = fin.naccept; stats->nreject = fin.nreject;
+            stats->t_final = fin.t; stats->dt_last = fin.dt;
+            stats->kernel_used = sub.k; stats->launches = 1;
+        }
+        if (fin.nonfinite) return fail(h, CNF_ERR_NONFINITE, "solver state became NaN/Inf");
+        return CNF_OK;
+    }
+    ++h->fallbacks;
+    const bool was = h->collecting;
+    h->collecting = true; h->no_persist = true;
+    s = inference_impl(h, sub.mode, sub.xs, sub.eps, sub.logpx, sub.regs, nullptr, sub.sums5, sub.B, &sub.opts, stats, sub.st);
+    h->no_persist = false; h->collecting = was;
+    return s;
+}
+
+// a handle destroyed with submissions outstanding gives up its claim on the process-wide launch order
+static void release_submitted(cnf_handle h) {
+    std::unique_lock<std::mutex> lock(g_persist_mu);
+    for (const auto& sub : h->submitted)
+        if (sub.launched) --g_submitted_inflight;
+    h->submitted.clear();
+}
+
+extern "C" cnf_status cnf_inference_submit(cnf_handle h, int mode, const float* xs, const float* eps, float* logpx,
+                                           float* regs, float* sums5, int B, const cnf_solve_opts* opts, void* stream) {
+    if (!h) return CNF_ERR_BAD_ARG;
+    if (h->submitted.size() >= 3) return fail(h, CNF_ERR_BAD_ARG, "three inferences are submitted already: collect one first");
+    h->collecting = true; h->submitting = true; h->sub_taken = false;
+    cnf_solve_stats st{};
+    const cnf_status s = inference_impl(h, mode, xs, eps, logpx, regs, nullptr, sums5, B, opts, &st, stream);
+    h->submitting = false; h->collecting = false;
+    if (!h->sub_taken) {                      // completed on the spot (another driver, an empty batch, or an error)
+        cnf_ctx::Submitted sub;
+        sub.status = s; sub.stats = st;
+        h->submitted.push_back(sub);
+    }
+    return CNF_OK;                            // (the outcome, errors included, is the matching collect call's)
+}
+
+extern "C" cnf_status cnf_inference_collect(cnf_handle h, cnf_solve_stats* stats) {
+    if (!h) return CNF_ERR_BAD_ARG;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (h->submitted.empty()) return fail(h, CNF_ERR_BAD_ARG, "no inference is submitted");
+    h->collecting = true;
+    const cnf_status s = collect_one(h, stats);
+    h->collecting = false;
+    return s;
+}
+
+extern "C" int cnf_inference_pending(cnf_handle h) { return h ? (int)h->submitted.size() : -1; }
 
 extern "C" cnf_status cnf_inference(cnf_handle h, int mode, const float* xs, const float* eps,
                                     float* logpx, float* regs, float* u_final, int B,

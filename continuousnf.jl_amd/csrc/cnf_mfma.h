@@ -77,7 +77,8 @@ struct Solve3Args {
     int spin_limit;       // polls a wait makes before it gives up (abort word; the caller then streams step launches)
     float* trace;         // null, or 4 floats per step attempt: (t, signed h, EEst, accepted) -- cnf_set_step_trace
     int trace_cap;        //   attempts the buffer holds
-    unsigned base;        // meetings held by earlier launches on this buffer: the indices go on from there
+    unsigned* base_dev;   // device word: meetings held by earlier launches on the buffer `part` (the indices go on from there;
+                          //   the launch advances it when it ends)
     int* abort_flag;      // set when a wait ran out
     unsigned long long* t_out;   // null, or {entry stamp, sum of durations, launches}: workgroup 0's 100 MHz real-time clock
     int maxiters;

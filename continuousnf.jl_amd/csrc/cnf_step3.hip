@@ -1852,6 +1852,9 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(abstol)));
     reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(reltol)));
     int nsync = 0;                                         // meetings so far (the same count in every workgroup)
+    // meetings held on this buffer by earlier launches: a device word, so that a launch can be queued behind another
+    // before the host knows how many meetings that one will hold (read once; workgroup 0 advances it at the very end)
+    const unsigned mbase = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sv.base_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     // The workgroups' partials (e, b) -> the sums of all of them, in msc[32], msc[33] for thread 0 (what the prologue of a
     // step launch computes from the previous launch's partials, in the same order).  Returns false when a wait ran out.
     auto meet = [&](float e_lane, float b_lane) -> bool {
@@ -1862,7 +1865,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
         // ticket -- thread i polls workgroup i's two words until both carry this meeting's index -- so a meeting costs one
         // store and one load round trip.  Two buffers by parity: a workgroup can be one meeting ahead of a reader, not two.
         unsigned long long* pb = reinterpret_cast<unsigned long long*>(sv.part) + (nsync & 1) * 1024;
-        const unsigned tag = sv.base + (unsigned)nsync + 1u;
+        const unsigned tag = mbase + (unsigned)nsync + 1u;
         if (tid == 0) {
             float e8 = 0.f, b8 = 0.f;
             for (int w = 0; w < 8; ++w) { e8 += msc[w]; b8 += msc[16 + w]; }
@@ -2152,7 +2155,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
             // workgroup partials (waves 4 and 6 hold them) -> tagged words, one more meeting index; workgroup 0 adds them in
             // workgroup order
             unsigned long long* qb = reinterpret_cast<unsigned long long*>(sv.part) + 2048;
-            const unsigned tag = sv.base + (unsigned)nsync + 1u;
+            const unsigned tag = mbase + (unsigned)nsync + 1u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v4[j] = s3_wave_sum(v4[j]);
             s3_bar();                                      // (red8 above read RED; msc below)
@@ -2192,12 +2195,17 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
                     sv.sums5[4] = (float)a.B;
                     float nl = 0.f;
                     for (int w = 0; w < 8; ++w) nl += msc[32 + w];
-                    if (nl != 0.f) ns->done = 0;               // the host sees the abort word and runs the solve again, streamed
+                    if (nl != 0.f) { ns->done = 0; ns->n_partials = -1; }               // the host sees the abort word and runs the solve again, streamed
                 }
             }
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
+        // A wait that ran out anywhere (this workgroup's `alive`, or another's abort word -- set before this workgroup
+        // could have passed the meeting in question) makes the launch void: the published state says so by itself
+        // (n_partials < 0), so that the host can tell for THIS launch even when others are queued behind it.
+        if (!alive || __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ns->done = 0; ns->n_partials = -1; }
+        __hip_atomic_store(sv.base_dev, mbase + (unsigned)nsync + 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (workgroups differ by <= 1 meeting; + the sums)
         ns->cur = multi ? cur : 0;
         *a.st_out = *ns;
         if (sv.t_out) { sv.t_out[1] += __builtin_amdgcn_s_memrealtime() - sv.t_out[0]; sv.t_out[2] += 1; }
@@ -2331,6 +2339,9 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
     abstol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(abstol)));
     reltol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(reltol)));
     int nsync = 0;                                         // meetings so far (the same count in every workgroup)
+    // meetings held on this buffer by earlier launches: a device word, so that a launch can be queued behind another
+    // before the host knows how many meetings that one will hold (read once; workgroup 0 advances it at the very end)
+    const unsigned mbase = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sv.base_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     // The workgroups' partials (e, b) -> the sums of all of them, in msc[32], msc[33] for thread 0 (what the prologue of a
     // step launch computes from the previous launch's partials, in the same order).  Returns false when a wait ran out.
     auto meet = [&](float e_lane, float b_lane) -> bool {
@@ -2341,7 +2352,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         // ticket -- thread i polls workgroup i's two words until both carry this meeting's index -- so a meeting costs one
         // store and one load round trip.  Two buffers by parity: a workgroup can be one meeting ahead of a reader, not two.
         unsigned long long* pb = reinterpret_cast<unsigned long long*>(sv.part) + (nsync & 1) * 1024;
-        const unsigned tag = sv.base + (unsigned)nsync + 1u;
+        const unsigned tag = mbase + (unsigned)nsync + 1u;
         if (tid == 0) {
             float e8 = 0.f, b8 = 0.f;
             for (int w = 0; w < 8; ++w) { e8 += msc[w]; b8 += msc[16 + w]; }
@@ -2599,7 +2610,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
             // workgroup partials (waves 4 and 6 hold them) -> tagged words, one more meeting index; workgroup 0 adds them in
             // workgroup order
             unsigned long long* qb = reinterpret_cast<unsigned long long*>(sv.part) + 2048;
-            const unsigned tag = sv.base + (unsigned)nsync + 1u;
+            const unsigned tag = mbase + (unsigned)nsync + 1u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v4[j] = s3_wave_sum(v4[j]);
             s3_bar();                                      // (red8 above read RED; msc below)
@@ -2639,12 +2650,17 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
                     sv.sums5[4] = (float)a.B;
                     float nl = 0.f;
                     for (int w = 0; w < 8; ++w) nl += msc[32 + w];
-                    if (nl != 0.f) ns->done = 0;               // the host sees the abort word and runs the solve again, streamed
+                    if (nl != 0.f) { ns->done = 0; ns->n_partials = -1; }               // the host sees the abort word and runs the solve again, streamed
                 }
             }
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
+        // A wait that ran out anywhere (this workgroup's `alive`, or another's abort word -- set before this workgroup
+        // could have passed the meeting in question) makes the launch void: the published state says so by itself
+        // (n_partials < 0), so that the host can tell for THIS launch even when others are queued behind it.
+        if (!alive || __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ns->done = 0; ns->n_partials = -1; }
+        __hip_atomic_store(sv.base_dev, mbase + (unsigned)nsync + 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (workgroups differ by <= 1 meeting; + the sums)
         ns->cur = multi ? cur : 0;
         *a.st_out = *ns;
         if (sv.t_out) { sv.t_out[1] += __builtin_amdgcn_s_memrealtime() - sv.t_out[0]; sv.t_out[2] += 1; }

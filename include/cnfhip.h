@@ -185,6 +185,21 @@ cnf_status cnf_inference_host(cnf_handle h, int mode, const float* xs, const flo
                               float* logpx, float* regs, float* u_final, int B,
                               const cnf_solve_opts* opts, cnf_solve_stats* stats);
 
+/* Submitted inferences -- what a loop over data batches (`loss` over the mini-batches of an epoch,
+ * src/exts/mlj_ext/core_icnf.jl:59-73; `logpdf` over many column blocks, src/exts/dist_ext/core_icnf.jl:23-31) needs to
+ * keep the GPU busy: cnf_inference_submit enqueues cnf_inference_sums (sums5 may be NULL) and returns without waiting for
+ * it when the solve is ONE launch (the headline path); cnf_inference_collect completes the OLDEST submitted inference and
+ * returns ITS status and statistics (errors of a submitted inference are reported there).  Up to three may be outstanding
+ * per handle; they must use the same stream and distinct output buffers.  An inference that does not take the one-launch
+ * path is simply completed inside the submit call; a launch that could not place its workgroups is run again on the
+ * streamed driver inside collect.  Any other call on the handle collects outstanding submissions first (their
+ * statistics are dropped).  cnf_inference_pending: how many are outstanding. */
+cnf_status cnf_inference_submit(cnf_handle h, int mode, const float* xs, const float* eps, float* logpx,
+                                float* regs, float* sums5 /* may be NULL */, int B, const cnf_solve_opts* opts,
+                                void* stream);
+cnf_status cnf_inference_collect(cnf_handle h, cnf_solve_stats* stats /* may be NULL */);
+int cnf_inference_pending(cnf_handle h);
+
 /* The local part of `loss` (src/icnf.jl:481-490; src/base_icnf.jl:489-497): writes
  * sums[5] = (sum logpx, sum E, sum n, sum A, B) to DEVICE memory.  These five floats are
  * the only cross-shard quantity: the caller all-reduces them (RCCL, ncclSum) and then

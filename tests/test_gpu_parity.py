@@ -681,8 +681,8 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for var, sel in (("CNF_PERSISTENT=0", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3 or "
-                                          "test_one_launch_solve or test_headline_kernels_strict"),
-                     ("CNF_SOLVE_POLL_LIMIT=1", "test_one_launch_solve_falls_back"),
+                                          "test_one_launch_solve or test_headline_kernels_strict or test_submitted_inferences"),
+                     ("CNF_SOLVE_POLL_LIMIT=1", "test_one_launch_solve_falls_back or test_submitted_inferences"),
                      ("CNF_PIPE=1", "test_headline_kernels_strict or test_adaptive_solve_vs_oracles and 3-mfma or "
                                     "test_loss_grad_headline or test_one_launch_solve_takes"),
                      ("CNF_STEP_FP32", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve or "
@@ -698,6 +698,65 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
                            text=True, timeout=900)
         assert r.returncode == 0, (var, r.stdout[-2000:], r.stderr[-1000:])
         assert " passed" in r.stdout and "failed" not in r.stdout, (var, r.stdout[-500:])
+
+
+def test_submitted_inferences_equal_the_synchronous_ones():
+    """cnf_inference_submit / cnf_inference_collect: up to three inferences enqueued back to back on one stream, collected
+    oldest first -- outputs, loss sums and statistics equal those of the synchronous call bit for bit (the same launch,
+    only waited for later), on every route (one launch, several tiles per workgroup, streamed, the forced fallback of
+    the CNF_SOLVE_POLL_LIMIT=1 child run); a fourth submission is refused, any other call on the handle collects first,
+    a submission that fails reports at its collect."""
+    cfg, _, _ = O.baseline_cfg(3)
+    rng = np.random.default_rng(911)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    tol = dict(reltol=3.45e-4, abstol=1.19e-7)
+    forced = os.environ.get("CNF_SOLVE_POLL_LIMIT") == "1"
+    for kernel, Bs in (("mfma", (8192, 1000, 8224)), ("generic", (64, 33, 7))):
+        ic = make_icnf(cnf, cfg, kernel=kernel, sol_kwargs=tol)
+        ins = [(_dev(rng.standard_normal((cfg.nvars, B))), _dev(rng.standard_normal((cfg.n_in, B)))) for B in Bs]
+        want = []
+        for xs, eps in ins:
+            lp, regs, sums = cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps, with_sums=True)
+            want.append((lp.clone(), [r.clone() for r in regs], sums.clone(), dict(ic.last_stats)))
+        fb0 = ic.solve_fallbacks()
+        outs = [cnf.inference_submit(ic, cnf.TrainMode(), xs, flat, {}, eps=eps, with_sums=True) for xs, eps in ins]
+        assert _lib.lib().cnf_inference_pending(ic.handle()) == 3
+        with pytest.raises(cnf.CNFError):
+            cnf.inference_submit(ic, cnf.TrainMode(), ins[0][0], flat, {}, eps=ins[0][1])
+        for (lp, regs, sums), (wlp, wregs, wsums, wst) in zip(outs, want):
+            st = cnf.inference_collect(ic)
+            torch.cuda.synchronize()
+            assert torch.equal(lp, wlp) and all(torch.equal(a, b) for a, b in zip(regs, wregs)) and torch.equal(sums, wsums)
+            for key in ("nf", "naccept", "nreject", "kernel_used"):
+                assert st[key] == wst[key], (kernel, key, st, wst)
+            if kernel == "mfma" and _one_launch_expected() and not forced and wst["launches"] == 1:
+                assert st["launches"] == 1, st
+        assert _lib.lib().cnf_inference_pending(ic.handle()) == 0
+        if forced and kernel == "mfma" and _one_launch_expected():
+            assert ic.solve_fallbacks() - fb0 == 3, ic.solve_fallbacks() - fb0
+        with pytest.raises(cnf.CNFError):
+            cnf.inference_collect(ic)                                   # nothing submitted
+        # any other call on the handle completes what is submitted first
+        o1 = cnf.inference_submit(ic, cnf.TrainMode(), ins[1][0], flat, {}, eps=ins[1][1])
+        lp2, _ = cnf.inference(ic, cnf.TrainMode(), ins[2][0], flat, {}, eps=ins[2][1])
+        torch.cuda.synchronize()
+        assert _lib.lib().cnf_inference_pending(ic.handle()) == 0
+        assert torch.equal(o1[0], want[1][0]) and torch.equal(lp2, want[2][0])
+        ic.close()
+    # an inference that fails (maxiters) reports at ITS collect, not at the submit; the handle goes on working
+    ic = make_icnf(cnf, cfg, sol_kwargs=dict(tol, maxiters=2))
+    xs, eps = ins[1] if False else (_dev(rng.standard_normal((cfg.nvars, 512))), _dev(rng.standard_normal((cfg.n_in, 512))))
+    cnf.inference_submit(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    with pytest.raises(cnf.CNFError):
+        cnf.inference_collect(ic)
+    ic.sol_kwargs = dict(tol)
+    ic._opts_cache = None
+    a = cnf.inference_submit(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    cnf.inference_collect(ic)
+    b, _ = cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b)
+    ic.close()
 
 
 def test_bare_solve_reads_and_writes_the_callers_columns():
