@@ -70,4 +70,41 @@ function HIPExt.rhs!(du::AMDGPU.ROCMatrix{Float32}, u::AMDGPU.ROCMatrix{Float32}
     nothing
 end
 
+# ---- submitted inferences (cnf_inference_submit / cnf_inference_collect): a loop over column blocks or mini-batches that
+# keeps the GPU going from one solve straight into the next.  `inference_submit!` enqueues inference_prob -> base_sol ->
+# inference_sol (src/base_icnf.jl:407-415) for the data columns `xs` and returns the device arrays the results will be in
+# (logp̂x, the 3 x B regulariser rows, and the five loss sums of src/icnf.jl:489); they are valid once `inference_collect!`
+# has returned for this submission (oldest first, up to three outstanding per ICNF, one stream).  Untested, as the rest.
+const SUBMITTED = IdDict{Any, Vector{Any}}()          # keeps the arrays of outstanding submissions alive
+function inference_submit!(icnf::ICNF{T, <:HIPMatrixMode}, mode, xs::AMDGPU.ROCMatrix{Float32}, ps, st;
+        ϵ::AMDGPU.ROCMatrix{Float32} = AMDGPU.ROCArray{Float32}(rand(icnf.rng, icnf.epsdist, size(xs, 2)))) where {T}
+    h = handle(icnf)
+    pending = @ccall libcnfhip.cnf_inference_pending(h::Ptr{Cvoid})::Cint
+    pending == 0 && set_params!(h, ps; force = true)       # parameters do not change under submitted work
+    B = size(xs, 2)
+    t0, t1 = CNF.steer_tspan(icnf, mode)
+    kw = icnf.sol_kwargs
+    opts = CnfSolveOpts(t0, t1, get(kw, :abstol, 1.0f-6), get(kw, :reltol, 1.0f-3), get(kw, :dt, 0.0f0),
+                        get(kw, :adaptive, true) ? 1 : 0, min(get(kw, :maxiters, 100_000), typemax(Int32)), 0)
+    logpx = AMDGPU.ROCArray{Float32}(undef, B)
+    regs = AMDGPU.ROCArray{Float32}(undef, B, 3)              # column-major B x 3 = the ABI's 3 rows of B
+    sums5 = AMDGPU.ROCArray{Float32}(undef, 5)
+    GC.@preserve xs ϵ logpx regs sums5 begin
+        check(@ccall(libcnfhip.cnf_inference_submit(h::Ptr{Cvoid}, mode_flag(mode)::Cint, devptr(xs)::Ptr{Float32},
+                                                    devptr(ϵ)::Ptr{Float32}, devptr(logpx)::Ptr{Float32},
+                                                    devptr(regs)::Ptr{Float32}, devptr(sums5)::Ptr{Float32}, B::Cint,
+                                                    Ref(opts)::Ptr{CnfSolveOpts}, raw_stream()::Ptr{Cvoid})::Cint), h)
+    end
+    push!(get!(SUBMITTED, icnf, Any[]), (xs, ϵ, logpx, regs, sums5))
+    logpx, regs, sums5
+end
+function inference_collect!(icnf::ICNF{T, <:HIPMatrixMode}) where {T}
+    h = handle(icnf)
+    stats = CnfSolveStats()
+    check(@ccall(libcnfhip.cnf_inference_collect(h::Ptr{Cvoid}, stats::Ref{CnfSolveStats})::Cint), h)
+    q = get(SUBMITTED, icnf, Any[])
+    isempty(q) || popfirst!(q)
+    stats
+end
+
 end # module
