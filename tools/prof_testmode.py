@@ -17,9 +17,14 @@ t0 = time.perf_counter()
 for _ in range(5): f()
 torch.cuda.synchronize()
 print(f"cfg3 TestMode RHS B={B}: {(time.perf_counter()-t0)/5*1e3:.3f} ms")
-xs = torch.from_numpy(rng.standard_normal((wl.nvars, B)).astype(np.float32)).cuda()
+# (column-major as the reference keeps it: a sample's rows contiguous -- no layout copy inside the call)
+xs = torch.from_numpy(rng.standard_normal((B, wl.nvars)).astype(np.float32)).cuda().t()
 ic = configs.build(wl, sol_kwargs=configs.README_TOLERANCES)
-g = lambda: cnf.inference(ic, cnf.TestMode(), xs, flat, {})
-g(); torch.cuda.synchronize()
-t0 = time.perf_counter(); g(); torch.cuda.synchronize()
-print(f"cfg3 TestMode inference B={B}: {(time.perf_counter()-t0)*1e3:.2f} ms", ic.last_stats)
+ps = torch.from_numpy(flat).cuda()
+g = lambda: cnf.inference(ic, cnf.TestMode(), xs, ps, {})
+g(); g(); torch.cuda.synchronize()
+n = 5
+t0 = time.perf_counter()
+for _ in range(n): g()
+torch.cuda.synchronize()
+print(f"cfg3 TestMode inference B={B}: {(time.perf_counter()-t0)/n*1e3:.2f} ms", ic.last_stats)
