@@ -116,6 +116,7 @@ def cpu_baseline(B, flat, xs, eps, kw, budget_s=9.0):
             "sample": f"{n} adaptive Tsit5 solves of the same workload (B={B}, nf={st['nf']} each); restatement "
                       f"of the reference path (the Julia package cannot run here)",
             "seconds": el}
+    CO.set_threads(BL.available_cores())                  # (torch may have sized the shared OpenMP runtime for the whole host)
     nf, n, el, st = _timed_solves(lambda: CO.solve(cfg, flat, u0, eps, True, **kw)[1], budget_s)
     port = {"value": nf / el, "unit": "RHS-evals/s", "cores": CO.threads(), "kind": "port",
             "host_cores": BL.os_cpu_count(), "available_cores": BL.available_cores(),
@@ -254,6 +255,17 @@ def run_rank(args):
     local_elapsed = elapsed
     k_mean_us, k_launches = C.c_float(), C.c_int()
     _lib.check(_lib.lib().cnf_solve_kernel_time(icnf.handle(), 0, C.byref(k_mean_us), C.byref(k_launches)), icnf.handle())
+    # beside it, outside the timed region: the same K steps one at a time (each call returns when its solve has finished)
+    one_at_a_time = None
+    if args.depth > 1 and world == 1:
+        t1 = time.perf_counter()
+        nf1 = 0
+        for _ in range(args.steps):
+            st1, _ = step()
+            nf1 += st1["nf"]
+        sync()
+        e1 = time.perf_counter() - t1
+        one_at_a_time = {"value": nf1 / e1, "ms_per_step": e1 / args.steps * 1e3}
     loss = cnf.loss_from_sums(icnf, mode, sums)
 
     ranks_seen, per_rank_ms, allreduce_us = 1, [elapsed / args.steps * 1e3], None
@@ -379,7 +391,7 @@ def run_rank(args):
             "per_rank_ms_per_step": per_rank_ms, "allreduce_us": allreduce_us,
             "sample_evals_per_s": nf_all / elapsed * B,
             "nf_per_solve": st["nf"], "naccept": st["naccept"], "nreject": st["nreject"],
-            "launches_per_solve": st["launches"], "steps_in_flight": args.depth, "loss": loss,
+            "launches_per_solve": st["launches"], "steps_in_flight": args.depth, "one_at_a_time": one_at_a_time, "loss": loss,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -112,3 +112,8 @@ def post(cfg, fsol, train):
 
 def threads():
     return lib().oc_threads()
+
+
+def set_threads(n):
+    """OpenMP threads of the following calls (the runtime may have been sized by another library of the process)."""
+    lib().oc_set_threads(int(n))

@@ -210,6 +210,8 @@ static size_t scratch_floats(const oc_net* net) {
     return (size_t)(2 * sumdim(net) + 2 * maxdim(net)) * NB;
 }
 
+/* threads of the following parallel regions (bench.py: the cores the process may run on, not the host's count) */
+void oc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 int oc_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
