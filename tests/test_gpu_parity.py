@@ -1223,7 +1223,26 @@ def test_loss_allreduce_through_the_c_abi_on_real_rccl():
     assert (ic2.last_stats["naccept"], ic2.last_stats["nreject"]) == (ref_st["naccept"], ref_st["nreject"])
     assert_parity(got.cpu().numpy(), ref.cpu().numpy(), "RCCL lock-step, 1 rank", rtol=1e-5)
     comm.lockstep(ic2, enable=False)
-    comm.close(); icnf.close(); ic2.close()
+    # bench.py's loop on the real RCCL: every step submitted, its all-reduce enqueued behind it on the same stream,
+    # collected one step later -- the collective sits between two one-launch solves of the headline shape
+    cfg3, _, _ = O.baseline_cfg(3)
+    rng = np.random.default_rng(12)
+    flat3 = O.glorot_params(cfg3.net, rng, np.float32, 0.1)
+    ic3 = make_icnf(cnf, cfg3, sol_kwargs=dict(reltol=3.45e-4, abstol=1.19e-7))
+    xs3, eps3 = _dev(rng.standard_normal((cfg3.nvars, 8192))), _dev(rng.standard_normal((cfg3.n_in, 8192)))
+    _, _, want = cnf.inference(ic3, cnf.TrainMode(), xs3, flat3, {}, eps=eps3, with_sums=True)
+    want = want.clone()
+    pend = []
+    for _ in range(6):
+        _, _, local = cnf.inference_submit(ic3, cnf.TrainMode(), xs3, flat3, {}, eps=eps3, with_sums=True)
+        pend.append(comm.allreduce_sums(ic3, local))
+        if len(pend) > 2:
+            cnf.inference_collect(ic3)
+            assert torch.equal(pend.pop(0), want)
+    while pend:
+        cnf.inference_collect(ic3)
+        assert torch.equal(pend.pop(0), want)
+    comm.close(); icnf.close(); ic2.close(); ic3.close()
 
 
 # ---------------------------------------------------------------------------------------
