@@ -340,6 +340,29 @@ def test_explicit_mfma_request_fails_loudly_when_unsupported():
     assert e.value.status == _lib.ERR_UNSUPPORTED
 
 
+def test_bench_line_on_this_gpu():
+    """bench.py end to end on the GPU in a child process, as the driver runs it (N = 1): one JSON line with BASELINE.json's
+    metric, the roofline and CPU-baseline objects, the submitted steps and the one-at-a-time figure beside them."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert base["metric"].startswith(d["metric"]) and d["unit"] == "RHS-evals/s" and d["n_gpus"] == 1
+    assert d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 1e4 and abs(d["value"] - d["nf_per_solve"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0.0 < rf["frac"] <= 1.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-9 and rf["launch_us"] * 1e-3 <= d["ms_per_step"] * 1.05
+    if _one_launch_expected():
+        assert d["launches_per_solve"] == 1 and d["steps_in_flight"] == 2
+        assert d["one_at_a_time"]["value"] > 1e4 and d["one_at_a_time"]["ms_per_step"] >= 0.9 * d["ms_per_step"]
+
+
 def test_rhs_work_model():
     cfg, B, _ = O.baseline_cfg(3)
     icnf = make_icnf(cnf, cfg)
