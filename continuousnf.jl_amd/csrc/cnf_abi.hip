@@ -818,7 +818,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         init->h = init->tdir * hh;
     }
     const bool hairer = opts->adaptive && opts->dt == 0.f;
-    // The whole solve in one cooperative launch where the handle and the batch allow it (k_solve3b): the weights and the
+    // The whole solve in ONE launch where the handle and the batch allow it (k_solve3b / k_solve3jb): the weights and the
     // Runge-Kutta rows stay on the CUs for all attempts, the workgroups exchange two floats per attempt.
     if (use_mfma && !lockstep && !h->no_persist) {
         // one such kernel at a time in this process: two of them would each hold CUs the other is waiting for.  Launches

@@ -3,6 +3,8 @@ src/icnf.jl:318-350 (out-of-place) and :352-382 (in-place) for
 ``ICNF{T, <:HIPMatrixMode}``.  One call = one fused launch over the whole batch."""
 from __future__ import annotations
 
+import numpy as np
+
 from . import _lib
 from .layers import CondLayer
 from .base_icnf import (ICNF, _KERNEL, _as_colmajor, _empty_like, _mode_id, _stream,
@@ -41,9 +43,22 @@ def augmented_f(*args):
             raise ValueError("eps must have one column per sample")
         if (eb.torch is None) != (ub.torch is None):
             raise ValueError("u and eps must both be host arrays or both be GPU tensors")
-    out = _empty_like(ub, D, B)
     l, h = _lib.lib(), icnf.handle()
     k = _KERNEL[icnf.compute_mode.kernel]
+    if du is not None:
+        if tuple(du.shape) != (D, B):
+            raise ValueError(f"du has shape {tuple(du.shape)}, expected {(D, B)}")
+        # the in-place form writes where the caller's du is, when du is laid out as the reference keeps it (column-major
+        # D x B: a sample's rows contiguous) -- no temporary, no copy; any other layout goes through one
+        if ub.torch is not None and isinstance(du, ub.torch.Tensor) and du.is_cuda and du.dtype == ub.torch.float32 \
+                and du.device == ub.arr.device and du.t().is_contiguous() and du.data_ptr() != ub.ptr:
+            _lib.check(l.cnf_rhs(h, m, k, ub.ptr, eb.ptr if eb else None, du.data_ptr(), B, _stream(ub)), h)
+            return None
+        if ub.torch is None and isinstance(du, np.ndarray) and du.dtype == np.float32 and du.flags.f_contiguous \
+                and du.flags.writeable and not np.shares_memory(du, ub.arr):
+            _lib.check(l.cnf_rhs_host(h, m, k, ub.ptr, eb.ptr if eb else None, du.ctypes.data, B), h)
+            return None
+    out = _empty_like(ub, D, B)
     if ub.torch is not None:
         _lib.check(l.cnf_rhs(h, m, k, ub.ptr, eb.ptr if eb else None, out.ptr, B, _stream(ub)), h)
     else:
@@ -51,8 +66,6 @@ def augmented_f(*args):
     res = out.view()
     if du is None:
         return res
-    if tuple(du.shape) != (D, B):
-        raise ValueError(f"du has shape {tuple(du.shape)}, expected {(D, B)}")
     if ub.torch is not None:
         du.copy_(res)
     else:

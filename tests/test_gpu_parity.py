@@ -75,6 +75,16 @@ def test_rhs_inplace_form(kernel):
     r = cnf.augmented_f(du, u, g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, eps)   # icnf.jl:352-382
     assert r is None
     assert_parity(du.cpu().numpy(), g["du_train_vjp"], "in-place", trace_row=cfg.n_in)
+    # du laid out as the reference keeps it (column-major D x B): written in place, no temporary -- device and host
+    D, B = u.shape
+    ucm, ecm = u.t().contiguous().t(), eps.t().contiguous().t()
+    ducm = torch.full((B, D), float("nan"), device=u.device).t()
+    assert cnf.augmented_f(ducm, ucm, g["flat"], 0.0, icnf, cnf.TrainMode(), icnf.nn, {}, ecm) is None
+    assert torch.equal(ducm, du)
+    duh = np.full((D, B), np.nan, dtype=np.float32, order="F")
+    assert cnf.augmented_f(duh, np.asfortranarray(g["u_train"], dtype=np.float32), g["flat"], 0.0, icnf, cnf.TrainMode(),
+                           icnf.nn, {}, np.asfortranarray(g["eps"], dtype=np.float32)) is None
+    assert np.array_equal(duh, du.cpu().numpy())
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
