@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=8192, help="columns per GPU")
     ap.add_argument("--fixed-dt", type=float, default=0.0, help="use fixed steps instead of adaptive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not start the rocprofv3 child passes that measure roofline.traffic")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2, 3],
                     help="steps in flight: 2 = each step is submitted while the one before it runs (default); 1 = one at a time")
     return ap.parse_args()
@@ -126,6 +127,40 @@ def cpu_baseline(B, flat, xs, eps, kw, budget_s=9.0):
             "sample": f"{n} adaptive Tsit5 solves of the same workload (B={B}, nf={st['nf']} each); restatement "
                       f"of the reference path (the Julia package cannot run here)", "seconds": el}
     return (blas, port) if blas["value"] >= port["value"] else (port, blas)
+
+
+def measure_traffic_live(kernel_substr, timeout_s=150):
+    """HBM bytes per launch of the headline kernel, measured NOW: two child runs of rocprofv3 (--pmc FETCH_SIZE, then
+    --pmc WRITE_SIZE: they cannot share a pass; each with --kernel-trace only) over tools/prof_rhs.py bench -- adaptive
+    solves of exactly this file's inputs --, combined as MI355X_MICROARCH.md's HBM section prescribes for gfx950
+    (2 x FETCH_SIZE KiB + WRITE_SIZE KiB).  bench.py cannot profile itself; the children are ordinary processes started
+    after the timed region.  Returns (bytes per launch, launches averaged) or (None, reason)."""
+    import csv, glob, shutil, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="cnf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", HIP_FORCE_DEV_KERNARG="1")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.join(ROOT, "tools", "prof_rhs.py"), "bench", "8"]
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                 if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter]
+            if not v:
+                return None, f"no {counter} rows for {kernel_substr}"
+            vals[counter] = (sum(v) / len(v), len(v))
+    except Exception as e:                                     # (a timeout, a parse error: the committed figure is used instead)
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return 2.0 * vals["FETCH_SIZE"][0] * 1024.0 + vals["WRITE_SIZE"][0] * 1024.0, min(vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1])
 
 
 def run_rank(args):
@@ -346,11 +381,23 @@ def run_rank(args):
         # REPLAYED from the committed summary of tools/collect_profiles.sh, and says so.
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, PMC_FILE)
-        if kernel_used == _lib.KERNEL_MFMA and os.path.exists(pmc) and B == 8192:
+        one_launch = "k_solve3b" in kname
+        if kernel_used == _lib.KERNEL_MFMA and B == 8192 and one_launch and world == 1 and not args.no_pmc:
+            # measured in THIS run (two rocprofv3 child passes over the same solves, after the timed region)
+            live, info = measure_traffic_live("k_solve3b<false")
+            if live is not None:
+                traffic = live
+                traffic_source = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over {info} launches of "
+                                  f"the same solves (tools/prof_rhs.py bench), 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch")
+            else:
+                traffic_source = f"live measurement unavailable ({info})"
+        if traffic is None and kernel_used == _lib.KERNEL_MFMA and os.path.exists(pmc) and B == 8192:
+            live_note = traffic_source
             rec = json.load(open(pmc))
             traffic = rec.get("hbm_bytes_per_launch")
             traffic_source = (f"{PMC_FILE} (rocprofv3 --pmc passes of tools/collect_profiles.sh over launches of "
-                              f"'{rec.get('kernel', '?')}'; built from commit {rec.get('commit', '?')}); not measured in this run")
+                              f"'{rec.get('kernel', '?')}'; built from commit {rec.get('commit', '?')}); not measured in this run"
+                              + (f" [{live_note}]" if live_note else ""))
             if ("k_solve3b" in rec.get("kernel", "")) != ("k_solve3b" in kname):
                 traffic, traffic_source = None, None        # the committed counters are of the other driver's kernel
         tf = units * fl.value / per_launch_s / 1e12
