@@ -1168,6 +1168,26 @@ def test_config4_full_batch_on_one_gpu():
     _, ref_lp, _, _ = O.inference(cfg, flat.astype(np.float64), xs[:, idx].astype(np.float64),
                                   eps[:, idx].astype(np.float64), True, dt=1 / 8, adaptive=False)
     assert_parity(logpx[torch.from_numpy(idx).cuda()].cpu().numpy(), ref_lp, "cfg4 full batch, sampled columns")
+    # the sharded leg of BASELINE config 4 on this one GPU: eight ranks' column blocks (parallel.shard_range), each solved
+    # as its own 8192-column one-launch solve (what each rank of an 8-GPU node runs), the 5-float sums added as the
+    # all-reduce adds them: the columns equal the unsharded solve's bit for bit (fixed dt: columns do not interact) and the
+    # loss of the summed sums is the unsharded loss
+    from continuousnf.jl_amd.parallel import shard_range
+    xd, ed = _dev(xs), _dev(eps)
+    tot = torch.zeros(5, device="cuda", dtype=torch.float64)
+    for r in range(8):
+        lo, hi = shard_range(B, 8, r)
+        assert hi - lo == 8192
+        lp_r, _, sums_r = cnf.inference(ic, cnf.TrainMode(), xd[:, lo:hi].contiguous(), flat, {}, eps=ed[:, lo:hi].contiguous(),
+                                        with_sums=True)
+        if _one_launch_expected():
+            assert ic.last_stats["launches"] == 1, ic.last_stats
+        assert torch.equal(lp_r, logpx[lo:hi]), (r, float((lp_r - logpx[lo:hi]).abs().max()))
+        tot += sums_r.double()
+    assert float(tot[4]) == B
+    loss_sharded = float(cnf.loss_from_sums(ic, cnf.TrainMode(), tot.float()))
+    loss_whole = float(cnf.loss_from_sums(ic, cnf.TrainMode(), sums))
+    assert abs(loss_sharded - loss_whole) <= 2e-6 * abs(loss_whole), (loss_sharded, loss_whole)
     kw = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
     ica = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=kw)
     lp_all, _ = cnf.inference(ica, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
