@@ -1568,12 +1568,13 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     const bool vjp_ok = p.variant == 2 && !p.ly.jvp;
     const bool jvp = (p.shape3 && p.ly.jvp) || (vjp_ok && !p.ly.norm_j && !dump);
     if (dump && !vjp_ok) return CNF_ERR_UNSUPPORTED;       // recording (gradient path): the VJP kernel only
-    if (off || fp32_only || step_v1() || !train || p.cond || !p.d_img3b || !(jvp || vjp_ok))
+    if (off || fp32_only || step_v1() || !train || !p.d_img3b || !(jvp || vjp_ok))
         return CNF_ERR_UNSUPPORTED;
+    if (p.cond && dump) return CNF_ERR_UNSUPPORTED;         // (conditional recording solves: k_mfma's step launches)
     // CNF_PIPE=1: k_solve3p, the interleaved schedule with the SIMD partners in complementary roles (cnf_step3p.hip) instead
     // of k_solve3b.  Parity-tested; measured SLOWER (48.7 against 33.2 us per attempt), so it is opt-in.
     static const bool pipe = [] { const char* e = getenv("CNF_PIPE"); return e && e[0] == '1'; }();
-    const bool use_p = pipe && !jvp;
+    const bool use_p = pipe && !jvp && !p.cond;
     const int ntile = (B + 31) / 32;
     const int resident = use_p ? step3p_solve_resident(dump != nullptr, device) : step3b_solve_resident(jvp, dump != nullptr, device);
     if (ntile < 1 || resident < 1) return CNF_ERR_UNSUPPORTED;
@@ -1603,6 +1604,7 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     }
     if (K1) { a.K1[0] = K1[0]; a.K1[1] = K1[1]; }
     a.mirror = mirror; a.seq = seq;
+    a.cond = p.cond; a.cbs = p.cbs;                          // conditional models: the per-sample first-layer bias rows
     a.dump = dump; a.dump_stride = dump_stride; a.dump_step_stride = dump_step_stride; a.dump_cap = dump_cap; a.hs_out = hs_out;
     sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
     if (use_p) return step3p_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, sv, device);

@@ -1241,6 +1241,7 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
             redw[2 * 32 * 8] = s3_dot4(tj, tj);
         };
 
+        constexpr bool S3B_COND = false;                   // (conditional models: k_mfma's step launches, or the one-launch solve)
 #include "cnf_step3jb_eval.inc"
         if (single) {
             float* out = (single == 1 ? a.du : a.Ks0) + (size_t)(tile * 32 + 16 * hf + s) * D;
@@ -1585,6 +1586,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
         S3T(21);
 
         constexpr bool S3B_RECORDS = false;                // (recording launches stay on k_mfma)
+        constexpr bool S3B_COND = false;                   // (conditional models: k_mfma's step launches, or the one-launch solve)
         float* const dmpw = nullptr; const size_t dmp_stride = 0;
         (void)dmpw; (void)dmp_stride;
 #include "cnf_step3b_eval.inc"
@@ -1720,7 +1722,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 // ---------------------------------------------------------------------------------------------------------------
 // RECORD (gradient path): every attempt files u_n and its stage states U_2..U_6 (z rows) in the trajectory slot of step
 // `naccept` (a.dump, as the recording launches of k_mfma do), its signed step size in a.hs_out.
-template <bool RECORD, bool MULTI>
+template <bool RECORD, bool MULTI, bool COND>
 __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __restrict__ imgb, int n_in, int norm_z,
                                                     int norm_j, const S3Tab tab, Solve3Args sv) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1928,6 +1930,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
     const size_t dmp_stride = a.dump_stride;
     auto evals = [&]() {
         constexpr bool S3B_RECORDS = RECORD;
+        constexpr bool S3B_COND = COND;
 #include "cnf_step3b_eval.inc"
     };
     // (x / sk)^2 onto acc, sk = atol + rtol |u|: the expressions of the single-evaluation launches, digit for digit
@@ -2226,7 +2229,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
 //   sample that is 2 D + n_in floats read and 2 D written (45 MB at B = 65 536: microseconds), against the weight stream,
 //   prologue and launch of a step kernel per attempt that it replaces.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool MULTI>
+template <bool MULTI, bool COND>
 __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __restrict__ imgb, int n_in, int norm_z,
                                                      int norm_j, const S3Tab tab, Solve3Args sv) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2418,6 +2421,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         redw[2 * 32 * 8] = s3_dot4(tj, tj);
     };
     auto evals = [&]() {
+        constexpr bool S3B_COND = COND;
 #include "cnf_step3jb_eval.inc"
     };
     auto add_norm = [&](float& acc, float u, float x) {
@@ -2743,10 +2747,12 @@ void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStre
     hipLaunchKernelGGL(k_pack_step3b, dim3((NT + 255) / 256), dim3(256), 0, s, nd, d_params, (char*)d_imgb);
 }
 // Function attributes and occupancy belong to a (function, device) pair: kept per device, set on first use there.
-static const void* solve3_fn(bool jvp, bool record, bool multi = false) {
-    if (jvp) return multi ? (const void*)k_solve3jb<true> : (const void*)k_solve3jb<false>;
-    if (record) return (const void*)k_solve3b<true, false>;
-    return multi ? (const void*)k_solve3b<false, true> : (const void*)k_solve3b<false, false>;
+static const void* solve3_fn(bool jvp, bool record, bool multi = false, bool cond = false) {
+    if (jvp) return cond ? (multi ? (const void*)k_solve3jb<true, true> : (const void*)k_solve3jb<false, true>)
+                         : (multi ? (const void*)k_solve3jb<true, false> : (const void*)k_solve3jb<false, false>);
+    if (record) return (const void*)k_solve3b<true, false, false>;
+    return cond ? (multi ? (const void*)k_solve3b<false, true, true> : (const void*)k_solve3b<false, false, true>)
+                : (multi ? (const void*)k_solve3b<false, true, false> : (const void*)k_solve3b<false, false, false>);
 }
 static size_t solve3_shm(bool jvp) { return jvp ? (size_t)s3b::TOTAL_BYTES : (size_t)s3v::TOTAL_BYTES; }
 int step3b_solve_resident(bool jvp, bool record, int device) {
@@ -2766,6 +2772,8 @@ int step3b_solve_resident(bool jvp, bool record, int device) {
         if (hipGetDevice(&cur) == hipSuccess && (cur == device || hipSetDevice(device) == hipSuccess)) {
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess &&
                 hipFuncSetAttribute(fn_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess &&
+                (record || (hipFuncSetAttribute(solve3_fn(jvp, false, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess &&
+                            hipFuncSetAttribute(solve3_fn(jvp, false, true, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess)) &&
                 hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, shm) == hipSuccess && per_cu >= 1 && n_cu >= 1)
                 // (148 KB of LDS per workgroup: one per CU whatever the API says about registers -- it is known to report
@@ -2794,7 +2802,9 @@ cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, 
     void* args[] = {&a_, &img, &n_in, &norm_z, &norm_j, &tab, &sv};
     const bool multi = (a.B + 31) / 32 > grid;             // several tiles per workgroup: the state lives in a.U / a.K1
     if (multi && (record || !a.K1[0] || !a.K1[1])) return CNF_ERR_UNSUPPORTED;
-    if (hipLaunchKernel(solve3_fn(jvp, record, multi), dim3(grid), dim3(512), args, solve3_shm(jvp), s) != hipSuccess) {
+    const bool cond = a.cond != nullptr;                   // conditional model: per-sample first-layer bias rows
+    if (cond && record) return CNF_ERR_UNSUPPORTED;
+    if (hipLaunchKernel(solve3_fn(jvp, record, multi, cond), dim3(grid), dim3(512), args, solve3_shm(jvp), s) != hipSuccess) {
         (void)hipGetLastError();
         return CNF_ERR_UNSUPPORTED;
     }

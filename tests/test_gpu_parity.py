@@ -478,6 +478,42 @@ def test_conditional_models(kernel, dims, nvars, naugs):
         assert _lib.lib().cnf_rhs(ic.handle(), 1, 0, x.data_ptr(), x.data_ptr(), x.data_ptr() + 4, B, None) == _lib.ERR_NO_PARAMS
 
 
+def test_conditional_model_of_the_headline_shape_is_one_launch():
+    """CondRNODE / CondFFJORD with the headline network behind the conditioning columns ((32 + 5)-128-128-32): the
+    per-sample first-layer bias rows (cnf_set_cond) are read by the one-launch solve itself -- one tile and several tiles
+    per workgroup, VJP and JVP compute modes -- against the float64 oracle on sampled columns and the streamed / generic
+    kernels on the rest."""
+    dims, nvars, n_cond = (37, 128, 128, 32), 32, 5
+    net = O.Net(dims, (O.ACT_TANH,) * 3)
+    rng = np.random.default_rng(3705)
+    flat = O.glorot_params(net, rng, np.float32, 0.1)
+    layers = [cnf.Dense(i, o, "tanh") for i, o in zip(dims[:-1], dims[1:])]
+    f64 = lambda a: a.astype(np.float64)
+    for B in (1000, 8224):
+        xs = rng.standard_normal((nvars, B)).astype(np.float32)
+        ys = rng.standard_normal((n_cond, B)).astype(np.float32)
+        eps = rng.standard_normal((nvars, B)).astype(np.float32)
+        for tag, jvp in ((cnf.CondRNODE, False), (cnf.CondRNODE, True), (cnf.CondFFJORD, False)):
+            cm = cnf.HIPJacVecMatrixMode("mfma") if jvp else cnf.HIPVecJacMatrixMode("mfma")
+            kw = dict(adaptive=False, dt=1 / 8)
+            lam = dict(lambda1=1e-2, lambda2=1e-2) if tag is cnf.CondRNODE else {}
+            ic = cnf.construct(tag, cnf.Chain(*layers), nvars, 0, compute_mode=cm, sol_kwargs=kw, **lam)
+            logpx, (E, n, A) = cnf.inference(ic, cnf.TrainMode(), _dev(xs), _dev(ys), flat, {}, eps=_dev(eps))
+            if _one_launch_expected() and os.environ.get("CNF_PIPE") != "1":
+                assert ic.last_stats["launches"] <= 3, (B, jvp, ic.last_stats)
+            idx = rng.choice(B, 40, replace=False)
+            cfg = O.Cfg(net, nvars, 0, 1e-2 if lam else 0.0, 1e-2 if lam else 0.0, 0.0, jvp)
+            _, ref_lp, (rE, rn, rA), _ = O.inference(cfg, f64(flat), f64(xs[:, idx]), f64(eps[:, idx]), True, f64(ys[:, idx]),
+                                                      dt=1 / 8, adaptive=False)
+            ii = torch.from_numpy(idx).cuda()
+            assert_parity(logpx[ii].cpu().numpy(), ref_lp, f"cond headline logpx B={B} jvp={jvp}")
+            assert_parity(np.stack([E[ii].cpu().numpy(), n[ii].cpu().numpy()]), np.stack([rE, rn]), f"cond headline regs B={B} jvp={jvp}")
+            # a different ys changes the result
+            lp2, _ = cnf.inference(ic, cnf.TrainMode(), _dev(xs), _dev(ys + 1.0), flat, {}, eps=_dev(eps))
+            assert float((lp2 - logpx).abs().max()) > 1e-3
+            ic.close()
+
+
 def test_full_size_cfg5_properties():
     """BASELINE config 5 at full size (RNODE 64+64, MLP 128-384-128, B = 2048): weights stay in
     HBM/L2, exact trace in closed form.  Size-independent checks + sampled columns vs the oracle."""
@@ -718,7 +754,8 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for var, sel in (("CNF_PERSISTENT=0", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3 or "
-                                          "test_one_launch_solve or test_headline_kernels_strict or test_submitted_inferences"),
+                                          "test_one_launch_solve or test_headline_kernels_strict or test_submitted_inferences or "
+                                          "test_conditional_model_of_the_headline"),
                      ("CNF_SOLVE_POLL_LIMIT=1", "test_one_launch_solve_falls_back or test_submitted_inferences"),
                      ("CNF_PIPE=1", "test_headline_kernels_strict or test_adaptive_solve_vs_oracles and 3-mfma or "
                                     "test_loss_grad_headline or test_one_launch_solve_takes"),
