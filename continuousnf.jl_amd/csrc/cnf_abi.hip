@@ -1018,8 +1018,14 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             h_attempt = snap->h;
             rec->hs.clear(); rec->n = 0;
         }
-        for (long it = 0;; ++it) {
+        // Lock-step over an RCCL communicator: nothing of an attempt leaves the stream (step kernel, the reduction of the
+        // partials, the all-reduce of three floats, the controller), so FOUR attempts are enqueued per look at the state --
+        // every shard holds the same state bit for bit, sees `done` in the same attempt and enqueues the same number of
+        // collectives; attempts queued past the end find `done` and change nothing.
+        const int chunk = (lockstep && h->shard_comm && use_mfma && !rec) ? 4 : 1;
+        for (long it = 0;; it += chunk) {
             if (it >= (long)opts->maxiters) return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
+          for (int c = 0; c < chunk && it + c < (long)opts->maxiters; ++c) {
             float* dump = nullptr;
             if (rec) {                                   // stage states of the attempt from u_{seen_accept}
                 float* slot;
@@ -1041,6 +1047,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                 launch_controller(h->d_state, h->partials, 2, (float)n, st);
                 launches += 1;
             }
+          }
             HIPCHK(h, hipMemcpyAsync(snap, h->d_state, sizeof(StepState), hipMemcpyDeviceToHost, st));
             HIPCHK(h, hipStreamSynchronize(st));
             if (rec && snap->naccept > seen_accept) {
