@@ -95,6 +95,7 @@ _SIGNATURES = {
     "cnf_loss_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, _fp, C.c_void_p]),
     "cnf_set_shard_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cnf_set_step_trace": (C.c_int, [C.c_void_p, _fp, C.c_int]),
+    "cnf_grad_x": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_void_p]),
     "cnf_solve_fallbacks": (C.c_int, [C.c_void_p]),
     "cnf_selftest_split_product": (C.c_int, [_fp, _fp, _fp, C.c_int]),
 }

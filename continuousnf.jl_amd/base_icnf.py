@@ -635,7 +635,7 @@ def loss(icnf: ICNF, mode, xs, *args, eps=None):
     return loss_from_sums(icnf, mode, sums)
 
 
-def loss_and_grad(icnf: ICNF, mode, xs, *args, eps=None):
+def loss_and_grad(icnf: ICNF, mode, xs, *args, eps=None, with_x=False):
     """``(loss, d loss / d ps)``: the pair ``MLJModelInterface.fit`` gets from Enzyme on
     ``loss(icnf, TrainMode(), xs, ps, st)`` (src/exts/mlj_ext/core_icnf.jl:59-73, src/icnf.jl:481-490),
     here from the discrete adjoint of the solve (cnf_loss_grad).  The gradient has the layout of
@@ -673,6 +673,20 @@ def loss_and_grad(icnf: ICNF, mode, xs, *args, eps=None):
     hs = np.empty(max(n, 1), dtype=np.float32)
     l.cnf_grad_steps(h, hs.ctypes.data, n)
     icnf.last_steps = hs[:n]             # signed step sizes the gradient was taken through
+    if with_x:
+        # d loss / d xs (the reference's call tests differentiate the loss w.r.t. the data too: test/call_tests.jl,
+        # `diff2_loss`): the adjoint state at t0, left behind by the backward sweep (cnf_grad_x) -- nvars x B, where xs lives
+        if xb.torch is not None:
+            gx = xb.torch.empty(B * icnf.nvars, dtype=xb.torch.float32, device=xb.arr.device)
+            _lib.check(l.cnf_grad_x(h, gx.data_ptr(), B, _stream(xb)), h)
+            gx = gx.view(B, icnf.nvars).t()
+        else:
+            import torch
+            dev = torch.device("cuda", icnf.device)
+            gd = torch.empty(B * icnf.nvars, dtype=torch.float32, device=dev)
+            _lib.check(l.cnf_grad_x(h, gd.data_ptr(), B, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), h)
+            gx = gd.cpu().numpy().reshape(B, icnf.nvars).T
+        return float(val.value), grad, gx
     return float(val.value), grad
 
 

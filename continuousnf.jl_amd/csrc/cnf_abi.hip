@@ -106,6 +106,7 @@ struct cnf_ctx {
     float* g_part = nullptr;      // GRAD_MAX_KSPLIT x n_params
     float* g_grad = nullptr;      // n_params (host-pointer variant)
     std::vector<float> last_hs;   // signed step sizes of the last cnf_loss_grad solve
+    int grad_last_B = 0;          // batch of the last cnf_loss_grad call (g_lam holds its d loss / d u(t0))
     float* d_ys = nullptr;        // conditional models: copy of ys (n_cond x cond_B), kept for the weight gradient
     float* stage = nullptr;       // device staging area of the *_host entry points, owned by the handle, grown on demand
     size_t stage_cap = 0;         //   (floats): no allocation per call, nothing to free on an error path
@@ -1577,9 +1578,21 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
         }
     }
     HIPCHK(h, launch_grad_reduce(h->g_part, grad, (int)h->n_params, ksplit, st));
+    h->grad_last_B = B;                                    // (g_lam now holds d loss / d u(t0): cnf_grad_x)
     HIPCHK(h, hipStreamSynchronize(st));
     if ((s = cnf_loss_from_sums(h, mode, sums, loss_out)) != CNF_OK) return s;
     if (stats) *stats = sst;
+    return CNF_OK;
+}
+
+// d loss / d xs of the last cnf_loss_grad call: the adjoint state at t0 is d loss / d u(t0), and u0 = (xs; zeros) -- its first
+// nvars rows, [B][nvars] as xs is laid out.  (The backward sweep leaves it in g_lam; nothing is recomputed.)
+extern "C" cnf_status cnf_grad_x(cnf_handle h, float* gx, int B, void* stream) {
+    if (!h || !gx) return CNF_ERR_BAD_ARG;
+    if (B < 1 || B != h->grad_last_B || !h->g_lam) return fail(h, CNF_ERR_BAD_ARG, "cnf_grad_x: no gradient of a batch of this size has been computed");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy2DAsync(gx, (size_t)h->nd.nvars * sizeof(float), h->g_lam, (size_t)h->nd.n_in * sizeof(float),
+                               (size_t)h->nd.nvars * sizeof(float), (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return CNF_OK;
 }
 

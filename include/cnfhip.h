@@ -263,6 +263,11 @@ cnf_status cnf_loss_grad_host(cnf_handle h, const float* xs, const float* eps, i
 /* The signed sizes of the steps the last cnf_loss_grad on this handle accepted (the discrete map
  * it differentiated): writes min(n, cap) floats to hs (may be NULL) and returns n. */
 int cnf_grad_steps(cnf_handle h, float* hs, int cap);
+/* d loss / d xs of the last cnf_loss_grad call on this handle (the other gradient the reference's own call tests take
+ * besides the one w.r.t. ps: test/call_tests.jl, `diff2_loss`): gx is nvars x B, laid out as xs, DEVICE memory, written
+ * stream-ordered.  It is the adjoint state at t0 restricted to the data rows (u0 = vcat(xs, zeros), src/base_icnf.jl:
+ * 275-276): left behind by the backward sweep, nothing is recomputed.  B must be that call's batch size. */
+cnf_status cnf_grad_x(cnf_handle h, float* gx, int B, void* stream);
 
 /* ---- introspection --------------------------------------------------------------- */
 const char* cnf_status_string(cnf_status s);

@@ -198,4 +198,7 @@ def loss_and_grad(cfg: O.Cfg, flat, xs, eps, ys=None, dts=None, **solve_kw):
         lam = lam.copy()
         for i in range(6):
             lam[:n_in] += ws[i]
+    # lam is now d loss / d u(t0); u0 = (xs; zeros): its first nvars rows are d loss / d xs (what the reference's call
+    # tests differentiate besides ps: test/call_tests.jl `diff2_loss`)
+    st.grad_x = lam[:cfg.nvars].copy()
     return val, grad, st

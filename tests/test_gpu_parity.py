@@ -652,13 +652,18 @@ def _grad_case(cfg, B, seed, kernel, sol_kw, ora_kw, jvp=False, n_cond=0, scale=
     args = (ys, flat, {}) if n_cond else (flat, {})
     conv = (lambda a: a) if host else _dev
     cargs = tuple(conv(a) if isinstance(a, np.ndarray) and a is not flat else a for a in args)
-    val, grad = cnf.loss_and_grad(icnf, cnf.TrainMode(), conv(xs), *cargs, eps=conv(eps))
+    val, grad, gx = cnf.loss_and_grad(icnf, cnf.TrainMode(), conv(xs), *cargs, eps=conv(eps), with_x=True)
     grad = grad.cpu().numpy() if hasattr(grad, "cpu") else grad
+    gx = gx.cpu().numpy() if hasattr(gx, "cpu") else gx
     c64 = O.Cfg(net, cfg.nvars, cfg.naugs, cfg.lam1, cfg.lam2, cfg.lam3, use_jvp=jvp, tspan=cfg.tspan)
     if ora_kw == "replay":            # differentiate exactly the steps the device took
         ora_kw = dict(dts=[float(d) for d in icnf.last_steps])
     rval, rgrad, st = G.loss_and_grad(c64, flat.astype(np.float64), xs.astype(np.float64), eps.astype(np.float64),
                                       None if ys is None else ys.astype(np.float64), **ora_kw)
+    # the gradient w.r.t. the data (test/call_tests.jl differentiates the loss w.r.t. x as well as ps): the adjoint state at t0
+    if "dts" in ora_kw or not sol_kw.get("adaptive", True):        # (same discrete map on both sides)
+        assert gx.shape == xs.shape
+        _assert_grad(gx, st.grad_x, "d loss / d xs", rtol=2e-4)
     return val, grad, rval, rgrad, icnf.last_stats, st
 
 

@@ -121,6 +121,26 @@ def test_grad_matches_finite_differences():
         e[i] = 1e-6
         fd = (L(flat + e) - L(flat - e)) / 2e-6
         assert abs(fd - grad[i]) <= 1e-6 * max(1.0, abs(grad[i])), (i, fd, grad[i])
+    # the gradient w.r.t. the data (st.grad_x: the adjoint state at t0, rows of xs) against finite differences, for every
+    # case shape (augmented rows included: they are zeros in u0 and have no entry in grad_x)
+    for c in CASES:
+        cfg = O.Cfg(O.Net(c["dims"], c["acts"]), c["nvars"], c["naugs"], *c["lam"], use_jvp=c["jvp"], tspan=(0.0, 1.0))
+        flat = O.glorot_params(cfg.net, rng, np.float64, 0.2)
+        xs = rng.standard_normal((cfg.nvars, B))
+        eps = rng.standard_normal((cfg.n_in, B))
+        ys = rng.standard_normal((c["ncond"], B)) if c.get("ncond") else None
+        _, _, st = G.loss_and_grad(cfg, flat, xs, eps, ys, **kw)
+        assert st.grad_x.shape == xs.shape
+
+        def Lx(x):
+            _, logpx, regs, _ = O.inference(cfg, flat, x, eps, True, ys, **kw)
+            return O.loss(cfg, logpx, regs, True)
+        for _ in range(6):
+            i, b = rng.integers(cfg.nvars), rng.integers(B)
+            e = np.zeros_like(xs)
+            e[i, b] = 1e-6
+            fd = (Lx(xs + e) - Lx(xs - e)) / 2e-6
+            assert abs(fd - st.grad_x[i, b]) <= 1e-6 * max(1.0, abs(fd)), (c["dims"], i, b, fd, st.grad_x[i, b])
 
 
 def test_rhs_vjp_matches_autograd_on_baseline_shapes():
