@@ -172,6 +172,15 @@ class ICNF:
             _OPEN[id(self)] = weakref.ref(self)
         return self._handle
 
+    def __call__(self, xs, ps, st, *, eps=None):
+        """The Lux-layer form, src/base_icnf.jl:528-543: ``icnf(xs, ps, st)`` (conditional: ``icnf((xs, ys), ps, st)``)
+        = ``(first(inference(icnf, TrainMode(), xs[, ys], ps, st)), st)``."""
+        from .types import TrainMode
+        if self.cond:
+            x, ys = xs
+            return inference(self, TrainMode(), x, ys, ps, st, eps=eps)[0], st
+        return inference(self, TrainMode(), xs, ps, st, eps=eps)[0], st
+
     def close(self):
         if self._handle is not None:
             _lib.lib().cnf_destroy(self._handle)

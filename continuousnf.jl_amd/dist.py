@@ -47,10 +47,13 @@ def pdf(d: ICNFDist, A, *, eps=None):
     return lp.exp() if _is_torch(lp) else np.exp(lp)
 
 
-def rand(d: ICNFDist, n: int, *, z0=None, eps=None):
-    """``rand(d, n)`` (src/exts/dist_ext/core_icnf.jl:46-58): ``generate(d.m, d.mode, d.ps, d.st, n)``."""
+def rand(d: ICNFDist, n: int = None, *, z0=None, eps=None):
+    """``rand(d, n)`` (src/exts/dist_ext/core_icnf.jl:46-58): ``generate(d.m, d.mode, d.ps, d.st, n)``; ``rand(d)``: one
+    draw, as a vector of nvars entries."""
     if not isinstance(d.m, ICNF):
         raise NotImplementedError("Not Implemented")
+    if n is None:
+        return rand(d, 1, z0=z0, eps=eps)[:, 0]
     if isinstance(d, CondICNFDist):
         return generate(d.m, d.mode, d.ps, d.st, n, ys=d.ys[:, :n], z0=z0, eps=eps)
     return generate(d.m, d.mode, d.ps, d.st, n, z0=z0, eps=eps)

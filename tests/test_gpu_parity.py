@@ -514,6 +514,66 @@ def test_conditional_model_of_the_headline_shape_is_one_launch():
             ic.close()
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_call_matrix_of_the_reference(kernel):
+    """The loops of test/call_tests.jl:1-252 at its own sizes (nvars = 2, ndata = 4): model types x modes x augmentation and
+    steering x in-place flag x compute modes (here: the two HIP matrix modes), and for each the calls it makes --
+    inference, generate, loss, the Lux-layer call, (Cond)ICNFDist logpdf / pdf / rand(d) / rand(d, n), and the gradients
+    of the loss w.r.t. ps and w.r.t. the data.  The reference asserts `!isnothing`; here every result is finite as well,
+    and inference is compared with the float64 oracle."""
+    nvars, ndata = 2, 4
+    rng = np.random.default_rng(2024)
+    f64 = lambda a: None if a is None else a.astype(np.float64)
+    for mt in (cnf.RNODE, cnf.FFJORD, cnf.CondRNODE, cnf.CondFFJORD):
+        cond = mt in (cnf.CondRNODE, cnf.CondFFJORD)
+        for aug_steer in (False, True):
+            naugs = nvars if aug_steer else 0
+            n_in = nvars + naugs
+            n_cond = nvars if cond else 0
+            dims = (n_in + n_cond, 3 * n_in, n_in)
+            net = O.Net(dims, (O.ACT_TANH, O.ACT_TANH))
+            layers = [cnf.Dense(i, o, "tanh") for i, o in zip(dims[:-1], dims[1:])]
+            flat = O.glorot_params(net, rng, np.float32, 0.1)
+            r = rng.standard_normal((nvars, ndata)).astype(np.float32)
+            r2 = rng.standard_normal((nvars, ndata)).astype(np.float32) if cond else None
+            eps = rng.standard_normal((n_in, ndata)).astype(np.float32)
+            for inplace in (False, True):
+                for cm in (cnf.HIPVecJacMatrixMode(kernel), cnf.HIPJacVecMatrixMode(kernel)):
+                    jvp = isinstance(cm, cnf.HIPJacVecMatrixMode)
+                    lam = dict(lambda1=1e-2, lambda2=1e-2) if mt in (cnf.RNODE, cnf.CondRNODE) else {}
+                    icnf = cnf.construct(mt, cnf.Chain(*layers), nvars, naugs, compute_mode=cm, inplace=inplace,
+                                         steer_rate=1e-1 if aug_steer else 0.0, lambda3=1e-2 if aug_steer else 0.0,
+                                         sol_kwargs=dict(adaptive=False, dt=1 / 8), **lam)
+                    for omode in (cnf.TrainMode(), cnf.TestMode()):
+                        train = isinstance(omode, cnf.TrainMode)
+                        if not _supported(icnf, omode, ndata):
+                            continue
+                        args = (r2, flat, {}) if cond else (flat, {})
+                        # (steering draws the end time from icnf.rng in TrainMode: fixed here so that the oracle runs the same span)
+                        icnf.steer_rate = 0.0
+                        logpx, regs = cnf.inference(icnf, omode, r, *args, eps=eps if train else None)
+                        cfg = O.Cfg(net, nvars, naugs, lam.get("lambda1", 0.0), lam.get("lambda2", 0.0),
+                                    1e-2 if aug_steer else 0.0, jvp)
+                        _, ref_lp, _, _ = O.inference(cfg, f64(flat), f64(r), f64(eps) if train else None, train, f64(r2),
+                                                      dt=1 / 8, adaptive=False)
+                        assert_parity(logpx, ref_lp, f"call matrix {mt.__name__} aug={aug_steer} ip={inplace} jvp={jvp} train={train}")
+                        icnf.steer_rate = 1e-1 if aug_steer else 0.0
+                        assert np.isfinite(cnf.inference(icnf, omode, r, *args)[0]).all()
+                        g = cnf.generate(icnf, omode, flat, {}, ndata, ys=r2)
+                        assert g.shape == (nvars, ndata) and np.isfinite(g).all()
+                        assert np.isfinite(cnf.loss(icnf, omode, r, *args))
+                        out, st_ = icnf((r, r2), flat, {}) if cond else icnf(r, flat, {})
+                        assert np.isfinite(out).all() and st_ == {}
+                        d = cnf.CondICNFDist(icnf, omode, r2, flat, {}) if cond else cnf.ICNFDist(icnf, omode, flat, {})
+                        assert np.isfinite(cnf.logpdf(d, r)).all() and np.isfinite(cnf.pdf(d, r)).all()
+                        assert cnf.rand(d).shape == (nvars,) and cnf.rand(d, ndata).shape == (nvars, ndata)
+                        if train:            # (the gradients are TrainMode's, the mode the reference trains in)
+                            val, gps, gx = cnf.loss_and_grad(icnf, omode, r, *args, with_x=True)
+                            assert np.isfinite(val) and np.isfinite(gps).all() and gps.shape == flat.shape
+                            assert gx.shape == r.shape and np.isfinite(gx).all()
+                    icnf.close()
+
+
 def test_full_size_cfg5_properties():
     """BASELINE config 5 at full size (RNODE 64+64, MLP 128-384-128, B = 2048): weights stay in
     HBM/L2, exact trace in closed form.  Size-independent checks + sampled columns vs the oracle."""
