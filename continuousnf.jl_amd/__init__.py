@@ -52,6 +52,7 @@ from .layers import Chain, CondLayer, Dense, setup
 from .types import (FFJORD, RNODE, CondFFJORD, CondPlanar, CondRNODE, HIPJacVecMatrixMode,
                     HIPMatrixMode, HIPVecJacMatrixMode, Planar, TestMode, TrainMode)
 from . import mlj, parallel
-from .mlj import Adam, ICNFModel, Lion, fit, fitted_params, load_params, save_params, transform
+from .mlj import (Adam, CondICNFModel, ICNFModel, Lion, Machine, fit, fit_, fitted_params, load_params, machine, save_params,
+                  transform)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

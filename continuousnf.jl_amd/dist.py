@@ -3,7 +3,6 @@ log-density evaluation.  ``logpdf(d, A)`` is ``first(inference(d.m, d.mode, A, d
 (core_icnf.jl:27)."""
 from __future__ import annotations
 
-from dataclasses import dataclass
 from typing import Any
 
 import numpy as np
@@ -11,22 +10,30 @@ import numpy as np
 from .base_icnf import ICNF, _is_torch, generate, inference
 
 
-@dataclass
+def _from_machine(m):
+    """``(icnf, ps, st)`` of a fitted machine (core_icnf.jl:8-11: ``fitted_params(mach)``, ``mach.model.m``)."""
+    if m.fitresult is None:
+        raise ValueError("the machine has not been fitted")
+    ps, st = m.fitresult
+    return m.model.m, ps, st
+
+
 class ICNFDist:
-    m: ICNF
-    mode: Any
-    ps: Any
-    st: Any = None
+    """``ICNFDist(icnf, mode, ps, st)`` or, from a fitted machine, ``ICNFDist(mach, mode)`` (core_icnf.jl:1-11)."""
+
+    def __init__(self, m, mode, ps=None, st=None):
+        if not isinstance(m, ICNF) and hasattr(m, "fitresult"):
+            m, ps, st = _from_machine(m)
+        self.m, self.mode, self.ps, self.st = m, mode, ps, st
 
 
-@dataclass
 class CondICNFDist:
-    """src/exts/dist_ext/core_cond_icnf.jl:1-7."""
-    m: ICNF
-    mode: Any
-    ys: Any
-    ps: Any
-    st: Any = None
+    """src/exts/dist_ext/core_cond_icnf.jl:1-16: ``CondICNFDist(icnf, mode, ys, ps, st)`` / ``CondICNFDist(mach, mode, ys)``."""
+
+    def __init__(self, m, mode, ys, ps=None, st=None):
+        if not isinstance(m, ICNF) and hasattr(m, "fitresult"):
+            m, ps, st = _from_machine(m)
+        self.m, self.mode, self.ys, self.ps, self.st = m, mode, ys, ps, st
 
 
 def logpdf(d, A, *, eps=None):

@@ -123,8 +123,13 @@ def fit(model: ICNFModel, verbosity: int, X, ys=None):
     return (ps.cpu().numpy(), st), None, report
 
 
-def transform(model: ICNFModel, fitresult, Xnew, ys=None):
-    """core_icnf.jl:96-123: ``logp_x`` of every row of ``Xnew`` in TestMode (exact trace)."""
+def transform(model, fitresult, Xnew=None, ys=None):
+    """core_icnf.jl:96-123: ``logp_x`` of every row of ``Xnew`` in TestMode (exact trace).  ``transform(mach, Xnew)`` /
+    ``transform(mach, (Xnew, Ynew))`` for a fitted ``Machine``."""
+    if isinstance(model, Machine):
+        data = fitresult
+        Xn, Yn = data if isinstance(data, tuple) else (data, None)
+        return transform(model.model, model.fitresult, Xn, Yn)
     icnf = model.m
     ps, st = fitresult
     x = _device_matrix(icnf, Xnew)
@@ -137,10 +142,37 @@ def transform(model: ICNFModel, fitresult, Xnew, ys=None):
     return logpx.cpu().numpy()
 
 
-def fitted_params(_model, fitresult):
-    """src/exts/mlj_ext/core.jl:1-4."""
+def fitted_params(_model, fitresult=None):
+    """src/exts/mlj_ext/core.jl:1-4; ``fitted_params(mach)`` for a fitted ``Machine``."""
+    if isinstance(_model, Machine):
+        _model, fitresult = _model.model, _model.fitresult
     ps, st = fitresult
     return {"learned_parameters": ps, "states": st}
+
+
+CondICNFModel = ICNFModel            # src/exts/mlj_ext/core_cond_icnf.jl: the same fields; the data are (X, Y)
+
+
+class Machine:
+    """The little of ``MLJBase.machine`` the reference's fit tests use (test/fit_tests.jl:160-200): ``machine(model, X)``
+    or ``machine(model, (X, Y))`` for the conditional models, ``fit_(mach)`` (= ``fit!``), ``transform(mach, Xnew)``,
+    ``fitted_params(mach)``, and ``ICNFDist(mach, mode)`` / ``CondICNFDist(mach, mode, ys)`` (src/exts/dist_ext/
+    core_icnf.jl:8-11, core_cond_icnf.jl:9-16).  MLJ's tables and machine caches are not mirrored."""
+
+    def __init__(self, model: ICNFModel, data):
+        self.model = model
+        self.X, self.Y = (data if isinstance(data, tuple) else (data, None))
+        self.fitresult = None
+        self.report = None
+
+
+def machine(model: ICNFModel, data) -> Machine:
+    return Machine(model, data)
+
+
+def fit_(mach: Machine, verbosity: int = 0) -> Machine:
+    mach.fitresult, _cache, mach.report = fit(mach.model, verbosity, mach.X, mach.Y)
+    return mach
 
 
 # ---------------------------------------------------------------------------------------

@@ -1073,6 +1073,40 @@ def test_fit_transform_front_end():
         assert np.array_equal(cnf.load_params(os.path.join(d, "p.cnfp"), icnf), ps)
 
 
+def test_fit_matrix_of_the_reference():
+    """The loops of test/fit_tests.jl at its own sizes (nvars = 2, ndata = 4, n_epochs = 2, one Dense layer): model types x
+    augmentation and steering x in-place flag x compute modes; machine -> fit! -> transform -> fitted_params, and the
+    distributions built from the fitted machine in both modes.  The reference asserts `!isnothing`; here everything is
+    finite as well and the parameters have moved."""
+    nvars, ndata, n_epochs = 2, 4, 2
+    rng = np.random.default_rng(77)
+    for mt in (cnf.RNODE, cnf.FFJORD, cnf.CondRNODE, cnf.CondFFJORD):
+        cond = mt in (cnf.CondRNODE, cnf.CondFFJORD)
+        for aug_steer in (False, True):
+            naugs = nvars if aug_steer else 0
+            n_in = nvars + naugs
+            nn = cnf.Chain(cnf.Dense(n_in + (nvars if cond else 0), n_in, "tanh"))      # fit_tests.jl:89-131
+            df = rng.beta(2.0, 4.0, size=(ndata, nvars)).astype(np.float32)             # rows = observations (DataFrame)
+            df2 = rng.beta(4.0, 2.0, size=(ndata, nvars)).astype(np.float32)
+            for inplace in (False, True):
+                for cm in (cnf.HIPVecJacMatrixMode(), cnf.HIPJacVecMatrixMode()):
+                    kw = dict(steer_rate=1e-1, lambda3=1e-2) if aug_steer else {}
+                    icnf = cnf.construct(mt, nn, nvars, naugs, compute_mode=cm, inplace=inplace, rng=5, **kw)
+                    model = (cnf.CondICNFModel if cond else cnf.ICNFModel)(icnf, n_epochs=n_epochs)
+                    mach = cnf.machine(model, (df, df2) if cond else df)
+                    ps0, _ = cnf.setup(5, icnf.nn)
+                    assert cnf.fit_(mach) is mach and mach.report["stats"]["iterations"] == n_epochs
+                    lp = cnf.transform(mach, (df, df2) if cond else df)
+                    assert lp.shape == (ndata,) and np.isfinite(lp).all()
+                    fp = cnf.fitted_params(mach)
+                    assert np.isfinite(fp["learned_parameters"]).all() and fp["learned_parameters"].shape == ps0.shape
+                    assert np.abs(fp["learned_parameters"] - ps0).max() > 0        # Lion moved every parameter it saw a sign for
+                    for mode in (cnf.TrainMode(), cnf.TestMode()):
+                        d = cnf.CondICNFDist(mach, mode, df2.T) if cond else cnf.ICNFDist(mach, mode)
+                        assert np.isfinite(cnf.logpdf(d, df.T)).all()
+                    icnf.close()
+
+
 def test_loss_grad_tiny_batches():
     """One sample and 17 samples (one full + one nearly empty MFMA column tile)."""
     cfg, _, _ = O.baseline_cfg(3)
