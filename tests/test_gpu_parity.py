@@ -1073,6 +1073,32 @@ def test_fit_transform_front_end():
         assert np.array_equal(cnf.load_params(os.path.join(d, "p.cnfp"), icnf), ps)
 
 
+def test_instability_config_of_the_reference():
+    """test/instability_tests.jl:9-45: RNODE 8 + 8, one Dense(16 => 16, tanh), tspan (0, 13), steer_rate 0.1, lambda3 1e-2, 64
+    columns of rand(Float32): `loss(icnf, TrainMode(), r, ps, st)` at the package's default solver tolerances (the call
+    the reference type-checks with JET).  Finite here, and equal to the float64 oracle's loss at the solver tolerance when
+    the probes and the steered end time are pinned."""
+    nvars = naugs = 8
+    n_in, n = nvars + naugs, 64
+    nn = cnf.Chain(cnf.Dense(n_in, n_in, "tanh"))
+    icnf = cnf.construct(cnf.RNODE, nn, nvars, naugs, compute_mode=cnf.HIPVecJacMatrixMode(), tspan=(0.0, 13.0),
+                         steer_rate=1e-1, lambda3=1e-2, rng=3)
+    ps, st = cnf.setup(icnf.rng, icnf.nn)
+    r = np.random.default_rng(3).random((nvars, n), dtype=np.float32)
+    L = cnf.loss(icnf, cnf.TrainMode(), r, ps, st)
+    assert np.isfinite(L)
+    icnf.steer_rate = 0.0
+    eps = np.random.default_rng(4).standard_normal((n_in, n)).astype(np.float32)
+    L2 = cnf.loss(icnf, cnf.TrainMode(), r, ps, st, eps=eps)
+    net = O.Net((n_in, n_in), (O.ACT_TANH,))
+    cfg = O.Cfg(net, nvars, naugs, 1e-2, 1e-2, 1e-2, False, tspan=(0.0, 13.0))
+    _, lp, regs, _ = O.inference(cfg, ps.astype(np.float64), r.astype(np.float64), eps.astype(np.float64), True,
+                                 reltol=1e-9, abstol=1e-9)
+    ref = O.loss(cfg, lp, regs, True)
+    assert abs(L2 - ref) <= 5e-3 * max(1.0, abs(ref)), (L2, ref)
+    icnf.close()
+
+
 def test_fit_matrix_of_the_reference():
     """The loops of test/fit_tests.jl at its own sizes (nvars = 2, ndata = 4, n_epochs = 2, one Dense layer): model types x
     augmentation and steering x in-place flag x compute modes; machine -> fit! -> transform -> fitted_params, and the
