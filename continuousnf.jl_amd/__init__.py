@@ -48,7 +48,7 @@ from .base_icnf import (ICNF, ODEProblem, base_sol, construct, generate, generat
                         n_augment_input, steer_tspan)
 from .dist import CondICNFDist, ICNFDist, logpdf, pdf, rand
 from .icnf import augmented_f
-from .layers import Chain, CondLayer, Dense, setup
+from .layers import Chain, CondLayer, Dense, PlanarLayer, setup
 from .types import (FFJORD, RNODE, CondFFJORD, CondPlanar, CondRNODE, HIPJacVecMatrixMode,
                     HIPMatrixMode, HIPVecJacMatrixMode, Planar, TestMode, TrainMode)
 from . import mlj, parallel

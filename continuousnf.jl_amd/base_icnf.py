@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _lib
 from .layers import Chain
-from .types import (AbstractICNF, CondFFJORD, CondRNODE, FFJORD, RNODE, HIPMatrixMode, HIPVecJacMatrixMode,
+from .types import (AbstractICNF, CondFFJORD, CondPlanar, CondRNODE, FFJORD, RNODE, HIPMatrixMode, HIPVecJacMatrixMode,
                     Mode, TestMode, TrainMode, _OutOfScope)
 
 _KERNEL = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "mfma": _lib.KERNEL_MFMA}
@@ -199,6 +199,31 @@ class ICNF:
         """Upload ``ps`` (the ``p`` of augmented_f) unless it is the vector already resident."""
         h = self.handle()
         l = _lib.lib()
+        if self.nn.planar is not None:
+            # (u, w, b) -> the MLP layout the kernels see (layers.Chain.to_internal); keyed on the caller's object below
+            ps_ext = ps
+            if _is_torch(ps):
+                prev = self._params_id
+                if prev is not None and prev[0] == "t" and prev[1] is ps_ext and prev[2] == ps_ext._version:
+                    return
+                import torch
+                p = self.nn.to_internal(ps.detach().to(torch.float32)).contiguous()
+                if p.is_cuda:
+                    st = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+                    _lib.check(l.cnf_set_params(h, p.data_ptr(), p.numel(), st), h)
+                    torch.cuda.current_stream(p.device).synchronize()
+                else:
+                    _lib.check(l.cnf_set_params_host(h, p.data_ptr(), p.numel()), h)
+                self._params_id = ("t", ps_ext, ps_ext._version)
+            else:
+                p = np.ascontiguousarray(self.nn.to_internal(np.asarray(ps, dtype=np.float32)), dtype=np.float32)
+                key = ("n", p.tobytes())
+                if self._params_id is not None and self._params_id[0] == "n" and key == self._params_id:
+                    return
+                _lib.check(l.cnf_set_params_host(h, p.ctypes.data, p.size), h)
+                self._params_id = key
+            self._cond_id = None
+            return
         if _is_torch(ps):
             # identity of a tensor this object keeps alive (+ its in-place version counter): an address
             # can be handed to a new tensor by the caching allocator, an object held here cannot
@@ -318,9 +343,9 @@ def construct(aicnf, nn: Chain, nvars: int, naugmented: int = 0, *, data_type=np
     if not (isinstance(aicnf, type) and issubclass(aicnf, AbstractICNF)):
         raise TypeError("first argument must be a model tag such as RNODE or FFJORD")
     if issubclass(aicnf, _OutOfScope):
-        raise NotImplementedError(f"{aicnf.__name__}: only the MLP vector fields are built (planar layers are not)")
+        raise NotImplementedError(f"{aicnf.__name__}: not built")
     if cond is None:
-        cond = issubclass(aicnf, (CondRNODE, CondFFJORD))          # src/base_icnf.jl:14
+        cond = issubclass(aicnf, (CondRNODE, CondFFJORD, CondPlanar))          # src/base_icnf.jl:14
     if np.dtype(data_type) != np.float32:
         raise NotImplementedError("the HIP backend computes in Float32 (the reference default, base_icnf.jl:6)")
     if compute_mode is None:
@@ -667,7 +692,7 @@ def loss_and_grad(icnf: ICNF, mode, xs, *args, eps=None, with_x=False):
     stats = _lib.cnf_solve_stats()
     val = C.c_float()
     l, h = _lib.lib(), icnf.handle()
-    n_params = icnf.nn.n_params
+    n_params = icnf.nn.n_params_internal
     if xb.torch is not None:
         t = xb.torch
         grad = t.empty(n_params, dtype=t.float32, device=xb.arr.device)
@@ -682,6 +707,7 @@ def loss_and_grad(icnf: ICNF, mode, xs, *args, eps=None, with_x=False):
     hs = np.empty(max(n, 1), dtype=np.float32)
     l.cnf_grad_steps(h, hs.ctypes.data, n)
     icnf.last_steps = hs[:n]             # signed step sizes the gradient was taken through
+    grad = icnf.nn.grad_to_external(grad)  # (PlanarLayer: back to the (u, w, b) order; identity for Dense chains)
     if with_x:
         # d loss / d xs (the reference's call tests differentiate the loss w.r.t. the data too: test/call_tests.jl,
         # `diff2_loss`): the adjoint state at t0, left behind by the backward sweep (cnf_grad_x) -- nvars x B, where xs lives

@@ -25,14 +25,73 @@ class Dense:
             raise ValueError("Dense dims must be positive")
 
 
+@dataclass(frozen=True)
+class PlanarLayer:
+    """``PlanarLayer(nvars, activation; use_bias, n_cond)`` (src/layers/planar_layer.jl): ``u * act.(w' * z .+ b)`` -- a
+    rank-one field.  To the kernels it is a two-layer MLP ``(nvars + n_cond) -> 1 -> nvars`` with ``W1 = w'``, ``b1 = b``,
+    ``W2 = u``, identity output and a zero output bias that is not a parameter; ``Chain`` maps the Lux parameter order
+    ``(u, w, b)`` (planar_layer.jl:43-57) to that layout and gradients back."""
+    nvars: int
+    activation: str = "identity"
+    use_bias: bool = True
+    n_cond: int = 0
+
+    def __post_init__(self):
+        if self.activation not in _lib.ACT:
+            raise ValueError(f"unsupported activation {self.activation!r}; have {sorted(_lib.ACT)}")
+        if self.nvars < 1 or self.n_cond < 0:
+            raise ValueError("PlanarLayer sizes must be positive")
+
+
 class Chain:
-    def __init__(self, *layers: Dense):
+    def __init__(self, *layers):
         if not layers:
             raise ValueError("empty Chain")
+        self.planar = layers[0] if isinstance(layers[0], PlanarLayer) else None
+        if self.planar is not None:
+            if len(layers) != 1:
+                raise ValueError("a PlanarLayer stands alone in its Chain (as in the reference's tests)")
+            p = self.planar
+            layers = (Dense(p.nvars + p.n_cond, 1, p.activation), Dense(1, p.nvars, "identity"))
         for a, b in zip(layers[:-1], layers[1:]):
             if a.out_dims != b.in_dims:
                 raise ValueError(f"layer size mismatch: {a.out_dims} -> {b.in_dims}")
         self.layers = tuple(layers)
+
+    # ---- parameter layouts: `external` = what the caller holds (Lux order), `internal` = the MLP layout of the C ABI ----
+    @property
+    def n_params_internal(self):
+        return sum(l.in_dims * l.out_dims + l.out_dims for l in self.layers)
+
+    def to_internal(self, ps):
+        """external -> internal (identity for Dense chains).  numpy arrays and torch tensors."""
+        if self.planar is None:
+            return ps
+        p = self.planar
+        nw = p.nvars + p.n_cond
+        flat = ps.reshape(-1)
+        if flat.shape[0] != self.n_params:
+            raise ValueError(f"PlanarLayer has {self.n_params} parameters, got {flat.shape[0]}")
+        u, w = flat[:p.nvars], flat[p.nvars:p.nvars + nw]
+        if hasattr(flat, "new_zeros"):                       # torch
+            import torch
+            b = flat[p.nvars + nw:] if p.use_bias else flat.new_zeros(1)
+            return torch.cat([w, b, u, flat.new_zeros(p.nvars)])
+        b = flat[p.nvars + nw:] if p.use_bias else np.zeros(1, dtype=flat.dtype)
+        return np.concatenate([w, b, u, np.zeros(p.nvars, dtype=flat.dtype)])
+
+    def grad_to_external(self, g):
+        """gradient in the internal layout -> the caller's layout (the zero output bias has no entry)."""
+        if self.planar is None:
+            return g
+        p = self.planar
+        nw = p.nvars + p.n_cond
+        gw, gb, gu = g[:nw], g[nw:nw + 1], g[nw + 1:nw + 1 + p.nvars]
+        parts = [gu, gw] + ([gb] if p.use_bias else [])
+        if hasattr(g, "new_zeros"):
+            import torch
+            return torch.cat(parts)
+        return np.concatenate(parts)
 
     @property
     def dims(self):
@@ -44,9 +103,15 @@ class Chain:
 
     @property
     def n_params(self):
+        if self.planar is not None:                           # planar_layer.jl:59-61
+            p = self.planar
+            return p.nvars + (p.nvars + p.n_cond) + (1 if p.use_bias else 0)
         return sum(l.in_dims * l.out_dims + l.out_dims for l in self.layers)
 
     def __repr__(self):
+        if self.planar is not None:
+            p = self.planar
+            return f"Chain(PlanarLayer({p.nvars}, {p.activation}; n_cond = {p.n_cond}))"
         return "Chain(" + ", ".join(f"Dense({l.in_dims} => {l.out_dims}, {l.activation})" for l in self.layers) + ")"
 
 
@@ -56,6 +121,14 @@ def setup(rng, nn: Chain):
     ``bias`` -- and an empty state.  Glorot-uniform weights, zero biases."""
     if isinstance(rng, (int, np.integer)):
         rng = np.random.default_rng(int(rng))
+    if nn.planar is not None:                                 # planar_layer.jl:43-57: (u, w, b), Glorot-uniform vectors, zero bias
+        p = nn.planar
+        nw = p.nvars + p.n_cond
+        lim_u, lim_w = math.sqrt(6.0 / (2 * p.nvars)), math.sqrt(6.0 / (2 * nw))
+        parts = [rng.uniform(-lim_u, lim_u, size=p.nvars), rng.uniform(-lim_w, lim_w, size=nw)]
+        if p.use_bias:
+            parts.append(np.zeros(1))
+        return np.concatenate(parts).astype(np.float32), {}
     parts = []
     for l in nn.layers:
         lim = math.sqrt(6.0 / (l.in_dims + l.out_dims))

@@ -189,6 +189,8 @@ _MAGIC = b"CNFP"
 
 def save_params(path, icnf: ICNF, ps):
     import struct
+    if icnf.nn.planar is not None:
+        raise NotImplementedError("CNFP files describe Dense chains; keep a PlanarLayer's (u, w, b) vector as it is")
     ps = ps.detach().cpu().numpy() if hasattr(ps, "detach") else np.asarray(ps)
     ps = np.ascontiguousarray(ps, dtype="<f4")
     dims, acts = icnf.nn.dims, icnf.nn.acts

@@ -71,7 +71,7 @@ class _OutOfScope(AbstractICNF):
     pass
 
 
-class Planar(_OutOfScope):       # rank-1 planar field: not the MLP hot path
+class Planar(AbstractICNF):       # any field without the RNODE defaults; used with PlanarLayer (layers.py maps it onto the MLP kernels)
     pass
 
 
@@ -83,5 +83,5 @@ class CondFFJORD(AbstractICNF):
     pass
 
 
-class CondPlanar(_OutOfScope):
+class CondPlanar(AbstractICNF):
     pass

@@ -524,16 +524,27 @@ def test_call_matrix_of_the_reference(kernel):
     nvars, ndata = 2, 4
     rng = np.random.default_rng(2024)
     f64 = lambda a: None if a is None else a.astype(np.float64)
-    for mt in (cnf.RNODE, cnf.FFJORD, cnf.CondRNODE, cnf.CondFFJORD):
-        cond = mt in (cnf.CondRNODE, cnf.CondFFJORD)
+    for mt in (cnf.RNODE, cnf.FFJORD, cnf.Planar, cnf.CondRNODE, cnf.CondFFJORD, cnf.CondPlanar):
+        cond = mt in (cnf.CondRNODE, cnf.CondFFJORD, cnf.CondPlanar)
+        planar = mt in (cnf.Planar, cnf.CondPlanar)
         for aug_steer in (False, True):
             naugs = nvars if aug_steer else 0
             n_in = nvars + naugs
             n_cond = nvars if cond else 0
-            dims = (n_in + n_cond, 3 * n_in, n_in)
-            net = O.Net(dims, (O.ACT_TANH, O.ACT_TANH))
-            layers = [cnf.Dense(i, o, "tanh") for i, o in zip(dims[:-1], dims[1:])]
-            flat = O.glorot_params(net, rng, np.float32, 0.1)
+            if planar:               # Lux.Chain(PlanarLayer(n_in, tanh; n_cond)): the MLP (n_in + n_cond) -> 1 -> n_in to the kernels
+                chain = cnf.Chain(cnf.PlanarLayer(n_in, "tanh", n_cond=n_cond))
+                dims = chain.dims
+                net = O.Net(dims, (O.ACT_TANH, O.ACT_IDENTITY))
+                layers = None
+                flat_ext = cnf.setup(int(rng.integers(1 << 30)), chain)[0]
+                flat_int = chain.to_internal(flat_ext)
+            else:
+                dims = (n_in + n_cond, 3 * n_in, n_in)
+                net = O.Net(dims, (O.ACT_TANH, O.ACT_TANH))
+                layers = [cnf.Dense(i, o, "tanh") for i, o in zip(dims[:-1], dims[1:])]
+                chain = cnf.Chain(*layers)
+                flat_ext = flat_int = O.glorot_params(net, rng, np.float32, 0.1)
+            flat = flat_ext
             r = rng.standard_normal((nvars, ndata)).astype(np.float32)
             r2 = rng.standard_normal((nvars, ndata)).astype(np.float32) if cond else None
             eps = rng.standard_normal((n_in, ndata)).astype(np.float32)
@@ -541,7 +552,7 @@ def test_call_matrix_of_the_reference(kernel):
                 for cm in (cnf.HIPVecJacMatrixMode(kernel), cnf.HIPJacVecMatrixMode(kernel)):
                     jvp = isinstance(cm, cnf.HIPJacVecMatrixMode)
                     lam = dict(lambda1=1e-2, lambda2=1e-2) if mt in (cnf.RNODE, cnf.CondRNODE) else {}
-                    icnf = cnf.construct(mt, cnf.Chain(*layers), nvars, naugs, compute_mode=cm, inplace=inplace,
+                    icnf = cnf.construct(mt, chain, nvars, naugs, compute_mode=cm, inplace=inplace,
                                          steer_rate=1e-1 if aug_steer else 0.0, lambda3=1e-2 if aug_steer else 0.0,
                                          sol_kwargs=dict(adaptive=False, dt=1 / 8), **lam)
                     for omode in (cnf.TrainMode(), cnf.TestMode()):
@@ -554,7 +565,7 @@ def test_call_matrix_of_the_reference(kernel):
                         logpx, regs = cnf.inference(icnf, omode, r, *args, eps=eps if train else None)
                         cfg = O.Cfg(net, nvars, naugs, lam.get("lambda1", 0.0), lam.get("lambda2", 0.0),
                                     1e-2 if aug_steer else 0.0, jvp)
-                        _, ref_lp, _, _ = O.inference(cfg, f64(flat), f64(r), f64(eps) if train else None, train, f64(r2),
+                        _, ref_lp, _, _ = O.inference(cfg, f64(flat_int), f64(r), f64(eps) if train else None, train, f64(r2),
                                                       dt=1 / 8, adaptive=False)
                         assert_parity(logpx, ref_lp, f"call matrix {mt.__name__} aug={aug_steer} ip={inplace} jvp={jvp} train={train}")
                         icnf.steer_rate = 1e-1 if aug_steer else 0.0
@@ -571,6 +582,13 @@ def test_call_matrix_of_the_reference(kernel):
                             val, gps, gx = cnf.loss_and_grad(icnf, omode, r, *args, with_x=True)
                             assert np.isfinite(val) and np.isfinite(gps).all() and gps.shape == flat.shape
                             assert gx.shape == r.shape and np.isfinite(gx).all()
+                            if planar:           # the (u, w, b) gradient against the oracle's, mapped from the MLP layout
+                                from oracle import cnf_grad_oracle as G
+                                icnf.steer_rate = 0.0
+                                v2, g2 = cnf.loss_and_grad(icnf, omode, r, *args, eps=eps)
+                                rv, rg, _ = G.loss_and_grad(cfg, f64(flat_int), f64(r), f64(eps), f64(r2), adaptive=False, dt=1 / 8)
+                                assert abs(v2 - rv) <= 1e-5 * max(1.0, abs(rv))
+                                _assert_grad(g2, chain.grad_to_external(rg), f"planar gradient aug={aug_steer} jvp={jvp}", rtol=2e-4)
                     icnf.close()
 
 
@@ -1106,12 +1124,15 @@ def test_fit_matrix_of_the_reference():
     finite as well and the parameters have moved."""
     nvars, ndata, n_epochs = 2, 4, 2
     rng = np.random.default_rng(77)
-    for mt in (cnf.RNODE, cnf.FFJORD, cnf.CondRNODE, cnf.CondFFJORD):
-        cond = mt in (cnf.CondRNODE, cnf.CondFFJORD)
+    for mt in (cnf.RNODE, cnf.FFJORD, cnf.Planar, cnf.CondRNODE, cnf.CondFFJORD, cnf.CondPlanar):
+        cond = mt in (cnf.CondRNODE, cnf.CondFFJORD, cnf.CondPlanar)
         for aug_steer in (False, True):
             naugs = nvars if aug_steer else 0
             n_in = nvars + naugs
-            nn = cnf.Chain(cnf.Dense(n_in + (nvars if cond else 0), n_in, "tanh"))      # fit_tests.jl:89-131
+            if mt in (cnf.Planar, cnf.CondPlanar):                                      # fit_tests.jl:89-131
+                nn = cnf.Chain(cnf.PlanarLayer(n_in, "tanh", n_cond=nvars if cond else 0))
+            else:
+                nn = cnf.Chain(cnf.Dense(n_in + (nvars if cond else 0), n_in, "tanh"))
             df = rng.beta(2.0, 4.0, size=(ndata, nvars)).astype(np.float32)             # rows = observations (DataFrame)
             df2 = rng.beta(4.0, 2.0, size=(ndata, nvars)).astype(np.float32)
             for inplace in (False, True):

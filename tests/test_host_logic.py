@@ -25,13 +25,46 @@ def test_construct_defaults_follow_reference():
     assert (j.lambda1, j.lambda2, j.lambda3) == (0.5, 0.0, 2.0) and not j.NORM_J and j.NORM_Z_AUG
 
 
+def test_planar_layer_is_a_two_layer_mlp_with_the_lux_parameter_order():
+    """PlanarLayer (src/layers/planar_layer.jl): u * act.(w' z + b) = the MLP (nvars + n_cond) -> 1 -> nvars with W1 = w', b1 = b,
+    W2 = u, identity output, zero output bias; parameters in Lux order (u, w, b), gradients mapped back."""
+    for use_bias, n_cond in ((True, 0), (False, 0), (True, 3)):
+        nn = cnf.Chain(cnf.PlanarLayer(4, "tanh", use_bias=use_bias, n_cond=n_cond))
+        assert nn.dims == (4 + n_cond, 1, 4) and nn.n_params == 4 + 4 + n_cond + (1 if use_bias else 0)
+        ps, st = cnf.setup(0, nn)
+        assert ps.shape == (nn.n_params,) and st == {}
+        ps = np.arange(1, nn.n_params + 1, dtype=np.float32)
+        pi = nn.to_internal(ps)
+        nw = 4 + n_cond
+        assert pi.shape == (nn.n_params_internal,) == (nw + 1 + 4 + 4,)
+        assert np.array_equal(pi[:nw], ps[4:4 + nw]) and np.array_equal(pi[nw + 1:nw + 5], ps[:4]) and not pi[nw + 5:].any()
+        assert pi[nw] == (ps[-1] if use_bias else 0.0)
+        g = nn.grad_to_external(np.arange(100, 100 + pi.size, dtype=np.float32))
+        assert g.shape == ps.shape and np.array_equal(g[:4], 100 + nw + 1 + np.arange(4)) and np.array_equal(g[4:4 + nw], 100 + np.arange(nw))
+        # the field itself against the closed form, through the float64 oracle's MLP on the internal layout
+        from oracle import cnf_oracle as O
+        net = O.Net(nn.dims, (O.ACT_TANH, O.ACT_IDENTITY))
+        rg = np.random.default_rng(1)
+        z, yc = rg.standard_normal((4, 5)), (rg.standard_normal((n_cond, 5)) if n_cond else None)
+        u, w = 0.1 * ps[:4].astype(np.float64), 0.1 * ps[4:4 + nw].astype(np.float64)
+        b = 0.1 * float(ps[-1]) if use_bias else 0.0
+        zin = z if yc is None else np.vstack([z, yc])
+        want = np.outer(u, np.tanh(w @ zin + b))
+        out = O.mlp_forward(net, 0.1 * pi.astype(np.float64), z, yc)
+        got = out[0] if isinstance(out, tuple) else out
+        got = got[-1] if isinstance(got, list) else got
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    p = cnf.construct(cnf.Planar, cnf.Chain(cnf.PlanarLayer(2, "tanh")), 2)
+    assert (p.lambda1, p.lambda2) == (0, 0) and not p.cond
+    c = cnf.construct(cnf.CondPlanar, cnf.Chain(cnf.PlanarLayer(2, "tanh", n_cond=2)), 2)
+    assert c.cond and c.n_cond == 2
+
+
 def test_construct_rejects_what_is_out_of_scope_or_malformed():
-    with pytest.raises(NotImplementedError):
-        cnf.construct(cnf.Planar, _nn(2), 2)
-    with pytest.raises(NotImplementedError):
-        cnf.construct(cnf.CondPlanar, _nn(2), 2)
     with pytest.raises(ValueError):
-        cnf.construct(cnf.CondRNODE, _nn(2), 2)         # a conditional nn needs n_in + n_cond inputs
+        cnf.construct(cnf.CondPlanar, _nn(2), 2)        # a conditional nn needs n_in + n_cond inputs
+    with pytest.raises(ValueError):
+        cnf.construct(cnf.CondRNODE, _nn(2), 2)
     with pytest.raises(NotImplementedError):
         cnf.construct(cnf.RNODE, _nn(2), 2, data_type=np.float64)
     with pytest.raises(ValueError):
