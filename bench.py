@@ -126,6 +126,15 @@ def cpu_baseline(B, flat, xs, eps, kw, budget_s=9.0):
                     "-march=x86-64-v3), libm tanhf (oracle/cnf_oracle.c)",
             "sample": f"{n} adaptive Tsit5 solves of the same workload (B={B}, nf={st['nf']} each); restatement "
                       f"of the reference path (the Julia package cannot run here)", "seconds": el}
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    blas["cpu_model"] = port["cpu_model"] = model
     return (blas, port) if blas["value"] >= port["value"] else (port, blas)
 
 
