@@ -28,6 +28,9 @@ __device__ __forceinline__ void s3b_split(float v, __bf16& h, __bf16& m, __bf16&
 typedef float f32x2_ __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void s3b_split2(float v0, float v1, unsigned& h2, unsigned& m2, unsigned& l2) {
+#ifdef S3_ABL_NOEPI
+    h2 = (__float_as_uint(v0) >> 16) | (__float_as_uint(v1) & 0xFFFF0000u); m2 = 0u; l2 = 0u; return;
+#endif
 #ifdef CNF_SPLIT_TRUNC
     __bf16 a0, b0, c0, a1, b1, c1;
     s3b_split(v0, a0, b0, c0); s3b_split(v1, a1, b1, c1);

@@ -24,11 +24,18 @@ static const S3Tab kS3Tab = {{
 // (the scheduling fences keep register-only instructions -- MFMAs -- in the interval the source puts them in)
 __device__ __forceinline__ void s3_bar() {
     __builtin_amdgcn_sched_barrier(0);
+#ifdef S3_ABL_NOBAR
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ f32x4 s3_tanh4(const f32x4& a) {
+#ifdef S3_ABL_NOEPI
+    return a * 0.25f;
+#endif
     return f32x4{tanh_fast(a.x), tanh_fast(a.y), tanh_fast(a.z), tanh_fast(a.w)};
 }
 __device__ __forceinline__ f32x4 s3_dtanh4(const f32x4& h) {       // sigma' from h
@@ -66,6 +73,9 @@ static_assert(F32 % 16 == 0 && W3I % 16 == 0, "16-byte loads");
 // 4 rows of one sample -> the three images (8 bytes each)
 typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void s3b_store4(char* img, int piece_bytes, const f32x4& v) {
+#ifdef S3_ABL_NOSTORE
+    { asm volatile("" :: "v"(v), "v"((unsigned)(size_t)img)); return; }
+#endif
     u32x2_ h, m, l;
     { unsigned h_, m_, l_; s3b_split2(v[0], v[1], h_, m_, l_); h.x = h_; m.x = m_; l.x = l_; }
     { unsigned h_, m_, l_; s3b_split2(v[2], v[3], h_, m_, l_); h.y = h_; m.y = m_; l.y = l_; }
@@ -74,6 +84,10 @@ __device__ __forceinline__ void s3b_store4(char* img, int piece_bytes, const f32
 struct S3bOp { bf16x8 h, m, l; };
 __device__ __forceinline__ S3bOp s3b_load(const char* img, int piece_bytes) {
     S3bOp o;
+#ifdef S3_ABL_NOLOAD
+    { typedef unsigned u4_ __attribute__((ext_vector_type(4))); u4_ z = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(z) : "v"((unsigned)(size_t)img));
+      o.h = o.m = o.l = __builtin_bit_cast(bf16x8, z); return o; }
+#endif
     o.h = *(const bf16x8*)img; o.m = *(const bf16x8*)(img + piece_bytes); o.l = *(const bf16x8*)(img + 2 * piece_bytes);
     return o;
 }
@@ -98,6 +112,9 @@ __device__ __forceinline__ void s3b_pin(S3bOp& o) {
 // term T (0..5, smallest first) of the product a x b into acc
 template <int T>
 __device__ __forceinline__ f32x4 s3b_term(const S3bOp& a, const S3bOp& b, const f32x4& acc) {
+#ifdef S3_ABL_NOMFMA
+    { u32x4 x = __builtin_bit_cast(u32x4, a.h), y = __builtin_bit_cast(u32x4, b.h); asm volatile("" :: "v"(x), "v"(y)); return acc; }
+#endif
     if (T == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, acc, 0, 0, 0);
     if (T == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, acc, 0, 0, 0);
     if (T == 2) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, acc, 0, 0, 0);
