@@ -1560,6 +1560,7 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
         }
         if (adj_mfma) {        // the six stage pullbacks and the lambda update of this step in ONE launch
             S.first = 5; S.last = 0; S.B = B; S.lam_update = 1; S.lam_out = h->g_lam;
+            for (int m = 0; m < 6; ++m) for (int d = 0; d < 5; ++d) S.kc[m][d] = m - 1 - d >= 0 ? A[m][m - 1 - d] : 0.f;
             HIPCHK(h, launch_adj_mfma_step(nd, gl, am, h->d_adj_img, S, st));
         } else {
             StageK ws{};

@@ -41,6 +41,7 @@ struct AdjStepArgs {
     int B;
     int lam_update;
     float* lam_out;
+    float kc[6][5];                 // kc[m][d] = a_{m, m-1-d} (0 past stage 0): what zbar_m adds to the sum of the d-th stage after it
 };
 
 struct StageK {
@@ -82,7 +83,5 @@ AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g);
 bool adj_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
 hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* P,
                                   float* img, hipStream_t s);
-hipError_t launch_adj_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
-                           const AdjArgs& a, hipStream_t s);
 hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                                 const AdjStepArgs& S, hipStream_t s);

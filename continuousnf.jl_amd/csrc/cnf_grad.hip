@@ -1094,6 +1094,11 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
 // and factor arrays are those of k_adj_mfma.
 // ---------------------------------------------------------------------------------------------------
 #define A3_NS 32
+#ifdef A3_ABL_NOMFMA      // ablation: no MFMAs, operands kept alive
+__device__ __forceinline__ f32x4 a3_mfma(float a, float b, f32x4 c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
+#else
+__device__ __forceinline__ f32x4 a3_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#endif
 // two column tiles against one A tile; B operands run two k-blocks ahead of the MFMAs (ring of 3)
 template <int KB>
 __device__ __forceinline__ void adj3_tile2(const f32x4 (&A)[KB], const float* X, int PS, int s, int q, const f32x4& init,
@@ -1114,11 +1119,11 @@ __device__ __forceinline__ void adj3_tile2(const f32x4 (&A)[KB], const float* X,
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (u & 1) {
-                a01 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][k], b0[u & 1][k], a01, 0, 0, 0);
-                a11 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][k], b1[u & 1][k], a11, 0, 0, 0);
+                a01 = a3_mfma(A[u][k], b0[u & 1][k], a01);
+                a11 = a3_mfma(A[u][k], b1[u & 1][k], a11);
             } else {
-                a00 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][k], b0[u & 1][k], a00, 0, 0, 0);
-                a10 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][k], b1[u & 1][k], a10, 0, 0, 0);
+                a00 = a3_mfma(A[u][k], b0[u & 1][k], a00);
+                a10 = a3_mfma(A[u][k], b1[u & 1][k], a10);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1138,36 +1143,25 @@ __device__ __forceinline__ f32x4 adj3_tile1(const f32x4 (&A)[KB], const float* X
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {       // two chains, alternating: a dependent MFMA would wait for its predecessor
-            if (k & 1) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][k], b[u % 3][k], a1, 0, 0, 0);
-            else a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][k], b[u % 3][k], a0, 0, 0, 0);
+            if (k & 1) a1 = a3_mfma(A[u][k], b[u % 3][k], a1);
+            else a0 = a3_mfma(A[u][k], b[u % 3][k], a0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (u + 2 < KB) b[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(x0 + 16 * (u + 2));
     }
     return a0 + a1;
 }
-// Stage inputs of one (sample, row) element, RAW (nothing is combined here, so nothing waits for the loads): state row
-// (or conditioning input), eps, lambda and the zbar of the four oldest later stages.  Unused a.w[] slots point at
-// lambda with coefficient 0 (cnf_abi.hip), so every request is unconditional and its pointer a scalar load.
-struct Adj3In { float x, e, lam, w[4]; };
-__device__ __forceinline__ void adj3_fetch(const AdjArgs& a, const NetDesc& nd, int eb, bool ev, int r, int n_in, int in0,
-                                           int D, Adj3In& o) {
-    o.x = 0.f; o.e = 0.f; o.lam = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) o.w[w] = 0.f;
+// The state row (or conditioning input) of one (sample, row) element of a stage: the only thing a stage reads from global
+// memory (eps and lambda are the same for every stage of the launch, the zbar of the later stages never leave the CU).
+__device__ __forceinline__ float adj3_fetch(const AdjArgs& a, const NetDesc& nd, int eb, bool ev, int r, int n_in, int in0, int D) {
     // both base pointers as scalars first: a per-lane choice between two pointer FIELDS makes the compiler fetch the
     // chosen field with a vector load and wait for it (and for every request in front of it)
     const float* pu = a.ustage;
     const float* py = a.ys ? a.ys : a.ustage;
     asm volatile("" ::"s"(pu), "s"(py));
-    if (ev && r < in0) o.x = *(r < n_in ? pu + (size_t)eb * D + r : py + (size_t)eb * nd.n_cond + (r - n_in));
-    if (ev && r < n_in) {
-        const size_t ix = (size_t)eb * n_in + r;
-        o.e = a.eps[ix];
-        o.lam = a.lam[ix];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) o.w[w] = a.w[w + 1][ix];
-    }
+    float x = 0.f;
+    if (ev && r < in0) x = *(r < n_in ? pu + (size_t)eb * D + r : py + (size_t)eb * nd.n_cond + (r - n_in));
+    return x;
 }
 
 static size_t adj3_lds_bytes(const AdjMfmaLayout& m) { return ((size_t)A3_NS * m.PS + (size_t)AM_EC * A3_NS) * sizeof(float); }
@@ -1219,7 +1213,22 @@ k_adj3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int r0w = 16 * wave + 4 * q, r0n = 16 * nt + 4 * q;       // first row of this lane in a wide / narrow tile
 
-    Adj3In pf[2];                                         // inputs of the coming stage (see below)
+    // Per thread: row ec of samples es and es + 16 in the elementwise passes.  lambda and eps are the same for every stage
+    // of the launch (registers / the E rows of LDS, written once); the zbar of a finished stage goes through LDS to these
+    // threads, which keep  K[d] = sum_{m done} a_{m, j} zbar_m  for the d-th stage still to come (a shift register: the
+    // stages run 5, 4, .., 0) and the running sum of all zbar for the lambda update -- nothing of it touches global memory,
+    // so no stage waits for its stores.
+    static_assert(AM_EC == NI, "one row of the 32 per thread in the elementwise passes");
+    float xpf[2], lamv[2], lsum[2] = {0.f, 0.f}, K[2][5];
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+        const int e2 = es + 16 * hs, eb = b0 + e2;
+        const bool evl = eb < S.B && ec < n_in;
+        lamv[hs] = evl ? S.st[S.first].lam[(size_t)eb * n_in + ec] : 0.f;
+        lds[e2 * PS + m.E + ec] = evl ? S.st[S.first].eps[(size_t)eb * n_in + ec] : 0.f;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) K[hs][d] = 0.f;
+    }
 
   for (int stg = S.first; stg >= S.last; --stg) {      // the stages of one Runge-Kutta step, last to first
     // opaque zero: keeps the compiler from hoisting the per-sample global addresses of all six array families out of
@@ -1238,28 +1247,27 @@ k_adj3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img
         const float* t4 = an.w[2];
         asm volatile("" ::"s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4));
     }
-    // ---- inputs: [z; ys; 0] -> S0, eps -> E; h_0 also goes out for the weight gradient ---------
-    // Everything a stage reads from global memory except the zbar of the stage just finished (a.w[0]) is known a
-    // stage ahead: it is fetched during the previous stage (`pf_*`, filled after its second sweep), so that only one
-    // request stands between the end-of-stage barrier and the first sweep.  The thread's element: row ec of samples
-    // es and es + 16.
-    static_assert(AM_EC == NI, "one row of the 32 per thread in the elementwise passes");
-    float kbv[2] = {0.f, 0.f};
+    // ---- inputs: [z; ys; 0] -> S0; h_0 also goes out for the weight gradient ---------
+    // The state row was requested during the previous stage (`xpf`, after its second sweep); the zbar of the stage just
+    // finished sits in the S1 rows (its last epilogue put it there in front of the end-of-stage barrier).
+    float kbv[2];
 #pragma unroll
     for (int hs = 0; hs < 2; ++hs) {
         const int e2 = es + 16 * hs, eb = b0v + e2;
         const bool ev = eb < S.B;
-        if (stg == S.first) adj3_fetch(a, nd, eb, ev, ec, n_in, in0, D, pf[hs]);
-        if (ev && ec < n_in) {
-            float kb = a.cb * pf[hs].lam;
-            kb = fmaf(a.wc[0], a.w[0][(size_t)eb * n_in + ec], kb);       // the stage just finished
+        if (stg == S.first) xpf[hs] = adj3_fetch(a, nd, eb, ev, ec, n_in, in0, D);
+        else {
+            const float w = lds[e2 * PS + m.S1 + ec];                 // zbar of stage stg + 1 (zero rows beyond the batch)
+            lsum[hs] += w;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) kb = fmaf(a.wc[w + 1], pf[hs].w[w], kb);
-            kbv[hs] = kb * a.hstep;
+            for (int d = 0; d < 5; ++d) K[hs][d] = fmaf(S.kc[stg + 1][d], w, K[hs][d]);
         }
-        lds[e2 * PS + m.S0 + ec] = pf[hs].x;
-        if (ev && ec < in0) a.HS[(size_t)eb * gl.sum_in + ec] = pf[hs].x;
-        lds[e2 * PS + m.E + ec] = pf[hs].e;
+        kbv[hs] = (ev && ec < n_in) ? fmaf(a.cb, lamv[hs], K[hs][0]) * a.hstep : 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) K[hs][d] = K[hs][d + 1];          // the next stage's sum moves to the front
+        K[hs][4] = 0.f;
+        lds[e2 * PS + m.S0 + ec] = xpf[hs];
+        if (ev && ec < in0) a.HS[(size_t)eb * gl.sum_in + ec] = xpf[hs];
     }
     am_barrier();
     AM_STAMP(0);
@@ -1388,7 +1396,7 @@ k_adj3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img
 #pragma unroll
         for (int hs = 0; hs < 2; ++hs) {
             const int eb = b0v + es + 16 * hs;
-            adj3_fetch(an, nd, eb, eb < S.B, ec, n_in, in0, D, pf[hs]);
+            xpf[hs] = adj3_fetch(an, nd, eb, eb < S.B, ec, n_in, in0, D);
         }
     }
     // ---- sweep 3: tangent chain; the last layer forms abar_L = ahat sigma' + eps q_L instead of t_L ----
@@ -1440,8 +1448,8 @@ k_adj3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img
                              *reinterpret_cast<const f32x4*>(Sw + m.D2 + oprev + r0);
             *reinterpret_cast<f32x4*>(Sw + nxt + r0) = ab;
             if (sv) am_store4(a.AB + gb * gl.sum_out + gl.out_off[l - 1] + r0, ab, r0, nd.dims[l], m.vec4o);
-        } else if (sv) {
-            am_store4(a.w_out + gb * n_in + r0, acc, r0, n_in, (n_in & 3) == 0);   // zbar
+        } else {
+            *reinterpret_cast<f32x4*>(Sw + nxt + r0) = sv ? acc : zero4;             // zbar: to the elementwise threads through LDS
         }
     };
     fetch_na(R1);
@@ -1455,24 +1463,15 @@ k_adj3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img
     am_barrier();
     AM_STAMP(12);
     { const int t_ = cur; cur = nxt; nxt = t_; }
-    if (narrow) hb_epi(0, r0n, nc, adj3_tile1(na, lds + cur + 16 * nc * PS, PS, s, q, zero4));
-    // zbar of this stage is input to the earlier stages (and to the lambda update): stores first, then everyone
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    am_barrier();
+    if (narrow) hb_epi(0, r0n, nc, adj3_tile1(na, lds + cur + 16 * nc * PS, PS, s, q, zero4));   // (nxt == S1 here: twelve swaps)
+    am_barrier();                                         // zbar of this stage visible to the elementwise threads
     AM_STAMP(13);
   }
-  if (S.lam_update) {        // lambda <- lambda + sum over the stages of zbar   (rows of this workgroup's samples)
+  // lambda <- lambda + sum over the stages of zbar   (rows of this workgroup's samples)
 #pragma unroll
-    for (int hs = 0; hs < 2; ++hs) {
-        const int eb = b0 + es + 16 * hs;
-        for (int r = ec; r < n_in; r += AM_EC) {
-            if (eb < S.B) {
-                float acc = S.st[0].lam[(size_t)eb * n_in + r];
-                for (int k = S.last; k <= S.first; ++k) acc += S.st[k].w_out[(size_t)eb * n_in + r];
-                S.lam_out[(size_t)eb * n_in + r] = acc;
-            }
-        }
-    }
+  for (int hs = 0; hs < 2; ++hs) {
+    const int e2 = es + 16 * hs, eb = b0 + e2;
+    if (eb < S.B && ec < n_in) S.lam_out[(size_t)eb * n_in + ec] = lamv[hs] + (lsum[hs] + lds[e2 * PS + m.S1 + ec]);
   }
 }
 
@@ -1495,7 +1494,7 @@ hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const Ad
     bool all_tanh = true;
     for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
     static const bool generic_only = [] { const char* e = getenv("CNF_ADJ_GENERIC"); return e && e[0] == '1'; }();
-    if (adj3_shape(nd, m) && !generic_only) {          // resident-fragment pullback (A/B switch: CNF_ADJ_GENERIC=1)
+    if (adj3_shape(nd, m) && !generic_only && S.first == 5 && S.last == 0 && S.lam_update && S.lam_out) {   // (whole steps: the zbar stay in the kernel)          // resident-fragment pullback (A/B switch: CNF_ADJ_GENERIC=1)
         const void* f3 = all_tanh ? (const void*)k_adj3<true> : (const void*)k_adj3<false>;
         const size_t lds3 = adj3_lds_bytes(m);
         hipError_t e3 = hipFuncSetAttribute(f3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
@@ -1513,12 +1512,4 @@ hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const Ad
     else
         hipLaunchKernelGGL(k_adj_mfma<false>, dim3((S.B + AM_NS - 1) / AM_NS), dim3(AM_THREADS), lds, s, nd, g, m, img, S);
     return hipGetLastError();
-}
-
-// one stage only (kept for callers that drive the stages themselves)
-hipError_t launch_adj_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
-                           const AdjArgs& a, hipStream_t s) {
-    AdjStepArgs S{};
-    S.st[0] = a; S.first = 0; S.last = 0; S.B = a.B; S.lam_update = 0; S.lam_out = nullptr;
-    return launch_adj_mfma_step(nd, g, m, img, S, s);
 }
