@@ -2,7 +2,7 @@
 #pragma once
 #include "cnf_dev.h"
 
-#define GRAD_MAX_KSPLIT 64
+#define GRAD_MAX_KSPLIT 128
 
 // Row layouts of the [sample][feature] arrays exchanged between k_adj and k_wgrad.
 struct GradLayout {

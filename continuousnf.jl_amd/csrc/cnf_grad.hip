@@ -488,24 +488,40 @@ k_wgrad_mfma(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const floa
 }
 
 // The same contraction with every fp32 product formed from six bf16 MFMA terms on exactly split operands
-// (v_mfma_f32_16x16x32_bf16: 32 samples per instruction; accuracy of the fp32 MFMA, cnf_split.h).  A thread fetches 8
-// consecutive samples of one column of each of the four factor arrays (the next 32 samples travel while the current ones
-// are multiplied), splits them and stores the three pieces as 16-byte chunks of [piece][column][32 samples] images whose
-// chunks are XOR-swizzled by the column, so that the operand reads (lane (q, x): column 16 tile + x, chunk q) have no
-// bank conflicts.  Output tile, K-splits and the reduction over them are those of k_wgrad_mfma.
+// (v_mfma_f32_16x16x32_bf16: 32 samples per instruction; accuracy of the fp32 MFMA, cnf_split.h).  64 x 64 output tile per
+// workgroup, wave w the 16-column strip w of the input side.  Per 32 samples:
+//   * output side (abar, pbar; every wave needs all four 16-row groups): thread (lc, lr) fetches 8 consecutive samples of
+//     column lc, splits them and stores the three pieces as 16-byte chunks of [piece][column][32 samples] images in LDS
+//     (chunks XOR-swizzled by the column: the operand reads -- lane (q, x): column 16 tile + x, chunk q -- are conflict-free);
+//   * input side (h, t): lane (x, q) of wave w fetches samples 8q .. 8q + 7 of column 16 w + x -- exactly ITS operand of
+//     the MFMAs -- and splits it in registers: that half of the factors never touches LDS (the kernel is bound by LDS
+//     traffic: ablations in DESIGN 7.0).
+// Two chunks are in flight in registers while a third is multiplied.  K-splits and the reduction over them as k_wgrad_mfma.
 #define WB_K 32
-// TS = 16-column groups per side of the output tile (4: 64 x 64, what launch_wgrad uses; 8: 128 x 128).  Tiles narrower
-// than that skip their empty strips.
-template <int TS>
+#ifdef WB_STAMPS      // per-phase cycle totals of wave 0 of one full-width tile's first K-split (tools/wgrad_stamps.py)
+__device__ unsigned long long wb_stamps[8];
+extern "C" int cnf_debug_wgrad_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wb_stamps), sizeof(unsigned long long) * 8);
+}
+#define WB_T(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); wbt[i] += n_ - wb_last; wb_last = n_; } while (0)
+#else
+#define WB_T(i)
+#endif
 __global__ void __launch_bounds__(256)
 k_wgrad_mfma_b(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const float* __restrict__ PB,
                const float* __restrict__ HS, const float* __restrict__ TSb, float* __restrict__ gpart,
                int n_params, int B, int chunk) {
-    constexpr int T = 16 * TS, CP = T / 64, NSW = TS / 4;              // tile side; columns per thread; strips per wave
-    constexpr int PIECE = T * 64;                                      // one piece of one array: T columns x 64 bytes
-    extern __shared__ __attribute__((aligned(16))) char simg[];        // A | P | H | T, three pieces each; then the bias sums
-    float* sbias = reinterpret_cast<float*>(simg + 4 * 3 * PIECE);     // [4][T]
-    int tile = blockIdx.x, l = 0, to_ = 0, ti = 0;
+    constexpr int T = 64, PIECE = T * 64;                              // tile side; one piece of one array: T columns x 64 bytes
+    extern __shared__ __attribute__((aligned(16))) char simg[];        // A | P, three pieces each; then the bias sums
+    float* sbias = reinterpret_cast<float*>(simg + 2 * 3 * PIECE);     // [4][T]
+    // Workgroups go to the 8 XCDs round-robin in launch order, and each XCD has its own L2: all tiles of a K-split -- which
+    // read the SAME sample rows -- run next to each other on ONE XCD.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int L = bx + gridDim.x * by, r = L >> 3;
+        bx = r % gridDim.x; by = (L & 7) + 8 * (r / gridDim.x);
+    }
+    int tile = bx, l = 0, to_ = 0, ti = 0;
     for (; l < nd.n_layers; ++l) {
         const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
         const int no = (out + T - 1) / T, ni = (in + T - 1) / T;
@@ -516,51 +532,91 @@ k_wgrad_mfma_b(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const fl
     const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
     const int o0 = to_ * T, i0 = ti * T;
     const int oo = gl.out_off[l], io = gl.in_off[l];
-    const int k0 = blockIdx.y * chunk, k1 = min(B, k0 + chunk);
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, x = lane & 15, q = lane >> 4;
-    const int nto = min(TS, (out - o0 + 15) / 16);                     // 16-row groups of the tile that exist
-    f32x4 acc[NSW][TS];
+    const int k0 = by * chunk, k1 = min(B, k0 + chunk);
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), x = lane & 15, q = lane >> 4;
+    const int nto = min(4, (out - o0 + 15) / 16);                      // 16-row groups of the tile that exist
+    const bool bstrip = i0 + 16 * w < in;                              // this wave's strip of the input side exists (wave-uniform)
+    f32x4 acc[4];
 #pragma unroll
-    for (int a = 0; a < NSW; ++a)
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const int lc = lane, lr = w;                            // output side: column lc, samples 8 lr .. 8 lr + 7 of a chunk
+    struct Buf { float a[8], p[8], h[8], t[8]; };
+    Buf bufA, bufB;
+    // Row bases are scalar arithmetic, a request is scalar base + 32-bit lane offset (BYTES).  Columns beyond the layer's
+    // widths re-read its last column (their products land in rows / columns of the tile that are never stored); rows beyond
+    // the K-split (its last, ragged chunk only) re-read its last row and are zeroed on arrival.
+    const unsigned ca = 4u * (unsigned)min(lc, out - o0 - 1);
+    const unsigned colb = (unsigned)min(16 * w + x, in - i0 - 1);
+    const unsigned cb = 4u * (colb + (unsigned)(8 * q) * (unsigned)gl.sum_in);
+#ifdef WB_ABL_NOLOAD
+    auto ld = [](const float* base, unsigned off) { float v; asm volatile("v_mov_b32 %0, 1.0" : "=v"(v) : "v"(off), "s"(base)); return v; };
+#else
+    auto ld = [](const float* base, unsigned off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off); };
+#endif
+    // per-lane byte offsets of the 8 rows of a chunk (loop-invariant registers): a request is then ONE instruction with a
+    // scalar chunk base -- no address arithmetic on either unit inside the loop (the scalar adds per request, ~400 per 32
+    // samples, were what a wave's instruction stream mostly consisted of)
+    unsigned offA[8], offB[8];
 #pragma unroll
-        for (int i = 0; i < TS; ++i) acc[a][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum[CP];
+    for (int j = 0; j < 8; ++j) {
+        offA[j] = ca + 4u * (unsigned)(8 * lr + j) * (unsigned)gl.sum_out;
+        offB[j] = cb + 4u * (unsigned)j * (unsigned)gl.sum_in;
+    }
+    auto fetch = [&](Buf& r, int kb) {
+        const float* bA = AB + (size_t)kb * gl.sum_out + oo + o0;
+        const float* bP = PB + (size_t)kb * gl.sum_out + oo + o0;
+        const float* bH = HS + (size_t)kb * gl.sum_in + io + i0;
+        const float* bT = TSb + (size_t)kb * gl.sum_in + io + i0;
+        if (kb + WB_K <= k1) {
 #pragma unroll
-    for (int c = 0; c < CP; ++c) bsum[c] = 0.f;
-    const int lc = t & 63, lr = t >> 6;                     // this thread: columns lc (+ 64), samples 8 lr .. 8 lr + 7 of a chunk
-    float ra[CP][8], rp[CP][8], rh[CP][8], rt[CP][8];
-    auto fetch = [&](int kb) {
-#pragma unroll
-        for (int c = 0; c < CP; ++c) {
-            const bool co = o0 + lc + 64 * c < out, ci = i0 + lc + 64 * c < in;
+            for (int j = 0; j < 8; ++j) { r.a[j] = ld(bA, offA[j]); r.p[j] = ld(bP, offA[j]); r.h[j] = ld(bH, offB[j]); r.t[j] = ld(bT, offB[j]); }
+        } else {                                                       // the last, ragged chunk: rows clamped to the split's last row
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int b = kb + 8 * lr + j;
-                const bool vb = b < k1;
-                ra[c][j] = (vb && co) ? AB[(size_t)b * gl.sum_out + oo + o0 + lc + 64 * c] : 0.f;
-                rp[c][j] = (vb && co) ? PB[(size_t)b * gl.sum_out + oo + o0 + lc + 64 * c] : 0.f;
-                rh[c][j] = (vb && ci) ? HS[(size_t)b * gl.sum_in + io + i0 + lc + 64 * c] : 0.f;
-                rt[c][j] = (vb && ci) ? TSb[(size_t)b * gl.sum_in + io + i0 + lc + 64 * c] : 0.f;
+                const unsigned oa = ca + 4u * (unsigned)(min(kb + 8 * lr + j, k1 - 1) - kb) * (unsigned)gl.sum_out;
+                const unsigned ob = 4u * (colb + (unsigned)(min(kb + 8 * q + j, k1 - 1) - kb) * (unsigned)gl.sum_in);
+                r.a[j] = ld(bA, oa); r.p[j] = ld(bP, oa); r.h[j] = ld(bH, ob); r.t[j] = ld(bT, ob);
             }
         }
     };
-    // chunk c (8 samples) of column r at chunk position c ^ ((-(r >> 2)) & 3) of its 64-byte row
-    auto put = [&](int arr, int col, const float (&v)[8]) {
-        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-        u32x4_ hp, mp, lp;
-        { unsigned h_, m_, l_; s3b_split2(v[0], v[1], h_, m_, l_); hp.x = h_; mp.x = m_; lp.x = l_; } { unsigned h_, m_, l_; s3b_split2(v[2], v[3], h_, m_, l_); hp.y = h_; mp.y = m_; lp.y = l_; }
-        { unsigned h_, m_, l_; s3b_split2(v[4], v[5], h_, m_, l_); hp.z = h_; mp.z = m_; lp.z = l_; } { unsigned h_, m_, l_; s3b_split2(v[6], v[7], h_, m_, l_); hp.w = h_; mp.w = m_; lp.w = l_; }
-        const bf16x8 h = __builtin_bit_cast(bf16x8, hp), m = __builtin_bit_cast(bf16x8, mp), lo = __builtin_bit_cast(bf16x8, lp);
-        char* d = simg + arr * 3 * PIECE + col * 64 + 16 * (lr ^ ((-(col >> 2)) & 3));
-        *(bf16x8*)d = h; *(bf16x8*)(d + PIECE) = m; *(bf16x8*)(d + 2 * PIECE) = lo;
+    auto arrived = [&](Buf& r, int kb) {
+        if (kb + WB_K > k1) {                                          // the last, ragged chunk of the K-split
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (kb + 8 * lr + j >= k1) { r.a[j] = 0.f; r.p[j] = 0.f; }
+                if (kb + 8 * q + j >= k1) { r.h[j] = 0.f; r.t[j] = 0.f; }
+            }
+        }
     };
     struct Op { bf16x8 h, m, l; };
+    auto split8 = [&](const float (&v)[8]) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        u32x4_ hp, mp, lp;
+#ifdef WB_ABL_NOSPLIT
+        hp.x = __float_as_uint(v[0]); hp.y = __float_as_uint(v[2]); hp.z = __float_as_uint(v[4]); hp.w = __float_as_uint(v[6]);
+        mp.x = __float_as_uint(v[1]); mp.y = __float_as_uint(v[3]); mp.z = __float_as_uint(v[5]); mp.w = __float_as_uint(v[7]); lp = hp;
+#else
+        { unsigned h_, m_, l_; s3b_split2(v[0], v[1], h_, m_, l_); hp.x = h_; mp.x = m_; lp.x = l_; } { unsigned h_, m_, l_; s3b_split2(v[2], v[3], h_, m_, l_); hp.y = h_; mp.y = m_; lp.y = l_; }
+        { unsigned h_, m_, l_; s3b_split2(v[4], v[5], h_, m_, l_); hp.z = h_; mp.z = m_; lp.z = l_; } { unsigned h_, m_, l_; s3b_split2(v[6], v[7], h_, m_, l_); hp.w = h_; mp.w = m_; lp.w = l_; }
+#endif
+        Op o; o.h = __builtin_bit_cast(bf16x8, hp); o.m = __builtin_bit_cast(bf16x8, mp); o.l = __builtin_bit_cast(bf16x8, lp);
+        return o;
+    };
+    // chunk c (8 samples) of column r at chunk position c ^ ((-(r >> 2)) & 3) of its 64-byte row
+    auto put = [&](int arr, int col, const Op& o) {
+        char* d = simg + arr * 3 * PIECE + col * 64 + 16 * (lr ^ ((-(col >> 2)) & 3));
+        *(bf16x8*)d = o.h; *(bf16x8*)(d + PIECE) = o.m; *(bf16x8*)(d + 2 * PIECE) = o.l;
+    };
     auto get = [&](int arr, int col) {                      // operand of this lane: column `col`, samples 8q .. 8q + 7
         const char* d = simg + arr * 3 * PIECE + col * 64 + 16 * (q ^ ((-(col >> 2)) & 3));
         Op o; o.h = *(const bf16x8*)d; o.m = *(const bf16x8*)(d + PIECE); o.l = *(const bf16x8*)(d + 2 * PIECE);
         return o;
     };
-    auto mm6 = [&](const Op& a, const Op& b, f32x4 c) {     // smallest terms first
+    auto mm6 = [&](const Op& a, const Op& b, f32x4 c) -> f32x4 {     // smallest terms first
+#ifdef WB_ABL_NOMFMA
+        asm volatile("" : "+v"(c) : "v"(a.h), "v"(a.m), "v"(a.l), "v"(b.h), "v"(b.m), "v"(b.l)); return c;
+#endif
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, c, 0, 0, 0);
@@ -568,55 +624,202 @@ k_wgrad_mfma_b(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const fl
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c, 0, 0, 0);
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
     };
-    fetch(k0);
-    for (int kb = k0; kb < k1; kb += WB_K) {
+#ifdef WB_STAMPS
+    unsigned long long wbt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wb_last = __builtin_amdgcn_s_memtime();
+#endif
+    auto body = [&](Buf& r, int kb) {
+        WB_T(5);
+        arrived(r, kb);
+        WB_T(0);
+        if (ti == 0) {
 #pragma unroll
-        for (int c = 0; c < CP; ++c) {
-            if (ti == 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bsum[c] += ra[c][j];
-            }
-            put(0, lc + 64 * c, ra[c]); put(1, lc + 64 * c, rp[c]); put(2, lc + 64 * c, rh[c]); put(3, lc + 64 * c, rt[c]);
+            for (int j = 0; j < 8; ++j) bsum += r.a[j];
         }
+        put(0, lc, split8(r.a)); put(1, lc, split8(r.p));
+        const Op bh = split8(r.h), bt = split8(r.t);                   // this lane's input-side operands, from its own registers
+        WB_T(1);
         __syncthreads();
-        if (kb + WB_K < k1) fetch(kb + WB_K);
+        WB_T(2);
+        if (kb + 2 * WB_K < k1) fetch(r, kb + 2 * WB_K);
+        WB_T(6);
+        if (bstrip) {
 #pragma unroll
-        for (int a = 0; a < NSW; ++a) {
-            const int strip = w + 4 * a;                               // this wave's a-th 16-column strip of the input side
-            if (i0 + 16 * strip < in) {                                // (wave-uniform)
-                const Op bh = get(2, 16 * strip + x), bt = get(3, 16 * strip + x);
-#pragma unroll
-                for (int to = 0; to < TS; ++to) {
-                    if (to < nto) {
-                        const Op aa = get(0, 16 * to + x), ap = get(1, 16 * to + x);
-                        acc[a][to] = mm6(aa, bh, acc[a][to]);
-                        acc[a][to] = mm6(ap, bt, acc[a][to]);
-                    }
+            for (int to = 0; to < 4; ++to) {
+                if (to < nto) {
+                    const Op aa = get(0, 16 * to + x), ap = get(1, 16 * to + x);
+                    acc[to] = mm6(aa, bh, acc[to]);
+                    acc[to] = mm6(ap, bt, acc[to]);
                 }
             }
         }
+        WB_T(3);
         __syncthreads();
+        WB_T(4);
+    };
+    if (k0 < k1) fetch(bufA, k0);
+    if (k0 + WB_K < k1) fetch(bufB, k0 + WB_K);
+    for (int kb = k0; kb < k1; kb += 2 * WB_K) {
+        body(bufA, kb);
+        if (kb + WB_K < k1) body(bufB, kb + WB_K);
     }
-    float* g = gpart + (size_t)blockIdx.y * n_params;
+#ifdef WB_STAMPS
+    if (l == 1 && to_ == 0 && ti == 0 && by == 0 && t == 0) { for (int i_ = 0; i_ < 8; ++i_) wb_stamps[i_] = wbt[i_]; wb_stamps[7] = (unsigned long long)((k1 - k0 + WB_K - 1) / WB_K); }   // (slot 6: issuing the requests)
+#endif
+    float* g = gpart + (size_t)by * n_params;
+    const int i = i0 + 16 * w + x;
 #pragma unroll
-    for (int a = 0; a < NSW; ++a) {
-        const int i = i0 + 16 * (w + 4 * a) + x;
+    for (int to = 0; to < 4; ++to) {
 #pragma unroll
-        for (int to = 0; to < TS; ++to) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int o = o0 + 16 * to + 4 * q + j;
-                if (o < out && i < in) g[nd.w_off[l] + o + (size_t)i * out] += acc[a][to][j];
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int o = o0 + 16 * to + 4 * q + j;
+            if (o < out && i < in) g[nd.w_off[l] + o + (size_t)i * out] += acc[to][j];
         }
     }
     if (ti == 0) {                                          // bias: the column sums of abar, four sample groups per column
-#pragma unroll
-        for (int c = 0; c < CP; ++c) sbias[lr * T + lc + 64 * c] = bsum[c];
+        sbias[lr * T + lc] = bsum;
         __syncthreads();
         for (int c = t; c < T; c += 256)
             if (o0 + c < out) g[nd.b_off[l] + o0 + c] += (sbias[c] + sbias[T + c]) + (sbias[2 * T + c] + sbias[3 * T + c]);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The contraction, wave-local (the default where the row layouts are 16-byte aligned).  What bounded k_wgrad_mfma_b was not
+// arithmetic, LDS or HBM but the NUMBER of vector-memory instructions: a 4-byte request per lane costs the address unit as
+// much as a 16-byte one (34 cycles per request with two workgroups per CU).  Here a lane fetches 4 consecutive
+// columns of a row with ONE 16-byte request, 8 rows of its sample group: lane (cg, sg) = columns 4 cg .. 4 cg + 3, samples
+// 8 sg .. 8 sg + 7 of the 32-sample chunk -- and that IS an MFMA operand layout (lane (x, q): 8 consecutive k) for the tile
+// made of the columns {4 x + c}: output "tile c" is a comb of every fourth column, which costs nothing (the rows and columns
+// of the result are just stored where they belong).  One wave holds the whole 64 x 32-sample chunk of all four factor
+// arrays in registers and multiplies the full 64 x 64 output tile (16 accumulator tiles): no LDS, no barriers, a quarter of
+// the memory instructions.  A workgroup is ONE wave (512 registers); K-splits x tiles waves fill the chip one per SIMD.
+// The next chunk is requested as soon as the current one has been split (its raw registers are free then) and travels
+// under the 192 MFMAs.
+__global__ void __launch_bounds__(64)
+k_wgrad_wave(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const float* __restrict__ PB,
+             const float* __restrict__ HS, const float* __restrict__ TSb, float* __restrict__ gpart,
+             int n_params, int B, int chunk) {
+    constexpr int T = 64;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {                            // all tiles of a K-split on one XCD (they read the same rows)
+        const int L = bx + gridDim.x * by, r = L >> 3;
+        bx = r % gridDim.x; by = (L & 7) + 8 * (r / gridDim.x);
+    }
+    int tile = bx, l = 0, to_ = 0, ti = 0;
+    for (; l < nd.n_layers; ++l) {
+        const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
+        const int no = (out + T - 1) / T, ni = (in + T - 1) / T;
+        if (tile < no * ni) { to_ = tile / ni; ti = tile % ni; break; }
+        tile -= no * ni;
+    }
+    if (l == nd.n_layers) return;
+    const int in = l == 0 ? gl.in0 : nd.dims[l], out = nd.dims[l + 1];
+    const int o0 = to_ * T, i0 = ti * T;
+    const int oo = gl.out_off[l], io = gl.in_off[l];
+    const int k0 = by * chunk, k1 = min(B, k0 + chunk);
+    if (k0 >= k1) return;
+    const int lane = threadIdx.x, cg = lane & 15, sg = lane >> 4;
+    // column groups beyond the layer's width re-read its last group (their products land in rows / columns of the tile
+    // that are never stored)
+    const int ga = min(4 * cg, ((out - o0 - 1) >> 2) << 2), gb = min(4 * cg, ((in - i0 - 1) >> 2) << 2);
+    const unsigned offA = 4u * ((unsigned)ga + (unsigned)(8 * sg) * (unsigned)gl.sum_out);     // BYTES from the chunk's first row
+    const unsigned offB = 4u * ((unsigned)gb + (unsigned)(8 * sg) * (unsigned)gl.sum_in);
+    struct Op { bf16x8 h, m, l; };
+    f32x4 ra[8], rp[8], rh[8], rt[8];                       // raw chunk: [row j of the sample group][4 columns]
+    // (plain loads: the compiler keeps track of what is in flight -- it moves registers around in this 440-register kernel,
+    // and a copy of a register whose load has not landed yet reads garbage; hand-written requests were tried and did that)
+    auto ld4 = [](const float* base, unsigned off) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off); };
+    auto fetch = [&](int kb) {
+        const float* bA = AB + (size_t)kb * gl.sum_out + oo + o0;
+        const float* bP = PB + (size_t)kb * gl.sum_out + oo + o0;
+        const float* bH = HS + (size_t)kb * gl.sum_in + io + i0;
+        const float* bT = TSb + (size_t)kb * gl.sum_in + io + i0;
+        if (kb + WB_K <= k1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                  // row bases: scalar arithmetic
+                ra[j] = ld4(bA + (size_t)j * gl.sum_out, offA); rp[j] = ld4(bP + (size_t)j * gl.sum_out, offA);
+                rh[j] = ld4(bH + (size_t)j * gl.sum_in, offB); rt[j] = ld4(bT + (size_t)j * gl.sum_in, offB);
+            }
+        } else {                                           // the last, ragged chunk: rows clamped to the split's last row
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned row = (unsigned)(min(kb + 8 * sg + j, k1 - 1) - kb);
+                const unsigned oa = 4u * ((unsigned)ga + row * (unsigned)gl.sum_out), ob = 4u * ((unsigned)gb + row * (unsigned)gl.sum_in);
+                ra[j] = ld4(bA, oa); rp[j] = ld4(bP, oa); rh[j] = ld4(bH, ob); rt[j] = ld4(bT, ob);
+            }
+        }
+    };
+    auto split8 = [&](const f32x4 (&r)[8], int c) {         // column c of the lane's four: its 8 samples -> three bf16x8 pieces
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        u32x4_ hp, mp, lp;
+        { unsigned h_, m_, l_; s3b_split2(r[0][c], r[1][c], h_, m_, l_); hp.x = h_; mp.x = m_; lp.x = l_; }
+        { unsigned h_, m_, l_; s3b_split2(r[2][c], r[3][c], h_, m_, l_); hp.y = h_; mp.y = m_; lp.y = l_; }
+        { unsigned h_, m_, l_; s3b_split2(r[4][c], r[5][c], h_, m_, l_); hp.z = h_; mp.z = m_; lp.z = l_; }
+        { unsigned h_, m_, l_; s3b_split2(r[6][c], r[7][c], h_, m_, l_); hp.w = h_; mp.w = m_; lp.w = l_; }
+        Op o; o.h = __builtin_bit_cast(bf16x8, hp); o.m = __builtin_bit_cast(bf16x8, mp); o.l = __builtin_bit_cast(bf16x8, lp);
+        return o;
+    };
+    f32x4 acc[4][4];                                        // [output comb ca][input comb cb]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f};                        // bias: column sums of abar over this lane's samples
+    fetch(k0);
+    for (int kb = k0; kb < k1; kb += WB_K) {
+        if (kb + WB_K > k1) {                               // ragged chunk: rows past the split are zeros
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (kb + 8 * sg + j >= k1) { ra[j] = f32x4{0.f, 0.f, 0.f, 0.f}; rp[j] = ra[j]; rh[j] = ra[j]; rt[j] = ra[j]; }
+        }
+        if (ti == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bs += ra[j];
+        }
+        Op A[4], P[4], H[4], Tg[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { A[c] = split8(ra, c); P[c] = split8(rp, c); H[c] = split8(rh, c); Tg[c] = split8(rt, c); }
+        if (kb + WB_K < k1) fetch(kb + WB_K);               // the raw registers are free: the next chunk travels under the MFMAs
+        // 16 accumulator tiles x 12 terms; consecutive MFMAs go to different accumulators (no back-to-back dependence)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+#define WGW_TERM(X, Y, xa, yb) _Pragma("unroll") for (int ca_ = 0; ca_ < 4; ++ca_) \
+            acc[ca_][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[ca_].xa, Y[cb].yb, acc[ca_][cb], 0, 0, 0);
+            WGW_TERM(A, H, l, h) WGW_TERM(P, Tg, l, h) WGW_TERM(A, H, h, l) WGW_TERM(P, Tg, h, l)      // smallest terms first
+            WGW_TERM(A, H, m, m) WGW_TERM(P, Tg, m, m) WGW_TERM(A, H, m, h) WGW_TERM(P, Tg, m, h)
+            WGW_TERM(A, H, h, m) WGW_TERM(P, Tg, h, m) WGW_TERM(A, H, h, h) WGW_TERM(P, Tg, h, h)
+#undef WGW_TERM
+        }
+    }
+    // acc[ca][cb][j] = sum over the samples of abar[.][o] * h[.][i] + pbar * t  with  o = o0 + 4 (4 sg + j) + ca,  i = i0 + 4 cg + cb
+    float* g = gpart + (size_t)by * n_params;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int i = i0 + 4 * cg + cb;
+#pragma unroll
+        for (int ca_ = 0; ca_ < 4; ++ca_) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = o0 + 4 * (4 * sg + j) + ca_;
+                if (o < out && i < in) g[nd.w_off[l] + o + (size_t)i * out] += acc[ca_][cb][j];
+            }
+        }
+    }
+    if (ti == 0) {                                          // bias: sum the four sample groups of a column group
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = bs[c];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            const int o = o0 + 4 * cg + c;
+            if (sg == 0 && 4 * cg == ga && o < out) g[nd.b_off[l] + o] += v;
+        }
+    }
+}
+
+static bool wgrad_wave_ok(const NetDesc& nd, const GradLayout& g) {      // 16-byte aligned rows and layer blocks
+    if ((g.sum_in & 3) || (g.sum_out & 3)) return false;
+    for (int l = 0; l < nd.n_layers; ++l) if ((g.in_off[l] & 3) || (g.out_off[l] & 3)) return false;
+    return true;
 }
 
 // grad[p] = sum over the K-splits, in a fixed order
@@ -730,12 +933,16 @@ int grad_wgrad_tiles(const NetDesc& nd, const GradLayout& g) {
     return n;
 }
 
+static bool wgrad_wave_ok(const NetDesc& nd, const GradLayout& g);
+static bool wgrad_lds_form() { static const bool v = getenv("CNF_WGRAD_LDS") != nullptr; return v; }   // A/B: k_wgrad_mfma_b
 void grad_ksplit(const NetDesc& nd, const GradLayout& g, int B, int* ksplit, int* chunk) {
     const int tiles = grad_wgrad_tiles(nd, g);
-    int ks = (1024 + tiles - 1) / tiles;                 // aim at ~1024 workgroups
+    int ks = (1024 + tiles - 1) / tiles;                 // aim at ~1024 workgroups: one wave per SIMD of k_wgrad_wave ...
     const int maxks = (B + 63) / 64;                     // at least 64 samples per split
     if (ks > maxks) ks = maxks;
-    if (ks > GRAD_MAX_KSPLIT) ks = GRAD_MAX_KSPLIT;
+    const int cap = (wgrad_wave_ok(nd, g) && !wgrad_lds_form()) ? GRAD_MAX_KSPLIT : 64;   // ... or two 256-thread workgroups per CU
+    if (ks > cap) ks = cap;
+    { static const int force = [] { const char* e = getenv("CNF_WGRAD_KS"); return e ? atoi(e) : 0; }(); if (force > 0 && force <= GRAD_MAX_KSPLIT) ks = force; }
     if (ks < 1) ks = 1;
     int ch = (B + ks - 1) / ks;
     ch = (ch + WB_K - 1) / WB_K * WB_K;                  // whole 32-sample groups (a multiple of the fp32 kernels' 16 too)
@@ -751,20 +958,19 @@ hipError_t launch_wgrad(const NetDesc& nd, const GradLayout& g, const float* AB,
         // 64 x 64 output tiles.  (128 x 128 -- every factor column read by one workgroup per K-split, 1.11x instead of
         // 1.56x the minimum traffic -- was measured: 96 KB of LDS leave one workgroup per CU and the launch 1.5 rounds of
         // them; the gradient went from 4.76 to 5.59 ms.)
-        constexpr int TSB = 4, TB = 16 * TSB;
-        constexpr size_t shm = (size_t)4 * 3 * TB * 64 + 4 * TB * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            if (hipFuncSetAttribute((const void*)k_wgrad_mfma_b<TSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
-                return hipGetLastError();
-            attr = true;
-        }
+        constexpr int TB = 64;
+        constexpr size_t shm = (size_t)2 * 3 * TB * 64 + 4 * TB * sizeof(float);
         int tiles = 0;
         for (int l = 0; l < nd.n_layers; ++l) {
             const int in = l == 0 ? g.in0 : nd.dims[l], out = nd.dims[l + 1];
             tiles += ((out + TB - 1) / TB) * ((in + TB - 1) / TB);
         }
-        hipLaunchKernelGGL(k_wgrad_mfma_b<TSB>, dim3(tiles, ksplit), dim3(256), shm, s, nd, g, AB, PB, HS, TS, gpart, n_params,
+        const bool lds_form = wgrad_lds_form();
+        const bool aligned = (((uintptr_t)AB | (uintptr_t)PB | (uintptr_t)HS | (uintptr_t)TS) & 15) == 0;
+        if (!lds_form && aligned && wgrad_wave_ok(nd, g))
+            hipLaunchKernelGGL(k_wgrad_wave, dim3(tiles, ksplit), dim3(64), 0, s, nd, g, AB, PB, HS, TS, gpart, n_params, B, chunk);
+        else
+        hipLaunchKernelGGL(k_wgrad_mfma_b, dim3(tiles, ksplit), dim3(256), shm, s, nd, g, AB, PB, HS, TS, gpart, n_params,
                            B, chunk);
     }
     else if (valu)

@@ -14,6 +14,6 @@ for lib in default "$@"; do
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     if any(k in r["Name"] for k in ("k_adj3", "k_wgrad", "k_solve3b<true")):
-        print("   %-40s calls %4s avg %9.1f us" % (r["Name"][:40], r["Calls"], float(r["AverageNs"]) / 1e3))
+        print("   %-40s calls %4s avg %9.1f us  min %9.1f  max %9.1f" % (r["Name"][:40], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 P
 done
