@@ -729,26 +729,23 @@ k_wgrad_wave(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const floa
     // (plain loads: the compiler keeps track of what is in flight -- it moves registers around in this 440-register kernel,
     // and a copy of a register whose load has not landed yet reads garbage; hand-written requests were tried and did that)
     auto ld4 = [](const float* base, unsigned off) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off); };
-    auto fetch = [&](int kb) {
-        const float* bA = AB + (size_t)kb * gl.sum_out + oo + o0;
-        const float* bP = PB + (size_t)kb * gl.sum_out + oo + o0;
-        const float* bH = HS + (size_t)kb * gl.sum_in + io + i0;
-        const float* bT = TSb + (size_t)kb * gl.sum_in + io + i0;
+    // one side of a chunk (X, Y = abar, pbar or h, t): 8 rows of the lane's sample group, row bases by scalar arithmetic
+    auto fetch2 = [&](f32x4 (&x)[8], f32x4 (&y)[8], const float* X, const float* Y, int sum, int col0, int g4, unsigned off, int kb) {
+        const float* bX = X + (size_t)kb * sum + col0;
+        const float* bY = Y + (size_t)kb * sum + col0;
         if (kb + WB_K <= k1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {                  // row bases: scalar arithmetic
-                ra[j] = ld4(bA + (size_t)j * gl.sum_out, offA); rp[j] = ld4(bP + (size_t)j * gl.sum_out, offA);
-                rh[j] = ld4(bH + (size_t)j * gl.sum_in, offB); rt[j] = ld4(bT + (size_t)j * gl.sum_in, offB);
-            }
+            for (int j = 0; j < 8; ++j) { x[j] = ld4(bX + (size_t)j * sum, off); y[j] = ld4(bY + (size_t)j * sum, off); }
         } else {                                           // the last, ragged chunk: rows clamped to the split's last row
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const unsigned row = (unsigned)(min(kb + 8 * sg + j, k1 - 1) - kb);
-                const unsigned oa = 4u * ((unsigned)ga + row * (unsigned)gl.sum_out), ob = 4u * ((unsigned)gb + row * (unsigned)gl.sum_in);
-                ra[j] = ld4(bA, oa); rp[j] = ld4(bP, oa); rh[j] = ld4(bH, ob); rt[j] = ld4(bT, ob);
+                const unsigned o = 4u * ((unsigned)g4 + (unsigned)(min(kb + 8 * sg + j, k1 - 1) - kb) * (unsigned)sum);
+                x[j] = ld4(bX, o); y[j] = ld4(bY, o);
             }
         }
     };
+    auto fetchAP = [&](int kb) { fetch2(ra, rp, AB, PB, gl.sum_out, oo + o0, ga, offA, kb); };
+    auto fetchHT = [&](int kb) { fetch2(rh, rt, HS, TSb, gl.sum_in, io + i0, gb, offB, kb); };
     auto split8 = [&](const f32x4 (&r)[8], int c) {         // column c of the lane's four: its 8 samples -> three bf16x8 pieces
         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
         u32x4_ hp, mp, lp;
@@ -765,7 +762,7 @@ k_wgrad_wave(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const floa
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bs = {0.f, 0.f, 0.f, 0.f};                        // bias: column sums of abar over this lane's samples
-    fetch(k0);
+    fetchAP(k0); fetchHT(k0);
     for (int kb = k0; kb < k1; kb += WB_K) {
         if (kb + WB_K > k1) {                               // ragged chunk: rows past the split are zeros
 #pragma unroll
@@ -776,19 +773,29 @@ k_wgrad_wave(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const floa
 #pragma unroll
             for (int j = 0; j < 8; ++j) bs += ra[j];
         }
-        Op A[4], P[4], H[4], Tg[4];
+        // A wave issues in order: vector work and MFMAs overlap only where independent instructions of both kinds sit next to
+        // each other.  So: split the output side (exposed), request its next chunk at once (those raw registers are free),
+        // then the input-side comb cb + 1 is split BESIDE the 48 MFMAs of comb cb, and the input side's next chunk is
+        // requested as soon as its last comb has been split.
+        const bool more = kb + WB_K < k1;
+        Op A[4], P[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { A[c] = split8(ra, c); P[c] = split8(rp, c); H[c] = split8(rh, c); Tg[c] = split8(rt, c); }
-        if (kb + WB_K < k1) fetch(kb + WB_K);               // the raw registers are free: the next chunk travels under the MFMAs
-        // 16 accumulator tiles x 12 terms; consecutive MFMAs go to different accumulators (no back-to-back dependence)
+        for (int c = 0; c < 4; ++c) { A[c] = split8(ra, c); P[c] = split8(rp, c); }
+        if (more) fetchAP(kb + WB_K);
+        Op Hc = split8(rh, 0), Tc = split8(rt, 0);
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
+            Op Hn = Hc, Tn = Tc;
+            if (cb < 3) { Hn = split8(rh, cb + 1); Tn = split8(rt, cb + 1); }
+            if (cb == 2 && more) fetchHT(kb + WB_K);         // (comb 3 has just been split: rh, rt are free)
+            // 4 accumulator tiles x 12 terms; consecutive MFMAs go to different accumulators (no back-to-back dependence)
 #define WGW_TERM(X, Y, xa, yb) _Pragma("unroll") for (int ca_ = 0; ca_ < 4; ++ca_) \
-            acc[ca_][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[ca_].xa, Y[cb].yb, acc[ca_][cb], 0, 0, 0);
-            WGW_TERM(A, H, l, h) WGW_TERM(P, Tg, l, h) WGW_TERM(A, H, h, l) WGW_TERM(P, Tg, h, l)      // smallest terms first
-            WGW_TERM(A, H, m, m) WGW_TERM(P, Tg, m, m) WGW_TERM(A, H, m, h) WGW_TERM(P, Tg, m, h)
-            WGW_TERM(A, H, h, m) WGW_TERM(P, Tg, h, m) WGW_TERM(A, H, h, h) WGW_TERM(P, Tg, h, h)
+            acc[ca_][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[ca_].xa, Y.yb, acc[ca_][cb], 0, 0, 0);
+            WGW_TERM(A, Hc, l, h) WGW_TERM(P, Tc, l, h) WGW_TERM(A, Hc, h, l) WGW_TERM(P, Tc, h, l)      // smallest terms first
+            WGW_TERM(A, Hc, m, m) WGW_TERM(P, Tc, m, m) WGW_TERM(A, Hc, m, h) WGW_TERM(P, Tc, m, h)
+            WGW_TERM(A, Hc, h, m) WGW_TERM(P, Tc, h, m) WGW_TERM(A, Hc, h, h) WGW_TERM(P, Tc, h, h)
 #undef WGW_TERM
+            Hc = Hn; Tc = Tn;
         }
     }
     // acc[ca][cb][j] = sum over the samples of abar[.][o] * h[.][i] + pbar * t  with  o = o0 + 4 (4 sg + j) + ca,  i = i0 + 4 cg + cb
