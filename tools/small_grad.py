@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 import continuousnf.jl_amd as cnf
 from continuousnf.jl_amd import configs
