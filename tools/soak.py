@@ -10,7 +10,7 @@ rng = np.random.default_rng(11)
 icnfs = [configs.build(wl, kernel="mfma", sol_kwargs=dict(configs.README_TOLERANCES)),
          configs.build(wl, kernel="mfma", jvp=True, sol_kwargs=dict(configs.README_TOLERANCES))]
 flat = torch.from_numpy(configs.glorot_params(wl.dims, 3)).to(dev)
-t0 = time.time(); n = 0; launches = set(); nsub = 0
+t0 = time.time(); n = 0; launches = set(); nsub = 0; ngrad = 0
 secs = float(os.environ.get("SOAK_S", "60"))
 while time.time() - t0 < secs:
     B = int(rng.choice([1, 7, 32, 33, 500, 4096, 8191, 8192, 8193, 12000]))
@@ -36,5 +36,10 @@ while time.time() - t0 < secs:
             if batch[i][2] is not None:
                 assert torch.equal(o[0], batch[i][2]) and torch.equal(o[2], batch[i][3]), (B, n)
         nsub += len(batch)
+    if n % 40 == 7 and B <= 8192:
+        # the gradient of the same columns twice: bit-equal (no atomics anywhere on the gradient path), finite
+        g = [cnf.loss_and_grad(icnfs[0], cnf.TrainMode(), xs, flat, {}, eps=eps) for _ in range(2)]
+        assert g[0][0] == g[1][0] and torch.equal(g[0][1], g[1][1]) and torch.isfinite(g[0][1]).all(), (B, n)
+        ngrad += 1
     n += 1
-print("soak:", n, "inferences +", nsub, "submitted in", int(secs), "s, all finite, submitted == synchronous;", sorted(launches))
+print("soak:", n, "inferences +", nsub, "submitted +", ngrad, "gradient pairs in", int(secs), "s, all finite, submitted == synchronous, gradients bit-equal;", sorted(launches))
