@@ -832,7 +832,8 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
     schedule of the one-launch solve), CNF_SOLVE_POLL_LIMIT=1 (every wait of the one-launch solve runs out: the streamed
     fallback), CNF_STEP_FP32 (the fp32-MFMA step
     kernels k_step3 / k_step3j instead of the split-bf16 ones), CNF_STEP_V1 /
-    CNF_TRACE_GENERIC / CNF_ADJ_GENERIC (the first-generation kernels): read once per process; each route runs its parity
+    CNF_TRACE_GENERIC / CNF_ADJ_GENERIC (the first-generation kernels), CNF_WGRAD_LDS (the contraction with LDS images,
+    k_wgrad_mfma_b, instead of the wave-local k_wgrad_wave): read once per process; each route runs its parity
     tests in a child process."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -847,7 +848,8 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
                      ("CNF_STEP_V1", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve"),
                      ("CNF_TRACE_GENERIC", "test_exact_trace_mfma_deep_networks"),
                      ("CNF_TRACE_FP32", "test_exact_trace_mfma_deep_networks"),
-                     ("CNF_ADJ_GENERIC", "test_loss_grad_fixed_dt_matches_oracle and 3-mfma or test_loss_grad_headline")):
+                     ("CNF_ADJ_GENERIC", "test_loss_grad_fixed_dt_matches_oracle and 3-mfma or test_loss_grad_headline"),
+                     ("CNF_WGRAD_LDS", "test_loss_grad_fixed_dt_matches_oracle and 3-mfma or test_loss_grad_headline")):
         name, _, val = var.partition("=")
         env = dict(os.environ, **{name: val or "1", "CNF_NO_PARITY_REPORT": "1"})
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x",
