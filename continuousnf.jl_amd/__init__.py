@@ -46,7 +46,7 @@ from .base_icnf import (ICNF, ODEProblem, base_sol, construct, generate, generat
                         inference, inference_collect, inference_prob, inference_submit,
                         inference_sol, loss, loss_and_grad, loss_from_sums, loss_sums, n_augment,
                         n_augment_input, steer_tspan)
-from .dist import CondICNFDist, ICNFDist, logpdf, pdf, rand
+from .dist import CondICNFDist, ICNFDist, ICNFDistribution, logpdf, pdf, rand, rand_
 from .icnf import augmented_f
 from .layers import Chain, CondLayer, Dense, PlanarLayer, setup
 from .types import (FFJORD, RNODE, CondFFJORD, CondPlanar, CondRNODE, HIPJacVecMatrixMode,

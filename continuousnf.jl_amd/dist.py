@@ -18,7 +18,19 @@ def _from_machine(m):
     return m.model.m, ps, st
 
 
-class ICNFDist:
+class ICNFDistribution:
+    """src/exts/dist_ext/core.jl:3-16 (``ICNFDistribution <: ContinuousMultivariateDistribution``): ``length(d)`` is the
+    number of variables, ``eltype(d)`` the model's float type."""
+
+    def __len__(self):
+        return self.m.nvars
+
+    @property
+    def eltype(self):
+        return np.float32                                 # (the HIP compute modes are Float32: types.py)
+
+
+class ICNFDist(ICNFDistribution):
     """``ICNFDist(icnf, mode, ps, st)`` or, from a fitted machine, ``ICNFDist(mach, mode)`` (core_icnf.jl:1-11)."""
 
     def __init__(self, m, mode, ps=None, st=None):
@@ -27,7 +39,7 @@ class ICNFDist:
         self.m, self.mode, self.ps, self.st = m, mode, ps, st
 
 
-class CondICNFDist:
+class CondICNFDist(ICNFDistribution):
     """src/exts/dist_ext/core_cond_icnf.jl:1-16: ``CondICNFDist(icnf, mode, ys, ps, st)`` / ``CondICNFDist(mach, mode, ys)``."""
 
     def __init__(self, m, mode, ys, ps=None, st=None):
@@ -64,3 +76,15 @@ def rand(d: ICNFDist, n: int = None, *, z0=None, eps=None):
     if isinstance(d, CondICNFDist):
         return generate(d.m, d.mode, d.ps, d.st, n, ys=d.ys[:, :n], z0=z0, eps=eps)
     return generate(d.m, d.mode, d.ps, d.st, n, z0=z0, eps=eps)
+
+
+def rand_(d: ICNFDist, A, *, z0=None, eps=None):
+    """``rand!(d, A)`` (src/exts/dist_ext/core_icnf.jl:34-58, ``Distributions._rand!``): fills the vector (one draw) or the
+    columns of the matrix ``A`` in place and returns it."""
+    vec = (A.dim() if _is_torch(A) else np.ndim(A)) == 1
+    draw = rand(d, None if vec else A.shape[1], z0=z0, eps=eps)
+    if _is_torch(A):
+        A.copy_(draw if _is_torch(draw) else type(A)(draw))
+    else:
+        A[...] = draw.cpu().numpy() if _is_torch(draw) else draw
+    return A

@@ -578,6 +578,11 @@ def test_call_matrix_of_the_reference(kernel):
                         d = cnf.CondICNFDist(icnf, omode, r2, flat, {}) if cond else cnf.ICNFDist(icnf, omode, flat, {})
                         assert np.isfinite(cnf.logpdf(d, r)).all() and np.isfinite(cnf.pdf(d, r)).all()
                         assert cnf.rand(d).shape == (nvars,) and cnf.rand(d, ndata).shape == (nvars, ndata)
+                        # (src/exts/dist_ext/core.jl:6-12, core_icnf.jl:34-58: length, eltype, rand!)
+                        assert len(d) == nvars and d.eltype == np.float32
+                        buf = np.full((nvars, ndata), np.nan, np.float32)
+                        assert cnf.rand_(d, buf) is buf and np.isfinite(buf).all()
+                        assert np.isfinite(cnf.rand_(d, np.full(nvars, np.nan, np.float32))).all()
                         if train:            # (the gradients are TrainMode's, the mode the reference trains in)
                             val, gps, gx = cnf.loss_and_grad(icnf, omode, r, *args, with_x=True)
                             assert np.isfinite(val) and np.isfinite(gps).all() and gps.shape == flat.shape
