@@ -328,7 +328,7 @@ def n_augment_input(icnf: ICNF) -> int:
 def construct(aicnf, nn: Chain, nvars: int, naugmented: int = 0, *, data_type=np.float32,
               compute_mode=None, inplace: bool = False, cond=None, resource=None,
               tspan=(0.0, 1.0), steer_rate: float = 0.0, sol_kwargs=None, rng=None,
-              lambda1=None, lambda2=None, lambda3=0.0, device: int = 0, **kw) -> ICNF:
+              lambda1=None, lambda2=None, lambda3=0.0, device: int = 0, basedist=None, epsdist=None, **kw) -> ICNF:
     """src/base_icnf.jl:1-77.  Keyword names follow the reference; the lambdas may also be
     given under their Julia names via ``**{"λ₁": ...}``.  RNODE defaults lambda1 = lambda2 = 1e-2
     (src/base_icnf.jl:28-37), everything else 0."""
@@ -340,6 +340,10 @@ def construct(aicnf, nn: Chain, nvars: int, naugmented: int = 0, *, data_type=np
             else: lambda3 = v
     if kw:
         raise TypeError(f"unknown keyword(s) {sorted(kw)}")
+    if basedist is not None or epsdist is not None:
+        # src/base_icnf.jl:16-25: both default to MvNormal(0, I) over the nvars + naugmented rows -- the log-density of the
+        # final state (inference_sol) and the draws of eps / z are built for that default only
+        raise NotImplementedError("basedist / epsdist other than the default MvNormal(Zeros, Eye) are not built")
     if not (isinstance(aicnf, type) and issubclass(aicnf, AbstractICNF)):
         raise TypeError("first argument must be a model tag such as RNODE or FFJORD")
     if issubclass(aicnf, _OutOfScope):

@@ -73,6 +73,9 @@ def test_construct_rejects_what_is_out_of_scope_or_malformed():
         cnf.construct(cnf.RNODE, _nn(2), 2, compute_mode="DIVecJacMatrixMode")
     with pytest.raises(TypeError):
         cnf.construct(cnf.RNODE, _nn(2), 2, bogus=1)
+    with pytest.raises(NotImplementedError):            # src/base_icnf.jl:16-25: only the default base / eps distributions
+        cnf.construct(cnf.RNODE, _nn(2), 2, basedist="Laplace")
+    cnf.construct(cnf.RNODE, _nn(2), 2, basedist=None, epsdist=None)
     with pytest.raises(ValueError):
         cnf.Chain(cnf.Dense(2, 3), cnf.Dense(4, 2))
     with pytest.raises(ValueError):
