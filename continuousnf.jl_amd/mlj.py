@@ -64,8 +64,10 @@ class ICNFModel:
     """src/exts/mlj_ext/core_icnf.jl:1-29 (same field names and defaults; ``adtype`` has no meaning
     here -- the derivative is the device adjoint)."""
     m: ICNF
+    loss: Callable | None = None                            # the reference's second positional argument; None = `loss` (src/icnf.jl:481-490)
     optimizers: tuple = field(default_factory=lambda: (Lion(),))
     n_epochs: int = 300
+    adtype: Any = None                                      # accepted, unused: the derivative is the device adjoint
     use_batch: bool = True
     batch_size: int = 32
     sol_kwargs: dict = field(default_factory=dict)
@@ -88,6 +90,10 @@ def fit(model: ICNFModel, verbosity: int, X, ys=None):
     a numpy array.  ``ys`` (n x n_cond) for the conditional models (core_cond_icnf.jl)."""
     import torch
     icnf = model.m
+    if model.loss is not None:
+        from .base_icnf import loss as _builtin_loss
+        if model.loss is not _builtin_loss:
+            raise NotImplementedError("ICNFModel.loss: the device adjoint differentiates the package's own loss (src/icnf.jl:481-490)")
     x = _device_matrix(icnf, X)
     n = x.shape[1]
     y = None

@@ -1146,7 +1146,8 @@ def test_fit_matrix_of_the_reference():
                 for cm in (cnf.HIPVecJacMatrixMode(), cnf.HIPJacVecMatrixMode()):
                     kw = dict(steer_rate=1e-1, lambda3=1e-2) if aug_steer else {}
                     icnf = cnf.construct(mt, nn, nvars, naugs, compute_mode=cm, inplace=inplace, rng=5, **kw)
-                    model = (cnf.CondICNFModel if cond else cnf.ICNFModel)(icnf, n_epochs=n_epochs)
+                    # (the reference's positional `loss` and its `adtype` keyword are accepted: core_icnf.jl:14-28)
+                    model = (cnf.CondICNFModel if cond else cnf.ICNFModel)(icnf, cnf.loss, n_epochs=n_epochs, adtype="AutoEnzyme")
                     mach = cnf.machine(model, (df, df2) if cond else df)
                     ps0, _ = cnf.setup(5, icnf.nn)
                     assert cnf.fit_(mach) is mach and mach.report["stats"]["iterations"] == n_epochs
