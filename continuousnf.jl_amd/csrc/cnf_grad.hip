@@ -725,27 +725,24 @@ k_wgrad_wave(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const floa
     const unsigned offA = 4u * ((unsigned)ga + (unsigned)(8 * sg) * (unsigned)gl.sum_out);     // BYTES from the chunk's first row
     const unsigned offB = 4u * ((unsigned)gb + (unsigned)(8 * sg) * (unsigned)gl.sum_in);
     struct Op { bf16x8 h, m, l; };
-    f32x4 ra[8], rp[8], rh[8], rt[8];                       // raw chunk: [row j of the sample group][4 columns]
-    // (plain loads: the compiler keeps track of what is in flight -- it moves registers around in this 440-register kernel,
-    // and a copy of a register whose load has not landed yet reads garbage; hand-written requests were tried and did that)
-    auto ld4 = [](const float* base, unsigned off) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off); };
-    // one side of a chunk (X, Y = abar, pbar or h, t): 8 rows of the lane's sample group, row bases by scalar arithmetic
-    auto fetch2 = [&](f32x4 (&x)[8], f32x4 (&y)[8], const float* X, const float* Y, int sum, int col0, int g4, unsigned off, int kb) {
-        const float* bX = X + (size_t)kb * sum + col0;
-        const float* bY = Y + (size_t)kb * sum + col0;
-        if (kb + WB_K <= k1) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { x[j] = ld4(bX + (size_t)j * sum, off); y[j] = ld4(bY + (size_t)j * sum, off); }
-        } else {                                           // the last, ragged chunk: rows clamped to the split's last row
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned o = 4u * ((unsigned)g4 + (unsigned)(min(kb + 8 * sg + j, k1 - 1) - kb) * (unsigned)sum);
-                x[j] = ld4(bX, o); y[j] = ld4(bY, o);
-            }
-        }
+    // raw chunk: [row j of the sample group][4 columns].  (A second chunk in flight -- 512 registers -- was measured: 256 against
+    // 240 us; the kernel runs at the same speed WITHOUT its MFMAs and splits: it is bound by the memory system's
+    // throughput on this access pattern, 0.91 GB from HBM + 0.7 GB of L2 hits per four-step launch.)
+    struct Raw { f32x4 a[8], p[8], h[8], t[8]; };
+    Raw r0_;
+    // Buffer loads: descriptor base = the K-split's first row at the tile's first column, record count = up to the split's
+    // last row, so rows past the split (its ragged last chunk) come back as zeros by the range check; a request is
+    // descriptor + the lane's byte offset (one register per side) + a scalar row offset.  (Plain loads cost 112 64-bit vector
+    // adds per chunk here, and hand-written requests are unsafe: the compiler copies their destination registers.)
+    auto rsrc = [&](const float* X, int sum, int col0) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + (size_t)k0 * sum + col0), 0, (int)(((size_t)(k1 - k0) * sum - col0) * 4), 0x00020000);
     };
-    auto fetchAP = [&](int kb) { fetch2(ra, rp, AB, PB, gl.sum_out, oo + o0, ga, offA, kb); };
-    auto fetchHT = [&](int kb) { fetch2(rh, rt, HS, TSb, gl.sum_in, io + i0, gb, offB, kb); };
+    const auto dA = rsrc(AB, gl.sum_out, oo + o0), dP = rsrc(PB, gl.sum_out, oo + o0);
+    const auto dH = rsrc(HS, gl.sum_in, io + i0), dT = rsrc(TSb, gl.sum_in, io + i0);
+    auto fetch = [&](f32x4 (&x)[8], decltype(dA) d, int sum, unsigned off, int kb) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d, (int)off, (kb - k0 + j) * sum * 4, 0));
+    };
     auto split8 = [&](const f32x4 (&r)[8], int c) {         // column c of the lane's four: its 8 samples -> three bf16x8 pieces
         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
         u32x4_ hp, mp, lp;
@@ -762,41 +759,48 @@ k_wgrad_wave(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const floa
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bs = {0.f, 0.f, 0.f, 0.f};                        // bias: column sums of abar over this lane's samples
-    fetchAP(k0); fetchHT(k0);
-    for (int kb = k0; kb < k1; kb += WB_K) {
-        if (kb + WB_K > k1) {                               // ragged chunk: rows past the split are zeros
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (kb + 8 * sg + j >= k1) { ra[j] = f32x4{0.f, 0.f, 0.f, 0.f}; rp[j] = ra[j]; rh[j] = ra[j]; rt[j] = ra[j]; }
-        }
-        if (ti == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bs += ra[j];
-        }
-        // A wave issues in order: vector work and MFMAs overlap only where independent instructions of both kinds sit next to
-        // each other.  So: split the output side (exposed), request its next chunk at once (those raw registers are free),
-        // then the input-side comb cb + 1 is split BESIDE the 48 MFMAs of comb cb, and the input side's next chunk is
-        // requested as soon as its last comb has been split.
+    auto fetch_all = [&](Raw& r, int kb) {
+        fetch(r.a, dA, gl.sum_out, offA, kb); fetch(r.h, dH, gl.sum_in, offB, kb);
+        fetch(r.p, dP, gl.sum_out, offA, kb); fetch(r.t, dT, gl.sum_in, offB, kb);
+    };
+    fetch_all(r0_, k0);
+    // One factor pair of a chunk, X (output side) x Y (input side): the two pairs (abar x h, pbar x t) go one after the other so
+    // that only one pair's split operands are alive (both at once pushed half of them through AGPR copies).  A wave issues in
+    // order, so vector work and MFMAs overlap only where independent instructions of both kinds sit next to each other:
+    // the output side is split first (exposed) and its next chunk requested at once (those raw registers are free), then
+    // input-side comb cb + 1 is split BESIDE the 24 MFMAs of comb cb, and the input side's next chunk is requested as soon
+    // as its last comb has been split.
+    auto pair = [&](f32x4 (&rx)[8], f32x4 (&ry)[8], decltype(dA) X, decltype(dA) Y, int kb, bool bias) {
         const bool more = kb + WB_K < k1;
-        Op A[4], P[4];
+        if (bias) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { A[c] = split8(ra, c); P[c] = split8(rp, c); }
-        if (more) fetchAP(kb + WB_K);
-        Op Hc = split8(rh, 0), Tc = split8(rt, 0);
+            for (int j = 0; j < 8; ++j) bs += rx[j];
+        }
+        Op O[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) O[c] = split8(rx, c);
+        if (more) fetch(rx, X, gl.sum_out, offA, kb + WB_K);
+        Op Ic = split8(ry, 0);
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
-            Op Hn = Hc, Tn = Tc;
-            if (cb < 3) { Hn = split8(rh, cb + 1); Tn = split8(rt, cb + 1); }
-            if (cb == 2 && more) fetchHT(kb + WB_K);         // (comb 3 has just been split: rh, rt are free)
-            // 4 accumulator tiles x 12 terms; consecutive MFMAs go to different accumulators (no back-to-back dependence)
-#define WGW_TERM(X, Y, xa, yb) _Pragma("unroll") for (int ca_ = 0; ca_ < 4; ++ca_) \
-            acc[ca_][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[ca_].xa, Y.yb, acc[ca_][cb], 0, 0, 0);
-            WGW_TERM(A, Hc, l, h) WGW_TERM(P, Tc, l, h) WGW_TERM(A, Hc, h, l) WGW_TERM(P, Tc, h, l)      // smallest terms first
-            WGW_TERM(A, Hc, m, m) WGW_TERM(P, Tc, m, m) WGW_TERM(A, Hc, m, h) WGW_TERM(P, Tc, m, h)
-            WGW_TERM(A, Hc, h, m) WGW_TERM(P, Tc, h, m) WGW_TERM(A, Hc, h, h) WGW_TERM(P, Tc, h, h)
+            Op In = Ic;
+            if (cb < 3) In = split8(ry, cb + 1);
+            if (cb == 2 && more) fetch(ry, Y, gl.sum_in, offB, kb + WB_K);   // (comb 3 has just been split: ry is free)
+            // 4 accumulator tiles x 6 terms; consecutive MFMAs go to different accumulators (no back-to-back dependence)
+#ifdef WB_ABL_NOMFMA
+#define WGW_TERM(xa, yb) _Pragma("unroll") for (int ca_ = 0; ca_ < 4; ++ca_) asm volatile("" : "+v"(acc[ca_][cb]) : "v"(O[ca_].xa), "v"(Ic.yb));
+#else
+#define WGW_TERM(xa, yb) _Pragma("unroll") for (int ca_ = 0; ca_ < 4; ++ca_) \
+            acc[ca_][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(O[ca_].xa, Ic.yb, acc[ca_][cb], 0, 0, 0);
+#endif
+            WGW_TERM(l, h) WGW_TERM(h, l) WGW_TERM(m, m) WGW_TERM(m, h) WGW_TERM(h, m) WGW_TERM(h, h)      // smallest terms first
 #undef WGW_TERM
-            Hc = Hn; Tc = Tn;
+            Ic = In;
         }
+    };
+    for (int kb = k0; kb < k1; kb += WB_K) {
+        pair(r0_.a, r0_.h, dA, dH, kb, ti == 0);
+        pair(r0_.p, r0_.t, dP, dT, kb, false);
     }
     // acc[ca][cb][j] = sum over the samples of abar[.][o] * h[.][i] + pbar * t  with  o = o0 + 4 (4 sg + j) + ca,  i = i0 + 4 cg + cb
     float* g = gpart + (size_t)by * n_params;
