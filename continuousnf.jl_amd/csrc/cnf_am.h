@@ -155,7 +155,13 @@ __device__ __forceinline__ float am_colnorm2(const float* X, int PS, int n, floa
 // 4 values of a global [sample][feature] row: one 16-byte store when the row layout allows it
 __device__ __forceinline__ void am_store4(float* g, f32x4 v, int r0, int n_valid, bool vec) {
 #ifndef AM_ABL_NOSTORE
+    // (non-temporal: the factor arrays are written once and read back a step group later by the contraction, 0.9 GB on -- with
+    // ordinary stores the contraction's reads ran 13 % slower, 239 against 209 us; A/B: -DAM_PLAIN_STORE)
+#ifdef AM_PLAIN_STORE
     if (vec && r0 + 3 < n_valid) *reinterpret_cast<f32x4*>(g) = v;
+#else
+    if (vec && r0 + 3 < n_valid) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g));
+#endif
     else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (r0 + j < n_valid) g[j] = v[j];

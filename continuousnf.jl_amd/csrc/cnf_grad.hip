@@ -741,7 +741,10 @@ k_wgrad_wave(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const floa
     const auto dH = rsrc(HS, gl.sum_in, io + i0), dT = rsrc(TSb, gl.sum_in, io + i0);
     auto fetch = [&](f32x4 (&x)[8], decltype(dA) d, int sum, unsigned off, int kb) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d, (int)off, (kb - k0 + j) * sum * 4, 0));
+#ifndef WGW_AUX
+#define WGW_AUX 0
+#endif
+        for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d, (int)off, (kb - k0 + j) * sum * 4, WGW_AUX));
     };
     auto split8 = [&](const f32x4 (&r)[8], int c) {         // column c of the lane's four: its 8 samples -> three bf16x8 pieces
         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
@@ -1484,7 +1487,7 @@ k_adj3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img
         for (int d = 0; d < 4; ++d) K[hs][d] = K[hs][d + 1];          // the next stage's sum moves to the front
         K[hs][4] = 0.f;
         lds[e2 * PS + m.S0 + ec] = xpf[hs];
-        if (ev && ec < in0) a.HS[(size_t)eb * gl.sum_in + ec] = xpf[hs];
+        if (ev && ec < in0) __builtin_nontemporal_store(xpf[hs], a.HS + (size_t)eb * gl.sum_in + ec);
     }
     am_barrier();
     AM_STAMP(0);
@@ -1600,7 +1603,7 @@ k_adj3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img
                 float v = 0.f;
                 if (r < n_in) v = fmaf(inv, lds[e2 * PS + cur + r], -a.c_l * lds[e2 * PS + m.E + r]);
                 lds[e2 * PS + nxt + r] = v;
-                if (ev && r < in0) a.TS[(size_t)eb * gl.sum_in + r] = v;
+                if (ev && r < in0) __builtin_nontemporal_store(v, a.TS + (size_t)eb * gl.sum_in + r);
             }
         }
     }
