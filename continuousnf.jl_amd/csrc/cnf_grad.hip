@@ -836,13 +836,19 @@ static bool wgrad_wave_ok(const NetDesc& nd, const GradLayout& g) {      // 16-b
     return true;
 }
 
-// grad[p] = sum over the K-splits, in a fixed order
-__global__ void k_grad_reduce(const float* __restrict__ gpart, float* __restrict__ grad, int n_params, int ksplit) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_params) return;
+// grad[p] = sum over the K-splits, in a fixed order: 64 parameters per workgroup, four threads per parameter take every
+// fourth split (up to 128 splits: one thread per parameter walked them in 31 us), their partial sums are added in order
+__global__ void __launch_bounds__(256)
+k_grad_reduce(const float* __restrict__ gpart, float* __restrict__ grad, int n_params, int ksplit) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += gpart[(size_t)k * n_params + p];
-    grad[p] = s;
+    if (p < n_params)
+        for (int k = q; k < ksplit; k += 4) s += gpart[(size_t)k * n_params + p];
+    part[q][c] = s;
+    __syncthreads();
+    if (q == 0 && p < n_params) grad[p] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
 // WT_l[i + o*in] = W_l[o + i*out]  (same offsets as the flat vector; biases are not copied)
@@ -997,7 +1003,7 @@ hipError_t launch_wgrad(const NetDesc& nd, const GradLayout& g, const float* AB,
 }
 
 hipError_t launch_grad_reduce(const float* gpart, float* grad, int n_params, int ksplit, hipStream_t s) {
-    hipLaunchKernelGGL(k_grad_reduce, dim3((n_params + 255) / 256), dim3(256), 0, s, gpart, grad, n_params, ksplit);
+    hipLaunchKernelGGL(k_grad_reduce, dim3((n_params + 63) / 64), dim3(256), 0, s, gpart, grad, n_params, ksplit);
     return hipGetLastError();
 }
 
