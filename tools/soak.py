@@ -10,7 +10,7 @@ rng = np.random.default_rng(11)
 icnfs = [configs.build(wl, kernel="mfma", sol_kwargs=dict(configs.README_TOLERANCES)),
          configs.build(wl, kernel="mfma", jvp=True, sol_kwargs=dict(configs.README_TOLERANCES))]
 flat = torch.from_numpy(configs.glorot_params(wl.dims, 3)).to(dev)
-t0 = time.time(); n = 0; launches = set(); nsub = 0; ngrad = 0
+t0 = time.time(); tlast = t0; n = 0; launches = set(); nsub = 0; ngrad = 0
 secs = float(os.environ.get("SOAK_S", "60"))
 while time.time() - t0 < secs:
     B = int(rng.choice([1, 7, 32, 33, 500, 4096, 8191, 8192, 8193, 12000]))
@@ -42,4 +42,6 @@ while time.time() - t0 < secs:
         assert g[0][0] == g[1][0] and torch.equal(g[0][1], g[1][1]) and torch.isfinite(g[0][1]).all(), (B, n)
         ngrad += 1
     n += 1
+    if time.time() - tlast > 60:                      # (a line a minute: a silent run is taken to be hung on the GPU box)
+        tlast = time.time(); print("  ...", n, "inferences,", int(tlast - t0), "s", flush=True)
 print("soak:", n, "inferences +", nsub, "submitted +", ngrad, "gradient pairs in", int(secs), "s, all finite, submitted == synchronous, gradients bit-equal;", sorted(launches))
