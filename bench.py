@@ -36,7 +36,7 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # kernel arguments in de
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0       # spec
-PMC_FILE = os.path.join("profiles", "round3_step_kernel_pmc.json")   # tools/collect_profiles.sh + summarize_profiles.py
+PMC_FILE = os.path.join("profiles", "round4_step_kernel_pmc.json")   # tools/collect_profiles.sh + summarize_profiles.py
 
 
 def parse_args():
@@ -49,6 +49,10 @@ def parse_args():
     ap.add_argument("--fixed-dt", type=float, default=0.0, help="use fixed steps instead of adaptive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not start the rocprofv3 child passes that measure roofline.traffic")
+    ap.add_argument("--prewarm", type=float, default=0.4,
+                    help="seconds of untimed solves before the W counted warm-up steps: holds the clocks (DVFS) so that a short "
+                         "timed region does not sit on the ramp")
+    ap.add_argument("--fp32-child", action="store_true", help=argparse.SUPPRESS)   # internal: the CNF_STEP_FP32=1 leg
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2, 3],
                     help="steps in flight: 2 = each step is submitted while the one before it runs (default); 1 = one at a time")
     return ap.parse_args()
@@ -103,6 +107,7 @@ def cpu_baseline(B, flat, xs, eps, kw, budget_s=9.0):
     os.environ.setdefault("OMP_NUM_THREADS", str(BL.available_cores()))     # before the OpenMP port is loaded
     from oracle import c_oracle as CO
     from oracle import cnf_oracle as O
+    march = CO.use_native()                               # -march=native on an AVX-512 host, else the portable x86-64-v3 build
     cfg, _, _ = O.baseline_cfg(3)
     u0 = O.inference_u0(cfg, xs, True)
     nthr, _ = BL.tune_threads(cfg, flat, u0, eps)         # the fastest thread count on this host (stated as `cores`)
@@ -111,6 +116,7 @@ def cpu_baseline(B, flat, xs, eps, kw, budget_s=9.0):
     blas = {"value": nf / el, "unit": "RHS-evals/s", "cores": nthr, "host_cores": BL.os_cpu_count(),
             "available_cores": BL.available_cores(), "kind": "port",
             "achieved_gflops": nf / el * B * (4.0 * M + 6.0 * cfg.n_in) / 1e9,
+            "nf_per_solve": st["nf"], "naccept": st.get("naccept"), "nreject": st.get("nreject"),
             "impl": "float32 sgemm over the full n x B matrices + tanh AND the Tsit5 driver (stage combinations, error "
                     "estimate, norms) as threaded torch-CPU ops on (D, B) tensors, no numpy round trips "
                     "(oracle/cnf_blas.py: solve_torch)",
@@ -122,8 +128,9 @@ def cpu_baseline(B, flat, xs, eps, kw, budget_s=9.0):
     port = {"value": nf / el, "unit": "RHS-evals/s", "cores": CO.threads(), "kind": "port",
             "host_cores": BL.os_cpu_count(), "available_cores": BL.available_cores(),
             "achieved_gflops": nf / el * B * (4.0 * M + 6.0 * cfg.n_in) / 1e9,
+            "nf_per_solve": st["nf"], "naccept": st.get("naccept"), "nreject": st.get("nreject"),
             "impl": "C/OpenMP restatement: 16-sample blocks, four output rows per pass over the operand (gcc -O3 "
-                    "-march=x86-64-v3), libm tanhf (oracle/cnf_oracle.c)",
+                    f"{march}, built on this host), libm tanhf (oracle/cnf_oracle.c)",
             "sample": f"{n} adaptive Tsit5 solves of the same workload (B={B}, nf={st['nf']} each); restatement "
                       f"of the reference path (the Julia package cannot run here)", "seconds": el}
     model = "unknown"
@@ -148,8 +155,14 @@ def measure_traffic_live(kernel_substr, timeout_s=150):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
+    # never start a profiler from under a profiler: the outer tool's preloaded library has initialised the GPU in this
+    # process tree, and the child launcher (a python script that then execs) is the forbidden exec on this pool
+    if any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR", "ROCPROF_OUTPUT_PATH", "ROCPROFILER_REGISTER_FORCE_LOAD")) \
+            or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "already under a profiler"
     tmp = tempfile.mkdtemp(prefix="cnf_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", HIP_FORCE_DEV_KERNARG="1")
+    env = {k: v for k, v in os.environ.items() if not (k.startswith("ROCP") or k == "LD_PRELOAD")}
+    env.update(TMPDIR="/tmp", HIP_FORCE_DEV_KERNARG="1")
     vals = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -170,6 +183,34 @@ def measure_traffic_live(kernel_substr, timeout_s=150):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return 2.0 * vals["FETCH_SIZE"][0] * 1024.0 + vals["WRITE_SIZE"][0] * 1024.0, min(vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1])
+
+
+def fp32_child_leg(args):
+    """The headline steps on the fp32-MFMA kernels (CNF_STEP_FP32=1: k_step3, streamed step launches), in a child process
+    started after the timed region.  Returns the child's figures, with the fp32 roofline fraction they amount to."""
+    env = {k: v for k, v in os.environ.items() if not (k.startswith("ROCP") or k == "LD_PRELOAD")}
+    env.update(CNF_STEP_FP32="1", HIP_FORCE_DEV_KERNARG="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--fp32-child", "--steps", str(max(10, min(args.steps, 50))), "--warmup", "3",
+           "--batch", str(args.batch), "--depth", "1", "--no-pmc", "--no-cpu-baseline", "--kernel", args.kernel]
+    if args.fixed_dt > 0:
+        cmd += ["--fixed-dt", str(args.fixed_dt)]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=180)
+        line = [l for l in r.stdout.splitlines() if l.startswith("FP32CHILD ")]
+        if r.returncode != 0 or not line:
+            return {"error": f"child rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+        rec = json.loads(line[-1][len("FP32CHILD "):])
+    except Exception as e:                                   # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    from continuousnf.jl_amd import configs
+    wl = configs.BASELINE[3]
+    M = sum(a * b for a, b in zip(wl.dims[:-1], wl.dims[1:]))
+    tf = rec["value"] * args.batch * (4.0 * M + 6.0 * wl.n_in) / 1e12
+    rec.update({"kernel": "k_step3 (v_mfma_f32_16x16x4_f32, one step attempt per launch), CNF_STEP_FP32=1",
+                "unit": "RHS-evals/s", "achieved_tflops_whole_step": tf, "frac_of_fp32_peak_whole_step": tf / PEAK_F32_TFLOPS})
+    return rec
 
 
 def run_rank(args):
@@ -265,9 +306,25 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # hold the clocks: `--prewarm` seconds of the same steps first (the driver's K and W can be a handful: 20 solves are
+    # 15 ms, which would sit on the DVFS ramp), then the W counted warm-up steps
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < args.prewarm:
+        step()
     for _ in range(args.warmup):
         step()
     sync()
+    if args.fp32_child:
+        # the CNF_STEP_FP32=1 leg of the parent's JSON line: the same steps on the fp32-MFMA kernels (k_step3), timed alone
+        t0 = time.perf_counter(); nf = 0
+        for _ in range(args.steps):
+            st, _ = step(); nf += st["nf"]
+        sync()
+        el = time.perf_counter() - t0
+        print("FP32CHILD " + json.dumps({"value": nf / el, "ms_per_step": el / args.steps * 1e3, "nf_per_solve": st["nf"],
+                                         "launches_per_solve": st["launches"], "steps": args.steps}), flush=True)
+        icnf.close()
+        return
     # the one-launch solve adds up its own durations on the device (100 MHz real-time clock, workgroup 0, entry to exit)
     # while the timed region runs: nothing is added to the region, the total is read after it
     import ctypes as C
@@ -279,16 +336,18 @@ def run_rank(args):
     t0 = time.perf_counter()
     nf_total = 0
     if args.depth > 1:
+        # (the all-reduce of a step's sums is enqueued AFTER its collect: a launch that fell back to the streamed driver
+        # has its sums only then; the next step is already running behind it, so the GPU still goes from solve to solve)
         pend = []
         for _ in range(args.steps):
             _, _, local = cnf.inference_submit(icnf, mode, xs, ps, {}, eps=eps, with_sums=True)
-            pend.append(reduce_sums(local))
+            pend.append(local)
             if len(pend) >= args.depth:
                 nf_total += cnf.inference_collect(icnf)["nf"]
-                sums = pend.pop(0)
+                sums = reduce_sums(pend.pop(0))
         while pend:
             nf_total += cnf.inference_collect(icnf)["nf"]
-            sums = pend.pop(0)
+            sums = reduce_sums(pend.pop(0))
         st = icnf.last_stats
     else:
         for _ in range(args.steps):
@@ -423,6 +482,10 @@ def run_rank(args):
                                "(tools/ubench/bf16_split.hip, parity suite unchanged)") if split else "v_mfma_f32_16x16x4_f32",
                 "executed": ({"unit": "TFLOP/s bf16", "achieved": 6.0 * tf, "peak": PEAK_BF16_TFLOPS,
                               "frac": 6.0 * tf / PEAK_BF16_TFLOPS} if split else None),
+                # the same, flat: the ceiling of the instructions the kernel ISSUES, in fp32-equivalent flops (six bf16 MFMA
+                # terms per fp32 product: 2500 / 6), and the fraction of it reached -- to be read beside `frac`
+                "ceiling_executed": (PEAK_BF16_TFLOPS / 6.0 if split else PEAK_F32_TFLOPS),
+                "frac_executed": (tf / (PEAK_BF16_TFLOPS / 6.0) if split else tf / PEAK_F32_TFLOPS),
                 "launch_us": per_launch_s * 1e6,
                 "algorithmic_flops_per_launch": units * fl.value,
                 "algorithmic_bytes_per_launch": units * by.value,
@@ -450,10 +513,17 @@ def run_rank(args):
             "launches_per_solve": st["launches"], "steps_in_flight": args.depth, "one_at_a_time": one_at_a_time, "loss": loss,
             "roofline": roof,
         }
+        if world == 1 and roof is not None and os.environ.get("CNF_STEP_FP32") != "1" and st["kernel_used"] == _lib.KERNEL_MFMA:
+            # beside the split-bf16 number, outside the timed region: the SAME steps on the exact-fp32 MFMA kernels
+            # (v_mfma_f32_16x16x4_f32; CNF_STEP_FP32 is read once per process, hence a child; this process idles meanwhile)
+            roof["fp32_mfma"] = fp32_child_leg(args)
         if world == 1 and not args.no_cpu_baseline:
             kwb = dict(dt=args.fixed_dt, adaptive=False) if args.fixed_dt > 0 else kw
             out["cpu_baseline"], out["cpu_other"] = cpu_baseline(B, flat, xs_h, eps_h, kwb)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["nf_gpu_vs_cpu"] = {"gpu": st["nf"], "cpu": out["cpu_baseline"].get("nf_per_solve"),
+                                    "note": "same workload and tolerances; the error estimate is at round-off level here, so the "
+                                            "step count differs by an attempt between arithmetics (profiles/round3_step_trace.md)"}
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()

@@ -265,6 +265,12 @@ class ICNF:
         """One-launch solves of this handle that ran out of a wait and were run again on the streamed driver."""
         return int(_lib.lib().cnf_solve_fallbacks(self.handle()))
 
+    def set_solve_wait(self, wait_us: int = 0, poll_limit: int = 0):
+        """cnf_set_solve_wait: how long a wait inside a one-launch solve lasts (microseconds per tile a workgroup carries;
+        default 2000) and / or how many polls it makes (1: every wait runs out at once) before the call falls back to the
+        streamed driver.  0 keeps a value."""
+        _lib.check(_lib.lib().cnf_set_solve_wait(self.handle(), int(wait_us), int(poll_limit)), self.handle())
+
     def set_shard_reduce(self, fn):
         """Lock-step sharded solves (cnf_set_shard_reduce): ``fn(values)`` receives a
         writable float32 numpy view of the local sums and must replace it IN PLACE by the sum over
@@ -628,9 +634,12 @@ def inference_submit(icnf: ICNF, mode, xs, *args, eps=None, with_sums=False):
     xb = _as_colmajor(xs, icnf.nvars, "xs")
     B = xb.B
     l, h = _lib.lib(), icnf.handle()
-    if not l.cnf_inference_pending(h):          # (parameters and conditioning are not to change under submitted work)
-        icnf.set_params(ps)
-        icnf.set_cond(ys, B)
+    _trim_submitted(icnf)
+    # Every submission runs with ITS parameters and conditioning: the upload caches make these two calls free when nothing
+    # changed (the mini-batches of an epoch); when something did, the library first brings the inferences already submitted
+    # to their end (cnf_set_params / cnf_set_cond settle the queue: they stay collectable) and only then changes its state.
+    icnf.set_params(ps)
+    icnf.set_cond(ys, B)
     if eps is not None:
         eb = _as_colmajor(eps, icnf.nvars + n_augment_input(icnf), "eps")
         if eb.B != B:
@@ -653,9 +662,20 @@ def inference_submit(icnf: ICNF, mode, xs, *args, eps=None, with_sums=False):
     return (logpx, (r[0], r[1], r[2]), sums) if with_sums else (logpx, (r[0], r[1], r[2]))
 
 
+def _trim_submitted(icnf: ICNF):
+    """The buffers kept alive for submitted launches follow the library's queue: a synchronous call on the handle completes
+    (and drops) what was submitted before it, so entries beyond ``cnf_inference_pending`` are released oldest first."""
+    sub = getattr(icnf, "_submitted", None)
+    if sub:
+        n = max(0, int(_lib.lib().cnf_inference_pending(icnf.handle())))
+        if len(sub) > n:
+            del sub[:len(sub) - n]
+
+
 def inference_collect(icnf: ICNF):
     """Completes the oldest submitted inference (cnf_inference_collect); its statistics become ``icnf.last_stats``."""
     l, h = _lib.lib(), icnf.handle()
+    _trim_submitted(icnf)
     stats = _lib.cnf_solve_stats()
     _lib.check(l.cnf_inference_collect(h, C.byref(stats)), h)
     if getattr(icnf, "_submitted", None):

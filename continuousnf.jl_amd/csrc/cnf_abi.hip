@@ -68,6 +68,7 @@ struct cnf_ctx {
     bool no_persist = false;      // the fallback of a collected launch: straight to the streamed driver
     bool time_kernel = false;     // cnf_solve_kernel_time: the one-launch solve kernel adds up its own durations
     int fallbacks = 0;            // one-launch solves that ran out of a wait and were run again on the streamed driver
+    int wait_us = 0, poll_limit = 0;   // cnf_set_solve_wait (0: the process defaults)
     float* step_trace = nullptr;  // cnf_set_step_trace: caller-owned device buffer, 4 floats per step attempt
     int step_trace_cap = 0;
     float* partials = nullptr;    // 2 * MAX_PARTIALS floats
@@ -241,6 +242,10 @@ static void sync_submitted(cnf_handle h) {
     for (const auto& sub : h->submitted)
         if (sub.launched) (void)hipStreamSynchronize(sub.st);
 }
+// Before the parameters or the conditioning of a handle change, every inference submitted on it is brought to its END --
+// outcome read, and a launch that ran out of a wait run again on the streamed driver NOW, with the parameters and the
+// conditioning it was submitted with -- and stays in the queue as a completed entry for its collect call.
+static cnf_status settle_submitted(cnf_handle h);
 
 extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (!h) return CNF_ERR_BAD_ARG;
@@ -274,7 +279,7 @@ extern "C" cnf_status cnf_set_params(cnf_handle h, const float* flat_dev, size_t
     if (n != h->n_params) return fail(h, CNF_ERR_BAD_SHAPE, "parameter count does not match the layer sizes");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(h, hipSetDevice(h->device));
-    sync_submitted(h);
+    { const cnf_status ss = settle_submitted(h); if (ss != CNF_OK) return ss; }
     HIPCHK(h, hipMemcpyAsync(h->d_params, flat_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     cnf_status ms = mfma_plan_pack(h->mfma, h->nd, h->d_params, s);
     if (ms != CNF_OK) return fail(h, ms, "MFMA weight packing failed");
@@ -290,7 +295,7 @@ extern "C" cnf_status cnf_set_params_host(cnf_handle h, const float* flat, size_
     if (!h || !flat) return CNF_ERR_BAD_ARG;
     if (n != h->n_params) return fail(h, CNF_ERR_BAD_SHAPE, "parameter count does not match the layer sizes");
     HIPCHK(h, hipSetDevice(h->device));
-    sync_submitted(h);
+    { const cnf_status ss = settle_submitted(h); if (ss != CNF_OK) return ss; }
     HIPCHK(h, hipMemcpy(h->d_params, flat, n * sizeof(float), hipMemcpyHostToDevice));
     cnf_status ms = mfma_plan_pack(h->mfma, h->nd, h->d_params, nullptr);
     if (ms != CNF_OK) return fail(h, ms, "MFMA weight packing failed");
@@ -362,6 +367,8 @@ extern "C" cnf_status cnf_set_cond(cnf_handle h, const float* ys, int B, void* s
     if (!h->have_params) return fail(h, CNF_ERR_NO_PARAMS, "cnf_set_params has not been called");
     if (!ys || B < 1) return fail(h, CNF_ERR_BAD_ARG, "ys must be n_cond x B with B >= 1");
     HIPCHK(h, hipSetDevice(h->device));
+    // (a submitted inference reads d_cond until it ends, and its fallback would read it again: none may be outstanding)
+    { const cnf_status ss = settle_submitted(h); if (ss != CNF_OK) return ss; }
     const int cbs = (h->nd.dims[1] + 15) & ~15;
     if (h->cond_B != B || h->cbs != cbs) {
         HIPCHK(h, hipDeviceSynchronize());
@@ -515,6 +522,12 @@ extern "C" cnf_status cnf_selftest_split_product(const float* A, const float* Bt
 }
 
 extern "C" int cnf_solve_fallbacks(cnf_handle h) { return h ? h->fallbacks : -1; }
+extern "C" cnf_status cnf_set_solve_wait(cnf_handle h, int wait_us, int poll_limit) {
+    if (!h) return CNF_ERR_BAD_ARG;
+    if (wait_us > 0) h->wait_us = wait_us;
+    if (poll_limit > 0) h->poll_limit = poll_limit;
+    return CNF_OK;
+}
 
 extern "C" cnf_status cnf_rhs_work(cnf_handle h, int mode, int B, double* flops, double* bytes) {
     if (!h || !flops || !bytes) return CNF_ERR_BAD_ARG;
@@ -748,7 +761,10 @@ static cnf_status finish_one_launch(cnf_handle h, unsigned seq, int slot, hipStr
     }
     *aborted = fin->n_partials < 0;
     if (*aborted) {
+        // A workgroup dispatched late may have run after workgroup 0 advanced the index base and left words tagged with
+        // the NEXT launch's first meeting: with the stream drained, the meeting words are cleared along with the abort word.
         HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, hipMemset(h->partials, 0, 8 * MAX_PARTIALS * sizeof(float)));
         HIPCHK(h, hipMemset(h->d_sums + 11, 0, sizeof(float)));
     } else if (!fin->done && !fin->nonfinite) return fail(h, CNF_ERR_MAXITERS, "maxiters reached before t1");
     return CNF_OK;
@@ -833,9 +849,15 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         sv.part = h->partials; sv.base_dev = reinterpret_cast<unsigned*>(h->d_sums + 10); sv.abort_flag = reinterpret_cast<int*>(h->d_sums + 11);
         sv.t_out = h->time_kernel ? reinterpret_cast<unsigned long long*>(h->d_sums + 12) : nullptr;
         sv.maxiters = (int)opts->maxiters; sv.hairer = hairer ? 1 : 0; sv.init = *init;
-        // polls a wait inside the kernel makes before it gives up (seconds at the default; CNF_SOLVE_POLL_LIMIT: tests)
-        static const int spin_limit = [] { const char* e = getenv("CNF_SOLVE_POLL_LIMIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 21); }();
-        sv.spin_limit = spin_limit;
+        // How long a wait inside the kernel lasts before it gives up: bounded in TIME (the kernel's 100 MHz clock) -- 2 ms per
+        // tile a workgroup carries (a meeting's arrivals are microseconds apart when every workgroup is placed; a workgroup
+        // that is not placed because another tenant holds its CU makes the launch give up after that long, and the streamed
+        // solve starts).  CNF_SOLVE_WAIT_US overrides; CNF_SOLVE_POLL_LIMIT bounds the number of polls instead (tests: 1).
+        static const int spin_limit = [] { const char* e = getenv("CNF_SOLVE_POLL_LIMIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0x7fffffff; }();
+        static const int wait_us = [] { const char* e = getenv("CNF_SOLVE_WAIT_US"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2000; }();
+        sv.spin_limit = h->poll_limit > 0 ? h->poll_limit : spin_limit;
+        const int wus = h->wait_us > 0 ? h->wait_us : wait_us;
+        sv.wait_ticks = wus < 20000000 ? 100u * (unsigned)wus : 2000000000u;   // (per tile: the launcher scales it)
         sv.trace = h->step_trace; sv.trace_cap = h->step_trace_cap;
         const bool fused_io = post && post->xs;            // inference: u0 from the data columns and the post-processing in the launch
         if (fused_io) { sv.xs = post->xs; sv.logpx = post->logpx; sv.regs = post->regs; sv.sums5 = post->sums5; }
@@ -1279,12 +1301,8 @@ static cnf_status inference_impl(cnf_handle h, int mode, const float* xs, const 
 }
 
 // ---- submitted inferences: enqueue now, collect later (the GPU goes from one solve straight into the next) ----
-// The oldest submitted inference: wait for its outcome; a launch that ran out of a wait is run again on the streamed driver.
-static cnf_status collect_one(cnf_handle h, cnf_solve_stats* stats) {
-    cnf_ctx::Submitted sub = h->submitted.front();
-    h->submitted.pop_front();
-    if (stats) *stats = sub.stats;
-    if (!sub.launched) return sub.status;
+// The end of one submitted launch: wait for its outcome; a launch that ran out of a wait is run again on the streamed driver.
+static cnf_status finish_submission(cnf_handle h, const cnf_ctx::Submitted& sub, cnf_solve_stats* stats) {
     HIPCHK(h, hipSetDevice(h->device));
     StepState fin{};
     bool aborted = false;
@@ -1312,6 +1330,29 @@ static cnf_status collect_one(cnf_handle h, cnf_solve_stats* stats) {
     s = inference_impl(h, sub.mode, sub.xs, sub.eps, sub.logpx, sub.regs, nullptr, sub.sums5, sub.B, &sub.opts, stats, sub.st);
     h->no_persist = false; h->collecting = was;
     return s;
+}
+
+// The oldest submitted inference, completed and taken off the queue.
+static cnf_status collect_one(cnf_handle h, cnf_solve_stats* stats) {
+    cnf_ctx::Submitted sub = h->submitted.front();
+    h->submitted.pop_front();
+    if (stats) *stats = sub.stats;
+    if (!sub.launched) return sub.status;
+    return finish_submission(h, sub, stats);
+}
+
+static cnf_status settle_submitted(cnf_handle h) {
+    const bool was = h->collecting;
+    h->collecting = true;                     // (the fallback's own calls must not drain the queue they are part of)
+    for (auto& sub : h->submitted) {
+        if (!sub.launched) continue;
+        cnf_solve_stats st{};
+        sub.status = finish_submission(h, sub, &st);
+        sub.stats = st;
+        sub.launched = false;
+    }
+    h->collecting = was;
+    return CNF_OK;                            // (each outcome, errors included, is its collect call's)
 }
 
 // a handle destroyed with submissions outstanding gives up its claim on the process-wide launch order

@@ -732,7 +732,7 @@ k_wgrad_wave(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const floa
     Raw r0_;
     // Buffer loads: descriptor base = the K-split's first row at the tile's first column, record count = up to the split's
     // last row, so rows past the split (its ragged last chunk) come back as zeros by the range check; a request is
-    // descriptor + the lane's byte offset (one register per side) + a scalar row offset.  (Plain loads cost 112 64-bit vector
+    // descriptor + the lane's byte offset, which carries the row offset (one vector add per request).  (Plain loads cost 112 64-bit vector
     // adds per chunk here, and hand-written requests are unsafe: the compiler copies their destination registers.)
     auto rsrc = [&](const float* X, int sum, int col0) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + (size_t)k0 * sum + col0), 0, (int)(((size_t)(k1 - k0) * sum - col0) * 4), 0x00020000);
@@ -744,7 +744,9 @@ k_wgrad_wave(NetDesc nd, GradLayout gl, const float* __restrict__ AB, const floa
 #ifndef WGW_AUX
 #define WGW_AUX 0
 #endif
-        for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d, (int)off, (kb - k0 + j) * sum * 4, WGW_AUX));
+        // the row offset is part of the CHECKED offset (voffset): soffset takes no part in the range check on gfx9 raw buffers,
+        // so a row past the split would otherwise come back as whatever an earlier, larger contraction left there
+        for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d, (int)(off + (unsigned)((kb - k0 + j) * sum * 4)), 0, WGW_AUX));
     };
     auto split8 = [&](const f32x4 (&r)[8], int c) {         // column c of the lane's four: its 8 samples -> three bf16x8 pieces
         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));

@@ -75,6 +75,7 @@ cnf_status mfma_step(const MfmaPlan& p, const NetDesc& nd, bool train, const Ste
 struct Solve3Args {
     float* part;          // error partials: two buffers (meeting index parity) of 2 x 512 words {meeting index, float}
     int spin_limit;       // polls a wait makes before it gives up (abort word; the caller then streams step launches)
+    unsigned wait_ticks;  // ... and how long it waits at most, in ticks of the 100 MHz real-time clock (whichever runs out first)
     float* trace;         // null, or 4 floats per step attempt: (t, signed h, EEst, accepted) -- cnf_set_step_trace
     int trace_cap;        //   attempts the buffer holds
     unsigned* base_dev;   // device word: meetings held by earlier launches on the buffer `part` (the indices go on from there;

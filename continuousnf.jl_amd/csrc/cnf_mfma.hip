@@ -1571,20 +1571,18 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     if (off || fp32_only || step_v1() || !train || !p.d_img3b || !(jvp || vjp_ok))
         return CNF_ERR_UNSUPPORTED;
     if (p.cond && dump) return CNF_ERR_UNSUPPORTED;         // (conditional recording solves: k_mfma's step launches)
-    // CNF_PIPE=1: k_solve3p, the interleaved schedule with the SIMD partners in complementary roles (cnf_step3p.hip) instead
-    // of k_solve3b.  Parity-tested; measured SLOWER (48.7 against 33.2 us per attempt), so it is opt-in.
-    static const bool pipe = [] { const char* e = getenv("CNF_PIPE"); return e && e[0] == '1'; }();
-    const bool use_p = pipe && !jvp && !p.cond;
     const int ntile = (B + 31) / 32;
-    const int resident = use_p ? step3p_solve_resident(dump != nullptr, device) : step3b_solve_resident(jvp, dump != nullptr, device);
+    const int resident = step3b_solve_resident(jvp, dump != nullptr, device);
     if (ntile < 1 || resident < 1) return CNF_ERR_UNSUPPORTED;
     // One 32-column tile per workgroup when the device holds them all at once; larger batches run several tiles per
     // workgroup with the state in the integrator's buffers (the tiles dealt evenly: ceil(ntile / rounds) workgroups)
     int grid = ntile;
     if (ntile > resident) {
-        if (use_p || dump || !K1) return CNF_ERR_UNSUPPORTED;
+        if (dump || !K1) return CNF_ERR_UNSUPPORTED;
         const int rounds = (ntile + resident - 1) / resident;
         grid = (ntile + rounds - 1) / rounds;
+        const unsigned long long wt = (unsigned long long)sv.wait_ticks * (unsigned)rounds;      // the bound is per tile carried
+        sv.wait_ticks = wt < 4000000000ull ? (unsigned)wt : 4000000000u;
     }
     if (grid > 512) return CNF_ERR_UNSUPPORTED;
     MfmaArgs a{};
@@ -1595,7 +1593,7 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     // Caller-owned columns.  One tile per workgroup: the launch reads u0 where the caller keeps it and writes the final
     // columns where the caller wants them -- no copy launches around the solve.  Otherwise the state lives in the
     // integrator's buffers between attempts: u0 is copied in, the caller copies the result out (sv.u_out = null says so).
-    const bool direct = grid == ntile && !use_p && !dump && sv.u_out != nullptr && !sv.xs;
+    const bool direct = grid == ntile && !dump && sv.u_out != nullptr && !sv.xs;
     if (!direct) sv.u_out = nullptr;
     if (sv.u0 && sv.u0 != U[0]) {
         if (direct) a.U[0] = const_cast<float*>(sv.u0);        // (read in the prologue only: the final store goes to sv.u_out)
@@ -1607,7 +1605,6 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     a.cond = p.cond; a.cbs = p.cbs;                          // conditional models: the per-sample first-layer bias rows
     a.dump = dump; a.dump_stride = dump_stride; a.dump_step_stride = dump_step_stride; a.dump_cap = dump_cap; a.hs_out = hs_out;
     sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
-    if (use_p) return step3p_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, sv, device);
     return step3b_solve_launch(a, p.d_img3b, p.ly.n_in, p.ly.norm_z, p.ly.norm_j, grid, s, sv, jvp, device);
 }
 

@@ -28,9 +28,3 @@ cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, 
 int step3b_solve_resident(bool jvp, bool record, int device);
 // C = A Bt^T (16 x K each, K a multiple of 32) on the split-bf16 six-term product of the kernels above: arithmetic self-test
 hipError_t split_product_test_launch(const float* dA, const float* dBt, float* dC, int K, hipStream_t s);
-// k_solve3p (cnf_step3p.hip): the one-launch solve of the VJP mode with the reverse sweep of evaluation e interleaved with
-// the forward sweep of evaluation e + 1 and the two waves of a SIMD in complementary roles.  Same contract as
-// step3b_solve_launch(jvp = false).  Opt-in (CNF_PIPE=1): measured slower than k_solve3b.
-cnf_status step3p_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, int grid, hipStream_t s,
-                               const Solve3Args& sv, int device);
-int step3p_solve_resident(bool record, int device);

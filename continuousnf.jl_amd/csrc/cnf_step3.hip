@@ -1714,7 +1714,7 @@ __global__ void __launch_bounds__(512, 2) k_step3b(MfmaArgs a, const char* __res
 // past the caches per poll), then every workgroup adds the same partials in the same order and runs the same controller,
 // as the launches of the streamed driver do.  No ticket, no fence, no cache flush: nothing else crosses workgroups.
 // Needs every workgroup resident: an ORDINARY launch whose grid the host bounds by what the device holds at once
-// (occupancy x CUs: step3b_solve_resident); every wait is bounded (sv.spin_limit polls), so a workgroup that never
+// (occupancy x CUs: step3b_solve_resident); every wait is bounded (sv.wait_ticks of the 100 MHz clock, sv.spin_limit polls), so a workgroup that never
 // arrives -- CUs held by another stream, process or CU mask -- ends the launch with the abort word and `done` = 0, and
 // the host runs the solve again on the streamed driver (cnf_abi.hip).  The two drivers run the same arithmetic from
 // separately compiled code: identical step counts on well-conditioned cases, results equal to the solver tolerance, not
@@ -1880,6 +1880,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
         int ok = 1;
         if (tid < (int)gridDim.x) {
             ok = 0;
+            const unsigned long long wait0 = __builtin_amdgcn_s_memrealtime();
             for (int spin = 0; spin < sv.spin_limit; ++spin) {
                 // both words of workgroup `tid` with ONE 16-byte load past the caches (each half carries its own index, so a
                 // torn pair is simply not accepted): half the polling traffic of two 8-byte atomic loads
@@ -1891,6 +1892,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
                     break;
                 }
                 if ((spin & 255) == 255 && __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if ((spin & 15) == 15 && __builtin_amdgcn_s_memrealtime() - wait0 > sv.wait_ticks) break;   // bounded in TIME
                 __builtin_amdgcn_s_sleep(4);
             }
             if (!ok) __hip_atomic_store(sv.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2174,9 +2176,11 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         int got = 0;
+                        const unsigned long long wait0 = __builtin_amdgcn_s_memrealtime();
                         for (int spin = 0; spin < sv.spin_limit; ++spin) {
                             const unsigned long long w = __hip_atomic_load(qb + 4 * tid + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((unsigned)(w >> 32) == tag) { c4[j] = __uint_as_float((unsigned)w); got = 1; break; }
+                            if ((spin & 15) == 15 && __builtin_amdgcn_s_memrealtime() - wait0 > sv.wait_ticks) break;
                             __builtin_amdgcn_s_sleep(1);
                         }
                         if (!got) late = 1.f;
@@ -2368,6 +2372,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         int ok = 1;
         if (tid < (int)gridDim.x) {
             ok = 0;
+            const unsigned long long wait0 = __builtin_amdgcn_s_memrealtime();
             for (int spin = 0; spin < sv.spin_limit; ++spin) {
                 // both words of workgroup `tid` with ONE 16-byte load past the caches (each half carries its own index, so a
                 // torn pair is simply not accepted): half the polling traffic of two 8-byte atomic loads
@@ -2379,6 +2384,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
                     break;
                 }
                 if ((spin & 255) == 255 && __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if ((spin & 15) == 15 && __builtin_amdgcn_s_memrealtime() - wait0 > sv.wait_ticks) break;   // bounded in TIME
                 __builtin_amdgcn_s_sleep(4);
             }
             if (!ok) __hip_atomic_store(sv.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2630,9 +2636,11 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         int got = 0;
+                        const unsigned long long wait0 = __builtin_amdgcn_s_memrealtime();
                         for (int spin = 0; spin < sv.spin_limit; ++spin) {
                             const unsigned long long w = __hip_atomic_load(qb + 4 * tid + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((unsigned)(w >> 32) == tag) { c4[j] = __uint_as_float((unsigned)w); got = 1; break; }
+                            if ((spin & 15) == 15 && __builtin_amdgcn_s_memrealtime() - wait0 > sv.wait_ticks) break;
                             __builtin_amdgcn_s_sleep(1);
                         }
                         if (!got) late = 1.f;

@@ -1,4 +1,4 @@
-// Device helpers shared by the step / solve kernels of the headline shape (cnf_step3.hip, cnf_step3p.hip): the Tsit5 table
+// Device helpers shared by the step / solve kernels of the headline shape (cnf_step3.hip): the Tsit5 table
 // as a kernel argument, the LDS-only barrier, wave reductions, the global weight image of the split kernels and the
 // three-piece bf16 operand algebra (split, images, six-term products).
 #pragma once

@@ -295,6 +295,12 @@ cnf_status cnf_set_step_trace(cnf_handle h, float* trace_dev, int cap_attempts);
 /* One-launch solves on this handle that ran out of a wait (CUs held by someone else) and were run again, from u0, on the
  * streamed driver; the calls returned CNF_OK with the streamed result. */
 int cnf_solve_fallbacks(cnf_handle h);
+/* How long a wait inside a one-launch solve of this handle lasts before the launch gives up and the call runs on the
+ * streamed driver: wait_us microseconds of the kernel's 100 MHz clock per tile a workgroup carries (default 2000; <= 0:
+ * keep), and/or poll_limit polls (default unbounded; 1 makes every wait run out at once -- tests; <= 0: keep).  The
+ * reference has no counterpart (its solve is a CPU loop, src/base_icnf.jl:137-143): this bounds the stall a co-tenant of
+ * the GPU can cause.  Environment defaults for new handles: CNF_SOLVE_WAIT_US, CNF_SOLVE_POLL_LIMIT. */
+cnf_status cnf_set_solve_wait(cnf_handle h, int wait_us, int poll_limit);
 /* Arithmetic self-test (no handle): C (16 x 16, row-major, HOST) = A Bt^T for HOST matrices A, Bt of 16 x K floats
  * (row-major, K a multiple of 32), computed on one wavefront with the operand split and the six-term bf16 MFMA product
  * the headline kernels use in place of the reference's sgemm (Lux Dense inside src/icnf.jl:331-332).  The parity suite

@@ -31,6 +31,30 @@ def build():
     return _PATH
 
 
+_NATIVE = os.path.join(_HERE, "liboracle_native.so")
+_flags = "-march=x86-64-v3"
+
+
+def use_native():
+    """bench.py's CPU baseline only: when the host has AVX-512, build the same source with -march=native on THIS host
+    (16-sample blocks = one zmm register) and load that build instead of the portable x86-64-v3 one the tests pin.  Must be
+    called before the library is first used; returns the -march flag in effect."""
+    global _PATH, _flags
+    if _lib is not None:
+        return _flags
+    try:
+        has512 = any("avx512f" in line for line in open("/proc/cpuinfo") if line.startswith("flags"))
+    except OSError:
+        has512 = False
+    if not has512:
+        return _flags
+    r = subprocess.run(["gcc", "-O3", "-march=native", "-ffp-contract=fast", "-fopenmp", "-fPIC", "-shared", "-o", _NATIVE,
+                        os.path.join(_HERE, "cnf_oracle.c"), "-lm"], capture_output=True, text=True)
+    if r.returncode == 0 and os.path.exists(_NATIVE):
+        _PATH, _flags = _NATIVE, "-march=native (AVX-512 host)"
+    return _flags
+
+
 def lib():
     global _lib
     if _lib is None:

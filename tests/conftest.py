@@ -36,9 +36,19 @@ def pytest_sessionfinish(session, exitstatus):
         k = r["what"]
         if k not in worst or r["err_over_bar"] > worst[k]["err_over_bar"]:
             worst[k] = r
-    out = {"bar": "|got-ref| <= 1e-4*|ref| + 1e-6 (dlogp row: 1e-4*(|ref| + rms(row)) + 1e-6); looser rtol where stated",
+    strict = [r for r in helpers.REPORT if r["rtol"] <= 1e-4 and "plain_bar" in r]
+    n_ent = sum(int(__import__("numpy").prod(r["shape"])) for r in strict) or 1
+    out = {"bar": "|got-ref| <= 1e-4*|ref| + 1e-6*max(1, rms(ref)) (dlogp row: 1e-4*(|ref| + rms(row)) + floor); looser rtol where stated",
+           "plain_bar": "|got-ref| <= 1e-4*|ref| + 1e-6 per entry, no row-scaled term and no rms-scaled floor: NOT asserted, reported "
+                        "per comparison under `plain_bar` (share of entries over it, the worst one)",
            "n_comparisons": len(helpers.REPORT), "max_err_over_bar": max(r["err_over_bar"] for r in helpers.REPORT),
-           "max_rel_err": max([r["max_rel_err"] for r in helpers.REPORT if r["rtol"] <= 1e-4] or [0.0]),
+           "max_rel_err": max([r["max_rel_err"] for r in strict] or [0.0]),
+           "strict_comparisons": len(strict),
+           "strict_entries_over_plain_bar": sum(r["plain_bar"]["n_over"] for r in strict),
+           "strict_entries": n_ent,
+           "strict_share_over_plain_bar": sum(r["plain_bar"]["n_over"] for r in strict) / n_ent,
+           "strict_worst_err_over_plain_bar": max([r["plain_bar"]["worst_err_over_plain_bar"] for r in strict] or [0.0]),
+           "notes": list(helpers.NOTES),
            "comparisons": sorted(worst.values(), key=lambda r: -r["err_over_bar"])}
     for path in (os.path.join(ROOT, "parity_report.json"), os.path.join(ROOT, "gpurun_out", "parity_report.json")):
         try:

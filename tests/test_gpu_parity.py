@@ -499,7 +499,7 @@ def test_conditional_model_of_the_headline_shape_is_one_launch():
             lam = dict(lambda1=1e-2, lambda2=1e-2) if tag is cnf.CondRNODE else {}
             ic = cnf.construct(tag, cnf.Chain(*layers), nvars, 0, compute_mode=cm, sol_kwargs=kw, **lam)
             logpx, (E, n, A) = cnf.inference(ic, cnf.TrainMode(), _dev(xs), _dev(ys), flat, {}, eps=_dev(eps))
-            if _one_launch_expected() and os.environ.get("CNF_PIPE") != "1":
+            if _one_launch_expected():
                 assert ic.last_stats["launches"] <= 3, (B, jvp, ic.last_stats)
             idx = rng.choice(B, 40, replace=False)
             cfg = O.Cfg(net, nvars, 0, 1e-2 if lam else 0.0, 1e-2 if lam else 0.0, 0.0, jvp)
@@ -833,8 +833,7 @@ def test_loss_grad_headline_shape_variants():
 
 
 def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
-    """CNF_PERSISTENT=0 (the streamed step launches instead of the one-launch solve), CNF_PIPE=1 (k_solve3p: the interleaved
-    schedule of the one-launch solve), CNF_SOLVE_POLL_LIMIT=1 (every wait of the one-launch solve runs out: the streamed
+    """CNF_PERSISTENT=0 (the streamed step launches instead of the one-launch solve), CNF_SOLVE_POLL_LIMIT=1 (every wait of the one-launch solve runs out: the streamed
     fallback), CNF_STEP_FP32 (the fp32-MFMA step
     kernels k_step3 / k_step3j instead of the split-bf16 ones), CNF_STEP_V1 /
     CNF_TRACE_GENERIC / CNF_ADJ_GENERIC (the first-generation kernels), CNF_WGRAD_LDS (the contraction with LDS images,
@@ -846,8 +845,6 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
                                           "test_one_launch_solve or test_headline_kernels_strict or test_submitted_inferences or "
                                           "test_conditional_model_of_the_headline"),
                      ("CNF_SOLVE_POLL_LIMIT=1", "test_one_launch_solve_falls_back or test_submitted_inferences"),
-                     ("CNF_PIPE=1", "test_headline_kernels_strict or test_adaptive_solve_vs_oracles and 3-mfma or "
-                                    "test_loss_grad_headline or test_one_launch_solve_takes"),
                      ("CNF_STEP_FP32", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve or "
                                        "test_jvp_mode_headline_shape_step_kernel or ragged or test_headline_kernels_strict"),
                      ("CNF_STEP_V1", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve"),
@@ -907,6 +904,26 @@ def test_submitted_inferences_equal_the_synchronous_ones():
         assert _lib.lib().cnf_inference_pending(ic.handle()) == 0
         assert torch.equal(o1[0], want[1][0]) and torch.equal(lp2, want[2][0])
         ic.close()
+    # every submission runs with ITS conditioning and ITS parameters (mini-batches of a conditional model; an optimiser
+    # step between two submissions): the library settles what is queued before either changes
+    n_cond = 8
+    net = O.Net((32 + n_cond, 128, 128, 32), (O.ACT_TANH,) * 3)
+    layers = [cnf.Dense(a, b, "tanh") for a, b in zip(net.dims[:-1], net.dims[1:])]
+    flats = [O.glorot_params(net, rng, np.float32, 0.1) for _ in range(2)]
+    ic = cnf.construct(cnf.CondRNODE, cnf.Chain(*layers), 32, 0, compute_mode=cnf.HIPVecJacMatrixMode("mfma"), sol_kwargs=tol)
+    batches = [(_dev(rng.standard_normal((32, 512))), _dev(rng.standard_normal((n_cond, 512))), _dev(rng.standard_normal((32, 512))),
+                flats[i // 2]) for i in range(3)]                       # ys differs per batch, ps changes before the third
+    want = [cnf.inference(ic, cnf.TrainMode(), xs, ys, fl, {}, eps=eps)[0].clone() for xs, ys, eps, fl in batches]
+    outs = [cnf.inference_submit(ic, cnf.TrainMode(), xs, ys, fl, {}, eps=eps)[0] for xs, ys, eps, fl in batches]
+    assert _lib.lib().cnf_inference_pending(ic.handle()) == 3 and len(ic._submitted) == 3
+    for _ in batches:
+        cnf.inference_collect(ic)
+    torch.cuda.synchronize()
+    assert not ic._submitted
+    for k, (got, w) in enumerate(zip(outs, want)):
+        assert torch.equal(got, w), ("conditional submission", k, float((got - w).abs().max()))
+    assert not torch.equal(want[0], want[1])
+    ic.close()
     # an inference that fails (maxiters) reports at ITS collect, not at the submit; the handle goes on working
     ic = make_icnf(cnf, cfg, sol_kwargs=dict(tol, maxiters=2))
     xs, eps = ins[1] if False else (_dev(rng.standard_normal((cfg.nvars, 512))), _dev(rng.standard_normal((cfg.n_in, 512))))
@@ -951,8 +968,7 @@ def test_bare_solve_reads_and_writes_the_callers_columns():
             out = torch.full_like(u0, float("nan"))
             _lib.check(l.cnf_solve_tsit5(h, 1, u0.data_ptr(), eps.data_ptr(), out.data_ptr(), B, C.byref(opts), C.byref(stats), sp), h)
             torch.cuda.synchronize()
-            one = persistent and (B <= 8192 or os.environ.get("CNF_PIPE") != "1")
-            if one and os.environ.get("CNF_PIPE") != "1":
+            if persistent:
                 assert stats.launches == (1 if B <= 8192 else 2), (jvp, B, stats.launches)
             assert torch.equal(u0, keep) and bool(torch.isfinite(out).all())
             inpl = u0.clone()
@@ -988,8 +1004,7 @@ def test_one_launch_solve_takes_the_headline_shape_and_agrees_with_the_streamed_
             ic = make_icnf(cnf, cfg, sol_kwargs=kw)
             logpx, regs = cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
             stt = ic.last_stats
-            # (B = 8224: two tiles per workgroup of the same launch; k_solve3p -- CNF_PIPE=1 -- holds one tile per workgroup)
-            one = persistent and (B <= 8192 or os.environ.get("CNF_PIPE") != "1")
+            one = persistent                  # (B = 8224: two tiles per workgroup of the same launch)
             assert (stt["launches"] <= 3) == one, (B, name, stt)
             assert stt["nf"] == (2 if name == "adaptive" else 1) + 6 * (stt["naccept"] + stt["nreject"])
             # the columns do not interact: a sub-batch through the other driver gives the same columns (to the tolerance
@@ -1160,6 +1175,30 @@ def test_fit_matrix_of_the_reference():
                         d = cnf.CondICNFDist(mach, mode, df2.T) if cond else cnf.ICNFDist(mach, mode)
                         assert np.isfinite(cnf.logpdf(d, df.T)).all()
                     icnf.close()
+
+
+def test_loss_grad_ragged_contraction_after_a_larger_batch():
+    """The weight-gradient contraction reads whole 32-row chunks of the factor arrays; rows past the end of a K-split must
+    count as zeros whatever an earlier, larger call left in the arena (k_wgrad_wave: the row offset is part of the
+    range-checked buffer offset).  One handle: a large batch first, then ragged ones (K = 6 x steps x B not a multiple
+    of 32, several contractions per call) against the float64 oracle."""
+    from oracle import cnf_grad_oracle as G
+    for cfg, Bbig, Bs in ((O.baseline_cfg(3)[0], 1100, (17, 70, 333)), (O.baseline_cfg(2)[0], 2100, (17, 45))):
+        cfg.tspan = (0.0, 0.5)
+        rng = np.random.default_rng(77)
+        flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+        icnf = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 10))       # 5 steps
+        for B in (Bbig,) + tuple(Bs):
+            xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32) * 3.0       # (large values first: a stale row would show)
+            eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+            val, grad = cnf.loss_and_grad(icnf, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+            if B == Bbig:
+                continue
+            rval, rgrad, _ = G.loss_and_grad(cfg, flat.astype(np.float64), xs.astype(np.float64), eps.astype(np.float64), None,
+                                             adaptive=False, dt=1 / 10)
+            assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+            _assert_grad(grad.cpu().numpy(), rgrad, f"ragged contraction B={B} after B={Bbig}")
+        icnf.close()
 
 
 def test_loss_grad_tiny_batches():
@@ -1501,15 +1540,16 @@ def _one_launch_expected():
         and os.environ.get("CNF_STEP_V1") != "1"
 
 
-@pytest.mark.parametrize("B", [1000, 8192, 8224])
-def test_headline_kernels_strict_vs_float64_at_size(B):
+@pytest.mark.parametrize("B,seed", [(1000, 0), (8192, 0), (8224, 0)] + [(8192, s) for s in range(1, 6)])
+def test_headline_kernels_strict_vs_float64_at_size(B, seed):
     """Fixed-dt inference of the headline shape (RNODE 32-128-128-32, VJP with the |eps^T J| row) through the kernels the
     bench number comes from: k_solve3b (B = 1000: 32 tiles, ragged; B = 8192: 256 workgroups that meet at every step;
     B = 8224: two tiles per workgroup, the state in the integrator's buffers) and k_step3b (every B in the
-    CNF_PERSISTENT=0 child run of test_ab_switches).  fsol (all rows), logpx and the regularisers of 288 sampled columns -- first and last tile, the
+    CNF_PERSISTENT=0 child run of test_ab_switches); seeds 1..5 at B = 8192 are SURVEY 8 d-inputs' five draws of
+    (xs, eps, weights).  fsol (all rows), logpx and the regularisers of 288 sampled columns -- first and last tile, the
     ragged tail, random ones -- against the float64 oracle at the 1e-4 bar, and the route is asserted (launches)."""
     cfg, _, _ = O.baseline_cfg(3)
-    rng = np.random.default_rng(1300 + B)
+    rng = np.random.default_rng(1300 + B + 7919 * seed)
     flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
     xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
     eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
@@ -1517,8 +1557,8 @@ def test_headline_kernels_strict_vs_float64_at_size(B):
     ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=kw)
     prob = cnf.inference_prob(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
     fsol = cnf.base_sol(ic, prob).view()
-    # (B = 8224: 257 tiles over 129 workgroups, the several-tiles instantiation of k_solve3b; k_solve3p has none)
-    one = _one_launch_expected() and (B <= 8192 or os.environ.get("CNF_PIPE") != "1")
+    # (B = 8224: 257 tiles over 129 workgroups, the several-tiles instantiation of k_solve3b)
+    one = _one_launch_expected()
     assert prob.stats["kernel_used"] == _lib.KERNEL_MFMA and prob.stats["nf"] == 1 + 6 * 8
     assert (prob.stats["launches"] <= 3) == one, prob.stats          # one launch (+ the copy of the final state), or streamed
     logpx, (E, n, A) = cnf.inference(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
@@ -1670,6 +1710,71 @@ def test_one_launch_solve_falls_back_when_a_workgroup_does_not_arrive():
     torch.cuda.synchronize()
     assert torch.allclose(lp2, logpx, rtol=2e-5, atol=2e-5)
     ic.close(); ref_ic.close()
+
+
+def test_one_launch_solve_gives_up_within_its_time_bound_on_a_cu_masked_stream():
+    """the stall a co-tenant can cause is bounded in TIME.  A stream restricted to half of the CUs
+    (hipExtStreamCreateWithCUMask) can never hold the 256 workgroups of the headline solve at once: the launch's waits
+    run out after cnf_set_solve_wait's bound (2 ms by default), the call falls back to the streamed driver on the same
+    stream and returns CNF_OK.  Compared with the same call when every wait gives up at its first poll (poll_limit = 1:
+    no waiting at all), the run-out may cost at most 10 ms."""
+    import ctypes as C, time
+    if not _one_launch_expected():
+        pytest.skip("the one-launch solve is switched off in this process")
+    cfg, _, _ = O.baseline_cfg(3)
+    rng = np.random.default_rng(1600)
+    B = 8192
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    xs, eps = _dev(rng.standard_normal((cfg.nvars, B))), _dev(rng.standard_normal((cfg.n_in, B)))
+    tol = dict(reltol=3.45e-4, abstol=1.19e-7)
+    hip = C.CDLL("libamdhip64.so")
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (ncu + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for cu in range(0, ncu, 2):                                # every second CU
+        mask[cu // 32] |= 1 << (cu % 32)
+    stream = C.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(C.byref(stream), C.c_uint32(words), mask) == 0
+    try:
+        ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=tol)
+        want, _ = cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)       # (default stream: the one-launch solve)
+        assert ic.last_stats["launches"] <= 3
+        want = want.clone()
+        l, h = _lib.lib(), ic.handle()
+        opts = cnf.base_icnf._solve_opts(ic, ic.tspan)
+        lp = torch.empty(B, device="cuda"); regs = torch.empty(3 * B, device="cuda")
+        xc, ec = xs.t().contiguous(), eps.t().contiguous()        # the C ABI's layout: a sample's rows contiguous (Julia column-major)
+        torch.cuda.synchronize()
+
+        def timed():
+            stats = _lib.cnf_solve_stats()
+            t0 = time.perf_counter()
+            _lib.check(l.cnf_inference(h, 1, xc.data_ptr(), ec.data_ptr(), lp.data_ptr(), regs.data_ptr(), None, B,
+                                       C.byref(opts), C.byref(stats), stream), h)
+            assert hip.hipStreamSynchronize(stream) == 0
+            return time.perf_counter() - t0, stats
+        fb0 = ic.solve_fallbacks()
+        ic.set_solve_wait(poll_limit=1)                         # every wait gives up at once: the fallback without the wait
+        t_now = min(timed()[0] for _ in range(3))
+        assert ic.solve_fallbacks() - fb0 == 3
+        assert torch.allclose(lp, want, rtol=5e-3, atol=5e-3)
+        ic.set_solve_wait(poll_limit=0x7fffffff)                # bounded by time alone (2 ms)
+        ts = [timed() for _ in range(3)]
+        assert ic.solve_fallbacks() - fb0 == 6, "a 256-workgroup launch was placed on 128 CUs?"
+        t_wait = min(t for t, _ in ts)
+        assert ts[-1][1].launches > 3
+        assert torch.allclose(lp, want, rtol=5e-3, atol=5e-3), float((lp - want).abs().max())
+        helpers.note(f"one-launch solve on a half-masked stream: fallback after the time bound {1e3 * t_wait:.2f} ms, "
+                     f"without waiting {1e3 * t_now:.2f} ms")
+        assert t_wait - t_now <= 10e-3, (t_wait, t_now)
+        assert t_wait - t_now >= 0.5e-3, (t_wait, t_now)       # (the bound was what ended the wait)
+        # back on an unrestricted stream the handle takes the one-launch path again
+        lp2, _ = cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+        assert ic.last_stats["launches"] <= 3 and torch.equal(lp2, want)
+        ic.close()
+    finally:
+        torch.cuda.synchronize()
+        hip.hipStreamDestroy(stream)
 
 
 def test_training_trajectories_of_device_and_oracle_gradients_agree():

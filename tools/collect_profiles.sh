@@ -11,7 +11,7 @@ export HIP_FORCE_DEV_KERNARG=1
 TAG=${1:-r3}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 bench.py --no-cpu-baseline --no-pmc > $OUT/bench_under_rocprof.log 2>&1
 echo "bench rc=$?"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/prof_rhs.py bench 16 > $OUT/pmc_fetch.log 2>&1
 echo "fetch rc=$?"
