@@ -7,6 +7,7 @@
 #include "cnf_grad.h"
 #include "cnf_trace.h"
 #include "cnf_mirror.h"
+#include "cnf_wave.h"
 #include "cnf_step3.h"
 #include <immintrin.h>
 #include <sched.h>
@@ -521,6 +522,20 @@ extern "C" cnf_status cnf_selftest_split_product(const float* A, const float* Bt
     return e == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 
+// test support: workgroups that hold a CU each (all of its LDS) for a bounded time
+__global__ void __launch_bounds__(64) k_hold_cu(unsigned long long ticks) {
+    extern __shared__ char hold_lds[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (threadIdx.x == 0) hold_lds[0] = 1;
+}
+extern "C" cnf_status cnf_selftest_hold_cus(int n_workgroups, int microseconds, void* stream) {
+    if (n_workgroups < 1 || n_workgroups > 4096 || microseconds < 1 || microseconds > 100000) return CNF_ERR_BAD_ARG;
+    constexpr int LDS = 160 * 1024;
+    if (hipFuncSetAttribute((const void*)k_hold_cu, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return CNF_ERR_HIP;
+    hipLaunchKernelGGL(k_hold_cu, dim3(n_workgroups), dim3(64), LDS, (hipStream_t)stream, 100ull * (unsigned long long)microseconds);
+    return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
 extern "C" int cnf_solve_fallbacks(cnf_handle h) { return h ? h->fallbacks : -1; }
 extern "C" cnf_status cnf_set_solve_wait(cnf_handle h, int wait_us, int poll_limit) {
     if (!h) return CNF_ERR_BAD_ARG;
@@ -837,7 +852,9 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     const bool hairer = opts->adaptive && opts->dt == 0.f;
     // The whole solve in ONE launch where the handle and the batch allow it (k_solve3b / k_solve3jb): the weights and the
     // Runge-Kutta rows stay on the CUs for all attempts, the workgroups exchange two floats per attempt.
-    if (use_mfma && !lockstep && !h->no_persist) {
+    // ... or of a small two-layer network, one wave per 16-sample tile, registers only (k_solve_wave, cnf_wave.hip)
+    const bool wave_ok = k == CNF_KERNEL_MFMA && !rec && wave_solve_supported(h->nd, train != 0, B);
+    if ((use_mfma || wave_ok) && !lockstep && !h->no_persist) {
         // one such kernel at a time in this process: two of them would each hold CUs the other is waiting for.  Launches
         // queued on ONE stream run one after the other by themselves (submitted inferences); a launch on another stream
         // waits for those first.
@@ -870,8 +887,13 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             slot = traj_slot_floats(h); dcap = h->traj_cap;
             dump = h->traj + n;                      // stage area of slot 0; u_n sits one array before
         }
-        s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror + mslot, base, sv, h->device,
-                                  dump, n, slot, dcap, h->traj_hs, h->K1);
+        s = CNF_ERR_UNSUPPORTED;
+        if (wave_ok)
+            s = wave_solve_launch(h->nd, train != 0, h->d_params, h->nd.n_cond > 0 ? h->d_cond : nullptr, h->cbs, h->d_state, h->U[0],
+                                  eps, B, st, h->d_mirror + mslot, base, sv);
+        if (s == CNF_ERR_UNSUPPORTED && use_mfma)
+            s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror + mslot, base, sv, h->device,
+                                      dump, n, slot, dcap, h->traj_hs, h->K1);
         if (s == CNF_OK) {
             ++launches;
             h->mirror_base = base + 1;

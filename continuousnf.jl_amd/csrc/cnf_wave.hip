@@ -1,0 +1,608 @@
+// k_solve_wave -- the WHOLE solve of a small two-layer network, one WAVE per 16-sample tile, nothing but registers.
+//
+// What the reference runs here: `augmented_f` (src/icnf.jl:318-350 Train/VJP, :384-420 Train/JVP, :148-164 Test with
+// src/utils.jl:1-36) six times per Tsit5 step inside `base_sol` (src/base_icnf.jl:137-143), wrapped by `inference_prob`
+// (:266-286) and `inference_sol` (:167-189) -- for the networks of its own README and regression test
+// (`Dense(n_in => 3 n_in, tanh), Dense(3 n_in => n_in, tanh)`, README.md:47, test/regression_tests.jl:7): BASELINE
+// configs 1 and 2.
+//
+// Why a kernel of its own: on k_mfma these solves are a LATENCY chain -- 6 evaluations x 6-7 barrier-delimited phases
+// per attempt at ~0.4 us each, 23-34 launches (profiles/round3_generic_one_launch.txt) -- with the chip empty
+// (4096 samples are 128 workgroups).  Here a network whose padded widths fit one wave's registers is evaluated by ONE
+// wave with no LDS and no barrier at all:
+//   * v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain).  The accumulator tile of a layer -- lane (q, c) holds
+//     rows 4q..4q+3 of sample c -- IS the B operand of the next layer's product: k-step j of input tile kt contracts
+//     feature 16 kt + 4q + j, taken from register j; the A operand (weights) is loaded in that k order once per solve.
+//     Activations never leave the registers that produced them.
+//   * row sums (eps.J eps, |zdot|^2, |eps^T J|^2) are two cross-row lane exchanges; afterwards every lane of a sample holds
+//     the totals, and lane group q keeps scalar row q (dlogp, E, n) of the Runge-Kutta state.
+//   * all six stages, the embedded error estimate, the controller (every lane runs it on the same numbers) and the
+//     automatic initial dt are inside; the waves of a launch MEET once per attempt through the tagged words of k_solve3b
+//     (cnf_step3.hip): one store and one poll round trip.  u0 assembly, post-processing and the five loss sums ride along:
+//     ONE launch per inference.
+// TestMode (exact trace): the closed form of two-layer networks, tr J = sigma'_1^T (W_1 .* W_2^T) sigma'_2: one more product
+// against C = W_1 .* W_2^T instead of the reverse sweep.  Conditional models: the per-sample first-layer bias rows stay in
+// registers for the whole solve.
+#include <cstdlib>
+
+#include "cnf_wave.h"
+#include "cnf_mfma_dev.h"
+
+namespace {
+
+constexpr int WV_VJP = 0, WV_JVP = 1, WV_TEST = 2;
+
+struct WaveArgs {
+    NetDesc nd;
+    const float* P;        // flat parameters (Lux order: per layer weight out x in column-major, then bias)
+    const float* eps;      // n_in x B
+    const float* cond;     // conditional models: per-sample first-layer bias [B][cbs] (W1[:, n_in:] ys + b1), else null
+    int cbs;
+    int B;
+    float n_total;         // D * B
+    float* U0;             // the integrator's buffer set 0 ([B][D])
+    StepState* st_out;
+    void* mirror;
+    unsigned seq;
+};
+
+__device__ __forceinline__ f32x4 mm4(const float (&A)[4], const f32x4& b, f32x4 acc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j], b[j], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ float wv_wave_sum(float v) {            // every lane ends with the same total (fixed tree)
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));
+    const int i = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
+}
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// Tsit5 rows a_{s+1, 1..6} by value in the kernel arguments (scalar loads, indexed by the stage of a ROLLED stage loop)
+struct WvTab { float a[7][8]; };
+static const WvTab kWvTab = {{
+    {0, 0, 0, 0, 0, 0, 0, 0},
+    {TS_A21, 0, 0, 0, 0, 0, 0, 0},
+    {TS_A31, TS_A32, 0, 0, 0, 0, 0, 0},
+    {TS_A41, TS_A42, TS_A43, 0, 0, 0, 0, 0},
+    {TS_A51, TS_A52, TS_A53, TS_A54, 0, 0, 0, 0},
+    {TS_A61, TS_A62, TS_A63, TS_A64, TS_A65, 0, 0, 0},
+    {TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76, 0, 0}}};
+
+// Sum over the four lanes of a sample (c, c + 16, c + 32, c + 48) on the VALU: v_permlane16_swap / v_permlane32_swap exchange
+// rows of 16 / halves of 32 lanes between two registers; with both operands the same value, the two results are the value
+// of this lane's row (half) partner pair, so their sum is the pair sum in every lane.  (The ds_bpermute form of
+// __shfl_xor is an LDS-crossbar round trip per exchange, six of them per evaluation.)
+__device__ __forceinline__ float wv_quad_sum(float v) {
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    u32x2_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r.x) + __uint_as_float(r.y);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+// NI / NH: 16-row tiles of n_in / of the hidden layer;  TANH: tanh on both layers (compile time: the evaluation is then one
+// straight-line block the scheduler can interleave -- a run-time switch per activation call cut it into 2000 blocks)
+template <int NI, int NH, int MODE, bool TANH>
+__global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, const WvTab tab) {
+    constexpr bool TRAIN = MODE != WV_TEST;
+    constexpr int NS = TRAIN ? 3 : 1;                      // scalar rows of the state
+    const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
+    const NetDesc& nd = a.nd;
+    const int n_in = nd.n_in, nh = nd.dims[1], D = n_in + NS;
+    const int act1 = nd.acts[0], act2 = nd.acts[1];
+    constexpr bool fast = TANH;                            // exp2 / rcp form, sigma' = 1 - h^2
+    const float* P = a.P;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (sv.t_out && blockIdx.x == 0 && lane == 0) sv.t_out[0] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- weights as A operands, in the k order the accumulator tiles present: lane (q, i), k-step j of input tile kt ->
+    // M[16 m + i][16 kt + 4 q + j].  Straight from the flat vector (L2 hits after the first wave), once per solve. ----
+    float fW1[NH][NI][4], fW2[NI][NH][4];
+    float fW2T[MODE == WV_VJP ? NH : 1][NI][4], fW1T[MODE == WV_VJP ? NI : 1][NH][4], fC[MODE == WV_TEST ? NH : 1][NI][4];
+    auto w1 = [&](int o, int k) { return (o < nh && k < n_in) ? P[nd.w_off[0] + o + (size_t)k * nh] : 0.f; };       // W1[o][k]
+    auto w2 = [&](int o, int k) { return (o < n_in && k < nh) ? P[nd.w_off[1] + o + (size_t)k * n_in] : 0.f; };     // W2[o][k]
+#pragma unroll
+    for (int m = 0; m < NH; ++m)
+#pragma unroll
+        for (int kt = 0; kt < NI; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = 16 * m + c, k = 16 * kt + 4 * q + j;
+                fW1[m][kt][j] = w1(o, k);
+                if (MODE == WV_VJP) fW2T[m][kt][j] = w2(k, o);                     // W2^T[o][k] = W2[k][o]
+                if (MODE == WV_TEST) fC[m][kt][j] = w1(o, k) * w2(k, o);           // C[o][k] = W1[o][k] W2[k][o]
+            }
+#pragma unroll
+    for (int m = 0; m < NI; ++m)
+#pragma unroll
+        for (int kt = 0; kt < NH; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = 16 * m + c, k = 16 * kt + 4 * q + j;
+                fW2[m][kt][j] = w2(o, k);
+                if (MODE == WV_VJP) fW1T[m][kt][j] = w1(k, o);                     // W1^T[o][k] = W1[k][o]
+            }
+    // biases in the accumulator layout (rows 16 m + 4 q + j); conditional models: a row per sample instead of b1
+    const int smp = blockIdx.x * 16 + c;
+    const bool live = smp < a.B;
+    const size_t sb = live ? (size_t)smp : 0;
+    f32x4 b1v[NH], b2v[NI], rmask[NI];
+#pragma unroll
+    for (int m = 0; m < NH; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 16 * m + 4 * q + j;
+            b1v[m][j] = r < nh ? (a.cond ? a.cond[sb * a.cbs + r] : P[nd.b_off[0] + r]) : 0.f;
+        }
+#pragma unroll
+    for (int m = 0; m < NI; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 16 * m + 4 * q + j;
+            b2v[m][j] = r < n_in ? P[nd.b_off[1] + r] : 0.f;
+            rmask[m][j] = r < n_in ? 1.f : 0.f;            // (rows beyond n_in carry act(0), which is not 0 for every activation)
+        }
+
+    // ---- state: z rows (u, k1..k7), the probe rows, and ONE scalar row per lane group (q = 0: dlogp, 1: E, 2: n) ----
+    f32x4 uz[NI], kz[7][NI], ep[NI];
+    float us, ks[7];
+    const bool sown = q < NS;                              // this lane group owns scalar row q
+#pragma unroll
+    for (int m = 0; m < NI; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 16 * m + 4 * q + j;
+            const bool ok = live && r < n_in;
+            float v = 0.f;
+            if (sv.xs) { if (ok && r < sv.nvars) v = sv.xs[sb * sv.nvars + r]; }     // u0 = (xs; 0)   src/base_icnf.jl:275-282
+            else if (ok) v = sv.u0[sb * D + r];
+            uz[m][j] = v;
+            ep[m][j] = (TRAIN && ok) ? a.eps[sb * n_in + r] : 0.f;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) kz[s][m][j] = 0.f;
+        }
+    us = (!sv.xs && live && sown) ? sv.u0[sb * D + n_in + q] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 7; ++s) ks[s] = 0.f;
+
+    // ---- one evaluation of augmented_f at z -> (zdot, this lane group's scalar row) ----
+    auto act4 = [&](int kind, const f32x4& pre, f32x4& h, f32x4& d) {
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h[j] = tanh_fast(pre[j]); d[j] = fmaf(-h[j], h[j], 1.f); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float hh, dd; cnf_act(kind, pre[j], hh, dd); h[j] = hh; d[j] = dd; }
+        }
+    };
+    auto rhs = [&](const f32x4 (&z)[NI], f32x4 (&zd)[NI], float& sd) {
+        f32x4 h1[NH], d1[NH];
+#pragma unroll
+        for (int m = 0; m < NH; ++m) {
+            f32x4 acc = b1v[m];
+#pragma unroll
+            for (int kt = 0; kt < NI; ++kt) acc = mm4(fW1[m][kt], z[kt], acc);
+            act4(act1, acc, h1[m], d1[m]);
+        }
+        f32x4 d2[NI];
+        float e2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < NI; ++m) {
+            // one chain per input tile (they run side by side in the matrix pipe), added in tile order
+            f32x4 part[NH];
+#pragma unroll
+            for (int kt = 0; kt < NH; ++kt) part[kt] = mm4(fW2[m][kt], h1[kt], kt == 0 ? b2v[m] : zero4);
+            f32x4 acc = part[0];
+#pragma unroll
+            for (int kt = 1; kt < NH; ++kt) acc += part[kt];
+            f32x4 h2;
+            act4(act2, acc, h2, d2[m]);
+            zd[m] = h2 * rmask[m];
+            d2[m] *= rmask[m];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e2 = fmaf(zd[m][j], zd[m][j], e2);
+        }
+        float ld = 0.f, n2 = 0.f;
+        if (MODE == WV_VJP) {
+            f32x4 g2[NI], g1[NH];
+#pragma unroll
+            for (int m = 0; m < NI; ++m) g2[m] = ep[m] * d2[m];
+#pragma unroll
+            for (int m = 0; m < NH; ++m) {
+                f32x4 acc = zero4;
+#pragma unroll
+                for (int kt = 0; kt < NI; ++kt) acc = mm4(fW2T[m][kt], g2[kt], acc);
+                g1[m] = acc * d1[m];
+            }
+#pragma unroll
+            for (int m = 0; m < NI; ++m) {
+                f32x4 part[NH];
+#pragma unroll
+                for (int kt = 0; kt < NH; ++kt) part[kt] = mm4(fW1T[m][kt], g1[kt], zero4);
+                f32x4 eJ = part[0];
+#pragma unroll
+                for (int kt = 1; kt < NH; ++kt) eJ += part[kt];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ld = fmaf(eJ[j], ep[m][j], ld); n2 = fmaf(eJ[j], eJ[j], n2); }
+            }
+        } else if (MODE == WV_JVP) {
+            f32x4 t1[NH];
+#pragma unroll
+            for (int m = 0; m < NH; ++m) {
+                f32x4 acc = zero4;
+#pragma unroll
+                for (int kt = 0; kt < NI; ++kt) acc = mm4(fW1[m][kt], ep[kt], acc);
+                t1[m] = acc * d1[m];
+            }
+#pragma unroll
+            for (int m = 0; m < NI; ++m) {
+                f32x4 part[NH];
+#pragma unroll
+                for (int kt = 0; kt < NH; ++kt) part[kt] = mm4(fW2[m][kt], t1[kt], zero4);
+                f32x4 acc = part[0];
+#pragma unroll
+                for (int kt = 1; kt < NH; ++kt) acc += part[kt];
+                const f32x4 t2 = acc * d2[m];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ld = fmaf(t2[j], ep[m][j], ld); n2 = fmaf(t2[j], t2[j], n2); }
+            }
+        } else {                                           // exact trace: sigma'_1^T (C sigma'_2)
+#pragma unroll
+            for (int m = 0; m < NH; ++m) {
+                f32x4 acc = zero4;
+#pragma unroll
+                for (int kt = 0; kt < NI; ++kt) acc = mm4(fC[m][kt], d2[kt], acc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ld = fmaf(acc[j], d1[m][j], ld);
+            }
+        }
+        // row sums: the four lanes of a sample (q = 0..3) exchange twice; every one of them ends with the totals
+        ld = wv_quad_sum(ld);
+        if (TRAIN) {
+            e2 = wv_quad_sum(e2); n2 = wv_quad_sum(n2);
+            // (v_sqrt_f32, 1 ulp, on the one value this lane group keeps: the IEEE form is ~15 instructions and two
+            // exec-masked branches per root)
+            const float r2 = q == 1 ? (nd.norm_z ? e2 : 0.f) : (q == 2 ? (nd.norm_j ? n2 : 0.f) : 0.f);
+            const float rt = __builtin_amdgcn_sqrtf(r2);
+            sd = q == 0 ? -ld : rt;
+        } else {
+            sd = q == 0 ? -ld : 0.f;
+        }
+    };
+
+    // ---- integrator state: every lane carries the same copy and runs the same controller on the same sums ----
+    StepState ns = sv.init;
+    float hstep = ns.h, abstol = ns.abstol, reltol = ns.reltol;
+    int nsync = 0;
+    const unsigned mbase = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sv.base_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const int G = gridDim.x;
+    float p0 = 0.f, p1 = 0.f;
+    // The waves' partials (e, b) -> the sums over all of them in p0, p1 (the same order in every wave).  false: a wait ran out.
+    auto meet = [&](float e_lane, float b_lane) -> bool {
+        const float e = wv_wave_sum(e_lane), b = wv_wave_sum(b_lane);
+        unsigned long long* pb = reinterpret_cast<unsigned long long*>(sv.part) + (nsync & 1) * 1024;
+        const unsigned tag = mbase + (unsigned)nsync + 1u;
+        if (lane == 0) {
+            __hip_atomic_store(pb + 2 * blockIdx.x, ((unsigned long long)tag << 32) | __float_as_uint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pb + 2 * blockIdx.x + 1, ((unsigned long long)tag << 32) | __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // lane i takes the words of waves i, i + 64, ... (at most 8): ALL of them requested at once per poll round -- one round
+        // trip per round whatever the grid (taken one after the other they cost a round trip each: 8.5 k cycles per meeting
+        // at 256 waves) --, each accepted when both halves carry this meeting's index, in wave order
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const auto prs = __builtin_amdgcn_make_buffer_rsrc(pb, 0, 16 * 512, 0x00020000);
+        const unsigned long long wait0 = __builtin_amdgcn_s_memrealtime();
+        float pe[8], pbv[8];
+        unsigned need = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { pe[i] = 0.f; pbv[i] = 0.f; if (lane + 64 * i < G) need |= 1u << i; }
+        int ok = 1;
+        for (int spin = 0; need != 0; ++spin) {
+            // (buffer loads past the caches, aux = sc0 | sc1: loads the compiler counts and waits for itself -- a hand-written
+            // request's destination register is not protected until its wait)
+            u32x4_ wq[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (64 * i < G)                            // (wave-uniform: rounds beyond the grid issue nothing)
+                    wq[i] = __builtin_bit_cast(u32x4_, __builtin_amdgcn_raw_buffer_load_b128(prs, 16 * min(lane + 64 * i, G - 1), 0, 0x11));
+                else wq[i] = u32x4_{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (64 * i < G && (need >> i & 1) && wq[i].y == tag && wq[i].w == tag) {
+                    pe[i] = __uint_as_float(wq[i].x); pbv[i] = __uint_as_float(wq[i].z); need &= ~(1u << i);
+                }
+            if (need == 0) break;
+            if (spin + 1 >= sv.spin_limit) { ok = 0; break; }
+            if ((spin & 63) == 63 && __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+            if ((spin & 15) == 15 && __builtin_amdgcn_s_memrealtime() - wait0 > sv.wait_ticks) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c0 += pe[i]; c1 += pbv[i]; }
+        if (!ok) __hip_atomic_store(sv.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p0 = wv_wave_sum(c0); p1 = wv_wave_sum(c1);
+        const float bad = wv_wave_sum(ok ? 0.f : 1.f);
+        ++nsync;
+        return bad == 0.f;
+    };
+    auto after_ctrl = [&]() {
+        hstep = uni(ns.h); abstol = uni(ns.abstol); reltol = uni(ns.reltol);
+    };
+    auto add_norm = [&](float& acc, float u, float x) {   // (x / sk)^2, sk = atol + rtol |u|
+        const float sk = fmaf(fabsf(u), reltol, abstol);
+        const float y = x / sk;
+        acc = fmaf(y, y, acc);
+    };
+
+    bool alive = true;
+    {
+        // ---- k1 = f(u0); automatic initial dt (Hairer): its two norms, f(u0 + h0 f0) and that norm ----
+        float e = 0.f, b = 0.f;
+        rhs(uz, kz[0], ks[0]);
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < NI; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (rmask[m][j] != 0.f) { add_norm(e, uz[m][j], uz[m][j]); add_norm(b, uz[m][j], kz[0][m][j]); }
+            if (sown) { add_norm(e, us, us); add_norm(b, us, ks[0]); }
+        }
+        if (sv.hairer) alive = meet(e, b);
+        if (sv.hairer && alive) {
+            ctrl_phase(&ns, 0, p0, p1, a.n_total);
+            after_ctrl();
+            e = 0.f;
+            f32x4 zt[NI], f1[NI];
+            float s1;
+#pragma unroll
+            for (int m = 0; m < NI; ++m) zt[m] = uz[m] + hstep * kz[0][m];
+            rhs(zt, f1, s1);
+            if (live) {
+#pragma unroll
+                for (int m = 0; m < NI; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (rmask[m][j] != 0.f) add_norm(e, uz[m][j], f1[m][j] - kz[0][m][j]);
+                if (sown) add_norm(e, us, s1 - ks[0]);
+            }
+            alive = meet(e, 0.f);
+            if (alive) { ctrl_phase(&ns, 1, p0, p1, a.n_total); after_ctrl(); }
+        }
+    }
+    // ---- step attempts ----
+    constexpr float BT[7] = {TS_BT1, TS_BT2, TS_BT3, TS_BT4, TS_BT5, TS_BT6, TS_BT7};
+    f32x4 zt[NI];
+#pragma unroll
+    for (int m = 0; m < NI; ++m) zt[m] = zero4;
+    for (int it = 0; alive && !__builtin_amdgcn_readfirstlane(ns.done) && it < sv.maxiters; ++it) {
+        float errsum = 0.f, badcnt = 0.f, sacc = 0.f;
+#ifdef WV_STAMPS
+        const unsigned long long wv_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        // stage state U_{s+1} = u + h sum_j a_{s+1,j} k_j, then k_{s+1} = f(U_{s+1}): ONE copy of the evaluation code, the
+        // stage's row of the table by scalar loads, its result filed by selects (an indexed store would go to scratch)
+#pragma unroll 1
+        for (int s = 1; s <= 6; ++s) {
+            float as[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) as[j] = tab.a[s][j];
+#pragma unroll
+            for (int m = 0; m < NI; ++m) {
+                f32x4 acc = as[0] * kz[0][m];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) acc += as[j] * kz[j][m];
+                zt[m] = uz[m] + hstep * acc;
+            }
+            if (s == 6) {                                  // a_7j = b_j: zt is the new solution (FSAL); its scalar row likewise
+                sacc = as[0] * ks[0];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) sacc += as[j] * ks[j];
+            }
+            f32x4 zd[NI];
+            float sd;
+            rhs(zt, zd, sd);
+#pragma unroll
+            for (int i = 1; i < 7; ++i) {
+#pragma unroll
+                for (int m = 0; m < NI; ++m) kz[i][m] = s == i ? zd[m] : kz[i][m];
+                ks[i] = s == i ? sd : ks[i];
+            }
+        }
+        const float uns = us + hstep * sacc;
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < NI; ++m) {
+                f32x4 ez = BT[0] * kz[0][m];
+#pragma unroll
+                for (int j = 1; j < 7; ++j) ez += BT[j] * kz[j][m];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (rmask[m][j] != 0.f) {
+                        const float scl = fmaf(fmaxf(fabsf(uz[m][j]), fabsf(zt[m][j])), reltol, abstol);
+                        const float x = hstep * ez[j] / scl;
+                        errsum = fmaf(x, x, errsum);
+                        badcnt += !(fabsf(zt[m][j]) <= 3.0e38f) ? 1.f : 0.f;
+                    }
+            }
+            if (sown) {
+                float es = BT[0] * ks[0];
+#pragma unroll
+                for (int j = 1; j < 7; ++j) es += BT[j] * ks[j];
+                const float scl = fmaf(fmaxf(fabsf(us), fabsf(uns)), reltol, abstol);
+                const float x = hstep * es / scl;
+                errsum = fmaf(x, x, errsum);
+                badcnt += !(fabsf(uns) <= 3.0e38f) ? 1.f : 0.f;
+            }
+        }
+#ifdef WV_STAMPS
+        const unsigned long long wv_t1 = __builtin_amdgcn_s_memtime();
+#endif
+        alive = meet(errsum, badcnt);
+#ifdef WV_STAMPS
+        const unsigned long long wv_t2 = __builtin_amdgcn_s_memtime();
+#endif
+        if (!alive) break;
+        const int acc0 = ns.naccept;
+        const float t_att = ns.t, h_att = ns.h;
+        ctrl_after_step(&ns, p0, p1, a.n_total);
+        const bool accepted = __builtin_amdgcn_readfirstlane(ns.naccept != acc0);
+        if (sv.trace && blockIdx.x == 0 && lane == 0 && it < sv.trace_cap) {
+            float* tr = sv.trace + 4 * it;
+            tr[0] = t_att; tr[1] = h_att; tr[2] = ns.eest; tr[3] = accepted ? 1.f : 0.f;
+#ifdef WV_STAMPS
+            tr[0] = (float)(wv_t1 - wv_t0); tr[1] = (float)(wv_t2 - wv_t1); tr[2] = (float)(__builtin_amdgcn_s_memtime() - wv_t2);   // stages+error | meeting | controller
+#endif
+        }
+        after_ctrl();
+        if (accepted) {                                    // u <- u_new, k1 <- k7
+#pragma unroll
+            for (int m = 0; m < NI; ++m) { uz[m] = zt[m]; kz[0][m] = kz[6][m]; }
+            us = uns; ks[0] = ks[6];
+        }
+    }
+    // ---- the final state: to the caller's columns (a bare solve) or to the integrator's buffer set 0; never to the
+    // caller's columns after an abort (the caller may be solving in place; the streamed driver starts again from u0) ----
+    float* out = sv.u_out ? sv.u_out : a.U0;
+    if ((alive || !sv.u_out) && live) {
+        float* o = out + (size_t)smp * D;
+#pragma unroll
+        for (int m = 0; m < NI; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int r = 16 * m + 4 * q + j; if (r < n_in) o[r] = uz[m][j]; }
+        if (sown) o[n_in + q] = us;
+    }
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sv.logpx && alive) {
+        // ---- inference_sol (src/base_icnf.jl:167-189): logp(z) - dlogp, the regulariser rows, |z_aug| ----
+        float ss = 0.f, sa = 0.f;
+#pragma unroll
+        for (int m = 0; m < NI; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 16 * m + 4 * q + j;
+                const float v = uz[m][j];
+                ss = fmaf(v, v, ss);
+                if (r >= sv.nvars) sa = fmaf(v, v, sa);
+            }
+        ss = wv_quad_sum(ss); sa = wv_quad_sum(sa);
+        // scalar rows of this sample: lane group q holds row q; bring E and n to group 0
+        const float s1 = __shfl(us, c + 16, 64), s2 = __shfl(us, c + 32, 64);
+        if (live && q == 0) {
+            const float log2pi = 1.8378770664093453f;
+            const float lp = -0.5f * fmaf((float)n_in, log2pi, ss) - us;
+            const float aa = (sv.norm_z_aug && sv.naugs > 0) ? sqrtf(sa) : 0.f;
+            const float Ev = TRAIN ? s1 : 0.f, Nv = TRAIN ? s2 : 0.f;
+            const size_t bb = (size_t)smp, Bz = (size_t)a.B;
+            sv.logpx[bb] = lp; sv.regs[bb] = Ev; sv.regs[Bz + bb] = Nv; sv.regs[2 * Bz + bb] = aa;
+            v4[0] = lp; v4[1] = Ev; v4[2] = Nv; v4[3] = aa;
+        }
+        if (sv.sums5) {
+            unsigned long long* qb = reinterpret_cast<unsigned long long*>(sv.part) + 2048;
+            const unsigned tag = mbase + (unsigned)nsync + 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v4[j] = wv_wave_sum(v4[j]);
+            if (lane < 4)
+                __hip_atomic_store(qb + 4 * blockIdx.x + lane, ((unsigned long long)tag << 32) | __float_as_uint(lane == 0 ? v4[0] : lane == 1 ? v4[1] : lane == 2 ? v4[2] : v4[3]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0) {                         // wave 0 adds the waves' partials in wave order
+                float c4[4] = {0.f, 0.f, 0.f, 0.f};
+                float late = 0.f;
+                const unsigned long long wait0 = __builtin_amdgcn_s_memrealtime();
+                for (int w = lane; w < G; w += 64) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int got = 0;
+                        for (int spin = 0; spin < sv.spin_limit; ++spin) {
+                            const unsigned long long ww = __hip_atomic_load(qb + 4 * w + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((unsigned)(ww >> 32) == tag) { c4[j] += __uint_as_float((unsigned)ww); got = 1; break; }
+                            if ((spin & 15) == 15 && __builtin_amdgcn_s_memrealtime() - wait0 > sv.wait_ticks) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (!got) late = 1.f;
+                    }
+                }
+                if (late != 0.f) __hip_atomic_store(sv.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c4[j] = wv_wave_sum(c4[j]);
+                late = wv_wave_sum(late);
+                if (lane == 0) {
+                    sv.sums5[0] = c4[0]; sv.sums5[1] = c4[1]; sv.sums5[2] = c4[2]; sv.sums5[3] = c4[3]; sv.sums5[4] = (float)a.B;
+                }
+                if (late != 0.f) alive = false;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && lane == 0) {
+        if (!alive || __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ns.done = 0; ns.n_partials = -1; }
+        __hip_atomic_store(sv.base_dev, mbase + (unsigned)nsync + 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ns.cur = 0;
+        *a.st_out = ns;
+        if (sv.t_out) { sv.t_out[1] += __builtin_amdgcn_s_memrealtime() - sv.t_out[0]; sv.t_out[2] += 1; }
+        mirror_store(a.mirror, a.seq, ns);
+    }
+}
+
+typedef void (*wave_fn)(WaveArgs, Solve3Args, const WvTab);
+template <int NI, int NH, bool TANH>
+wave_fn pick_mode(int mode) {
+    return mode == WV_VJP ? (wave_fn)k_solve_wave<NI, NH, WV_VJP, TANH>
+         : mode == WV_JVP ? (wave_fn)k_solve_wave<NI, NH, WV_JVP, TANH> : (wave_fn)k_solve_wave<NI, NH, WV_TEST, TANH>;
+}
+template <bool TANH>
+wave_fn pick_shape_t(int ni, int nh, int mode) {
+    if (ni == 1 && nh == 1) return pick_mode<1, 1, TANH>(mode);
+    if (ni == 1 && nh == 2) return pick_mode<1, 2, TANH>(mode);
+    if (ni == 1 && nh == 3) return pick_mode<1, 3, TANH>(mode);
+    if (ni == 1 && nh == 4) return pick_mode<1, 4, TANH>(mode);
+    if (ni == 2 && nh == 6) return pick_mode<2, 6, TANH>(mode);
+    return nullptr;
+}
+wave_fn pick_shape(int ni, int nh, int mode, bool tanh2 = true) {
+    return tanh2 ? pick_shape_t<true>(ni, nh, mode) : pick_shape_t<false>(ni, nh, mode);
+}
+
+}  // namespace
+
+// Two-layer networks whose tile counts have an instantiation (n_in <= 16 with up to 64 hidden units; 32 -> 96 -> 32); every
+// activation of the library runs (cnf_act returns sigma' from the forward pass).  One 16-sample tile per wave, one meeting
+// word pair per wave: up to 512 x 16 columns.
+bool wave_solve_supported(const NetDesc& nd, bool train, int B) {
+    if (nd.n_layers != 2 || B < 1) return false;
+    const int ni = (nd.n_in + 15) / 16, nh = (nd.dims[1] + 15) / 16;
+    if (pick_shape(ni, nh, 0) == nullptr) return false;
+    (void)train;
+    return B <= 16 * 512;
+}
+
+cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_params, const float* cond, int cbs, StepState* st_out,
+                             float* U0, const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, const Solve3Args& sv_) {
+    if (!wave_solve_supported(nd, train, B)) return CNF_ERR_UNSUPPORTED;
+    static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); const char* w = getenv("CNF_WAVE"); return (e && e[0] == '0') || (w && w[0] == '0'); }();
+    if (off) return CNF_ERR_UNSUPPORTED;
+    const int ni = (nd.n_in + 15) / 16, nh = (nd.dims[1] + 15) / 16;
+    const int grid = (B + 15) / 16;
+    const int mode = !train ? WV_TEST : (nd.jvp ? WV_JVP : WV_VJP);
+    wave_fn fn = pick_shape(ni, nh, mode, nd.acts[0] == 1 && nd.acts[1] == 1);
+    if (!fn || grid > 512) return CNF_ERR_UNSUPPORTED;
+    WaveArgs a{};
+    a.nd = nd; a.P = d_params; a.eps = eps; a.cond = cond; a.cbs = cbs; a.B = B;
+    a.n_total = (float)((size_t)(nd.n_in + (train ? 3 : 1)) * B);
+    a.U0 = U0; a.st_out = st_out; a.mirror = mirror; a.seq = seq;
+    Solve3Args sv = sv_;
+    sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
+    // (a bare solve reads u0 and writes u_out where the caller keeps them; an inference assembles u0 from sv.xs)
+    if (!sv.xs && !sv.u0) return CNF_ERR_BAD_ARG;
+    WvTab tab = kWvTab;
+    void* args[] = {&a, &sv, &tab};
+    if (hipLaunchKernel((const void*)fn, dim3(grid), dim3(64), args, 0, s) != hipSuccess) {
+        (void)hipGetLastError();
+        return CNF_ERR_UNSUPPORTED;
+    }
+    return CNF_OK;
+}

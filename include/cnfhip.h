@@ -306,6 +306,10 @@ cnf_status cnf_set_solve_wait(cnf_handle h, int wait_us, int poll_limit);
  * the headline kernels use in place of the reference's sgemm (Lux Dense inside src/icnf.jl:331-332).  The parity suite
  * bounds |C - float64| by a multiple of eps32 * sum_k |a b|. */
 cnf_status cnf_selftest_split_product(const float* A, const float* Bt, float* C, int K);
+/* Test support (no handle): n_workgroups workgroups that each claim a whole CU (all of its LDS) and do nothing for
+ * `microseconds` (at most 100000) on `stream` -- a bounded stand-in for another tenant of the GPU, so that the behaviour of a
+ * one-launch solve whose workgroups cannot all be placed (cnf_set_solve_wait, cnf_solve_fallbacks) can be tested. */
+cnf_status cnf_selftest_hold_cus(int n_workgroups, int microseconds, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1712,13 +1712,13 @@ def test_one_launch_solve_falls_back_when_a_workgroup_does_not_arrive():
     ic.close(); ref_ic.close()
 
 
-def test_one_launch_solve_gives_up_within_its_time_bound_on_a_cu_masked_stream():
-    """the stall a co-tenant can cause is bounded in TIME.  A stream restricted to half of the CUs
-    (hipExtStreamCreateWithCUMask) can never hold the 256 workgroups of the headline solve at once: the launch's waits
-    run out after cnf_set_solve_wait's bound (2 ms by default), the call falls back to the streamed driver on the same
-    stream and returns CNF_OK.  Compared with the same call when every wait gives up at its first poll (poll_limit = 1:
-    no waiting at all), the run-out may cost at most 10 ms."""
-    import ctypes as C, time
+def test_one_launch_solve_gives_up_within_its_time_bound_when_cus_are_held():
+    """the stall a co-tenant can cause is bounded in TIME.  128 workgroups of another stream hold a
+    whole CU each for 8 ms (cnf_selftest_hold_cus): the 256 workgroups of the headline solve cannot all be placed, the
+    launch's waits run out after cnf_set_solve_wait's bound (2 ms by default), the call falls back to the streamed driver
+    and returns CNF_OK.  Compared with the same call when every wait gives up at its first poll (poll_limit = 1: no
+    waiting at all), the run-out may cost at most 10 ms -- and did cost something (the bound was what ended the wait)."""
+    import time
     if not _one_launch_expected():
         pytest.skip("the one-launch solve is switched off in this process")
     cfg, _, _ = O.baseline_cfg(3)
@@ -1727,54 +1727,138 @@ def test_one_launch_solve_gives_up_within_its_time_bound_on_a_cu_masked_stream()
     flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
     xs, eps = _dev(rng.standard_normal((cfg.nvars, B))), _dev(rng.standard_normal((cfg.n_in, B)))
     tol = dict(reltol=3.45e-4, abstol=1.19e-7)
-    hip = C.CDLL("libamdhip64.so")
+    ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=tol)
+    want, _ = cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    assert ic.last_stats["launches"] <= 3
+    want = want.clone()
+    side = torch.cuda.Stream()
+    l = _lib.lib()
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    words = (ncu + 31) // 32
-    mask = (C.c_uint32 * words)()
-    for cu in range(0, ncu, 2):                                # every second CU
-        mask[cu // 32] |= 1 << (cu % 32)
-    stream = C.c_void_p()
-    assert hip.hipExtStreamCreateWithCUMask(C.byref(stream), C.c_uint32(words), mask) == 0
-    try:
-        ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=tol)
-        want, _ = cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)       # (default stream: the one-launch solve)
-        assert ic.last_stats["launches"] <= 3
-        want = want.clone()
-        l, h = _lib.lib(), ic.handle()
-        opts = cnf.base_icnf._solve_opts(ic, ic.tspan)
-        lp = torch.empty(B, device="cuda"); regs = torch.empty(3 * B, device="cuda")
-        xc, ec = xs.t().contiguous(), eps.t().contiguous()        # the C ABI's layout: a sample's rows contiguous (Julia column-major)
-        torch.cuda.synchronize()
 
-        def timed():
-            stats = _lib.cnf_solve_stats()
-            t0 = time.perf_counter()
-            _lib.check(l.cnf_inference(h, 1, xc.data_ptr(), ec.data_ptr(), lp.data_ptr(), regs.data_ptr(), None, B,
-                                       C.byref(opts), C.byref(stats), stream), h)
-            assert hip.hipStreamSynchronize(stream) == 0
-            return time.perf_counter() - t0, stats
-        fb0 = ic.solve_fallbacks()
-        ic.set_solve_wait(poll_limit=1)                         # every wait gives up at once: the fallback without the wait
-        t_now = min(timed()[0] for _ in range(3))
-        assert ic.solve_fallbacks() - fb0 == 3
-        assert torch.allclose(lp, want, rtol=5e-3, atol=5e-3)
-        ic.set_solve_wait(poll_limit=0x7fffffff)                # bounded by time alone (2 ms)
-        ts = [timed() for _ in range(3)]
-        assert ic.solve_fallbacks() - fb0 == 6, "a 256-workgroup launch was placed on 128 CUs?"
-        t_wait = min(t for t, _ in ts)
-        assert ts[-1][1].launches > 3
-        assert torch.allclose(lp, want, rtol=5e-3, atol=5e-3), float((lp - want).abs().max())
-        helpers.note(f"one-launch solve on a half-masked stream: fallback after the time bound {1e3 * t_wait:.2f} ms, "
-                     f"without waiting {1e3 * t_now:.2f} ms")
-        assert t_wait - t_now <= 10e-3, (t_wait, t_now)
-        assert t_wait - t_now >= 0.5e-3, (t_wait, t_now)       # (the bound was what ended the wait)
-        # back on an unrestricted stream the handle takes the one-launch path again
-        lp2, _ = cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
-        assert ic.last_stats["launches"] <= 3 and torch.equal(lp2, want)
-        ic.close()
-    finally:
+    def held():
         torch.cuda.synchronize()
-        hip.hipStreamDestroy(stream)
+        assert l.cnf_selftest_hold_cus(ncu // 2, 8000, C.c_void_p(side.cuda_stream)) == 0
+        time.sleep(0.001)                                       # (the holders are placed before the solve is launched)
+        t0 = time.perf_counter()
+        lp, _ = cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+        torch.cuda.current_stream().synchronize()
+        dt = time.perf_counter() - t0
+        return dt, lp, dict(ic.last_stats)
+    fb0 = ic.solve_fallbacks()
+    ic.set_solve_wait(poll_limit=1)                             # every wait gives up at once: the fallback without the wait
+    runs = [held() for _ in range(3)]
+    assert ic.solve_fallbacks() - fb0 == 3
+    assert all(torch.allclose(lp, want, rtol=5e-3, atol=5e-3) for _, lp, _ in runs)
+    t_now = min(r[0] for r in runs)
+    ic.set_solve_wait(poll_limit=0x7fffffff)                    # bounded by time alone (2 ms)
+    runs = [held() for _ in range(3)]
+    assert ic.solve_fallbacks() - fb0 == 6, ("the launch was placed although half of the CUs were held?", [(r[0], r[2]) for r in runs])
+    assert all(torch.allclose(lp, want, rtol=5e-3, atol=5e-3) for _, lp, _ in runs)
+    assert runs[-1][2]["launches"] > 3
+    t_wait = min(r[0] for r in runs)
+    helpers.note(f"one-launch solve with half of the CUs held by another stream: fallback after the time bound {1e3 * t_wait:.2f} ms, "
+                 f"without waiting {1e3 * t_now:.2f} ms")
+    assert t_wait - t_now <= 10e-3, (t_wait, t_now)
+    assert t_wait - t_now >= 0.5e-3, (t_wait, t_now)
+    # with the CUs free again the handle takes the one-launch path
+    torch.cuda.synchronize()
+    lp2, _ = cnf.inference(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    assert ic.last_stats["launches"] <= 3 and torch.equal(lp2, want)
+    ic.close()
+
+
+@pytest.mark.parametrize("dims,nvars,naugs,acts", [
+    ((2, 6, 2), 1, 1, ("tanh", "tanh")),                      # BASELINE config 1 (README.md:47)
+    ((16, 48, 16), 8, 8, ("tanh", "tanh")),                   # BASELINE config 2 (test/regression_tests.jl:7)
+    ((8, 24, 8), 8, 0, ("tanh", "tanh")),
+    ((13, 50, 13), 9, 4, ("softplus", "sigmoid")),            # odd sizes, sigma(0) != 0 in the padded rows
+    ((32, 96, 32), 32, 0, ("tanh", "identity")),              # two input tiles, six hidden tiles
+])
+def test_wave_local_solve_small_networks(dims, nvars, naugs, acts):
+    """k_solve_wave (cnf_wave.hip): two-layer networks whose padded widths fit one wave -- the whole solve in ONE launch,
+    one wave per 16 samples, registers only.  VJP, JVP and TestMode (closed-form exact trace), fixed dt strictly against the
+    float64 oracle and adaptive at the solver tolerance, ragged batches, the route asserted by the launch count, the
+    CNF_WAVE=0 route (k_mfma behind the streamed driver) beside it for the same numbers."""
+    act_id = {"tanh": O.ACT_TANH, "softplus": O.ACT_SOFTPLUS, "sigmoid": O.ACT_SIGMOID, "identity": O.ACT_IDENTITY}
+    net = O.Net(dims, tuple(act_id[a] for a in acts))
+    rng = np.random.default_rng(sum(dims) + 17)
+    flat = O.glorot_params(net, rng, np.float32, 0.1)
+    flat[-dims[2]:] = 0.1 * rng.standard_normal(dims[2]).astype(np.float32)          # non-zero biases
+    layers = [cnf.Dense(i, o, a) for i, o, a in zip(dims[:-1], dims[1:], acts)]
+    n_in = nvars + naugs
+    f64 = lambda a: a.astype(np.float64)
+    one = _one_launch_expected() and os.environ.get("CNF_WAVE") != "0"
+    lam3 = 1e-2 if naugs else 0.0
+    tol = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+    for B in (1, 17, 1000):
+        xs = rng.standard_normal((nvars, B)).astype(np.float32)
+        eps = rng.standard_normal((n_in, B)).astype(np.float32)
+        for jvp in (False, True):
+            cm = cnf.HIPJacVecMatrixMode("mfma") if jvp else cnf.HIPVecJacMatrixMode("mfma")
+            cfg = O.Cfg(net, nvars, naugs, 1e-2, 1e-2, lam3, jvp, tspan=(0.0, 2.0))
+            ic = cnf.construct(cnf.RNODE, cnf.Chain(*layers), nvars, naugs, compute_mode=cm, tspan=(0.0, 2.0), lambda3=lam3,
+                               sol_kwargs=dict(adaptive=False, dt=1 / 8))
+            if not _supported(ic, cnf.TrainMode(), B):
+                ic.close()
+                continue
+            # TrainMode, fixed dt: the final state, logpx and the regularisers at the strict bar
+            prob = cnf.inference_prob(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+            fsol = cnf.base_sol(ic, prob).view().cpu().numpy()
+            assert (prob.stats["launches"] <= 3) == one, (dims, B, jvp, prob.stats)
+            assert prob.stats["nf"] == 1 + 6 * 16
+            rf, ref_lp, ref_regs, _ = O.inference(cfg, f64(flat), f64(xs), f64(eps), True, dt=1 / 8, adaptive=False)
+            assert_parity(fsol, rf, f"wave {dims} fsol jvp={jvp} B={B}", trace_row=n_in)
+            logpx, (E, n, A) = cnf.inference(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+            assert (ic.last_stats["launches"] <= 3) == one
+            assert_parity(logpx.cpu().numpy(), ref_lp, f"wave {dims} logpx jvp={jvp} B={B}")
+            assert_parity(torch.stack([E, n, A]).cpu().numpy(), np.stack(ref_regs), f"wave {dims} regs jvp={jvp} B={B}")
+            # loss sums in the same launch
+            _, _, sums = cnf.inference(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps), with_sums=True)
+            assert float(sums[4]) == B and abs(float(sums[0]) - float(logpx.double().sum())) <= 1e-5 * (abs(float(sums[0])) + 1.0)
+            ic.close()
+        # TestMode: the closed-form exact trace
+        cfg = O.Cfg(net, nvars, naugs, 1e-2, 1e-2, lam3, False, tspan=(0.0, 2.0))
+        ic = cnf.construct(cnf.RNODE, cnf.Chain(*layers), nvars, naugs, compute_mode=cnf.HIPVecJacMatrixMode("mfma"), tspan=(0.0, 2.0),
+                           lambda3=lam3, sol_kwargs=dict(adaptive=False, dt=1 / 8))
+        if _supported(ic, cnf.TestMode(), B):
+            logpx, (E, n, A) = cnf.inference(ic, cnf.TestMode(), _dev(xs), flat, {})
+            assert (ic.last_stats["launches"] <= 3) == one, ic.last_stats
+            _, ref_lp, ref_regs, _ = O.inference(cfg, f64(flat), f64(xs), None, False, dt=1 / 8, adaptive=False)
+            assert_parity(logpx.cpu().numpy(), ref_lp, f"wave {dims} TestMode logpx B={B}")
+            assert float(E.abs().max()) == 0.0 and float(n.abs().max()) == 0.0
+            assert_parity(A.cpu().numpy(), ref_regs[2], f"wave {dims} TestMode A B={B}")
+        ic.close()
+    # adaptive (README tolerances), B = 1000: against a tight float64 solve at the solver tolerance, step counts consistent
+    B = 1000
+    xs = rng.standard_normal((nvars, B)).astype(np.float32)
+    eps = rng.standard_normal((n_in, B)).astype(np.float32)
+    cfg = O.Cfg(net, nvars, naugs, 1e-2, 1e-2, lam3, False, tspan=(0.0, 2.0))
+    ic = cnf.construct(cnf.RNODE, cnf.Chain(*layers), nvars, naugs, compute_mode=cnf.HIPVecJacMatrixMode("mfma"), tspan=(0.0, 2.0),
+                       lambda3=lam3, sol_kwargs=tol)
+    if _supported(ic, cnf.TrainMode(), B):
+        prob = cnf.inference_prob(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+        fsol = cnf.base_sol(ic, prob).view().cpu().numpy()
+        st = prob.stats
+        assert (st["launches"] <= 3) == one and st["nf"] == 2 + 6 * (st["naccept"] + st["nreject"]) and abs(st["t_final"] - 2.0) < 1e-6
+        u0 = O.inference_u0(cfg, xs, True)
+        ref64, _ = O.tsit5_solve(cfg.rhs(f64(flat), f64(eps), True), f64(u0), 0.0, 2.0, reltol=1e-10, abstol=1e-10)
+        assert_parity(fsol, ref64, f"wave {dims} adaptive vs float64", rtol=5e-3, trace_row=n_in)
+        _, cst = CO.solve(cfg, flat, u0, eps, True, **tol)
+        # (abstol = eps: the error estimate of the rows that start at 0 is rounding noise, the step count follows it)
+        assert abs(st["naccept"] - cst["naccept"]) <= max(3, 0.15 * cst["naccept"]), (st, cst)
+    ic.close()
+
+
+def test_wave_local_solve_ab_route():
+    """CNF_WAVE=0 in a child process: the same tests on k_mfma behind the streamed driver (the route the wave kernel
+    replaced) -- both routes stay parity-green against the same oracle."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CNF_WAVE="0", CNF_NO_PARITY_REPORT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-p", "no:cacheprovider", "-k", "test_wave_local_solve_small_networks"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-2000:], r.stderr[-500:])
 
 
 def test_training_trajectories_of_device_and_oracle_gradients_agree():
