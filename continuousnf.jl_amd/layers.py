@@ -115,10 +115,15 @@ class Chain:
         return "Chain(" + ", ".join(f"Dense({l.in_dims} => {l.out_dims}, {l.activation})" for l in self.layers) + ")"
 
 
-def setup(rng, nn: Chain):
+def setup(rng, nn: Chain, init: str = "glorot"):
     """``ps, st = Lux.setup(rng, nn); ps = ComponentArray(ps)`` (mlj_ext/core_icnf.jl:37-38):
     returns the flat Float32 vector -- per layer ``weight`` (out x in, column-major) then
-    ``bias`` -- and an empty state.  Glorot-uniform weights, zero biases."""
+    ``bias`` -- and an empty state.  Lux is not in /root/reference; two initialisations are offered:
+    ``"glorot"`` (default): Glorot-uniform weights, zero biases (Lux 0.5's Dense default);
+    ``"lux_v1"``: Lux >= 1.0's Dense default as remembered (unverifiable here): kaiming-uniform weights
+    U(+-gain sqrt(3 / in)) with gain 5/3 for tanh and 1 otherwise, biases U(+-1 / sqrt(in)).
+    The parameters are an INPUT of the hot path, so neither choice touches parity; it does decide how the
+    reference's regression configuration trains (profiles/round4_training_ablation.md)."""
     if isinstance(rng, (int, np.integer)):
         rng = np.random.default_rng(int(rng))
     if nn.planar is not None:                                 # planar_layer.jl:43-57: (u, w, b), Glorot-uniform vectors, zero bias
@@ -129,11 +134,19 @@ def setup(rng, nn: Chain):
         if p.use_bias:
             parts.append(np.zeros(1))
         return np.concatenate(parts).astype(np.float32), {}
+    if init not in ("glorot", "lux_v1"):
+        raise ValueError("init must be 'glorot' or 'lux_v1'")
     parts = []
     for l in nn.layers:
-        lim = math.sqrt(6.0 / (l.in_dims + l.out_dims))
-        parts.append(rng.uniform(-lim, lim, size=l.in_dims * l.out_dims))
-        parts.append(np.zeros(l.out_dims))
+        if init == "glorot":
+            lim = math.sqrt(6.0 / (l.in_dims + l.out_dims))
+            parts.append(rng.uniform(-lim, lim, size=l.in_dims * l.out_dims))
+            parts.append(np.zeros(l.out_dims))
+        else:
+            gain = 5.0 / 3.0 if l.activation == "tanh" else 1.0
+            lim = gain * math.sqrt(3.0 / l.in_dims)
+            parts.append(rng.uniform(-lim, lim, size=l.in_dims * l.out_dims))
+            parts.append(rng.uniform(-1.0 / math.sqrt(l.in_dims), 1.0 / math.sqrt(l.in_dims), size=l.out_dims))
     return np.concatenate(parts).astype(np.float32), {}
 
 

@@ -24,10 +24,19 @@ from .types import TestMode, TrainMode
 
 @dataclass
 class Lion:
-    """Optimisers.Lion(eta = 0.001, beta = (0.9, 0.999)): x -= eta * sign(b1 m + (1 - b1) g);
-    m = b2 m + (1 - b2) g  (Chen et al. 2023)."""
+    """Optimisers.Lion(eta = 0.001, beta = (0.9, 0.999)), the reference's default optimiser (core_icnf.jl:17).  Optimisers.jl
+    is not in /root/reference, so the rule is restated, in two readings (``rule``):
+
+    * ``"paper"`` (default) -- Chen et al. 2023: x -= eta * sign(b1 m + (1 - b1) g), then m = b2 m + (1 - b2) g;
+    * ``"optimisers"`` -- the update as Optimisers.jl's source states it, from memory and unverifiable here: the state is
+      refreshed FIRST as ``b2 * g + (1 - b2) * state`` (with b2 = 0.999 it is the current gradient to a part in a thousand)
+      and the step is ``eta * sign((b2 - b1) * g + b1 * state)`` -- in effect sign-SGD.
+
+    Which of the two a given Optimisers.jl release runs decides whether the reference's regression configuration trains
+    at all (profiles/round4_training_ablation.md): the momentum form overshoots on the stiff tspan (0, 13) flow."""
     eta: float = 1e-3
     beta: Tuple[float, float] = (0.9, 0.999)
+    rule: str = "paper"
 
     def init(self, ps):
         return {"m": ps.new_zeros(ps.shape)}
@@ -35,8 +44,14 @@ class Lion:
     def apply(self, state, ps, g):
         import torch
         b1, b2 = self.beta
-        ps.sub_(torch.sign(state["m"] * b1 + g * (1 - b1)), alpha=self.eta)
-        state["m"].mul_(b2).add_(g, alpha=1 - b2)
+        if self.rule == "optimisers":
+            state["m"].mul_(1 - b2).add_(g, alpha=b2)
+            ps.sub_(torch.sign(g * (b2 - b1) + state["m"] * b1), alpha=self.eta)
+        elif self.rule == "paper":
+            ps.sub_(torch.sign(state["m"] * b1 + g * (1 - b1)), alpha=self.eta)
+            state["m"].mul_(b2).add_(g, alpha=1 - b2)
+        else:
+            raise ValueError("Lion.rule must be 'paper' or 'optimisers'")
 
 
 @dataclass
@@ -72,6 +87,7 @@ class ICNFModel:
     batch_size: int = 32
     sol_kwargs: dict = field(default_factory=dict)
     callback: Callable[[int, float], Any] | None = None     # (iteration, loss) per batch; not in the reference
+    init: str = "glorot"                                    # layers.setup: "glorot" or "lux_v1" (not in the reference: Lux.setup decides there)
 
 
 def _device_matrix(icnf: ICNF, X):
@@ -101,7 +117,7 @@ def fit(model: ICNFModel, verbosity: int, X, ys=None):
         if ys is None:
             raise ValueError("conditional model: ys is required")
         y = torch.from_numpy(np.ascontiguousarray(np.asarray(ys, dtype=np.float32).T)).to(x.device)
-    ps_host, st = setup(icnf.rng, icnf.nn)                            # core_icnf.jl:37-38
+    ps_host, st = setup(icnf.rng, icnf.nn, init=model.init)           # core_icnf.jl:37-38
     ps = torch.from_numpy(ps_host).to(x.device)
     bs = model.batch_size if model.use_batch else n                   # core_icnf.jl:47-53
     it = 0

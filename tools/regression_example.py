@@ -31,6 +31,10 @@ def main():
     ap.add_argument("--naugs", type=int, default=8)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--eta", type=float, default=1e-3)
+    ap.add_argument("--opt", default="lion", choices=["lion", "lion_optimisers", "adam"],
+                    help="lion: Chen et al.'s rule; lion_optimisers: the rule as Optimisers.jl states it (from memory); adam")
+    ap.add_argument("--init", default="glorot", choices=["glorot", "lux_v1"])
+    ap.add_argument("--data", default="beta", choices=["beta"])
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -52,7 +56,8 @@ def main():
         if it % 960 == 0:
             marks.append((it, float(np.mean(seen[-320:]))))
             print(f"iteration {it}: mean loss of the last 320 batches {marks[-1][1]:.4f}", flush=True)
-    model = mlj.ICNFModel(icnf, optimizers=(mlj.Lion(eta=a.eta),), n_epochs=a.epochs, batch_size=a.batch, callback=cb)
+    opt = {"lion": mlj.Lion(eta=a.eta), "lion_optimisers": mlj.Lion(eta=a.eta, rule="optimisers"), "adam": mlj.Adam(eta=a.eta)}[a.opt]
+    model = mlj.ICNFModel(icnf, optimizers=(opt,), n_epochs=a.epochs, batch_size=a.batch, callback=cb, init=a.init)
     t0 = time.perf_counter()
     fitresult, _, report = mlj.fit(model, 0, r.T)
     t_fit = time.perf_counter() - t0
@@ -66,7 +71,9 @@ def main():
     mad_ = float(np.mean(np.abs(est - act)))                                   # Distances.meanad
     msd_ = float(np.mean((est - act) ** 2))                                    # Distances.msd
     tv_dis = float(np.sum(np.abs(est - act)) / 2 / a.n)                        # totalvariation / n
-    res = dict(config="test/regression_tests.jl:1-49", nvars=nvars, naugs=naugs, n=a.n, epochs=a.epochs,
+    test_nll = float(-est_logpdf.mean())
+    res = dict(config="test/regression_tests.jl:1-49", nvars=nvars, naugs=naugs, n=a.n, epochs=a.epochs, opt=a.opt, init=a.init, eta=a.eta,
+               test_nll_exact_trace=test_nll, true_nll_on_sample=float(-act_logpdf.mean()),
                iterations=int(report["stats"]["iterations"]), fit_seconds=t_fit, ms_per_gradient_step=1e3 * t_fit / max(1, len(seen)),
                pdf_seconds=t_pdf, first_loss=float(np.mean(report["losses"][:32])), last_loss=float(np.mean(report["losses"][-32:])),
                entropy_bound=float(nvars * stats.beta(2.0, 4.0).entropy()),   # E[-log p] of the true density: the NLL cannot go below it
