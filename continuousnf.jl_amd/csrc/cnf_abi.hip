@@ -8,6 +8,7 @@
 #include "cnf_trace.h"
 #include "cnf_mirror.h"
 #include "cnf_wave.h"
+#include "cnf_bcast.h"
 #include "cnf_step3.h"
 #include <immintrin.h>
 #include <sched.h>
@@ -92,6 +93,8 @@ struct cnf_ctx {
     float* d_adj_img = nullptr;   // padded forward/reverse weight images of the MFMA pullback kernel
     bool pt_valid = false;
     bool img_valid = false;       // d_adj_img holds the images of the current parameters
+    float* d_bimg = nullptr;      // k_solve_bcast's images (cnf_bcast.hip), packed on first use after a parameter change
+    bool bimg_valid = false;
     bool trace_on = false;        // this call evaluates through an auxiliary MFMA kernel (cnf_trace.hip) behind the generic driver
     bool aux_train = false;       //   false: TestMode exact trace; true: TrainMode JVP
     const float* aux_eps = nullptr;
@@ -260,6 +263,7 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (h->d_ys) (void)hipFree(h->d_ys);
     if (h->d_PT) (void)hipFree(h->d_PT);
     if (h->d_adj_img) (void)hipFree(h->d_adj_img);
+    if (h->d_bimg) (void)hipFree(h->d_bimg);
     if (h->grad_arena) (void)hipFree(h->grad_arena);
     if (h->traj) (void)hipFree(h->traj);
     if (h->traj_hs) (void)hipFree(h->traj_hs);
@@ -288,6 +292,7 @@ extern "C" cnf_status cnf_set_params(cnf_handle h, const float* flat_dev, size_t
     h->have_params = true;
     h->pt_valid = false;
     h->img_valid = false;
+    h->bimg_valid = false;
     h->cond_B = 0;       // the conditioning bias depends on W1 and b1
     return CNF_OK;
 }
@@ -304,6 +309,7 @@ extern "C" cnf_status cnf_set_params_host(cnf_handle h, const float* flat, size_
     h->have_params = true;
     h->pt_valid = false;
     h->img_valid = false;
+    h->bimg_valid = false;
     h->cond_B = 0;
     return CNF_OK;
 }
@@ -854,7 +860,13 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     // Runge-Kutta rows stay on the CUs for all attempts, the workgroups exchange two floats per attempt.
     // ... or of a small two-layer network, one wave per 16-sample tile, registers only (k_solve_wave, cnf_wave.hip)
     const bool wave_ok = k == CNF_KERNEL_MFMA && !rec && wave_solve_supported(h->nd, train != 0, B);
-    if ((use_mfma || wave_ok) && !lockstep && !h->no_persist) {
+    // ... or of config 5's network at eight columns per CU (k_solve_bcast, cnf_bcast.hip)
+    const bool bcast_ok = k == CNF_KERNEL_MFMA && !rec && !wave_ok && bcast_solve_supported(h->nd, train != 0, B, h->device);
+    if (bcast_ok && !lockstep && !h->no_persist) {
+        if (!h->d_bimg) HIPCHK(h, hipMalloc(&h->d_bimg, bcast_img_floats() * sizeof(float)));
+        if (!h->bimg_valid) { bcast_pack(h->nd, h->d_params, h->d_bimg, st); HIPCHK(h, hipGetLastError()); h->bimg_valid = true; }
+    }
+    if ((use_mfma || wave_ok || bcast_ok) && !lockstep && !h->no_persist) {
         // one such kernel at a time in this process: two of them would each hold CUs the other is waiting for.  Launches
         // queued on ONE stream run one after the other by themselves (submitted inferences); a launch on another stream
         // waits for those first.
@@ -891,6 +903,8 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         if (wave_ok)
             s = wave_solve_launch(h->nd, train != 0, h->d_params, h->nd.n_cond > 0 ? h->d_cond : nullptr, h->cbs, h->d_state, h->U[0],
                                   eps, B, st, h->d_mirror + mslot, base, sv);
+        if (bcast_ok)
+            s = bcast_solve_launch(h->nd, train != 0, h->d_params, h->d_bimg, h->d_state, h->U[0], eps, B, st, h->d_mirror + mslot, base, sv, h->device);
         if (s == CNF_ERR_UNSUPPORTED && use_mfma)
             s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror + mslot, base, sv, h->device,
                                       dump, n, slot, dcap, h->traj_hs, h->K1);

@@ -1,0 +1,14 @@
+// k_solve_bcast (cnf_bcast.hip): the whole Tsit5 solve of BASELINE config 5's network (two tanh layers, 64 < n_in <= 128,
+// 256 < hidden <= 384) at eight samples per CU in one launch: v_mfma_f32_4x4x1_16B_f32 with the activations broadcast as the
+// A operand, W1 resident in registers in both orientations, W2 streamed.  TrainMode / VJP and TestMode (closed-form trace).
+#pragma once
+#include "cnf_mfma.h"
+
+size_t bcast_img_floats();
+// the packed weight images (resident fragments, the W2 streams, C = W1 .* W2^T) from the flat parameter vector
+void bcast_pack(const NetDesc& nd, const float* d_params, float* d_img, hipStream_t s);
+// this network, compute mode and batch (at most 8 columns per CU of `device`)
+bool bcast_solve_supported(const NetDesc& nd, bool train, int B, int device);
+// sv as for mfma_solve_persistent; CNF_ERR_UNSUPPORTED: not this network / batch
+cnf_status bcast_solve_launch(const NetDesc& nd, bool train, const float* d_params, const float* d_img, StepState* st_out, float* U0,
+                              const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, const Solve3Args& sv, int device);

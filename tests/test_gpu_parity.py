@@ -845,6 +845,7 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
                                           "test_one_launch_solve or test_headline_kernels_strict or test_submitted_inferences or "
                                           "test_conditional_model_of_the_headline"),
                      ("CNF_SOLVE_POLL_LIMIT=1", "test_one_launch_solve_falls_back or test_submitted_inferences"),
+                     ("CNF_BCAST=0", "test_config5_one_launch_solve_strict and 1000"),
                      ("CNF_STEP_FP32", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve or "
                                        "test_jvp_mode_headline_shape_step_kernel or ragged or test_headline_kernels_strict"),
                      ("CNF_STEP_V1", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve"),
@@ -1920,6 +1921,61 @@ def test_wave_local_solve_small_networks(dims, nvars, naugs, acts):
         # (abstol = eps: the error estimate of the rows that start at 0 is rounding noise, the step count follows it)
         assert abs(st["naccept"] - cst["naccept"]) <= max(3, 0.15 * cst["naccept"]), (st, cst)
     ic.close()
+
+
+@pytest.mark.parametrize("B", [2048, 1000, 5])
+def test_config5_one_launch_solve_strict_vs_float64(B):
+    """k_solve_bcast (cnf_bcast.hip): BASELINE config 5's network (RNODE 64 + 64, 128-384-128 tanh) at eight columns per CU --
+    4x4x1 MFMA blocks with the activations broadcast, W1 resident, W2 streamed -- in ONE launch.  TrainMode / VJP and
+    TestMode (the closed-form exact trace) at fixed dt: fsol, logpx and the regularisers of sampled columns against the
+    float64 oracle at the strict bar; adaptive: step count and values at the solver tolerance; the route is asserted; ragged
+    batches and a network narrower than the padding; CNF_BCAST=0 (k_mfma behind the streamed driver) runs the same test
+    in test_ab_switches' child."""
+    cases = [(O.baseline_cfg(5)[0], "cfg5")]
+    if B == 1000:
+        cases.append((O.Cfg(O.Net((100, 300, 100), (O.ACT_TANH,) * 2), 70, 30, 1e-2, 1e-2, 1e-2), "100-300-100"))
+    one = _one_launch_expected() and os.environ.get("CNF_BCAST") != "0"
+    f64 = lambda a: a.astype(np.float64)
+    for cfg, name in cases:
+        rng = np.random.default_rng(1700 + B)
+        flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+        xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+        eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
+        idx = np.unique(np.concatenate([np.arange(min(B, 16)), np.arange(max(0, B - 24), B), rng.choice(B, min(B, 96), replace=False)]))
+        ti = torch.from_numpy(idx).cuda()
+        for train in (True, False):
+            mode = cnf.TrainMode() if train else cnf.TestMode()
+            ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
+            logpx, (E, n, A) = cnf.inference(ic, mode, _dev(xs), flat, {}, eps=_dev(eps) if train else None)
+            assert (ic.last_stats["launches"] <= 3) == one, (name, B, train, ic.last_stats)
+            assert ic.last_stats["nf"] == 1 + 6 * 8 and ic.last_stats["kernel_used"] == _lib.KERNEL_MFMA
+            _, ref_lp, ref_regs, _ = O.inference(cfg, f64(flat), f64(xs[:, idx]), f64(eps[:, idx]) if train else None, train,
+                                                 dt=1 / 8, adaptive=False)
+            assert_parity(logpx[ti].cpu().numpy(), ref_lp, f"bcast {name} logpx train={train} B={B}")
+            if train:
+                assert_parity(torch.stack([E, n, A])[:, ti].cpu().numpy(), np.stack(ref_regs), f"bcast {name} regs B={B}")
+            else:
+                assert float(E.abs().max()) == 0.0 and float(n.abs().max()) == 0.0
+                assert_parity(A[ti].cpu().numpy(), ref_regs[2], f"bcast {name} TestMode A B={B}")
+            prob = cnf.inference_prob(ic, mode, _dev(xs), flat, {}, eps=_dev(eps) if train else None)
+            fsol = cnf.base_sol(ic, prob).view()
+            assert (prob.stats["launches"] <= 3) == one
+            u0 = O.inference_u0(cfg, xs[:, idx], train)
+            ref, _ = O.tsit5_solve(cfg.rhs(f64(flat), f64(eps[:, idx]) if train else None, train), f64(u0), *cfg.tspan, dt=1 / 8, adaptive=False)
+            assert_parity(fsol[:, ti].cpu().numpy(), ref, f"bcast {name} fsol train={train} B={B}", trace_row=cfg.n_in)
+            assert ic.solve_fallbacks() == 0
+            ic.close()
+        # adaptive, TrainMode
+        tol = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+        ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=tol)
+        prob = cnf.inference_prob(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+        fsol = cnf.base_sol(ic, prob).view()
+        st = prob.stats
+        assert (st["launches"] <= 3) == one and st["nf"] == 2 + 6 * (st["naccept"] + st["nreject"]) and abs(st["t_final"] - cfg.tspan[1]) < 1e-6
+        u0 = O.inference_u0(cfg, xs[:, idx], True)
+        ref64, _ = O.tsit5_solve(cfg.rhs(f64(flat), f64(eps[:, idx]), True), f64(u0), *cfg.tspan, reltol=1e-10, abstol=1e-10)
+        assert_parity(fsol[:, ti].cpu().numpy(), ref64, f"bcast {name} adaptive vs float64 B={B}", rtol=5e-3, trace_row=cfg.n_in)
+        ic.close()
 
 
 def test_wave_local_solve_ab_route():
