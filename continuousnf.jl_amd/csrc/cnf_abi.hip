@@ -866,7 +866,10 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         if (!h->d_bimg) HIPCHK(h, hipMalloc(&h->d_bimg, bcast_img_floats() * sizeof(float)));
         if (!h->bimg_valid) { bcast_pack(h->nd, h->d_params, h->d_bimg, st); HIPCHK(h, hipGetLastError()); h->bimg_valid = true; }
     }
-    if ((use_mfma || wave_ok || bcast_ok) && !lockstep && !h->no_persist) {
+    // ... or of the 32-128-128-32 network in TestMode (exact trace: k_trace3s<SOLVE>, cnf_trace.hip)
+    const bool tsolve_ok = trace_fused && !wave_ok && !bcast_ok && !use_mfma && (!h->nd.n_cond) &&
+                           trace_solve_supported(h->nd, adj_mfma_layout(h->nd, grad_layout(h->nd)), B, h->device);
+    if ((use_mfma || wave_ok || bcast_ok || tsolve_ok) && !lockstep && !h->no_persist) {
         // one such kernel at a time in this process: two of them would each hold CUs the other is waiting for.  Launches
         // queued on ONE stream run one after the other by themselves (submitted inferences); a launch on another stream
         // waits for those first.
@@ -888,9 +891,16 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         const int wus = h->wait_us > 0 ? h->wait_us : wait_us;
         sv.wait_ticks = wus < 20000000 ? 100u * (unsigned)wus : 2000000000u;   // (per tile: the launcher scales it)
         sv.trace = h->step_trace; sv.trace_cap = h->step_trace_cap;
-        const bool fused_io = post && post->xs;            // inference: u0 from the data columns and the post-processing in the launch
+        // (k_trace3s<SOLVE> works on the integrator's buffers: u0 is assembled / copied into U[0] in front of it, the
+        // post-processing follows it -- three launches per inference)
+        if (tsolve_ok) {
+            if (post && post->xs) launch_build_u0(post->xs, h->U[0], h->nd.nvars, D, B, st);
+            else if (u0 != h->U[0]) HIPCHK(h, hipMemcpyAsync(h->U[0], u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+            ++launches;
+        }
+        const bool fused_io = post && post->xs && !tsolve_ok;   // inference: u0 from the data columns and the post-processing in the launch
         if (fused_io) { sv.xs = post->xs; sv.logpx = post->logpx; sv.regs = post->regs; sv.sums5 = post->sums5; }
-        else { sv.u0 = u0; sv.u_out = rec ? nullptr : u_out; }   // (the launcher reads u0 in place or copies it into U[0])
+        else { sv.u0 = u0; sv.u_out = (rec || tsolve_ok) ? nullptr : u_out; }   // (the launcher reads u0 in place or copies it into U[0])
         // gradient path: every attempt files u_n and its stage states in the slot of step `naccept` (as the streamed
         // recording does); the store is sized beforehand and the solve repeated if it took more steps than fit
         float* dump = nullptr; size_t slot = 0; int dcap = 0;
@@ -903,6 +913,17 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         if (wave_ok)
             s = wave_solve_launch(h->nd, train != 0, h->d_params, h->nd.n_cond > 0 ? h->d_cond : nullptr, h->cbs, h->d_state, h->U[0],
                                   eps, B, st, h->d_mirror + mslot, base, sv);
+        if (tsolve_ok) {
+            const GradLayout g = grad_layout(h->nd);
+            const AdjMfmaLayout m = adj_mfma_layout(h->nd, g);
+            TraceArgs ta{};
+            ta.B = B; ta.U[0] = h->U[0]; ta.U[1] = h->U[1]; ta.K1[0] = h->K1[0]; ta.K1[1] = h->K1[1];
+            for (int i = 0; i < 5; ++i) ta.Ks[i] = h->Ks[i];
+            ta.norm_kind = -1; ta.st_mut = h->d_state; ta.n_total = (float)n;
+            ta.mirror = h->d_mirror + mslot; ta.seq = base;
+            s = launch_trace_solve(h->nd, g, m, h->d_adj_img, ta, sv, st) == hipSuccess ? CNF_OK : CNF_ERR_UNSUPPORTED;
+            if (s != CNF_OK) (void)hipGetLastError();
+        }
         if (bcast_ok)
             s = bcast_solve_launch(h->nd, train != 0, h->d_params, h->d_bimg, h->d_state, h->U[0], eps, B, st, h->d_mirror + mslot, base, sv, h->device);
         if (s == CNF_ERR_UNSUPPORTED && use_mfma)

@@ -45,6 +45,11 @@ hipError_t launch_trace_mfma(const NetDesc& nd, const GradLayout& g, const AdjMf
                              const TraceArgs& a, hipStream_t s);
 bool trace_fused_supported(const NetDesc& nd, const AdjMfmaLayout& m, int B);
 int trace_fused_grid(int B);          // workgroups (= error partials) of a fused launch
+// the whole TestMode solve in one launch (k_trace3s<SOLVE>): needs Solve3Args (cnf_mfma.h)
+struct Solve3Args;
+bool trace_solve_supported(const NetDesc& nd, const AdjMfmaLayout& m, int B, int device);
+hipError_t launch_trace_solve(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                              const TraceArgs& a, const Solve3Args& sv, hipStream_t s);
 bool jvp_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
 hipError_t launch_jvp_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                            const TraceArgs& a, const float* eps, hipStream_t s);

@@ -10,6 +10,7 @@
 // closed form in cnf_mfma.hip instead.
 #include <cstdlib>
 #include "cnf_trace.h"
+#include "cnf_mfma.h"
 #include "cnf_am.h"
 
 #define TR_NCMAX 8
@@ -469,13 +470,21 @@ k_trace3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const float
 //   launch per attempt.  norm_kind 0 / 1 fuse the two norms of the automatic initial dt into the plain launches likewise.
 // ---------------------------------------------------------------------------------------------------
 #include "cnf_split.h"
-template <bool ALL_TANH, bool STEP, int NS, int NIP, int H1, int H2>
+//   SOLVE: the WHOLE solve in this launch (the state in a.U[0] on entry, in a.U[cur] on exit): k1 = f(u0), the two
+//   evaluations and norms of the automatic initial dt, then the step attempts -- STEP's six stages each -- with the
+//   workgroups MEETING once per norm through the tagged words of k_solve3b (cnf_step3.hip) instead of a ticket and a launch
+//   boundary: every workgroup adds the same partials in the same order and runs the same controller.  Needs every
+//   workgroup resident (the launcher bounds the grid by the CU count); every wait is bounded (sv.wait_ticks / spin_limit),
+//   a run-out ends the launch with the abort word and the host streams the launches instead.
+template <bool ALL_TANH, bool STEP, int NS, int NIP, int H1, int H2, bool SOLVE = false>
 __global__ void __launch_bounds__(AM_THREADS, 2)
-k_trace3s(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const float* __restrict__ img, TraceArgs a) {
+k_trace3s(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const float* __restrict__ img, TraceArgs a, Solve3Args sv) {
     extern __shared__ float lds[];
-    const StepState* stp = a.st ? a.st : reinterpret_cast<const StepState*>(img);
-    const int st_done = stp->done, st_cur = stp->cur;
-    const float st_h = stp->h;
+    static_assert(!(SOLVE && STEP), "SOLVE contains STEP's attempt");
+    const StepState* stp = (a.st && !SOLVE) ? a.st : reinterpret_cast<const StepState*>(img);
+    const int st_done = SOLVE ? 0 : stp->done;
+    int st_cur = SOLVE ? 0 : stp->cur;
+    float st_h = SOLVE ? sv.init.h : stp->h;
     constexpr int TI = NIP / 16, KB = H1 / 16, K0 = NIP / 16;
     static_assert(NIP == 32 && H1 == 128 && H2 == 128 && AM_WAVES == 8, "one row tile of W1 and of W2 per wave, K = n_in = one k-block");
     const int PD = tl.PD;
@@ -491,7 +500,7 @@ k_trace3s(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const floa
     unsigned long long ts1 = 0, ts2 = 0, ts3 = 0;
 #endif
     const int es = tid >> 5, er = tid & 31;                            // (sample, input row): NIP == 32 rows
-    if (a.st && st_done) {                           // queued past the end of the solve: keep the host's view current and leave
+    if (!SOLVE && a.st && st_done) {                 // queued past the end of the solve: keep the host's view current and leave
         if (a.ticket && blockIdx.x == 0 && tid == 0) mirror_store(a.mirror, a.seq, *a.st);
         return;
     }
@@ -545,24 +554,39 @@ k_trace3s(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const floa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ts1 = __builtin_amdgcn_s_memtime();
 #endif
-  for (int stage = 1; stage <= (STEP ? 6 : 1); ++stage) {
-    // this evaluation's stage state and destination (STEP: of stage `stage`; else as the arguments say)
-    const int nk = STEP ? stage : a.nk;
+    // SOLVE: the passes of the solve -- 0: k1 = f(u0) (+ the first norms of the automatic initial dt), 1: f(u0 + h0 k1) and its
+    // norm, 2..: step attempts; the integrator state lives in LDS (thread 0 runs the controller on it after every meeting)
+    float* const sol = red + NS * AM_WAVES;              // SOLVE scratch: [0] h, [1] cur, [2] done, [3] alive; [8..] the StepState
+    StepState* const ns = reinterpret_cast<StepState*>(sol + 8);
+    static_assert(sizeof(StepState) <= 24 * sizeof(float), "fits the scratch words");
+    int pass = 0, nsync = 0, it_ = 0;
+    unsigned mbase = 0;
+    if (SOLVE) {
+        if (tid == 0) *ns = sv.init;
+        mbase = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sv.base_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (sv.t_out && blockIdx.x == 0 && tid == 0) sv.t_out[0] = __builtin_amdgcn_s_memrealtime();
+    }
+    bool sol_alive = true;
+  for (;;) {
+    const bool attempt = SOLVE ? pass >= 2 : STEP;
+  for (int stage = 1; stage <= (attempt ? 6 : 1); ++stage) {
+    // this evaluation's stage state and destination (an attempt: of stage `stage`; else as the arguments / the pass say)
+    const int nk = attempt ? stage : (SOLVE ? pass : a.nk);
     float cf[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) cf[j] = STEP ? kTsit5Row[stage][j] : a.coef[j];
-    const bool is_k7 = STEP ? stage == 6 : (a.st && a.du_is_k7), also_unew = STEP ? stage == 6 : a.also_unew != 0;
+    for (int j = 0; j < 6; ++j) cf[j] = attempt ? kTsit5Row[stage][j] : (SOLVE ? (j == 0 ? 1.f : 0.f) : a.coef[j]);
+    const bool is_k7 = attempt ? stage == 6 : (!SOLVE && a.st && a.du_is_k7), also_unew = attempt ? stage == 6 : (!SOLVE && a.also_unew != 0);
     float* du = is_k7 ? (st_cur ? a.K1[0] : a.K1[1])
-                      : (STEP ? const_cast<float*>(stage == 1 ? a.Ks[0] : stage == 2 ? a.Ks[1] : stage == 3 ? a.Ks[2] : stage == 4 ? a.Ks[3] : a.Ks[4])
-                              : a.du);
+                      : (attempt ? const_cast<float*>(stage == 1 ? a.Ks[0] : stage == 2 ? a.Ks[1] : stage == 3 ? a.Ks[2] : stage == 4 ? a.Ks[3] : a.Ks[4])
+                                 : (SOLVE ? (pass == 0 ? (st_cur ? a.K1[1] : a.K1[0]) : const_cast<float*>(a.Ks[0])) : a.du));
     // entry `idx` of the state the evaluation runs at (trace_in with this stage's coefficients).  An opaque zero in the
     // index, new in every stage, keeps the compiler from hoisting the 64-bit addresses of the seven arrays (two sample halves,
     // two rows each) out of the stage loop -- 56 registers it then has to spill around the trace loop.
     int oz = 0;
-    if (STEP) asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+    if (STEP || SOLVE) asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
     auto state_in = [&](size_t idx) {
         idx += (size_t)oz;
-        if (nk == 0) return a.u[idx];
+        if (nk == 0) return SOLVE ? (st_cur ? a.U[1] : a.U[0])[idx] : a.u[idx];
         float acc = cf[0] * (st_cur ? a.K1[1] : a.K1[0])[idx];
         if (nk > 1) acc = fmaf(cf[1], a.Ks[0][idx], acc);
         if (nk > 2) acc = fmaf(cf[2], a.Ks[1][idx], acc);
@@ -754,8 +778,132 @@ k_trace3s(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const floa
     }
     // The stage derivative just written is read back by OTHER threads of this workgroup (the next stage state, the norms):
     // the stores have to be complete before anybody loads those lines (nothing of them is in this CU's L1 yet).
-    if (STEP || a.norm_kind >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); am_barrier(); }
+    if (STEP || SOLVE || a.norm_kind >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); am_barrier(); }
   }
+    if (SOLVE) {
+        // ---- the norm of this pass over this workgroup's entries, the meeting, the controller ----
+        const int nkind = pass >= 2 ? 2 : pass;
+        const bool hairer = sv.hairer != 0;
+        if (pass == 0 && !hairer) { pass = 2; continue; }
+        const float abstol = ns->abstol, reltol = ns->reltol;
+        const float* U = st_cur ? a.U[1] : a.U[0];
+        const float* K1c = st_cur ? a.K1[1] : a.K1[0];
+        float p0 = 0.f, p1 = 0.f;
+        auto entry = [&](size_t i) {
+            if (nkind == 0) {
+                const float uv = U[i], sk = fmaf(fabsf(uv), reltol, abstol);
+                const float x = uv / sk, y = K1c[i] / sk;
+                p0 = fmaf(x, x, p0); p1 = fmaf(y, y, p1);
+            } else if (nkind == 1) {
+                const float uv = U[i], sk = fmaf(fabsf(uv), reltol, abstol);
+                const float x = (a.Ks[0][i] - K1c[i]) / sk;
+                p0 = fmaf(x, x, p0);
+            } else {
+                const float* un = st_cur ? a.U[0] : a.U[1];
+                const float* k7 = st_cur ? a.K1[0] : a.K1[1];
+                float e = TS_BT1 * K1c[i];
+                e = fmaf(TS_BT2, a.Ks[0][i], e); e = fmaf(TS_BT3, a.Ks[1][i], e); e = fmaf(TS_BT4, a.Ks[2][i], e);
+                e = fmaf(TS_BT5, a.Ks[3][i], e); e = fmaf(TS_BT6, a.Ks[4][i], e); e = fmaf(TS_BT7, k7[i], e);
+                e *= st_h;
+                const float uv = U[i], nv = un[i];
+                const float sc = fmaf(fmaxf(fabsf(uv), fabsf(nv)), reltol, abstol);
+                const float x = e / sc;
+                p0 = fmaf(x, x, p0);
+                if (!(fabsf(nv) <= 3.0e38f)) p1 += 1.f;
+            }
+        };
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+            const int sm = es + 16 * hf;
+            if (b0 + sm < a.B) {
+                if (er < n_in) entry((size_t)(b0 + sm) * D + er);
+                if (er == 0) entry((size_t)(b0 + sm) * D + n_in);
+            }
+        }
+        auto wsum = [&](float v) {
+            v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+            v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+            v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
+            v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));
+            const int i = __float_as_int(v);
+            return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
+                   (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
+        };
+        float* nr = red;
+        p0 = wsum(p0); p1 = wsum(p1);
+        if (lane == 0) { nr[wave] = p0; nr[8 + wave] = p1; }
+        am_barrier();
+        unsigned long long* pb = reinterpret_cast<unsigned long long*>(sv.part) + (nsync & 1) * 1024;
+        const unsigned tag = mbase + (unsigned)nsync + 1u;
+        if (tid == 0) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int w = 0; w < AM_WAVES; ++w) { s0 += nr[w]; s1 += nr[8 + w]; }
+            __hip_atomic_store(pb + 2 * blockIdx.x, ((unsigned long long)tag << 32) | __float_as_uint(s0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pb + 2 * blockIdx.x + 1, ((unsigned long long)tag << 32) | __float_as_uint(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float q0 = 0.f, q1 = 0.f;
+        int ok = 1;
+        if (tid < (int)gridDim.x) {                      // thread i polls workgroup i's two words (grid <= AM_THREADS)
+            typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+            const auto prs = __builtin_amdgcn_make_buffer_rsrc(pb, 0, 16 * 512, 0x00020000);
+            ok = 0;
+            const unsigned long long wait0 = __builtin_amdgcn_s_memrealtime();
+            for (int spin = 0; spin < sv.spin_limit; ++spin) {
+                const u32x4p wq = __builtin_bit_cast(u32x4p, __builtin_amdgcn_raw_buffer_load_b128(prs, 16 * tid, 0, 0x11));
+                if (wq.y == tag && wq.w == tag) { q0 = __uint_as_float(wq.x); q1 = __uint_as_float(wq.z); ok = 1; break; }
+                if ((spin & 63) == 63 && __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if ((spin & 15) == 15 && __builtin_amdgcn_s_memrealtime() - wait0 > sv.wait_ticks) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok) __hip_atomic_store(sv.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        q0 = wsum(q0); q1 = wsum(q1);
+        const float bad = wsum(ok ? 0.f : 1.f);
+        am_barrier();                                    // (thread 0 has read nr[])
+        if (lane == 0) { nr[wave] = q0; nr[8 + wave] = q1; nr[16 + wave] = bad; }
+        am_barrier();
+        ++nsync;
+        if (tid == 0) {
+            float s0 = 0.f, s1 = 0.f, sb = 0.f;
+            for (int w = 0; w < AM_WAVES; ++w) { s0 += nr[w]; s1 += nr[8 + w]; sb += nr[16 + w]; }
+            int accepted = 0;
+            if (sb == 0.f) {
+                if (nkind < 2) ctrl_phase(ns, nkind, s0, s1, a.n_total);
+                else {
+                    const int acc0 = ns->naccept;
+                    const float t_att = ns->t, h_att = ns->h;
+                    ctrl_after_step(ns, s0, s1, a.n_total);
+                    accepted = ns->naccept != acc0;
+                    if (sv.trace && blockIdx.x == 0 && it_ < sv.trace_cap) {
+                        float* tr = sv.trace + 4 * it_;
+                        tr[0] = t_att; tr[1] = h_att; tr[2] = ns->eest; tr[3] = accepted ? 1.f : 0.f;
+                    }
+                }
+            }
+            sol[0] = ns->h; sol[1] = __int_as_float(ns->cur); sol[2] = __int_as_float(ns->done); sol[3] = sb == 0.f ? 1.f : 0.f;
+        }
+        am_barrier();
+        st_h = sol[0]; st_cur = __float_as_int(sol[1]);
+        const int done = __float_as_int(sol[2]);
+        sol_alive = sol[3] != 0.f;
+        am_barrier();
+        if (pass >= 2) ++it_;
+        pass = pass < 2 ? pass + 1 : 2;
+        if (!sol_alive || done || it_ >= sv.maxiters) break;
+        continue;
+    }
+    break;
+  }
+    if (SOLVE) {
+        if (blockIdx.x == 0 && tid == 0) {
+            if (!sol_alive || __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ns->done = 0; ns->n_partials = -1; }
+            __hip_atomic_store(sv.base_dev, mbase + (unsigned)nsync + 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *a.st_mut = *ns;
+            if (sv.t_out) { sv.t_out[1] += __builtin_amdgcn_s_memrealtime() - sv.t_out[0]; sv.t_out[2] += 1; }
+            mirror_store(a.mirror, a.seq, *ns);
+        }
+        return;
+    }
     if (a.norm_kind < 0) return;
     // ---- fused norm (k_norm_partials: kind 0 / 1 = the two norms of the automatic initial dt, 2 = the error estimate of
     // the attempt) over this workgroup's 32 x D entries, then -- in the workgroup that draws the last ticket -- the controller
@@ -981,6 +1129,36 @@ bool trace_fused_supported(const NetDesc& nd, const AdjMfmaLayout& m, int B) {
 static int trace3s_ns(int B) { return B >= 32 * 256 ? 32 : 16; }
 int trace_fused_grid(int B) { const int ns = trace3s_ns(B); return (B + ns - 1) / ns; }
 
+// The whole TestMode solve of the 32-128-128-32 network in one launch (k_trace3s<SOLVE>): the state in a.U[0], the final state
+// in a.U[cur]; a.st_mut receives the final integrator state, sv carries the initial state and the meeting words.  The grid
+// must be resident at once: one workgroup per CU.
+bool trace_solve_supported(const NetDesc& nd, const AdjMfmaLayout& m, int B, int device) {
+    if (!trace_fused_supported(nd, m, B)) return false;
+    static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); const char* w = getenv("CNF_TRACE_SOLVE"); return (e && e[0] == '0') || (w && w[0] == '0'); }();
+    if (off) return false;
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return trace_fused_grid(B) <= n_cu && trace_fused_grid(B) <= AM_THREADS;
+}
+hipError_t launch_trace_solve(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                              const TraceArgs& a, const Solve3Args& sv, hipStream_t s) {
+    const TraceLayout tl = trace_layout(nd, m);
+    bool all_tanh = true;
+    for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
+    const int PSf = pad8m16(m.maxd);
+    const int ns = trace3s_ns(a.B);
+    const size_t lds = (size_t)(ns * tl.PD + 2 * ns * PSf + AM_WAVES * ns * (32 + 4) + ns * AM_WAVES + 32) * sizeof(float);
+    const dim3 grid((a.B + ns - 1) / ns), block(AM_THREADS);
+    const void* fn;
+    if (ns == 32) fn = all_tanh ? (const void*)k_trace3s<true, false, 32, 32, 128, 128, true> : (const void*)k_trace3s<false, false, 32, 32, 128, 128, true>;
+    else fn = all_tanh ? (const void*)k_trace3s<true, false, 16, 32, 128, 128, true> : (const void*)k_trace3s<false, false, 16, 32, 128, 128, true>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    NetDesc nd_ = nd; GradLayout g_ = g; AdjMfmaLayout m_ = m; TraceLayout tl_ = tl; TraceArgs a_ = a; Solve3Args sv_ = sv;
+    void* args[] = {&nd_, &g_, &m_, &tl_, &img, &a_, &sv_};
+    return hipLaunchKernel(fn, grid, block, args, lds, s);
+}
+
 hipError_t launch_trace_mfma(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                              const TraceArgs& a, hipStream_t s) {
     const TraceLayout tl = trace_layout(nd, m);
@@ -1005,7 +1183,8 @@ hipError_t launch_trace_mfma(const NetDesc& nd, const GradLayout& g, const AdjMf
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         NetDesc nd_ = nd; GradLayout g_ = g; AdjMfmaLayout m_ = m; TraceLayout tl_ = tl; TraceArgs a_ = a;
-        void* args[] = {&nd_, &g_, &m_, &tl_, &img, &a_};
+        Solve3Args sv_{};
+        void* args[] = {&nd_, &g_, &m_, &tl_, &img, &a_, &sv_};
         return hipLaunchKernel(fn, grid, block, args, lds, s);
     }
     if (trace3_shape(nd, m) && !generic_only) {          // resident-fragment kernel (A/B switch: CNF_TRACE_GENERIC=1)

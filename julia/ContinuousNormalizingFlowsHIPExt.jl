@@ -112,11 +112,19 @@ end
 # of that object plus a version counter -- no pass over the data per call.  Code that updates `p` IN PLACE between solves
 # (an optimiser) bumps the counter with `params_updated!(p)`; `base_sol` (once per solve) uploads unconditionally, which
 # costs one 100 KB copy per solve and cannot go stale.
-const UPLOADED = Dict{Ptr{Cvoid}, Tuple{UInt, UInt}}()
+# The key also carries a cheap FINGERPRINT of the content (length, first and last entry, the sum of 64 strided entries:
+# ~70 loads, no pass over the vector), so that an in-place update without `params_updated!`, or an `objectid` reused by a
+# new vector after garbage collection, is caught unless it leaves all of those unchanged.
+const UPLOADED = Dict{Ptr{Cvoid}, Tuple{UInt, UInt, UInt}}()
 const PARAM_VERSION = IdDict{Any, UInt}()
 params_updated!(p) = (PARAM_VERSION[p] = get(PARAM_VERSION, p, UInt(0)) + UInt(1); p)
+function fingerprint(p)
+    n = length(p)
+    n == 0 && return UInt(0)
+    hash((n, p[begin], p[end], sum(@view p[begin:max(1, n ÷ 64):end])))
+end
 function set_params!(h, p; force::Bool = false)
-    key = (objectid(p), get(PARAM_VERSION, p, UInt(0)))
+    key = (objectid(p), get(PARAM_VERSION, p, UInt(0)), fingerprint(p))
     !force && get(UPLOADED, h, nothing) == key && return nothing
     v = Vector{Float32}(p)
     check(@ccall(libcnfhip.cnf_set_params_host(h::Ptr{Cvoid}, v::Ptr{Float32}, length(v)::Csize_t)::Cint), h)

@@ -696,7 +696,10 @@ def test_lockstep_shards_follow_the_unsharded_solve(kernel):
     # smoothly except at its dead zone (1 <= q <= 1.2 -> q = 1), so dt is compared loosely
     assert st[0]["dt_last"] == st[1]["dt_last"] and st[0]["naccept"] == st[1]["naccept"]
     assert abs(st[0]["naccept"] - ref_st["naccept"]) <= 1 and st[0]["nreject"] == ref_st["nreject"], (st, ref_st)
-    assert abs(st[0]["dt_last"] - ref_st["dt_last"]) <= 0.25 * ref_st["dt_last"]
+    # (the unsharded solve of a small network runs on another kernel -- k_solve_wave -- than the lock-step shards -- step
+    # launches of k_mfma: where the two take a different number of steps, the last, clipped step differs as well)
+    if st[0]["naccept"] == ref_st["naccept"]:
+        assert abs(st[0]["dt_last"] - ref_st["dt_last"]) <= 0.25 * ref_st["dt_last"]
     assert calls[0] == calls[1] == 2 + st[0]["naccept"] + st[0]["nreject"]
     assert_parity(got, ref, "lock-step shards vs unsharded", rtol=1e-4, trace_row=cfg.n_in)
 
@@ -846,6 +849,7 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
                                           "test_conditional_model_of_the_headline"),
                      ("CNF_SOLVE_POLL_LIMIT=1", "test_one_launch_solve_falls_back or test_submitted_inferences"),
                      ("CNF_BCAST=0", "test_config5_one_launch_solve_strict and 1000"),
+                     ("CNF_TRACE_SOLVE=0", "test_exact_trace_mfma_deep_networks or test_testmode_headline_network_is_three_launches"),
                      ("CNF_STEP_FP32", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve or "
                                        "test_jvp_mode_headline_shape_step_kernel or ragged or test_headline_kernels_strict"),
                      ("CNF_STEP_V1", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve"),
@@ -1976,6 +1980,39 @@ def test_config5_one_launch_solve_strict_vs_float64(B):
         ref64, _ = O.tsit5_solve(cfg.rhs(f64(flat), f64(eps[:, idx]), True), f64(u0), *cfg.tspan, reltol=1e-10, abstol=1e-10)
         assert_parity(fsol[:, ti].cpu().numpy(), ref64, f"bcast {name} adaptive vs float64 B={B}", rtol=5e-3, trace_row=cfg.n_in)
         ic.close()
+
+
+def test_testmode_headline_network_is_three_launches():
+    """TestMode (`logpdf` of the README, README.md:98; exact trace, src/icnf.jl:148-164) on the
+    32-128-128-32 network at B = 8192: u0 assembly, the WHOLE adaptive solve (k_trace3s<SOLVE>: k1, the automatic initial dt,
+    every step attempt with its six stages, norm and controller; the workgroups meet once per norm) and the post-processing
+    = three launches (round 3: 15).  Values equal the streamed route's to the solver tolerance (same kernel body, same
+    controller; CNF_TRACE_SOLVE=0 runs this test on the streamed route in test_ab_switches' child) and sampled columns
+    match the float64 oracle."""
+    cfg, _, _ = O.baseline_cfg(3)
+    rng = np.random.default_rng(1800)
+    B = 8192
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+    tol = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+    ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=tol)
+    logpx, (E, n, A) = cnf.inference(ic, cnf.TestMode(), _dev(xs), flat, {})
+    st = ic.last_stats
+    one = _one_launch_expected() and os.environ.get("CNF_TRACE_SOLVE") != "0" and os.environ.get("CNF_TRACE_FP32") != "1" \
+        and os.environ.get("CNF_TRACE_GENERIC") != "1" and os.environ.get("CNF_TRACE_UNFUSED") != "1"
+    assert (st["launches"] <= 3) == one, st
+    assert st["nf"] == 2 + 6 * (st["naccept"] + st["nreject"]) and abs(st["t_final"] - 1.0) < 1e-6
+    idx = rng.choice(B, 48, replace=False)
+    f64 = lambda a: a.astype(np.float64)
+    _, ref_lp, _, _ = O.inference(cfg, f64(flat), f64(xs[:, idx]), None, False, reltol=1e-10, abstol=1e-10)
+    assert_parity(logpx[torch.from_numpy(idx).cuda()].cpu().numpy(), ref_lp, "TestMode headline network, one-launch solve vs float64", rtol=5e-3)
+    # fixed dt: strict
+    ic2 = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
+    lp2, _ = cnf.inference(ic2, cnf.TestMode(), _dev(xs), flat, {})
+    assert (ic2.last_stats["launches"] <= 3) == one and ic2.last_stats["nf"] == 1 + 6 * 8
+    _, ref2, _, _ = O.inference(cfg, f64(flat), f64(xs[:, idx]), None, False, dt=1 / 8, adaptive=False)
+    assert_parity(lp2[torch.from_numpy(idx).cuda()].cpu().numpy(), ref2, "TestMode headline network, one-launch solve, fixed dt")
+    ic.close(); ic2.close()
 
 
 def test_wave_local_solve_ab_route():
