@@ -66,24 +66,31 @@ static const BcTab kBcTab = {{
 //   TestMode:  phases W1, W2, C; blocks 2, 5, 8, 11 stream (16 requests per phase, 48 per evaluation), the others are
 //              resident (128 per phase, 384 in all).
 // Image per mode and wave: [resident: 96 x (lane 64 x 4)] then [stream: SLEN x (lane 64 x 4)] floats.
+//   TrainMode, JVP compute mode (src/icnf.jl:384-420): ONE forward sweep of the state and the tangent columns -- phases
+//              W1 [z, eps] and W2 [h1, tau1], no transposed weights -- so W1 and W2 are resident WHOLLY (2 x 192) and nothing
+//              streams at all.
 constexpr int BC_NRES = 384;
-__host__ __device__ constexpr int bc_slen(bool test) { return test ? 48 : 96; }
-__host__ __device__ constexpr int bc_wave_floats(bool test) { return (BC_NRES + 4 * bc_slen(test)) * 64; }
-constexpr int BC_TRAIN = 0, BC_TEST = 4 * bc_wave_floats(false), BC_IMG_FLOATS = BC_TEST + 4 * bc_wave_floats(true);
-__host__ __device__ constexpr bool bc_streamed(bool test, int i) { return test ? (i % 3 == 2) : (i & 1); }
+constexpr int BC_VJP = 0, BC_TESTM = 1, BC_JVP = 2;       // kernel modes
+__host__ __device__ constexpr int bc_slen(int mode) { return mode == BC_VJP ? 96 : (mode == BC_TESTM ? 48 : 0); }
+__host__ __device__ constexpr int bc_wave_floats(int mode) { return (BC_NRES + 4 * bc_slen(mode)) * 64; }
+constexpr int BC_TRAIN = 0, BC_TEST = 4 * bc_wave_floats(BC_VJP), BC_JVPI = BC_TEST + 4 * bc_wave_floats(BC_TESTM),
+              BC_IMG_FLOATS = BC_JVPI + 4 * bc_wave_floats(BC_JVP);
+__host__ __device__ constexpr bool bc_streamed(int mode, int i) { return mode == BC_VJP ? (i & 1) : (mode == BC_TESTM ? (i % 3 == 2) : false); }
 
 __global__ void k_bcast_pack(NetDesc nd, const float* __restrict__ P, float* __restrict__ img) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= BC_IMG_FLOATS) return;
-    const bool test = e >= BC_TEST;
-    const int x = test ? e - BC_TEST : e;
-    const int wf = bc_wave_floats(test);
+    const int mode = e >= BC_JVPI ? BC_JVP : (e >= BC_TEST ? BC_TESTM : BC_VJP);
+    const bool test = mode == BC_TESTM;
+    const int x = e - (mode == BC_JVP ? BC_JVPI : (test ? BC_TEST : BC_TRAIN));
+    const int wf = bc_wave_floats(mode);
     const int w = x / wf, y = x % wf;
     const int lane = (y / 4) % 64, c = y % 4;
     int p, i, j;                                           // phase, block, k within the block
     if (y < BC_NRES * 64) {                                // resident register r = 4 (y / 256) + c
         const int r = 4 * (y / 256) + c;
-        if (test) { p = r / 128; const int rb = (r % 128) / 16; i = rb + rb / 2; }
+        if (mode == BC_JVP) { p = r / 192; i = (r % 192) / 16; }
+        else if (test) { p = r / 128; const int rb = (r % 128) / 16; i = rb + rb / 2; }
         else { p = r / 96; i = 2 * ((r % 96) / 16); }
         j = r % 16;
     } else {                                               // stream request q, element c
@@ -147,15 +154,18 @@ struct I1 { static constexpr int value = 1; };
 struct I2 { static constexpr int value = 2; };
 struct I3 { static constexpr int value = 3; };
 
-template <bool TEST>
+template <int MODE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
+    constexpr bool TEST = MODE == BC_TESTM, JVP = MODE == BC_JVP;
     constexpr int NS = TEST ? 1 : 3;
-    __shared__ __attribute__((aligned(16))) float Aimg[2][24][64];          // the next product's A operands: [sample group][16 k's][lane 4 j + s]
-    __shared__ __attribute__((aligned(16))) float Pbuf[6][2][2][64][4];     // partial outputs: [tile][K half][sample group][feature][4 samples]
+    constexpr int NK = JVP ? 2 : 1;                        // operand kinds side by side: the state columns, and (JVP) the tangent columns
+    constexpr int NLB = JVP ? 3 : 4;                       // 16-register blocks of the resident set that live in LDS
+    __shared__ __attribute__((aligned(16))) float Aimg[NK][2][24][64];      // the next product's A operands: [kind][sample group][16 k's][lane 4 j + s]
+    __shared__ __attribute__((aligned(16))) float Pbuf[NK][6][2][2][64][4]; // partial outputs: [kind][tile][K half][sample group][feature][4 samples]
     __shared__ __attribute__((aligned(16))) float Kz[7][256][4];           // Runge-Kutta rows k1..k7 of the z rows, next to their owner threads
     __shared__ __attribute__((aligned(16))) float red[4][2][3][4];          // per wave, sample group, quantity: 4 samples
-    __shared__ __attribute__((aligned(16))) float wBL[4][4][4][64][4];       // the last 64 resident B registers of each wave: [wave][block][quad][lane][4] (64 KB; a lane's quad = one ds_read_b128)
+    __shared__ __attribute__((aligned(16))) float wBL[4][NLB][4][64][4];     // the last resident B registers of each wave: [wave][block][quad][lane][4] (a lane's quad = one ds_read_b128)
     __shared__ float Ssc[8][8][3];                                           // scalar rows: [sample][u, k1..k7][dlogp, E, n]
     __shared__ float msc[48];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -167,9 +177,9 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
     // file (an "a" operand: an MFMA reads its B operand from there directly -- left to itself the allocator keeps all the
     // load destinations in the 256 architectural registers at once and spills the weights to scratch for the whole solve),
     // 80 are ordinary registers, the last 64 live in LDS and are read a block ahead of their use. ----
-    constexpr int NRA = 240, NRV = 80;
+    constexpr int NRA = 240, NRV = BC_NRES - NRA - 16 * NLB;
     float RA[NRA], RV[NRV];
-    const float* wimg = a.img + (TEST ? BC_TEST : BC_TRAIN) + (size_t)wave * bc_wave_floats(TEST);
+    const float* wimg = a.img + (JVP ? BC_JVPI : (TEST ? BC_TEST : BC_TRAIN)) + (size_t)wave * bc_wave_floats(MODE);
     {
         const f32x4* pr = reinterpret_cast<const f32x4*>(wimg) + lane;
 #pragma unroll
@@ -187,15 +197,17 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
     // ---- the stream: SLEN requests per evaluation and wave, cyclic, a ring of them in flight across phase and evaluation
     // boundaries.  Buffer loads: descriptor + the lane's 16-byte slot + a SCALAR offset per request (with flat addresses the
     // compiler precomputed the 64-bit addresses of a whole cycle, 192 registers of them). ----
-    constexpr int SLEN = bc_slen(TEST);
-    const auto srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wimg + BC_NRES * 64), 0, SLEN * 1024, 0x00020000);
+    constexpr int SLEN = bc_slen(MODE);
+    const auto srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wimg + BC_NRES * 64), 0, (SLEN ? SLEN : 1) * 1024, 0x00020000);
     auto sload = [&](int pos) __attribute__((always_inline)) {       // request number `pos` of the cycle
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, 16 * lane, pos * 1024, 0));
     };
     f32x4 ring[BC_RING];
     int spos = 0;                                          // next request to issue (0 .. SLEN-1)
+    if (SLEN > 0) {
 #pragma unroll
-    for (int p = 0; p < BC_RING; ++p) { ring[p] = sload(spos); spos = spos + 1 == SLEN ? 0 : spos + 1; }
+        for (int p = 0; p < BC_RING; ++p) { ring[p] = sload(spos); spos = spos + 1 == SLEN ? 0 : spos + 1; }
+    }
 
     // ---- ownership of the elementwise work ----
     // 128-row arrays (z, zdot, eps^T J): thread -> (tile ot, feature of, sample group osg): one f32x4 = 4 samples
@@ -206,7 +218,7 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
     float omask[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) omask[s] = (orow_ok && smp0 + s < a.B) ? 1.f : 0.f;
-    float* const aimg_own = &Aimg[osg][ok_row >> 4][4 * (ok_row & 15)];
+    float* const aimg_own = &Aimg[0][osg][ok_row >> 4][4 * (ok_row & 15)];
     // 384-row arrays: three (tile, feature, sample group) units per thread
     int h_t[3], h_f[3], h_sg[3];
     float b1v[3];
@@ -245,23 +257,26 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
     // ---- one evaluation of augmented_f at the owned rows `z` -> zdot (owned rows); the scalar rows land in msc[8 q + sample] ----
     f32x4 d1[3];
     // One product (phase PH of the evaluation): 12 blocks of 16 k's, resident or streamed by the mode's pattern.  Block i's A
-    // registers (one per sample group: 16 k's x 4 samples) and, for the resident registers that live in LDS, its 16 B values
-    // are requested one block AHEAD; the two sample groups and the two parities of k keep FOUR accumulator chains going
-    // (2 chains: 8.5 cycles per instruction measured, 4: 8.3).
-    //   KIND 0: out 384 x K 128 (three 64-k segments -> Pbuf[(3 w + seg) / 2][(3 w + seg) % 2]);  1: out 128 x K 384 (-> Pbuf[w / 2][w % 2])
+    // registers (one per sample group and operand kind: 16 k's x 4 samples) and, for the resident registers that live in LDS, its
+    // 16 B values are requested one block AHEAD; sample groups, kinds and the two parities of k keep 4 (JVP: 8) accumulator
+    // chains going (2 chains: 8.5 cycles per instruction measured, 4: 8.3).
+    //   KIND 0: out 384 x K 128 (three 64-k segments -> Pbuf[.][(3 w + seg) / 2][(3 w + seg) % 2]);  1: out 128 x K 384 (-> Pbuf[.][w / 2][w % 2])
     auto product = [&](auto kind_c, auto phase_c) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_c)::value, PH = decltype(phase_c)::value;
-        constexpr int NRP = TEST ? 128 : 96;               // resident registers per phase
-        f32x4 acc[2][2];                                   // [sample group][parity of k]; a segment's sums leave for Pbuf when it ends
+        constexpr int NRP = JVP ? 192 : (TEST ? 128 : 96); // resident registers per phase
+        constexpr int NA = 2 * NK;                         // A registers per block: [kind][sample group]
+        f32x4 acc[NA][2];                                  // [..][parity of k]; a segment's sums leave for Pbuf when it ends
 #pragma unroll
-        for (int x = 0; x < 4; ++x) acc[x >> 1][x & 1] = zero4;
+        for (int x = 0; x < 2 * NA; ++x) acc[x >> 1][x & 1] = zero4;
         auto kb_of = [&](int i) { return KIND == 0 ? (even ? (i & 7) : ((i + 4) & 7)) : 12 * (wave & 1) + i; };
-        float a_cur[2] = {Aimg[0][kb_of(0)][lane], Aimg[1][kb_of(0)][lane]}, a_nxt[2] = {0.f, 0.f};
+        float a_cur[NA], a_nxt[NA];
+#pragma unroll
+        for (int x = 0; x < NA; ++x) { a_cur[x] = Aimg[x >> 1][x & 1][kb_of(0)][lane]; a_nxt[x] = 0.f; }
         float bl_cur[16], bl_nxt[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) { bl_cur[j] = 0.f; bl_nxt[j] = 0.f; }
         // resident register of block i (a resident one), k j
-        auto rbase = [&](int i) { return PH * NRP + 16 * (TEST ? i - (i + 1) / 3 : i / 2); };
+        auto rbase = [&](int i) { return PH * NRP + 16 * (JVP ? i : (TEST ? i - (i + 1) / 3 : i / 2)); };
         auto tail = [&](float (&dst)[16], int rb) __attribute__((always_inline)) {       // the 16 values of an LDS-resident block: four 16-byte reads
             const int blk = (rb - NRA - NRV) >> 4;
 #pragma unroll
@@ -271,25 +286,25 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
                 for (int c = 0; c < 4; ++c) dst[4 * c4 + c] = v[c];
             }
         };
-        if (!bc_streamed(TEST, 0) && rbase(0) >= NRA + NRV) tail(bl_cur, rbase(0));
+        if (!bc_streamed(MODE, 0) && rbase(0) >= NRA + NRV) tail(bl_cur, rbase(0));
         int nreq = 0;                                      // requests consumed in this phase (a compile-time count after unrolling)
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             if (i + 1 < 12) {
-                a_nxt[0] = Aimg[0][kb_of(i + 1)][lane]; a_nxt[1] = Aimg[1][kb_of(i + 1)][lane];
-                if (!bc_streamed(TEST, i + 1) && rbase(i + 1) >= NRA + NRV) tail(bl_nxt, rbase(i + 1));
+#pragma unroll
+                for (int x = 0; x < NA; ++x) a_nxt[x] = Aimg[x >> 1][x & 1][kb_of(i + 1)][lane];
+                if (!bc_streamed(MODE, i + 1) && rbase(i + 1) >= NRA + NRV) tail(bl_nxt, rbase(i + 1));
             }
-            if (bc_streamed(TEST, i)) {
+            if (bc_streamed(MODE, i)) {
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
                     const int slot = (nreq + c4) % BC_RING;
                     const f32x4 bq = ring[slot];
                     ring[slot] = sload(spos); spos = spos + 1 == SLEN ? 0 : spos + 1;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        acc[0][c & 1] = mfma_bc(a_cur[0], bq[c], acc[0][c & 1], 4 * c4 + c);
-                        acc[1][c & 1] = mfma_bc(a_cur[1], bq[c], acc[1][c & 1], 4 * c4 + c);
-                    }
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int x = 0; x < NA; ++x) acc[x][c & 1] = mfma_bc(a_cur[x], bq[c], acc[x][c & 1], 4 * c4 + c);
                 }
                 nreq += 4;
             } else {
@@ -298,19 +313,21 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
                 for (int j = 0; j < 16; ++j) {
                     const int r = rb + j;
                     const float bw = r < NRA ? RA[r < NRA ? r : 0] : (r < NRA + NRV ? RV[(r >= NRA && r < NRA + NRV) ? r - NRA : 0] : bl_cur[j]);
-                    acc[0][j & 1] = mfma_bc(a_cur[0], bw, acc[0][j & 1], j);
-                    acc[1][j & 1] = mfma_bc(a_cur[1], bw, acc[1][j & 1], j);
+#pragma unroll
+                    for (int x = 0; x < NA; ++x) acc[x][j & 1] = mfma_bc(a_cur[x], bw, acc[x][j & 1], j);
                 }
             }
-            a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
+#pragma unroll
+            for (int x = 0; x < NA; ++x) a_cur[x] = a_nxt[x];
 #pragma unroll
             for (int j = 0; j < 16; ++j) bl_cur[j] = bl_nxt[j];
             if (KIND == 0 ? (i & 3) == 3 : i == 11) {      // the segment is complete
                 const int fs = KIND == 0 ? 3 * wave + (i >> 2) : wave;
-                *(f32x4*)Pbuf[fs >> 1][fs & 1][0][lane] = acc[0][0] + acc[0][1];
-                *(f32x4*)Pbuf[fs >> 1][fs & 1][1][lane] = acc[1][0] + acc[1][1];
 #pragma unroll
-                for (int x = 0; x < 4; ++x) acc[x >> 1][x & 1] = zero4;
+                for (int x = 0; x < NA; ++x) {
+                    *(f32x4*)Pbuf[x >> 1][fs >> 1][fs & 1][x & 1][lane] = acc[x][0] + acc[x][1];
+                    acc[x][0] = zero4; acc[x][1] = zero4;
+                }
             }
         }
     };
@@ -326,69 +343,82 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
         bt_ = __builtin_amdgcn_s_memtime();
 #endif
         *(f32x4*)aimg_own = z;
+        if (JVP) *(f32x4*)&Aimg[NK - 1][osg][ok_row >> 4][4 * (ok_row & 15)] = ep;       // the tangent seed tau0 = eps beside the state
         bc_bar();
         BC_T(0)
-        product(I0{}, I0{});                               // phase 0: h1 pre-activations = W1 z
+        product(I0{}, I0{});                               // phase 0: W1 z  (JVP: W1 [z, eps])
         BC_T(1)
         bc_bar();
         BC_T(0)
+        f32x4 ldc = zero4, n2c = zero4, e2c = zero4;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const f32x4 v = *(const f32x4*)Pbuf[h_t[i]][0][h_sg[i]][h_f[i]] + *(const f32x4*)Pbuf[h_t[i]][1][h_sg[i]][h_f[i]] + b1v[i];
+            const f32x4 v = *(const f32x4*)Pbuf[0][h_t[i]][0][h_sg[i]][h_f[i]] + *(const f32x4*)Pbuf[0][h_t[i]][1][h_sg[i]][h_f[i]] + b1v[i];
             f32x4 h;
 #pragma unroll
             for (int s = 0; s < 4; ++s) { h[s] = tanh_fast(v[s]); d1[i][s] = fmaf(-h[s], h[s], 1.f); }
             const int k = 64 * h_t[i] + h_f[i];
-            *(f32x4*)&Aimg[h_sg[i]][k >> 4][4 * (k & 15)] = h;
+            *(f32x4*)&Aimg[0][h_sg[i]][k >> 4][4 * (k & 15)] = h;
+            if (JVP) {                                     // tau1 = sigma'_1 .* (W1 eps)
+                const f32x4 w = *(const f32x4*)Pbuf[NK - 1][h_t[i]][0][h_sg[i]][h_f[i]] + *(const f32x4*)Pbuf[NK - 1][h_t[i]][1][h_sg[i]][h_f[i]];
+                *(f32x4*)&Aimg[NK - 1][h_sg[i]][k >> 4][4 * (k & 15)] = w * d1[i];
+            }
         }
         BC_T(5)
         bc_bar();
         BC_T(0)
-        product(I1{}, I1{});                               // phase 1: zdot pre-activations = W2 h1
+        product(I1{}, I1{});                               // phase 1: W2 h1  (JVP: W2 [h1, tau1])
         BC_T(2)
         bc_bar();
         BC_T(0)
-        f32x4 d2, e2c = zero4;
+        f32x4 d2;
         {
-            const f32x4 v = *(const f32x4*)Pbuf[ot][0][osg][of] + *(const f32x4*)Pbuf[ot][1][osg][of] + b2v;
+            const f32x4 v = *(const f32x4*)Pbuf[0][ot][0][osg][of] + *(const f32x4*)Pbuf[0][ot][1][osg][of] + b2v;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const float h = tanh_fast(v[s]) * omask[s];
                 zd[s] = h; d2[s] = fmaf(-h, h, 1.f) * omask[s]; e2c[s] = h * h;
             }
-            *(f32x4*)aimg_own = TEST ? d2 : ep * d2;        // g2 = eps .* sigma'_2 (VJP seed)  |  sigma'_2 (exact trace)
+            if (JVP) {                                     // J eps = sigma'_2 .* (W2 tau1):  ldot = -eps . (J eps),  ndot = |J eps|   (src/icnf.jl:404-413)
+                const f32x4 w = *(const f32x4*)Pbuf[NK - 1][ot][0][osg][of] + *(const f32x4*)Pbuf[NK - 1][ot][1][osg][of];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { const float t2 = w[s] * d2[s]; ldc[s] = t2 * ep[s]; n2c[s] = t2 * t2; }
+            } else {
+                *(f32x4*)aimg_own = TEST ? d2 : ep * d2;    // g2 = eps .* sigma'_2 (VJP seed)  |  sigma'_2 (exact trace)
+            }
         }
-        BC_T(5)
-        bc_bar();
-        BC_T(0)
-        product(I0{}, I2{});                               // phase 2: W2^T g2  |  C sigma'_2
-        BC_T(3)
-        bc_bar();
-        BC_T(0)
-        f32x4 ldc = zero4, n2c = zero4;
-        if (TEST) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const f32x4 v = *(const f32x4*)Pbuf[h_t[i]][0][h_sg[i]][h_f[i]] + *(const f32x4*)Pbuf[h_t[i]][1][h_sg[i]][h_f[i]];
-                ldc += v * d1[i];                          // (the units of a thread share its sample group: tid & 1)
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const f32x4 v = *(const f32x4*)Pbuf[h_t[i]][0][h_sg[i]][h_f[i]] + *(const f32x4*)Pbuf[h_t[i]][1][h_sg[i]][h_f[i]];
-                const int k = 64 * h_t[i] + h_f[i];
-                *(f32x4*)&Aimg[h_sg[i]][k >> 4][4 * (k & 15)] = v * d1[i];      // g1
-            }
+        if (!JVP) {
             BC_T(5)
             bc_bar();
             BC_T(0)
-            product(I1{}, I3{});                           // phase 3: eps^T J = W1^T g1
-            BC_T(4)
+            product(I0{}, I2{});                           // phase 2: W2^T g2  |  C sigma'_2
+            BC_T(3)
             bc_bar();
             BC_T(0)
-            const f32x4 eJ = *(const f32x4*)Pbuf[ot][0][osg][of] + *(const f32x4*)Pbuf[ot][1][osg][of];
+            if (TEST) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) { const float e = eJ[s] * omask[s]; ldc[s] = e * ep[s]; n2c[s] = e * e; }
+                for (int i = 0; i < 3; ++i) {
+                    const f32x4 v = *(const f32x4*)Pbuf[0][h_t[i]][0][h_sg[i]][h_f[i]] + *(const f32x4*)Pbuf[0][h_t[i]][1][h_sg[i]][h_f[i]];
+                    ldc += v * d1[i];                      // (the units of a thread share its sample group: tid & 1)
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const f32x4 v = *(const f32x4*)Pbuf[0][h_t[i]][0][h_sg[i]][h_f[i]] + *(const f32x4*)Pbuf[0][h_t[i]][1][h_sg[i]][h_f[i]];
+                    const int k = 64 * h_t[i] + h_f[i];
+                    *(f32x4*)&Aimg[0][h_sg[i]][k >> 4][4 * (k & 15)] = v * d1[i];      // g1
+                }
+                BC_T(5)
+                bc_bar();
+                BC_T(0)
+                product(I1{}, I3{});                       // phase 3: eps^T J = W1^T g1
+                BC_T(4)
+                bc_bar();
+                BC_T(0)
+                const f32x4 eJ = *(const f32x4*)Pbuf[0][ot][0][osg][of] + *(const f32x4*)Pbuf[0][ot][1][osg][of];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { const float e = eJ[s] * omask[s]; ldc[s] = e * ep[s]; n2c[s] = e * e; }
+            }
         }
         // sums over the features: the lanes of a wave with this lane's parity, then the four waves
 #pragma unroll
@@ -674,7 +704,6 @@ static int bcast_resident(int device) {
 
 bool bcast_solve_supported(const NetDesc& nd, bool train, int B, int device) {
     if (nd.n_layers != 2 || nd.acts[0] != 1 || nd.acts[1] != 1 || nd.n_cond > 0) return false;
-    if (train && nd.jvp) return false;
     if (nd.n_in <= 64 || nd.n_in > 128 || nd.dims[1] <= 256 || nd.dims[1] > 384) return false;
     static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); const char* w = getenv("CNF_BCAST"); return (e && e[0] == '0') || (w && w[0] == '0'); }();
     if (off) return false;
@@ -693,7 +722,7 @@ cnf_status bcast_solve_launch(const NetDesc& nd, bool train, const float* d_para
     if (!sv.xs && !sv.u0) return CNF_ERR_BAD_ARG;
     BcTab tab = kBcTab;
     void* args[] = {&a, &sv, &tab};
-    const void* fn = train ? (const void*)k_solve_bcast<false> : (const void*)k_solve_bcast<true>;
+    const void* fn = !train ? (const void*)k_solve_bcast<BC_TESTM> : (nd.jvp ? (const void*)k_solve_bcast<BC_JVP> : (const void*)k_solve_bcast<BC_VJP>);
     if (hipLaunchKernel(fn, dim3((B + 7) / 8), dim3(256), args, 0, s) != hipSuccess) {
         (void)hipGetLastError();
         return CNF_ERR_UNSUPPORTED;

@@ -1947,17 +1947,18 @@ def test_config5_one_launch_solve_strict_vs_float64(B):
         eps = rng.standard_normal((cfg.n_in, B)).astype(np.float32)
         idx = np.unique(np.concatenate([np.arange(min(B, 16)), np.arange(max(0, B - 24), B), rng.choice(B, min(B, 96), replace=False)]))
         ti = torch.from_numpy(idx).cuda()
-        for train in (True, False):
+        for train, jvp in ((True, False), (True, True), (False, False)):
             mode = cnf.TrainMode() if train else cnf.TestMode()
-            ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
+            cfg.use_jvp = jvp                                   # (JVP compute mode, src/icnf.jl:384-420: ndot = |J eps|)
+            ic = make_icnf(cnf, cfg, jvp=jvp, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
             logpx, (E, n, A) = cnf.inference(ic, mode, _dev(xs), flat, {}, eps=_dev(eps) if train else None)
             assert (ic.last_stats["launches"] <= 3) == one, (name, B, train, ic.last_stats)
             assert ic.last_stats["nf"] == 1 + 6 * 8 and ic.last_stats["kernel_used"] == _lib.KERNEL_MFMA
             _, ref_lp, ref_regs, _ = O.inference(cfg, f64(flat), f64(xs[:, idx]), f64(eps[:, idx]) if train else None, train,
                                                  dt=1 / 8, adaptive=False)
-            assert_parity(logpx[ti].cpu().numpy(), ref_lp, f"bcast {name} logpx train={train} B={B}")
+            assert_parity(logpx[ti].cpu().numpy(), ref_lp, f"bcast {name} logpx train={train} jvp={jvp} B={B}")
             if train:
-                assert_parity(torch.stack([E, n, A])[:, ti].cpu().numpy(), np.stack(ref_regs), f"bcast {name} regs B={B}")
+                assert_parity(torch.stack([E, n, A])[:, ti].cpu().numpy(), np.stack(ref_regs), f"bcast {name} regs jvp={jvp} B={B}")
             else:
                 assert float(E.abs().max()) == 0.0 and float(n.abs().max()) == 0.0
                 assert_parity(A[ti].cpu().numpy(), ref_regs[2], f"bcast {name} TestMode A B={B}")
@@ -1966,9 +1967,10 @@ def test_config5_one_launch_solve_strict_vs_float64(B):
             assert (prob.stats["launches"] <= 3) == one
             u0 = O.inference_u0(cfg, xs[:, idx], train)
             ref, _ = O.tsit5_solve(cfg.rhs(f64(flat), f64(eps[:, idx]) if train else None, train), f64(u0), *cfg.tspan, dt=1 / 8, adaptive=False)
-            assert_parity(fsol[:, ti].cpu().numpy(), ref, f"bcast {name} fsol train={train} B={B}", trace_row=cfg.n_in)
+            assert_parity(fsol[:, ti].cpu().numpy(), ref, f"bcast {name} fsol train={train} jvp={jvp} B={B}", trace_row=cfg.n_in)
             assert ic.solve_fallbacks() == 0
             ic.close()
+        cfg.use_jvp = False
         # adaptive, TrainMode
         tol = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
         ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=tol)
