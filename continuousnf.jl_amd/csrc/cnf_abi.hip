@@ -109,6 +109,8 @@ struct cnf_ctx {
     float* g_lam = nullptr;
     float *g_HS = nullptr, *g_TS = nullptr, *g_AB = nullptr, *g_PB = nullptr;
     float* g_part = nullptr;      // GRAD_MAX_KSPLIT x n_params
+    float* wg_traj = nullptr;     // k_solve_wave<GRAD>: z rows of u_n per accepted step, as the lanes hold them; + WV_GCAP step sizes
+    size_t wg_traj_floats = 0;
     float* g_grad = nullptr;      // n_params (host-pointer variant)
     std::vector<float> last_hs;   // signed step sizes of the last cnf_loss_grad solve
     int grad_last_B = 0;          // batch of the last cnf_loss_grad call (g_lam holds its d loss / d u(t0))
@@ -267,6 +269,7 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (h->grad_arena) (void)hipFree(h->grad_arena);
     if (h->traj) (void)hipFree(h->traj);
     if (h->traj_hs) (void)hipFree(h->traj_hs);
+    if (h->wg_traj) (void)hipFree(h->wg_traj);
     if (h->arena) (void)hipFree(h->arena);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->partials) (void)hipFree(h->partials);
@@ -705,6 +708,10 @@ struct Recorder {
     std::vector<float> hs;        // signed step of accepted step n (u_n -> u_{n+1})
     int n = 0;                    // accepted steps recorded; slot n holds u_n and the stage states of step n
     bool overflow = false;        // the solve took more steps than the store holds: grow it and solve again
+    // the whole gradient in the launch of the solve (k_solve_wave<GRAD>): where it keeps its trajectory and leaves its results;
+    // wg_done: it ran (hs holds the step sizes); wg_failed: it could not (not this network, a wait ran out, too many steps)
+    const WaveGradArgs* wg = nullptr;
+    bool wg_done = false, wg_failed = false;
 };
 static size_t traj_slot_floats(cnf_handle h) { return 6 * ((size_t)h->nd.n_in + 3) * h->grad_cap_B; }
 // make room for `steps` slots (contiguous: the step kernel indexes it by the accepted-step counter)
@@ -859,7 +866,9 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     // The whole solve in ONE launch where the handle and the batch allow it (k_solve3b / k_solve3jb): the weights and the
     // Runge-Kutta rows stay on the CUs for all attempts, the workgroups exchange two floats per attempt.
     // ... or of a small two-layer network, one wave per 16-sample tile, registers only (k_solve_wave, cnf_wave.hip)
-    const bool wave_ok = k == CNF_KERNEL_MFMA && !rec && wave_solve_supported(h->nd, train != 0, B);
+    const bool wave_ok = k == CNF_KERNEL_MFMA && (!rec || (rec->wg && post && post->xs && wave_grad_supported(h->nd, B))) &&
+                         wave_solve_supported(h->nd, train != 0, B);
+    if (rec && rec->wg && !(wave_ok && !lockstep && !h->no_persist)) { rec->wg_failed = true; return CNF_OK; }
     // ... or of config 5's network at eight columns per CU (k_solve_bcast, cnf_bcast.hip)
     const bool bcast_ok = k == CNF_KERNEL_MFMA && !rec && !wave_ok && bcast_solve_supported(h->nd, train != 0, B, h->device);
     if (bcast_ok && !lockstep && !h->no_persist) {
@@ -904,7 +913,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         // gradient path: every attempt files u_n and its stage states in the slot of step `naccept` (as the streamed
         // recording does); the store is sized beforehand and the solve repeated if it took more steps than fit
         float* dump = nullptr; size_t slot = 0; int dcap = 0;
-        if (rec) {
+        if (rec && !rec->wg) {
             if ((s = traj_reserve(h, 64)) != CNF_OK) return s;
             slot = traj_slot_floats(h); dcap = h->traj_cap;
             dump = h->traj + n;                      // stage area of slot 0; u_n sits one array before
@@ -912,7 +921,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         s = CNF_ERR_UNSUPPORTED;
         if (wave_ok)
             s = wave_solve_launch(h->nd, train != 0, h->d_params, h->nd.n_cond > 0 ? h->d_cond : nullptr, h->cbs, h->d_state, h->U[0],
-                                  eps, B, st, h->d_mirror + mslot, base, sv);
+                                  eps, B, st, h->d_mirror + mslot, base, sv, rec ? rec->wg : nullptr);
         if (tsolve_ok) {
             const GradLayout g = grad_layout(h->nd);
             const AdjMfmaLayout m = adj_mfma_layout(h->nd, g);
@@ -958,12 +967,13 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                 HIPCHK(h, hipGetLastError());
                 if (rec) {                               // step sizes back from the device
                     rec->n = fin.naccept;
-                    rec->overflow = fin.naccept > h->traj_cap;
+                    rec->overflow = !rec->wg && fin.naccept > h->traj_cap;
                     rec->hs.assign((size_t)(rec->overflow ? 0 : fin.naccept), 0.f);
                     if (!rec->overflow && fin.naccept > 0)
-                        HIPCHK(h, hipMemcpyAsync(rec->hs.data(), h->traj_hs, (size_t)fin.naccept * sizeof(float),
+                        HIPCHK(h, hipMemcpyAsync(rec->hs.data(), rec->wg ? rec->wg->hs_out : h->traj_hs, (size_t)fin.naccept * sizeof(float),
                                                  hipMemcpyDeviceToHost, st));
-                    final_sync = true;
+                    if (rec->wg) rec->wg_done = true;
+                    else final_sync = true;
                 }
                 if (final_sync) HIPCHK(h, hipStreamSynchronize(st));
                 if (stats) {
@@ -982,6 +992,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             // mask).  The launch has ended (every wait is bounded); nothing of its result is used.  The solve runs again from
             // u0 on the streamed driver below, which needs no co-residency.
             ++h->fallbacks;
+            if (rec && rec->wg) { rec->wg_failed = true; return CNF_OK; }      // (the caller runs the streamed gradient path)
             if (!fused_io && u0 == h->U[0])
                 return fail(h, CNF_ERR_HIP, "one-launch solve: a workgroup did not arrive and u0 was solved in place (set CNF_PERSISTENT=0)");
         } else if (s != CNF_ERR_UNSUPPORTED) return fail(h, s, "one-launch solve failed to start");
@@ -1593,6 +1604,42 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
         HIPCHK(h, launch_transpose_params(nd, h->d_params, h->d_PT, st));
         HIPCHK(h, launch_pack_adj_images(nd, gl, am, h->d_params, h->d_adj_img, st));
         h->pt_valid = true;
+    }
+
+    // ---- small batches of a small two-layer tanh network: the solve, the loss sums and the whole discrete adjoint in ONE
+    // launch, one wave per 16 samples (k_solve_wave<GRAD>, cnf_wave.hip), then the sum of the waves' partials ----
+    if (opts->kernel != CNF_KERNEL_GENERIC && wave_grad_supported(nd, B)) {
+        const size_t per_step = wave_grad_traj_floats(nd, B);
+        int cap = WV_GCAP;
+        while (cap > 64 && per_step * cap > ((size_t)1 << 26)) cap /= 2;       // <= 256 MiB of trajectory
+        const size_t need = per_step * cap + WV_GCAP;
+        if (need > h->wg_traj_floats) {
+            HIPCHK(h, hipDeviceSynchronize());
+            if (h->wg_traj) { (void)hipFree(h->wg_traj); h->wg_traj = nullptr; h->wg_traj_floats = 0; }
+            HIPCHK(h, hipMalloc(&h->wg_traj, need * sizeof(float)));
+            h->wg_traj_floats = need;
+        }
+        WaveGradArgs wg;
+        wg.traj = h->wg_traj; wg.traj_cap = cap; wg.hs_out = h->wg_traj + per_step * cap;
+        wg.gpart = h->g_part; wg.lam_out = h->g_lam; wg.n_params = (int)h->n_params;
+        wg.lam1 = h->lam[0]; wg.lam2 = h->lam[1]; wg.lam3 = h->lam[2];
+        Recorder rec;
+        rec.wg = &wg;
+        cnf_solve_stats sst{};
+        PostHook ph{h->tmp_logpx, h->tmp_regs, h->d_sums, xs};
+        if ((s = solve_core(h, mode, h->U[0], eps, nullptr, B, opts, &sst, stream, &rec, false, &ph)) != CNF_OK) return s;
+        if (rec.wg_done) {
+            HIPCHK(h, launch_grad_reduce(h->g_part, grad, (int)h->n_params, wave_grad_waves(B), st));
+            float* sums = reinterpret_cast<float*>(&h->h_state[2]);
+            HIPCHK(h, hipMemcpyAsync(sums, h->d_sums, 5 * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            h->last_hs = rec.hs;
+            h->grad_last_B = B;
+            sst.launches += 1;
+            if ((s = cnf_loss_from_sums(h, mode, sums, loss_out)) != CNF_OK) return s;
+            if (stats) *stats = sst;
+            return CNF_OK;
+        }
     }
 
     // ---- forward: u0, recorded solve, loss ------------------------------------------------------

@@ -31,6 +31,9 @@
 namespace {
 
 constexpr int WV_VJP = 0, WV_JVP = 1, WV_TEST = 2;
+#ifndef WV_GRAD_TANH_ACCURATE
+#define WV_GRAD_TANH_ACCURATE true     // the pullback's own forward half: cnf_tanh (2 ulp everywhere) instead of the exp2 / rcp form
+#endif
 
 struct WaveArgs {
     NetDesc nd;
@@ -44,6 +47,7 @@ struct WaveArgs {
     StepState* st_out;
     void* mirror;
     unsigned seq;
+    WaveGradArgs g;        // gradient path (GRAD instantiations): the discrete adjoint of the accepted steps in the same launch
 };
 
 __device__ __forceinline__ f32x4 mm4(const float (&A)[4], const f32x4& b, f32x4 acc) {
@@ -59,6 +63,18 @@ __device__ __forceinline__ float wv_wave_sum(float v) {            // every lane
     const int i = __float_as_int(v);
     return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
            (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
+}
+// tanh for the gradient path: the exp2 / rcp form loses RELATIVE accuracy near 0 (1 - 2/(t + 1) with t ~ 1: an absolute
+// 6e-8), which a long span turns into 1e-4 of the gradient's scale on the 2-6-2 network; below 0.25 the odd Taylor polynomial
+// up to x^9 (truncation 2e-9 relative) takes over -- both forms on the signed argument, one select
+__device__ __forceinline__ float tanh_grad(float a) {
+    const float x2 = a * a;
+    float p = 0.021869488f;                       // 62/2835
+    p = fmaf(p, x2, -0.053968254f);               // -17/315
+    p = fmaf(p, x2, 0.13333333f);                 // 2/15
+    p = fmaf(p, x2, -0.33333334f);                // -1/3
+    const float small = fmaf(a * x2, p, a);
+    return fabsf(a) < 0.25f ? small : tanh_fast(a);
 }
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
@@ -87,8 +103,19 @@ __device__ __forceinline__ float wv_quad_sum(float v) {
 
 // NI / NH: 16-row tiles of n_in / of the hidden layer;  TANH: tanh on both layers (compile time: the evaluation is then one
 // straight-line block the scheduler can interleave -- a run-time switch per activation call cut it into 2000 blocks)
-template <int NI, int NH, int MODE, bool TANH>
+//
+// GRAD (loss_and_grad of small batches: the reference's training step, src/exts/mlj_ext/core_icnf.jl:59-73, on its README /
+// regression networks at batch_size 32): the same launch goes on with the DISCRETE ADJOINT of the steps it accepted.  The
+// forward pass files the z rows of u_n per accepted step (each lane its own registers: read back by the same lane) and
+// the step sizes in LDS; the backward pass recomputes the stage states of a step from u_n (five forward evaluations), then
+// pulls the cotangent back through the six stages -- the four sweeps of k_adj (cnf_grad.hip; algebra in
+// oracle/cnf_grad_oracle.py) as MFMA products on the register-resident weights -- and contracts the weight-gradient
+// factors over the wave's 16 samples with MFMAs whose k index is the SAMPLE (the factor tiles transposed through a
+// wave-private LDS buffer: one 16-byte write, four 4-byte reads per tile).  The weight-gradient tiles stay in registers for
+// the whole backward pass; each wave writes one partial, k_grad_reduce adds them in wave order (bit-reproducible).
+template <int NI, int NH, int MODE, bool TANH, bool GRAD = false>
 __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, const WvTab tab) {
+    static_assert(!GRAD || (MODE == WV_VJP && TANH), "the in-launch adjoint is written for the VJP compute mode of tanh networks");
     constexpr bool TRAIN = MODE != WV_TEST;
     constexpr int NS = TRAIN ? 3 : 1;                      // scalar rows of the state
     const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
@@ -171,10 +198,10 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
     for (int s = 0; s < 7; ++s) ks[s] = 0.f;
 
     // ---- one evaluation of augmented_f at z -> (zdot, this lane group's scalar row) ----
-    auto act4 = [&](int kind, const f32x4& pre, f32x4& h, f32x4& d) {
+    auto act4 = [&](int kind, const f32x4& pre, f32x4& h, f32x4& d, bool accurate = false) __attribute__((always_inline)) {
         if (fast) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { h[j] = tanh_fast(pre[j]); d[j] = fmaf(-h[j], h[j], 1.f); }
+            for (int j = 0; j < 4; ++j) { h[j] = (GRAD || accurate) ? tanh_grad(pre[j]) : tanh_fast(pre[j]); d[j] = fmaf(-h[j], h[j], 1.f); }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { float hh, dd; cnf_act(kind, pre[j], hh, dd); h[j] = hh; d[j] = dd; }
@@ -275,6 +302,9 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
         }
     };
 
+    __shared__ float hsL[GRAD ? WV_GCAP : 1];                                           // step sizes of the accepted steps
+    __shared__ __attribute__((aligned(16))) float tbuf[GRAD ? 4 * (NI + NH) * 256 : 4];  // factor tiles, [sample][row]
+    bool gover = false;                                    // more accepted steps than the trajectory store holds
     // ---- integrator state: every lane carries the same copy and runs the same controller on the same sums ----
     StepState ns = sv.init;
     float hstep = ns.h, abstol = ns.abstol, reltol = ns.reltol;
@@ -387,6 +417,14 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
 #endif
         // stage state U_{s+1} = u + h sum_j a_{s+1,j} k_j, then k_{s+1} = f(U_{s+1}): ONE copy of the evaluation code, the
         // stage's row of the table by scalar loads, its result filed by selects (an indexed store would go to scratch)
+        // gradient path: every attempt files its stage states U_1 = u_n, U_2..U_6 in the slot of step `naccept` (a rejected
+        // attempt's are overwritten by the next one), each lane its own registers
+        f32x4* tjs = nullptr;
+        if (GRAD && ns.naccept < a.g.traj_cap) {
+            tjs = reinterpret_cast<f32x4*>(a.g.traj) + ((size_t)ns.naccept * 6 * G + blockIdx.x) * (64 * NI) + lane * NI;
+#pragma unroll
+            for (int m = 0; m < NI; ++m) tjs[m] = uz[m];
+        }
 #pragma unroll 1
         for (int s = 1; s <= 6; ++s) {
             float as[6];
@@ -398,6 +436,10 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
 #pragma unroll
                 for (int j = 1; j < 6; ++j) acc += as[j] * kz[j][m];
                 zt[m] = uz[m] + hstep * acc;
+            }
+            if (GRAD && tjs && s < 6) {
+#pragma unroll
+                for (int m = 0; m < NI; ++m) tjs[(size_t)s * G * (64 * NI) + m] = zt[m];
             }
             if (s == 6) {                                  // a_7j = b_j: zt is the new solution (FSAL); its scalar row likewise
                 sacc = as[0] * ks[0];
@@ -460,6 +502,12 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
 #endif
         }
         after_ctrl();
+        if (GRAD && accepted) {                            // h_n of this step (its stage states were filed by the attempt)
+            if (acc0 < a.g.traj_cap && acc0 < WV_GCAP) {
+                hsL[acc0] = h_att;
+                if (blockIdx.x == 0 && lane == 0) a.g.hs_out[acc0] = h_att;
+            } else gover = true;
+        }
         if (accepted) {                                    // u <- u_new, k1 <- k7
 #pragma unroll
             for (int m = 0; m < NI; ++m) { uz[m] = zt[m]; kz[0][m] = kz[6][m]; }
@@ -538,7 +586,299 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
             }
         }
     }
+    if constexpr (GRAD) {
+        if (alive && !gover && __builtin_amdgcn_readfirstlane(ns.done)) {
+            // ================= backward: discrete adjoint of the accepted steps (oracle/cnf_grad_oracle.py) =================
+            const float invB = 1.0f / (float)a.B;
+            const float cl0 = invB, cE0 = a.g.lam1 * invB, cn0 = a.g.lam2 * invB;   // cotangents of the scalar rows: constants
+            // d loss / d z(t1) = (z + lam3 unit(z_aug) on the augmented rows) / B      (k_final_cotangent)
+            f32x4 lam[NI];
+            {
+                float sa = 0.f;
+                const bool aug = nd.norm_z_aug && nd.naugs > 0;
+#pragma unroll
+                for (int m = 0; m < NI; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int r = 16 * m + 4 * q + j; if (aug && r >= nd.nvars) sa = fmaf(uz[m][j], uz[m][j], sa); }
+                sa = wv_quad_sum(sa);
+                const float nrm = sqrtf(sa);
+#pragma unroll
+                for (int m = 0; m < NI; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 16 * m + 4 * q + j;
+                        float v = uz[m][j];
+                        if (aug && r >= nd.nvars && nrm > 0.f) v = fmaf(a.g.lam3, uz[m][j] / nrm, v);
+                        lam[m][j] = live ? v * invB : 0.f;
+                    }
+            }
+            f32x4 gW2[NI][NH], gW1[NH][NI], gb1[NH], gb2[NI];
+#pragma unroll
+            for (int m = 0; m < NI; ++m) {
+                gb2[m] = zero4;
+#pragma unroll
+                for (int k = 0; k < NH; ++k) { gW2[m][k] = zero4; gW1[k][m] = zero4; }
+            }
+#pragma unroll
+            for (int k = 0; k < NH; ++k) gb1[k] = zero4;
+            // the forward half of an evaluation: nn(z) and the activations' derivatives
+            auto fwd2 = [&](const f32x4 (&z)[NI], f32x4 (&h1)[NH], f32x4 (&d1)[NH], f32x4 (&zd)[NI], f32x4 (&d2)[NI]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int m = 0; m < NH; ++m) {
+                    f32x4 acc = b1v[m];
+#pragma unroll
+                    for (int kt = 0; kt < NI; ++kt) acc = mm4(fW1[m][kt], z[kt], acc);
+                    act4(act1, acc, h1[m], d1[m], WV_GRAD_TANH_ACCURATE);
+                }
+#pragma unroll
+                for (int m = 0; m < NI; ++m) {
+                    f32x4 part[NH];
+#pragma unroll
+                    for (int kt = 0; kt < NH; ++kt) part[kt] = mm4(fW2[m][kt], h1[kt], kt == 0 ? b2v[m] : zero4);
+                    f32x4 acc = part[0];
+#pragma unroll
+                    for (int kt = 1; kt < NH; ++kt) acc += part[kt];
+                    f32x4 h2;
+                    act4(act2, acc, h2, d2[m], WV_GRAD_TANH_ACCURATE);
+                    zd[m] = h2 * rmask[m];
+                    d2[m] *= rmask[m];
+                }
+            };
+            // sigma'' from what the forward half kept (tanh: -2 h sigma'); other activations: from the pre-activation again
+            auto dd_of = [&](int kind, const f32x4& h, const f32x4& d) __attribute__((always_inline)) {
+                f32x4 r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = -2.0f * h[j] * d[j];
+                (void)kind;
+                return r;
+            };
+            const int nacc = __builtin_amdgcn_readfirstlane(ns.naccept);
+            const f32x4* tj0 = reinterpret_cast<const f32x4*>(a.g.traj) + (size_t)blockIdx.x * (64 * NI) + lane * NI;
+            const size_t tstage = (size_t)G * (64 * NI), tstep = 6 * tstage;
+            f32x4 U_next[6][NI];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int m = 0; m < NI; ++m) U_next[i][m] = nacc > 0 ? tj0[(size_t)(nacc - 1) * tstep + i * tstage + m] : zero4;
+            auto tput = [&](int slot, const f32x4& v) __attribute__((always_inline)) {
+                reinterpret_cast<f32x4*>(tbuf + slot * 256)[c * 4 + q] = v;
+            };
+            auto tget = [&](int slot, float (&o)[4]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = tbuf[slot * 256 + (4 * j + q) * 16 + c];
+            };
+            for (int n = nacc - 1; n >= 0; --n) {
+                const float hn = hsL[n];
+                f32x4 U[6][NI];                            // the stage states the forward pass filed; the next step's are requested a step ahead
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) U[i][m] = U_next[i][m];
+                if (n > 0) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int m = 0; m < NI; ++m) U_next[i][m] = tj0[(size_t)(n - 1) * tstep + i * tstage + m];
+                }
+                f32x4 ws[6][NI];
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) ws[i][m] = zero4;
+#pragma unroll 1
+                for (int i = 5; i >= 0; --i) {
+                    // ---- this stage's point and the cotangent of its k:  kbar = h (b_i lam + sum_{m > i} a_{m,i} w_m) ----
+                    f32x4 z[NI], kb[NI];
+                    const float bi = tab.a[6][i];
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) {
+                        z[m] = U[0][m];
+#pragma unroll
+                        for (int k = 1; k < 6; ++k) z[m] = i == k ? U[k][m] : z[m];
+                        f32x4 acc = bi * lam[m];
+#pragma unroll
+                        for (int k = 1; k < 6; ++k) acc += tab.a[k][i] * ws[k][m];     // (a_{k,i} = 0 for k <= i)
+                        kb[m] = hn * acc;
+                    }
+                    const float c_l = hn * bi * cl0, c_E = hn * bi * cE0, c_n = hn * bi * cn0;
+                    // ---- forward: h_1, sigma', sigma'' ; zdot ; ahat = kbar + c_E zdot / |zdot| ----
+                    f32x4 h1[NH], d1[NH], zd[NI], d2[NI];
+                    fwd2(z, h1, d1, zd, d2);
+                    float e2 = 0.f;
+#pragma unroll
+                    for (int m = 0; m < NI; ++m)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) e2 = fmaf(zd[m][j], zd[m][j], e2);
+                    f32x4 ahat[NI];
+                    {
+                        const float nz = nd.norm_z ? sqrtf(wv_quad_sum(e2)) : 0.f;
+                        const float sc = (nd.norm_z && nz > 0.f && live) ? c_E / nz : 0.f;
+#pragma unroll
+                        for (int m = 0; m < NI; ++m) ahat[m] = kb[m] + sc * zd[m];
+                    }
+                    // ---- reverse sweep of eps (tbar chain: omega = eps): pbar_2 = eps s'_2, tbar_1 = W_2' pbar_2, pbar_1 = tbar_1 s'_1, eJ ----
+                    f32x4 pb2[NI], tb1[NH], pb1[NH], eJ[NI];
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) pb2[m] = ep[m] * d2[m];
+#pragma unroll
+                    for (int m = 0; m < NH; ++m) {
+                        f32x4 acc = zero4;
+#pragma unroll
+                        for (int kt = 0; kt < NI; ++kt) acc = mm4(fW2T[m][kt], pb2[kt], acc);
+                        tb1[m] = acc;
+                        pb1[m] = acc * d1[m];
+                    }
+                    float n2 = 0.f;
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) {
+                        f32x4 part[NH];
+#pragma unroll
+                        for (int kt = 0; kt < NH; ++kt) part[kt] = mm4(fW1T[m][kt], pb1[kt], zero4);
+                        eJ[m] = part[0];
+#pragma unroll
+                        for (int kt = 1; kt < NH; ++kt) eJ[m] += part[kt];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) n2 = fmaf(eJ[m][j], eJ[m][j], n2);
+                    }
+                    // ---- tau = -c_l eps + c_n eJ / |eJ| ; tangent sweep: p_1 = W_1 tau, t_1 = s'_1 p_1, p_2 = W_2 t_1 ----
+                    f32x4 tau[NI], p1[NH], t1[NH], p2[NI];
+                    {
+                        const float nj = nd.norm_j ? sqrtf(wv_quad_sum(n2)) : 0.f;
+                        const float sc = (nd.norm_j && nj > 0.f) ? c_n / nj : 0.f;
+#pragma unroll
+                        for (int m = 0; m < NI; ++m) tau[m] = sc * eJ[m] - c_l * ep[m];
+                    }
+#pragma unroll
+                    for (int m = 0; m < NH; ++m) {
+                        f32x4 acc = zero4;
+#pragma unroll
+                        for (int kt = 0; kt < NI; ++kt) acc = mm4(fW1[m][kt], tau[kt], acc);
+                        p1[m] = acc;
+                        t1[m] = acc * d1[m];
+                    }
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) {
+                        f32x4 part[NH];
+#pragma unroll
+                        for (int kt = 0; kt < NH; ++kt) part[kt] = mm4(fW2[m][kt], t1[kt], zero4);
+                        p2[m] = part[0];
+#pragma unroll
+                        for (int kt = 1; kt < NH; ++kt) p2[m] += part[kt];
+                    }
+                    // ---- reverse sweep of the cotangent: abar_l = hbar_l s'_l + tbar_l s''_l p_l ; hbar_{l-1} = W_l' abar_l ----
+                    f32x4 ab2[NI], ab1[NH], w[NI];
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) ab2[m] = ahat[m] * d2[m] + ep[m] * dd_of(act2, zd[m], d2[m]) * p2[m];
+#pragma unroll
+                    for (int m = 0; m < NH; ++m) {
+                        f32x4 acc = zero4;
+#pragma unroll
+                        for (int kt = 0; kt < NI; ++kt) acc = mm4(fW2T[m][kt], ab2[kt], acc);
+                        ab1[m] = acc * d1[m] + tb1[m] * dd_of(act1, h1[m], d1[m]) * p1[m];
+                    }
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) {
+                        f32x4 part[NH];
+#pragma unroll
+                        for (int kt = 0; kt < NH; ++kt) part[kt] = mm4(fW1T[m][kt], ab1[kt], zero4);
+                        w[m] = part[0];
+#pragma unroll
+                        for (int kt = 1; kt < NH; ++kt) w[m] += part[kt];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+#pragma unroll
+                        for (int m = 0; m < NI; ++m) ws[k][m] = i == k ? w[m] : ws[k][m];
+                    // ---- weight gradient: Wbar_l += abar_l h_{l-1}' + pbar_l t_{l-1}' over the wave's 16 samples; bbar_l += abar_l ----
+                    // slots: [0, NI) abar_2 | [NI, 2NI) pbar_2 | [2NI, 3NI) z | [3NI, 4NI) tau | then NH each: h_1, t_1, abar_1, pbar_1
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) { tput(m, ab2[m]); tput(NI + m, pb2[m]); tput(2 * NI + m, z[m]); tput(3 * NI + m, tau[m]); gb2[m] += ab2[m]; }
+#pragma unroll
+                    for (int m = 0; m < NH; ++m) {
+                        tput(4 * NI + m, h1[m]); tput(4 * NI + NH + m, t1[m]); tput(4 * NI + 2 * NH + m, ab1[m]); tput(4 * NI + 3 * NH + m, pb1[m]);
+                        gb1[m] += ab1[m];
+                    }
+                    __syncthreads();
+                    {
+                        float A2[NI][4], P2[NI][4], Z0[NI][4], T0[NI][4];
+#pragma unroll
+                        for (int m = 0; m < NI; ++m) { tget(m, A2[m]); tget(NI + m, P2[m]); tget(2 * NI + m, Z0[m]); tget(3 * NI + m, T0[m]); }
+#pragma unroll
+                        for (int k = 0; k < NH; ++k) {
+                            float H1[4], T1[4], A1[4], P1[4];
+                            tget(4 * NI + k, H1); tget(4 * NI + NH + k, T1); tget(4 * NI + 2 * NH + k, A1); tget(4 * NI + 3 * NH + k, P1);
+#pragma unroll
+                            for (int m = 0; m < NI; ++m) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[m][j], H1[j], gW2[m][k], 0, 0, 0);
+                                    gW1[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], Z0[m][j], gW1[k][m], 0, 0, 0);
+                                }
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(P2[m][j], T1[j], gW2[m][k], 0, 0, 0);
+                                    gW1[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(P1[j], T0[m][j], gW1[k][m], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                // lambda <- lambda + sum_i w_i
+#pragma unroll
+                for (int m = 0; m < NI; ++m) lam[m] += ((ws[0][m] + ws[1][m]) + (ws[2][m] + ws[3][m])) + (ws[4][m] + ws[5][m]);
+            }
+            // ---- outputs: d loss / d z(t0), this wave's partial of the flat gradient (Lux order: W out x in column-major, then b) ----
+            if (live) {
+#pragma unroll
+                for (int m = 0; m < NI; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int r = 16 * m + 4 * q + j; if (r < n_in) a.g.lam_out[(size_t)smp * n_in + r] = lam[m][j]; }
+            }
+            float* gp = a.g.gpart + (size_t)blockIdx.x * a.g.n_params;
+#pragma unroll
+            for (int m = 0; m < NI; ++m)
+#pragma unroll
+                for (int k = 0; k < NH; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        {   // Wbar_2[o][kk]: row o = 16 m + 4 q + j, column kk = 16 k + c
+                            const int o = 16 * m + 4 * q + j, kk = 16 * k + c;
+                            if (o < n_in && kk < nh) gp[nd.w_off[1] + o + (size_t)kk * n_in] = gW2[m][k][j];
+                        }
+                        {   // Wbar_1[o][kk]: row o = 16 k + 4 q + j, column kk = 16 m + c
+                            const int o = 16 * k + 4 * q + j, kk = 16 * m + c;
+                            if (o < nh && kk < n_in) gp[nd.w_off[0] + o + (size_t)kk * nh] = gW1[k][m][j];
+                        }
+                    }
+            // bias gradients: the sum over the 16 samples of a lane group's rows (DPP row reduction, fixed order)
+            auto row_sum = [&](float v) __attribute__((always_inline)) {
+                v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+                v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+                return v;
+            };
+#pragma unroll
+            for (int k = 0; k < NH; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = row_sum(gb1[k][j]);
+                    const int r = 16 * k + 4 * q + j;
+                    if (c == 0 && r < nh) gp[nd.b_off[0] + r] = v;
+                }
+#pragma unroll
+            for (int m = 0; m < NI; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = row_sum(gb2[m][j]);
+                    const int r = 16 * m + 4 * q + j;
+                    if (c == 0 && r < n_in) gp[nd.b_off[1] + r] = v;
+                }
+        }
+    }
     if (blockIdx.x == 0 && lane == 0) {
+        if (GRAD && gover) { ns.done = 0; ns.n_partials = -1; }       // (the caller runs the streamed gradient path)
         if (!alive || __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ns.done = 0; ns.n_partials = -1; }
         __hip_atomic_store(sv.base_dev, mbase + (unsigned)nsync + 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ns.cur = 0;
@@ -549,6 +889,16 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
 }
 
 typedef void (*wave_fn)(WaveArgs, Solve3Args, const WvTab);
+wave_fn pick_grad(int ni, int nh) {
+    if (ni != 1) return nullptr;
+    switch (nh) {
+        case 1: return (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true>;
+        case 2: return (wave_fn)k_solve_wave<1, 2, WV_VJP, true, true>;
+        case 3: return (wave_fn)k_solve_wave<1, 3, WV_VJP, true, true>;
+        case 4: return (wave_fn)k_solve_wave<1, 4, WV_VJP, true, true>;
+    }
+    return nullptr;
+}
 template <int NI, int NH, bool TANH>
 wave_fn pick_mode(int mode) {
     return mode == WV_VJP ? (wave_fn)k_solve_wave<NI, NH, WV_VJP, TANH>
@@ -580,20 +930,33 @@ bool wave_solve_supported(const NetDesc& nd, bool train, int B) {
     return B <= 16 * 512;
 }
 
+int wave_grad_waves(int B) { return (B + 15) / 16; }
+size_t wave_grad_traj_floats(const NetDesc& nd, int B) { return (size_t)6 * wave_grad_waves(B) * 64 * ((nd.n_in + 15) / 16) * 4; }
+bool wave_grad_supported(const NetDesc& nd, int B) {
+    static const bool off = [] { const char* e = getenv("CNF_WAVE_GRAD"); return e && e[0] == '0'; }();
+    if (off || !wave_solve_supported(nd, true, B)) return false;
+    if (nd.jvp || nd.n_cond > 0 || nd.acts[0] != 1 || nd.acts[1] != 1) return false;
+    return pick_grad((nd.n_in + 15) / 16, (nd.dims[1] + 15) / 16) != nullptr && wave_grad_waves(B) <= 128;
+}
+
 cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_params, const float* cond, int cbs, StepState* st_out,
-                             float* U0, const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, const Solve3Args& sv_) {
+                             float* U0, const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, const Solve3Args& sv_,
+                             const WaveGradArgs* grad) {
     if (!wave_solve_supported(nd, train, B)) return CNF_ERR_UNSUPPORTED;
+    if (grad && (!train || !wave_grad_supported(nd, B) || !grad->traj || !grad->gpart || !grad->lam_out || !grad->hs_out || grad->traj_cap < 1))
+        return CNF_ERR_UNSUPPORTED;
     static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); const char* w = getenv("CNF_WAVE"); return (e && e[0] == '0') || (w && w[0] == '0'); }();
     if (off) return CNF_ERR_UNSUPPORTED;
     const int ni = (nd.n_in + 15) / 16, nh = (nd.dims[1] + 15) / 16;
     const int grid = (B + 15) / 16;
     const int mode = !train ? WV_TEST : (nd.jvp ? WV_JVP : WV_VJP);
-    wave_fn fn = pick_shape(ni, nh, mode, nd.acts[0] == 1 && nd.acts[1] == 1);
+    wave_fn fn = grad ? pick_grad(ni, nh) : pick_shape(ni, nh, mode, nd.acts[0] == 1 && nd.acts[1] == 1);
     if (!fn || grid > 512) return CNF_ERR_UNSUPPORTED;
     WaveArgs a{};
     a.nd = nd; a.P = d_params; a.eps = eps; a.cond = cond; a.cbs = cbs; a.B = B;
     a.n_total = (float)((size_t)(nd.n_in + (train ? 3 : 1)) * B);
     a.U0 = U0; a.st_out = st_out; a.mirror = mirror; a.seq = seq;
+    if (grad) a.g = *grad;
     Solve3Args sv = sv_;
     sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
     // (a bare solve reads u0 and writes u_out where the caller keeps them; an inference assembles u0 from sv.xs)

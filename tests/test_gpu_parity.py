@@ -1291,6 +1291,47 @@ def test_loss_grad_tiny_batches():
             _assert_grad(grad, rgrad, f"B={B} {kernel}")
 
 
+def test_loss_grad_wave_local_small_networks(monkeypatch):
+    """loss_and_grad of small two-layer tanh networks (the README / regression networks, n_in <= 16, up to 64 hidden units) at
+    small batches: solve, loss sums and the whole discrete adjoint in ONE launch, one wave per 16 samples (k_solve_wave<GRAD>),
+    + the sum of the waves' partials.  Against the float64 oracle differentiating the same accepted steps: every hidden tile
+    count, widths below the padding, ragged and one-sample batches, the regression span (0, 13), lambda3 with augmentation
+    and without; bit-reproducible; and A/B against the streamed gradient path (CNF_WAVE_GRAD=0 is read once per process, so
+    the A/B runs on the GENERIC kernel choice, which never takes the wave path)."""
+    tol = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+    cases = [
+        (O.Cfg(O.Net((16, 48, 16), (O.ACT_TANH,) * 2), 8, 8, 1e-2, 1e-2, 1e-2, tspan=(0.0, 13.0)), 32, "replay", dict()),   # regression_tests.jl
+        (O.Cfg(O.Net((2, 6, 2), (O.ACT_TANH,) * 2), 1, 1, 1e-2, 1e-2, 1e-2, tspan=(0.0, 13.0)), 32, "replay", dict()),      # README.md:47
+        (O.Cfg(O.Net((16, 48, 16), (O.ACT_TANH,) * 2), 8, 8, 1e-2, 1e-2, 1e-2), 77, "replay", dict(tol)),
+        (O.Cfg(O.Net((12, 20, 12), (O.ACT_TANH,) * 2), 12, 0, 1e-2, 0.0, 0.0), 5, dict(adaptive=False, dt=1 / 6), dict(adaptive=False, dt=1 / 6)),
+        (O.Cfg(O.Net((16, 64, 16), (O.ACT_TANH,) * 2), 10, 6, 0.0, 1e-2, 5e-2), 300, dict(adaptive=False, dt=1 / 5), dict(adaptive=False, dt=1 / 5)),
+        (O.Cfg(O.Net((7, 13, 7), (O.ACT_TANH,) * 2), 4, 3, 1e-2, 1e-2, 1e-2, tspan=(1.0, 0.0)), 1, dict(adaptive=False, dt=1 / 4), dict(adaptive=False, dt=1 / 4)),
+        (O.Cfg(O.Net((16, 32, 16), (O.ACT_TANH,) * 2), 16, 0, 0.0, 0.0, 0.0), 2048, "replay", dict()),                      # FFJORD, 128 waves
+    ]
+    for ci, (cfg, B, ora_kw, sol_kw) in enumerate(cases):
+        val, grad, rval, rgrad, st, ost = _grad_case(cfg, B, 900 + ci, "mfma", dict(sol_kw), ora_kw, scale=0.5)
+        what = f"wave-local gradient {cfg.net.dims} B={B}"
+        assert st["launches"] <= 2, (what, st)
+        assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval)), (what, val, rval)
+        _assert_grad(grad, rgrad, what)
+        helpers.note(f"{what}: {st['naccept']} steps, {st['launches']} launches, |grad| {np.abs(rgrad).max():.3g}")
+    # bit-reproducible, and the same gradient as the streamed path to rounding
+    cfg = cases[0][0]
+    rng = np.random.default_rng(5)
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.5)
+    xs = rng.standard_normal((cfg.nvars, 32)).astype(np.float32)
+    eps = rng.standard_normal((cfg.n_in, 32)).astype(np.float32)
+    out = []
+    for kernel in ("mfma", "mfma", "generic"):
+        ic = make_icnf(cnf, cfg, kernel=kernel)
+        v, g = cnf.loss_and_grad(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+        out.append((v, g.cpu().numpy(), ic.last_stats["launches"]))
+        ic.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    assert out[0][2] <= 2 < out[2][2]
+    _assert_grad(out[0][1], out[2][1].astype(np.float64), "wave-local vs streamed gradient", rtol=5e-4)
+
+
 def test_exact_trace_mfma_deep_networks():
     """TestMode for networks with three or more layers runs the MFMA exact-trace kernel
     (cnf_trace.hip: tr J = sum_i [D_L W_L T_{L-1}]_ii with the tangent columns of a group of samples sharing
