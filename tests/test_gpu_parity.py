@@ -1498,6 +1498,17 @@ def test_loss_grad_more_steps_than_the_trajectory_store():
     _assert_grad(grad, rgrad, "100 steps")
 
 
+def test_loss_grad_wave_local_hands_over_beyond_its_step_store():
+    """k_solve_wave<GRAD> keeps the step sizes of at most WV_GCAP = 1024 accepted steps: a solve with more ends without a
+    gradient and the call runs again on the streamed gradient path -- same loss, same gradient as the oracle."""
+    cfg = O.Cfg(O.Net((6, 12, 6), (O.ACT_TANH,) * 2), 6, 0, 1e-2, 1e-2, 0.0)
+    val, grad, rval, rgrad, st, _ = _grad_case(cfg, 20, 951, "mfma", dict(adaptive=False, dt=1 / 1100),
+                                               dict(adaptive=False, dt=1 / 1100))
+    assert st["naccept"] == 1100 and st["launches"] > 2, st
+    assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+    _assert_grad(grad, rgrad, "1100 steps")
+
+
 def test_config4_full_batch_on_one_gpu():
     """BASELINE config 4 unsharded: FFJORD, 65536 columns on one GPU (2048 tiles over 512 workgroups: several
     tiles per workgroup, 512 error partials).  Sampled columns of a fixed-dt solve against the oracle; the
