@@ -109,6 +109,7 @@ struct cnf_ctx {
     float* g_lam = nullptr;
     float *g_HS = nullptr, *g_TS = nullptr, *g_AB = nullptr, *g_PB = nullptr;
     float* g_part = nullptr;      // GRAD_MAX_KSPLIT x n_params
+    NetDesc nd_wave{};            // what the wave kernels see: nd, or a one-layer tanh network with an identity layer appended
     float* wg_traj = nullptr;     // k_solve_wave<GRAD>: z rows of u_n per accepted step, as the lanes hold them; + WV_GCAP step sizes
     size_t wg_traj_floats = 0;
     float* g_grad = nullptr;      // n_params (host-pointer variant)
@@ -216,8 +217,24 @@ extern "C" cnf_status cnf_create(cnf_handle* out, const cnf_config* cfg) {
     nd.sum_dims = sum;
     h->lam[0] = cfg->lambda1; h->lam[1] = cfg->lambda2; h->lam[2] = cfg->lambda3;
 
+    // A ONE-layer tanh network (`Dense(n => n, tanh)`: the network of the reference's benchmark suite, benchmark/benchmarks.jl:29)
+    // runs on the two-layer wave kernels as (that layer, identity): W_2 = I and b_2 = 0 are kept behind the parameters.
+    h->nd_wave = nd;
+    size_t id_tail = 0;
+    if (cfg->n_layers == 1 && cfg->acts[0] == CNF_ACT_TANH && n_in <= 16) {
+        NetDesc& w = h->nd_wave;
+        w.n_layers = 2; w.dims[2] = n_in; w.acts[1] = CNF_ACT_IDENTITY;
+        w.w_off[1] = off; w.b_off[1] = off + n_in * n_in;
+        w.sum_dims = sum + n_in; w.id2 = 1;
+        id_tail = (size_t)n_in * n_in + n_in;
+    }
     hipError_t e = hipSetDevice(h->device);
-    if (e == hipSuccess) e = hipMalloc(&h->d_params, h->n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&h->d_params, (h->n_params + id_tail) * sizeof(float));
+    if (e == hipSuccess && id_tail) {
+        std::vector<float> idm(id_tail, 0.f);
+        for (int i = 0; i < n_in; ++i) idm[(size_t)i * n_in + i] = 1.f;
+        e = hipMemcpy(h->d_params + h->n_params, idm.data(), id_tail * sizeof(float), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc(&h->d_state, 2 * sizeof(StepState));
     // (the one-launch solve uses it as 8-byte words: 2 x 1024 of the meetings, 2048 of the loss-sum partials)
     if (e == hipSuccess) e = hipMalloc(&h->partials, 8 * MAX_PARTIALS * sizeof(float));
@@ -866,8 +883,11 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     // The whole solve in ONE launch where the handle and the batch allow it (k_solve3b / k_solve3jb): the weights and the
     // Runge-Kutta rows stay on the CUs for all attempts, the workgroups exchange two floats per attempt.
     // ... or of a small two-layer network, one wave per 16-sample tile, registers only (k_solve_wave, cnf_wave.hip)
-    const bool wave_ok = k == CNF_KERNEL_MFMA && (!rec || (rec->wg && post && post->xs && wave_grad_supported(h->nd, B))) &&
-                         wave_solve_supported(h->nd, train != 0, B);
+    // (a one-layer tanh network has no other MFMA kernel: AUTO resolves to GENERIC for it, and the wave kernels take it
+    // through its appended identity layer unless GENERIC was asked for)
+    const bool wave_k = k == CNF_KERNEL_MFMA || (h->nd_wave.id2 && opts->kernel != CNF_KERNEL_GENERIC);
+    const bool wave_ok = wave_k && (!rec || (rec->wg && post && post->xs && wave_grad_supported(h->nd_wave, B))) &&
+                         wave_solve_supported(h->nd_wave, train != 0, B);
     if (rec && rec->wg && !(wave_ok && !lockstep && !h->no_persist)) { rec->wg_failed = true; return CNF_OK; }
     // ... or of config 5's network at eight columns per CU (k_solve_bcast, cnf_bcast.hip)
     const bool bcast_ok = k == CNF_KERNEL_MFMA && !rec && !wave_ok && bcast_solve_supported(h->nd, train != 0, B, h->device);
@@ -920,7 +940,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         }
         s = CNF_ERR_UNSUPPORTED;
         if (wave_ok)
-            s = wave_solve_launch(h->nd, train != 0, h->d_params, h->nd.n_cond > 0 ? h->d_cond : nullptr, h->cbs, h->d_state, h->U[0],
+            s = wave_solve_launch(h->nd_wave, train != 0, h->d_params, h->nd.n_cond > 0 ? h->d_cond : nullptr, h->cbs, h->d_state, h->U[0],
                                   eps, B, st, h->d_mirror + mslot, base, sv, rec ? rec->wg : nullptr);
         if (tsolve_ok) {
             const GradLayout g = grad_layout(h->nd);
@@ -982,7 +1002,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                     stats->nreject = fin.nreject;
                     stats->t_final = fin.t;
                     stats->dt_last = fin.dt;
-                    stats->kernel_used = k;
+                    stats->kernel_used = wave_ok ? CNF_KERNEL_MFMA : k;
                     stats->launches = launches;
                 }
                 if (fin.nonfinite) return fail(h, CNF_ERR_NONFINITE, "solver state became NaN/Inf");
@@ -1608,8 +1628,8 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
 
     // ---- small batches of a small two-layer tanh network: the solve, the loss sums and the whole discrete adjoint in ONE
     // launch, one wave per 16 samples (k_solve_wave<GRAD>, cnf_wave.hip), then the sum of the waves' partials ----
-    if (opts->kernel != CNF_KERNEL_GENERIC && wave_grad_supported(nd, B)) {
-        const size_t per_step = wave_grad_traj_floats(nd, B);
+    if (opts->kernel != CNF_KERNEL_GENERIC && wave_grad_supported(h->nd_wave, B)) {
+        const size_t per_step = wave_grad_traj_floats(h->nd_wave, B);
         int cap = WV_GCAP;
         while (cap > 64 && per_step * cap > ((size_t)1 << 26)) cap /= 2;       // <= 256 MiB of trajectory
         const size_t need = per_step * cap + WV_GCAP;

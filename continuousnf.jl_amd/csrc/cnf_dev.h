@@ -20,6 +20,8 @@ struct NetDesc {
     int n_cond;                     // conditioning rows; dims[0] stays n_in, the first layer's weight has
                                     // n_in + n_cond columns (column-major: the z columns come first)
     int wy_off;                     // float offset of the conditioning columns of layer 0's weight
+    int id2;                        // layer 1 is an identity map (W = I, b = 0) appended behind the parameters of a ONE-layer
+                                    // network so that the two-layer wave kernels take it (cnf_abi.hip, cnf_wave.hip)
 };
 
 // Device-resident integrator state: lets the step controller run on the GPU so that a

@@ -113,8 +113,13 @@ __device__ __forceinline__ float wv_quad_sum(float v) {
 // factors over the wave's 16 samples with MFMAs whose k index is the SAMPLE (the factor tiles transposed through a
 // wave-private LDS buffer: one 16-byte write, four 4-byte reads per tile).  The weight-gradient tiles stay in registers for
 // the whole backward pass; each wave writes one partial, k_grad_reduce adds them in wave order (bit-reproducible).
-template <int NI, int NH, int MODE, bool TANH, bool GRAD = false>
+//
+// ID2: the second layer is the identity map appended by the caller to a ONE-layer network (`Dense(n => n, tanh)`, the
+// network of the reference's benchmark suite, benchmark/benchmarks.jl:29: W_2 = I, b_2 = 0, identity activation -- exact in
+// fp32: products with 1 and 0, sums with 0); its activation is compiled out and its gradient is not written.
+template <int NI, int NH, int MODE, bool TANH, bool GRAD = false, bool ID2 = false>
 __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, const WvTab tab) {
+    static_assert(!ID2 || TANH, "ID2 is instantiated for tanh first layers");
     static_assert(!GRAD || (MODE == WV_VJP && TANH), "the in-launch adjoint is written for the VJP compute mode of tanh networks");
     constexpr bool TRAIN = MODE != WV_TEST;
     constexpr int NS = TRAIN ? 3 : 1;                      // scalar rows of the state
@@ -198,8 +203,11 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
     for (int s = 0; s < 7; ++s) ks[s] = 0.f;
 
     // ---- one evaluation of augmented_f at z -> (zdot, this lane group's scalar row) ----
-    auto act4 = [&](int kind, const f32x4& pre, f32x4& h, f32x4& d, bool accurate = false) __attribute__((always_inline)) {
-        if (fast) {
+    auto act4 = [&](int kind, const f32x4& pre, f32x4& h, f32x4& d, bool accurate = false, bool second = false) __attribute__((always_inline)) {
+        if (ID2 && second) {
+            h = pre;
+            d = f32x4{1.f, 1.f, 1.f, 1.f};
+        } else if (fast) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { h[j] = (GRAD || accurate) ? tanh_grad(pre[j]) : tanh_fast(pre[j]); d[j] = fmaf(-h[j], h[j], 1.f); }
         } else {
@@ -228,7 +236,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
 #pragma unroll
             for (int kt = 1; kt < NH; ++kt) acc += part[kt];
             f32x4 h2;
-            act4(act2, acc, h2, d2[m]);
+            act4(act2, acc, h2, d2[m], false, true);
             zd[m] = h2 * rmask[m];
             d2[m] *= rmask[m];
 #pragma unroll
@@ -639,17 +647,16 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
 #pragma unroll
                     for (int kt = 1; kt < NH; ++kt) acc += part[kt];
                     f32x4 h2;
-                    act4(act2, acc, h2, d2[m], WV_GRAD_TANH_ACCURATE);
+                    act4(act2, acc, h2, d2[m], WV_GRAD_TANH_ACCURATE, true);
                     zd[m] = h2 * rmask[m];
                     d2[m] *= rmask[m];
                 }
             };
             // sigma'' from what the forward half kept (tanh: -2 h sigma'); other activations: from the pre-activation again
-            auto dd_of = [&](int kind, const f32x4& h, const f32x4& d) __attribute__((always_inline)) {
+            auto dd_of = [&](bool second, const f32x4& h, const f32x4& d) __attribute__((always_inline)) {
                 f32x4 r;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) r[j] = -2.0f * h[j] * d[j];
-                (void)kind;
+                for (int j = 0; j < 4; ++j) r[j] = (ID2 && second) ? 0.f : -2.0f * h[j] * d[j];
                 return r;
             };
             const int nacc = __builtin_amdgcn_readfirstlane(ns.naccept);
@@ -768,13 +775,13 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                     // ---- reverse sweep of the cotangent: abar_l = hbar_l s'_l + tbar_l s''_l p_l ; hbar_{l-1} = W_l' abar_l ----
                     f32x4 ab2[NI], ab1[NH], w[NI];
 #pragma unroll
-                    for (int m = 0; m < NI; ++m) ab2[m] = ahat[m] * d2[m] + ep[m] * dd_of(act2, zd[m], d2[m]) * p2[m];
+                    for (int m = 0; m < NI; ++m) ab2[m] = ahat[m] * d2[m] + ep[m] * dd_of(true, zd[m], d2[m]) * p2[m];
 #pragma unroll
                     for (int m = 0; m < NH; ++m) {
                         f32x4 acc = zero4;
 #pragma unroll
                         for (int kt = 0; kt < NI; ++kt) acc = mm4(fW2T[m][kt], ab2[kt], acc);
-                        ab1[m] = acc * d1[m] + tb1[m] * dd_of(act1, h1[m], d1[m]) * p1[m];
+                        ab1[m] = acc * d1[m] + tb1[m] * dd_of(false, h1[m], d1[m]) * p1[m];
                     }
 #pragma unroll
                     for (int m = 0; m < NI; ++m) {
@@ -811,12 +818,12 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                             for (int m = 0; m < NI; ++m) {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-                                    gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[m][j], H1[j], gW2[m][k], 0, 0, 0);
+                                    if (!ID2) gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[m][j], H1[j], gW2[m][k], 0, 0, 0);
                                     gW1[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], Z0[m][j], gW1[k][m], 0, 0, 0);
                                 }
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-                                    gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(P2[m][j], T1[j], gW2[m][k], 0, 0, 0);
+                                    if (!ID2) gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(P2[m][j], T1[j], gW2[m][k], 0, 0, 0);
                                     gW1[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(P1[j], T0[m][j], gW1[k][m], 0, 0, 0);
                                 }
                             }
@@ -842,7 +849,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                 for (int k = 0; k < NH; ++k)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        {   // Wbar_2[o][kk]: row o = 16 m + 4 q + j, column kk = 16 k + c
+                        if (!ID2) {   // Wbar_2[o][kk]: row o = 16 m + 4 q + j, column kk = 16 k + c
                             const int o = 16 * m + 4 * q + j, kk = 16 * k + c;
                             if (o < n_in && kk < nh) gp[nd.w_off[1] + o + (size_t)kk * n_in] = gW2[m][k][j];
                         }
@@ -873,7 +880,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                 for (int j = 0; j < 4; ++j) {
                     const float v = row_sum(gb2[m][j]);
                     const int r = 16 * m + 4 * q + j;
-                    if (c == 0 && r < n_in) gp[nd.b_off[1] + r] = v;
+                    if (!ID2 && c == 0 && r < n_in) gp[nd.b_off[1] + r] = v;
                 }
         }
     }
@@ -889,8 +896,9 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
 }
 
 typedef void (*wave_fn)(WaveArgs, Solve3Args, const WvTab);
-wave_fn pick_grad(int ni, int nh) {
+wave_fn pick_grad(int ni, int nh, bool id2) {
     if (ni != 1) return nullptr;
+    if (id2) return nh == 1 ? (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true, true> : nullptr;
     switch (nh) {
         case 1: return (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true>;
         case 2: return (wave_fn)k_solve_wave<1, 2, WV_VJP, true, true>;
@@ -913,9 +921,15 @@ wave_fn pick_shape_t(int ni, int nh, int mode) {
     if (ni == 2 && nh == 6) return pick_mode<2, 6, TANH>(mode);
     return nullptr;
 }
-wave_fn pick_shape(int ni, int nh, int mode, bool tanh2 = true) {
+wave_fn pick_shape(int ni, int nh, int mode, bool tanh2 = true, bool id2 = false) {
+    if (id2)       // (tanh, appended identity): n_in <= 16
+        return ni == 1 && nh == 1 ? (mode == WV_VJP ? (wave_fn)k_solve_wave<1, 1, WV_VJP, true, false, true>
+                                   : mode == WV_JVP ? (wave_fn)k_solve_wave<1, 1, WV_JVP, true, false, true>
+                                                    : (wave_fn)k_solve_wave<1, 1, WV_TEST, true, false, true>) : nullptr;
     return tanh2 ? pick_shape_t<true>(ni, nh, mode) : pick_shape_t<false>(ni, nh, mode);
 }
+// a one-layer tanh network seen as (tanh layer, identity layer): cnf_abi.hip appends W_2 = I, b_2 = 0 behind the parameters
+bool is_id2(const NetDesc& nd) { return nd.n_layers == 2 && nd.acts[0] == 1 && nd.acts[1] == 0 && nd.id2; }
 
 }  // namespace
 
@@ -935,8 +949,8 @@ size_t wave_grad_traj_floats(const NetDesc& nd, int B) { return (size_t)6 * wave
 bool wave_grad_supported(const NetDesc& nd, int B) {
     static const bool off = [] { const char* e = getenv("CNF_WAVE_GRAD"); return e && e[0] == '0'; }();
     if (off || !wave_solve_supported(nd, true, B)) return false;
-    if (nd.jvp || nd.n_cond > 0 || nd.acts[0] != 1 || nd.acts[1] != 1) return false;
-    return pick_grad((nd.n_in + 15) / 16, (nd.dims[1] + 15) / 16) != nullptr && wave_grad_waves(B) <= 128;
+    if (nd.jvp || nd.n_cond > 0 || nd.acts[0] != 1 || !(nd.acts[1] == 1 || is_id2(nd))) return false;
+    return pick_grad((nd.n_in + 15) / 16, (nd.dims[1] + 15) / 16, is_id2(nd)) != nullptr && wave_grad_waves(B) <= 128;
 }
 
 cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_params, const float* cond, int cbs, StepState* st_out,
@@ -950,7 +964,7 @@ cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_param
     const int ni = (nd.n_in + 15) / 16, nh = (nd.dims[1] + 15) / 16;
     const int grid = (B + 15) / 16;
     const int mode = !train ? WV_TEST : (nd.jvp ? WV_JVP : WV_VJP);
-    wave_fn fn = grad ? pick_grad(ni, nh) : pick_shape(ni, nh, mode, nd.acts[0] == 1 && nd.acts[1] == 1);
+    wave_fn fn = grad ? pick_grad(ni, nh, is_id2(nd)) : pick_shape(ni, nh, mode, nd.acts[0] == 1 && nd.acts[1] == 1, is_id2(nd));
     if (!fn || grid > 512) return CNF_ERR_UNSUPPORTED;
     WaveArgs a{};
     a.nd = nd; a.P = d_params; a.eps = eps; a.cond = cond; a.cbs = cbs; a.B = B;

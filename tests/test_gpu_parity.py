@@ -1498,6 +1498,49 @@ def test_loss_grad_more_steps_than_the_trajectory_store():
     _assert_grad(grad, rgrad, "100 steps")
 
 
+def test_one_layer_network_of_the_reference_benchmark_suite():
+    """benchmark/benchmarks.jl:24-59: RNODE nvars = naugs = 8, nn = Chain(Dense(16 => 16, tanh)) -- ONE layer --, 64 samples,
+    tspan (0, 13), lambda3 = 1e-2; its four benchmarks are loss(TrainMode), loss(TestMode) and their gradients.  The wave
+    kernels take the network through an appended identity layer (W_2 = I, b_2 = 0: exact): inference in Train and TestMode in
+    ONE launch and loss_and_grad(TrainMode) in two, against the float64 oracle of the one-layer network; other one-layer
+    widths; the kernel = generic route beside it."""
+    f64 = lambda a: a.astype(np.float64)
+    one = _one_launch_expected() and os.environ.get("CNF_WAVE") != "0"
+    for (n_in, nvars, naugs, B) in ((16, 8, 8, 64), (5, 3, 2, 33), (16, 16, 0, 1)):
+        net = O.Net((n_in, n_in), (O.ACT_TANH,))
+        rng = np.random.default_rng(70 + n_in + B)
+        flat = O.glorot_params(net, rng, np.float32, 0.6)
+        flat[-n_in:] = 0.1 * rng.standard_normal(n_in).astype(np.float32)
+        xs = rng.random((nvars, B)).astype(np.float32)                     # rand(rng, Float32, nvars, n)  benchmarks.jl:48
+        eps = rng.standard_normal((n_in, B)).astype(np.float32)
+        lam3 = 1e-2 if naugs else 0.0
+        cfg = O.Cfg(net, nvars, naugs, 1e-2, 1e-2, lam3, tspan=(0.0, 13.0))
+        outs = {}
+        for kernel in ("auto", "generic"):
+            ic = make_icnf(cnf, cfg, kernel=kernel, tag=cnf.RNODE, sol_kwargs=dict(adaptive=False, dt=13 / 32))
+            lp, (E, n, A) = cnf.inference(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+            if kernel == "auto":
+                assert (ic.last_stats["launches"] == 1) == one, ic.last_stats
+            _, ref_lp, ref_regs, _ = O.inference(cfg, f64(flat), f64(xs), f64(eps), True, dt=13 / 32, adaptive=False)
+            assert_parity(lp.cpu().numpy(), ref_lp, f"one-layer {n_in} TrainMode logpx {kernel}")
+            assert_parity(torch.stack([E, n, A]).cpu().numpy(), np.stack(ref_regs), f"one-layer {n_in} TrainMode regs {kernel}")
+            lpt, _ = cnf.inference(ic, cnf.TestMode(), _dev(xs), flat, {})
+            if kernel == "auto":
+                assert (ic.last_stats["launches"] == 1) == one, ic.last_stats
+            _, ref_lpt, _, _ = O.inference(cfg, f64(flat), f64(xs), None, False, dt=13 / 32, adaptive=False)
+            assert_parity(lpt.cpu().numpy(), ref_lpt, f"one-layer {n_in} TestMode logpx {kernel}")
+            outs[kernel] = lp.cpu().numpy()
+            ic.close()
+        assert_parity(outs["auto"], outs["generic"].astype(np.float64), f"one-layer {n_in}: wave kernel vs generic")
+        # the gradient of the TrainMode loss, adaptive at the package's default tolerances, the oracle on the same steps
+        val, grad, rval, rgrad, st, ost = _grad_case(cfg, B, 80 + n_in, "auto", dict(), "replay", scale=0.6)
+        assert grad.size == net.n_params
+        if one:
+            assert st["launches"] <= 2, st
+        assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+        _assert_grad(grad, rgrad, f"one-layer {n_in} gradient")
+
+
 def test_loss_grad_wave_local_hands_over_beyond_its_step_store():
     """k_solve_wave<GRAD> keeps the step sizes of at most WV_GCAP = 1024 accepted steps: a solve with more ends without a
     gradient and the call runs again on the streamed gradient path -- same loss, same gradient as the oracle."""
