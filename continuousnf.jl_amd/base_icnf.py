@@ -700,7 +700,7 @@ def loss_and_grad(icnf: ICNF, mode, xs, *args, eps=None, with_x=False):
     ``ps`` and lives where ``xs`` lives (torch.cuda tensor or numpy array).  Conditional models:
     ``(xs, ys, ps, st)`` as everywhere else.  Steering draws t1 exactly as ``loss`` does."""
     if _mode_id(mode) != _lib.MODE_TRAIN:
-        raise NotImplementedError("gradients are implemented for TrainMode (the mode the reference trains in)")
+        return _loss_and_grad_test(icnf, mode, xs, *args, with_x=with_x)
     ys, ps, st = _split_cond_args(icnf, args)
     xb = _as_colmajor(xs, icnf.nvars, "xs")
     B = xb.B
@@ -747,6 +747,52 @@ def loss_and_grad(icnf: ICNF, mode, xs, *args, eps=None, with_x=False):
             gx = gd.cpu().numpy().reshape(B, icnf.nvars).T
         return float(val.value), grad, gx
     return float(val.value), grad
+
+
+def _loss_and_grad_test(icnf: ICNF, mode, xs, *args, with_x=False):
+    """``loss(icnf, TestMode(), xs, ps, st)`` and its gradient through the exact-trace solve (cnf_loss_grad_test): what the
+    reference's call tests and benchmark suite differentiate besides the TrainMode loss (test/call_tests.jl ``diff_loss``,
+    benchmark/benchmarks.jl:60-99).  Small two-layer (or one-layer) tanh networks; ``NotImplementedError`` otherwise."""
+    import torch
+    ys, ps, st = _split_cond_args(icnf, args)
+    if ys is not None:
+        raise NotImplementedError("TestMode gradients: unconditional models")
+    xb = _as_colmajor(xs, icnf.nvars, "xs")
+    B = xb.B
+    icnf.set_params(ps)
+    opts = _solve_opts(icnf, steer_tspan(icnf, mode))
+    stats = _lib.cnf_solve_stats()
+    val = C.c_float()
+    l, h = _lib.lib(), icnf.handle()
+    n_params = icnf.nn.n_params_internal
+    if xb.torch is not None:
+        xd, stream = xb.arr, _stream(xb)
+        dev = xb.arr.device
+    else:                                                  # host data: staged here (the ABI entry takes device pointers)
+        dev = torch.device("cuda", icnf.device)
+        xd = torch.from_numpy(np.ascontiguousarray(xb.arr)).to(dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    grad = torch.empty(n_params, dtype=torch.float32, device=dev)
+    rc = l.cnf_loss_grad_test(h, xd.data_ptr(), B, C.byref(opts), C.byref(val), grad.data_ptr(), C.byref(stats), stream)
+    if rc == _lib.ERR_UNSUPPORTED:
+        raise NotImplementedError("TestMode gradients are implemented for small two-layer tanh networks (k_solve_wave); "
+                                  "the reference trains in TrainMode")
+    _lib.check(rc, h)
+    icnf.last_stats = stats.as_dict()
+    n = l.cnf_grad_steps(h, None, 0)
+    hs = np.empty(max(n, 1), dtype=np.float32)
+    l.cnf_grad_steps(h, hs.ctypes.data, n)
+    icnf.last_steps = hs[:n]
+    gx = None
+    if with_x:
+        gx = torch.empty(B * icnf.nvars, dtype=torch.float32, device=dev)
+        _lib.check(l.cnf_grad_x(h, gx.data_ptr(), B, stream), h)
+        gx = gx.view(B, icnf.nvars).t()
+    if xb.torch is None:
+        grad = grad.cpu().numpy()
+        gx = gx.cpu().numpy() if gx is not None else None
+    grad = icnf.nn.grad_to_external(grad)
+    return (float(val.value), grad, gx) if with_x else (float(val.value), grad)
 
 
 def loss_sums(icnf: ICNF, logpx, regs):

@@ -886,7 +886,7 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     // (a one-layer tanh network has no other MFMA kernel: AUTO resolves to GENERIC for it, and the wave kernels take it
     // through its appended identity layer unless GENERIC was asked for)
     const bool wave_k = k == CNF_KERNEL_MFMA || (h->nd_wave.id2 && opts->kernel != CNF_KERNEL_GENERIC);
-    const bool wave_ok = wave_k && (!rec || (rec->wg && post && post->xs && wave_grad_supported(h->nd_wave, B))) &&
+    const bool wave_ok = wave_k && (!rec || (rec->wg && post && post->xs && wave_grad_supported(h->nd_wave, B, train != 0))) &&
                          wave_solve_supported(h->nd_wave, train != 0, B);
     if (rec && rec->wg && !(wave_ok && !lockstep && !h->no_persist)) { rec->wg_failed = true; return CNF_OK; }
     // ... or of config 5's network at eight columns per CU (k_solve_bcast, cnf_bcast.hip)
@@ -1601,34 +1601,18 @@ static cnf_status ensure_grad_capacity(cnf_handle h, int B) {
     return CNF_OK;
 }
 
-extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* eps, int B,
-                                    const cnf_solve_opts* opts, float* loss_out, float* grad,
-                                    cnf_solve_stats* stats, void* stream) {
-    const int mode = CNF_MODE_TRAIN;
-    cnf_status s = check_call(h, mode, B);
-    if (s != CNF_OK) return s;
-    if (!xs || !eps || !opts || !loss_out || !grad) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
-    if (B < 1) return fail(h, CNF_ERR_BAD_SHAPE, "the loss is a mean over the batch: B must be >= 1");
-    const GradLayout gl = grad_layout(h->nd);
-    if (!grad_supported(h->nd, gl)) return fail(h, CNF_ERR_UNSUPPORTED, "network too wide for the gradient kernels");
-    if ((s = ensure_capacity(h, B)) != CNF_OK) return s;
-    if ((s = ensure_grad_capacity(h, B)) != CNF_OK) return s;
+// loss_and_grad of small batches of a small two-layer tanh network (or a one-layer one through its appended identity layer):
+// the solve, the loss sums and the whole discrete adjoint in ONE launch, one wave per 16 samples (k_solve_wave<GRAD>,
+// cnf_wave.hip), then the sum of the waves' partials.  TrainMode (VJP compute mode) and TestMode (exact trace).  *done = false:
+// not this network / batch, or the launch gave up (a wait ran out, more steps than its store holds) -- nothing was written.
+static cnf_status wave_loss_grad(cnf_handle h, int mode, const float* xs, const float* eps, int B, const cnf_solve_opts* opts,
+                                 float* loss_out, float* grad, cnf_solve_stats* stats, void* stream, bool* done) {
+    *done = false;
+    cnf_status s = CNF_OK;
     hipStream_t st = (hipStream_t)stream;
-    const NetDesc& nd = h->nd;
-    const int n_in = nd.n_in, D = n_in + 3;
-    const size_t n = (size_t)D * B;
-    const AdjMfmaLayout am = adj_mfma_layout(nd, gl);
-    // the pullback kernel follows the kernel choice of the solve: GENERIC -> VALU, otherwise MFMA when it fits
-    const bool adj_mfma = opts->kernel != CNF_KERNEL_GENERIC && adj_mfma_supported(nd, am);
-    if (!h->pt_valid) {
-        HIPCHK(h, launch_transpose_params(nd, h->d_params, h->d_PT, st));
-        HIPCHK(h, launch_pack_adj_images(nd, gl, am, h->d_params, h->d_adj_img, st));
-        h->pt_valid = true;
-    }
-
-    // ---- small batches of a small two-layer tanh network: the solve, the loss sums and the whole discrete adjoint in ONE
-    // launch, one wave per 16 samples (k_solve_wave<GRAD>, cnf_wave.hip), then the sum of the waves' partials ----
-    if (opts->kernel != CNF_KERNEL_GENERIC && wave_grad_supported(h->nd_wave, B)) {
+    const bool train = mode == CNF_MODE_TRAIN;
+    if (opts->kernel == CNF_KERNEL_GENERIC || !wave_grad_supported(h->nd_wave, B, train)) return CNF_OK;
+    {
         const size_t per_step = wave_grad_traj_floats(h->nd_wave, B);
         int cap = WV_GCAP;
         while (cap > 64 && per_step * cap > ((size_t)1 << 26)) cap /= 2;       // <= 256 MiB of trajectory
@@ -1658,8 +1642,40 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
             sst.launches += 1;
             if ((s = cnf_loss_from_sums(h, mode, sums, loss_out)) != CNF_OK) return s;
             if (stats) *stats = sst;
-            return CNF_OK;
+            *done = true;
         }
+    }
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* eps, int B,
+                                    const cnf_solve_opts* opts, float* loss_out, float* grad,
+                                    cnf_solve_stats* stats, void* stream) {
+    const int mode = CNF_MODE_TRAIN;
+    cnf_status s = check_call(h, mode, B);
+    if (s != CNF_OK) return s;
+    if (!xs || !eps || !opts || !loss_out || !grad) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    if (B < 1) return fail(h, CNF_ERR_BAD_SHAPE, "the loss is a mean over the batch: B must be >= 1");
+    const GradLayout gl = grad_layout(h->nd);
+    if (!grad_supported(h->nd, gl)) return fail(h, CNF_ERR_UNSUPPORTED, "network too wide for the gradient kernels");
+    if ((s = ensure_capacity(h, B)) != CNF_OK) return s;
+    if ((s = ensure_grad_capacity(h, B)) != CNF_OK) return s;
+    hipStream_t st = (hipStream_t)stream;
+    const NetDesc& nd = h->nd;
+    const int n_in = nd.n_in, D = n_in + 3;
+    const size_t n = (size_t)D * B;
+    const AdjMfmaLayout am = adj_mfma_layout(nd, gl);
+    // the pullback kernel follows the kernel choice of the solve: GENERIC -> VALU, otherwise MFMA when it fits
+    const bool adj_mfma = opts->kernel != CNF_KERNEL_GENERIC && adj_mfma_supported(nd, am);
+    if (!h->pt_valid) {
+        HIPCHK(h, launch_transpose_params(nd, h->d_params, h->d_PT, st));
+        HIPCHK(h, launch_pack_adj_images(nd, gl, am, h->d_params, h->d_adj_img, st));
+        h->pt_valid = true;
+    }
+
+    {   // small batches of a small two-layer tanh network: everything in one launch (wave_loss_grad above)
+        bool done = false;
+        if ((s = wave_loss_grad(h, mode, xs, eps, B, opts, loss_out, grad, stats, stream, &done)) != CNF_OK || done) return s;
     }
 
     // ---- forward: u0, recorded solve, loss ------------------------------------------------------
@@ -1748,6 +1764,26 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
     HIPCHK(h, hipStreamSynchronize(st));
     if ((s = cnf_loss_from_sums(h, mode, sums, loss_out)) != CNF_OK) return s;
     if (stats) *stats = sst;
+    return CNF_OK;
+}
+
+// TestMode: loss(icnf, TestMode(), xs, ps, st) = -mean(logpx) (src/base_icnf.jl:489-497) and its gradient w.r.t. the flat
+// parameters through the exact-trace solve -- what the reference's call tests and its benchmark suite differentiate besides
+// the TrainMode loss (test/call_tests.jl `diff_loss` with omode = TestMode(); benchmark/benchmarks.jl:60-99 "AD-1-order" /
+// "test").  Implemented for the networks k_solve_wave<GRAD> takes (two tanh layers or one, n_in <= 16, <= 64 hidden units,
+// unconditional, B <= 2048); CNF_ERR_UNSUPPORTED otherwise.
+extern "C" cnf_status cnf_loss_grad_test(cnf_handle h, const float* xs, int B, const cnf_solve_opts* opts, float* loss_out,
+                                         float* grad, cnf_solve_stats* stats, void* stream) {
+    const int mode = CNF_MODE_TEST;
+    cnf_status s = check_call(h, mode, B);
+    if (s != CNF_OK) return s;
+    if (!xs || !opts || !loss_out || !grad) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    if (B < 1) return fail(h, CNF_ERR_BAD_SHAPE, "the loss is a mean over the batch: B must be >= 1");
+    if ((s = ensure_capacity(h, B)) != CNF_OK) return s;
+    if ((s = ensure_grad_capacity(h, B)) != CNF_OK) return s;
+    bool done = false;
+    if ((s = wave_loss_grad(h, mode, xs, nullptr, B, opts, loss_out, grad, stats, stream, &done)) != CNF_OK) return s;
+    if (!done) return fail(h, CNF_ERR_UNSUPPORTED, "the TestMode gradient is implemented for small two-layer tanh networks (k_solve_wave)");
     return CNF_OK;
 }
 

@@ -18,8 +18,9 @@ struct WaveGradArgs {
 // floats of trajectory store per accepted step, waves of a launch
 size_t wave_grad_traj_floats(const NetDesc& nd, int B);
 int wave_grad_waves(int B);
-// two tanh layers, n_in <= 16, VJP compute mode, no conditioning, at most GRAD_MAX_KSPLIT waves
-bool wave_grad_supported(const NetDesc& nd, int B);
+// two tanh layers (or one + the appended identity), n_in <= 16, no conditioning, at most GRAD_MAX_KSPLIT waves; TrainMode:
+// the VJP compute mode; TestMode: the adjoint of the exact-trace solve (closed form of two-layer networks)
+bool wave_grad_supported(const NetDesc& nd, int B, bool train = true);
 
 // a two-layer network whose 16-row tile counts have an instantiation, B within the meeting buffer's reach
 bool wave_solve_supported(const NetDesc& nd, bool train, int B);

@@ -120,7 +120,8 @@ __device__ __forceinline__ float wv_quad_sum(float v) {
 template <int NI, int NH, int MODE, bool TANH, bool GRAD = false, bool ID2 = false>
 __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, const WvTab tab) {
     static_assert(!ID2 || TANH, "ID2 is instantiated for tanh first layers");
-    static_assert(!GRAD || (MODE == WV_VJP && TANH), "the in-launch adjoint is written for the VJP compute mode of tanh networks");
+    static_assert(!GRAD || ((MODE == WV_VJP || MODE == WV_TEST) && TANH), "the in-launch adjoint is written for TrainMode / VJP and TestMode of tanh networks");
+    constexpr bool GTEST = GRAD && MODE == WV_TEST;         // the adjoint of the exact-trace solve
     constexpr bool TRAIN = MODE != WV_TEST;
     constexpr int NS = TRAIN ? 3 : 1;                      // scalar rows of the state
     const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
@@ -135,7 +136,8 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
     // ---- weights as A operands, in the k order the accumulator tiles present: lane (q, i), k-step j of input tile kt ->
     // M[16 m + i][16 kt + 4 q + j].  Straight from the flat vector (L2 hits after the first wave), once per solve. ----
     float fW1[NH][NI][4], fW2[NI][NH][4];
-    float fW2T[MODE == WV_VJP ? NH : 1][NI][4], fW1T[MODE == WV_VJP ? NI : 1][NH][4], fC[MODE == WV_TEST ? NH : 1][NI][4];
+    float fW2T[(MODE == WV_VJP || GTEST) ? NH : 1][NI][4], fW1T[(MODE == WV_VJP || GTEST) ? NI : 1][NH][4], fC[MODE == WV_TEST ? NH : 1][NI][4];
+    float fCT[GTEST ? NI : 1][NH][4];
     auto w1 = [&](int o, int k) { return (o < nh && k < n_in) ? P[nd.w_off[0] + o + (size_t)k * nh] : 0.f; };       // W1[o][k]
     auto w2 = [&](int o, int k) { return (o < n_in && k < nh) ? P[nd.w_off[1] + o + (size_t)k * n_in] : 0.f; };     // W2[o][k]
 #pragma unroll
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
             for (int j = 0; j < 4; ++j) {
                 const int o = 16 * m + c, k = 16 * kt + 4 * q + j;
                 fW1[m][kt][j] = w1(o, k);
-                if (MODE == WV_VJP) fW2T[m][kt][j] = w2(k, o);                     // W2^T[o][k] = W2[k][o]
+                if (MODE == WV_VJP || GTEST) fW2T[m][kt][j] = w2(k, o);            // W2^T[o][k] = W2[k][o]
                 if (MODE == WV_TEST) fC[m][kt][j] = w1(o, k) * w2(k, o);           // C[o][k] = W1[o][k] W2[k][o]
             }
 #pragma unroll
@@ -157,7 +159,8 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
             for (int j = 0; j < 4; ++j) {
                 const int o = 16 * m + c, k = 16 * kt + 4 * q + j;
                 fW2[m][kt][j] = w2(o, k);
-                if (MODE == WV_VJP) fW1T[m][kt][j] = w1(k, o);                     // W1^T[o][k] = W1[k][o]
+                if (MODE == WV_VJP || GTEST) fW1T[m][kt][j] = w1(k, o);            // W1^T[o][k] = W1[k][o]
+                if (GTEST) fCT[m][kt][j] = w1(k, o) * w2(o, k);                    // C^T[o][k] = C[k][o] = W1[k][o] W2[o][k]
             }
     // biases in the accumulator layout (rows 16 m + 4 q + j); conditional models: a row per sample instead of b1
     const int smp = blockIdx.x * 16 + c;
@@ -603,7 +606,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
             f32x4 lam[NI];
             {
                 float sa = 0.f;
-                const bool aug = nd.norm_z_aug && nd.naugs > 0;
+                const bool aug = TRAIN && nd.norm_z_aug && nd.naugs > 0;      // (TestMode: loss = -mean(logpx), src/base_icnf.jl:489-497)
 #pragma unroll
                 for (int m = 0; m < NI; ++m)
 #pragma unroll
@@ -621,11 +624,12 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                     }
             }
             f32x4 gW2[NI][NH], gW1[NH][NI], gb1[NH], gb2[NI];
+            f32x4 gH[GTEST ? NH : 1][NI];                   // TestMode: sum over stages and samples of c_l s'_1 s'_2' (see below)
 #pragma unroll
             for (int m = 0; m < NI; ++m) {
                 gb2[m] = zero4;
 #pragma unroll
-                for (int k = 0; k < NH; ++k) { gW2[m][k] = zero4; gW1[k][m] = zero4; }
+                for (int k = 0; k < NH; ++k) { gW2[m][k] = zero4; gW1[k][m] = zero4; if (GTEST) gH[k][m] = zero4; }
             }
 #pragma unroll
             for (int k = 0; k < NH; ++k) gb1[k] = zero4;
@@ -708,9 +712,57 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                         kb[m] = hn * acc;
                     }
                     const float c_l = hn * bi * cl0, c_E = hn * bi * cE0, c_n = hn * bi * cn0;
+                    (void)c_E; (void)c_n;
                     // ---- forward: h_1, sigma', sigma'' ; zdot ; ahat = kbar + c_E zdot / |zdot| ----
                     f32x4 h1[NH], d1[NH], zd[NI], d2[NI];
                     fwd2(z, h1, d1, zd, d2);
+                    // what the weight-gradient contraction takes: abar_2, abar_1 and a second factor pair per layer
+                    f32x4 ab2[NI], ab1[NH], w[NI], pb2[NI], t1[NH], pb1[NH], tau[NI];
+                    if constexpr (GTEST) {
+                        // ---- TestMode: Phi = kbar' nn(z) - c_l tr J,  tr J = s'_1' C s'_2 with C = W_1 .* W_2' (closed form).
+                        // r = C s'_2, s = C' s'_1;  abar_2 = kbar s'_2 - c_l s''_2 s,  abar_1 = (W_2' abar_2) s'_1 - c_l s''_1 r;
+                        // d tr / d W_1 = (s'_1 s'_2') .* W_2', d tr / d W_2 = (s'_2 s'_1') .* W_1': the sum H of c_l s'_1 s'_2' over
+                        // stages and samples is contracted like a factor pair and multiplied by the weights once, at the end ----
+                        const float c_lv = live ? c_l : 0.f;    // (columns past the batch carry no cotangent)
+                        f32x4 r[NH], sv2[NI];
+#pragma unroll
+                        for (int m = 0; m < NH; ++m) {
+                            f32x4 acc = zero4;
+#pragma unroll
+                            for (int kt = 0; kt < NI; ++kt) acc = mm4(fC[m][kt], d2[kt], acc);
+                            r[m] = acc;
+                        }
+#pragma unroll
+                        for (int m = 0; m < NI; ++m) {
+                            f32x4 part[NH];
+#pragma unroll
+                            for (int kt = 0; kt < NH; ++kt) part[kt] = mm4(fCT[m][kt], d1[kt], zero4);
+                            sv2[m] = part[0];
+#pragma unroll
+                            for (int kt = 1; kt < NH; ++kt) sv2[m] += part[kt];
+                            ab2[m] = kb[m] * d2[m] - c_lv * dd_of(true, zd[m], d2[m]) * sv2[m];
+                        }
+#pragma unroll
+                        for (int m = 0; m < NH; ++m) {
+                            f32x4 acc = zero4;
+#pragma unroll
+                            for (int kt = 0; kt < NI; ++kt) acc = mm4(fW2T[m][kt], ab2[kt], acc);
+                            ab1[m] = acc * d1[m] - c_lv * dd_of(false, h1[m], d1[m]) * r[m];
+                            t1[m] = c_lv * d1[m];           // second pair of layer 1's slot: (c_l s'_1) x s'_2 -> H
+                            pb1[m] = zero4;
+                        }
+#pragma unroll
+                        for (int m = 0; m < NI; ++m) {
+                            f32x4 part[NH];
+#pragma unroll
+                            for (int kt = 0; kt < NH; ++kt) part[kt] = mm4(fW1T[m][kt], ab1[kt], zero4);
+                            w[m] = part[0];
+#pragma unroll
+                            for (int kt = 1; kt < NH; ++kt) w[m] += part[kt];
+                            pb2[m] = d2[m];
+                            tau[m] = zero4;
+                        }
+                    } else {
                     float e2 = 0.f;
 #pragma unroll
                     for (int m = 0; m < NI; ++m)
@@ -724,7 +776,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                         for (int m = 0; m < NI; ++m) ahat[m] = kb[m] + sc * zd[m];
                     }
                     // ---- reverse sweep of eps (tbar chain: omega = eps): pbar_2 = eps s'_2, tbar_1 = W_2' pbar_2, pbar_1 = tbar_1 s'_1, eJ ----
-                    f32x4 pb2[NI], tb1[NH], pb1[NH], eJ[NI];
+                    f32x4 tb1[NH], eJ[NI];
 #pragma unroll
                     for (int m = 0; m < NI; ++m) pb2[m] = ep[m] * d2[m];
 #pragma unroll
@@ -748,7 +800,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                         for (int j = 0; j < 4; ++j) n2 = fmaf(eJ[m][j], eJ[m][j], n2);
                     }
                     // ---- tau = -c_l eps + c_n eJ / |eJ| ; tangent sweep: p_1 = W_1 tau, t_1 = s'_1 p_1, p_2 = W_2 t_1 ----
-                    f32x4 tau[NI], p1[NH], t1[NH], p2[NI];
+                    f32x4 p1[NH], p2[NI];
                     {
                         const float nj = nd.norm_j ? sqrtf(wv_quad_sum(n2)) : 0.f;
                         const float sc = (nd.norm_j && nj > 0.f) ? c_n / nj : 0.f;
@@ -773,7 +825,6 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                         for (int kt = 1; kt < NH; ++kt) p2[m] += part[kt];
                     }
                     // ---- reverse sweep of the cotangent: abar_l = hbar_l s'_l + tbar_l s''_l p_l ; hbar_{l-1} = W_l' abar_l ----
-                    f32x4 ab2[NI], ab1[NH], w[NI];
 #pragma unroll
                     for (int m = 0; m < NI; ++m) ab2[m] = ahat[m] * d2[m] + ep[m] * dd_of(true, zd[m], d2[m]) * p2[m];
 #pragma unroll
@@ -792,6 +843,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
 #pragma unroll
                         for (int kt = 1; kt < NH; ++kt) w[m] += part[kt];
                     }
+                    }   // (VJP)
 #pragma unroll
                     for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -823,8 +875,12 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                                 }
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-                                    if (!ID2) gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(P2[m][j], T1[j], gW2[m][k], 0, 0, 0);
-                                    gW1[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(P1[j], T0[m][j], gW1[k][m], 0, 0, 0);
+                                    if (GTEST) {               // H[hidden][input] += (c_l s'_1) s'_2'
+                                        gH[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(T1[j], P2[m][j], gH[k][m], 0, 0, 0);
+                                    } else {
+                                        if (!ID2) gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(P2[m][j], T1[j], gW2[m][k], 0, 0, 0);
+                                        gW1[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(P1[j], T0[m][j], gW1[k][m], 0, 0, 0);
+                                    }
                                 }
                             }
                         }
@@ -841,6 +897,25 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                 for (int m = 0; m < NI; ++m)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { const int r = 16 * m + 4 * q + j; if (r < n_in) a.g.lam_out[(size_t)smp * n_in + r] = lam[m][j]; }
+            }
+            if constexpr (GTEST) {
+                // Wbar_1[k][i] -= H[k][i] W_2[i][k];  Wbar_2[i][k] -= H[k][i] W_1[k][i]  (H's tile transposed through the LDS buffer)
+#pragma unroll
+                for (int k = 0; k < NH; ++k)
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) {
+                        tput(0, gH[k][m]);
+                        __syncthreads();
+                        float Ht[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Ht[j] = tbuf[(4 * q + j) * 16 + c];     // H[16 k + c][16 m + 4 q + j]
+                        __syncthreads();
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            gW1[k][m][j] -= gH[k][m][j] * w2(16 * m + c, 16 * k + 4 * q + j);
+                            gW2[m][k][j] -= Ht[j] * w1(16 * k + c, 16 * m + 4 * q + j);
+                        }
+                    }
             }
             float* gp = a.g.gpart + (size_t)blockIdx.x * a.g.n_params;
 #pragma unroll
@@ -896,9 +971,17 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
 }
 
 typedef void (*wave_fn)(WaveArgs, Solve3Args, const WvTab);
-wave_fn pick_grad(int ni, int nh, bool id2) {
+wave_fn pick_grad(int ni, int nh, bool id2, bool test = false) {
     if (ni != 1) return nullptr;
-    if (id2) return nh == 1 ? (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true, true> : nullptr;
+    if (id2) return nh != 1 ? nullptr : test ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, true, true> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true, true>;
+    if (test)
+        switch (nh) {
+            case 1: return (wave_fn)k_solve_wave<1, 1, WV_TEST, true, true>;
+            case 2: return (wave_fn)k_solve_wave<1, 2, WV_TEST, true, true>;
+            case 3: return (wave_fn)k_solve_wave<1, 3, WV_TEST, true, true>;
+            case 4: return (wave_fn)k_solve_wave<1, 4, WV_TEST, true, true>;
+            default: return nullptr;
+        }
     switch (nh) {
         case 1: return (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true>;
         case 2: return (wave_fn)k_solve_wave<1, 2, WV_VJP, true, true>;
@@ -946,10 +1029,10 @@ bool wave_solve_supported(const NetDesc& nd, bool train, int B) {
 
 int wave_grad_waves(int B) { return (B + 15) / 16; }
 size_t wave_grad_traj_floats(const NetDesc& nd, int B) { return (size_t)6 * wave_grad_waves(B) * 64 * ((nd.n_in + 15) / 16) * 4; }
-bool wave_grad_supported(const NetDesc& nd, int B) {
+bool wave_grad_supported(const NetDesc& nd, int B, bool train) {
     static const bool off = [] { const char* e = getenv("CNF_WAVE_GRAD"); return e && e[0] == '0'; }();
-    if (off || !wave_solve_supported(nd, true, B)) return false;
-    if (nd.jvp || nd.n_cond > 0 || nd.acts[0] != 1 || !(nd.acts[1] == 1 || is_id2(nd))) return false;
+    if (off || !wave_solve_supported(nd, train, B)) return false;
+    if ((train && nd.jvp) || nd.n_cond > 0 || nd.acts[0] != 1 || !(nd.acts[1] == 1 || is_id2(nd))) return false;
     return pick_grad((nd.n_in + 15) / 16, (nd.dims[1] + 15) / 16, is_id2(nd)) != nullptr && wave_grad_waves(B) <= 128;
 }
 
@@ -957,14 +1040,14 @@ cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_param
                              float* U0, const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, const Solve3Args& sv_,
                              const WaveGradArgs* grad) {
     if (!wave_solve_supported(nd, train, B)) return CNF_ERR_UNSUPPORTED;
-    if (grad && (!train || !wave_grad_supported(nd, B) || !grad->traj || !grad->gpart || !grad->lam_out || !grad->hs_out || grad->traj_cap < 1))
+    if (grad && (!wave_grad_supported(nd, B, train) || !grad->traj || !grad->gpart || !grad->lam_out || !grad->hs_out || grad->traj_cap < 1))
         return CNF_ERR_UNSUPPORTED;
     static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); const char* w = getenv("CNF_WAVE"); return (e && e[0] == '0') || (w && w[0] == '0'); }();
     if (off) return CNF_ERR_UNSUPPORTED;
     const int ni = (nd.n_in + 15) / 16, nh = (nd.dims[1] + 15) / 16;
     const int grid = (B + 15) / 16;
     const int mode = !train ? WV_TEST : (nd.jvp ? WV_JVP : WV_VJP);
-    wave_fn fn = grad ? pick_grad(ni, nh, is_id2(nd)) : pick_shape(ni, nh, mode, nd.acts[0] == 1 && nd.acts[1] == 1, is_id2(nd));
+    wave_fn fn = grad ? pick_grad(ni, nh, is_id2(nd), !train) : pick_shape(ni, nh, mode, nd.acts[0] == 1 && nd.acts[1] == 1, is_id2(nd));
     if (!fn || grid > 512) return CNF_ERR_UNSUPPORTED;
     WaveArgs a{};
     a.nd = nd; a.P = d_params; a.eps = eps; a.cond = cond; a.cbs = cbs; a.B = B;

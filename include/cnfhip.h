@@ -260,6 +260,14 @@ cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* eps, int B,
 cnf_status cnf_loss_grad_host(cnf_handle h, const float* xs, const float* eps, int B,
                               const cnf_solve_opts* opts, float* loss_out, float* grad,
                               cnf_solve_stats* stats);
+/* loss(icnf, TestMode(), xs, ps, st) = -mean(logpx) (src/base_icnf.jl:489-497) and its gradient w.r.t. the flat parameters
+ * through the exact-trace solve: the derivative the reference's call tests and benchmark suite take besides the TrainMode
+ * one (test/call_tests.jl `diff_loss` with omode = TestMode(); benchmark/benchmarks.jl:60-99, "AD-1-order" / "test").
+ * Device pointers, arguments as cnf_loss_grad (no eps: the exact trace draws nothing); cnf_grad_steps / cnf_grad_x apply
+ * to it as well.  Implemented where the whole gradient runs in the launch of the solve -- two tanh layers (closed-form
+ * trace) or one, n_in <= 16, <= 64 hidden units, unconditional, B <= 2048 --, CNF_ERR_UNSUPPORTED otherwise. */
+cnf_status cnf_loss_grad_test(cnf_handle h, const float* xs, int B, const cnf_solve_opts* opts, float* loss_out,
+                              float* grad, cnf_solve_stats* stats, void* stream);
 /* The signed sizes of the steps the last cnf_loss_grad on this handle accepted (the discrete map
  * it differentiated): writes min(n, cap) floats to hs (may be NULL) and returns n. */
 int cnf_grad_steps(cnf_handle h, float* hs, int cap);

@@ -202,3 +202,96 @@ def loss_and_grad(cfg: O.Cfg, flat, xs, eps, ys=None, dts=None, **solve_kw):
     # tests differentiate besides ps: test/call_tests.jl `diff2_loss`)
     st.grad_x = lam[:cfg.nvars].copy()
     return val, grad, st
+
+
+# ---------------------------------------------------------------------------------------
+# TestMode (exact trace): the gradient of ``loss(icnf, TestMode(), xs, ps, st)`` = -mean(logpx) (src/base_icnf.jl:489-497),
+# which the reference differentiates in its call tests and in its benchmark suite (test/call_tests.jl `diff_loss` for
+# omode = TestMode(); benchmark/benchmarks.jl:60-99 "AD-1-order"/"test") by running Enzyme through ``jacobian_batched``
+# (src/utils.jl:1-36) and the solve.  Restated as the same discrete adjoint with the pullback of
+#     f(z) = (nn(z), -tr J(z)),      J = D_L W_L ... D_1 W_1,  D_l = diag(s'(a_l))
+# written out by hand: with P_l = M_{l-1} ... M_1 (P_1 = [I; 0]), Q_l = M_L ... M_{l+1}, M_l = D_l W_l and G_l = (P_l Q_l)',
+#     d tr / d W_l = D_l G_l,      d tr / d a_l (direct) = s''(a_l) .* rowsum(W_l .* G_l),
+# and the indirect dependence through h_{l-1} by ordinary back-propagation.  Pinned by torch autograd
+# (tests/test_grad_oracle.py::test_testmode_grad_matches_torch_autograd).
+# ---------------------------------------------------------------------------------------
+def rhs_vjp_test(net: O.Net, flat, z, kbar_z, c, ys=None):
+    """Pullback of augmented_f (TestMode) at z: cotangent ``kbar_z`` [n_in x B] of zdot and ``c`` [1 x B] (or scalar) of
+    ldot = -tr J.  Returns (zbar [n_in x B], grad [n_params] summed over the columns)."""
+    n_in, B = z.shape
+    Ws, bs = O.unflatten_params(net, flat)
+    L = len(Ws)
+    x0 = z if ys is None else np.vstack([z, ys])
+    hs, d1, d2 = [x0], [], []
+    h = x0
+    for l, (W, b) in enumerate(zip(Ws, bs)):
+        a = W @ h + b[:, None]
+        h, d = O.act_apply(net.acts[l], a)
+        hs.append(h); d1.append(d); d2.append(act_d2(net.acts[l], a))
+    # per-sample M_l = D_l W_l  [B, out, in]
+    Ms = [d1[l].T[:, :, None] * Ws[l][None, :, :] for l in range(L)]
+    P = [None] * L
+    P[0] = np.broadcast_to(np.eye(x0.shape[0], n_in, dtype=z.dtype), (B, x0.shape[0], n_in))
+    for l in range(1, L):
+        P[l] = Ms[l - 1] @ P[l - 1]
+    Q = [None] * L
+    Q[L - 1] = np.broadcast_to(np.eye(n_in, dtype=z.dtype), (B, n_in, n_in))
+    for l in range(L - 2, -1, -1):
+        Q[l] = Q[l + 1] @ Ms[l + 1]
+    cc = np.broadcast_to(np.asarray(c, dtype=z.dtype).reshape(1, -1), (1, B))[0]      # cotangent of ldot per sample
+    hbar = kbar_z
+    gWs, gbs = [None] * L, [None] * L
+    for l in reversed(range(L)):
+        G = np.transpose(P[l] @ Q[l], (0, 2, 1))                       # [B, out_l, in_l]
+        u = np.einsum("jk,bjk->jb", Ws[l], G)                          # rowsum(W_l .* G_l)
+        # Phi = kbar_z' h_L + c * ldot = kbar_z' h_L - c tr J
+        abar = hbar * d1[l] + cc[None, :] * (-1.0) * d2[l] * u
+        gWs[l] = abar @ hs[l].T - np.einsum("b,jb,bjk->jk", cc, d1[l], G)
+        gbs[l] = abar.sum(axis=1)
+        hbar = Ws[l].T @ abar
+    return hbar[:n_in], flatten_grads(net, gWs, gbs)
+
+
+def loss_and_grad_test(cfg: O.Cfg, flat, xs, ys=None, dts=None, **solve_kw):
+    """(loss, d loss / d flat, stats) of the TestMode loss -mean(logpx) through the Tsit5 solve of the (n_in + 1)-row state
+    (exact trace); ``dts`` as in loss_and_grad; ``stats.grad_x`` = d loss / d xs."""
+    flat = np.asarray(flat)
+    u0 = O.inference_u0(cfg, xs, False)
+    f = cfg.rhs(flat, None, False, ys)
+    if dts is None:
+        fsol, st = O.tsit5_solve(f, u0, cfg.tspan[0], cfg.tspan[1], **solve_kw)
+    else:
+        st = O.SolveStats(naccept=len(dts), dts=[abs(float(d)) for d in dts])
+    us = forward_record(f, u0, cfg.tspan[0], cfg.tspan[1], st.dts)
+    fsol = us[-1]
+    logpx, regs = O.inference_sol(cfg, fsol, False)
+    val = O.loss(cfg, logpx, regs, False)
+    T = u0.dtype.type
+    tdir = 1.0 if cfg.tspan[1] >= cfg.tspan[0] else -1.0
+    n_in, B = cfg.n_in, xs.shape[1]
+    lam = fsol[:n_in] / B                                                # -logpx = |z|^2 / 2 + const + dlogp
+    lam_l = 1.0 / B
+    grad = np.zeros(flat.size, dtype=flat.dtype)
+    A, Bc = O.TSIT5_A, O.TSIT5_B
+    for n in reversed(range(len(st.dts))):
+        h = T(tdir * st.dts[n])
+        u = us[n]
+        ks, Us = [], []
+        for s in range(6):
+            acc = np.zeros_like(u)
+            for j in range(s):
+                acc = acc + T(A[s][j]) * ks[j]
+            U = u + h * acc
+            Us.append(U)
+            ks.append(f(U))
+        ws = [None] * 6
+        for i in reversed(range(6)):
+            kb = T(Bc[i]) * lam
+            for m in range(i + 1, 6):
+                kb = kb + T(A[m][i]) * ws[m]
+            zbar, g = rhs_vjp_test(cfg.net, flat, Us[i][:n_in], h * kb, h * T(Bc[i]) * lam_l, ys)
+            ws[i] = zbar
+            grad += g
+        lam = lam + sum(ws)
+    st.grad_x = lam[:cfg.nvars].copy()
+    return val, grad, st

@@ -1541,6 +1541,53 @@ def test_one_layer_network_of_the_reference_benchmark_suite():
         _assert_grad(grad, rgrad, f"one-layer {n_in} gradient")
 
 
+def test_testmode_loss_gradient_small_networks():
+    """The other derivative the reference takes: loss(icnf, TestMode(), xs, ps, st) = -mean(logpx) through the EXACT-TRACE solve,
+    w.r.t. ps and xs (test/call_tests.jl `diff_loss` / `diff2_loss` with omode = TestMode(); benchmark/benchmarks.jl:60-99
+    "AD-1-order" / "test").  cnf_loss_grad_test (k_solve_wave<TEST, GRAD>: the closed-form trace of two-layer networks and its
+    pullback in the launch of the solve) against the float64 oracle on the same accepted steps (itself pinned by torch
+    autograd, tests/test_grad_oracle.py): the benchmark's one-layer network, the regression / README networks, ragged
+    batches, host arrays; networks it does not take raise NotImplementedError."""
+    from oracle import cnf_grad_oracle as G
+    T2 = (O.ACT_TANH,) * 2
+    cases = [
+        (O.Cfg(O.Net((16, 16), (O.ACT_TANH,)), 8, 8, 1e-2, 1e-2, 1e-2, tspan=(0.0, 13.0)), 64, dict()),        # benchmarks.jl:24-59
+        (O.Cfg(O.Net((16, 48, 16), T2), 8, 8, 1e-2, 1e-2, 1e-2, tspan=(0.0, 13.0)), 32, dict()),               # regression_tests.jl
+        (O.Cfg(O.Net((2, 6, 2), T2), 1, 1, 1e-2, 1e-2, 1e-2, tspan=(0.0, 13.0)), 77, dict()),                  # README.md:47
+        (O.Cfg(O.Net((12, 20, 12), T2), 12, 0, 0.0, 0.0, 0.0), 5, dict(adaptive=False, dt=1 / 6)),
+        (O.Cfg(O.Net((16, 64, 16), T2), 10, 6, 1e-2, 1e-2, 1e-2, tspan=(1.0, 0.0)), 300, dict(adaptive=False, dt=1 / 5)),
+        (O.Cfg(O.Net((7, 7), (O.ACT_TANH,)), 4, 3, 1e-2, 1e-2, 1e-2), 1, dict(adaptive=False, dt=1 / 4)),
+    ]
+    for ci, (cfg, B, sol_kw) in enumerate(cases):
+        rng = np.random.default_rng(600 + ci)
+        flat = O.glorot_params(cfg.net, rng, np.float32, 0.5)
+        flat[-cfg.n_in:] = 0.1 * rng.standard_normal(cfg.n_in).astype(np.float32)
+        xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+        ic = make_icnf(cnf, cfg, kernel="auto", tag=cnf.RNODE, sol_kwargs=dict(sol_kw))
+        host = ci == 3
+        val, grad, gx = cnf.loss_and_grad(ic, cnf.TestMode(), xs if host else _dev(xs), flat, {}, with_x=True)
+        if not host:
+            grad, gx = grad.cpu().numpy(), gx.cpu().numpy()
+        st = ic.last_stats
+        rval, rgrad, ost = G.loss_and_grad_test(cfg, flat.astype(np.float64), xs.astype(np.float64), dts=[float(d) for d in ic.last_steps])
+        what = f"TestMode gradient {cfg.net.dims} B={B}"
+        assert st["launches"] <= 2 and st["naccept"] == ost.naccept, (what, st)
+        assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval)), (what, val, rval)
+        _assert_grad(grad, rgrad, what)
+        _assert_grad(gx, ost.grad_x, what + " d/dxs", rtol=2e-4)
+        # the loss value is the one loss() returns (its launch evaluates tanh in the exp2 / rcp form, this one with the
+        # polynomial near 0: rounding apart)
+        assert abs(val - cnf.loss(ic, cnf.TestMode(), _dev(xs), flat, {})) <= 1e-5 * max(1.0, abs(val))
+        ic.close()
+    # outside the wave kernels: not implemented (the reference trains in TrainMode)
+    cfg3, _, _ = O.baseline_cfg(3)
+    ic = make_icnf(cnf, cfg3, kernel="auto")
+    flat = O.glorot_params(cfg3.net, np.random.default_rng(1), np.float32, 0.2)
+    with pytest.raises(NotImplementedError):
+        cnf.loss_and_grad(ic, cnf.TestMode(), _dev(np.zeros((cfg3.nvars, 8), np.float32)), flat, {})
+    ic.close()
+
+
 def test_loss_grad_wave_local_hands_over_beyond_its_step_store():
     """k_solve_wave<GRAD> keeps the step sizes of at most WV_GCAP = 1024 accepted steps: a solve with more ends without a
     gradient and the call runs again on the streamed gradient path -- same loss, same gradient as the oracle."""

@@ -161,3 +161,75 @@ def test_rhs_vjp_matches_autograd_on_baseline_shapes():
         assert np.abs(g - ft.grad.numpy()).max() <= 1e-10 * max(1.0, np.abs(g).max())
         assert np.abs(zbar - ut.grad.numpy()[:cfg.n_in]).max() <= 1e-10
         assert np.abs(ut.grad.numpy()[cfg.n_in:]).max() == 0
+
+
+# ---- TestMode (exact trace): oracle/cnf_grad_oracle.py::loss_and_grad_test against torch autograd -------------------
+def _torch_loss_test(cfg, flat, xs, ys, dts):
+    """-mean(logpx) of the TestMode solve replayed on the steps ``dts``: the Jacobian of every column is formed layer by layer
+    (J = D_L W_L ... D_1 W_1) and its trace taken -- plain differentiable tensor operations."""
+    net, n_in = cfg.net, cfg.n_in
+    Ws, bs, off = [], [], 0
+    for i, o in zip(net.dims[:-1], net.dims[1:]):
+        Ws.append(flat[off:off + i * o].reshape(i, o).T); off += i * o
+        bs.append(flat[off:off + o]); off += o
+    D1 = {O.ACT_IDENTITY: lambda a: torch.ones_like(a), O.ACT_TANH: lambda a: 1 - torch.tanh(a) ** 2,
+          O.ACT_SIGMOID: lambda a: torch.sigmoid(a) * (1 - torch.sigmoid(a)), O.ACT_SOFTPLUS: torch.sigmoid}
+
+    def f(u):
+        z = u[:n_in]
+        h = z if ys is None else torch.cat([z, ys], 0)
+        Bn = z.shape[1]
+        J = torch.eye(h.shape[0], n_in, dtype=u.dtype).expand(Bn, h.shape[0], n_in)
+        for W, b, k in zip(Ws, bs, net.acts):
+            a = W @ h + b[:, None]
+            J = D1[k](a).T[:, :, None] * (W[None] @ J)
+            h = ACT_T[k](a)
+        tr = torch.diagonal(J, dim1=1, dim2=2).sum(1)
+        return torch.cat([h, -tr[None, :]], 0)
+    B = xs.shape[1]
+    u = torch.cat([xs, torch.zeros(cfg.naugs + 1, B, dtype=xs.dtype)], 0)
+    tdir = 1.0 if cfg.tspan[1] >= cfg.tspan[0] else -1.0
+    for h in dts:
+        h = tdir * h
+        ks = []
+        for s in range(6):
+            acc = torch.zeros_like(u)
+            for j in range(s):
+                acc = acc + O.TSIT5_A[s][j] * ks[j]
+            ks.append(f(u + h * acc))
+        acc = torch.zeros_like(u)
+        for j in range(6):
+            acc = acc + O.TSIT5_B[j] * ks[j]
+        u = u + h * acc
+    z = u[:n_in]
+    logpx = -0.5 * (n_in * np.log(2 * np.pi) + (z * z).sum(0)) - u[n_in]
+    return (-logpx).mean()
+
+
+TEST_CASES = [
+    dict(dims=(4, 9, 4), acts=(O.ACT_TANH, O.ACT_TANH), nvars=2, naugs=2),
+    dict(dims=(5, 5), acts=(O.ACT_TANH,), nvars=3, naugs=2),                                 # the benchmark suite's one-layer form
+    dict(dims=(3, 8, 5, 3), acts=(O.ACT_TANH, O.ACT_SOFTPLUS, O.ACT_IDENTITY), nvars=3, naugs=0),
+    dict(dims=(5, 6, 3), acts=(O.ACT_SIGMOID, O.ACT_TANH), nvars=3, naugs=0, ncond=2),
+]
+
+
+@pytest.mark.parametrize("case", range(len(TEST_CASES)))
+def test_testmode_grad_matches_torch_autograd(case):
+    c = TEST_CASES[case]
+    cfg = O.Cfg(O.Net(c["dims"], c["acts"]), c["nvars"], c["naugs"], 1e-2, 1e-2, 1e-2, tspan=(0.0, 1.0))
+    rng = np.random.default_rng(200 + case)
+    B = 6
+    flat = O.glorot_params(cfg.net, rng, np.float64, 0.4)
+    flat[-cfg.n_in:] = 0.1 * rng.standard_normal(cfg.n_in)
+    xs = rng.standard_normal((cfg.nvars, B))
+    ys = rng.standard_normal((c["ncond"], B)) if c.get("ncond") else None
+    val, grad, st = G.loss_and_grad_test(cfg, flat, xs, ys, adaptive=True, reltol=1e-5, abstol=1e-7)
+    ft = torch.tensor(flat, requires_grad=True)
+    xt = torch.tensor(xs, requires_grad=True)
+    lt = _torch_loss_test(cfg, ft, xt, None if ys is None else torch.tensor(ys), st.dts)
+    lt.backward()
+    assert abs(val - float(lt)) <= 1e-12 * max(1.0, abs(val))
+    ref = ft.grad.numpy()
+    assert np.abs(grad - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), np.abs(grad - ref).max()
+    assert np.abs(st.grad_x - xt.grad.numpy()).max() <= 1e-10 * max(1.0, np.abs(xt.grad.numpy()).max())

@@ -1,7 +1,7 @@
 """In-kernel cycle stamps of k_solve_wave (needs a -DWV_STAMPS build loaded through CNFHIP_LIB): per step attempt, the
 cycles wave 0 spends in the six stage evaluations + error estimate, in the meeting, and in the controller.
 
-    CNFHIP_LIB=build_abl/lib_wvstamps.so python tools/wave_stamps.py [cfg]"""
+    CNFHIP_LIB=build_abl/lib_wvstamps.so python tools/wave_stamps.py [cfg ...]      (WV_BATCH=n: that batch instead of the config's)"""
 import os
 import sys
 
@@ -15,6 +15,9 @@ from continuousnf.jl_amd import configs
 
 for i in ([int(a) for a in sys.argv[1:]] or [1, 2]):
     wl = configs.BASELINE[i]
+    if os.environ.get("WV_BATCH"):
+        import dataclasses
+        wl = dataclasses.replace(wl, batch=int(os.environ["WV_BATCH"]))
     icnf = configs.build(wl, sol_kwargs=dict(adaptive=False, dt=(wl.tspan[1] - wl.tspan[0]) / 32))
     flat = configs.glorot_params(wl.dims, 1)
     xs_h, eps_h = configs.synthetic_inputs(wl, wl.batch, 1)
