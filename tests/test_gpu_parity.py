@@ -583,7 +583,12 @@ def test_call_matrix_of_the_reference(kernel):
                         buf = np.full((nvars, ndata), np.nan, np.float32)
                         assert cnf.rand_(d, buf) is buf and np.isfinite(buf).all()
                         assert np.isfinite(cnf.rand_(d, np.full(nvars, np.nan, np.float32))).all()
-                        if train:            # (the gradients are TrainMode's, the mode the reference trains in)
+                        if not train and not cond and not planar and kernel != "generic":
+                            # (TestMode gradients: the Dense chains of this matrix run on k_solve_wave<TEST, GRAD>)
+                            val, gps, gx = cnf.loss_and_grad(icnf, omode, r, flat, {}, with_x=True)
+                            assert np.isfinite(val) and np.isfinite(gps).all() and gps.shape == flat.shape
+                            assert gx.shape == r.shape and np.isfinite(gx).all()
+                        if train:            # (every model type: the mode the reference trains in)
                             val, gps, gx = cnf.loss_and_grad(icnf, omode, r, *args, with_x=True)
                             assert np.isfinite(val) and np.isfinite(gps).all() and gps.shape == flat.shape
                             assert gx.shape == r.shape and np.isfinite(gx).all()
