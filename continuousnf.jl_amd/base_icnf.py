@@ -688,6 +688,9 @@ def loss(icnf: ICNF, mode, xs, *args, eps=None):
     """TrainMode: mean(-logpx + l1 E + l2 n + l3 A) (src/icnf.jl:481-490); otherwise
     -mean(logpx) (src/base_icnf.jl:489-497).  Single process; the sharded form is
     ``parallel.distributed_loss``."""
+    if _is_torch(xs):                 # the five sums come out of the launch of the solve (cnf_inference_sums): no second kernel
+        _, _, sums = inference(icnf, mode, xs, *args, eps=eps, with_sums=True)
+        return loss_from_sums(icnf, mode, sums)
     logpx, (E, n, A) = inference(icnf, mode, xs, *args, eps=eps)
     sums = loss_sums(icnf, logpx, (E, n, A))
     return loss_from_sums(icnf, mode, sums)

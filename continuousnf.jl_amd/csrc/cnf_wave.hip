@@ -117,21 +117,26 @@ __device__ __forceinline__ float wv_quad_sum(float v) {
 // ID2: the second layer is the identity map appended by the caller to a ONE-layer network (`Dense(n => n, tanh)`, the
 // network of the reference's benchmark suite, benchmark/benchmarks.jl:29: W_2 = I, b_2 = 0, identity activation -- exact in
 // fp32: products with 1 and 0, sums with 0); its activation is compiled out and its gradient is not written.
-template <int NI, int NH, int MODE, bool TANH, bool GRAD = false, bool ID2 = false>
-__global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, const WvTab tab) {
+//
+// WGW = 4: the tiles of a batch of at most 64 samples (the reference's training batch of 32, its benchmark's 64 samples) as the
+// WAVES OF ONE WORKGROUP, one per SIMD: they meet through LDS and a workgroup barrier (~0.1 k cycles) instead of the tagged
+// words in memory (2.4-2.9 k cycles per attempt: 10-18 % of an attempt of these networks).
+template <int NI, int NH, int MODE, bool TANH, bool GRAD = false, bool ID2 = false, int WGW = 1>
+__global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args sv, const WvTab tab) {
     static_assert(!ID2 || TANH, "ID2 is instantiated for tanh first layers");
     static_assert(!GRAD || ((MODE == WV_VJP || MODE == WV_TEST) && TANH), "the in-launch adjoint is written for TrainMode / VJP and TestMode of tanh networks");
     constexpr bool GTEST = GRAD && MODE == WV_TEST;         // the adjoint of the exact-trace solve
     constexpr bool TRAIN = MODE != WV_TEST;
     constexpr int NS = TRAIN ? 3 : 1;                      // scalar rows of the state
-    const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wid = WGW > 1 ? (int)(threadIdx.x >> 6) : (int)blockIdx.x;      // this wave's tile
     const NetDesc& nd = a.nd;
     const int n_in = nd.n_in, nh = nd.dims[1], D = n_in + NS;
     const int act1 = nd.acts[0], act2 = nd.acts[1];
     constexpr bool fast = TANH;                            // exp2 / rcp form, sigma' = 1 - h^2
     const float* P = a.P;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    if (sv.t_out && blockIdx.x == 0 && lane == 0) sv.t_out[0] = __builtin_amdgcn_s_memrealtime();
+    if (sv.t_out && wid == 0 && lane == 0) sv.t_out[0] = __builtin_amdgcn_s_memrealtime();
 
     // ---- weights as A operands, in the k order the accumulator tiles present: lane (q, i), k-step j of input tile kt ->
     // M[16 m + i][16 kt + 4 q + j].  Straight from the flat vector (L2 hits after the first wave), once per solve. ----
@@ -163,7 +168,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                 if (GTEST) fCT[m][kt][j] = w1(k, o) * w2(o, k);                    // C^T[o][k] = C[k][o] = W1[k][o] W2[o][k]
             }
     // biases in the accumulator layout (rows 16 m + 4 q + j); conditional models: a row per sample instead of b1
-    const int smp = blockIdx.x * 16 + c;
+    const int smp = wid * 16 + c;
     const bool live = smp < a.B;
     const size_t sb = live ? (size_t)smp : 0;
     f32x4 b1v[NH], b2v[NI], rmask[NI];
@@ -314,23 +319,35 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
     };
 
     __shared__ float hsL[GRAD ? WV_GCAP : 1];                                           // step sizes of the accepted steps
-    __shared__ __attribute__((aligned(16))) float tbuf[GRAD ? 4 * (NI + NH) * 256 : 4];  // factor tiles, [sample][row]
+    __shared__ __attribute__((aligned(16))) float tbuf_all[GRAD ? WGW * 4 * (NI + NH) * 256 : 4];   // factor tiles, [sample][row], per wave
+    float* const tbuf = tbuf_all + (GRAD && WGW > 1 ? (threadIdx.x >> 6) * (4 * (NI + NH) * 256) : 0);
+    __shared__ float mw[2][WGW][2];                        // WGW > 1: the waves' meeting words
     bool gover = false;                                    // more accepted steps than the trajectory store holds
     // ---- integrator state: every lane carries the same copy and runs the same controller on the same sums ----
     StepState ns = sv.init;
     float hstep = ns.h, abstol = ns.abstol, reltol = ns.reltol;
     int nsync = 0;
     const unsigned mbase = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sv.base_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const int G = gridDim.x;
+    const int G = WGW > 1 ? (int)(blockDim.x >> 6) : (int)gridDim.x;
     float p0 = 0.f, p1 = 0.f;
     // The waves' partials (e, b) -> the sums over all of them in p0, p1 (the same order in every wave).  false: a wait ran out.
     auto meet = [&](float e_lane, float b_lane) -> bool {
         const float e = wv_wave_sum(e_lane), b = wv_wave_sum(b_lane);
+        if constexpr (WGW > 1) {                           // the waves of one workgroup: LDS words (two sets by parity) and a barrier
+            const int par = nsync & 1;
+            if (lane == 0) { mw[par][wid][0] = e; mw[par][wid][1] = b; }
+            __syncthreads();
+            float c0 = 0.f, c1 = 0.f;
+            for (int w = 0; w < G; ++w) { c0 += mw[par][w][0]; c1 += mw[par][w][1]; }
+            p0 = c0; p1 = c1;
+            ++nsync;
+            return true;
+        }
         unsigned long long* pb = reinterpret_cast<unsigned long long*>(sv.part) + (nsync & 1) * 1024;
         const unsigned tag = mbase + (unsigned)nsync + 1u;
         if (lane == 0) {
-            __hip_atomic_store(pb + 2 * blockIdx.x, ((unsigned long long)tag << 32) | __float_as_uint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pb + 2 * blockIdx.x + 1, ((unsigned long long)tag << 32) | __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pb + 2 * wid, ((unsigned long long)tag << 32) | __float_as_uint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pb + 2 * wid + 1, ((unsigned long long)tag << 32) | __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // lane i takes the words of waves i, i + 64, ... (at most 8): ALL of them requested at once per poll round -- one round
         // trip per round whatever the grid (taken one after the other they cost a round trip each: 8.5 k cycles per meeting
@@ -432,7 +449,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
         // attempt's are overwritten by the next one), each lane its own registers
         f32x4* tjs = nullptr;
         if (GRAD && ns.naccept < a.g.traj_cap) {
-            tjs = reinterpret_cast<f32x4*>(a.g.traj) + ((size_t)ns.naccept * 6 * G + blockIdx.x) * (64 * NI) + lane * NI;
+            tjs = reinterpret_cast<f32x4*>(a.g.traj) + ((size_t)ns.naccept * 6 * G + wid) * (64 * NI) + lane * NI;
 #pragma unroll
             for (int m = 0; m < NI; ++m) tjs[m] = uz[m];
         }
@@ -505,7 +522,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
         const float t_att = ns.t, h_att = ns.h;
         ctrl_after_step(&ns, p0, p1, a.n_total);
         const bool accepted = __builtin_amdgcn_readfirstlane(ns.naccept != acc0);
-        if (sv.trace && blockIdx.x == 0 && lane == 0 && it < sv.trace_cap) {
+        if (sv.trace && wid == 0 && lane == 0 && it < sv.trace_cap) {
             float* tr = sv.trace + 4 * it;
             tr[0] = t_att; tr[1] = h_att; tr[2] = ns.eest; tr[3] = accepted ? 1.f : 0.f;
 #ifdef WV_STAMPS
@@ -516,7 +533,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
         if (GRAD && accepted) {                            // h_n of this step (its stage states were filed by the attempt)
             if (acc0 < a.g.traj_cap && acc0 < WV_GCAP) {
                 hsL[acc0] = h_att;
-                if (blockIdx.x == 0 && lane == 0) a.g.hs_out[acc0] = h_att;
+                if (wid == 0 && lane == 0) a.g.hs_out[acc0] = h_att;
             } else gover = true;
         }
         if (accepted) {                                    // u <- u_new, k1 <- k7
@@ -567,9 +584,9 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
 #pragma unroll
             for (int j = 0; j < 4; ++j) v4[j] = wv_wave_sum(v4[j]);
             if (lane < 4)
-                __hip_atomic_store(qb + 4 * blockIdx.x + lane, ((unsigned long long)tag << 32) | __float_as_uint(lane == 0 ? v4[0] : lane == 1 ? v4[1] : lane == 2 ? v4[2] : v4[3]),
+                __hip_atomic_store(qb + 4 * wid + lane, ((unsigned long long)tag << 32) | __float_as_uint(lane == 0 ? v4[0] : lane == 1 ? v4[1] : lane == 2 ? v4[2] : v4[3]),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (blockIdx.x == 0) {                         // wave 0 adds the waves' partials in wave order
+            if (wid == 0) {                         // wave 0 adds the waves' partials in wave order
                 float c4[4] = {0.f, 0.f, 0.f, 0.f};
                 float late = 0.f;
                 const unsigned long long wait0 = __builtin_amdgcn_s_memrealtime();
@@ -664,13 +681,20 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                 return r;
             };
             const int nacc = __builtin_amdgcn_readfirstlane(ns.naccept);
-            const f32x4* tj0 = reinterpret_cast<const f32x4*>(a.g.traj) + (size_t)blockIdx.x * (64 * NI) + lane * NI;
+            const f32x4* tj0 = reinterpret_cast<const f32x4*>(a.g.traj) + (size_t)wid * (64 * NI) + lane * NI;
             const size_t tstage = (size_t)G * (64 * NI), tstep = 6 * tstage;
             f32x4 U_next[6][NI];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int m = 0; m < NI; ++m) U_next[i][m] = nacc > 0 ? tj0[(size_t)(nacc - 1) * tstep + i * tstage + m] : zero4;
+            // between the writes and the reads of the wave's OWN transposition buffer: a one-wave workgroup's barrier; with
+            // several waves per workgroup nothing but this wave's LDS traffic in order (its DS instructions execute in issue
+            // order) -- a workgroup barrier here would tie the waves' backward passes together for nothing
+            auto tsync = [&]() __attribute__((always_inline)) {
+                if constexpr (WGW == 1) __syncthreads();
+                else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
+            };
             auto tput = [&](int slot, const f32x4& v) __attribute__((always_inline)) {
                 reinterpret_cast<f32x4*>(tbuf + slot * 256)[c * 4 + q] = v;
             };
@@ -857,7 +881,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                         tput(4 * NI + m, h1[m]); tput(4 * NI + NH + m, t1[m]); tput(4 * NI + 2 * NH + m, ab1[m]); tput(4 * NI + 3 * NH + m, pb1[m]);
                         gb1[m] += ab1[m];
                     }
-                    __syncthreads();
+                    tsync();
                     {
                         float A2[NI][4], P2[NI][4], Z0[NI][4], T0[NI][4];
 #pragma unroll
@@ -885,7 +909,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                             }
                         }
                     }
-                    __syncthreads();
+                    tsync();
                 }
                 // lambda <- lambda + sum_i w_i
 #pragma unroll
@@ -905,11 +929,11 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
 #pragma unroll
                     for (int m = 0; m < NI; ++m) {
                         tput(0, gH[k][m]);
-                        __syncthreads();
+                        tsync();
                         float Ht[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) Ht[j] = tbuf[(4 * q + j) * 16 + c];     // H[16 k + c][16 m + 4 q + j]
-                        __syncthreads();
+                        tsync();
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             gW1[k][m][j] -= gH[k][m][j] * w2(16 * m + c, 16 * k + 4 * q + j);
@@ -917,7 +941,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                         }
                     }
             }
-            float* gp = a.g.gpart + (size_t)blockIdx.x * a.g.n_params;
+            float* gp = a.g.gpart + (size_t)wid * a.g.n_params;
 #pragma unroll
             for (int m = 0; m < NI; ++m)
 #pragma unroll
@@ -959,7 +983,7 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
                 }
         }
     }
-    if (blockIdx.x == 0 && lane == 0) {
+    if (wid == 0 && lane == 0) {
         if (GRAD && gover) { ns.done = 0; ns.n_partials = -1; }       // (the caller runs the streamed gradient path)
         if (!alive || __hip_atomic_load(sv.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ns.done = 0; ns.n_partials = -1; }
         __hip_atomic_store(sv.base_dev, mbase + (unsigned)nsync + 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -971,6 +995,23 @@ __global__ void __launch_bounds__(64) k_solve_wave(WaveArgs a, Solve3Args sv, co
 }
 
 typedef void (*wave_fn)(WaveArgs, Solve3Args, const WvTab);
+// one workgroup of up to four waves (B <= 64): the README / regression networks and the one-layer benchmark network, TrainMode
+// (VJP) and TestMode, plain solve and gradient
+wave_fn pick_wg(int ni, int nh, int mode, bool grad, bool id2, bool tanh2) {
+    if (ni != 1 || mode == WV_JVP || !(tanh2 || id2)) return nullptr;
+    const bool t = mode == WV_TEST;
+    if (id2)
+        return nh != 1 ? nullptr
+             : grad ? (t ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, true, true, 4> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true, true, 4>)
+                    : (t ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, false, true, 4> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, false, true, 4>);
+    if (nh == 1)
+        return grad ? (t ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, true, false, 4> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true, false, 4>)
+                    : (t ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, false, false, 4> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, false, false, 4>);
+    if (nh == 3)
+        return grad ? (t ? (wave_fn)k_solve_wave<1, 3, WV_TEST, true, true, false, 4> : (wave_fn)k_solve_wave<1, 3, WV_VJP, true, true, false, 4>)
+                    : (t ? (wave_fn)k_solve_wave<1, 3, WV_TEST, true, false, false, 4> : (wave_fn)k_solve_wave<1, 3, WV_VJP, true, false, false, 4>);
+    return nullptr;
+}
 wave_fn pick_grad(int ni, int nh, bool id2, bool test = false) {
     if (ni != 1) return nullptr;
     if (id2) return nh != 1 ? nullptr : test ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, true, true> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true, true>;
@@ -1045,10 +1086,15 @@ cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_param
     static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); const char* w = getenv("CNF_WAVE"); return (e && e[0] == '0') || (w && w[0] == '0'); }();
     if (off) return CNF_ERR_UNSUPPORTED;
     const int ni = (nd.n_in + 15) / 16, nh = (nd.dims[1] + 15) / 16;
-    const int grid = (B + 15) / 16;
+    int grid = (B + 15) / 16;
     const int mode = !train ? WV_TEST : (nd.jvp ? WV_JVP : WV_VJP);
     wave_fn fn = grad ? pick_grad(ni, nh, is_id2(nd), !train) : pick_shape(ni, nh, mode, nd.acts[0] == 1 && nd.acts[1] == 1, is_id2(nd));
     if (!fn || grid > 512) return CNF_ERR_UNSUPPORTED;
+    // at most four tiles: the waves of ONE workgroup (they meet through LDS), where that form is instantiated
+    static const bool wg_off = [] { const char* e = getenv("CNF_WAVE_WG"); return e && e[0] == '0'; }();
+    wave_fn wfn = (grid <= 4 && !wg_off && !cond) ? pick_wg(ni, nh, mode, grad != nullptr, is_id2(nd), nd.acts[0] == 1 && nd.acts[1] == 1) : nullptr;
+    const int waves = grid;
+    if (wfn) { fn = wfn; grid = 1; }
     WaveArgs a{};
     a.nd = nd; a.P = d_params; a.eps = eps; a.cond = cond; a.cbs = cbs; a.B = B;
     a.n_total = (float)((size_t)(nd.n_in + (train ? 3 : 1)) * B);
@@ -1060,7 +1106,7 @@ cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_param
     if (!sv.xs && !sv.u0) return CNF_ERR_BAD_ARG;
     WvTab tab = kWvTab;
     void* args[] = {&a, &sv, &tab};
-    if (hipLaunchKernel((const void*)fn, dim3(grid), dim3(64), args, 0, s) != hipSuccess) {
+    if (hipLaunchKernel((const void*)fn, dim3(grid), dim3(wfn ? 64 * waves : 64), args, 0, s) != hipSuccess) {
         (void)hipGetLastError();
         return CNF_ERR_UNSUPPORTED;
     }
