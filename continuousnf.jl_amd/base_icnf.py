@@ -769,14 +769,14 @@ def _loss_and_grad_test(icnf: ICNF, mode, xs, *args, with_x=False):
     l, h = _lib.lib(), icnf.handle()
     n_params = icnf.nn.n_params_internal
     if xb.torch is not None:
-        xd, stream = xb.arr, _stream(xb)
-        dev = xb.arr.device
-    else:                                                  # host data: staged here (the ABI entry takes device pointers)
+        dev, stream = xb.arr.device, _stream(xb)
+        grad = torch.empty(n_params, dtype=torch.float32, device=dev)
+        rc = l.cnf_loss_grad_test(h, xb.ptr, B, C.byref(opts), C.byref(val), grad.data_ptr(), C.byref(stats), stream)
+    else:                                                  # host arrays in, host gradient out
         dev = torch.device("cuda", icnf.device)
-        xd = torch.from_numpy(np.ascontiguousarray(xb.arr)).to(dev)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    grad = torch.empty(n_params, dtype=torch.float32, device=dev)
-    rc = l.cnf_loss_grad_test(h, xd.data_ptr(), B, C.byref(opts), C.byref(val), grad.data_ptr(), C.byref(stats), stream)
+        grad = np.empty(n_params, dtype=np.float32)
+        rc = l.cnf_loss_grad_test_host(h, xb.ptr, B, C.byref(opts), C.byref(val), grad.ctypes.data, C.byref(stats))
     if rc == _lib.ERR_UNSUPPORTED:
         raise NotImplementedError("TestMode gradients are implemented for small two-layer tanh networks (k_solve_wave); "
                                   "the reference trains in TrainMode")
@@ -791,9 +791,8 @@ def _loss_and_grad_test(icnf: ICNF, mode, xs, *args, with_x=False):
         gx = torch.empty(B * icnf.nvars, dtype=torch.float32, device=dev)
         _lib.check(l.cnf_grad_x(h, gx.data_ptr(), B, stream), h)
         gx = gx.view(B, icnf.nvars).t()
-    if xb.torch is None:
-        grad = grad.cpu().numpy()
-        gx = gx.cpu().numpy() if gx is not None else None
+    if xb.torch is None and gx is not None:
+        gx = gx.cpu().numpy()
     grad = icnf.nn.grad_to_external(grad)
     return (float(val.value), grad, gx) if with_x else (float(val.value), grad)
 

@@ -1787,6 +1787,22 @@ extern "C" cnf_status cnf_loss_grad_test(cnf_handle h, const float* xs, int B, c
     return CNF_OK;
 }
 
+extern "C" cnf_status cnf_loss_grad_test_host(cnf_handle h, const float* xs, int B, const cnf_solve_opts* opts, float* loss_out,
+                                              float* grad, cnf_solve_stats* stats) {
+    cnf_status s = check_call(h, CNF_MODE_TEST, B);
+    if (s != CNF_OK) return s;
+    if (!xs || !grad) return fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    if (B < 1) return fail(h, CNF_ERR_BAD_SHAPE, "the loss is a mean over the batch: B must be >= 1");
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((s = ensure_grad_capacity(h, B)) != CNF_OK) return s;
+    const size_t nx = (size_t)h->nd.nvars * B;
+    if ((s = ensure_stage(h, nx)) != CNF_OK) return s;
+    HIPCHK(h, hipMemcpy(h->stage, xs, nx * sizeof(float), hipMemcpyHostToDevice));
+    if ((s = cnf_loss_grad_test(h, h->stage, B, opts, loss_out, h->g_grad, stats, nullptr)) != CNF_OK) return s;
+    HIPCHK(h, hipMemcpy(grad, h->g_grad, h->n_params * sizeof(float), hipMemcpyDeviceToHost));
+    return CNF_OK;
+}
+
 // d loss / d xs of the last cnf_loss_grad call: the adjoint state at t0 is d loss / d u(t0), and u0 = (xs; zeros) -- its first
 // nvars rows, [B][nvars] as xs is laid out.  (The backward sweep leaves it in g_lam; nothing is recomputed.)
 extern "C" cnf_status cnf_grad_x(cnf_handle h, float* gx, int B, void* stream) {

@@ -268,6 +268,8 @@ cnf_status cnf_loss_grad_host(cnf_handle h, const float* xs, const float* eps, i
  * trace) or one, n_in <= 16, <= 64 hidden units, unconditional, B <= 2048 --, CNF_ERR_UNSUPPORTED otherwise. */
 cnf_status cnf_loss_grad_test(cnf_handle h, const float* xs, int B, const cnf_solve_opts* opts, float* loss_out,
                               float* grad, cnf_solve_stats* stats, void* stream);
+cnf_status cnf_loss_grad_test_host(cnf_handle h, const float* xs, int B, const cnf_solve_opts* opts, float* loss_out,
+                                   float* grad, cnf_solve_stats* stats);      /* xs and grad in HOST memory */
 /* The signed sizes of the steps the last cnf_loss_grad on this handle accepted (the discrete map
  * it differentiated): writes min(n, cap) floats to hs (may be NULL) and returns n. */
 int cnf_grad_steps(cnf_handle h, float* hs, int cap);
