@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=8192, help="columns per GPU")
     ap.add_argument("--fixed-dt", type=float, default=0.0, help="use fixed steps instead of adaptive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-suite", action="store_true", help="skip the reference's own benchmark suite (a second of small calls after the timed region)")
     ap.add_argument("--no-pmc", action="store_true", help="do not start the rocprofv3 child passes that measure roofline.traffic")
     ap.add_argument("--prewarm", type=float, default=0.4,
                     help="seconds of untimed solves before the W counted warm-up steps: holds the clocks (DVFS) so that a short "
@@ -185,6 +186,39 @@ def measure_traffic_live(kernel_substr, timeout_s=150):
     return 2.0 * vals["FETCH_SIZE"][0] * 1024.0 + vals["WRITE_SIZE"][0] * 1024.0, min(vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1])
 
 
+def reference_suite(samples=100):
+    """The four benchmarks of the reference's OWN suite (benchmark/benchmarks.jl:24-99: RNODE 8 + 8, Chain(Dense(16 => 16, tanh)),
+    64 samples, tspan (0, 13), steer 0.1, lambda3 1e-2; loss in Train / TestMode and the gradient of each w.r.t. ps), outside
+    the timed region, median microseconds per call (tools/reference_benchmarks.py prints the full table with the CPU
+    restatement beside it).  The reference stores no results for this suite, so there is nothing to divide by."""
+    import time
+    import numpy as np
+    import torch
+    import continuousnf.jl_amd as cnf
+    from continuousnf.jl_amd import layers
+    nn = cnf.Chain(cnf.Dense(16, 16, "tanh"))
+    ic = cnf.construct(cnf.RNODE, nn, 8, 8, compute_mode=cnf.HIPVecJacMatrixMode(), tspan=(0.0, 13.0), steer_rate=0.1, lambda3=1e-2, rng=1)
+    ps, st = layers.setup(ic.rng, nn, init="lux_v1")
+    dr = torch.from_numpy(np.random.default_rng(1).random((8, 64)).astype(np.float32)).cuda()
+    rows = {"direct/train": lambda: cnf.loss(ic, cnf.TrainMode(), dr, ps, st), "direct/test": lambda: cnf.loss(ic, cnf.TestMode(), dr, ps, st),
+            "AD-1-order/train": lambda: cnf.loss_and_grad(ic, cnf.TrainMode(), dr, ps, st),
+            "AD-1-order/test": lambda: cnf.loss_and_grad(ic, cnf.TestMode(), dr, ps, st)}
+    res = {"suite": "benchmark/benchmarks.jl:24-99", "unit": "us per call (median)", "samples": samples}
+    try:
+        for name, fn in rows.items():
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(samples):
+                t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(1e6 * (time.perf_counter() - t0))
+            res[name] = {"median_us": float(np.median(ts)), "launches": int(ic.last_stats["launches"]), "nf": int(ic.last_stats["nf"])}
+    except Exception as e:            # (the headline line must not depend on this leg)
+        res["error"] = repr(e)
+    ic.close()
+    return res
+
+
 def fp32_child_leg(args):
     """The headline steps on the fp32-MFMA kernels (CNF_STEP_FP32=1: k_step3, streamed step launches), in a child process
     started after the timed region.  Returns the child's figures, with the fp32 roofline fraction they amount to."""
@@ -193,7 +227,7 @@ def fp32_child_leg(args):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--fp32-child", "--steps", str(max(10, min(args.steps, 50))), "--warmup", "3",
-           "--batch", str(args.batch), "--depth", "1", "--no-pmc", "--no-cpu-baseline", "--kernel", args.kernel]
+           "--batch", str(args.batch), "--depth", "1", "--no-pmc", "--no-cpu-baseline", "--no-reference-suite", "--kernel", args.kernel]
     if args.fixed_dt > 0:
         cmd += ["--fixed-dt", str(args.fixed_dt)]
     try:
@@ -524,6 +558,8 @@ def run_rank(args):
             out["nf_gpu_vs_cpu"] = {"gpu": st["nf"], "cpu": out["cpu_baseline"].get("nf_per_solve"),
                                     "note": "same workload and tolerances; the error estimate is at round-off level here, so the "
                                             "step count differs by an attempt between arithmetics (profiles/round3_step_trace.md)"}
+        if world == 1 and not args.no_reference_suite:
+            out["reference_suite"] = reference_suite()
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
