@@ -1615,8 +1615,12 @@ static cnf_status wave_loss_grad(cnf_handle h, int mode, const float* xs, const 
     {
         const size_t per_step = wave_grad_traj_floats(h->nd_wave, B);
         int cap = WV_GCAP;
-        while (cap > 64 && per_step * cap > ((size_t)1 << 26)) cap /= 2;       // <= 256 MiB of trajectory
-        const size_t need = per_step * cap + WV_GCAP;
+        while (cap > 64 && per_step * cap > ((size_t)1 << 28)) cap /= 2;       // <= 1 GiB of trajectory (B = 8192: 256 steps)
+        // behind the trajectory: the step sizes, and one partial of the flat gradient per wave when there are more waves than
+        // the arena's GRAD_MAX_KSPLIT partials
+        const int waves = wave_grad_waves(B);
+        const size_t part_f = waves > GRAD_MAX_KSPLIT ? (size_t)waves * h->n_params : 0;
+        const size_t need = per_step * cap + WV_GCAP + part_f;
         if (need > h->wg_traj_floats) {
             HIPCHK(h, hipDeviceSynchronize());
             if (h->wg_traj) { (void)hipFree(h->wg_traj); h->wg_traj = nullptr; h->wg_traj_floats = 0; }
@@ -1625,7 +1629,8 @@ static cnf_status wave_loss_grad(cnf_handle h, int mode, const float* xs, const 
         }
         WaveGradArgs wg;
         wg.traj = h->wg_traj; wg.traj_cap = cap; wg.hs_out = h->wg_traj + per_step * cap;
-        wg.gpart = h->g_part; wg.lam_out = h->g_lam; wg.n_params = (int)h->n_params;
+        wg.gpart = part_f ? h->wg_traj + per_step * cap + WV_GCAP : h->g_part;
+        wg.lam_out = h->g_lam; wg.n_params = (int)h->n_params;
         wg.lam1 = h->lam[0]; wg.lam2 = h->lam[1]; wg.lam3 = h->lam[2];
         Recorder rec;
         rec.wg = &wg;
@@ -1633,7 +1638,7 @@ static cnf_status wave_loss_grad(cnf_handle h, int mode, const float* xs, const 
         PostHook ph{h->tmp_logpx, h->tmp_regs, h->d_sums, xs};
         if ((s = solve_core(h, mode, h->U[0], eps, nullptr, B, opts, &sst, stream, &rec, false, &ph)) != CNF_OK) return s;
         if (rec.wg_done) {
-            HIPCHK(h, launch_grad_reduce(h->g_part, grad, (int)h->n_params, wave_grad_waves(B), st));
+            HIPCHK(h, launch_grad_reduce(wg.gpart, grad, (int)h->n_params, waves, st));
             float* sums = reinterpret_cast<float*>(&h->h_state[2]);
             HIPCHK(h, hipMemcpyAsync(sums, h->d_sums, 5 * sizeof(float), hipMemcpyDeviceToHost, st));
             HIPCHK(h, hipStreamSynchronize(st));
@@ -1771,7 +1776,7 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
 // parameters through the exact-trace solve -- what the reference's call tests and its benchmark suite differentiate besides
 // the TrainMode loss (test/call_tests.jl `diff_loss` with omode = TestMode(); benchmark/benchmarks.jl:60-99 "AD-1-order" /
 // "test").  Implemented for the networks k_solve_wave<GRAD> takes (two tanh layers or one, n_in <= 16, <= 64 hidden units,
-// unconditional, B <= 2048); CNF_ERR_UNSUPPORTED otherwise.
+// unconditional, B <= 8192); CNF_ERR_UNSUPPORTED otherwise.
 extern "C" cnf_status cnf_loss_grad_test(cnf_handle h, const float* xs, int B, const cnf_solve_opts* opts, float* loss_out,
                                          float* grad, cnf_solve_stats* stats, void* stream) {
     const int mode = CNF_MODE_TEST;

@@ -18,7 +18,7 @@ struct WaveGradArgs {
 // floats of trajectory store per accepted step, waves of a launch
 size_t wave_grad_traj_floats(const NetDesc& nd, int B);
 int wave_grad_waves(int B);
-// two tanh layers (or one + the appended identity), n_in <= 16, no conditioning, at most GRAD_MAX_KSPLIT waves; TrainMode:
+// two tanh layers (or one + the appended identity), n_in <= 16, no conditioning, at most 512 waves (B <= 8192); TrainMode:
 // the VJP compute mode; TestMode: the adjoint of the exact-trace solve (closed form of two-layer networks)
 bool wave_grad_supported(const NetDesc& nd, int B, bool train = true);
 

@@ -1074,7 +1074,7 @@ bool wave_grad_supported(const NetDesc& nd, int B, bool train) {
     static const bool off = [] { const char* e = getenv("CNF_WAVE_GRAD"); return e && e[0] == '0'; }();
     if (off || !wave_solve_supported(nd, train, B)) return false;
     if ((train && nd.jvp) || nd.n_cond > 0 || nd.acts[0] != 1 || !(nd.acts[1] == 1 || is_id2(nd))) return false;
-    return pick_grad((nd.n_in + 15) / 16, (nd.dims[1] + 15) / 16, is_id2(nd)) != nullptr && wave_grad_waves(B) <= 128;
+    return pick_grad((nd.n_in + 15) / 16, (nd.dims[1] + 15) / 16, is_id2(nd)) != nullptr && wave_grad_waves(B) <= 512;
 }
 
 cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_params, const float* cond, int cbs, StepState* st_out,

@@ -1312,6 +1312,7 @@ def test_loss_grad_wave_local_small_networks(monkeypatch):
         (O.Cfg(O.Net((16, 64, 16), (O.ACT_TANH,) * 2), 10, 6, 0.0, 1e-2, 5e-2), 300, dict(adaptive=False, dt=1 / 5), dict(adaptive=False, dt=1 / 5)),
         (O.Cfg(O.Net((7, 13, 7), (O.ACT_TANH,) * 2), 4, 3, 1e-2, 1e-2, 1e-2, tspan=(1.0, 0.0)), 1, dict(adaptive=False, dt=1 / 4), dict(adaptive=False, dt=1 / 4)),
         (O.Cfg(O.Net((16, 32, 16), (O.ACT_TANH,) * 2), 16, 0, 0.0, 0.0, 0.0), 2048, "replay", dict()),                      # FFJORD, 128 waves
+        (O.Cfg(O.Net((16, 48, 16), (O.ACT_TANH,) * 2), 8, 8, 1e-2, 1e-2, 1e-2), 4099, "replay", dict()),                    # config 2's batch + 3: 257 waves, their own partials
     ]
     for ci, (cfg, B, ora_kw, sol_kw) in enumerate(cases):
         val, grad, rval, rgrad, st, ost = _grad_case(cfg, B, 900 + ci, "mfma", dict(sol_kw), ora_kw, scale=0.5)

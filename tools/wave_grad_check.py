@@ -16,6 +16,7 @@ cases = [
     (O.Cfg(O.Net((2, 6, 2), T2), 1, 1, 1e-2, 1e-2, 1e-2, tspan=(0.0, 13.0)), 32, dict()),
     (O.Cfg(O.Net((16, 64, 16), T2), 10, 6, 0.0, 1e-2, 5e-2), 300, dict()),
     (O.Cfg(O.Net((16, 32, 16), T2), 16, 0, 0.0, 0.0, 0.0), 2048, dict()),
+    (O.Cfg(O.Net((16, 48, 16), T2), 8, 8, 1e-2, 1e-2, 1e-2), 4096, dict()),                  # BASELINE config 2's batch
 ]
 for ci, (cfg, B, sol_kw) in enumerate(cases):
     rng = np.random.default_rng(900 + ci)
