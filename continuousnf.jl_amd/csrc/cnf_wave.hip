@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
         }
     }
     if constexpr (GRAD) {
-        if (alive && !gover && __builtin_amdgcn_readfirstlane(ns.done)) {
+        if (alive && !gover && __builtin_amdgcn_readfirstlane(ns.done) && !__builtin_amdgcn_readfirstlane(ns.nonfinite)) {
             // ================= backward: discrete adjoint of the accepted steps (oracle/cnf_grad_oracle.py) =================
             const float invB = 1.0f / (float)a.B;
             const float cl0 = invB, cE0 = a.g.lam1 * invB, cn0 = a.g.lam2 * invB;   // cotangents of the scalar rows: constants
