@@ -758,11 +758,10 @@ def _loss_and_grad_test(icnf: ICNF, mode, xs, *args, with_x=False):
     benchmark/benchmarks.jl:60-99).  Small two-layer (or one-layer) tanh networks; ``NotImplementedError`` otherwise."""
     import torch
     ys, ps, st = _split_cond_args(icnf, args)
-    if ys is not None:
-        raise NotImplementedError("TestMode gradients: unconditional models")
     xb = _as_colmajor(xs, icnf.nvars, "xs")
     B = xb.B
     icnf.set_params(ps)
+    icnf.set_cond(ys, B)
     opts = _solve_opts(icnf, steer_tspan(icnf, mode))
     stats = _lib.cnf_solve_stats()
     val = C.c_float()

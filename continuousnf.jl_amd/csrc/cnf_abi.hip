@@ -1631,6 +1631,7 @@ static cnf_status wave_loss_grad(cnf_handle h, int mode, const float* xs, const 
         wg.traj = h->wg_traj; wg.traj_cap = cap; wg.hs_out = h->wg_traj + per_step * cap;
         wg.gpart = part_f ? h->wg_traj + per_step * cap + WV_GCAP : h->g_part;
         wg.lam_out = h->g_lam; wg.n_params = (int)h->n_params;
+        wg.ys = h->nd.n_cond > 0 ? h->d_ys : nullptr;
         wg.lam1 = h->lam[0]; wg.lam2 = h->lam[1]; wg.lam3 = h->lam[2];
         Recorder rec;
         rec.wg = &wg;
@@ -1776,7 +1777,7 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
 // parameters through the exact-trace solve -- what the reference's call tests and its benchmark suite differentiate besides
 // the TrainMode loss (test/call_tests.jl `diff_loss` with omode = TestMode(); benchmark/benchmarks.jl:60-99 "AD-1-order" /
 // "test").  Implemented for the networks k_solve_wave<GRAD> takes (two tanh layers or one, n_in <= 16, <= 64 hidden units,
-// unconditional, B <= 8192); CNF_ERR_UNSUPPORTED otherwise.
+// n_in + n_cond <= 16, B <= 8192); CNF_ERR_UNSUPPORTED otherwise.
 extern "C" cnf_status cnf_loss_grad_test(cnf_handle h, const float* xs, int B, const cnf_solve_opts* opts, float* loss_out,
                                          float* grad, cnf_solve_stats* stats, void* stream) {
     const int mode = CNF_MODE_TEST;

@@ -12,13 +12,15 @@ struct WaveGradArgs {
     float* hs_out = nullptr;           // [traj_cap] signed step sizes (the host's copy: cnf_grad_steps)
     float* gpart = nullptr;            // [waves][n_params]
     float* lam_out = nullptr;          // [B][n_in]  d loss / d z(t0)   (cnf_grad_x)
+    const float* ys = nullptr;         // conditional models: [B][n_cond] (the columns of W_1 behind z get their gradient from them)
     int n_params = 0;
     float lam1 = 0.f, lam2 = 0.f, lam3 = 0.f;
 };
 // floats of trajectory store per accepted step, waves of a launch
 size_t wave_grad_traj_floats(const NetDesc& nd, int B);
 int wave_grad_waves(int B);
-// two tanh layers (or one + the appended identity), n_in <= 16, no conditioning, at most 512 waves (B <= 8192); TrainMode:
+// two tanh layers (or one + the appended identity), n_in (+ n_cond of a conditional model) <= 16, at most 512 waves
+// (B <= 8192); TrainMode:
 // the VJP compute mode; TestMode: the adjoint of the exact-trace solve (closed form of two-layer networks)
 bool wave_grad_supported(const NetDesc& nd, int B, bool train = true);
 

@@ -680,6 +680,16 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                 for (int j = 0; j < 4; ++j) r[j] = (ID2 && second) ? 0.f : -2.0f * h[j] * d[j];
                 return r;
             };
+            // conditional models: the conditioning inputs ys sit behind z in the first layer's input (h_0 = [z; ys], src/base_icnf.jl:
+            // 288-309); they enter the backward pass only as rows n_in .. n_in + n_cond - 1 of the operand Wbar_1 is contracted with
+            f32x4 ysv[NI];
+#pragma unroll
+            for (int m = 0; m < NI; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 16 * m + 4 * q + j;
+                    ysv[m][j] = (a.g.ys && live && r >= n_in && r < n_in + nd.n_cond) ? a.g.ys[sb * nd.n_cond + (r - n_in)] : 0.f;
+                }
             const int nacc = __builtin_amdgcn_readfirstlane(ns.naccept);
             const f32x4* tj0 = reinterpret_cast<const f32x4*>(a.g.traj) + (size_t)wid * (64 * NI) + lane * NI;
             const size_t tstage = (size_t)G * (64 * NI), tstep = 6 * tstage;
@@ -875,7 +885,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                     // ---- weight gradient: Wbar_l += abar_l h_{l-1}' + pbar_l t_{l-1}' over the wave's 16 samples; bbar_l += abar_l ----
                     // slots: [0, NI) abar_2 | [NI, 2NI) pbar_2 | [2NI, 3NI) z | [3NI, 4NI) tau | then NH each: h_1, t_1, abar_1, pbar_1
 #pragma unroll
-                    for (int m = 0; m < NI; ++m) { tput(m, ab2[m]); tput(NI + m, pb2[m]); tput(2 * NI + m, z[m]); tput(3 * NI + m, tau[m]); gb2[m] += ab2[m]; }
+                    for (int m = 0; m < NI; ++m) { tput(m, ab2[m]); tput(NI + m, pb2[m]); tput(2 * NI + m, z[m] + ysv[m]); tput(3 * NI + m, tau[m]); gb2[m] += ab2[m]; }
 #pragma unroll
                     for (int m = 0; m < NH; ++m) {
                         tput(4 * NI + m, h1[m]); tput(4 * NI + NH + m, t1[m]); tput(4 * NI + 2 * NH + m, ab1[m]); tput(4 * NI + 3 * NH + m, pb1[m]);
@@ -954,7 +964,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                         }
                         {   // Wbar_1[o][kk]: row o = 16 k + 4 q + j, column kk = 16 m + c
                             const int o = 16 * k + 4 * q + j, kk = 16 * m + c;
-                            if (o < nh && kk < n_in) gp[nd.w_off[0] + o + (size_t)kk * nh] = gW1[k][m][j];
+                            if (o < nh && kk < n_in + nd.n_cond) gp[nd.w_off[0] + o + (size_t)kk * nh] = gW1[k][m][j];
                         }
                     }
             // bias gradients: the sum over the 16 samples of a lane group's rows (DPP row reduction, fixed order)
@@ -1073,7 +1083,8 @@ size_t wave_grad_traj_floats(const NetDesc& nd, int B) { return (size_t)6 * wave
 bool wave_grad_supported(const NetDesc& nd, int B, bool train) {
     static const bool off = [] { const char* e = getenv("CNF_WAVE_GRAD"); return e && e[0] == '0'; }();
     if (off || !wave_solve_supported(nd, train, B)) return false;
-    if ((train && nd.jvp) || nd.n_cond > 0 || nd.acts[0] != 1 || !(nd.acts[1] == 1 || is_id2(nd))) return false;
+    if ((train && nd.jvp) || nd.acts[0] != 1 || !(nd.acts[1] == 1 || is_id2(nd))) return false;
+    if (nd.n_cond > 0 && nd.n_in + nd.n_cond > 16 * ((nd.n_in + 15) / 16)) return false;       // [z; ys] within the input tiles
     return pick_grad((nd.n_in + 15) / 16, (nd.dims[1] + 15) / 16, is_id2(nd)) != nullptr && wave_grad_waves(B) <= 512;
 }
 
@@ -1081,6 +1092,7 @@ cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_param
                              float* U0, const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, const Solve3Args& sv_,
                              const WaveGradArgs* grad) {
     if (!wave_solve_supported(nd, train, B)) return CNF_ERR_UNSUPPORTED;
+    if (grad && nd.n_cond > 0 && !grad->ys) return CNF_ERR_BAD_ARG;
     if (grad && (!wave_grad_supported(nd, B, train) || !grad->traj || !grad->gpart || !grad->lam_out || !grad->hs_out || grad->traj_cap < 1))
         return CNF_ERR_UNSUPPORTED;
     static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); const char* w = getenv("CNF_WAVE"); return (e && e[0] == '0') || (w && w[0] == '0'); }();

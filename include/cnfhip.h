@@ -265,7 +265,7 @@ cnf_status cnf_loss_grad_host(cnf_handle h, const float* xs, const float* eps, i
  * one (test/call_tests.jl `diff_loss` with omode = TestMode(); benchmark/benchmarks.jl:60-99, "AD-1-order" / "test").
  * Device pointers, arguments as cnf_loss_grad (no eps: the exact trace draws nothing); cnf_grad_steps / cnf_grad_x apply
  * to it as well.  Implemented where the whole gradient runs in the launch of the solve -- two tanh layers (closed-form
- * trace) or one, n_in <= 16, <= 64 hidden units, unconditional, B <= 8192 --, CNF_ERR_UNSUPPORTED otherwise. */
+ * trace) or one, n_in <= 16, <= 64 hidden units, n_in + n_cond <= 16, B <= 8192 --, CNF_ERR_UNSUPPORTED otherwise. */
 cnf_status cnf_loss_grad_test(cnf_handle h, const float* xs, int B, const cnf_solve_opts* opts, float* loss_out,
                               float* grad, cnf_solve_stats* stats, void* stream);
 cnf_status cnf_loss_grad_test_host(cnf_handle h, const float* xs, int B, const cnf_solve_opts* opts, float* loss_out,

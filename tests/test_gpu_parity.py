@@ -1321,6 +1321,14 @@ def test_loss_grad_wave_local_small_networks(monkeypatch):
         assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval)), (what, val, rval)
         _assert_grad(grad, rgrad, what)
         helpers.note(f"{what}: {st['naccept']} steps, {st['launches']} launches, |grad| {np.abs(rgrad).max():.3g}")
+    # conditional models ([z; ys] within the input tile): the conditioning columns of W_1 get their gradient from the same contraction
+    for ci, (dims, nvars, naugs, n_cond, B) in enumerate((((6, 18, 6), 4, 2, 5, 40), ((2, 6, 2), 2, 0, 2, 33))):
+        cfg = O.Cfg(O.Net(dims, (O.ACT_TANH,) * 2), nvars, naugs, 1e-2, 1e-2, 1e-2 if naugs else 0.0)
+        val, grad, rval, rgrad, st, _ = _grad_case(cfg, B, 930 + ci, "mfma", dict(adaptive=False, dt=1 / 6), dict(adaptive=False, dt=1 / 6),
+                                                   n_cond=n_cond, scale=0.5)
+        assert st["launches"] <= 2, st
+        assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+        _assert_grad(grad, rgrad, f"wave-local gradient, conditional {dims} + {n_cond}")
     # bit-reproducible, and the same gradient as the streamed path to rounding
     cfg = cases[0][0]
     rng = np.random.default_rng(5)
@@ -1585,6 +1593,24 @@ def test_testmode_loss_gradient_small_networks():
         # polynomial near 0: rounding apart)
         assert abs(val - cnf.loss(ic, cnf.TestMode(), _dev(xs), flat, {})) <= 1e-5 * max(1.0, abs(val))
         ic.close()
+    # a conditional model (CondRNODE 4 + 2 with 3 conditioning inputs)
+    net = O.Net((9, 18, 6), T2)
+    cfg = O.Cfg(O.Net((6, 18, 6), T2), 4, 2, 1e-2, 1e-2, 1e-2)
+    rng = np.random.default_rng(77)
+    flat = O.glorot_params(net, rng, np.float32, 0.5)
+    xs = rng.standard_normal((4, 21)).astype(np.float32)
+    ys = rng.standard_normal((3, 21)).astype(np.float32)
+    layers = [cnf.Dense(9, 18, "tanh"), cnf.Dense(18, 6, "tanh")]
+    ic = cnf.construct(cnf.CondRNODE, cnf.Chain(*layers), 4, 2, compute_mode=cnf.HIPVecJacMatrixMode("auto"), tspan=(0.0, 1.0),
+                       lambda3=1e-2, sol_kwargs=dict(adaptive=False, dt=1 / 6))
+    val, grad, gx = cnf.loss_and_grad(ic, cnf.TestMode(), _dev(xs), _dev(ys), flat, {}, with_x=True)
+    c64 = O.Cfg(net, 4, 2, 1e-2, 1e-2, 1e-2)
+    rval, rgrad, ost = G.loss_and_grad_test(c64, flat.astype(np.float64), xs.astype(np.float64), ys.astype(np.float64), adaptive=False, dt=1 / 6)
+    assert ic.last_stats["launches"] <= 2
+    assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+    _assert_grad(grad.cpu().numpy(), rgrad, "TestMode gradient, conditional")
+    _assert_grad(gx.cpu().numpy(), ost.grad_x, "TestMode gradient, conditional, d/dxs", rtol=2e-4)
+    ic.close()
     # outside the wave kernels: not implemented (the reference trains in TrainMode)
     cfg3, _, _ = O.baseline_cfg(3)
     ic = make_icnf(cnf, cfg3, kernel="auto")
