@@ -942,6 +942,9 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
         if (wave_ok)
             s = wave_solve_launch(h->nd_wave, train != 0, h->d_params, h->nd.n_cond > 0 ? h->d_cond : nullptr, h->cbs, h->d_state, h->U[0],
                                   eps, B, st, h->d_mirror + mslot, base, sv, rec ? rec->wg : nullptr);
+        // (the gradient in the launch of the solve exists on the wave kernel only: if that launch could not start, the caller
+        // runs the streamed gradient path)
+        if (rec && rec->wg && s != CNF_OK) { rec->wg_failed = true; return CNF_OK; }
         if (tsolve_ok) {
             const GradLayout g = grad_layout(h->nd);
             const AdjMfmaLayout m = adj_mfma_layout(h->nd, g);

@@ -21,7 +21,7 @@ size_t wave_grad_traj_floats(const NetDesc& nd, int B);
 int wave_grad_waves(int B);
 // two tanh layers (or one + the appended identity), n_in (+ n_cond of a conditional model) <= 16, at most 512 waves
 // (B <= 8192); TrainMode:
-// the VJP compute mode; TestMode: the adjoint of the exact-trace solve (closed form of two-layer networks)
+// both compute modes; TestMode: the adjoint of the exact-trace solve (closed form of two-layer networks)
 bool wave_grad_supported(const NetDesc& nd, int B, bool train = true);
 
 // a two-layer network whose 16-row tile counts have an instantiation, B within the meeting buffer's reach

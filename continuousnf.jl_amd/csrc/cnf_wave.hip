@@ -124,7 +124,7 @@ __device__ __forceinline__ float wv_quad_sum(float v) {
 template <int NI, int NH, int MODE, bool TANH, bool GRAD = false, bool ID2 = false, int WGW = 1>
 __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args sv, const WvTab tab) {
     static_assert(!ID2 || TANH, "ID2 is instantiated for tanh first layers");
-    static_assert(!GRAD || ((MODE == WV_VJP || MODE == WV_TEST) && TANH), "the in-launch adjoint is written for TrainMode / VJP and TestMode of tanh networks");
+    static_assert(!GRAD || TANH, "the in-launch adjoint is written for tanh networks");
     constexpr bool GTEST = GRAD && MODE == WV_TEST;         // the adjoint of the exact-trace solve
     constexpr bool TRAIN = MODE != WV_TEST;
     constexpr int NS = TRAIN ? 3 : 1;                      // scalar rows of the state
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
     // ---- weights as A operands, in the k order the accumulator tiles present: lane (q, i), k-step j of input tile kt ->
     // M[16 m + i][16 kt + 4 q + j].  Straight from the flat vector (L2 hits after the first wave), once per solve. ----
     float fW1[NH][NI][4], fW2[NI][NH][4];
-    float fW2T[(MODE == WV_VJP || GTEST) ? NH : 1][NI][4], fW1T[(MODE == WV_VJP || GTEST) ? NI : 1][NH][4], fC[MODE == WV_TEST ? NH : 1][NI][4];
+    float fW2T[(MODE == WV_VJP || GRAD) ? NH : 1][NI][4], fW1T[(MODE == WV_VJP || GRAD) ? NI : 1][NH][4], fC[MODE == WV_TEST ? NH : 1][NI][4];
     float fCT[GTEST ? NI : 1][NH][4];
     auto w1 = [&](int o, int k) { return (o < nh && k < n_in) ? P[nd.w_off[0] + o + (size_t)k * nh] : 0.f; };       // W1[o][k]
     auto w2 = [&](int o, int k) { return (o < n_in && k < nh) ? P[nd.w_off[1] + o + (size_t)k * n_in] : 0.f; };     // W2[o][k]
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
             for (int j = 0; j < 4; ++j) {
                 const int o = 16 * m + c, k = 16 * kt + 4 * q + j;
                 fW1[m][kt][j] = w1(o, k);
-                if (MODE == WV_VJP || GTEST) fW2T[m][kt][j] = w2(k, o);            // W2^T[o][k] = W2[k][o]
+                if (MODE == WV_VJP || GRAD) fW2T[m][kt][j] = w2(k, o);             // W2^T[o][k] = W2[k][o]
                 if (MODE == WV_TEST) fC[m][kt][j] = w1(o, k) * w2(k, o);           // C[o][k] = W1[o][k] W2[k][o]
             }
 #pragma unroll
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
             for (int j = 0; j < 4; ++j) {
                 const int o = 16 * m + c, k = 16 * kt + 4 * q + j;
                 fW2[m][kt][j] = w2(o, k);
-                if (MODE == WV_VJP || GTEST) fW1T[m][kt][j] = w1(k, o);            // W1^T[o][k] = W1[k][o]
+                if (MODE == WV_VJP || GRAD) fW1T[m][kt][j] = w1(k, o);             // W1^T[o][k] = W1[k][o]
                 if (GTEST) fCT[m][kt][j] = w1(k, o) * w2(o, k);                    // C^T[o][k] = C[k][o] = W1[k][o] W2[o][k]
             }
     // biases in the accumulator layout (rows 16 m + 4 q + j); conditional models: a row per sample instead of b1
@@ -690,6 +690,16 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                     const int r = 16 * m + 4 * q + j;
                     ysv[m][j] = (a.g.ys && live && r >= n_in && r < n_in + nd.n_cond) ? a.g.ys[sb * nd.n_cond + (r - n_in)] : 0.f;
                 }
+            f32x4 W1eps[MODE == WV_JVP ? NH : 1];           // JVP mode: p_1 = W_1 eps, the same at every stage
+            if constexpr (MODE == WV_JVP) {
+#pragma unroll
+                for (int m = 0; m < NH; ++m) {
+                    f32x4 acc = zero4;
+#pragma unroll
+                    for (int kt = 0; kt < NI; ++kt) acc = mm4(fW1[m][kt], ep[kt], acc);
+                    W1eps[m] = acc;
+                }
+            }
             const int nacc = __builtin_amdgcn_readfirstlane(ns.naccept);
             const f32x4* tj0 = reinterpret_cast<const f32x4*>(a.g.traj) + (size_t)wid * (64 * NI) + lane * NI;
             const size_t tstage = (size_t)G * (64 * NI), tstep = 6 * tstage;
@@ -809,10 +819,44 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
 #pragma unroll
                         for (int m = 0; m < NI; ++m) ahat[m] = kb[m] + sc * zd[m];
                     }
-                    // ---- reverse sweep of eps (tbar chain: omega = eps): pbar_2 = eps s'_2, tbar_1 = W_2' pbar_2, pbar_1 = tbar_1 s'_1, eJ ----
-                    f32x4 tb1[NH], eJ[NI];
+                    f32x4 tb1[NH], p1[NH], p2[NI], tb2[NI];
+                    if constexpr (MODE == WV_JVP) {
+                    // ---- JVP compute mode (src/icnf.jl:384-420): tau = eps, omega = -c_l eps + c_n Je / |Je|.  Tangent sweep first
+                    // (p_1 = W_1 eps is the same for every stage: kept from the start of the backward pass), then the tbar chain ----
+                    float n2 = 0.f;
 #pragma unroll
-                    for (int m = 0; m < NI; ++m) pb2[m] = ep[m] * d2[m];
+                    for (int m = 0; m < NH; ++m) { p1[m] = W1eps[m]; t1[m] = p1[m] * d1[m]; }
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) {
+                        f32x4 part[NH];
+#pragma unroll
+                        for (int kt = 0; kt < NH; ++kt) part[kt] = mm4(fW2[m][kt], t1[kt], zero4);
+                        p2[m] = part[0];
+#pragma unroll
+                        for (int kt = 1; kt < NH; ++kt) p2[m] += part[kt];
+                        tau[m] = ep[m];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const float je = p2[m][j] * d2[m][j]; n2 = fmaf(je, je, n2); }
+                    }
+                    {
+                        const float nj = nd.norm_j ? sqrtf(wv_quad_sum(n2)) : 0.f;
+                        const float sc = (nd.norm_j && nj > 0.f) ? c_n / nj : 0.f;
+#pragma unroll
+                        for (int m = 0; m < NI; ++m) { tb2[m] = sc * (p2[m] * d2[m]) - c_l * ep[m]; pb2[m] = tb2[m] * d2[m]; }
+                    }
+#pragma unroll
+                    for (int m = 0; m < NH; ++m) {
+                        f32x4 acc = zero4;
+#pragma unroll
+                        for (int kt = 0; kt < NI; ++kt) acc = mm4(fW2T[m][kt], pb2[kt], acc);
+                        tb1[m] = acc;
+                        pb1[m] = acc * d1[m];
+                    }
+                    } else {
+                    // ---- reverse sweep of eps (tbar chain: omega = eps): pbar_2 = eps s'_2, tbar_1 = W_2' pbar_2, pbar_1 = tbar_1 s'_1, eJ ----
+                    f32x4 eJ[NI];
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) { tb2[m] = ep[m]; pb2[m] = ep[m] * d2[m]; }
 #pragma unroll
                     for (int m = 0; m < NH; ++m) {
                         f32x4 acc = zero4;
@@ -834,7 +878,6 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                         for (int j = 0; j < 4; ++j) n2 = fmaf(eJ[m][j], eJ[m][j], n2);
                     }
                     // ---- tau = -c_l eps + c_n eJ / |eJ| ; tangent sweep: p_1 = W_1 tau, t_1 = s'_1 p_1, p_2 = W_2 t_1 ----
-                    f32x4 p1[NH], p2[NI];
                     {
                         const float nj = nd.norm_j ? sqrtf(wv_quad_sum(n2)) : 0.f;
                         const float sc = (nd.norm_j && nj > 0.f) ? c_n / nj : 0.f;
@@ -858,9 +901,10 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
 #pragma unroll
                         for (int kt = 1; kt < NH; ++kt) p2[m] += part[kt];
                     }
+                    }   // (VJP: tbar chain, tau, tangent sweep)
                     // ---- reverse sweep of the cotangent: abar_l = hbar_l s'_l + tbar_l s''_l p_l ; hbar_{l-1} = W_l' abar_l ----
 #pragma unroll
-                    for (int m = 0; m < NI; ++m) ab2[m] = ahat[m] * d2[m] + ep[m] * dd_of(true, zd[m], d2[m]) * p2[m];
+                    for (int m = 0; m < NI; ++m) ab2[m] = ahat[m] * d2[m] + tb2[m] * dd_of(true, zd[m], d2[m]) * p2[m];
 #pragma unroll
                     for (int m = 0; m < NH; ++m) {
                         f32x4 acc = zero4;
@@ -877,7 +921,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
 #pragma unroll
                         for (int kt = 1; kt < NH; ++kt) w[m] += part[kt];
                     }
-                    }   // (VJP)
+                    }   // (TrainMode)
 #pragma unroll
                     for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -1022,8 +1066,18 @@ wave_fn pick_wg(int ni, int nh, int mode, bool grad, bool id2, bool tanh2) {
                     : (t ? (wave_fn)k_solve_wave<1, 3, WV_TEST, true, false, false, 4> : (wave_fn)k_solve_wave<1, 3, WV_VJP, true, false, false, 4>);
     return nullptr;
 }
-wave_fn pick_grad(int ni, int nh, bool id2, bool test = false) {
+wave_fn pick_grad(int ni, int nh, bool id2, bool test = false, bool jvp = false) {
     if (ni != 1) return nullptr;
+    if (jvp && !test) {
+        if (id2) return nh == 1 ? (wave_fn)k_solve_wave<1, 1, WV_JVP, true, true, true> : nullptr;
+        switch (nh) {
+            case 1: return (wave_fn)k_solve_wave<1, 1, WV_JVP, true, true>;
+            case 2: return (wave_fn)k_solve_wave<1, 2, WV_JVP, true, true>;
+            case 3: return (wave_fn)k_solve_wave<1, 3, WV_JVP, true, true>;
+            case 4: return (wave_fn)k_solve_wave<1, 4, WV_JVP, true, true>;
+            default: return nullptr;
+        }
+    }
     if (id2) return nh != 1 ? nullptr : test ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, true, true> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true, true>;
     if (test)
         switch (nh) {
@@ -1083,7 +1137,7 @@ size_t wave_grad_traj_floats(const NetDesc& nd, int B) { return (size_t)6 * wave
 bool wave_grad_supported(const NetDesc& nd, int B, bool train) {
     static const bool off = [] { const char* e = getenv("CNF_WAVE_GRAD"); return e && e[0] == '0'; }();
     if (off || !wave_solve_supported(nd, train, B)) return false;
-    if ((train && nd.jvp) || nd.acts[0] != 1 || !(nd.acts[1] == 1 || is_id2(nd))) return false;
+    if (nd.acts[0] != 1 || !(nd.acts[1] == 1 || is_id2(nd))) return false;
     if (nd.n_cond > 0 && nd.n_in + nd.n_cond > 16 * ((nd.n_in + 15) / 16)) return false;       // [z; ys] within the input tiles
     return pick_grad((nd.n_in + 15) / 16, (nd.dims[1] + 15) / 16, is_id2(nd)) != nullptr && wave_grad_waves(B) <= 512;
 }
@@ -1100,7 +1154,7 @@ cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_param
     const int ni = (nd.n_in + 15) / 16, nh = (nd.dims[1] + 15) / 16;
     int grid = (B + 15) / 16;
     const int mode = !train ? WV_TEST : (nd.jvp ? WV_JVP : WV_VJP);
-    wave_fn fn = grad ? pick_grad(ni, nh, is_id2(nd), !train) : pick_shape(ni, nh, mode, nd.acts[0] == 1 && nd.acts[1] == 1, is_id2(nd));
+    wave_fn fn = grad ? pick_grad(ni, nh, is_id2(nd), !train, nd.jvp != 0) : pick_shape(ni, nh, mode, nd.acts[0] == 1 && nd.acts[1] == 1, is_id2(nd));
     if (!fn || grid > 512) return CNF_ERR_UNSUPPORTED;
     // at most four tiles: the waves of ONE workgroup (they meet through LDS), where that form is instantiated
     static const bool wg_off = [] { const char* e = getenv("CNF_WAVE_WG"); return e && e[0] == '0'; }();

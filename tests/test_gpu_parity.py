@@ -1329,6 +1329,15 @@ def test_loss_grad_wave_local_small_networks(monkeypatch):
         assert st["launches"] <= 2, st
         assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
         _assert_grad(grad, rgrad, f"wave-local gradient, conditional {dims} + {n_cond}")
+    # the JVP compute mode (src/icnf.jl:384-420: omega = -c_l eps + c_n J eps / |J eps|, tau = eps), incl. a conditional model
+    for ci, (dims, nvars, naugs, n_cond, B, kw) in enumerate((((16, 48, 16), 8, 8, 0, 32, "replay"), ((5, 9, 5), 3, 2, 0, 50, dict(adaptive=False, dt=1 / 6)),
+                                                               ((6, 18, 6), 4, 2, 3, 20, dict(adaptive=False, dt=1 / 6)))):
+        cfg = O.Cfg(O.Net(dims, (O.ACT_TANH,) * 2), nvars, naugs, 1e-2, 1e-2, 1e-2, tspan=(0.0, 2.0))
+        sol_kw = dict() if kw == "replay" else dict(kw)
+        val, grad, rval, rgrad, st, _ = _grad_case(cfg, B, 940 + ci, "mfma", sol_kw, kw, jvp=True, n_cond=n_cond, scale=0.5)
+        assert st["launches"] <= 2, st
+        assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+        _assert_grad(grad, rgrad, f"wave-local gradient, JVP mode {dims} + {n_cond}")
     # bit-reproducible, and the same gradient as the streamed path to rounding
     cfg = cases[0][0]
     rng = np.random.default_rng(5)
