@@ -114,9 +114,9 @@ __device__ __forceinline__ float wv_quad_sum(float v) {
 // wave-private LDS buffer: one 16-byte write, four 4-byte reads per tile).  The weight-gradient tiles stay in registers for
 // the whole backward pass; each wave writes one partial, k_grad_reduce adds them in wave order (bit-reproducible).
 //
-// ID2: the second layer is the identity map appended by the caller to a ONE-layer network (`Dense(n => n, tanh)`, the
+// ID2: the second layer's activation is the identity -- a PlanarLayer's, or the identity map appended by the caller to a ONE-layer network (`Dense(n => n, tanh)`, the
 // network of the reference's benchmark suite, benchmark/benchmarks.jl:29: W_2 = I, b_2 = 0, identity activation -- exact in
-// fp32: products with 1 and 0, sums with 0); its activation is compiled out and its gradient is not written.
+// fp32: products with 1 and 0, sums with 0; nd.id2: its gradient is not written); the activation is compiled out.
 //
 // WGW = 4: the tiles of a batch of at most 64 samples (the reference's training batch of 32, its benchmark's 64 samples) as the
 // WAVES OF ONE WORKGROUP, one per SIMD: they meet through LDS and a workgroup barrier (~0.1 k cycles) instead of the tagged
@@ -948,7 +948,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                             for (int m = 0; m < NI; ++m) {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-                                    if (!ID2) gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[m][j], H1[j], gW2[m][k], 0, 0, 0);
+                                    gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[m][j], H1[j], gW2[m][k], 0, 0, 0);
                                     gW1[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], Z0[m][j], gW1[k][m], 0, 0, 0);
                                 }
 #pragma unroll
@@ -956,7 +956,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                                     if (GTEST) {               // H[hidden][input] += (c_l s'_1) s'_2'
                                         gH[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(T1[j], P2[m][j], gH[k][m], 0, 0, 0);
                                     } else {
-                                        if (!ID2) gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(P2[m][j], T1[j], gW2[m][k], 0, 0, 0);
+                                        gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(P2[m][j], T1[j], gW2[m][k], 0, 0, 0);
                                         gW1[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(P1[j], T0[m][j], gW1[k][m], 0, 0, 0);
                                     }
                                 }
@@ -1002,7 +1002,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                 for (int k = 0; k < NH; ++k)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (!ID2) {   // Wbar_2[o][kk]: row o = 16 m + 4 q + j, column kk = 16 k + c
+                        if (!nd.id2) {   // Wbar_2[o][kk]: row o = 16 m + 4 q + j, column kk = 16 k + c   (an APPENDED identity layer has no parameters)
                             const int o = 16 * m + 4 * q + j, kk = 16 * k + c;
                             if (o < n_in && kk < nh) gp[nd.w_off[1] + o + (size_t)kk * n_in] = gW2[m][k][j];
                         }
@@ -1033,7 +1033,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                 for (int j = 0; j < 4; ++j) {
                     const float v = row_sum(gb2[m][j]);
                     const int r = 16 * m + 4 * q + j;
-                    if (!ID2 && c == 0 && r < n_in) gp[nd.b_off[1] + r] = v;
+                    if (!nd.id2 && c == 0 && r < n_in) gp[nd.b_off[1] + r] = v;
                 }
         }
     }
@@ -1110,14 +1110,15 @@ wave_fn pick_shape_t(int ni, int nh, int mode) {
     return nullptr;
 }
 wave_fn pick_shape(int ni, int nh, int mode, bool tanh2 = true, bool id2 = false) {
-    if (id2)       // (tanh, appended identity): n_in <= 16
-        return ni == 1 && nh == 1 ? (mode == WV_VJP ? (wave_fn)k_solve_wave<1, 1, WV_VJP, true, false, true>
-                                   : mode == WV_JVP ? (wave_fn)k_solve_wave<1, 1, WV_JVP, true, false, true>
-                                                    : (wave_fn)k_solve_wave<1, 1, WV_TEST, true, false, true>) : nullptr;
+    if (id2 && ni == 1 && nh == 1)       // (tanh, identity) with one tile each: the activation compiled out
+        return mode == WV_VJP ? (wave_fn)k_solve_wave<1, 1, WV_VJP, true, false, true>
+             : mode == WV_JVP ? (wave_fn)k_solve_wave<1, 1, WV_JVP, true, false, true> : (wave_fn)k_solve_wave<1, 1, WV_TEST, true, false, true>;
     return tanh2 ? pick_shape_t<true>(ni, nh, mode) : pick_shape_t<false>(ni, nh, mode);
 }
 // a one-layer tanh network seen as (tanh layer, identity layer): cnf_abi.hip appends W_2 = I, b_2 = 0 behind the parameters
-bool is_id2(const NetDesc& nd) { return nd.n_layers == 2 && nd.acts[0] == 1 && nd.acts[1] == 0 && nd.id2; }
+// ... or a real second layer with the identity activation (PlanarLayer: tanh(w'z + b) u): the same instantiations, its
+// gradient is written (nd.id2 = 0)
+bool is_id2(const NetDesc& nd) { return nd.n_layers == 2 && nd.acts[0] == 1 && nd.acts[1] == 0; }
 
 }  // namespace
 

@@ -583,9 +583,9 @@ def test_call_matrix_of_the_reference(kernel):
                         buf = np.full((nvars, ndata), np.nan, np.float32)
                         assert cnf.rand_(d, buf) is buf and np.isfinite(buf).all()
                         assert np.isfinite(cnf.rand_(d, np.full(nvars, np.nan, np.float32))).all()
-                        if not train and not cond and not planar and kernel != "generic":
-                            # (TestMode gradients: the Dense chains of this matrix run on k_solve_wave<TEST, GRAD>)
-                            val, gps, gx = cnf.loss_and_grad(icnf, omode, r, flat, {}, with_x=True)
+                        if not train and kernel != "generic":
+                            # (TestMode gradients: every network of this matrix runs on k_solve_wave<TEST, GRAD>)
+                            val, gps, gx = cnf.loss_and_grad(icnf, omode, r, *args, with_x=True)
                             assert np.isfinite(val) and np.isfinite(gps).all() and gps.shape == flat.shape
                             assert gx.shape == r.shape and np.isfinite(gx).all()
                         if train:            # (every model type: the mode the reference trains in)
@@ -1313,6 +1313,7 @@ def test_loss_grad_wave_local_small_networks(monkeypatch):
         (O.Cfg(O.Net((7, 13, 7), (O.ACT_TANH,) * 2), 4, 3, 1e-2, 1e-2, 1e-2, tspan=(1.0, 0.0)), 1, dict(adaptive=False, dt=1 / 4), dict(adaptive=False, dt=1 / 4)),
         (O.Cfg(O.Net((16, 32, 16), (O.ACT_TANH,) * 2), 16, 0, 0.0, 0.0, 0.0), 2048, "replay", dict()),                      # FFJORD, 128 waves
         (O.Cfg(O.Net((16, 48, 16), (O.ACT_TANH,) * 2), 8, 8, 1e-2, 1e-2, 1e-2), 4099, "replay", dict()),                    # config 2's batch + 3: 257 waves, their own partials
+        (O.Cfg(O.Net((6, 1, 6), (O.ACT_TANH, O.ACT_IDENTITY)), 6, 0, 1e-2, 1e-2, 0.0), 40, dict(adaptive=False, dt=1 / 5), dict(adaptive=False, dt=1 / 5)),   # a planar flow's MLP form
     ]
     for ci, (cfg, B, ora_kw, sol_kw) in enumerate(cases):
         val, grad, rval, rgrad, st, ost = _grad_case(cfg, B, 900 + ci, "mfma", dict(sol_kw), ora_kw, scale=0.5)
@@ -1580,6 +1581,7 @@ def test_testmode_loss_gradient_small_networks():
         (O.Cfg(O.Net((12, 20, 12), T2), 12, 0, 0.0, 0.0, 0.0), 5, dict(adaptive=False, dt=1 / 6)),
         (O.Cfg(O.Net((16, 64, 16), T2), 10, 6, 1e-2, 1e-2, 1e-2, tspan=(1.0, 0.0)), 300, dict(adaptive=False, dt=1 / 5)),
         (O.Cfg(O.Net((7, 7), (O.ACT_TANH,)), 4, 3, 1e-2, 1e-2, 1e-2), 1, dict(adaptive=False, dt=1 / 4)),
+        (O.Cfg(O.Net((6, 1, 6), (O.ACT_TANH, O.ACT_IDENTITY)), 6, 0, 0.0, 0.0, 0.0), 40, dict(adaptive=False, dt=1 / 5)),   # a planar flow's MLP form
     ]
     for ci, (cfg, B, sol_kw) in enumerate(cases):
         rng = np.random.default_rng(600 + ci)
