@@ -1322,6 +1322,13 @@ def test_loss_grad_wave_local_small_networks(monkeypatch):
         assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval)), (what, val, rval)
         _assert_grad(grad, rgrad, what)
         helpers.note(f"{what}: {st['naccept']} steps, {st['launches']} launches, |grad| {np.abs(rgrad).max():.3g}")
+    # rejected attempts (a first step of half the span): their stage states, filed in the slot of the step still to be accepted, are
+    # overwritten by the attempt that is
+    cfg = O.Cfg(O.Net((16, 48, 16), (O.ACT_TANH,) * 2), 8, 8, 1e-2, 1e-2, 1e-2, tspan=(0.0, 6.0))
+    val, grad, rval, rgrad, st, _ = _grad_case(cfg, 40, 925, "mfma", dict(dt=3.0, reltol=1e-4, abstol=1e-6), "replay", scale=3.0)
+    assert st["nreject"] >= 2 and st["launches"] <= 2, st
+    assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+    _assert_grad(grad, rgrad, "wave-local gradient with rejected attempts")
     # conditional models ([z; ys] within the input tile): the conditioning columns of W_1 get their gradient from the same contraction
     for ci, (dims, nvars, naugs, n_cond, B) in enumerate((((6, 18, 6), 4, 2, 5, 40), ((2, 6, 2), 2, 0, 2, 33))):
         cfg = O.Cfg(O.Net(dims, (O.ACT_TANH,) * 2), nvars, naugs, 1e-2, 1e-2, 1e-2 if naugs else 0.0)
