@@ -252,8 +252,8 @@ cnf_status cnf_set_shard_comm(cnf_handle h, cnf_comm comm);
  * inference_prob src/base_icnf.jl:277-278); *loss_out is a HOST float; grad: n_params floats in the
  * layout of cnf_set_params (device pointer; host pointer in the _host variant).  Both are means
  * over the B columns given; a caller that shards the batch combines (loss, grad) weighted by B.
- * Conditional models: call cnf_set_cond first, as for any other solve.  TrainMode only (the
- * reference trains in TrainMode: core_icnf.jl:60). */
+ * Conditional models: call cnf_set_cond first, as for any other solve.  TrainMode (the mode the
+ * reference trains in: core_icnf.jl:60); the TestMode loss has cnf_loss_grad_test below. */
 cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* eps, int B,
                          const cnf_solve_opts* opts, float* loss_out, float* grad,
                          cnf_solve_stats* stats, void* stream);
