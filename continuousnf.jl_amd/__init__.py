@@ -44,7 +44,7 @@ from . import _lib
 from ._lib import CNFError, build
 from .base_icnf import (ICNF, ODEProblem, base_sol, construct, generate, generate_prob, generate_sol,
                         inference, inference_collect, inference_prob, inference_submit,
-                        inference_sol, loss, loss_and_grad, loss_from_sums, loss_sums, n_augment,
+                        inference_sol, loss, loss_and_grad, loss_and_grad_collect, loss_and_grad_submit, loss_from_sums, loss_sums, n_augment,
                         n_augment_input, steer_tspan)
 from .dist import CondICNFDist, ICNFDist, ICNFDistribution, logpdf, pdf, rand, rand_
 from .icnf import augmented_f

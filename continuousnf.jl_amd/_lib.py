@@ -83,6 +83,9 @@ _SIGNATURES = {
                                      C.POINTER(cnf_solve_stats), C.c_void_p]),
     "cnf_loss_grad_test_host": (C.c_int, [C.c_void_p, _fp, C.c_int, C.POINTER(cnf_solve_opts), C.POINTER(C.c_float), _fp,
                                           C.POINTER(cnf_solve_stats)]),
+    "cnf_loss_grad_submit": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, C.c_int, C.POINTER(cnf_solve_opts), _fp, _fp, C.c_void_p]),
+    "cnf_loss_grad_collect": (C.c_int, [C.c_void_p, C.POINTER(cnf_solve_stats)]),
+    "cnf_set_params_async": (C.c_int, [C.c_void_p, _fp, C.c_size_t, C.c_void_p]),
     "cnf_grad_steps": (C.c_int, [C.c_void_p, _fp, C.c_int]),
     "cnf_solve_kernel_time": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "cnf_abi_version": (C.c_int, []),

@@ -195,6 +195,21 @@ class ICNF:
         except Exception:
             pass
 
+    def set_params_async(self, ps):
+        """``set_params`` for a device tensor without host waits (cnf_set_params_async): the copy is enqueued on the current
+        stream.  The parameter update between two submitted gradients (``loss_and_grad_submit``); every launch on this ICNF must
+        go to that stream."""
+        import torch
+        if self.nn.planar is not None or not (_is_torch(ps) and ps.is_cuda):
+            return self.set_params(ps)
+        p = ps.detach().to(torch.float32).contiguous().reshape(-1)
+        h = self.handle()
+        st = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+        _lib.check(_lib.lib().cnf_set_params_async(h, p.data_ptr(), p.numel(), st), h)
+        self._params_id = ("t", ps, ps._version)
+        self._cond_id = None
+        self._keep_ps = p                       # (the copy is in flight: keep its source)
+
     def set_params(self, ps):
         """Upload ``ps`` (the ``p`` of augmented_f) unless it is the vector already resident."""
         h = self.handle()
@@ -409,7 +424,18 @@ def draw_eps(icnf: ICNF, like: _Buf, B: int):
     n_in = icnf.nvars + n_augment_input(icnf)
     e = icnf.rng.standard_normal((B, n_in)).astype(np.float32).reshape(-1)
     if like.torch is not None:
-        return _Buf(like.torch.from_numpy(e).to(like.arr.device), n_in, B, like.torch)
+        # through a small ring of PINNED staging buffers: the copy is enqueued (a pageable source makes the host wait for the
+        # stream, which would put a bubble between two submitted gradients); a buffer is reused four draws later, long after
+        # its copy (at most three launches are ever in flight)
+        t = like.torch
+        ring = getattr(icnf, "_eps_pin", None)
+        if ring is None or ring[0].numel() < e.size:
+            ring = icnf._eps_pin = [t.empty(max(e.size, 1024), dtype=t.float32).pin_memory() for _ in range(4)]
+            icnf._eps_pin_i = 0
+        buf = ring[icnf._eps_pin_i % 4]
+        icnf._eps_pin_i += 1
+        buf[:e.size].copy_(t.from_numpy(e))
+        return _Buf(buf[:e.size].to(like.arr.device, non_blocking=True), n_in, B, t)
     return _Buf(e, n_in, B, None)
 
 
@@ -750,6 +776,49 @@ def loss_and_grad(icnf: ICNF, mode, xs, *args, eps=None, with_x=False):
             gx = gd.cpu().numpy().reshape(B, icnf.nvars).T
         return float(val.value), grad, gx
     return float(val.value), grad
+
+
+def loss_and_grad_submit(icnf: ICNF, mode, xs, *args, eps=None):
+    """``loss_and_grad`` on device tensors, SUBMITTED (cnf_loss_grad_submit): solve, loss, adjoint and the sum of the partials are
+    enqueued and the call returns ``(loss, grad)`` as device tensors (one float; ``n_params`` floats) that are valid in stream
+    order -- an optimiser update enqueued next on the same stream consumes the gradient without the host ever waiting.
+    ``loss_and_grad_collect(icnf)`` completes the oldest submission (at most three in flight).  ``ps`` must be a device tensor;
+    it is uploaded with ``set_params_async``.  ``NotImplementedError`` where the gradient does not run in the launch of the
+    solve (use ``loss_and_grad``)."""
+    import torch
+    if not _is_torch(xs):
+        raise ValueError("loss_and_grad_submit needs device tensors")
+    ys, ps, st = _split_cond_args(icnf, args)
+    m = _mode_id(mode)
+    xb = _as_colmajor(xs, icnf.nvars, "xs")
+    B = xb.B
+    _trim_submitted(icnf)
+    icnf.set_params_async(ps)
+    icnf.set_cond(ys, B)
+    if m != _lib.MODE_TRAIN:
+        eb = None
+    elif eps is not None:
+        eb = _as_colmajor(eps, icnf.nvars + n_augment_input(icnf), "eps")
+    else:
+        eb = draw_eps(icnf, xb, B)
+    opts = _solve_opts(icnf, steer_tspan(icnf, mode))
+    l, h = _lib.lib(), icnf.handle()
+    out = torch.empty(icnf.nn.n_params_internal + 1, dtype=torch.float32, device=xb.arr.device)
+    grad, lossd = out[:-1], out[-1:]
+    rc = l.cnf_loss_grad_submit(h, m, xb.ptr, eb.ptr if eb is not None else None, B, C.byref(opts), lossd.data_ptr(), grad.data_ptr(),
+                                _stream(xb))
+    if rc == _lib.ERR_UNSUPPORTED:
+        raise NotImplementedError("no in-launch gradient for this network / batch: use loss_and_grad")
+    _lib.check(rc, h)
+    icnf._submitted = getattr(icnf, "_submitted", [])
+    icnf._submitted.append((xb, eb, out))
+    return lossd, icnf.nn.grad_to_external(grad)
+
+
+def loss_and_grad_collect(icnf: ICNF):
+    """Completes the oldest submitted gradient (cnf_loss_grad_collect); returns its statistics.  Raises ``RuntimeError`` if that
+    launch gave up (it delivered zeros and a NaN loss): run the batch again with ``loss_and_grad``."""
+    return inference_collect(icnf)
 
 
 def _loss_and_grad_test(icnf: ICNF, mode, xs, *args, with_x=False):

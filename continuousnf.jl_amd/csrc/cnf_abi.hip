@@ -54,6 +54,7 @@ struct cnf_ctx {
         unsigned seq = 0;         // its launch index = the tag it publishes its final state with
         int slot = 0;             // ... into this slot of the host mirror
         bool hairer = false;
+        bool grad = false;        // a submitted GRADIENT (cnf_loss_grad_submit): nothing is run again if it gave up
         int mode = 0, B = 0, k = 0;
         const float *xs = nullptr, *eps = nullptr;
         float *logpx = nullptr, *regs = nullptr, *sums5 = nullptr;
@@ -728,7 +729,7 @@ struct Recorder {
     // the whole gradient in the launch of the solve (k_solve_wave<GRAD>): where it keeps its trajectory and leaves its results;
     // wg_done: it ran (hs holds the step sizes); wg_failed: it could not (not this network, a wait ran out, too many steps)
     const WaveGradArgs* wg = nullptr;
-    bool wg_done = false, wg_failed = false;
+    bool wg_done = false, wg_failed = false, wg_submitted = false;     // wg_submitted: launched and left in flight (cnf_loss_grad_submit)
 };
 static size_t traj_slot_floats(cnf_handle h) { return 6 * ((size_t)h->nd.n_in + 3) * h->grad_cap_B; }
 // make room for `steps` slots (contiguous: the step kernel indexes it by the accepted-step counter)
@@ -967,6 +968,18 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             ++h->one_launch_count;
             h->last_state = h->d_state;
             HIPCHK(h, hipGetLastError());
+            if (h->submitting && rec && rec->wg) {
+                // a submitted gradient: the launch is on its way; cnf_loss_grad_collect reads its outcome from its mirror slot
+                cnf_ctx::Submitted sub;
+                sub.launched = true; sub.grad = true; sub.seq = base; sub.slot = mslot; sub.hairer = hairer; sub.mode = mode; sub.B = B;
+                sub.k = CNF_KERNEL_MFMA; sub.opts = *opts; sub.st = st;
+                h->submitted.push_back(sub);
+                h->sub_taken = true;
+                ++g_submitted_inflight; g_submitted_stream = st;
+                if (post) post->launched = true;
+                rec->wg_submitted = true;
+                return CNF_OK;
+            }
             if (h->submitting && fused_io && !rec && !u_out) {
                 // submitted: the launch is on its way; cnf_inference_collect reads its outcome from its mirror slot
                 cnf_ctx::Submitted sub;
@@ -1416,6 +1429,9 @@ static cnf_status finish_submission(cnf_handle h, const cnf_ctx::Submitted& sub,
         return CNF_OK;
     }
     ++h->fallbacks;
+    if (sub.grad)         // (its gradient was written as zeros and its loss as NaN by k_grad_finish: the caller runs the batch again)
+        return fail(h, CNF_ERR_UNSUPPORTED, "the submitted gradient launch gave up (a wait ran out, or more steps than its store holds): "
+                                            "zeros were delivered; run the batch again with cnf_loss_grad");
     const bool was = h->collecting;
     h->collecting = true; h->no_persist = true;
     s = inference_impl(h, sub.mode, sub.xs, sub.eps, sub.logpx, sub.regs, nullptr, sub.sums5, sub.B, &sub.opts, stats, sub.st);
@@ -1609,7 +1625,8 @@ static cnf_status ensure_grad_capacity(cnf_handle h, int B) {
 // cnf_wave.hip), then the sum of the waves' partials.  TrainMode (VJP compute mode) and TestMode (exact trace).  *done = false:
 // not this network / batch, or the launch gave up (a wait ran out, more steps than its store holds) -- nothing was written.
 static cnf_status wave_loss_grad(cnf_handle h, int mode, const float* xs, const float* eps, int B, const cnf_solve_opts* opts,
-                                 float* loss_out, float* grad, cnf_solve_stats* stats, void* stream, bool* done) {
+                                 float* loss_out, float* grad, cnf_solve_stats* stats, void* stream, bool* done,
+                                 float* loss_dev = nullptr /* submit: the loss goes here (device), nothing is waited for */) {
     *done = false;
     cnf_status s = CNF_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -1641,6 +1658,13 @@ static cnf_status wave_loss_grad(cnf_handle h, int mode, const float* xs, const 
         cnf_solve_stats sst{};
         PostHook ph{h->tmp_logpx, h->tmp_regs, h->d_sums, xs};
         if ((s = solve_core(h, mode, h->U[0], eps, nullptr, B, opts, &sst, stream, &rec, false, &ph)) != CNF_OK) return s;
+        if (rec.wg_submitted) {
+            HIPCHK(h, launch_grad_finish(wg.gpart, grad, (int)h->n_params, waves, h->d_state, h->d_sums, h->lam[0], h->lam[1], h->lam[2],
+                                         train ? 1 : 0, loss_dev, st));
+            h->grad_last_B = B;
+            *done = true;
+            return CNF_OK;
+        }
         if (rec.wg_done) {
             HIPCHK(h, launch_grad_reduce(wg.gpart, grad, (int)h->n_params, waves, st));
             float* sums = reinterpret_cast<float*>(&h->h_state[2]);
@@ -1809,6 +1833,57 @@ extern "C" cnf_status cnf_loss_grad_test_host(cnf_handle h, const float* xs, int
     HIPCHK(h, hipMemcpy(h->stage, xs, nx * sizeof(float), hipMemcpyHostToDevice));
     if ((s = cnf_loss_grad_test(h, h->stage, B, opts, loss_out, h->g_grad, stats, nullptr)) != CNF_OK) return s;
     HIPCHK(h, hipMemcpy(grad, h->g_grad, h->n_params * sizeof(float), hipMemcpyDeviceToHost));
+    return CNF_OK;
+}
+
+// ---- submitted gradients: a training loop that never waits for the GPU ---------------------------------------------------------
+// cnf_loss_grad_submit enqueues what cnf_loss_grad (TrainMode) / cnf_loss_grad_test (TestMode) compute -- solve, loss, discrete
+// adjoint, the sum of the partials -- and returns; the loss (one float) and the gradient are left in DEVICE memory, stream-
+// ordered, for whatever the caller enqueues next (the optimiser's update, then cnf_set_params_async with the new parameters and
+// the next submission).  cnf_loss_grad_collect (oldest first; the queue is the one of cnf_inference_submit: at most three in
+// flight, all on one stream) reports how the launch ended; a launch that gave up has delivered ZEROS and a NaN loss and is
+// reported as CNF_ERR_UNSUPPORTED.  Only where the gradient runs in the launch of the solve (k_solve_wave<GRAD>); otherwise
+// CNF_ERR_UNSUPPORTED at once, and the caller uses the synchronous call.
+extern "C" cnf_status cnf_loss_grad_submit(cnf_handle h, int mode, const float* xs, const float* eps, int B, const cnf_solve_opts* opts,
+                                           float* loss_dev, float* grad, void* stream) {
+    if (!h) return CNF_ERR_BAD_ARG;
+    if (h->submitted.size() >= 3) return fail(h, CNF_ERR_BAD_ARG, "three launches are submitted already: collect one first");
+    h->collecting = true;
+    cnf_status s = check_call(h, mode, B);
+    if (s == CNF_OK && (!xs || !opts || !loss_dev || !grad || (mode == CNF_MODE_TRAIN && !eps))) s = fail(h, CNF_ERR_BAD_ARG, "null pointer");
+    if (s == CNF_OK && B < 1) s = fail(h, CNF_ERR_BAD_SHAPE, "the loss is a mean over the batch: B must be >= 1");
+    if (s == CNF_OK) s = ensure_capacity(h, B);
+    if (s == CNF_OK) s = ensure_grad_capacity(h, B);
+    bool done = false;
+    if (s == CNF_OK) {
+        h->submitting = true; h->sub_taken = false;
+        s = wave_loss_grad(h, mode, xs, eps, B, opts, nullptr, grad, nullptr, stream, &done, loss_dev);
+        h->submitting = false;
+    }
+    h->collecting = false;
+    if (s != CNF_OK) return s;
+    if (!done) return fail(h, CNF_ERR_UNSUPPORTED, "no in-launch gradient for this network / batch: use cnf_loss_grad");
+    return CNF_OK;
+}
+
+extern "C" cnf_status cnf_loss_grad_collect(cnf_handle h, cnf_solve_stats* stats) { return cnf_inference_collect(h, stats); }
+
+// cnf_set_params without the host waits: the copy (and the packing launches) are enqueued on `stream` and the call returns.
+// For a caller whose every launch on this handle goes to that one stream (then stream order is all the synchronisation there
+// is to do): the parameter update between two submitted gradients.
+extern "C" cnf_status cnf_set_params_async(cnf_handle h, const float* flat_dev, size_t n, void* stream) {
+    if (!h || !flat_dev) return CNF_ERR_BAD_ARG;
+    if (n != h->n_params) return fail(h, CNF_ERR_BAD_SHAPE, "parameter count does not match the layer sizes");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (g_submitted_inflight > 0 && g_submitted_stream != s)
+        return fail(h, CNF_ERR_BAD_ARG, "cnf_set_params_async: launches are in flight on another stream");
+    HIPCHK(h, hipMemcpyAsync(h->d_params, flat_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    cnf_status ms = mfma_plan_pack(h->mfma, h->nd, h->d_params, s);
+    if (ms != CNF_OK) return fail(h, ms, "MFMA weight packing failed");
+    h->have_params = true;
+    h->pt_valid = false; h->img_valid = false; h->bimg_valid = false;
+    h->cond_B = 0;
     return CNF_OK;
 }
 

@@ -57,6 +57,9 @@ hipError_t launch_adj(const NetDesc& nd, const GradLayout& g, const AdjArgs& a, 
 hipError_t launch_wgrad(const NetDesc& nd, const GradLayout& g, const float* AB, const float* PB, const float* HS,
                         const float* TS, float* gpart, int n_params, int B, int ksplit, int chunk, hipStream_t s);
 hipError_t launch_grad_reduce(const float* gpart, float* grad, int n_params, int ksplit, hipStream_t s);
+// the same sum guarded by the final state of the launch that wrote the partials (zeros if it gave up) + the loss, in device memory
+hipError_t launch_grad_finish(const float* gpart, float* grad, int n_params, int ksplit, const StepState* state, const float* sums5,
+                              float l1, float l2, float l3, int train, float* loss_dev, hipStream_t s);
 hipError_t launch_transpose_params(const NetDesc& nd, const float* P, float* PT, hipStream_t s);
 hipError_t launch_stage_combine(const float* u, const StageK& ks, float h, float* out, size_t n, hipStream_t s);
 hipError_t launch_lambda_update(float* lam, const StageK& ws, size_t n, hipStream_t s);

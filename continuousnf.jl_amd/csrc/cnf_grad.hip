@@ -853,6 +853,30 @@ k_grad_reduce(const float* __restrict__ gpart, float* __restrict__ grad, int n_p
     if (q == 0 && p < n_params) grad[p] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
+// The end of a SUBMITTED gradient (cnf_loss_grad_submit): the sum of the partials as k_grad_reduce forms it -- or zeros when the
+// launch that wrote them gave up (its final state says so: nothing downstream of an unwaited launch may consume garbage) --
+// and the loss from the five sums (cnf_loss_from_sums' arithmetic), both left in device memory.
+__global__ void __launch_bounds__(256)
+k_grad_finish(const float* __restrict__ gpart, float* __restrict__ grad, int n_params, int ksplit, const StepState* __restrict__ state,
+              const float* __restrict__ sums5, float l1, float l2, float l3, int train, float* __restrict__ loss_dev) {
+    __shared__ float part[4][64];
+    const bool ok = state->n_partials >= 0 && state->done && !state->nonfinite;
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (ok && p < n_params)
+        for (int k = q; k < ksplit; k += 4) s += gpart[(size_t)k * n_params + p];
+    part[q][c] = s;
+    __syncthreads();
+    if (q == 0 && p < n_params) grad[p] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_dev) {
+        const double cnt = sums5[4];
+        const double v = train ? (-(double)sums5[0] + (double)l1 * sums5[1] + (double)l2 * sums5[2] + (double)l3 * sums5[3]) / cnt
+                               : -(double)sums5[0] / cnt;
+        *loss_dev = ok ? (float)v : __builtin_nanf("");
+    }
+}
+
 // WT_l[i + o*in] = W_l[o + i*out]  (same offsets as the flat vector; biases are not copied)
 __global__ void k_transpose_params(NetDesc nd, int in0, const float* __restrict__ P, float* __restrict__ PT) {
     const int l = blockIdx.y;
@@ -1006,6 +1030,13 @@ hipError_t launch_wgrad(const NetDesc& nd, const GradLayout& g, const float* AB,
 
 hipError_t launch_grad_reduce(const float* gpart, float* grad, int n_params, int ksplit, hipStream_t s) {
     hipLaunchKernelGGL(k_grad_reduce, dim3((n_params + 63) / 64), dim3(256), 0, s, gpart, grad, n_params, ksplit);
+    return hipGetLastError();
+}
+
+hipError_t launch_grad_finish(const float* gpart, float* grad, int n_params, int ksplit, const StepState* state, const float* sums5,
+                              float l1, float l2, float l3, int train, float* loss_dev, hipStream_t s) {
+    hipLaunchKernelGGL(k_grad_finish, dim3((n_params + 63) / 64), dim3(256), 0, s, gpart, grad, n_params, ksplit, state, sums5, l1, l2, l3,
+                       train, loss_dev);
     return hipGetLastError();
 }
 

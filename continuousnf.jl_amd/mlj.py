@@ -17,7 +17,7 @@ from typing import Any, Callable, Tuple
 
 import numpy as np
 
-from .base_icnf import ICNF, inference, loss_and_grad
+from .base_icnf import ICNF, inference, loss_and_grad, loss_and_grad_collect, loss_and_grad_submit
 from .layers import setup
 from .types import TestMode, TrainMode
 
@@ -88,6 +88,7 @@ class ICNFModel:
     sol_kwargs: dict = field(default_factory=dict)
     callback: Callable[[int, float], Any] | None = None     # (iteration, loss) per batch; not in the reference
     init: str = "glorot"                                    # layers.setup: "glorot" or "lux_v1" (not in the reference: Lux.setup decides there)
+    pipelined: bool = True                                  # submit the gradients (no host wait per iteration) where the backend can; not in the reference
 
 
 def _device_matrix(icnf: ICNF, X):
@@ -123,6 +124,23 @@ def fit(model: ICNFModel, verbosity: int, X, ys=None):
     it = 0
     t0 = time.perf_counter()
     losses = []
+    # Without a per-iteration callback nothing on the host needs an iteration's loss before the next one starts: the gradients
+    # are SUBMITTED (loss_and_grad_submit: solve + adjoint enqueued, loss and gradient left on the device), the optimiser's
+    # update and the next parameter upload are enqueued behind them on the same stream, and the host only ever waits for the
+    # launch before the previous one -- the GPU goes from one gradient straight into the next.  Where the gradient does not run
+    # in the launch of the solve (larger networks), or a submitted launch gives up, the loop below is the synchronous one.
+    pipelined = model.callback is None and model.pipelined and x.is_cuda
+    pending = []                                                      # loss tensors of the launches still in flight
+    dev_losses = []
+
+    def drain(keep):
+        nonlocal pipelined
+        while len(pending) > keep:
+            pending.pop(0)
+            try:
+                loss_and_grad_collect(icnf)
+            except Exception:                                         # a launch gave up (zeros were applied: a lost step); go on synchronously
+                pipelined = False
     for opt in model.optimizers:                                      # core_icnf.jl:64-73
         state = opt.init(ps)
         for _epoch in range(model.n_epochs):
@@ -131,6 +149,20 @@ def fit(model: ICNFModel, verbosity: int, X, ys=None):
                 idx = perm[lo:lo + bs]
                 xb = x[:, idx]
                 args = (xb, y[:, idx], ps, st) if y is not None else (xb, ps, st)
+                if pipelined:
+                    try:
+                        lossd, g = loss_and_grad_submit(icnf, TrainMode(), *args)
+                    except NotImplementedError:
+                        pipelined = False
+                if pipelined:
+                    opt.apply(state, ps, g)
+                    pending.append(lossd)
+                    dev_losses.append((len(losses), lossd))
+                    losses.append(float("nan"))                       # filled in from the device at the end
+                    it += 1
+                    drain(1)
+                    continue
+                drain(0)
                 val, g = loss_and_grad(icnf, TrainMode(), *args)
                 opt.apply(state, ps, g)
                 losses.append(val)
@@ -140,8 +172,13 @@ def fit(model: ICNFModel, verbosity: int, X, ys=None):
             if verbosity > 0:
                 k = max(1, (n + bs - 1) // bs)
                 print(f"epoch {_epoch + 1}/{model.n_epochs}: mean loss {np.mean(losses[-k:]):.5f}", flush=True)
+    drain(0)
     torch.cuda.synchronize(x.device)
-    report = {"stats": {"time": time.perf_counter() - t0, "iterations": it}, "losses": np.asarray(losses)}
+    if dev_losses:
+        vals = torch.cat([t for _, t in dev_losses]).cpu().numpy()
+        for (i, _), v in zip(dev_losses, vals):
+            losses[i] = float(v)
+    report = {"stats": {"time": time.perf_counter() - t0, "iterations": it, "pipelined": bool(dev_losses)}, "losses": np.asarray(losses)}
     return (ps.cpu().numpy(), st), None, report
 
 

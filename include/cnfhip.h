@@ -270,6 +270,20 @@ cnf_status cnf_loss_grad_test(cnf_handle h, const float* xs, int B, const cnf_so
                               float* grad, cnf_solve_stats* stats, void* stream);
 cnf_status cnf_loss_grad_test_host(cnf_handle h, const float* xs, int B, const cnf_solve_opts* opts, float* loss_out,
                                    float* grad, cnf_solve_stats* stats);      /* xs and grad in HOST memory */
+/* Submitted gradients -- a training loop that never waits for the GPU (the loop of MLJModelInterface.fit,
+ * src/exts/mlj_ext/core_icnf.jl:59-73, with the optimiser's update on the device).  cnf_loss_grad_submit enqueues what
+ * cnf_loss_grad (mode = CNF_MODE_TRAIN) / cnf_loss_grad_test (CNF_MODE_TEST, eps = NULL) compute and returns: the loss (one float)
+ * and the gradient are left in DEVICE memory, stream-ordered, for what the caller enqueues next -- the parameter update, then
+ * cnf_set_params_async with the new parameters and the next submission.  cnf_loss_grad_collect completes the oldest submission
+ * (the queue is cnf_inference_submit's: at most three in flight, all on one stream) and reports how it ended; a launch that gave
+ * up has delivered ZEROS and a NaN loss and is reported as CNF_ERR_UNSUPPORTED (run that batch again with cnf_loss_grad).  Exists
+ * where the gradient runs in the launch of the solve (see cnf_loss_grad_test); CNF_ERR_UNSUPPORTED at once otherwise. */
+cnf_status cnf_loss_grad_submit(cnf_handle h, int mode, const float* xs, const float* eps, int B, const cnf_solve_opts* opts,
+                                float* loss_dev, float* grad, void* stream);
+cnf_status cnf_loss_grad_collect(cnf_handle h, cnf_solve_stats* stats);
+/* cnf_set_params (device pointer) without its host waits: copy and packing are enqueued on `stream`.  For callers whose every
+ * launch on this handle goes to that one stream. */
+cnf_status cnf_set_params_async(cnf_handle h, const float* flat_dev, size_t n, void* stream);
 /* The signed sizes of the steps the last cnf_loss_grad on this handle accepted (the discrete map
  * it differentiated): writes min(n, cap) floats to hs (may be NULL) and returns n. */
 int cnf_grad_steps(cnf_handle h, float* hs, int cap);

@@ -1642,6 +1642,65 @@ def test_testmode_loss_gradient_small_networks():
     ic.close()
 
 
+def test_submitted_gradients_equal_the_synchronous_ones():
+    """cnf_loss_grad_submit / cnf_loss_grad_collect / cnf_set_params_async: gradients enqueued back to back with a parameter
+    update between them and nothing waited for -- loss and gradient (device tensors) equal those of the synchronous calls bit
+    for bit; TestMode likewise; a fourth submission is refused; networks without an in-launch gradient raise
+    NotImplementedError; and `fit` run pipelined ends with the very parameters of the synchronous loop."""
+    cfg = O.Cfg(O.Net((16, 48, 16), (O.ACT_TANH,) * 2), 8, 8, 1e-2, 1e-2, 1e-2, tspan=(0.0, 4.0))
+    rng = np.random.default_rng(17)
+    flat0 = O.glorot_params(cfg.net, rng, np.float32, 0.5)
+    batches = [(_dev(rng.standard_normal((8, B))), _dev(rng.standard_normal((16, B)))) for B in (32, 33, 64)]
+    for mode in (cnf.TrainMode(), cnf.TestMode()):
+        train = isinstance(mode, cnf.TrainMode)
+        # synchronous: three gradients with a (sign-SGD) parameter update after each
+        ic = make_icnf(cnf, cfg, kernel="mfma")
+        ps = torch.from_numpy(flat0.copy()).cuda()
+        want = []
+        for xs, eps in batches:
+            v, g = cnf.loss_and_grad(ic, mode, xs, ps, {}, **(dict(eps=eps) if train else {}))
+            want.append((v, g.clone()))
+            ps.sub_(torch.sign(g), alpha=1e-3)
+        ps_sync = ps.clone()
+        ic.close()
+        # submitted: the same three, nothing waited for in between
+        ic = make_icnf(cnf, cfg, kernel="mfma")
+        ps = torch.from_numpy(flat0.copy()).cuda()
+        got = []
+        for xs, eps in batches:
+            lossd, g = cnf.loss_and_grad_submit(ic, mode, xs, ps, {}, **(dict(eps=eps) if train else {}))
+            got.append((lossd, g))
+            ps.sub_(torch.sign(g), alpha=1e-3)
+        with pytest.raises(cnf.CNFError):
+            cnf.loss_and_grad_submit(ic, mode, batches[0][0], ps, {}, **(dict(eps=batches[0][1]) if train else {}))
+        for _ in range(3):
+            st = cnf.loss_and_grad_collect(ic)
+            assert st["launches"] == 1 and st["naccept"] > 0
+        torch.cuda.synchronize()
+        for (v, g), (lossd, gd) in zip(want, got):
+            assert float(lossd[0]) == np.float32(v) and torch.equal(g, gd), mode
+        assert torch.equal(ps, ps_sync)
+        ic.close()
+    cfg3, _, _ = O.baseline_cfg(3)
+    ic = make_icnf(cnf, cfg3, kernel="mfma")
+    f3 = torch.from_numpy(O.glorot_params(cfg3.net, rng, np.float32, 0.1)).cuda()
+    with pytest.raises(NotImplementedError):
+        cnf.loss_and_grad_submit(ic, cnf.TrainMode(), _dev(np.zeros((cfg3.nvars, 8), np.float32)), f3, {})
+    ic.close()
+    # fit: pipelined and synchronous loops end with the same parameters and report the same losses
+    data = np.random.default_rng(3).beta(2.0, 4.0, size=(256, 2)).astype(np.float32)
+    res = []
+    for pipelined in (True, False):
+        nn = cnf.Chain(cnf.Dense(4, 12, "tanh"), cnf.Dense(12, 4, "tanh"))
+        icf = cnf.construct(cnf.RNODE, nn, 2, 2, compute_mode=cnf.HIPVecJacMatrixMode(), tspan=(0.0, 3.0), steer_rate=0.1, lambda3=1e-2, rng=5)
+        model = cnf.ICNFModel(icf, optimizers=(cnf.Adam(eta=1e-3),), n_epochs=2, batch_size=32, pipelined=pipelined)
+        (psf, _), _, rep = cnf.fit(model, 0, data)
+        assert rep["stats"]["pipelined"] == pipelined
+        res.append((psf, rep["losses"]))
+        icf.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 def test_loss_grad_wave_local_hands_over_beyond_its_step_store():
     """k_solve_wave<GRAD> keeps the step sizes of at most WV_GCAP = 1024 accepted steps: a solve with more ends without a
     gradient and the call runs again on the streamed gradient path -- same loss, same gradient as the oracle."""
