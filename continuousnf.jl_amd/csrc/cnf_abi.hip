@@ -1640,7 +1640,12 @@ static cnf_status wave_loss_grad(cnf_handle h, int mode, const float* xs, const 
         // the arena's GRAD_MAX_KSPLIT partials
         const int waves = wave_grad_waves(B);
         const size_t part_f = waves > GRAD_MAX_KSPLIT ? (size_t)waves * h->n_params : 0;
-        const size_t need = per_step * cap + WV_GCAP + part_f;
+        // TrainMode / VJP at small batches: the forward pass also files its evaluations' intermediates (the backward pass then
+        // skips half of its products), while at least 256 steps of them fit in 256 MiB
+        size_t rich_step = wave_grad_rich_floats(h->nd_wave, B, train);
+        if (rich_step * 256 > ((size_t)1 << 26)) rich_step = 0;
+        if (rich_step) { while (rich_step * cap > ((size_t)1 << 26)) cap /= 2; }
+        const size_t need = per_step * cap + WV_GCAP + part_f + rich_step * cap;
         if (need > h->wg_traj_floats) {
             HIPCHK(h, hipDeviceSynchronize());
             if (h->wg_traj) { (void)hipFree(h->wg_traj); h->wg_traj = nullptr; h->wg_traj_floats = 0; }
@@ -1652,6 +1657,7 @@ static cnf_status wave_loss_grad(cnf_handle h, int mode, const float* xs, const 
         wg.gpart = part_f ? h->wg_traj + per_step * cap + WV_GCAP : h->g_part;
         wg.lam_out = h->g_lam; wg.n_params = (int)h->n_params;
         wg.ys = h->nd.n_cond > 0 ? h->d_ys : nullptr;
+        wg.rich = rich_step ? h->wg_traj + per_step * cap + WV_GCAP + part_f : nullptr;
         wg.lam1 = h->lam[0]; wg.lam2 = h->lam[1]; wg.lam3 = h->lam[2];
         Recorder rec;
         rec.wg = &wg;

@@ -12,6 +12,8 @@ struct WaveGradArgs {
     float* hs_out = nullptr;           // [traj_cap] signed step sizes (the host's copy: cnf_grad_steps)
     float* gpart = nullptr;            // [waves][n_params]
     float* lam_out = nullptr;          // [B][n_in]  d loss / d z(t0)   (cnf_grad_x)
+    float* rich = nullptr;             // TrainMode / VJP, small batches: [traj_cap][6][waves][64][3 (n_in + hidden tiles)] x 4 floats -- the
+                                       // forward evaluations' intermediates, so that the backward pass does not form them again
     const float* ys = nullptr;         // conditional models: [B][n_cond] (the columns of W_1 behind z get their gradient from them)
     int n_params = 0;
     float lam1 = 0.f, lam2 = 0.f, lam3 = 0.f;
@@ -19,6 +21,7 @@ struct WaveGradArgs {
 // floats of trajectory store per accepted step, waves of a launch
 size_t wave_grad_traj_floats(const NetDesc& nd, int B);
 int wave_grad_waves(int B);
+size_t wave_grad_rich_floats(const NetDesc& nd, int B, bool train);   // per accepted step; 0: no such form
 // two tanh layers (or one + the appended identity), n_in (+ n_cond of a conditional model) <= 16, at most 512 waves
 // (B <= 8192); TrainMode:
 // both compute modes; TestMode: the adjoint of the exact-trace solve (closed form of two-layer networks)

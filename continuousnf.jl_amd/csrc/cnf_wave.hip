@@ -121,8 +121,22 @@ __device__ __forceinline__ float wv_quad_sum(float v) {
 // WGW = 4: the tiles of a batch of at most 64 samples (the reference's training batch of 32, its benchmark's 64 samples) as the
 // WAVES OF ONE WORKGROUP, one per SIMD: they meet through LDS and a workgroup barrier (~0.1 k cycles) instead of the tagged
 // words in memory (2.4-2.9 k cycles per attempt: 10-18 % of an attempt of these networks).
-template <int NI, int NH, int MODE, bool TANH, bool GRAD = false, bool ID2 = false, int WGW = 1>
-__global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args sv, const WvTab tab) {
+//
+// RICH (TrainMode / VJP gradients while the store is affordable: small batches): the forward pass also files what its evaluation
+// at every stage point already holds -- h_1, sigma'_1, tbar_1 = W_2' (eps sigma'_2), zdot, sigma'_2, eps'J -- and the backward pass
+// reads them back (a stage ahead) instead of forming them again: 4 of its 8 products and all of its tanh go (the very same
+// numbers: the gradient is bit-identical to the recomputing form's).
+//
+// HELP (every GRAD instantiation with one tile per workgroup): a SECOND wave of the workgroup, on another SIMD of the CU, does
+// the weight-gradient contraction -- it keeps the Wbar tiles, reads the factor tiles the main wave files in LDS (two sets, one
+// workgroup barrier per stage evaluation) and issues the 48 MFMAs of a stage beside the main wave's next stage: the
+// contraction (a quarter of the backward pass: LDS round trip + MFMAs) leaves the main wave's dependent chain.
+template <int NI, int NH, int MODE, bool TANH, bool GRAD = false, bool ID2 = false, int WGW = 1, bool RICH = false>
+__global__ void __launch_bounds__(GRAD && WGW == 1 ? 128 : 64 * WGW) k_solve_wave(WaveArgs a, Solve3Args sv, const WvTab tab) {
+    constexpr bool HELP = GRAD && WGW == 1;
+    static_assert(!RICH || (GRAD && MODE == WV_VJP), "RICH is a form of the TrainMode / VJP gradient");
+    constexpr int RR = 3 * NH + 3 * NI;                     // f32x4 per lane and stage evaluation in the rich store
+    f32x4* rich_ptr = nullptr;                             // where the next evaluation files them (null: nowhere)
     static_assert(!ID2 || TANH, "ID2 is instantiated for tanh first layers");
     static_assert(!GRAD || TANH, "the in-launch adjoint is written for tanh networks");
     constexpr bool GTEST = GRAD && MODE == WV_TEST;         // the adjoint of the exact-trace solve
@@ -261,6 +275,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
 #pragma unroll
                 for (int kt = 0; kt < NI; ++kt) acc = mm4(fW2T[m][kt], g2[kt], acc);
                 g1[m] = acc * d1[m];
+                if (RICH && rich_ptr) { rich_ptr[m] = h1[m]; rich_ptr[NH + m] = d1[m]; rich_ptr[2 * NH + m] = acc; }
             }
 #pragma unroll
             for (int m = 0; m < NI; ++m) {
@@ -272,6 +287,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                 for (int kt = 1; kt < NH; ++kt) eJ += part[kt];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { ld = fmaf(eJ[j], ep[m][j], ld); n2 = fmaf(eJ[j], eJ[j], n2); }
+                if (RICH && rich_ptr) { rich_ptr[3 * NH + m] = zd[m]; rich_ptr[3 * NH + NI + m] = d2[m]; rich_ptr[3 * NH + 2 * NI + m] = eJ; }
             }
         } else if (MODE == WV_JVP) {
             f32x4 t1[NH];
@@ -319,8 +335,98 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
     };
 
     __shared__ float hsL[GRAD ? WV_GCAP : 1];                                           // step sizes of the accepted steps
-    __shared__ __attribute__((aligned(16))) float tbuf_all[GRAD ? WGW * 4 * (NI + NH) * 256 : 4];   // factor tiles, [sample][row], per wave
-    float* const tbuf = tbuf_all + (GRAD && WGW > 1 ? (threadIdx.x >> 6) * (4 * (NI + NH) * 256) : 0);
+    constexpr int TBW = 4 * (NI + NH) * 256;                // floats of one set of factor tiles
+    // factor tiles, [sample][row]: one set per wave -- HELP: two sets, filed by the main wave and contracted by the helper in turn
+    __shared__ __attribute__((aligned(16))) float tbuf_all[GRAD ? (HELP ? 2 : WGW) * TBW : 4];
+    float* tbuf = tbuf_all + (GRAD && WGW > 1 ? (threadIdx.x >> 6) * TBW : 0);
+    __shared__ int hcnt;                                    // HELP: stage evaluations the helper has to contract (0: none)
+    if constexpr (HELP) {
+        if ((threadIdx.x >> 6) == 1) {
+            // ================= the helper wave: Wbar_l += abar_l h_{l-1}' + pbar_l t_{l-1}' over the tile's 16 samples =================
+            // MFMAs whose k index is the SAMPLE, on the factor tiles the main wave filed [sample][row] (slots: [0, NI) abar_2 |
+            // pbar_2 | z | tau | then NH each: h_1, t_1, abar_1, pbar_1;  TestMode: pbar_2 = s'_2, t_1 = c_l s'_1 -> H)
+            f32x4 gW2[NI][NH], gW1[NH][NI], gH[GTEST ? NH : 1][NI];
+#pragma unroll
+            for (int m = 0; m < NI; ++m)
+#pragma unroll
+                for (int k = 0; k < NH; ++k) { gW2[m][k] = zero4; gW1[k][m] = zero4; if (GTEST) gH[k][m] = zero4; }
+            __syncthreads();                               // the main wave has said how many stage evaluations there are
+            const int cnt = __builtin_amdgcn_readfirstlane(hcnt);
+            const float* set = tbuf_all;
+            for (int it = 0; it < cnt; ++it) {
+                __syncthreads();                           // ... and has filed the next one's tiles in `set`
+                auto hget = [&](int slot, float (&o)[4]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = set[slot * 256 + (4 * j + q) * 16 + c];
+                };
+                float A2[NI][4], P2[NI][4], Z0[NI][4], T0[NI][4];
+#pragma unroll
+                for (int m = 0; m < NI; ++m) { hget(m, A2[m]); hget(NI + m, P2[m]); hget(2 * NI + m, Z0[m]); hget(3 * NI + m, T0[m]); }
+#pragma unroll
+                for (int k = 0; k < NH; ++k) {
+                    float H1[4], T1[4], A1[4], P1[4];
+                    hget(4 * NI + k, H1); hget(4 * NI + NH + k, T1); hget(4 * NI + 2 * NH + k, A1); hget(4 * NI + 3 * NH + k, P1);
+#pragma unroll
+                    for (int m = 0; m < NI; ++m) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[m][j], H1[j], gW2[m][k], 0, 0, 0);
+                            gW1[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], Z0[m][j], gW1[k][m], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (GTEST) {
+                                gH[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(T1[j], P2[m][j], gH[k][m], 0, 0, 0);
+                            } else {
+                                gW2[m][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(P2[m][j], T1[j], gW2[m][k], 0, 0, 0);
+                                gW1[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(P1[j], T0[m][j], gW1[k][m], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+                set = set == tbuf_all ? tbuf_all + TBW : tbuf_all;
+            }
+            if (cnt > 0) {
+                if constexpr (GTEST) {
+                    // Wbar_1[k][i] -= H[k][i] W_2[i][k];  Wbar_2[i][k] -= H[k][i] W_1[k][i]  (H's tile transposed through LDS: the
+                    // main wave files nothing after its last barrier)
+#pragma unroll
+                    for (int k = 0; k < NH; ++k)
+#pragma unroll
+                        for (int m = 0; m < NI; ++m) {
+                            reinterpret_cast<f32x4*>(tbuf_all)[c * 4 + q] = gH[k][m];
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+                            float Ht[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) Ht[j] = tbuf_all[(4 * q + j) * 16 + c];     // H[16 k + c][16 m + 4 q + j]
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                gW1[k][m][j] -= gH[k][m][j] * w2(16 * m + c, 16 * k + 4 * q + j);
+                                gW2[m][k][j] -= Ht[j] * w1(16 * k + c, 16 * m + 4 * q + j);
+                            }
+                        }
+                }
+                float* gp = a.g.gpart + (size_t)wid * a.g.n_params;
+#pragma unroll
+                for (int m = 0; m < NI; ++m)
+#pragma unroll
+                    for (int k = 0; k < NH; ++k)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (!nd.id2) {   // Wbar_2[o][kk]: row o = 16 m + 4 q + j, column kk = 16 k + c   (an APPENDED identity layer has no parameters)
+                                const int o = 16 * m + 4 * q + j, kk = 16 * k + c;
+                                if (o < n_in && kk < nh) gp[nd.w_off[1] + o + (size_t)kk * n_in] = gW2[m][k][j];
+                            }
+                            {   // Wbar_1[o][kk]: row o = 16 k + 4 q + j, column kk = 16 m + c
+                                const int o = 16 * k + 4 * q + j, kk = 16 * m + c;
+                                if (o < nh && kk < n_in + nd.n_cond) gp[nd.w_off[0] + o + (size_t)kk * nh] = gW1[k][m][j];
+                            }
+                        }
+            }
+            return;
+        }
+    }
     __shared__ float mw[2][WGW][2];                        // WGW > 1: the waves' meeting words
     bool gover = false;                                    // more accepted steps than the trajectory store holds
     // ---- integrator state: every lane carries the same copy and runs the same controller on the same sums ----
@@ -329,6 +435,11 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
     int nsync = 0;
     const unsigned mbase = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sv.base_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     const int G = WGW > 1 ? (int)(blockDim.x >> 6) : (int)gridDim.x;
+    // the rich store's slot of (step, stage): [step][stage][wave][lane][RR]
+    auto rich_slot = [&](int step, int stage) -> f32x4* {
+        if (!RICH || !a.g.rich || step >= a.g.traj_cap) return nullptr;
+        return reinterpret_cast<f32x4*>(a.g.rich) + (((size_t)step * 6 + stage) * G + wid) * (size_t)(64 * RR) + lane * RR;
+    };
     float p0 = 0.f, p1 = 0.f;
     // The waves' partials (e, b) -> the sums over all of them in p0, p1 (the same order in every wave).  false: a wait ran out.
     auto meet = [&](float e_lane, float b_lane) -> bool {
@@ -402,7 +513,9 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
     {
         // ---- k1 = f(u0); automatic initial dt (Hairer): its two norms, f(u0 + h0 f0) and that norm ----
         float e = 0.f, b = 0.f;
+        rich_ptr = rich_slot(0, 0);                        // k1 = f(u_0): stage 1 of step 0
         rhs(uz, kz[0], ks[0]);
+        rich_ptr = nullptr;
         if (live) {
 #pragma unroll
             for (int m = 0; m < NI; ++m)
@@ -476,7 +589,11 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
             }
             f32x4 zd[NI];
             float sd;
+            // (stages 2..6 of this step; the evaluation at the new solution is stage 1 of the NEXT step -- FSAL --: a rejected
+            // attempt's is overwritten by the accepted one's)
+            rich_ptr = s < 6 ? rich_slot(ns.naccept, s) : rich_slot(ns.naccept + 1, 0);
             rhs(zt, zd, sd);
+            rich_ptr = nullptr;
 #pragma unroll
             for (int i = 1; i < 7; ++i) {
 #pragma unroll
@@ -615,7 +732,12 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
         }
     }
     if constexpr (GRAD) {
-        if (alive && !gover && __builtin_amdgcn_readfirstlane(ns.done) && !__builtin_amdgcn_readfirstlane(ns.nonfinite)) {
+        const bool run_bwd = alive && !gover && __builtin_amdgcn_readfirstlane(ns.done) && !__builtin_amdgcn_readfirstlane(ns.nonfinite);
+        if constexpr (HELP) {                              // the helper learns how many stage evaluations it will be handed
+            if (lane == 0) hcnt = run_bwd ? 6 * __builtin_amdgcn_readfirstlane(ns.naccept) : 0;
+            __syncthreads();
+        }
+        if (run_bwd) {
             // ================= backward: discrete adjoint of the accepted steps (oracle/cnf_grad_oracle.py) =================
             const float invB = 1.0f / (float)a.B;
             const float cl0 = invB, cE0 = a.g.lam1 * invB, cn0 = a.g.lam2 * invB;   // cotangents of the scalar rows: constants
@@ -722,6 +844,12 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = tbuf[slot * 256 + (4 * j + q) * 16 + c];
             };
+            f32x4 Rnx[RICH ? RR : 1];
+            if constexpr (RICH) {
+                const f32x4* nx = nacc > 0 ? rich_slot(nacc - 1, 5) : nullptr;
+#pragma unroll
+                for (int r = 0; r < RR; ++r) Rnx[r] = nx ? nx[r] : zero4;
+            }
             for (int n = nacc - 1; n >= 0; --n) {
                 const float hn = hsL[n];
                 f32x4 U[6][NI];                            // the stage states the forward pass filed; the next step's are requested a step ahead
@@ -759,7 +887,23 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                     (void)c_E; (void)c_n;
                     // ---- forward: h_1, sigma', sigma'' ; zdot ; ahat = kbar + c_E zdot / |zdot| ----
                     f32x4 h1[NH], d1[NH], zd[NI], d2[NI];
-                    fwd2(z, h1, d1, zd, d2);
+                    f32x4 Rc[RICH ? RR : 1];                // RICH: what the forward pass filed for this stage point, read a stage ahead
+                    if constexpr (RICH) {
+#pragma unroll
+                        for (int r = 0; r < RR; ++r) Rc[r] = Rnx[r];
+                        // the next stage point backwards: (n, i - 1), or the last one of the step before
+                        const f32x4* nx = i > 0 ? rich_slot(n, i - 1) : (n > 0 ? rich_slot(n - 1, 5) : nullptr);
+                        if (nx) {
+#pragma unroll
+                            for (int r = 0; r < RR; ++r) Rnx[r] = nx[r];
+                        }
+#pragma unroll
+                        for (int m = 0; m < NH; ++m) { h1[m] = Rc[m]; d1[m] = Rc[NH + m]; }
+#pragma unroll
+                        for (int m = 0; m < NI; ++m) { zd[m] = Rc[3 * NH + m]; d2[m] = Rc[3 * NH + NI + m]; }
+                    } else {
+                        fwd2(z, h1, d1, zd, d2);
+                    }
                     // what the weight-gradient contraction takes: abar_2, abar_1 and a second factor pair per layer
                     f32x4 ab2[NI], ab1[NH], w[NI], pb2[NI], t1[NH], pb1[NH], tau[NI];
                     if constexpr (GTEST) {
@@ -857,6 +1001,17 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                     f32x4 eJ[NI];
 #pragma unroll
                     for (int m = 0; m < NI; ++m) { tb2[m] = ep[m]; pb2[m] = ep[m] * d2[m]; }
+                    float n2 = 0.f;
+                    if constexpr (RICH) {                  // tbar_1 and eps'J as the forward pass formed them
+#pragma unroll
+                        for (int m = 0; m < NH; ++m) { tb1[m] = Rc[2 * NH + m]; pb1[m] = tb1[m] * d1[m]; }
+#pragma unroll
+                        for (int m = 0; m < NI; ++m) {
+                            eJ[m] = Rc[3 * NH + 2 * NI + m];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) n2 = fmaf(eJ[m][j], eJ[m][j], n2);
+                        }
+                    } else {
 #pragma unroll
                     for (int m = 0; m < NH; ++m) {
                         f32x4 acc = zero4;
@@ -865,7 +1020,6 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                         tb1[m] = acc;
                         pb1[m] = acc * d1[m];
                     }
-                    float n2 = 0.f;
 #pragma unroll
                     for (int m = 0; m < NI; ++m) {
                         f32x4 part[NH];
@@ -876,6 +1030,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                         for (int kt = 1; kt < NH; ++kt) eJ[m] += part[kt];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) n2 = fmaf(eJ[m][j], eJ[m][j], n2);
+                    }
                     }
                     // ---- tau = -c_l eps + c_n eJ / |eJ| ; tangent sweep: p_1 = W_1 tau, t_1 = s'_1 p_1, p_2 = W_2 t_1 ----
                     {
@@ -935,6 +1090,10 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                         tput(4 * NI + m, h1[m]); tput(4 * NI + NH + m, t1[m]); tput(4 * NI + 2 * NH + m, ab1[m]); tput(4 * NI + 3 * NH + m, pb1[m]);
                         gb1[m] += ab1[m];
                     }
+                    if constexpr (HELP) {
+                        __syncthreads();                   // handed to the helper; the next stage files the other set
+                        tbuf = tbuf == tbuf_all ? tbuf_all + TBW : tbuf_all;
+                    } else {
                     tsync();
                     {
                         float A2[NI][4], P2[NI][4], Z0[NI][4], T0[NI][4];
@@ -964,6 +1123,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                         }
                     }
                     tsync();
+                    }   // (!HELP)
                 }
                 // lambda <- lambda + sum_i w_i
 #pragma unroll
@@ -976,7 +1136,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { const int r = 16 * m + 4 * q + j; if (r < n_in) a.g.lam_out[(size_t)smp * n_in + r] = lam[m][j]; }
             }
-            if constexpr (GTEST) {
+            if constexpr (GTEST && !HELP) {
                 // Wbar_1[k][i] -= H[k][i] W_2[i][k];  Wbar_2[i][k] -= H[k][i] W_1[k][i]  (H's tile transposed through the LDS buffer)
 #pragma unroll
                 for (int k = 0; k < NH; ++k)
@@ -996,6 +1156,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                     }
             }
             float* gp = a.g.gpart + (size_t)wid * a.g.n_params;
+            if constexpr (!HELP) {                         // (HELP: the weight tiles are the helper wave's)
 #pragma unroll
             for (int m = 0; m < NI; ++m)
 #pragma unroll
@@ -1011,6 +1172,7 @@ __global__ void __launch_bounds__(64 * WGW) k_solve_wave(WaveArgs a, Solve3Args 
                             if (o < nh && kk < n_in + nd.n_cond) gp[nd.w_off[0] + o + (size_t)kk * nh] = gW1[k][m][j];
                         }
                     }
+            }
             // bias gradients: the sum over the 16 samples of a lane group's rows (DPP row reduction, fixed order)
             auto row_sum = [&](float v) __attribute__((always_inline)) {
                 v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
@@ -1052,18 +1214,28 @@ typedef void (*wave_fn)(WaveArgs, Solve3Args, const WvTab);
 // one workgroup of up to four waves (B <= 64): the README / regression networks and the one-layer benchmark network, TrainMode
 // (VJP) and TestMode, plain solve and gradient
 wave_fn pick_wg(int ni, int nh, int mode, bool grad, bool id2, bool tanh2) {
+    if (grad) return nullptr;            // (gradients: one tile per workgroup + its helper wave, whatever the batch)
     if (ni != 1 || mode == WV_JVP || !(tanh2 || id2)) return nullptr;
     const bool t = mode == WV_TEST;
     if (id2)
         return nh != 1 ? nullptr
-             : grad ? (t ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, true, true, 4> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true, true, 4>)
-                    : (t ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, false, true, 4> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, false, true, 4>);
+             : (t ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, false, true, 4> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, false, true, 4>);
     if (nh == 1)
-        return grad ? (t ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, true, false, 4> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true, false, 4>)
-                    : (t ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, false, false, 4> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, false, false, 4>);
+        return t ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, false, false, 4> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, false, false, 4>;
     if (nh == 3)
-        return grad ? (t ? (wave_fn)k_solve_wave<1, 3, WV_TEST, true, true, false, 4> : (wave_fn)k_solve_wave<1, 3, WV_VJP, true, true, false, 4>)
-                    : (t ? (wave_fn)k_solve_wave<1, 3, WV_TEST, true, false, false, 4> : (wave_fn)k_solve_wave<1, 3, WV_VJP, true, false, false, 4>);
+        return t ? (wave_fn)k_solve_wave<1, 3, WV_TEST, true, false, false, 4> : (wave_fn)k_solve_wave<1, 3, WV_VJP, true, false, false, 4>;
+    return nullptr;
+}
+// the RICH form of the TrainMode / VJP gradient (the forward pass files its intermediates)
+wave_fn pick_grad_rich(int nh, bool id2, bool wg) {
+    if (wg) return nullptr;
+    if (id2) return nh == 1 ? (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true, true, 1, true> : nullptr;
+    switch (nh) {
+        case 1: return (wave_fn)k_solve_wave<1, 1, WV_VJP, true, true, false, 1, true>;
+        case 2: return (wave_fn)k_solve_wave<1, 2, WV_VJP, true, true, false, 1, true>;
+        case 3: return (wave_fn)k_solve_wave<1, 3, WV_VJP, true, true, false, 1, true>;
+        case 4: return (wave_fn)k_solve_wave<1, 4, WV_VJP, true, true, false, 1, true>;
+    }
     return nullptr;
 }
 wave_fn pick_grad(int ni, int nh, bool id2, bool test = false, bool jvp = false) {
@@ -1134,6 +1306,13 @@ bool wave_solve_supported(const NetDesc& nd, bool train, int B) {
 }
 
 int wave_grad_waves(int B) { return (B + 15) / 16; }
+// floats per accepted step of the rich store (0: this network / mode has no RICH form)
+size_t wave_grad_rich_floats(const NetDesc& nd, int B, bool train) {
+    static const bool off = [] { const char* e = getenv("CNF_WAVE_RICH"); return e && e[0] == '0'; }();
+    const int ni = (nd.n_in + 15) / 16, nh = (nd.dims[1] + 15) / 16;
+    if (off || !train || nd.jvp || ni != 1 || nh > 4 || (nd.acts[1] != 1 && nh != 1)) return 0;
+    return (size_t)6 * wave_grad_waves(B) * 64 * (3 * nh + 3 * ni) * 4;
+}
 size_t wave_grad_traj_floats(const NetDesc& nd, int B) { return (size_t)6 * wave_grad_waves(B) * 64 * ((nd.n_in + 15) / 16) * 4; }
 bool wave_grad_supported(const NetDesc& nd, int B, bool train) {
     static const bool off = [] { const char* e = getenv("CNF_WAVE_GRAD"); return e && e[0] == '0'; }();
@@ -1161,6 +1340,10 @@ cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_param
     static const bool wg_off = [] { const char* e = getenv("CNF_WAVE_WG"); return e && e[0] == '0'; }();
     wave_fn wfn = (grid <= 4 && !wg_off && !cond) ? pick_wg(ni, nh, mode, grad != nullptr, is_id2(nd), nd.acts[0] == 1 && nd.acts[1] == 1) : nullptr;
     const int waves = grid;
+    if (grad && grad->rich && mode == WV_VJP && ni == 1) {   // the forward pass files its intermediates: the RICH instantiations
+        if (wave_fn r = pick_grad_rich(nh, is_id2(nd), wfn != nullptr)) { if (wfn) wfn = r; else fn = r; }
+        else return CNF_ERR_BAD_ARG;                       // (wave_grad_rich_floats said it exists)
+    }
     if (wfn) { fn = wfn; grid = 1; }
     WaveArgs a{};
     a.nd = nd; a.P = d_params; a.eps = eps; a.cond = cond; a.cbs = cbs; a.B = B;
@@ -1173,7 +1356,8 @@ cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_param
     if (!sv.xs && !sv.u0) return CNF_ERR_BAD_ARG;
     WvTab tab = kWvTab;
     void* args[] = {&a, &sv, &tab};
-    if (hipLaunchKernel((const void*)fn, dim3(grid), dim3(wfn ? 64 * waves : 64), args, 0, s) != hipSuccess) {
+    // (a gradient: the tile's main wave and its helper)
+    if (hipLaunchKernel((const void*)fn, dim3(grid), dim3(wfn ? 64 * waves : (grad ? 128 : 64)), args, 0, s) != hipSuccess) {
         (void)hipGetLastError();
         return CNF_ERR_UNSUPPORTED;
     }
