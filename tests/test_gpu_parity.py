@@ -846,7 +846,8 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
     kernels k_step3 / k_step3j instead of the split-bf16 ones), CNF_STEP_V1 /
     CNF_TRACE_GENERIC / CNF_ADJ_GENERIC (the first-generation kernels), CNF_WGRAD_LDS (the contraction with LDS images,
     k_wgrad_mfma_b, instead of the wave-local k_wgrad_wave), CNF_WAVE_GRAD=0 (the streamed gradient path for the small networks
-    k_solve_wave<GRAD> otherwise takes), CNF_WAVE_WG=0 (one workgroup per wave at small batches): read once per process; each
+    k_solve_wave<GRAD> otherwise takes), CNF_WAVE_WG=0 (one workgroup per wave at small batches), CNF_WAVE_RICH=0 (the gradient
+    recomputes the forward half of its stages): read once per process; each
     route runs its parity tests in a child process."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -857,7 +858,8 @@ def test_ab_switches_take_the_other_kernels_and_stay_parity_green():
                      ("CNF_BCAST=0", "test_config5_one_launch_solve_strict and 1000"),
                      ("CNF_WAVE_GRAD=0", "test_loss_grad_fixed_dt_matches_oracle or test_loss_grad_adaptive_jvp_cond or "
                                          "test_loss_grad_more_steps_than_the_trajectory_store or test_fit_readme_example"),
-                     ("CNF_WAVE_WG=0", "test_loss_grad_wave_local_small or test_one_layer_network or test_testmode_loss_gradient"),
+                     ("CNF_WAVE_WG=0", "test_wave_local_solve_small_networks or test_one_layer_network"),
+                     ("CNF_WAVE_RICH=0", "test_loss_grad_wave_local_small or test_submitted_gradients or test_one_layer_network"),
                      ("CNF_TRACE_SOLVE=0", "test_exact_trace_mfma_deep_networks or test_testmode_headline_network_is_three_launches"),
                      ("CNF_STEP_FP32", "test_adaptive_solve_vs_oracles and 3-mfma or test_full_size_cfg3_solve or "
                                        "test_jvp_mode_headline_shape_step_kernel or ragged or test_headline_kernels_strict"),
