@@ -23,6 +23,15 @@
 // TestMode (exact trace): the closed form of two-layer networks, tr J = sigma'_1^T (W_1 .* W_2^T) sigma'_2: one more product
 // against C = W_1 .* W_2^T instead of the reverse sweep.  Conditional models: the per-sample first-layer bias rows stay in
 // registers for the whole solve.
+//
+// Forms of the one kernel template (the comments at the template say what each does and what it measured):
+//   GRAD  loss_and_grad in the same launch: the discrete adjoint of the accepted steps behind the solve -- TrainMode in both
+//         compute modes (src/exts/mlj_ext/core_icnf.jl:59-73 at its batch_size of 32) and TestMode (the exact-trace adjoint:
+//         test/call_tests.jl, benchmark/benchmarks.jl) --, the weight-gradient tiles contracted by a HELPER wave (HELP) from
+//         factor tiles filed in LDS; RICH: the forward pass also files its evaluations' intermediates for the backward pass;
+//   ID2   the second activation is the identity (a PlanarLayer, or the identity layer cnf_create appends to a ONE-layer
+//         network: the network of the reference's benchmark suite);
+//   WGW   the tiles of a batch of at most 64 samples as the waves of one workgroup (LDS meeting), plain solves.
 #include <cstdlib>
 
 #include "cnf_wave.h"
