@@ -1689,6 +1689,25 @@ def test_submitted_gradients_equal_the_synchronous_ones():
     with pytest.raises(NotImplementedError):
         cnf.loss_and_grad_submit(ic, cnf.TrainMode(), _dev(np.zeros((cfg3.nvars, 8), np.float32)), f3, {})
     ic.close()
+    # a submitted launch that gives up (every wait of its 128 waves runs out after one poll): nothing downstream of it may see
+    # garbage -- zeros and a NaN loss are delivered, the collect reports it; the synchronous call falls back to the streamed path
+    ic = make_icnf(cnf, cfg, kernel="mfma")
+    ps = torch.from_numpy(flat0.copy()).cuda()
+    xs, eps = _dev(rng.standard_normal((8, 2048))), _dev(rng.standard_normal((16, 2048)))
+    ic.set_solve_wait(poll_limit=1)
+    lossd, g = cnf.loss_and_grad_submit(ic, cnf.TrainMode(), xs, ps, {}, eps=eps)
+    with pytest.raises(cnf.CNFError):
+        cnf.loss_and_grad_collect(ic)
+    torch.cuda.synchronize()
+    assert torch.isnan(lossd).all() and float(g.abs().max()) == 0.0
+    fb = ic.solve_fallbacks()
+    v, g2 = cnf.loss_and_grad(ic, cnf.TrainMode(), xs, ps, {}, eps=eps)          # (gives up as well, then the streamed gradient path)
+    assert ic.solve_fallbacks() == fb + 1 and ic.last_stats["launches"] > 2
+    ic.set_solve_wait(poll_limit=0x7fffffff)
+    v3, g3 = cnf.loss_and_grad(ic, cnf.TrainMode(), xs, ps, {}, eps=eps)
+    assert ic.last_stats["launches"] <= 2 and abs(v - v3) <= 1e-5 * max(1.0, abs(v3))
+    _assert_grad(g2.cpu().numpy(), g3.cpu().numpy().astype(np.float64), "streamed fallback vs in-launch gradient", rtol=5e-4)
+    ic.close()
     # fit: pipelined and synchronous loops end with the same parameters and report the same losses
     data = np.random.default_rng(3).beta(2.0, 4.0, size=(256, 2)).astype(np.float32)
     res = []
