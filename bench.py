@@ -283,7 +283,7 @@ def run_rank(args):
         os.environ.setdefault("CNF_PERSISTENT", "0")
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    comm, collective = None, "none (1 rank)"
+    comm, collective, rccl_attempt = None, "none (1 rank)", None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -307,6 +307,25 @@ def run_rank(args):
                 collective = "cnf_loss_allreduce (RCCL ncclAllReduce via the C ABI)"
             else:
                 comm = None
+        elif os.environ.get("CNF_BENCH_TRY_RCCL") == "1":
+            # rehearsal on one card: the C ABI's communicator is ATTEMPTED (RCCL refuses two ranks on one GPU: "Duplicate GPU
+            # detected"); whatever it answers, every rank must agree on the outcome and carry on over the rehearsal backend
+            ok, why = 1, ""
+            try:
+                comm = RcclComm.from_torch_group(dev_index)
+                ok = int(comm.size() == world)
+            except Exception as e:                                    # noqa: BLE001
+                ok, why = 0, f"{type(e).__name__}: {e}"
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag) == 1:
+                collective = "cnf_loss_allreduce (RCCL ncclAllReduce via the C ABI)"
+                rccl_attempt = "accepted"
+            else:
+                if comm is not None:
+                    comm.close()
+                comm = None
+                rccl_attempt = "refused, fell back to the rehearsal backend: " + why[-300:]
 
     wl = configs.BASELINE[3]
     B = args.batch
@@ -406,15 +425,17 @@ def run_rank(args):
     loss = cnf.loss_from_sums(icnf, mode, sums)
 
     ranks_seen, per_rank_ms, allreduce_us = 1, [elapsed / args.steps * 1e3], None
+    per_rank_loss = [loss]
     if world > 1:
         tdev = dev if backend == "nccl" else "cpu"
         t = torch.tensor([elapsed, float(nf_total), 1.0], dtype=torch.float64, device=tdev)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed, nf_all, ranks_seen = float(tmax[0]), float(tsum[1]), int(round(float(tsum[2])))
-        gathered = [torch.zeros(1, dtype=torch.float64, device=tdev) for _ in range(world)]
-        dist.all_gather(gathered, torch.tensor([local_elapsed / args.steps * 1e3], dtype=torch.float64, device=tdev))
-        per_rank_ms = [float(g) for g in gathered]
+        gathered = [torch.zeros(2, dtype=torch.float64, device=tdev) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([local_elapsed / args.steps * 1e3, loss], dtype=torch.float64, device=tdev))
+        per_rank_ms = [float(g[0]) for g in gathered]
+        per_rank_loss = [float(g[1]) for g in gathered]             # (every rank forms the loss from the all-reduced sums)
         # the collective by itself: 5 floats, latency-bound
         probe = torch.ones(5, dtype=torch.float32, device=dev)
         for _ in range(5):
@@ -541,7 +562,8 @@ def run_rank(args):
                        "global_batch": B * world, "parallelism": f"columns sharded x{world}",
                        "kernel": {1: "generic", 2: "mfma"}.get(st["kernel_used"], "?")},
             "ranks_seen": ranks_seen, "backend": backend if world > 1 else None, "collective": collective,
-            "per_rank_ms_per_step": per_rank_ms, "allreduce_us": allreduce_us,
+            "per_rank_ms_per_step": per_rank_ms, "per_rank_loss": per_rank_loss, "allreduce_us": allreduce_us,
+            "rccl_attempt": rccl_attempt,
             "sample_evals_per_s": nf_all / elapsed * B,
             "nf_per_solve": st["nf"], "naccept": st["naccept"], "nreject": st["nreject"],
             "launches_per_solve": st["launches"], "steps_in_flight": args.depth, "one_at_a_time": one_at_a_time, "loss": loss,

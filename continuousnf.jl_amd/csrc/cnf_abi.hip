@@ -1021,7 +1021,11 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                     stats->kernel_used = wave_ok ? CNF_KERNEL_MFMA : k;
                     stats->launches = launches;
                 }
-                if (fin.nonfinite) return fail(h, CNF_ERR_NONFINITE, "solver state became NaN/Inf");
+                if (fin.nonfinite) {
+                    // (the step sizes above may still be on their way into rec->hs, which the caller drops on this return)
+                    if (rec && rec->wg) HIPCHK(h, hipStreamSynchronize(st));
+                    return fail(h, CNF_ERR_NONFINITE, "solver state became NaN/Inf");
+                }
                 return CNF_OK;
             }
             // A workgroup did not arrive within the wait bound: something else holds CUs (another stream or process, a CU
@@ -1029,7 +1033,9 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             // u0 on the streamed driver below, which needs no co-residency.
             ++h->fallbacks;
             if (rec && rec->wg) { rec->wg_failed = true; return CNF_OK; }      // (the caller runs the streamed gradient path)
-            if (!fused_io && u0 == h->U[0])
+            // (u0 == h->U[0] was solved in place; it can only be rebuilt when the caller's data columns are still at hand --
+            // `inference_impl` passes them in post->xs, the streamed driver below assembles u0 from them again)
+            if (!fused_io && u0 == h->U[0] && !(post && post->xs))
                 return fail(h, CNF_ERR_HIP, "one-launch solve: a workgroup did not arrive and u0 was solved in place (set CNF_PERSISTENT=0)");
         } else if (s != CNF_ERR_UNSUPPORTED) return fail(h, s, "one-launch solve failed to start");
         persist_lock.unlock();
@@ -1884,6 +1890,11 @@ extern "C" cnf_status cnf_set_params_async(cnf_handle h, const float* flat_dev, 
     HIPCHK(h, hipSetDevice(h->device));
     if (g_submitted_inflight > 0 && g_submitted_stream != s)
         return fail(h, CNF_ERR_BAD_ARG, "cnf_set_params_async: launches are in flight on another stream");
+    // A submitted INFERENCE that gives up is run again by its collect call -- with the parameters (and conditioning) the handle
+    // holds then.  Changing them under it would silently change its result: such submissions are settled first (host wait).
+    // Submitted gradients are not re-run (a launch that gave up reports CNF_ERR_UNSUPPORTED), so they stay in flight.
+    for (const auto& sub : h->submitted)
+        if (sub.launched && !sub.grad) { const cnf_status ss = settle_submitted(h); if (ss != CNF_OK) return ss; break; }
     HIPCHK(h, hipMemcpyAsync(h->d_params, flat_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     cnf_status ms = mfma_plan_pack(h->mfma, h->nd, h->d_params, s);
     if (ms != CNF_OK) return fail(h, ms, "MFMA weight packing failed");

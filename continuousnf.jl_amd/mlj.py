@@ -27,31 +27,42 @@ class Lion:
     """Optimisers.Lion(eta = 0.001, beta = (0.9, 0.999)), the reference's default optimiser (core_icnf.jl:17).  Optimisers.jl
     is not in /root/reference, so the rule is restated, in two readings (``rule``):
 
-    * ``"paper"`` (default) -- Chen et al. 2023: x -= eta * sign(b1 m + (1 - b1) g), then m = b2 m + (1 - b2) g;
-    * ``"optimisers"`` -- the update as Optimisers.jl's source states it, from memory and unverifiable here: the state is
-      refreshed FIRST as ``b2 * g + (1 - b2) * state`` (with b2 = 0.999 it is the current gradient to a part in a thousand)
-      and the step is ``eta * sign((b2 - b1) * g + b1 * state)`` -- in effect sign-SGD.
+    * ``"optimisers"`` (default: the reference trains with ``Optimisers.Lion``, so its rule is the one a drop-in must run) --
+      the update as Optimisers.jl's source states it, from memory and unverifiable here: the state is refreshed FIRST as
+      ``b2 * g + (1 - b2) * state`` (with b2 = 0.999 it is the current gradient to a part in a thousand) and the step is
+      ``eta * sign((b2 - b1) * g + b1 * state)`` -- in effect sign-SGD;
+    * ``"paper"`` (opt-in) -- Chen et al. 2023: x -= eta * sign(b1 m + (1 - b1) g), then m = b2 m + (1 - b2) g.
 
-    Which of the two a given Optimisers.jl release runs decides whether the reference's regression configuration trains
-    at all (profiles/round4_training_ablation.md): the momentum form overshoots on the stiff tspan (0, 13) flow."""
+    The choice decides whether the reference's regression configuration trains at all (DESIGN 7.00,
+    profiles/round4_training_ablation.md): the momentum form overshoots on the stiff tspan (0, 13) flow.
+
+    ``apply(..., gate)``: a one-element device tensor (1.0 / 0.0); with 0 neither the parameters nor the state move -- a
+    submitted gradient whose launch gave up (zeros, NaN loss) must not be a momentum-only step."""
     eta: float = 1e-3
     beta: Tuple[float, float] = (0.9, 0.999)
-    rule: str = "paper"
+    rule: str = "optimisers"
 
     def init(self, ps):
         return {"m": ps.new_zeros(ps.shape)}
 
-    def apply(self, state, ps, g):
+    def apply(self, state, ps, g, gate=None):
         import torch
         b1, b2 = self.beta
+        m = state["m"]
         if self.rule == "optimisers":
-            state["m"].mul_(1 - b2).add_(g, alpha=b2)
-            ps.sub_(torch.sign(g * (b2 - b1) + state["m"] * b1), alpha=self.eta)
+            new_m = m * (1 - b2) + g * b2
+            step = torch.sign(g * (b2 - b1) + new_m * b1)
         elif self.rule == "paper":
-            ps.sub_(torch.sign(state["m"] * b1 + g * (1 - b1)), alpha=self.eta)
-            state["m"].mul_(b2).add_(g, alpha=1 - b2)
+            step = torch.sign(m * b1 + g * (1 - b1))
+            new_m = m * b2 + g * (1 - b2)
         else:
             raise ValueError("Lion.rule must be 'paper' or 'optimisers'")
+        if gate is not None:                                          # (where, not a product: a gated-off gradient may hold NaN)
+            on = gate > 0
+            step = torch.where(on, step, torch.zeros_like(step))
+            new_m = torch.where(on, new_m, m)
+        ps.sub_(step, alpha=self.eta)
+        m.copy_(new_m)
 
 
 @dataclass
@@ -62,16 +73,25 @@ class Adam:
     epsilon: float = 1e-8
 
     def init(self, ps):
-        return {"m": ps.new_zeros(ps.shape), "v": ps.new_zeros(ps.shape), "t": 0}
+        # (the step count lives on the device so that a gated-off step -- see Lion.apply -- does not advance it)
+        return {"m": ps.new_zeros(ps.shape), "v": ps.new_zeros(ps.shape), "t": ps.new_zeros(1)}
 
-    def apply(self, state, ps, g):
+    def apply(self, state, ps, g, gate=None):
         b1, b2 = self.beta
-        state["t"] += 1
-        state["m"].mul_(b1).add_(g, alpha=1 - b1)
-        state["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
-        mhat = state["m"] / (1 - b1 ** state["t"])
-        vhat = state["v"] / (1 - b2 ** state["t"])
-        ps.sub_(mhat / (vhat.sqrt() + self.epsilon), alpha=self.eta)
+        m, v, t = state["m"], state["v"], state["t"]
+        new_t = t + 1
+        new_m = m * b1 + g * (1 - b1)
+        new_v = v * b2 + g * g * (1 - b2)
+        mhat = new_m / (1 - b1 ** new_t)
+        vhat = new_v / (1 - b2 ** new_t)
+        step = mhat / (vhat.sqrt() + self.epsilon)
+        if gate is not None:
+            import torch
+            on = gate > 0
+            step = torch.where(on, step, torch.zeros_like(step))
+            new_m, new_v, new_t = torch.where(on, new_m, m), torch.where(on, new_v, v), torch.where(on, new_t, t)
+        ps.sub_(step, alpha=self.eta)
+        m.copy_(new_m); v.copy_(new_v); t.copy_(new_t)
 
 
 @dataclass
@@ -130,55 +150,83 @@ def fit(model: ICNFModel, verbosity: int, X, ys=None):
     # launch before the previous one -- the GPU goes from one gradient straight into the next.  Where the gradient does not run
     # in the launch of the solve (larger networks), or a submitted launch gives up, the loop below is the synchronous one.
     pipelined = model.callback is None and model.pipelined and x.is_cuda
-    pending = []                                                      # loss tensors of the launches still in flight
-    dev_losses = []
+    n_iter = len(model.optimizers) * model.n_epochs * ((n + bs - 1) // bs)
+    losses_dev = torch.full((max(1, n_iter),), float("nan"), dtype=torch.float32, device=x.device)   # one scalar per iteration: no gradient buffer is kept
+    pending = []                                                      # (loss index, batch indices) of the launches still in flight
+    redo = []                                                         # batches whose launch gave up: run again synchronously
+    was_pipelined = False
+    from . import _lib as _L
 
-    def drain(keep):
+    def fill_from_device():
+        vals = losses_dev[:len(losses)].cpu().numpy()
+        for i, v in enumerate(vals):
+            if np.isnan(losses[i]) and not np.isnan(v):
+                losses[i] = float(v)
+
+    def sync_step(opt, state, idx, slot):
+        xb = x[:, idx]
+        args = (xb, y[:, idx], ps, st) if y is not None else (xb, ps, st)
+        val, g = loss_and_grad(icnf, TrainMode(), *args)
+        opt.apply(state, ps, g)
+        losses[slot] = val
+        return val
+
+    def drain(keep, opt, state):
         nonlocal pipelined
         while len(pending) > keep:
-            pending.pop(0)
+            slot, idx = pending.pop(0)
             try:
                 loss_and_grad_collect(icnf)
-            except Exception:                                         # a launch gave up (zeros were applied: a lost step); go on synchronously
+            except _L.CNFError as e:
+                # Only "the launch gave up" (a wait ran out: CNF_ERR_UNSUPPORTED) is survivable: that launch delivered zeros and a
+                # NaN loss, its update was gated off on the device (no parameter or momentum moved), the launches queued behind it
+                # give up too (the abort word stays set until the host has collected) and are gated off the same way.  All of them
+                # run again below, synchronously.  NaN states, MAXITERS and HIP errors are the caller's to see.
+                if e.status != _L.ERR_UNSUPPORTED:
+                    raise
                 pipelined = False
+                redo.append((slot, idx))
+        if not pipelined:
+            while redo and not pending:
+                slot, idx = redo.pop(0)
+                sync_step(opt, state, idx, slot)
     for opt in model.optimizers:                                      # core_icnf.jl:64-73
         state = opt.init(ps)
         for _epoch in range(model.n_epochs):
             perm = torch.from_numpy(icnf.rng.permutation(n)).to(x.device)     # shuffle = true
             for lo in range(0, n, bs):                                # partial = true
                 idx = perm[lo:lo + bs]
-                xb = x[:, idx]
-                args = (xb, y[:, idx], ps, st) if y is not None else (xb, ps, st)
                 if pipelined:
+                    xb = x[:, idx]
+                    args = (xb, y[:, idx], ps, st) if y is not None else (xb, ps, st)
                     try:
                         lossd, g = loss_and_grad_submit(icnf, TrainMode(), *args)
                     except NotImplementedError:
                         pipelined = False
                 if pipelined:
-                    opt.apply(state, ps, g)
-                    pending.append(lossd)
-                    dev_losses.append((len(losses), lossd))
-                    losses.append(float("nan"))                       # filled in from the device at the end
+                    opt.apply(state, ps, g, gate=torch.isfinite(lossd).to(g.dtype))
+                    losses_dev[len(losses)].copy_(lossd[0])
+                    was_pipelined = True
+                    pending.append((len(losses), idx))
+                    losses.append(float("nan"))                       # filled in from the device (per epoch when printing, else at the end)
                     it += 1
-                    drain(1)
+                    drain(1, opt, state)
                     continue
-                drain(0)
-                val, g = loss_and_grad(icnf, TrainMode(), *args)
-                opt.apply(state, ps, g)
-                losses.append(val)
+                drain(0, opt, state)
+                losses.append(float("nan"))
+                val = sync_step(opt, state, idx, len(losses) - 1)
                 it += 1
                 if model.callback is not None:
                     model.callback(it, val)
             if verbosity > 0:
                 k = max(1, (n + bs - 1) // bs)
-                print(f"epoch {_epoch + 1}/{model.n_epochs}: mean loss {np.mean(losses[-k:]):.5f}", flush=True)
-    drain(0)
+                drain(0, opt, state)
+                fill_from_device()
+                print(f"epoch {_epoch + 1}/{model.n_epochs}: mean loss {np.nanmean(losses[-k:]):.5f}", flush=True)
+        drain(0, opt, state)
     torch.cuda.synchronize(x.device)
-    if dev_losses:
-        vals = torch.cat([t for _, t in dev_losses]).cpu().numpy()
-        for (i, _), v in zip(dev_losses, vals):
-            losses[i] = float(v)
-    report = {"stats": {"time": time.perf_counter() - t0, "iterations": it, "pipelined": bool(dev_losses)}, "losses": np.asarray(losses)}
+    fill_from_device()
+    report = {"stats": {"time": time.perf_counter() - t0, "iterations": it, "pipelined": was_pipelined}, "losses": np.asarray(losses)}
     return (ps.cpu().numpy(), st), None, report
 
 

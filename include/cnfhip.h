@@ -282,7 +282,8 @@ cnf_status cnf_loss_grad_submit(cnf_handle h, int mode, const float* xs, const f
                                 float* loss_dev, float* grad, void* stream);
 cnf_status cnf_loss_grad_collect(cnf_handle h, cnf_solve_stats* stats);
 /* cnf_set_params (device pointer) without its host waits: copy and packing are enqueued on `stream`.  For callers whose every
- * launch on this handle goes to that one stream. */
+ * launch on this handle goes to that one stream.  Submitted GRADIENTS stay in flight across it (they are never run again);
+ * submitted INFERENCES are settled first (a host wait), because one that gave up is run again with the handle's parameters. */
 cnf_status cnf_set_params_async(cnf_handle h, const float* flat_dev, size_t n, void* stream);
 /* The signed sizes of the steps the last cnf_loss_grad on this handle accepted (the discrete map
  * it differentiated): writes min(n, cap) floats to hs (may be NULL) and returns n. */

@@ -2121,6 +2121,37 @@ def test_one_launch_solve_gives_up_within_its_time_bound_when_cus_are_held():
     ic.close()
 
 
+def test_testmode_one_launch_solve_falls_back_to_the_streamed_driver():
+    """ADVICE round 4 (cnf_abi.hip, solve_core): TestMode of the headline network runs k_trace3s<SOLVE> on a state that was
+    assembled in the integrator's own buffer (no fused I/O).  When a wait of that launch runs out the call must rebuild u0
+    from the caller's data columns and run on the streamed driver -- it used to return CNF_ERR_HIP.  poll_limit = 1 makes
+    every wait run out at its first poll, so the abort path is taken for certain."""
+    if not _one_launch_expected():
+        pytest.skip("the one-launch solve is switched off in this process")
+    cfg, _, _ = O.baseline_cfg(3)
+    rng = np.random.default_rng(1650)
+    B = 2048
+    flat = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    xs = _dev(rng.standard_normal((cfg.nvars, B)))
+    tol = dict(reltol=3.45e-4, abstol=1.19e-7)
+    ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=tol)
+    want, _ = cnf.inference(ic, cnf.TestMode(), xs, flat, {})
+    one = ic.last_stats["launches"]
+    want = want.clone()
+    fb0 = ic.solve_fallbacks()
+    ic.set_solve_wait(poll_limit=1)
+    got, _ = cnf.inference(ic, cnf.TestMode(), xs, flat, {})
+    torch.cuda.synchronize()
+    if one <= 3:                                                 # the one-launch TestMode solve is what ran the first time
+        assert ic.solve_fallbacks() - fb0 == 1 and ic.last_stats["launches"] > 3, ic.last_stats
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got, want, rtol=5e-3, atol=5e-3), float((got - want).abs().max())
+    ic.set_solve_wait(poll_limit=0x7fffffff)
+    again, _ = cnf.inference(ic, cnf.TestMode(), xs, flat, {})
+    assert ic.last_stats["launches"] == one and torch.equal(again, want)
+    ic.close()
+
+
 @pytest.mark.parametrize("dims,nvars,naugs,acts", [
     ((2, 6, 2), 1, 1, ("tanh", "tanh")),                      # BASELINE config 1 (README.md:47)
     ((16, 48, 16), 8, 8, ("tanh", "tanh")),                   # BASELINE config 2 (test/regression_tests.jl:7)

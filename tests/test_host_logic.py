@@ -188,15 +188,33 @@ def test_param_file_roundtrip_and_optimisers(tmp_path):
     (tmp_path / "cut.cnfp").write_bytes(raw[:-4])
     with pytest.raises(ValueError):
         cnf.load_params(tmp_path / "cut.cnfp")
-    # Lion: sign update with the interpolated momentum; Adam: bias-corrected first step = eta * sign(g)
-    x = torch.tensor([1.0, -2.0, 0.5])
+    # Lion: the default is the rule of Optimisers.jl (the reference's optimiser, core_icnf.jl:17): state refreshed first with
+    # weight b2 on the gradient, then the sign step; "paper" = Chen et al.: sign step with the interpolated momentum, then the
+    # state refreshed with weight 1 - b2.  Adam: bias-corrected first step = eta * sign(g).
     g = torch.tensor([0.3, -0.1, 0.0])
-    o = cnf.Lion(eta=0.1)
-    stt = o.init(x)
-    o.apply(stt, x, g)
-    assert torch.allclose(x, torch.tensor([0.9, -1.9, 0.5])) and torch.allclose(stt["m"], 0.001 * g)
+    assert cnf.Lion().rule == "optimisers"
+    for rule, m_w in (("optimisers", 0.999), ("paper", 0.001)):
+        x = torch.tensor([1.0, -2.0, 0.5])
+        o = cnf.Lion(eta=0.1, rule=rule)
+        stt = o.init(x)
+        o.apply(stt, x, g)
+        assert torch.allclose(x, torch.tensor([0.9, -1.9, 0.5])) and torch.allclose(stt["m"], m_w * g)
+        # second step with a small opposite gradient g' = -g / 500: the paper's rule still follows its momentum
+        # (0.9 * 0.001 g outweighs 0.1 g'), Optimisers.jl's follows the new gradient (its state IS the new gradient)
+        o.apply(stt, x, -g / 500)
+        want = torch.tensor([1.0, -2.0, 0.5]) if rule == "optimisers" else torch.tensor([0.8, -1.8, 0.5])
+        assert torch.allclose(x, want), (rule, x)
+        # a gated-off step moves neither the parameters nor the state, whatever the gradient holds
+        x0, m0 = x.clone(), stt["m"].clone()
+        o.apply(stt, x, torch.tensor([float("nan"), 1.0, -1.0]), gate=torch.zeros(1))
+        assert torch.equal(x, x0) and torch.equal(stt["m"], m0)
     x = torch.tensor([1.0, -2.0])
     o = cnf.Adam(eta=0.1)
     stt = o.init(x)
     o.apply(stt, x, torch.tensor([0.3, -0.1]))
     assert torch.allclose(x, torch.tensor([0.9, -1.9]), atol=1e-6)
+    x0 = x.clone()
+    o.apply(stt, x, torch.tensor([float("nan"), 0.0]), gate=torch.zeros(1))
+    assert torch.equal(x, x0) and float(stt["t"]) == 1.0
+    o.apply(stt, x, torch.tensor([0.3, -0.1]), gate=torch.ones(1))
+    assert float(stt["t"]) == 2.0 and torch.allclose(x, torch.tensor([0.8, -1.8]), atol=1e-5)
