@@ -97,6 +97,7 @@ _SIGNATURES = {
     "cnf_comm_destroy": (C.c_int, [C.c_void_p]),
     "cnf_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "cnf_comm_allreduce": (C.c_int, [C.c_void_p, _fp, C.c_size_t, C.c_void_p]),
+    "cnf_comm_device_key": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "cnf_comm_last_error": (C.c_char_p, []),
     "cnf_comm_library": (C.c_char_p, []),
     "cnf_loss_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, _fp, C.c_void_p]),

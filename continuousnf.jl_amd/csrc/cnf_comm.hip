@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -89,6 +90,34 @@ extern "C" const char* cnf_comm_last_error(void) { return t_err.c_str(); }
 extern "C" const char* cnf_comm_library(void) {
     const Rccl* r = rccl();
     return r ? r->path.c_str() : "";
+}
+
+// "<hostname>/<pci bus id>" of a device: what the ranks exchange BEFORE cnf_comm_init to make sure that no two of them sit
+// on one GPU.  RCCL 2.26 does not survive that: through torch's communicator it answers ncclInvalidUsage ("Duplicate GPU
+// detected"), through a plain ncclCommInitRank both ranks were seen to block for good (gpurun_out/r5b2.log) -- and a blocked
+// ncclCommInitRank cannot be cancelled.  The check therefore belongs to the caller's bootstrap, where the ranks can still talk.
+extern "C" cnf_status cnf_comm_device_key(int device, char* out, size_t cap) {
+    if (!out || cap < 2) return CNF_ERR_BAD_ARG;
+    out[0] = 0;
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { t_err = "no current device"; return CNF_ERR_NO_DEVICE; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { t_err = "no gfx950 device"; return CNF_ERR_NO_DEVICE; }
+    if (dev >= ndev) { t_err = "device ordinal out of range"; return CNF_ERR_BAD_ARG; }
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) { t_err = "hipDeviceGetPCIBusId failed"; return CNF_ERR_HIP; }
+    char host[128] = {0};
+    if (gethostname(host, sizeof host - 1) != 0) snprintf(host, sizeof host, "?");
+    // (two containers of one machine may share a hostname or not; the boot id tells machines apart where it is readable)
+    char boot[64] = {0};
+    if (FILE* f = fopen("/proc/sys/kernel/random/boot_id", "r")) {
+        if (!fgets(boot, sizeof boot, f)) boot[0] = 0;
+        fclose(f);
+        for (char* c = boot; *c; ++c) if (*c == '\n') *c = 0;
+    }
+    const int n = snprintf(out, cap, "%s|%s/%s", host, boot, bus);
+    if (n < 0 || (size_t)n >= cap) { t_err = "key buffer too small"; return CNF_ERR_BAD_ARG; }
+    return CNF_OK;
 }
 
 extern "C" cnf_status cnf_comm_unique_id(char* id) {

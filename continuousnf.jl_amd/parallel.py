@@ -65,12 +65,31 @@ class RcclComm:
             raise _lib.CNFError(st, l.cnf_comm_last_error().decode())
         return buf.raw
 
+    @staticmethod
+    def device_key(device: int) -> str:
+        """cnf_comm_device_key: "<hostname>|<boot id>/<pci bus id>" of ``device``."""
+        from . import _lib
+        import ctypes as C
+        buf = C.create_string_buffer(192)
+        l = _lib.lib()
+        st = l.cnf_comm_device_key(device, buf, len(buf))
+        if st != _lib.OK:
+            raise _lib.CNFError(st, l.cnf_comm_last_error().decode())
+        return buf.value.decode()
+
     @classmethod
     def from_torch_group(cls, device: int, group=None):
         """Bootstrap over an initialised torch.distributed group (any backend): rank 0 draws the id,
         the group broadcasts the 128 bytes."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+        # No two ranks on one GPU: RCCL refuses that at best and blocks for good at worst (cnf_comm_device_key, cnfhip.h), so it
+        # is settled here, where the ranks can still talk -- every rank sees every key and all of them fail together.
+        keys = [None] * world
+        dist.all_gather_object(keys, cls.device_key(device), group=group)
+        if len(set(keys)) != world:
+            dup = sorted(k for k in set(keys) if keys.count(k) > 1)
+            raise RuntimeError(f"RCCL needs one GPU per rank: ranks share {dup} (ranks by device: {keys})")
         uid, err = None, None
         if rank == 0:
             try:

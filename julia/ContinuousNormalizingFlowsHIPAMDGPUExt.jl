@@ -10,7 +10,7 @@
 # ROCArray that inference_sol slices on the device (src/base_icnf.jl:173-188).
 module ContinuousNormalizingFlowsHIPAMDGPUExt
 
-import AMDGPU, SciMLBase
+import AMDGPU, ComponentArrays, SciMLBase
 import ContinuousNormalizingFlows as CNF
 import ContinuousNormalizingFlows: ICNF, AbstractICNF, TrainMode, TestMode, rng_AT, base_AT, base_sol
 import ..ContinuousNormalizingFlowsHIPExt as HIPExt
@@ -22,6 +22,12 @@ import ..ContinuousNormalizingFlowsHIPExt: ROCmLibs, HIPMatrixMode, libcnfhip, h
 @inline function base_AT(::ROCmLibs, ::AbstractICNF{T}, dims...) where {T <: AbstractFloat}
     AMDGPU.ROCArray{T}(undef, dims...)
 end
+
+# `fit` / `transform` of the MLJ extension keep data, parameters and states on the device for this resource: the ROCm reading of
+# `Lux.gpu_device()` in the CUDALibs branch of src/exts/mlj_ext/core_icnf.jl:32-41, 96-101
+HIPExt.move(::ROCmLibs, x::AbstractArray{<:AbstractFloat}) = AMDGPU.ROCArray(x)
+HIPExt.move(::ROCmLibs, x::ComponentArrays.ComponentArray) =
+    ComponentArrays.ComponentArray(AMDGPU.ROCArray(ComponentArrays.getdata(x)), ComponentArrays.getaxes(x))
 
 devptr(x::AMDGPU.ROCArray{Float32}) = Base.unsafe_convert(Ptr{Float32}, x)     # device address of element 1
 raw_stream() = Base.unsafe_convert(Ptr{Cvoid}, AMDGPU.stream())                # hipStream_t of the task-local stream (from memory)

@@ -40,6 +40,11 @@ struct ROCmLibs <: ComputationalResources.AbstractResource end
     Array{T}(undef, dims...)
 end
 
+# Where `fit` / `transform` put their arrays for a resource (julia/ContinuousNormalizingFlowsHIPMLJExt.jl): the counterpart of
+# the `tdev` the reference picks by `resource isa CUDALibs` (src/exts/mlj_ext/core_icnf.jl:32-36, 96-100).  Host arrays here;
+# the AMDGPU extension adds the device method for ROCmLibs.
+move(::Any, x) = x
+
 # ---- compute modes (src/types.jl:17-23 pattern) ------------------------------------------
 abstract type HIPMatrixMode{ADBack} <: MatrixMode{ADBack} end
 struct HIPVecJacMatrixMode <: HIPMatrixMode{Nothing} end   # <-> DIVecJacMatrixMode
@@ -206,6 +211,11 @@ end
 # socket, MPI.bcast); every rank then builds the communicator and reduces the five sums of cnf_loss_sums in place.
 comm_unique_id() = (id = Vector{UInt8}(undef, 128);
     check(@ccall(libcnfhip.cnf_comm_unique_id(id::Ptr{UInt8})::Cint), C_NULL); id)
+# "<hostname>|<boot id>/<pci bus id>" of a device: exchange these over the same channel as the id and stop if two ranks hold the
+# same key -- RCCL does not accept two ranks on one GPU, and a blocked ncclCommInitRank cannot be cancelled (cnfhip.h)
+comm_device_key(device::Integer) = (buf = Vector{UInt8}(undef, 192);
+    check(@ccall(libcnfhip.cnf_comm_device_key(device::Cint, buf::Ptr{UInt8}, length(buf)::Csize_t)::Cint), C_NULL);
+    unsafe_string(pointer(buf)))
 function comm_init(world_size::Integer, rank::Integer, id::Vector{UInt8}, device::Integer)
     c = Ref{Ptr{Cvoid}}(C_NULL)
     check(@ccall(libcnfhip.cnf_comm_init(c::Ptr{Ptr{Cvoid}}, world_size::Cint, rank::Cint, id::Ptr{UInt8},
@@ -251,9 +261,10 @@ end
 # analytic gradient of the OptimizationFunction instead of `model.adtype`:
 #     optfunc = SciMLBase.OptimizationFunction(make_opt_loss(model.m, TrainMode(), st, model.loss);
 #                   grad = (G, u, data) -> (G .= last(loss_and_grad(model.m, first(data), u, st))))
-function loss_and_grad(icnf::ICNF{T, <:HIPMatrixMode}, xs::AbstractMatrix{<:Real}, ps, st) where {T}
+function loss_and_grad(icnf::ICNF{T, <:HIPMatrixMode}, xs::AbstractMatrix{<:Real}, ps, st;
+        params_resident::Bool = false) where {T}
     h = handle(icnf)
-    set_params!(h, ps; force = true)
+    params_resident || set_params!(h, ps; force = true)      # (an upload drops the handle's conditioning: cnf_set_params, cnfhip.h)
     x = Matrix{Float32}(xs)
     B = size(x, 2)
     n_in = icnf.nvars + icnf.naugmented
@@ -269,6 +280,16 @@ function loss_and_grad(icnf::ICNF{T, <:HIPMatrixMode}, xs::AbstractMatrix{<:Real
                                               Ref(opts)::Ptr{CnfSolveOpts}, val::Ref{Float32}, grad::Ptr{Float32},
                                               stats::Ref{CnfSolveStats})::Cint), h)
     val[], grad
+end
+
+# Conditional models (src/exts/mlj_ext/core.jl:17-20: `loss_(icnf, mode, xs, ys, u, st)`): the conditioning columns are handed to
+# the handle first (cnf_set_cond_host), the gradient is w.r.t. all of ps -- the first layer's `ys` columns included.
+function loss_and_grad(icnf::ICNF{T, <:HIPMatrixMode}, xs::AbstractMatrix{<:Real}, ys::AbstractMatrix{<:Real}, ps, st) where {T}
+    h = handle(icnf)
+    set_params!(h, ps; force = true)
+    y = Matrix{Float32}(ys)
+    check(@ccall(libcnfhip.cnf_set_cond_host(h::Ptr{Cvoid}, y::Ptr{Float32}, size(y, 2)::Cint)::Cint), h)
+    loss_and_grad(icnf, xs, ps, st; params_resident = true)
 end
 
 # The other derivative the package's call tests and benchmark suite take (test/call_tests.jl `diff_loss` with omode = TestMode(),

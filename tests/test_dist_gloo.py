@@ -117,6 +117,10 @@ def _comm_worker(rank, world, port, fake, q):
         bad = C.c_void_p()
         assert l.cnf_comm_init(C.byref(bad), world, world, box[0], -1) == _lib.ERR_BAD_ARG
         assert l.cnf_comm_destroy(comm) == _lib.OK
+        # the key the ranks compare before cnf_comm_init: no device here, so a status code (and an empty key), not a crash
+        key = C.create_string_buffer(192)
+        assert l.cnf_comm_device_key(0, key, len(key)) in (_lib.ERR_NO_DEVICE, _lib.ERR_HIP) and key.value == b""
+        assert l.cnf_comm_device_key(0, None, 0) == _lib.ERR_BAD_ARG
         q.put((rank, out, l.cnf_comm_library().decode()))
     finally:
         dist.destroy_process_group()
