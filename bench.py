@@ -258,6 +258,10 @@ def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CNF_BENCH_WATCHDOG"):
+        # a rank that is still running after this many seconds prints every thread's Python stack and exits (rehearsals, tests)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["CNF_BENCH_WATCHDOG"]), exit=True)
     # one rank per GPU; CNF_BENCH_BACKEND=gloo lets several ranks share one card for a rehearsal
     backend = os.environ.get("CNF_BENCH_BACKEND", "nccl")
     if os.environ.get("CNF_BENCH_DRYRUN") == "1":
@@ -361,9 +365,12 @@ def run_rank(args):
 
     # hold the clocks: `--prewarm` seconds of the same steps first (the driver's K and W can be a handful: 20 solves are
     # 15 ms, which would sit on the DVFS ramp), then the W counted warm-up steps
+    # (the pre-warm is bounded by each rank's own clock, so ranks run DIFFERENT numbers of it: nothing collective may be in
+    # it -- a rank still all-reducing while its peer has moved on to the barrier below is a deadlock, seen in the two-rank
+    # rehearsal of round 5.  Local solves only; the counted warm-up steps and the timed steps carry the all-reduce.)
     tw = time.perf_counter()
     while time.perf_counter() - tw < args.prewarm:
-        step()
+        cnf.inference(icnf, mode, xs, ps, {}, eps=eps, with_sums=True)
     for _ in range(args.warmup):
         step()
     sync()

@@ -93,9 +93,9 @@ extern "C" const char* cnf_comm_library(void) {
 }
 
 // "<hostname>/<pci bus id>" of a device: what the ranks exchange BEFORE cnf_comm_init to make sure that no two of them sit
-// on one GPU.  RCCL 2.26 does not survive that: through torch's communicator it answers ncclInvalidUsage ("Duplicate GPU
-// detected"), through a plain ncclCommInitRank both ranks were seen to block for good (gpurun_out/r5b2.log) -- and a blocked
-// ncclCommInitRank cannot be cancelled.  The check therefore belongs to the caller's bootstrap, where the ranks can still talk.
+// on one GPU.  RCCL 2.26 answers that with ncclInvalidUsage ("Duplicate GPU detected", gpurun_out/rccl2.log) from inside
+// ncclCommInitRank -- after its own bootstrap, on every rank, with the failed communicator's resources to clean up.  Settling it
+// in the caller's bootstrap, where the ranks can still talk, gives every rank the same plain answer before RCCL is entered.
 extern "C" cnf_status cnf_comm_device_key(int device, char* out, size_t cap) {
     if (!out || cap < 2) return CNF_ERR_BAD_ARG;
     out[0] = 0;

@@ -83,11 +83,12 @@ class RcclComm:
         the group broadcasts the 128 bytes."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        # No two ranks on one GPU: RCCL refuses that at best and blocks for good at worst (cnf_comm_device_key, cnfhip.h), so it
-        # is settled here, where the ranks can still talk -- every rank sees every key and all of them fail together.
+        # No two ranks on one GPU: RCCL refuses that from inside ncclCommInitRank (cnf_comm_device_key, cnfhip.h); it is settled
+        # here, where the ranks can still talk -- every rank sees every key and all of them fail together, before RCCL is entered.
         keys = [None] * world
         dist.all_gather_object(keys, cls.device_key(device), group=group)
-        if len(set(keys)) != world:
+        import os
+        if len(set(keys)) != world and os.environ.get("CNF_COMM_ALLOW_SHARED_GPU") != "1":     # (the switch: to see RCCL's own answer)
             dup = sorted(k for k in set(keys) if keys.count(k) > 1)
             raise RuntimeError(f"RCCL needs one GPU per rank: ranks share {dup} (ranks by device: {keys})")
         uid, err = None, None

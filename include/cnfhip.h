@@ -228,8 +228,8 @@ cnf_status cnf_comm_init(cnf_comm* out, int world_size, int rank,
 cnf_status cnf_comm_destroy(cnf_comm comm);
 /* "<hostname>|<boot id>/<pci bus id>" of `device` (< 0: the current one), NUL-terminated into out[cap] (128 bytes suffice).
  * The ranks exchange these keys over their own bootstrap BEFORE cnf_comm_init and must not go on when two are equal: RCCL
- * does not accept two ranks on one GPU (ncclInvalidUsage "Duplicate GPU detected" at best; a plain ncclCommInitRank was
- * seen to block for good, and it cannot be cancelled).  No reference counterpart (the reference has no multi-GPU code). */
+ * does not accept two ranks on one GPU (ncclInvalidUsage "Duplicate GPU detected" out of ncclCommInitRank, on every rank, after
+ * its bootstrap).  No reference counterpart (the reference has no multi-GPU code). */
 cnf_status cnf_comm_device_key(int device, char* out, size_t cap);
 cnf_status cnf_comm_size(cnf_comm comm, int* world_size);                     /* ncclCommCount */
 /* In-place sum over the ranks of n DEVICE floats, stream-ordered (ncclAllReduce). */

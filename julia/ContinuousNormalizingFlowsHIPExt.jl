@@ -212,7 +212,7 @@ end
 comm_unique_id() = (id = Vector{UInt8}(undef, 128);
     check(@ccall(libcnfhip.cnf_comm_unique_id(id::Ptr{UInt8})::Cint), C_NULL); id)
 # "<hostname>|<boot id>/<pci bus id>" of a device: exchange these over the same channel as the id and stop if two ranks hold the
-# same key -- RCCL does not accept two ranks on one GPU, and a blocked ncclCommInitRank cannot be cancelled (cnfhip.h)
+# same key -- RCCL does not accept two ranks on one GPU (cnfhip.h)
 comm_device_key(device::Integer) = (buf = Vector{UInt8}(undef, 192);
     check(@ccall(libcnfhip.cnf_comm_device_key(device::Cint, buf::Ptr{UInt8}, length(buf)::Csize_t)::Cint), C_NULL);
     unsafe_string(pointer(buf)))
