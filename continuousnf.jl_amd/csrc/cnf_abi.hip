@@ -95,6 +95,8 @@ struct cnf_ctx {
     bool pt_valid = false;
     bool img_valid = false;       // d_adj_img holds the images of the current parameters
     float* d_bimg = nullptr;      // k_solve_bcast's images (cnf_bcast.hip), packed on first use after a parameter change
+    float* d_bstore = nullptr;    // ... and the store of its tiles' Runge-Kutta rows when a workgroup carries several (bcast_store_floats)
+    size_t bstore_floats = 0;
     bool bimg_valid = false;
     bool trace_on = false;        // this call evaluates through an auxiliary MFMA kernel (cnf_trace.hip) behind the generic driver
     bool aux_train = false;       //   false: TestMode exact trace; true: TrainMode JVP
@@ -284,6 +286,7 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (h->d_PT) (void)hipFree(h->d_PT);
     if (h->d_adj_img) (void)hipFree(h->d_adj_img);
     if (h->d_bimg) (void)hipFree(h->d_bimg);
+    if (h->d_bstore) (void)hipFree(h->d_bstore);
     if (h->grad_arena) (void)hipFree(h->grad_arena);
     if (h->traj) (void)hipFree(h->traj);
     if (h->traj_hs) (void)hipFree(h->traj_hs);
@@ -895,6 +898,13 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
     if (bcast_ok && !lockstep && !h->no_persist) {
         if (!h->d_bimg) HIPCHK(h, hipMalloc(&h->d_bimg, bcast_img_floats() * sizeof(float)));
         if (!h->bimg_valid) { bcast_pack(h->nd, h->d_params, h->d_bimg, st); HIPCHK(h, hipGetLastError()); h->bimg_valid = true; }
+        const size_t need = bcast_store_floats(B, h->device);        // several tiles per workgroup: their rows live in global memory
+        if (need > h->bstore_floats) {
+            HIPCHK(h, hipStreamSynchronize(st));
+            if (h->d_bstore) { (void)hipFree(h->d_bstore); h->d_bstore = nullptr; h->bstore_floats = 0; }
+            HIPCHK(h, hipMalloc(&h->d_bstore, need * sizeof(float)));
+            h->bstore_floats = need;
+        }
     }
     // ... or of the 32-128-128-32 network in TestMode (exact trace: k_trace3s<SOLVE>, cnf_trace.hip)
     const bool tsolve_ok = trace_fused && !wave_ok && !bcast_ok && !use_mfma && (!h->nd.n_cond) &&
@@ -958,7 +968,8 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             if (s != CNF_OK) (void)hipGetLastError();
         }
         if (bcast_ok)
-            s = bcast_solve_launch(h->nd, train != 0, h->d_params, h->d_bimg, h->d_state, h->U[0], eps, B, st, h->d_mirror + mslot, base, sv, h->device);
+            s = bcast_solve_launch(h->nd, train != 0, h->d_params, h->d_bimg, h->d_state, h->U[0], eps, B, st, h->d_mirror + mslot, base, sv, h->device,
+                                   h->d_bstore, h->nd.n_cond > 0 ? h->d_cond : nullptr, h->cbs);
         if (s == CNF_ERR_UNSUPPORTED && use_mfma)
             s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror + mslot, base, sv, h->device,
                                       dump, n, slot, dcap, h->traj_hs, h->K1);

@@ -7,8 +7,13 @@
 size_t bcast_img_floats();
 // the packed weight images (resident fragments, the W2 streams, C = W1 .* W2^T) from the flat parameter vector
 void bcast_pack(const NetDesc& nd, const float* d_params, float* d_img, hipStream_t s);
-// this network, compute mode and batch (at most 8 columns per CU of `device`)
+// this network, compute mode and batch: any batch (beyond 8 columns per CU of `device` every workgroup carries several tiles and
+// their Runge-Kutta rows live in a store in global memory: bcast_store_floats); conditional models with one tile per workgroup
 bool bcast_solve_supported(const NetDesc& nd, bool train, int B, int device);
-// sv as for mfma_solve_persistent; CNF_ERR_UNSUPPORTED: not this network / batch
+// floats of the tile store such a launch needs (0: none)
+size_t bcast_store_floats(int B, int device);
+// sv as for mfma_solve_persistent; CNF_ERR_UNSUPPORTED: not this network / batch.  store: bcast_store_floats(B) floats or null;
+// cond / cbs: the per-sample first-layer bias of a conditional model ([B][cbs]) or null
 cnf_status bcast_solve_launch(const NetDesc& nd, bool train, const float* d_params, const float* d_img, StepState* st_out, float* U0,
-                              const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, const Solve3Args& sv, int device);
+                              const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, const Solve3Args& sv, int device,
+                              float* store = nullptr, const float* cond = nullptr, int cbs = 0);

@@ -45,6 +45,9 @@ struct BcArgs {
     StepState* st_out;
     void* mirror;
     unsigned seq;
+    float* store;          // MULTI: the tiles' Runge-Kutta rows (bcast_store_floats)
+    const float* cond;     // conditional models: the per-sample first-layer bias W1y ys + b1, [B][cbs]   (src/base_icnf.jl:288-309)
+    int cbs;
 };
 struct BcTab { float a[7][8]; };
 static const BcTab kBcTab = {{
@@ -71,6 +74,13 @@ static const BcTab kBcTab = {{
 //              streams at all.
 constexpr int BC_NRES = 384;
 constexpr int BC_VJP = 0, BC_TESTM = 1, BC_JVP = 2;       // kernel modes
+// MULTI (more tiles than the device holds workgroups: B > 8 x CUs): every workgroup carries several 8-sample tiles, one after the
+// other per stage, and their Runge-Kutta rows live in a store in global memory instead of registers / LDS -- per tile
+// BC_TROWS rows of 256 x f32x4 in the owner threads' own order (a thread only ever reads what it wrote itself: no visibility
+// question, fully coalesced 4 KB rows, L2 / MALL resident) and 8 x 32 scalars.  Rows: u and k1 twice (accepted / candidate, by the
+// parity `cur` -- an accepted step flips it, nothing is copied), k2..k6, the probe:
+constexpr int BC_TROWS = 10, BC_R_U = 0, BC_R_K1 = 2, BC_R_K2 = 4, BC_R_EP = 9;
+constexpr int BC_TSC = 8 * 32;                             // scalars per tile: [sample][row 0..8: u x2, k1 x2, k2..k6][3], padded to 32
 __host__ __device__ constexpr int bc_slen(int mode) { return mode == BC_VJP ? 96 : (mode == BC_TESTM ? 48 : 0); }
 __host__ __device__ constexpr int bc_wave_floats(int mode) { return (BC_NRES + 4 * bc_slen(mode)) * 64; }
 constexpr int BC_TRAIN = 0, BC_TEST = 4 * bc_wave_floats(BC_VJP), BC_JVPI = BC_TEST + 4 * bc_wave_floats(BC_TESTM),
@@ -154,7 +164,7 @@ struct I1 { static constexpr int value = 1; };
 struct I2 { static constexpr int value = 2; };
 struct I3 { static constexpr int value = 3; };
 
-template <int MODE>
+template <int MODE, bool MULTI>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
     constexpr bool TEST = MODE == BC_TESTM, JVP = MODE == BC_JVP;
@@ -163,7 +173,8 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
     constexpr int NLB = JVP ? 3 : 4;                       // 16-register blocks of the resident set that live in LDS
     __shared__ __attribute__((aligned(16))) float Aimg[NK][2][24][64];      // the next product's A operands: [kind][sample group][16 k's][lane 4 j + s]
     __shared__ __attribute__((aligned(16))) float Pbuf[NK][6][2][2][64][4]; // partial outputs: [kind][tile][K half][sample group][feature][4 samples]
-    __shared__ __attribute__((aligned(16))) float Kz[7][256][4];           // Runge-Kutta rows k1..k7 of the z rows, next to their owner threads
+    __shared__ __attribute__((aligned(16))) float Kz[MULTI ? 1 : 7][256][4]; // Runge-Kutta rows k1..k7 of the z rows, next to their owner threads (MULTI: in the store)
+    __shared__ __attribute__((aligned(16))) float cbias[JVP || MULTI ? 1 : 384][8];   // conditional models: this tile's first-layer bias, [hidden unit][sample]
     __shared__ __attribute__((aligned(16))) float red[4][2][3][4];          // per wave, sample group, quantity: 4 samples
     __shared__ __attribute__((aligned(16))) float wBL[4][NLB][4][64][4];     // the last resident B registers of each wave: [wave][block][quad][lane][4] (a lane's quad = one ds_read_b128)
     __shared__ float Ssc[8][8][3];                                           // scalar rows: [sample][u, k1..k7][dlogp, E, n]
@@ -214,10 +225,16 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
     const int ot = tid >> 7, of = (tid & 127) >> 1, osg = tid & 1;
     const int ok_row = 64 * ot + of;                       // feature
     const bool orow_ok = ok_row < n_in;
-    const int smp0 = blockIdx.x * 8 + 4 * osg;             // first of this thread's 4 samples
+    int tile = blockIdx.x;                                 // the 8-sample tile being worked on (MULTI: blockIdx.x, + gridDim.x, ...)
+    int smp0 = tile * 8 + 4 * osg;                         // first of this thread's 4 samples
     float omask[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) omask[s] = (orow_ok && smp0 + s < a.B) ? 1.f : 0.f;
+    auto set_tile = [&](int t) __attribute__((always_inline)) {
+        tile = t; smp0 = t * 8 + 4 * osg;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) omask[s] = (orow_ok && smp0 + s < a.B) ? 1.f : 0.f;
+    };
     float* const aimg_own = &Aimg[0][osg][ok_row >> 4][4 * (ok_row & 15)];
     // 384-row arrays: three (tile, feature, sample group) units per thread
     int h_t[3], h_f[3], h_sg[3];
@@ -232,25 +249,40 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
     const float b2v = orow_ok ? a.P[nd.b_off[1] + ok_row] : 0.f;
     // state of the owned z rows; probes
     f32x4 uz = zero4, ep = zero4;
+    auto load_u0 = [&]() __attribute__((always_inline)) {   // (of the current tile)
+        uz = zero4; ep = zero4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        if (omask[s] != 0.f) {
-            const size_t sb = (size_t)(smp0 + s);
-            if (sv.xs) uz[s] = ok_row < sv.nvars ? sv.xs[sb * sv.nvars + ok_row] : 0.f;
-            else uz[s] = sv.u0[sb * D + ok_row];
-            if (!TEST) ep[s] = a.eps[sb * n_in + ok_row];
+        for (int s = 0; s < 4; ++s) {
+            if (omask[s] != 0.f) {
+                const size_t sb = (size_t)(smp0 + s);
+                if (sv.xs) uz[s] = ok_row < sv.nvars ? sv.xs[sb * sv.nvars + ok_row] : 0.f;
+                else uz[s] = sv.u0[sb * D + ok_row];
+                if (!TEST) ep[s] = a.eps[sb * n_in + ok_row];
+            }
+        }
+    };
+    if (!MULTI) {
+        load_u0();
+#pragma unroll
+        for (int j = 0; j < (MULTI ? 1 : 7); ++j) *(f32x4*)Kz[j][tid] = zero4;
+        if (tid < 8) {
+            const int smp = blockIdx.x * 8 + tid;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Ssc[tid][j][q] = 0.f;
+            if (!sv.xs && smp < a.B)
+                for (int q = 0; q < NS; ++q) Ssc[tid][0][q] = sv.u0[(size_t)smp * D + n_in + q];
         }
     }
-#pragma unroll
-    for (int j = 0; j < 7; ++j) *(f32x4*)Kz[j][tid] = zero4;
-    if (tid < 8) {
-        const int smp = blockIdx.x * 8 + tid;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) Ssc[tid][j][q] = 0.f;
-        if (!sv.xs && smp < a.B)
-            for (int q = 0; q < NS; ++q) Ssc[tid][0][q] = sv.u0[(size_t)smp * D + n_in + q];
+    // conditional models: nn(vcat(z, ys)) -- the conditioning columns of W1 act as a per-sample bias that the handle forms once per
+    // call (cnf_set_cond); the tile's 8 x nh of them are staged in LDS once per solve and replace b1 in the first elementwise phase
+    const bool has_cond = !JVP && !MULTI && a.cond != nullptr;
+    if (has_cond) {
+        for (int idx = tid; idx < 8 * 384; idx += 256) {
+            const int s8 = idx / 384, r = idx - 384 * s8, smp = blockIdx.x * 8 + s8;
+            cbias[JVP || MULTI ? 0 : r][s8] = (r < nh && smp < a.B) ? a.cond[(size_t)smp * a.cbs + r] : 0.f;
+        }
     }
     const bool even = (wave & 1) == 0;
 
@@ -353,11 +385,13 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
         f32x4 ldc = zero4, n2c = zero4, e2c = zero4;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const f32x4 v = *(const f32x4*)Pbuf[0][h_t[i]][0][h_sg[i]][h_f[i]] + *(const f32x4*)Pbuf[0][h_t[i]][1][h_sg[i]][h_f[i]] + b1v[i];
+            const int k = 64 * h_t[i] + h_f[i];
+            f32x4 v = *(const f32x4*)Pbuf[0][h_t[i]][0][h_sg[i]][h_f[i]] + *(const f32x4*)Pbuf[0][h_t[i]][1][h_sg[i]][h_f[i]];
+            if (has_cond) v += *(const f32x4*)&cbias[JVP || MULTI ? 0 : k][4 * h_sg[i]];
+            else v += b1v[i];
             f32x4 h;
 #pragma unroll
             for (int s = 0; s < 4; ++s) { h[s] = tanh_fast(v[s]); d1[i][s] = fmaf(-h[s], h[s], 1.f); }
-            const int k = 64 * h_t[i] + h_f[i];
             *(f32x4*)&Aimg[0][h_sg[i]][k >> 4][4 * (k & 15)] = h;
             if (JVP) {                                     // tau1 = sigma'_1 .* (W1 eps)
                 const f32x4 w = *(const f32x4*)Pbuf[NK - 1][h_t[i]][0][h_sg[i]][h_f[i]] + *(const f32x4*)Pbuf[NK - 1][h_t[i]][1][h_sg[i]][h_f[i]];
@@ -493,117 +527,13 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
     const int my_s = tid & 7;                              // scalar owner threads: tid < 8 (sample tid)
     const bool s_live = tid < 8 && blockIdx.x * 8 + tid < a.B;
 
-    bool alive = true;
-    {
-        // ---- k1 = f(u0); automatic initial dt ----
-        float e = 0.f, b = 0.f;
-        f32x4 k1;
-        rhs(uz, k1);
-        bc_bar();
-        *(f32x4*)Kz[0][tid] = k1;
-        if (tid < 8) for (int q = 0; q < NS; ++q) Ssc[tid][1][q] = msc[8 * q + my_s];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) if (omask[s] != 0.f) { add_norm(e, uz[s], uz[s]); add_norm(b, uz[s], k1[s]); }
-        if (s_live) for (int q = 0; q < NS; ++q) { add_norm(e, Ssc[tid][0][q], Ssc[tid][0][q]); add_norm(b, Ssc[tid][0][q], Ssc[tid][1][q]); }
-        if (sv.hairer) alive = meet(e, b);
-        if (sv.hairer && alive) {
-            ctrl_phase(&ns, 0, p0, p1, a.n_total);
-            after_ctrl();
-            e = 0.f;
-            f32x4 f1;
-            rhs(uz + hstep * k1, f1);
-            bc_bar();
-#pragma unroll
-            for (int s = 0; s < 4; ++s) if (omask[s] != 0.f) add_norm(e, uz[s], f1[s] - k1[s]);
-            if (s_live) for (int q = 0; q < NS; ++q) add_norm(e, Ssc[tid][0][q], msc[8 * q + my_s] - Ssc[tid][1][q]);
-            alive = meet(e, 0.f);
-            if (alive) { ctrl_phase(&ns, 1, p0, p1, a.n_total); after_ctrl(); }
-        }
-    }
-    constexpr float BT[7] = {TS_BT1, TS_BT2, TS_BT3, TS_BT4, TS_BT5, TS_BT6, TS_BT7};
-    f32x4 zt = zero4;
-    for (int it = 0; alive && !__builtin_amdgcn_readfirstlane(ns.done) && it < sv.maxiters; ++it) {
-        float errsum = 0.f, badcnt = 0.f;
-#pragma unroll 1
-        for (int s = 1; s <= 6; ++s) {
-            float as[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) as[j] = tab.a[s][j];
-            f32x4 acc = as[0] * *(const f32x4*)Kz[0][tid];
-#pragma unroll
-            for (int j = 1; j < 6; ++j) acc += as[j] * *(const f32x4*)Kz[j][tid];     // (rows beyond the stage are zero or stale times a zero coefficient)
-            zt = uz + hstep * acc;
-            f32x4 zd;
-            rhs(zt, zd);
-            bc_bar();
-            *(f32x4*)Kz[s][tid] = zd;
-            if (tid < 8) for (int q = 0; q < NS; ++q) Ssc[tid][1 + s][q] = msc[8 * q + my_s];
-        }
-        // the new solution is the last stage state (a_7j = b_j); error estimate
-        {
-            f32x4 ez = BT[0] * *(const f32x4*)Kz[0][tid];
-#pragma unroll
-            for (int j = 1; j < 7; ++j) ez += BT[j] * *(const f32x4*)Kz[j][tid];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                if (omask[s] != 0.f) {
-                    const float scl = fmaf(fmaxf(fabsf(uz[s]), fabsf(zt[s])), reltol, abstol);
-                    const float x = hstep * ez[s] / scl;
-                    errsum = fmaf(x, x, errsum);
-                    badcnt += !(fabsf(zt[s]) <= 3.0e38f) ? 1.f : 0.f;
-                }
-        }
-        float uns[3] = {0.f, 0.f, 0.f};
-        if (tid < 8) {
-            for (int q = 0; q < NS; ++q) {
-                float acc = 0.f, es = 0.f;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc = fmaf(tab.a[6][j], Ssc[tid][1 + j][q], acc);
-#pragma unroll
-                for (int j = 0; j < 7; ++j) es = fmaf(BT[j], Ssc[tid][1 + j][q], es);
-                const float us = Ssc[tid][0][q];
-                uns[q] = us + hstep * acc;
-                if (s_live) {
-                    const float scl = fmaf(fmaxf(fabsf(us), fabsf(uns[q])), reltol, abstol);
-                    const float x = hstep * es / scl;
-                    errsum = fmaf(x, x, errsum);
-                    badcnt += !(fabsf(uns[q]) <= 3.0e38f) ? 1.f : 0.f;
-                }
-            }
-        }
-#ifdef BC_STAMPS
-        bt_ = __builtin_amdgcn_s_memtime();
-#endif
-        alive = meet(errsum, badcnt);
-        BC_T(7)
-        if (!alive) break;
-        const int acc0 = ns.naccept;
-        const float t_att = ns.t, h_att = ns.h;
-        ctrl_after_step(&ns, p0, p1, a.n_total);
-        const bool accepted = __builtin_amdgcn_readfirstlane(ns.naccept != acc0);
-        if (sv.trace && blockIdx.x == 0 && tid == 0 && it < sv.trace_cap) {
-            float* tr = sv.trace + 4 * it;
-            tr[0] = t_att; tr[1] = h_att; tr[2] = ns.eest; tr[3] = accepted ? 1.f : 0.f;
-        }
-        after_ctrl();
-        if (accepted) {                                    // u <- u_new, k1 <- k7
-            uz = zt;
-            *(f32x4*)Kz[0][tid] = *(const f32x4*)Kz[6][tid];
-            if (tid < 8) for (int q = 0; q < NS; ++q) { Ssc[tid][0][q] = uns[q]; Ssc[tid][1][q] = Ssc[tid][7][q]; }
-        }
-    }
-    // ---- final state ----
-    float* out = sv.u_out ? sv.u_out : a.U0;
-    if (alive || !sv.u_out) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) if (omask[s] != 0.f) out[(size_t)(smp0 + s) * D + ok_row] = uz[s];
-        if (s_live) for (int q = 0; q < NS; ++q) out[(size_t)(blockIdx.x * 8 + tid) * D + n_in + q] = Ssc[tid][0][q];
-    }
-    if (sv.logpx && alive) {
-        // inference_sol (src/base_icnf.jl:167-189)
+    // ---- inference_sol (src/base_icnf.jl:167-189) of one tile: logp(z) - dlogp, the regulariser rows, |z_aug|; the four loss sums
+    // of the workgroup's tiles accumulate in v4 (owner threads tid < 8) ----
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
+    auto post_tile = [&](const f32x4& uzt, float sc0, float sc1, float sc2, bool slive) __attribute__((always_inline)) {
         f32x4 ssc, sac;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { ssc[s] = uz[s] * uz[s]; sac[s] = ok_row >= sv.nvars ? uz[s] * uz[s] : 0.f; }
+        for (int s = 0; s < 4; ++s) { ssc[s] = uzt[s] * uzt[s]; sac[s] = ok_row >= sv.nvars ? uzt[s] * uzt[s] : 0.f; }
         bc_bar();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -611,19 +541,289 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
             if (lane < 2) { red[wave][lane][0][s] = x; red[wave][lane][1][s] = y; }
         }
         bc_bar();
-        float v4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (s_live) {
+        if (slive) {
             const int g = tid >> 2, s = tid & 3;
             const float ss = (red[0][g][0][s] + red[1][g][0][s]) + (red[2][g][0][s] + red[3][g][0][s]);
             const float sa = (red[0][g][1][s] + red[1][g][1][s]) + (red[2][g][1][s] + red[3][g][1][s]);
             const float log2pi = 1.8378770664093453f;
-            const float lp = -0.5f * fmaf((float)n_in, log2pi, ss) - Ssc[tid][0][0];
+            const float lp = -0.5f * fmaf((float)n_in, log2pi, ss) - sc0;
             const float aa = (sv.norm_z_aug && sv.naugs > 0) ? sqrtf(sa) : 0.f;
-            const float Ev = TEST ? 0.f : Ssc[tid][0][1], Nv = TEST ? 0.f : Ssc[tid][0][2];
-            const size_t bb = (size_t)blockIdx.x * 8 + tid, Bz = (size_t)a.B;
+            const float Ev = TEST ? 0.f : sc1, Nv = TEST ? 0.f : sc2;
+            const size_t bb = (size_t)tile * 8 + tid, Bz = (size_t)a.B;
             sv.logpx[bb] = lp; sv.regs[bb] = Ev; sv.regs[Bz + bb] = Nv; sv.regs[2 * Bz + bb] = aa;
-            v4[0] = lp; v4[1] = Ev; v4[2] = Nv; v4[3] = aa;
+            v4[0] += lp; v4[1] += Ev; v4[2] += Nv; v4[3] += aa;
         }
+    };
+    bool alive = true;
+    if constexpr (!MULTI) {
+        {
+            // ---- k1 = f(u0); automatic initial dt ----
+            float e = 0.f, b = 0.f;
+            f32x4 k1;
+            rhs(uz, k1);
+            bc_bar();
+            *(f32x4*)Kz[0][tid] = k1;
+            if (tid < 8) for (int q = 0; q < NS; ++q) Ssc[tid][1][q] = msc[8 * q + my_s];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) if (omask[s] != 0.f) { add_norm(e, uz[s], uz[s]); add_norm(b, uz[s], k1[s]); }
+            if (s_live) for (int q = 0; q < NS; ++q) { add_norm(e, Ssc[tid][0][q], Ssc[tid][0][q]); add_norm(b, Ssc[tid][0][q], Ssc[tid][1][q]); }
+            if (sv.hairer) alive = meet(e, b);
+            if (sv.hairer && alive) {
+                ctrl_phase(&ns, 0, p0, p1, a.n_total);
+                after_ctrl();
+                e = 0.f;
+                f32x4 f1;
+                rhs(uz + hstep * k1, f1);
+                bc_bar();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) if (omask[s] != 0.f) add_norm(e, uz[s], f1[s] - k1[s]);
+                if (s_live) for (int q = 0; q < NS; ++q) add_norm(e, Ssc[tid][0][q], msc[8 * q + my_s] - Ssc[tid][1][q]);
+                alive = meet(e, 0.f);
+                if (alive) { ctrl_phase(&ns, 1, p0, p1, a.n_total); after_ctrl(); }
+            }
+        }
+        constexpr float BT[7] = {TS_BT1, TS_BT2, TS_BT3, TS_BT4, TS_BT5, TS_BT6, TS_BT7};
+        f32x4 zt = zero4;
+        for (int it = 0; alive && !__builtin_amdgcn_readfirstlane(ns.done) && it < sv.maxiters; ++it) {
+            float errsum = 0.f, badcnt = 0.f;
+#pragma unroll 1
+            for (int s = 1; s <= 6; ++s) {
+                float as[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) as[j] = tab.a[s][j];
+                f32x4 acc = as[0] * *(const f32x4*)Kz[0][tid];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) acc += as[j] * *(const f32x4*)Kz[j][tid];     // (rows beyond the stage are zero or stale times a zero coefficient)
+                zt = uz + hstep * acc;
+                f32x4 zd;
+                rhs(zt, zd);
+                bc_bar();
+                *(f32x4*)Kz[s][tid] = zd;
+                if (tid < 8) for (int q = 0; q < NS; ++q) Ssc[tid][1 + s][q] = msc[8 * q + my_s];
+            }
+            // the new solution is the last stage state (a_7j = b_j); error estimate
+            {
+                f32x4 ez = BT[0] * *(const f32x4*)Kz[0][tid];
+#pragma unroll
+                for (int j = 1; j < 7; ++j) ez += BT[j] * *(const f32x4*)Kz[j][tid];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (omask[s] != 0.f) {
+                        const float scl = fmaf(fmaxf(fabsf(uz[s]), fabsf(zt[s])), reltol, abstol);
+                        const float x = hstep * ez[s] / scl;
+                        errsum = fmaf(x, x, errsum);
+                        badcnt += !(fabsf(zt[s]) <= 3.0e38f) ? 1.f : 0.f;
+                    }
+            }
+            float uns[3] = {0.f, 0.f, 0.f};
+            if (tid < 8) {
+                for (int q = 0; q < NS; ++q) {
+                    float acc = 0.f, es = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc = fmaf(tab.a[6][j], Ssc[tid][1 + j][q], acc);
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) es = fmaf(BT[j], Ssc[tid][1 + j][q], es);
+                    const float us = Ssc[tid][0][q];
+                    uns[q] = us + hstep * acc;
+                    if (s_live) {
+                        const float scl = fmaf(fmaxf(fabsf(us), fabsf(uns[q])), reltol, abstol);
+                        const float x = hstep * es / scl;
+                        errsum = fmaf(x, x, errsum);
+                        badcnt += !(fabsf(uns[q]) <= 3.0e38f) ? 1.f : 0.f;
+                    }
+                }
+            }
+#ifdef BC_STAMPS
+            bt_ = __builtin_amdgcn_s_memtime();
+#endif
+            alive = meet(errsum, badcnt);
+            BC_T(7)
+            if (!alive) break;
+            const int acc0 = ns.naccept;
+            const float t_att = ns.t, h_att = ns.h;
+            ctrl_after_step(&ns, p0, p1, a.n_total);
+            const bool accepted = __builtin_amdgcn_readfirstlane(ns.naccept != acc0);
+            if (sv.trace && blockIdx.x == 0 && tid == 0 && it < sv.trace_cap) {
+                float* tr = sv.trace + 4 * it;
+                tr[0] = t_att; tr[1] = h_att; tr[2] = ns.eest; tr[3] = accepted ? 1.f : 0.f;
+            }
+            after_ctrl();
+            if (accepted) {                                    // u <- u_new, k1 <- k7
+                uz = zt;
+                *(f32x4*)Kz[0][tid] = *(const f32x4*)Kz[6][tid];
+                if (tid < 8) for (int q = 0; q < NS; ++q) { Ssc[tid][0][q] = uns[q]; Ssc[tid][1][q] = Ssc[tid][7][q]; }
+            }
+        }
+        // ---- final state ----
+        float* out = sv.u_out ? sv.u_out : a.U0;
+        if (alive || !sv.u_out) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) if (omask[s] != 0.f) out[(size_t)(smp0 + s) * D + ok_row] = uz[s];
+            if (s_live) for (int q = 0; q < NS; ++q) out[(size_t)(blockIdx.x * 8 + tid) * D + n_in + q] = Ssc[tid][0][q];
+        }
+        if (sv.logpx && alive) post_tile(uz, Ssc[my_s][0][0], Ssc[my_s][0][1], Ssc[my_s][0][2], s_live);
+    } else {
+        // ================= several tiles per workgroup: the Runge-Kutta rows in the store =================
+        const int ntiles = (a.B + 7) / 8;
+        f32x4* const rows = reinterpret_cast<f32x4*>(a.store);
+        float* const gsc = a.store + (size_t)ntiles * BC_TROWS * 1024 + 32 * tid;      // + BC_TSC * tile: the scalar rows of sample `tid` (tid < 8)
+        auto trow = [&](int r) -> f32x4* { return rows + ((size_t)tile * BC_TROWS + r) * 256 + tid; };
+        auto tlive = [&]() { return tid < 8 && tile * 8 + tid < a.B; };
+        int cur = 0;                                       // accepted u / k1 are rows BC_R_U + cur, BC_R_K1 + cur (scalars: rows cur, 2 + cur)
+        {
+            // ---- u0 and the probes into the store; k1 = f(u0); automatic initial dt ----
+            float e = 0.f, b = 0.f;
+            for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+                set_tile(t);
+                load_u0();
+                *trow(BC_R_U) = uz;
+                if (!TEST) *trow(BC_R_EP) = ep;
+                float* gs = gsc + (size_t)BC_TSC * t;
+                float su[3] = {0.f, 0.f, 0.f};
+                if (tid < 8) {
+                    if (!sv.xs && tlive()) for (int q = 0; q < NS; ++q) su[q] = sv.u0[(size_t)(t * 8 + tid) * D + n_in + q];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) gs[j] = j < 3 ? su[j] : 0.f;
+                }
+                f32x4 k1;
+                rhs(uz, k1);
+                bc_bar();
+                *trow(BC_R_K1) = k1;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) if (omask[s] != 0.f) { add_norm(e, uz[s], uz[s]); add_norm(b, uz[s], k1[s]); }
+                if (tid < 8) {
+                    for (int q = 0; q < NS; ++q) {
+                        const float kq = msc[8 * q + my_s];
+                        gs[3 * 2 + q] = kq;
+                        if (tlive()) { add_norm(e, su[q], su[q]); add_norm(b, su[q], kq); }
+                    }
+                }
+            }
+            if (sv.hairer) alive = meet(e, b);
+            if (sv.hairer && alive) {
+                ctrl_phase(&ns, 0, p0, p1, a.n_total);
+                after_ctrl();
+                e = 0.f;
+                for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+                    set_tile(t);
+                    uz = *trow(BC_R_U);
+                    const f32x4 k1 = *trow(BC_R_K1);
+                    if (!TEST) ep = *trow(BC_R_EP);
+                    f32x4 f1;
+                    rhs(uz + hstep * k1, f1);
+                    bc_bar();
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) if (omask[s] != 0.f) add_norm(e, uz[s], f1[s] - k1[s]);
+                    if (tlive()) {
+                        const float* gs = gsc + (size_t)BC_TSC * t;
+                        for (int q = 0; q < NS; ++q) add_norm(e, gs[q], msc[8 * q + my_s] - gs[3 * 2 + q]);
+                    }
+                }
+                alive = meet(e, 0.f);
+                if (alive) { ctrl_phase(&ns, 1, p0, p1, a.n_total); after_ctrl(); }
+            }
+        }
+        constexpr float BT[7] = {TS_BT1, TS_BT2, TS_BT3, TS_BT4, TS_BT5, TS_BT6, TS_BT7};
+        for (int it = 0; alive && !__builtin_amdgcn_readfirstlane(ns.done) && it < sv.maxiters; ++it) {
+            float errsum = 0.f, badcnt = 0.f;
+#pragma unroll 1
+            for (int s = 1; s <= 6; ++s) {
+                float as[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) as[j] = tab.a[s][j];
+                for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+                    set_tile(t);
+                    // the rows of the stages done so far (k_j, j < s: row BC_R_K1 + cur, then BC_R_K2 ...; the others are not
+                    // read: the store is not initialised), all requested at once
+                    uz = *trow(BC_R_U + cur);
+                    if (!TEST) ep = *trow(BC_R_EP);
+                    f32x4 kk[6];
+                    kk[0] = *trow(BC_R_K1 + cur);
+#pragma unroll
+                    for (int j = 1; j < 6; ++j) kk[j] = j < s ? *trow(BC_R_K2 + j - 1) : zero4;
+                    f32x4 acc = as[0] * kk[0];
+#pragma unroll
+                    for (int j = 1; j < 6; ++j) acc += as[j] * kk[j];
+                    const f32x4 zt = uz + hstep * acc;
+                    f32x4 ezp = zero4;                     // the error estimate's share of k1..k6 (the last stage adds k7)
+                    if (s == 6) {
+                        ezp = BT[0] * kk[0];
+#pragma unroll
+                        for (int j = 1; j < 6; ++j) ezp += BT[j] * kk[j];
+                        *trow(BC_R_U + (cur ^ 1)) = zt;    // the candidate solution is the last stage state (a_7j = b_j)
+                    }
+                    f32x4 zd;
+                    rhs(zt, zd);
+                    bc_bar();
+                    *trow(s < 6 ? BC_R_K2 + s - 1 : BC_R_K1 + (cur ^ 1)) = zd;
+                    float* gs = gsc + (size_t)BC_TSC * t;
+                    if (tid < 8) for (int q = 0; q < NS; ++q) gs[3 * (s < 6 ? 3 + s : 2 + (cur ^ 1)) + q] = msc[8 * q + my_s];
+                    if (s == 6) {
+                        const f32x4 ez = ezp + BT[6] * zd;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x)
+                            if (omask[x] != 0.f) {
+                                const float scl = fmaf(fmaxf(fabsf(uz[x]), fabsf(zt[x])), reltol, abstol);
+                                const float y = hstep * ez[x] / scl;
+                                errsum = fmaf(y, y, errsum);
+                                badcnt += !(fabsf(zt[x]) <= 3.0e38f) ? 1.f : 0.f;
+                            }
+                        if (tid < 8) {
+                            for (int q = 0; q < NS; ++q) {
+                                float kq[7];
+                                kq[0] = gs[3 * (2 + cur) + q];
+#pragma unroll
+                                for (int j = 1; j < 6; ++j) kq[j] = gs[3 * (3 + j) + q];
+                                kq[6] = msc[8 * q + my_s];
+                                float acq = 0.f, es = 0.f;
+#pragma unroll
+                                for (int j = 0; j < 6; ++j) acq = fmaf(tab.a[6][j], kq[j], acq);
+#pragma unroll
+                                for (int j = 0; j < 7; ++j) es = fmaf(BT[j], kq[j], es);
+                                const float us = gs[3 * cur + q];
+                                const float un = us + hstep * acq;
+                                gs[3 * (cur ^ 1) + q] = un;
+                                if (tlive()) {
+                                    const float scl = fmaf(fmaxf(fabsf(us), fabsf(un)), reltol, abstol);
+                                    const float y = hstep * es / scl;
+                                    errsum = fmaf(y, y, errsum);
+                                    badcnt += !(fabsf(un) <= 3.0e38f) ? 1.f : 0.f;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            alive = meet(errsum, badcnt);
+            if (!alive) break;
+            const int acc0 = ns.naccept;
+            const float t_att = ns.t, h_att = ns.h;
+            ctrl_after_step(&ns, p0, p1, a.n_total);
+            const bool accepted = __builtin_amdgcn_readfirstlane(ns.naccept != acc0);
+            if (sv.trace && blockIdx.x == 0 && tid == 0 && it < sv.trace_cap) {
+                float* tr = sv.trace + 4 * it;
+                tr[0] = t_att; tr[1] = h_att; tr[2] = ns.eest; tr[3] = accepted ? 1.f : 0.f;
+            }
+            after_ctrl();
+            if (accepted) cur ^= 1;                        // u <- u_new, k1 <- k7: the other set of rows
+        }
+        // ---- final state, post-processing ----
+        float* out = sv.u_out ? sv.u_out : a.U0;
+        for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+            set_tile(t);
+            uz = *trow(BC_R_U + cur);
+            const float* gs = gsc + (size_t)BC_TSC * t;
+            float sc[3] = {0.f, 0.f, 0.f};
+            if (tid < 8) for (int q = 0; q < NS; ++q) sc[q] = gs[3 * cur + q];
+            if (alive || !sv.u_out) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) if (omask[s] != 0.f) out[(size_t)(smp0 + s) * D + ok_row] = uz[s];
+                if (tlive()) for (int q = 0; q < NS; ++q) out[(size_t)(t * 8 + tid) * D + n_in + q] = sc[q];
+            }
+            if (sv.logpx && alive) post_tile(uz, sc[0], sc[1], sc[2], tlive());
+        }
+    }
+    if (sv.logpx && alive) {
         if (sv.sums5) {
             unsigned long long* qb = reinterpret_cast<unsigned long long*>(sv.part) + 2048;
             const unsigned tag = mbase + (unsigned)nsync + 1u;
@@ -703,27 +903,52 @@ static int bcast_resident(int device) {
 }
 
 bool bcast_solve_supported(const NetDesc& nd, bool train, int B, int device) {
-    if (nd.n_layers != 2 || nd.acts[0] != 1 || nd.acts[1] != 1 || nd.n_cond > 0) return false;
+    if (nd.n_layers != 2 || nd.acts[0] != 1 || nd.acts[1] != 1) return false;
     if (nd.n_in <= 64 || nd.n_in > 128 || nd.dims[1] <= 256 || nd.dims[1] > 384) return false;
     static const bool off = [] { const char* e = getenv("CNF_PERSISTENT"); const char* w = getenv("CNF_BCAST"); return (e && e[0] == '0') || (w && w[0] == '0'); }();
-    if (off) return false;
-    return B >= 1 && (B + 7) / 8 <= bcast_resident(device);
+    if (off || B < 1) return false;
+    const int res = bcast_resident(device);
+    if (res <= 0) return false;
+    const bool multi = (B + 7) / 8 > res;
+    // conditional models: the per-sample first-layer bias is staged in LDS per tile -- one tile per workgroup, VJP / TestMode
+    if (nd.n_cond > 0 && (multi || (train && nd.jvp))) return false;
+    return true;
+}
+
+// floats of the tile store a launch needs (0: every workgroup owns one tile, the rows stay on the CU)
+size_t bcast_store_floats(int B, int device) {
+    const int res = bcast_resident(device), ntiles = (B + 7) / 8;
+    if (res <= 0 || ntiles <= res) return 0;
+    return (size_t)ntiles * (BC_TROWS * 1024 + BC_TSC);
 }
 
 cnf_status bcast_solve_launch(const NetDesc& nd, bool train, const float* d_params, const float* d_img, StepState* st_out, float* U0,
-                              const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, const Solve3Args& sv_, int device) {
+                              const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, const Solve3Args& sv_, int device,
+                              float* store, const float* cond, int cbs) {
     if (!bcast_solve_supported(nd, train, B, device) || !d_img) return CNF_ERR_UNSUPPORTED;
+    const int res = bcast_resident(device), ntiles = (B + 7) / 8;
+    const bool multi = ntiles > res;
+    if (multi && !store) return CNF_ERR_BAD_ARG;
+    if (nd.n_cond > 0 && !cond) return CNF_ERR_BAD_ARG;
     BcArgs a{};
     a.nd = nd; a.P = d_params; a.img = d_img; a.eps = eps; a.B = B;
     a.n_total = (float)((size_t)(nd.n_in + (train ? 3 : 1)) * B);
     a.U0 = U0; a.st_out = st_out; a.mirror = mirror; a.seq = seq;
+    a.store = store; a.cond = nd.n_cond > 0 ? cond : nullptr; a.cbs = cbs;
     Solve3Args sv = sv_;
     sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
     if (!sv.xs && !sv.u0) return CNF_ERR_BAD_ARG;
+    const int grid = multi ? res : ntiles;
+    if (multi) {                                           // (a wait lasts as long as the slowest workgroup's tiles take)
+        const unsigned long long w = (unsigned long long)sv.wait_ticks * (unsigned)((ntiles + grid - 1) / grid);
+        sv.wait_ticks = w > 2000000000ull ? 2000000000u : (unsigned)w;
+    }
     BcTab tab = kBcTab;
     void* args[] = {&a, &sv, &tab};
-    const void* fn = !train ? (const void*)k_solve_bcast<BC_TESTM> : (nd.jvp ? (const void*)k_solve_bcast<BC_JVP> : (const void*)k_solve_bcast<BC_VJP>);
-    if (hipLaunchKernel(fn, dim3((B + 7) / 8), dim3(256), args, 0, s) != hipSuccess) {
+    const void* fn;
+    if (multi) fn = !train ? (const void*)k_solve_bcast<BC_TESTM, true> : (nd.jvp ? (const void*)k_solve_bcast<BC_JVP, true> : (const void*)k_solve_bcast<BC_VJP, true>);
+    else fn = !train ? (const void*)k_solve_bcast<BC_TESTM, false> : (nd.jvp ? (const void*)k_solve_bcast<BC_JVP, false> : (const void*)k_solve_bcast<BC_VJP, false>);
+    if (hipLaunchKernel(fn, dim3(grid), dim3(256), args, 0, s) != hipSuccess) {
         (void)hipGetLastError();
         return CNF_ERR_UNSUPPORTED;
     }

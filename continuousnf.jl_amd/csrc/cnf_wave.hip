@@ -33,6 +33,8 @@
 //         network: the network of the reference's benchmark suite);
 //   WGW   the tiles of a batch of at most 64 samples as the waves of one workgroup (LDS meeting), plain solves.
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "cnf_wave.h"
 #include "cnf_mfma_dev.h"
@@ -152,7 +154,11 @@ __global__ void __launch_bounds__(GRAD && WGW == 1 ? 128 : 64 * WGW) k_solve_wav
     constexpr bool TRAIN = MODE != WV_TEST;
     constexpr int NS = TRAIN ? 3 : 1;                      // scalar rows of the state
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int wid = WGW > 1 ? (int)(threadIdx.x >> 6) : (int)blockIdx.x;      // this wave's tile
+    // WGW > 1: the waves of a workgroup are consecutive tiles.  One workgroup (B <= 64): they meet through LDS alone; SEVERAL
+    // workgroups (large batches: up to 512 workgroups x WGW tiles): LDS inside the workgroup, the tagged words between them
+    const int wloc = WGW > 1 ? (int)(threadIdx.x >> 6) : 0, nwg = WGW > 1 ? (int)(blockDim.x >> 6) : 1;
+    const bool xwg = WGW > 1 && gridDim.x > 1;
+    const int wid = WGW > 1 ? (int)blockIdx.x * nwg + wloc : (int)blockIdx.x;      // this wave's tile
     const NetDesc& nd = a.nd;
     const int n_in = nd.n_in, nh = nd.dims[1], D = n_in + NS;
     const int act1 = nd.acts[0], act2 = nd.acts[1];
@@ -437,13 +443,15 @@ __global__ void __launch_bounds__(GRAD && WGW == 1 ? 128 : 64 * WGW) k_solve_wav
         }
     }
     __shared__ float mw[2][WGW][2];                        // WGW > 1: the waves' meeting words
+    __shared__ float mx[2][4];                             // ... and what wave 0 brought back from the other workgroups
+    __shared__ float mv[WGW][4];                           // ... and the waves' loss-sum partials
     bool gover = false;                                    // more accepted steps than the trajectory store holds
     // ---- integrator state: every lane carries the same copy and runs the same controller on the same sums ----
     StepState ns = sv.init;
     float hstep = ns.h, abstol = ns.abstol, reltol = ns.reltol;
     int nsync = 0;
     const unsigned mbase = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sv.base_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const int G = WGW > 1 ? (int)(blockDim.x >> 6) : (int)gridDim.x;
+    const int G = WGW > 1 ? (int)gridDim.x * nwg : (int)gridDim.x;      // tiles
     // the rich store's slot of (step, stage): [step][stage][wave][lane][RR]
     auto rich_slot = [&](int step, int stage) -> f32x4* {
         if (!RICH || !a.g.rich || step >= a.g.traj_cap) return nullptr;
@@ -451,34 +459,25 @@ __global__ void __launch_bounds__(GRAD && WGW == 1 ? 128 : 64 * WGW) k_solve_wav
     };
     float p0 = 0.f, p1 = 0.f;
     // The waves' partials (e, b) -> the sums over all of them in p0, p1 (the same order in every wave).  false: a wait ran out.
-    auto meet = [&](float e_lane, float b_lane) -> bool {
-        const float e = wv_wave_sum(e_lane), b = wv_wave_sum(b_lane);
-        if constexpr (WGW > 1) {                           // the waves of one workgroup: LDS words (two sets by parity) and a barrier
-            const int par = nsync & 1;
-            if (lane == 0) { mw[par][wid][0] = e; mw[par][wid][1] = b; }
-            __syncthreads();
-            float c0 = 0.f, c1 = 0.f;
-            for (int w = 0; w < G; ++w) { c0 += mw[par][w][0]; c1 += mw[par][w][1]; }
-            p0 = c0; p1 = c1;
-            ++nsync;
-            return true;
-        }
+    // The tagged-word exchange: party `me` of `parties` files (e, b) and collects everyone's; the sums land in p0, p1 (the same
+    // order in every party).  false: a wait ran out.
+    auto exchange = [&](float e, float b, int me, int parties) -> bool {
         unsigned long long* pb = reinterpret_cast<unsigned long long*>(sv.part) + (nsync & 1) * 1024;
         const unsigned tag = mbase + (unsigned)nsync + 1u;
         if (lane == 0) {
-            __hip_atomic_store(pb + 2 * wid, ((unsigned long long)tag << 32) | __float_as_uint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pb + 2 * wid + 1, ((unsigned long long)tag << 32) | __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pb + 2 * me, ((unsigned long long)tag << 32) | __float_as_uint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pb + 2 * me + 1, ((unsigned long long)tag << 32) | __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // lane i takes the words of waves i, i + 64, ... (at most 8): ALL of them requested at once per poll round -- one round
+        // lane i takes the words of parties i, i + 64, ... (at most 8): ALL of them requested at once per poll round -- one round
         // trip per round whatever the grid (taken one after the other they cost a round trip each: 8.5 k cycles per meeting
-        // at 256 waves) --, each accepted when both halves carry this meeting's index, in wave order
+        // at 256 waves) --, each accepted when both halves carry this meeting's index, in party order
         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
         const auto prs = __builtin_amdgcn_make_buffer_rsrc(pb, 0, 16 * 512, 0x00020000);
         const unsigned long long wait0 = __builtin_amdgcn_s_memrealtime();
         float pe[8], pbv[8];
         unsigned need = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { pe[i] = 0.f; pbv[i] = 0.f; if (lane + 64 * i < G) need |= 1u << i; }
+        for (int i = 0; i < 8; ++i) { pe[i] = 0.f; pbv[i] = 0.f; if (lane + 64 * i < parties) need |= 1u << i; }
         int ok = 1;
         for (int spin = 0; need != 0; ++spin) {
             // (buffer loads past the caches, aux = sc0 | sc1: loads the compiler counts and waits for itself -- a hand-written
@@ -486,12 +485,12 @@ __global__ void __launch_bounds__(GRAD && WGW == 1 ? 128 : 64 * WGW) k_solve_wav
             u32x4_ wq[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (64 * i < G)                            // (wave-uniform: rounds beyond the grid issue nothing)
-                    wq[i] = __builtin_bit_cast(u32x4_, __builtin_amdgcn_raw_buffer_load_b128(prs, 16 * min(lane + 64 * i, G - 1), 0, 0x11));
+                if (64 * i < parties)                      // (wave-uniform: rounds beyond the grid issue nothing)
+                    wq[i] = __builtin_bit_cast(u32x4_, __builtin_amdgcn_raw_buffer_load_b128(prs, 16 * min(lane + 64 * i, parties - 1), 0, 0x11));
                 else wq[i] = u32x4_{0u, 0u, 0u, 0u};
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (64 * i < G && (need >> i & 1) && wq[i].y == tag && wq[i].w == tag) {
+                if (64 * i < parties && (need >> i & 1) && wq[i].y == tag && wq[i].w == tag) {
                     pe[i] = __uint_as_float(wq[i].x); pbv[i] = __uint_as_float(wq[i].z); need &= ~(1u << i);
                 }
             if (need == 0) break;
@@ -506,8 +505,32 @@ __global__ void __launch_bounds__(GRAD && WGW == 1 ? 128 : 64 * WGW) k_solve_wav
         if (!ok) __hip_atomic_store(sv.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         p0 = wv_wave_sum(c0); p1 = wv_wave_sum(c1);
         const float bad = wv_wave_sum(ok ? 0.f : 1.f);
-        ++nsync;
         return bad == 0.f;
+    };
+    // The waves' partials (e, b) -> the sums over all of them in p0, p1 (the same order in every wave).  false: a wait ran out.
+    auto meet = [&](float e_lane, float b_lane) -> bool {
+        const float e = wv_wave_sum(e_lane), b = wv_wave_sum(b_lane);
+        if constexpr (WGW > 1) {                           // the waves of one workgroup: LDS words (two sets by parity) and a barrier
+            const int par = nsync & 1;
+            if (lane == 0) { mw[par][wloc][0] = e; mw[par][wloc][1] = b; }
+            __syncthreads();
+            float c0 = 0.f, c1 = 0.f;
+            for (int w = 0; w < nwg; ++w) { c0 += mw[par][w][0]; c1 += mw[par][w][1]; }
+            if (!xwg) { p0 = c0; p1 = c1; ++nsync; return true; }
+            // several workgroups: wave 0 carries the workgroup's sums to the others and brings theirs back
+            if (wloc == 0) {
+                const bool ok = exchange(c0, c1, (int)blockIdx.x, (int)gridDim.x);
+                if (lane == 0) { mx[par][0] = p0; mx[par][1] = p1; mx[par][2] = ok ? 0.f : 1.f; }
+            }
+            __syncthreads();
+            p0 = mx[par][0]; p1 = mx[par][1];
+            const float bad = mx[par][2];
+            ++nsync;
+            return uni(bad) == 0.f;
+        }
+        const bool ok = exchange(e, b, wid, (int)gridDim.x);
+        ++nsync;
+        return ok;
     };
     auto after_ctrl = [&]() {
         hstep = uni(ns.h); abstol = uni(ns.abstol); reltol = uni(ns.reltol);
@@ -709,14 +732,25 @@ __global__ void __launch_bounds__(GRAD && WGW == 1 ? 128 : 64 * WGW) k_solve_wav
             const unsigned tag = mbase + (unsigned)nsync + 1u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v4[j] = wv_wave_sum(v4[j]);
-            if (lane < 4)
-                __hip_atomic_store(qb + 4 * wid + lane, ((unsigned long long)tag << 32) | __float_as_uint(lane == 0 ? v4[0] : lane == 1 ? v4[1] : lane == 2 ? v4[2] : v4[3]),
+            int slot = wid, parties = G;                   // one word quadruple per wave ...
+            bool files = true;
+            if constexpr (WGW > 1) {
+                if (xwg) {                                 // ... or per workgroup: its waves' partials added in wave order first
+                    if (lane == 0) { mv[wloc][0] = v4[0]; mv[wloc][1] = v4[1]; mv[wloc][2] = v4[2]; mv[wloc][3] = v4[3]; }
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { float t = 0.f; for (int w = 0; w < nwg; ++w) t += mv[w][j]; v4[j] = t; }
+                    slot = (int)blockIdx.x; parties = (int)gridDim.x; files = wloc == 0;
+                }
+            }
+            if (files && lane < 4)
+                __hip_atomic_store(qb + 4 * slot + lane, ((unsigned long long)tag << 32) | __float_as_uint(lane == 0 ? v4[0] : lane == 1 ? v4[1] : lane == 2 ? v4[2] : v4[3]),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (wid == 0) {                         // wave 0 adds the waves' partials in wave order
+            if (wid == 0) {                         // wave 0 adds the partials in wave (workgroup) order
                 float c4[4] = {0.f, 0.f, 0.f, 0.f};
                 float late = 0.f;
                 const unsigned long long wait0 = __builtin_amdgcn_s_memrealtime();
-                for (int w = lane; w < G; w += 64) {
+                for (int w = lane; w < parties; w += 64) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         int got = 0;
@@ -1224,15 +1258,20 @@ typedef void (*wave_fn)(WaveArgs, Solve3Args, const WvTab);
 // (VJP) and TestMode, plain solve and gradient
 wave_fn pick_wg(int ni, int nh, int mode, bool grad, bool id2, bool tanh2) {
     if (grad) return nullptr;            // (gradients: one tile per workgroup + its helper wave, whatever the batch)
-    if (ni != 1 || mode == WV_JVP || !(tanh2 || id2)) return nullptr;
+    if (ni != 1 || !(tanh2 || id2)) return nullptr;
     const bool t = mode == WV_TEST;
     if (id2)
-        return nh != 1 ? nullptr
+        return (nh != 1 || mode == WV_JVP) ? nullptr
              : (t ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, false, true, 4> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, false, true, 4>);
-    if (nh == 1)
-        return t ? (wave_fn)k_solve_wave<1, 1, WV_TEST, true, false, false, 4> : (wave_fn)k_solve_wave<1, 1, WV_VJP, true, false, false, 4>;
-    if (nh == 3)
-        return t ? (wave_fn)k_solve_wave<1, 3, WV_TEST, true, false, false, 4> : (wave_fn)k_solve_wave<1, 3, WV_VJP, true, false, false, 4>;
+#define WV_WG(NHV) (mode == WV_VJP ? (wave_fn)k_solve_wave<1, NHV, WV_VJP, true, false, false, 4> \
+                  : mode == WV_JVP ? (wave_fn)k_solve_wave<1, NHV, WV_JVP, true, false, false, 4> : (wave_fn)k_solve_wave<1, NHV, WV_TEST, true, false, false, 4>)
+    switch (nh) {
+        case 1: return WV_WG(1);
+        case 2: return WV_WG(2);
+        case 3: return WV_WG(3);
+        case 4: return WV_WG(4);
+    }
+#undef WV_WG
     return nullptr;
 }
 // the RICH form of the TrainMode / VJP gradient (the forward pass files its intermediates)
@@ -1306,12 +1345,32 @@ bool is_id2(const NetDesc& nd) { return nd.n_layers == 2 && nd.acts[0] == 1 && n
 // Two-layer networks whose tile counts have an instantiation (n_in <= 16 with up to 64 hidden units; 32 -> 96 -> 32); every
 // activation of the library runs (cnf_act returns sigma' from the forward pass).  One 16-sample tile per wave, one meeting
 // word pair per wave: up to 512 x 16 columns.
+// Beyond 512 tiles (B > 8192): four tiles per workgroup where that form is instantiated (n_in <= 16, tanh networks, no
+// conditioning) -- up to 512 workgroups = 32768 columns, provided the device holds them all at once.
+static int wave_xwg_capacity(wave_fn fn) {                 // workgroups of four waves the current device holds at once
+    int dev = 0, n_cu = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, 256, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n_cu * per_cu;
+}
+static bool wave_xwg_ok(const NetDesc& nd, bool train, int B) {
+    if (B > 16 * 4 * 512 || nd.n_cond > 0) return false;
+    const int ni = (nd.n_in + 15) / 16, nh = (nd.dims[1] + 15) / 16;
+    const int mode = !train ? WV_TEST : (nd.jvp ? WV_JVP : WV_VJP);
+    wave_fn fn = pick_wg(ni, nh, mode, false, is_id2(nd), nd.acts[0] == 1 && nd.acts[1] == 1);
+    if (!fn) return false;
+    static std::mutex mu;
+    static std::map<const void*, int> cap;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cap.find((const void*)fn);
+    if (it == cap.end()) it = cap.emplace((const void*)fn, wave_xwg_capacity(fn)).first;
+    return (B + 63) / 64 <= it->second;
+}
 bool wave_solve_supported(const NetDesc& nd, bool train, int B) {
     if (nd.n_layers != 2 || B < 1) return false;
     const int ni = (nd.n_in + 15) / 16, nh = (nd.dims[1] + 15) / 16;
     if (pick_shape(ni, nh, 0) == nullptr) return false;
-    (void)train;
-    return B <= 16 * 512;
+    return B <= 16 * 512 || wave_xwg_ok(nd, train, B);
 }
 
 int wave_grad_waves(int B) { return (B + 15) / 16; }
@@ -1344,16 +1403,22 @@ cnf_status wave_solve_launch(const NetDesc& nd, bool train, const float* d_param
     int grid = (B + 15) / 16;
     const int mode = !train ? WV_TEST : (nd.jvp ? WV_JVP : WV_VJP);
     wave_fn fn = grad ? pick_grad(ni, nh, is_id2(nd), !train, nd.jvp != 0) : pick_shape(ni, nh, mode, nd.acts[0] == 1 && nd.acts[1] == 1, is_id2(nd));
-    if (!fn || grid > 512) return CNF_ERR_UNSUPPORTED;
-    // at most four tiles: the waves of ONE workgroup (they meet through LDS), where that form is instantiated
+    if (!fn || (grid > 512 && grad)) return CNF_ERR_UNSUPPORTED;
+    // at most four tiles: the waves of ONE workgroup (they meet through LDS), where that form is instantiated; more than 512
+    // tiles: workgroups of four tiles (LDS inside, the tagged words between them: wave_solve_supported has checked that they fit)
     static const bool wg_off = [] { const char* e = getenv("CNF_WAVE_WG"); return e && e[0] == '0'; }();
-    wave_fn wfn = (grid <= 4 && !wg_off && !cond) ? pick_wg(ni, nh, mode, grad != nullptr, is_id2(nd), nd.acts[0] == 1 && nd.acts[1] == 1) : nullptr;
-    const int waves = grid;
+    // (CNF_WAVE_XWG_MIN=<tiles>: take the four-tile workgroups from that many tiles on -- measurements; the default is what 512
+    // meeting words force)
+    static const int xwg_min = [] { const char* e = getenv("CNF_WAVE_XWG_MIN"); const int v = e ? atoi(e) : 0; return v > 4 ? v : 513; }();
+    const bool xwg = grid > 512 || (grid >= xwg_min && !cond && !grad && pick_wg(ni, nh, mode, false, is_id2(nd), nd.acts[0] == 1 && nd.acts[1] == 1));
+    wave_fn wfn = ((grid <= 4 && !wg_off && !cond) || xwg) ? pick_wg(ni, nh, mode, grad != nullptr, is_id2(nd), nd.acts[0] == 1 && nd.acts[1] == 1) : nullptr;
+    if (xwg && (!wfn || cond)) return CNF_ERR_UNSUPPORTED;
+    const int waves = xwg ? 4 : grid;
     if (grad && grad->rich && mode == WV_VJP && ni == 1) {   // the forward pass files its intermediates: the RICH instantiations
         if (wave_fn r = pick_grad_rich(nh, is_id2(nd), wfn != nullptr)) { if (wfn) wfn = r; else fn = r; }
         else return CNF_ERR_BAD_ARG;                       // (wave_grad_rich_floats said it exists)
     }
-    if (wfn) { fn = wfn; grid = 1; }
+    if (wfn) { fn = wfn; grid = xwg ? (grid + 3) / 4 : 1; }
     WaveArgs a{};
     a.nd = nd; a.P = d_params; a.eps = eps; a.cond = cond; a.cbs = cbs; a.B = B;
     a.n_total = (float)((size_t)(nd.n_in + (train ? 3 : 1)) * B);

@@ -20,7 +20,7 @@ from oracle import c_oracle as CO
 from oracle import cnf_oracle as O
 from tests.helpers import make_icnf, parity_err
 
-which = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 5, 13, 14, 23]
+which = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 5, 13, 14, 23, 12, 15, 25]
 dev = torch.device("cuda", 0)
 for case in which:
     # 13 / 14: configs 3 / 4 at 65536 columns on ONE GPU (several tiles per workgroup of the one-launch solve);
@@ -31,6 +31,9 @@ for case in which:
         B = 8192                      # per-GPU shard of the 65536-column batch
     if case in (13, 14):
         B = 65536
+    # beyond the BASELINE batches (round 5: no batch-size cliffs): config 2 at 32768 columns (k_solve_wave, four tiles per workgroup),
+    # config 5 at 4096 / 16384 (k_solve_bcast, several tiles per workgroup)
+    B = {12: 32768, 15: 4096, 25: 16384}.get(case, B)
     rng = np.random.default_rng(i)
     flat = O.glorot_params(cfg.net, rng, np.float32)
     modes = [("train", True)] if train else [("test", False), ("train", True)]
@@ -62,7 +65,7 @@ for case in which:
         torch.cuda.synchronize()
         rhs_us = (time.perf_counter() - t0) / nrep * 1e6
         # parity on a column sample
-        ns = min(B, 128 if (i == 5 and not tr) else 512)
+        ns = min(B, 128 if (i == 5 and not tr) else (256 if case in (15, 25) else 512))
         got = du.view(B, D)[:ns].cpu().numpy().T
         ref = CO.rhs(cfg, flat, u_h[:, :ns], eps_h[:, :ns], tr)
         perr = parity_err(got, ref, trace_row=cfg.n_in)
@@ -70,6 +73,15 @@ for case in which:
         l.cnf_rhs_work(h, m, B, C.byref(fl), C.byref(by))
         out = {"cfg": i, "case": case, "mode": mname, "B": B, "kernel": {1: "generic", 2: "mfma"}[kern], "rhs_us": round(rhs_us, 1),
                "rhs_TFLOPs": round(fl.value / rhs_us / 1e6, 2), "parity_err_vs_c_oracle": float(f"{perr:.2e}")}
+        if not tr and len(cfg.net.dims) > 3:
+            # (cnf_rhs_work prices the reference's n_in tangent sweeps for a >= 3-layer exact trace; the kernel executes the
+            # re-associated form tr(D3 W3 D2 (W2 D1 W1)): forward + one d2 x d1 x d0 product per sample + the contraction)
+            d = cfg.net.dims
+            M = sum(a * b for a, b in zip(d[:-1], d[1:]))
+            ex = B * (2.0 * M + 2.0 * d[0] * d[1] * d[2] + 2.0 * d[2] * d[3])
+            out["rhs_TFLOPs_reference_formulation"] = out.pop("rhs_TFLOPs")
+            out["rhs_TFLOPs"] = round(ex / rhs_us / 1e6, 2)
+            out["rhs_flops_note"] = "executed (re-associated) formulation; split-bf16 products: ceiling 416.7 TFLOP/s fp32-equivalent"
         # solves
         u0 = u.clone()
         u0.view(B, D)[:, cfg.n_in:] = 0

@@ -2234,7 +2234,56 @@ def test_wave_local_solve_small_networks(dims, nvars, naugs, acts):
     ic.close()
 
 
-@pytest.mark.parametrize("B", [2048, 1000, 5])
+@pytest.mark.parametrize("B", [9000, 32768])
+def test_wave_local_solve_beyond_512_tiles(B):
+    """VERDICT round 4, item 2 (src/base_icnf.jl:266-286 takes any column count): BASELINE config 2's network beyond 8192 columns
+    stays on k_solve_wave -- workgroups of four tiles that meet through LDS inside and the tagged words between them (up to 512
+    workgroups = 32768 columns) -- instead of falling to 23-34 step launches.  Fixed dt, sampled columns strictly against the
+    float64 oracle (VJP, JVP, TestMode), the loss sums against the whole batch's logpx, the route by the launch count; adaptive:
+    the same step counts as the C oracle on a column sample would not be comparable (the norm is over ALL columns), so the
+    adaptive solve is checked against a tight float64 solve of sampled columns at the solver tolerance."""
+    cfg, _, _ = O.baseline_cfg(2)
+    net = cfg.net
+    rng = np.random.default_rng(2200 + B)
+    flat = O.glorot_params(net, rng, np.float32, 0.1)
+    nvars, naugs, n_in = cfg.nvars, cfg.naugs, cfg.n_in
+    xs = rng.standard_normal((nvars, B)).astype(np.float32)
+    eps = rng.standard_normal((n_in, B)).astype(np.float32)
+    one = _one_launch_expected() and os.environ.get("CNF_WAVE") != "0"
+    f64 = lambda a: a.astype(np.float64)
+    sub = np.r_[0:48, B // 2 - 7:B // 2 + 9, B - 64:B]                 # first / middle / last tiles (the last workgroup may be partial)
+    for jvp in (False, True):
+        c = O.Cfg(net, nvars, naugs, cfg.lam1, cfg.lam2, cfg.lam3, jvp, tspan=cfg.tspan)
+        ic = make_icnf(cnf, c, jvp=jvp, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
+        logpx, (E, n, A), sums = cnf.inference(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps), with_sums=True)
+        assert (ic.last_stats["launches"] <= 3) == one, ic.last_stats
+        assert ic.last_stats["nf"] == 1 + 6 * 8
+        _, ref_lp, ref_regs, _ = O.inference(c, f64(flat), f64(xs[:, sub]), f64(eps[:, sub]), True, dt=1 / 8, adaptive=False)
+        assert_parity(logpx.cpu().numpy()[sub], ref_lp, f"wave xwg logpx jvp={jvp} B={B}")
+        assert_parity(torch.stack([E, n, A]).cpu().numpy()[:, sub], np.stack(ref_regs), f"wave xwg regs jvp={jvp} B={B}")
+        assert float(sums[4]) == B and abs(float(sums[0]) - float(logpx.double().sum())) <= 1e-5 * (abs(float(sums[0])) + 1.0)
+        assert abs(float(sums[1]) - float(E.double().sum())) <= 1e-5 * (abs(float(sums[1])) + 1.0)
+        ic.close()
+    ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
+    logpx, _ = cnf.inference(ic, cnf.TestMode(), _dev(xs), flat, {})
+    assert (ic.last_stats["launches"] <= 3) == one, ic.last_stats
+    _, ref_lp, _, _ = O.inference(cfg, f64(flat), f64(xs[:, sub]), None, False, dt=1 / 8, adaptive=False)
+    assert_parity(logpx.cpu().numpy()[sub], ref_lp, f"wave xwg TestMode logpx B={B}")
+    ic.close()
+    # adaptive at the README tolerances: one launch, consistent counters, sampled columns at the solver tolerance
+    tol = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+    ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=tol)
+    prob = cnf.inference_prob(ic, cnf.TrainMode(), _dev(xs), flat, {}, eps=_dev(eps))
+    fsol = cnf.base_sol(ic, prob).view().cpu().numpy()
+    st = prob.stats
+    assert (st["launches"] <= 3) == one and st["nf"] == 2 + 6 * (st["naccept"] + st["nreject"]) and abs(st["t_final"] - cfg.tspan[1]) < 1e-6
+    u0 = O.inference_u0(cfg, xs[:, sub], True)
+    ref64, _ = O.tsit5_solve(cfg.rhs(f64(flat), f64(eps[:, sub]), True), f64(u0), cfg.tspan[0], cfg.tspan[1], reltol=1e-10, abstol=1e-10)
+    assert_parity(fsol[:, sub], ref64, f"wave xwg adaptive vs float64 B={B}", rtol=5e-3, trace_row=n_in)
+    ic.close()
+
+
+@pytest.mark.parametrize("B", [2048, 1000, 5, 4096, 4100, 16384])      # (beyond 2048: several tiles per workgroup, rows in global memory)
 def test_config5_one_launch_solve_strict_vs_float64(B):
     """k_solve_bcast (cnf_bcast.hip): BASELINE config 5's network (RNODE 64 + 64, 128-384-128 tanh) at eight columns per CU --
     4x4x1 MFMA blocks with the activations broadcast, W1 resident, W2 streamed -- in ONE launch.  TrainMode / VJP and
@@ -2289,6 +2338,41 @@ def test_config5_one_launch_solve_strict_vs_float64(B):
         ref64, _ = O.tsit5_solve(cfg.rhs(f64(flat), f64(eps[:, idx]), True), f64(u0), *cfg.tspan, reltol=1e-10, abstol=1e-10)
         assert_parity(fsol[:, ti].cpu().numpy(), ref64, f"bcast {name} adaptive vs float64 B={B}", rtol=5e-3, trace_row=cfg.n_in)
         ic.close()
+
+
+def test_config5_shape_conditional_model_on_the_one_launch_solve():
+    """VERDICT round 4, item 2 (second half): a CONDITIONAL model of config 5's shape -- CondRNODE, nn(vcat(z, ys)) with
+    Dense(128 + n_cond => 384, tanh), Dense(384 => 128, tanh) (src/layers/cond_layer.jl:7-9, src/base_icnf.jl:288-309) -- runs on
+    k_solve_bcast: the conditioning columns of W1 enter as a per-sample first-layer bias staged in LDS.  Fixed dt strictly against
+    the float64 oracle (TrainMode VJP and TestMode), route asserted by the launch count."""
+    n_cond = 5
+    nvars, naugs = 64, 64
+    n_in = nvars + naugs
+    net = O.Net((n_in + n_cond, 384, n_in), (O.ACT_TANH,) * 2)
+    cfg = O.Cfg(net, nvars, naugs, 1e-2, 1e-2, 1e-2)
+    one = _one_launch_expected() and os.environ.get("CNF_BCAST") != "0"
+    f64 = lambda a: a.astype(np.float64)
+    for B in (2048, 999):
+        rng = np.random.default_rng(1750 + B)
+        flat = O.glorot_params(net, rng, np.float32, 0.1)
+        xs = rng.standard_normal((nvars, B)).astype(np.float32)
+        ys = rng.standard_normal((n_cond, B)).astype(np.float32)
+        eps = rng.standard_normal((n_in, B)).astype(np.float32)
+        idx = np.unique(np.concatenate([np.arange(min(B, 16)), np.arange(max(0, B - 24), B), rng.choice(B, 64, replace=False)]))
+        ti = torch.from_numpy(idx).cuda()
+        nn = cnf.Chain(cnf.Dense(n_in + n_cond, 384, "tanh"), cnf.Dense(384, n_in, "tanh"))
+        for train in (True, False):
+            mode = cnf.TrainMode() if train else cnf.TestMode()
+            ic = cnf.construct(cnf.CondRNODE, nn, nvars, naugs, compute_mode=cnf.HIPVecJacMatrixMode("mfma"), lambda1=1e-2, lambda2=1e-2,
+                               lambda3=1e-2, sol_kwargs=dict(adaptive=False, dt=1 / 8))
+            logpx, (E, n, A) = cnf.inference(ic, mode, _dev(xs), _dev(ys), flat, {}, eps=_dev(eps) if train else None)
+            assert (ic.last_stats["launches"] <= 3) == one, (B, train, ic.last_stats)
+            _, ref_lp, ref_regs, _ = O.inference(cfg, f64(flat), f64(xs[:, idx]), f64(eps[:, idx]) if train else None, train,
+                                                 dt=1 / 8, adaptive=False, ys=f64(ys[:, idx]))
+            assert_parity(logpx[ti].cpu().numpy(), ref_lp, f"bcast cond logpx train={train} B={B}")
+            if train:
+                assert_parity(torch.stack([E, n, A])[:, ti].cpu().numpy(), np.stack(ref_regs), f"bcast cond regs B={B}")
+            ic.close()
 
 
 def test_testmode_headline_network_is_three_launches():
