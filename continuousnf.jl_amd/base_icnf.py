@@ -838,7 +838,9 @@ def loss_and_grad_collect(icnf: ICNF):
 def _loss_and_grad_test(icnf: ICNF, mode, xs, *args, with_x=False):
     """``loss(icnf, TestMode(), xs, ps, st)`` and its gradient through the exact-trace solve (cnf_loss_grad_test): what the
     reference's call tests and benchmark suite differentiate besides the TrainMode loss (test/call_tests.jl ``diff_loss``,
-    benchmark/benchmarks.jl:60-99).  Small two-layer (or one-layer) tanh networks; ``NotImplementedError`` otherwise."""
+    benchmark/benchmarks.jl:60-99).  Small two-layer (or one-layer) tanh networks in the launch of the solve; every other Dense
+    chain through the recorded solve and the generic adjoint kernel (cnf_gradt.hip); ``NotImplementedError`` only where that
+    kernel's LDS budget is exceeded."""
     import torch
     ys, ps, st = _split_cond_args(icnf, args)
     xb = _xs_colmajor(icnf, xs)
@@ -860,8 +862,7 @@ def _loss_and_grad_test(icnf: ICNF, mode, xs, *args, with_x=False):
         grad = np.empty(n_params, dtype=np.float32)
         rc = l.cnf_loss_grad_test_host(h, xb.ptr, B, C.byref(opts), C.byref(val), grad.ctypes.data, C.byref(stats))
     if rc == _lib.ERR_UNSUPPORTED:
-        raise NotImplementedError("TestMode gradients are implemented for small two-layer tanh networks (k_solve_wave); "
-                                  "the reference trains in TrainMode")
+        raise NotImplementedError("TestMode gradient: network too wide for the adjoint kernels: " + l.cnf_last_error(h).decode())
     _lib.check(rc, h)
     icnf.last_stats = stats.as_dict()
     n = l.cnf_grad_steps(h, None, 0)

@@ -9,6 +9,7 @@
 #include "cnf_mirror.h"
 #include "cnf_wave.h"
 #include "cnf_bcast.h"
+#include "cnf_gradt.h"
 #include "cnf_step3.h"
 #include <immintrin.h>
 #include <sched.h>
@@ -95,6 +96,8 @@ struct cnf_ctx {
     bool pt_valid = false;
     bool img_valid = false;       // d_adj_img holds the images of the current parameters
     float* d_bimg = nullptr;      // k_solve_bcast's images (cnf_bcast.hip), packed on first use after a parameter change
+    float* d_gt = nullptr;        // k_adj_test: one partial of the flat gradient and a scratch per workgroup (cnf_gradt.hip)
+    size_t gt_floats = 0;
     float* d_bstore = nullptr;    // ... and the store of its tiles' Runge-Kutta rows when a workgroup carries several (bcast_store_floats)
     size_t bstore_floats = 0;
     bool bimg_valid = false;
@@ -287,6 +290,7 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (h->d_adj_img) (void)hipFree(h->d_adj_img);
     if (h->d_bimg) (void)hipFree(h->d_bimg);
     if (h->d_bstore) (void)hipFree(h->d_bstore);
+    if (h->d_gt) (void)hipFree(h->d_gt);
     if (h->grad_arena) (void)hipFree(h->grad_arena);
     if (h->traj) (void)hipFree(h->traj);
     if (h->traj_hs) (void)hipFree(h->traj_hs);
@@ -1839,7 +1843,55 @@ extern "C" cnf_status cnf_loss_grad_test(cnf_handle h, const float* xs, int B, c
     if ((s = ensure_grad_capacity(h, B)) != CNF_OK) return s;
     bool done = false;
     if ((s = wave_loss_grad(h, mode, xs, nullptr, B, opts, loss_out, grad, stats, stream, &done)) != CNF_OK) return s;
-    if (!done) return fail(h, CNF_ERR_UNSUPPORTED, "the TestMode gradient is implemented for small two-layer tanh networks (k_solve_wave)");
+    if (done) return CNF_OK;
+    // ---- every other network: the recorded exact-trace solve, then k_adj_test (cnf_gradt.hip) over all of its steps in one launch ----
+    hipStream_t st = (hipStream_t)stream;
+    const NetDesc& nd = h->nd;
+    const int n_in = nd.n_in, D = n_in + 1;
+    float* u0 = h->g_US[0];
+    launch_build_u0(xs, u0, nd.nvars, D, B, st);
+    // the recorded forward pass files u_n after every accepted step (host-driven, one attempt at a time: solve_core's recording
+    // branch of the streamed driver).  Networks whose TestMode runs inside the fused step kernels (two layers, closed-form trace)
+    // take the generic right-hand side there: that branch is the one place where a TestMode solve records.
+    cnf_solve_opts ropts = *opts;
+    if (mfma_supported(h->mfma, nd, false, B)) ropts.kernel = CNF_KERNEL_GENERIC;
+    Recorder rec;
+    cnf_solve_stats sst{};
+    float* fsol = h->g_US[1];
+    for (;;) {
+        if ((s = solve_core(h, mode, u0, nullptr, fsol, B, &ropts, &sst, stream, &rec)) != CNF_OK) return s;
+        if (!rec.overflow) break;
+        if ((s = traj_reserve(h, rec.n + 8)) != CNF_OK) return s;
+    }
+    h->last_hs = rec.hs;
+    launch_post(nd, 0, fsol, h->tmp_logpx, h->tmp_regs, B, st);
+    launch_loss_sums(h->tmp_logpx, h->tmp_regs, B, h->d_sums, st);
+    float* sums = reinterpret_cast<float*>(&h->h_state[2]);
+    HIPCHK(h, hipMemcpyAsync(sums, h->d_sums, 5 * sizeof(float), hipMemcpyDeviceToHost, st));
+    // the step sizes to the device (behind the steps in the trajectory store's step-size array), scratch and partials of the kernel
+    if ((s = traj_reserve(h, rec.n + 1)) != CNF_OK) return s;
+    if (rec.n > 0) HIPCHK(h, hipMemcpyAsync(h->traj_hs, rec.hs.data(), (size_t)rec.n * sizeof(float), hipMemcpyHostToDevice, st));
+    const int G = adj_test_workgroups(B);
+    const size_t per_wg = adj_test_scratch_floats(nd) + h->n_params;
+    if ((size_t)G * per_wg > h->gt_floats) {
+        HIPCHK(h, hipStreamSynchronize(st));
+        if (h->d_gt) { (void)hipFree(h->d_gt); h->d_gt = nullptr; h->gt_floats = 0; }
+        HIPCHK(h, hipMalloc(&h->d_gt, (size_t)G * per_wg * sizeof(float)));
+        h->gt_floats = (size_t)G * per_wg;
+    }
+    float* first;
+    if ((s = traj_slot(h, 0, &first)) != CNF_OK) return s;
+    AdjTestArgs ta{};
+    ta.P = h->d_params; ta.traj = first; ta.slot_stride = traj_slot_floats(h); ta.hs = h->traj_hs; ta.nsteps = rec.n;
+    ta.ys = nd.n_cond > 0 ? h->d_ys : nullptr; ta.lam_l = 1.0f / (float)B; ta.lam_out = h->g_lam;
+    ta.gpart = h->d_gt; ta.scratch = h->d_gt + (size_t)G * h->n_params; ta.scratch_per_wg = adj_test_scratch_floats(nd);
+    ta.B = B; ta.n_params = (int)h->n_params;
+    if (launch_adj_test(nd, ta, st) != hipSuccess) { (void)hipGetLastError(); return fail(h, CNF_ERR_UNSUPPORTED, "network too wide for the TestMode adjoint kernel"); }
+    HIPCHK(h, launch_grad_reduce(h->d_gt, grad, (int)h->n_params, G, st));
+    h->grad_last_B = B;                                    // (g_lam holds d loss / d z(t0): cnf_grad_x)
+    HIPCHK(h, hipStreamSynchronize(st));
+    if ((s = cnf_loss_from_sums(h, mode, sums, loss_out)) != CNF_OK) return s;
+    if (stats) { *stats = sst; stats->launches += 2; }
     return CNF_OK;
 }
 

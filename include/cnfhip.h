@@ -269,8 +269,10 @@ cnf_status cnf_loss_grad_host(cnf_handle h, const float* xs, const float* eps, i
  * through the exact-trace solve: the derivative the reference's call tests and benchmark suite take besides the TrainMode
  * one (test/call_tests.jl `diff_loss` with omode = TestMode(); benchmark/benchmarks.jl:60-99, "AD-1-order" / "test").
  * Device pointers, arguments as cnf_loss_grad (no eps: the exact trace draws nothing); cnf_grad_steps / cnf_grad_x apply
- * to it as well.  Implemented where the whole gradient runs in the launch of the solve -- two tanh layers (closed-form
- * trace) or one, n_in <= 16, <= 64 hidden units, n_in + n_cond <= 16, B <= 8192 --, CNF_ERR_UNSUPPORTED otherwise. */
+ * to it as well.  Where the whole gradient runs in the launch of the solve -- two tanh layers (closed-form trace) or one,
+ * n_in <= 16, <= 64 hidden units, n_in + n_cond <= 16, B <= 8192 -- it does (k_solve_wave<TEST, GRAD>); every other Dense chain
+ * (deeper, wider, any activation, conditional) takes a recorded exact-trace solve followed by ONE launch of a generic adjoint
+ * kernel over all accepted steps (k_adj_test: coverage first, VALU; CNF_ERR_UNSUPPORTED only beyond its LDS budget). */
 cnf_status cnf_loss_grad_test(cnf_handle h, const float* xs, int B, const cnf_solve_opts* opts, float* loss_out,
                               float* grad, cnf_solve_stats* stats, void* stream);
 cnf_status cnf_loss_grad_test_host(cnf_handle h, const float* xs, int B, const cnf_solve_opts* opts, float* loss_out,

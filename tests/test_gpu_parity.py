@@ -1099,8 +1099,9 @@ def test_loss_grad_is_reproducible_and_descends():
     step = 1e-2 / np.linalg.norm(g)
     l2 = cnf.loss(icnf, cnf.TrainMode(), xs, (flat - step * g).astype(np.float32), {}, eps=eps)
     assert l2 < l0 and abs((l0 - l2) - step * np.dot(g, g)) <= 0.05 * step * np.dot(g, g)
-    with pytest.raises(NotImplementedError):
-        cnf.loss_and_grad(icnf, cnf.TestMode(), xs, flat, {})
+    # (the TestMode loss has a gradient on every network as well: test_testmode_loss_gradient_beyond_the_wave_kernels)
+    lt, gt = cnf.loss_and_grad(icnf, cnf.TestMode(), xs, flat, {})
+    assert np.isfinite(lt) and torch.isfinite(gt).all() and float(gt.abs().max()) > 0
 
 
 def test_fit_transform_front_end():
@@ -1635,12 +1636,63 @@ def test_testmode_loss_gradient_small_networks():
     _assert_grad(grad.cpu().numpy(), rgrad, "TestMode gradient, conditional")
     _assert_grad(gx.cpu().numpy(), ost.grad_x, "TestMode gradient, conditional, d/dxs", rtol=2e-4)
     ic.close()
-    # outside the wave kernels: not implemented (the reference trains in TrainMode)
-    cfg3, _, _ = O.baseline_cfg(3)
-    ic = make_icnf(cnf, cfg3, kernel="auto")
-    flat = O.glorot_params(cfg3.net, np.random.default_rng(1), np.float32, 0.2)
-    with pytest.raises(NotImplementedError):
-        cnf.loss_and_grad(ic, cnf.TestMode(), _dev(np.zeros((cfg3.nvars, 8), np.float32)), flat, {})
+
+
+def test_testmode_loss_gradient_beyond_the_wave_kernels():
+    """VERDICT round 4, item 7 / "missing" 5 (test/call_tests.jl:239-252 differentiates the TestMode loss for EVERY model;
+    benchmark/benchmarks.jl:60-99): cnf_loss_grad_test for networks k_solve_wave<TEST, GRAD> does not take -- a recorded exact-trace
+    solve and ONE launch of the generic adjoint kernel k_adj_test over all accepted steps (cnf_gradt.hip).  The headline network
+    32-128-128-32 at B = 256 (adaptive, README tolerances, and fixed dt), a four-layer mixed-activation chain, config 5's
+    128-384-128 (the P / Q matrices in the global scratch), a one-layer network wider than the wave kernels take and a
+    conditional three-layer model, against the float64 oracle on the same accepted steps (itself pinned by torch autograd,
+    tests/test_grad_oracle.py); the gradient w.r.t. the data from the same sweep; bit-reproducible."""
+    from oracle import cnf_grad_oracle as G
+    T = O.ACT_TANH
+    tol = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+    cases = [
+        (O.baseline_cfg(3)[0], 256, tol, "mfma"),
+        (O.baseline_cfg(3)[0], 37, dict(adaptive=False, dt=1 / 4), "auto"),
+        (O.Cfg(O.Net((10, 24, 17, 24, 10), (T, O.ACT_SOFTPLUS, O.ACT_SIGMOID, T)), 7, 3, 0.0, 0.0, 1e-2), 19, dict(adaptive=False, dt=1 / 5), "auto"),
+        (O.baseline_cfg(5)[0], 6, dict(adaptive=False, dt=1 / 2), "auto"),
+        (O.Cfg(O.Net((40, 40), (T,)), 40, 0, 0.0, 0.0, 0.0, tspan=(1.0, 0.0)), 9, dict(adaptive=False, dt=1 / 5), "auto"),
+    ]
+    for ci, (cfg, B, sol_kw, kernel) in enumerate(cases):
+        rng = np.random.default_rng(640 + ci)
+        flat = O.glorot_params(cfg.net, rng, np.float32, 0.3)
+        flat[-cfg.n_in:] = 0.1 * rng.standard_normal(cfg.n_in).astype(np.float32)
+        xs = rng.standard_normal((cfg.nvars, B)).astype(np.float32)
+        ic = make_icnf(cnf, cfg, kernel=kernel, tag=cnf.RNODE, sol_kwargs=dict(sol_kw))
+        val, grad, gx = cnf.loss_and_grad(ic, cnf.TestMode(), _dev(xs), flat, {}, with_x=True)
+        grad, gx = grad.cpu().numpy(), gx.cpu().numpy()
+        st = ic.last_stats
+        rval, rgrad, ost = G.loss_and_grad_test(cfg, flat.astype(np.float64), xs.astype(np.float64), dts=[float(d) for d in ic.last_steps])
+        what = f"TestMode gradient (k_adj_test) {cfg.net.dims} B={B}"
+        assert st["naccept"] == ost.naccept == len(ic.last_steps), (what, st)
+        assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval)), (what, val, rval)
+        _assert_grad(grad, rgrad, what)
+        _assert_grad(gx, ost.grad_x, what + " d/dxs", rtol=2e-4)
+        # equal to the loss an inference call returns (its solve runs the fast exact-trace kernels: the solver tolerance apart)
+        lv = cnf.loss(ic, cnf.TestMode(), _dev(xs), flat, {})
+        assert abs(val - lv) <= (5e-3 if sol_kw.get("adaptive", True) else 1e-5) * max(1.0, abs(val)), (what, val, lv)
+        if ci == 1:                                            # the same call again: the same bits
+            val2, grad2 = cnf.loss_and_grad(ic, cnf.TestMode(), _dev(xs), flat, {})
+            assert val2 == val and np.array_equal(grad2.cpu().numpy(), grad)
+        ic.close()
+    # a conditional three-layer model (CondRNODE 5 + 2 with 3 conditioning inputs)
+    net = O.Net((10, 20, 20, 7), (T,) * 3)
+    rng = np.random.default_rng(78)
+    flat = O.glorot_params(net, rng, np.float32, 0.4)
+    xs = rng.standard_normal((5, 23)).astype(np.float32)
+    ys = rng.standard_normal((3, 23)).astype(np.float32)
+    layers = [cnf.Dense(10, 20, "tanh"), cnf.Dense(20, 20, "tanh"), cnf.Dense(20, 7, "tanh")]
+    ic = cnf.construct(cnf.CondRNODE, cnf.Chain(*layers), 5, 2, compute_mode=cnf.HIPVecJacMatrixMode("auto"), tspan=(0.0, 1.0),
+                       lambda3=1e-2, sol_kwargs=dict(adaptive=False, dt=1 / 6))
+    val, grad, gx = cnf.loss_and_grad(ic, cnf.TestMode(), _dev(xs), _dev(ys), flat, {}, with_x=True)
+    c64 = O.Cfg(net, 5, 2, 1e-2, 1e-2, 1e-2)
+    rval, rgrad, ost = G.loss_and_grad_test(c64, flat.astype(np.float64), xs.astype(np.float64), ys.astype(np.float64), adaptive=False, dt=1 / 6)
+    assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval))
+    _assert_grad(grad.cpu().numpy(), rgrad, "TestMode gradient (k_adj_test), conditional")
+    _assert_grad(gx.cpu().numpy(), ost.grad_x, "TestMode gradient (k_adj_test), conditional, d/dxs", rtol=2e-4)
     ic.close()
 
 
