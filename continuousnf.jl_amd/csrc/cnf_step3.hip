@@ -19,8 +19,14 @@
 //    concurrently with the first layer of the NEXT evaluation on waves 0-3 (it only needs the new stage state).
 //  * Runge-Kutta state of the z rows: u, k1 and the running stage sum in the lanes that produce zdot (waves
 //    0-3), k2..k7 in LDS (written and read back by the same lane); the three scalar rows in LDS.
-// LDS images are [sample][feature] with row strides == 8 (mod 16) floats: conflict-free ds_read_b128 B operands;
-// an accumulator tile is stored with one ds_write_b128 per lane (lane = sample, 4 rows).
+// LDS images of k_step3 (fp32) are [sample][feature] with row strides == 8 (mod 16) floats: conflict-free ds_read_b128 B
+// operands; an accumulator tile is stored with one ds_write_b128 per lane (lane = sample, 4 rows).
+// The split-bf16 kernels (k_step3b / k_solve3b, below: namespace s3v) keep XOR-swizzled unpadded bf16 rows instead: their
+// operand READS are conflict-free as well, their 8-byte epilogue STORES are two-way by construction (the 16 lanes of an MFMA
+// accumulator row group all write the same half of their 16-byte chunks: positions p and p + 8 share banks).  Measured by
+// ablation under rocprofv3 (tools/lds_conflict_ablation.sh, profiles/round5_headline_lds_conflicts.md): 69 % of the launch's
+// SQ_LDS_BANK_CONFLICT cycles are those stores (exactly half of their LDS cycles), none are operand reads, the rest are the
+// fp32 Runge-Kutta rows; the LDS pipe is 35 % busy, so the conflicts cost 5.6 % of ITS time and nothing measurable of the launch's.
 #include "cnf_step3_dev.h"
 #include <mutex>
 
