@@ -888,6 +888,8 @@ void bcast_pack(const NetDesc& nd, const float* d_params, float* d_img, hipStrea
 }
 
 // workgroups the device holds at once: one per CU (four waves of 512 registers)
+// CNF_BCAST_FORCE_MULTI=1 (measurements): the several-tiles-per-workgroup form even when every tile has a CU of its own
+static bool bcast_force_multi() { static const bool v = [] { const char* e = getenv("CNF_BCAST_FORCE_MULTI"); return e && e[0] == '1'; }(); return v; }
 static int bcast_resident(int device) {
     constexpr int MAXDEV = 64;
     static std::mutex mu;
@@ -909,7 +911,7 @@ bool bcast_solve_supported(const NetDesc& nd, bool train, int B, int device) {
     if (off || B < 1) return false;
     const int res = bcast_resident(device);
     if (res <= 0) return false;
-    const bool multi = (B + 7) / 8 > res;
+    const bool multi = (B + 7) / 8 > res || bcast_force_multi();
     // conditional models: the per-sample first-layer bias is staged in LDS per tile -- one tile per workgroup, VJP / TestMode
     if (nd.n_cond > 0 && (multi || (train && nd.jvp))) return false;
     return true;
@@ -918,7 +920,7 @@ bool bcast_solve_supported(const NetDesc& nd, bool train, int B, int device) {
 // floats of the tile store a launch needs (0: every workgroup owns one tile, the rows stay on the CU)
 size_t bcast_store_floats(int B, int device) {
     const int res = bcast_resident(device), ntiles = (B + 7) / 8;
-    if (res <= 0 || ntiles <= res) return 0;
+    if (res <= 0 || (ntiles <= res && !bcast_force_multi())) return 0;
     return (size_t)ntiles * (BC_TROWS * 1024 + BC_TSC);
 }
 
@@ -927,7 +929,7 @@ cnf_status bcast_solve_launch(const NetDesc& nd, bool train, const float* d_para
                               float* store, const float* cond, int cbs) {
     if (!bcast_solve_supported(nd, train, B, device) || !d_img) return CNF_ERR_UNSUPPORTED;
     const int res = bcast_resident(device), ntiles = (B + 7) / 8;
-    const bool multi = ntiles > res;
+    const bool multi = ntiles > res || bcast_force_multi();
     if (multi && !store) return CNF_ERR_BAD_ARG;
     if (nd.n_cond > 0 && !cond) return CNF_ERR_BAD_ARG;
     BcArgs a{};
@@ -938,7 +940,7 @@ cnf_status bcast_solve_launch(const NetDesc& nd, bool train, const float* d_para
     Solve3Args sv = sv_;
     sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
     if (!sv.xs && !sv.u0) return CNF_ERR_BAD_ARG;
-    const int grid = multi ? res : ntiles;
+    const int grid = multi ? (ntiles < res ? ntiles : res) : ntiles;
     if (multi) {                                           // (a wait lasts as long as the slowest workgroup's tiles take)
         const unsigned long long w = (unsigned long long)sv.wait_ticks * (unsigned)((ntiles + grid - 1) / grid);
         sv.wait_ticks = w > 2000000000ull ? 2000000000u : (unsigned)w;

@@ -735,7 +735,9 @@ k_trace3s(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const floa
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am_[t], bc.h, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bc.m, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bc.h, c, 0, 0, 0);
+#ifndef TR3S_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
+#endif
             if (t < 4) split_q(t, vlo, vhi);
             if (t > 0) {
                 // cprev[r] = d2[j] Z[k = 16 (t-1) + 4q + r][j = 16 wave + s]; W2[j][k] = wa[t-1][r], d1[k] = d1n[r]
@@ -744,6 +746,16 @@ k_trace3s(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const floa
                 for (int r = 0; r < 4; ++r) sum[r] = fmaf(cprev[r], wd[r], sum[r]);
             }
             d1n = *reinterpret_cast<const f32x4*>(db + m.o_off[0] + 16 * t + 4 * q);
+#ifdef TR3S_INTERLEAVE
+            // -DTR3S_INTERLEAVE=<n> (A/B, round 5): the tile's vector work BETWEEN its six dependent MFMAs, n VALU instructions per gap,
+            // instead of behind them.  Measured on the TestMode solve of the headline network (B = 8192, 74 evaluations): n = 3:
+            // 3.76-3.81 ms, n = 5: 3.60-3.70 ms, as shipped: 3.59-3.63 ms -- no gain: not the default.
+#pragma unroll
+            for (int g_ = 0; g_ < 6; ++g_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, TR3S_INTERLEAVE, 0);
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             cprev = c;
         }
