@@ -1804,6 +1804,53 @@ def test_submitted_gradients_equal_the_synchronous_ones():
         res.append((psf, rep["losses"]))
         icf.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    # ... and a pipelined fit whose submitted launches GIVE UP (every wait runs out at its first poll) loses no step: the gated
+    # update leaves parameters and momentum alone, the batches run again synchronously (on the streamed gradient path, since the
+    # synchronous in-launch attempt gives up as well) and no NaN reaches the report (mlj.py)
+    nn = cnf.Chain(cnf.Dense(4, 12, "tanh"), cnf.Dense(12, 4, "tanh"))
+    icf = cnf.construct(cnf.RNODE, nn, 2, 2, compute_mode=cnf.HIPVecJacMatrixMode(), tspan=(0.0, 3.0), steer_rate=0.1, lambda3=1e-2, rng=5)
+    icf.set_solve_wait(poll_limit=1)
+    model = cnf.ICNFModel(icf, optimizers=(cnf.Adam(eta=1e-3),), n_epochs=2, batch_size=32, pipelined=True)
+    fb0 = icf.solve_fallbacks()
+    (psg, _), _, repg = cnf.fit(model, 0, data)
+    assert icf.solve_fallbacks() > fb0, "no launch gave up: the test did not exercise the path"
+    # (a batch that runs again draws new probes and a new steered end time, so the runs are not comparable number by number:
+    # every iteration has a finite loss of the same size, and the parameters moved as far as 16 Adam steps move them)
+    assert np.isfinite(repg["losses"]).all() and len(repg["losses"]) == len(res[1][1]) == repg["stats"]["iterations"]
+    assert abs(np.mean(repg["losses"]) / np.mean(res[1][1]) - 1.0) <= 0.25, (repg["losses"], res[1][1])
+    assert np.isfinite(psg).all() and 0 < np.abs(psg - res[1][0]).max() <= 2 * 16 * 1e-3
+    icf.close()
+
+
+def test_set_params_async_does_not_change_a_submitted_inference():
+    """ADVICE round 4 (cnf_abi.hip): a submitted INFERENCE that gives up is run again by its collect call with the parameters the
+    handle holds THEN, so cnf_set_params_async must not slip new parameters under it: it settles such submissions first.  A
+    submission whose launch gives up for certain (poll_limit = 1), new parameters uploaded asynchronously before the collect: the
+    collected result is the one of the parameters it was submitted with."""
+    cfg, _, _ = O.baseline_cfg(3)
+    rng = np.random.default_rng(1850)
+    B = 8192
+    flat_a = O.glorot_params(cfg.net, rng, np.float32, 0.1)
+    flat_b = (flat_a * 0.5).astype(np.float32)
+    xs, eps = _dev(rng.standard_normal((cfg.nvars, B))), _dev(rng.standard_normal((cfg.n_in, B)))
+    ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=dict(adaptive=False, dt=1 / 8))
+    pa, pb = torch.from_numpy(flat_a).cuda(), torch.from_numpy(flat_b).cuda()
+    want_a, _ = cnf.inference(ic, cnf.TrainMode(), xs, pa, {}, eps=eps)
+    want_a = want_a.clone()
+    want_b, _ = cnf.inference(ic, cnf.TrainMode(), xs, pb, {}, eps=eps)
+    want_b = want_b.clone()
+    assert float((want_a - want_b).abs().max()) > 1e-2
+    if _one_launch_expected():
+        ic.set_solve_wait(poll_limit=1)                              # the submitted launch gives up; its collect runs it again
+    logpx, _, _ = cnf.inference_submit(ic, cnf.TrainMode(), xs, pa, {}, eps=eps, with_sums=True)
+    ic.set_params_async(pb)                                          # settles the submission first (host wait), then uploads
+    cnf.inference_collect(ic)
+    torch.cuda.synchronize()
+    assert torch.allclose(logpx, want_a, rtol=2e-5, atol=2e-5), float((logpx - want_a).abs().max())
+    ic.set_solve_wait(poll_limit=0x7fffffff)
+    got_b, _ = cnf.inference(ic, cnf.TrainMode(), xs, pb, {}, eps=eps)
+    assert torch.allclose(got_b, want_b, rtol=2e-5, atol=2e-5)
+    ic.close()
 
 
 def test_loss_grad_wave_local_hands_over_beyond_its_step_store():
