@@ -10,6 +10,7 @@
 #include "cnf_wave.h"
 #include "cnf_bcast.h"
 #include "cnf_gradt.h"
+#include "cnf_adj3b.h"
 #include "cnf_step3.h"
 #include <immintrin.h>
 #include <sched.h>
@@ -1802,7 +1803,9 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
         if (adj_mfma) {        // the six stage pullbacks and the lambda update of this step in ONE launch
             S.first = 5; S.last = 0; S.B = B; S.lam_update = 1; S.lam_out = h->g_lam;
             for (int m = 0; m < 6; ++m) for (int d = 0; d < 5; ++d) S.kc[m][d] = m - 1 - d >= 0 ? A[m][m - 1 - d] : 0.f;
-            HIPCHK(h, launch_adj_mfma_step(nd, gl, am, h->d_adj_img, S, st));
+            // (the headline shape: the same step on split-bf16 products, cnf_adj3b.hip -- the image is the forward kernels')
+            if (adj3b_supported(nd) && h->mfma.d_img3b) HIPCHK(h, launch_adj3b(nd, gl, h->mfma.d_img3b, S, st));
+            else HIPCHK(h, launch_adj_mfma_step(nd, gl, am, h->d_adj_img, S, st));
         } else {
             StageK ws{};
             ws.nk = 6;

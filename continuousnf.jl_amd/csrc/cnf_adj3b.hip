@@ -1,0 +1,479 @@
+// k_adj3b -- the pullback of one Runge-Kutta step of the headline shape 32 -> 128 -> 128 -> 32 (tanh) on SPLIT-bf16 products:
+// what k_adj3 (cnf_grad.hip) computes on v_mfma_f32_16x16x4_f32, with every fp32 product formed from six
+// v_mfma_f32_16x16x32_bf16 terms on operands split exactly into three bf16 pieces (cnf_split.h) -- the arithmetic of the
+// forward kernels k_step3b / k_solve3b (cnf_step3.hip), at 2.7x the matrix rate of the fp32 MFMA.
+//
+// What it is the derivative of: `augmented_f` in TrainMode / VJP (src/icnf.jl:318-350) inside the Tsit5 step the forward solve
+// accepted -- the reference gets it from Enzyme + SciMLSensitivity inside MLJModelInterface.fit
+// (src/exts/mlj_ext/core_icnf.jl:59-73).  Algebra: oracle/cnf_grad_oracle.py (rhs_vjp) and the header of k_adj3: per stage, with
+// ahat = kbar_z + c_E zdot/|zdot|, omega = eps, tau = -c_l eps + c_n eJ/|eJ|, four sweeps over the three layers --
+// forward (h, s', s''), reverse of eps (tbar, pbar = tbar s'), forward tangent of tau (t, q = s'' W t), reverse cotangent
+// (abar = hbar s' + tbar q) -- emitting the four factor arrays of the weight gradient (abar_l, pbar_l | h_{l-1}, t_{l-1}) and
+// zbar; the six stages of the step run last to first inside the launch, zbar and the running sums stay on the CU.
+//
+// Layout = k_step3b's: one workgroup of 8 waves per 32 samples; wave w owns the 16-row tile w of both wide layers in both
+// directions (A fragments of W1, W2, W3^T, W2^T resident in registers as split pieces for the whole launch: 120 VGPRs), the
+// K = 128 operands of the 32-row products (rows of W3 on waves 0-3, rows of W1^T on waves 4-7) are split LDS images; the
+// activations travel between layers as XOR-swizzled split images (conflict-free ds_read_b128 operands).  What is new against
+// k_adj3: the elementwise state of the WIDE layers (s', s'', tbar: the producing lane is the consuming lane in every sweep)
+// lives in REGISTERS (48 VGPRs) instead of 119 KB of LDS -- which is what makes room for the split images -- and the per-row
+// state of the 32-row arrays (lambda, the zbar shift register, eps, ahat, s'_3, s''_3) sits in swizzled fp32 LDS rows owned by
+// the lanes that produce zdot / zbar (waves w and w + 4 share the addresses: 13 barrier intervals per stage).
+#include "cnf_adj3b.h"
+#include "cnf_step3_dev.h"
+#include "cnf_mfma_dev.h"
+
+#include <cstdlib>
+
+namespace a3b {
+constexpr int WS = 256, WP = 32 * WS, WI = 3 * WP;        // K = 128 split image: [piece][32 rows][128 bf16], chunks XOR-swizzled by the row
+constexpr int NS = 64, NP = 32 * NS, NI = 3 * NP;         // K = 32
+// fp32 area (float offsets).  Owner rows: [32 samples][32 rows], 16-byte chunk c of sample r at chunk position c ^ (r & 7)
+constexpr int OWN = 32 * 32;
+constexpr int KS = 0;                                      // zbar shift register: 5 owner arrays
+constexpr int LAM = KS + 5 * OWN, LSUM = LAM + OWN, EPSA = LSUM + OWN, AHAT = EPSA + OWN, D13 = AHAT + OWN, D23 = D13 + OWN;
+constexpr int EJ = D23 + OWN;                              // eJ, then zbar: from waves 4-7 to the owner lanes
+constexpr int RED = EJ + OWN;                              // partials [|zdot|^2 | |eJ|^2][32 samples][8]
+constexpr int BIAS = RED + 2 * 32 * 8;                     // b1 (128), b2 (128), b3 (32)
+constexpr int FP_END = BIAS + 2 * 128 + 32;
+constexpr int H1G = FP_END * 4, H2G = H1G + WI, W3I = H2G + WI, W1TI = W3I + WI, X0S = W1TI + WI, G3S = X0S + NI;
+constexpr int TOTAL_BYTES = G3S + NI;
+static_assert(H1G % 16 == 0 && TOTAL_BYTES <= 160 * 1024, "LDS plan");
+static_assert(WI == s3g::WI, "the global image of k_step3b");
+}  // namespace a3b
+
+namespace {
+
+#ifdef A3B_STAMPS
+#define A3T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); a3acc[i] += t_ - a3last; a3last = t_; } while (0)
+#else
+#define A3T(i) do {} while (0)
+#endif
+
+__device__ __forceinline__ f32x4 a3b_d2tanh4(const f32x4& h, const f32x4& d1) {      // s'' = -2 h s'
+    return f32x4{-2.f * h.x * d1.x, -2.f * h.y * d1.y, -2.f * h.z * d1.z, -2.f * h.w * d1.w};
+}
+
+__global__ void __launch_bounds__(512, 2)
+k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* ldsb = reinterpret_cast<char*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_in = nd.n_in, D = n_in + 3;
+    const int s = lane & 15, q = lane >> 4;
+    const int t = wave & 1, hf = (wave >> 1) & 1;         // 32-row products: row tile and sample half of this wave
+    const bool zown = wave < 4;                           // waves 0-3: the W3 products and the owner rows; waves 4-7: the W1^T products
+    const int smp = 16 * hf + s;                          // sample of this lane in the 32-row products
+    const int r0 = 16 * t + 4 * q;                        // first of its 4 rows there
+    const int nv = n_in - r0;                             // valid rows among them (<= 0 .. >= 4)
+    const int b0 = blockIdx.x * 32;
+    const bool olive = b0 + smp < S.B;                    // the owner lane's sample exists
+    const int ga = b0 + s, gb = b0 + 16 + s;              // the two samples of this lane in the wide products
+    const bool la = ga < S.B, lb = gb < S.B;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- weights: resident split fragments (as k_step3b), the two K = 128 LDS images by LDS-DMA, biases ----
+    constexpr int NCI = 2 * a3b::WI / 16, NCB = (2 * 128 + 32) / 4;
+    typedef __attribute__((address_space(3))) char* lds_c;
+    typedef const __attribute__((address_space(1))) char* glb_c;
+    const f32x4 sgb = reinterpret_cast<const f32x4*>(imgb + s3g::BIASB)[min(tid, NCB - 1)];
+    S3bOp wF1, wF2[4], wB3, wB2[4];
+    {
+        const char* fw = imgb + s3g::F32 + (size_t)wave * 10 * 2048 + 16 * lane;
+        constexpr int AH = 5;
+        f32x4 raw[10][2];
+#pragma unroll
+        for (int f = 0; f < AH; ++f) { raw[f][0] = *(const f32x4*)(fw + f * 2048); raw[f][1] = *(const f32x4*)(fw + f * 2048 + 1024); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 10; ++f) {
+            if (f + AH < 10) {
+                raw[f + AH][0] = *(const f32x4*)(fw + (f + AH) * 2048);
+                raw[f + AH][1] = *(const f32x4*)(fw + (f + AH) * 2048 + 1024);
+            }
+            S3bOp o = s3b_split8(raw[f][0], raw[f][1]);
+            s3b_pin(o);
+            if (f == 0) wF1 = o; else if (f < 5) wF2[f - 1] = o; else if (f == 5) wB3 = o; else wB2[f - 6] = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (NCI + 511) / 512; ++i) {
+        const int c = 512 * i + 64 * wave;
+        if (c < NCI)
+            __builtin_amdgcn_global_load_lds((glb_c)(imgb + s3g::W3I + 16 * (c + lane)), (lds_c)(ldsb + a3b::W3I + 16 * c), 16, 0, 0);
+    }
+    if (tid < NCB) reinterpret_cast<f32x4*>(lds + a3b::BIAS)[tid] = sgb;
+
+    // ---- addresses (k_step3b's) ----
+    const int wb_rd = s * a3b::WS + 16 * (q ^ s);
+    const int wb_wr = s * a3b::WS + 16 * ((2 * wave + (q >> 1)) ^ s) + 8 * (q & 1);
+    constexpr int HBW = 16 * a3b::WS;
+    const char* nrA = ldsb + (zown ? a3b::W3I : a3b::W1TI) + 16 * t * a3b::WS;
+    const char* nrB = ldsb + (zown ? a3b::H2G : a3b::H1G) + 16 * hf * a3b::WS;
+    const int nsw = (-(s >> 2)) & 3;
+    const int nw = smp * a3b::NS + 16 * ((2 * t + (q >> 1)) ^ nsw) + 8 * (q & 1);
+    char* x0w = ldsb + a3b::X0S + nw;
+    char* g3w = ldsb + a3b::G3S + nw;
+    const int nb_rd = s * a3b::NS + 16 * (q ^ nsw);
+    constexpr int HBN = 16 * a3b::NS;
+    const float* bias = lds + a3b::BIAS;
+    // owner rows: this lane's 4 rows of sample smp (waves w and w + 4 share the address: the hand-over of eJ / zbar)
+    const int own = smp * 32 + 4 * (((r0 >> 2)) ^ (smp & 7));
+    float* redw = lds + a3b::RED + smp * 8 + 4 * t + q;
+    auto red8 = [&](int kind) {
+        const float* r = lds + a3b::RED + (kind * 32 + smp) * 8;
+        const f32x4 a_ = *(const f32x4*)r, b_ = *(const f32x4*)(r + 4);
+        return ((a_.x + a_.y) + (a_.z + a_.w)) + ((b_.x + b_.y) + (b_.z + b_.w));
+    };
+    auto ownp = [&](int arr) -> f32x4* { return reinterpret_cast<f32x4*>(lds + arr + own); };
+
+    // ---- per launch: eps into the owner rows (waves 0-3 use it); lambda, the running sum, the shift register and the state of
+    // the first stage are the business of waves 4-7, which produce zbar: they do the bookkeeping of a finished stage themselves,
+    // in the interval that produced its zbar (no interval of its own) ----
+    auto stage_entry = [&](int stg, const f32x4& xz, const f32x4& w, bool have_w) __attribute__((always_inline)) {
+        // zbar `w` of stage stg + 1 -> running sum and shift register; kbar_z of stage `stg` -> AHAT; its state -> X0S, HS
+        const AdjArgs& a = S.st[stg];
+        const int ocnt = olive ? nv : 0;
+        f32x4 k0 = *ownp(a3b::KS);
+        if (have_w) {
+            *ownp(a3b::LSUM) = *ownp(a3b::LSUM) + w;
+            k0 += S.kc[stg + 1][0] * w;
+#pragma unroll
+            for (int d = 1; d < 5; ++d) *ownp(a3b::KS + (d - 1) * a3b::OWN) = *ownp(a3b::KS + d * a3b::OWN) + S.kc[stg + 1][d] * w;
+            *ownp(a3b::KS + 4 * a3b::OWN) = zero4;
+        }
+        *ownp(a3b::AHAT) = ld4_mask((a.cb * *ownp(a3b::LAM) + k0) * a.hstep, ocnt);      // (completed to ahat behind the forward sweep)
+        s3b_store4(x0w, a3b::NP, xz);
+        if (ocnt > 0) st4(a.HS + (size_t)(b0 + smp) * gl.sum_in + r0, xz, ocnt);
+    };
+    {
+        const AdjArgs& a0 = S.st[S.first];
+        const int cnt = olive ? nv : 0;
+        if (zown) *ownp(a3b::EPSA) = ld4(a0.eps + (size_t)(b0 + smp) * n_in + r0, cnt);
+        else {
+            *ownp(a3b::LAM) = ld4(a0.lam + (size_t)(b0 + smp) * n_in + r0, cnt);
+            *ownp(a3b::LSUM) = zero4;
+#pragma unroll
+            for (int d = 0; d < 5; ++d) *ownp(a3b::KS + d * a3b::OWN) = zero4;
+            stage_entry(S.first, ld4(a0.ustage + (size_t)(b0 + smp) * D + r0, cnt), zero4, false);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA pieces have landed
+    s3_bar();
+
+    // elementwise state of the wide layers, tile `wave`, halves A / B: lane (q, s) = rows 16 wave + 4q .. of samples s, 16 + s
+    f32x4 D11[2], D21[2], TB1[2], D12[2], D22[2], TB2[2];
+#ifdef A3B_STAMPS
+    unsigned long long a3acc[32] = {0};
+    unsigned long long a3last = __builtin_amdgcn_s_memtime();
+#endif
+    f32x4 xpf = zero4;
+    const int wrow = 16 * wave + 4 * q;                    // first of this lane's 4 rows in a wide tile
+
+    for (int stg = S.first; stg >= S.last; --stg) {
+        const AdjArgs& a = S.st[stg];
+        // (32-bit element offsets into the factor arrays: the 64-bit addresses are formed at the stores, not carried)
+        const int iA = ga * gl.sum_in + wrow, iB = gb * gl.sum_in + wrow, oA = ga * gl.sum_out + wrow, oB = gb * gl.sum_out + wrow;
+        float* const hsA = a.HS + iA; float* const hsB = a.HS + iB;
+        float* const tsA = a.TS + iA; float* const tsB = a.TS + iB;
+        float* const abA = a.AB + oA; float* const abB = a.AB + oB;
+        float* const pbA = a.PB + oA; float* const pbB = a.PB + oB;
+        const size_t orow = (size_t)(b0 + smp);
+        const int ocnt = olive ? nv : 0;
+        // ---- sweep 1: forward.  I0: layer 1, tile `wave`, both halves (K = 32) ----
+        {
+            const f32x4 bv = *(const f32x4*)(bias + wrow);
+            S3bOp b[2];
+            b[0] = s3b_load(ldsb + a3b::X0S + nb_rd, a3b::NP);
+            b[1] = s3b_load(ldsb + a3b::X0S + nb_rd + HBN, a3b::NP);
+            S3_SB();
+            f32x4 acc[2] = {zero4, zero4};
+            s3b_mm<2>(acc, wF1, b);
+            const f32x4 ha = s3_tanh4(acc[0] + bv), hb = s3_tanh4(acc[1] + bv);
+            D11[0] = s3_dtanh4(ha); D11[1] = s3_dtanh4(hb);
+            D21[0] = a3b_d2tanh4(ha, D11[0]); D21[1] = a3b_d2tanh4(hb, D11[1]);
+            s3b_store4(ldsb + a3b::H1G + wb_wr, a3b::WP, ha);
+            s3b_store4(ldsb + a3b::H1G + wb_wr + HBW, a3b::WP, hb);
+            if (la) st4_wide(hsA + gl.in_off[1], ha);
+            if (lb) st4_wide(hsB + gl.in_off[1], hb);
+        }
+        A3T(0);
+        s3_bar();
+        A3T(1);
+        // I1: layer 2
+        {
+            const f32x4 bv = *(const f32x4*)(bias + 128 + wrow);
+            f32x4 acc[2] = {zero4, zero4};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                S3bOp b[2];
+                b[0] = s3b_load(ldsb + a3b::H1G + (wb_rd ^ (64 * kb)), a3b::WP);
+                b[1] = s3b_load(ldsb + a3b::H1G + HBW + (wb_rd ^ (64 * kb)), a3b::WP);
+                S3_SB();
+                s3b_mm<2>(acc, wF2[kb], b);
+                S3_SB();
+            }
+            const f32x4 ha = s3_tanh4(acc[0] + bv), hb = s3_tanh4(acc[1] + bv);
+            D12[0] = s3_dtanh4(ha); D12[1] = s3_dtanh4(hb);
+            D22[0] = a3b_d2tanh4(ha, D12[0]); D22[1] = a3b_d2tanh4(hb, D12[1]);
+            s3b_store4(ldsb + a3b::H2G + wb_wr, a3b::WP, ha);
+            s3b_store4(ldsb + a3b::H2G + wb_wr + HBW, a3b::WP, hb);
+            if (la) st4_wide(hsA + gl.in_off[2], ha);
+            if (lb) st4_wide(hsB + gl.in_off[2], hb);
+        }
+        A3T(2);
+        s3_bar();
+        A3T(3);
+        // I2 (waves 0-3): layer 3: zdot rows r0 .. r0+3 of sample smp; pbar_3 = eps s'_3 -> G3S, PB
+        f32x4 zdv = zero4;
+        if (zown) {
+            const f32x4 bv3 = *(const f32x4*)(bias + 256 + r0);
+            f32x4 z0 = zero4, z1 = zero4;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), a3b::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), a3b::WP);
+                S3_SB();
+                z0 = s3b_term<0>(av, bvv, z0); z1 = s3b_term<3>(av, bvv, z1);
+                z0 = s3b_term<1>(av, bvv, z0); z1 = s3b_term<4>(av, bvv, z1);
+                z0 = s3b_term<2>(av, bvv, z0); z1 = s3b_term<5>(av, bvv, z1);
+                S3_SB();
+            }
+            zdv = s3_tanh4(z0 + z1 + bv3);                 // padded rows: zero weights and bias -> 0
+            const f32x4 d13 = s3_dtanh4(zdv);
+            *ownp(a3b::D13) = d13;
+            *ownp(a3b::D23) = a3b_d2tanh4(zdv, d13);
+            const f32x4 pb = *ownp(a3b::EPSA) * d13;       // (eps is zero in padded rows and beyond the batch)
+            s3b_store4(g3w, a3b::NP, pb);
+            if (ocnt > 0) st4(a.PB + orow * gl.sum_out + gl.out_off[2] + r0, pb, ocnt);
+            redw[0] = s3_dot4(zdv, zdv);
+        }
+        A3T(4);
+        s3_bar();
+        A3T(5);
+        // ---- sweep 2: the tbar chain (omega = eps).  I3: W3^T pbar_3 = tbar_2; pbar_2 = tbar_2 s'_2 over h2 in place ----
+        {
+            S3bOp b[2];
+            b[0] = s3b_load(ldsb + a3b::G3S + nb_rd, a3b::NP);
+            b[1] = s3b_load(ldsb + a3b::G3S + nb_rd + HBN, a3b::NP);
+            S3_SB();
+            f32x4 acc[2] = {zero4, zero4};
+            s3b_mm<2>(acc, wB3, b);
+            TB2[0] = acc[0]; TB2[1] = acc[1];
+            const f32x4 pa = acc[0] * D12[0], pb = acc[1] * D12[1];
+            s3b_store4(ldsb + a3b::H2G + wb_wr, a3b::WP, pa);
+            s3b_store4(ldsb + a3b::H2G + wb_wr + HBW, a3b::WP, pb);
+            if (la) st4_wide(pbA + gl.out_off[1], pa);
+            if (lb) st4_wide(pbB + gl.out_off[1], pb);
+            if (zown) {                                    // ahat = kbar_z + c_E zdot / |zdot|   (|zdot|^2: complete since the barrier)
+                const float nz = red8(0);
+                const float inv = (nd.norm_z && nz > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz) : 0.f;
+                *ownp(a3b::AHAT) = ld4_mask(*ownp(a3b::AHAT) + inv * zdv, ocnt);
+            }
+        }
+        A3T(6);
+        s3_bar();
+        A3T(7);
+        // I4: W2^T pbar_2 = tbar_1; pbar_1 = tbar_1 s'_1 over h1 in place
+        {
+            f32x4 acc[2] = {zero4, zero4};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                S3bOp b[2];
+                b[0] = s3b_load(ldsb + a3b::H2G + (wb_rd ^ (64 * kb)), a3b::WP);
+                b[1] = s3b_load(ldsb + a3b::H2G + HBW + (wb_rd ^ (64 * kb)), a3b::WP);
+                S3_SB();
+                s3b_mm<2>(acc, wB2[kb], b);
+                S3_SB();
+            }
+            TB1[0] = acc[0]; TB1[1] = acc[1];
+            const f32x4 pa = acc[0] * D11[0], pb = acc[1] * D11[1];
+            s3b_store4(ldsb + a3b::H1G + wb_wr, a3b::WP, pa);
+            s3b_store4(ldsb + a3b::H1G + wb_wr + HBW, a3b::WP, pb);
+            if (la) st4_wide(pbA + gl.out_off[0], pa);
+            if (lb) st4_wide(pbB + gl.out_off[0], pb);
+        }
+        A3T(8);
+        s3_bar();
+        A3T(9);
+        // I5 (waves 4-7): eJ = W1^T pbar_1 -> the owner rows; |eJ|^2 partials
+        if (!zown) {
+            f32x4 j0 = zero4, j1 = zero4;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), a3b::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), a3b::WP);
+                S3_SB();
+                j0 = s3b_term<0>(av, bvv, j0); j1 = s3b_term<3>(av, bvv, j1);
+                j0 = s3b_term<1>(av, bvv, j0); j1 = s3b_term<4>(av, bvv, j1);
+                j0 = s3b_term<2>(av, bvv, j0); j1 = s3b_term<5>(av, bvv, j1);
+                S3_SB();
+            }
+            const f32x4 ej = ld4_mask(j0 + j1, nv);        // (rows of z only)
+            *ownp(a3b::EJ) = ej;
+            redw[32 * 8] = s3_dot4(ej, ej);
+            if (stg > S.last) xpf = ld4(S.st[stg - 1].ustage + orow * D + r0, ocnt);      // the next stage's state: in flight during sweeps 3 and 4
+        }
+        A3T(10);
+        s3_bar();
+        A3T(11);
+        // E1 (owner lanes): tau = -c_l eps + c_n eJ / |eJ| -> X0S as t_0, TS; the next stage's state is requested
+        if (zown) {
+            const float nj = red8(1);
+            const float inv = (nd.norm_j && nj > 0.f) ? a.c_n * __builtin_amdgcn_rsqf(nj) : 0.f;
+            const f32x4 tau = ld4_mask(inv * *ownp(a3b::EJ) - a.c_l * *ownp(a3b::EPSA), nv);
+            s3b_store4(x0w, a3b::NP, tau);
+            if (ocnt > 0) st4(a.TS + orow * gl.sum_in + r0, tau, ocnt);
+        }
+        A3T(12);
+        s3_bar();
+        A3T(13);
+        // ---- sweep 3: the tangent chain.  I0': t_1 = s'_1 (W1 t_0), q_1 = s''_1 (W1 t_0) ----
+        {
+            S3bOp b[2];
+            b[0] = s3b_load(ldsb + a3b::X0S + nb_rd, a3b::NP);
+            b[1] = s3b_load(ldsb + a3b::X0S + nb_rd + HBN, a3b::NP);
+            S3_SB();
+            f32x4 acc[2] = {zero4, zero4};
+            s3b_mm<2>(acc, wF1, b);
+            const f32x4 ta = D11[0] * acc[0], tb = D11[1] * acc[1];
+            D21[0] = D21[0] * acc[0]; D21[1] = D21[1] * acc[1];                      // q_1 over s''_1
+            s3b_store4(ldsb + a3b::H1G + wb_wr, a3b::WP, ta);
+            s3b_store4(ldsb + a3b::H1G + wb_wr + HBW, a3b::WP, tb);
+            if (la) st4_wide(tsA + gl.in_off[1], ta);
+            if (lb) st4_wide(tsB + gl.in_off[1], tb);
+        }
+        A3T(14);
+        s3_bar();
+        A3T(15);
+        // I1': t_2, q_2
+        {
+            f32x4 acc[2] = {zero4, zero4};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                S3bOp b[2];
+                b[0] = s3b_load(ldsb + a3b::H1G + (wb_rd ^ (64 * kb)), a3b::WP);
+                b[1] = s3b_load(ldsb + a3b::H1G + HBW + (wb_rd ^ (64 * kb)), a3b::WP);
+                S3_SB();
+                s3b_mm<2>(acc, wF2[kb], b);
+                S3_SB();
+            }
+            const f32x4 ta = D12[0] * acc[0], tb = D12[1] * acc[1];
+            D22[0] = D22[0] * acc[0]; D22[1] = D22[1] * acc[1];
+            s3b_store4(ldsb + a3b::H2G + wb_wr, a3b::WP, ta);
+            s3b_store4(ldsb + a3b::H2G + wb_wr + HBW, a3b::WP, tb);
+            if (la) st4_wide(tsA + gl.in_off[2], ta);
+            if (lb) st4_wide(tsB + gl.in_off[2], tb);
+        }
+        A3T(16);
+        s3_bar();
+        A3T(17);
+        // I2' (waves 0-3): abar_3 = ahat s'_3 + eps (s''_3 W3 t_2) -> G3S, AB
+        if (zown) {
+            f32x4 z0 = zero4, z1 = zero4;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), a3b::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), a3b::WP);
+                S3_SB();
+                z0 = s3b_term<0>(av, bvv, z0); z1 = s3b_term<3>(av, bvv, z1);
+                z0 = s3b_term<1>(av, bvv, z0); z1 = s3b_term<4>(av, bvv, z1);
+                z0 = s3b_term<2>(av, bvv, z0); z1 = s3b_term<5>(av, bvv, z1);
+                S3_SB();
+            }
+            const f32x4 q3 = *ownp(a3b::D23) * (z0 + z1);
+            const f32x4 ab = *ownp(a3b::AHAT) * *ownp(a3b::D13) + *ownp(a3b::EPSA) * q3;
+            s3b_store4(g3w, a3b::NP, ab);
+            if (ocnt > 0) st4(a.AB + orow * gl.sum_out + gl.out_off[2] + r0, ab, ocnt);
+        }
+        A3T(18);
+        s3_bar();
+        A3T(19);
+        // ---- sweep 4: the hbar chain.  I3': abar_2 = (W3^T abar_3) s'_2 + tbar_2 q_2 ----
+        {
+            S3bOp b[2];
+            b[0] = s3b_load(ldsb + a3b::G3S + nb_rd, a3b::NP);
+            b[1] = s3b_load(ldsb + a3b::G3S + nb_rd + HBN, a3b::NP);
+            S3_SB();
+            f32x4 acc[2] = {zero4, zero4};
+            s3b_mm<2>(acc, wB3, b);
+            const f32x4 aa = acc[0] * D12[0] + TB2[0] * D22[0], ab = acc[1] * D12[1] + TB2[1] * D22[1];
+            s3b_store4(ldsb + a3b::H2G + wb_wr, a3b::WP, aa);
+            s3b_store4(ldsb + a3b::H2G + wb_wr + HBW, a3b::WP, ab);
+            if (la) st4_wide(abA + gl.out_off[1], aa);
+            if (lb) st4_wide(abB + gl.out_off[1], ab);
+        }
+        A3T(20);
+        s3_bar();
+        A3T(21);
+        // I4': abar_1 = (W2^T abar_2) s'_1 + tbar_1 q_1
+        {
+            f32x4 acc[2] = {zero4, zero4};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                S3bOp b[2];
+                b[0] = s3b_load(ldsb + a3b::H2G + (wb_rd ^ (64 * kb)), a3b::WP);
+                b[1] = s3b_load(ldsb + a3b::H2G + HBW + (wb_rd ^ (64 * kb)), a3b::WP);
+                S3_SB();
+                s3b_mm<2>(acc, wB2[kb], b);
+                S3_SB();
+            }
+            const f32x4 aa = acc[0] * D11[0] + TB1[0] * D21[0], ab = acc[1] * D11[1] + TB1[1] * D21[1];
+            s3b_store4(ldsb + a3b::H1G + wb_wr, a3b::WP, aa);
+            s3b_store4(ldsb + a3b::H1G + wb_wr + HBW, a3b::WP, ab);
+            if (la) st4_wide(abA + gl.out_off[0], aa);
+            if (lb) st4_wide(abB + gl.out_off[0], ab);
+        }
+        A3T(22);
+        s3_bar();
+        A3T(23);
+        // I5' (waves 4-7): zbar = W1^T abar_1 -> the owner rows (zero beyond the batch and in padded rows)
+        if (!zown) {
+            f32x4 j0 = zero4, j1 = zero4;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), a3b::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), a3b::WP);
+                S3_SB();
+                j0 = s3b_term<0>(av, bvv, j0); j1 = s3b_term<3>(av, bvv, j1);
+                j0 = s3b_term<1>(av, bvv, j0); j1 = s3b_term<4>(av, bvv, j1);
+                j0 = s3b_term<2>(av, bvv, j0); j1 = s3b_term<5>(av, bvv, j1);
+                S3_SB();
+            }
+            const f32x4 zb = ld4_mask(j0 + j1, ocnt);
+            if (stg > S.last) stage_entry(stg - 1, xpf, zb, true);
+            else if (ocnt > 0)                             // lambda <- lambda + sum over the stages of zbar
+                st4(S.lam_out + orow * n_in + r0, *ownp(a3b::LAM) + (*ownp(a3b::LSUM) + zb), ocnt);
+        }
+        A3T(24);
+        s3_bar();
+        A3T(25);
+    }
+#ifdef A3B_STAMPS
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 5))
+        printf("k_adj3b wave %d, cycles per step (work | barrier wait) per interval: I0 %llu|%llu I1 %llu|%llu I2 %llu|%llu I3 %llu|%llu I4 %llu|%llu I5 %llu|%llu E1 %llu|%llu "
+               "I0' %llu|%llu I1' %llu|%llu I2' %llu|%llu I3' %llu|%llu I4' %llu|%llu I5' %llu|%llu\n", wave,
+               a3acc[0], a3acc[1], a3acc[2], a3acc[3], a3acc[4], a3acc[5], a3acc[6], a3acc[7], a3acc[8], a3acc[9], a3acc[10], a3acc[11], a3acc[12], a3acc[13],
+               a3acc[14], a3acc[15], a3acc[16], a3acc[17], a3acc[18], a3acc[19], a3acc[20], a3acc[21], a3acc[22], a3acc[23], a3acc[24], a3acc[25]);
+#endif
+}
+
+}  // namespace
+
+bool adj3b_supported(const NetDesc& nd) {
+    static const bool off = [] { const char* e = getenv("CNF_ADJ3B"); return e && e[0] == '0'; }();
+    if (off || nd.n_layers != 3 || nd.n_cond > 0 || nd.jvp) return false;
+    if (nd.dims[0] > 32 || nd.dims[1] != 128 || nd.dims[2] != 128 || nd.dims[3] > 32 || nd.dims[0] != nd.dims[3]) return false;
+    if (nd.n_in != nd.dims[0]) return false;
+    for (int l = 0; l < 3; ++l) if (nd.acts[l] != 1) return false;
+    return true;
+}
+
+hipError_t launch_adj3b(const NetDesc& nd, const GradLayout& g, const void* d_img3b, const AdjStepArgs& S, hipStream_t s) {
+    if (!adj3b_supported(nd) || !d_img3b || S.first != 5 || S.last != 0 || !S.lam_update || !S.lam_out) return hipErrorInvalidValue;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_adj3b, hipFuncAttributeMaxDynamicSharedMemorySize, a3b::TOTAL_BYTES);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_adj3b, dim3((S.B + 31) / 32), dim3(512), a3b::TOTAL_BYTES, s, nd, g, (const char*)d_img3b, S);
+    return hipGetLastError();
+}
