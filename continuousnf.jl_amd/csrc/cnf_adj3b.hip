@@ -16,7 +16,7 @@
 // K = 128 operands of the 32-row products (rows of W3 on waves 0-3, rows of W1^T on waves 4-7) are split LDS images; the
 // activations travel between layers as XOR-swizzled split images (conflict-free ds_read_b128 operands).  What is new against
 // k_adj3: the elementwise state of the WIDE layers (s', s'', tbar: the producing lane is the consuming lane in every sweep)
-// lives in REGISTERS (48 VGPRs) instead of 119 KB of LDS -- which is what makes room for the split images -- and the per-row
+// lives in REGISTERS (32 VGPRs: h and tbar, s' and s'' formed again from h) instead of 119 KB of LDS -- which is what makes room for the split images -- and the per-row
 // state of the 32-row arrays (lambda, the zbar shift register, eps, ahat, s'_3, s''_3) sits in swizzled fp32 LDS rows owned by
 // the lanes that produce zdot / zbar (waves w and w + 4 share the addresses: 13 barrier intervals per stage).
 #include "cnf_adj3b.h"
@@ -68,8 +68,6 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
     const int nv = n_in - r0;                             // valid rows among them (<= 0 .. >= 4)
     const int b0 = blockIdx.x * 32;
     const bool olive = b0 + smp < S.B;                    // the owner lane's sample exists
-    const int ga = b0 + s, gb = b0 + 16 + s;              // the two samples of this lane in the wide products
-    const bool la = ga < S.B, lb = gb < S.B;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // ---- weights: resident split fragments (as k_step3b), the two K = 128 LDS images by LDS-DMA, biases ----
@@ -127,6 +125,37 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
         return ((a_.x + a_.y) + (a_.z + a_.w)) + ((b_.x + b_.y) + (b_.z + b_.w));
     };
     auto ownp = [&](int arr) -> f32x4* { return reinterpret_cast<f32x4*>(lds + arr + own); };
+    // The factor rows of the WIDE layers leave for global memory one interval after they were formed, read back from the split
+    // images (the three pieces sum to the fp32 value exactly) by the four waves that IDLE in the next 32-row interval: a wide
+    // interval then issues no global store at all.  (On this ISA stores and loads share one in-order counter: a register the
+    // allocator spilled is reloaded behind every store in front of it, and with the stores in the wide epilogues each such
+    // reload -- the kernel sits at 256 registers -- waited for a write acknowledgement: ~1 k cycles per interval.)
+    // 4 waves = 256 lanes cover 32 samples x 128 features: 4 x (4 features) per lane, rows coalesced
+    const int fl_li = (wave & 3) * 64 + lane;
+    auto flush = [&](int img, float* arr, int row_len, int off) __attribute__((always_inline)) {
+        // (the lane's position behind an opaque zero: otherwise every address below is loop invariant, hoisted and spilled)
+        int li = fl_li;
+        asm volatile("" : "+v"(li));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = li + 256 * j, r = idx >> 5, k = 4 * (idx & 31);
+            const f32x4 v = s3b_load4(ldsb + img + r * a3b::WS + 16 * ((k >> 3) ^ (r & 15)) + 2 * (k & 7), a3b::WP);
+            if (b0 + r < S.B) st4_wide(arr + (size_t)(b0 + r) * row_len + off + k, v);
+        }
+    };
+    // ... and the rows of the 32-row arrays (x, tau; pbar_3, abar_3) from the K = 32 images likewise: one 4-feature group per lane
+    auto flush32 = [&](int img, float* arr, int row_len, int off) __attribute__((always_inline)) {
+        int li = fl_li;
+        asm volatile("" : "+v"(li));
+        const int r = li >> 3, k = 4 * (li & 7);
+        const f32x4 v = s3b_load4(ldsb + img + r * a3b::NS + 16 * ((k >> 3) ^ ((-(r >> 2)) & 3)) + 2 * (k & 7), a3b::NP);
+        const int cnt = b0 + r < S.B ? n_in - k : 0;
+        if (cnt >= 4) st4_wide(arr + (size_t)(b0 + r) * row_len + off + k, v);
+        else if (cnt > 0) st4(arr + (size_t)(b0 + r) * row_len + off + k, v, cnt);
+    };
+    // (measured, round 5: waiting here for the stores' acknowledgements -- the flushing waves idle until the barrier anyway -- costs
+    // nothing at B <= 2048 and 18 % at B = 8192, where the 226 MB of factor rows per step keep the write path busy: no wait)
+#define A3B_FLUSHED() do {} while (0)
 
     // ---- per launch: eps into the owner rows (waves 0-3 use it); lambda, the running sum, the shift register and the state of
     // the first stage are the business of waves 4-7, which produce zbar: they do the bookkeeping of a finished stage themselves,
@@ -145,7 +174,6 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
         }
         *ownp(a3b::AHAT) = ld4_mask((a.cb * *ownp(a3b::LAM) + k0) * a.hstep, ocnt);      // (completed to ahat behind the forward sweep)
         s3b_store4(x0w, a3b::NP, xz);
-        if (ocnt > 0) st4(a.HS + (size_t)(b0 + smp) * gl.sum_in + r0, xz, ocnt);
     };
     {
         const AdjArgs& a0 = S.st[S.first];
@@ -163,7 +191,9 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
     s3_bar();
 
     // elementwise state of the wide layers, tile `wave`, halves A / B: lane (q, s) = rows 16 wave + 4q .. of samples s, 16 + s
-    f32x4 D11[2], D21[2], TB1[2], D12[2], D22[2], TB2[2];
+    // (h of the two wide layers and tbar -- from the tangent sweep on tbar .* q -- : s' = 1 - h^2 and s'' = -2 h s' are formed again where
+    // they are used, which is cheaper than the 16 registers they would occupy)
+    f32x4 H1r[2], TB1[2], H2r[2], TB2[2];
 #ifdef A3B_STAMPS
     unsigned long long a3acc[32] = {0};
     unsigned long long a3last = __builtin_amdgcn_s_memtime();
@@ -173,13 +203,10 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
 
     for (int stg = S.first; stg >= S.last; --stg) {
         const AdjArgs& a = S.st[stg];
-        // (32-bit element offsets into the factor arrays: the 64-bit addresses are formed at the stores, not carried)
-        const int iA = ga * gl.sum_in + wrow, iB = gb * gl.sum_in + wrow, oA = ga * gl.sum_out + wrow, oB = gb * gl.sum_out + wrow;
-        float* const hsA = a.HS + iA; float* const hsB = a.HS + iB;
-        float* const tsA = a.TS + iA; float* const tsB = a.TS + iB;
-        float* const abA = a.AB + oA; float* const abB = a.AB + oB;
-        float* const pbA = a.PB + oA; float* const pbB = a.PB + oB;
-        const size_t orow = (size_t)(b0 + smp);
+        // (an opaque zero per stage keeps the compiler from hoisting the 64-bit addresses of all array families out of the loop)
+        int zopq = 0;
+        asm volatile("" : "+v"(zopq));
+        const int orow = b0 + smp + zopq;
         const int ocnt = olive ? nv : 0;
         // ---- sweep 1: forward.  I0: layer 1, tile `wave`, both halves (K = 32) ----
         {
@@ -191,12 +218,9 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             f32x4 acc[2] = {zero4, zero4};
             s3b_mm<2>(acc, wF1, b);
             const f32x4 ha = s3_tanh4(acc[0] + bv), hb = s3_tanh4(acc[1] + bv);
-            D11[0] = s3_dtanh4(ha); D11[1] = s3_dtanh4(hb);
-            D21[0] = a3b_d2tanh4(ha, D11[0]); D21[1] = a3b_d2tanh4(hb, D11[1]);
+            H1r[0] = ha; H1r[1] = hb;
             s3b_store4(ldsb + a3b::H1G + wb_wr, a3b::WP, ha);
             s3b_store4(ldsb + a3b::H1G + wb_wr + HBW, a3b::WP, hb);
-            if (la) st4_wide(hsA + gl.in_off[1], ha);
-            if (lb) st4_wide(hsB + gl.in_off[1], hb);
         }
         A3T(0);
         s3_bar();
@@ -215,12 +239,9 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
                 S3_SB();
             }
             const f32x4 ha = s3_tanh4(acc[0] + bv), hb = s3_tanh4(acc[1] + bv);
-            D12[0] = s3_dtanh4(ha); D12[1] = s3_dtanh4(hb);
-            D22[0] = a3b_d2tanh4(ha, D12[0]); D22[1] = a3b_d2tanh4(hb, D12[1]);
+            H2r[0] = ha; H2r[1] = hb;
             s3b_store4(ldsb + a3b::H2G + wb_wr, a3b::WP, ha);
             s3b_store4(ldsb + a3b::H2G + wb_wr + HBW, a3b::WP, hb);
-            if (la) st4_wide(hsA + gl.in_off[2], ha);
-            if (lb) st4_wide(hsB + gl.in_off[2], hb);
         }
         A3T(2);
         s3_bar();
@@ -245,8 +266,12 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             *ownp(a3b::D23) = a3b_d2tanh4(zdv, d13);
             const f32x4 pb = *ownp(a3b::EPSA) * d13;       // (eps is zero in padded rows and beyond the batch)
             s3b_store4(g3w, a3b::NP, pb);
-            if (ocnt > 0) st4(a.PB + orow * gl.sum_out + gl.out_off[2] + r0, pb, ocnt);
             redw[0] = s3_dot4(zdv, zdv);
+        } else {                                           // (waves 4-7: h1, h2 -> HS)
+            flush(a3b::H1G, a.HS, gl.sum_in, gl.in_off[1]);
+            flush(a3b::H2G, a.HS, gl.sum_in, gl.in_off[2]);
+            flush32(a3b::X0S, a.HS, gl.sum_in, 0);         // (the stage state: h_0)
+            A3B_FLUSHED();
         }
         A3T(4);
         s3_bar();
@@ -260,11 +285,9 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             f32x4 acc[2] = {zero4, zero4};
             s3b_mm<2>(acc, wB3, b);
             TB2[0] = acc[0]; TB2[1] = acc[1];
-            const f32x4 pa = acc[0] * D12[0], pb = acc[1] * D12[1];
+            const f32x4 pa = acc[0] * s3_dtanh4(H2r[0]), pb = acc[1] * s3_dtanh4(H2r[1]);
             s3b_store4(ldsb + a3b::H2G + wb_wr, a3b::WP, pa);
             s3b_store4(ldsb + a3b::H2G + wb_wr + HBW, a3b::WP, pb);
-            if (la) st4_wide(pbA + gl.out_off[1], pa);
-            if (lb) st4_wide(pbB + gl.out_off[1], pb);
             if (zown) {                                    // ahat = kbar_z + c_E zdot / |zdot|   (|zdot|^2: complete since the barrier)
                 const float nz = red8(0);
                 const float inv = (nd.norm_z && nz > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz) : 0.f;
@@ -287,11 +310,9 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
                 S3_SB();
             }
             TB1[0] = acc[0]; TB1[1] = acc[1];
-            const f32x4 pa = acc[0] * D11[0], pb = acc[1] * D11[1];
+            const f32x4 pa = acc[0] * s3_dtanh4(H1r[0]), pb = acc[1] * s3_dtanh4(H1r[1]);
             s3b_store4(ldsb + a3b::H1G + wb_wr, a3b::WP, pa);
             s3b_store4(ldsb + a3b::H1G + wb_wr + HBW, a3b::WP, pb);
-            if (la) st4_wide(pbA + gl.out_off[0], pa);
-            if (lb) st4_wide(pbB + gl.out_off[0], pb);
         }
         A3T(8);
         s3_bar();
@@ -311,7 +332,12 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             const f32x4 ej = ld4_mask(j0 + j1, nv);        // (rows of z only)
             *ownp(a3b::EJ) = ej;
             redw[32 * 8] = s3_dot4(ej, ej);
-            if (stg > S.last) xpf = ld4(S.st[stg - 1].ustage + orow * D + r0, ocnt);      // the next stage's state: in flight during sweeps 3 and 4
+            if (stg > S.last) xpf = ld4(S.st[stg - 1].ustage + (size_t)orow * D + r0, ocnt);      // the next stage's state: in flight during sweeps 3 and 4
+        } else {                                           // (waves 0-3: pbar_2, pbar_1 -> PB)
+            flush(a3b::H2G, a.PB, gl.sum_out, gl.out_off[1]);
+            flush(a3b::H1G, a.PB, gl.sum_out, gl.out_off[0]);
+            flush32(a3b::G3S, a.PB, gl.sum_out, gl.out_off[2]);
+            A3B_FLUSHED();
         }
         A3T(10);
         s3_bar();
@@ -322,7 +348,6 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             const float inv = (nd.norm_j && nj > 0.f) ? a.c_n * __builtin_amdgcn_rsqf(nj) : 0.f;
             const f32x4 tau = ld4_mask(inv * *ownp(a3b::EJ) - a.c_l * *ownp(a3b::EPSA), nv);
             s3b_store4(x0w, a3b::NP, tau);
-            if (ocnt > 0) st4(a.TS + orow * gl.sum_in + r0, tau, ocnt);
         }
         A3T(12);
         s3_bar();
@@ -335,12 +360,12 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             S3_SB();
             f32x4 acc[2] = {zero4, zero4};
             s3b_mm<2>(acc, wF1, b);
-            const f32x4 ta = D11[0] * acc[0], tb = D11[1] * acc[1];
-            D21[0] = D21[0] * acc[0]; D21[1] = D21[1] * acc[1];                      // q_1 over s''_1
+            const f32x4 da = s3_dtanh4(H1r[0]), db = s3_dtanh4(H1r[1]);
+            const f32x4 ta = da * acc[0], tb = db * acc[1];
+            TB1[0] = TB1[0] * (a3b_d2tanh4(H1r[0], da) * acc[0]);                    // tbar_1 q_1, q_1 = s''_1 (W1 t_0): all sweep 4 needs of them
+            TB1[1] = TB1[1] * (a3b_d2tanh4(H1r[1], db) * acc[1]);
             s3b_store4(ldsb + a3b::H1G + wb_wr, a3b::WP, ta);
             s3b_store4(ldsb + a3b::H1G + wb_wr + HBW, a3b::WP, tb);
-            if (la) st4_wide(tsA + gl.in_off[1], ta);
-            if (lb) st4_wide(tsB + gl.in_off[1], tb);
         }
         A3T(14);
         s3_bar();
@@ -357,12 +382,12 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
                 s3b_mm<2>(acc, wF2[kb], b);
                 S3_SB();
             }
-            const f32x4 ta = D12[0] * acc[0], tb = D12[1] * acc[1];
-            D22[0] = D22[0] * acc[0]; D22[1] = D22[1] * acc[1];
+            const f32x4 da = s3_dtanh4(H2r[0]), db = s3_dtanh4(H2r[1]);
+            const f32x4 ta = da * acc[0], tb = db * acc[1];
+            TB2[0] = TB2[0] * (a3b_d2tanh4(H2r[0], da) * acc[0]);
+            TB2[1] = TB2[1] * (a3b_d2tanh4(H2r[1], db) * acc[1]);
             s3b_store4(ldsb + a3b::H2G + wb_wr, a3b::WP, ta);
             s3b_store4(ldsb + a3b::H2G + wb_wr + HBW, a3b::WP, tb);
-            if (la) st4_wide(tsA + gl.in_off[2], ta);
-            if (lb) st4_wide(tsB + gl.in_off[2], tb);
         }
         A3T(16);
         s3_bar();
@@ -382,7 +407,11 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             const f32x4 q3 = *ownp(a3b::D23) * (z0 + z1);
             const f32x4 ab = *ownp(a3b::AHAT) * *ownp(a3b::D13) + *ownp(a3b::EPSA) * q3;
             s3b_store4(g3w, a3b::NP, ab);
-            if (ocnt > 0) st4(a.AB + orow * gl.sum_out + gl.out_off[2] + r0, ab, ocnt);
+        } else {                                           // (waves 4-7: t_1, t_2 -> TS)
+            flush(a3b::H1G, a.TS, gl.sum_in, gl.in_off[1]);
+            flush(a3b::H2G, a.TS, gl.sum_in, gl.in_off[2]);
+            flush32(a3b::X0S, a.TS, gl.sum_in, 0);         // (tau: t_0)
+            A3B_FLUSHED();
         }
         A3T(18);
         s3_bar();
@@ -395,11 +424,9 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             S3_SB();
             f32x4 acc[2] = {zero4, zero4};
             s3b_mm<2>(acc, wB3, b);
-            const f32x4 aa = acc[0] * D12[0] + TB2[0] * D22[0], ab = acc[1] * D12[1] + TB2[1] * D22[1];
+            const f32x4 aa = acc[0] * s3_dtanh4(H2r[0]) + TB2[0], ab = acc[1] * s3_dtanh4(H2r[1]) + TB2[1];
             s3b_store4(ldsb + a3b::H2G + wb_wr, a3b::WP, aa);
             s3b_store4(ldsb + a3b::H2G + wb_wr + HBW, a3b::WP, ab);
-            if (la) st4_wide(abA + gl.out_off[1], aa);
-            if (lb) st4_wide(abB + gl.out_off[1], ab);
         }
         A3T(20);
         s3_bar();
@@ -416,11 +443,9 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
                 s3b_mm<2>(acc, wB2[kb], b);
                 S3_SB();
             }
-            const f32x4 aa = acc[0] * D11[0] + TB1[0] * D21[0], ab = acc[1] * D11[1] + TB1[1] * D21[1];
+            const f32x4 aa = acc[0] * s3_dtanh4(H1r[0]) + TB1[0], ab = acc[1] * s3_dtanh4(H1r[1]) + TB1[1];
             s3b_store4(ldsb + a3b::H1G + wb_wr, a3b::WP, aa);
             s3b_store4(ldsb + a3b::H1G + wb_wr + HBW, a3b::WP, ab);
-            if (la) st4_wide(abA + gl.out_off[0], aa);
-            if (lb) st4_wide(abB + gl.out_off[0], ab);
         }
         A3T(22);
         s3_bar();
@@ -440,7 +465,12 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             const f32x4 zb = ld4_mask(j0 + j1, ocnt);
             if (stg > S.last) stage_entry(stg - 1, xpf, zb, true);
             else if (ocnt > 0)                             // lambda <- lambda + sum over the stages of zbar
-                st4(S.lam_out + orow * n_in + r0, *ownp(a3b::LAM) + (*ownp(a3b::LSUM) + zb), ocnt);
+                st4(S.lam_out + (size_t)orow * n_in + r0, *ownp(a3b::LAM) + (*ownp(a3b::LSUM) + zb), ocnt);
+        } else {                                           // (waves 0-3: abar_2, abar_1 -> AB)
+            flush(a3b::H2G, a.AB, gl.sum_out, gl.out_off[1]);
+            flush(a3b::H1G, a.AB, gl.sum_out, gl.out_off[0]);
+            flush32(a3b::G3S, a.AB, gl.sum_out, gl.out_off[2]);
+            A3B_FLUSHED();
         }
         A3T(24);
         s3_bar();
