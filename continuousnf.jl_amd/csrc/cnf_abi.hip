@@ -1759,7 +1759,11 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
 
     // ---- backward: discrete adjoint of the recorded steps ---------------------------------------
     // capacity is in samples of cap_B; with B <= cap_B at least grad_fsteps steps fit
-    const int fsteps = (int)std::min<size_t>(32, (size_t)h->grad_fsteps * h->grad_cap_B / (size_t)B);
+    // (CNF_GRAD_FSTEPS=n: contract after every n steps instead -- measurements: fewer steps per contraction keep the factor rows
+    // in the infinity cache, more amortise its launch)
+    static const int fsteps_env = [] { const char* e = getenv("CNF_GRAD_FSTEPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    int fsteps = (int)std::min<size_t>(32, (size_t)h->grad_fsteps * h->grad_cap_B / (size_t)B);
+    if (fsteps_env > 0 && fsteps_env < fsteps) fsteps = fsteps_env;
     int ksplit = 1, filed = 0;
     HIPCHK(h, hipMemsetAsync(h->g_part, 0, (size_t)GRAD_MAX_KSPLIT * h->n_params * sizeof(float), st));
     HIPCHK(h, launch_final_cotangent(nd, h->lam[2], fsol, h->g_lam, B, st));
