@@ -331,8 +331,14 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
                     const int slot = (nreq + c4) % BC_RING;
+#ifdef BC_ABL_NOSTREAM
+                    // (ablation: the streamed half of the weights replaced by resident registers -- wrong numbers, the time of a
+                    // kernel whose stream costs nothing)
+                    const f32x4 bq = {RV[(4 * c4) % NRV], RV[(4 * c4 + 1) % NRV], RV[(4 * c4 + 2) % NRV], RV[(4 * c4 + 3) % NRV]};
+#else
                     const f32x4 bq = ring[slot];
                     ring[slot] = sload(spos); spos = spos + 1 == SLEN ? 0 : spos + 1;
+#endif
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
 #pragma unroll
