@@ -2172,6 +2172,8 @@ def test_adaptive_solves_on_their_own_step_sequence(which, regime):
     jvp = which.endswith("-jvp")
     train = not which.endswith("-test")
     stiff = regime == "stiff"
+    if stiff and which in ("cfg3-jvp", "cfg5-test"):
+        pytest.skip("the stiff regime runs on the three kernel families' VJP forms (suite time)")
     ci = int(which[3])
     cfg, _, _ = O.baseline_cfg(ci)
     cfg.use_jvp = jvp
