@@ -498,12 +498,9 @@ bool adj3b_supported(const NetDesc& nd) {
 
 hipError_t launch_adj3b(const NetDesc& nd, const GradLayout& g, const void* d_img3b, const AdjStepArgs& S, hipStream_t s) {
     if (!adj3b_supported(nd) || !d_img3b || S.first != 5 || S.last != 0 || !S.lam_update || !S.lam_out) return hipErrorInvalidValue;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_adj3b, hipFuncAttributeMaxDynamicSharedMemorySize, a3b::TOTAL_BYTES);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    // (per launch: the attribute belongs to the current device, and a process may drive several)
+    hipError_t e = hipFuncSetAttribute((const void*)k_adj3b, hipFuncAttributeMaxDynamicSharedMemorySize, a3b::TOTAL_BYTES);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_adj3b, dim3((S.B + 31) / 32), dim3(512), a3b::TOTAL_BYTES, s, nd, g, (const char*)d_img3b, S);
     return hipGetLastError();
 }
