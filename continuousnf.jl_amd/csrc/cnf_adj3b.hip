@@ -153,6 +153,42 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
         if (cnt >= 4) st4_wide(arr + (size_t)(b0 + r) * row_len + off + k, v);
         else if (cnt > 0) st4(arr + (size_t)(b0 + r) * row_len + off + k, v, cnt);
     };
+    // One 32-row product (K = 128) of this wave: rows 16 t .. of W3 / W1^T against the wave's sample half, both from split images.
+    // -DA3B_NARROW_PREFETCH (A/B, round 5): the operands of k-block kb + 1 requested before the MFMAs of k-block kb issue (double
+    // buffer) and two PAIRS of accumulators in turn.  Measured: 2.52 against 2.20 ms per gradient at B = 32, 5.4 against 4.2 at
+    // 8192 -- the extra live registers push three more weight pieces into scratch (320 against 168 bytes per lane), and every
+    // reload waits behind the stores in front of it.  At 256 registers this kernel pays for each one.
+    auto narrow = [&]() __attribute__((always_inline)) -> f32x4 {
+#ifndef A3B_NARROW_PREFETCH
+        f32x4 z0 = zero4, z1 = zero4;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), a3b::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), a3b::WP);
+            S3_SB();
+            z0 = s3b_term<0>(av, bvv, z0); z1 = s3b_term<3>(av, bvv, z1);
+            z0 = s3b_term<1>(av, bvv, z0); z1 = s3b_term<4>(av, bvv, z1);
+            z0 = s3b_term<2>(av, bvv, z0); z1 = s3b_term<5>(av, bvv, z1);
+            S3_SB();
+        }
+        return z0 + z1;
+#else
+        f32x4 z[4] = {zero4, zero4, zero4, zero4};
+        S3bOp av = s3b_load(nrA + wb_rd, a3b::WP), bvv = s3b_load(nrB + wb_rd, a3b::WP);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            S3bOp an = av, bn = bvv;
+            if (kb + 1 < 4) { an = s3b_load(nrA + (wb_rd ^ (64 * (kb + 1))), a3b::WP); bn = s3b_load(nrB + (wb_rd ^ (64 * (kb + 1))), a3b::WP); }
+            S3_SB();
+            f32x4& za = z[2 * (kb & 1)]; f32x4& zb_ = z[2 * (kb & 1) + 1];
+            za = s3b_term<0>(av, bvv, za); zb_ = s3b_term<3>(av, bvv, zb_);
+            za = s3b_term<1>(av, bvv, za); zb_ = s3b_term<4>(av, bvv, zb_);
+            za = s3b_term<2>(av, bvv, za); zb_ = s3b_term<5>(av, bvv, zb_);
+            S3_SB();
+            av = an; bvv = bn;
+        }
+        return (z[0] + z[1]) + (z[2] + z[3]);
+#endif
+    };
     // (measured, round 5: waiting here for the stores' acknowledgements -- the flushing waves idle until the barrier anyway -- costs
     // nothing at B <= 2048 and 18 % at B = 8192, where the 226 MB of factor rows per step keep the write path busy: no wait)
 #define A3B_FLUSHED() do {} while (0)
@@ -250,17 +286,8 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
         f32x4 zdv = zero4;
         if (zown) {
             const f32x4 bv3 = *(const f32x4*)(bias + 256 + r0);
-            f32x4 z0 = zero4, z1 = zero4;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), a3b::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), a3b::WP);
-                S3_SB();
-                z0 = s3b_term<0>(av, bvv, z0); z1 = s3b_term<3>(av, bvv, z1);
-                z0 = s3b_term<1>(av, bvv, z0); z1 = s3b_term<4>(av, bvv, z1);
-                z0 = s3b_term<2>(av, bvv, z0); z1 = s3b_term<5>(av, bvv, z1);
-                S3_SB();
-            }
-            zdv = s3_tanh4(z0 + z1 + bv3);                 // padded rows: zero weights and bias -> 0
+            const f32x4 zsum = narrow();
+            zdv = s3_tanh4(zsum + bv3);                 // padded rows: zero weights and bias -> 0
             const f32x4 d13 = s3_dtanh4(zdv);
             *ownp(a3b::D13) = d13;
             *ownp(a3b::D23) = a3b_d2tanh4(zdv, d13);
@@ -319,17 +346,8 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
         A3T(9);
         // I5 (waves 4-7): eJ = W1^T pbar_1 -> the owner rows; |eJ|^2 partials
         if (!zown) {
-            f32x4 j0 = zero4, j1 = zero4;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), a3b::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), a3b::WP);
-                S3_SB();
-                j0 = s3b_term<0>(av, bvv, j0); j1 = s3b_term<3>(av, bvv, j1);
-                j0 = s3b_term<1>(av, bvv, j0); j1 = s3b_term<4>(av, bvv, j1);
-                j0 = s3b_term<2>(av, bvv, j0); j1 = s3b_term<5>(av, bvv, j1);
-                S3_SB();
-            }
-            const f32x4 ej = ld4_mask(j0 + j1, nv);        // (rows of z only)
+            const f32x4 jsum = narrow();
+            const f32x4 ej = ld4_mask(jsum, nv);        // (rows of z only)
             *ownp(a3b::EJ) = ej;
             redw[32 * 8] = s3_dot4(ej, ej);
             if (stg > S.last) xpf = ld4(S.st[stg - 1].ustage + (size_t)orow * D + r0, ocnt);      // the next stage's state: in flight during sweeps 3 and 4
@@ -394,17 +412,8 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
         A3T(17);
         // I2' (waves 0-3): abar_3 = ahat s'_3 + eps (s''_3 W3 t_2) -> G3S, AB
         if (zown) {
-            f32x4 z0 = zero4, z1 = zero4;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), a3b::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), a3b::WP);
-                S3_SB();
-                z0 = s3b_term<0>(av, bvv, z0); z1 = s3b_term<3>(av, bvv, z1);
-                z0 = s3b_term<1>(av, bvv, z0); z1 = s3b_term<4>(av, bvv, z1);
-                z0 = s3b_term<2>(av, bvv, z0); z1 = s3b_term<5>(av, bvv, z1);
-                S3_SB();
-            }
-            const f32x4 q3 = *ownp(a3b::D23) * (z0 + z1);
+            const f32x4 zsum = narrow();
+            const f32x4 q3 = *ownp(a3b::D23) * zsum;
             const f32x4 ab = *ownp(a3b::AHAT) * *ownp(a3b::D13) + *ownp(a3b::EPSA) * q3;
             s3b_store4(g3w, a3b::NP, ab);
         } else {                                           // (waves 4-7: t_1, t_2 -> TS)
@@ -452,17 +461,8 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
         A3T(23);
         // I5' (waves 4-7): zbar = W1^T abar_1 -> the owner rows (zero beyond the batch and in padded rows)
         if (!zown) {
-            f32x4 j0 = zero4, j1 = zero4;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const S3bOp av = s3b_load(nrA + (wb_rd ^ (64 * kb)), a3b::WP), bvv = s3b_load(nrB + (wb_rd ^ (64 * kb)), a3b::WP);
-                S3_SB();
-                j0 = s3b_term<0>(av, bvv, j0); j1 = s3b_term<3>(av, bvv, j1);
-                j0 = s3b_term<1>(av, bvv, j0); j1 = s3b_term<4>(av, bvv, j1);
-                j0 = s3b_term<2>(av, bvv, j0); j1 = s3b_term<5>(av, bvv, j1);
-                S3_SB();
-            }
-            const f32x4 zb = ld4_mask(j0 + j1, ocnt);
+            const f32x4 jsum = narrow();
+            const f32x4 zb = ld4_mask(jsum, ocnt);
             if (stg > S.last) stage_entry(stg - 1, xpf, zb, true);
             else if (ocnt > 0)                             // lambda <- lambda + sum over the stages of zbar
                 st4(S.lam_out + (size_t)orow * n_in + r0, *ownp(a3b::LAM) + (*ownp(a3b::LSUM) + zb), ocnt);
