@@ -1777,6 +1777,31 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
         {TS_A51, TS_A52, TS_A53, TS_A54, 0},
         {TS_A61, TS_A62, TS_A63, TS_A64, TS_A65}};
     static const float Bw[6] = {TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76};
+    if (adj_mfma && adj3b_supported(nd) && h->mfma.d_img3b) {
+        // The headline shape: the steps whose factor rows fit the arena in ONE launch on split-bf16 products (cnf_adj3b.hip;
+        // the image is the forward kernels'), then one contraction over them -- 2 launches per run of steps instead of one
+        // per step and one per run.
+        if ((s = traj_reserve(h, rec.n)) != CNF_OK) return s;
+        const int run = std::min(fsteps, ADJ3B_MAX_STEPS);
+        for (int hi = rec.n - 1; hi >= 0; hi -= run) {
+            const int lo = std::max(0, hi - run + 1), cnt = hi - lo + 1;
+            Adj3bSteps M{};
+            M.traj = h->traj; M.slot_stride = traj_slot_floats(h); M.n = n;
+            M.step_hi = hi; M.step_lo = lo;
+            for (int j = 0; j < cnt; ++j) M.hs[j] = rec.hs[hi - j];
+            M.eps = eps; M.lam = h->g_lam; M.lam_out = h->g_lam;
+            M.HS = h->g_HS; M.TS = h->g_TS; M.AB = h->g_AB; M.PB = h->g_PB;
+            M.lam_l = lam_l; M.lam_E = lam_E; M.lam_n = lam_n;
+            for (int i = 0; i < 6; ++i) M.bw[i] = Bw[i];
+            for (int m = 0; m < 6; ++m) for (int d = 0; d < 5; ++d) M.kc[m][d] = m - 1 - d >= 0 ? A[m][m - 1 - d] : 0.f;
+            M.B = B;
+            HIPCHK(h, launch_adj3b(nd, gl, h->mfma.d_img3b, M, st));
+            int ks, ch;
+            grad_ksplit(nd, gl, 6 * cnt * B, &ks, &ch);
+            if (ks > ksplit) ksplit = ks;
+            HIPCHK(h, launch_wgrad(nd, gl, h->g_AB, h->g_PB, h->g_HS, h->g_TS, h->g_part, (int)h->n_params, 6 * cnt * B, ks, ch, st));
+        }
+    } else
     for (int step = rec.n - 1; step >= 0; --step) {
         float* un;
         if ((s = traj_slot(h, step, &un)) != CNF_OK) return s;
@@ -1807,9 +1832,7 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
         if (adj_mfma) {        // the six stage pullbacks and the lambda update of this step in ONE launch
             S.first = 5; S.last = 0; S.B = B; S.lam_update = 1; S.lam_out = h->g_lam;
             for (int m = 0; m < 6; ++m) for (int d = 0; d < 5; ++d) S.kc[m][d] = m - 1 - d >= 0 ? A[m][m - 1 - d] : 0.f;
-            // (the headline shape: the same step on split-bf16 products, cnf_adj3b.hip -- the image is the forward kernels')
-            if (adj3b_supported(nd) && h->mfma.d_img3b) HIPCHK(h, launch_adj3b(nd, gl, h->mfma.d_img3b, S, st));
-            else HIPCHK(h, launch_adj_mfma_step(nd, gl, am, h->d_adj_img, S, st));
+            HIPCHK(h, launch_adj_mfma_step(nd, gl, am, h->d_adj_img, S, st));
         } else {
             StageK ws{};
             ws.nk = 6;

@@ -55,7 +55,7 @@ __device__ __forceinline__ f32x4 a3b_d2tanh4(const f32x4& h, const f32x4& d1) { 
 }
 
 __global__ void __launch_bounds__(512, 2)
-k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S) {
+k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, Adj3bSteps M) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* ldsb = reinterpret_cast<char*>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,7 +67,7 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
     const int r0 = 16 * t + 4 * q;                        // first of its 4 rows there
     const int nv = n_in - r0;                             // valid rows among them (<= 0 .. >= 4)
     const int b0 = blockIdx.x * 32;
-    const bool olive = b0 + smp < S.B;                    // the owner lane's sample exists
+    const bool olive = b0 + smp < M.B;                    // the owner lane's sample exists
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // ---- weights: resident split fragments (as k_step3b), the two K = 128 LDS images by LDS-DMA, biases ----
@@ -140,7 +140,7 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
         for (int j = 0; j < 4; ++j) {
             const int idx = li + 256 * j, r = idx >> 5, k = 4 * (idx & 31);
             const f32x4 v = s3b_load4(ldsb + img + r * a3b::WS + 16 * ((k >> 3) ^ (r & 15)) + 2 * (k & 7), a3b::WP);
-            if (b0 + r < S.B) st4_wide(arr + (size_t)(b0 + r) * row_len + off + k, v);
+            if (b0 + r < M.B) st4_wide(arr + (size_t)(b0 + r) * row_len + off + k, v);
         }
     };
     // ... and the rows of the 32-row arrays (x, tau; pbar_3, abar_3) from the K = 32 images likewise: one 4-feature group per lane
@@ -149,7 +149,7 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
         asm volatile("" : "+v"(li));
         const int r = li >> 3, k = 4 * (li & 7);
         const f32x4 v = s3b_load4(ldsb + img + r * a3b::NS + 16 * ((k >> 3) ^ ((-(r >> 2)) & 3)) + 2 * (k & 7), a3b::NP);
-        const int cnt = b0 + r < S.B ? n_in - k : 0;
+        const int cnt = b0 + r < M.B ? n_in - k : 0;
         if (cnt >= 4) st4_wide(arr + (size_t)(b0 + r) * row_len + off + k, v);
         else if (cnt > 0) st4(arr + (size_t)(b0 + r) * row_len + off + k, v, cnt);
     };
@@ -196,31 +196,46 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
     // ---- per launch: eps into the owner rows (waves 0-3 use it); lambda, the running sum, the shift register and the state of
     // the first stage are the business of waves 4-7, which produce zbar: they do the bookkeeping of a finished stage themselves,
     // in the interval that produced its zbar (no interval of its own) ----
-    auto stage_entry = [&](int stg, const f32x4& xz, const f32x4& w, bool have_w) __attribute__((always_inline)) {
-        // zbar `w` of stage stg + 1 -> running sum and shift register; kbar_z of stage `stg` -> AHAT; its state -> X0S, HS
-        const AdjArgs& a = S.st[stg];
+    // One stage of one step: where its state and its factor rows are, its step size and the cotangents of its scalar rows
+    struct Stage { size_t qi, qo; float cb, hstep; };
+    auto stage_of = [&](int step, int stg) __attribute__((always_inline)) -> Stage {
+        Stage a;
+        const float hs = M.hs[M.step_hi - step];
+        const size_t q = (size_t)(M.step_hi - step) * 6 + stg;              // this stage's slot in the factor arrays
+        a.qi = q * M.B * gl.sum_in; a.qo = q * M.B * gl.sum_out;           // (floats in front of its rows in HS/TS and in AB/PB)
+        a.cb = M.bw[stg]; a.hstep = hs;
+        return a;
+    };
+    // Entering stage `stg` (waves 4-7, behind the zbar `w` of the stage evaluated before it).  Within a step: w joins the running
+    // sum and the shift register of kbar_z.  A new step (stg == 5 behind stage 0 of the step after it): lambda <- lambda + the sum
+    // over that step's stages of zbar; the shift register is all zero by then (kc[m][d] = 0 past stage 0).
+    auto stage_entry = [&](const Stage& a, int stg, const f32x4& xz, const f32x4& w, bool have_w) __attribute__((always_inline)) {
         const int ocnt = olive ? nv : 0;
-        f32x4 k0 = *ownp(a3b::KS);
-        if (have_w) {
+        f32x4 k0 = zero4, lam = *ownp(a3b::LAM);
+        if (have_w && stg < 5) {
+            k0 = *ownp(a3b::KS) + M.kc[stg + 1][0] * w;
             *ownp(a3b::LSUM) = *ownp(a3b::LSUM) + w;
-            k0 += S.kc[stg + 1][0] * w;
 #pragma unroll
-            for (int d = 1; d < 5; ++d) *ownp(a3b::KS + (d - 1) * a3b::OWN) = *ownp(a3b::KS + d * a3b::OWN) + S.kc[stg + 1][d] * w;
+            for (int d = 1; d < 5; ++d) *ownp(a3b::KS + (d - 1) * a3b::OWN) = *ownp(a3b::KS + d * a3b::OWN) + M.kc[stg + 1][d] * w;
             *ownp(a3b::KS + 4 * a3b::OWN) = zero4;
+        } else if (have_w) {
+            lam = lam + (*ownp(a3b::LSUM) + w);
+            *ownp(a3b::LAM) = lam;
+            *ownp(a3b::LSUM) = zero4;
         }
-        *ownp(a3b::AHAT) = ld4_mask((a.cb * *ownp(a3b::LAM) + k0) * a.hstep, ocnt);      // (completed to ahat behind the forward sweep)
+        *ownp(a3b::AHAT) = ld4_mask((a.cb * lam + k0) * a.hstep, ocnt);      // (completed to ahat behind the forward sweep)
         s3b_store4(x0w, a3b::NP, xz);
     };
     {
-        const AdjArgs& a0 = S.st[S.first];
         const int cnt = olive ? nv : 0;
-        if (zown) *ownp(a3b::EPSA) = ld4(a0.eps + (size_t)(b0 + smp) * n_in + r0, cnt);
+        if (zown) *ownp(a3b::EPSA) = ld4(M.eps + (size_t)(b0 + smp) * n_in + r0, cnt);
         else {
-            *ownp(a3b::LAM) = ld4(a0.lam + (size_t)(b0 + smp) * n_in + r0, cnt);
+            *ownp(a3b::LAM) = ld4(M.lam + (size_t)(b0 + smp) * n_in + r0, cnt);
             *ownp(a3b::LSUM) = zero4;
 #pragma unroll
             for (int d = 0; d < 5; ++d) *ownp(a3b::KS + d * a3b::OWN) = zero4;
-            stage_entry(S.first, ld4(a0.ustage + (size_t)(b0 + smp) * D + r0, cnt), zero4, false);
+            const Stage a0 = stage_of(M.step_hi, 5);
+            stage_entry(a0, 5, ld4(M.traj + (size_t)M.step_hi * M.slot_stride + 5 * M.n + (size_t)(b0 + smp) * D + r0, cnt), zero4, false);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA pieces have landed
@@ -237,8 +252,11 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
     f32x4 xpf = zero4;
     const int wrow = 16 * wave + 4 * q;                    // first of this lane's 4 rows in a wide tile
 
-    for (int stg = S.first; stg >= S.last; --stg) {
-        const AdjArgs& a = S.st[stg];
+    // the stages of the steps of this launch, last to first
+    for (int step = M.step_hi, stg = 5;;) {
+        const Stage a = stage_of(step, stg);
+        const bool last = stg == 0 && step == M.step_lo;
+        const int nstep = stg > 0 ? step : step - 1, nstg = stg > 0 ? stg - 1 : 5;       // the stage evaluated next
         // (an opaque zero per stage keeps the compiler from hoisting the 64-bit addresses of all array families out of the loop)
         int zopq = 0;
         asm volatile("" : "+v"(zopq));
@@ -295,9 +313,9 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             s3b_store4(g3w, a3b::NP, pb);
             redw[0] = s3_dot4(zdv, zdv);
         } else {                                           // (waves 4-7: h1, h2 -> HS)
-            flush(a3b::H1G, a.HS, gl.sum_in, gl.in_off[1]);
-            flush(a3b::H2G, a.HS, gl.sum_in, gl.in_off[2]);
-            flush32(a3b::X0S, a.HS, gl.sum_in, 0);         // (the stage state: h_0)
+            flush(a3b::H1G, M.HS + a.qi, gl.sum_in, gl.in_off[1]);
+            flush(a3b::H2G, M.HS + a.qi, gl.sum_in, gl.in_off[2]);
+            flush32(a3b::X0S, M.HS + a.qi, gl.sum_in, 0);         // (the stage state: h_0)
             A3B_FLUSHED();
         }
         A3T(4);
@@ -317,7 +335,7 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             s3b_store4(ldsb + a3b::H2G + wb_wr + HBW, a3b::WP, pb);
             if (zown) {                                    // ahat = kbar_z + c_E zdot / |zdot|   (|zdot|^2: complete since the barrier)
                 const float nz = red8(0);
-                const float inv = (nd.norm_z && nz > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz) : 0.f;
+                const float inv = (nd.norm_z && nz > 0.f) ? (a.hstep * a.cb * M.lam_E) * __builtin_amdgcn_rsqf(nz) : 0.f;
                 *ownp(a3b::AHAT) = ld4_mask(*ownp(a3b::AHAT) + inv * zdv, ocnt);
             }
         }
@@ -350,11 +368,12 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             const f32x4 ej = ld4_mask(jsum, nv);        // (rows of z only)
             *ownp(a3b::EJ) = ej;
             redw[32 * 8] = s3_dot4(ej, ej);
-            if (stg > S.last) xpf = ld4(S.st[stg - 1].ustage + (size_t)orow * D + r0, ocnt);      // the next stage's state: in flight during sweeps 3 and 4
+            // the next stage's state (of this step, or the last stage of the step before it): in flight during sweeps 3 and 4
+            if (!last) xpf = ld4(M.traj + (size_t)nstep * M.slot_stride + (size_t)nstg * M.n + (size_t)orow * D + r0, ocnt);
         } else {                                           // (waves 0-3: pbar_2, pbar_1 -> PB)
-            flush(a3b::H2G, a.PB, gl.sum_out, gl.out_off[1]);
-            flush(a3b::H1G, a.PB, gl.sum_out, gl.out_off[0]);
-            flush32(a3b::G3S, a.PB, gl.sum_out, gl.out_off[2]);
+            flush(a3b::H2G, M.PB + a.qo, gl.sum_out, gl.out_off[1]);
+            flush(a3b::H1G, M.PB + a.qo, gl.sum_out, gl.out_off[0]);
+            flush32(a3b::G3S, M.PB + a.qo, gl.sum_out, gl.out_off[2]);
             A3B_FLUSHED();
         }
         A3T(10);
@@ -363,8 +382,8 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
         // E1 (owner lanes): tau = -c_l eps + c_n eJ / |eJ| -> X0S as t_0, TS; the next stage's state is requested
         if (zown) {
             const float nj = red8(1);
-            const float inv = (nd.norm_j && nj > 0.f) ? a.c_n * __builtin_amdgcn_rsqf(nj) : 0.f;
-            const f32x4 tau = ld4_mask(inv * *ownp(a3b::EJ) - a.c_l * *ownp(a3b::EPSA), nv);
+            const float inv = (nd.norm_j && nj > 0.f) ? (a.hstep * a.cb * M.lam_n) * __builtin_amdgcn_rsqf(nj) : 0.f;
+            const f32x4 tau = ld4_mask(inv * *ownp(a3b::EJ) - (a.hstep * a.cb * M.lam_l) * *ownp(a3b::EPSA), nv);
             s3b_store4(x0w, a3b::NP, tau);
         }
         A3T(12);
@@ -417,9 +436,9 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
             const f32x4 ab = *ownp(a3b::AHAT) * *ownp(a3b::D13) + *ownp(a3b::EPSA) * q3;
             s3b_store4(g3w, a3b::NP, ab);
         } else {                                           // (waves 4-7: t_1, t_2 -> TS)
-            flush(a3b::H1G, a.TS, gl.sum_in, gl.in_off[1]);
-            flush(a3b::H2G, a.TS, gl.sum_in, gl.in_off[2]);
-            flush32(a3b::X0S, a.TS, gl.sum_in, 0);         // (tau: t_0)
+            flush(a3b::H1G, M.TS + a.qi, gl.sum_in, gl.in_off[1]);
+            flush(a3b::H2G, M.TS + a.qi, gl.sum_in, gl.in_off[2]);
+            flush32(a3b::X0S, M.TS + a.qi, gl.sum_in, 0);         // (tau: t_0)
             A3B_FLUSHED();
         }
         A3T(18);
@@ -463,18 +482,20 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, AdjStepArgs S)
         if (!zown) {
             const f32x4 jsum = narrow();
             const f32x4 zb = ld4_mask(jsum, ocnt);
-            if (stg > S.last) stage_entry(stg - 1, xpf, zb, true);
-            else if (ocnt > 0)                             // lambda <- lambda + sum over the stages of zbar
-                st4(S.lam_out + (size_t)orow * n_in + r0, *ownp(a3b::LAM) + (*ownp(a3b::LSUM) + zb), ocnt);
+            if (!last) stage_entry(stage_of(nstep, nstg), nstg, xpf, zb, true);
+            else if (ocnt > 0)                             // the cotangent in front of the first step of the run
+                st4(M.lam_out + (size_t)orow * n_in + r0, *ownp(a3b::LAM) + (*ownp(a3b::LSUM) + zb), ocnt);
         } else {                                           // (waves 0-3: abar_2, abar_1 -> AB)
-            flush(a3b::H2G, a.AB, gl.sum_out, gl.out_off[1]);
-            flush(a3b::H1G, a.AB, gl.sum_out, gl.out_off[0]);
-            flush32(a3b::G3S, a.AB, gl.sum_out, gl.out_off[2]);
+            flush(a3b::H2G, M.AB + a.qo, gl.sum_out, gl.out_off[1]);
+            flush(a3b::H1G, M.AB + a.qo, gl.sum_out, gl.out_off[0]);
+            flush32(a3b::G3S, M.AB + a.qo, gl.sum_out, gl.out_off[2]);
             A3B_FLUSHED();
         }
         A3T(24);
         s3_bar();
         A3T(25);
+        if (last) break;
+        step = nstep; stg = nstg;
     }
 #ifdef A3B_STAMPS
     if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 5))
@@ -496,11 +517,12 @@ bool adj3b_supported(const NetDesc& nd) {
     return true;
 }
 
-hipError_t launch_adj3b(const NetDesc& nd, const GradLayout& g, const void* d_img3b, const AdjStepArgs& S, hipStream_t s) {
-    if (!adj3b_supported(nd) || !d_img3b || S.first != 5 || S.last != 0 || !S.lam_update || !S.lam_out) return hipErrorInvalidValue;
+hipError_t launch_adj3b(const NetDesc& nd, const GradLayout& g, const void* d_img3b, const Adj3bSteps& M, hipStream_t s) {
+    if (!adj3b_supported(nd) || !d_img3b || !M.lam_out || M.step_lo < 0 || M.step_hi < M.step_lo ||
+        M.step_hi - M.step_lo >= ADJ3B_MAX_STEPS || M.B < 1) return hipErrorInvalidValue;
     // (per launch: the attribute belongs to the current device, and a process may drive several)
     hipError_t e = hipFuncSetAttribute((const void*)k_adj3b, hipFuncAttributeMaxDynamicSharedMemorySize, a3b::TOTAL_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_adj3b, dim3((S.B + 31) / 32), dim3(512), a3b::TOTAL_BYTES, s, nd, g, (const char*)d_img3b, S);
+    hipLaunchKernelGGL(k_adj3b, dim3((M.B + 31) / 32), dim3(512), a3b::TOTAL_BYTES, s, nd, g, (const char*)d_img3b, M);
     return hipGetLastError();
 }
