@@ -31,8 +31,8 @@ __device__ __forceinline__ void cnf_act2(int kind, float a, float& h, float& d1,
 
 #define AM_NS 16
 #ifndef AM_WAVES
-#define AM_WAVES 8            // measured at config 3, B = 8192: (waves, chunk) = (8, 2) 11.1 ms per gradient,
-#endif                        // (8, 4) 11.6, (4, 8) 12.3
+#define AM_WAVES 8            // measured at config 3, B = 8192 (round 3, row-major images): (waves, chunk) = (8, 2) 11.1 ms
+#endif                        // per gradient, (8, 4) 11.6, (4, 8) 12.3
 
 #define AM_EC (AM_WAVES * 4)          // feature lanes of an elementwise pass: AM_THREADS / 16 samples
 #define AM_THREADS (AM_WAVES * 64)
@@ -50,8 +50,13 @@ __device__ __forceinline__ void am_barrier() {
 // in registers and has the NEXT chunk in flight while it multiplies: the next chunk of the same tile,
 // else the first chunk of its next tile, else the first chunk of the NEXT sweep's image -- that one is
 // issued before the barrier and the elementwise pass between the sweeps.
+// The images are in FRAGMENT order (AdjMfmaLayout::ff_off / fr_off: 1 KB per tile and k-block, lane L's four values at
+// 16 L), so a wave's load is one contiguous KB.  Round 5, config 5's pullback (k_adj_mfma, B = 2048, phase stamps of
+// -DAM_STAMPS): with the row-major images (a wave's b128 load = 16 rows x 64 bytes, four lanes 16 apart per row) the loads
+// cost 42 k of a stage's 142 k cycles whatever the chunk depth -- the address unit, not the latency; in fragment order 24 k at
+// AM_CH = 2, 17 k at 4 (loss_and_grad 12.2 -> 11.3 -> 10.8 ms), 8 no better.
 #ifndef AM_CH
-#define AM_CH 2
+#define AM_CH 4
 #endif
 struct AFrag { f32x4 a[AM_CH]; };
 
@@ -60,11 +65,11 @@ struct AFrag { f32x4 a[AM_CH]; };
 // loads are unconditional; k-blocks past the end re-read the last valid fragment and are never used.
 __device__ __forceinline__ void am_load(AFrag& f, const float* __restrict__ p, int last) {
 #pragma unroll
-    for (int i = 0; i < AM_CH; ++i) f.a[i] = *reinterpret_cast<const f32x4*>(p + 16 * min(i, last));
+    for (int i = 0; i < AM_CH; ++i) f.a[i] = *reinterpret_cast<const f32x4*>(p + 256 * min(i, last));
 }
 __device__ __forceinline__ const float* am_addr(const float* __restrict__ img, int k_p, int tile, int u0) {
     const int lane = threadIdx.x & 63;
-    return img + (size_t)(16 * tile + (lane & 15)) * k_p + 4 * (lane >> 4) + 16 * u0;
+    return img + ((size_t)(tile * (k_p >> 4) + u0) * 64 + lane) * 4;      // fragment order: AdjMfmaLayout::ff_off / fr_off
 }
 __device__ __forceinline__ void am_first(AFrag& f, const float* __restrict__ img, int rows_p, int k_p) {
     const int wave = threadIdx.x >> 6;

@@ -72,6 +72,9 @@ struct AdjMfmaLayout {
     int dp[CNF_MAX_LAYERS + 1];     // dims padded to 16; dp[0] = pad16(n_in + n_cond)
     int f_off[CNF_MAX_LAYERS];      // forward image  F_l [dp[l+1]][dp[l]]   (row-major, k contiguous)
     int r_off[CNF_MAX_LAYERS];      // reverse image  R_l [dp[l]][dp[l+1]]
+    // the same two images in FRAGMENT order for the am_* stream (cnf_am.h): 1 KB per (16-row tile, 16-column k-block), lane L's
+    // four values at 16 L -- one fully coalesced b128 per lane instead of 16 rows x 64 bytes per wave load
+    int ff_off[CNF_MAX_LAYERS], fr_off[CNF_MAX_LAYERS];
     int b_off[CNF_MAX_LAYERS];      // padded bias
     int o_off[CNF_MAX_LAYERS];      // offset of layer l's output side in the D1/D2/TB rows
     int sum_o;                      // padded row length of D1/D2/TB

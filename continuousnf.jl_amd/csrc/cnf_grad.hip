@@ -1091,6 +1091,10 @@ AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g) {
         m.o_off[l] = oo; oo += m.dp[l + 1];
         if (m.dp[l + 1] > mx) mx = m.dp[l + 1];
     }
+    for (int l = 0; l < m.L; ++l) {
+        m.ff_off[l] = off; off += m.dp[l + 1] * m.dp[l];
+        m.fr_off[l] = off; off += m.dp[l] * m.dp[l + 1];
+    }
     m.img_floats = off;
     m.sum_o = oo; m.maxd = mx; m.nin_p = pad16(nd.n_in);
     int p = 0;
@@ -1124,13 +1128,19 @@ __global__ void k_pack_adj_images(NetDesc nd, GradLayout gl, AdjMfmaLayout m, co
     const int inp = m.dp[l], outp = m.dp[l + 1];
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < outp * inp) {
+        // (row r, column k) of a [rows][kp] image in fragment order: tile r / 16, k-block k / 16, lane 16 (k % 16 / 4) + r % 16
+        auto frag = [](int r, int k, int kp) { return (((r >> 4) * (kp >> 4) + (k >> 4)) * 64 + 16 * ((k & 15) >> 2) + (r & 15)) * 4 + (k & 3); };
         {   // forward image [o][k]
             const int o = e / inp, k = e % inp;
-            img[m.f_off[l] + e] = (o < out && k < in) ? P[nd.w_off[l] + o + (size_t)k * out] : 0.f;
+            const float v = (o < out && k < in) ? P[nd.w_off[l] + o + (size_t)k * out] : 0.f;
+            img[m.f_off[l] + e] = v;
+            img[m.ff_off[l] + frag(o, k, inp)] = v;
         }
         {   // reverse image [i][o]
             const int i = e / outp, o = e % outp;
-            img[m.r_off[l] + e] = (o < out && i < in) ? P[nd.w_off[l] + o + (size_t)i * out] : 0.f;
+            const float v = (o < out && i < in) ? P[nd.w_off[l] + o + (size_t)i * out] : 0.f;
+            img[m.r_off[l] + e] = v;
+            img[m.fr_off[l] + frag(i, o, outp)] = v;
         }
     }
     if (e < outp) img[m.b_off[l] + e] = e < out ? P[nd.b_off[l] + e] : 0.f;
@@ -1164,7 +1174,7 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
     const AdjArgs& a = S.st[stg];
     AM_STAMP(0);
     AFrag pf;
-    am_first(pf, img + m.f_off[0], m.dp[1], m.dp[0]);
+    am_first(pf, img + m.ff_off[0], m.dp[1], m.dp[0]);
     // ---- inputs: [z; ys; 0] -> S0, eps -> E; h_0 also goes out for the weight gradient ---------
     for (int r = ec; r < m.dp[0]; r += AM_EC) {
         float v = 0.f;
@@ -1184,8 +1194,8 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
         const int oo = m.o_off[l];
         const bool last = l + 1 == NL;
         const int hs_off = last ? -1 : gl.in_off[l + 1];
-        am_gemm(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PS, pf,
-                img + (last ? m.r_off[NL - 1] : m.f_off[l + 1]), last ? m.dp[NL - 1] : m.dp[l + 2],
+        am_gemm(img + m.ff_off[l], m.dp[l + 1], m.dp[l], lds + cur, PS, pf,
+                img + (last ? m.fr_off[NL - 1] : m.ff_off[l + 1]), last ? m.dp[NL - 1] : m.dp[l + 2],
                 last ? m.dp[NL] : m.dp[l + 1], img + m.b_off[l],
                 [&](int r0, int s, f32x4 acc, f32x4 bias) {
             f32x4 h, d1, d2;
@@ -1222,8 +1232,8 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
         const float* X = l == NL - 1 ? lds + m.TB + oL : lds + cur;
         const int oprev = l > 0 ? m.o_off[l - 1] : 0, outp = l > 0 ? nd.dims[l] : 0;
         const int gprev = l > 0 ? gl.out_off[l - 1] : 0;
-        am_gemm(img + m.r_off[l], m.dp[l], m.dp[l + 1], X, PS, pf,
-                img + (l > 0 ? m.r_off[l - 1] : m.f_off[0]), l > 0 ? m.dp[l - 1] : m.dp[1], l > 0 ? m.dp[l] : m.dp[0],
+        am_gemm(img + m.fr_off[l], m.dp[l], m.dp[l + 1], X, PS, pf,
+                img + (l > 0 ? m.fr_off[l - 1] : m.ff_off[0]), l > 0 ? m.dp[l - 1] : m.dp[1], l > 0 ? m.dp[l] : m.dp[0],
                 nullptr, [&](int r0, int s, f32x4 acc, f32x4) {
             float* S = lds + s * PS;
             if (l > 0) {
@@ -1244,14 +1254,27 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
             float nz = 0.f;
             if (nd.norm_z) nz = am_colnorm2(lds + zd, PS, n_in, red);
             const float inv = (nd.norm_z && nz > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz) : 0.f;
-            for (int r = ec; r < m.nin_p; r += AM_EC) {
-                float v = 0.f;
-                if (ev && r < n_in) {
-                    float kb = a.cb * a.lam[(size_t)eb * n_in + r];
-                    for (int w = 0; w < a.nw; ++w) kb = fmaf(a.wc[w], a.w[w][(size_t)eb * n_in + r], kb);
-                    v = fmaf(inv, lds[es * PS + zd + r], kb * a.hstep);
+            // (all five zbar slots are read -- the unused ones point at a readable array with weight 0 -- and four rows per thread
+            // are requested before the first is used: one round trip to memory per four rows instead of up to six per row)
+            for (int rb = ec; rb < m.nin_p; rb += 4 * AM_EC) {
+                float kb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = rb + i * AM_EC;
+                    kb[i] = 0.f;
+                    if (ev && r < n_in) {
+                        const size_t at = (size_t)eb * n_in + r;
+                        float k = a.cb * a.lam[at];
+#pragma unroll
+                        for (int w = 0; w < 5; ++w) k = fmaf(a.wc[w], a.w[w][at], k);
+                        kb[i] = k;
+                    }
                 }
-                lds[es * PS + m.AH + r] = v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = rb + i * AM_EC;
+                    if (r < m.nin_p) lds[es * PS + m.AH + r] = (ev && r < n_in) ? fmaf(inv, lds[es * PS + zd + r], kb[i] * a.hstep) : 0.f;
+                }
             }
             am_barrier();                                   // zdot's buffer is the next epilogue's target
         }
@@ -1278,8 +1301,8 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
         const int out = nd.dims[l + 1], oo = m.o_off[l];
         const bool last = l + 1 == NL;
         const int ts_off = last ? -1 : gl.in_off[l + 1];
-        am_gemm(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PS, pf,
-                img + (last ? m.r_off[NL - 1] : m.f_off[l + 1]), last ? m.dp[NL - 1] : m.dp[l + 2],
+        am_gemm(img + m.ff_off[l], m.dp[l + 1], m.dp[l], lds + cur, PS, pf,
+                img + (last ? m.fr_off[NL - 1] : m.ff_off[l + 1]), last ? m.dp[NL - 1] : m.dp[l + 2],
                 last ? m.dp[NL] : m.dp[l + 1], nullptr,
                 [&](int r0, int s, f32x4 acc, f32x4) {
             float* S = lds + s * PS;
@@ -1308,8 +1331,8 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
     for (int l = NL - 1; l >= 0; --l) {
         const int oprev = l > 0 ? m.o_off[l - 1] : 0, outp = l > 0 ? nd.dims[l] : 0;
         const int gprev = l > 0 ? gl.out_off[l - 1] : 0;
-        am_gemm(img + m.r_off[l], m.dp[l], m.dp[l + 1], lds + cur, PS, pf,
-                l > 0 ? img + m.r_off[l - 1] : nullptr, l > 0 ? m.dp[l - 1] : 0, l > 0 ? m.dp[l] : 0,
+        am_gemm(img + m.fr_off[l], m.dp[l], m.dp[l + 1], lds + cur, PS, pf,
+                l > 0 ? img + m.fr_off[l - 1] : nullptr, l > 0 ? m.dp[l - 1] : 0, l > 0 ? m.dp[l] : 0,
                 nullptr, [&](int r0, int s, f32x4 acc, f32x4) {
             float* S = lds + s * PS;
             const bool sv = b0 + s < a.B;

@@ -104,7 +104,7 @@ k_trace_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const f
     float* red = lds + tl.off_red;
 
     AFrag pf;
-    am_first(pf, img + m.f_off[0], m.dp[1], m.dp[0]);
+    am_first(pf, img + m.ff_off[0], m.dp[1], m.dp[0]);
     int cur = tl.off_T0, nxt = tl.off_T0 + AM_NS * PSf;
     for (int r = ec; r < m.dp[0]; r += AM_EC) {
         float v = 0.f;
@@ -121,8 +121,8 @@ k_trace_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const f
     for (int l = 0; l < NL; ++l) {
         const int out = nd.dims[l + 1], act = nd.acts[l], oo = m.o_off[l];
         const bool last = l + 1 == NL;
-        am_gemm(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PSf, pf,
-                img + (last ? m.f_off[1] : m.f_off[l + 1]), last ? m.dp[2] : m.dp[l + 2], last ? m.dp[1] : m.dp[l + 1],
+        am_gemm(img + m.ff_off[l], m.dp[l + 1], m.dp[l], lds + cur, PSf, pf,
+                img + (last ? m.ff_off[1] : m.ff_off[l + 1]), last ? m.dp[2] : m.dp[l + 2], last ? m.dp[1] : m.dp[l + 1],
                 img + m.b_off[l], [&](int r0, int s, f32x4 acc, f32x4 bias) {
             f32x4 h, d1;
 #pragma unroll
@@ -174,9 +174,9 @@ k_trace_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, TraceLayout tl, const f
         for (int l = 1; l <= NL - 2; ++l) {
             const bool lastmid = l == NL - 2;
             const int oo = m.o_off[l];
-            const float* nimg = lastmid ? img + m.f_off[1] : img + m.f_off[l + 1];
+            const float* nimg = lastmid ? img + m.ff_off[1] : img + m.ff_off[l + 1];
             const int nr = lastmid ? m.dp[2] : m.dp[l + 2], nk = lastmid ? m.dp[1] : m.dp[l + 1];
-            am_gemm_multi<NCT>(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + tc, PT, pf, nimg, nr, nk,
+            am_gemm_multi<NCT>(img + m.ff_off[l], m.dp[l + 1], m.dp[l], lds + tc, PT, pf, nimg, nr, nk,
                                [&](int r0, int s, f32x4 (&acc)[NCT]) {
 #pragma unroll
                 for (int c = 0; c < NCT; ++c) {
@@ -1048,7 +1048,7 @@ k_jvp_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, JvpLayout jl, const float
     float* red = lds + jl.off_red;
 
     AFrag pf;
-    am_first(pf, img + m.f_off[0], m.dp[1], m.dp[0]);
+    am_first(pf, img + m.ff_off[0], m.dp[1], m.dp[0]);
     int cur = 0, nxt = 32 * PX;
     for (int r = ec; r < m.dp[0]; r += AM_EC) {
         float v = 0.f, e = 0.f;
@@ -1066,8 +1066,8 @@ k_jvp_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, JvpLayout jl, const float
     for (int l = 0; l < NL; ++l) {
         const int out = nd.dims[l + 1], act = nd.acts[l];
         const bool last = l + 1 == NL;
-        am_gemm_multi<2>(img + m.f_off[l], m.dp[l + 1], m.dp[l], lds + cur, PX, pf,
-                         last ? nullptr : img + m.f_off[l + 1], last ? 0 : m.dp[l + 2], last ? 0 : m.dp[l + 1],
+        am_gemm_multi<2>(img + m.ff_off[l], m.dp[l + 1], m.dp[l], lds + cur, PX, pf,
+                         last ? nullptr : img + m.ff_off[l + 1], last ? 0 : m.dp[l + 2], last ? 0 : m.dp[l + 1],
                          [&](int r0, int s, f32x4 (&acc)[2]) {
             f32x4 h, t;
 #pragma unroll

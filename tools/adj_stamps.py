@@ -1,6 +1,6 @@
 """In-kernel phase stamps of the MFMA pullback kernel (diagnostic build only):
     hipcc ... -DAM_STAMPS -c cnf_grad.hip ; link as build_abl/libcnf_STAMPS.so ;
-    CNFHIP_LIB=$PWD/build_abl/libcnf_STAMPS.so python tools/adj_stamps.py [B]
+    CNFHIP_LIB=$PWD/build_abl/libcnf_STAMPS.so python tools/adj_stamps.py [B [cfg]]
 Prints the s_memtime deltas between the barriers of workgroup 0 (ids in cnf_grad.hip: AM_STAMP)."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -8,7 +8,7 @@ import numpy as np, torch
 import continuousnf.jl_amd as cnf
 from continuousnf.jl_amd import _lib
 from continuousnf.jl_amd import configs
-wl = configs.BASELINE[3]
+wl = configs.BASELINE[int(sys.argv[2]) if len(sys.argv) > 2 else 3]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 flat = torch.from_numpy(configs.glorot_params(wl.dims, 1, 0.05)).cuda()
 xs_h, eps_h = configs.synthetic_inputs(wl, B, 1)
