@@ -58,6 +58,15 @@ __device__ __forceinline__ void am_barrier() {
 #ifndef AM_CH
 #define AM_CH 4
 #endif
+#ifdef AM_ROWPAD               // A/B: row-major images with a stride of k_p + 4 floats (k_mfma's streamed layout): 11.1 against
+                               // 10.8 ms at config 5.  (The reverse experiment, k_mfma's stream in fragment order: 25 against
+                               // 17 us per evaluation -- its rows are re-used from L1 by the next k-block, here they are not.)
+#define AM_IMG_PAD 4
+#define AM_KSTEP 16
+#else
+#define AM_IMG_PAD 0
+#define AM_KSTEP 256
+#endif
 struct AFrag { f32x4 a[AM_CH]; };
 
 // Straight-line loads only: a branch around a load makes the compiler copy the loaded registers into
@@ -65,11 +74,15 @@ struct AFrag { f32x4 a[AM_CH]; };
 // loads are unconditional; k-blocks past the end re-read the last valid fragment and are never used.
 __device__ __forceinline__ void am_load(AFrag& f, const float* __restrict__ p, int last) {
 #pragma unroll
-    for (int i = 0; i < AM_CH; ++i) f.a[i] = *reinterpret_cast<const f32x4*>(p + 256 * min(i, last));
+    for (int i = 0; i < AM_CH; ++i) f.a[i] = *reinterpret_cast<const f32x4*>(p + AM_KSTEP * min(i, last));
 }
 __device__ __forceinline__ const float* am_addr(const float* __restrict__ img, int k_p, int tile, int u0) {
     const int lane = threadIdx.x & 63;
+#ifdef AM_ROWPAD
+    return img + (size_t)(16 * tile + (lane & 15)) * (k_p + AM_IMG_PAD) + 4 * (lane >> 4) + 16 * u0;
+#else
     return img + ((size_t)(tile * (k_p >> 4) + u0) * 64 + lane) * 4;      // fragment order: AdjMfmaLayout::ff_off / fr_off
+#endif
 }
 __device__ __forceinline__ void am_first(AFrag& f, const float* __restrict__ img, int rows_p, int k_p) {
     const int wave = threadIdx.x >> 6;

@@ -1092,8 +1092,8 @@ AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g) {
         if (m.dp[l + 1] > mx) mx = m.dp[l + 1];
     }
     for (int l = 0; l < m.L; ++l) {
-        m.ff_off[l] = off; off += m.dp[l + 1] * m.dp[l];
-        m.fr_off[l] = off; off += m.dp[l] * m.dp[l + 1];
+        m.ff_off[l] = off; off += m.dp[l + 1] * (m.dp[l] + AM_IMG_PAD);
+        m.fr_off[l] = off; off += m.dp[l] * (m.dp[l + 1] + AM_IMG_PAD);
     }
     m.img_floats = off;
     m.sum_o = oo; m.maxd = mx; m.nin_p = pad16(nd.n_in);
@@ -1129,7 +1129,11 @@ __global__ void k_pack_adj_images(NetDesc nd, GradLayout gl, AdjMfmaLayout m, co
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < outp * inp) {
         // (row r, column k) of a [rows][kp] image in fragment order: tile r / 16, k-block k / 16, lane 16 (k % 16 / 4) + r % 16
+#ifdef AM_ROWPAD
+        auto frag = [](int r, int k, int kp) { return r * (kp + AM_IMG_PAD) + k; };
+#else
         auto frag = [](int r, int k, int kp) { return (((r >> 4) * (kp >> 4) + (k >> 4)) * 64 + 16 * ((k & 15) >> 2) + (r & 15)) * 4 + (k & 3); };
+#endif
         {   // forward image [o][k]
             const int o = e / inp, k = e % inp;
             const float v = (o < out && k < in) ? P[nd.w_off[l] + o + (size_t)k * out] : 0.f;
