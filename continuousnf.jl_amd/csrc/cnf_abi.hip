@@ -115,6 +115,7 @@ struct cnf_ctx {
     float* g_W[6] = {};           // zbar per stage
     float* g_lam = nullptr;
     float *g_HS = nullptr, *g_TS = nullptr, *g_AB = nullptr, *g_PB = nullptr;
+    float* g_sc = nullptr;        // scratch rows of the two-launch MFMA pullback (adj_mfma_scratch_floats), or null
     float* g_part = nullptr;      // GRAD_MAX_KSPLIT x n_params
     NetDesc nd_wave{};            // what the wave kernels see: nd, or a one-layer tanh network with an identity layer appended
     float* wg_traj = nullptr;     // k_solve_wave<GRAD>: z rows of u_n per accepted step, as the lanes hold them; + WV_GCAP step sizes
@@ -1625,7 +1626,9 @@ static cnf_status ensure_grad_capacity(cnf_handle h, int B) {
     if (fsteps < 1) fsteps = 1;
     if (fsteps > 32) fsteps = 32;
     h->grad_fsteps = (int)fsteps;
-    const size_t total = 5 * D * cap + 7 * n_in * cap + fsteps * per_step +
+    const AdjMfmaLayout am = adj_mfma_layout(h->nd, g);
+    const size_t sc = adj_mfma_supported(h->nd, am) ? adj_mfma_scratch_floats(am, cap) : 0;   // scratch rows of the two-launch pullback
+    const size_t total = 5 * D * cap + 7 * n_in * cap + fsteps * per_step + sc +
                          ((size_t)GRAD_MAX_KSPLIT + 1) * h->n_params;
     HIPCHK(h, hipMalloc(&h->grad_arena, total * sizeof(float)));
     float* p = h->grad_arena;
@@ -1636,6 +1639,7 @@ static cnf_status ensure_grad_capacity(cnf_handle h, int B) {
     h->g_TS = p; p += fsteps * 6 * (size_t)g.sum_in * cap;
     h->g_AB = p; p += fsteps * 6 * (size_t)g.sum_out * cap;
     h->g_PB = p; p += fsteps * 6 * (size_t)g.sum_out * cap;
+    h->g_sc = sc ? p : nullptr; p += sc;
     h->g_part = p; p += (size_t)GRAD_MAX_KSPLIT * h->n_params;
     h->g_grad = p;
     h->grad_cap_B = cap;
@@ -1832,7 +1836,7 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
         if (adj_mfma) {        // the six stage pullbacks and the lambda update of this step in ONE launch
             S.first = 5; S.last = 0; S.B = B; S.lam_update = 1; S.lam_out = h->g_lam;
             for (int m = 0; m < 6; ++m) for (int d = 0; d < 5; ++d) S.kc[m][d] = m - 1 - d >= 0 ? A[m][m - 1 - d] : 0.f;
-            HIPCHK(h, launch_adj_mfma_step(nd, gl, am, h->d_adj_img, S, st));
+            HIPCHK(h, launch_adj_mfma_step(nd, gl, am, h->d_adj_img, S, st, h->g_sc));
         } else {
             StageK ws{};
             ws.nk = 6;

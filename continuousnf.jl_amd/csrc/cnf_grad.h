@@ -84,10 +84,14 @@ struct AdjMfmaLayout {
     // per-sample LDS offsets (floats) and stride
     int D1, D2, TB, S0, S1, E, AH, PS;
     int vec4, vec4o;                // HS/TS resp. AB/PB rows are 16-byte aligned: vector stores in the epilogues
+    int SR;                         // floats per sample and stage of the scratch rows of the two-launch form: sigma', q, tbar, zdot
 };
 AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g);
 bool adj_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
 hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* P,
                                   float* img, hipStream_t s);
+// scratch: 6 B m.SR floats (adj_mfma_scratch_floats) or null; with it, batches that leave CUs idle run a step as two launches
+// (sweeps 1-3 of all stages side by side, then the hbar chains in turn: k_adj_mfma<PHASE 1 / 2>); CNF_ADJ_SPLIT=0: never
 hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
-                                const AdjStepArgs& S, hipStream_t s);
+                                const AdjStepArgs& S, hipStream_t s, float* scratch = nullptr);
+size_t adj_mfma_scratch_floats(const AdjMfmaLayout& m, size_t B);

@@ -21,6 +21,8 @@
 //   weight transpose.
 // DESIGN.md section 4.4 has the measurements.
 #include "cnf_grad.h"
+#include <type_traits>
+
 #include "cnf_am.h"
 #include "cnf_split.h"
 #include <cstdlib>
@@ -1106,6 +1108,7 @@ AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g) {
     m.E = p; p += m.nin_p;
     m.AH = m.TB + m.o_off[m.L - 1];       // ahat reuses the tbar_L slot (free after the first reverse GEMM)
     m.PS = ((p + 15) & ~15) + 8;          // stride = 8 mod 16 floats: conflict-free b128 columns
+    m.SR = 3 * oo + m.nin_p;
     m.vec4 = (g.sum_in & 3) == 0;         // rows of HS/TS start 16-byte aligned ...
     for (int l = 0; l < m.L; ++l) if (g.in_off[l] & 3) m.vec4 = 0;   // ... and so does every layer's block
     m.vec4o = (g.sum_out & 3) == 0;
@@ -1150,6 +1153,23 @@ __global__ void k_pack_adj_images(NetDesc nd, GradLayout gl, AdjMfmaLayout m, co
     if (e < outp) img[m.b_off[l] + e] = e < out ? P[nd.b_off[l] + e] : 0.f;
 }
 
+// kbar_z of four rows of one sample: b_i lambda + sum over the later stages of a_{m,i} zbar_m.  All five zbar slots are read (the
+// unused ones point at a readable array with weight 0) and the four rows are requested before the first is used.
+__device__ __forceinline__ void am_kbar4(const AdjArgs& a, bool ev, int eb, int n_in, int rb, float (&kb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = rb + i * AM_EC;
+        kb[i] = 0.f;
+        if (ev && r < n_in) {
+            const size_t at = (size_t)eb * n_in + r;
+            float k = a.cb * a.lam[at];
+#pragma unroll
+            for (int w = 0; w < 5; ++w) k = fmaf(a.wc[w], a.w[w][at], k);
+            kb[i] = k;
+        }
+    }
+}
+
 #ifdef AM_STAMPS
 __device__ unsigned long long am_stamps[64];
 #define AM_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) am_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1159,9 +1179,18 @@ extern "C" int cnf_debug_adj_stamps(unsigned long long* out, int n) {
 #else
 #define AM_STAMP(i)
 #endif
-template <bool ALL_TANH>
+// PHASE 0: the whole pullback of the stages S.first .. S.last of one step, one after the other (a workgroup = 16 samples).
+// Three of its four sweeps do not depend on the adjoint state at all -- the forward sweep, the tbar chain (omega = eps) and the
+// tangent chain (tau is made of eps, eJ and the constant cotangents of the scalar rows): only ahat = kbar_z + c_E zdot/|zdot|
+// and the hbar chain behind it carry lambda and the zbar of the later stages.  So when the batch leaves CUs idle
+// (launch_adj_mfma_step decides), a step runs as TWO launches:
+//   PHASE 1, grid (tiles, stages): sweeps 1-3 of ALL stages side by side; HS, PB, TS filed as before; sigma', q = sigma'' .* p,
+//            tbar and zdot of every sample parked in the scratch rows SC [stage][B][m.SR];
+//   PHASE 2, grid (tiles): per stage the scratch rows back into LDS, abar_L = ahat sigma'_L + eps q_L, the hbar chain (AB, zbar),
+//            then lambda <- lambda + sum zbar -- a quarter of the sequential work.
+template <bool ALL_TANH, int PHASE>
 __global__ void __launch_bounds__(AM_THREADS)
-k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, AdjStepArgs S) {
+k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, AdjStepArgs S, float* __restrict__ SC) {
     extern __shared__ float lds[];
     const int PS = m.PS, NL = m.L;
     float* red = lds + (size_t)AM_NS * PS;
@@ -1174,10 +1203,14 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
     const bool ev = eb < S.B;
     const int oL = m.o_off[NL - 1];
 
-  for (int stg = S.first; stg >= S.last; --stg) {      // the stages of one Runge-Kutta step, last to first
+  const int stg_hi = PHASE == 1 ? S.first - (int)blockIdx.y : S.first, stg_lo = PHASE == 1 ? stg_hi : S.last;
+  for (int stg = stg_hi; stg >= stg_lo; --stg) {       // the stages of one Runge-Kutta step, last to first
     const AdjArgs& a = S.st[stg];
+    float* scrow = SC + ((size_t)stg * S.B + eb) * m.SR;  // PHASE 1 / 2: this thread's sample in the scratch rows (if ev)
     AM_STAMP(0);
     AFrag pf;
+    int cur = m.S0, nxt = m.S1;
+   if (PHASE != 2) {
     am_first(pf, img + m.ff_off[0], m.dp[1], m.dp[0]);
     // ---- inputs: [z; ys; 0] -> S0, eps -> E; h_0 also goes out for the weight gradient ---------
     for (int r = ec; r < m.dp[0]; r += AM_EC) {
@@ -1190,7 +1223,6 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
     am_barrier();
     AM_STAMP(1);
 
-    int cur = m.S0, nxt = m.S1;
     // ---- sweep 1: forward.  The last layer's epilogue also forms pbar_L = eps .* sigma'_L (the first
     //      operand of the tbar chain, tbar_L = omega = eps), parked in the tbar_L slot of TB ------------
     for (int l = 0; l < NL; ++l) {
@@ -1253,6 +1285,9 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
         AM_STAMP(7 + (NL - 1 - l));
         const int t_ = cur; cur = nxt; nxt = t_;
         if (l == NL - 1) {
+            if (PHASE == 1) {                                // zdot -> scratch (ahat is formed in PHASE 2)
+                for (int r = ec; r < m.nin_p; r += AM_EC) if (ev) scrow[3 * m.sum_o + r] = lds[es * PS + zd + r];
+            } else {
             // zdot still sits in S[zd]: ahat = kbar_z + c_E zdot/|zdot| -> AH.  AH shares the tbar_L slot of TB,
             // free now that pbar_L (parked there by sweep 1) has been consumed by this GEMM.
             float nz = 0.f;
@@ -1262,23 +1297,13 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
             // are requested before the first is used: one round trip to memory per four rows instead of up to six per row)
             for (int rb = ec; rb < m.nin_p; rb += 4 * AM_EC) {
                 float kb[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = rb + i * AM_EC;
-                    kb[i] = 0.f;
-                    if (ev && r < n_in) {
-                        const size_t at = (size_t)eb * n_in + r;
-                        float k = a.cb * a.lam[at];
-#pragma unroll
-                        for (int w = 0; w < 5; ++w) k = fmaf(a.wc[w], a.w[w][at], k);
-                        kb[i] = k;
-                    }
-                }
+                am_kbar4(a, ev, eb, n_in, rb, kb);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = rb + i * AM_EC;
                     if (r < m.nin_p) lds[es * PS + m.AH + r] = (ev && r < n_in) ? fmaf(inv, lds[es * PS + zd + r], kb[i] * a.hstep) : 0.f;
                 }
+            }
             }
             am_barrier();                                   // zdot's buffer is the next epilogue's target
         }
@@ -1318,7 +1343,7 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
                 const f32x4 t = d1 * acc;
                 *reinterpret_cast<f32x4*>(S + nxt + r0) = t;
                 if (sv) am_store4(a.TS + (size_t)(b0 + s) * gl.sum_in + ts_off + r0, t, r0, out, m.vec4);
-            } else {
+            } else if (PHASE == 0) {
                 const f32x4 ab = *reinterpret_cast<const f32x4*>(S + m.AH + r0) * d1 +
                                  *reinterpret_cast<const f32x4*>(S + m.E + r0) * q;
                 *reinterpret_cast<f32x4*>(S + nxt + r0) = ab;
@@ -1329,6 +1354,45 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
         AM_STAMP(14 + l);
         const int t_ = cur; cur = nxt; nxt = t_;
     }
+
+    if (PHASE == 1) {                                       // sigma', q, tbar of this stage -> scratch; the stage is PHASE 2's from here
+        for (int r = 4 * ec; r < 3 * m.sum_o; r += 4 * AM_EC)
+            if (ev) *reinterpret_cast<f32x4*>(scrow + r) = *reinterpret_cast<const f32x4*>(lds + es * PS + m.D1 + r);
+        break;
+    }
+   } else {
+    // ---- PHASE 2: the scratch rows back into LDS (sigma', q, tbar: one contiguous block of the sample row; zdot -> S0), eps -> E;
+    //      abar_L = ahat sigma'_L + eps q_L -> S1 and AB, elementwise (ahat never leaves the registers) ----
+    am_first(pf, img + m.fr_off[NL - 1], m.dp[NL - 1], m.dp[NL]);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 4 * ec; r < 3 * m.sum_o; r += 4 * AM_EC)
+        *reinterpret_cast<f32x4*>(lds + es * PS + m.D1 + r) = ev ? *reinterpret_cast<const f32x4*>(scrow + r) : z4;
+    for (int r = ec; r < m.nin_p; r += AM_EC) {
+        lds[es * PS + m.S0 + r] = ev ? scrow[3 * m.sum_o + r] : 0.f;
+        lds[es * PS + m.E + r] = (ev && r < n_in) ? a.eps[(size_t)eb * n_in + r] : 0.f;
+    }
+    am_barrier();
+    float nz = 0.f;
+    if (nd.norm_z) nz = am_colnorm2(lds + m.S0, PS, n_in, red);
+    const float inv = (nd.norm_z && nz > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz) : 0.f;
+    for (int rb = ec; rb < m.nin_p; rb += 4 * AM_EC) {
+        float kb[4];
+        am_kbar4(a, ev, eb, n_in, rb, kb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rb + i * AM_EC;
+            if (r < m.nin_p) {
+                const float* Sr = lds + es * PS;
+                const float ah = (ev && r < n_in) ? fmaf(inv, Sr[m.S0 + r], kb[i] * a.hstep) : 0.f;
+                const float ab = fmaf(ah, Sr[m.D1 + oL + r], Sr[m.E + r] * Sr[m.D2 + oL + r]);
+                lds[es * PS + m.S1 + r] = ab;
+                if (ev && r < n_in) a.AB[(size_t)eb * gl.sum_out + gl.out_off[NL - 1] + r] = ab;
+            }
+        }
+    }
+    am_barrier();
+    cur = m.S1; nxt = m.S0;
+   }
 
     // ---- sweep 4: hbar chain.  Layer l's GEMM turns abar_l into hbar_{l-1}; its epilogue forms
     //      abar_{l-1} = hbar_{l-1} sigma' + tbar_{l-1} q_{l-1}; the last one is zbar -------------------------
@@ -1359,7 +1423,7 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     am_barrier();
   }
-  if (S.lam_update) {        // lambda <- lambda + sum over the stages of zbar   (rows of this workgroup's samples)
+  if (PHASE != 1 && S.lam_update) {        // lambda <- lambda + sum over the stages of zbar   (rows of this workgroup's samples)
     for (int r = ec; r < n_in; r += AM_EC) {
         if (ev) {
             float acc = S.st[0].lam[(size_t)eb * n_in + r];
@@ -1775,7 +1839,7 @@ hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const 
 }
 
 hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
-                                const AdjStepArgs& S, hipStream_t s) {
+                                const AdjStepArgs& S, hipStream_t s, float* scratch) {
     const size_t lds = adj_mfma_lds_bytes(m);
     bool all_tanh = true;
     for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
@@ -1790,12 +1854,39 @@ hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const Ad
         else hipLaunchKernelGGL(k_adj3<false>, grid3, dim3(AM_THREADS), lds3, s, nd, g, m, img, S);
         return hipGetLastError();
     }
-    const void* fn = all_tanh ? (const void*)k_adj_mfma<true> : (const void*)k_adj_mfma<false>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int tiles = (S.B + AM_NS - 1) / AM_NS, nstg = S.first - S.last + 1;
+    // Two launches when that is less sequential work: the stage-parallel phase costs ~0.7 of a stage per round of CUs workgroups
+    // (1 per CU: 156 KB of LDS), the sequential phase ~0.3 of a stage per stage (phase stamps at config 5).
+    static const bool no_split = [] { const char* e = getenv("CNF_ADJ_SPLIT"); return e && e[0] == '0'; }();
+    bool split = false;
+    if (scratch && !no_split && nstg > 1) {
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+            if (cus < 1) cus = 1;
+        }
+        const int rounds = (nstg * tiles + cus - 1) / cus;
+        split = 0.7 * rounds + 0.3 * nstg < 0.95 * nstg;
+    }
+    auto go = [&](auto tanh_c, auto phase_c, dim3 grid) -> hipError_t {
+        constexpr bool T = decltype(tanh_c)::value;
+        constexpr int PH = decltype(phase_c)::value;
+        hipError_t e = hipFuncSetAttribute((const void*)k_adj_mfma<T, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_adj_mfma<T, PH>), grid, dim3(AM_THREADS), lds, s, nd, g, m, img, S, scratch);
+        return hipGetLastError();
+    };
+    using T1 = std::integral_constant<bool, true>;
+    using T0 = std::integral_constant<bool, false>;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
+    if (!split) return all_tanh ? go(T1{}, P0{}, dim3(tiles)) : go(T0{}, P0{}, dim3(tiles));
+    hipError_t e = all_tanh ? go(T1{}, P1{}, dim3(tiles, nstg)) : go(T0{}, P1{}, dim3(tiles, nstg));
     if (e != hipSuccess) return e;
-    if (all_tanh)
-        hipLaunchKernelGGL(k_adj_mfma<true>, dim3((S.B + AM_NS - 1) / AM_NS), dim3(AM_THREADS), lds, s, nd, g, m, img, S);
-    else
-        hipLaunchKernelGGL(k_adj_mfma<false>, dim3((S.B + AM_NS - 1) / AM_NS), dim3(AM_THREADS), lds, s, nd, g, m, img, S);
-    return hipGetLastError();
+    return all_tanh ? go(T1{}, P2{}, dim3(tiles)) : go(T0{}, P2{}, dim3(tiles));
 }
+
+size_t adj_mfma_scratch_floats(const AdjMfmaLayout& m, size_t B) { return 6 * B * (size_t)m.SR; }
