@@ -115,6 +115,8 @@ struct cnf_ctx {
     float* g_W[6] = {};           // zbar per stage
     float* g_lam = nullptr;
     float *g_HS = nullptr, *g_TS = nullptr, *g_AB = nullptr, *g_PB = nullptr;
+    float* d_park = nullptr;      // parked state of the two-launch headline pullback (adj3b_park_floats)
+    size_t park_floats = 0;
     float* g_sc = nullptr;        // scratch rows of the two-launch MFMA pullback (adj_mfma_scratch_floats), or null
     float* g_part = nullptr;      // GRAD_MAX_KSPLIT x n_params
     NetDesc nd_wave{};            // what the wave kernels see: nd, or a one-layer tanh network with an identity layer appended
@@ -290,6 +292,7 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (h->d_ys) (void)hipFree(h->d_ys);
     if (h->d_PT) (void)hipFree(h->d_PT);
     if (h->d_adj_img) (void)hipFree(h->d_adj_img);
+    if (h->d_park) (void)hipFree(h->d_park);
     if (h->d_bimg) (void)hipFree(h->d_bimg);
     if (h->d_bstore) (void)hipFree(h->d_bstore);
     if (h->d_gt) (void)hipFree(h->d_gt);
@@ -1799,6 +1802,16 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
             for (int i = 0; i < 6; ++i) M.bw[i] = Bw[i];
             for (int m = 0; m < 6; ++m) for (int d = 0; d < 5; ++d) M.kc[m][d] = m - 1 - d >= 0 ? A[m][m - 1 - d] : 0.f;
             M.B = B;
+            if (adj3b_split(B, cnt)) {          // (batches that leave CUs idle: two launches, the parked state in between)
+                const size_t need = adj3b_park_floats(B, cnt);
+                if (need > h->park_floats) {
+                    HIPCHK(h, hipStreamSynchronize(st));
+                    if (h->d_park) { (void)hipFree(h->d_park); h->d_park = nullptr; h->park_floats = 0; }
+                    HIPCHK(h, hipMalloc(&h->d_park, need * sizeof(float)));
+                    h->park_floats = need;
+                }
+                M.park = h->d_park;
+            }
             HIPCHK(h, launch_adj3b(nd, gl, h->mfma.d_img3b, M, st));
             int ks, ch;
             grad_ksplit(nd, gl, 6 * cnt * B, &ks, &ch);

@@ -6,6 +6,7 @@
 #include "cnf_grad.h"
 
 constexpr int ADJ3B_MAX_STEPS = 32;               // steps per launch (their sizes travel in the kernel arguments)
+constexpr int ADJ3B_PARK_FLOATS = 8 * 2048 + 3 * 1024;   // two-launch form: parked state per stage and 32-sample workgroup
 
 struct Adj3bSteps {
     const float* traj;              // the trajectory store: slot s holds the six stage states of step s, [6][B][n_in + 3]
@@ -22,8 +23,13 @@ struct Adj3bSteps {
     float bw[6];                    // b_i
     float kc[6][5];                 // kc[m][d] = a_{m, m-1-d} (0 past stage 0): what zbar_m adds to the sum of the d-th stage after it
     int B;
+    float* park;                    // two-launch form: adj3b_park_floats(B, steps of the run) floats, or null (one launch)
 };
 
 bool adj3b_supported(const NetDesc& nd);          // 32-128-128-32 (padded), tanh, VJP handle, no conditioning; CNF_ADJ3B=0 switches it off
 // d_img3b: the split-fragment image of k_step3b (MfmaPlan::d_img3b)
+// Whether a run of `steps` steps at batch B is better served by two launches (the stage-parallel sweeps 1-3, then the hbar chains
+// in turn) on this device -- then M.park must hold adj3b_park_floats(B, steps); CNF_ADJ_SPLIT=0: never
+bool adj3b_split(int B, int steps);
+size_t adj3b_park_floats(int B, int steps);
 hipError_t launch_adj3b(const NetDesc& nd, const GradLayout& g, const void* d_img3b, const Adj3bSteps& M, hipStream_t s);

@@ -19,6 +19,8 @@
 // lives in REGISTERS (32 VGPRs: h and tbar, s' and s'' formed again from h) instead of 119 KB of LDS -- which is what makes room for the split images -- and the per-row
 // state of the 32-row arrays (lambda, the zbar shift register, eps, ahat, s'_3, s''_3) sits in swizzled fp32 LDS rows owned by
 // the lanes that produce zdot / zbar (waves w and w + 4 share the addresses: 13 barrier intervals per stage).
+#include <type_traits>
+
 #include "cnf_adj3b.h"
 #include "cnf_step3_dev.h"
 #include "cnf_mfma_dev.h"
@@ -54,6 +56,16 @@ __device__ __forceinline__ f32x4 a3b_d2tanh4(const f32x4& h, const f32x4& d1) { 
     return f32x4{-2.f * h.x * d1.x, -2.f * h.y * d1.y, -2.f * h.z * d1.z, -2.f * h.w * d1.w};
 }
 
+// PHASE 0: everything, stage after stage.  The first three sweeps of a stage do not depend on the adjoint state (the tbar chain
+// starts from eps, tau is made of eps, eJ and the constant cotangents of the scalar rows): only ahat and the hbar chain behind it
+// carry lambda and the zbar of the later stages.  Where the batch leaves CUs idle (launch_adj3b decides) a run of steps is TWO
+// launches:
+//   PHASE 1, grid (tiles, stages of the run): sweeps 1-3 of ALL stages side by side; HS, PB, TS filed as always; what sweep 4
+//            needs is parked in M.park, per stage and workgroup ADJ3B_PARK_FLOATS: the lanes' own registers h_1, h_2,
+//            tbar_1 q_1, tbar_2 q_2 (lane order: coalesced both ways) and the owner rows s'_3, eps q_3, c_E zdot / |zdot|;
+//   PHASE 2, grid (tiles): per stage the parked state back, abar_3 = ahat s'_3 + eps q_3, the hbar chain (AB), zbar and the
+//            bookkeeping of lambda -- four barrier intervals instead of thirteen, and only the transposed weights resident.
+template <int PHASE>
 __global__ void __launch_bounds__(512, 2)
 k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, Adj3bSteps M) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -78,13 +90,13 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, Adj3bSteps M) 
     S3bOp wF1, wF2[4], wB3, wB2[4];
     {
         const char* fw = imgb + s3g::F32 + (size_t)wave * 10 * 2048 + 16 * lane;
-        constexpr int AH = 5;
+        constexpr int AH = 5, F0 = PHASE == 2 ? 5 : 0;     // (PHASE 2: the transposed fragments only)
         f32x4 raw[10][2];
 #pragma unroll
-        for (int f = 0; f < AH; ++f) { raw[f][0] = *(const f32x4*)(fw + f * 2048); raw[f][1] = *(const f32x4*)(fw + f * 2048 + 1024); }
+        for (int f = F0; f < F0 + AH; ++f) { raw[f][0] = *(const f32x4*)(fw + f * 2048); raw[f][1] = *(const f32x4*)(fw + f * 2048 + 1024); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int f = 0; f < 10; ++f) {
+        for (int f = F0; f < 10; ++f) {
             if (f + AH < 10) {
                 raw[f + AH][0] = *(const f32x4*)(fw + (f + AH) * 2048);
                 raw[f + AH][1] = *(const f32x4*)(fw + (f + AH) * 2048 + 1024);
@@ -226,16 +238,23 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, Adj3bSteps M) 
         *ownp(a3b::AHAT) = ld4_mask((a.cb * lam + k0) * a.hstep, ocnt);      // (completed to ahat behind the forward sweep)
         s3b_store4(x0w, a3b::NP, xz);
     };
+    // PHASE 1: the one stage of this workgroup
+    const int step1 = M.step_hi - (int)blockIdx.y / 6, stg1 = 5 - (int)blockIdx.y % 6;
     {
         const int cnt = olive ? nv : 0;
-        if (zown) *ownp(a3b::EPSA) = ld4(M.eps + (size_t)(b0 + smp) * n_in + r0, cnt);
-        else {
+        if (zown) {
+            if (PHASE != 2) *ownp(a3b::EPSA) = ld4(M.eps + (size_t)(b0 + smp) * n_in + r0, cnt);
+        } else if (PHASE == 1) {
+            s3b_store4(x0w, a3b::NP, ld4(M.traj + (size_t)step1 * M.slot_stride + (size_t)stg1 * M.n + (size_t)(b0 + smp) * D + r0, cnt));
+        } else {
             *ownp(a3b::LAM) = ld4(M.lam + (size_t)(b0 + smp) * n_in + r0, cnt);
             *ownp(a3b::LSUM) = zero4;
 #pragma unroll
             for (int d = 0; d < 5; ++d) *ownp(a3b::KS + d * a3b::OWN) = zero4;
             const Stage a0 = stage_of(M.step_hi, 5);
-            stage_entry(a0, 5, ld4(M.traj + (size_t)M.step_hi * M.slot_stride + 5 * M.n + (size_t)(b0 + smp) * D + r0, cnt), zero4, false);
+            f32x4 x5 = zero4;                              // (PHASE 2 has no forward sweep: the state image is not read)
+            if (PHASE == 0) x5 = ld4(M.traj + (size_t)M.step_hi * M.slot_stride + 5 * M.n + (size_t)(b0 + smp) * D + r0, cnt);
+            stage_entry(a0, 5, x5, zero4, false);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA pieces have landed
@@ -253,15 +272,20 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, Adj3bSteps M) 
     const int wrow = 16 * wave + 4 * q;                    // first of this lane's 4 rows in a wide tile
 
     // the stages of the steps of this launch, last to first
-    for (int step = M.step_hi, stg = 5;;) {
+    // this lane's parked state of (stage slot q, this workgroup): 8 register quads of all lanes, then 3 owner quads of waves 0-3
+    auto park_at = [&](int step, int stg) __attribute__((always_inline)) -> float* {
+        return M.park + ((size_t)((M.step_hi - step) * 6 + stg) * gridDim.x + blockIdx.x) * ADJ3B_PARK_FLOATS + 4 * tid;
+    };
+    for (int step = PHASE == 1 ? step1 : M.step_hi, stg = PHASE == 1 ? stg1 : 5;;) {
         const Stage a = stage_of(step, stg);
-        const bool last = stg == 0 && step == M.step_lo;
+        const bool last = PHASE == 1 || (stg == 0 && step == M.step_lo);
         const int nstep = stg > 0 ? step : step - 1, nstg = stg > 0 ? stg - 1 : 5;       // the stage evaluated next
         // (an opaque zero per stage keeps the compiler from hoisting the 64-bit addresses of all array families out of the loop)
         int zopq = 0;
         asm volatile("" : "+v"(zopq));
         const int orow = b0 + smp + zopq;
         const int ocnt = olive ? nv : 0;
+      if (PHASE != 2) {
         // ---- sweep 1: forward.  I0: layer 1, tile `wave`, both halves (K = 32) ----
         {
             const f32x4 bv = *(const f32x4*)(bias + wrow);
@@ -336,7 +360,8 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, Adj3bSteps M) 
             if (zown) {                                    // ahat = kbar_z + c_E zdot / |zdot|   (|zdot|^2: complete since the barrier)
                 const float nz = red8(0);
                 const float inv = (nd.norm_z && nz > 0.f) ? (a.hstep * a.cb * M.lam_E) * __builtin_amdgcn_rsqf(nz) : 0.f;
-                *ownp(a3b::AHAT) = ld4_mask(*ownp(a3b::AHAT) + inv * zdv, ocnt);
+                if (PHASE == 1) *ownp(a3b::AHAT) = ld4_mask(inv * zdv, ocnt);      // (parked; PHASE 2 adds kbar_z)
+                else *ownp(a3b::AHAT) = ld4_mask(*ownp(a3b::AHAT) + inv * zdv, ocnt);
             }
         }
         A3T(6);
@@ -433,17 +458,47 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, Adj3bSteps M) 
         if (zown) {
             const f32x4 zsum = narrow();
             const f32x4 q3 = *ownp(a3b::D23) * zsum;
-            const f32x4 ab = *ownp(a3b::AHAT) * *ownp(a3b::D13) + *ownp(a3b::EPSA) * q3;
-            s3b_store4(g3w, a3b::NP, ab);
+            if (PHASE == 1) {                              // the owner rows sweep 4 needs -> park
+                float* pk = park_at(step, stg) + 8 * 2048;
+                *reinterpret_cast<f32x4*>(pk) = *ownp(a3b::D13);
+                *reinterpret_cast<f32x4*>(pk + 1024) = *ownp(a3b::EPSA) * q3;
+                *reinterpret_cast<f32x4*>(pk + 2048) = *ownp(a3b::AHAT);
+            } else {
+                const f32x4 ab = *ownp(a3b::AHAT) * *ownp(a3b::D13) + *ownp(a3b::EPSA) * q3;
+                s3b_store4(g3w, a3b::NP, ab);
+            }
         } else {                                           // (waves 4-7: t_1, t_2 -> TS)
             flush(a3b::H1G, M.TS + a.qi, gl.sum_in, gl.in_off[1]);
             flush(a3b::H2G, M.TS + a.qi, gl.sum_in, gl.in_off[2]);
             flush32(a3b::X0S, M.TS + a.qi, gl.sum_in, 0);         // (tau: t_0)
             A3B_FLUSHED();
         }
+        if (PHASE == 1) {                                  // the lanes' registers -> park; the stage is PHASE 2's from here
+            float* pk = park_at(step, stg);
+            *reinterpret_cast<f32x4*>(pk) = H1r[0]; *reinterpret_cast<f32x4*>(pk + 2048) = H1r[1];
+            *reinterpret_cast<f32x4*>(pk + 2 * 2048) = H2r[0]; *reinterpret_cast<f32x4*>(pk + 3 * 2048) = H2r[1];
+            *reinterpret_cast<f32x4*>(pk + 4 * 2048) = TB1[0]; *reinterpret_cast<f32x4*>(pk + 5 * 2048) = TB1[1];
+            *reinterpret_cast<f32x4*>(pk + 6 * 2048) = TB2[0]; *reinterpret_cast<f32x4*>(pk + 7 * 2048) = TB2[1];
+            break;
+        }
         A3T(18);
         s3_bar();
         A3T(19);
+      } else {
+        // ---- PHASE 2: the parked state of this stage back; abar_3 = (kbar_z h + c_E zdot / |zdot|) s'_3 + eps q_3 -> G3S ----
+        const float* pk = park_at(step, stg);
+        H1r[0] = *reinterpret_cast<const f32x4*>(pk); H1r[1] = *reinterpret_cast<const f32x4*>(pk + 2048);
+        H2r[0] = *reinterpret_cast<const f32x4*>(pk + 2 * 2048); H2r[1] = *reinterpret_cast<const f32x4*>(pk + 3 * 2048);
+        TB1[0] = *reinterpret_cast<const f32x4*>(pk + 4 * 2048); TB1[1] = *reinterpret_cast<const f32x4*>(pk + 5 * 2048);
+        TB2[0] = *reinterpret_cast<const f32x4*>(pk + 6 * 2048); TB2[1] = *reinterpret_cast<const f32x4*>(pk + 7 * 2048);
+        if (zown) {
+            const float* po = pk + 8 * 2048;
+            const f32x4 d13 = *reinterpret_cast<const f32x4*>(po), eq3 = *reinterpret_cast<const f32x4*>(po + 1024),
+                        zt = *reinterpret_cast<const f32x4*>(po + 2048);
+            s3b_store4(g3w, a3b::NP, (*ownp(a3b::AHAT) + zt) * d13 + eq3);
+        }
+        s3_bar();
+      }
         // ---- sweep 4: the hbar chain.  I3': abar_2 = (W3^T abar_3) s'_2 + tbar_2 q_2 ----
         {
             S3bOp b[2];
@@ -517,12 +572,39 @@ bool adj3b_supported(const NetDesc& nd) {
     return true;
 }
 
+bool adj3b_split(int B, int steps) {
+    static const int forced = [] { const char* e = getenv("CNF_ADJ_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();   // A/B: 0 never, 1 always
+    if (forced == 0 || B < 1 || steps < 1) return false;
+    if (forced == 1) return true;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+        if (cus < 1) cus = 1;
+    }
+    // in units of one stage of the one-launch form: the parallel launch costs ~0.75 per round of `cus` workgroups, the sequential
+    // one ~0.3 per stage (4 of 13 barrier intervals)
+    const long nst = 6L * steps, rounds = (nst * ((B + 31) / 32) + cus - 1) / cus;
+    return 0.75 * rounds + 0.3 * nst < 0.95 * nst;
+}
+
+size_t adj3b_park_floats(int B, int steps) { return (size_t)6 * steps * ((B + 31) / 32) * ADJ3B_PARK_FLOATS; }
+
 hipError_t launch_adj3b(const NetDesc& nd, const GradLayout& g, const void* d_img3b, const Adj3bSteps& M, hipStream_t s) {
     if (!adj3b_supported(nd) || !d_img3b || !M.lam_out || M.step_lo < 0 || M.step_hi < M.step_lo ||
         M.step_hi - M.step_lo >= ADJ3B_MAX_STEPS || M.B < 1) return hipErrorInvalidValue;
+    const int tiles = (M.B + 31) / 32, steps = M.step_hi - M.step_lo + 1;
     // (per launch: the attribute belongs to the current device, and a process may drive several)
-    hipError_t e = hipFuncSetAttribute((const void*)k_adj3b, hipFuncAttributeMaxDynamicSharedMemorySize, a3b::TOTAL_BYTES);
+    auto go = [&](auto phase_c, dim3 grid) -> hipError_t {
+        constexpr int PH = decltype(phase_c)::value;
+        hipError_t e = hipFuncSetAttribute((const void*)k_adj3b<PH>, hipFuncAttributeMaxDynamicSharedMemorySize, a3b::TOTAL_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_adj3b<PH>), grid, dim3(512), a3b::TOTAL_BYTES, s, nd, g, (const char*)d_img3b, M);
+        return hipGetLastError();
+    };
+    if (!M.park || !adj3b_split(M.B, steps)) return go(std::integral_constant<int, 0>{}, dim3(tiles));
+    hipError_t e = go(std::integral_constant<int, 1>{}, dim3(tiles, 6 * steps));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_adj3b, dim3((M.B + 31) / 32), dim3(512), a3b::TOTAL_BYTES, s, nd, g, (const char*)d_img3b, M);
-    return hipGetLastError();
+    return go(std::integral_constant<int, 2>{}, dim3(tiles));
 }
