@@ -106,6 +106,7 @@ _SIGNATURES = {
     "cnf_grad_x": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_void_p]),
     "cnf_solve_fallbacks": (C.c_int, [C.c_void_p]),
     "cnf_set_solve_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "cnf_set_grad_split": (C.c_int, [C.c_int]),
     "cnf_selftest_hold_cus": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "cnf_selftest_split_product": (C.c_int, [_fp, _fp, _fp, C.c_int]),
 }

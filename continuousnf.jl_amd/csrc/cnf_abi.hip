@@ -576,6 +576,12 @@ extern "C" cnf_status cnf_selftest_hold_cus(int n_workgroups, int microseconds, 
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 extern "C" int cnf_solve_fallbacks(cnf_handle h) { return h ? h->fallbacks : -1; }
+extern "C" int cnf_set_grad_split(int mode) {
+    const int was = adj_split_mode();
+    set_adj_split_mode(mode);
+    return was;
+}
+
 extern "C" cnf_status cnf_set_solve_wait(cnf_handle h, int wait_us, int poll_limit) {
     if (!h) return CNF_ERR_BAD_ARG;
     if (wait_us > 0) h->wait_us = wait_us;

@@ -573,7 +573,7 @@ bool adj3b_supported(const NetDesc& nd) {
 }
 
 bool adj3b_split(int B, int steps) {
-    static const int forced = [] { const char* e = getenv("CNF_ADJ_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();   // A/B: 0 never, 1 always
+    const int forced = adj_split_mode();                  // A/B and tests: 0 never, 1 always
     if (forced == 0 || B < 1 || steps < 1) return false;
     if (forced == 1) return true;
     static int cus = 0;

@@ -95,3 +95,7 @@ hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const 
 hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
                                 const AdjStepArgs& S, hipStream_t s, float* scratch = nullptr);
 size_t adj_mfma_scratch_floats(const AdjMfmaLayout& m, size_t B);
+// the two-launch forms of the pullback kernels (k_adj_mfma, k_adj3b): -1 where it pays (default; CNF_ADJ_SPLIT=0|1 overrides at
+// start-up), 0 never, 1 wherever the parked state fits -- process-wide, for A/B runs and the parity tests (cnf_debug_adj_split)
+int adj_split_mode();
+void set_adj_split_mode(int mode);

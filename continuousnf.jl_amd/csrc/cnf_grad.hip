@@ -21,6 +21,7 @@
 //   weight transpose.
 // DESIGN.md section 4.4 has the measurements.
 #include "cnf_grad.h"
+#include <atomic>
 #include <type_traits>
 
 #include "cnf_am.h"
@@ -1857,9 +1858,9 @@ hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const Ad
     const int tiles = (S.B + AM_NS - 1) / AM_NS, nstg = S.first - S.last + 1;
     // Two launches when that is less sequential work: the stage-parallel phase costs ~0.7 of a stage per round of CUs workgroups
     // (1 per CU: 156 KB of LDS), the sequential phase ~0.3 of a stage per stage (phase stamps at config 5).
-    static const bool no_split = [] { const char* e = getenv("CNF_ADJ_SPLIT"); return e && e[0] == '0'; }();
+    const int mode = adj_split_mode();
     bool split = false;
-    if (scratch && !no_split && nstg > 1) {
+    if (scratch && mode != 0 && nstg > 1) {
         static int cus = 0;
         if (!cus) {
             int dev = 0;
@@ -1868,7 +1869,7 @@ hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const Ad
             if (cus < 1) cus = 1;
         }
         const int rounds = (nstg * tiles + cus - 1) / cus;
-        split = 0.7 * rounds + 0.3 * nstg < 0.95 * nstg;
+        split = mode == 1 || 0.7 * rounds + 0.3 * nstg < 0.95 * nstg;
     }
     auto go = [&](auto tanh_c, auto phase_c, dim3 grid) -> hipError_t {
         constexpr bool T = decltype(tanh_c)::value;
@@ -1890,3 +1891,7 @@ hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const Ad
 }
 
 size_t adj_mfma_scratch_floats(const AdjMfmaLayout& m, size_t B) { return 6 * B * (size_t)m.SR; }
+
+static std::atomic<int> g_adj_split{[] { const char* e = getenv("CNF_ADJ_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }()};
+int adj_split_mode() { return g_adj_split.load(std::memory_order_relaxed); }
+void set_adj_split_mode(int mode) { g_adj_split.store(mode < 0 ? -1 : (mode > 0 ? 1 : 0), std::memory_order_relaxed); }

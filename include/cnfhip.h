@@ -333,6 +333,12 @@ int cnf_solve_fallbacks(cnf_handle h);
  * reference has no counterpart (its solve is a CPU loop, src/base_icnf.jl:137-143): this bounds the stall a co-tenant of
  * the GPU can cause.  Environment defaults for new handles: CNF_SOLVE_WAIT_US, CNF_SOLVE_POLL_LIMIT. */
 cnf_status cnf_set_solve_wait(cnf_handle h, int wait_us, int poll_limit);
+/* The gradient's pullback kernels (loss_and_grad, src/exts/mlj_ext/core_icnf.jl:59-73) run a step either as one launch or --
+ * where the batch leaves compute units idle -- as two: the three sweeps of every stage that do not depend on the adjoint state
+ * side by side, then the remaining chain stage by stage.  mode -1: chosen per call (default; CNF_ADJ_SPLIT=0|1 presets it),
+ * 0: always one launch, 1: always two.  Process-wide; both forms compute the same gradient (A/B runs, the parity tests).
+ * Returns the mode that was in force. */
+int cnf_set_grad_split(int mode);
 /* Arithmetic self-test (no handle): C (16 x 16, row-major, HOST) = A Bt^T for HOST matrices A, Bt of 16 x K floats
  * (row-major, K a multiple of 32), computed on one wavefront with the operand split and the six-term bf16 MFMA product
  * the headline kernels use in place of the reference's sgemm (Lux Dense inside src/icnf.jl:331-332).  The parity suite

@@ -1528,6 +1528,42 @@ def test_loss_grad_config5_network():
         _assert_grad(grad, rgrad, f"config 5 {kernel}")
 
 
+@pytest.mark.parametrize("which", ["headline", "config5", "conditional-3-layer"])
+def test_loss_grad_one_launch_and_two_launch_pullbacks_agree(which):
+    """The pullback kernels' two forms (cnf_set_grad_split: one launch per run of steps, or the adjoint-independent sweeps of all
+    stages side by side + the hbar chains in turn) against the float64 adjoint and against each other -- k_adj3b at the
+    headline shape, k_adj_mfma at config 5's network and on a conditional three-layer model, ragged batches, adaptive steps."""
+    l = _lib.lib()
+    if which == "headline":
+        cfg = O.Cfg(O.Net((32, 128, 128, 32), (O.ACT_TANH,) * 3), 32, 0, 0.01, 0.01)
+        n_cond, B, scale = 0, 77, 0.1
+    elif which == "config5":
+        cfg, _, _ = O.baseline_cfg(5)
+        n_cond, B, scale = 0, 40, 0.1
+    else:
+        cfg = O.Cfg(O.Net((12, 64, 48, 12), (O.ACT_TANH, O.ACT_SOFTPLUS, O.ACT_TANH)), 8, 4, 0.01, 0.01, 0.01)
+        n_cond, B, scale = 3, 50, 0.3
+    cfg.tspan = (0.0, 0.5)
+    tol = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+    got = {}
+    was = l.cnf_set_grad_split(-1)
+    try:
+        for mode in (0, 1):
+            l.cnf_set_grad_split(mode)
+            for tag, sol_kw, ora_kw in (("fixed", dict(adaptive=False, dt=1 / 4), dict(adaptive=False, dt=1 / 4)),
+                                        ("adaptive", dict(tol), "replay")):
+                val, grad, rval, rgrad, st, _ = _grad_case(cfg, B, 870, "mfma", sol_kw, ora_kw, n_cond=n_cond, scale=scale)
+                assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval)), (which, mode, tag)
+                _assert_grad(grad, rgrad, f"{which} split={mode} {tag}")
+                got[mode, tag] = (val, grad, st["naccept"])
+    finally:
+        l.cnf_set_grad_split(was)
+    for tag in ("fixed", "adaptive"):
+        (v0, g0, n0), (v1, g1, n1) = got[0, tag], got[1, tag]
+        assert n0 == n1 and v0 == v1, (which, tag)
+        assert np.abs(g0 - g1).max() <= 2e-6 * (np.abs(g0).max() + 1e-30), (which, tag, np.abs(g0 - g1).max(), np.abs(g0).max())
+
+
 def test_streamed_weights_run_the_fused_step_kernel_on_16_sample_tiles():
     """Config 5's network (weights streamed from L2) at ragged batches that leave the last 16-sample workgroup
     partly empty: kernel = auto and kernel = mfma are the same fused step kernel (one launch per step, 16-sample
