@@ -276,6 +276,17 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, Adj3bSteps M) 
     auto park_at = [&](int step, int stg) __attribute__((always_inline)) -> float* {
         return M.park + ((size_t)((M.step_hi - step) * 6 + stg) * gridDim.x + blockIdx.x) * ADJ3B_PARK_FLOATS + 4 * tid;
     };
+    f32x4 pfr[8], pfo[3];                                  // PHASE 2: the parked state of the stage after this one, in flight
+    auto park_load = [&](int step, int stg) __attribute__((always_inline)) {
+        const float* pk = park_at(step, stg);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pfr[j] = *reinterpret_cast<const f32x4*>(pk + j * 2048);
+        if (zown) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pfo[j] = *reinterpret_cast<const f32x4*>(pk + 8 * 2048 + j * 1024);
+        }
+    };
+    if (PHASE == 2) park_load(M.step_hi, 5);
     for (int step = PHASE == 1 ? step1 : M.step_hi, stg = PHASE == 1 ? stg1 : 5;;) {
         const Stage a = stage_of(step, stg);
         const bool last = PHASE == 1 || (stg == 0 && step == M.step_lo);
@@ -485,18 +496,14 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, Adj3bSteps M) 
         s3_bar();
         A3T(19);
       } else {
-        // ---- PHASE 2: the parked state of this stage back; abar_3 = (kbar_z h + c_E zdot / |zdot|) s'_3 + eps q_3 -> G3S ----
-        const float* pk = park_at(step, stg);
-        H1r[0] = *reinterpret_cast<const f32x4*>(pk); H1r[1] = *reinterpret_cast<const f32x4*>(pk + 2048);
-        H2r[0] = *reinterpret_cast<const f32x4*>(pk + 2 * 2048); H2r[1] = *reinterpret_cast<const f32x4*>(pk + 3 * 2048);
-        TB1[0] = *reinterpret_cast<const f32x4*>(pk + 4 * 2048); TB1[1] = *reinterpret_cast<const f32x4*>(pk + 5 * 2048);
-        TB2[0] = *reinterpret_cast<const f32x4*>(pk + 6 * 2048); TB2[1] = *reinterpret_cast<const f32x4*>(pk + 7 * 2048);
-        if (zown) {
-            const float* po = pk + 8 * 2048;
-            const f32x4 d13 = *reinterpret_cast<const f32x4*>(po), eq3 = *reinterpret_cast<const f32x4*>(po + 1024),
-                        zt = *reinterpret_cast<const f32x4*>(po + 2048);
-            s3b_store4(g3w, a3b::NP, (*ownp(a3b::AHAT) + zt) * d13 + eq3);
-        }
+        // ---- PHASE 2: the parked state of this stage (requested a stage ahead: `pfr`, `pfo`) takes its place, the next stage's
+        //      is requested and travels under this stage's four intervals; abar_3 = (kbar_z h + c_E zdot / |zdot|) s'_3 + eps q_3
+        //      -> G3S ----
+        H1r[0] = pfr[0]; H1r[1] = pfr[1]; H2r[0] = pfr[2]; H2r[1] = pfr[3];
+        TB1[0] = pfr[4]; TB1[1] = pfr[5]; TB2[0] = pfr[6]; TB2[1] = pfr[7];
+        const f32x4 d13 = pfo[0], eq3 = pfo[1], zt = pfo[2];
+        if (!last) park_load(nstep, nstg);
+        if (zown) s3b_store4(g3w, a3b::NP, (*ownp(a3b::AHAT) + zt) * d13 + eq3);
         s3_bar();
       }
         // ---- sweep 4: the hbar chain.  I3': abar_2 = (W3^T abar_3) s'_2 + tbar_2 q_2 ----
