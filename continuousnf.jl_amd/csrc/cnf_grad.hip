@@ -1109,7 +1109,7 @@ AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g) {
     m.E = p; p += m.nin_p;
     m.AH = m.TB + m.o_off[m.L - 1];       // ahat reuses the tbar_L slot (free after the first reverse GEMM)
     m.PS = ((p + 15) & ~15) + 8;          // stride = 8 mod 16 floats: conflict-free b128 columns
-    m.SR = 3 * oo + m.nin_p;
+    m.SR = 3 * oo + m.nin_p + 16;         // sigma', q, tbar | zdot | |zdot|^2 (padded to a 64-byte row)
     m.vec4 = (g.sum_in & 3) == 0;         // rows of HS/TS start 16-byte aligned ...
     for (int l = 0; l < m.L; ++l) if (g.in_off[l] & 3) m.vec4 = 0;   // ... and so does every layer's block
     m.vec4o = (g.sum_out & 3) == 0;
@@ -1286,8 +1286,11 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
         AM_STAMP(7 + (NL - 1 - l));
         const int t_ = cur; cur = nxt; nxt = t_;
         if (l == NL - 1) {
-            if (PHASE == 1) {                                // zdot -> scratch (ahat is formed in PHASE 2)
+            if (PHASE == 1) {                                // zdot and |zdot|^2 -> scratch (ahat is formed in PHASE 2)
+                float nz = 0.f;
+                if (nd.norm_z) nz = am_colnorm2(lds + zd, PS, n_in, red);
                 for (int r = ec; r < m.nin_p; r += AM_EC) if (ev) scrow[3 * m.sum_o + r] = lds[es * PS + zd + r];
+                if (ev && ec == 0) scrow[3 * m.sum_o + m.nin_p] = nz;
             } else {
             // zdot still sits in S[zd]: ahat = kbar_z + c_E zdot/|zdot| -> AH.  AH shares the tbar_L slot of TB,
             // free now that pbar_L (parked there by sweep 1) has been consumed by this GEMM.
@@ -1366,6 +1369,11 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
     //      abar_L = ahat sigma'_L + eps q_L -> S1 and AB, elementwise (ahat never leaves the registers) ----
     am_first(pf, img + m.fr_off[NL - 1], m.dp[NL - 1], m.dp[NL]);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // (kbar_z of this thread's first four rows and |zdot|^2 are requested before anything waits: their trip to memory runs under
+    // the copy of the scratch rows)
+    float kb0[4];
+    am_kbar4(a, ev, eb, n_in, ec, kb0);
+    const float nz = (nd.norm_z && ev) ? scrow[3 * m.sum_o + m.nin_p] : 0.f;
     for (int r = 4 * ec; r < 3 * m.sum_o; r += 4 * AM_EC)
         *reinterpret_cast<f32x4*>(lds + es * PS + m.D1 + r) = ev ? *reinterpret_cast<const f32x4*>(scrow + r) : z4;
     for (int r = ec; r < m.nin_p; r += AM_EC) {
@@ -1373,12 +1381,11 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
         lds[es * PS + m.E + r] = (ev && r < n_in) ? a.eps[(size_t)eb * n_in + r] : 0.f;
     }
     am_barrier();
-    float nz = 0.f;
-    if (nd.norm_z) nz = am_colnorm2(lds + m.S0, PS, n_in, red);
     const float inv = (nd.norm_z && nz > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz) : 0.f;
     for (int rb = ec; rb < m.nin_p; rb += 4 * AM_EC) {
         float kb[4];
-        am_kbar4(a, ev, eb, n_in, rb, kb);
+        if (rb == ec) { kb[0] = kb0[0]; kb[1] = kb0[1]; kb[2] = kb0[2]; kb[3] = kb0[3]; }
+        else am_kbar4(a, ev, eb, n_in, rb, kb);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = rb + i * AM_EC;
