@@ -23,6 +23,12 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 echo "wait rc=$?"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/grad -- python3 tools/prof_grad.py 3 8192 3 > $OUT/grad.log 2>&1
 echo "grad rc=$?"
+# the same network at the reference's training batch (two-launch pullback), and config 5's network (generic MFMA pullback)
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/grad_b32 -- python3 tools/prof_grad.py 3 32 6 > $OUT/grad_b32.log 2>&1
+echo "grad_b32 rc=$?"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/grad_cfg5 -- python3 tools/prof_grad.py 5 2048 4 > $OUT/grad_cfg5.log 2>&1
+echo "grad_cfg5 rc=$?"
+timeout -k 10 200 python3 tools/prof_grad.py > $OUT/grad_table.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/testmode -- python3 tools/prof_testmode.py > $OUT/testmode.log 2>&1
 echo "testmode rc=$?"
 # every BASELINE configuration at full size (uses the oracle as the checker: tests/measure_configs.py)

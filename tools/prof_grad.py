@@ -37,5 +37,5 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 5)
     else:
-        for i, B in ((1, 32), (2, 32), (2, 4096), (3, 32), (3, 8192), (5, 2048)):
+        for i, B in ((1, 32), (2, 32), (2, 4096), (3, 32), (3, 256), (3, 2048), (3, 4096), (3, 8192), (5, 32), (5, 256), (5, 2048)):
             run(i, B)
