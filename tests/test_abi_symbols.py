@@ -39,6 +39,20 @@ def test_abi_version_and_status_strings():
     assert b"shape" in l.cnf_status_string(_lib.ERR_BAD_SHAPE)
 
 
+def test_grad_split_switch_is_a_plain_process_setting():
+    """cnf_set_grad_split touches no device: it returns the mode that was in force and clamps what it is given."""
+    l = _lib.lib()
+    was = l.cnf_set_grad_split(1)
+    try:
+        assert was in (-1, 0, 1)
+        assert l.cnf_set_grad_split(0) == 1
+        assert l.cnf_set_grad_split(-7) == 0
+        assert l.cnf_set_grad_split(5) == -1
+        assert l.cnf_set_grad_split(-1) == 1
+    finally:
+        l.cnf_set_grad_split(was)
+
+
 def test_create_validates_before_touching_the_device():
     l = _lib.lib()
     h = ctypes.c_void_p()
