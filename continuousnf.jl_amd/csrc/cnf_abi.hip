@@ -1636,7 +1636,10 @@ static cnf_status ensure_grad_capacity(cnf_handle h, int B) {
     if (fsteps > 32) fsteps = 32;
     h->grad_fsteps = (int)fsteps;
     const AdjMfmaLayout am = adj_mfma_layout(h->nd, g);
-    const size_t sc = adj_mfma_supported(h->nd, am) ? adj_mfma_scratch_floats(am, cap) : 0;   // scratch rows of the two-launch pullback
+    // scratch rows of the two-launch pullback: only batches that leave CUs idle take that form (launch_adj_mfma_step: at most
+    // five rounds of 16-sample workgroups for the six stages), and the headline shape has its own parked state (d_park)
+    const bool may_split = adj_mfma_supported(h->nd, am) && !(adj3b_supported(h->nd) && h->mfma.d_img3b) && cap <= (size_t)16 * 1024;
+    const size_t sc = may_split ? adj_mfma_scratch_floats(am, cap) : 0;
     const size_t total = 5 * D * cap + 7 * n_in * cap + fsteps * per_step + sc +
                          ((size_t)GRAD_MAX_KSPLIT + 1) * h->n_params;
     HIPCHK(h, hipMalloc(&h->grad_arena, total * sizeof(float)));
