@@ -909,7 +909,9 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                          wave_solve_supported(h->nd_wave, train != 0, B);
     if (rec && rec->wg && !(wave_ok && !lockstep && !h->no_persist)) { rec->wg_failed = true; return CNF_OK; }
     // ... or of config 5's network at eight columns per CU (k_solve_bcast, cnf_bcast.hip)
-    const bool bcast_ok = k == CNF_KERNEL_MFMA && !rec && !wave_ok && bcast_solve_supported(h->nd, train != 0, B, h->device);
+    // (the gradient's recorded forward too, where one tile per workgroup holds the batch: VJP compute mode)
+    const bool bcast_rec = rec && !rec->wg && train && !h->nd.jvp && bcast_store_floats(B, h->device) == 0;
+    const bool bcast_ok = k == CNF_KERNEL_MFMA && (!rec || bcast_rec) && !wave_ok && bcast_solve_supported(h->nd, train != 0, B, h->device);
     if (bcast_ok && !lockstep && !h->no_persist) {
         if (!h->d_bimg) HIPCHK(h, hipMalloc(&h->d_bimg, bcast_img_floats() * sizeof(float)));
         if (!h->bimg_valid) { bcast_pack(h->nd, h->d_params, h->d_bimg, st); HIPCHK(h, hipGetLastError()); h->bimg_valid = true; }
@@ -982,9 +984,14 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             s = launch_trace_solve(h->nd, g, m, h->d_adj_img, ta, sv, st) == hipSuccess ? CNF_OK : CNF_ERR_UNSUPPORTED;
             if (s != CNF_OK) (void)hipGetLastError();
         }
-        if (bcast_ok)
-            s = bcast_solve_launch(h->nd, train != 0, h->d_params, h->d_bimg, h->d_state, h->U[0], eps, B, st, h->d_mirror + mslot, base, sv, h->device,
-                                   h->d_bstore, h->nd.n_cond > 0 ? h->d_cond : nullptr, h->cbs);
+        if (bcast_ok) {
+            BcastRecord brec{dump, n, slot, dcap, h->traj_hs};
+            Solve3Args svb = sv;
+            if (rec && u_out) svb.u_out = u_out;         // (this kernel writes the final state where it is wanted)
+            s = bcast_solve_launch(h->nd, train != 0, h->d_params, h->d_bimg, h->d_state, h->U[0], eps, B, st, h->d_mirror + mslot, base, svb, h->device,
+                                   h->d_bstore, h->nd.n_cond > 0 ? h->d_cond : nullptr, h->cbs, rec ? &brec : nullptr);
+            if (s == CNF_OK && rec && u_out) sv.u_out = u_out;
+        }
         if (s == CNF_ERR_UNSUPPORTED && use_mfma)
             s = mfma_solve_persistent(h->mfma, h->nd, train, h->d_state, h->U, eps, B, st, h->d_mirror + mslot, base, sv, h->device,
                                       dump, n, slot, dcap, h->traj_hs, h->K1);

@@ -48,6 +48,10 @@ struct BcArgs {
     float* store;          // MULTI: the tiles' Runge-Kutta rows (bcast_store_floats)
     const float* cond;     // conditional models: the per-sample first-layer bias W1y ys + b1, [B][cbs]   (src/base_icnf.jl:288-309)
     int cbs;
+    // RECORD (gradient path, as k_solve3b<RECORD>): every attempt files u_n and its stage states U_2..U_6 (z rows, [B][D]) in the
+    // trajectory slot of step `naccept` -- dump = the U_2 array of slot 0, u_n sits dump_n floats in front of it -- and its signed
+    // step size in hs_out
+    float* dump; size_t dump_n, dump_slot; int dump_cap; float* hs_out;
 };
 struct BcTab { float a[7][8]; };
 static const BcTab kBcTab = {{
@@ -164,9 +168,10 @@ struct I1 { static constexpr int value = 1; };
 struct I2 { static constexpr int value = 2; };
 struct I3 { static constexpr int value = 3; };
 
-template <int MODE, bool MULTI>
+template <int MODE, bool MULTI, bool RECORD = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
+    static_assert(!RECORD || (MODE == BC_VJP && !MULTI), "the recording form: VJP compute mode, one tile per workgroup");
     constexpr bool TEST = MODE == BC_TESTM, JVP = MODE == BC_JVP;
     constexpr int NS = TEST ? 1 : 3;
     constexpr int NK = JVP ? 2 : 1;                        // operand kinds side by side: the state columns, and (JVP) the tangent columns
@@ -592,6 +597,17 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
         f32x4 zt = zero4;
         for (int it = 0; alive && !__builtin_amdgcn_readfirstlane(ns.done) && it < sv.maxiters; ++it) {
             float errsum = 0.f, badcnt = 0.f;
+            // RECORD: where this attempt's stage states go (null: more steps than slots -- the host grows the store and solves again)
+            float* dmp = nullptr;
+            if (RECORD) {
+                const int nacc = __builtin_amdgcn_readfirstlane(ns.naccept);
+                if (nacc < a.dump_cap) {
+                    dmp = a.dump + (size_t)nacc * a.dump_slot + (size_t)smp0 * D + ok_row;
+                    if (blockIdx.x == 0 && tid == 0) a.hs_out[nacc] = hstep;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) if (omask[x] != 0.f) (dmp - a.dump_n)[(size_t)x * D] = uz[x];      // u_n = U_1
+                }
+            }
 #pragma unroll 1
             for (int s = 1; s <= 6; ++s) {
                 float as[6];
@@ -601,6 +617,10 @@ k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
 #pragma unroll
                 for (int j = 1; j < 6; ++j) acc += as[j] * *(const f32x4*)Kz[j][tid];     // (rows beyond the stage are zero or stale times a zero coefficient)
                 zt = uz + hstep * acc;
+                if (RECORD && dmp && s < 6) {                  // U_{s+1}
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) if (omask[x] != 0.f) (dmp + (size_t)(s - 1) * a.dump_n)[(size_t)x * D] = zt[x];
+                }
                 f32x4 zd;
                 rhs(zt, zd);
                 bc_bar();
@@ -932,10 +952,11 @@ size_t bcast_store_floats(int B, int device) {
 
 cnf_status bcast_solve_launch(const NetDesc& nd, bool train, const float* d_params, const float* d_img, StepState* st_out, float* U0,
                               const float* eps, int B, hipStream_t s, void* mirror, unsigned seq, const Solve3Args& sv_, int device,
-                              float* store, const float* cond, int cbs) {
+                              float* store, const float* cond, int cbs, const BcastRecord* rec) {
     if (!bcast_solve_supported(nd, train, B, device) || !d_img) return CNF_ERR_UNSUPPORTED;
     const int res = bcast_resident(device), ntiles = (B + 7) / 8;
     const bool multi = ntiles > res || bcast_force_multi();
+    if (rec && (multi || !train || nd.jvp)) return CNF_ERR_UNSUPPORTED;      // (the recording form: VJP, one tile per workgroup)
     if (multi && !store) return CNF_ERR_BAD_ARG;
     if (nd.n_cond > 0 && !cond) return CNF_ERR_BAD_ARG;
     BcArgs a{};
@@ -943,6 +964,7 @@ cnf_status bcast_solve_launch(const NetDesc& nd, bool train, const float* d_para
     a.n_total = (float)((size_t)(nd.n_in + (train ? 3 : 1)) * B);
     a.U0 = U0; a.st_out = st_out; a.mirror = mirror; a.seq = seq;
     a.store = store; a.cond = nd.n_cond > 0 ? cond : nullptr; a.cbs = cbs;
+    if (rec) { a.dump = rec->dump; a.dump_n = rec->n; a.dump_slot = rec->slot; a.dump_cap = rec->cap; a.hs_out = rec->hs_out; }
     Solve3Args sv = sv_;
     sv.nvars = nd.nvars; sv.naugs = nd.naugs; sv.norm_z_aug = nd.norm_z_aug;
     if (!sv.xs && !sv.u0) return CNF_ERR_BAD_ARG;
@@ -956,6 +978,7 @@ cnf_status bcast_solve_launch(const NetDesc& nd, bool train, const float* d_para
     const void* fn;
     if (multi) fn = !train ? (const void*)k_solve_bcast<BC_TESTM, true> : (nd.jvp ? (const void*)k_solve_bcast<BC_JVP, true> : (const void*)k_solve_bcast<BC_VJP, true>);
     else fn = !train ? (const void*)k_solve_bcast<BC_TESTM, false> : (nd.jvp ? (const void*)k_solve_bcast<BC_JVP, false> : (const void*)k_solve_bcast<BC_VJP, false>);
+    if (rec) fn = (const void*)k_solve_bcast<BC_VJP, false, true>;
     if (hipLaunchKernel(fn, dim3(grid), dim3(256), args, 0, s) != hipSuccess) {
         (void)hipGetLastError();
         return CNF_ERR_UNSUPPORTED;
