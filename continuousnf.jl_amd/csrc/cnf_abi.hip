@@ -117,7 +117,11 @@ struct cnf_ctx {
     float *g_HS = nullptr, *g_TS = nullptr, *g_AB = nullptr, *g_PB = nullptr;
     float* d_park = nullptr;      // parked state of the two-launch headline pullback (adj3b_park_floats)
     size_t park_floats = 0;
-    float* g_sc = nullptr;        // scratch rows of the two-launch MFMA pullback (adj_mfma_scratch_floats), or null
+    float* d_sc = nullptr;        // scratch rows of the two-launch MFMA pullback (adj_mfma_scratch_floats)
+    size_t sc_floats = 0;
+    AdjStepArgs* d_steps = nullptr;      // ... and the arguments of the steps of its runs: device array and pinned staging
+    AdjStepArgs* h_steps = nullptr;
+    int steps_cap = 0;
     float* g_part = nullptr;      // GRAD_MAX_KSPLIT x n_params
     NetDesc nd_wave{};            // what the wave kernels see: nd, or a one-layer tanh network with an identity layer appended
     float* wg_traj = nullptr;     // k_solve_wave<GRAD>: z rows of u_n per accepted step, as the lanes hold them; + WV_GCAP step sizes
@@ -293,6 +297,9 @@ extern "C" cnf_status cnf_destroy(cnf_handle h) {
     if (h->d_PT) (void)hipFree(h->d_PT);
     if (h->d_adj_img) (void)hipFree(h->d_adj_img);
     if (h->d_park) (void)hipFree(h->d_park);
+    if (h->d_sc) (void)hipFree(h->d_sc);
+    if (h->d_steps) (void)hipFree(h->d_steps);
+    if (h->h_steps) (void)hipHostFree(h->h_steps);
     if (h->d_bimg) (void)hipFree(h->d_bimg);
     if (h->d_bstore) (void)hipFree(h->d_bstore);
     if (h->d_gt) (void)hipFree(h->d_gt);
@@ -1642,12 +1649,7 @@ static cnf_status ensure_grad_capacity(cnf_handle h, int B) {
     if (fsteps < 1) fsteps = 1;
     if (fsteps > 32) fsteps = 32;
     h->grad_fsteps = (int)fsteps;
-    const AdjMfmaLayout am = adj_mfma_layout(h->nd, g);
-    // scratch rows of the two-launch pullback: only batches that leave CUs idle take that form (launch_adj_mfma_step: at most
-    // five rounds of 16-sample workgroups for the six stages), and the headline shape has its own parked state (d_park)
-    const bool may_split = adj_mfma_supported(h->nd, am) && !(adj3b_supported(h->nd) && h->mfma.d_img3b) && cap <= (size_t)16 * 1024;
-    const size_t sc = may_split ? adj_mfma_scratch_floats(am, cap) : 0;
-    const size_t total = 5 * D * cap + 7 * n_in * cap + fsteps * per_step + sc +
+    const size_t total = 5 * D * cap + 7 * n_in * cap + fsteps * per_step +
                          ((size_t)GRAD_MAX_KSPLIT + 1) * h->n_params;
     HIPCHK(h, hipMalloc(&h->grad_arena, total * sizeof(float)));
     float* p = h->grad_arena;
@@ -1658,7 +1660,6 @@ static cnf_status ensure_grad_capacity(cnf_handle h, int B) {
     h->g_TS = p; p += fsteps * 6 * (size_t)g.sum_in * cap;
     h->g_AB = p; p += fsteps * 6 * (size_t)g.sum_out * cap;
     h->g_PB = p; p += fsteps * 6 * (size_t)g.sum_out * cap;
-    h->g_sc = sc ? p : nullptr; p += sc;
     h->g_part = p; p += (size_t)GRAD_MAX_KSPLIT * h->n_params;
     h->g_grad = p;
     h->grad_cap_B = cap;
@@ -1834,7 +1835,20 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
             if (ks > ksplit) ksplit = ks;
             HIPCHK(h, launch_wgrad(nd, gl, h->g_AB, h->g_PB, h->g_HS, h->g_TS, h->g_part, (int)h->n_params, 6 * cnt * B, ks, ch, st));
         }
-    } else
+    } else {
+    // (MFMA pullback: the steps of a run are gathered and launched together -- as two launches over the whole run where the batch
+    // leaves CUs idle, else one launch per step)
+    int run0 = 0;                                          // first entry of the current run in h_steps
+    if (adj_mfma && rec.n > h->steps_cap) {
+        HIPCHK(h, hipStreamSynchronize(st));
+        if (h->d_steps) { (void)hipFree(h->d_steps); h->d_steps = nullptr; }
+        if (h->h_steps) { (void)hipHostFree(h->h_steps); h->h_steps = nullptr; }
+        h->steps_cap = 0;
+        const int cap = rec.n + 32;
+        HIPCHK(h, hipMalloc(&h->d_steps, (size_t)cap * sizeof(AdjStepArgs)));
+        HIPCHK(h, hipHostMalloc(&h->h_steps, (size_t)cap * sizeof(AdjStepArgs)));
+        h->steps_cap = cap;
+    }
     for (int step = rec.n - 1; step >= 0; --step) {
         float* un;
         if ((s = traj_slot(h, step, &un)) != CNF_OK) return s;
@@ -1865,7 +1879,7 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
         if (adj_mfma) {        // the six stage pullbacks and the lambda update of this step in ONE launch
             S.first = 5; S.last = 0; S.B = B; S.lam_update = 1; S.lam_out = h->g_lam;
             for (int m = 0; m < 6; ++m) for (int d = 0; d < 5; ++d) S.kc[m][d] = m - 1 - d >= 0 ? A[m][m - 1 - d] : 0.f;
-            HIPCHK(h, launch_adj_mfma_step(nd, gl, am, h->d_adj_img, S, st, h->g_sc));
+            h->h_steps[rec.n - 1 - step] = S;
         } else {
             StageK ws{};
             ws.nk = 6;
@@ -1874,6 +1888,31 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
         }
         // Wbar += sum over the filed stage evaluations and their samples: one contraction with K = 6 filed B
         if (++filed == fsteps || step == 0) {
+            if (adj_mfma) {                                // the run's pullbacks
+                const int cnt = filed;
+                // (two launches per SUB-run of steps whose parked rows stay in the infinity cache -- measured at config 5's network:
+                // whole runs of 10-22 steps, 0.2-0.8 GB of rows, cost 2 % at B = 256 and 6 % at 2048 against step by step)
+                const size_t per_step = adj_mfma_scratch_floats(am, (size_t)B, 1);
+                int nsub = (int)std::max<size_t>(1, std::min<size_t>((size_t)cnt, ((size_t)48 << 20) / (per_step * sizeof(float))));
+                bool two = adj_mfma_run_split(nd, am, B, nsub);
+                if (two) {
+                    const size_t need = per_step * nsub;
+                    if (need > h->sc_floats) {
+                        HIPCHK(h, hipStreamSynchronize(st));
+                        if (h->d_sc) { (void)hipFree(h->d_sc); h->d_sc = nullptr; h->sc_floats = 0; }
+                        if (hipMalloc(&h->d_sc, need * sizeof(float)) == hipSuccess) h->sc_floats = need;
+                        else { (void)hipGetLastError(); two = false; }          // (no room for the parked rows: one launch per step)
+                    }
+                }
+                if (two) {
+                    HIPCHK(h, hipMemcpyAsync(h->d_steps + run0, h->h_steps + run0, (size_t)cnt * sizeof(AdjStepArgs), hipMemcpyHostToDevice, st));
+                    for (int j = 0; j < cnt; j += nsub)
+                        HIPCHK(h, launch_adj_mfma_run(nd, gl, am, h->d_adj_img, h->d_steps + run0 + j, std::min(nsub, cnt - j), B, h->d_sc, st));
+                } else {
+                    for (int j = 0; j < cnt; ++j) HIPCHK(h, launch_adj_mfma_step(nd, gl, am, h->d_adj_img, h->h_steps[run0 + j], st));
+                }
+                run0 += cnt;
+            }
             int ks, ch;
             grad_ksplit(nd, gl, 6 * filed * B, &ks, &ch);
             if (ks > ksplit) ksplit = ks;
@@ -1881,6 +1920,7 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
                                    6 * filed * B, ks, ch, st));
             filed = 0;
         }
+    }
     }
     HIPCHK(h, launch_grad_reduce(h->g_part, grad, (int)h->n_params, ksplit, st));
     h->grad_last_B = B;                                    // (g_lam now holds d loss / d u(t0): cnf_grad_x)

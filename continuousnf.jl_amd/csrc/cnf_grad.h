@@ -90,11 +90,16 @@ AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g);
 bool adj_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m);
 hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* P,
                                   float* img, hipStream_t s);
-// scratch: 6 B m.SR floats (adj_mfma_scratch_floats) or null; with it, batches that leave CUs idle run a step as two launches
-// (sweeps 1-3 of all stages side by side, then the hbar chains in turn: k_adj_mfma<PHASE 1 / 2>); CNF_ADJ_SPLIT=0: never
+// one launch per step (the six stage pullbacks and the lambda update)
 hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
-                                const AdjStepArgs& S, hipStream_t s, float* scratch = nullptr);
-size_t adj_mfma_scratch_floats(const AdjMfmaLayout& m, size_t B);
+                                const AdjStepArgs& S, hipStream_t s);
+// ... or a RUN of whole steps (first = 5, last = 0, lam_update) as two launches where the batch leaves CUs idle: sweeps 1-3 of
+// all stages of all steps side by side, then the hbar chains in turn (k_adj_mfma_run<PHASE 1 / 2>).  d_steps: the steps' arguments
+// in DEVICE memory, last step first; scratch: adj_mfma_scratch_floats(m, B, nsteps) floats.
+bool adj_mfma_run_split(const NetDesc& nd, const AdjMfmaLayout& m, int B, int nsteps);
+hipError_t launch_adj_mfma_run(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                               const AdjStepArgs* d_steps, int nsteps, int B, float* scratch, hipStream_t s);
+size_t adj_mfma_scratch_floats(const AdjMfmaLayout& m, size_t B, int nsteps);
 // the two-launch forms of the pullback kernels (k_adj_mfma, k_adj3b): -1 where it pays (default; CNF_ADJ_SPLIT=0|1 overrides at
 // start-up), 0 never, 1 wherever the parked state fits -- process-wide, for A/B runs and the parity tests (cnf_debug_adj_split)
 int adj_split_mode();

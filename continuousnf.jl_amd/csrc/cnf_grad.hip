@@ -1189,9 +1189,11 @@ extern "C" int cnf_debug_adj_stamps(unsigned long long* out, int n) {
 //            tbar and zdot of every sample parked in the scratch rows SC [stage][B][m.SR];
 //   PHASE 2, grid (tiles): per stage the scratch rows back into LDS, abar_L = ahat sigma'_L + eps q_L, the hbar chain (AB, zbar),
 //            then lambda <- lambda + sum zbar -- a quarter of the sequential work.
+// The two-launch form takes a RUN of steps: their AdjStepArgs in a device array (last step first), scratch slot 6 j + stage for
+// step j; PHASE 1 grid (tiles, 6 steps), PHASE 2 grid (tiles) walks the steps in order (k_adj_mfma_run below).
 template <bool ALL_TANH, int PHASE>
-__global__ void __launch_bounds__(AM_THREADS)
-k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, AdjStepArgs S, float* __restrict__ SC) {
+__device__ __forceinline__ void adj_mfma_body(const NetDesc& nd, const GradLayout& gl, const AdjMfmaLayout& m, const float* __restrict__ img,
+                                              const AdjStepArgs& S, float* __restrict__ SC, int ystage) {
     extern __shared__ float lds[];
     const int PS = m.PS, NL = m.L;
     float* red = lds + (size_t)AM_NS * PS;
@@ -1204,7 +1206,7 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
     const bool ev = eb < S.B;
     const int oL = m.o_off[NL - 1];
 
-  const int stg_hi = PHASE == 1 ? S.first - (int)blockIdx.y : S.first, stg_lo = PHASE == 1 ? stg_hi : S.last;
+  const int stg_hi = PHASE == 1 ? S.first - ystage : S.first, stg_lo = PHASE == 1 ? stg_hi : S.last;
   for (int stg = stg_hi; stg >= stg_lo; --stg) {       // the stages of one Runge-Kutta step, last to first
     const AdjArgs& a = S.st[stg];
     float* scrow = SC + ((size_t)stg * S.B + eb) * m.SR;  // PHASE 1 / 2: this thread's sample in the scratch rows (if ev)
@@ -1439,7 +1441,29 @@ k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__
             S.lam_out[(size_t)eb * n_in + r] = acc;
         }
     }
+    if (PHASE == 2) {                      // (a run of steps: the next step's kbar_z reads this lambda)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        am_barrier();
+    }
   }
+}
+
+template <bool ALL_TANH>
+__global__ void __launch_bounds__(AM_THREADS)
+k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, AdjStepArgs S) {
+    adj_mfma_body<ALL_TANH, 0>(nd, gl, m, img, S, nullptr, 0);
+}
+
+template <bool ALL_TANH, int PHASE>
+__global__ void __launch_bounds__(AM_THREADS)
+k_adj_mfma_run(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, const AdjStepArgs* __restrict__ SA, int nsteps,
+               float* __restrict__ SC) {
+    if (PHASE == 1) {
+        const int j = blockIdx.y / 6;
+        adj_mfma_body<ALL_TANH, 1>(nd, gl, m, img, SA[j], SC + (size_t)6 * j * SA[j].B * m.SR, blockIdx.y % 6);
+    } else {
+        for (int j = 0; j < nsteps; ++j) adj_mfma_body<ALL_TANH, 2>(nd, gl, m, img, SA[j], SC + (size_t)6 * j * SA[j].B * m.SR, 0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1847,7 +1871,7 @@ hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const 
 }
 
 hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
-                                const AdjStepArgs& S, hipStream_t s, float* scratch) {
+                                const AdjStepArgs& S, hipStream_t s) {
     const size_t lds = adj_mfma_lds_bytes(m);
     bool all_tanh = true;
     for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
@@ -1862,42 +1886,59 @@ hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const Ad
         else hipLaunchKernelGGL(k_adj3<false>, grid3, dim3(AM_THREADS), lds3, s, nd, g, m, img, S);
         return hipGetLastError();
     }
-    const int tiles = (S.B + AM_NS - 1) / AM_NS, nstg = S.first - S.last + 1;
-    // Two launches when that is less sequential work: the stage-parallel phase costs ~0.7 of a stage per round of CUs workgroups
-    // (1 per CU: 156 KB of LDS), the sequential phase ~0.3 of a stage per stage (phase stamps at config 5).
+    const int tiles = (S.B + AM_NS - 1) / AM_NS;
+    const void* fn = all_tanh ? (const void*)k_adj_mfma<true> : (const void*)k_adj_mfma<false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (all_tanh) hipLaunchKernelGGL(k_adj_mfma<true>, dim3(tiles), dim3(AM_THREADS), lds, s, nd, g, m, img, S);
+    else hipLaunchKernelGGL(k_adj_mfma<false>, dim3(tiles), dim3(AM_THREADS), lds, s, nd, g, m, img, S);
+    return hipGetLastError();
+}
+
+// Two launches for a run of whole steps when that is less sequential work: the stage-parallel launch costs ~0.7 of a stage per
+// round of CUs workgroups (1 per CU: 156 KB of LDS), the sequential one ~0.3 of a stage per stage (phase stamps at config 5,
+// DESIGN 4.4).
+bool adj_mfma_run_split(const NetDesc& nd, const AdjMfmaLayout& m, int B, int nsteps) {
     const int mode = adj_split_mode();
-    bool split = false;
-    if (scratch && mode != 0 && nstg > 1) {
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t pr;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
-            if (cus < 1) cus = 1;
-        }
-        const int rounds = (nstg * tiles + cus - 1) / cus;
-        split = mode == 1 || 0.7 * rounds + 0.3 * nstg < 0.95 * nstg;
+    static const bool generic_only = [] { const char* e = getenv("CNF_ADJ_GENERIC"); return e && e[0] == '1'; }();
+    if (mode == 0 || nsteps < 1 || B < 1 || (adj3_shape(nd, m) && !generic_only)) return false;      // (k_adj3 has one form)
+    if (mode == 1) return true;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+        if (cus < 1) cus = 1;
     }
+    const long nst = 6L * nsteps, rounds = (nst * ((B + AM_NS - 1) / AM_NS) + cus - 1) / cus;
+    return 0.7 * rounds + 0.3 * nst < 0.95 * nst;
+}
+
+hipError_t launch_adj_mfma_run(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
+                               const AdjStepArgs* d_steps, int nsteps, int B, float* scratch, hipStream_t s) {
+    if (!d_steps || !scratch || nsteps < 1 || 6 * nsteps > 65535) return hipErrorInvalidValue;
+    const size_t lds = adj_mfma_lds_bytes(m);
+    bool all_tanh = true;
+    for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
+    const int tiles = (B + AM_NS - 1) / AM_NS;
     auto go = [&](auto tanh_c, auto phase_c, dim3 grid) -> hipError_t {
         constexpr bool T = decltype(tanh_c)::value;
         constexpr int PH = decltype(phase_c)::value;
-        hipError_t e = hipFuncSetAttribute((const void*)k_adj_mfma<T, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_adj_mfma_run<T, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_adj_mfma<T, PH>), grid, dim3(AM_THREADS), lds, s, nd, g, m, img, S, scratch);
+        hipLaunchKernelGGL((k_adj_mfma_run<T, PH>), grid, dim3(AM_THREADS), lds, s, nd, g, m, img, d_steps, nsteps, scratch);
         return hipGetLastError();
     };
     using T1 = std::integral_constant<bool, true>;
     using T0 = std::integral_constant<bool, false>;
-    using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     using P2 = std::integral_constant<int, 2>;
-    if (!split) return all_tanh ? go(T1{}, P0{}, dim3(tiles)) : go(T0{}, P0{}, dim3(tiles));
-    hipError_t e = all_tanh ? go(T1{}, P1{}, dim3(tiles, nstg)) : go(T0{}, P1{}, dim3(tiles, nstg));
+    hipError_t e = all_tanh ? go(T1{}, P1{}, dim3(tiles, 6 * nsteps)) : go(T0{}, P1{}, dim3(tiles, 6 * nsteps));
     if (e != hipSuccess) return e;
     return all_tanh ? go(T1{}, P2{}, dim3(tiles)) : go(T0{}, P2{}, dim3(tiles));
 }
 
-size_t adj_mfma_scratch_floats(const AdjMfmaLayout& m, size_t B) { return 6 * B * (size_t)m.SR; }
+size_t adj_mfma_scratch_floats(const AdjMfmaLayout& m, size_t B, int nsteps) { return (size_t)6 * nsteps * B * (size_t)m.SR; }
 
 static std::atomic<int> g_adj_split{[] { const char* e = getenv("CNF_ADJ_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }()};
 int adj_split_mode() { return g_adj_split.load(std::memory_order_relaxed); }
