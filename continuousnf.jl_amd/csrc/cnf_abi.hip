@@ -1907,7 +1907,8 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
                 if (two) {
                     HIPCHK(h, hipMemcpyAsync(h->d_steps + run0, h->h_steps + run0, (size_t)cnt * sizeof(AdjStepArgs), hipMemcpyHostToDevice, st));
                     for (int j = 0; j < cnt; j += nsub)
-                        HIPCHK(h, launch_adj_mfma_run(nd, gl, am, h->d_adj_img, h->d_steps + run0 + j, std::min(nsub, cnt - j), B, h->d_sc, st));
+                        HIPCHK(h, launch_adj_mfma_run(nd, gl, am, h->d_adj_img, h->d_steps + run0 + j, h->h_steps + run0 + j, std::min(nsub, cnt - j),
+                                                      B, h->d_sc, st));
                 } else {
                     for (int j = 0; j < cnt; ++j) HIPCHK(h, launch_adj_mfma_step(nd, gl, am, h->d_adj_img, h->h_steps[run0 + j], st));
                 }

@@ -97,8 +97,9 @@ hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const Ad
 // all stages of all steps side by side, then the hbar chains in turn (k_adj_mfma_run<PHASE 1 / 2>).  d_steps: the steps' arguments
 // in DEVICE memory, last step first; scratch: adj_mfma_scratch_floats(m, B, nsteps) floats.
 bool adj_mfma_run_split(const NetDesc& nd, const AdjMfmaLayout& m, int B, int nsteps);
+// (h_steps: the same arguments in host memory -- a run of one step passes them by value)
 hipError_t launch_adj_mfma_run(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* img,
-                               const AdjStepArgs* d_steps, int nsteps, int B, float* scratch, hipStream_t s);
+                               const AdjStepArgs* d_steps, const AdjStepArgs* h_steps, int nsteps, int B, float* scratch, hipStream_t s);
 size_t adj_mfma_scratch_floats(const AdjMfmaLayout& m, size_t B, int nsteps);
 // the two-launch forms of the pullback kernels (k_adj_mfma, k_adj3b): -1 where it pays (default; CNF_ADJ_SPLIT=0|1 overrides at
 // start-up), 0 never, 1 wherever the parked state fits -- process-wide, for A/B runs and the parity tests (cnf_debug_adj_split)
