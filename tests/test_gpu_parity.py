@@ -1564,6 +1564,31 @@ def test_loss_grad_one_launch_and_two_launch_pullbacks_agree(which):
         assert np.abs(g0 - g1).max() <= 2e-6 * (np.abs(g0).max() + 1e-30), (which, tag, np.abs(g0 - g1).max(), np.abs(g0).max())
 
 
+@pytest.mark.parametrize("which", ["headline", "three-layer"])
+def test_loss_grad_more_steps_than_one_run_of_the_pullback(which):
+    """40 fixed steps: more than the 32 steps one launch (pair) of the pullback kernels takes -- two runs, each with its own
+    contraction, in both forms of the pullback (k_adj3b at the headline shape, k_adj_mfma_run elsewhere)."""
+    l = _lib.lib()
+    if which == "headline":
+        cfg = O.Cfg(O.Net((32, 128, 128, 32), (O.ACT_TANH,) * 3), 32, 0, 0.01, 0.01)
+        B, scale = 40, 0.1
+    else:
+        cfg = O.Cfg(O.Net((12, 64, 48, 12), (O.ACT_TANH, O.ACT_TANH, O.ACT_TANH)), 8, 4, 0.01, 0.01, 0.01)
+        B, scale = 20, 0.3
+    cfg.tspan = (0.0, 0.5)
+    was = l.cnf_set_grad_split(-1)
+    try:
+        for mode in (0, 1):
+            l.cnf_set_grad_split(mode)
+            val, grad, rval, rgrad, st, _ = _grad_case(cfg, B, 880, "mfma", dict(adaptive=False, dt=0.5 / 40),
+                                                       dict(adaptive=False, dt=0.5 / 40), scale=scale)
+            assert st["naccept"] == 40
+            assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval)), (which, mode)
+            _assert_grad(grad, rgrad, f"{which} 40 steps split={mode}")
+    finally:
+        l.cnf_set_grad_split(was)
+
+
 def test_streamed_weights_run_the_fused_step_kernel_on_16_sample_tiles():
     """Config 5's network (weights streamed from L2) at ragged batches that leave the last 16-sample workgroup
     partly empty: kernel = auto and kernel = mfma are the same fused step kernel (one launch per step, 16-sample
