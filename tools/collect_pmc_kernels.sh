@@ -20,11 +20,20 @@ run_set() {       # name, then the program and its arguments
     timeout -k 10 150 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/$name/sq -- "$@" > $OUT/$name.sq.log 2>&1 || return 1
     echo "$name pmc done"
 }
+if [ "${2:-all}" = grad ]; then        # only the gradient programs (the other directories of the tag stay as they are)
+run_set cfg3_grad python3 tools/prof_grad.py 3 8192 4 &&
+run_set cfg3_b32_grad python3 tools/prof_grad.py 3 32 8 &&
+run_set cfg5_grad python3 tools/prof_grad.py 5 2048 4
+echo "grad rc=$?"
+exit 0
+fi
 run_set cfg2_train python3 tools/prof_solve.py 2 train 16 &&
 run_set cfg1_train python3 tools/prof_solve.py 1 train 16 &&
 run_set cfg5_train python3 tools/prof_solve.py 5 train 16 &&
 run_set cfg5_test python3 tools/prof_solve.py 5 test 16 &&
 run_set cfg5_jvp python3 tools/prof_solve.py 5 jvp 16 &&
 run_set cfg3_test python3 tools/prof_solve.py 3 test 6 &&
-run_set cfg3_grad python3 tools/prof_grad.py 3 8192 4
+run_set cfg3_grad python3 tools/prof_grad.py 3 8192 4 &&
+run_set cfg3_b32_grad python3 tools/prof_grad.py 3 32 8 &&
+run_set cfg5_grad python3 tools/prof_grad.py 5 2048 4
 echo "all rc=$?"

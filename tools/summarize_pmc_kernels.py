@@ -59,7 +59,7 @@ for prog in sorted(os.listdir(SRC)):
     info = line_of(prog)
     # the kernels of weight: everything above 8 % of the program's GPU time (the gradient has two)
     for kname, calls, avg_us, pct in ks:
-        if pct < 8.0:
+        if pct < 8.0 and not (prog.endswith("_grad") and kname.startswith("k_adj")):      # (the pullback's parallel launch is short)
             continue
         c = {}
         for sub in ("fetch", "write", "sq"):
@@ -90,14 +90,28 @@ for prog in sorted(os.listdir(SRC)):
                                                        "contraction; cnf_rhs_work prices the reference's n_in tangent sweeps, which the kernel does not execute",
                                                "flops_per_launch": ex, "achieved_TFLOPs": round(ex / (avg_us * 1e-6) / 1e12, 2),
                                                "frac_of_split_bf16_ceiling_416.7": round(ex / (avg_us * 1e-6) / (2500e12 / 6), 3)}
-        elif prog.endswith("_grad") and kname.startswith(("k_adj3", "k_wgrad")):
-            B, M, P = 8192, 32 * 128 + 128 * 128 + 128 * 32, 32 * 128 + 128 * 128 + 128 * 32 + 288
-            if kname.startswith("k_adj3"):
-                fl = 6 * B * 8.0 * M                      # six stage pullbacks per launch, four sweeps of 2M each
-                rec["workload"] = "config 3 gradient: one accepted step per launch (six stage pullbacks), B = 8192"
+        elif prog.endswith("_grad") and kname.startswith(("k_adj", "k_wgrad")):
+            # the gradient programs (tools/prof_grad.py cfg B): "cfgN B=...: ... steps S+R" in the log; the pullback model of DESIGN 4.4:
+            # a stage pullback is four sweeps of 2M flops per sample (three in the stage-parallel launch, one in the sequential one)
+            import re
+            txt = open(os.path.join(SRC, prog + ".log")).read()
+            mm = re.search(r"cfg(\d) B=(\d+):.*steps (\d+)\+", txt)
+            cfgn, B, steps = int(mm.group(1)), int(mm.group(2)), int(mm.group(3))
+            dims = {3: (32, 128, 128, 32), 5: (128, 384, 128)}[cfgn]
+            M = sum(x * y for x, y in zip(dims[:-1], dims[1:]))
+            P = M + sum(dims[1:])
+            # launches of this kernel per gradient = calls / gradients; prof_grad runs loss_and_grad (reps + 1) times
+            grads = {"cfg3_grad": 5, "cfg3_b32_grad": 9, "cfg5_grad": 5}.get(prog, 5)
+            lpg = calls / grads
+            stage_samples = steps * 6 * B / lpg               # (stage, sample) pairs one launch covers
+            if kname.startswith("k_wgrad"):
+                fl = stage_samples * 4.0 * P
+                rec["workload"] = f"config {cfgn}'s network gradient, B = {B}: weight-gradient contraction, {lpg:.1f} launches per gradient"
             else:
-                fl = 4 * 6 * B * 4.0 * P                  # the contraction of four steps' factor arrays per launch
-                rec["workload"] = "config 3 gradient: weight-gradient contraction of four steps' factor arrays per launch, B = 8192"
+                sweeps = 3 if ("<1>" in kname or ", 1>" in kname) else (1 if ("<2>" in kname or ", 2>" in kname) else 4)
+                fl = stage_samples * sweeps * 2.0 * M
+                form = {4: "one launch: all four sweeps", 3: "stage-parallel launch: sweeps 1-3", 1: "sequential launch: the hbar chain"}[sweeps]
+                rec["workload"] = f"config {cfgn}'s network gradient, B = {B}, {steps} steps: {form}, {lpg:.1f} launches per gradient"
             rec.update({"algorithmic_flops_per_launch": fl, "achieved_TFLOPs": round(fl / (avg_us * 1e-6) / 1e12, 2),
                         "frac_of_fp32_peak": round(fl / (avg_us * 1e-6) / PEAK_F32, 3)})
             if "hbm_bytes_per_launch" in rec:
