@@ -226,6 +226,40 @@ def reference_suite(samples=100):
     return res
 
 
+def gradient_leg(reps=5):
+    """loss_and_grad (row f3, src/exts/mlj_ext/core_icnf.jl:59-73) on the headline network beside the forward loss, outside the
+    timed region: the reference's training batch (32) and the BASELINE batch; milliseconds per call (tools/prof_grad.py prints
+    the table over more shapes).  Informational: the metric of this bench is the forward path's."""
+    import time
+    import torch
+    import continuousnf.jl_amd as cnf
+    from continuousnf.jl_amd import configs
+    res = {"unit": "ms per call", "network": "32-128-128-32 (config 3), adaptive Tsit5 at the README tolerances", "reps": reps}
+    try:
+        wl = configs.BASELINE[3]
+        for B in (32, 8192):
+            flat = torch.from_numpy(configs.glorot_params(wl.dims, 3, 0.05)).cuda()
+            xs_h, eps_h = configs.synthetic_inputs(wl, B, 3)
+            xs, eps = torch.from_numpy(xs_h).cuda(), torch.from_numpy(eps_h).cuda()
+            ic = configs.build(wl, sol_kwargs=configs.README_TOLERANCES)
+            row = {}
+            for name, fn in (("loss", lambda: cnf.loss(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)),
+                             ("loss_and_grad", lambda: cnf.loss_and_grad(ic, cnf.TrainMode(), xs, flat, {}, eps=eps))):
+                fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                row[name] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+            row["accepted_steps"] = int(ic.last_stats["naccept"])
+            res[f"B={B}"] = row
+            ic.close()
+    except Exception as e:            # (the headline line must not depend on this leg)
+        res["error"] = repr(e)
+    return res
+
+
 def fp32_child_leg(args):
     """The headline steps on the fp32-MFMA kernels (CNF_STEP_FP32=1: k_step3, streamed step launches), in a child process
     started after the timed region.  Returns the child's figures, with the fp32 roofline fraction they amount to."""
@@ -596,6 +630,7 @@ def run_rank(args):
                                             "step count differs by an attempt between arithmetics (profiles/round3_step_trace.md)"}
         if world == 1 and not args.no_reference_suite:
             out["reference_suite"] = reference_suite()
+            out["gradient"] = gradient_leg()
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
