@@ -500,7 +500,9 @@ k_adj3b(NetDesc nd, GradLayout gl, const char* __restrict__ imgb, Adj3bSteps M) 
         //      is requested and travels under this stage's four intervals; abar_3 = (kbar_z h + c_E zdot / |zdot|) s'_3 + eps q_3
         //      -> G3S.  (Measured: abar_3 formed by waves 4-7 in the I5' that produced the zbar in front of it, into alternating
         //      images -- three intervals per stage instead of four -- is SLOWER, 1.16 against 1.12 ms at B = 32: that interval's
-        //      chain, product -> zbar -> bookkeeping -> abar_3 -> split store, grows by more than the interval saved.) ----
+        //      chain, product -> zbar -> bookkeeping -> abar_3 -> split store, grows by more than the interval saved.  Also slower,
+        //      1.19 ms: every wave forming the B operand of the W3^T product itself in registers -- ahat's owner rows from LDS, its
+        //      own copy of the parked rows, eight splits per lane -- instead of this interval.) ----
         H1r[0] = pfr[0]; H1r[1] = pfr[1]; H2r[0] = pfr[2]; H2r[1] = pfr[3];
         TB1[0] = pfr[4]; TB1[1] = pfr[5]; TB2[0] = pfr[6]; TB2[1] = pfr[7];
         const f32x4 d13 = pfo[0], eq3 = pfo[1], zt = pfo[2];
