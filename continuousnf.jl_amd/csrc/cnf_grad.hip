@@ -1109,7 +1109,7 @@ AdjMfmaLayout adj_mfma_layout(const NetDesc& nd, const GradLayout& g) {
     m.E = p; p += m.nin_p;
     m.AH = m.TB + m.o_off[m.L - 1];       // ahat reuses the tbar_L slot (free after the first reverse GEMM)
     m.PS = ((p + 15) & ~15) + 8;          // stride = 8 mod 16 floats: conflict-free b128 columns
-    m.SR = 3 * oo + m.nin_p + 16;         // sigma', q, tbar | zdot | |zdot|^2 (padded to a 64-byte row)
+    m.SR = 3 * oo + 2 * m.nin_p + 16;     // sigma', q, tbar | zdot | |zdot|^2 (padded to a 64-byte row) | omega (JVP compute mode)
     m.vec4 = (g.sum_in & 3) == 0;         // rows of HS/TS start 16-byte aligned ...
     for (int l = 0; l < m.L; ++l) if (g.in_off[l] & 3) m.vec4 = 0;   // ... and so does every layer's block
     m.vec4o = (g.sum_out & 3) == 0;
@@ -1122,7 +1122,7 @@ static size_t adj_mfma_lds_bytes(const AdjMfmaLayout& m) {
 }
 
 bool adj_mfma_supported(const NetDesc& nd, const AdjMfmaLayout& m) {
-    return !nd.jvp && nd.dims[nd.n_layers] == nd.n_in && adj_mfma_lds_bytes(m) <= 160 * 1024;
+    return nd.dims[nd.n_layers] == nd.n_in && adj_mfma_lds_bytes(m) <= 160 * 1024;      // (both compute modes: k_adj_mfma<.., JM>)
 }
 
 __global__ void k_pack_adj_images(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ P,
@@ -1191,7 +1191,12 @@ extern "C" int cnf_debug_adj_stamps(unsigned long long* out, int n) {
 //            then lambda <- lambda + sum zbar -- a quarter of the sequential work.
 // The two-launch form takes a RUN of steps: their AdjStepArgs in a device array (last step first), scratch slot 6 j + stage for
 // step j; PHASE 1 grid (tiles, 6 steps), PHASE 2 grid (tiles) walks the steps in order (k_adj_mfma_run below).
-template <bool ALL_TANH, int PHASE>
+// JM: the JVP compute mode (src/icnf.jl:384-456; ldot = -eps . J eps, ndot = |J eps|): sweep 2 is the TANGENT chain from
+// tau_0 = eps (q_l = s''_l .* (W_l tau_{l-1}), tau_l = s'_l .* (W_l tau_{l-1})), then omega = -c_l eps + c_n J eps / |J eps| takes
+// eps's place in E and sweep 3 is the tbar chain from it, layers L .. 2 (tbar_0 is nobody's); the hbar chain and the parked rows are
+// those of the VJP mode with tbar_L = omega where that has eps.  Factor rows: HS = h_{l-1}, TS = tau_{l-1}, AB = abar_l,
+// PB = s'_l .* tbar_l, so the contraction kernels do not know the difference.
+template <bool ALL_TANH, int PHASE, bool JM = false>
 __device__ __forceinline__ void adj_mfma_body(const NetDesc& nd, const GradLayout& gl, const AdjMfmaLayout& m, const float* __restrict__ img,
                                               const AdjStepArgs& S, float* __restrict__ SC, int ystage) {
     extern __shared__ float lds[];
@@ -1226,6 +1231,127 @@ __device__ __forceinline__ void adj_mfma_body(const NetDesc& nd, const GradLayou
     am_barrier();
     AM_STAMP(1);
 
+   if (JM) {
+    // ======== JVP compute mode ========
+    // ---- sweep 1: forward ----
+    for (int l = 0; l < NL; ++l) {
+        const int out = nd.dims[l + 1], act = nd.acts[l];
+        const int oo = m.o_off[l];
+        const bool last = l + 1 == NL;
+        const int hs_off = last ? -1 : gl.in_off[l + 1];
+        am_gemm(img + m.ff_off[l], m.dp[l + 1], m.dp[l], lds + cur, PS, pf,
+                img + (last ? m.ff_off[0] : m.ff_off[l + 1]), last ? m.dp[1] : m.dp[l + 2], last ? m.dp[0] : m.dp[l + 1], img + m.b_off[l],
+                [&](int r0, int s, f32x4 acc, f32x4 bias) {
+            f32x4 h, d1, d2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float hh, dd1, dd2;
+                if (ALL_TANH) { hh = cnf_tanh(acc[j] + bias[j]); dd1 = fmaf(-hh, hh, 1.0f); dd2 = -2.0f * hh * dd1; }
+                else cnf_act2(act, acc[j] + bias[j], hh, dd1, dd2);
+                const bool live = r0 + j < out;            // padded rows stay exactly zero
+                h[j] = live ? hh : 0.f; d1[j] = live ? dd1 : 0.f; d2[j] = live ? dd2 : 0.f;
+            }
+            float* S = lds + s * PS;
+            *reinterpret_cast<f32x4*>(S + nxt + r0) = h;
+            *reinterpret_cast<f32x4*>(S + m.D1 + oo + r0) = d1;
+            *reinterpret_cast<f32x4*>(S + m.D2 + oo + r0) = d2;
+            if (!last && b0 + s < a.B) am_store4(a.HS + (size_t)(b0 + s) * gl.sum_in + hs_off + r0, h, r0, out, m.vec4);
+        });
+        am_barrier();
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+    {   // zdot sits in S[cur]: ahat = kbar_z + c_E zdot/|zdot| -> AH (PHASE 1: zdot and |zdot|^2 -> scratch instead)
+        const int zd = cur;
+        float nz = 0.f;
+        if (nd.norm_z) nz = am_colnorm2(lds + zd, PS, n_in, red);
+        if (PHASE == 1) {
+            for (int r = ec; r < m.nin_p; r += AM_EC) if (ev) scrow[3 * m.sum_o + r] = lds[es * PS + zd + r];
+            if (ev && ec == 0) scrow[3 * m.sum_o + m.nin_p] = nz;
+        } else {
+            const float inv = (nd.norm_z && nz > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz) : 0.f;
+            for (int rb = ec; rb < m.nin_p; rb += 4 * AM_EC) {
+                float kb[4];
+                am_kbar4(a, ev, eb, n_in, rb, kb);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = rb + i * AM_EC;
+                    if (r < m.nin_p) lds[es * PS + m.AH + r] = (ev && r < n_in) ? fmaf(inv, lds[es * PS + zd + r], kb[i] * a.hstep) : 0.f;
+                }
+            }
+        }
+        // tau_0 = [eps; 0] -> the other buffer, TS
+        for (int r = ec; r < m.dp[0]; r += AM_EC) {
+            const float v = r < n_in ? lds[es * PS + m.E + r] : 0.f;
+            lds[es * PS + nxt + r] = v;
+            if (ev && r < in0) a.TS[(size_t)eb * gl.sum_in + r] = v;
+        }
+        am_barrier();                                      // (zdot's buffer is the tangent sweep's first target)
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+    // ---- sweep 2: the tangent chain ----
+    for (int l = 0; l < NL; ++l) {
+        const int out = nd.dims[l + 1], oo = m.o_off[l];
+        const bool last = l + 1 == NL;
+        const int ts_off = last ? -1 : gl.in_off[l + 1];
+        am_gemm(img + m.ff_off[l], m.dp[l + 1], m.dp[l], lds + cur, PS, pf,
+                img + (last ? m.fr_off[NL - 1] : m.ff_off[l + 1]), last ? m.dp[NL - 1] : m.dp[l + 2], last ? m.dp[NL] : m.dp[l + 1], nullptr,
+                [&](int r0, int s, f32x4 acc, f32x4) {
+            float* S = lds + s * PS;
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(S + m.D1 + oo + r0);
+            *reinterpret_cast<f32x4*>(S + m.D2 + oo + r0) = *reinterpret_cast<const f32x4*>(S + m.D2 + oo + r0) * acc;   // q_l
+            const f32x4 t = d1 * acc;
+            *reinterpret_cast<f32x4*>(S + nxt + r0) = t;
+            if (!last && b0 + s < a.B) am_store4(a.TS + (size_t)(b0 + s) * gl.sum_in + ts_off + r0, t, r0, out, m.vec4);
+        });
+        am_barrier();
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+    {   // J eps in S[cur]: omega = -c_l eps + c_n J eps / |J eps| -> E (over eps); pbar_L = s'_L .* omega -> S[nxt], PB
+        float nj = 0.f;
+        if (nd.norm_j) nj = am_colnorm2(lds + cur, PS, n_in, red);
+        const float inv = (nd.norm_j && nj > 0.f) ? a.c_n * __builtin_amdgcn_rsqf(nj) : 0.f;
+        for (int r = ec; r < m.dp[NL]; r += AM_EC) {
+            float* Sr = lds + es * PS;
+            const float om = r < n_in ? fmaf(inv, Sr[cur + r], -a.c_l * Sr[m.E + r]) : 0.f;
+            const float pb = om * Sr[m.D1 + oL + r];
+            if (r < m.nin_p) Sr[m.E + r] = om;
+            Sr[nxt + r] = pb;
+            if (ev && r < n_in) a.PB[(size_t)eb * gl.sum_out + gl.out_off[NL - 1] + r] = pb;
+        }
+        am_barrier();
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+    // ---- sweep 3: the tbar chain, layers L .. 2: layer l's product turns pbar_l into tbar_{l-1} ----
+    for (int l = NL - 1; l >= 1; --l) {
+        const int oprev = m.o_off[l - 1], outp = nd.dims[l], gprev = gl.out_off[l - 1];
+        am_gemm(img + m.fr_off[l], m.dp[l], m.dp[l + 1], lds + cur, PS, pf,
+                img + (l > 1 ? m.fr_off[l - 1] : m.fr_off[NL - 1]), l > 1 ? m.dp[l - 1] : m.dp[NL - 1], l > 1 ? m.dp[l] : m.dp[NL], nullptr,
+                [&](int r0, int s, f32x4 acc, f32x4) {
+            float* S = lds + s * PS;
+            *reinterpret_cast<f32x4*>(S + m.TB + oprev + r0) = acc;
+            const f32x4 pb = acc * *reinterpret_cast<const f32x4*>(S + m.D1 + oprev + r0);
+            *reinterpret_cast<f32x4*>(S + nxt + r0) = pb;
+            if (b0 + s < a.B) am_store4(a.PB + (size_t)(b0 + s) * gl.sum_out + gprev + r0, pb, r0, outp, m.vec4o);
+        });
+        am_barrier();
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+    if (PHASE == 1) {                                       // sigma', q, tbar and omega of this stage -> scratch
+        for (int r = 4 * ec; r < 3 * m.sum_o; r += 4 * AM_EC)
+            if (ev) *reinterpret_cast<f32x4*>(scrow + r) = *reinterpret_cast<const f32x4*>(lds + es * PS + m.D1 + r);
+        for (int r = ec; r < m.nin_p; r += AM_EC) if (ev) scrow[3 * m.sum_o + m.nin_p + 16 + r] = lds[es * PS + m.E + r];
+        break;
+    }
+    // abar_L = ahat s'_L + omega q_L -> S[nxt], AB
+    for (int r = ec; r < m.dp[NL]; r += AM_EC) {
+        float* Sr = lds + es * PS;
+        const float ab = r < m.nin_p ? fmaf(Sr[m.AH + r], Sr[m.D1 + oL + r], Sr[m.E + r] * Sr[m.D2 + oL + r]) : 0.f;
+        Sr[nxt + r] = ab;
+        if (ev && r < n_in) a.AB[(size_t)eb * gl.sum_out + gl.out_off[NL - 1] + r] = ab;
+    }
+    am_barrier();
+    { const int t_ = cur; cur = nxt; nxt = t_; }
+   } else {
     // ---- sweep 1: forward.  The last layer's epilogue also forms pbar_L = eps .* sigma'_L (the first
     //      operand of the tbar chain, tbar_L = omega = eps), parked in the tbar_L slot of TB ------------
     for (int l = 0; l < NL; ++l) {
@@ -1366,6 +1492,7 @@ __device__ __forceinline__ void adj_mfma_body(const NetDesc& nd, const GradLayou
             if (ev) *reinterpret_cast<f32x4*>(scrow + r) = *reinterpret_cast<const f32x4*>(lds + es * PS + m.D1 + r);
         break;
     }
+   }
    } else {
     // ---- PHASE 2: the scratch rows back into LDS (sigma', q, tbar: one contiguous block of the sample row; zdot -> S0), eps -> E;
     //      abar_L = ahat sigma'_L + eps q_L -> S1 and AB, elementwise (ahat never leaves the registers) ----
@@ -1380,7 +1507,8 @@ __device__ __forceinline__ void adj_mfma_body(const NetDesc& nd, const GradLayou
         *reinterpret_cast<f32x4*>(lds + es * PS + m.D1 + r) = ev ? *reinterpret_cast<const f32x4*>(scrow + r) : z4;
     for (int r = ec; r < m.nin_p; r += AM_EC) {
         lds[es * PS + m.S0 + r] = ev ? scrow[3 * m.sum_o + r] : 0.f;
-        lds[es * PS + m.E + r] = (ev && r < n_in) ? a.eps[(size_t)eb * n_in + r] : 0.f;
+        lds[es * PS + m.E + r] = JM ? (ev ? scrow[3 * m.sum_o + m.nin_p + 16 + r] : 0.f)        // (omega, parked)
+                                    : ((ev && r < n_in) ? a.eps[(size_t)eb * n_in + r] : 0.f);
     }
     am_barrier();
     const float inv = (nd.norm_z && nz > 0.f) ? a.c_E * __builtin_amdgcn_rsqf(nz) : 0.f;
@@ -1448,29 +1576,29 @@ __device__ __forceinline__ void adj_mfma_body(const NetDesc& nd, const GradLayou
   }
 }
 
-template <bool ALL_TANH>
+template <bool ALL_TANH, bool JM>
 __global__ void __launch_bounds__(AM_THREADS)
 k_adj_mfma(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, AdjStepArgs S) {
-    adj_mfma_body<ALL_TANH, 0>(nd, gl, m, img, S, nullptr, 0);
+    adj_mfma_body<ALL_TANH, 0, JM>(nd, gl, m, img, S, nullptr, 0);
 }
 
 // (one step in two launches with its arguments by value: 5 % faster than through the device array -- 128 + 124 against
 // 137 + 129 us per step at config 5, B = 2048 -- so a sub-run of ONE step takes this form)
-template <bool ALL_TANH, int PHASE>
+template <bool ALL_TANH, int PHASE, bool JM>
 __global__ void __launch_bounds__(AM_THREADS)
 k_adj_mfma_split(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, AdjStepArgs S, float* __restrict__ SC) {
-    adj_mfma_body<ALL_TANH, PHASE>(nd, gl, m, img, S, SC, blockIdx.y);
+    adj_mfma_body<ALL_TANH, PHASE, JM>(nd, gl, m, img, S, SC, blockIdx.y);
 }
 
-template <bool ALL_TANH, int PHASE>
+template <bool ALL_TANH, int PHASE, bool JM>
 __global__ void __launch_bounds__(AM_THREADS)
 k_adj_mfma_run(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img, const AdjStepArgs* __restrict__ SA, int nsteps,
                float* __restrict__ SC) {
     if (PHASE == 1) {
         const int j = blockIdx.y / 6;
-        adj_mfma_body<ALL_TANH, 1>(nd, gl, m, img, SA[j], SC + (size_t)6 * j * SA[j].B * m.SR, blockIdx.y % 6);
+        adj_mfma_body<ALL_TANH, 1, JM>(nd, gl, m, img, SA[j], SC + (size_t)6 * j * SA[j].B * m.SR, blockIdx.y % 6);
     } else {
-        for (int j = 0; j < nsteps; ++j) adj_mfma_body<ALL_TANH, 2>(nd, gl, m, img, SA[j], SC + (size_t)6 * j * SA[j].B * m.SR, 0);
+        for (int j = 0; j < nsteps; ++j) adj_mfma_body<ALL_TANH, 2, JM>(nd, gl, m, img, SA[j], SC + (size_t)6 * j * SA[j].B * m.SR, 0);
     }
 }
 
@@ -1866,8 +1994,8 @@ k_adj3(NetDesc nd, GradLayout gl, AdjMfmaLayout m, const float* __restrict__ img
 }
 
 static bool adj3_shape(const NetDesc& nd, const AdjMfmaLayout& m) {
-    return nd.n_layers == 3 && m.dp[0] == 32 && m.dp[1] == 128 && m.dp[2] == 128 && m.dp[3] == 32 && m.nin_p == 32 &&
-           AM_WAVES == 8 && adj3_lds_bytes(m) <= 160 * 1024;
+    return !nd.jvp && nd.n_layers == 3 && m.dp[0] == 32 && m.dp[1] == 128 && m.dp[2] == 128 && m.dp[3] == 32 && m.nin_p == 32 &&
+           AM_WAVES == 8 && adj3_lds_bytes(m) <= 160 * 1024;       // (k_adj3 is written for the VJP compute mode)
 }
 
 hipError_t launch_pack_adj_images(const NetDesc& nd, const GradLayout& g, const AdjMfmaLayout& m, const float* P,
@@ -1895,12 +2023,17 @@ hipError_t launch_adj_mfma_step(const NetDesc& nd, const GradLayout& g, const Ad
         return hipGetLastError();
     }
     const int tiles = (S.B + AM_NS - 1) / AM_NS;
-    const void* fn = all_tanh ? (const void*)k_adj_mfma<true> : (const void*)k_adj_mfma<false>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    if (all_tanh) hipLaunchKernelGGL(k_adj_mfma<true>, dim3(tiles), dim3(AM_THREADS), lds, s, nd, g, m, img, S);
-    else hipLaunchKernelGGL(k_adj_mfma<false>, dim3(tiles), dim3(AM_THREADS), lds, s, nd, g, m, img, S);
-    return hipGetLastError();
+    auto go = [&](auto tanh_c, auto jm_c) -> hipError_t {
+        constexpr bool T = decltype(tanh_c)::value, J = decltype(jm_c)::value;
+        hipError_t e = hipFuncSetAttribute((const void*)k_adj_mfma<T, J>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_adj_mfma<T, J>), dim3(tiles), dim3(AM_THREADS), lds, s, nd, g, m, img, S);
+        return hipGetLastError();
+    };
+    using B1 = std::integral_constant<bool, true>;
+    using B0 = std::integral_constant<bool, false>;
+    if (nd.jvp) return all_tanh ? go(B1{}, B1{}) : go(B0{}, B1{});
+    return all_tanh ? go(B1{}, B0{}) : go(B0{}, B0{});
 }
 
 // Two launches for a run of whole steps when that is less sequential work: the stage-parallel launch costs ~0.7 of a stage per
@@ -1929,34 +2062,27 @@ hipError_t launch_adj_mfma_run(const NetDesc& nd, const GradLayout& g, const Adj
     bool all_tanh = true;
     for (int l = 0; l < nd.n_layers; ++l) all_tanh = all_tanh && nd.acts[l] == 1;
     const int tiles = (B + AM_NS - 1) / AM_NS;
-    auto go = [&](auto tanh_c, auto phase_c, dim3 grid) -> hipError_t {
-        constexpr bool T = decltype(tanh_c)::value;
-        constexpr int PH = decltype(phase_c)::value;
-        hipError_t e = hipFuncSetAttribute((const void*)k_adj_mfma_run<T, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto pair = [&](auto tanh_c, auto jm_c) -> hipError_t {
+        constexpr bool T = decltype(tanh_c)::value, J = decltype(jm_c)::value;
+        if (nsteps == 1) {                                 // one step: its arguments by value
+            hipError_t e = hipFuncSetAttribute((const void*)k_adj_mfma_split<T, 1, J>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_adj_mfma_split<T, 2, J>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_adj_mfma_split<T, 1, J>), dim3(tiles, 6), dim3(AM_THREADS), lds, s, nd, g, m, img, h_steps[0], scratch);
+            hipLaunchKernelGGL((k_adj_mfma_split<T, 2, J>), dim3(tiles), dim3(AM_THREADS), lds, s, nd, g, m, img, h_steps[0], scratch);
+            return hipGetLastError();
+        }
+        hipError_t e = hipFuncSetAttribute((const void*)k_adj_mfma_run<T, 1, J>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_adj_mfma_run<T, 2, J>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_adj_mfma_run<T, PH>), grid, dim3(AM_THREADS), lds, s, nd, g, m, img, d_steps, nsteps, scratch);
+        hipLaunchKernelGGL((k_adj_mfma_run<T, 1, J>), dim3(tiles, 6 * nsteps), dim3(AM_THREADS), lds, s, nd, g, m, img, d_steps, nsteps, scratch);
+        hipLaunchKernelGGL((k_adj_mfma_run<T, 2, J>), dim3(tiles), dim3(AM_THREADS), lds, s, nd, g, m, img, d_steps, nsteps, scratch);
         return hipGetLastError();
     };
-    auto go1 = [&](auto tanh_c, auto phase_c, dim3 grid) -> hipError_t {           // one step: its arguments by value
-        constexpr bool T = decltype(tanh_c)::value;
-        constexpr int PH = decltype(phase_c)::value;
-        hipError_t e = hipFuncSetAttribute((const void*)k_adj_mfma_split<T, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_adj_mfma_split<T, PH>), grid, dim3(AM_THREADS), lds, s, nd, g, m, img, h_steps[0], scratch);
-        return hipGetLastError();
-    };
-    using T1 = std::integral_constant<bool, true>;
-    using T0 = std::integral_constant<bool, false>;
-    using P1 = std::integral_constant<int, 1>;
-    using P2 = std::integral_constant<int, 2>;
-    if (nsteps == 1) {
-        hipError_t e = all_tanh ? go1(T1{}, P1{}, dim3(tiles, 6)) : go1(T0{}, P1{}, dim3(tiles, 6));
-        if (e != hipSuccess) return e;
-        return all_tanh ? go1(T1{}, P2{}, dim3(tiles)) : go1(T0{}, P2{}, dim3(tiles));
-    }
-    hipError_t e = all_tanh ? go(T1{}, P1{}, dim3(tiles, 6 * nsteps)) : go(T0{}, P1{}, dim3(tiles, 6 * nsteps));
-    if (e != hipSuccess) return e;
-    return all_tanh ? go(T1{}, P2{}, dim3(tiles)) : go(T0{}, P2{}, dim3(tiles));
+    using B1 = std::integral_constant<bool, true>;
+    using B0 = std::integral_constant<bool, false>;
+    if (nd.jvp) return all_tanh ? pair(B1{}, B1{}) : pair(B0{}, B1{});
+    return all_tanh ? pair(B1{}, B0{}) : pair(B0{}, B0{});
 }
 
 size_t adj_mfma_scratch_floats(const AdjMfmaLayout& m, size_t B, int nsteps) { return (size_t)6 * nsteps * B * (size_t)m.SR; }

@@ -1528,12 +1528,14 @@ def test_loss_grad_config5_network():
         _assert_grad(grad, rgrad, f"config 5 {kernel}")
 
 
-@pytest.mark.parametrize("which", ["headline", "config5", "conditional-3-layer"])
+@pytest.mark.parametrize("which", ["headline", "config5", "conditional-3-layer", "headline-jvp", "config5-jvp", "conditional-3-layer-jvp"])
 def test_loss_grad_one_launch_and_two_launch_pullbacks_agree(which):
     """The pullback kernels' two forms (cnf_set_grad_split: one launch per run of steps, or the adjoint-independent sweeps of all
     stages side by side + the hbar chains in turn) against the float64 adjoint and against each other -- k_adj3b at the
     headline shape, k_adj_mfma at config 5's network and on a conditional three-layer model, ragged batches, adaptive steps."""
     l = _lib.lib()
+    jvp = which.endswith("-jvp")               # the JVP compute mode (src/icnf.jl:384-456): k_adj_mfma<.., JM> on every shape
+    which = which[:-4] if jvp else which
     if which == "headline":
         cfg = O.Cfg(O.Net((32, 128, 128, 32), (O.ACT_TANH,) * 3), 32, 0, 0.01, 0.01)
         n_cond, B, scale = 0, 77, 0.1
@@ -1552,9 +1554,9 @@ def test_loss_grad_one_launch_and_two_launch_pullbacks_agree(which):
             l.cnf_set_grad_split(mode)
             for tag, sol_kw, ora_kw in (("fixed", dict(adaptive=False, dt=1 / 4), dict(adaptive=False, dt=1 / 4)),
                                         ("adaptive", dict(tol), "replay")):
-                val, grad, rval, rgrad, st, _ = _grad_case(cfg, B, 870, "mfma", sol_kw, ora_kw, n_cond=n_cond, scale=scale)
-                assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval)), (which, mode, tag)
-                _assert_grad(grad, rgrad, f"{which} split={mode} {tag}")
+                val, grad, rval, rgrad, st, _ = _grad_case(cfg, B, 870, "mfma", sol_kw, ora_kw, n_cond=n_cond, scale=scale, jvp=jvp)
+                assert abs(val - rval) <= 1e-5 * max(1.0, abs(rval)), (which, jvp, mode, tag)
+                _assert_grad(grad, rgrad, f"{which} jvp={jvp} split={mode} {tag}")
                 got[mode, tag] = (val, grad, st["naccept"])
     finally:
         l.cnf_set_grad_split(was)
