@@ -1567,7 +1567,8 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     // (FFJORD: zdot and ldot do not depend on the mode); k_solve3b: VJP handles with that row
     const bool vjp_ok = p.variant == 2 && !p.ly.jvp;
     const bool jvp = (p.shape3 && p.ly.jvp) || (vjp_ok && !p.ly.norm_j && !dump);
-    if (dump && !vjp_ok) return CNF_ERR_UNSUPPORTED;       // recording (gradient path): the VJP kernel only
+    // recording (gradient path): k_solve3b<RECORD> for VJP handles, k_solve3jb<.., RECORD> for JVP handles of the shape
+    if (dump && !(vjp_ok || (p.shape3 && p.ly.jvp))) return CNF_ERR_UNSUPPORTED;
     if (off || fp32_only || step_v1() || !train || !p.d_img3b || !(jvp || vjp_ok))
         return CNF_ERR_UNSUPPORTED;
     if (p.cond && dump) return CNF_ERR_UNSUPPORTED;         // (conditional recording solves: k_mfma's step launches)

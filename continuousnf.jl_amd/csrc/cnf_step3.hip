@@ -1248,6 +1248,9 @@ __global__ void __launch_bounds__(512, 2) k_step3jb(MfmaArgs a, const char* __re
         };
 
         constexpr bool S3B_COND = false;                   // (conditional models: k_mfma's step launches, or the one-launch solve)
+        constexpr bool S3JB_RECORDS = false;               // (recording launches stay on k_mfma)
+        float* const dmpw = nullptr; const size_t dmp_stride = 0;
+        (void)dmpw; (void)dmp_stride;
 #include "cnf_step3jb_eval.inc"
         if (single) {
             float* out = (single == 1 ? a.du : a.Ks0) + (size_t)(tile * 32 + 16 * hf + s) * D;
@@ -2239,9 +2242,12 @@ __global__ void __launch_bounds__(512, 2) k_solve3b(MfmaArgs a, const char* __re
 //   sample that is 2 D + n_in floats read and 2 D written (45 MB at B = 65 536: microseconds), against the weight stream,
 //   prologue and launch of a step kernel per attempt that it replaces.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool MULTI, bool COND>
+// RECORD (gradient path of JVP-mode handles, as k_solve3b<RECORD>): every attempt files u_n and U_2..U_6 (z rows) in the trajectory
+// slot of step `naccept`, its signed step size in a.hs_out; one tile per workgroup, no conditioning.
+template <bool MULTI, bool COND, bool RECORD = false>
 __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __restrict__ imgb, int n_in, int norm_z,
                                                      int norm_j, const S3Tab tab, Solve3Args sv) {
+    static_assert(!RECORD || (!MULTI && !COND), "the recording form: one tile per workgroup, no conditioning");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* ldsb = reinterpret_cast<char*>(lds);
     const float* img3 = reinterpret_cast<const float*>(imgb);      // (a valid address for masked loads)
@@ -2432,8 +2438,11 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         redw[32 * 8] = -s3_dot4(tj, *(const f32x4*)epw);
         redw[2 * 32 * 8] = s3_dot4(tj, tj);
     };
+    float* dmpw = nullptr;                                 // RECORD: this lane's rows of the current step's slot (null: not filed)
+    const size_t dmp_stride = a.dump_stride;
     auto evals = [&]() {
         constexpr bool S3B_COND = COND;
+        constexpr bool S3JB_RECORDS = RECORD;
 #include "cnf_step3jb_eval.inc"
     };
     auto add_norm = [&](float& acc, float u, float x) {
@@ -2528,6 +2537,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
     }
     // ---- step attempts ----
     int done = 0;
+    int nacc = 0;                                          // accepted steps so far (the same count in every workgroup)
     for (int it = 0; alive && !done && it < sv.maxiters; ++it) {
         float errsum = 0.f, badcnt = 0.f;
         for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -2535,6 +2545,16 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
 #pragma unroll
             for (int j = 1; j < 7; ++j) kz[j] = zero4;
             if (zown) { un = uz + (hstep * TS_A21) * kz[0]; s3b_store4(x0w, s3b::NP, un); }      // U_2 = u + h a21 k1
+            if (RECORD) {
+                if (zown) {
+                    dmpw = (live && nacc < a.dump_cap) ? a.dump + (size_t)nacc * a.dump_step_stride + gcol + r0 : nullptr;
+                    if (dmpw && nv > 0) {
+                        if (nv >= 4) { st4_wide(dmpw - dmp_stride, uz); st4_wide(dmpw, un); }
+                        else { st4(dmpw - dmp_stride, uz, nv); st4(dmpw, un, nv); }
+                    }
+                }
+                if (blockIdx.x == 0 && tid == 0 && nacc < a.dump_cap) a.hs_out[nacc] = hstep;
+            }
             s3_bar();
             nstg = 6; evals();
             if (live && zown) {
@@ -2581,6 +2601,7 @@ __global__ void __launch_bounds__(512, 2) k_solve3jb(MfmaArgs a, const char* __r
         const int fl = share();
         done = fl & 1;
         if (fl & 2) {                                                      // accepted: u <- u_new, k1 <- k7 (FSAL)
+            ++nacc;
             if (multi) cur ^= 1;
             else {
                 if (zown) { uz = un; kz[0] = kz[6]; }
@@ -2762,6 +2783,7 @@ void step3b_pack(const NetDesc& nd, const float* d_params, void* d_imgb, hipStre
 }
 // Function attributes and occupancy belong to a (function, device) pair: kept per device, set on first use there.
 static const void* solve3_fn(bool jvp, bool record, bool multi = false, bool cond = false) {
+    if (jvp && record) return (const void*)k_solve3jb<false, false, true>;
     if (jvp) return cond ? (multi ? (const void*)k_solve3jb<true, true> : (const void*)k_solve3jb<false, true>)
                          : (multi ? (const void*)k_solve3jb<true, false> : (const void*)k_solve3jb<false, false>);
     if (record) return (const void*)k_solve3b<true, false, false>;
@@ -2772,9 +2794,9 @@ static size_t solve3_shm(bool jvp) { return jvp ? (size_t)s3b::TOTAL_BYTES : (si
 int step3b_solve_resident(bool jvp, bool record, int device) {
     constexpr int MAXDEV = 64;
     static std::mutex mu;
-    static int resident[MAXDEV][3];                         // 0: not asked yet, -1: unusable, else workgroups the device holds
+    static int resident[MAXDEV][4];                         // 0: not asked yet, -1: unusable, else workgroups the device holds
     if (device < 0 || device >= MAXDEV) return 0;
-    const int which = jvp ? 2 : (record ? 1 : 0);
+    const int which = jvp ? (record ? 3 : 2) : (record ? 1 : 0);
     std::lock_guard<std::mutex> lk(mu);
     int& r = resident[device][which];
     if (r == 0) {
@@ -2801,8 +2823,7 @@ int step3b_solve_resident(bool jvp, bool record, int device) {
 }
 cnf_status step3b_solve_launch(const MfmaArgs& a, const void* d_imgb, int n_in, int norm_z, int norm_j, int grid, hipStream_t s,
                                const Solve3Args& sv_, bool jvp, int device) {
-    const bool record = a.dump != nullptr;                 // (the JVP kernel does not record)
-    if (record && jvp) return CNF_ERR_UNSUPPORTED;
+    const bool record = a.dump != nullptr;
     // Every workgroup must be resident for the whole launch: the grid is bounded by what THIS device holds at once.  An
     // ordinary launch places all of them as soon as the CUs are free; the caller keeps the one-launch solves of this process
     // apart (a mutex); whatever else holds CUs (another stream, process, a CU mask) makes a wait run out, and the caller
