@@ -916,8 +916,8 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
                          wave_solve_supported(h->nd_wave, train != 0, B);
     if (rec && rec->wg && !(wave_ok && !lockstep && !h->no_persist)) { rec->wg_failed = true; return CNF_OK; }
     // ... or of config 5's network at eight columns per CU (k_solve_bcast, cnf_bcast.hip)
-    // (the gradient's recorded forward too, where one tile per workgroup holds the batch: VJP compute mode)
-    const bool bcast_rec = rec && !rec->wg && train && !h->nd.jvp && bcast_store_floats(B, h->device) == 0;
+    // (the gradient's recorded forward too, where one tile per workgroup holds the batch)
+    const bool bcast_rec = rec && !rec->wg && train && bcast_store_floats(B, h->device) == 0;
     const bool bcast_ok = k == CNF_KERNEL_MFMA && (!rec || bcast_rec) && !wave_ok && bcast_solve_supported(h->nd, train != 0, B, h->device);
     if (bcast_ok && !lockstep && !h->no_persist) {
         if (!h->d_bimg) HIPCHK(h, hipMalloc(&h->d_bimg, bcast_img_floats() * sizeof(float)));

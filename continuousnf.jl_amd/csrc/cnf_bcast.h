@@ -14,7 +14,7 @@ bool bcast_solve_supported(const NetDesc& nd, bool train, int B, int device);
 size_t bcast_store_floats(int B, int device);
 // sv as for mfma_solve_persistent; CNF_ERR_UNSUPPORTED: not this network / batch.  store: bcast_store_floats(B) floats or null;
 // cond / cbs: the per-sample first-layer bias of a conditional model ([B][cbs]) or null
-// rec (gradient path; VJP compute mode, one tile per workgroup -- CNF_ERR_UNSUPPORTED otherwise): every attempt files u_n and its
+// rec (gradient path; TrainMode, one tile per workgroup -- CNF_ERR_UNSUPPORTED otherwise): every attempt files u_n and its
 // stage states U_2..U_6 ([B][n_in + 3], rows of z) in the trajectory slot of step `naccept` and its signed step size in hs_out
 struct BcastRecord {
     float* dump;           // the U_2 array of slot 0; u_n sits `n` floats in front of it, U_3.. behind

@@ -171,7 +171,7 @@ struct I3 { static constexpr int value = 3; };
 template <int MODE, bool MULTI, bool RECORD = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_solve_bcast(BcArgs a, Solve3Args sv, const BcTab tab) {
-    static_assert(!RECORD || (MODE == BC_VJP && !MULTI), "the recording form: VJP compute mode, one tile per workgroup");
+    static_assert(!RECORD || (MODE != BC_TESTM && !MULTI), "the recording form: TrainMode (either compute mode), one tile per workgroup");
     constexpr bool TEST = MODE == BC_TESTM, JVP = MODE == BC_JVP;
     constexpr int NS = TEST ? 1 : 3;
     constexpr int NK = JVP ? 2 : 1;                        // operand kinds side by side: the state columns, and (JVP) the tangent columns
@@ -956,7 +956,7 @@ cnf_status bcast_solve_launch(const NetDesc& nd, bool train, const float* d_para
     if (!bcast_solve_supported(nd, train, B, device) || !d_img) return CNF_ERR_UNSUPPORTED;
     const int res = bcast_resident(device), ntiles = (B + 7) / 8;
     const bool multi = ntiles > res || bcast_force_multi();
-    if (rec && (multi || !train || nd.jvp)) return CNF_ERR_UNSUPPORTED;      // (the recording form: VJP, one tile per workgroup)
+    if (rec && (multi || !train)) return CNF_ERR_UNSUPPORTED;                // (the recording form: TrainMode, one tile per workgroup)
     if (multi && !store) return CNF_ERR_BAD_ARG;
     if (nd.n_cond > 0 && !cond) return CNF_ERR_BAD_ARG;
     BcArgs a{};
@@ -978,7 +978,7 @@ cnf_status bcast_solve_launch(const NetDesc& nd, bool train, const float* d_para
     const void* fn;
     if (multi) fn = !train ? (const void*)k_solve_bcast<BC_TESTM, true> : (nd.jvp ? (const void*)k_solve_bcast<BC_JVP, true> : (const void*)k_solve_bcast<BC_VJP, true>);
     else fn = !train ? (const void*)k_solve_bcast<BC_TESTM, false> : (nd.jvp ? (const void*)k_solve_bcast<BC_JVP, false> : (const void*)k_solve_bcast<BC_VJP, false>);
-    if (rec) fn = (const void*)k_solve_bcast<BC_VJP, false, true>;
+    if (rec) fn = nd.jvp ? (const void*)k_solve_bcast<BC_JVP, false, true> : (const void*)k_solve_bcast<BC_VJP, false, true>;
     if (hipLaunchKernel(fn, dim3(grid), dim3(256), args, 0, s) != hipSuccess) {
         (void)hipGetLastError();
         return CNF_ERR_UNSUPPORTED;
