@@ -39,3 +39,5 @@ if __name__ == "__main__":
     else:
         for i, B in ((1, 32), (2, 32), (2, 4096), (3, 32), (3, 256), (3, 2048), (3, 4096), (3, 8192), (5, 32), (5, 256), (5, 2048)):
             run(i, B)
+        for i, B in ((2, 32), (3, 32), (3, 2048), (3, 8192), (5, 32), (5, 2048)):
+            run(i, B, jvp=True)
