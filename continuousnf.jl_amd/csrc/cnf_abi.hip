@@ -1824,8 +1824,8 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
                 if (need > h->park_floats) {
                     HIPCHK(h, hipStreamSynchronize(st));
                     if (h->d_park) { (void)hipFree(h->d_park); h->d_park = nullptr; h->park_floats = 0; }
-                    HIPCHK(h, hipMalloc(&h->d_park, need * sizeof(float)));
-                    h->park_floats = need;
+                    if (hipMalloc(&h->d_park, need * sizeof(float)) == hipSuccess) h->park_floats = need;
+                    else { (void)hipGetLastError(); h->d_park = nullptr; }      // (no room for the parked state: one launch per run)
                 }
                 M.park = h->d_park;
             }
