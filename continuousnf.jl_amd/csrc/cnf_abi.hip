@@ -963,8 +963,8 @@ static cnf_status solve_core(cnf_handle h, int mode, const float* u0, const floa
             ++launches;
         }
         const bool fused_io = post && post->xs && !tsolve_ok;   // inference: u0 from the data columns and the post-processing in the launch
-        if (fused_io) { sv.xs = post->xs; sv.logpx = post->logpx; sv.regs = post->regs; sv.sums5 = post->sums5; }
-        else { sv.u0 = u0; sv.u_out = (rec || tsolve_ok) ? nullptr : u_out; }   // (the launcher reads u0 in place or copies it into U[0])
+        if (fused_io) { sv.xs = post->xs; sv.logpx = post->logpx; sv.regs = post->regs; sv.sums5 = post->sums5; if (rec) sv.u_out = u_out; }
+        else { sv.u0 = u0; sv.u_out = tsolve_ok ? nullptr : u_out; }   // (the launcher reads u0 in place or copies it into U[0])
         // gradient path: every attempt files u_n and its stage states in the slot of step `naccept` (as the streamed
         // recording does); the store is sized beforehand and the solve repeated if it took more steps than fit
         float* dump = nullptr; size_t slot = 0; int dcap = 0;
@@ -1764,19 +1764,24 @@ extern "C" cnf_status cnf_loss_grad(cnf_handle h, const float* xs, const float* 
     }
 
     // ---- forward: u0, recorded solve, loss ------------------------------------------------------
-    float* u0 = h->g_US[0];
-    launch_build_u0(xs, u0, nd.nvars, D, B, st);
+    // (as an inference does: u0 is assembled from the data columns and the post-processing and the five loss sums are formed
+    // inside the one-launch solves -- the recording forms included --, behind the solve otherwise; the final state goes
+    // straight to fsol where the kernel can write it there)
     Recorder rec;
     cnf_solve_stats sst{};
     float* fsol = h->g_US[1];
+    PostHook ph{h->tmp_logpx, h->tmp_regs, h->d_sums, xs};
     for (;;) {
-        if ((s = solve_core(h, mode, u0, eps, fsol, B, opts, &sst, stream, &rec)) != CNF_OK) return s;
+        ph.launched = false;
+        if ((s = solve_core(h, mode, h->U[0], eps, fsol, B, opts, &sst, stream, &rec, true, &ph)) != CNF_OK) return s;
         if (!rec.overflow) break;
         if ((s = traj_reserve(h, rec.n + 8)) != CNF_OK) return s;       // more steps than slots: grow, solve again
     }
     h->last_hs = rec.hs;
-    launch_post(nd, 1, fsol, h->tmp_logpx, h->tmp_regs, B, st);
-    launch_loss_sums(h->tmp_logpx, h->tmp_regs, B, h->d_sums, st);     // 5 floats; d_sums holds 8
+    if (!ph.launched) {                                    // (the one-attempt-at-a-time drivers leave it to the caller)
+        enqueue_post(h, 1, h->last_state, ph, B, false, st);
+        HIPCHK(h, hipGetLastError());
+    }
     // (the five sums travel to the host behind the backward pass: the loss VALUE is not needed to start it)
     float* sums = reinterpret_cast<float*>(&h->h_state[2]);             // pinned; the initial-state slot is free by now
     HIPCHK(h, hipMemcpyAsync(sums, h->d_sums, 5 * sizeof(float), hipMemcpyDeviceToHost, st));

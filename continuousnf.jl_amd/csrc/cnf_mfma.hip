@@ -1595,7 +1595,7 @@ cnf_status mfma_solve_persistent(const MfmaPlan& p, const NetDesc& nd, bool trai
     // columns where the caller wants them -- no copy launches around the solve.  Otherwise the state lives in the
     // integrator's buffers between attempts: u0 is copied in, the caller copies the result out (sv.u_out = null says so).
     const bool direct = grid == ntile && !dump && sv.u_out != nullptr && !sv.xs;
-    if (!direct) sv.u_out = nullptr;
+    if (grid != ntile) sv.u_out = nullptr;                 // (one tile per workgroup: the final columns go where the caller wants them)
     if (sv.u0 && sv.u0 != U[0]) {
         if (direct) a.U[0] = const_cast<float*>(sv.u0);        // (read in the prologue only: the final store goes to sv.u_out)
         else if (hipMemcpyAsync(U[0], sv.u0, (size_t)B * (nd.n_in + 3) * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
