@@ -1591,6 +1591,36 @@ def test_loss_grad_more_steps_than_one_run_of_the_pullback(which):
         l.cnf_set_grad_split(was)
 
 
+@pytest.mark.parametrize("i", [3, 5])
+def test_loss_grad_recording_solve_that_gives_up_falls_back_to_step_launches(i):
+    """The gradient's forward is a recording ONE-launch solve (k_solve3b<RECORD>, k_solve_bcast<RECORD>) that also assembles u0 and
+    forms the loss sums; when its waits run out (here: after one poll) the call records with step launches instead, forms the
+    post-processing behind them, and returns the same loss and gradient."""
+    if not _one_launch_expected():
+        pytest.skip("the one-launch solve is switched off in this process")
+    cfg, _, _ = O.baseline_cfg(i)
+    cfg.tspan = (0.0, 0.5)
+    rng = np.random.default_rng(60 + i)
+    B = 300 if i == 3 else 120                                   # several workgroups: a meeting that can run out
+    flat = torch.from_numpy(O.glorot_params(cfg.net, rng, np.float32, 0.1)).cuda()
+    xs, eps = _dev(rng.standard_normal((cfg.nvars, B))), _dev(rng.standard_normal((cfg.n_in, B)))
+    tol = dict(reltol=float(np.sqrt(np.finfo(np.float32).eps)), abstol=float(np.finfo(np.float32).eps))
+    ic = make_icnf(cnf, cfg, kernel="mfma", sol_kwargs=tol)
+    v0, g0 = cnf.loss_and_grad(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    n0, fb0 = ic.last_stats["launches"], ic.solve_fallbacks()
+    g0 = g0.clone()
+    ic.set_solve_wait(poll_limit=1)
+    v1, g1 = cnf.loss_and_grad(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    assert ic.solve_fallbacks() == fb0 + 1 and ic.last_stats["launches"] > n0, (ic.last_stats, n0)
+    ic.set_solve_wait(poll_limit=0x7fffffff)
+    v2, g2 = cnf.loss_and_grad(ic, cnf.TrainMode(), xs, flat, {}, eps=eps)
+    assert ic.last_stats["launches"] == n0 and v2 == v0 and torch.equal(g2, g0)
+    # (the streamed solve takes the same accepted steps up to the rounding of a different kernel's error norm)
+    assert abs(v1 - v0) <= 2e-4 * max(1.0, abs(v0)), (v1, v0)
+    _assert_grad(g1.cpu().numpy(), g0.cpu().numpy().astype(np.float64), f"config {i}: streamed fallback vs one-launch recording", rtol=5e-3)
+    ic.close()
+
+
 def test_streamed_weights_run_the_fused_step_kernel_on_16_sample_tiles():
     """Config 5's network (weights streamed from L2) at ragged batches that leave the last 16-sample workgroup
     partly empty: kernel = auto and kernel = mfma are the same fused step kernel (one launch per step, 16-sample
